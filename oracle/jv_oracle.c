@@ -1,0 +1,628 @@
+/*
+ * jv_oracle.c — CPU oracle (scalar, Java-semantics) for the JVector distance/quantization
+ * hot path.  TEST INFRASTRUCTURE ONLY — see jv_oracle.h for who may load this and for the
+ * parity-pin status.  Build: see oracle/Makefile (-O2 -ffp-contract=off, no fast-math).
+ *
+ * Every function cites the reference lines it restates (paths relative to /root/reference,
+ * B/ = jvector-base/src/main/java/io/github/jbellis/jvector/).
+ *
+ * Java float semantics reproduced here:
+ *   - binary32 arithmetic with one rounding per operation, never contracted into FMA;
+ *   - `x += a + b + c` evaluates the right-hand side left-to-right first, then adds to x;
+ *   - (float)(double expr) narrows with round-to-nearest-even.
+ */
+#include "jv_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Row 1 — dot / L2 / cosine   (B/vector/DefaultVectorUtilSupport.java)
+ * ---------------------------------------------------------------------------------------- */
+
+/* DefaultVectorUtilSupport.dotProduct(av, bv) :38-105.
+ * NOTE the remainder elements are the FIRST len%8 (:50-52), then 32-blocks (:56-89) as four
+ * statements each adding a left-to-right sum of eight products, then 8-blocks (:90-100). */
+float jvo_dot(const float *a, const float *b, int n)
+{
+    float res = 0.0f;
+    int i;
+    for (i = 0; i < n % 8; i++) res += b[i] * a[i];
+    if (n < 8) return res;
+    for (; i + 31 < n; i += 32) {
+        for (int s = 0; s < 32; s += 8) {
+            const float *x = a + i + s, *y = b + i + s;
+            float t = y[0] * x[0] + y[1] * x[1];
+            t = t + y[2] * x[2];
+            t = t + y[3] * x[3];
+            t = t + y[4] * x[4];
+            t = t + y[5] * x[5];
+            t = t + y[6] * x[6];
+            t = t + y[7] * x[7];
+            res += t;
+        }
+    }
+    for (; i + 7 < n; i += 8) {
+        const float *x = a + i, *y = b + i;
+        float t = y[0] * x[0] + y[1] * x[1];
+        t = t + y[2] * x[2];
+        t = t + y[3] * x[3];
+        t = t + y[4] * x[4];
+        t = t + y[5] * x[5];
+        t = t + y[6] * x[6];
+        t = t + y[7] * x[7];
+        res += t;
+    }
+    return res;
+}
+
+/* DefaultVectorUtilSupport.dotProduct(av, aoffset, bv, boffset, length) :107-119 — sequential. */
+float jvo_dot_off(const float *a, int aoff, const float *b, int boff, int n)
+{
+    float sum = 0.0f;
+    for (int i = 0; i < n; i++) sum += a[aoff + i] * b[boff + i];
+    return sum;
+}
+
+/* DefaultVectorUtilSupport.squareDistance(av, bv) :158-193 (blocks of 8 via squareDistanceUnrolled
+ * :175-193: eight diffs, left-to-right sum of eight squares, then added to squareSum; sequential tail). */
+float jvo_l2(const float *a, const float *b, int n)
+{
+    float sq = 0.0f;
+    int i;
+    for (i = 0; i + 8 <= n; i += 8) {
+        float d0 = a[i + 0] - b[i + 0], d1 = a[i + 1] - b[i + 1];
+        float d2 = a[i + 2] - b[i + 2], d3 = a[i + 3] - b[i + 3];
+        float d4 = a[i + 4] - b[i + 4], d5 = a[i + 5] - b[i + 5];
+        float d6 = a[i + 6] - b[i + 6], d7 = a[i + 7] - b[i + 7];
+        float t = d0 * d0 + d1 * d1;
+        t = t + d2 * d2;
+        t = t + d3 * d3;
+        t = t + d4 * d4;
+        t = t + d5 * d5;
+        t = t + d6 * d6;
+        t = t + d7 * d7;
+        sq += t;
+    }
+    for (; i < n; i++) {
+        float d = a[i] - b[i];
+        sq += d * d;
+    }
+    return sq;
+}
+
+/* DefaultVectorUtilSupport.squareDistance(av, aoffset, bv, boffset, length) :195-208 — sequential. */
+float jvo_l2_off(const float *a, int aoff, const float *b, int boff, int n)
+{
+    float sq = 0.0f;
+    for (int i = 0; i < n; i++) {
+        float d = a[aoff + i] - b[boff + i];
+        sq += d * d;
+    }
+    return sq;
+}
+
+/* DefaultVectorUtilSupport.cosine :121-156 — three sequential float accumulators; the product
+ * norm1*norm2 is formed in float, sqrt and divide are done in double, then narrowed (:138,:155). */
+float jvo_cosine_off(const float *a, int aoff, const float *b, int boff, int n)
+{
+    float sum = 0.0f, norm1 = 0.0f, norm2 = 0.0f;
+    for (int i = 0; i < n; i++) {
+        float e1 = a[aoff + i], e2 = b[boff + i];
+        sum += e1 * e2;
+        norm1 += e1 * e1;
+        norm2 += e2 * e2;
+    }
+    float prod = norm1 * norm2;
+    return (float)((double)sum / sqrt((double)prod));
+}
+float jvo_cosine(const float *a, const float *b, int n) { return jvo_cosine_off(a, 0, b, 0, n); }
+
+/* Score transforms: VectorSimilarityFunction.compare B/vector/VectorSimilarityFunction.java:40,54,67;
+ * same formulas in PQDecoder.java:68,79,126 and FusedPQDecoder.java:125,139,217. */
+float jvo_score_from_raw(int vsf, float raw)
+{
+    switch (vsf) {
+    case JVO_EUCLIDEAN:   return 1.0f / (1.0f + raw);
+    case JVO_DOT_PRODUCT: return (1.0f + raw) / 2.0f;
+    default:              return (1.0f + raw) / 2.0f;
+    }
+}
+
+float jvo_compare(int vsf, const float *a, const float *b, int n)
+{
+    switch (vsf) {
+    case JVO_EUCLIDEAN:   return jvo_score_from_raw(vsf, jvo_l2(a, b, n));
+    case JVO_DOT_PRODUCT: return jvo_score_from_raw(vsf, jvo_dot(a, b, n));
+    default:              return jvo_score_from_raw(vsf, jvo_cosine(a, b, n));
+    }
+}
+
+/* DefaultVectorUtilSupport.sub(a, aOffset, b, bOffset, length) :282-288 */
+void jvo_sub(const float *a, const float *b, float *out, int n)
+{
+    for (int i = 0; i < n; i++) out[i] = a[i] - b[i];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Rows 2, 5, 6 — ADC tables and lookups
+ * ---------------------------------------------------------------------------------------- */
+
+/* DefaultVectorUtilSupport.assembleAndSum :302-309 */
+float jvo_assemble_and_sum(const float *data, int dataBase, const uint8_t *offs, int offsOff, int len)
+{
+    float sum = 0.0f;
+    for (int i = 0; i < len; i++) sum += data[dataBase * i + (int)offs[i + offsOff]];
+    return sum;
+}
+
+/* DefaultVectorUtilSupport.assembleAndSumPQ :311-339 (upper-triangular table) */
+float jvo_assemble_and_sum_pq(const float *tri, int M, const uint8_t *c1v, int o1,
+                              const uint8_t *c2v, int o2, int k)
+{
+    const int blockSize = k * (k + 1) / 2;
+    float res = 0.0f;
+    for (int i = 0; i < M; i++) {
+        int c1 = c1v[i + o1], c2 = c2v[i + o2];
+        int r = c1 < c2 ? c1 : c2;
+        int c = c1 < c2 ? c2 : c1;
+        int offsetRow = r * k - (r * (r - 1) / 2);
+        int idxInBlock = offsetRow + (c - r);
+        res += tri[i * blockSize + idxInBlock];
+    }
+    return res;
+}
+
+/* DefaultVectorUtilSupport.calculatePartialSums :351-365 — the *offset* (sequential) forms */
+void jvo_calculate_partial_sums(const float *codebook, int cbIndex, int size, int k,
+                                const float *query, int qoff, int vsf, float *out)
+{
+    int base = cbIndex * k;
+    for (int i = 0; i < k; i++) {
+        if (vsf == JVO_DOT_PRODUCT)
+            out[base + i] = jvo_dot_off(codebook, i * size, query, qoff, size);
+        else
+            out[base + i] = jvo_l2_off(codebook, i * size, query, qoff, size);
+    }
+}
+
+/* VectorUtilSupport.calculatePartialSelfMagnitudes (default) B/vector/VectorUtilSupport.java:137-142 */
+void jvo_calculate_partial_self_magnitudes(const float *codebook, int cbIndex, int size, int k, float *out)
+{
+    int base = cbIndex * k;
+    for (int i = 0; i < k; i++)
+        out[base + i] = jvo_dot_off(codebook, i * size, codebook, i * size, size);
+}
+
+/* VectorUtilSupport.pqDecodedCosineSimilarity (default) :152-165 */
+float jvo_pq_decoded_cosine(const uint8_t *enc, int encOff, int encLen, int k,
+                            const float *partialSums, const float *aMagT, float bMag)
+{
+    float sum = 0.0f, aMag = 0.0f;
+    for (int m = 0; m < encLen; ++m) {
+        int idx = m * k + (int)enc[m + encOff];
+        sum += partialSums[idx];
+        aMag += aMagT[idx];
+    }
+    float prod = aMag * bMag;
+    return (float)((double)sum / sqrt((double)prod));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Row 3 — ProductQuantization  (B/quantization/ProductQuantization.java)
+ * ---------------------------------------------------------------------------------------- */
+
+/* getSubvectorSizesAndOffsets :535-550 */
+void jvo_subvector_sizes_offsets(int D, int M, int *sizes, int *offsets)
+{
+    int baseSize = D / M, rem = D % M, off = 0;
+    for (int i = 0; i < M; i++) {
+        int size = baseSize + (i < rem ? 1 : 0);
+        sizes[i] = size;
+        offsets[i] = off;
+        off += size;
+    }
+}
+
+static const float *pq_codebook(const jvo_pq *pq, int m)
+{
+    size_t off = 0;
+    for (int i = 0; i < m; i++) off += (size_t)pq->k * pq->sizes[i];
+    return pq->codebooks + off;
+}
+
+/* closestCentroidIndex :507-520 — minDist = Float.MAX_VALUE, strict '<', first minimum wins */
+static int closest_centroid(const float *vec, int voff, const float *cb, int size, int k)
+{
+    int index = 0;
+    float minDist = 3.4028234663852886e+38f; /* Float.MAX_VALUE */
+    for (int i = 0; i < k; i++) {
+        float dist = jvo_l2_off(vec, voff, cb, i * size, size);
+        if (dist < minDist) { minDist = dist; index = i; }
+    }
+    return index;
+}
+
+int jvo_closest_centroid(const jvo_pq *pq, const float *vec, int m)
+{
+    return closest_centroid(vec, pq->offsets[m], pq_codebook(pq, m), pq->sizes[m], pq->k);
+}
+
+/* encodeTo :439-449 (centre, then encodeUnweighted :422-426).  Anisotropic path is out of scope
+ * (only when anisotropicThreshold > -1; default UNWEIGHTED). */
+void jvo_pq_encode(const jvo_pq *pq, const float *vec, uint8_t *dst)
+{
+    float *tmp = NULL;
+    const float *v = vec;
+    if (pq->centroid) {
+        tmp = (float *)malloc(sizeof(float) * (size_t)pq->D);
+        jvo_sub(vec, pq->centroid, tmp, pq->D);
+        v = tmp;
+    }
+    size_t cboff = 0;
+    for (int m = 0; m < pq->M; m++) {
+        dst[m] = (uint8_t)closest_centroid(v, pq->offsets[m], pq->codebooks + cboff, pq->sizes[m], pq->k);
+        cboff += (size_t)pq->k * pq->sizes[m];
+    }
+    free(tmp);
+}
+
+typedef struct { const jvo_pq *pq; const float *vecs; uint8_t *dst; int64_t lo, hi; } enc_job;
+static void *enc_worker(void *p)
+{
+    enc_job *j = (enc_job *)p;
+    for (int64_t i = j->lo; i < j->hi; i++)
+        jvo_pq_encode(j->pq, j->vecs + i * j->pq->D, j->dst + i * j->pq->M);
+    return NULL;
+}
+
+/* PQVectors.encodeAndBuild :137-149 — parallel forEach over ordinals; output ordinal-major */
+void jvo_pq_encode_all(const jvo_pq *pq, const float *vecs, int64_t n, uint8_t *dst, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    pthread_t th[64];
+    enc_job jobs[64];
+    int64_t per = (n + nthreads - 1) / nthreads;
+    int started = 0;
+    for (int t = 0; t < nthreads; t++) {
+        int64_t lo = t * per, hi = lo + per > n ? n : lo + per;
+        if (lo >= hi) break;
+        jobs[t] = (enc_job){pq, vecs, dst, lo, hi};
+        pthread_create(&th[t], NULL, enc_worker, &jobs[t]);
+        started++;
+    }
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
+
+/* decode :454-471 */
+void jvo_pq_decode(const jvo_pq *pq, const uint8_t *code, float *dst)
+{
+    size_t cboff = 0;
+    for (int m = 0; m < pq->M; m++) {
+        int size = pq->sizes[m];
+        memcpy(dst + pq->offsets[m], pq->codebooks + cboff + (size_t)code[m] * size, sizeof(float) * (size_t)size);
+        cboff += (size_t)pq->k * size;
+    }
+    if (pq->centroid)
+        for (int i = 0; i < pq->D; i++) dst[i] = dst[i] + pq->centroid[i];
+}
+
+/* createCodebookPartialSums :609-628 */
+void jvo_pq_codebook_partial_sums(const jvo_pq *pq, int vsf, float *out)
+{
+    size_t idx = 0, cboff = 0;
+    for (int m = 0; m < pq->M; m++) {
+        int size = pq->sizes[m];
+        const float *cb = pq->codebooks + cboff;
+        for (int i = 0; i < pq->k; i++)
+            for (int j = i; j < pq->k; j++)
+                out[idx++] = (vsf == JVO_EUCLIDEAN) ? jvo_l2_off(cb, i * size, cb, j * size, size)
+                                                    : jvo_dot_off(cb, i * size, cb, j * size, size);
+        cboff += (size_t)pq->k * size;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * PQDecoder / FusedPQDecoder set-up and per-node scores
+ * ---------------------------------------------------------------------------------------- */
+
+static void build_tables(const jvo_pq *pq, const float *cq, int lutVsf, float *lut, float *amag)
+{
+    size_t cboff = 0;
+    for (int m = 0; m < pq->M; m++) {
+        int size = pq->sizes[m];
+        jvo_calculate_partial_sums(pq->codebooks + cboff, m, size, pq->k, cq, pq->offsets[m], lutVsf, lut);
+        if (amag) jvo_calculate_partial_self_magnitudes(pq->codebooks + cboff, m, size, pq->k, amag);
+        cboff += (size_t)pq->k * size;
+    }
+}
+
+/* PQDecoder.CachingDecoder ctor B/quantization/PQDecoder.java:41-54 (dot / L2) and
+ * PQDecoder.CosineDecoder ctor :88-122 (dot LUT + aMagnitude table + bMagnitude =
+ * dotProduct(centeredQuery, centeredQuery) using the FULL-vector form, :121). */
+void jvo_pqdecoder_init(const jvo_pq *pq, const float *query, int vsf, float *lut, float *amag, float *bmag)
+{
+    float *tmp = NULL;
+    const float *cq = query;
+    if (pq->centroid) {
+        tmp = (float *)malloc(sizeof(float) * (size_t)pq->D);
+        jvo_sub(query, pq->centroid, tmp, pq->D);
+        cq = tmp;
+    }
+    if (vsf == JVO_COSINE) {
+        build_tables(pq, cq, JVO_DOT_PRODUCT, lut, amag);
+        if (bmag) *bmag = jvo_dot(cq, cq, pq->D);
+    } else {
+        build_tables(pq, cq, vsf, lut, NULL);
+    }
+    free(tmp);
+}
+
+/* FusedPQDecoder ctor B/quantization/FusedPQDecoder.java:49-77 (dot / L2) and CosineDecoder ctor
+ * :146-192: same tables, but queryMagnitudeSquared = sum over subspaces of the OFFSET-form
+ * dotProduct(centeredQuery, off, centeredQuery, off, size) accumulated in a float (:188). */
+void jvo_fuseddecoder_init(const jvo_pq *pq, const float *query, int vsf, float *lut, float *amag, float *bmag)
+{
+    float *tmp = NULL;
+    const float *cq = query;
+    if (pq->centroid) {
+        tmp = (float *)malloc(sizeof(float) * (size_t)pq->D);
+        jvo_sub(query, pq->centroid, tmp, pq->D);
+        cq = tmp;
+    }
+    if (vsf == JVO_COSINE) {
+        build_tables(pq, cq, JVO_DOT_PRODUCT, lut, amag);
+        float qm = 0.0f;
+        for (int m = 0; m < pq->M; m++)
+            qm += jvo_dot_off(cq, pq->offsets[m], cq, pq->offsets[m], pq->sizes[m]);
+        if (bmag) *bmag = qm;
+    } else {
+        build_tables(pq, cq, vsf, lut, NULL);
+    }
+    free(tmp);
+}
+
+/* PQDecoder.{DotProduct,Euclidean,Cosine}Decoder.similarityTo :65-80,124-135 and
+ * FusedPQDecoder.similarityToNeighbor :104-111,206-213 (identical arithmetic). */
+float jvo_adc_score(int vsf, int M, int k, const float *lut, const float *amag, float bmag, const uint8_t *code)
+{
+    if (vsf == JVO_COSINE)
+        return jvo_score_from_raw(vsf, jvo_pq_decoded_cosine(code, 0, M, k, lut, amag, bmag));
+    return jvo_score_from_raw(vsf, jvo_assemble_and_sum(lut, k, code, 0, M));
+}
+
+void jvo_adc_scores(int vsf, int M, int k, const float *lut, const float *amag, float bmag,
+                    const uint8_t *codes, const int32_t *ord, int64_t n, float *scores)
+{
+    for (int64_t i = 0; i < n; i++) {
+        int64_t o = ord ? (int64_t)ord[i] : i;
+        scores[i] = jvo_adc_score(vsf, M, k, lut, amag, bmag, codes + o * M);
+    }
+}
+
+/* PQVectors.scoreFunctionFor B/quantization/PQVectors.java:222-280 (direct, table-free path) */
+float jvo_pq_direct_score(const jvo_pq *pq, const float *query, int vsf, const uint8_t *code)
+{
+    float *tmp = NULL;
+    const float *cq = query;
+    if (pq->centroid) {
+        tmp = (float *)malloc(sizeof(float) * (size_t)pq->D);
+        jvo_sub(query, pq->centroid, tmp, pq->D);
+        cq = tmp;
+    }
+    float result;
+    size_t cboff = 0;
+    if (vsf == JVO_DOT_PRODUCT) {
+        float dp = 0.0f;
+        for (int m = 0; m < pq->M; m++) {
+            int len = pq->sizes[m];
+            dp += jvo_dot_off(pq->codebooks + cboff, code[m] * len, cq, pq->offsets[m], len);
+            cboff += (size_t)pq->k * len;
+        }
+        result = (1.0f + dp) / 2.0f;
+    } else if (vsf == JVO_COSINE) {
+        float norm1 = jvo_dot(cq, cq, pq->D), sum = 0.0f, norm2 = 0.0f;
+        for (int m = 0; m < pq->M; m++) {
+            int len = pq->sizes[m];
+            const float *cb = pq->codebooks + cboff;
+            sum += jvo_dot_off(cb, code[m] * len, cq, pq->offsets[m], len);
+            norm2 += jvo_dot_off(cb, code[m] * len, cb, code[m] * len, len);
+            cboff += (size_t)pq->k * len;
+        }
+        float prod = norm1 * norm2;
+        float cosine = sum / (float)sqrt((double)prod);
+        result = (1.0f + cosine) / 2.0f;
+    } else {
+        float sum = 0.0f;
+        for (int m = 0; m < pq->M; m++) {
+            int len = pq->sizes[m];
+            sum += jvo_l2_off(pq->codebooks + cboff, code[m] * len, cq, pq->offsets[m], len);
+            cboff += (size_t)pq->k * len;
+        }
+        result = 1.0f / (1.0f + sum);
+    }
+    free(tmp);
+    return result;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Row 9 — NodeQueue order  (B/graph/NodeQueue.java:125-137, B/util/NumericUtils.java:49-65)
+ * ---------------------------------------------------------------------------------------- */
+
+int32_t jvo_float_to_sortable_int(float v)
+{
+    int32_t bits;
+    if (v != v) bits = 0x7fc00000; /* Float.floatToIntBits canonicalises NaN */
+    else memcpy(&bits, &v, 4);
+    return bits ^ ((bits >> 31) & 0x7fffffff);
+}
+
+float jvo_sortable_int_to_float(int32_t e)
+{
+    int32_t bits = e ^ ((e >> 31) & 0x7fffffff);
+    float v;
+    memcpy(&v, &bits, 4);
+    return v;
+}
+
+/* NodeQueue.encode with MAX_HEAP order (identity): (sortableInt(score) << 32) | (0xFFFFFFFF & ~node) */
+int64_t jvo_nodequeue_encode(int32_t node, float score)
+{
+    return (int64_t)(((uint64_t)(uint32_t)jvo_float_to_sortable_int(score)) << 32) |
+           (int64_t)(0xFFFFFFFFULL & (uint64_t)(uint32_t)(~node));
+}
+
+static int cmp_desc_i64(const void *x, const void *y)
+{
+    int64_t a = *(const int64_t *)x, b = *(const int64_t *)y;
+    return a < b ? 1 : (a > b ? -1 : 0);
+}
+
+/* Best-first top-k under the NodeQueue total order: higher score first, ties -> smaller node id.
+ * (GraphSearcher.reranking emits results best-first, B/graph/GraphSearcher.java:495-506.) */
+int jvo_topk(const int32_t *ids, const float *scores, int64_t n, int k, int32_t *out_ids, float *out_scores)
+{
+    int64_t *keys = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; i++)
+        keys[i] = jvo_nodequeue_encode(ids ? ids[i] : (int32_t)i, scores[i]);
+    qsort(keys, (size_t)n, sizeof(int64_t), cmp_desc_i64);
+    int cnt = (int)(n < k ? n : k);
+    for (int i = 0; i < cnt; i++) {
+        out_ids[i] = (int32_t)~(uint32_t)(keys[i] & 0xFFFFFFFFLL);
+        out_scores[i] = jvo_sortable_int_to_float((int32_t)(keys[i] >> 32));
+    }
+    free(keys);
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * PQVectors.PQLayout  (B/quantization/PQVectors.java:515-540) — int arithmetic as in Java
+ * ---------------------------------------------------------------------------------------- */
+static int highest_one_bit(int v)
+{
+    if (v <= 0) return v == 0 ? 0 : (int)0x80000000;
+    int r = 1;
+    while ((v >>= 1) != 0) r <<= 1;
+    return r;
+}
+
+int jvo_pq_layout_compute(int vectorCount, int compressedDimension, jvo_pq_layout *o)
+{
+    if (vectorCount <= 0) return -1;          /* IllegalArgumentException :518 */
+    if (compressedDimension <= 0) return -2;  /* IllegalArgumentException :523 */
+    /* Java int arithmetic wraps; do the shifts/multiplies in uint32 to get the same bits */
+    int32_t layoutBytesPerVector =
+        compressedDimension == 1 ? 1 : (int32_t)((uint32_t)highest_one_bit(compressedDimension - 1) << 1);
+    int addressable = 2147483647 / layoutBytesPerVector;
+    o->fullChunkVectors = vectorCount < addressable ? vectorCount : addressable;
+    o->lastChunkVectors = vectorCount % o->fullChunkVectors;
+    o->fullChunkBytes = (int32_t)((uint32_t)o->fullChunkVectors * (uint32_t)compressedDimension);
+    o->lastChunkBytes = (int32_t)((uint32_t)o->lastChunkVectors * (uint32_t)compressedDimension);
+    o->fullSizeChunks = vectorCount / o->fullChunkVectors;
+    o->totalChunks = o->fullSizeChunks + (o->lastChunkVectors == 0 ? 0 : 1);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ProductQuantization.load :649-693 / write :560-599 — big-endian (B/disk/IndexWriter.java:36-42)
+ * ---------------------------------------------------------------------------------------- */
+#define PQ_MAGIC 0x75EC4012
+
+static int32_t rd_i32(const uint8_t *p)
+{
+    return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]);
+}
+static float rd_f32(const uint8_t *p)
+{
+    int32_t b = rd_i32(p);
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+static void wr_i32(uint8_t *p, int32_t v)
+{
+    p[0] = (uint8_t)((uint32_t)v >> 24); p[1] = (uint8_t)((uint32_t)v >> 16);
+    p[2] = (uint8_t)((uint32_t)v >> 8);  p[3] = (uint8_t)v;
+}
+static void wr_f32(uint8_t *p, float f)
+{
+    int32_t b;
+    memcpy(&b, &f, 4);
+    wr_i32(p, b);
+}
+
+int jvo_pq_parse(const uint8_t *buf, size_t len, int *version, int *D, int *M, int *k,
+                 int *centroidLen, float *aniso, int *sizes, int maxM,
+                 float *centroid, float *codebooks, size_t codebookCap, size_t *consumed)
+{
+    size_t p = 0;
+#define NEED(nb) do { if (p + (nb) > len) return -1; } while (0)
+    NEED(4);
+    int32_t maybeMagic = rd_i32(buf + p); p += 4;
+    int ver, gcl;
+    if (maybeMagic != PQ_MAGIC) { ver = 0; gcl = maybeMagic; }
+    else { NEED(8); ver = rd_i32(buf + p); p += 4; gcl = rd_i32(buf + p); p += 4; }
+    *version = ver;
+    *centroidLen = gcl;
+    if (gcl > 0) {
+        NEED((size_t)gcl * 4);
+        for (int i = 0; i < gcl; i++) { if (centroid) centroid[i] = rd_f32(buf + p); p += 4; }
+    }
+    NEED(4);
+    int m = rd_i32(buf + p); p += 4;
+    if (m <= 0 || m > maxM) return -2;
+    *M = m;
+    int dim = 0;
+    NEED((size_t)m * 4);
+    for (int i = 0; i < m; i++) { sizes[i] = rd_i32(buf + p); p += 4; dim += sizes[i]; }
+    *D = dim;
+    if (ver < 3) *aniso = -1.0f; /* UNWEIGHTED, KMeansPlusPlusClusterer.java:41 */
+    else { NEED(4); *aniso = rd_f32(buf + p); p += 4; }
+    NEED(4);
+    int clusters = rd_i32(buf + p); p += 4;
+    *k = clusters;
+    size_t total = 0;
+    for (int i = 0; i < m; i++) total += (size_t)clusters * (size_t)sizes[i];
+    if (total > codebookCap) return -3;
+    NEED(total * 4);
+    for (size_t i = 0; i < total; i++) { codebooks[i] = rd_f32(buf + p); p += 4; }
+    if (consumed) *consumed = p;
+    return 0;
+#undef NEED
+}
+
+size_t jvo_pq_serialize(int version, int D, int M, int k, const int *sizes, const float *centroid,
+                        float aniso, const float *codebooks, uint8_t *out, size_t cap)
+{
+    size_t total = 0;
+    for (int i = 0; i < M; i++) total += (size_t)k * (size_t)sizes[i];
+    size_t need = (version >= 3 ? 8 : 0) + 4 + (centroid ? (size_t)D * 4 : 0) + 4 + (size_t)M * 4 +
+                  (version >= 3 ? 4 : 0) + 4 + total * 4;
+    if (need > cap) return 0;
+    size_t p = 0;
+    if (version >= 3) { wr_i32(out + p, PQ_MAGIC); p += 4; wr_i32(out + p, version); p += 4; }
+    if (!centroid) { wr_i32(out + p, 0); p += 4; }
+    else {
+        wr_i32(out + p, D); p += 4;
+        for (int i = 0; i < D; i++) { wr_f32(out + p, centroid[i]); p += 4; }
+    }
+    wr_i32(out + p, M); p += 4;
+    for (int i = 0; i < M; i++) { wr_i32(out + p, sizes[i]); p += 4; }
+    if (version >= 3) { wr_f32(out + p, aniso); p += 4; }
+    wr_i32(out + p, k); p += 4;
+    for (size_t i = 0; i < total; i++) { wr_f32(out + p, codebooks[i]); p += 4; }
+    return p;
+}
+
+/* NC/tests/test_helpers.cpp:78-87 — the reference's deterministic known-answer generator */
+void jvo_make_vec(float *v, size_t n, float seed)
+{
+    for (size_t i = 0; i < n; ++i) {
+        v[i] = seed * (1.0f + (float)(i % 7) * 0.13f);
+        if (i % 3 == 0) v[i] = -v[i];
+        v[i] += 0.5f;
+    }
+}

@@ -1,0 +1,134 @@
+/*
+ * jv_oracle.h — CPU oracle for the JVector distance / quantization hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library.  The product
+ * (jvector_amd/, libjvector_hip.so) never links, imports or calls it.
+ *
+ * It is a plain-C restatement of the *scalar* reference implementation
+ * (DefaultVectorUtilSupport + ProductQuantization + PQDecoder + FusedPQDecoder +
+ * NodeQueue ordering) with Java's floating-point semantics reproduced exactly:
+ * strict IEEE-754 binary32, left-to-right evaluation, NO fused multiply-add
+ * (compile with -ffp-contract=off, never -ffast-math).
+ *
+ * Path abbreviations in citations (relative to /root/reference):
+ *   B/  = jvector-base/src/main/java/io/github/jbellis/jvector/
+ *   NC/ = jvector-native/src/main/native/
+ *   TS/ = jvector-tests/src/test/java/io/github/jbellis/jvector/
+ *
+ * Parity pin status:
+ *   dot / L2 / cosine ........ pinned by the reference's native known-answer generator
+ *                              (NC/tests/test_helpers.cpp:78-87 make_vec + 19 lengths, tol 1e-4 rel)
+ *   PQ file format ........... pinned by the binary fixture jvector-tests/resources/version0.pq
+ *                              (TS/quantization/TestProductQuantization.java:215-248, byte-exact re-save)
+ *   PQLayout chunk math ...... pinned by the literal table in TestProductQuantization.java:305-340
+ *   ADC / LUT / encode ....... pinned only through restated Java-test *properties*
+ *                              (ADC == direct 1e-6, perfect reconstruction, fused == unfused);
+ *                              the reference holds no literal golden values for these and cannot be
+ *                              run here (no JDK, Highway submodule empty) => "parity unpinned at
+ *                              the literal-value level" for PQ code bytes and ADC sums.
+ */
+#ifndef JV_ORACLE_H
+#define JV_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* VectorSimilarityFunction ordinal order: B/vector/VectorSimilarityFunction.java:34-69 */
+enum { JVO_EUCLIDEAN = 0, JVO_DOT_PRODUCT = 1, JVO_COSINE = 2 };
+
+/* ---- row 1: full-resolution distances (DefaultVectorUtilSupport) ---- */
+float jvo_dot(const float *a, const float *b, int n);
+float jvo_dot_off(const float *a, int aoff, const float *b, int boff, int n);
+float jvo_l2(const float *a, const float *b, int n);
+float jvo_l2_off(const float *a, int aoff, const float *b, int boff, int n);
+float jvo_cosine(const float *a, const float *b, int n);
+float jvo_cosine_off(const float *a, int aoff, const float *b, int boff, int n);
+/* VectorSimilarityFunction.compare: raw distance -> similarity score */
+float jvo_compare(int vsf, const float *a, const float *b, int n);
+float jvo_score_from_raw(int vsf, float raw);
+void  jvo_sub(const float *a, const float *b, float *out, int n);
+
+/* ---- rows 2,5,6: ADC tables and lookups ---- */
+float jvo_assemble_and_sum(const float *data, int dataBase, const uint8_t *offs, int offsOff, int len);
+float jvo_assemble_and_sum_pq(const float *tri, int M, const uint8_t *c1, int o1,
+                              const uint8_t *c2, int o2, int k);
+void  jvo_calculate_partial_sums(const float *codebook, int cbIndex, int size, int k,
+                                 const float *query, int qoff, int vsf, float *out);
+void  jvo_calculate_partial_self_magnitudes(const float *codebook, int cbIndex, int size, int k,
+                                            float *out);
+float jvo_pq_decoded_cosine(const uint8_t *enc, int encOff, int encLen, int k,
+                            const float *partialSums, const float *aMag, float bMag);
+
+/* ---- ProductQuantization as flat arrays ----
+ * codebooks: concatenation over m of k*size_m floats (centroid-major), exactly the
+ * order ProductQuantization.write emits them (B/quantization/ProductQuantization.java:593-598). */
+typedef struct {
+    int D, M, k;
+    const int *sizes;      /* [M] */
+    const int *offsets;    /* [M] */
+    const float *codebooks;/* [sum_m k*sizes[m]] */
+    const float *centroid; /* [D] or NULL */
+} jvo_pq;
+
+void jvo_subvector_sizes_offsets(int D, int M, int *sizes, int *offsets);
+int  jvo_closest_centroid(const jvo_pq *pq, const float *vec /*already centred*/, int m);
+void jvo_pq_encode(const jvo_pq *pq, const float *vec, uint8_t *dst);
+void jvo_pq_encode_all(const jvo_pq *pq, const float *vecs, int64_t n, uint8_t *dst, int nthreads);
+void jvo_pq_decode(const jvo_pq *pq, const uint8_t *code, float *dst);
+/* createCodebookPartialSums: M*k*(k+1)/2 floats */
+void jvo_pq_codebook_partial_sums(const jvo_pq *pq, int vsf, float *out);
+
+/* PQDecoder (precomputedScoreFunctionFor): builds LUT (M*k floats), for cosine also the
+ * aMagnitude table and bMagnitude.  lut/amag caller-allocated; amag/bmag may be NULL unless cosine. */
+void  jvo_pqdecoder_init(const jvo_pq *pq, const float *query, int vsf,
+                         float *lut, float *amag, float *bmag);
+/* FusedPQDecoder variant: identical tables, but the cosine query magnitude is accumulated
+ * per subspace (B/quantization/FusedPQDecoder.java:178-191). */
+void  jvo_fuseddecoder_init(const jvo_pq *pq, const float *query, int vsf,
+                            float *lut, float *amag, float *bmag);
+/* similarityTo(node): score of one code row under the prepared tables */
+float jvo_adc_score(int vsf, int M, int k, const float *lut, const float *amag, float bmag,
+                    const uint8_t *code);
+/* batched convenience: scores[i] = jvo_adc_score(codes + ord[i]*M) ; ord==NULL => i */
+void  jvo_adc_scores(int vsf, int M, int k, const float *lut, const float *amag, float bmag,
+                     const uint8_t *codes, const int32_t *ord, int64_t n, float *scores);
+/* PQVectors.scoreFunctionFor (non-precomputed, decode-free direct path):
+ * B/quantization/PQVectors.java:222-280 — used by the ADC==direct property test */
+float jvo_pq_direct_score(const jvo_pq *pq, const float *query, int vsf, const uint8_t *code);
+
+/* ---- row 9: NodeQueue total order ---- */
+int32_t jvo_float_to_sortable_int(float v);
+float   jvo_sortable_int_to_float(int32_t v);
+int64_t jvo_nodequeue_encode(int32_t node, float score);
+/* top-k of (ids[i], scores[i]) under the NodeQueue order, best first.  returns count written */
+int     jvo_topk(const int32_t *ids, const float *scores, int64_t n, int k,
+                 int32_t *out_ids, float *out_scores);
+
+/* ---- PQVectors.PQLayout chunk math: B/quantization/PQVectors.java:515-540 ---- */
+typedef struct {
+    int fullChunkVectors, lastChunkVectors, fullSizeChunks, totalChunks, fullChunkBytes, lastChunkBytes;
+} jvo_pq_layout;
+int jvo_pq_layout_compute(int vectorCount, int compressedDimension, jvo_pq_layout *out);
+
+/* ---- ProductQuantization.load / write (big-endian) ----
+ * Parses header; returns 0 on success.  Pointers into caller's output arrays. */
+int  jvo_pq_parse(const uint8_t *buf, size_t len, int *version, int *D, int *M, int *k,
+                  int *centroidLen, float *anisoThreshold,
+                  int *sizes /*cap maxM*/, int maxM,
+                  float *centroid /*cap D*/, float *codebooks /*cap*/, size_t codebookCap,
+                  size_t *consumed);
+size_t jvo_pq_serialize(int version, int D, int M, int k, const int *sizes, const float *centroid,
+                        float anisoThreshold, const float *codebooks, uint8_t *out, size_t cap);
+
+/* ---- the reference's native known-answer generator: NC/tests/test_helpers.cpp:78-87 ---- */
+void jvo_make_vec(float *v, size_t n, float seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

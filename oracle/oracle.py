@@ -1,0 +1,312 @@
+"""ctypes binding for the CPU oracle (oracle/libjv_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under jvector_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libjv_oracle.so")
+
+EUCLIDEAN, DOT_PRODUCT, COSINE = 0, 1, 2
+VSF_NAMES = {EUCLIDEAN: "EUCLIDEAN", DOT_PRODUCT: "DOT_PRODUCT", COSINE: "COSINE"}
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("jv_oracle.c", "jv_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "libjv_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class _PQ(C.Structure):
+    _fields_ = [("D", C.c_int), ("M", C.c_int), ("k", C.c_int),
+                ("sizes", C.POINTER(C.c_int)), ("offsets", C.POINTER(C.c_int)),
+                ("codebooks", C.POINTER(C.c_float)), ("centroid", C.POINTER(C.c_float))]
+
+
+class _Layout(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("fullChunkVectors", "lastChunkVectors", "fullSizeChunks",
+                                       "totalChunks", "fullChunkBytes", "lastChunkBytes")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        fp, u8p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+        pqp = C.POINTER(_PQ)
+
+        def sig(name, res, *args):
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = list(args)
+
+        sig("jvo_dot", C.c_float, fp, fp, C.c_int)
+        sig("jvo_dot_off", C.c_float, fp, C.c_int, fp, C.c_int, C.c_int)
+        sig("jvo_l2", C.c_float, fp, fp, C.c_int)
+        sig("jvo_l2_off", C.c_float, fp, C.c_int, fp, C.c_int, C.c_int)
+        sig("jvo_cosine", C.c_float, fp, fp, C.c_int)
+        sig("jvo_cosine_off", C.c_float, fp, C.c_int, fp, C.c_int, C.c_int)
+        sig("jvo_compare", C.c_float, C.c_int, fp, fp, C.c_int)
+        sig("jvo_score_from_raw", C.c_float, C.c_int, C.c_float)
+        sig("jvo_assemble_and_sum", C.c_float, fp, C.c_int, u8p, C.c_int, C.c_int)
+        sig("jvo_assemble_and_sum_pq", C.c_float, fp, C.c_int, u8p, C.c_int, u8p, C.c_int, C.c_int)
+        sig("jvo_calculate_partial_sums", None, fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp)
+        sig("jvo_calculate_partial_self_magnitudes", None, fp, C.c_int, C.c_int, C.c_int, fp)
+        sig("jvo_pq_decoded_cosine", C.c_float, u8p, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float)
+        sig("jvo_subvector_sizes_offsets", None, C.c_int, C.c_int, i32p, i32p)
+        sig("jvo_closest_centroid", C.c_int, pqp, fp, C.c_int)
+        sig("jvo_pq_encode", None, pqp, fp, u8p)
+        sig("jvo_pq_encode_all", None, pqp, fp, C.c_int64, u8p, C.c_int)
+        sig("jvo_pq_decode", None, pqp, u8p, fp)
+        sig("jvo_pq_codebook_partial_sums", None, pqp, C.c_int, fp)
+        sig("jvo_pqdecoder_init", None, pqp, fp, C.c_int, fp, fp, fp)
+        sig("jvo_fuseddecoder_init", None, pqp, fp, C.c_int, fp, fp, fp)
+        sig("jvo_adc_score", C.c_float, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, u8p)
+        sig("jvo_adc_scores", None, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, u8p, i32p, C.c_int64, fp)
+        sig("jvo_pq_direct_score", C.c_float, pqp, fp, C.c_int, u8p)
+        sig("jvo_float_to_sortable_int", C.c_int32, C.c_float)
+        sig("jvo_sortable_int_to_float", C.c_float, C.c_int32)
+        sig("jvo_nodequeue_encode", C.c_int64, C.c_int32, C.c_float)
+        sig("jvo_topk", C.c_int, i32p, fp, C.c_int64, C.c_int, i32p, fp)
+        sig("jvo_pq_layout_compute", C.c_int, C.c_int, C.c_int, C.POINTER(_Layout))
+        sig("jvo_pq_parse", C.c_int, u8p, C.c_size_t, i32p, i32p, i32p, i32p, i32p, fp, i32p, C.c_int,
+            fp, fp, C.c_size_t, C.POINTER(C.c_size_t))
+        sig("jvo_pq_serialize", C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp, C.c_float, fp,
+            u8p, C.c_size_t)
+        sig("jvo_make_vec", None, fp, C.c_size_t, C.c_float)
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u8(a):
+    assert a.dtype == np.uint8 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _i32(a):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+# ---- row 1 ----
+def dot(a, b):
+    a, b = f32(a), f32(b)
+    return float(lib().jvo_dot(_f(a), _f(b), a.size))
+
+
+def l2(a, b):
+    a, b = f32(a), f32(b)
+    return float(lib().jvo_l2(_f(a), _f(b), a.size))
+
+
+def cosine(a, b):
+    a, b = f32(a), f32(b)
+    return float(lib().jvo_cosine(_f(a), _f(b), a.size))
+
+
+def dot_off(a, ao, b, bo, n):
+    a, b = f32(a), f32(b)
+    return float(lib().jvo_dot_off(_f(a), ao, _f(b), bo, n))
+
+
+def l2_off(a, ao, b, bo, n):
+    a, b = f32(a), f32(b)
+    return float(lib().jvo_l2_off(_f(a), ao, _f(b), bo, n))
+
+
+def cosine_off(a, ao, b, bo, n):
+    a, b = f32(a), f32(b)
+    return float(lib().jvo_cosine_off(_f(a), ao, _f(b), bo, n))
+
+
+def compare(vsf, a, b):
+    a, b = f32(a), f32(b)
+    return float(lib().jvo_compare(vsf, _f(a), _f(b), a.size))
+
+
+def compare_many(vsf, q, vecs):
+    """scores[i] = VectorSimilarityFunction.compare(q, vecs[i])"""
+    q, vecs = f32(q), f32(vecs)
+    out = np.empty(vecs.shape[0], np.float32)
+    L = lib()
+    for i in range(vecs.shape[0]):
+        out[i] = L.jvo_compare(vsf, _f(q), _f(vecs[i]), q.size)
+    return out
+
+
+def score_from_raw(vsf, raw):
+    return float(lib().jvo_score_from_raw(vsf, C.c_float(raw)))
+
+
+def make_vec(n, seed):
+    v = np.empty(n, np.float32)
+    lib().jvo_make_vec(_f(v), n, C.c_float(seed))
+    return v
+
+
+def assemble_and_sum(data, data_base, offs, offs_off, length):
+    data, offs = f32(data), np.ascontiguousarray(offs, np.uint8)
+    return float(lib().jvo_assemble_and_sum(_f(data), data_base, _u8(offs), offs_off, length))
+
+
+def float_to_sortable_int(v):
+    return int(lib().jvo_float_to_sortable_int(C.c_float(v)))
+
+
+def nodequeue_encode(node, score):
+    return int(lib().jvo_nodequeue_encode(node, C.c_float(score)))
+
+
+def topk(ids, scores, k):
+    scores = f32(scores)
+    n = scores.size
+    ids_a = None if ids is None else np.ascontiguousarray(ids, np.int32)
+    oi = np.empty(k, np.int32)
+    os_ = np.empty(k, np.float32)
+    cnt = lib().jvo_topk(None if ids_a is None else _i32(ids_a), _f(scores), n, k, _i32(oi), _f(os_))
+    return oi[:cnt].copy(), os_[:cnt].copy()
+
+
+def pq_layout(vector_count, compressed_dim):
+    lay = _Layout()
+    rc = lib().jvo_pq_layout_compute(vector_count, compressed_dim, C.byref(lay))
+    if rc != 0:
+        raise ValueError("Invalid vector count" if rc == -1 else "Invalid compressed dimension")
+    return {n: getattr(lay, n) for n, _ in _Layout._fields_}
+
+
+def subvector_sizes_offsets(D, M):
+    if M > D:
+        raise ValueError("Number of subspaces must be less than or equal to the vector dimension")
+    s, o = np.empty(M, np.int32), np.empty(M, np.int32)
+    lib().jvo_subvector_sizes_offsets(D, M, _i32(s), _i32(o))
+    return s, o
+
+
+class OraclePQ:
+    """Flat-array ProductQuantization for the oracle (codebooks concatenated centroid-major)."""
+
+    def __init__(self, D, M, codebooks, centroid=None, k=256, sizes=None):
+        self.D, self.M, self.k = int(D), int(M), int(k)
+        if sizes is None:
+            self.sizes, self.offsets = subvector_sizes_offsets(D, M)
+        else:
+            self.sizes = np.ascontiguousarray(sizes, np.int32)
+            self.offsets = np.concatenate([[0], np.cumsum(self.sizes)[:-1]]).astype(np.int32)
+        self.codebooks = f32(np.asarray(codebooks).reshape(-1))
+        assert self.codebooks.size == self.k * int(self.sizes.sum())
+        self.centroid = None if centroid is None else f32(centroid)
+        self._s = _PQ(self.D, self.M, self.k, _i32(self.sizes), _i32(self.offsets), _f(self.codebooks),
+                      None if self.centroid is None else _f(self.centroid))
+
+    @property
+    def ref(self):
+        return C.byref(self._s)
+
+    def codebook(self, m):
+        off = int(self.k * self.sizes[:m].sum())
+        return self.codebooks[off: off + self.k * int(self.sizes[m])]
+
+    def encode(self, vec):
+        vec = f32(vec)
+        out = np.empty(self.M, np.uint8)
+        lib().jvo_pq_encode(self.ref, _f(vec), _u8(out))
+        return out
+
+    def encode_all(self, vecs, nthreads=8):
+        vecs = f32(vecs)
+        n = vecs.shape[0]
+        out = np.empty((n, self.M), np.uint8)
+        lib().jvo_pq_encode_all(self.ref, _f(vecs), n, _u8(out), nthreads)
+        return out
+
+    def decode(self, code):
+        code = np.ascontiguousarray(code, np.uint8)
+        out = np.empty(self.D, np.float32)
+        lib().jvo_pq_decode(self.ref, _u8(code), _f(out))
+        return out
+
+    def decoder(self, query, vsf, fused=False):
+        """Returns (lut[M*k], amag[M*k] | None, bmag)."""
+        query = f32(query)
+        lut = np.empty(self.M * self.k, np.float32)
+        amag = np.empty(self.M * self.k, np.float32) if vsf == COSINE else None
+        bm = C.c_float(0.0)
+        fn = lib().jvo_fuseddecoder_init if fused else lib().jvo_pqdecoder_init
+        fn(self.ref, _f(query), vsf, _f(lut), None if amag is None else _f(amag), C.byref(bm))
+        return lut, amag, float(bm.value)
+
+    def adc_scores(self, query, vsf, codes, ordinals=None, fused=False):
+        lut, amag, bm = self.decoder(query, vsf, fused)
+        codes = np.ascontiguousarray(codes, np.uint8)
+        if ordinals is None:
+            n = codes.reshape(-1, self.M).shape[0]
+            ordp = None
+        else:
+            ordinals = np.ascontiguousarray(ordinals, np.int32)
+            n = ordinals.size
+            ordp = _i32(ordinals)
+        out = np.empty(n, np.float32)
+        lib().jvo_adc_scores(vsf, self.M, self.k, _f(lut), None if amag is None else _f(amag),
+                             C.c_float(bm), _u8(codes), ordp, n, _f(out))
+        return out
+
+    def direct_score(self, query, vsf, code):
+        query, code = f32(query), np.ascontiguousarray(code, np.uint8)
+        return float(lib().jvo_pq_direct_score(self.ref, _f(query), vsf, _u8(code)))
+
+    def codebook_partial_sums(self, vsf):
+        out = np.empty(self.M * self.k * (self.k + 1) // 2, np.float32)
+        lib().jvo_pq_codebook_partial_sums(self.ref, vsf, _f(out))
+        return out
+
+    def serialize(self, version, aniso=-1.0):
+        cap = 64 + 4 * (self.D + self.M + self.codebooks.size)
+        buf = np.empty(cap, np.uint8)
+        n = lib().jvo_pq_serialize(version, self.D, self.M, self.k, _i32(self.sizes),
+                                   None if self.centroid is None else _f(self.centroid),
+                                   C.c_float(aniso), _f(self.codebooks), _u8(buf), cap)
+        return bytes(buf[:n])
+
+    @staticmethod
+    def parse(data: bytes):
+        buf = np.frombuffer(data, np.uint8).copy()
+        ver, D, M, k, cl = (C.c_int32() for _ in range(5))
+        aniso = C.c_float()
+        max_m = 4096
+        sizes = np.empty(max_m, np.int32)
+        centroid = np.empty(max(1, len(data) // 4), np.float32)
+        cbs = np.empty(max(1, len(data) // 4), np.float32)
+        consumed = C.c_size_t()
+        rc = lib().jvo_pq_parse(_u8(buf), len(data), C.byref(ver), C.byref(D), C.byref(M), C.byref(k),
+                                C.byref(cl), C.byref(aniso), _i32(sizes), max_m, _f(centroid), _f(cbs),
+                                cbs.size, C.byref(consumed))
+        if rc != 0:
+            raise ValueError(f"jvo_pq_parse failed rc={rc}")
+        szs = sizes[:M.value].copy()
+        total = int(k.value * szs.sum())
+        pq = OraclePQ(D.value, M.value, cbs[:total].copy(),
+                      centroid[:cl.value].copy() if cl.value > 0 else None, k.value, sizes=szs)
+        return pq, ver.value, float(aniso.value), consumed.value
