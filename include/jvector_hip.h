@@ -1,0 +1,222 @@
+/*
+ * jvector_hip.h — C ABI of libjvector_hip.so, the MI355X (gfx950) distance / quantization
+ * engine that sits behind JVector's VectorizationProvider / VectorUtilSupport plugin surface.
+ *
+ * Boundary rules (mirroring the reference's native boundary):
+ *   - extern "C", plain pointers and sizes, no C++/torch types;
+ *   - the CALLER owns every user buffer; the library never retains a user pointer beyond the call
+ *     (device-resident copies are explicit objects: jv_pq, jv_codes, jv_vectors, jv_fused, jv_luts);
+ *   - unlike the reference's per-pair, never-failing kernels
+ *     (jvector-native/src/main/native/src/jvector_simd.h:30-57), a GPU call can fail, so every entry
+ *     point returns a jv_status and jv_hip_last_error() returns a thread-local message;
+ *   - thread-safety: a jv_ctx is owned by ONE host thread (it holds that thread's HIP stream and
+ *     scratch, the analogue of the reference's ThreadLocal scratch, ProductQuantization.java:237);
+ *     jv_pq / jv_codes / jv_vectors / jv_fused are immutable after upload and may be shared by all
+ *     contexts of the same device.
+ *   - user pointers may be HOST (pageable or pinned) or DEVICE pointers; the library classifies them
+ *     with hipPointerGetAttributes.  Host buffers are staged through the context's pinned scratch on
+ *     the context's stream; device buffers are used in place (zero copy).
+ *   - every call is asynchronous on the context's stream unless it returns data to a HOST buffer (then it
+ *     synchronises the stream before returning).  jv_hip_ctx_sync() is the explicit barrier.
+ *   - there is NO CPU fallback: without a usable gfx950 device every call fails with JV_ERR_NO_DEVICE.
+ *
+ * Each entry point cites the reference interface it batches/replaces (paths relative to /root/reference;
+ * B/ = jvector-base/src/main/java/io/github/jbellis/jvector/).
+ */
+#ifndef JVECTOR_HIP_H
+#define JVECTOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JV_API __attribute__((visibility("default")))
+
+typedef enum {
+    JV_OK = 0,
+    JV_ERR_INVALID = -1,      /* bad argument (the reference would throw IllegalArgumentException / assert) */
+    JV_ERR_NO_DEVICE = -2,    /* no usable gfx950 device / HIP runtime */
+    JV_ERR_HIP = -3,          /* a HIP runtime call failed; see jv_hip_last_error() */
+    JV_ERR_OOM = -4,          /* device or pinned-host allocation failed */
+    JV_ERR_UNSUPPORTED = -5   /* e.g. clusterCount != 256, anisotropic PQ */
+} jv_status;
+
+/* VectorSimilarityFunction ordinals — B/vector/VectorSimilarityFunction.java:34-69 */
+typedef enum { JV_EUCLIDEAN = 0, JV_DOT_PRODUCT = 1, JV_COSINE = 2 } jv_vsf;
+
+/* Which reference decoder's query-side arithmetic to reproduce (they differ only in how the cosine
+ * query magnitude is accumulated): PQDecoder (B/quantization/PQDecoder.java:88-122, full-vector
+ * dotProduct) or FusedPQDecoder (B/quantization/FusedPQDecoder.java:178-191, per-subspace sums). */
+typedef enum { JV_DECODER_PQ = 0, JV_DECODER_FUSED = 1 } jv_decoder_kind;
+
+typedef struct jv_ctx jv_ctx;
+typedef struct jv_pq jv_pq;
+typedef struct jv_codes jv_codes;
+typedef struct jv_vectors jv_vectors;
+typedef struct jv_fused jv_fused;
+typedef struct jv_luts jv_luts;
+
+/* ---------------------------------------------------------------------------------------------
+ * Library / context
+ * ------------------------------------------------------------------------------------------- */
+JV_API const char *jv_hip_version(void);
+/* Thread-local description of the last failure on the calling thread ("" if none). Static storage. */
+JV_API const char *jv_hip_last_error(void);
+/* Number of visible gfx950 devices (0 when there is no GPU / no HIP runtime). Never fails. */
+JV_API int jv_hip_device_count(void);
+/* Diagnostic twin of jvector_simd_get_active_isa (jvector_simd.h:47): e.g. "gfx950:sramecc+:xnack-". */
+JV_API const char *jv_hip_active_arch(int device);
+
+/* stream: an existing hipStream_t to enqueue on (e.g. the caller framework's current stream), or NULL
+ * to let the context create its own non-blocking stream. */
+JV_API int jv_hip_ctx_create(int device, void *stream, jv_ctx **out);
+JV_API int jv_hip_ctx_destroy(jv_ctx *ctx);
+JV_API int jv_hip_ctx_sync(jv_ctx *ctx);
+JV_API void *jv_hip_ctx_stream(jv_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------------------
+ * ProductQuantization (device-resident codebooks)
+ *   replaces: the codebook arguments of calculate_partial_sums_*_f32 (jvector_simd_kernel_list.h:53-55)
+ *   and ProductQuantization's fields (B/quantization/ProductQuantization.java:66-75).
+ * codebooks: concatenation over m of k*sizes[m] floats, centroid-major — the order
+ *   ProductQuantization.write emits (:593-598).  sizes==NULL => getSubvectorSizesAndOffsets(D, M) (:535-550).
+ * centroid: globalCentroid (D floats) or NULL.  k must be 256 (FusedPQ.java:57-59; one code byte).
+ * ------------------------------------------------------------------------------------------- */
+JV_API int jv_hip_pq_create(jv_ctx *ctx, int D, int M, int k, const int *sizes, const float *codebooks,
+                            const float *centroid, jv_pq **out);
+/* Parses the reference's big-endian wire format (ProductQuantization.load :649-693; v0..v6). */
+JV_API int jv_hip_pq_load(jv_ctx *ctx, const uint8_t *buf, size_t len, size_t *consumed, jv_pq **out);
+JV_API int jv_hip_pq_destroy(jv_pq *pq);
+JV_API int jv_hip_pq_info(const jv_pq *pq, int *D, int *M, int *k, int *has_centroid);
+
+/* ---------------------------------------------------------------------------------------------
+ * PQVectors (device-resident code store, ordinal-major: code of ordinal o at bytes [o*M, (o+1)*M))
+ *   replaces: PQVectors.compressedDataChunks + getChunk/getOffsetInChunk (B/quantization/PQVectors.java:377-395);
+ *   the 2 GiB chunking (PQLayout :515-540) is a JVM-array artefact and does not exist on the device.
+ * ------------------------------------------------------------------------------------------- */
+JV_API int jv_hip_codes_create(jv_ctx *ctx, const jv_pq *pq, int64_t count, jv_codes **out);
+/* wrap caller-owned DEVICE memory (count*M bytes, 16-byte aligned) without copying */
+JV_API int jv_hip_codes_wrap(jv_ctx *ctx, const jv_pq *pq, int64_t count, void *device_codes, jv_codes **out);
+JV_API int jv_hip_codes_upload(jv_ctx *ctx, jv_codes *codes, int64_t first, int64_t count, const uint8_t *src);
+JV_API int jv_hip_codes_download(jv_ctx *ctx, const jv_codes *codes, int64_t first, int64_t count, uint8_t *dst);
+JV_API int jv_hip_codes_destroy(jv_codes *codes);
+JV_API int64_t jv_hip_codes_count(const jv_codes *codes);
+JV_API void *jv_hip_codes_device_ptr(const jv_codes *codes);
+
+/* ---------------------------------------------------------------------------------------------
+ * Full-resolution vectors (device-resident, row-major N x D float32)
+ *   replaces: RandomAccessVectorValues.getVector / getVectorInto as used by rerankerFor
+ *   (B/graph/RandomAccessVectorValues.java:114-124; OnDiskGraphIndex.java:565-581).
+ * ------------------------------------------------------------------------------------------- */
+JV_API int jv_hip_vectors_create(jv_ctx *ctx, int64_t count, int D, jv_vectors **out);
+JV_API int jv_hip_vectors_wrap(jv_ctx *ctx, int64_t count, int D, void *device_vectors, jv_vectors **out);
+JV_API int jv_hip_vectors_upload(jv_ctx *ctx, jv_vectors *v, int64_t first, int64_t count, const float *src);
+JV_API int jv_hip_vectors_destroy(jv_vectors *v);
+
+/* ---------------------------------------------------------------------------------------------
+ * ProductQuantization.encode — SURVEY §8a row 3
+ *   replaces: PQVectors.encodeAndBuild's parallel forEach (B/quantization/PQVectors.java:137-149) ->
+ *   ProductQuantization.encodeTo/encodeUnweighted/closestCentroidIndex (:422-449,:507-520).
+ *   Bit-exact: centring by float subtraction, sequential non-fused (v-c)^2 sums, strict '<' first-min.
+ * vectors: count x D floats (host or device); codes_out: count x M bytes (host or device).
+ * ------------------------------------------------------------------------------------------- */
+JV_API int jv_hip_pq_encode(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t count, uint8_t *codes_out);
+/* encode rows [first, first+count) of a device-resident vector set straight into a code store */
+JV_API int jv_hip_pq_encode_into(jv_ctx *ctx, const jv_pq *pq, const jv_vectors *v, int64_t first, int64_t count,
+                                 jv_codes *codes);
+
+/* ---------------------------------------------------------------------------------------------
+ * ADC look-up tables for a batch of queries — SURVEY §8a row 2
+ *   replaces: PQDecoder.CachingDecoder / CosineDecoder constructors (B/quantization/PQDecoder.java:41-54,
+ *   88-122) and FusedPQDecoder constructors (B/quantization/FusedPQDecoder.java:49-77,146-192), i.e.
+ *   M calls of VectorUtil.calculatePartialSums (VectorUtilSupport.java:135; native
+ *   calculate_partial_sums_{dot,euclidean}_f32) per query, + calculatePartialSelfMagnitudes once per PQ.
+ * queries: Q x D floats (host or device), NOT pre-centred (the library subtracts globalCentroid).
+ * The returned object owns Q x M x 256 floats on the device and is reusable: calling build again on the
+ * same object with Q' <= capacity re-fills it without allocation.
+ * ------------------------------------------------------------------------------------------- */
+JV_API int jv_hip_luts_create(jv_ctx *ctx, const jv_pq *pq, int max_queries, jv_luts **out);
+JV_API int jv_hip_luts_build(jv_ctx *ctx, jv_luts *luts, const float *queries, int Q, jv_vsf vsf,
+                             jv_decoder_kind kind);
+JV_API int jv_hip_luts_destroy(jv_luts *luts);
+/* test/diagnostic access: copies query q's table (M*256 floats) and bMagnitude to host */
+JV_API int jv_hip_luts_download(jv_ctx *ctx, const jv_luts *luts, int q, float *lut_out, float *bmag_out);
+/* copies the PQ's cosine self-magnitude table (M*256 floats; calculatePartialSelfMagnitudes) to host */
+JV_API int jv_hip_pq_self_magnitudes(jv_ctx *ctx, const jv_pq *pq, float *out);
+
+/* ---------------------------------------------------------------------------------------------
+ * ADC scoring — SURVEY §8a rows 5 and 6
+ *   replaces: one assemble_and_sum_f32 / pq_decoded_cosine_similarity_f32 call per candidate
+ *   (jvector_simd_kernel_list.h:50,52; PQDecoder.similarityTo B/quantization/PQDecoder.java:65-80,124-135)
+ *   including the score transform 1/(1+d), (1+s)/2, (1+c)/2.
+ * scan:   scores_out[q*count + i] = similarityTo(first + i)   for i in [0,count), all Q queries of `luts`
+ * gather: scores_out[q*B + j]     = similarityTo(ordinals[q*B + j]); an ordinal < 0 yields -INFINITY
+ * scores_out / ordinals: host or device.
+ * ------------------------------------------------------------------------------------------- */
+JV_API int jv_hip_adc_scan(jv_ctx *ctx, const jv_luts *luts, const jv_codes *codes, int64_t first, int64_t count,
+                           float *scores_out);
+JV_API int jv_hip_adc_scores(jv_ctx *ctx, const jv_luts *luts, const jv_codes *codes, const int32_t *ordinals,
+                             int B, float *scores_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused-PQ ("FusedADC") L0 blocks — SURVEY §8a row 7
+ *   replaces: FusedPQDecoder.enableSimilarityToNeighbors + similarityToNeighbor
+ *   (B/quantization/FusedPQDecoder.java:85-111,206-213) over the block written by FusedPQ.writeInline
+ *   (B/graph/disk/feature/FusedPQ.java:146-161): neighbour i's code at bytes [i*M,(i+1)*M) of the origin
+ *   node's block, zero-padded to maxDegree*M.
+ * blocks:    count x (maxDegree*M) bytes;  neighbors: count x maxDegree int32 (pad -1), as in the L0 record
+ *            (B/graph/disk/OnDiskGraphIndex.java:538-547).
+ * scores_out[q*maxDegree + i] = similarityToNeighbor(origins[q], i); slots with neighbour id -1 get -INFINITY.
+ * ------------------------------------------------------------------------------------------- */
+JV_API int jv_hip_fused_create(jv_ctx *ctx, const jv_pq *pq, int64_t count, int maxDegree, jv_fused **out);
+JV_API int jv_hip_fused_upload(jv_ctx *ctx, jv_fused *f, int64_t first, int64_t count, const uint8_t *blocks,
+                               const int32_t *neighbors);
+JV_API int jv_hip_fused_destroy(jv_fused *f);
+JV_API int jv_hip_fused_scores(jv_ctx *ctx, const jv_luts *luts, const jv_fused *f, const int32_t *origins,
+                               float *scores_out, int32_t *neighbors_out /* nullable: Q x maxDegree ids */);
+
+/* ---------------------------------------------------------------------------------------------
+ * Full-resolution scoring — SURVEY §8a row 1
+ *   replaces: VectorSimilarityFunction.compare (B/vector/VectorSimilarityFunction.java:37-69) ->
+ *   dot_product_f32 / euclidean_f32 / cosine_f32 (jvector_simd_kernel_list.h:38-40), one call per pair, as
+ *   driven by NodeQueue.rerank (B/graph/NodeQueue.java:160-195).
+ *   Accumulation order is the scalar DefaultVectorUtilSupport order (bit-exact to it).
+ * gather: scores_out[q*B + j] = compare(queries[q], vectors[ordinals[q*B+j]]); ordinal < 0 -> -INFINITY
+ * scan:   scores_out[q*count + i] = compare(queries[q], vectors[first+i])  (brute force / ground truth)
+ * ------------------------------------------------------------------------------------------- */
+JV_API int jv_hip_exact_scores(jv_ctx *ctx, const jv_vectors *v, const float *queries, int Q, jv_vsf vsf,
+                               const int32_t *ordinals, int B, float *scores_out);
+JV_API int jv_hip_exact_scan(jv_ctx *ctx, const jv_vectors *v, const float *queries, int Q, jv_vsf vsf,
+                             int64_t first, int64_t count, float *scores_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Top-k under the NodeQueue total order — SURVEY §8a row 9
+ *   replaces: NodeQueue.encode + BoundedLongHeap.push (B/graph/NodeQueue.java:125-129,
+ *   B/util/BoundedLongHeap.java:59-69, B/util/NumericUtils.java:49-65): higher score first, ties -> smaller id.
+ * scores: Q rows of n floats (row stride `stride` elements);  ids: matching int32 rows, or NULL meaning
+ *   id = id_base + column.  Entries whose id < 0 (explicit ids) are ignored.
+ * out_ids / out_scores: Q x k, best first; when fewer than k valid entries exist the tail is (-1, -INFINITY).
+ * Also the merge step of the sharded configuration: feed the all-gathered partial lists with global ids.
+ * ------------------------------------------------------------------------------------------- */
+JV_API int jv_hip_topk(jv_ctx *ctx, const float *scores, const int32_t *ids, int Q, int64_t n, int64_t stride,
+                       int32_t id_base, int k, int32_t *out_ids, float *out_scores);
+
+/* ---------------------------------------------------------------------------------------------
+ * Two-pass flat search: LUT build -> ADC scan of all codes -> top-rerankK -> exact rerank -> top-K.
+ *   Arithmetic per candidate identical to GraphSearcher's scoring calls (B/graph/GraphSearcher.java:443-450,
+ *   471-507); the candidate SET is the whole shard instead of a graph frontier.
+ *   id_base is added to every returned id (shard offset in the sharded configuration).
+ *   vectors == NULL or rerankK == 0  => no rerank, results are the ADC top-K.
+ * out_ids / out_scores: Q x topK (host or device).
+ * ------------------------------------------------------------------------------------------- */
+JV_API int jv_hip_search_flat(jv_ctx *ctx, jv_luts *luts, const jv_codes *codes, const jv_vectors *vectors,
+                              const float *queries, int Q, jv_vsf vsf, int topK, int rerankK, int32_t id_base,
+                              int32_t *out_ids, float *out_scores);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JVECTOR_HIP_H */

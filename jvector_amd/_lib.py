@@ -1,0 +1,146 @@
+"""ctypes loader for libjvector_hip.so (the C ABI declared in include/jvector_hip.h).
+
+There is no Python/CPU implementation behind this module: if the shared library is missing or no gfx950
+device is usable, the calls raise.  Build the library with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C jvector_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjvector_hip.so")
+
+JV_OK, JV_ERR_INVALID, JV_ERR_NO_DEVICE, JV_ERR_HIP, JV_ERR_OOM, JV_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+
+class JVectorHipError(RuntimeError):
+    """A HIP runtime failure inside libjvector_hip (JV_ERR_HIP / JV_ERR_OOM)."""
+
+
+class NoDeviceError(JVectorHipError):
+    """No usable gfx950 device: the engine has no CPU fallback."""
+
+
+class UnsupportedError(JVectorHipError):
+    """The reference feature exists but is outside the HIP engine's scope (UnsupportedOperationException)."""
+
+
+_p = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/jvector_hip.h one to one
+SIGNATURES = {
+    "jv_hip_version": (C.c_char_p, []),
+    "jv_hip_last_error": (C.c_char_p, []),
+    "jv_hip_device_count": (_i, []),
+    "jv_hip_active_arch": (C.c_char_p, [_i]),
+    "jv_hip_ctx_create": (_i, [_i, _p, C.POINTER(_p)]),
+    "jv_hip_ctx_destroy": (_i, [_p]),
+    "jv_hip_ctx_sync": (_i, [_p]),
+    "jv_hip_ctx_stream": (_p, [_p]),
+    "jv_hip_pq_create": (_i, [_p, _i, _i, _i, _p, _p, _p, C.POINTER(_p)]),
+    "jv_hip_pq_load": (_i, [_p, _p, _sz, C.POINTER(_sz), C.POINTER(_p)]),
+    "jv_hip_pq_destroy": (_i, [_p]),
+    "jv_hip_pq_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "jv_hip_pq_self_magnitudes": (_i, [_p, _p, _p]),
+    "jv_hip_codes_create": (_i, [_p, _p, _i64, C.POINTER(_p)]),
+    "jv_hip_codes_wrap": (_i, [_p, _p, _i64, _p, C.POINTER(_p)]),
+    "jv_hip_codes_upload": (_i, [_p, _p, _i64, _i64, _p]),
+    "jv_hip_codes_download": (_i, [_p, _p, _i64, _i64, _p]),
+    "jv_hip_codes_destroy": (_i, [_p]),
+    "jv_hip_codes_count": (_i64, [_p]),
+    "jv_hip_codes_device_ptr": (_p, [_p]),
+    "jv_hip_vectors_create": (_i, [_p, _i64, _i, C.POINTER(_p)]),
+    "jv_hip_vectors_wrap": (_i, [_p, _i64, _i, _p, C.POINTER(_p)]),
+    "jv_hip_vectors_upload": (_i, [_p, _p, _i64, _i64, _p]),
+    "jv_hip_vectors_destroy": (_i, [_p]),
+    "jv_hip_pq_encode": (_i, [_p, _p, _p, _i64, _p]),
+    "jv_hip_pq_encode_into": (_i, [_p, _p, _p, _i64, _i64, _p]),
+    "jv_hip_luts_create": (_i, [_p, _p, _i, C.POINTER(_p)]),
+    "jv_hip_luts_build": (_i, [_p, _p, _p, _i, _i, _i]),
+    "jv_hip_luts_destroy": (_i, [_p]),
+    "jv_hip_luts_download": (_i, [_p, _p, _i, _p, _p]),
+    "jv_hip_adc_scan": (_i, [_p, _p, _p, _i64, _i64, _p]),
+    "jv_hip_adc_scores": (_i, [_p, _p, _p, _p, _i, _p]),
+    "jv_hip_fused_create": (_i, [_p, _p, _i64, _i, C.POINTER(_p)]),
+    "jv_hip_fused_upload": (_i, [_p, _p, _i64, _i64, _p, _p]),
+    "jv_hip_fused_destroy": (_i, [_p]),
+    "jv_hip_fused_scores": (_i, [_p, _p, _p, _p, _p, _p]),
+    "jv_hip_exact_scores": (_i, [_p, _p, _p, _i, _i, _p, _i, _p]),
+    "jv_hip_exact_scan": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _p]),
+    "jv_hip_topk": (_i, [_p, _p, _p, _i, _i64, _i64, C.c_int32, _i, _p, _p]),
+    "jv_hip_search_flat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_int32, _p, _p]),
+}
+
+# the reference's per-pair SPI, exported unchanged (include/jvector_simd_compat.h)
+_f = C.c_float
+_fp = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_ubyte)
+COMPAT_SIGNATURES = {
+    "cosine_f32": (_f, [_fp, _sz, _fp, _sz, _sz]),
+    "dot_product_f32": (_f, [_fp, _sz, _fp, _sz, _sz]),
+    "euclidean_f32": (_f, [_fp, _sz, _fp, _sz, _sz]),
+    "add_in_place_f32": (None, [_fp, _fp, _sz]),
+    "add_scalar_in_place_f32": (None, [_fp, _f, _sz]),
+    "sub_in_place_f32": (None, [_fp, _fp, _sz]),
+    "sub_scalar_in_place_f32": (None, [_fp, _f, _sz]),
+    "max_f32": (_f, [_fp, _sz]),
+    "min_in_place_f32": (None, [_fp, _fp, _sz]),
+    "assemble_and_sum_f32": (_f, [_fp, _i, _u8p, _i, _sz]),
+    "assemble_and_sum_pq_f32": (_f, [_fp, _sz, _u8p, _i, _u8p, _i, _i]),
+    "pq_decoded_cosine_similarity_f32": (_f, [_u8p, _i, _sz, _i, _fp, _fp, _f]),
+    "calculate_partial_sums_dot_f32": (None, [_fp, _i, _sz, _i, _fp, _i, _fp]),
+    "calculate_partial_sums_euclidean_f32": (None, [_fp, _i, _sz, _i, _fp, _i, _fp]),
+    "calculate_partial_sums_self_magnitude_f32": (None, [_fp, _i, _sz, _i, _fp]),
+    "nvq_quantize_8bit": (None, [_fp, _sz, _f, _f, _f, _f, _u8p]),
+    "nvq_loss": (_f, [_fp, _sz, _f, _f, _f, _f, _i]),
+    "nvq_uniform_loss": (_f, [_fp, _sz, _f, _f, _i]),
+    "nvq_square_l2_distance_8bit": (_f, [_fp, _u8p, _sz, _f, _f, _f, _f]),
+    "nvq_dot_product_8bit": (_f, [_fp, _u8p, _sz, _f, _f, _f, _f]),
+    "nvq_cosine_8bit_packed": (C.c_int64, [_fp, _u8p, _sz, _f, _f, _f, _f, _fp]),
+    "nvq_shuffle_query_in_place_8bit": (None, [_fp, _sz]),
+    "jvector_simd_get_active_isa": (C.c_char_p, []),
+    "jvector_simd_get_max_isa_env": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libjvector_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JVectorHipError(
+                f"{LIB_PATH} not found: build it with `make -C jvector_amd/csrc` (there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for table in (SIGNATURES, COMPAT_SIGNATURES):
+            for name, (res, args) in table.items():
+                fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+                fn.restype = res
+                fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().jv_hip_last_error().decode("utf-8", "replace")
+
+
+def check(status: int):
+    if status == JV_OK:
+        return
+    msg = last_error() or f"libjvector_hip status {status}"
+    if status == JV_ERR_INVALID:
+        raise ValueError(msg)  # IllegalArgumentException / IndexOutOfBoundsException in the reference
+    if status == JV_ERR_NO_DEVICE:
+        raise NoDeviceError(msg)
+    if status == JV_ERR_UNSUPPORTED:
+        raise UnsupportedError(msg)
+    if status == JV_ERR_OOM:
+        raise MemoryError(msg)
+    raise JVectorHipError(msg)

@@ -1,0 +1,966 @@
+// cabi.cpp — host side of libjvector_hip.so: contexts, device-resident objects, staging of host
+// buffers, and the extern "C" entry points declared in include/jvector_hip.h.
+//
+// No CPU fallback lives here: every compute entry point launches HIP kernels on the context's stream and
+// fails with JV_ERR_NO_DEVICE / JV_ERR_HIP when that is impossible.
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+
+#include "jv_device.h"
+#include "jv_internal.h"
+
+namespace jv {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+void clear_error() { g_err[0] = 0; }
+
+int Buffer::reserve(size_t bytes)
+{
+    if (bytes <= cap) return JV_OK;
+    size_t want = std::max(bytes, cap + cap / 2);
+    want = (want + 4095) & ~(size_t)4095;
+    void *np = nullptr;
+    hipError_t e = pinned_host ? hipHostMalloc(&np, want, hipHostMallocDefault) : hipMalloc(&np, want);
+    if (e != hipSuccess) {
+        set_error("%s of %zu bytes failed: %s", pinned_host ? "hipHostMalloc" : "hipMalloc", want, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return JV_ERR_OOM;
+    }
+    release();
+    ptr = np;
+    cap = want;
+    return JV_OK;
+}
+
+void Buffer::release()
+{
+    if (ptr) {
+        if (pinned_host) (void)hipHostFree(ptr);
+        else (void)hipFree(ptr);
+    }
+    ptr = nullptr;
+    cap = 0;
+}
+
+// true when p is device-accessible memory we can hand to a kernel directly
+static bool is_device_ptr(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// Brings `bytes` at `src` onto the device.  Device pointers pass through; host memory is copied through
+// the pinned staging buffer `pin` into `dev` on the context's stream.
+static int stage_in(jv_ctx *ctx, const void *src, size_t bytes, Buffer &pin, Buffer &dev, const void **out)
+{
+    if (bytes == 0) {
+        *out = src;
+        return JV_OK;
+    }
+    if (is_device_ptr(src)) {
+        *out = src;
+        return JV_OK;
+    }
+    JV_TRY(dev.reserve(bytes));
+    // The pinned buffer is reused across calls: make sure the previous async copy out of it has finished.
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    JV_TRY(pin.reserve(bytes));
+    memcpy(pin.ptr, src, bytes);
+    JV_HIP_CHECK(hipMemcpyAsync(dev.ptr, pin.ptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *out = dev.ptr;
+    return JV_OK;
+}
+
+struct OutStage {
+    void *user = nullptr;   // user pointer
+    void *dev = nullptr;    // device pointer kernels write to
+    size_t bytes = 0;
+    bool host = false;
+};
+
+static int stage_out_begin(jv_ctx *ctx, void *dst, size_t bytes, Buffer &dev, OutStage *st)
+{
+    st->user = dst;
+    st->bytes = bytes;
+    if (bytes == 0 || is_device_ptr(dst)) {
+        st->dev = dst;
+        st->host = false;
+        return JV_OK;
+    }
+    JV_TRY(dev.reserve(bytes));
+    st->dev = dev.ptr;
+    st->host = true;
+    return JV_OK;
+}
+
+// Copies a staged output back to the user's host buffer (synchronises the stream); no-op for device outputs.
+static int stage_out_end(jv_ctx *ctx, const OutStage &st)
+{
+    if (!st.host || st.bytes == 0) return JV_OK;
+    JV_TRY(ctx->h_out.reserve(st.bytes));
+    JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, st.dev, st.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memcpy(st.user, ctx->h_out.ptr, st.bytes);
+    return JV_OK;
+}
+
+static int to_kernel_vsf(jv_vsf v)
+{
+    switch (v) {
+    case JV_EUCLIDEAN: return VSF_L2;
+    case JV_DOT_PRODUCT: return VSF_DOT;
+    default: return VSF_COS;
+    }
+}
+
+static int use_device(int device)
+{
+    JV_HIP_CHECK(hipSetDevice(device));
+    return JV_OK;
+}
+
+// big-endian readers for the reference's wire format (B/disk/IndexWriter.java:36-42)
+static int32_t rd_i32(const uint8_t *p)
+{
+    return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]);
+}
+static float rd_f32(const uint8_t *p)
+{
+    int32_t b = rd_i32(p);
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+static int ensure_code_norms(jv_ctx *ctx, jv_codes *codes)
+{
+    if (codes->norms_valid) return JV_OK;
+    if (!codes->d_norms) JV_HIP_CHECK(hipMalloc((void **)&codes->d_norms, sizeof(float) * (size_t)std::max<int64_t>(codes->count, 1)));
+    JV_TRY(launch_code_norms(ctx->stream, ctx, codes->pq->d_self_mag, codes->M, codes->d_codes, codes->count,
+                             codes->d_norms));
+    codes->norms_valid = true;
+    return JV_OK;
+}
+
+static int ensure_fused_norms(jv_ctx *ctx, jv_fused *f)
+{
+    if (f->norms_valid) return JV_OK;
+    const int64_t rows = f->count * f->maxDegree;
+    if (!f->d_norms) JV_HIP_CHECK(hipMalloc((void **)&f->d_norms, sizeof(float) * (size_t)std::max<int64_t>(rows, 1)));
+    JV_TRY(launch_code_norms(ctx->stream, ctx, f->pq->d_self_mag, f->M, f->d_blocks, rows, f->d_norms));
+    f->norms_valid = true;
+    return JV_OK;
+}
+
+}  // namespace jv
+
+using namespace jv;
+
+extern "C" {
+
+const char *jv_hip_version(void) { return "jvector-hip 0.1 (gfx950)"; }
+const char *jv_hip_last_error(void) { return g_err; }
+
+int jv_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *jv_hip_active_arch(int device)
+{
+    static thread_local char name[256];
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return "none";
+    }
+    snprintf(name, sizeof(name), "%s", prop.gcnArchName);
+    return name;
+}
+
+int jv_hip_ctx_create(int device, void *stream, jv_ctx **out)
+{
+    clear_error();
+    JV_REQUIRE(out != nullptr, "ctx_create: out is NULL");
+    *out = nullptr;
+    int n = jv_hip_device_count();
+    if (n <= 0) {
+        set_error("no HIP device visible (libjvector_hip has no CPU fallback)");
+        return JV_ERR_NO_DEVICE;
+    }
+    JV_REQUIRE(device >= 0 && device < n, "ctx_create: device %d out of range [0,%d)", device, n);
+    JV_TRY(use_device(device));
+    hipDeviceProp_t prop;
+    JV_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library contains gfx950 code objects only", device, prop.gcnArchName);
+        return JV_ERR_NO_DEVICE;
+    }
+    jv_ctx *c = new jv_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    c->lds_per_block = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor
+                                                             : (size_t)prop.sharedMemPerBlock;
+    if (c->lds_per_block > 160 * 1024) c->lds_per_block = 160 * 1024;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->owns_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete c;
+            return JV_ERR_HIP;
+        }
+        c->owns_stream = true;
+    }
+    c->h_in.pinned_host = true;
+    c->h_out.pinned_host = true;
+    *out = c;
+    return JV_OK;
+}
+
+int jv_hip_ctx_destroy(jv_ctx *ctx)
+{
+    if (!ctx) return JV_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->h_in.release();
+    ctx->h_out.release();
+    ctx->d_in.release();
+    ctx->d_out.release();
+    ctx->d_scratch.release();
+    ctx->d_scratch2.release();
+    ctx->d_scratch3.release();
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return JV_OK;
+}
+
+int jv_hip_ctx_sync(jv_ctx *ctx)
+{
+    JV_REQUIRE(ctx, "ctx is NULL");
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return JV_OK;
+}
+
+void *jv_hip_ctx_stream(jv_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------------
+// ProductQuantization
+// ------------------------------------------------------------------------------------------------
+int jv_hip_pq_create(jv_ctx *ctx, int D, int M, int k, const int *sizes, const float *codebooks, const float *centroid,
+                     jv_pq **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && out && codebooks, "pq_create: NULL argument");
+    *out = nullptr;
+    JV_REQUIRE(D > 0 && M > 0, "pq_create: D and M must be positive");
+    // ProductQuantization.getSubvectorSizesAndOffsets :536-538
+    JV_REQUIRE(M <= D, "Number of subspaces must be less than or equal to the vector dimension");
+    if (k != kClusters) {
+        set_error("pq_create: clusterCount %d unsupported (codes are one byte: k must be 256)", k);
+        return JV_ERR_UNSUPPORTED;
+    }
+    JV_TRY(use_device(ctx->device));
+    jv_pq *pq = new jv_pq();
+    pq->device = ctx->device;
+    pq->D = D;
+    pq->M = M;
+    pq->k = k;
+    pq->sizes.resize(M);
+    pq->offsets.resize(M);
+    pq->cb_offsets.resize(M);
+    int off = 0;
+    int64_t cbo = 0;
+    for (int m = 0; m < M; ++m) {
+        int size = sizes ? sizes[m] : (D / M + (m < D % M ? 1 : 0));
+        if (size <= 0) {
+            delete pq;
+            set_error("pq_create: subvector size %d at m=%d", size, m);
+            return JV_ERR_INVALID;
+        }
+        pq->sizes[m] = size;
+        pq->offsets[m] = off;
+        pq->cb_offsets[m] = cbo;
+        off += size;
+        cbo += (int64_t)k * size;
+        pq->max_size = std::max(pq->max_size, size);
+    }
+    if (off != D) {
+        delete pq;
+        set_error("pq_create: subvector sizes sum to %d, expected D=%d", off, D);
+        return JV_ERR_INVALID;
+    }
+    pq->uniform = std::all_of(pq->sizes.begin(), pq->sizes.end(), [&](int s) { return s == pq->sizes[0]; });
+
+    auto fail = [&](int st) {
+        jv_hip_pq_destroy(pq);
+        return st;
+    };
+#define PQ_CHECK(expr)                                                                   \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            set_error("%s failed: %s", #expr, hipGetErrorString(_e));                    \
+            (void)hipGetLastError();                                                     \
+            return fail(_e == hipErrorOutOfMemory ? JV_ERR_OOM : JV_ERR_HIP);            \
+        }                                                                                \
+    } while (0)
+    PQ_CHECK(hipMalloc((void **)&pq->d_sizes, sizeof(int) * M));
+    PQ_CHECK(hipMalloc((void **)&pq->d_offsets, sizeof(int) * M));
+    PQ_CHECK(hipMalloc((void **)&pq->d_cb_offsets, sizeof(int64_t) * M));
+    PQ_CHECK(hipMalloc((void **)&pq->d_codebooks, sizeof(float) * (size_t)cbo));
+    PQ_CHECK(hipMalloc((void **)&pq->d_self_mag, sizeof(float) * (size_t)M * k));
+    PQ_CHECK(hipMemcpy(pq->d_sizes, pq->sizes.data(), sizeof(int) * M, hipMemcpyHostToDevice));
+    PQ_CHECK(hipMemcpy(pq->d_offsets, pq->offsets.data(), sizeof(int) * M, hipMemcpyHostToDevice));
+    PQ_CHECK(hipMemcpy(pq->d_cb_offsets, pq->cb_offsets.data(), sizeof(int64_t) * M, hipMemcpyHostToDevice));
+    PQ_CHECK(hipMemcpy(pq->d_codebooks, codebooks, sizeof(float) * (size_t)cbo, hipMemcpyDefault));
+    if (centroid) {
+        PQ_CHECK(hipMalloc((void **)&pq->d_centroid, sizeof(float) * D));
+        PQ_CHECK(hipMemcpy(pq->d_centroid, centroid, sizeof(float) * D, hipMemcpyDefault));
+    }
+#undef PQ_CHECK
+    int st = launch_self_magnitudes(ctx->stream, pq);
+    if (st != JV_OK) return fail(st);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        set_error("pq_create: self-magnitude kernel failed");
+        return fail(JV_ERR_HIP);
+    }
+    *out = pq;
+    return JV_OK;
+}
+
+int jv_hip_pq_load(jv_ctx *ctx, const uint8_t *buf, size_t len, size_t *consumed, jv_pq **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && buf && out, "pq_load: NULL argument");
+    // ProductQuantization.load :649-693
+    size_t p = 0;
+#define NEED(nb) JV_REQUIRE(p + (size_t)(nb) <= len, "pq_load: truncated input at byte %zu", p)
+    NEED(4);
+    int32_t maybeMagic = rd_i32(buf + p);
+    p += 4;
+    int version, gcl;
+    if (maybeMagic != 0x75EC4012) {
+        version = 0;
+        gcl = maybeMagic;
+    } else {
+        NEED(8);
+        version = rd_i32(buf + p);
+        p += 4;
+        gcl = rd_i32(buf + p);
+        p += 4;
+    }
+    JV_REQUIRE(gcl >= 0 && gcl < (1 << 24), "pq_load: implausible centroid length %d", gcl);
+    std::vector<float> centroid;
+    if (gcl > 0) {
+        NEED((size_t)gcl * 4);
+        centroid.resize(gcl);
+        for (int i = 0; i < gcl; ++i, p += 4) centroid[i] = rd_f32(buf + p);
+    }
+    NEED(4);
+    int M = rd_i32(buf + p);
+    p += 4;
+    JV_REQUIRE(M > 0 && M < (1 << 20), "pq_load: implausible M %d", M);
+    NEED((size_t)M * 4);
+    std::vector<int> sizes(M);
+    int D = 0;
+    for (int i = 0; i < M; ++i, p += 4) {
+        sizes[i] = rd_i32(buf + p);
+        JV_REQUIRE(sizes[i] > 0, "pq_load: bad subvector size");
+        D += sizes[i];
+    }
+    float aniso = -1.0f;
+    if (version >= 3) {
+        NEED(4);
+        aniso = rd_f32(buf + p);
+        p += 4;
+    }
+    if (aniso > -1.0f) {
+        set_error("pq_load: anisotropic PQ (threshold %g) is not supported by the HIP encoder", (double)aniso);
+        return JV_ERR_UNSUPPORTED;
+    }
+    NEED(4);
+    int k = rd_i32(buf + p);
+    p += 4;
+    JV_REQUIRE(k > 0 && k <= 65536, "pq_load: implausible cluster count %d", k);
+    size_t total = (size_t)k * (size_t)D;
+    NEED(total * 4);
+    std::vector<float> cbs(total);
+    for (size_t i = 0; i < total; ++i, p += 4) cbs[i] = rd_f32(buf + p);
+#undef NEED
+    JV_REQUIRE(gcl == 0 || gcl == D, "Global centroid length %d does not match vector dimensionality %d", gcl, D);
+    if (consumed) *consumed = p;
+    return jv_hip_pq_create(ctx, D, M, k, sizes.data(), cbs.data(), gcl ? centroid.data() : nullptr, out);
+}
+
+int jv_hip_pq_destroy(jv_pq *pq)
+{
+    if (!pq) return JV_OK;
+    (void)hipSetDevice(pq->device);
+    (void)hipFree(pq->d_sizes);
+    (void)hipFree(pq->d_offsets);
+    (void)hipFree(pq->d_cb_offsets);
+    (void)hipFree(pq->d_codebooks);
+    (void)hipFree(pq->d_centroid);
+    (void)hipFree(pq->d_self_mag);
+    delete pq;
+    return JV_OK;
+}
+
+int jv_hip_pq_info(const jv_pq *pq, int *D, int *M, int *k, int *has_centroid)
+{
+    JV_REQUIRE(pq, "pq is NULL");
+    if (D) *D = pq->D;
+    if (M) *M = pq->M;
+    if (k) *k = pq->k;
+    if (has_centroid) *has_centroid = pq->d_centroid != nullptr;
+    return JV_OK;
+}
+
+int jv_hip_pq_self_magnitudes(jv_ctx *ctx, const jv_pq *pq, float *out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && out, "NULL argument");
+    JV_TRY(use_device(ctx->device));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    JV_HIP_CHECK(hipMemcpy(out, pq->d_self_mag, sizeof(float) * (size_t)pq->M * pq->k, hipMemcpyDefault));
+    return JV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PQVectors code store
+// ------------------------------------------------------------------------------------------------
+int jv_hip_codes_create(jv_ctx *ctx, const jv_pq *pq, int64_t count, jv_codes **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && out, "codes_create: NULL argument");
+    JV_REQUIRE(count > 0, "Invalid vector count %lld", (long long)count);  // PQLayout :516-518
+    JV_TRY(use_device(ctx->device));
+    jv_codes *c = new jv_codes();
+    c->device = ctx->device;
+    c->pq = pq;
+    c->count = count;
+    c->M = pq->M;
+    c->owns = true;
+    hipError_t e = hipMalloc((void **)&c->d_codes, (size_t)count * pq->M + 64);
+    if (e != hipSuccess) {
+        set_error("codes_create: hipMalloc(%lld x %d) failed: %s", (long long)count, pq->M, hipGetErrorString(e));
+        (void)hipGetLastError();
+        delete c;
+        return JV_ERR_OOM;
+    }
+    *out = c;
+    return JV_OK;
+}
+
+int jv_hip_codes_wrap(jv_ctx *ctx, const jv_pq *pq, int64_t count, void *device_codes, jv_codes **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && out && device_codes, "codes_wrap: NULL argument");
+    JV_REQUIRE(count > 0, "Invalid vector count %lld", (long long)count);
+    JV_REQUIRE(is_device_ptr(device_codes), "codes_wrap: pointer is not device memory");
+    jv_codes *c = new jv_codes();
+    c->device = ctx->device;
+    c->pq = pq;
+    c->count = count;
+    c->M = pq->M;
+    c->owns = false;
+    c->d_codes = (uint8_t *)device_codes;
+    *out = c;
+    return JV_OK;
+}
+
+int jv_hip_codes_upload(jv_ctx *ctx, jv_codes *codes, int64_t first, int64_t count, const uint8_t *src)
+{
+    clear_error();
+    JV_REQUIRE(ctx && codes && src, "codes_upload: NULL argument");
+    JV_REQUIRE(first >= 0 && count >= 0 && first + count <= codes->count,
+               "Ordinal range [%lld,%lld) out of bounds for vector count %lld", (long long)first,
+               (long long)(first + count), (long long)codes->count);
+    JV_TRY(use_device(ctx->device));
+    JV_HIP_CHECK(hipMemcpyAsync(codes->d_codes + first * codes->M, src, (size_t)count * codes->M, hipMemcpyDefault,
+                                ctx->stream));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    codes->norms_valid = false;
+    return JV_OK;
+}
+
+int jv_hip_codes_download(jv_ctx *ctx, const jv_codes *codes, int64_t first, int64_t count, uint8_t *dst)
+{
+    clear_error();
+    JV_REQUIRE(ctx && codes && dst, "codes_download: NULL argument");
+    JV_REQUIRE(first >= 0 && count >= 0 && first + count <= codes->count, "Ordinal range out of bounds");
+    JV_TRY(use_device(ctx->device));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    JV_HIP_CHECK(hipMemcpy(dst, codes->d_codes + first * codes->M, (size_t)count * codes->M, hipMemcpyDefault));
+    return JV_OK;
+}
+
+int jv_hip_codes_destroy(jv_codes *c)
+{
+    if (!c) return JV_OK;
+    (void)hipSetDevice(c->device);
+    if (c->owns) (void)hipFree(c->d_codes);
+    (void)hipFree(c->d_norms);
+    delete c;
+    return JV_OK;
+}
+
+int64_t jv_hip_codes_count(const jv_codes *c) { return c ? c->count : 0; }
+void *jv_hip_codes_device_ptr(const jv_codes *c) { return c ? (void *)c->d_codes : nullptr; }
+
+// ------------------------------------------------------------------------------------------------
+// full-resolution vectors
+// ------------------------------------------------------------------------------------------------
+int jv_hip_vectors_create(jv_ctx *ctx, int64_t count, int D, jv_vectors **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && out, "vectors_create: NULL argument");
+    JV_REQUIRE(count > 0 && D > 0, "vectors_create: count and D must be positive");
+    JV_TRY(use_device(ctx->device));
+    jv_vectors *v = new jv_vectors();
+    v->device = ctx->device;
+    v->count = count;
+    v->D = D;
+    v->owns = true;
+    hipError_t e = hipMalloc((void **)&v->d_vecs, sizeof(float) * (size_t)count * D);
+    if (e != hipSuccess) {
+        set_error("vectors_create: hipMalloc failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        delete v;
+        return JV_ERR_OOM;
+    }
+    *out = v;
+    return JV_OK;
+}
+
+int jv_hip_vectors_wrap(jv_ctx *ctx, int64_t count, int D, void *device_vectors, jv_vectors **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && out && device_vectors, "vectors_wrap: NULL argument");
+    JV_REQUIRE(count > 0 && D > 0, "vectors_wrap: count and D must be positive");
+    JV_REQUIRE(is_device_ptr(device_vectors), "vectors_wrap: pointer is not device memory");
+    jv_vectors *v = new jv_vectors();
+    v->device = ctx->device;
+    v->count = count;
+    v->D = D;
+    v->owns = false;
+    v->d_vecs = (float *)device_vectors;
+    *out = v;
+    return JV_OK;
+}
+
+int jv_hip_vectors_upload(jv_ctx *ctx, jv_vectors *v, int64_t first, int64_t count, const float *src)
+{
+    clear_error();
+    JV_REQUIRE(ctx && v && src, "vectors_upload: NULL argument");
+    JV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->count, "vectors_upload: range out of bounds");
+    JV_TRY(use_device(ctx->device));
+    JV_HIP_CHECK(hipMemcpyAsync(v->d_vecs + first * v->D, src, sizeof(float) * (size_t)count * v->D, hipMemcpyDefault,
+                                ctx->stream));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return JV_OK;
+}
+
+int jv_hip_vectors_destroy(jv_vectors *v)
+{
+    if (!v) return JV_OK;
+    (void)hipSetDevice(v->device);
+    if (v->owns) (void)hipFree(v->d_vecs);
+    delete v;
+    return JV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode
+// ------------------------------------------------------------------------------------------------
+int jv_hip_pq_encode(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t count, uint8_t *codes_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq, "pq_encode: NULL argument");
+    JV_REQUIRE(count >= 0, "pq_encode: negative count");
+    if (count == 0) return JV_OK;
+    JV_REQUIRE(vectors && codes_out, "pq_encode: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    const void *d_v = nullptr;
+    JV_TRY(stage_in(ctx, vectors, sizeof(float) * (size_t)count * pq->D, ctx->h_in, ctx->d_in, &d_v));
+    OutStage os;
+    JV_TRY(stage_out_begin(ctx, codes_out, (size_t)count * pq->M, ctx->d_out, &os));
+    JV_TRY(launch_pq_encode(ctx->stream, pq, (const float *)d_v, count, (uint8_t *)os.dev));
+    return stage_out_end(ctx, os);
+}
+
+int jv_hip_pq_encode_into(jv_ctx *ctx, const jv_pq *pq, const jv_vectors *v, int64_t first, int64_t count,
+                          jv_codes *codes)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && v && codes, "pq_encode_into: NULL argument");
+    JV_REQUIRE(v->D == pq->D, "vector dimension %d does not match PQ dimension %d", v->D, pq->D);
+    JV_REQUIRE(codes->M == pq->M, "code store M %d does not match PQ M %d", codes->M, pq->M);
+    JV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->count && first + count <= codes->count,
+               "pq_encode_into: range out of bounds");
+    JV_TRY(use_device(ctx->device));
+    JV_TRY(launch_pq_encode(ctx->stream, pq, v->d_vecs + first * v->D, count, codes->d_codes + first * codes->M));
+    codes->norms_valid = false;
+    return JV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LUTs
+// ------------------------------------------------------------------------------------------------
+int jv_hip_luts_create(jv_ctx *ctx, const jv_pq *pq, int max_queries, jv_luts **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && out, "luts_create: NULL argument");
+    JV_REQUIRE(max_queries > 0, "luts_create: max_queries must be positive");
+    JV_TRY(use_device(ctx->device));
+    jv_luts *l = new jv_luts();
+    l->device = ctx->device;
+    l->pq = pq;
+    l->capacity = max_queries;
+    auto fail = [&](hipError_t e) {
+        set_error("luts_create: hipMalloc failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        jv_hip_luts_destroy(l);
+        return JV_ERR_OOM;
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&l->d_luts, sizeof(float) * (size_t)max_queries * pq->M * kClusters)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&l->d_bmag, sizeof(float) * (size_t)max_queries)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&l->d_queries, sizeof(float) * (size_t)max_queries * pq->D)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc((void **)&l->d_raw_queries, sizeof(float) * (size_t)max_queries * pq->D)) != hipSuccess) return fail(e);
+    *out = l;
+    return JV_OK;
+}
+
+int jv_hip_luts_destroy(jv_luts *l)
+{
+    if (!l) return JV_OK;
+    (void)hipSetDevice(l->device);
+    (void)hipFree(l->d_luts);
+    (void)hipFree(l->d_bmag);
+    (void)hipFree(l->d_queries);
+    (void)hipFree(l->d_raw_queries);
+    delete l;
+    return JV_OK;
+}
+
+int jv_hip_luts_build(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_vsf vsf, jv_decoder_kind kind)
+{
+    clear_error();
+    JV_REQUIRE(ctx && l, "luts_build: NULL argument");
+    JV_REQUIRE(Q >= 0 && Q <= l->capacity, "luts_build: Q=%d exceeds capacity %d", Q, l->capacity);
+    JV_REQUIRE(vsf == JV_EUCLIDEAN || vsf == JV_DOT_PRODUCT || vsf == JV_COSINE, "Unsupported similarity function %d",
+               (int)vsf);
+    l->Q = Q;
+    l->vsf = vsf;
+    l->kind = kind;
+    if (Q == 0) return JV_OK;
+    JV_REQUIRE(queries, "luts_build: queries is NULL");
+    JV_TRY(use_device(ctx->device));
+    const jv_pq *pq = l->pq;
+    const size_t qbytes = sizeof(float) * (size_t)Q * pq->D;
+    if (is_device_ptr(queries)) {
+        JV_HIP_CHECK(hipMemcpyAsync(l->d_raw_queries, queries, qbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        JV_TRY(ctx->h_in.reserve(qbytes));
+        memcpy(ctx->h_in.ptr, queries, qbytes);
+        JV_HIP_CHECK(hipMemcpyAsync(l->d_raw_queries, ctx->h_in.ptr, qbytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    JV_TRY(launch_center_queries(ctx->stream, pq, l->d_raw_queries, Q, l->d_queries));
+    // cosine numerator uses the DOT_PRODUCT partial sums (PQDecoder.java:117, FusedPQDecoder.java:187)
+    const int lut_vsf = (vsf == JV_EUCLIDEAN) ? VSF_L2 : VSF_DOT;
+    JV_TRY(launch_lut_build(ctx->stream, pq, l->d_queries, Q, lut_vsf, l->d_luts));
+    if (vsf == JV_COSINE)
+        JV_TRY(launch_query_magnitudes(ctx->stream, pq, l->d_queries, Q, kind == JV_DECODER_FUSED ? 1 : 0, l->d_bmag));
+    return JV_OK;
+}
+
+int jv_hip_luts_download(jv_ctx *ctx, const jv_luts *l, int q, float *lut_out, float *bmag_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && l, "luts_download: NULL argument");
+    JV_REQUIRE(q >= 0 && q < l->Q, "luts_download: query %d out of range", q);
+    JV_TRY(use_device(ctx->device));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const size_t n = (size_t)l->pq->M * kClusters;
+    if (lut_out) JV_HIP_CHECK(hipMemcpy(lut_out, l->d_luts + (size_t)q * n, sizeof(float) * n, hipMemcpyDefault));
+    if (bmag_out) {
+        if (l->vsf == JV_COSINE) JV_HIP_CHECK(hipMemcpy(bmag_out, l->d_bmag + q, sizeof(float), hipMemcpyDefault));
+        else *bmag_out = 0.0f;
+    }
+    return JV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ADC
+// ------------------------------------------------------------------------------------------------
+int jv_hip_adc_scan(jv_ctx *ctx, const jv_luts *l, const jv_codes *codes, int64_t first, int64_t count,
+                    float *scores_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && l && codes, "adc_scan: NULL argument");
+    JV_REQUIRE(codes->pq == l->pq, "adc_scan: LUTs and codes belong to different ProductQuantizations");
+    JV_REQUIRE(first >= 0 && count >= 0 && first + count <= codes->count,
+               "Ordinal range [%lld,%lld) out of bounds for vector count %lld", (long long)first,
+               (long long)(first + count), (long long)codes->count);
+    if (l->Q == 0 || count == 0) return JV_OK;
+    JV_REQUIRE(scores_out, "adc_scan: scores_out is NULL");
+    JV_TRY(use_device(ctx->device));
+    if (l->vsf == JV_COSINE) JV_TRY(ensure_code_norms(ctx, const_cast<jv_codes *>(codes)));
+    OutStage os;
+    JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)l->Q * count, ctx->d_out, &os));
+    JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, codes->M, to_kernel_vsf(l->vsf), codes->d_codes,
+                      codes->d_norms, codes->count, first, count, nullptr, (float *)os.dev));
+    return stage_out_end(ctx, os);
+}
+
+int jv_hip_adc_scores(jv_ctx *ctx, const jv_luts *l, const jv_codes *codes, const int32_t *ordinals, int B,
+                      float *scores_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && l && codes, "adc_scores: NULL argument");
+    JV_REQUIRE(codes->pq == l->pq, "adc_scores: LUTs and codes belong to different ProductQuantizations");
+    JV_REQUIRE(B >= 0, "adc_scores: negative batch");
+    if (l->Q == 0 || B == 0) return JV_OK;
+    JV_REQUIRE(ordinals && scores_out, "adc_scores: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    if (l->vsf == JV_COSINE) JV_TRY(ensure_code_norms(ctx, const_cast<jv_codes *>(codes)));
+    const void *d_ord = nullptr;
+    JV_TRY(stage_in(ctx, ordinals, sizeof(int32_t) * (size_t)l->Q * B, ctx->h_in, ctx->d_in, &d_ord));
+    OutStage os;
+    JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)l->Q * B, ctx->d_out, &os));
+    JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, codes->M, to_kernel_vsf(l->vsf), codes->d_codes,
+                      codes->d_norms, codes->count, 0, B, (const int32_t *)d_ord, (float *)os.dev));
+    return stage_out_end(ctx, os);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused PQ
+// ------------------------------------------------------------------------------------------------
+int jv_hip_fused_create(jv_ctx *ctx, const jv_pq *pq, int64_t count, int maxDegree, jv_fused **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && out, "fused_create: NULL argument");
+    JV_REQUIRE(count > 0 && maxDegree > 0 && maxDegree < 2048, "fused_create: bad count/maxDegree");
+    // FusedPQ requires a 256-cluster PQ (FusedPQ.java:57-59) — already guaranteed by pq_create
+    JV_TRY(use_device(ctx->device));
+    jv_fused *f = new jv_fused();
+    f->device = ctx->device;
+    f->pq = pq;
+    f->count = count;
+    f->maxDegree = maxDegree;
+    f->M = pq->M;
+    hipError_t e1 = hipMalloc((void **)&f->d_blocks, (size_t)count * maxDegree * pq->M + 64);
+    hipError_t e2 = hipMalloc((void **)&f->d_neighbors, sizeof(int32_t) * (size_t)count * maxDegree);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        set_error("fused_create: hipMalloc failed");
+        (void)hipGetLastError();
+        jv_hip_fused_destroy(f);
+        return JV_ERR_OOM;
+    }
+    *out = f;
+    return JV_OK;
+}
+
+int jv_hip_fused_upload(jv_ctx *ctx, jv_fused *f, int64_t first, int64_t count, const uint8_t *blocks,
+                        const int32_t *neighbors)
+{
+    clear_error();
+    JV_REQUIRE(ctx && f && blocks && neighbors, "fused_upload: NULL argument");
+    JV_REQUIRE(first >= 0 && count >= 0 && first + count <= f->count, "fused_upload: range out of bounds");
+    JV_TRY(use_device(ctx->device));
+    const size_t bsz = (size_t)f->maxDegree * f->M;
+    JV_HIP_CHECK(hipMemcpyAsync(f->d_blocks + first * bsz, blocks, (size_t)count * bsz, hipMemcpyDefault, ctx->stream));
+    JV_HIP_CHECK(hipMemcpyAsync(f->d_neighbors + first * f->maxDegree, neighbors,
+                                sizeof(int32_t) * (size_t)count * f->maxDegree, hipMemcpyDefault, ctx->stream));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    f->norms_valid = false;
+    return JV_OK;
+}
+
+int jv_hip_fused_destroy(jv_fused *f)
+{
+    if (!f) return JV_OK;
+    (void)hipSetDevice(f->device);
+    (void)hipFree(f->d_blocks);
+    (void)hipFree(f->d_neighbors);
+    (void)hipFree(f->d_norms);
+    delete f;
+    return JV_OK;
+}
+
+int jv_hip_fused_scores(jv_ctx *ctx, const jv_luts *l, const jv_fused *f, const int32_t *origins, float *scores_out,
+                        int32_t *neighbors_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && l && f, "fused_scores: NULL argument");
+    JV_REQUIRE(f->pq == l->pq, "fused_scores: LUTs and fused blocks belong to different ProductQuantizations");
+    if (l->Q == 0) return JV_OK;
+    JV_REQUIRE(origins && scores_out, "fused_scores: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    if (l->vsf == JV_COSINE) JV_TRY(ensure_fused_norms(ctx, const_cast<jv_fused *>(f)));
+    const void *d_org = nullptr;
+    JV_TRY(stage_in(ctx, origins, sizeof(int32_t) * (size_t)l->Q, ctx->h_in, ctx->d_in, &d_org));
+    OutStage os, ns;
+    const size_t cells = (size_t)l->Q * f->maxDegree;
+    JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * cells, ctx->d_out, &os));
+    if (neighbors_out) JV_TRY(stage_out_begin(ctx, neighbors_out, sizeof(int32_t) * cells, ctx->d_scratch, &ns));
+    JV_TRY(launch_fused(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, f->M, to_kernel_vsf(l->vsf), f->d_blocks,
+                        f->d_neighbors, f->d_norms, f->maxDegree, f->count, (const int32_t *)d_org, (float *)os.dev,
+                        neighbors_out ? (int32_t *)ns.dev : nullptr));
+    JV_TRY(stage_out_end(ctx, os));
+    if (neighbors_out) JV_TRY(stage_out_end(ctx, ns));
+    return JV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact scoring
+// ------------------------------------------------------------------------------------------------
+int jv_hip_exact_scores(jv_ctx *ctx, const jv_vectors *v, const float *queries, int Q, jv_vsf vsf,
+                        const int32_t *ordinals, int B, float *scores_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && v, "exact_scores: NULL argument");
+    JV_REQUIRE(Q >= 0 && B >= 0, "exact_scores: negative sizes");
+    if (Q == 0 || B == 0) return JV_OK;
+    JV_REQUIRE(queries && ordinals && scores_out, "exact_scores: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    // two host inputs may both need staging: use separate device buffers, one pinned staging pass each
+    const void *d_q = nullptr, *d_ord = nullptr;
+    JV_TRY(stage_in(ctx, queries, sizeof(float) * (size_t)Q * v->D, ctx->h_in, ctx->d_in, &d_q));
+    JV_TRY(stage_in(ctx, ordinals, sizeof(int32_t) * (size_t)Q * B, ctx->h_in, ctx->d_scratch2, &d_ord));
+    JV_TRY(ctx->d_scratch3.reserve(sizeof(float) * (size_t)Q));
+    OutStage os;
+    JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)Q * B, ctx->d_out, &os));
+    JV_TRY(launch_exact_gather(ctx->stream, v->d_vecs, v->count, v->D, (const float *)d_q, Q, to_kernel_vsf(vsf),
+                               (const int32_t *)d_ord, B, (float *)os.dev, (float *)ctx->d_scratch3.ptr));
+    return stage_out_end(ctx, os);
+}
+
+int jv_hip_exact_scan(jv_ctx *ctx, const jv_vectors *v, const float *queries, int Q, jv_vsf vsf, int64_t first,
+                      int64_t count, float *scores_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && v, "exact_scan: NULL argument");
+    JV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->count, "exact_scan: range out of bounds");
+    if (Q == 0 || count == 0) return JV_OK;
+    JV_REQUIRE(queries && scores_out, "exact_scan: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    const void *d_q = nullptr;
+    JV_TRY(stage_in(ctx, queries, sizeof(float) * (size_t)Q * v->D, ctx->h_in, ctx->d_in, &d_q));
+    JV_TRY(ctx->d_scratch3.reserve(sizeof(float) * (size_t)Q));
+    OutStage os;
+    JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)Q * count, ctx->d_out, &os));
+    JV_TRY(launch_exact_scan(ctx->stream, ctx, v->d_vecs, v->D, (const float *)d_q, Q, to_kernel_vsf(vsf), first, count,
+                             (float *)os.dev, (float *)ctx->d_scratch3.ptr));
+    return stage_out_end(ctx, os);
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k
+// ------------------------------------------------------------------------------------------------
+int jv_hip_topk(jv_ctx *ctx, const float *scores, const int32_t *ids, int Q, int64_t n, int64_t stride,
+                int32_t id_base, int k, int32_t *out_ids, float *out_scores)
+{
+    clear_error();
+    JV_REQUIRE(ctx, "topk: ctx is NULL");
+    JV_REQUIRE(Q >= 0 && n >= 0 && k >= 0 && stride >= n, "topk: bad sizes");
+    if (Q == 0 || k == 0) return JV_OK;
+    JV_REQUIRE(scores && out_ids && out_scores, "topk: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    const void *d_scores = nullptr, *d_ids = nullptr;
+    const size_t cells = (size_t)(Q - 1) * stride + n;
+    JV_TRY(stage_in(ctx, scores, sizeof(float) * cells, ctx->h_in, ctx->d_in, &d_scores));
+    if (ids) JV_TRY(stage_in(ctx, ids, sizeof(int32_t) * cells, ctx->h_in, ctx->d_scratch2, &d_ids));
+    JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, k)));
+    OutStage oi, osc;
+    JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * k, ctx->d_out, &oi));
+    JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * k, ctx->d_scratch3, &osc));
+    JV_TRY(launch_topk(ctx->stream, ctx, (const float *)d_scores, (const int32_t *)d_ids, Q, n, stride, id_base, k,
+                       (int32_t *)oi.dev, (float *)osc.dev, ctx->d_scratch.ptr));
+    JV_TRY(stage_out_end(ctx, oi));
+    return stage_out_end(ctx, osc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// flat two-pass search
+// ------------------------------------------------------------------------------------------------
+int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_vectors *vectors, const float *queries,
+                       int Q, jv_vsf vsf, int topK, int rerankK, int32_t id_base, int32_t *out_ids, float *out_scores)
+{
+    clear_error();
+    JV_REQUIRE(ctx && l && codes, "search_flat: NULL argument");
+    JV_REQUIRE(topK > 0, "search_flat: topK must be positive");
+    const bool rerank = vectors != nullptr && rerankK > 0;
+    // GraphSearcher.search :233 — rerankK must be >= topK
+    JV_REQUIRE(!rerank || rerankK >= topK, "rerankK %d must be >= topK %d", rerankK, topK);
+    JV_REQUIRE(!rerank || vectors->D == l->pq->D, "search_flat: vector dimension mismatch");
+    JV_REQUIRE(!rerank || vectors->count >= codes->count, "search_flat: fewer vectors than codes");
+    if (Q == 0) return JV_OK;
+    JV_REQUIRE(out_ids && out_scores, "search_flat: NULL output");
+    JV_TRY(use_device(ctx->device));
+    JV_TRY(jv_hip_luts_build(ctx, l, queries, Q, vsf, JV_DECODER_PQ));
+    if (vsf == JV_COSINE) JV_TRY(ensure_code_norms(ctx, const_cast<jv_codes *>(codes)));
+    const int64_t N = codes->count;
+    const int kvsf = to_kernel_vsf(vsf);
+    const int k1 = rerank ? rerankK : topK;
+
+    // scratch: approximate scores Q x N
+    JV_TRY(ctx->d_scratch2.reserve(sizeof(float) * (size_t)Q * N));
+    float *d_scores = (float *)ctx->d_scratch2.ptr;
+    JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes, codes->d_norms, N, 0, N,
+                      nullptr, d_scores));
+
+    OutStage oi, osc;
+    JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_out, &oi));
+    JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * topK, ctx->d_in, &osc));
+
+    // scratch3: [cand ids Q*k1][cand approx scores Q*k1][exact scores Q*k1][qnorm Q]
+    const size_t c1 = (size_t)Q * k1;
+    JV_TRY(ctx->d_scratch3.reserve(sizeof(int32_t) * c1 + sizeof(float) * c1 * 2 + sizeof(float) * (size_t)Q + 1024));
+    int32_t *d_cand = (int32_t *)ctx->d_scratch3.ptr;
+    float *d_cand_sc = (float *)(d_cand + c1);
+    float *d_exact = d_cand_sc + c1;
+    float *d_qnorm = d_exact + c1;
+    JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, std::max(k1, topK))));
+
+    if (!rerank) {
+        JV_TRY(launch_topk(ctx->stream, ctx, d_scores, nullptr, Q, N, N, 0, topK, (int32_t *)oi.dev, (float *)osc.dev,
+                           ctx->d_scratch.ptr));
+    } else {
+        JV_TRY(launch_topk(ctx->stream, ctx, d_scores, nullptr, Q, N, N, 0, k1, d_cand, d_cand_sc, ctx->d_scratch.ptr));
+        JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf,
+                                   d_cand, k1, d_exact, d_qnorm));
+        JV_TRY(launch_topk(ctx->stream, ctx, d_exact, d_cand, Q, k1, k1, 0, topK, (int32_t *)oi.dev, (float *)osc.dev,
+                           ctx->d_scratch.ptr));
+    }
+    JV_TRY(launch_add_id_base(ctx->stream, (int32_t *)oi.dev, (int64_t)Q * topK, id_base));
+    JV_TRY(stage_out_end(ctx, oi));
+    return stage_out_end(ctx, osc);
+}
+
+}  // extern "C"

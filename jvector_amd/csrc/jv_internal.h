@@ -1,0 +1,156 @@
+// jv_internal.h — internal structures of libjvector_hip.so (not part of the ABI)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/jvector_hip.h"
+
+namespace jv {
+
+constexpr int kClusters = 256;  // ProductQuantization.DEFAULT_CLUSTERS (ProductQuantization.java:62)
+
+void set_error(const char *fmt, ...);
+void clear_error();
+
+#define JV_HIP_CHECK(expr)                                                                         \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            jv::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            (void)hipGetLastError();                                                               \
+            return (_e == hipErrorOutOfMemory) ? JV_ERR_OOM : JV_ERR_HIP;                          \
+        }                                                                                          \
+    } while (0)
+
+#define JV_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            jv::set_error(__VA_ARGS__);  \
+            return JV_ERR_INVALID;       \
+        }                                \
+    } while (0)
+
+#define JV_TRY(expr)                 \
+    do {                             \
+        int _s = (expr);             \
+        if (_s != JV_OK) return _s;  \
+    } while (0)
+
+// growable device / pinned-host scratch owned by a context
+struct Buffer {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    bool pinned_host = false;
+    int reserve(size_t bytes);
+    void release();
+};
+
+}  // namespace jv
+
+struct jv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int num_cus = 256;
+    size_t lds_per_block = 65536;  // hipDeviceProp_t.sharedMemPerBlock / maxSharedMemoryPerMultiProcessor
+    // staging: host->device inputs, device->host outputs (pinned), device scratch
+    jv::Buffer h_in, h_out, d_in, d_out, d_scratch, d_scratch2, d_scratch3;
+};
+
+struct jv_pq {
+    int device = 0;
+    int D = 0, M = 0, k = 0;
+    bool uniform = false;      // all subvector sizes equal
+    int max_size = 0;
+    std::vector<int> sizes, offsets;
+    std::vector<int64_t> cb_offsets;  // float offset of codebook m inside d_codebooks
+    int *d_sizes = nullptr, *d_offsets = nullptr;
+    int64_t *d_cb_offsets = nullptr;
+    float *d_codebooks = nullptr;
+    float *d_centroid = nullptr;   // nullable
+    float *d_self_mag = nullptr;   // M*k floats, built at create (calculatePartialSelfMagnitudes)
+};
+
+struct jv_codes {
+    int device = 0;
+    const jv_pq *pq = nullptr;
+    int64_t count = 0;
+    int M = 0;
+    uint8_t *d_codes = nullptr;
+    bool owns = false;
+    // cosine: per-ordinal decoded squared magnitude sum_m aMag[m*256+code[m]] (query independent);
+    // (re)built lazily after uploads.  See DESIGN.md "cosine ADC".
+    float *d_norms = nullptr;
+    bool norms_valid = false;
+};
+
+struct jv_vectors {
+    int device = 0;
+    int64_t count = 0;
+    int D = 0;
+    float *d_vecs = nullptr;
+    bool owns = false;
+};
+
+struct jv_fused {
+    int device = 0;
+    const jv_pq *pq = nullptr;
+    int64_t count = 0;
+    int maxDegree = 0, M = 0;
+    uint8_t *d_blocks = nullptr;    // count x maxDegree x M
+    int32_t *d_neighbors = nullptr; // count x maxDegree
+    float *d_norms = nullptr;       // count x maxDegree (cosine), lazily built
+    bool norms_valid = false;
+};
+
+struct jv_luts {
+    int device = 0;
+    const jv_pq *pq = nullptr;
+    int capacity = 0;
+    int Q = 0;
+    jv_vsf vsf = JV_EUCLIDEAN;
+    jv_decoder_kind kind = JV_DECODER_PQ;
+    float *d_luts = nullptr;   // capacity x M x 256
+    float *d_bmag = nullptr;   // capacity
+    float *d_queries = nullptr; // capacity x D : centred queries (cq = q - globalCentroid)
+    float *d_raw_queries = nullptr; // capacity x D : un-centred copy (rerank)
+};
+
+// ---- kernel launchers (implemented in the .hip translation units) ----
+namespace jv {
+
+int launch_self_magnitudes(hipStream_t s, const jv_pq *pq);
+int launch_center_queries(hipStream_t s, const jv_pq *pq, const float *d_q, int Q, float *d_cq);
+int launch_lut_build(hipStream_t s, const jv_pq *pq, const float *d_cq, int Q, int lut_vsf, float *d_luts);
+int launch_query_magnitudes(hipStream_t s, const jv_pq *pq, const float *d_cq, int Q, int kind, float *d_bmag);
+int launch_pq_encode(hipStream_t s, const jv_pq *pq, const float *d_vecs, int64_t count, uint8_t *d_codes);
+
+// raw table sums (used for the cosine norms): out[i] = sum_m table[m*256+code[m]]
+int launch_code_norms(hipStream_t s, const jv_ctx *ctx, const float *d_table, int M, const uint8_t *d_codes,
+                      int64_t count, float *d_out);
+// ADC: ordinals==nullptr -> contiguous scan of [first, first+count); else gather Q x B
+int launch_adc(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const float *d_bmag, int Q, int M, int vsf,
+               const uint8_t *d_codes, const float *d_norms, int64_t n_codes, int64_t first, int64_t count,
+               const int32_t *d_ordinals, float *d_out);
+int launch_fused(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const float *d_bmag, int Q, int M, int vsf,
+                 const uint8_t *d_blocks, const int32_t *d_neighbors, const float *d_norms, int maxDegree,
+                 int64_t n_nodes, const int32_t *d_origins, float *d_out, int32_t *d_neighbors_out);
+
+int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf,
+                        const int32_t *d_ord, int B, float *d_out, float *d_qnorm);
+int launch_exact_scan(hipStream_t s, const jv_ctx *ctx, const float *d_vecs, int D, const float *d_q, int Q, int vsf,
+                      int64_t first, int64_t count, float *d_out, float *d_qnorm);
+
+size_t topk_scratch_bytes(int Q, int k);
+int launch_topk(hipStream_t s, const jv_ctx *ctx, const float *d_scores, const int32_t *d_ids, int Q, int64_t n,
+                int64_t stride, int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, void *d_scratch);
+int launch_add_id_base(hipStream_t s, int32_t *d_ids, int64_t n, int32_t base);
+
+}  // namespace jv

@@ -1,0 +1,254 @@
+// k_topk.hip — exact, deterministic top-k under the NodeQueue total order.
+//
+// Order: key64 = (ordered_u32(score) << 32) | (~id as u32), larger key = better — bit-for-bit the order
+// of NodeQueue.encode (NodeQueue.java:125-129) over NumericUtils.floatToSortableInt (NumericUtils.java:
+// 49-65): higher score first, equal scores -> smaller node id first.  Ids within a row are unique, hence
+// keys are unique and "the k largest keys" is a well-defined set: no tie handling, no overflow path.
+//
+// Algorithm: MSB radix select on the 64-bit key in digits of 11/11/10 | 11/11/10 bits.  Each pass is a
+// grid-wide histogram of the current digit over the elements matching the already-decided prefix, then a
+// one-workgroup-per-query selection of the bin holding the k-th largest.  Passes stop (device-side flag,
+// remaining launches exit immediately) as soon as the bin is needed in full — in practice after the three
+// score digits, the id digits only run when the k-th score is tied.  A collect pass gathers the k keys and
+// a one-workgroup bitonic sort orders them best-first.
+#include "jv_device.h"
+#include "jv_internal.h"
+
+namespace jv {
+
+constexpr int kBins = 2048;
+constexpr int kPasses = 6;
+constexpr int kMaxK = 8192;
+
+struct SelState {
+    unsigned long long prefix;  // decided high bits of the threshold key
+    unsigned int k_rem;         // how many still to take inside the current prefix
+    unsigned int k_eff;         // min(k, valid elements)
+    unsigned int done;          // threshold final: select key >= prefix
+    unsigned int collected;     // collect-pass cursor
+    unsigned int pad[2];
+};
+
+__device__ __constant__ int c_shift[kPasses] = {53, 42, 32, 21, 10, 0};
+__device__ __constant__ int c_width[kPasses] = {11, 11, 10, 11, 11, 10};
+
+__device__ __forceinline__ bool load_key(const float *__restrict__ scores, const int32_t *__restrict__ ids,
+                                         int64_t row_off, int64_t col, int32_t id_base, unsigned long long &key)
+{
+    int32_t id = ids ? ids[row_off + col] : (int32_t)(id_base + col);
+    if (id < 0) return false;
+    const uint32_t u = float_to_ordered_u32(scores[row_off + col]);
+    key = ((unsigned long long)u << 32) | (unsigned long long)(uint32_t)(~id);
+    return true;
+}
+
+// grid (nblk, Q), block 256
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float *__restrict__ scores,
+                                                        const int32_t *__restrict__ ids, int64_t n, int64_t stride,
+                                                        int32_t id_base, int pass, const SelState *__restrict__ st,
+                                                        unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int lh[kBins];
+    const int q = blockIdx.y;
+    if (pass > 0 && st[q].done) return;
+    for (int i = threadIdx.x; i < kBins; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int shift = c_shift[pass], width = c_width[pass];
+    const unsigned long long prefix = pass > 0 ? st[q].prefix : 0ull;
+    const int hi = shift + width;  // bits >= hi are decided
+    const int64_t row_off = (int64_t)q * stride;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        unsigned long long key;
+        if (!load_key(scores, ids, row_off, i, id_base, key)) continue;
+        if (hi < 64 && (key >> hi) != (prefix >> hi)) continue;
+        const unsigned int bin = (unsigned int)((key >> shift) & ((1u << width) - 1u));
+        atomicAdd(&lh[bin], 1u);
+    }
+    __syncthreads();
+    unsigned int *gh = hist + ((int64_t)q * kPasses + pass) * kBins;
+    for (int i = threadIdx.x; i < kBins; i += 256) {
+        const unsigned int c = lh[i];
+        if (c) atomicAdd(&gh[i], c);
+    }
+}
+
+// grid (Q), block 256: walk the bins from the top until the cumulative count reaches k_rem.
+__global__ __launch_bounds__(256) void topk_select_kernel(int pass, int k, SelState *__restrict__ st,
+                                                          const unsigned int *__restrict__ hist)
+{
+    __shared__ unsigned int lh[kBins];
+    __shared__ unsigned int chunk_sum[256];
+    const int q = blockIdx.x;
+    SelState s = st[q];
+    if (pass > 0 && s.done) return;
+    const unsigned int *gh = hist + ((int64_t)q * kPasses + pass) * kBins;
+    const int nb = 1 << c_width[pass];
+    // thread t owns bins [t*8, t*8+8) counted from the TOP (descending key order)
+    unsigned int local = 0;
+    for (int j = 0; j < kBins / 256; ++j) {
+        const int pos = threadIdx.x * (kBins / 256) + j;  // 0 = top bin
+        const int bin = nb - 1 - pos;
+        const unsigned int c = (bin >= 0) ? gh[bin] : 0u;
+        lh[pos] = c;
+        local += c;
+    }
+    chunk_sum[threadIdx.x] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int total = 0;
+        for (int t = 0; t < 256; ++t) total += chunk_sum[t];
+        if (pass == 0) {
+            s.prefix = 0ull;
+            s.k_eff = total < (unsigned int)k ? total : (unsigned int)k;
+            s.k_rem = s.k_eff;
+            s.done = 0;
+            s.collected = 0;
+            if (total <= (unsigned int)k) {  // everything valid is selected
+                s.done = 1;
+                st[q] = s;
+                return;
+            }
+        }
+        // find chunk, then bin
+        unsigned int cum = 0;
+        int t = 0;
+        for (; t < 256; ++t) {
+            if (cum + chunk_sum[t] >= s.k_rem) break;
+            cum += chunk_sum[t];
+        }
+        int pos = t * (kBins / 256);
+        for (;; ++pos) {
+            if (cum + lh[pos] >= s.k_rem) break;
+            cum += lh[pos];
+        }
+        const int bin = nb - 1 - pos;
+        s.prefix |= ((unsigned long long)bin) << c_shift[pass];
+        s.k_rem -= cum;                       // still needed from inside this bin
+        if (lh[pos] == s.k_rem || pass == kPasses - 1) s.done = 1;  // whole bin needed: lower bits irrelevant
+        st[q] = s;
+    }
+}
+
+// grid (nblk, Q): gather every key >= threshold (exactly k_eff of them)
+__global__ __launch_bounds__(256) void topk_collect_kernel(const float *__restrict__ scores,
+                                                           const int32_t *__restrict__ ids, int64_t n, int64_t stride,
+                                                           int32_t id_base, SelState *__restrict__ st,
+                                                           unsigned long long *__restrict__ keys, int kpad)
+{
+    const int q = blockIdx.y;
+    const unsigned long long thr = st[q].prefix;
+    const unsigned int k_eff = st[q].k_eff;
+    const int64_t row_off = (int64_t)q * stride;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        unsigned long long key;
+        if (!load_key(scores, ids, row_off, i, id_base, key)) continue;
+        if (key >= thr) {
+            const unsigned int pos = atomicAdd(&st[q].collected, 1u);
+            if (pos < k_eff) keys[(int64_t)q * kpad + pos] = key;
+        }
+    }
+}
+
+// grid (Q), block 1024: bitonic sort (descending) of kpad keys in LDS, emit ids / scores best first
+__global__ __launch_bounds__(1024) void topk_sort_kernel(const SelState *__restrict__ st,
+                                                         const unsigned long long *__restrict__ keys, int kpad, int k,
+                                                         int32_t *__restrict__ out_ids, float *__restrict__ out_scores)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
+    const int q = blockIdx.x;
+    const unsigned int k_eff = st[q].k_eff;
+    for (int i = threadIdx.x; i < kpad; i += 1024) sk[i] = (i < (int)k_eff) ? keys[(int64_t)q * kpad + i] : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= kpad; size <<= 1) {
+        for (int strd = size >> 1; strd > 0; strd >>= 1) {
+            for (int i = threadIdx.x; i < kpad / 2; i += 1024) {
+                const int lo = (i / strd) * (strd << 1) + (i % strd);
+                const int hi = lo + strd;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = sk[lo], b = sk[hi];
+                if ((a < b) == desc) {
+                    sk[lo] = b;
+                    sk[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < k; i += 1024) {
+        if (i < (int)k_eff) {
+            const unsigned long long key = sk[i];
+            out_ids[(int64_t)q * k + i] = (int32_t)(~(uint32_t)(key & 0xFFFFFFFFull));
+            out_scores[(int64_t)q * k + i] = ordered_u32_to_float((uint32_t)(key >> 32));
+        } else {
+            out_ids[(int64_t)q * k + i] = -1;
+            out_scores[(int64_t)q * k + i] = -INFINITY;
+        }
+    }
+}
+
+static int next_pow2(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// scratch layout: [SelState Q] [hist Q*6*2048 u32] [keys Q*kpad u64]
+size_t topk_scratch_bytes(int Q, int k)
+{
+    const size_t kpad = (size_t)next_pow2(k < 2 ? 2 : k);
+    size_t b = 0;
+    b += ((sizeof(SelState) * (size_t)Q + 255) / 256) * 256;
+    b += sizeof(unsigned int) * (size_t)Q * kPasses * kBins;
+    b += sizeof(unsigned long long) * (size_t)Q * kpad;
+    return b + 256;
+}
+
+int launch_topk(hipStream_t s, const jv_ctx *ctx, const float *d_scores, const int32_t *d_ids, int Q, int64_t n,
+                int64_t stride, int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, void *d_scratch)
+{
+    if (Q == 0 || k == 0) return JV_OK;
+    if (k > kMaxK) {
+        set_error("topk: k=%d exceeds the supported maximum %d", k, kMaxK);
+        return JV_ERR_UNSUPPORTED;
+    }
+    const int kpad = next_pow2(k < 2 ? 2 : k);
+    char *base = (char *)d_scratch;
+    SelState *st = (SelState *)base;
+    size_t off = ((sizeof(SelState) * (size_t)Q + 255) / 256) * 256;
+    unsigned int *hist = (unsigned int *)(base + off);
+    const size_t hist_bytes = sizeof(unsigned int) * (size_t)Q * kPasses * kBins;
+    unsigned long long *keys = (unsigned long long *)(base + off + hist_bytes);
+    JV_HIP_CHECK(hipMemsetAsync(base, 0, off + hist_bytes, s));
+
+    int nblk = (int)((n + 256 * 16 - 1) / (256 * 16));
+    const int max_blk = ctx->num_cus * 8 / (Q < 8 ? Q : 8);
+    if (nblk > max_blk) nblk = max_blk;
+    if (nblk < 1) nblk = 1;
+    dim3 grid(nblk, Q);
+    for (int pass = 0; pass < kPasses; ++pass) {
+        hipLaunchKernelGGL(topk_hist_kernel, grid, dim3(256), 0, s, d_scores, d_ids, n, stride, id_base, pass, st, hist);
+        hipLaunchKernelGGL(topk_select_kernel, dim3(Q), dim3(256), 0, s, pass, k, st, hist);
+    }
+    hipLaunchKernelGGL(topk_collect_kernel, grid, dim3(256), 0, s, d_scores, d_ids, n, stride, id_base, st, keys, kpad);
+    size_t lds = sizeof(unsigned long long) * (size_t)kpad;
+    hipLaunchKernelGGL(topk_sort_kernel, dim3(Q), dim3(1024), lds, s, st, keys, kpad, k, d_out_ids, d_out_scores);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+__global__ void add_base_kernel(int32_t *ids, int64_t n, int32_t base)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && ids[i] >= 0) ids[i] += base;
+}
+
+int launch_add_id_base(hipStream_t s, int32_t *d_ids, int64_t n, int32_t base)
+{
+    if (n == 0 || base == 0) return JV_OK;
+    hipLaunchKernelGGL(add_base_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_ids, n, base);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+}  // namespace jv

@@ -1,0 +1,390 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C ABI.
+
+Names follow the reference: VectorSimilarityFunction, ProductQuantization (encode / encodeAll /
+load), PQVectors (precomputedScoreFunctionFor -> batched similarityTo), FusedPQ (similarityToNeighbor), NodeQueue
+order top-k, and the two-pass search.  Every method is a thin call into libjvector_hip.so — there is no Python
+arithmetic here and no CPU fallback: without the shared library or a gfx950 device the calls raise.
+
+Arrays may be numpy arrays (host) or torch tensors (host or device).  Outputs follow the `like` rule: when the
+driving input is a device torch tensor the result is a device torch tensor (zero copy, asynchronous on the
+context's stream); otherwise a numpy array (the call synchronises).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+class VectorSimilarityFunction(enum.IntEnum):
+    """B/vector/VectorSimilarityFunction.java:34-69 (ordinal order preserved)."""
+    EUCLIDEAN = 0
+    DOT_PRODUCT = 1
+    COSINE = 2
+
+
+class DecoderKind(enum.IntEnum):
+    PQ = 0      # PQDecoder (B/quantization/PQDecoder.java)
+    FUSED = 1   # FusedPQDecoder (B/quantization/FusedPQDecoder.java)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x, dtype=None):
+    """(c_void_p, keepalive) of a numpy array / torch tensor; validates dtype + contiguity."""
+    if x is None:
+        return None, None
+    if _is_torch(x):
+        import torch
+        if dtype is not None:
+            want = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32}[dtype]
+            if x.dtype != want:
+                raise ValueError(f"expected tensor dtype {want}, got {x.dtype}")
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return C.c_void_p(x.data_ptr()), x
+    a = np.ascontiguousarray(x, dtype=dtype)
+    return C.c_void_p(a.ctypes.data), a
+
+
+def _empty(shape, dtype, like):
+    if like is not None and _is_torch(like) and like.is_cuda:
+        import torch
+        tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32}[dtype]
+        return torch.empty(shape, dtype=tdt, device=like.device)
+    return np.empty(shape, dtype=dtype)
+
+
+def device_count() -> int:
+    return int(_lib.load().jv_hip_device_count())
+
+
+class HipContext:
+    """One per host thread: owns the HIP stream + staging scratch (jv_ctx).
+
+    stream: an existing hipStream_t handle (int), e.g. torch.cuda.current_stream().cuda_stream, or None.
+    """
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.jv_hip_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    @property
+    def arch(self) -> str:
+        return self._lib.jv_hip_active_arch(self.device).decode()
+
+    def sync(self):
+        check(self._lib.jv_hip_ctx_sync(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ProductQuantization:
+    """Device-resident codebooks (B/quantization/ProductQuantization.java)."""
+
+    DEFAULT_CLUSTERS = 256
+
+    def __init__(self, ctx: HipContext, handle):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self._h = handle
+        D, M, k, hc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.jv_hip_pq_info(handle, C.byref(D), C.byref(M), C.byref(k), C.byref(hc)))
+        self.original_dimension, self.M, self.cluster_count = D.value, M.value, k.value
+        self.has_global_centroid = bool(hc.value)
+
+    @classmethod
+    def from_codebooks(cls, ctx, D, M, codebooks, global_centroid=None, cluster_count=256, sizes=None):
+        """codebooks: concatenation over m of k*size_m floats, centroid-major (ProductQuantization.write order)."""
+        cb_p, cb_keep = _ptr(codebooks, np.float32)
+        ce_p, ce_keep = _ptr(global_centroid, np.float32)
+        sz_p, sz_keep = _ptr(sizes, np.int32)
+        h = C.c_void_p()
+        check(ctx._lib.jv_hip_pq_create(ctx._h, int(D), int(M), int(cluster_count), sz_p, cb_p, ce_p, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def load(cls, ctx, data: bytes):
+        """ProductQuantization.load (:649-693): the reference's big-endian wire format."""
+        buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+        h, consumed = C.c_void_p(), C.c_size_t()
+        check(ctx._lib.jv_hip_pq_load(ctx._h, C.cast(buf, C.c_void_p), len(data), C.byref(consumed), C.byref(h)))
+        pq = cls(ctx, h)
+        pq.bytes_consumed = consumed.value
+        return pq
+
+    def get_subspace_count(self):
+        return self.M
+
+    def get_cluster_count(self):
+        return self.cluster_count
+
+    def encode_all(self, vectors, out=None):
+        """PQVectors.encodeAndBuild's arithmetic for a batch: (n, D) float32 -> (n, M) uint8."""
+        n = int(vectors.shape[0])
+        if vectors.shape[1] != self.original_dimension:
+            raise ValueError(f"vector dimensions differ: {vectors.shape[1]}!={self.original_dimension}")
+        v_p, keep = _ptr(vectors, np.float32)
+        if out is None:
+            out = _empty((n, self.M), np.uint8, vectors)
+        o_p, okeep = _ptr(out, np.uint8)
+        check(self._lib.jv_hip_pq_encode(self.ctx._h, self._h, v_p, n, o_p))
+        return out
+
+    def encode(self, vector):
+        return self.encode_all(np.asarray(vector, np.float32).reshape(1, -1))[0]
+
+    def self_magnitudes(self):
+        out = np.empty(self.M * self.cluster_count, np.float32)
+        check(self._lib.jv_hip_pq_self_magnitudes(self.ctx._h, self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_pq_destroy(self._h)
+            self._h = None
+
+
+class VectorSet:
+    """Device-resident full-resolution vectors (RandomAccessVectorValues for the reranker)."""
+
+    def __init__(self, ctx, vectors):
+        self.ctx, self._lib = ctx, ctx._lib
+        n, D = int(vectors.shape[0]), int(vectors.shape[1])
+        h = C.c_void_p()
+        if _is_torch(vectors) and vectors.is_cuda:
+            p, self._keep = _ptr(vectors, np.float32)
+            check(self._lib.jv_hip_vectors_wrap(ctx._h, n, D, p, C.byref(h)))
+        else:
+            check(self._lib.jv_hip_vectors_create(ctx._h, n, D, C.byref(h)))
+            p, keep = _ptr(vectors, np.float32)
+            check(self._lib.jv_hip_vectors_upload(ctx._h, h, 0, n, p))
+        self._h, self.count, self.dimension = h, n, D
+
+    def size(self):
+        return self.count
+
+    def scores(self, queries, vsf, ordinals):
+        """rerank form: out[q, j] = vsf.compare(queries[q], vectors[ordinals[q, j]])"""
+        Q, B = int(ordinals.shape[0]), int(ordinals.shape[1])
+        q_p, qk = _ptr(queries, np.float32)
+        o_p, ok = _ptr(ordinals, np.int32)
+        out = _empty((Q, B), np.float32, ordinals)
+        out_p, outk = _ptr(out, np.float32)
+        check(self._lib.jv_hip_exact_scores(self.ctx._h, self._h, q_p, Q, int(vsf), o_p, B, out_p))
+        return out
+
+    def scan(self, queries, vsf, first=0, count=None, out=None):
+        """brute-force form: out[q, i] = vsf.compare(queries[q], vectors[first + i])"""
+        Q = int(queries.shape[0])
+        count = self.count - first if count is None else int(count)
+        q_p, qk = _ptr(queries, np.float32)
+        if out is None:
+            out = _empty((Q, count), np.float32, queries)
+        out_p, outk = _ptr(out, np.float32)
+        check(self._lib.jv_hip_exact_scan(self.ctx._h, self._h, q_p, Q, int(vsf), int(first), count, out_p))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_vectors_destroy(self._h)
+            self._h = None
+
+
+class PQVectors:
+    """Device-resident code store, ordinal-major (B/quantization/PQVectors.java)."""
+
+    def __init__(self, ctx, pq: ProductQuantization, codes=None, count=None):
+        self.ctx, self._lib, self.pq = ctx, ctx._lib, pq
+        h = C.c_void_p()
+        if codes is not None and _is_torch(codes) and codes.is_cuda:
+            n = int(codes.shape[0])
+            p, self._keep = _ptr(codes, np.uint8)
+            check(self._lib.jv_hip_codes_wrap(ctx._h, pq._h, n, p, C.byref(h)))
+        else:
+            n = int(count if codes is None else codes.shape[0])
+            check(self._lib.jv_hip_codes_create(ctx._h, pq._h, n, C.byref(h)))
+            if codes is not None:
+                p, keep = _ptr(codes, np.uint8)
+                check(self._lib.jv_hip_codes_upload(ctx._h, h, 0, n, p))
+        self._h, self._count = h, n
+
+    @classmethod
+    def encode_and_build(cls, ctx, pq, vectors: VectorSet):
+        """PQVectors.encodeAndBuild (:109-152) on device-resident vectors."""
+        self = cls(ctx, pq, count=vectors.count)
+        check(ctx._lib.jv_hip_pq_encode_into(ctx._h, pq._h, vectors._h, 0, vectors.count, self._h))
+        return self
+
+    def count(self):
+        return self._count
+
+    def get(self, first, n=1):
+        out = np.empty((n, self.pq.M), np.uint8)
+        check(self._lib.jv_hip_codes_download(self.ctx._h, self._h, int(first), int(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def precomputed_score_function_for(self, queries, vsf, luts=None):
+        """PQVectors.precomputedScoreFunctionFor (:210-221), batched over Q queries."""
+        luts = luts or QueryTables(self.ctx, self.pq, int(queries.shape[0]))
+        luts.build(queries, vsf, DecoderKind.PQ)
+        return ApproximateScoreFunction(self, luts)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_codes_destroy(self._h)
+            self._h = None
+
+
+class QueryTables:
+    """ADC look-up tables of a query batch (the state PQDecoder / FusedPQDecoder constructors compute)."""
+
+    def __init__(self, ctx, pq, max_queries):
+        self.ctx, self._lib, self.pq = ctx, ctx._lib, pq
+        h = C.c_void_p()
+        check(self._lib.jv_hip_luts_create(ctx._h, pq._h, int(max_queries), C.byref(h)))
+        self._h, self.capacity, self.Q, self.vsf = h, int(max_queries), 0, None
+
+    def build(self, queries, vsf, kind=DecoderKind.PQ):
+        Q = int(queries.shape[0])
+        if queries.shape[1] != self.pq.original_dimension:
+            raise ValueError(f"vector dimensions differ: {queries.shape[1]}!={self.pq.original_dimension}")
+        p, keep = _ptr(queries, np.float32)
+        check(self._lib.jv_hip_luts_build(self.ctx._h, self._h, p, Q, int(vsf), int(kind)))
+        self.Q, self.vsf = Q, VectorSimilarityFunction(int(vsf))
+        return self
+
+    def table(self, q):
+        lut = np.empty(self.pq.M * 256, np.float32)
+        bm = C.c_float()
+        check(self._lib.jv_hip_luts_download(self.ctx._h, self._h, int(q), lut.ctypes.data_as(C.c_void_p),
+                                             C.cast(C.byref(bm), C.c_void_p)))
+        return lut, float(bm.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_luts_destroy(self._h)
+            self._h = None
+
+
+class ApproximateScoreFunction:
+    """Batched ScoreFunction.ApproximateScoreFunction (B/graph/similarity/ScoreFunction.java:30-80)."""
+
+    def __init__(self, cv: PQVectors, luts: QueryTables):
+        self.cv, self.luts = cv, luts
+
+    def similarity_to(self, ordinals):
+        """out[q, j] = similarityTo(ordinals[q, j]) ; negative ordinals -> -inf"""
+        Q, B = int(ordinals.shape[0]), int(ordinals.shape[1])
+        if Q != self.luts.Q:
+            raise ValueError("ordinals must have one row per query")
+        o_p, ok = _ptr(ordinals, np.int32)
+        out = _empty((Q, B), np.float32, ordinals)
+        out_p, outk = _ptr(out, np.float32)
+        check(self.cv._lib.jv_hip_adc_scores(self.cv.ctx._h, self.luts._h, self.cv._h, o_p, B, out_p))
+        return out
+
+    def similarity_to_range(self, first, count, out=None, like=None):
+        """out[q, i] = similarityTo(first + i) — the flat-scan form"""
+        if out is None:
+            out = _empty((self.luts.Q, int(count)), np.float32, like)
+        out_p, outk = _ptr(out, np.float32)
+        check(self.cv._lib.jv_hip_adc_scan(self.cv.ctx._h, self.luts._h, self.cv._h, int(first), int(count), out_p))
+        return out
+
+
+class FusedPQ:
+    """Device-resident L0 fused blocks (B/graph/disk/feature/FusedPQ.java:146-161 layout)."""
+
+    def __init__(self, ctx, pq, blocks, neighbors):
+        self.ctx, self._lib, self.pq = ctx, ctx._lib, pq
+        n, max_degree = int(neighbors.shape[0]), int(neighbors.shape[1])
+        h = C.c_void_p()
+        check(self._lib.jv_hip_fused_create(ctx._h, pq._h, n, max_degree, C.byref(h)))
+        b_p, bk = _ptr(blocks, np.uint8)
+        n_p, nk = _ptr(neighbors, np.int32)
+        check(self._lib.jv_hip_fused_upload(ctx._h, h, 0, n, b_p, n_p))
+        self._h, self.count, self.max_degree = h, n, max_degree
+
+    def approximate_score_function_for(self, queries, vsf, luts=None):
+        luts = luts or QueryTables(self.ctx, self.pq, int(queries.shape[0]))
+        luts.build(queries, vsf, DecoderKind.FUSED)
+        return FusedScoreFunction(self, luts)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_fused_destroy(self._h)
+            self._h = None
+
+
+class FusedScoreFunction:
+    """Batched FusedPQDecoder: enableSimilarityToNeighbors(origin) + similarityToNeighbor(origin, i) for all i."""
+
+    def __init__(self, fused: FusedPQ, luts: QueryTables):
+        self.fused, self.luts = fused, luts
+
+    def similarity_to_neighbors(self, origins, return_neighbors=False):
+        Q = int(origins.shape[0])
+        o_p, ok = _ptr(origins, np.int32)
+        out = _empty((Q, self.fused.max_degree), np.float32, origins)
+        out_p, outk = _ptr(out, np.float32)
+        nb = _empty((Q, self.fused.max_degree), np.int32, origins) if return_neighbors else None
+        nb_p, nbk = _ptr(nb, np.int32)
+        check(self.fused._lib.jv_hip_fused_scores(self.fused.ctx._h, self.luts._h, self.fused._h, o_p, out_p, nb_p))
+        return (out, nb) if return_neighbors else out
+
+
+def topk(ctx, scores, k, ids=None, id_base=0):
+    """NodeQueue-order top-k of each row (higher score first, ties -> smaller id). Returns (ids, scores)."""
+    Q, n = int(scores.shape[0]), int(scores.shape[1])
+    s_p, sk = _ptr(scores, np.float32)
+    i_p, ik = _ptr(ids, np.int32)
+    oi = _empty((Q, k), np.int32, scores)
+    osc = _empty((Q, k), np.float32, scores)
+    oi_p, oik = _ptr(oi, np.int32)
+    os_p, osk = _ptr(osc, np.float32)
+    check(ctx._lib.jv_hip_topk(ctx._h, s_p, i_p, Q, n, n, int(id_base), int(k), oi_p, os_p))
+    return oi, osc
+
+
+class FlatSearcher:
+    """Two-pass search over one shard: ADC scan of every code -> top rerankK -> exact rerank -> topK.
+
+    Same per-candidate arithmetic as GraphSearcher.search's scoring calls (GraphSearcher.java:443-450,471-507)
+    with the whole shard as the candidate set (the recall-bearing path before a graph exists)."""
+
+    def __init__(self, ctx, pq, pq_vectors: PQVectors, vectors: VectorSet | None, max_queries=256, id_base=0):
+        self.ctx, self.pq, self.cv, self.vectors, self.id_base = ctx, pq, pq_vectors, vectors, int(id_base)
+        self.luts = QueryTables(ctx, pq, max_queries)
+
+    def search(self, queries, vsf, top_k, rerank_k, out_ids=None, out_scores=None):
+        Q = int(queries.shape[0])
+        q_p, qk = _ptr(queries, np.float32)
+        if out_ids is None:
+            out_ids = _empty((Q, top_k), np.int32, queries)
+        if out_scores is None:
+            out_scores = _empty((Q, top_k), np.float32, queries)
+        oi_p, oik = _ptr(out_ids, np.int32)
+        os_p, osk = _ptr(out_scores, np.float32)
+        check(self.ctx._lib.jv_hip_search_flat(self.ctx._h, self.luts._h, self.cv._h,
+                                               self.vectors._h if self.vectors is not None else None, q_p, Q, int(vsf),
+                                               int(top_k), int(rerank_k), self.id_base, oi_p, os_p))
+        return out_ids, out_scores
