@@ -117,6 +117,15 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise JVectorHipError(
                 f"{LIB_PATH} not found: build it with `make -C jvector_amd/csrc` (there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64 and
+        # dlopen them by absolute path, so loading /opt/rocm's copy first leaves torch with a second, GPU-less
+        # runtime ("No HIP GPUs are available").  Importing torch first makes our NEEDED libamdhip64.so.7 resolve
+        # (by soname) to the runtime torch already loaded.  Pure plumbing; set JVECTOR_HIP_NO_TORCH=1 to skip.
+        if os.environ.get("JVECTOR_HIP_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = C.CDLL(LIB_PATH)
         for table in (SIGNATURES, COMPAT_SIGNATURES):
             for name, (res, args) in table.items():
