@@ -76,6 +76,13 @@ JV_API int jv_hip_ctx_create(int device, void *stream, jv_ctx **out);
 JV_API int jv_hip_ctx_destroy(jv_ctx *ctx);
 JV_API int jv_hip_ctx_sync(jv_ctx *ctx);
 JV_API void *jv_hip_ctx_stream(jv_ctx *ctx);
+/* Device-side timing of the engine's kernel regions with HIP events recorded on the context's stream
+ * (the analogue of the reference's per-phase bench diagnostics, EX/benchmarks/diagnostics/).
+ * regions: "adc" (ADC scan/gather/fused kernels), "topk", "exact", "lut", "encode", "norms".
+ * profile(ctx, 1) clears the counters and starts recording; profile_read synchronises the stream and returns
+ * the summed elapsed milliseconds and the number of recorded regions (one per API-level launch group). */
+JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
+JV_API int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, int64_t *count);
 
 /* ---------------------------------------------------------------------------------------------
  * ProductQuantization (device-resident codebooks)

@@ -119,6 +119,34 @@ static int stage_out_end(jv_ctx *ctx, const OutStage &st)
     return JV_OK;
 }
 
+// RAII region timer: two hipEventRecord calls on the context's stream when profiling is on, nothing otherwise.
+struct ProfScope {
+    jv_ctx *ctx;
+    int idx = -1;
+    ProfScope(jv_ctx *c, int region) : ctx(c)
+    {
+        if (!ctx->profiling) return;
+        ProfEvent e;
+        e.region = region;
+        auto get = [&](hipEvent_t *ev) {
+            if (!ctx->prof_free.empty()) {
+                *ev = ctx->prof_free.back();
+                ctx->prof_free.pop_back();
+                return true;
+            }
+            return hipEventCreate(ev) == hipSuccess;
+        };
+        if (!get(&e.start) || !get(&e.stop)) return;
+        (void)hipEventRecord(e.start, ctx->stream);
+        ctx->prof_pending.push_back(e);
+        idx = (int)ctx->prof_pending.size() - 1;
+    }
+    ~ProfScope()
+    {
+        if (idx >= 0) (void)hipEventRecord(ctx->prof_pending[idx].stop, ctx->stream);
+    }
+};
+
 static int to_kernel_vsf(jv_vsf v)
 {
     switch (v) {
@@ -151,8 +179,11 @@ static int ensure_code_norms(jv_ctx *ctx, jv_codes *codes)
 {
     if (codes->norms_valid) return JV_OK;
     if (!codes->d_norms) JV_HIP_CHECK(hipMalloc((void **)&codes->d_norms, sizeof(float) * (size_t)std::max<int64_t>(codes->count, 1)));
-    JV_TRY(launch_code_norms(ctx->stream, ctx, codes->pq->d_self_mag, codes->M, codes->d_codes, codes->count,
-                             codes->d_norms));
+    {
+        ProfScope ps(ctx, R_NORMS);
+        JV_TRY(launch_code_norms(ctx->stream, ctx, codes->pq->d_self_mag, codes->M, codes->d_codes, codes->count,
+                                 codes->d_norms));
+    }
     codes->norms_valid = true;
     return JV_OK;
 }
@@ -252,6 +283,11 @@ int jv_hip_ctx_destroy(jv_ctx *ctx)
     ctx->d_scratch.release();
     ctx->d_scratch2.release();
     ctx->d_scratch3.release();
+    for (auto &e : ctx->prof_pending) {
+        (void)hipEventDestroy(e.start);
+        (void)hipEventDestroy(e.stop);
+    }
+    for (auto &e : ctx->prof_free) (void)hipEventDestroy(e);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return JV_OK;
@@ -265,6 +301,55 @@ int jv_hip_ctx_sync(jv_ctx *ctx)
 }
 
 void *jv_hip_ctx_stream(jv_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+static int prof_resolve(jv_ctx *ctx)
+{
+    if (ctx->prof_pending.empty()) return JV_OK;
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (auto &e : ctx->prof_pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.start, e.stop) == hipSuccess) {
+            ctx->prof_ms[e.region] += ms;
+            ctx->prof_count[e.region] += 1;
+        } else {
+            (void)hipGetLastError();
+        }
+        ctx->prof_free.push_back(e.start);
+        ctx->prof_free.push_back(e.stop);
+    }
+    ctx->prof_pending.clear();
+    return JV_OK;
+}
+
+int jv_hip_ctx_profile(jv_ctx *ctx, int enable)
+{
+    clear_error();
+    JV_REQUIRE(ctx, "ctx is NULL");
+    JV_TRY(use_device(ctx->device));
+    JV_TRY(prof_resolve(ctx));
+    for (int r = 0; r < R_COUNT; ++r) {
+        ctx->prof_ms[r] = 0.0;
+        ctx->prof_count[r] = 0;
+    }
+    ctx->profiling = enable != 0;
+    return JV_OK;
+}
+
+int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, int64_t *count)
+{
+    clear_error();
+    JV_REQUIRE(ctx && region, "NULL argument");
+    static const char *names[R_COUNT] = {"adc", "topk", "exact", "lut", "encode", "norms"};
+    int r = -1;
+    for (int i = 0; i < R_COUNT; ++i)
+        if (strcmp(names[i], region) == 0) r = i;
+    JV_REQUIRE(r >= 0, "unknown profile region '%s'", region);
+    JV_TRY(use_device(ctx->device));
+    JV_TRY(prof_resolve(ctx));
+    if (total_ms) *total_ms = ctx->prof_ms[r];
+    if (count) *count = ctx->prof_count[r];
+    return JV_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // ProductQuantization
@@ -608,7 +693,10 @@ int jv_hip_pq_encode(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t
     JV_TRY(stage_in(ctx, vectors, sizeof(float) * (size_t)count * pq->D, ctx->h_in, ctx->d_in, &d_v));
     OutStage os;
     JV_TRY(stage_out_begin(ctx, codes_out, (size_t)count * pq->M, ctx->d_out, &os));
-    JV_TRY(launch_pq_encode(ctx->stream, pq, (const float *)d_v, count, (uint8_t *)os.dev));
+    {
+        ProfScope ps(ctx, R_ENCODE);
+        JV_TRY(launch_pq_encode(ctx->stream, pq, (const float *)d_v, count, (uint8_t *)os.dev));
+    }
     return stage_out_end(ctx, os);
 }
 
@@ -622,7 +710,10 @@ int jv_hip_pq_encode_into(jv_ctx *ctx, const jv_pq *pq, const jv_vectors *v, int
     JV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->count && first + count <= codes->count,
                "pq_encode_into: range out of bounds");
     JV_TRY(use_device(ctx->device));
-    JV_TRY(launch_pq_encode(ctx->stream, pq, v->d_vecs + first * v->D, count, codes->d_codes + first * codes->M));
+    {
+        ProfScope ps(ctx, R_ENCODE);
+        JV_TRY(launch_pq_encode(ctx->stream, pq, v->d_vecs + first * v->D, count, codes->d_codes + first * codes->M));
+    }
     codes->norms_valid = false;
     return JV_OK;
 }
@@ -690,6 +781,7 @@ int jv_hip_luts_build(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_v
         memcpy(ctx->h_in.ptr, queries, qbytes);
         JV_HIP_CHECK(hipMemcpyAsync(l->d_raw_queries, ctx->h_in.ptr, qbytes, hipMemcpyHostToDevice, ctx->stream));
     }
+    ProfScope ps(ctx, R_LUT);
     JV_TRY(launch_center_queries(ctx->stream, pq, l->d_raw_queries, Q, l->d_queries));
     // cosine numerator uses the DOT_PRODUCT partial sums (PQDecoder.java:117, FusedPQDecoder.java:187)
     const int lut_vsf = (vsf == JV_EUCLIDEAN) ? VSF_L2 : VSF_DOT;
@@ -733,8 +825,11 @@ int jv_hip_adc_scan(jv_ctx *ctx, const jv_luts *l, const jv_codes *codes, int64_
     if (l->vsf == JV_COSINE) JV_TRY(ensure_code_norms(ctx, const_cast<jv_codes *>(codes)));
     OutStage os;
     JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)l->Q * count, ctx->d_out, &os));
-    JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, codes->M, to_kernel_vsf(l->vsf), codes->d_codes,
-                      codes->d_norms, codes->count, first, count, nullptr, (float *)os.dev));
+    {
+        ProfScope ps(ctx, R_ADC);
+        JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, codes->M, to_kernel_vsf(l->vsf), codes->d_codes,
+                          codes->d_norms, codes->count, first, count, nullptr, (float *)os.dev));
+    }
     return stage_out_end(ctx, os);
 }
 
@@ -753,8 +848,11 @@ int jv_hip_adc_scores(jv_ctx *ctx, const jv_luts *l, const jv_codes *codes, cons
     JV_TRY(stage_in(ctx, ordinals, sizeof(int32_t) * (size_t)l->Q * B, ctx->h_in, ctx->d_in, &d_ord));
     OutStage os;
     JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)l->Q * B, ctx->d_out, &os));
-    JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, codes->M, to_kernel_vsf(l->vsf), codes->d_codes,
-                      codes->d_norms, codes->count, 0, B, (const int32_t *)d_ord, (float *)os.dev));
+    {
+        ProfScope ps(ctx, R_ADC);
+        JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, codes->M, to_kernel_vsf(l->vsf), codes->d_codes,
+                          codes->d_norms, codes->count, 0, B, (const int32_t *)d_ord, (float *)os.dev));
+    }
     return stage_out_end(ctx, os);
 }
 
@@ -829,9 +927,12 @@ int jv_hip_fused_scores(jv_ctx *ctx, const jv_luts *l, const jv_fused *f, const 
     const size_t cells = (size_t)l->Q * f->maxDegree;
     JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * cells, ctx->d_out, &os));
     if (neighbors_out) JV_TRY(stage_out_begin(ctx, neighbors_out, sizeof(int32_t) * cells, ctx->d_scratch, &ns));
-    JV_TRY(launch_fused(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, f->M, to_kernel_vsf(l->vsf), f->d_blocks,
-                        f->d_neighbors, f->d_norms, f->maxDegree, f->count, (const int32_t *)d_org, (float *)os.dev,
-                        neighbors_out ? (int32_t *)ns.dev : nullptr));
+    {
+        ProfScope ps(ctx, R_ADC);
+        JV_TRY(launch_fused(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, f->M, to_kernel_vsf(l->vsf), f->d_blocks,
+                            f->d_neighbors, f->d_norms, f->maxDegree, f->count, (const int32_t *)d_org, (float *)os.dev,
+                            neighbors_out ? (int32_t *)ns.dev : nullptr));
+    }
     JV_TRY(stage_out_end(ctx, os));
     if (neighbors_out) JV_TRY(stage_out_end(ctx, ns));
     return JV_OK;
@@ -856,8 +957,11 @@ int jv_hip_exact_scores(jv_ctx *ctx, const jv_vectors *v, const float *queries, 
     JV_TRY(ctx->d_scratch3.reserve(sizeof(float) * (size_t)Q));
     OutStage os;
     JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)Q * B, ctx->d_out, &os));
-    JV_TRY(launch_exact_gather(ctx->stream, v->d_vecs, v->count, v->D, (const float *)d_q, Q, to_kernel_vsf(vsf),
-                               (const int32_t *)d_ord, B, (float *)os.dev, (float *)ctx->d_scratch3.ptr));
+    {
+        ProfScope ps(ctx, R_EXACT);
+        JV_TRY(launch_exact_gather(ctx->stream, v->d_vecs, v->count, v->D, (const float *)d_q, Q, to_kernel_vsf(vsf),
+                                   (const int32_t *)d_ord, B, (float *)os.dev, (float *)ctx->d_scratch3.ptr));
+    }
     return stage_out_end(ctx, os);
 }
 
@@ -875,8 +979,11 @@ int jv_hip_exact_scan(jv_ctx *ctx, const jv_vectors *v, const float *queries, in
     JV_TRY(ctx->d_scratch3.reserve(sizeof(float) * (size_t)Q));
     OutStage os;
     JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)Q * count, ctx->d_out, &os));
-    JV_TRY(launch_exact_scan(ctx->stream, ctx, v->d_vecs, v->D, (const float *)d_q, Q, to_kernel_vsf(vsf), first, count,
-                             (float *)os.dev, (float *)ctx->d_scratch3.ptr));
+    {
+        ProfScope ps(ctx, R_EXACT);
+        JV_TRY(launch_exact_scan(ctx->stream, ctx, v->d_vecs, v->D, (const float *)d_q, Q, to_kernel_vsf(vsf), first,
+                                 count, (float *)os.dev, (float *)ctx->d_scratch3.ptr));
+    }
     return stage_out_end(ctx, os);
 }
 
@@ -900,8 +1007,11 @@ int jv_hip_topk(jv_ctx *ctx, const float *scores, const int32_t *ids, int Q, int
     OutStage oi, osc;
     JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * k, ctx->d_out, &oi));
     JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * k, ctx->d_scratch3, &osc));
-    JV_TRY(launch_topk(ctx->stream, ctx, (const float *)d_scores, (const int32_t *)d_ids, Q, n, stride, id_base, k,
-                       (int32_t *)oi.dev, (float *)osc.dev, ctx->d_scratch.ptr));
+    {
+        ProfScope ps(ctx, R_TOPK);
+        JV_TRY(launch_topk(ctx->stream, ctx, (const float *)d_scores, (const int32_t *)d_ids, Q, n, stride, id_base, k,
+                           (int32_t *)oi.dev, (float *)osc.dev, ctx->d_scratch.ptr));
+    }
     JV_TRY(stage_out_end(ctx, oi));
     return stage_out_end(ctx, osc);
 }
@@ -932,8 +1042,11 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
     // scratch: approximate scores Q x N
     JV_TRY(ctx->d_scratch2.reserve(sizeof(float) * (size_t)Q * N));
     float *d_scores = (float *)ctx->d_scratch2.ptr;
-    JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes, codes->d_norms, N, 0, N,
-                      nullptr, d_scores));
+    {
+        ProfScope ps(ctx, R_ADC);
+        JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes, codes->d_norms, N, 0,
+                          N, nullptr, d_scores));
+    }
 
     OutStage oi, osc;
     JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_out, &oi));
@@ -949,12 +1062,21 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
     JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, std::max(k1, topK))));
 
     if (!rerank) {
+        ProfScope ps(ctx, R_TOPK);
         JV_TRY(launch_topk(ctx->stream, ctx, d_scores, nullptr, Q, N, N, 0, topK, (int32_t *)oi.dev, (float *)osc.dev,
                            ctx->d_scratch.ptr));
     } else {
-        JV_TRY(launch_topk(ctx->stream, ctx, d_scores, nullptr, Q, N, N, 0, k1, d_cand, d_cand_sc, ctx->d_scratch.ptr));
-        JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf,
-                                   d_cand, k1, d_exact, d_qnorm));
+        {
+            ProfScope ps(ctx, R_TOPK);
+            JV_TRY(launch_topk(ctx->stream, ctx, d_scores, nullptr, Q, N, N, 0, k1, d_cand, d_cand_sc,
+                               ctx->d_scratch.ptr));
+        }
+        {
+            ProfScope ps(ctx, R_EXACT);
+            JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q,
+                                       kvsf, d_cand, k1, d_exact, d_qnorm));
+        }
+        ProfScope ps(ctx, R_TOPK);
         JV_TRY(launch_topk(ctx->stream, ctx, d_exact, d_cand, Q, k1, k1, 0, topK, (int32_t *)oi.dev, (float *)osc.dev,
                            ctx->d_scratch.ptr));
     }

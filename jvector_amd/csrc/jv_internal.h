@@ -54,7 +54,20 @@ struct Buffer {
 
 }  // namespace jv
 
+namespace jv {
+enum Region : int { R_ADC = 0, R_TOPK, R_EXACT, R_LUT, R_ENCODE, R_NORMS, R_COUNT };
+struct ProfEvent {
+    int region;
+    hipEvent_t start, stop;
+};
+}  // namespace jv
+
 struct jv_ctx {
+    bool profiling = false;
+    std::vector<jv::ProfEvent> prof_pending;   // recorded, not yet resolved
+    std::vector<hipEvent_t> prof_free;         // event pool
+    double prof_ms[jv::R_COUNT] = {0};
+    int64_t prof_count[jv::R_COUNT] = {0};
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;

@@ -85,6 +85,16 @@ class HipContext:
     def sync(self):
         check(self._lib.jv_hip_ctx_sync(self._h))
 
+    def profile(self, enable=True):
+        """Start (and reset) / stop HIP-event timing of the kernel regions on this context's stream."""
+        check(self._lib.jv_hip_ctx_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self, region):
+        """(total_ms, count) of a region: 'adc', 'topk', 'exact', 'lut', 'encode', 'norms'. Synchronises."""
+        ms, cnt = C.c_double(), C.c_int64()
+        check(self._lib.jv_hip_ctx_profile_read(self._h, region.encode(), C.byref(ms), C.byref(cnt)))
+        return float(ms.value), int(cnt.value)
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.jv_hip_ctx_destroy(self._h)

@@ -626,3 +626,166 @@ void jvo_make_vec(float *v, size_t n, float seed)
         v[i] += 0.5f;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * CPU baseline driver ("port"): the two-pass flat search the GPU bench times, restated with the
+ * oracle's per-candidate arithmetic, one query per worker thread (the reference parallelises over
+ * queries: ThroughputBenchmark's parallel stream, EX/benchmarks/ThroughputBenchmark.java:146-231).
+ * Bounded-heap top-k replaces the full sort of jvo_topk (same order, NodeQueue keys).
+ * ---------------------------------------------------------------------------------------- */
+static void heap_sift_down(int64_t *h, int n, int i)
+{
+    for (;;) {
+        int l = 2 * i + 1, r = l + 1, s = i;
+        if (l < n && h[l] < h[s]) s = l;
+        if (r < n && h[r] < h[s]) s = r;
+        if (s == i) return;
+        int64_t t = h[i]; h[i] = h[s]; h[s] = t;
+        i = s;
+    }
+}
+
+/* min-heap of the k largest keys (BoundedLongHeap.push semantics: reject value < top) */
+static int topk_heap_push(int64_t *h, int size, int k, int64_t key)
+{
+    if (size < k) {
+        int i = size++;
+        h[i] = key;
+        while (i > 0 && h[(i - 1) / 2] > h[i]) {
+            int p = (i - 1) / 2;
+            int64_t t = h[i]; h[i] = h[p]; h[p] = t;
+            i = p;
+        }
+        return size;
+    }
+    if (key < h[0]) return size;
+    h[0] = key;
+    heap_sift_down(h, size, 0);
+    return size;
+}
+
+typedef struct {
+    const jvo_pq *pq;
+    const uint8_t *codes;
+    const float *vecs;   /* N x D, may be NULL (no rerank) */
+    int64_t n;
+    const float *queries;
+    int q_lo, q_hi, vsf, topK, rerankK;
+    int32_t *out_ids;
+    float *out_scores;
+} flat_job;
+
+static void *flat_worker(void *arg)
+{
+    flat_job *j = (flat_job *)arg;
+    const jvo_pq *pq = j->pq;
+    const int M = pq->M, k = pq->k, D = pq->D;
+    float *lut = (float *)malloc(sizeof(float) * (size_t)M * k);
+    float *amag = (float *)malloc(sizeof(float) * (size_t)M * k);
+    const int k1 = (j->vecs && j->rerankK > 0) ? j->rerankK : j->topK;
+    int64_t *heap = (int64_t *)malloc(sizeof(int64_t) * (size_t)k1);
+    int64_t *heap2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)j->topK);
+    for (int q = j->q_lo; q < j->q_hi; q++) {
+        const float *query = j->queries + (size_t)q * D;
+        float bmag = 0.0f;
+        jvo_pqdecoder_init(pq, query, j->vsf, lut, amag, &bmag);
+        int size = 0;
+        for (int64_t i = 0; i < j->n; i++) {
+            float s = jvo_adc_score(j->vsf, M, k, lut, amag, bmag, j->codes + i * M);
+            size = topk_heap_push(heap, size, k1, jvo_nodequeue_encode((int32_t)i, s));
+        }
+        int64_t *res = heap;
+        int rsize = size;
+        if (j->vecs && j->rerankK > 0) {
+            int s2 = 0;
+            for (int c = 0; c < size; c++) {
+                int32_t id = (int32_t)~(uint32_t)(heap[c] & 0xFFFFFFFFLL);
+                float ex = jvo_compare(j->vsf, query, j->vecs + (size_t)id * D, D);
+                s2 = topk_heap_push(heap2, s2, j->topK, jvo_nodequeue_encode(id, ex));
+            }
+            res = heap2;
+            rsize = s2;
+        }
+        qsort(res, (size_t)rsize, sizeof(int64_t), cmp_desc_i64);
+        for (int c = 0; c < j->topK; c++) {
+            if (c < rsize) {
+                j->out_ids[(size_t)q * j->topK + c] = (int32_t)~(uint32_t)(res[c] & 0xFFFFFFFFLL);
+                j->out_scores[(size_t)q * j->topK + c] = jvo_sortable_int_to_float((int32_t)(res[c] >> 32));
+            } else {
+                j->out_ids[(size_t)q * j->topK + c] = -1;
+                j->out_scores[(size_t)q * j->topK + c] = -INFINITY;
+            }
+        }
+    }
+    free(lut); free(amag); free(heap); free(heap2);
+    return NULL;
+}
+
+void jvo_search_flat(const jvo_pq *pq, const uint8_t *codes, const float *vecs, int64_t n, const float *queries,
+                     int Q, int vsf, int topK, int rerankK, int32_t *out_ids, float *out_scores, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    if (nthreads > Q) nthreads = Q > 0 ? Q : 1;
+    pthread_t th[64];
+    flat_job jobs[64];
+    int per = (Q + nthreads - 1) / nthreads, started = 0;
+    for (int t = 0; t < nthreads; t++) {
+        int lo = t * per, hi = lo + per > Q ? Q : lo + per;
+        if (lo >= hi) break;
+        jobs[t] = (flat_job){pq, codes, vecs, n, queries, lo, hi, vsf, topK, rerankK, out_ids, out_scores};
+        pthread_create(&th[t], NULL, flat_worker, &jobs[t]);
+        started++;
+    }
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
+
+/* Exact rerank of pre-gathered candidates (NodeQueue.rerank's scoring, B/graph/NodeQueue.java:160-195, with the
+ * deterministic (score desc, id asc) order): cand_vecs holds Q x R rows of D floats, cand_ids Q x R ids (-1 = skip). */
+typedef struct {
+    const float *queries, *cand_vecs; const int32_t *cand_ids;
+    int q_lo, q_hi, R, D, vsf, topK; int32_t *out_ids; float *out_scores;
+} rr_job;
+
+static void *rr_worker(void *arg)
+{
+    rr_job *j = (rr_job *)arg;
+    int64_t *heap = (int64_t *)malloc(sizeof(int64_t) * (size_t)j->topK);
+    for (int q = j->q_lo; q < j->q_hi; q++) {
+        int size = 0;
+        for (int c = 0; c < j->R; c++) {
+            int32_t id = j->cand_ids[(size_t)q * j->R + c];
+            if (id < 0) continue;
+            float ex = jvo_compare(j->vsf, j->queries + (size_t)q * j->D,
+                                   j->cand_vecs + ((size_t)q * j->R + c) * j->D, j->D);
+            size = topk_heap_push(heap, size, j->topK, jvo_nodequeue_encode(id, ex));
+        }
+        qsort(heap, (size_t)size, sizeof(int64_t), cmp_desc_i64);
+        for (int c = 0; c < j->topK; c++) {
+            j->out_ids[(size_t)q * j->topK + c] = c < size ? (int32_t)~(uint32_t)(heap[c] & 0xFFFFFFFFLL) : -1;
+            j->out_scores[(size_t)q * j->topK + c] =
+                c < size ? jvo_sortable_int_to_float((int32_t)(heap[c] >> 32)) : -INFINITY;
+        }
+    }
+    free(heap);
+    return NULL;
+}
+
+void jvo_rerank(const float *queries, const float *cand_vecs, const int32_t *cand_ids, int Q, int R, int D, int vsf,
+                int topK, int32_t *out_ids, float *out_scores, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    if (nthreads > Q) nthreads = Q > 0 ? Q : 1;
+    pthread_t th[64];
+    rr_job jobs[64];
+    int per = (Q + nthreads - 1) / nthreads, started = 0;
+    for (int t = 0; t < nthreads; t++) {
+        int lo = t * per, hi = lo + per > Q ? Q : lo + per;
+        if (lo >= hi) break;
+        jobs[t] = (rr_job){queries, cand_vecs, cand_ids, lo, hi, R, D, vsf, topK, out_ids, out_scores};
+        pthread_create(&th[t], NULL, rr_worker, &jobs[t]);
+        started++;
+    }
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}

@@ -109,6 +109,16 @@ int64_t jvo_nodequeue_encode(int32_t node, float score);
 int     jvo_topk(const int32_t *ids, const float *scores, int64_t n, int k,
                  int32_t *out_ids, float *out_scores);
 
+/* CPU-baseline driver: two-pass flat search (ADC scan of all codes -> top rerankK -> exact rerank -> topK),
+ * one query per worker thread.  vecs may be NULL (then no rerank).  Used by bench.py's cpu_baseline leg and
+ * by tests as the end-to-end checker. */
+void jvo_search_flat(const jvo_pq *pq, const uint8_t *codes, const float *vecs, int64_t n, const float *queries,
+                     int Q, int vsf, int topK, int rerankK, int32_t *out_ids, float *out_scores, int nthreads);
+
+/* exact rerank of pre-gathered candidate rows (Q x R x D), one query per worker thread */
+void jvo_rerank(const float *queries, const float *cand_vecs, const int32_t *cand_ids, int Q, int R, int D, int vsf,
+                int topK, int32_t *out_ids, float *out_scores, int nthreads);
+
 /* ---- PQVectors.PQLayout chunk math: B/quantization/PQVectors.java:515-540 ---- */
 typedef struct {
     int fullChunkVectors, lastChunkVectors, fullSizeChunks, totalChunks, fullChunkBytes, lastChunkBytes;

@@ -81,6 +81,8 @@ def lib():
         sig("jvo_sortable_int_to_float", C.c_float, C.c_int32)
         sig("jvo_nodequeue_encode", C.c_int64, C.c_int32, C.c_float)
         sig("jvo_topk", C.c_int, i32p, fp, C.c_int64, C.c_int, i32p, fp)
+        sig("jvo_search_flat", None, pqp, u8p, fp, C.c_int64, fp, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp, C.c_int)
+        sig("jvo_rerank", None, fp, fp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp, C.c_int)
         sig("jvo_pq_layout_compute", C.c_int, C.c_int, C.c_int, C.POINTER(_Layout))
         sig("jvo_pq_parse", C.c_int, u8p, C.c_size_t, i32p, i32p, i32p, i32p, i32p, fp, i32p, C.c_int,
             fp, fp, C.c_size_t, C.POINTER(C.c_size_t))
@@ -189,6 +191,18 @@ def topk(ids, scores, k):
     return oi[:cnt].copy(), os_[:cnt].copy()
 
 
+def rerank(queries, cand_vecs, cand_ids, vsf, top_k, nthreads=1):
+    """exact rerank of pre-gathered candidates: cand_vecs (Q, R, D), cand_ids (Q, R) -> (ids, scores) (Q, top_k)"""
+    queries, cand_vecs = f32(queries), f32(cand_vecs)
+    cand_ids = np.ascontiguousarray(cand_ids, np.int32)
+    Q, R = cand_ids.shape
+    ids = np.empty((Q, top_k), np.int32)
+    sc = np.empty((Q, top_k), np.float32)
+    lib().jvo_rerank(_f(queries), _f(cand_vecs), _i32(cand_ids), Q, R, queries.shape[1], vsf, top_k, _i32(ids),
+                     _f(sc), nthreads)
+    return ids, sc
+
+
 def pq_layout(vector_count, compressed_dim):
     lay = _Layout()
     rc = lib().jvo_pq_layout_compute(vector_count, compressed_dim, C.byref(lay))
@@ -272,6 +286,17 @@ class OraclePQ:
         lib().jvo_adc_scores(vsf, self.M, self.k, _f(lut), None if amag is None else _f(amag),
                              C.c_float(bm), _u8(codes), ordp, n, _f(out))
         return out
+
+    def search_flat(self, codes, vecs, queries, vsf, top_k, rerank_k, nthreads=1):
+        codes = np.ascontiguousarray(codes, np.uint8)
+        queries = f32(queries)
+        vecs = None if vecs is None else f32(vecs)
+        Q = queries.shape[0]
+        ids = np.empty((Q, top_k), np.int32)
+        sc = np.empty((Q, top_k), np.float32)
+        lib().jvo_search_flat(self.ref, _u8(codes), None if vecs is None else _f(vecs), codes.shape[0], _f(queries), Q,
+                              vsf, top_k, rerank_k, _i32(ids), _f(sc), nthreads)
+        return ids, sc
 
     def direct_score(self, query, vsf, code):
         query, code = f32(query), np.ascontiguousarray(code, np.uint8)
