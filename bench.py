@@ -206,6 +206,7 @@ def main():
         rerank_k = rk
         if rec >= 0.95:
             break
+    torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
 
     def barrier():

@@ -70,8 +70,14 @@ JV_API int jv_hip_device_count(void);
 /* Diagnostic twin of jvector_simd_get_active_isa (jvector_simd.h:47): e.g. "gfx950:sramecc+:xnack-". */
 JV_API const char *jv_hip_active_arch(int device);
 
-/* stream: an existing hipStream_t to enqueue on (e.g. the caller framework's current stream), or NULL
- * to let the context create its own non-blocking stream. */
+/* stream: the hipStream_t every call of this context enqueues on.
+ *   - an existing stream handle (e.g. the caller framework's current stream) — the engine's work is then
+ *     ordered with the caller's own work on that stream;
+ *   - NULL: the HIP null (legacy default) stream, which is ordered with all blocking streams;
+ *   - JV_STREAM_PRIVATE: the context creates (and owns) its own non-blocking stream; the caller must then
+ *     order its own producers/consumers of device buffers with jv_hip_ctx_sync() — device memory written by
+ *     another stream and handed to the engine without that ordering is a data race. */
+#define JV_STREAM_PRIVATE ((void *)(intptr_t)-1)
 JV_API int jv_hip_ctx_create(int device, void *stream, jv_ctx **out);
 JV_API int jv_hip_ctx_destroy(jv_ctx *ctx);
 JV_API int jv_hip_ctx_sync(jv_ctx *ctx);

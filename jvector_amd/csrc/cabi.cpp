@@ -253,8 +253,8 @@ int jv_hip_ctx_create(int device, void *stream, jv_ctx **out)
     c->lds_per_block = prop.maxSharedMemoryPerMultiProcessor ? (size_t)prop.maxSharedMemoryPerMultiProcessor
                                                              : (size_t)prop.sharedMemPerBlock;
     if (c->lds_per_block > 160 * 1024) c->lds_per_block = 160 * 1024;
-    if (stream) {
-        c->stream = (hipStream_t)stream;
+    if (stream != JV_STREAM_PRIVATE) {
+        c->stream = (hipStream_t)stream;  // NULL = the legacy default stream
         c->owns_stream = false;
     } else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -110,20 +110,23 @@ __global__ __launch_bounds__(256) void topk_select_kernel(int pass, int k, SelSt
             }
         }
         // find chunk, then bin
+        // (every loop is bounded: if the input is modified concurrently by another stream the histogram may
+        //  be inconsistent with k_rem; we then settle on the last bin instead of spinning)
         unsigned int cum = 0;
         int t = 0;
-        for (; t < 256; ++t) {
+        for (; t < 255; ++t) {
             if (cum + chunk_sum[t] >= s.k_rem) break;
             cum += chunk_sum[t];
         }
         int pos = t * (kBins / 256);
-        for (;; ++pos) {
+        for (; pos < kBins - 1; ++pos) {
             if (cum + lh[pos] >= s.k_rem) break;
             cum += lh[pos];
         }
+        if (pos > nb - 1) pos = nb - 1;
         const int bin = nb - 1 - pos;
         s.prefix |= ((unsigned long long)bin) << c_shift[pass];
-        s.k_rem -= cum;                       // still needed from inside this bin
+        s.k_rem = s.k_rem > cum ? s.k_rem - cum : 0u;  // still needed from inside this bin
         if (lh[pos] == s.k_rem || pass == kPasses - 1) s.done = 1;  // whole bin needed: lower bits irrelevant
         st[q] = s;
     }

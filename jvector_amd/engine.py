@@ -68,13 +68,27 @@ def device_count() -> int:
 class HipContext:
     """One per host thread: owns the HIP stream + staging scratch (jv_ctx).
 
-    stream: an existing hipStream_t handle (int), e.g. torch.cuda.current_stream().cuda_stream, or None.
+    stream: a hipStream_t handle (int; 0 = the legacy default stream), "private" for a context-owned non-blocking
+    stream, or None = the stream torch is currently using on that device (so engine calls are ordered with the
+    tensors the caller produces/consumes), falling back to the default stream without torch.
     """
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream=None):
         self._lib = _lib.load()
         h = C.c_void_p()
-        check(self._lib.jv_hip_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        if stream == "private":
+            sp = C.c_void_p(-1)  # JV_STREAM_PRIVATE
+        elif stream is None:
+            sp = None
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    sp = C.c_void_p(torch.cuda.current_stream(int(device)).cuda_stream or None)
+            except ImportError:
+                pass
+        else:
+            sp = C.c_void_p(int(stream) or None)
+        check(self._lib.jv_hip_ctx_create(int(device), sp, C.byref(h)))
         self._h = h
         self.device = int(device)
 
