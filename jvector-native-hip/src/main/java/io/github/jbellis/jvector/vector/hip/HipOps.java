@@ -1,0 +1,166 @@
+/*
+ * FFM (Java 22) downcall handles for include/jvector_hip.h — hand-written in the shape jextract generates for
+ * the reference (jvector-native/.../vector/cnative/NativeSimdOps.java:59-60,1152-1211), with two differences:
+ *   - NO Linker.Option.critical(true): batched GPU calls block for milliseconds and must not pin the GC;
+ *   - every buffer handed to a jv_hip_* call is an OFF-HEAP MemorySegment (Arena.ofShared / ofConfined).
+ * Type map: pointer -> ADDRESS, size_t/int64_t -> JAVA_LONG, int/enum -> JAVA_INT.
+ * NOT compiled in this repository (no JDK in the build image).
+ */
+package io.github.jbellis.jvector.vector.hip;
+
+import java.io.File;
+import java.lang.foreign.*;
+import java.lang.invoke.MethodHandle;
+import java.nio.file.Files;
+
+import static java.lang.foreign.ValueLayout.*;
+
+public final class HipOps {
+    private HipOps() {}
+
+    private static final Linker LINKER = Linker.nativeLinker();
+    private static SymbolLookup LOOKUP;
+
+    /** Same two-step strategy as LibraryLoader.loadJvector (cnative/LibraryLoader.java:28-55). */
+    public static synchronized boolean load() {
+        if (LOOKUP != null) return true;
+        try {
+            System.loadLibrary("jvector_hip");
+        } catch (UnsatisfiedLinkError e) {
+            try {
+                String libName = System.mapLibraryName("jvector_hip");
+                File tmp = File.createTempFile("libjvector_hip", ".so");
+                try (var in = HipOps.class.getResourceAsStream("/" + libName); var out = Files.newOutputStream(tmp.toPath())) {
+                    if (in == null) return false;
+                    in.transferTo(out);
+                }
+                System.load(tmp.getAbsolutePath());
+            } catch (Exception | UnsatisfiedLinkError e2) {
+                return false;
+            }
+        }
+        LOOKUP = SymbolLookup.loaderLookup().or(LINKER.defaultLookup());
+        return true;
+    }
+
+    private static MethodHandle h(String name, FunctionDescriptor d) {
+        return LINKER.downcallHandle(LOOKUP.find(name).orElseThrow(() -> new UnsatisfiedLinkError(name)), d);
+    }
+
+    private static final class H {
+        static final MethodHandle lastError = h("jv_hip_last_error", FunctionDescriptor.of(ADDRESS));
+        static final MethodHandle deviceCount = h("jv_hip_device_count", FunctionDescriptor.of(JAVA_INT));
+        static final MethodHandle activeArch = h("jv_hip_active_arch", FunctionDescriptor.of(ADDRESS, JAVA_INT));
+        static final MethodHandle ctxCreate = h("jv_hip_ctx_create", FunctionDescriptor.of(JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle ctxDestroy = h("jv_hip_ctx_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle ctxSync = h("jv_hip_ctx_sync", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle pqCreate = h("jv_hip_pq_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle pqLoad = h("jv_hip_pq_load", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS));
+        static final MethodHandle pqDestroy = h("jv_hip_pq_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle codesCreate = h("jv_hip_codes_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS));
+        static final MethodHandle codesUpload = h("jv_hip_codes_upload", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));
+        static final MethodHandle codesDestroy = h("jv_hip_codes_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle vectorsCreate = h("jv_hip_vectors_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, JAVA_INT, ADDRESS));
+        static final MethodHandle vectorsUpload = h("jv_hip_vectors_upload", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));
+        static final MethodHandle vectorsDestroy = h("jv_hip_vectors_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle pqEncode = h("jv_hip_pq_encode", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS));
+        static final MethodHandle lutsCreate = h("jv_hip_luts_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS));
+        static final MethodHandle lutsBuild = h("jv_hip_luts_build", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT));
+        static final MethodHandle lutsDestroy = h("jv_hip_luts_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle adcScores = h("jv_hip_adc_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, ADDRESS));
+        static final MethodHandle adcScan = h("jv_hip_adc_scan", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));
+        static final MethodHandle fusedCreate = h("jv_hip_fused_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_INT, ADDRESS));
+        static final MethodHandle fusedUpload = h("jv_hip_fused_upload", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS, ADDRESS));
+        static final MethodHandle fusedScores = h("jv_hip_fused_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle exactScores = h("jv_hip_exact_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
+        static final MethodHandle topk = h("jv_hip_topk", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_LONG, JAVA_LONG, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle searchFlat = h("jv_hip_search_flat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+    }
+
+    /** jv_status -> Java exception, mirroring the reference's exception types (include/jvector_hip.h:38-45). */
+    static void check(int status) {
+        if (status == 0) return;
+        String msg = lastError();
+        switch (status) {
+            case -1: throw new IllegalArgumentException(msg);
+            case -2: throw new UnsupportedOperationException(msg);   // no device: provider lookup falls back
+            case -4: throw new OutOfMemoryError(msg);
+            case -5: throw new UnsupportedOperationException(msg);
+            default: throw new IllegalStateException(msg);
+        }
+    }
+
+    public static String lastError() {
+        try {
+            return ((MemorySegment) H.lastError.invokeExact()).reinterpret(Long.MAX_VALUE).getString(0);
+        } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    public static int deviceCount() {
+        try { return (int) H.deviceCount.invokeExact(); } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    public static String activeArch(int device) {
+        try {
+            return ((MemorySegment) H.activeArch.invokeExact(device)).reinterpret(Long.MAX_VALUE).getString(0);
+        } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    // --- thin typed wrappers (only the ones HipBatchScorer needs are spelled out; the rest follow the same shape) ---
+    public static MemorySegment ctxCreate(Arena arena, int device) {
+        MemorySegment out = arena.allocate(ADDRESS);
+        try { check((int) H.ctxCreate.invokeExact(device, MemorySegment.ofAddress(-1L) /* JV_STREAM_PRIVATE */, out)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+        return out.get(ADDRESS, 0);
+    }
+
+    public static void ctxDestroy(MemorySegment ctx) {
+        try { check((int) H.ctxDestroy.invokeExact(ctx)); } catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    public static MemorySegment pqLoad(Arena arena, MemorySegment ctx, MemorySegment bytes) {
+        MemorySegment out = arena.allocate(ADDRESS);
+        try { check((int) H.pqLoad.invokeExact(ctx, bytes, bytes.byteSize(), MemorySegment.NULL, out)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+        return out.get(ADDRESS, 0);
+    }
+
+    public static MemorySegment codesCreate(Arena arena, MemorySegment ctx, MemorySegment pq, long count) {
+        MemorySegment out = arena.allocate(ADDRESS);
+        try { check((int) H.codesCreate.invokeExact(ctx, pq, count, out)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+        return out.get(ADDRESS, 0);
+    }
+
+    public static void codesUpload(MemorySegment ctx, MemorySegment codes, long first, long count, MemorySegment src) {
+        try { check((int) H.codesUpload.invokeExact(ctx, codes, first, count, src)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    public static MemorySegment lutsCreate(Arena arena, MemorySegment ctx, MemorySegment pq, int maxQueries) {
+        MemorySegment out = arena.allocate(ADDRESS);
+        try { check((int) H.lutsCreate.invokeExact(ctx, pq, maxQueries, out)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+        return out.get(ADDRESS, 0);
+    }
+
+    public static void lutsBuild(MemorySegment ctx, MemorySegment luts, MemorySegment queries, int q, int vsf, int kind) {
+        try { check((int) H.lutsBuild.invokeExact(ctx, luts, queries, q, vsf, kind)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    public static void adcScores(MemorySegment ctx, MemorySegment luts, MemorySegment codes, MemorySegment ordinals, int b, MemorySegment out) {
+        try { check((int) H.adcScores.invokeExact(ctx, luts, codes, ordinals, b, out)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    public static void fusedScores(MemorySegment ctx, MemorySegment luts, MemorySegment fused, MemorySegment origins, MemorySegment out, MemorySegment neighborsOut) {
+        try { check((int) H.fusedScores.invokeExact(ctx, luts, fused, origins, out, neighborsOut)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    public static void exactScores(MemorySegment ctx, MemorySegment vectors, MemorySegment queries, int q, int vsf, MemorySegment ordinals, int b, MemorySegment out) {
+        try { check((int) H.exactScores.invokeExact(ctx, vectors, queries, q, vsf, ordinals, b, out)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+    }
+}
