@@ -827,8 +827,13 @@ int jv_hip_adc_scan(jv_ctx *ctx, const jv_luts *l, const jv_codes *codes, int64_
     JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)l->Q * count, ctx->d_out, &os));
     {
         ProfScope ps(ctx, R_ADC);
-        JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, codes->M, to_kernel_vsf(l->vsf), codes->d_codes,
-                          codes->d_norms, codes->count, first, count, nullptr, (float *)os.dev));
+        // >= 2 queries over the same range: the multi-query kernel (4 queries per LDS gather); else single-query
+        if (l->Q >= 2 && adc_mq_supported(codes->M, codes->d_codes))
+            JV_TRY(launch_adc_mq_store(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, codes->M, to_kernel_vsf(l->vsf),
+                                       codes->d_codes, codes->d_norms, first, count, 1, (float *)os.dev));
+        else
+            JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, l->Q, codes->M, to_kernel_vsf(l->vsf),
+                              codes->d_codes, codes->d_norms, codes->count, first, count, nullptr, (float *)os.dev));
     }
     return stage_out_end(ctx, os);
 }
@@ -1018,7 +1023,24 @@ int jv_hip_topk(jv_ctx *ctx, const float *scores, const int32_t *ids, int Q, int
 
 // ------------------------------------------------------------------------------------------------
 // flat two-pass search
+//
+// Pass 1 (approximate): two strategies producing the SAME exact top-k1 of the ADC scores.
+//   * materialised: scan writes all Q x N scores, radix-select top-k1 reads them back (any shape);
+//   * threshold-filtered (multi-query kernel shapes, large N): a strided sample of S candidates is scored
+//     first; its k_s-th best score tau_q bounds the k1-th best of the full set from below with overwhelming
+//     probability (the expected number of candidates >= tau_q is c_target >= 8*k1); the full scan then appends
+//     only candidates with score >= tau_q to a small per-query list and top-k1 runs over that list.  The set
+//     {score >= tau} contains the true top-k1 whenever it has >= k1 members, so the result is exact; the host
+//     checks the per-query counts (k1 <= count <= capacity) and falls back to the materialised strategy otherwise.
+// Pass 2 (exact): gather-score the k1 candidates at full resolution, top-K under the NodeQueue order.
 // ------------------------------------------------------------------------------------------------
+static int next_pow2_i64(int64_t v)
+{
+    int64_t p = 1;
+    while (p < v) p <<= 1;
+    return (int)p;
+}
+
 int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_vectors *vectors, const float *queries,
                        int Q, jv_vsf vsf, int topK, int rerankK, int32_t id_base, int32_t *out_ids, float *out_scores)
 {
@@ -1039,15 +1061,6 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
     const int kvsf = to_kernel_vsf(vsf);
     const int k1 = rerank ? rerankK : topK;
 
-    // scratch: approximate scores Q x N
-    JV_TRY(ctx->d_scratch2.reserve(sizeof(float) * (size_t)Q * N));
-    float *d_scores = (float *)ctx->d_scratch2.ptr;
-    {
-        ProfScope ps(ctx, R_ADC);
-        JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes, codes->d_norms, N, 0,
-                          N, nullptr, d_scores));
-    }
-
     OutStage oi, osc;
     JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_out, &oi));
     JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * topK, ctx->d_in, &osc));
@@ -1059,18 +1072,82 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
     float *d_cand_sc = (float *)(d_cand + c1);
     float *d_exact = d_cand_sc + c1;
     float *d_qnorm = d_exact + c1;
-    JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, std::max(k1, topK))));
+    int32_t *d_k1_ids = rerank ? d_cand : (int32_t *)oi.dev;
+    float *d_k1_sc = rerank ? d_cand_sc : (float *)osc.dev;
 
-    if (!rerank) {
-        ProfScope ps(ctx, R_TOPK);
-        JV_TRY(launch_topk(ctx->stream, ctx, d_scores, nullptr, Q, N, N, 0, topK, (int32_t *)oi.dev, (float *)osc.dev,
-                           ctx->d_scratch.ptr));
-    } else {
-        {
-            ProfScope ps(ctx, R_TOPK);
-            JV_TRY(launch_topk(ctx->stream, ctx, d_scores, nullptr, Q, N, N, 0, k1, d_cand, d_cand_sc,
-                               ctx->d_scratch.ptr));
+    // ---------------- pass 1 ----------------
+    bool done1 = false;
+    const bool mq = adc_mq_supported(codes->M, codes->d_codes) && Q >= 2;
+    if (mq && N >= (1 << 18) && (int64_t)k1 * 64 <= N && getenv("JVECTOR_HIP_NO_FILTER") == nullptr) {
+        const int64_t c_target = std::max<int64_t>(8 * (int64_t)k1, 4096);
+        int64_t S_target = std::max<int64_t>(16384, next_pow2_i64(32 * N / c_target));
+        const int64_t stride = std::max<int64_t>(1, N / S_target);
+        const int64_t S = N / stride;  // sampled rows: 0, stride, 2*stride, ...
+        const int k_s = (int)std::max<int64_t>(16, (c_target * S + N - 1) / N);
+        const int cap = (int)std::min<int64_t>(N, 4 * c_target);
+        if (k_s <= 4096 && S >= k_s) {
+            // scratch2: [sample scores Q*S][sample top ids Q*k_s][sample top scores Q*k_s][cand ids Q*cap][cand sc Q*cap][counts Q]
+            const size_t b_samp = sizeof(float) * (size_t)Q * S, b_ks = sizeof(float) * (size_t)Q * k_s;
+            const size_t b_cap = sizeof(float) * (size_t)Q * cap;
+            JV_TRY(ctx->d_scratch2.reserve(b_samp + 2 * b_ks + 2 * b_cap + sizeof(unsigned int) * (size_t)Q + 1024));
+            char *base = (char *)ctx->d_scratch2.ptr;
+            float *d_samp = (float *)base;
+            int32_t *d_ks_ids = (int32_t *)(base + b_samp);
+            float *d_ks_sc = (float *)(base + b_samp + b_ks);
+            int32_t *d_f_ids = (int32_t *)(base + b_samp + 2 * b_ks);
+            float *d_f_sc = (float *)(base + b_samp + 2 * b_ks + b_cap);
+            unsigned int *d_cnt = (unsigned int *)(base + b_samp + 2 * b_ks + 2 * b_cap);
+            JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, std::max(std::max(k1, topK), k_s))));
+            {
+                ProfScope ps(ctx, R_ADC);
+                JV_TRY(launch_adc_mq_store(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes,
+                                           codes->d_norms, 0, S, stride, d_samp));
+            }
+            {
+                ProfScope ps(ctx, R_TOPK);
+                JV_TRY(launch_topk(ctx->stream, ctx, d_samp, nullptr, Q, S, S, 0, k_s, d_ks_ids, d_ks_sc, ctx->d_scratch.ptr));
+            }
+            JV_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * (size_t)Q, ctx->stream));
+            {
+                ProfScope ps(ctx, R_ADC);
+                JV_TRY(launch_adc_mq_filter(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes,
+                                            codes->d_norms, 0, N, d_ks_sc + (k_s - 1), k_s, d_f_ids, d_f_sc, d_cnt, cap));
+            }
+            // host check of the per-query list sizes (one small D2H + sync per call)
+            JV_TRY(ctx->h_out.reserve(sizeof(unsigned int) * (size_t)Q));
+            JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_cnt, sizeof(unsigned int) * (size_t)Q, hipMemcpyDeviceToHost,
+                                        ctx->stream));
+            JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            const unsigned int *cnt = (const unsigned int *)ctx->h_out.ptr;
+            bool ok = true;
+            for (int q = 0; q < Q; ++q) ok = ok && cnt[q] >= (unsigned int)k1 && cnt[q] <= (unsigned int)cap;
+            if (ok) {
+                ProfScope ps(ctx, R_TOPK);
+                JV_TRY(launch_topk(ctx->stream, ctx, d_f_sc, d_f_ids, Q, cap, cap, 0, k1, d_k1_ids, d_k1_sc,
+                                   ctx->d_scratch.ptr, d_cnt));
+                done1 = true;
+            }
         }
+    }
+    if (!done1) {
+        JV_TRY(ctx->d_scratch2.reserve(sizeof(float) * (size_t)Q * N));
+        float *d_scores = (float *)ctx->d_scratch2.ptr;
+        JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, std::max(k1, topK))));
+        {
+            ProfScope ps(ctx, R_ADC);
+            if (mq)
+                JV_TRY(launch_adc_mq_store(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes,
+                                           codes->d_norms, 0, N, 1, d_scores));
+            else
+                JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes,
+                                  codes->d_norms, N, 0, N, nullptr, d_scores));
+        }
+        ProfScope ps(ctx, R_TOPK);
+        JV_TRY(launch_topk(ctx->stream, ctx, d_scores, nullptr, Q, N, N, 0, k1, d_k1_ids, d_k1_sc, ctx->d_scratch.ptr));
+    }
+
+    // ---------------- pass 2 ----------------
+    if (rerank) {
         {
             ProfScope ps(ctx, R_EXACT);
             JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q,

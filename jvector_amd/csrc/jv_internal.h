@@ -163,7 +163,16 @@ int launch_exact_scan(hipStream_t s, const jv_ctx *ctx, const float *d_vecs, int
 
 size_t topk_scratch_bytes(int Q, int k);
 int launch_topk(hipStream_t s, const jv_ctx *ctx, const float *d_scores, const int32_t *d_ids, int Q, int64_t n,
-                int64_t stride, int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, void *d_scratch);
+                int64_t stride, int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, void *d_scratch,
+                const unsigned int *d_row_counts = nullptr);
+bool adc_mq_supported(int M, const uint8_t *d_codes);
+int launch_adc_mq_store(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const float *d_bmag, int Q, int M,
+                        int vsf, const uint8_t *d_codes, const float *d_norms, int64_t first, int64_t count,
+                        int64_t row_stride, float *d_out);
+int launch_adc_mq_filter(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const float *d_bmag, int Q, int M,
+                         int vsf, const uint8_t *d_codes, const float *d_norms, int64_t first, int64_t count,
+                         const float *d_tau, int tau_stride, int32_t *d_cand_ids, float *d_cand_scores,
+                         unsigned int *d_cand_count, int cap);
 int launch_add_id_base(hipStream_t s, int32_t *d_ids, int64_t n, int32_t base);
 
 }  // namespace jv

@@ -33,8 +33,9 @@ __device__ __constant__ int c_shift[kPasses] = {53, 42, 32, 21, 10, 0};
 __device__ __constant__ int c_width[kPasses] = {11, 11, 10, 11, 11, 10};
 
 __device__ __forceinline__ bool load_key(const float *__restrict__ scores, const int32_t *__restrict__ ids,
-                                         int64_t row_off, int64_t col, int32_t id_base, unsigned long long &key)
+                                         int64_t row_off, int64_t col, int32_t id_base, unsigned long long &key, int64_t row_n)
 {
+    if (col >= row_n) return false;
     int32_t id = ids ? ids[row_off + col] : (int32_t)(id_base + col);
     if (id < 0) return false;
     const uint32_t u = float_to_ordered_u32(scores[row_off + col]);
@@ -45,7 +46,7 @@ __device__ __forceinline__ bool load_key(const float *__restrict__ scores, const
 // grid (nblk, Q), block 256
 __global__ __launch_bounds__(256) void topk_hist_kernel(const float *__restrict__ scores,
                                                         const int32_t *__restrict__ ids, int64_t n, int64_t stride,
-                                                        int32_t id_base, int pass, const SelState *__restrict__ st,
+                                                        int32_t id_base, int pass, const SelState *__restrict__ st, const unsigned int *__restrict__ row_counts,
                                                         unsigned int *__restrict__ hist)
 {
     __shared__ unsigned int lh[kBins];
@@ -57,9 +58,10 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const float *__restrict_
     const unsigned long long prefix = pass > 0 ? st[q].prefix : 0ull;
     const int hi = shift + width;  // bits >= hi are decided
     const int64_t row_off = (int64_t)q * stride;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t row_n = row_counts ? (row_counts[q] < (unsigned long long)n ? (int64_t)row_counts[q] : n) : n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < row_n; i += (int64_t)gridDim.x * 256) {
         unsigned long long key;
-        if (!load_key(scores, ids, row_off, i, id_base, key)) continue;
+        if (!load_key(scores, ids, row_off, i, id_base, key, row_n)) continue;
         if (hi < 64 && (key >> hi) != (prefix >> hi)) continue;
         const unsigned int bin = (unsigned int)((key >> shift) & ((1u << width) - 1u));
         atomicAdd(&lh[bin], 1u);
@@ -135,16 +137,17 @@ __global__ __launch_bounds__(256) void topk_select_kernel(int pass, int k, SelSt
 // grid (nblk, Q): gather every key >= threshold (exactly k_eff of them)
 __global__ __launch_bounds__(256) void topk_collect_kernel(const float *__restrict__ scores,
                                                            const int32_t *__restrict__ ids, int64_t n, int64_t stride,
-                                                           int32_t id_base, SelState *__restrict__ st,
+                                                           int32_t id_base, SelState *__restrict__ st, const unsigned int *__restrict__ row_counts,
                                                            unsigned long long *__restrict__ keys, int kpad)
 {
     const int q = blockIdx.y;
     const unsigned long long thr = st[q].prefix;
     const unsigned int k_eff = st[q].k_eff;
     const int64_t row_off = (int64_t)q * stride;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t row_n = row_counts ? (row_counts[q] < (unsigned long long)n ? (int64_t)row_counts[q] : n) : n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < row_n; i += (int64_t)gridDim.x * 256) {
         unsigned long long key;
-        if (!load_key(scores, ids, row_off, i, id_base, key)) continue;
+        if (!load_key(scores, ids, row_off, i, id_base, key, row_n)) continue;
         if (key >= thr) {
             const unsigned int pos = atomicAdd(&st[q].collected, 1u);
             if (pos < k_eff) keys[(int64_t)q * kpad + pos] = key;
@@ -208,7 +211,8 @@ size_t topk_scratch_bytes(int Q, int k)
 }
 
 int launch_topk(hipStream_t s, const jv_ctx *ctx, const float *d_scores, const int32_t *d_ids, int Q, int64_t n,
-                int64_t stride, int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, void *d_scratch)
+                int64_t stride, int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, void *d_scratch,
+                const unsigned int *d_row_counts)
 {
     if (Q == 0 || k == 0) return JV_OK;
     if (k > kMaxK) {
@@ -230,10 +234,12 @@ int launch_topk(hipStream_t s, const jv_ctx *ctx, const float *d_scores, const i
     if (nblk < 1) nblk = 1;
     dim3 grid(nblk, Q);
     for (int pass = 0; pass < kPasses; ++pass) {
-        hipLaunchKernelGGL(topk_hist_kernel, grid, dim3(256), 0, s, d_scores, d_ids, n, stride, id_base, pass, st, hist);
+        hipLaunchKernelGGL(topk_hist_kernel, grid, dim3(256), 0, s, d_scores, d_ids, n, stride, id_base, pass, st,
+                           d_row_counts, hist);
         hipLaunchKernelGGL(topk_select_kernel, dim3(Q), dim3(256), 0, s, pass, k, st, hist);
     }
-    hipLaunchKernelGGL(topk_collect_kernel, grid, dim3(256), 0, s, d_scores, d_ids, n, stride, id_base, st, keys, kpad);
+    hipLaunchKernelGGL(topk_collect_kernel, grid, dim3(256), 0, s, d_scores, d_ids, n, stride, id_base, st, d_row_counts,
+                       keys, kpad);
     size_t lds = sizeof(unsigned long long) * (size_t)kpad;
     hipLaunchKernelGGL(topk_sort_kernel, dim3(Q), dim3(1024), lds, s, st, keys, kpad, k, d_out_ids, d_out_scores);
     JV_HIP_CHECK(hipGetLastError());

@@ -435,3 +435,64 @@ def test_c2_full_size_properties(ctx):
     rid, rsc = s.search(queries, VSF.EUCLIDEAN, 10, 100)
     ctx.sync()
     assert torch.all(rsc[:, 0] == 1.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-query ADC kernel (4 queries per LDS gather) and the threshold-filtered flat search
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,M,N,Q", [(128, 16, 30000, 2), (768, 96, 20000, 5), (1536, 192, 9000, 3),
+                                     (384, 48, 12000, 7), (512, 64, 12000, 4), (256, 32, 10000, 9)])
+def test_adc_multi_query_scan_bit_exact(ctx, D, M, N, Q):
+    rng = np.random.default_rng(N + Q)
+    pq, opq = make_pq(ctx, rng, D, M, center=True)
+    codes = rng.integers(0, 256, (N, M)).astype(np.uint8)
+    queries = rng.standard_normal((Q, D)).astype(np.float32)
+    cv = J.PQVectors(ctx, pq, codes)
+    for vsf in ALL_VSF:
+        sf = cv.precomputed_score_function_for(queries, vsf)
+        got = sf.similarity_to_range(0, N)
+        sub = sf.similarity_to_range(777, 8200)
+        for q in range(Q):
+            want = opq.adc_scores(queries[q], int(vsf), codes)
+            assert np.array_equal(got[q], want), (vsf, q)
+            assert np.array_equal(sub[q], want[777:777 + 8200])
+
+
+@pytest.mark.parametrize("vsf", ALL_VSF)
+def test_filtered_search_matches_oracle(ctx, vsf):
+    """N large enough for the sampled-threshold strategy; quantised scores create many exact ties at the threshold"""
+    rng = np.random.default_rng(77)
+    N, D, M, Q = 300_000, 64, 16, 6
+    base = np.round(rng.standard_normal((N, D)) * 2).astype(np.float32)  # small integer grid -> massive score ties
+    base[base == 0] = 1.0
+    queries = base[rng.integers(0, N, Q)].copy()
+    sizes, offs = O.subvector_sizes_offsets(D, M)
+    pick = rng.choice(N, 256, replace=False)
+    cb = np.concatenate([base[pick, offs[m]: offs[m] + sizes[m]].reshape(-1) for m in range(M)])
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    opq = O.OraclePQ(D, M, cb)
+    vs = J.VectorSet(ctx, base)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    s = J.FlatSearcher(ctx, pq, cv, vs, max_queries=8)
+    ids, sc = s.search(queries, vsf, 10, 200)
+    ids_nr, sc_nr = J.FlatSearcher(ctx, pq, cv, None, max_queries=8).search(queries, vsf, 50, 0)
+    wi, ws = opq.search_flat(codes, base, queries, int(vsf), 10, 200, nthreads=4)
+    wi_nr, ws_nr = opq.search_flat(codes, None, queries, int(vsf), 50, 0, nthreads=4)
+    assert np.array_equal(ids, wi) and np.array_equal(sc, ws)
+    assert np.array_equal(ids_nr, wi_nr) and np.array_equal(sc_nr, ws_nr)
+
+
+def test_filtered_search_overflow_falls_back(ctx):
+    """all candidates identical: every score ties with the threshold, the candidate list overflows, the engine
+    must fall back to the materialised strategy and return the smallest ids (NodeQueue tie rule)"""
+    N, D, M, Q = 300_000, 32, 16, 3
+    rng = np.random.default_rng(1)
+    base = np.tile(rng.standard_normal((1, D)).astype(np.float32), (N, 1))
+    cb = rng.standard_normal(256 * D).astype(np.float32)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, base)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    ids, sc = J.FlatSearcher(ctx, pq, cv, vs, max_queries=4).search(base[:Q], VSF.EUCLIDEAN, 10, 100)
+    assert np.array_equal(ids, np.tile(np.arange(10, dtype=np.int32), (Q, 1)))
+    assert np.all(sc == 1.0)
