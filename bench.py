@@ -225,7 +225,7 @@ def main():
         searcher.search(timed_q[s * Q:(s + 1) * Q], VSF, K, rerank_k, out_ids, out_sc)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = {r: ctx.profile_read(r) for r in ("adc", "topk", "exact", "lut")}
+    prof = {r: ctx.profile_read(r) for r in ("adc", "sample", "topk", "exact", "lut")}
     ctx.profile(False)
 
     if world > 1:
@@ -265,10 +265,16 @@ def main():
             "recall_at_10": rec,
             "recall_ok": rec >= 0.95,
             "adc_distances_per_s": float(Q) * N * args.steps * world / elapsed,
-            "roofline": {"bound": "hbm", "kernel": "adc_kernel<COSINE,6,LDS,1024> (ADC scan)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "adc_mq_kernel<COSINE,SLCH=2,R=8,FILTER> (threshold-filtered multi-query ADC scan of "
+                                   "all N codes; 4 queries per ds_read_b128)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": bytes_per_launch, "avg_launch_ms": adc_avg_s * 1e3, "launches": adc_n},
+                         "bytes_per_launch": bytes_per_launch, "avg_launch_ms": adc_avg_s * 1e3, "launches": adc_n,
+                         "note": "algorithmic bytes = Q*N*(M+4) (SURVEY 8d: codes re-streamed per query); the kernel shares "
+                                 "each code row among 4 queries in registers and among query groups through L2/MALL, so "
+                                 "frac can exceed 1 while HBM traffic (PMC) stays far below peak; the physical bound is "
+                                 "the LDS gather rate (DESIGN.md §4)"},
             "kernel_ms_per_step": {r: prof[r][0] / args.steps for r in prof},
             "encode": {"vectors_per_s": N / (enc_ms / 1e3) if enc_ms > 0 else None, "ms": enc_ms},
             "setup_s": setup_s,

@@ -339,7 +339,7 @@ int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, i
 {
     clear_error();
     JV_REQUIRE(ctx && region, "NULL argument");
-    static const char *names[R_COUNT] = {"adc", "topk", "exact", "lut", "encode", "norms"};
+    static const char *names[R_COUNT] = {"adc", "topk", "exact", "lut", "encode", "norms", "sample"};
     int r = -1;
     for (int i = 0; i < R_COUNT; ++i)
         if (strcmp(names[i], region) == 0) r = i;
@@ -1099,7 +1099,7 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
             unsigned int *d_cnt = (unsigned int *)(base + b_samp + 2 * b_ks + 2 * b_cap);
             JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, std::max(std::max(k1, topK), k_s))));
             {
-                ProfScope ps(ctx, R_ADC);
+                ProfScope ps(ctx, R_SAMPLE);
                 JV_TRY(launch_adc_mq_store(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes,
                                            codes->d_norms, 0, S, stride, d_samp));
             }
