@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--m", type=int, default=96)
-    ap.add_argument("--queries", type=int, default=128, help="queries per step (batch)")
+    ap.add_argument("--queries", type=int, default=256, help="queries per step (batch)")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95")
     ap.add_argument("--no-cpu-baseline", action="store_true")
