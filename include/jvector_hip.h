@@ -229,6 +229,32 @@ JV_API int jv_hip_search_flat(jv_ctx *ctx, jv_luts *luts, const jv_codes *codes,
                               const float *queries, int Q, jv_vsf vsf, int topK, int rerankK, int32_t id_base,
                               int32_t *out_ids, float *out_scores);
 
+/* ---------------------------------------------------------------------------------------------
+ * Host batched graph searcher — SURVEY §8f rank 1 ("next" row): a lock-step, multi-query restatement of
+ *   GraphSearcher.search / searchOneLayer / reranking (B/graph/GraphSearcher.java:222-507) +
+ *   View.processNeighbors (B/graph/disk/OnDiskGraphIndex.java:639-661, B/graph/OnHeapGraphIndex.java:475-483).
+ * The traversal (candidate heap, bounded result heap, visited set) stays on the HOST; every round ships one
+ * expanded node per live query to the GPU: layer 0 with FusedPQ -> jv_fused block scores
+ * (FusedPQDecoder.similarityToNeighbor), otherwise an ADC gather of the unvisited neighbours' codes.
+ * Per query the visit order, scores and results equal the reference's sequential search on the same graph.
+ *
+ * Graph: level 0 holds every node (count == n_nodes, node_ids == NULL); upper levels list their node ids in
+ * ascending order.  neighbors: count x degree int32, packed, padded with -1 (the L0 record layout,
+ * OnDiskGraphIndex.java:538-547).  Adjacency is HOST memory and is copied.
+ * search: `luts` is (re)built inside for the Q queries with the decoder kind implied by `fused`;
+ *   vectors == NULL => no rerank (results are the approximate top-K);
+ *   stats (nullable): Q x 2 int64 = {visitedCount, expandedCount} per query (SearchResult counters).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct jv_graph jv_graph;
+JV_API int jv_hip_graph_create(jv_ctx *ctx, int64_t n_nodes, int n_levels, jv_graph **out);
+JV_API int jv_hip_graph_set_level(jv_ctx *ctx, jv_graph *g, int level, int count, const int32_t *node_ids,
+                                  const int32_t *neighbors, int degree);
+JV_API int jv_hip_graph_set_entry(jv_graph *g, int32_t node, int level);
+JV_API int jv_hip_graph_destroy(jv_graph *g);
+JV_API int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *luts, const jv_codes *codes,
+                               const jv_fused *fused, const jv_vectors *vectors, const float *queries, int Q,
+                               jv_vsf vsf, int topK, int rerankK, int32_t *out_ids, float *out_scores, int64_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

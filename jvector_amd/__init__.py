@@ -10,6 +10,8 @@ from .engine import (  # noqa: F401
     FlatSearcher,
     FusedPQ,
     FusedScoreFunction,
+    GraphIndex,
+    GraphSearcher,
     HipContext,
     PQVectors,
     ProductQuantization,

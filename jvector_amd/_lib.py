@@ -76,6 +76,11 @@ SIGNATURES = {
     "jv_hip_exact_scan": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _p]),
     "jv_hip_topk": (_i, [_p, _p, _p, _i, _i64, _i64, C.c_int32, _i, _p, _p]),
     "jv_hip_search_flat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_int32, _p, _p]),
+    "jv_hip_graph_create": (_i, [_p, _i64, _i, C.POINTER(_p)]),
+    "jv_hip_graph_set_level": (_i, [_p, _p, _i, _i, _p, _p, _i]),
+    "jv_hip_graph_set_entry": (_i, [_p, C.c_int32, _i]),
+    "jv_hip_graph_destroy": (_i, [_p]),
+    "jv_hip_graph_search": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
 }
 
 # the reference's per-pair SPI, exported unchanged (include/jvector_simd_compat.h)

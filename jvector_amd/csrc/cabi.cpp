@@ -52,7 +52,7 @@ void Buffer::release()
 }
 
 // true when p is device-accessible memory we can hand to a kernel directly
-static bool is_device_ptr(const void *p)
+bool is_device_ptr(const void *p)
 {
     if (!p) return false;
     hipPointerAttribute_t attr;
@@ -66,7 +66,7 @@ static bool is_device_ptr(const void *p)
 
 // Brings `bytes` at `src` onto the device.  Device pointers pass through; host memory is copied through
 // the pinned staging buffer `pin` into `dev` on the context's stream.
-static int stage_in(jv_ctx *ctx, const void *src, size_t bytes, Buffer &pin, Buffer &dev, const void **out)
+int stage_in(jv_ctx *ctx, const void *src, size_t bytes, Buffer &pin, Buffer &dev, const void **out)
 {
     if (bytes == 0) {
         *out = src;
@@ -86,14 +86,7 @@ static int stage_in(jv_ctx *ctx, const void *src, size_t bytes, Buffer &pin, Buf
     return JV_OK;
 }
 
-struct OutStage {
-    void *user = nullptr;   // user pointer
-    void *dev = nullptr;    // device pointer kernels write to
-    size_t bytes = 0;
-    bool host = false;
-};
-
-static int stage_out_begin(jv_ctx *ctx, void *dst, size_t bytes, Buffer &dev, OutStage *st)
+int stage_out_begin(jv_ctx *ctx, void *dst, size_t bytes, Buffer &dev, OutStage *st)
 {
     st->user = dst;
     st->bytes = bytes;
@@ -109,7 +102,7 @@ static int stage_out_begin(jv_ctx *ctx, void *dst, size_t bytes, Buffer &dev, Ou
 }
 
 // Copies a staged output back to the user's host buffer (synchronises the stream); no-op for device outputs.
-static int stage_out_end(jv_ctx *ctx, const OutStage &st)
+int stage_out_end(jv_ctx *ctx, const OutStage &st)
 {
     if (!st.host || st.bytes == 0) return JV_OK;
     JV_TRY(ctx->h_out.reserve(st.bytes));
@@ -119,35 +112,7 @@ static int stage_out_end(jv_ctx *ctx, const OutStage &st)
     return JV_OK;
 }
 
-// RAII region timer: two hipEventRecord calls on the context's stream when profiling is on, nothing otherwise.
-struct ProfScope {
-    jv_ctx *ctx;
-    int idx = -1;
-    ProfScope(jv_ctx *c, int region) : ctx(c)
-    {
-        if (!ctx->profiling) return;
-        ProfEvent e;
-        e.region = region;
-        auto get = [&](hipEvent_t *ev) {
-            if (!ctx->prof_free.empty()) {
-                *ev = ctx->prof_free.back();
-                ctx->prof_free.pop_back();
-                return true;
-            }
-            return hipEventCreate(ev) == hipSuccess;
-        };
-        if (!get(&e.start) || !get(&e.stop)) return;
-        (void)hipEventRecord(e.start, ctx->stream);
-        ctx->prof_pending.push_back(e);
-        idx = (int)ctx->prof_pending.size() - 1;
-    }
-    ~ProfScope()
-    {
-        if (idx >= 0) (void)hipEventRecord(ctx->prof_pending[idx].stop, ctx->stream);
-    }
-};
-
-static int to_kernel_vsf(jv_vsf v)
+int to_kernel_vsf(jv_vsf v)
 {
     switch (v) {
     case JV_EUCLIDEAN: return VSF_L2;
@@ -156,7 +121,7 @@ static int to_kernel_vsf(jv_vsf v)
     }
 }
 
-static int use_device(int device)
+int use_device(int device)
 {
     JV_HIP_CHECK(hipSetDevice(device));
     return JV_OK;
@@ -175,7 +140,7 @@ static float rd_f32(const uint8_t *p)
     return f;
 }
 
-static int ensure_code_norms(jv_ctx *ctx, jv_codes *codes)
+int ensure_code_norms(jv_ctx *ctx, jv_codes *codes)
 {
     if (codes->norms_valid) return JV_OK;
     if (!codes->d_norms) JV_HIP_CHECK(hipMalloc((void **)&codes->d_norms, sizeof(float) * (size_t)std::max<int64_t>(codes->count, 1)));
@@ -188,7 +153,7 @@ static int ensure_code_norms(jv_ctx *ctx, jv_codes *codes)
     return JV_OK;
 }
 
-static int ensure_fused_norms(jv_ctx *ctx, jv_fused *f)
+int ensure_fused_norms(jv_ctx *ctx, jv_fused *f)
 {
     if (f->norms_valid) return JV_OK;
     const int64_t rows = f->count * f->maxDegree;
@@ -276,6 +241,7 @@ int jv_hip_ctx_destroy(jv_ctx *ctx)
     if (!ctx) return JV_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->host_pool && ctx->host_pool_destroy) ctx->host_pool_destroy(ctx->host_pool);
     ctx->h_in.release();
     ctx->h_out.release();
     ctx->d_in.release();

@@ -75,6 +75,9 @@ struct jv_ctx {
     size_t lds_per_block = 65536;  // hipDeviceProp_t.sharedMemPerBlock / maxSharedMemoryPerMultiProcessor
     // staging: host->device inputs, device->host outputs (pinned), device scratch
     jv::Buffer h_in, h_out, d_in, d_out, d_scratch, d_scratch2, d_scratch3;
+    // host batched graph searcher: worker pool (graph_search.cpp owns the type) and its destructor
+    void *host_pool = nullptr;
+    void (*host_pool_destroy)(void *) = nullptr;
 };
 
 struct jv_pq {
@@ -135,6 +138,54 @@ struct jv_luts {
     float *d_queries = nullptr; // capacity x D : centred queries (cq = q - globalCentroid)
     float *d_raw_queries = nullptr; // capacity x D : un-centred copy (rerank)
 };
+
+// ---- host helpers shared by cabi.cpp and graph_search.cpp ----
+namespace jv {
+
+struct OutStage {
+    void *user = nullptr;   // user pointer
+    void *dev = nullptr;    // device pointer kernels write to
+    size_t bytes = 0;
+    bool host = false;
+};
+bool is_device_ptr(const void *p);
+int stage_in(jv_ctx *ctx, const void *src, size_t bytes, Buffer &pin, Buffer &dev, const void **out);
+int stage_out_begin(jv_ctx *ctx, void *dst, size_t bytes, Buffer &dev, OutStage *st);
+int stage_out_end(jv_ctx *ctx, const OutStage &st);
+int to_kernel_vsf(jv_vsf v);
+int use_device(int device);
+int ensure_code_norms(jv_ctx *ctx, jv_codes *codes);
+int ensure_fused_norms(jv_ctx *ctx, jv_fused *f);
+
+// RAII region timer: two hipEventRecord calls on the context's stream when profiling is on, nothing otherwise.
+struct ProfScope {
+    jv_ctx *ctx;
+    int idx = -1;
+    ProfScope(jv_ctx *c, int region) : ctx(c)
+    {
+        if (!ctx->profiling) return;
+        ProfEvent e;
+        e.region = region;
+        auto get = [&](hipEvent_t *ev) {
+            if (!ctx->prof_free.empty()) {
+                *ev = ctx->prof_free.back();
+                ctx->prof_free.pop_back();
+                return true;
+            }
+            return hipEventCreate(ev) == hipSuccess;
+        };
+        if (!get(&e.start) || !get(&e.stop)) return;
+        (void)hipEventRecord(e.start, ctx->stream);
+        ctx->prof_pending.push_back(e);
+        idx = (int)ctx->prof_pending.size() - 1;
+    }
+    ~ProfScope()
+    {
+        if (idx >= 0) (void)hipEventRecord(ctx->prof_pending[idx].stop, ctx->stream);
+    }
+};
+
+}  // namespace jv
 
 // ---- kernel launchers (implemented in the .hip translation units) ----
 namespace jv {

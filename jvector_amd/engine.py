@@ -412,3 +412,54 @@ class FlatSearcher:
                                                self.vectors._h if self.vectors is not None else None, q_p, Q, int(vsf),
                                                int(top_k), int(rerank_k), self.id_base, oi_p, os_p))
         return out_ids, out_scores
+
+
+class GraphIndex:
+    """Host-resident multi-level adjacency (the reference keeps the graph on the host: OnHeapGraphIndex /
+    OnDiskGraphIndex.View).  levels[0] = (None, neighbors[n_nodes, maxDegree]); upper levels = (sorted node ids,
+    neighbors[count, degree]); rows packed and padded with -1."""
+
+    def __init__(self, ctx, n_nodes, levels, entry_node, entry_level):
+        self.ctx, self._lib = ctx, ctx._lib
+        h = C.c_void_p()
+        check(self._lib.jv_hip_graph_create(ctx._h, int(n_nodes), len(levels), C.byref(h)))
+        self._h = h
+        self.n_nodes, self.max_degree = int(n_nodes), int(levels[0][1].shape[1])
+        for lv, (ids, nbrs) in enumerate(levels):
+            nb = np.ascontiguousarray(nbrs.cpu().numpy() if _is_torch(nbrs) else nbrs, dtype=np.int32)
+            idp = None
+            if ids is not None:
+                ida = np.ascontiguousarray(ids.cpu().numpy() if _is_torch(ids) else ids, dtype=np.int32)
+                idp = C.c_void_p(ida.ctypes.data)
+            check(self._lib.jv_hip_graph_set_level(ctx._h, h, lv, nb.shape[0], idp, C.c_void_p(nb.ctypes.data),
+                                                   nb.shape[1]))
+        check(self._lib.jv_hip_graph_set_entry(h, int(entry_node), int(entry_level)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_graph_destroy(self._h)
+            self._h = None
+
+
+class GraphSearcher:
+    """Batched GraphSearcher (B/graph/GraphSearcher.java): host traversal in lock-step over the query batch, GPU
+    scoring of each round's frontier (FusedPQ blocks at layer 0 when `fused` is given, ADC gathers otherwise)."""
+
+    def __init__(self, ctx, graph: GraphIndex, pq, pq_vectors: PQVectors, fused: FusedPQ | None = None,
+                 vectors: VectorSet | None = None, max_queries=4096):
+        self.ctx, self.graph, self.cv, self.fused, self.vectors = ctx, graph, pq_vectors, fused, vectors
+        self.luts = QueryTables(ctx, pq, max_queries)
+
+    def search(self, queries, vsf, top_k, rerank_k, return_stats=False):
+        Q = int(queries.shape[0])
+        q_p, qk = _ptr(queries, np.float32)
+        out_ids = _empty((Q, top_k), np.int32, queries)
+        out_sc = _empty((Q, top_k), np.float32, queries)
+        oi_p, oik = _ptr(out_ids, np.int32)
+        os_p, osk = _ptr(out_sc, np.float32)
+        stats = np.zeros((Q, 2), np.int64)
+        check(self.ctx._lib.jv_hip_graph_search(
+            self.ctx._h, self.graph._h, self.luts._h, self.cv._h, self.fused._h if self.fused is not None else None,
+            self.vectors._h if self.vectors is not None else None, q_p, Q, int(vsf), int(top_k), int(rerank_k), oi_p, os_p,
+            C.c_void_p(stats.ctypes.data) if return_stats else None))
+        return (out_ids, out_sc, stats) if return_stats else (out_ids, out_sc)

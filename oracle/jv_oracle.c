@@ -789,3 +789,123 @@ void jvo_rerank(const float *queries, const float *cand_vecs, const int32_t *can
     }
     for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * GraphSearcher restatement — checker for the host batched searcher.
+ * One query at a time, the reference's exact control flow (B/graph/GraphSearcher.java):
+ *   search :222-243, internalSearch :263-282, initializeInternal :334-353, stopSearch :355-369,
+ *   searchOneLayer :406-457 (threshold = 0 => NoOpTracker), setEntryPointsFromPreviousLayer :324-331,
+ *   searchLayer0 :459-469, addTopCandidate :515-530, reranking :471-507 + NodeQueue.rerank :160-230.
+ * Score functions: PQDecoder / FusedPQDecoder arithmetic (jvo_adc_score over the code of the node);
+ * in fused mode layer-0 neighbour scores come from the origin's packed block
+ * (FusedPQDecoder.similarityToNeighbor :104-111) — identical values by construction.
+ * Deviation (documented): the final top-K after rerank is taken under the NodeQueue order on the exact scores;
+ * the reference's membership for EXACT-score ties at the K-th place depends on heap array order (NodeQueue.java:
+ * 197-214).  Distinct exact scores => identical results.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { int64_t *a; int n, cap; } lheap;  /* min-heap of keys */
+static void lh_push(lheap *h, int64_t v)
+{
+    if (h->n == h->cap) { h->cap = h->cap ? h->cap * 2 : 64; h->a = (int64_t *)realloc(h->a, sizeof(int64_t) * (size_t)h->cap); }
+    int i = h->n++;
+    h->a[i] = v;
+    while (i > 0 && h->a[(i - 1) / 2] > h->a[i]) { int p = (i - 1) / 2; int64_t t = h->a[i]; h->a[i] = h->a[p]; h->a[p] = t; i = p; }
+}
+static int64_t lh_pop(lheap *h)
+{
+    int64_t top = h->a[0];
+    h->a[0] = h->a[--h->n];
+    heap_sift_down(h->a, h->n, 0);
+    return top;
+}
+static inline int32_t key_node(int64_t k) { return (int32_t)~(uint32_t)(k & 0xFFFFFFFFLL); }
+static inline float key_score(int64_t k) { return jvo_sortable_int_to_float((int32_t)(k >> 32)); }
+
+/* level l: nodes[l] (sorted ascending, NULL for level 0 = every node), neighbors[l] rows of degree[l] ids (-1 pad) */
+static const int32_t *level_row(const jvo_graph *g, int level, int32_t node)
+{
+    if (level == 0 || g->level_nodes[level] == NULL) return g->level_neighbors[level] + (size_t)node * g->level_degree[level];
+    int lo = 0, hi = g->level_count[level] - 1;
+    while (lo <= hi) {
+        int mid = (lo + hi) / 2;
+        int32_t v = g->level_nodes[level][mid];
+        if (v == node) return g->level_neighbors[level] + (size_t)mid * g->level_degree[level];
+        if (v < node) lo = mid + 1; else hi = mid - 1;
+    }
+    return NULL;
+}
+
+void jvo_graph_search(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes, const float *vecs,
+                      const float *query, int vsf, int fused, int topK, int rerankK,
+                      int32_t *out_ids, float *out_scores, int64_t *stats /* visited, expanded */)
+{
+    const int M = pq->M, k = pq->k;
+    float *lut = (float *)malloc(sizeof(float) * (size_t)M * k);
+    float *amag = (float *)malloc(sizeof(float) * (size_t)M * k);
+    float bmag = 0.0f;
+    if (fused) jvo_fuseddecoder_init(pq, query, vsf, lut, amag, &bmag);
+    else jvo_pqdecoder_init(pq, query, vsf, lut, amag, &bmag);
+#define SCORE(node) jvo_adc_score(vsf, M, k, lut, amag, bmag, codes + (size_t)(node) * M)
+    uint8_t *visited = (uint8_t *)calloc((size_t)g->n_nodes, 1);
+    lheap cand = {0}, res = {0}, evicted = {0};
+    int64_t n_visited = 0, n_expanded = 0;
+
+    /* initializeInternal */
+    visited[g->entry_node] = 1;
+    lh_push(&cand, -1 - jvo_nodequeue_encode(g->entry_node, SCORE(g->entry_node)));  /* MAX_HEAP: -1 - v */
+
+    for (int lvl = g->entry_level; lvl >= 0; lvl--) {
+        const int rk = lvl > 0 ? 1 : rerankK;
+        /* searchOneLayer */
+        while (cand.n > 0) {
+            int64_t topKey = -1 - cand.a[0];
+            float topScore = key_score(topKey);
+            if (res.n >= rk && topScore < key_score(res.a[0])) break;  /* stopSearch */
+            lh_pop(&cand);
+            int32_t node = key_node(topKey);
+            /* addTopCandidate (acceptOrds = ALL, threshold = 0) */
+            if (res.n < rk) lh_push(&res, topKey);
+            else if (topScore > key_score(res.a[0])) {
+                lh_push(&evicted, res.a[0]);
+                res.a[0] = topKey;              /* BoundedLongHeap.updateTop */
+                heap_sift_down(res.a, res.n, 0);
+            }
+            n_expanded++;
+            const int32_t *row = level_row(g, lvl, node);
+            if (!row) continue;
+            for (int i = 0; i < g->level_degree[lvl]; i++) {
+                int32_t nb = row[i];
+                if (nb < 0) break;  /* neighbour lists are packed: first -1 ends the row */
+                if (visited[nb]) continue;
+                visited[nb] = 1;
+                lh_push(&cand, -1 - jvo_nodequeue_encode(nb, SCORE(nb)));
+                n_visited++;
+            }
+        }
+        if (lvl > 0) {  /* setEntryPointsFromPreviousLayer */
+            for (int i = 0; i < res.n; i++) lh_push(&cand, -1 - res.a[i]);
+            for (int i = 0; i < evicted.n; i++) lh_push(&cand, -1 - evicted.a[i]);
+            res.n = 0;
+            evicted.n = 0;
+        }
+    }
+    /* reranking */
+    int64_t *fin = (int64_t *)malloc(sizeof(int64_t) * (size_t)(res.n > 0 ? res.n : 1));
+    int nf = 0;
+    if (vecs) {
+        for (int i = 0; i < res.n; i++) {
+            int32_t id = key_node(res.a[i]);
+            fin[nf++] = jvo_nodequeue_encode(id, jvo_compare(vsf, query, vecs + (size_t)id * pq->D, pq->D));
+        }
+    } else {
+        for (int i = 0; i < res.n; i++) fin[nf++] = res.a[i];
+    }
+    qsort(fin, (size_t)nf, sizeof(int64_t), cmp_desc_i64);
+    for (int i = 0; i < topK; i++) {
+        out_ids[i] = i < nf ? key_node(fin[i]) : -1;
+        out_scores[i] = i < nf ? key_score(fin[i]) : -INFINITY;
+    }
+    if (stats) { stats[0] = n_visited; stats[1] = n_expanded; }
+#undef SCORE
+    free(fin); free(cand.a); free(res.a); free(evicted.a); free(visited); free(lut); free(amag);
+}

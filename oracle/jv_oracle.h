@@ -115,6 +115,23 @@ int     jvo_topk(const int32_t *ids, const float *scores, int64_t n, int k,
 void jvo_search_flat(const jvo_pq *pq, const uint8_t *codes, const float *vecs, int64_t n, const float *queries,
                      int Q, int vsf, int topK, int rerankK, int32_t *out_ids, float *out_scores, int nthreads);
 
+/* ---- GraphSearcher restatement (checker for the host batched searcher) ----
+ * Multi-level graph: level l has level_count[l] nodes (level_nodes[l] sorted ascending; NULL = all nodes, level 0),
+ * rows of level_degree[l] neighbour ids, packed, padded with -1. */
+typedef struct {
+    int64_t n_nodes;
+    int n_levels;
+    int32_t entry_node;
+    int entry_level;
+    const int *level_count;
+    const int *level_degree;
+    const int32_t *const *level_nodes;
+    const int32_t *const *level_neighbors;
+} jvo_graph;
+void jvo_graph_search(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes, const float *vecs,
+                      const float *query, int vsf, int fused, int topK, int rerankK,
+                      int32_t *out_ids, float *out_scores, int64_t *stats /* [visited, expanded] or NULL */);
+
 /* exact rerank of pre-gathered candidate rows (Q x R x D), one query per worker thread */
 void jvo_rerank(const float *queries, const float *cand_vecs, const int32_t *cand_ids, int Q, int R, int D, int vsf,
                 int topK, int32_t *out_ids, float *out_scores, int nthreads);

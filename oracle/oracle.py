@@ -37,6 +37,43 @@ class _Layout(C.Structure):
                                        "totalChunks", "fullChunkBytes", "lastChunkBytes")]
 
 
+class _Graph(C.Structure):
+    _fields_ = [("n_nodes", C.c_int64), ("n_levels", C.c_int), ("entry_node", C.c_int32), ("entry_level", C.c_int),
+                ("level_count", C.POINTER(C.c_int)), ("level_degree", C.POINTER(C.c_int)),
+                ("level_nodes", C.POINTER(C.POINTER(C.c_int32))), ("level_neighbors", C.POINTER(C.POINTER(C.c_int32)))]
+
+
+class OracleGraph:
+    """levels: list of (node_ids | None, neighbors[n_l, degree_l] int32 packed, -1 padded); level 0 first."""
+
+    def __init__(self, n_nodes, levels, entry_node, entry_level):
+        self.levels = [(None if ids is None else np.ascontiguousarray(ids, np.int32),
+                        np.ascontiguousarray(nb, np.int32)) for ids, nb in levels]
+        L = len(self.levels)
+        self._count = (C.c_int * L)(*[nb.shape[0] for _, nb in self.levels])
+        self._deg = (C.c_int * L)(*[nb.shape[1] for _, nb in self.levels])
+        i32p = C.POINTER(C.c_int32)
+        self._nodes = (i32p * L)(*[C.cast(None, i32p) if ids is None else ids.ctypes.data_as(i32p)
+                                   for ids, _ in self.levels])
+        self._nbrs = (i32p * L)(*[nb.ctypes.data_as(i32p) for _, nb in self.levels])
+        self._s = _Graph(n_nodes, L, entry_node, entry_level, self._count, self._deg, self._nodes, self._nbrs)
+
+    def search(self, pq, codes, vecs, queries, vsf, top_k, rerank_k, fused=False):
+        codes = np.ascontiguousarray(codes, np.uint8)
+        queries = f32(queries)
+        vecs = None if vecs is None else f32(vecs)
+        Q = queries.shape[0]
+        ids = np.empty((Q, top_k), np.int32)
+        sc = np.empty((Q, top_k), np.float32)
+        stats = np.zeros((Q, 2), np.int64)
+        L = lib()
+        for q in range(Q):
+            L.jvo_graph_search(C.byref(self._s), pq.ref, _u8(codes), None if vecs is None else _f(vecs), _f(queries[q]),
+                               vsf, 1 if fused else 0, top_k, rerank_k, _i32(ids[q]), _f(sc[q]),
+                               stats[q].ctypes.data_as(C.POINTER(C.c_int64)))
+        return ids, sc, stats
+
+
 _lib = None
 
 
@@ -82,6 +119,8 @@ def lib():
         sig("jvo_nodequeue_encode", C.c_int64, C.c_int32, C.c_float)
         sig("jvo_topk", C.c_int, i32p, fp, C.c_int64, C.c_int, i32p, fp)
         sig("jvo_search_flat", None, pqp, u8p, fp, C.c_int64, fp, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp, C.c_int)
+        sig("jvo_graph_search", None, C.POINTER(_Graph), pqp, u8p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp,
+            C.POINTER(C.c_int64))
         sig("jvo_rerank", None, fp, fp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp, C.c_int)
         sig("jvo_pq_layout_compute", C.c_int, C.c_int, C.c_int, C.POINTER(_Layout))
         sig("jvo_pq_parse", C.c_int, u8p, C.c_size_t, i32p, i32p, i32p, i32p, i32p, fp, i32p, C.c_int,

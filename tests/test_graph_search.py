@@ -1,0 +1,110 @@
+"""Host batched graph searcher against the oracle's sequential GraphSearcher restatement:
+same graph, same queries -> identical result ids, scores, visitedCount and expandedCount per query."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import jvector_amd as J
+from jvector_amd import VectorSimilarityFunction as VSF
+from oracle import oracle as O
+
+
+def build_problem(seed, N=6000, D=64, M=8, deg=16, top_n=60, top_deg=8, levels=2):
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((25, D)).astype(np.float32)
+    v = (centers[rng.integers(0, 25, N)] + 0.5 * rng.standard_normal((N, D))).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    sims = v @ v.T
+    np.fill_diagonal(sims, -9)
+    order = np.argsort(-sims, axis=1)
+    nb = np.full((N, deg), -1, np.int32)
+    for i in range(N):                      # ragged degrees, a few long-range edges
+        d = int(rng.integers(deg // 2, deg + 1))
+        row = list(order[i, : d - 2]) + list(rng.choice(N, 2, replace=False))
+        row = [x for j, x in enumerate(row) if x != i and x not in row[:j]]
+        nb[i, : len(row)] = row
+    lv = [(None, nb)]
+    entry, entry_level = 0, 0
+    if levels > 1:
+        top = np.sort(rng.choice(N, top_n, replace=False)).astype(np.int32)
+        s2 = v[top] @ v[top].T
+        np.fill_diagonal(s2, -9)
+        nb2 = top[np.argsort(-s2, axis=1)[:, :top_deg]].astype(np.int32)
+        lv.append((top, nb2))
+        entry, entry_level = int(top[3]), 1
+    if levels > 2:
+        top3 = np.sort(rng.choice(lv[1][0], 10, replace=False)).astype(np.int32)
+        s3 = v[top3] @ v[top3].T
+        np.fill_diagonal(s3, -9)
+        nb3 = top3[np.argsort(-s3, axis=1)[:, :4]].astype(np.int32)
+        lv.append((top3, nb3))
+        entry, entry_level = int(top3[1]), 2
+    sizes, offs = O.subvector_sizes_offsets(D, M)
+    pick = rng.choice(N, 256, replace=False)
+    cb = np.concatenate([v[pick, offs[m]: offs[m] + sizes[m]].reshape(-1) for m in range(M)])
+    q = (v[rng.integers(0, N, 40)] + 0.05 * rng.standard_normal((40, D))).astype(np.float32)
+    return v, lv, entry, entry_level, cb, q
+
+
+def fused_blocks(codes, nb):
+    N, deg = nb.shape
+    M = codes.shape[1]
+    blocks = np.zeros((N, deg * M), np.uint8)
+    for n in range(N):
+        d = int((nb[n] >= 0).sum())
+        blocks[n, : d * M] = codes[nb[n, :d]].reshape(-1)
+    return blocks
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = J.HipContext(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("levels,use_fused,D,M", [(1, False, 64, 8), (1, True, 64, 8), (2, True, 64, 8),
+                                                  (3, False, 64, 8), (2, True, 128, 16), (2, False, 96, 12)])
+def test_graph_search_matches_oracle(ctx, levels, use_fused, D, M):
+    v, lv, entry, entry_level, cb, q = build_problem(levels * 10 + D, D=D, M=M, levels=levels)
+    N = v.shape[0]
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    assert np.array_equal(codes, opq.encode_all(v))
+    og = O.OracleGraph(N, lv, entry, entry_level)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+    fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
+    for vsf in VSF:
+        for rerank, top_k, rk in ((True, 10, 40), (False, 5, 20), (True, 1, 1)):
+            s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=64)
+            ids, sc, stats = s.search(q, vsf, top_k, rk, return_stats=True)
+            wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused)
+            assert np.array_equal(stats, wst), (vsf, rerank)           # same visited / expanded counts
+            assert np.array_equal(ids, wi), (vsf, rerank, top_k)
+            assert np.array_equal(sc, ws), (vsf, rerank, top_k)
+
+
+def test_graph_search_large_batch_and_errors(ctx):
+    v, lv, entry, entry_level, cb, q = build_problem(3, N=3000, levels=2)
+    N, D, M = v.shape[0], 64, 8
+    rng = np.random.default_rng(9)
+    q = (v[rng.integers(0, N, 700)] + 0.1 * rng.standard_normal((700, D))).astype(np.float32)
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+    fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1])
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=1024)
+    ids, sc, stats = s.search(q, VSF.COSINE, 10, 60, return_stats=True)
+    wi, ws, wst = O.OracleGraph(N, lv, entry, entry_level).search(opq, codes, v, q, O.COSINE, 10, 60, fused=True)
+    assert np.array_equal(ids, wi) and np.array_equal(sc, ws) and np.array_equal(stats, wst)
+    with pytest.raises(ValueError):  # rerankK < topK (GraphSearcher.java:233)
+        s.search(q[:4], VSF.COSINE, 10, 5)
+    with pytest.raises(ValueError):  # more queries than the LUT capacity
+        J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=2).search(q[:4], VSF.COSINE, 1, 1)
