@@ -290,6 +290,8 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
 
     // pinned host + device buffers for the per-round exchange
     const size_t cells = (size_t)Q * max_deg;
+    // luts_build may still be DMA-ing the queries out of the pinned staging buffer: drain before reusing it
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     JV_TRY(ctx->h_in.reserve(sizeof(int32_t) * cells));
     JV_TRY(ctx->h_out.reserve(sizeof(float) * cells));
     JV_TRY(ctx->d_in.reserve(sizeof(int32_t) * cells));
