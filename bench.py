@@ -2,27 +2,29 @@
 """bench.py — the hot path's headline benchmark on MI355X (contract: see the repo brief).
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic 10M x 768 cosine
-("ada-002-like"), PQ-96 (256 clusters, 8-dim sub-vectors).  One *step* = one batch of Q queries through the
-two-pass search of the hot path, inputs resident in HBM:
+("ada-002-like"), PQ-96 (256 clusters, 8-dim sub-vectors), FusedADC graph blocks (maxDegree 32).
+One *step* = one batch of Q queries through the hot path, inputs resident in HBM.  Two search modes:
 
-    ADC LUT build (Q x 96 x 256)  ->  ADC scan of all 10M codes for every query (assembleAndSum / PQ cosine)
-    ->  top-rerankK under the NodeQueue order  ->  exact float32 cosine rerank  ->  top-10
+  --mode graph (default)  host batched GraphSearcher (lock-step traversal on the host cores, each round's frontier
+                          scored on the GPU from the FusedPQ neighbour blocks) -> exact rerank -> top-10
+                          [GraphSearcher.search + FusedPQDecoder + NodeQueue.rerank, batched]
+  --mode flat             LUT build -> multi-query ADC scan of all N codes (threshold-filtered) -> top-rerankK
+                          -> exact rerank -> top-10   (no graph; the brute-force-over-codes path)
 
-value = whole-job queries/s at recall@10 >= 0.95 (recall measured against exact brute-force ground truth computed
-by the engine's bit-exact exact-scan kernel, outside the timed region).  `roofline` prices the dominant kernel
-(the ADC scan) in algorithmic bytes (M + 4 B per candidate) against the 8 TB/s HBM peak, from HIP
-events recorded on the engine's stream inside the timed region.  `cpu_baseline` times the CPU oracle ("port" of
-the scalar reference) on the host cores on a bounded sample of the same workload.
+value = whole-job queries/s at recall@10 >= 0.95; recall is measured against exact brute-force ground truth
+computed by the engine's bit-exact exact-scan kernel, outside the timed region, on (a subset of) the timed queries.
+`roofline` prices the mode's dominant kernel in algorithmic bytes against the 8 TB/s HBM peak from
+HIP events recorded on the engine's stream inside the timed region.  `cpu_baseline` times the CPU oracle ("port"
+of the scalar reference arithmetic) on the host cores on a bounded sample of the same workload, same mode.
 
-N > 1 (launched by torch.distributed.run): every rank holds a full replica of the 10M index and serves its own
-query batch (the 10M x 768 configuration fits one GPU; the sharded 100M configuration with the RCCL all-gather of
-partial top-k is `--mode sharded`).  No data-path collective in replica mode; scaling = weak.
+N > 1 (launched by torch.distributed.run): every rank holds a full replica of the index and serves its own
+query batches (10M x 768 fits one GPU); no data-path collective; scaling = weak.  The sharded 100M configuration
+(RCCL all-gather of partial top-k) is jvector_amd/sharded.py, covered by tests, not a bench line.
 """
 from __future__ import annotations
 
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -34,114 +36,66 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
+from benchlib import (Mixture, build_graph, fused_blocks_from, ground_truth, recall_at_k,  # noqa: E402
+                      train_codebooks)
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable copy)
 
 
-# ------------------------------------------------------------------------------------------------------
-# synthetic "ada-002-like" data (seeded; generated on the device, never materialised on the host)
-# Embedding-like structure: a low intrinsic dimension (latent L-dim mixture of clusters) linearly embedded in
-# D dims plus small isotropic noise, then L2-normalised.  Pure input preparation (torch is plumbing here).
-# ------------------------------------------------------------------------------------------------------
-class Mixture:
-    def __init__(self, D, seed, device, n_clusters=1000, latent=32, spread=0.35, noise=0.08):
-        g = torch.Generator(device="cpu").manual_seed(seed)
-        self.D, self.L, self.device = D, latent, device
-        self.spread, self.noise = spread, noise
-        self.centers = torch.randn(n_clusters, latent, generator=g).to(device)
-        self.centers /= self.centers.norm(dim=1, keepdim=True)
-        proj = torch.randn(latent, D, generator=g)
-        q, _ = torch.linalg.qr(proj.t())          # D x L with orthonormal columns
-        self.proj = q.t().contiguous().to(device)  # L x D
-
-    def sample(self, n, seed, chunk=1_000_000, out=None):
-        g = torch.Generator(device=self.device).manual_seed(seed)
-        if out is None:
-            out = torch.empty(n, self.D, dtype=torch.float32, device=self.device)
-        for s in range(0, n, chunk):
-            e = min(n, s + chunk)
-            cid = torch.randint(0, self.centers.shape[0], (e - s,), generator=g, device=self.device)
-            z = self.centers[cid] + self.spread * torch.randn(e - s, self.L, generator=g, device=self.device) / math.sqrt(self.L)
-            x = z @ self.proj
-            x += self.noise * torch.randn(e - s, self.D, generator=g, device=self.device) / math.sqrt(self.D)
-            x /= x.norm(dim=1, keepdim=True)
-            out[s:e] = x
-        return out
-
-
-def train_codebooks(base, M, seed, iters=6, sample=128_000, k=256):
-    """Fixed synthetic codebooks: Lloyd iterations per subspace on a sample (the reference trains on <= 128k
-    vectors for 6 iterations, ProductQuantization.java:63-64).  Input preparation only — PQ training is a
-    'next' row, not part of the measured path.  Returns float32 [M*k*size] centroid-major."""
-    n, D = base.shape
-    size = D // M
-    g = torch.Generator(device=base.device).manual_seed(seed)
-    idx = torch.randperm(n, generator=g, device=base.device)[: min(sample, n)]
-    X = base[idx].reshape(-1, M, size).permute(1, 0, 2).contiguous()      # M x S x size
-    S = X.shape[1]
-    cent = X[:, torch.randperm(S, generator=g, device=base.device)[:k], :].clone()  # M x k x size
-    for _ in range(iters):
-        assign = torch.empty(M, S, dtype=torch.long, device=base.device)
-        for s in range(0, S, 16384):
-            xs = X[:, s:s + 16384]
-            d = (xs * xs).sum(-1, keepdim=True) - 2 * torch.bmm(xs, cent.transpose(1, 2)) + (cent * cent).sum(-1).unsqueeze(1)
-            assign[:, s:s + 16384] = d.argmin(-1)
-        sums = torch.zeros_like(cent)
-        sums.scatter_add_(1, assign.unsqueeze(-1).expand(-1, -1, size), X)
-        cnt = torch.zeros(M, k, device=base.device).scatter_add_(1, assign, torch.ones(M, S, device=base.device))
-        cent = torch.where(cnt.unsqueeze(-1) > 0, sums / cnt.clamp(min=1).unsqueeze(-1), cent)
-    return cent.reshape(-1).contiguous()
-
-
-def recall_at_k(found, truth):
-    """AccuracyMetrics.recallFromSearchResults (EX/util/AccuracyMetrics.java:38-90): |top-k ∩ gt-k| / k averaged."""
-    hits = 0
-    for f, t in zip(found, truth):
-        hits += len(set(int(x) for x in f if x >= 0) & set(int(x) for x in t))
-    return hits / float(truth.shape[0] * truth.shape[1])
-
-
-def ground_truth(J, ctx, vs, queries, vsf, k, chunk=1_000_000):
-    """Exact top-k by brute force with the engine's bit-exact exact-scan kernel + NodeQueue-order top-k."""
-    Q, N = queries.shape[0], vs.count
-    part_ids, part_sc = [], []
-    buf = torch.empty(Q, min(chunk, N), dtype=torch.float32, device=queries.device)
-    for s in range(0, N, chunk):
-        c = min(chunk, N - s)
-        out = buf[:, :c] if c == buf.shape[1] else torch.empty(Q, c, dtype=torch.float32, device=queries.device)
-        vs.scan(queries, vsf, first=s, count=c, out=out)
-        ids, sc = J.topk(ctx, out, k, id_base=s)
-        part_ids.append(ids)
-        part_sc.append(sc)
-    ids, sc = J.topk(ctx, torch.cat(part_sc, 1).contiguous(), k, ids=torch.cat(part_ids, 1).contiguous())
-    ctx.sync()
-    return ids
-
-
-def cpu_baseline(pq_cb, D, M, codes_dev, base_dev, queries_dev, vsf, top_k, rerank_k, gpu_ids):
-    """Times the CPU oracle (scalar port of the reference arithmetic) on a bounded sample: one query per host
-    core through the same two-pass search.  Returns the cpu_baseline JSON object."""
+def cpu_baseline_flat(cb, D, M, codes_h, base_dev, queries_dev, vsf, top_k, rerank_k, gpu_ids):
+    """CPU oracle on a bounded sample of the flat workload: one query per host thread."""
     from oracle import oracle as O
-
-    cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
+    threads = max(1, min(os.cpu_count() or 1, 64))
     nq = min(threads, queries_dev.shape[0])
-    opq = O.OraclePQ(D, M, pq_cb)
-    codes = codes_dev.cpu().numpy()
+    opq = O.OraclePQ(D, M, cb)
     q = queries_dev[:nq].cpu().numpy()
     t0 = time.perf_counter()
-    cand, _ = opq.search_flat(codes, None, q, int(vsf), rerank_k, 0, nthreads=threads)
+    cand, _ = opq.search_flat(codes_h, None, q, int(vsf), rerank_k, 0, nthreads=threads)
     t1 = time.perf_counter()
     cand_t = torch.from_numpy(cand.astype(np.int64)).to(base_dev.device)
     cand_vecs = base_dev[cand_t.reshape(-1)].reshape(nq, rerank_k, D).cpu().numpy()  # the rows the CPU would fetch
     t2 = time.perf_counter()
-    ids, sc = O.rerank(q, cand_vecs, cand, int(vsf), top_k, nthreads=threads)
+    ids, _ = O.rerank(q, cand_vecs, cand, int(vsf), top_k, nthreads=threads)
     t3 = time.perf_counter()
     cpu_s = (t1 - t0) + (t3 - t2)
-    agree = bool(np.array_equal(ids, gpu_ids[:nq]))
     return {"value": nq / cpu_s, "unit": "queries/s", "cores": threads, "kind": "port",
-            "sample": f"{nq} queries x {codes.shape[0]} codes two-pass search (ADC scan + top-{rerank_k} + exact rerank), "
-                      f"one query per thread, scalar oracle; {cpu_s:.1f}s wall",
-            "matches_gpu_topk": agree}
+            "sample": f"{nq} queries x {codes_h.shape[0]} codes, two-pass flat search (ADC scan + top-{rerank_k} + exact "
+                      f"rerank), one query per thread, scalar oracle; {cpu_s:.1f}s wall",
+            "matches_gpu_topk": bool(np.array_equal(ids, gpu_ids[:nq]))}
+
+
+def cpu_baseline_graph(cb, D, M, codes_h, levels, entry, entry_level, base_dev, queries_dev, vsf, top_k, rerank_k,
+                       gpu_ids):
+    """CPU oracle on a bounded sample of the graph workload: the sequential GraphSearcher restatement (ADC scores
+    via the oracle's FusedPQDecoder arithmetic), queries spread over the host cores (ctypes releases the GIL), then
+    the exact rerank of the returned candidates."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    nq = min(16 * threads, queries_dev.shape[0])
+    opq = O.OraclePQ(D, M, cb)
+    og = O.OracleGraph(codes_h.shape[0], levels, entry, entry_level)
+    q = queries_dev[:nq].cpu().numpy()
+
+    def one(lo):
+        return og.search(opq, codes_h, None, q[lo:lo + 16], int(vsf), rerank_k, rerank_k, fused=True)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(one, range(0, nq, 16)))
+    t1 = time.perf_counter()
+    cand = np.concatenate([p[0] for p in parts])
+    cand_t = torch.from_numpy(cand.astype(np.int64).clip(min=0)).to(base_dev.device)
+    cand_vecs = base_dev[cand_t.reshape(-1)].reshape(nq, rerank_k, D).cpu().numpy()
+    t2 = time.perf_counter()
+    ids, _ = O.rerank(q, cand_vecs, cand, int(vsf), top_k, nthreads=threads)
+    t3 = time.perf_counter()
+    cpu_s = (t1 - t0) + (t3 - t2)
+    return {"value": nq / cpu_s, "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"{nq} queries, sequential GraphSearcher restatement over the same graph (fused ADC, rerankK "
+                      f"{rerank_k}) + exact rerank, 16 queries per task on {threads} threads, scalar oracle; {cpu_s:.1f}s wall",
+            "matches_gpu_topk": bool(np.array_equal(ids, gpu_ids[:nq]))}
 
 
 def main():
@@ -149,60 +103,80 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=["graph", "flat"], default="graph")
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--m", type=int, default=96)
-    ap.add_argument("--queries", type=int, default=256, help="queries per step (batch)")
+    ap.add_argument("--degree", type=int, default=32)
+    ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 4096 graph / 256 flat)")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95")
+    ap.add_argument("--eval-queries", type=int, default=1024, help="timed queries with ground truth (recall)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        dist.init_process_group("nccl", device_id=dev)
 
     import jvector_amd as J
     VSF = J.VectorSimilarityFunction.COSINE
     ctx = J.HipContext(local, stream=torch.cuda.current_stream().cuda_stream)
 
-    N, D, M, Q, K = args.n, args.dim, args.m, args.queries, args.topk
+    N, D, M, K = args.n, args.dim, args.m, args.topk
+    graph_mode = args.mode == "graph"
+    Q = args.queries or (4096 if graph_mode else 256)
     t_setup = time.perf_counter()
     mix = Mixture(D, seed=5, device=dev)
     base = mix.sample(N, seed=5)
-    n_eval = Q * args.steps
     queries_all = mix.sample(Q * (args.steps + args.warmup), seed=6 + 1000 * rank)
     cb = train_codebooks(base, M, seed=4)
     pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb.cpu().numpy())
     vs = J.VectorSet(ctx, base)
 
     # PQ encode (row 3), timed with the engine's own events
+    codes_t = torch.empty(N, M, dtype=torch.uint8, device=dev)
+    cv = J.PQVectors(ctx, pq, codes_t)
     ctx.profile(True)
-    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    J._lib.check(ctx._lib.jv_hip_pq_encode_into(ctx._h, pq._h, vs._h, 0, N, cv._h))
     enc_ms, _ = ctx.profile_read("encode")
     ctx.profile(False)
 
-    searcher = J.FlatSearcher(ctx, pq, cv, vs, max_queries=Q)
-    timed_q = queries_all[args.warmup * Q:]
-    gt = ground_truth(J, ctx, vs, timed_q, VSF, K).cpu().numpy()
+    build_s = None
+    if graph_mode:
+        tb = time.perf_counter()
+        levels, entry, entry_level, nbrs_dev = build_graph(base, max_degree=args.degree)
+        fused = J.FusedPQ(ctx, pq, fused_blocks_from(codes_t, nbrs_dev), nbrs_dev)
+        graph = J.GraphIndex(ctx, N, levels, entry, entry_level)
+        searcher = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=Q)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - tb
 
-    # rerankK: smallest rung reaching recall@10 >= 0.95 on the timed queries (calibration is untimed)
-    ladder = [args.rerank] if args.rerank > 0 else [50, 100, 200, 400, 800, 1600, 3200]
+        def run(qs, rk):
+            return searcher.search(qs, VSF, K, rk)
+    else:
+        flat = J.FlatSearcher(ctx, pq, cv, vs, max_queries=Q)
+
+        def run(qs, rk):
+            return flat.search(qs, VSF, K, rk)
+
+    timed_q = queries_all[args.warmup * Q:]
+    n_eval = min(args.eval_queries, timed_q.shape[0])
+    gt = ground_truth(J, ctx, vs, timed_q[:n_eval].contiguous(), VSF, K).cpu().numpy()
+
+    # rerankK: smallest rung reaching recall@10 >= 0.95 on the evaluated timed queries (calibration is untimed)
+    ladder = [args.rerank] if args.rerank > 0 else [50, 100, 150, 200, 300, 400, 600, 800, 1600]
     rerank_k, rec = ladder[-1], 0.0
     for rk in ladder:
-        found = []
-        for s in range(0, timed_q.shape[0], Q):
-            ids, _ = searcher.search(timed_q[s:s + Q], VSF, K, rk)
-            found.append(ids.clone())
+        found = [run(timed_q[s:s + Q], rk)[0].clone() for s in range(0, n_eval, Q)]
         ctx.sync()
-        rec = recall_at_k(torch.cat(found).cpu().numpy(), gt)
+        rec = recall_at_k(torch.cat(found)[:n_eval].cpu().numpy(), gt)
         rerank_k = rk
         if rec >= 0.95:
             break
@@ -214,15 +188,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    out_ids = torch.empty(Q, K, dtype=torch.int32, device=dev)
-    out_sc = torch.empty(Q, K, dtype=torch.float32, device=dev)
     for w in range(args.warmup):
-        searcher.search(queries_all[w * Q:(w + 1) * Q], VSF, K, rerank_k, out_ids, out_sc)
+        run(queries_all[w * Q:(w + 1) * Q], rerank_k)
     barrier()
     ctx.profile(True)
     t0 = time.perf_counter()
     for s in range(args.steps):
-        searcher.search(timed_q[s * Q:(s + 1) * Q], VSF, K, rerank_k, out_ids, out_sc)
+        run(timed_q[s * Q:(s + 1) * Q], rerank_k)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = {r: ctx.profile_read(r) for r in ("adc", "sample", "topk", "exact", "lut")}
@@ -233,13 +205,28 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # roofline of the dominant kernel (ADC scan): algorithmic bytes = (M code bytes + 4 B score out) per candidate
     adc_ms, adc_n = prof["adc"]
     adc_avg_s = adc_ms / 1e3 / max(adc_n, 1)
-    bytes_per_launch = float(Q) * N * (M + 4)
+    if graph_mode:
+        # dominant kernel: fused-block scoring, one launch per traversal round.
+        # algorithmic bytes per launch: Q x (maxDegree*M block + 4*maxDegree scores out)
+        bytes_per_launch = float(Q) * (args.degree * M + 4 * args.degree)
+        kernel = "adc_kernel<COSINE,6,LUT-in-L2,64> in fused addressing mode (one launch per traversal round: Q origin " \
+                 "blocks of maxDegree*M bytes)"
+        note = ("graph mode is bound by the host traversal and the per-round launch/sync latency, not by this kernel: "
+                "each round scores only Q*maxDegree candidates; see kernel_ms_per_step vs ms_per_step")
+        tfile = "graph_traffic_r1.json"
+    else:
+        bytes_per_launch = float(Q) * N * (M + 4)
+        kernel = "adc_mq_kernel<COSINE,SLCH=2,R=8,FILTER> (threshold-filtered multi-query ADC scan of all N codes; " \
+                 "4 queries per ds_read_b128)"
+        note = ("algorithmic bytes = Q*N*(M+4) (SURVEY 8d: codes re-streamed per query); the kernel shares each code row "
+                "among 4 queries in registers and among query groups through L2/MALL, so frac can exceed 1 while HBM "
+                "traffic (PMC) stays far below peak; the physical bound is the LDS gather rate (DESIGN.md §4)")
+        tfile = "adc_traffic_r1.json"
     achieved = bytes_per_launch / adc_avg_s / 1e9 if adc_avg_s > 0 else 0.0
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "adc_traffic_r1.json")
+    tpath = os.path.join(ROOT, "profiles", tfile)
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
@@ -256,36 +243,40 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic {N}x{D} cosine (latent-32 mixture of 1000 clusters, unit norm), PQ-{M} "
-                                   f"(k=256, Lloyd x6 on 128k sample), two-pass flat search: ADC scan of all codes -> "
-                                   f"top-{rerank_k} -> exact rerank -> top-{K}",
-                       "n_vectors": N, "dim": D, "pq_subspaces": M, "queries_per_step": Q, "topK": K,
+            "config": {"workload": (f"synthetic {N}x{D} cosine (latent-32 mixture of 1000 clusters, unit norm), PQ-{M} (k=256, "
+                                    f"Lloyd x6 on a 128k sample), " +
+                                    (f"FusedADC graph search: synthetic kNN+robust-prune graph (maxDegree {args.degree}, 2 levels), "
+                                     f"host batched GraphSearcher, GPU fused-block scoring, rerankK {rerank_k} -> exact rerank -> top-{K}"
+                                     if graph_mode else
+                                     f"two-pass flat search: ADC scan of all codes -> top-{rerank_k} -> exact rerank -> top-{K}")),
+                       "mode": args.mode, "n_vectors": N, "dim": D, "pq_subspaces": M, "queries_per_step": Q, "topK": K,
                        "rerankK": rerank_k, "similarity": "COSINE",
                        "parallelism": "1 GPU" if world == 1 else f"{world} replicas, queries sharded, no collective"},
-            "recall_at_10": rec,
-            "recall_ok": rec >= 0.95,
-            "adc_distances_per_s": float(Q) * N * args.steps * world / elapsed,
-            "roofline": {"bound": "hbm",
-                         "kernel": "adc_mq_kernel<COSINE,SLCH=2,R=8,FILTER> (threshold-filtered multi-query ADC scan of "
-                                   "all N codes; 4 queries per ds_read_b128)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": bytes_per_launch, "avg_launch_ms": adc_avg_s * 1e3, "launches": adc_n,
-                         "note": "algorithmic bytes = Q*N*(M+4) (SURVEY 8d: codes re-streamed per query); the kernel shares "
-                                 "each code row among 4 queries in registers and among query groups through L2/MALL, so "
-                                 "frac can exceed 1 while HBM traffic (PMC) stays far below peak; the physical bound is "
-                                 "the LDS gather rate (DESIGN.md §4)"},
+            "recall_at_10": rec, "recall_ok": rec >= 0.95, "recall_eval_queries": n_eval,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bytes_per_launch,
+                         "avg_launch_ms": adc_avg_s * 1e3, "launches": adc_n, "note": note},
             "kernel_ms_per_step": {r: prof[r][0] / args.steps for r in prof},
             "encode": {"vectors_per_s": N / (enc_ms / 1e3) if enc_ms > 0 else None, "ms": enc_ms},
-            "setup_s": setup_s,
+            "setup_s": setup_s, "graph_build_s": build_s,
         }
+        if graph_mode:
+            _, _, st = searcher.search(timed_q[:Q], VSF, K, rerank_k, return_stats=True)
+            line["avg_visited"] = float(st[:, 0].mean())
+            line["avg_expanded"] = float(st[:, 1].mean())
+            line["adc_distances_per_s"] = float(st[:, 0].mean()) * total_queries / elapsed
+        else:
+            line["adc_distances_per_s"] = float(Q) * N * args.steps * world / elapsed
         if world == 1 and not args.no_cpu_baseline:
-            ids_gpu, _ = searcher.search(timed_q[:Q], VSF, K, rerank_k)
+            ids_gpu, _ = run(timed_q[:Q], rerank_k)
             ctx.sync()
-            # codes live in the engine's store; read them back through the ABI (device -> host)
-            codes_h = cv.get(0, N)
-            line["cpu_baseline"] = cpu_baseline(cb.cpu().numpy(), D, M, torch.from_numpy(codes_h), base, timed_q, VSF, K,
-                                                rerank_k, ids_gpu.cpu().numpy())
+            codes_h = codes_t.cpu().numpy()
+            if graph_mode:
+                line["cpu_baseline"] = cpu_baseline_graph(cb.cpu().numpy(), D, M, codes_h, levels, entry, entry_level, base,
+                                                          timed_q, VSF, K, rerank_k, ids_gpu.cpu().numpy())
+            else:
+                line["cpu_baseline"] = cpu_baseline_flat(cb.cpu().numpy(), D, M, codes_h, base, timed_q, VSF, K, rerank_k,
+                                                         ids_gpu.cpu().numpy())
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()
