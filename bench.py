@@ -36,7 +36,8 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-from benchlib import (Mixture, build_graph, fused_blocks_from, ground_truth, recall_at_k,  # noqa: E402
+from benchgraph import build_hier_graph  # noqa: E402
+from benchlib import (Mixture, fused_blocks_from, ground_truth, recall_at_k,  # noqa: E402
                       train_codebooks)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable copy)
@@ -151,7 +152,7 @@ def main():
     build_s = None
     if graph_mode:
         tb = time.perf_counter()
-        levels, entry, entry_level, nbrs_dev = build_graph(base, max_degree=args.degree)
+        levels, entry, entry_level, nbrs_dev = build_hier_graph(base, max_degree=args.degree)
         fused = J.FusedPQ(ctx, pq, fused_blocks_from(codes_t, nbrs_dev), nbrs_dev)
         graph = J.GraphIndex(ctx, N, levels, entry, entry_level)
         searcher = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=Q)

@@ -17,7 +17,7 @@ import torch
 # D dims plus small isotropic noise, then L2-normalised.  Pure input preparation (torch is plumbing here).
 # ------------------------------------------------------------------------------------------------------
 class Mixture:
-    def __init__(self, D, seed, device, n_clusters=1000, latent=32, spread=0.35, noise=0.08):
+    def __init__(self, D, seed, device, n_clusters=1000, latent=32, spread=0.7, noise=0.08):
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.D, self.L, self.device = D, latent, device
         self.spread, self.noise = spread, noise

@@ -17,6 +17,7 @@
 // (NodeQueue.java:197-214).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <functional>
@@ -321,6 +322,12 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
         }
     });
 
+    using clk = std::chrono::steady_clock;
+    const bool timing = getenv("JVECTOR_HIP_GRAPH_TIMING") != nullptr;
+    double t_pre = 0, t_gpu = 0, t_post = 0;
+    long n_rounds = 0;
+    auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+
     for (int lvl = g->entry_level; lvl >= 0; --lvl) {
         const int rk = lvl > 0 ? 1 : rerankK;
         const int deg = g->levels[lvl].degree;
@@ -328,6 +335,7 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
         for (auto &s : st) s.active = true;
         for (;;) {
             std::atomic<int> n_active{0};
+            auto tp0 = clk::now();
             // ---- host: stop test, pop, addTopCandidate, choose origin (searchOneLayer :421-433) ----
             pool->parallel_for(Q, [&](int lo, int hi) {
                 int local_active = 0;
@@ -375,6 +383,9 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
                 n_active += local_active;
             });
             if (n_active.load() == 0) break;
+            t_pre += since(tp0);
+            ++n_rounds;
+            auto tg0 = clk::now();
             // ---- GPU: score this round's frontier ----
             const size_t n_ord = use_fused ? (size_t)Q : (size_t)Q * deg;
             JV_HIP_CHECK(hipMemcpyAsync(d_ord, h_ord, sizeof(int32_t) * n_ord, hipMemcpyHostToDevice, ctx->stream));
@@ -390,6 +401,8 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
             }
             JV_HIP_CHECK(hipMemcpyAsync(h_sc, d_sc, sizeof(float) * (size_t)Q * deg, hipMemcpyDeviceToHost, ctx->stream));
             JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            t_gpu += since(tg0);
+            auto tq0 = clk::now();
             // ---- host: push the scored neighbours (View.processNeighbors) ----
             pool->parallel_for(Q, [&](int lo, int hi) {
                 for (int q = lo; q < hi; ++q) {
@@ -417,6 +430,7 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
                     }
                 }
             });
+            t_post += since(tq0);
         }
         if (lvl > 0) {  // setEntryPointsFromPreviousLayer :324-331
             pool->parallel_for(Q, [&](int lo, int hi) {
@@ -431,6 +445,9 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
         }
     }
 
+    if (timing)
+        fprintf(stderr, "[jv graph_search] Q=%d rounds=%ld threads=%d host-pre %.2f ms, gpu+copies %.2f ms, host-post %.2f ms\n", Q,
+                n_rounds, pool->size(), t_pre, t_gpu, t_post);
     // ---- reranking :471-507 ----
     OutStage oi, osc;
     JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_scratch2, &oi));
