@@ -33,6 +33,10 @@ namespace jv {
 // ---------------------------------------------------------------------------------------------
 class HostPool {
 public:
+    // Persistent workers.  Inside a search (between begin() and end()) they SPIN on an atomic generation counter:
+    // a traversal round is two parallel phases of a few tens of microseconds each, far below the cost of a
+    // mutex/condvar wake-up of ~100 threads (measured: 1.5-2 ms per phase with 128 condvar workers).  Outside a
+    // search they sleep on a condition variable.
     explicit HostPool(int nthreads) : n_(nthreads)
     {
         for (int t = 1; t < n_; ++t) threads_.emplace_back([this, t] { worker(t); });
@@ -41,33 +45,43 @@ public:
     {
         {
             std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
-            ++gen_;
+            stop_.store(true);
+            awake_ = true;
         }
         cv_.notify_all();
+        gen_.fetch_add(1, std::memory_order_release);
         for (auto &th : threads_) th.join();
     }
     int size() const { return n_; }
+    void begin()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            awake_ = true;
+        }
+        cv_.notify_all();
+    }
+    void end()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        awake_ = false;
+    }
     void parallel_for(int n, const std::function<void(int, int)> &fn)
     {
         if (n_ == 1 || n < 2 * n_) {
             fn(0, n);
             return;
         }
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn;
-            total_ = n;
-            pending_ = n_ - 1;
-            ++gen_;
-        }
-        cv_.notify_all();
+        fn_ = &fn;
+        total_ = n;
+        done_.store(0, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
         run_chunk(0);
-        std::unique_lock<std::mutex> lk(m_);
-        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        while (done_.load(std::memory_order_acquire) != n_ - 1) cpu_relax();
     }
 
 private:
+    static inline void cpu_relax() { __builtin_ia32_pause(); }
     void run_chunk(int t)
     {
         const int per = (total_ + n_ - 1) / n_;
@@ -76,29 +90,48 @@ private:
     }
     void worker(int t)
     {
-        uint64_t seen = 0;
+        uint64_t seen = gen_.load(std::memory_order_acquire);
         for (;;) {
-            {
+            {   // sleep while no search is running
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
+                cv_.wait(lk, [&] { return awake_ || stop_.load(); });
             }
-            run_chunk(t);
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                if (--pending_ == 0) done_cv_.notify_one();
+            if (stop_.load()) return;
+            // spin for work while awake
+            long idle = 0;
+            for (;;) {
+                const uint64_t g = gen_.load(std::memory_order_acquire);
+                if (g != seen) {
+                    seen = g;
+                    if (stop_.load()) return;
+                    run_chunk(t);
+                    done_.fetch_add(1, std::memory_order_release);
+                    idle = 0;
+                    continue;
+                }
+                cpu_relax();
+                if (++idle > 4096) {
+                    idle = 0;
+                    bool aw;
+                    {
+                        std::lock_guard<std::mutex> lk(m_);
+                        aw = awake_;
+                    }
+                    if (!aw || stop_.load()) break;  // back to the condvar
+                }
             }
         }
     }
     int n_;
     std::vector<std::thread> threads_;
     std::mutex m_;
-    std::condition_variable cv_, done_cv_;
+    std::condition_variable cv_;
+    bool awake_ = false;
+    std::atomic<bool> stop_{false};
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> done_{0};
     const std::function<void(int, int)> *fn_ = nullptr;
-    int total_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
+    int total_ = 0;
 };
 
 static void destroy_pool(void *p) { delete static_cast<HostPool *>(p); }
@@ -106,9 +139,11 @@ static void destroy_pool(void *p) { delete static_cast<HostPool *>(p); }
 static HostPool *get_pool(jv_ctx *ctx)
 {
     if (!ctx->host_pool) {
-        int n = (int)std::thread::hardware_concurrency();
+        // default: half the hardware threads (one per physical core, like the reference's PhysicalCoreExecutor,
+        // B/util/PhysicalCoreExecutor.java:121), capped at 64
+        int n = (int)std::thread::hardware_concurrency() / 2;
         if (const char *e = getenv("JVECTOR_HIP_HOST_THREADS")) n = atoi(e);
-        n = std::max(1, std::min(n, 128));
+        n = std::max(1, std::min(n, 64));
         ctx->host_pool = new HostPool(n);
         ctx->host_pool_destroy = destroy_pool;
     }
@@ -158,6 +193,16 @@ struct IntSet {
         slots[i] = v;
         ++count;
         return true;
+    }
+    bool contains(int32_t v) const
+    {
+        const uint32_t mask = (uint32_t)slots.size() - 1;
+        uint32_t i = hash(v) & mask;
+        while (slots[i] != -1) {
+            if (slots[i] == v) return true;
+            i = (i + 1) & mask;
+        }
+        return false;
     }
     void grow()
     {
@@ -286,169 +331,282 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
         if (fused) JV_TRY(ensure_fused_norms(ctx, const_cast<jv_fused *>(fused)));
     }
     HostPool *pool = get_pool(ctx);
-    int max_deg = 0;
-    for (int lv = 0; lv <= g->entry_level; ++lv) max_deg = std::max(max_deg, g->levels[lv].degree);
+    struct PoolSession {
+        HostPool *p;
+        explicit PoolSession(HostPool *pp) : p(pp) { p->begin(); }
+        ~PoolSession() { p->end(); }
+    } pool_session(pool);
+    int W = 0;
+    for (int lv = 0; lv <= g->entry_level; ++lv) W = std::max(W, g->levels[lv].degree);
+    JV_REQUIRE(W <= 64, "graph_search: degree %d > 64 is not supported", W);
 
-    // pinned host + device buffers for the per-round exchange
-    const size_t cells = (size_t)Q * max_deg;
+    // ---- slots: queries stream through a fixed number of traversal slots (continuous batching), in NG groups that
+    //      alternate between the host phase and the GPU phase so that one group's scoring overlaps the other's
+    //      heap work.  Per query nothing changes: its own pop -> score -> push sequence is the reference's.
+    int S_total = 4096;
+    if (const char *e = getenv("JVECTOR_HIP_GRAPH_SLOTS")) S_total = std::max(1, atoi(e));
+    S_total = std::min(S_total, Q);
+    int NG = (S_total >= 512) ? 2 : 1;
+    if (const char *e = getenv("JVECTOR_HIP_GRAPH_GROUPS")) NG = std::max(1, std::min(4, atoi(e)));
+    const int SG = (S_total + NG - 1) / NG;  // slots per group
+
     // luts_build may still be DMA-ing the queries out of the pinned staging buffer: drain before reusing it
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    JV_TRY(ctx->h_in.reserve(sizeof(int32_t) * cells));
-    JV_TRY(ctx->h_out.reserve(sizeof(float) * cells));
-    JV_TRY(ctx->d_in.reserve(sizeof(int32_t) * cells));
-    JV_TRY(ctx->d_out.reserve(sizeof(float) * cells));
-    int32_t *h_ord = (int32_t *)ctx->h_in.ptr;   // fused: Q origins; gather: Q x deg ordinals
-    float *h_sc = (float *)ctx->h_out.ptr;
-    int32_t *d_ord = (int32_t *)ctx->d_in.ptr;
-    float *d_sc = (float *)ctx->d_out.ptr;
+    // per group, control block (int32): [slot_query SG][origins SG][ord_index SG][ords SG*W]; scores SG*W floats
+    const size_t ctrl_ints = (size_t)SG * (3 + W);
+    const size_t sc_floats = (size_t)SG * W;
+    JV_TRY(ctx->h_in.reserve(std::max(sizeof(int32_t) * ctrl_ints * NG, sizeof(int32_t) * (size_t)Q)));
+    JV_TRY(ctx->h_out.reserve(std::max(sizeof(float) * sc_floats * NG, sizeof(float) * (size_t)Q)));
+    JV_TRY(ctx->d_in.reserve(std::max(sizeof(int32_t) * ctrl_ints * NG, sizeof(int32_t) * (size_t)Q)));
+    JV_TRY(ctx->d_out.reserve(std::max(sizeof(float) * sc_floats * NG, sizeof(float) * (size_t)Q)));
 
-    std::vector<QState> st((size_t)Q);
-    // initializeInternal: score the entry node for every query (one gather of Q x 1)
-    for (int q = 0; q < Q; ++q) h_ord[q] = g->entry_node;
-    JV_HIP_CHECK(hipMemcpyAsync(d_ord, h_ord, sizeof(int32_t) * (size_t)Q, hipMemcpyHostToDevice, ctx->stream));
+    // initializeInternal for every query: score the entry node (one gather of Q x 1)
+    std::vector<float> entry_score((size_t)Q);
     {
-        ProfScope ps(ctx, R_ADC);
-        JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes, codes->d_norms,
-                          codes->count, 0, 1, d_ord, d_sc));
-    }
-    JV_HIP_CHECK(hipMemcpyAsync(h_sc, d_sc, sizeof(float) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
-    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    pool->parallel_for(Q, [&](int lo, int hi) {
-        for (int q = lo; q < hi; ++q) {
-            QState &s = st[q];
-            s.visited.reset(1024);
-            s.visited.add(g->entry_node);
-            s.cand.push_back(nq_encode(g->entry_node, h_sc[q]));
+        int32_t *h = (int32_t *)ctx->h_in.ptr;
+        for (int q = 0; q < Q; ++q) h[q] = g->entry_node;
+        JV_HIP_CHECK(hipMemcpyAsync(ctx->d_in.ptr, h, sizeof(int32_t) * (size_t)Q, hipMemcpyHostToDevice, ctx->stream));
+        {
+            ProfScope ps(ctx, R_ADC);
+            JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes, codes->d_norms,
+                              codes->count, 0, 1, (const int32_t *)ctx->d_in.ptr, (float *)ctx->d_out.ptr));
         }
-    });
+        JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, ctx->d_out.ptr, sizeof(float) * (size_t)Q, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        memcpy(entry_score.data(), ctx->h_out.ptr, sizeof(float) * (size_t)Q);
+    }
+
+    struct Slot {
+        QState st;
+        int query = -1;
+        int lvl = 0;
+    };
+    struct Group {
+        std::vector<Slot> slots;
+        int32_t *h_ctrl = nullptr, *d_ctrl = nullptr;
+        float *h_sc = nullptr, *d_sc = nullptr;
+        hipEvent_t ev = nullptr;
+        bool launched = false;
+        int n_active = 0, n_gather = 0;
+    };
+    std::vector<Group> groups((size_t)NG);
+    for (int gi = 0; gi < NG; ++gi) {
+        Group &G = groups[gi];
+        const int lo = gi * SG, hi = std::min(S_total, lo + SG);
+        G.slots.resize((size_t)std::max(0, hi - lo));
+        G.h_ctrl = (int32_t *)ctx->h_in.ptr + ctrl_ints * gi;
+        G.d_ctrl = (int32_t *)ctx->d_in.ptr + ctrl_ints * gi;
+        G.h_sc = (float *)ctx->h_out.ptr + sc_floats * gi;
+        G.d_sc = (float *)ctx->d_out.ptr + sc_floats * gi;
+        JV_HIP_CHECK(hipEventCreateWithFlags(&G.ev, hipEventDisableTiming));
+    }
+    struct EventGuard {
+        std::vector<Group> &gs;
+        ~EventGuard() { for (auto &G : gs) if (G.ev) (void)hipEventDestroy(G.ev); }
+    } event_guard{groups};
+
+    std::vector<std::vector<int64_t>> fin((size_t)Q);       // per query: kept approximate results (keys)
+    std::vector<int64_t> q_visited((size_t)Q, 0), q_expanded((size_t)Q, 0);
+    std::atomic<int> next_q{0};
+    const int deg0 = g->levels[0].degree;
+
+    auto start_query = [&](Slot &s) -> bool {
+        const int qi = next_q.fetch_add(1);
+        if (qi >= Q) {
+            s.query = -1;
+            return false;
+        }
+        s.query = qi;
+        s.lvl = g->entry_level;
+        QState &st = s.st;
+        st.cand.clear();
+        st.res.clear();
+        st.evicted.clear();
+        st.visited.reset(1024);
+        st.visited.add(g->entry_node);
+        st.cand.push_back(nq_encode(g->entry_node, entry_score[qi]));
+        st.n_visited = st.n_expanded = 0;
+        return true;
+    };
 
     using clk = std::chrono::steady_clock;
     const bool timing = getenv("JVECTOR_HIP_GRAPH_TIMING") != nullptr;
-    double t_pre = 0, t_gpu = 0, t_post = 0;
+    double t_host = 0, t_wait = 0;
     long n_rounds = 0;
     auto since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
 
-    for (int lvl = g->entry_level; lvl >= 0; --lvl) {
-        const int rk = lvl > 0 ? 1 : rerankK;
-        const int deg = g->levels[lvl].degree;
-        const bool use_fused = (lvl == 0 && fused != nullptr);
-        for (auto &s : st) s.active = true;
-        for (;;) {
-            std::atomic<int> n_active{0};
-            auto tp0 = clk::now();
-            // ---- host: stop test, pop, addTopCandidate, choose origin (searchOneLayer :421-433) ----
-            pool->parallel_for(Q, [&](int lo, int hi) {
-                int local_active = 0;
-                for (int q = lo; q < hi; ++q) {
-                    QState &s = st[q];
-                    s.origin = -1;
-                    s.n_pending = 0;
-                    int32_t *ords = h_ord + (use_fused ? (size_t)q : (size_t)q * deg);
-                    if (use_fused) ords[0] = -1;
-                    else std::fill(ords, ords + deg, -1);
-                    if (!s.active) continue;
-                    if (s.cand.empty()) { s.active = false; continue; }
-                    const int64_t top = s.cand.front();
-                    const float top_score = nq_score(top);
-                    if ((int)s.res.size() >= rk && top_score < nq_score(s.res.front())) { s.active = false; continue; }  // stopSearch
-                    std::pop_heap(s.cand.begin(), s.cand.end());
-                    s.cand.pop_back();
-                    const int32_t node = nq_node(top);
-                    // addTopCandidate :515-530
-                    if ((int)s.res.size() < rk) {
-                        s.res.push_back(top);
-                        std::push_heap(s.res.begin(), s.res.end(), std::greater<int64_t>());
-                    } else if (top_score > nq_score(s.res.front())) {
-                        s.evicted.push_back(s.res.front());
-                        std::pop_heap(s.res.begin(), s.res.end(), std::greater<int64_t>());
-                        s.res.back() = top;
-                        std::push_heap(s.res.begin(), s.res.end(), std::greater<int64_t>());
+    // ---- host phase A: advance every slot of the group to its next expansion (searchOneLayer :421-433) ----
+    auto pre = [&](Group &G) {
+        const int SGn = (int)G.slots.size();
+        int32_t *slot_query = G.h_ctrl, *origins = G.h_ctrl + SG, *ord_index = G.h_ctrl + 2 * SG;
+        int32_t *ords = G.h_ctrl + 3 * SG;
+        std::atomic<int> n_active{0}, n_gather{0};
+        pool->parallel_for(SGn, [&](int lo, int hi) {
+            int local_active = 0;
+            for (int si = lo; si < hi; ++si) {
+                Slot &s = G.slots[si];
+                QState &st = s.st;
+                st.origin = -1;
+                st.n_pending = 0;
+                slot_query[si] = -1;
+                origins[si] = -1;
+                ord_index[si] = -1;
+                if (s.query < 0 && !start_query(s)) continue;
+                for (;;) {
+                    const int rk = s.lvl > 0 ? 1 : rerankK;
+                    bool layer_done = st.cand.empty();
+                    int64_t top = 0;
+                    float top_score = 0.0f;
+                    if (!layer_done) {
+                        top = st.cand.front();
+                        top_score = nq_score(top);
+                        layer_done = (int)st.res.size() >= rk && top_score < nq_score(st.res.front());  // stopSearch
                     }
-                    s.n_expanded++;
-                    s.origin = node;
-                    ++local_active;
-                    if (use_fused) {
-                        ords[0] = node;
-                    } else {
-                        const int32_t *row = g->row(lvl, node);
-                        if (row) {
-                            for (int i = 0; i < deg; ++i) {
-                                const int32_t nb = row[i];
-                                if (nb < 0) break;
-                                if (s.visited.add(nb)) ords[s.n_pending++] = nb;  // visited.mark, in neighbour order
-                            }
+                    if (layer_done) {
+                        if (s.lvl > 0) {  // setEntryPointsFromPreviousLayer :324-331
+                            for (int64_t k : st.res) { st.cand.push_back(k); std::push_heap(st.cand.begin(), st.cand.end()); }
+                            for (int64_t k : st.evicted) { st.cand.push_back(k); std::push_heap(st.cand.begin(), st.cand.end()); }
+                            st.res.clear();
+                            st.evicted.clear();
+                            s.lvl--;
+                            continue;
                         }
+                        fin[s.query].assign(st.res.begin(), st.res.end());
+                        q_visited[s.query] = st.n_visited;
+                        q_expanded[s.query] = st.n_expanded;
+                        if (!start_query(s)) break;
+                        continue;
                     }
-                }
-                n_active += local_active;
-            });
-            if (n_active.load() == 0) break;
-            t_pre += since(tp0);
-            ++n_rounds;
-            auto tg0 = clk::now();
-            // ---- GPU: score this round's frontier ----
-            const size_t n_ord = use_fused ? (size_t)Q : (size_t)Q * deg;
-            JV_HIP_CHECK(hipMemcpyAsync(d_ord, h_ord, sizeof(int32_t) * n_ord, hipMemcpyHostToDevice, ctx->stream));
-            {
-                ProfScope ps(ctx, R_ADC);
-                if (use_fused)
-                    JV_TRY(launch_fused(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, fused->M, kvsf, fused->d_blocks,
-                                        fused->d_neighbors, fused->d_norms, fused->maxDegree, fused->count, d_ord, d_sc,
-                                        nullptr));
-                else
-                    JV_TRY(launch_adc(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes,
-                                      codes->d_norms, codes->count, 0, deg, d_ord, d_sc));
-            }
-            JV_HIP_CHECK(hipMemcpyAsync(h_sc, d_sc, sizeof(float) * (size_t)Q * deg, hipMemcpyDeviceToHost, ctx->stream));
-            JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            t_gpu += since(tg0);
-            auto tq0 = clk::now();
-            // ---- host: push the scored neighbours (View.processNeighbors) ----
-            pool->parallel_for(Q, [&](int lo, int hi) {
-                for (int q = lo; q < hi; ++q) {
-                    QState &s = st[q];
-                    if (s.origin < 0) continue;
-                    const float *sc = h_sc + (size_t)q * deg;
-                    if (use_fused) {
-                        const int32_t *row = g->row(0, s.origin);
+                    std::pop_heap(st.cand.begin(), st.cand.end());
+                    st.cand.pop_back();
+                    const int32_t node = nq_node(top);
+                    if ((int)st.res.size() < rk) {  // addTopCandidate :515-530
+                        st.res.push_back(top);
+                        std::push_heap(st.res.begin(), st.res.end(), std::greater<int64_t>());
+                    } else if (top_score > nq_score(st.res.front())) {
+                        st.evicted.push_back(st.res.front());
+                        std::pop_heap(st.res.begin(), st.res.end(), std::greater<int64_t>());
+                        st.res.back() = top;
+                        std::push_heap(st.res.begin(), st.res.end(), std::greater<int64_t>());
+                    }
+                    st.n_expanded++;
+                    const int32_t *row = g->row(s.lvl, node);
+                    if (!row) continue;  // node without a row at this level: nothing to score
+                    if (s.lvl == 0 && fused) {
+                        // scored from the packed block; skip the GPU round when every neighbour is already visited
+                        bool any = false;
+                        for (int i = 0; i < deg0 && row[i] >= 0; ++i)
+                            if (!st.visited.contains(row[i])) { any = true; break; }
+                        if (!any) continue;
+                        origins[si] = node;
+                    } else {
+                        const int deg = g->levels[s.lvl].degree;
+                        int32_t tmp[64];
+                        int np = 0;
                         for (int i = 0; i < deg; ++i) {
                             const int32_t nb = row[i];
                             if (nb < 0) break;
-                            if (s.visited.add(nb)) {
-                                s.cand.push_back(nq_encode(nb, sc[i]));
-                                std::push_heap(s.cand.begin(), s.cand.end());
-                                s.n_visited++;
-                            }
+                            if (st.visited.add(nb)) tmp[np++] = nb;  // visited.mark, in neighbour order
                         }
-                    } else {
-                        const int32_t *ords = h_ord + (size_t)q * deg;
-                        for (int j = 0; j < s.n_pending; ++j) {
-                            s.cand.push_back(nq_encode(ords[j], sc[j]));
-                            std::push_heap(s.cand.begin(), s.cand.end());
-                            s.n_visited++;
+                        if (np == 0) continue;
+                        const int oi = n_gather.fetch_add(1);
+                        ord_index[si] = oi;
+                        int32_t *dst = ords + (size_t)oi * W;
+                        for (int j = 0; j < W; ++j) dst[j] = j < np ? tmp[j] : -1;
+                        st.n_pending = np;
+                    }
+                    st.origin = node;
+                    slot_query[si] = s.query;
+                    ++local_active;
+                    break;
+                }
+            }
+            n_active += local_active;
+        });
+        G.n_active = n_active.load();
+        G.n_gather = n_gather.load();
+    };
+
+    auto launch = [&](Group &G) -> int {
+        const int SGn = (int)G.slots.size();
+        const size_t n_ctrl = (size_t)3 * SG + (size_t)G.n_gather * W;
+        JV_HIP_CHECK(hipMemcpyAsync(G.d_ctrl, G.h_ctrl, sizeof(int32_t) * n_ctrl, hipMemcpyHostToDevice, ctx->stream));
+        {
+            ProfScope ps(ctx, R_ADC);
+            JV_TRY(launch_frontier(ctx->stream, kvsf, l->d_luts, l->d_bmag, G.d_ctrl, G.d_ctrl + SG, G.d_ctrl + 2 * SG,
+                                   G.d_ctrl + 3 * SG, fused, codes, G.d_sc, SGn, W));
+        }
+        JV_HIP_CHECK(hipMemcpyAsync(G.h_sc, G.d_sc, sizeof(float) * (size_t)SGn * W, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipEventRecord(G.ev, ctx->stream));
+        G.launched = true;
+        return JV_OK;
+    };
+
+    // ---- host phase B: push the scored neighbours (View.processNeighbors) ----
+    auto post = [&](Group &G) {
+        const int SGn = (int)G.slots.size();
+        const int32_t *ord_index = G.h_ctrl + 2 * SG, *ords = G.h_ctrl + 3 * SG;
+        pool->parallel_for(SGn, [&](int lo, int hi) {
+            for (int si = lo; si < hi; ++si) {
+                Slot &s = G.slots[si];
+                QState &st = s.st;
+                if (st.origin < 0) continue;
+                const float *sc = G.h_sc + (size_t)si * W;
+                if (ord_index[si] < 0) {  // fused layer 0
+                    const int32_t *row = g->row(0, st.origin);
+                    for (int i = 0; i < deg0; ++i) {
+                        const int32_t nb = row[i];
+                        if (nb < 0) break;
+                        if (st.visited.add(nb)) {
+                            st.cand.push_back(nq_encode(nb, sc[i]));
+                            std::push_heap(st.cand.begin(), st.cand.end());
+                            st.n_visited++;
                         }
                     }
+                } else {
+                    const int32_t *o = ords + (size_t)ord_index[si] * W;
+                    for (int j = 0; j < st.n_pending; ++j) {
+                        st.cand.push_back(nq_encode(o[j], sc[j]));
+                        std::push_heap(st.cand.begin(), st.cand.end());
+                        st.n_visited++;
+                    }
                 }
-            });
-            t_post += since(tq0);
-        }
-        if (lvl > 0) {  // setEntryPointsFromPreviousLayer :324-331
-            pool->parallel_for(Q, [&](int lo, int hi) {
-                for (int q = lo; q < hi; ++q) {
-                    QState &s = st[q];
-                    for (int64_t k : s.res) { s.cand.push_back(k); std::push_heap(s.cand.begin(), s.cand.end()); }
-                    for (int64_t k : s.evicted) { s.cand.push_back(k); std::push_heap(s.cand.begin(), s.cand.end()); }
-                    s.res.clear();
-                    s.evicted.clear();
-                }
-            });
-        }
-    }
+            }
+        });
+    };
 
+    // ---- the pipeline: while one group's frontier is on the GPU the other group is in its host phases ----
+    for (auto &G : groups) {
+        auto t0 = clk::now();
+        pre(G);
+        t_host += since(t0);
+        if (G.n_active > 0) JV_TRY(launch(G));
+    }
+    for (;;) {
+        bool any = false;
+        for (auto &G : groups) {
+            if (!G.launched) continue;
+            any = true;
+            auto tw = clk::now();
+            JV_HIP_CHECK(hipEventSynchronize(G.ev));
+            t_wait += since(tw);
+            G.launched = false;
+            ++n_rounds;
+            auto t0 = clk::now();
+            post(G);
+            pre(G);
+            t_host += since(t0);
+            if (G.n_active > 0) JV_TRY(launch(G));
+        }
+        if (!any) break;
+    }
     if (timing)
-        fprintf(stderr, "[jv graph_search] Q=%d rounds=%ld threads=%d host-pre %.2f ms, gpu+copies %.2f ms, host-post %.2f ms\n", Q,
-                n_rounds, pool->size(), t_pre, t_gpu, t_post);
+        fprintf(stderr, "[jv graph_search] Q=%d slots=%d groups=%d threads=%d rounds=%ld host %.2f ms, gpu-wait %.2f ms\n", Q,
+                S_total, NG, pool->size(), n_rounds, t_host, t_wait);
+
     // ---- reranking :471-507 ----
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     OutStage oi, osc;
     JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_scratch2, &oi));
     JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * topK, ctx->d_scratch3, &osc));
@@ -458,11 +616,11 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
     float *h_cand_sc = (float *)(h_cand + c1);
     pool->parallel_for(Q, [&](int lo, int hi) {
         for (int q = lo; q < hi; ++q) {
-            const QState &s = st[q];
+            const std::vector<int64_t> &r = fin[q];
             for (int i = 0; i < rerankK; ++i) {
-                const bool have = i < (int)s.res.size();
-                h_cand[(size_t)q * rerankK + i] = have ? nq_node(s.res[i]) : -1;
-                h_cand_sc[(size_t)q * rerankK + i] = have ? nq_score(s.res[i]) : -INFINITY;
+                const bool have = i < (int)r.size();
+                h_cand[(size_t)q * rerankK + i] = have ? nq_node(r[i]) : -1;
+                h_cand_sc[(size_t)q * rerankK + i] = have ? nq_score(r[i]) : -INFINITY;
             }
         }
     });
@@ -489,8 +647,8 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (stats) {
         for (int q = 0; q < Q; ++q) {
-            stats[2 * q] = st[q].n_visited;
-            stats[2 * q + 1] = st[q].n_expanded;
+            stats[2 * q] = q_visited[q];
+            stats[2 * q + 1] = q_expanded[q];
         }
     }
     return JV_OK;

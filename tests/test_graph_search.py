@@ -108,3 +108,28 @@ def test_graph_search_large_batch_and_errors(ctx):
         s.search(q[:4], VSF.COSINE, 10, 5)
     with pytest.raises(ValueError):  # more queries than the LUT capacity
         J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=2).search(q[:4], VSF.COSINE, 1, 1)
+
+
+@pytest.mark.parametrize("slots,groups", [(16, 1), (64, 2), (500, 3)])
+def test_graph_search_continuous_batching(ctx, slots, groups, monkeypatch):
+    """queries streaming through a few traversal slots (continuous batching) and alternating slot groups
+    (host/GPU pipelining) must not change any per-query result"""
+    v, lv, entry, entry_level, cb, q = build_problem(5, N=3000, levels=3)
+    N, D, M = v.shape[0], 64, 8
+    rng = np.random.default_rng(4)
+    q = (v[rng.integers(0, N, 333)] + 0.1 * rng.standard_normal((333, D))).astype(np.float32)
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+    og = O.OracleGraph(N, lv, entry, entry_level)
+    monkeypatch.setenv("JVECTOR_HIP_GRAPH_SLOTS", str(slots))
+    monkeypatch.setenv("JVECTOR_HIP_GRAPH_GROUPS", str(groups))
+    for use_fused in (True, False):
+        fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
+        s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=512)
+        ids, sc, stats = s.search(q, VSF.DOT_PRODUCT, 10, 30, return_stats=True)
+        wi, ws, wst = og.search(opq, codes, v, q, O.DOT_PRODUCT, 10, 30, fused=use_fused)
+        assert np.array_equal(stats, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
