@@ -43,10 +43,28 @@ from benchlib import (Mixture, fused_blocks_from, ground_truth, recall_at_k,  # 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable copy)
 
 
+def effective_cpus():
+    """Host cores this process may actually use: min(affinity, cgroup CPU quota), capped at 64."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p)))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline_flat(cb, D, M, codes_h, base_dev, queries_dev, vsf, top_k, rerank_k, gpu_ids):
     """CPU oracle on a bounded sample of the flat workload: one query per host thread."""
     from oracle import oracle as O
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    threads = effective_cpus()
     nq = min(threads, queries_dev.shape[0])
     opq = O.OraclePQ(D, M, cb)
     q = queries_dev[:nq].cpu().numpy()
@@ -73,7 +91,7 @@ def cpu_baseline_graph(cb, D, M, codes_h, levels, entry, entry_level, base_dev, 
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as O
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    threads = effective_cpus()
     nq = min(16 * threads, queries_dev.shape[0])
     opq = O.OraclePQ(D, M, cb)
     og = O.OracleGraph(codes_h.shape[0], levels, entry, entry_level)
@@ -246,7 +264,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"synthetic {N}x{D} cosine (latent-32 mixture of 1000 clusters, unit norm), PQ-{M} (k=256, "
                                     f"Lloyd x6 on a 128k sample), " +
-                                    (f"FusedADC graph search: synthetic kNN+robust-prune graph (maxDegree {args.degree}, 2 levels), "
+                                    (f"FusedADC graph search: synthetic kNN+robust-prune graph (maxDegree {args.degree}, {len(levels)} nested levels), "
                                      f"host batched GraphSearcher, GPU fused-block scoring, rerankK {rerank_k} -> exact rerank -> top-{K}"
                                      if graph_mode else
                                      f"two-pass flat search: ADC scan of all codes -> top-{rerank_k} -> exact rerank -> top-{K}")),
