@@ -5,11 +5,13 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 
 ("ada-002-like"), PQ-96 (256 clusters, 8-dim sub-vectors), FusedADC graph blocks (maxDegree 32).
 One *step* = one batch of Q queries through the hot path, inputs resident in HBM.  Two search modes:
 
-  --mode graph (default)  host batched GraphSearcher (lock-step traversal on the host cores, each round's frontier
+  --mode graph            host batched GraphSearcher (lock-step traversal on the host cores, each round's frontier
                           scored on the GPU from the FusedPQ neighbour blocks) -> exact rerank -> top-10
                           [GraphSearcher.search + FusedPQDecoder + NodeQueue.rerank, batched]
   --mode flat             LUT build -> multi-query ADC scan of all N codes (threshold-filtered) -> top-rerankK
                           -> exact rerank -> top-10   (no graph; the brute-force-over-codes path)
+  --mode auto (default)   graph when the rank has >= 8 host cores for the traversal (the graph path is host-bound),
+                          else flat (GPU-bound)
 
 value = whole-job queries/s at recall@10 >= 0.95; recall is measured against exact brute-force ground truth
 computed by the engine's bit-exact exact-scan kernel, outside the timed region, on (a subset of) the timed queries.
@@ -92,7 +94,7 @@ def cpu_baseline_graph(cb, D, M, codes_h, levels, entry, entry_level, base_dev, 
 
     from oracle import oracle as O
     threads = effective_cpus()
-    nq = min(16 * threads, queries_dev.shape[0])
+    nq = min(256 * threads, queries_dev.shape[0])
     opq = O.OraclePQ(D, M, cb)
     og = O.OracleGraph(codes_h.shape[0], levels, entry, entry_level)
     q = queries_dev[:nq].cpu().numpy()
@@ -122,12 +124,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=["graph", "flat"], default="graph")
+    ap.add_argument("--mode", choices=["auto", "graph", "flat"], default="auto",
+                    help="auto = graph when this rank has >= 8 host cores for the traversal, else flat")
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--m", type=int, default=96)
     ap.add_argument("--degree", type=int, default=32)
-    ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 4096 graph / 256 flat)")
+    ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 16384 graph / 256 flat)")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95")
     ap.add_argument("--eval-queries", type=int, default=1024, help="timed queries with ground truth (recall)")
@@ -149,8 +152,12 @@ def main():
     ctx = J.HipContext(local, stream=torch.cuda.current_stream().cuda_stream)
 
     N, D, M, K = args.n, args.dim, args.m, args.topk
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    host_cores = max(1, effective_cpus() // max(1, local_world))
+    if args.mode == "auto":
+        args.mode = "graph" if host_cores >= 8 else "flat"
     graph_mode = args.mode == "graph"
-    Q = args.queries or (4096 if graph_mode else 256)
+    Q = args.queries or (16384 if graph_mode else 256)
     t_setup = time.perf_counter()
     mix = Mixture(D, seed=5, device=dev)
     base = mix.sample(N, seed=5)
@@ -226,14 +233,20 @@ def main():
 
     adc_ms, adc_n = prof["adc"]
     adc_avg_s = adc_ms / 1e3 / max(adc_n, 1)
+    graph_stats = None
     if graph_mode:
-        # dominant kernel: fused-block scoring, one launch per traversal round.
-        # algorithmic bytes per launch: Q x (maxDegree*M block + 4*maxDegree scores out)
-        bytes_per_launch = float(Q) * (args.degree * M + 4 * args.degree)
-        kernel = "adc_kernel<COSINE,6,LUT-in-L2,64> in fused addressing mode (one launch per traversal round: Q origin " \
-                 "blocks of maxDegree*M bytes)"
-        note = ("graph mode is bound by the host traversal and the per-round launch/sync latency, not by this kernel: "
-                "each round scores only Q*maxDegree candidates; see kernel_ms_per_step vs ms_per_step")
+        # dominant kernel: frontier scoring, one launch per traversal round of a slot group.
+        # algorithmic bytes per launch: expansions scored per launch x (maxDegree*M block bytes +
+        # 4*maxDegree scores out), with the expansion count measured (SearchResult.expandedCount).
+        _, _, graph_stats = searcher.search(timed_q[:Q], VSF, K, rerank_k, return_stats=True)
+        exp_per_step = float(graph_stats[:, 1].sum())
+        launches_per_step = max(adc_n / args.steps, 1.0)
+        bytes_per_launch = exp_per_step / launches_per_step * (args.degree * M + 4 * args.degree)
+        kernel = "frontier_kernel<COSINE,CH16=6,two slots per wave> (FusedPQ neighbour-block scoring, LUT gathered from " \
+                 "L2/HBM; one launch per traversal round of a slot group)"
+        note = ("graph mode is bound by the HOST traversal (16-CPU cgroup quota on the GPU box), not by this kernel: each "
+                "launch scores only ~2k expansions x maxDegree candidates and overlaps the other slot group's host phase; "
+                "see kernel_ms_per_step vs ms_per_step and DESIGN.md §5")
         tfile = "graph_traffic_r1.json"
     else:
         bytes_per_launch = float(Q) * N * (M + 4)
@@ -280,10 +293,11 @@ def main():
             "setup_s": setup_s, "graph_build_s": build_s,
         }
         if graph_mode:
-            _, _, st = searcher.search(timed_q[:Q], VSF, K, rerank_k, return_stats=True)
+            st = graph_stats
             line["avg_visited"] = float(st[:, 0].mean())
             line["avg_expanded"] = float(st[:, 1].mean())
             line["adc_distances_per_s"] = float(st[:, 0].mean()) * total_queries / elapsed
+            line["host_threads"] = host_cores
         else:
             line["adc_distances_per_s"] = float(Q) * N * args.steps * world / elapsed
         if world == 1 and not args.no_cpu_baseline:

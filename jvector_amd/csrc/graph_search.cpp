@@ -163,6 +163,11 @@ static HostPool *get_pool(jv_ctx *ctx)
             }
             if (quota >= 1.0) n = std::min(n, (int)quota);
         }
+        // one process per GPU: share the host cores between the ranks of this node (torchrun sets LOCAL_WORLD_SIZE)
+        if (const char *lw = getenv("LOCAL_WORLD_SIZE")) {
+            const int ranks = atoi(lw);
+            if (ranks > 1) n = std::max(1, n / ranks);
+        }
         if (const char *e = getenv("JVECTOR_HIP_HOST_THREADS")) n = atoi(e);
         n = std::max(1, std::min(n, 64));
         ctx->host_pool = new HostPool(n);
