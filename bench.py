@@ -226,6 +226,23 @@ def main():
     prof = {r: ctx.profile_read(r) for r in ("adc", "sample", "topk", "exact", "lut")}
     ctx.profile(False)
 
+    # developer aid: JVECTOR_BENCH_SWEEP="slots:groups,slots:groups,..." re-times the graph steps under other slot
+    # configurations (stderr only; the reported line is the default configuration above)
+    if graph_mode and os.environ.get("JVECTOR_BENCH_SWEEP"):
+        for cfg in os.environ["JVECTOR_BENCH_SWEEP"].split(","):
+            sl, gr = cfg.split(":")
+            os.environ["JVECTOR_HIP_GRAPH_SLOTS"], os.environ["JVECTOR_HIP_GRAPH_GROUPS"] = sl, gr
+            run(timed_q[:Q], rerank_k)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for s in range(min(3, args.steps)):
+                run(timed_q[s * Q:(s + 1) * Q], rerank_k)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - ts) / min(3, args.steps)
+            print(f"[sweep] slots={sl} groups={gr}: {dt * 1e3:.1f} ms/step, {Q / dt:.0f} QPS", file=sys.stderr)
+        os.environ.pop("JVECTOR_HIP_GRAPH_SLOTS", None)
+        os.environ.pop("JVECTOR_HIP_GRAPH_GROUPS", None)
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -220,6 +220,7 @@ struct IntSet {
         ++count;
         return true;
     }
+    void prefetch(int32_t v) const { __builtin_prefetch(&slots[hash(v) & ((uint32_t)slots.size() - 1)]); }
     bool contains(int32_t v) const
     {
         const uint32_t mask = (uint32_t)slots.size() - 1;
@@ -525,6 +526,8 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
                         // scores, OnDiskGraphIndex.java:646-650); the bitmask of newly marked neighbours tells the
                         // push phase which block scores to use.  No unvisited neighbour => no GPU round needed.
                         uint64_t mask = 0;
+                        // the <= maxDegree probes are independent: issue their cache misses together
+                        for (int i = 0; i < deg0 && row[i] >= 0; ++i) st.visited.prefetch(row[i]);
                         for (int i = 0; i < deg0; ++i) {
                             const int32_t nb = row[i];
                             if (nb < 0) break;
@@ -602,6 +605,14 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
                         st.cand.push_back(nq_encode(o[j], sc[j]));
                         std::push_heap(st.cand.begin(), st.cand.end());
                         st.n_visited++;
+                    }
+                }
+                // the next pop is (almost always) the current heap top: start fetching its adjacency row now
+                if (s.lvl == 0 && !st.cand.empty()) {
+                    const int32_t *nr = g->row(0, nq_node(st.cand.front()));
+                    if (nr) {
+                        __builtin_prefetch(nr);
+                        __builtin_prefetch(nr + 16);
                     }
                 }
             }
