@@ -8,9 +8,9 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=/tmp/prof_$TAG; K=$R/gpurun_out/prof_$TAG
 mkdir -p $O $K
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > $K/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > $K/stats.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $C --output-format csv -d $O/$C -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $K/$C.log 2>&1
+  timeout 600 rocprofv3 --pmc $C --output-format csv -d $O/$C -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-flat "$@" > $K/$C.log 2>&1
 done
 cp $O/stats/*kernel_stats.csv $K/ 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -3,9 +3,10 @@
   profiles/<tag>_kernel_stats.csv         rocprofv3 --kernel-trace --stats (all kernels)
   profiles/<tag>_pmc_{fetch,write}.csv    per-dispatch FETCH_SIZE / WRITE_SIZE of the engine's kernels
   profiles/adc_traffic_r1.json            HBM bytes per launch of the dominant kernel (read by bench.py)
-usage: scripts/summarize_profile.py <tag> <dominant-kernel-substring>"""
+usage: scripts/summarize_profile.py <tag> <dominant-kernel-substring> [traffic-json-name]"""
 import csv, json, os, shutil, sys
 tag, dom = sys.argv[1], sys.argv[2]
+traffic_name = sys.argv[3] if len(sys.argv) > 3 else "adc_traffic_r1.json"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -25,7 +26,8 @@ for c, name in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     # the full-N launches are the ones with the largest grid
     g = max(int(r["Grid_Size"]) for r in d)
     vals = [float(r["Counter_Value"]) for r in d if int(r["Grid_Size"]) == g]
-    res[name] = sum(vals[-3:]) / len(vals[-3:]) * 1024
+    vals = vals[len(vals) // 2:] if len(vals) > 6 else vals[-3:]   # steady-state launches
+    res[name] = sum(vals) / len(vals) * 1024
     res[name + "_grid"] = g
 fetch2 = res["fetch"] * 2  # MI355X_MICROARCH.md §HBM: gfx950 FETCH_SIZE counts 128-B requests as 64 B -> x2
 json.dump({"kernel": dom, "tag": tag, "fetch_size_raw_bytes": res["fetch"], "fetch_bytes_corrected_x2": fetch2,
@@ -33,7 +35,7 @@ json.dump({"kernel": dom, "tag": tag, "fetch_size_raw_bytes": res["fetch"], "fet
            "correction": "FETCH_SIZE doubled per MI355X_MICROARCH.md (calibrated in r1 v0: a Q*N*4-byte coalesced read "
                          "reported exactly half); WRITE_SIZE used as is (KiB; calibrated: Q*N*4-byte store reported exactly)",
            "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; profiles/{tag}_pmc_*.csv"},
-          open(os.path.join(dst, "adc_traffic_r1.json"), "w"), indent=1)
-print(open(os.path.join(dst, "adc_traffic_r1.json")).read())
+          open(os.path.join(dst, traffic_name), "w"), indent=1)
+print(open(os.path.join(dst, traffic_name)).read())
 for r in list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))))[:8]:
     print(r["Name"][:80], r["Calls"], r["AverageNs"], r["Percentage"])
