@@ -205,6 +205,7 @@ def main():
         ctx.sync()
         rec = recall_at_k(torch.cat(found)[:n_eval].cpu().numpy(), gt)
         rerank_k = rk
+        print(f"[calibrate] mode={args.mode} rerankK={rk}: recall@{K} = {rec:.4f}", file=sys.stderr)
         if rec >= 0.95:
             break
     torch.cuda.synchronize()

@@ -46,7 +46,7 @@ def _robust_prune(score, pair, keep_n, alpha_max=1.2):
     return kept
 
 
-def _select(x_rows, row_ids, x_pool, pool_ids, x_all, n_cand, n_rand, fwd_degree, max_degree, gen):
+def _select(x_rows, row_ids, x_pool, pool_ids, x_all, n_cand, n_rand, fwd_degree, max_degree, gen, segs=None, per_seg=8):
     """Forward neighbours of `x_rows` (level-local ids `row_ids`): candidates = exact top-`n_cand` of the pool
     (level-local ids `pool_ids`) + `n_rand` uniformly random level nodes (Vamana's random initial edges — they are
     what survives occlusion as long-range links), robust-pruned.  Returns [b, max_degree] level-local ids, -1 padded."""
@@ -56,6 +56,25 @@ def _select(x_rows, row_ids, x_pool, pool_ids, x_all, n_cand, n_rand, fwd_degree
     s = x_rows @ x_pool.t()
     s[pool_ids[None, :] == row_ids[:, None]] = -2.0                       # no self edge
     sc, ci = s.topk(k, dim=1)
+    if segs is not None and len(segs) > 1:
+        # diversified candidates: besides the global top-k (dominated by the node's own dense cluster), the best
+        # `per_seg` nodes of EVERY neighbouring coarse cell — the medium-range edges a search-based builder finds
+        # along its paths, which robust-prune keeps because own-cluster neighbours do not occlude them
+        extra_sc, extra_ci = [], []
+        for lo, hi in segs[1:]:
+            if hi - lo <= 0:
+                continue
+            kk = min(per_seg, hi - lo)
+            e_sc, e_ci = s[:, lo:hi].topk(kk, dim=1)
+            extra_sc.append(e_sc)
+            extra_ci.append(e_ci + lo)
+        if extra_sc:
+            e_sc, e_ci = torch.cat(extra_sc, 1), torch.cat(extra_ci, 1)
+            dup = (e_ci[:, :, None] == ci[:, None, :]).any(2)
+            e_sc = torch.where(dup, torch.full_like(e_sc, float("-inf")), e_sc)
+            sc, ci = torch.cat([sc, e_sc], 1), torch.cat([ci, e_ci], 1)
+            o = torch.argsort(sc, dim=1, descending=True, stable=True)
+            sc, ci = sc.gather(1, o), ci.gather(1, o)
     cid = pool_ids[ci]                                                    # [b, k] level-local ids
     if n_rand > 0:
         rid = torch.randint(0, x_all.shape[0], (b, n_rand), generator=gen, device=dev)
@@ -106,7 +125,7 @@ def _add_reverse_and_pack(nbrs, max_degree):
     return packed
 
 
-def _level_knn(x, max_degree, fwd_degree, n_cand, seed, n_probe=2, row_chunk=4096, n_rand=32):
+def _level_knn(x, max_degree, fwd_degree, n_cand, seed, n_probe=5, row_chunk=4096, n_rand=32):
     """x [n, D] unit vectors of ONE level -> [n, max_degree] local neighbour ids (packed, -1 padded)."""
     dev = x.device
     n = x.shape[0]
@@ -114,9 +133,13 @@ def _level_knn(x, max_degree, fwd_degree, n_cand, seed, n_probe=2, row_chunk=409
     gen = torch.Generator(device=dev).manual_seed(seed + 7919)
     if n <= 40000:
         all_ids = torch.arange(n, device=dev)
-        for r0 in range(0, n, row_chunk):
-            r1 = min(n, r0 + row_chunk)
-            nbrs[r0:r1] = _select(x[r0:r1], all_ids[r0:r1], x, all_ids, x, n_cand, n_rand, fwd_degree, max_degree, gen)
+        # small (upper) levels do the routing between clusters: give robust-prune a WIDE candidate list (up to 512
+        # nearest) so the kept edges cover all directions (MRNG-like; greedy descent with beam 1 then rarely stalls)
+        k_here = min(n - 1, 512 if n <= 12000 else 256)
+        chunk = 512 if n <= 12000 else 1024
+        for r0 in range(0, n, chunk):
+            r1 = min(n, r0 + chunk)
+            nbrs[r0:r1] = _select(x[r0:r1], all_ids[r0:r1], x, all_ids, x, k_here, n_rand, fwd_degree, max_degree, gen)
         return _add_reverse_and_pack(nbrs, max_degree)
     C = max(8, min(8192, n // 2500))
     cent = _kmeans(x, C, seed)
@@ -135,15 +158,21 @@ def _level_knn(x, max_degree, fwd_degree, n_cand, seed, n_probe=2, row_chunk=409
         if hi == lo:
             continue
         own = order[lo:hi]
-        pool = torch.cat([own] + [order[offs_h[p]:offs_h[p + 1]] for p in near[c]])
+        parts = [own] + [order[offs_h[p]:offs_h[p + 1]] for p in near[c]]
+        pool = torch.cat(parts)
+        segs, acc = [], 0
+        for part in parts:
+            segs.append((acc, acc + part.shape[0]))
+            acc += part.shape[0]
         xp = x[pool]
         for r0 in range(0, hi - lo, row_chunk):
             r1 = min(hi - lo, r0 + row_chunk)
-            nbrs[own[r0:r1]] = _select(xp[r0:r1], own[r0:r1], xp, pool, x, n_cand, n_rand, fwd_degree, max_degree, gen)
+            nbrs[own[r0:r1]] = _select(xp[r0:r1], own[r0:r1], xp, pool, x, n_cand, n_rand, fwd_degree, max_degree, gen,
+                                       segs=segs)
     return _add_reverse_and_pack(nbrs, max_degree)
 
 
-def build_hier_graph(base, max_degree=32, upper_degree=32, fanout=32, seed=11, n_cand=64, min_top=16):
+def build_hier_graph(base, max_degree=32, upper_degree=32, fanout=8, seed=11, n_cand=64, min_top=16):
     """Returns (levels, entry_node, entry_level, nbrs0_dev):
     levels[l] = (None | sorted int32 node ids, int32 neighbours [count, degree]) on the HOST (numpy);
     nbrs0_dev = level-0 neighbours on the device (for building the FusedPQ blocks)."""
