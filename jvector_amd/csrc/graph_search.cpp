@@ -242,8 +242,68 @@ struct IntSet {
     }
 };
 
+// 8-ary max-heap of NodeQueue keys for the candidate queue (the reference's GrowableLongHeap is binary; only the
+// pop ORDER is observable and keys are unique, so any correct heap yields the same sequence).  Between two rounds a
+// slot's heap falls out of the core's caches: a binary sift walks ~log2(n) dependent cache misses, an 8-ary heap
+// whose 8 children share one 64-byte line walks ~log8(n).
+struct MaxHeap8 {
+    int64_t *a = nullptr;   // 64-byte aligned; element i lives at a[i + 7] so that children 8i+1..8i+8 share a line
+    int n = 0, cap = 0;
+    ~MaxHeap8() { free(a); }
+    MaxHeap8() = default;
+    MaxHeap8(const MaxHeap8 &) = delete;
+    MaxHeap8 &operator=(const MaxHeap8 &) = delete;
+    MaxHeap8(MaxHeap8 &&o) noexcept : a(o.a), n(o.n), cap(o.cap) { o.a = nullptr; o.n = o.cap = 0; }
+    void clear() { n = 0; }
+    bool empty() const { return n == 0; }
+    int64_t top() const { return a[7]; }
+    const void *root_line() const { return a ? a + 7 : nullptr; }
+    void reserve(int c)
+    {
+        if (c <= cap) return;
+        int nc = cap ? cap : 1024;
+        while (nc < c) nc *= 2;
+        int64_t *na = (int64_t *)aligned_alloc(64, sizeof(int64_t) * ((size_t)nc + 8));
+        if (a) memcpy(na, a, sizeof(int64_t) * ((size_t)n + 7));
+        free(a);
+        a = na;
+        cap = nc;
+    }
+    void push(int64_t v)
+    {
+        reserve(n + 1);
+        int i = n++;
+        while (i > 0) {
+            const int p = (i - 1) >> 3;
+            if (a[p + 7] >= v) break;
+            a[i + 7] = a[p + 7];
+            i = p;
+        }
+        a[i + 7] = v;
+    }
+    void pop()
+    {
+        const int64_t v = a[--n + 7];
+        if (n == 0) return;
+        int i = 0;
+        for (;;) {
+            const int c0 = 8 * i + 1;
+            if (c0 >= n) break;
+            const int c1 = c0 + 8 < n ? c0 + 8 : n;
+            int best = c0;
+            int64_t bv = a[c0 + 7];
+            for (int c = c0 + 1; c < c1; ++c)
+                if (a[c + 7] > bv) { bv = a[c + 7]; best = c; }
+            if (bv <= v) break;
+            a[i + 7] = bv;
+            i = best;
+        }
+        a[i + 7] = v;
+    }
+};
+
 struct QState {
-    std::vector<int64_t> cand;     // max-heap
+    MaxHeap8 cand;                 // max-heap (best candidate on top)
     std::vector<int64_t> res;      // min-heap (top = worst kept)
     std::vector<int64_t> evicted;
     IntSet visited;
@@ -453,7 +513,7 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
         st.evicted.clear();
         st.visited.reset(1024);
         st.visited.add(g->entry_node);
-        st.cand.push_back(nq_encode(g->entry_node, entry_score[qi]));
+        st.cand.push(nq_encode(g->entry_node, entry_score[qi]));
         st.n_visited = st.n_expanded = 0;
         return true;
     };
@@ -475,6 +535,11 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
             for (int si = lo; si < hi; ++si) {
                 Slot &s = G.slots[si];
                 QState &st = s.st;
+                if (si + 1 < hi) {  // the next slot's heap roots have gone cold since the last round
+                    const QState &nx = G.slots[si + 1].st;
+                    __builtin_prefetch(nx.cand.root_line());
+                    if (!nx.res.empty()) __builtin_prefetch(nx.res.data());
+                }
                 st.origin = -1;
                 st.n_pending = 0;
                 slot_query[si] = -1;
@@ -487,14 +552,14 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
                     int64_t top = 0;
                     float top_score = 0.0f;
                     if (!layer_done) {
-                        top = st.cand.front();
+                        top = st.cand.top();
                         top_score = nq_score(top);
                         layer_done = (int)st.res.size() >= rk && top_score < nq_score(st.res.front());  // stopSearch
                     }
                     if (layer_done) {
                         if (s.lvl > 0) {  // setEntryPointsFromPreviousLayer :324-331
-                            for (int64_t k : st.res) { st.cand.push_back(k); std::push_heap(st.cand.begin(), st.cand.end()); }
-                            for (int64_t k : st.evicted) { st.cand.push_back(k); std::push_heap(st.cand.begin(), st.cand.end()); }
+                            for (int64_t k : st.res) st.cand.push(k);
+                            for (int64_t k : st.evicted) st.cand.push(k);
                             st.res.clear();
                             st.evicted.clear();
                             s.lvl--;
@@ -506,8 +571,7 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
                         if (!start_query(s)) break;
                         continue;
                     }
-                    std::pop_heap(st.cand.begin(), st.cand.end());
-                    st.cand.pop_back();
+                    st.cand.pop();
                     const int32_t node = nq_node(top);
                     if ((int)st.res.size() < rk) {  // addTopCandidate :515-530
                         st.res.push_back(top);
@@ -587,6 +651,7 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
             for (int si = lo; si < hi; ++si) {
                 Slot &s = G.slots[si];
                 QState &st = s.st;
+                if (si + 1 < hi) __builtin_prefetch(G.h_sc + (size_t)(si + 1) * W);
                 if (st.origin < 0) continue;
                 const float *sc = G.h_sc + (size_t)si * W;
                 if (ord_index[si] < 0) {  // fused layer 0
@@ -595,21 +660,19 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
                     while (mask) {  // ascending bit order == neighbour order
                         const int i = __builtin_ctzll(mask);
                         mask &= mask - 1;
-                        st.cand.push_back(nq_encode(row[i], sc[i]));
-                        std::push_heap(st.cand.begin(), st.cand.end());
+                        st.cand.push(nq_encode(row[i], sc[i]));
                         st.n_visited++;
                     }
                 } else {
                     const int32_t *o = ords + (size_t)ord_index[si] * W;
                     for (int j = 0; j < st.n_pending; ++j) {
-                        st.cand.push_back(nq_encode(o[j], sc[j]));
-                        std::push_heap(st.cand.begin(), st.cand.end());
+                        st.cand.push(nq_encode(o[j], sc[j]));
                         st.n_visited++;
                     }
                 }
                 // the next pop is (almost always) the current heap top: start fetching its adjacency row now
                 if (s.lvl == 0 && !st.cand.empty()) {
-                    const int32_t *nr = g->row(0, nq_node(st.cand.front()));
+                    const int32_t *nr = g->row(0, nq_node(st.cand.top()));
                     if (nr) {
                         __builtin_prefetch(nr);
                         __builtin_prefetch(nr + 16);
