@@ -261,8 +261,9 @@ def main():
         exp_per_step = float(graph_stats[:, 1].sum())
         launches_per_step = max(adc_n / args.steps, 1.0)
         bytes_per_launch = exp_per_step / launches_per_step * (args.degree * M + 4 * args.degree)
-        kernel = "frontier_kernel<COSINE,CH16=6,two slots per wave> (FusedPQ neighbour-block scoring, LUT gathered from " \
-                 "L2/HBM; one launch per traversal round of a slot group)"
+        kernel = "frontier_direct_kernel<COSINE,CH16=6,two slots per wave> (table-free FusedPQ neighbour-block scoring: " \
+                 "the needed ADC entries are recomputed from the L2-resident codebook; one launch per traversal round of " \
+                 "a slot group)"
         note = ("graph mode is bound by the HOST traversal (16-CPU cgroup quota on the GPU box), not by this kernel: each "
                 "launch scores only ~2k expansions x maxDegree candidates and overlaps the other slot group's host phase; "
                 "see kernel_ms_per_step vs ms_per_step and DESIGN.md §5")

@@ -635,7 +635,7 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
         {
             ProfScope ps(ctx, R_ADC);
             JV_TRY(launch_frontier(ctx->stream, kvsf, l->d_luts, l->d_bmag, G.d_ctrl, G.d_ctrl + SG, G.d_ctrl + 2 * SG,
-                                   G.d_ctrl + 3 * SG, fused, codes, G.d_sc, SGn, W));
+                                   G.d_ctrl + 3 * SG, fused, codes, G.d_sc, SGn, W, l->pq, l->d_queries));
         }
         JV_HIP_CHECK(hipMemcpyAsync(G.h_sc, G.d_sc, sizeof(float) * (size_t)SGn * W, hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipEventRecord(G.ev, ctx->stream));

@@ -214,7 +214,8 @@ int launch_exact_scan(hipStream_t s, const jv_ctx *ctx, const float *d_vecs, int
 
 int launch_frontier(hipStream_t s, int vsf, const float *d_luts, const float *d_bmag, const int32_t *d_slot_query,
                     const int32_t *d_origins, const int32_t *d_ord_index, const int32_t *d_ords, const jv_fused *fused,
-                    const jv_codes *codes, float *d_out, int S, int W);
+                    const jv_codes *codes, float *d_out, int S, int W, const jv_pq *pq = nullptr,
+                    const float *d_cq = nullptr);
 size_t topk_scratch_bytes(int Q, int k);
 int launch_topk(hipStream_t s, const jv_ctx *ctx, const float *d_scores, const int32_t *d_ids, int Q, int64_t n,
                 int64_t stride, int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, void *d_scratch,
