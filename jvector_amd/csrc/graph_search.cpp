@@ -499,6 +499,10 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
     std::atomic<int> next_q{0};
     const int deg0 = g->levels[0].degree;
 
+    // visited-set capacity hint: a search marks roughly maxDegree/2 x rerankK nodes; starting at 1024 cost three
+    // rehashes per query (~10 % of the host time at rerankK 150).  Growth stays automatic beyond the hint.
+    int visited_cap = 1024;
+    while (visited_cap < 32 * rerankK && visited_cap < (1 << 16)) visited_cap <<= 1;
     auto start_query = [&](Slot &s) -> bool {
         const int qi = next_q.fetch_add(1);
         if (qi >= Q) {
@@ -511,7 +515,7 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
         st.cand.clear();
         st.res.clear();
         st.evicted.clear();
-        st.visited.reset(1024);
+        st.visited.reset(visited_cap);
         st.visited.add(g->entry_node);
         st.cand.push(nq_encode(g->entry_node, entry_score[qi]));
         st.n_visited = st.n_expanded = 0;
