@@ -93,138 +93,6 @@ def ground_truth(J, ctx, vs, queries, vsf, k, chunk=1_000_000):
 
 
 
-# ------------------------------------------------------------------------------------------------------
-# Synthetic graph index (INPUT PREPARATION — not the reference's GraphIndexBuilder, which is host-side and out of
-# scope; SURVEY §8f ranks GPU-assisted construction as a later row).  Produces a Vamana-shaped structure the
-# searcher can traverse: layer 0 = every node with <= max_degree diverse neighbours, layer 1 = one medoid per
-# coarse cluster, entry = the medoid nearest the global mean.
-#   1. coarse k-means (C ~ N/2500 clusters, torch matmul)
-#   2. per cluster: exact similarities against the pool {own cluster + `n_probe` nearest clusters}, top-`n_cand`
-#   3. robust prune (VamanaDiversityProvider.retainDiverse's rule, B/graph/diversity/VamanaDiversityProvider.java:
-#      45-96: keep i iff for every kept j: sim(i,j) <= score(i) * alpha, alpha ramp 1.0 -> 1.2), scores in the
-#      similarity domain (1 + cos) / 2
-#   4. reverse edges fill the remaining slots (a light-weight stand-in for backlink + prune)
-# ------------------------------------------------------------------------------------------------------
-def _kmeans(x, C, seed, iters=8, sample_per=128):
-    g = torch.Generator(device=x.device).manual_seed(seed)
-    n = x.shape[0]
-    idx = torch.randperm(n, generator=g, device=x.device)[: min(n, C * sample_per)]
-    xs = x[idx]
-    cent = xs[torch.randperm(xs.shape[0], generator=g, device=x.device)[:C]].clone()
-    for _ in range(iters):
-        a = torch.cat([(xs[s:s + 262144] @ cent.t()).argmax(1) for s in range(0, xs.shape[0], 262144)])
-        sums = torch.zeros_like(cent).index_add_(0, a, xs)
-        cnt = torch.zeros(C, device=x.device).index_add_(0, a, torch.ones_like(a, dtype=torch.float32))
-        cent = torch.where(cnt[:, None] > 0, sums / cnt.clamp(min=1)[:, None], cent)
-        cent = cent / cent.norm(dim=1, keepdim=True).clamp(min=1e-12)
-    return cent
-
-
-def _robust_prune(score, pair, keep_n, alpha_max=1.2):
-    """score [B, K] candidate similarities to the node (descending); pair [B, K, K] candidate-candidate
-    similarities.  Returns a bool mask [B, K] of kept candidates (<= keep_n per row)."""
-    B, K = score.shape
-    kept = torch.zeros(B, K, dtype=torch.bool, device=score.device)
-    n_kept = torch.zeros(B, dtype=torch.long, device=score.device)
-    for alpha in (1.0, alpha_max):
-        for i in range(K):
-            # candidate i is occluded if some kept j has pair[i, j] > score[i] * alpha
-            occl = ((pair[:, i, :] > (score[:, i] * alpha)[:, None]) & kept).any(1)
-            take = (~occl) & (~kept[:, i]) & (n_kept < keep_n) & torch.isfinite(score[:, i])
-            kept[:, i] |= take
-            n_kept += take.long()
-    return kept
-
-
-def build_graph(base, max_degree=32, seed=11, n_cand=64, n_probe=2, fwd_degree=24, top_degree=16):
-    dev = base.device
-    N, D = base.shape
-    C = max(8, min(8192, N // 2500))
-    cent = _kmeans(base, C, seed)
-    assign = torch.empty(N, dtype=torch.long, device=dev)
-    for s in range(0, N, 1_000_000):
-        assign[s:s + 1_000_000] = (base[s:s + 1_000_000] @ cent.t()).argmax(1)
-    order = torch.argsort(assign, stable=True)
-    counts = torch.bincount(assign, minlength=C)
-    offs = torch.zeros(C + 1, dtype=torch.long, device=dev)
-    offs[1:] = torch.cumsum(counts, 0)
-    offs_h = offs.cpu().tolist()
-    csim = cent @ cent.t()
-    csim.fill_diagonal_(-2.0)
-    near = csim.topk(min(n_probe, C - 1), dim=1).indices.cpu().tolist()
-
-    nbrs = torch.full((N, max_degree), -1, dtype=torch.int32, device=dev)
-    medoids = torch.empty(C, dtype=torch.long, device=dev)
-    for c in range(C):
-        lo, hi = offs_h[c], offs_h[c + 1]
-        if hi == lo:
-            medoids[c] = -1
-            continue
-        own = order[lo:hi]
-        pool = torch.cat([own] + [order[offs_h[p]:offs_h[p + 1]] for p in near[c]])
-        xp = base[pool]
-        n_c, n_p = own.shape[0], pool.shape[0]
-        medoids[c] = own[(xp[:n_c] @ cent[c]).argmax()]
-        k = min(n_cand, n_p - 1)
-        for r0 in range(0, n_c, 4096):
-            r1 = min(n_c, r0 + 4096)
-            s = xp[r0:r1] @ xp.t()                                   # [b, n_p] cosine (unit vectors)
-            s[torch.arange(r1 - r0, device=dev), torch.arange(r0, r1, device=dev)] = -2.0   # no self edge
-            sc, ci = s.topk(k, dim=1)                                # descending
-            cv = xp[ci]                                              # [b, k, D]
-            pair = torch.bmm(cv, cv.transpose(1, 2))                 # [b, k, k]
-            kept = _robust_prune((1 + sc) / 2, (1 + pair) / 2, fwd_degree)
-            # compact kept candidates to the front, in score order
-            rank = torch.cumsum(kept.long(), 1) - 1
-            sel = torch.full((r1 - r0, max_degree), -1, dtype=torch.int32, device=dev)
-            rows = torch.arange(r1 - r0, device=dev)[:, None].expand_as(ci)
-            sel[rows[kept], rank[kept]] = pool[ci[kept]].int()
-            nbrs[own[r0:r1]] = sel
-    # reverse edges into the free slots (closest-first is not tracked; deterministic by source id order)
-    deg = (nbrs >= 0).sum(1)
-    src = torch.arange(N, device=dev)[:, None].expand(N, max_degree)[nbrs >= 0]
-    dst = nbrs[nbrs >= 0].long()
-    o = torch.argsort(dst, stable=True)
-    src, dst = src[o], dst[o]
-    first = torch.searchsorted(dst, torch.arange(N, device=dev))
-    pos_in_dst = torch.arange(dst.shape[0], device=dev) - first[dst]
-    slot = deg[dst] + pos_in_dst
-    ok = slot < max_degree
-    # drop reverse edges that already exist as forward edges
-    exists = (nbrs[dst[ok]] == src[ok].int()[:, None]).any(1)
-    d2, s2, sl2 = dst[ok][~exists], src[ok][~exists], slot[ok][~exists]
-    nbrs[d2, sl2] = s2.int()
-    # re-pack rows (holes left by dropped duplicates)
-    valid = nbrs >= 0
-    rank = torch.cumsum(valid.long(), 1) - 1
-    packed = torch.full_like(nbrs, -1)
-    rows = torch.arange(N, device=dev)[:, None].expand_as(nbrs)
-    packed[rows[valid], rank[valid]] = nbrs[valid]
-
-    # layer 1: the medoids, kNN + prune among themselves
-    med = torch.sort(medoids[medoids >= 0]).values
-    xm = base[med]
-    sm = xm @ xm.t()
-    sm.fill_diagonal_(-2.0)
-    k1 = min(4 * top_degree, med.shape[0] - 1)
-    sc, ci = sm.topk(k1, dim=1)
-    pair = torch.stack([sm[ci[i]][:, ci[i]] for i in range(med.shape[0])]) if med.shape[0] <= 512 else None
-    if pair is None:
-        pair = torch.empty(med.shape[0], k1, k1, device=dev)
-        for s in range(0, med.shape[0], 256):
-            cvm = xm[ci[s:s + 256]]
-            pair[s:s + 256] = torch.bmm(cvm, cvm.transpose(1, 2))
-    kept = _robust_prune((1 + sc) / 2, (1 + pair) / 2, top_degree)
-    rank = torch.cumsum(kept.long(), 1) - 1
-    top_nbrs = torch.full((med.shape[0], top_degree), -1, dtype=torch.int32, device=dev)
-    rows = torch.arange(med.shape[0], device=dev)[:, None].expand_as(ci)
-    top_nbrs[rows[kept], rank[kept]] = med[ci[kept]].int()
-    mean = base[torch.randperm(N, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))[:100000]].mean(0)
-    entry = int(med[(xm @ mean).argmax()])
-    levels = [(None, packed.cpu().numpy()), (med.int().cpu().numpy(), top_nbrs.cpu().numpy())]
-    return levels, entry, 1, packed
-
-
 def fused_blocks_from(codes, nbrs):
     """FusedPQ.writeInline layout on the device: neighbour i's code at bytes [i*M, (i+1)*M), zero padded."""
     N, deg = nbrs.shape

@@ -74,6 +74,11 @@ public final class HipOps {
         static final MethodHandle fusedScores = h("jv_hip_fused_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle exactScores = h("jv_hip_exact_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
         static final MethodHandle topk = h("jv_hip_topk", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_LONG, JAVA_LONG, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle graphCreate = h("jv_hip_graph_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, JAVA_INT, ADDRESS));
+        static final MethodHandle graphSetLevel = h("jv_hip_graph_set_level", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, JAVA_INT));
+        static final MethodHandle graphSetEntry = h("jv_hip_graph_set_entry", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT));
+        static final MethodHandle graphDestroy = h("jv_hip_graph_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle graphSearch = h("jv_hip_graph_search", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle searchFlat = h("jv_hip_search_flat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
     }
 
@@ -156,6 +161,14 @@ public final class HipOps {
 
     public static void fusedScores(MemorySegment ctx, MemorySegment luts, MemorySegment fused, MemorySegment origins, MemorySegment out, MemorySegment neighborsOut) {
         try { check((int) H.fusedScores.invokeExact(ctx, luts, fused, origins, out, neighborsOut)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    /** GraphSearcher.search for a whole batch (host traversal inside the library, GPU frontier scoring). */
+    public static void graphSearch(MemorySegment ctx, MemorySegment graph, MemorySegment luts, MemorySegment codes, MemorySegment fusedOrNull,
+                                   MemorySegment vectorsOrNull, MemorySegment queries, int q, int vsf, int topK, int rerankK,
+                                   MemorySegment outIds, MemorySegment outScores, MemorySegment statsOrNull) {
+        try { check((int) H.graphSearch.invokeExact(ctx, graph, luts, codes, fusedOrNull, vectorsOrNull, queries, q, vsf, topK, rerankK, outIds, outScores, statsOrNull)); }
         catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
     }
 

@@ -45,12 +45,6 @@ struct AdcParams {
     int maxDegree;          // fused
 };
 
-template <bool LDS>
-__device__ __forceinline__ float lut_at(const float *lut, int idx)
-{
-    return lut[idx];
-}
-
 // row: pointer to the candidate's code bytes at m_begin.  Accumulates table[(m)*256 + code[m]] for the
 // pass's subspaces, in ascending m.
 template <int CH16>
