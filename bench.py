@@ -208,6 +208,10 @@ def main():
         print(f"[calibrate] mode={args.mode} rerankK={rk}: recall@{K} = {rec:.4f}", file=sys.stderr)
         if rec >= 0.95:
             break
+    if world > 1:  # every rank serves with the same (largest calibrated) rerankK
+        t_rk = torch.tensor([rerank_k], dtype=torch.int64, device=dev)
+        torch.distributed.all_reduce(t_rk, op=torch.distributed.ReduceOp.MAX)
+        rerank_k = int(t_rk.item())
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
 
