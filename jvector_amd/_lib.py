@@ -114,6 +114,38 @@ COMPAT_SIGNATURES = {
     "jvector_simd_get_max_isa_env": (C.c_char_p, []),
 }
 
+# host-side format readers (include/jvector_formats.h)
+JV_ODGI_MAX_LAYERS = 32
+JV_ODGI_MAX_FEATURES = 8
+
+
+class OdgiInfo(C.Structure):
+    """struct jv_odgi_info (include/jvector_formats.h)."""
+    _fields_ = [
+        ("version", C.c_int32), ("dimension", C.c_int32), ("entry_node", C.c_int32), ("entry_level", C.c_int32),
+        ("id_upper_bound", C.c_int32), ("n_layers", C.c_int32),
+        ("layer_size", C.c_int32 * JV_ODGI_MAX_LAYERS), ("layer_degree", C.c_int32 * JV_ODGI_MAX_LAYERS),
+        ("n_features", C.c_int32), ("feature_id", C.c_int32 * JV_ODGI_MAX_FEATURES),
+        ("header_off", C.c_int64), ("l0_off", C.c_int64), ("record_stride", C.c_int64),
+        ("inline_vectors_off", C.c_int64), ("fused_off", C.c_int64), ("neighbors_off", C.c_int64),
+        ("pq_off", C.c_int64), ("pq_len", C.c_int64), ("pq_M", C.c_int32),
+        ("upper_off", C.c_int64), ("hierarchy_off", C.c_int64), ("hierarchy_count", C.c_int32),
+        ("separated_vectors_off", C.c_int64),
+    ]
+
+
+_ip = C.POINTER(_i)
+FORMAT_SIGNATURES = {
+    "jv_fmt_pq_describe": (_i, [_p, _sz, C.POINTER(_sz), _ip, _ip, _ip, _ip, _ip, C.POINTER(C.c_float)]),
+    "jv_fmt_pqvectors_describe": (_i, [_p, _sz, C.POINTER(_sz), C.POINTER(_i64), _ip, C.POINTER(_sz)]),
+    "jv_fmt_odgi_describe": (_i, [_p, _sz, C.POINTER(OdgiInfo)]),
+    "jv_fmt_odgi_read_l0": (_i, [_p, _sz, C.POINTER(OdgiInfo), _p, _p, _p]),
+    "jv_fmt_odgi_read_level": (_i, [_p, _sz, C.POINTER(OdgiInfo), _i, _p, _p]),
+    "jv_fmt_odgi_read_hierarchy_codes": (_i, [_p, _sz, C.POINTER(OdgiInfo), _p, _p]),
+    "jv_fmt_xvecs_describe": (_i, [_p, _sz, C.POINTER(_i64), _ip]),
+    "jv_fmt_xvecs_read": (_i, [_p, _sz, _p]),
+}
+
 _lib = None
 
 
@@ -134,7 +166,7 @@ def load():
             except ImportError:
                 pass
         lib = C.CDLL(LIB_PATH)
-        for table in (SIGNATURES, COMPAT_SIGNATURES):
+        for table in (SIGNATURES, COMPAT_SIGNATURES, FORMAT_SIGNATURES):
             for name, (res, args) in table.items():
                 fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
                 fn.restype = res

@@ -1,0 +1,206 @@
+"""Ingest what a real JVector writes: ProductQuantization / PQVectors blobs, OnDiskGraphIndex files, fvecs/ivecs.
+
+Thin ctypes mirror of include/jvector_formats.h.  The parsing is host code inside libjvector_hip.so (no device needed:
+`describe_*` / `read_*` work on a machine without a GPU); the `load_*` functions then hand the unpacked sections to
+the device objects of engine.py.  Reference: PQVectors.load (B/quantization/PQVectors.java:54-75),
+OnDiskGraphIndex.load (B/graph/disk/OnDiskGraphIndex.java:235-316), SiftLoader (EX/util/SiftLoader.java:37-83).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ._lib import OdgiInfo, check, load
+
+FEATURE_NAMES = ("INLINE_VECTORS", "FUSED_PQ", "NVQ_VECTORS", "SEPARATED_VECTORS", "SEPARATED_NVQ")
+
+
+def _buf(data):
+    """bytes / bytearray / memoryview / np.uint8 array (e.g. np.memmap) -> (uint8 view, void*, length); no copy."""
+    a = data if isinstance(data, np.ndarray) else np.frombuffer(data, dtype=np.uint8)
+    if a.dtype != np.uint8 or a.ndim != 1 or not a.flags.c_contiguous:
+        raise ValueError("expected a contiguous byte buffer")
+    return a, C.c_void_p(a.ctypes.data if a.size else None), a.size
+
+
+# ---- fvecs / ivecs ---------------------------------------------------------------------------------------------
+def _read_xvecs(data, dtype):
+    lib = load()
+    a, p, n = _buf(data)
+    rows, dim = C.c_int64(), C.c_int()
+    check(lib.jv_fmt_xvecs_describe(p, n, C.byref(rows), C.byref(dim)))
+    out = np.empty((rows.value, dim.value), dtype=dtype)
+    check(lib.jv_fmt_xvecs_read(p, n, C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def read_fvecs(data) -> np.ndarray:
+    """SiftLoader.readFvecs (:37-58): rows x dim float32."""
+    return _read_xvecs(data, np.float32)
+
+
+def read_ivecs(data) -> np.ndarray:
+    """SiftLoader.readIvecs (:60-83): rows x dim int32 (ground-truth neighbour lists)."""
+    return _read_xvecs(data, np.int32)
+
+
+# ---- ProductQuantization / PQVectors ---------------------------------------------------------------------------
+@dataclass
+class PQDescription:
+    block_len: int
+    version: int
+    dimension: int
+    subspaces: int
+    clusters: int
+    has_centroid: bool
+    anisotropic_threshold: float
+
+
+def describe_pq(data) -> PQDescription:
+    lib = load()
+    a, p, n = _buf(data)
+    bl, ver, D, M, k, hc, an = C.c_size_t(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_float()
+    check(lib.jv_fmt_pq_describe(p, n, C.byref(bl), C.byref(ver), C.byref(D), C.byref(M), C.byref(k), C.byref(hc),
+                                 C.byref(an)))
+    return PQDescription(bl.value, ver.value, D.value, M.value, k.value, bool(hc.value), an.value)
+
+
+def describe_pqvectors(data):
+    """-> (pq_block_len, count, M, codes_off) of a PQVectors.write blob."""
+    lib = load()
+    a, p, n = _buf(data)
+    bl, cnt, M, off = C.c_size_t(), C.c_int64(), C.c_int(), C.c_size_t()
+    check(lib.jv_fmt_pqvectors_describe(p, n, C.byref(bl), C.byref(cnt), C.byref(M), C.byref(off)))
+    return bl.value, cnt.value, M.value, off.value
+
+
+def pqvectors_codes(data) -> np.ndarray:
+    """The count x M code table of a PQVectors blob as a zero-copy uint8 view."""
+    a, _, _ = _buf(data)
+    _, cnt, M, off = describe_pqvectors(a)
+    return a[off:off + cnt * M].reshape(cnt, M)
+
+
+def load_pqvectors(ctx, data):
+    """PQVectors.load: -> (ProductQuantization, PQVectors) resident on ctx's device."""
+    from .engine import PQVectors, ProductQuantization
+    a, _, _ = _buf(data)
+    bl, cnt, M, off = describe_pqvectors(a)
+    pq = ProductQuantization.load(ctx, a[:bl].tobytes())
+    return pq, PQVectors(ctx, pq, np.ascontiguousarray(a[off:off + cnt * M].reshape(cnt, M)))
+
+
+# ---- OnDiskGraphIndex ------------------------------------------------------------------------------------------
+@dataclass
+class OnDiskGraph:
+    """Host-side unpacking of one OnDiskGraphIndex file (numpy arrays in host byte order)."""
+    version: int
+    dimension: int
+    entry_node: int
+    entry_level: int
+    id_upper_bound: int
+    features: tuple
+    levels: list                      # [(None, nbrs[N, deg0])] + [(ids[size_l], nbrs[size_l, deg_l]) ...]
+    vectors: np.ndarray | None        # N x D float32 (inline or separated), None if the index stores none
+    fused_blocks: np.ndarray | None   # N x deg0 x M uint8
+    pq_bytes: bytes | None            # FusedPQ's ProductQuantization block
+    hierarchy_nodes: np.ndarray | None = None
+    hierarchy_codes: np.ndarray | None = None
+    info: OdgiInfo = field(default=None, repr=False)
+
+    def codes_from_fused(self) -> np.ndarray:
+        """Rebuild the N x M code table from the fused blocks (+ hierarchy source codes): a node's code sits in the
+        block of every node that lists it as a neighbour.  Nodes nobody points at (unreachable from any other node)
+        and that are not hierarchy nodes keep an all-zero code.  For upper-level scoring without a PQVectors file
+        (the reference scores the hierarchy from the same cached codes, FusedPQDecoder.java:85-111)."""
+        if self.fused_blocks is None:
+            raise ValueError("the index has no FUSED_PQ feature")
+        nbrs = self.levels[0][1]
+        N, deg = nbrs.shape
+        M = self.fused_blocks.shape[2]
+        codes = np.zeros((N, M), dtype=np.uint8)
+        valid = nbrs >= 0
+        codes[nbrs[valid]] = self.fused_blocks[valid]
+        if self.hierarchy_nodes is not None and len(self.hierarchy_nodes):
+            codes[self.hierarchy_nodes] = self.hierarchy_codes
+        return codes
+
+
+def describe_odgi(data) -> OdgiInfo:
+    lib = load()
+    a, p, n = _buf(data)
+    info = OdgiInfo()
+    check(lib.jv_fmt_odgi_describe(p, n, C.byref(info)))
+    return info
+
+
+def read_odgi(data, want_vectors=True) -> OnDiskGraph:
+    """Unpack every section the engine consumes.  Host only (no GPU needed)."""
+    lib = load()
+    a, p, n = _buf(data)
+    info = describe_odgi(a)
+    N, D, deg0, M = info.id_upper_bound, info.dimension, info.layer_degree[0], info.pq_M
+    nbrs = np.empty((N, deg0), dtype=np.int32)
+    has_vec = info.inline_vectors_off >= 0 or info.separated_vectors_off >= 0
+    vectors = np.empty((N, D), dtype=np.float32) if (has_vec and want_vectors) else None
+    fused = np.empty((N, deg0, M), dtype=np.uint8) if info.fused_off >= 0 else None
+    check(lib.jv_fmt_odgi_read_l0(p, n, C.byref(info), C.c_void_p(nbrs.ctypes.data),
+                                  C.c_void_p(vectors.ctypes.data) if vectors is not None else None,
+                                  C.c_void_p(fused.ctypes.data) if fused is not None else None))
+    levels = [(None, nbrs)]
+    for lvl in range(1, info.n_layers):
+        ids = np.empty(info.layer_size[lvl], dtype=np.int32)
+        nb = np.empty((info.layer_size[lvl], info.layer_degree[lvl]), dtype=np.int32)
+        check(lib.jv_fmt_odgi_read_level(p, n, C.byref(info), lvl, C.c_void_p(ids.ctypes.data), C.c_void_p(nb.ctypes.data)))
+        levels.append((ids, nb))
+    h_nodes = h_codes = None
+    if info.hierarchy_off >= 0:
+        h_nodes = np.empty(info.hierarchy_count, dtype=np.int32)
+        h_codes = np.empty((info.hierarchy_count, M), dtype=np.uint8)
+        check(lib.jv_fmt_odgi_read_hierarchy_codes(p, n, C.byref(info), C.c_void_p(h_nodes.ctypes.data),
+                                                   C.c_void_p(h_codes.ctypes.data)))
+    pq_bytes = a[info.pq_off:info.pq_off + info.pq_len].tobytes() if info.pq_off >= 0 else None
+    feats = tuple(FEATURE_NAMES[info.feature_id[i]] for i in range(info.n_features))
+    return OnDiskGraph(info.version, D, info.entry_node, info.entry_level, N, feats, levels, vectors, fused, pq_bytes,
+                       h_nodes, h_codes, info)
+
+
+@dataclass
+class LoadedIndex:
+    """Device objects built from one OnDiskGraphIndex file (+ optionally a PQVectors file)."""
+    graph: object
+    pq: object
+    pq_vectors: object
+    fused: object
+    vectors: object
+    host: OnDiskGraph
+
+    def searcher(self, max_queries=4096):
+        from .engine import GraphSearcher
+        return GraphSearcher(self.graph.ctx, self.graph, self.pq, self.pq_vectors, fused=self.fused, vectors=self.vectors,
+                             max_queries=max_queries)
+
+
+def load_index(ctx, odgi_data, pqvectors_data=None) -> LoadedIndex:
+    """OnDiskGraphIndex.load (+ PQVectors.load) -> GraphIndex / FusedPQ / VectorSet / PQVectors on ctx's device.
+    Without a PQVectors blob the code table is rebuilt from the fused blocks (OnDiskGraph.codes_from_fused)."""
+    from .engine import FusedPQ, GraphIndex, PQVectors, ProductQuantization, VectorSet
+    g = read_odgi(odgi_data)
+    if g.entry_node < 0:
+        raise ValueError("the index is empty (ENTRY_NODE_ABSENT)")
+    pq = cv = None
+    if pqvectors_data is not None:
+        pq, cv = load_pqvectors(ctx, pqvectors_data)
+        if cv.count() != g.id_upper_bound:
+            raise ValueError(f"PQVectors holds {cv.count()} codes, the index {g.id_upper_bound} nodes")
+    elif g.pq_bytes is not None:
+        pq = ProductQuantization.load(ctx, g.pq_bytes)
+        cv = PQVectors(ctx, pq, g.codes_from_fused())
+    else:
+        raise ValueError("no PQ codes: the index has no FUSED_PQ feature and no PQVectors blob was given")
+    fused = FusedPQ(ctx, pq, g.fused_blocks.reshape(g.id_upper_bound, -1), g.levels[0][1]) if g.fused_blocks is not None else None
+    vectors = VectorSet(ctx, g.vectors) if g.vectors is not None else None
+    graph = GraphIndex(ctx, g.id_upper_bound, g.levels, g.entry_node, g.entry_level)
+    return LoadedIndex(graph, pq, cv, fused, vectors, g)

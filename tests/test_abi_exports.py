@@ -25,8 +25,9 @@ def lib():
 
 
 def test_every_declared_symbol_is_exported(lib):
-    names = declared_symbols("jvector_hip.h", "JV_API") + declared_symbols("jvector_simd_compat.h", "JVC_API")
-    assert len(names) >= 60
+    names = (declared_symbols("jvector_hip.h", "JV_API") + declared_symbols("jvector_simd_compat.h", "JVC_API")
+             + declared_symbols("jvector_formats.h", "JV_API"))
+    assert len(names) >= 68
     raw = ctypes.CDLL(os.path.join(ROOT, "jvector_amd", "libjvector_hip.so"))
     missing = [n for n in names if not hasattr(raw, n)]
     assert not missing, missing
@@ -38,6 +39,8 @@ def test_python_signature_table_matches_header():
     assert hdr == set(L.SIGNATURES), hdr ^ set(L.SIGNATURES)
     compat = set(declared_symbols("jvector_simd_compat.h", "JVC_API"))
     assert compat == set(L.COMPAT_SIGNATURES), compat ^ set(L.COMPAT_SIGNATURES)
+    fmt = set(declared_symbols("jvector_formats.h", "JV_API"))
+    assert fmt == set(L.FORMAT_SIGNATURES) and len(fmt) == 8, fmt ^ set(L.FORMAT_SIGNATURES)
     # the reference's own kernel list: 22 kernels + 2 getters (jvector_simd_kernel_list.h:36-62, jvector_simd.h:47,53)
     assert len(compat) == 24
 
@@ -49,6 +52,23 @@ def test_no_gpu_means_loud_failure(lib):
     with pytest.raises(J.NoDeviceError):
         J.HipContext(0)
     assert "no CPU fallback" in lib.jv_hip_last_error().decode()
+
+
+def test_odgi_info_struct_matches_the_header():
+    """ctypes mirror of struct jv_odgi_info: same field names in the same order as include/jvector_formats.h."""
+    import jvector_amd._lib as L
+    text = open(os.path.join(ROOT, "include", "jvector_formats.h")).read()
+    body = re.search(r"typedef struct jv_odgi_info \{(.*?)\} jv_odgi_info;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        m = re.match(r"\s*(int32_t|int64_t)\s+(.*)", decl.strip(), flags=re.S)
+        if m:
+            for name in m.group(2).split(","):
+                fields.append((re.sub(r"\[.*", "", name.strip()), m.group(1)))
+    got = [(n, "int64_t" if (t is ctypes.c_int64) else "int32_t") for n, t in
+           [(n, t._type_ if issubclass(t, ctypes.Array) else t) for n, t in L.OdgiInfo._fields_]]
+    assert fields == got
 
 
 def test_product_never_imports_oracle():
