@@ -1,0 +1,501 @@
+// gs_body.h — device-resident graph traversal: one 64-lane wavefront runs one query's whole GraphSearcher loop.
+//
+// This is the body of graph_search_kernel (k_gsearch.hip).  It is written against a tiny wave API so that the very
+// same source also compiles as plain C++ for the lane-level emulator the CPU tests use (tests/emu/): the includer
+// defines
+//     GS_FN                                   function qualifier (__device__ __forceinline__ / inline)
+//     gs_lane()                               0..63
+//     gs_barrier()                            block barrier (the block IS one wavefront)
+//     gs_ballot(bool) -> uint64_t             wave vote
+//     gs_shfl(long long v, int src)           read lane src's v
+//     gs_shfl_xor(long long v, int laneMask)  butterfly exchange
+//     gs_cas(int32_t *p, int32_t expect, int32_t desired) -> old      (device-scope atomic)
+//     gs_fetch_add(uint32_t *p, uint32_t v) -> old                    (device-scope atomic)
+//     gs_fence()                              device-scope memory fence
+//     gs_sqrt(double)
+//
+// What it computes is GraphSearcher.search for threshold 0 / acceptOrds ALL (B/graph/GraphSearcher.java:222-243,
+// 263-282 internalSearch, 334-353 initializeInternal, 355-369 stopSearch, 406-457 searchOneLayer, 324-331
+// setEntryPointsFromPreviousLayer, 515-530 addTopCandidate) with the approximate score function of PQDecoder /
+// FusedPQDecoder (B/quantization/PQDecoder.java:65-80,124-135, FusedPQDecoder.java:104-111,206-213): the same
+// per-query state machine the host searcher (graph_search.cpp) runs, so results, visitedCount and expandedCount
+// are identical.  The three queues only ever need "max / min under the NodeQueue key order" and set membership, and
+// NodeQueue keys (sortableInt(score) << 32 | ~node, NodeQueue.java:125-129) are unique per query, so they are
+// kept as UNSORTED arrays that the wave scans in parallel instead of heaps a single lane would have to sift:
+//   candidates  (NodeQueue MAX_HEAP, unbounded)   LDS tier of cand_cap keys + a global spill tier.  Invariant:
+//               every LDS key > spill_max >= every spilled key, so the LDS maximum is the global maximum.  When
+//               the LDS tier would overflow, keys <= the median of 64 samples move to the spill tier.  A search
+//               stops long before it has to pop from the spill tier; that path exists but is a plain scan.
+//   results     (BoundedLongHeap(rerankK), MIN_HEAP)  LDS array + cached minimum; replace-min = rescan.
+//   evicted     (upper layers, rk = 1)               LDS array.
+//   visited     open-addressing hash table of node ids in global memory (one per worker, cleared per query);
+//               the <= 64 neighbours of an expansion are inserted by their lanes concurrently with CAS.
+// Scores: table-free ADC (k_frontier.hip's direct variant): lane i recomputes the look-up entries its neighbour's
+// code selects from the L2-resident codebook, summing in ascending m into one f32 — bit-identical to
+// assembleAndSum / pqDecodedCosineSimilarity on the decoder's tables (uniform 8-dim sub-vectors only).
+// Anything that does not fit the fixed-size structures (hash table half full, spill tier or evicted list full)
+// marks the query GS_OVERFLOW; the host re-runs such queries through the host searcher.
+#pragma once
+
+#include <cstdint>
+
+namespace jv {
+
+constexpr int GS_MAX_LEVELS = 32;
+constexpr int GS_EVICT_CAP = 128;
+enum : int32_t { GS_OK = 0, GS_OVERFLOW = 1 };
+
+struct GsLevel {
+    const int32_t *nbrs;    // count x degree, packed rows padded with -1
+    const int32_t *hkeys;   // upper levels: open-addressing map node id -> row (keys, -1 = empty); level 0: nullptr
+    const int32_t *hvals;
+    uint32_t hmask;         // table size - 1
+    int32_t hshift;         // 32 - log2(table size)
+    int32_t count, degree;
+};
+
+struct GsParams {
+    GsLevel lv[GS_MAX_LEVELS];
+    int32_t entry_node, entry_level;
+    // scoring
+    const float *codebooks;   // [M][256][8]
+    const float *cq;          // [Q][D] centred queries
+    const float *bmag;        // [Q] query magnitude (cosine)
+    const uint8_t *codes;     // [n][M]
+    const float *code_norms;  // [n] decoded magnitudes (cosine)
+    const uint8_t *blocks;    // layer-0 FusedPQ blocks [n][deg0][M], or nullptr
+    const float *fused_norms; // [n][deg0] (cosine)
+    int32_t D, M, deg0;
+    // search
+    int32_t Q, rerankK;
+    // per-worker scratch
+    int32_t *visited;         // [workers][1 << vcap_log2]
+    int32_t vcap_log2;
+    long long *spill;         // [workers][spill_cap]
+    int32_t spill_cap;
+    int32_t cand_cap;         // LDS tier capacity (>= 256)
+    // outputs
+    int32_t *out_ids;         // [Q][rerankK] kept approximate results (unordered), -1 padded
+    float *out_scores;        // [Q][rerankK] their approximate scores, -inf padded
+    long long *out_stats;     // [Q][2] visitedCount, expandedCount
+    int32_t *out_status;      // [Q] GS_OK / GS_OVERFLOW
+    uint32_t *next_query;     // work counter (zeroed by the host before the launch)
+};
+
+// LDS bytes one worker needs
+inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap)
+{
+    return sizeof(float) * (size_t)D + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + GS_EVICT_CAP + 64);
+}
+
+struct alignas(16) gs_f4 { float x, y, z, w; };
+struct alignas(16) gs_u4 { uint32_t x, y, z, w; };
+
+GS_FN int32_t gs_float_bits(float f)
+{
+    int32_t b;
+    __builtin_memcpy(&b, &f, 4);
+    return b;
+}
+GS_FN float gs_bits_float(int32_t b)
+{
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+// NodeQueue.encode (NodeQueue.java:125-129) with NumericUtils.floatToSortableInt (:49-65)
+GS_FN long long gs_key(int32_t node, float score)
+{
+    const int32_t bits = (score != score) ? 0x7fc00000 : gs_float_bits(score);
+    const int32_t s = bits ^ ((bits >> 31) & 0x7fffffff);
+    return (long long)((((unsigned long long)(uint32_t)s) << 32) | (unsigned long long)(uint32_t)(~node));
+}
+GS_FN int32_t gs_key_node(long long k) { return (int32_t)~(uint32_t)((unsigned long long)k & 0xFFFFFFFFull); }
+GS_FN float gs_key_score(long long k)
+{
+    const int32_t e = (int32_t)(k >> 32);
+    return gs_bits_float(e ^ ((e >> 31) & 0x7fffffff));
+}
+
+constexpr long long GS_KEY_MIN = (long long)0x8000000000000000ull;
+constexpr long long GS_KEY_MAX = (long long)0x7fffffffffffffffull;
+
+GS_FN long long gs_wave_max(long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long t = gs_shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+GS_FN long long gs_wave_min(long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long t = gs_shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+GS_FN int gs_popc(uint64_t m) { return __builtin_popcountll(m); }
+GS_FN int gs_first(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
+
+// max (or min) key of a[0..n) and its index; n > 0; result uniform across the wave
+template <bool MAX>
+GS_FN long long gs_scan_extreme(const long long *a, int n, int *idx_out)
+{
+    const int lane = gs_lane();
+    long long best = MAX ? GS_KEY_MIN : GS_KEY_MAX;
+    int bi = -1;
+    for (int i = lane; i < n; i += 64) {
+        const long long k = a[i];
+        if (MAX ? (k > best) : (k < best)) {
+            best = k;
+            bi = i;
+        }
+    }
+    const long long m = MAX ? gs_wave_max(best) : gs_wave_min(best);
+    const uint64_t who = gs_ballot(bi >= 0 && best == m);
+    *idx_out = (int)gs_shfl((long long)bi, gs_first(who));
+    return m;
+}
+
+// ---- table-free ADC row score: DefaultVectorUtilSupport.calculatePartialSums (:351-365) entry by entry, summed in
+//      ascending m (assembleAndSum :323-330).  qs = the centred query in LDS.  Same arithmetic as
+//      frontier_direct_kernel; -ffp-contract=off keeps every mul and add separate.
+template <int VSF, int CH16>
+GS_FN float gs_row_sum(const float *codebooks, const float *qs, const uint8_t *rp)
+{
+    const gs_u4 *r4 = reinterpret_cast<const gs_u4 *>(rp);
+    gs_u4 w[CH16];
+#pragma unroll
+    for (int c = 0; c < CH16; ++c) w[c] = r4[c];
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH16; ++c) {
+        const uint32_t d[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int m = c * 16 + e * 4 + b;
+                const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
+                const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(codebooks + ((int64_t)(m * 256) + code) * 8);
+                const gs_f4 c0 = cp[0], c1 = cp[1];
+                const float *q = qs + m * 8;
+                float ent = 0.0f;
+                if (VSF == 0 /* L2 */) {
+                    float t;
+                    t = c0.x - q[0]; ent += t * t;
+                    t = c0.y - q[1]; ent += t * t;
+                    t = c0.z - q[2]; ent += t * t;
+                    t = c0.w - q[3]; ent += t * t;
+                    t = c1.x - q[4]; ent += t * t;
+                    t = c1.y - q[5]; ent += t * t;
+                    t = c1.z - q[6]; ent += t * t;
+                    t = c1.w - q[7]; ent += t * t;
+                } else {
+                    ent += c0.x * q[0];
+                    ent += c0.y * q[1];
+                    ent += c0.z * q[2];
+                    ent += c0.w * q[3];
+                    ent += c1.x * q[4];
+                    ent += c1.y * q[5];
+                    ent += c1.z * q[6];
+                    ent += c1.w * q[7];
+                }
+                sum += ent;
+            }
+        }
+    }
+    return sum;
+}
+
+// raw table sum -> similarity (jv_device.h score_from_raw / cosine_finish; PQDecoder.java:68,79,126)
+template <int VSF>
+GS_FN float gs_finish(float sum, float node_mag, float query_mag)
+{
+    if (VSF == 0) return 1.0f / (1.0f + sum);
+    if (VSF == 2) {
+        const float prod = node_mag * query_mag;
+        sum = (float)((double)sum / gs_sqrt((double)prod));
+    }
+    return (1.0f + sum) / 2.0f;
+}
+
+// visited.add: true iff the node was not in the set.  Linear probing; callers keep the load <= 1/2.
+GS_FN bool gs_visit(int32_t *tab, uint32_t mask, int shift, int32_t node)
+{
+    uint32_t h = ((uint32_t)node * 0x9E3779B1u) >> shift;
+    for (;;) {
+        const int32_t old = gs_cas(tab + h, -1, node);
+        if (old == -1) return true;
+        if (old == node) return false;
+        h = (h + 1) & mask;
+    }
+}
+
+// upper-level adjacency row of `node`, or nullptr (uniform: every lane probes the same slots)
+GS_FN const int32_t *gs_level_row(const GsLevel &L, int32_t node)
+{
+    if (!L.hkeys) return (node >= 0 && node < L.count) ? L.nbrs + (int64_t)node * L.degree : nullptr;
+    uint32_t h = ((uint32_t)node * 0x9E3779B1u) >> L.hshift;
+    for (;;) {
+        const int32_t k = L.hkeys[h];
+        if (k == node) return L.nbrs + (int64_t)L.hvals[h] * L.degree;
+        if (k == -1) return nullptr;
+        h = (h + 1) & L.hmask;
+    }
+}
+
+// Per-query traversal state.  Every member is wave-uniform (all 64 lanes hold the same value).
+struct GsState {
+    long long *cand, *res, *evicted, *samp;  // LDS
+    long long *spill;                        // global
+    int cand_n, spill_n, res_n, ev_n, res_min_idx;
+    long long spill_max, res_min;
+    int32_t status;
+};
+
+// Move every LDS-tier key <= the median of 64 samples to the spill tier (cand_n >= 64).
+GS_FN void gs_partition(GsState &s, const GsParams &p)
+{
+    const int lane = gs_lane();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const long long mine = s.cand[(int)(((long long)lane * s.cand_n) >> 6)];
+    s.samp[lane] = mine;
+    gs_barrier();
+    int rank = 0;
+    for (int j = 0; j < 64; ++j) rank += (s.samp[j] < mine) ? 1 : 0;
+    const long long pivot = gs_shfl(mine, gs_first(gs_ballot(rank == 31)));
+    int new_n = 0, moved = 0;
+    for (int base = 0; base < s.cand_n; base += 64) {
+        const int i = base + lane;
+        const bool in = i < s.cand_n;
+        const long long k = in ? s.cand[i] : 0;
+        const bool hi = in && k > pivot;
+        const bool lo = in && !hi;
+        const uint64_t mh = gs_ballot(hi), ml = gs_ballot(lo);  // every lane has read its key before any lane writes
+        if (hi) s.cand[new_n + gs_popc(mh & lt)] = k;          // in place: target index <= i
+        if (lo) {
+            const int pos = s.spill_n + moved + gs_popc(ml & lt);
+            if (pos < p.spill_cap) s.spill[pos] = k;
+        }
+        new_n += gs_popc(mh);
+        moved += gs_popc(ml);
+        gs_barrier();
+    }
+    if (s.spill_n + moved > p.spill_cap) s.status = GS_OVERFLOW;
+    s.spill_n += moved;
+    s.cand_n = new_n;
+    s.spill_max = pivot;  // the pivot itself moved, everything that stayed is larger
+}
+
+// candidates.push for up to one key per lane
+GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
+{
+    const int lane = gs_lane();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    bool to_lds;
+    uint64_t ml;
+    for (;;) {
+        to_lds = has && (s.spill_n == 0 || key > s.spill_max);
+        ml = gs_ballot(to_lds);
+        if (s.cand_n + gs_popc(ml) <= p.cand_cap) break;
+        gs_partition(s, p);
+        if (s.status != GS_OK) return;
+    }
+    if (to_lds) s.cand[s.cand_n + gs_popc(ml & lt)] = key;
+    s.cand_n += gs_popc(ml);
+    const bool to_sp = has && !to_lds;
+    const uint64_t ms = gs_ballot(to_sp);
+    if (ms) {
+        if (s.spill_n + gs_popc(ms) > p.spill_cap) {
+            s.status = GS_OVERFLOW;
+            return;
+        }
+        if (to_sp) s.spill[s.spill_n + gs_popc(ms & lt)] = key;
+        s.spill_n += gs_popc(ms);
+    }
+    gs_barrier();
+}
+
+// One query, start to finish.  lds: gs_lds_bytes() bytes, 16-byte aligned.
+template <int VSF, int CH16>
+GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
+{
+    const int lane = gs_lane();
+    float *qs = reinterpret_cast<float *>(lds);
+    GsState s;
+    s.res = reinterpret_cast<long long *>(lds + sizeof(float) * (size_t)p.D);
+    s.cand = s.res + p.rerankK;
+    s.evicted = s.cand + p.cand_cap;
+    s.samp = s.evicted + GS_EVICT_CAP;
+    s.spill = p.spill + (int64_t)worker * p.spill_cap;
+    s.cand_n = s.spill_n = s.res_n = s.ev_n = 0;
+    s.res_min_idx = -1;
+    s.spill_max = GS_KEY_MIN;
+    s.res_min = GS_KEY_MAX;
+    s.status = GS_OK;
+    const int vcap = 1 << p.vcap_log2;
+    const uint32_t vmask = (uint32_t)vcap - 1u;
+    const int vshift = 32 - p.vcap_log2;
+    int32_t *vis = p.visited + (int64_t)worker * vcap;
+    long long n_visited = 0, n_expanded = 0;
+
+    // ---- per-query setup: clear the visited table, stage the centred query ----
+    {
+        gs_u4 *v4 = reinterpret_cast<gs_u4 *>(vis);
+        const gs_u4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        for (int i = lane; i < vcap / 4; i += 64) v4[i] = ones;
+        const gs_f4 *src = reinterpret_cast<const gs_f4 *>(p.cq + (int64_t)q * p.D);
+        gs_f4 *dst = reinterpret_cast<gs_f4 *>(qs);
+        for (int i = lane; i < p.D / 4; i += 64) dst[i] = src[i];
+    }
+    gs_fence();
+    gs_barrier();
+    const float query_mag = (VSF == 2) ? p.bmag[q] : 0.0f;
+
+    // ---- initializeInternal :334-353: mark and score the entry node ----
+    {
+        const int32_t e = p.entry_node;
+        if (lane == 0) (void)gs_visit(vis, vmask, vshift, e);
+        float sc = gs_row_sum<VSF, CH16>(p.codebooks, qs, p.codes + (int64_t)e * p.M);
+        sc = gs_finish<VSF>(sc, (VSF == 2) ? p.code_norms[e] : 0.0f, query_mag);
+        if (lane == 0) s.cand[0] = gs_key(e, sc);
+        s.cand_n = 1;
+        gs_barrier();
+    }
+
+    for (int lvl = p.entry_level; lvl >= 0 && s.status == GS_OK; --lvl) {
+        const int rk = lvl > 0 ? 1 : p.rerankK;
+        const GsLevel &L = p.lv[lvl];
+        // ---- searchOneLayer :406-457 ----
+        for (;;) {
+            if (s.cand_n == 0 && s.spill_n == 0) break;
+            int idx;
+            long long top;
+            const bool from_lds = s.cand_n > 0;
+            if (from_lds) {
+                top = gs_scan_extreme<true>(s.cand, s.cand_n, &idx);
+            } else {  // the LDS tier ran dry: the best candidate is somewhere in the spill tier
+                gs_fence();
+                top = gs_scan_extreme<true>(s.spill, s.spill_n, &idx);
+            }
+            const float top_score = gs_key_score(top);
+            if (s.res_n >= rk && top_score < gs_key_score(s.res_min)) break;  // stopSearch :355-369
+            // candidates.pop()
+            if (from_lds) {
+                if (lane == 0) s.cand[idx] = s.cand[s.cand_n - 1];
+                s.cand_n--;
+            } else {
+                if (lane == 0) s.spill[idx] = s.spill[s.spill_n - 1];
+                s.spill_n--;
+                s.spill_max = top;  // still an upper bound of what is left
+                gs_fence();
+            }
+            // addTopCandidate :515-530 (BoundedLongHeap.push / updateTop)
+            if (s.res_n < rk) {
+                if (lane == 0) s.res[s.res_n] = top;
+                if (top < s.res_min) {
+                    s.res_min = top;
+                    s.res_min_idx = s.res_n;
+                }
+                s.res_n++;
+                gs_barrier();
+            } else if (top_score > gs_key_score(s.res_min)) {
+                if (lvl > 0) {
+                    if (s.ev_n >= GS_EVICT_CAP) {
+                        s.status = GS_OVERFLOW;
+                        break;
+                    }
+                    if (lane == 0) s.evicted[s.ev_n] = s.res_min;
+                    s.ev_n++;
+                }
+                if (lane == 0) s.res[s.res_min_idx] = top;
+                gs_barrier();
+                s.res_min = gs_scan_extreme<false>(s.res, s.res_n, &s.res_min_idx);
+            } else {
+                gs_barrier();
+            }
+            n_expanded++;
+
+            // ---- expand: visited.mark + score + candidates.push for every unvisited neighbour ----
+            const int32_t node = gs_key_node(top);
+            const int32_t *row = gs_level_row(L, node);
+            if (!row) continue;
+            const int deg = L.degree;
+            const int32_t nb = lane < deg ? row[lane] : -1;
+            const int first_neg = gs_first(gs_ballot(nb < 0));  // rows are packed: the first -1 ends the row
+            const bool fresh = lane < first_neg && gs_visit(vis, vmask, vshift, nb);
+            const uint64_t fm = gs_ballot(fresh);
+            if (fm == 0) continue;
+            n_visited += gs_popc(fm);
+            if ((n_visited + 1) * 2 > vcap) {
+                s.status = GS_OVERFLOW;
+                break;
+            }
+            long long key = 0;
+            if (fresh) {
+                const uint8_t *rp;
+                float node_mag = 0.0f;
+                if (lvl == 0 && p.blocks) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block
+                    const int64_t r = (int64_t)node * p.deg0 + lane;
+                    rp = p.blocks + r * p.M;
+                    if (VSF == 2) node_mag = p.fused_norms[r];
+                } else {                     // PQDecoder.similarityTo: the neighbour's own code
+                    rp = p.codes + (int64_t)nb * p.M;
+                    if (VSF == 2) node_mag = p.code_norms[nb];
+                }
+                const float sum = gs_row_sum<VSF, CH16>(p.codebooks, qs, rp);
+                key = gs_key(nb, gs_finish<VSF>(sum, node_mag, query_mag));
+            }
+            gs_push(s, p, key, fresh);
+            if (s.status != GS_OK) break;
+        }
+        if (s.status != GS_OK) break;
+        if (lvl > 0) {  // setEntryPointsFromPreviousLayer :324-331
+            for (int base = 0; base < s.res_n && s.status == GS_OK; base += 64) {
+                const bool has = base + lane < s.res_n;
+                gs_push(s, p, has ? s.res[base + lane] : 0, has);
+            }
+            for (int base = 0; base < s.ev_n && s.status == GS_OK; base += 64) {
+                const bool has = base + lane < s.ev_n;
+                gs_push(s, p, has ? s.evicted[base + lane] : 0, has);
+            }
+            s.res_n = 0;
+            s.ev_n = 0;
+            s.res_min = GS_KEY_MAX;
+            s.res_min_idx = -1;
+        }
+    }
+
+    // ---- hand the kept approximate results to the rerank stage ----
+    gs_barrier();
+    for (int i = lane; i < p.rerankK; i += 64) {
+        const bool have = s.status == GS_OK && i < s.res_n;
+        const long long k = have ? s.res[i] : 0;
+        p.out_ids[(int64_t)q * p.rerankK + i] = have ? gs_key_node(k) : -1;
+        p.out_scores[(int64_t)q * p.rerankK + i] = have ? gs_key_score(k) : -__builtin_inff();
+    }
+    if (lane == 0) {
+        p.out_stats[2 * (int64_t)q] = n_visited;
+        p.out_stats[2 * (int64_t)q + 1] = n_expanded;
+        p.out_status[q] = s.status;
+    }
+    gs_barrier();
+}
+
+// Persistent worker: pulls queries off the shared counter until none are left.
+template <int VSF, int CH16>
+GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
+{
+    for (;;) {
+        long long qv = 0;
+        if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
+        const int q = (int)gs_shfl(qv, 0);
+        if (q >= p.Q) break;
+        gs_search_one<VSF, CH16>(p, q, worker, lds);
+    }
+}
+
+}  // namespace jv

@@ -1,0 +1,122 @@
+// gs_emu.cpp — compiles the device-resident graph search body (jvector_amd/csrc/gs_body.h) for the lane emulator and
+// exposes one C entry point to the CPU tests.  TEST HARNESS: g++ -O2 -ffp-contract=off, never linked into the product.
+#include <vector>
+
+#include "hip_emu.h"
+
+#define GS_FN inline
+static inline int gs_lane() { return emu::lane(); }
+static inline void gs_barrier() { emu::barrier(); }
+static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
+static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
+static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
+static inline int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired)
+{
+    const int32_t old = *p;
+    if (old == expect) *p = desired;
+    return old;
+}
+static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
+{
+    const uint32_t old = *p;
+    *p = old + v;
+    return old;
+}
+static inline void gs_fence() {}
+static inline double gs_sqrt(double x) { return std::sqrt(x); }
+
+#include "../../jvector_amd/csrc/gs_body.h"
+#include "../../jvector_amd/csrc/gs_host.h"
+
+namespace {
+struct Launch {
+    const jv::GsParams *p;
+    int vsf, ch, worker;
+    char *lds;
+};
+
+template <int VSF>
+void run_ch(const Launch &L)
+{
+    switch (L.ch) {
+    case 1: jv::gs_worker<VSF, 1>(*L.p, L.worker, L.lds); break;
+    case 2: jv::gs_worker<VSF, 2>(*L.p, L.worker, L.lds); break;
+    case 3: jv::gs_worker<VSF, 3>(*L.p, L.worker, L.lds); break;
+    case 4: jv::gs_worker<VSF, 4>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gs_worker<VSF, 6>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
+void lane_main(void *arg)
+{
+    const Launch &L = *(const Launch *)arg;
+    if (L.vsf == 0) run_ch<0>(L);
+    else if (L.vsf == 1) run_ch<1>(L);
+    else run_ch<2>(L);
+}
+}  // namespace
+
+extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, const int32_t *const *lv_nbrs, const int32_t *lv_count,
+                              const int32_t *lv_degree, int entry_node, int entry_level, const float *codebooks, const float *cq,
+                              const float *bmag, const uint8_t *codes, const float *code_norms, const uint8_t *blocks,
+                              const float *fused_norms, int D, int M, int deg0, int Q, int rerankK, int vsf, int vcap_log2,
+                              int spill_cap, int cand_cap, int workers, int32_t *out_ids, float *out_scores, long long *out_stats,
+                              int32_t *out_status)
+{
+    if (n_levels < 1 || n_levels > jv::GS_MAX_LEVELS || M % 16 != 0 || D != 8 * M || cand_cap < 256) return -1;
+    jv::GsParams p{};
+    std::vector<jv::GsLevelMap> maps((size_t)n_levels);
+    for (int l = 0; l < n_levels; ++l) {
+        p.lv[l].nbrs = lv_nbrs[l];
+        p.lv[l].count = lv_count[l];
+        p.lv[l].degree = lv_degree[l];
+        if (l > 0) {
+            maps[l] = jv::gs_build_level_map(lv_nodes[l], lv_count[l]);
+            p.lv[l].hkeys = maps[l].keys.data();
+            p.lv[l].hvals = maps[l].vals.data();
+            p.lv[l].hmask = maps[l].mask;
+            p.lv[l].hshift = maps[l].shift;
+        }
+    }
+    p.entry_node = entry_node;
+    p.entry_level = entry_level;
+    p.codebooks = codebooks; p.cq = cq; p.bmag = bmag; p.codes = codes; p.code_norms = code_norms;
+    p.blocks = blocks; p.fused_norms = fused_norms;
+    p.D = D; p.M = M; p.deg0 = deg0; p.Q = Q; p.rerankK = rerankK;
+    const size_t vcap = (size_t)1 << vcap_log2;
+    int32_t *visited = (int32_t *)aligned_alloc(64, sizeof(int32_t) * vcap * workers);
+    long long *spill = (long long *)aligned_alloc(64, sizeof(long long) * (size_t)(spill_cap > 0 ? spill_cap : 1) * workers + 64);
+    memset(visited, 0x5a, sizeof(int32_t) * vcap * workers);  // garbage: the kernel must clear it itself
+    p.visited = visited; p.vcap_log2 = vcap_log2; p.spill = spill; p.spill_cap = spill_cap; p.cand_cap = cand_cap;
+    p.out_ids = out_ids; p.out_scores = out_scores; p.out_stats = out_stats; p.out_status = out_status;
+    uint32_t next = 0;
+    p.next_query = &next;
+    long collectives = 0;
+    // "workers" waves run one after another; each drains part of the queue so that scratch reuse across queries and
+    // distinct worker slices are both exercised
+    for (int w = 0; w < workers; ++w) {
+        jv::GsParams pw = p;
+        pw.Q = (int)((long long)Q * (w + 1) / workers);
+        char *lds = (char *)aligned_alloc(64, jv::gs_lds_bytes(D, rerankK, cand_cap) + 64);
+        memset(lds, 0xa5, jv::gs_lds_bytes(D, rerankK, cand_cap));
+        Launch L{&pw, vsf, M / 16, w, lds};
+        collectives += emu::run_wave(lane_main, &L);
+        next = (uint32_t)pw.Q;  // the drained worker overshot the counter by one
+        free(lds);
+    }
+    free(visited);
+    free(spill);
+    return collectives;
+}
+
+// gs_host.h's map builder, probed the way the device does (for a direct unit test)
+extern "C" int gs_emu_level_lookup(const int32_t *nodes, int count, int32_t node)
+{
+    jv::GsLevelMap m = jv::gs_build_level_map(nodes, count);
+    uint32_t h = ((uint32_t)node * 0x9E3779B1u) >> m.shift;
+    for (;;) {
+        if (m.keys[h] == node) return m.vals[h];
+        if (m.keys[h] == -1) return -1;
+        h = (h + 1) & m.mask;
+    }
+}

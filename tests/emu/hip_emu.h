@@ -1,0 +1,183 @@
+// hip_emu.h — a minimal lane-level emulator for wave-synchronous device code (TEST HARNESS, x86-64 only).
+//
+// It runs one 64-lane "wavefront" as 64 cooperatively scheduled fibers on one host thread.  A lane runs until it
+// reaches a collective (barrier / ballot / shuffle), then the next lane runs; when all live lanes have arrived the
+// collective completes.  That is enough to execute jvector_amd/csrc/gs_body.h — the body of the device-resident graph
+// search kernel — unchanged on the CPU and compare it with the oracle, lane divergence, in-place compaction and
+// hash-table races (as far as a deterministic schedule shows them) included.  What it cannot show: hardware memory
+// ordering, register pressure, anything the real compiler does.  Not part of the product; nothing under jvector_amd/
+// includes it.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace emu {
+
+constexpr int WAVE = 64;
+constexpr size_t STACK_BYTES = 256 * 1024;
+
+extern "C" void emu_switch(void **save_sp, void *next_sp);
+// callee-saved registers + stack pointer swap (System V x86-64)
+__asm__(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch,.-emu_switch
+)");
+
+struct Wave {
+    void *sp[WAVE];
+    char *stack[WAVE];
+    bool done[WAVE];
+    void *main_sp;
+    int cur, live, arrived;
+    unsigned gen;
+    long long xbuf[WAVE];
+    void (*fn)(void *);
+    void *arg;
+    long collectives;
+};
+
+inline Wave *&current()
+{
+    static Wave *w = nullptr;
+    return w;
+}
+inline int lane() { return current()->cur; }
+
+inline void switch_to_next_live()
+{
+    Wave &w = *current();
+    const int me = w.cur;
+    int nx = me;
+    for (int i = 1; i <= WAVE; ++i) {
+        const int c = (me + i) % WAVE;
+        if (!w.done[c]) {
+            nx = c;
+            break;
+        }
+    }
+    if (nx == me) return;
+    w.cur = nx;
+    emu_switch(&w.sp[me], w.sp[nx]);
+}
+
+inline void barrier()
+{
+    Wave &w = *current();
+    const unsigned g = w.gen;
+    if (++w.arrived >= w.live) {
+        w.arrived = 0;
+        w.gen++;
+        w.collectives++;
+        return;
+    }
+    while (w.gen == g) switch_to_next_live();
+}
+
+inline void lane_exit()
+{
+    Wave &w = *current();
+    const int me = w.cur;
+    w.done[me] = true;
+    w.xbuf[me] = 0;
+    w.live--;
+    if (w.live == 0) {
+        void *dummy;
+        emu_switch(&dummy, w.main_sp);  // never returns
+    }
+    if (w.arrived >= w.live) {  // the others were waiting for this lane only
+        w.arrived = 0;
+        w.gen++;
+    }
+    int nx = me;
+    for (int i = 1; i <= WAVE; ++i) {
+        const int c = (me + i) % WAVE;
+        if (!w.done[c]) {
+            nx = c;
+            break;
+        }
+    }
+    w.cur = nx;
+    void *dummy;
+    emu_switch(&dummy, w.sp[nx]);  // never returns
+}
+
+inline void lane_entry()
+{
+    Wave &w = *current();
+    w.fn(w.arg);
+    lane_exit();
+    abort();
+}
+
+// run fn(arg) on 64 lanes until every lane has returned
+inline long run_wave(void (*fn)(void *), void *arg)
+{
+    Wave *w = new Wave();
+    memset(w, 0, sizeof(*w));
+    w->fn = fn;
+    w->arg = arg;
+    w->live = WAVE;
+    for (int i = 0; i < WAVE; ++i) {
+        w->stack[i] = (char *)aligned_alloc(64, STACK_BYTES);
+        uintptr_t top = ((uintptr_t)(w->stack[i] + STACK_BYTES)) & ~(uintptr_t)15;
+        void **sp = (void **)top;
+        *--sp = nullptr;                 // fake return address of lane_entry (keeps rsp % 16 == 8 at entry)
+        *--sp = (void *)&lane_entry;     // `ret` target of the first switch
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;  // rbp rbx r12 r13 r14 r15
+        w->sp[i] = (void *)sp;
+    }
+    Wave *prev = current();
+    current() = w;
+    w->cur = 0;
+    emu_switch(&w->main_sp, w->sp[0]);
+    current() = prev;
+    const long n = w->collectives;
+    for (int i = 0; i < WAVE; ++i) free(w->stack[i]);
+    delete w;
+    return n;
+}
+
+inline uint64_t ballot(bool p)
+{
+    Wave &w = *current();
+    w.xbuf[w.cur] = p ? 1 : 0;
+    barrier();
+    uint64_t m = 0;
+    for (int i = 0; i < WAVE; ++i)
+        if (!w.done[i] && w.xbuf[i]) m |= 1ull << i;
+    barrier();
+    return m;
+}
+inline long long shfl(long long v, int src)
+{
+    Wave &w = *current();
+    w.xbuf[w.cur] = v;
+    barrier();
+    const long long r = w.xbuf[src & 63];
+    barrier();
+    return r;
+}
+
+}  // namespace emu

@@ -1,0 +1,158 @@
+"""CPU check of the device-resident graph traversal (jvector_amd/csrc/gs_body.h — the body of graph_search_kernel):
+the kernel source is compiled unchanged for a 64-lane wave emulator (tests/emu/) and must reproduce the oracle's
+sequential GraphSearcher restatement — same kept result set, same approximate scores bit for bit, same visitedCount /
+expandedCount — including the paths a GPU run rarely takes (spill-tier partition, popping from the spill tier,
+overflow reporting).  The GPU twin of this test is tests/test_zz_device_traversal_gpu.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from test_graph_search import build_problem, fused_blocks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = [os.path.join(ROOT, "tests", "emu", "gs_emu.cpp"), os.path.join(ROOT, "tests", "emu", "hip_emu.h"),
+       os.path.join(ROOT, "jvector_amd", "csrc", "gs_body.h"), os.path.join(ROOT, "jvector_amd", "csrc", "gs_host.h")]
+LIB = os.path.join(ROOT, "build", "emu", "libgs_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in SRC):
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                               SRC[0], "-o", LIB])
+    lib = C.CDLL(LIB)
+    lib.gs_emu_search.restype = C.c_long
+    return lib
+
+
+def seq_sum_f32(table, codes):
+    """sum_m table[m*256 + code[m]] in ascending m, one f32 accumulator (assembleAndSum order), per row."""
+    acc = np.zeros(codes.shape[0], np.float32)
+    for m in range(codes.shape[1]):
+        acc = (acc + table[m * 256 + codes[:, m].astype(np.int64)]).astype(np.float32)
+    return acc
+
+
+def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vcap_log2=14, spill_cap=8192, cand_cap=256,
+            workers=2):
+    N, M, D = codes.shape[0], opq.M, opq.D
+    Q = q.shape[0]
+    deg0 = lv[0][1].shape[1]
+    i32p = C.POINTER(C.c_int32)
+    L = len(lv)
+    nodes = (i32p * L)(*[C.cast(None, i32p) if ids is None else np.ascontiguousarray(ids, np.int32).ctypes.data_as(i32p)
+                         for ids, _ in lv])
+    keep = [np.ascontiguousarray(nb, np.int32) for _, nb in lv]
+    nbrs = (i32p * L)(*[a.ctypes.data_as(i32p) for a in keep])
+    count = (C.c_int32 * L)(*[a.shape[0] for a in keep])
+    degree = (C.c_int32 * L)(*[a.shape[1] for a in keep])
+    cq = np.ascontiguousarray(q if opq.centroid is None else (q - opq.centroid).astype(np.float32), np.float32)
+    bmag = np.zeros(Q, np.float32)
+    code_norms = fnorms = None
+    blocks = fused_blocks(codes, lv[0][1]) if fused else None
+    if vsf == O.COSINE:
+        amag = None
+        for i in range(Q):
+            _, amag, bmag[i] = opq.decoder(q[i], vsf, fused)
+        code_norms = seq_sum_f32(amag, codes)
+        if fused:
+            nb0 = lv[0][1]
+            fnorms = np.where(nb0 >= 0, code_norms[np.maximum(nb0, 0)], 0).astype(np.float32)
+    out_ids = np.empty((Q, rerank_k), np.int32)
+    out_sc = np.empty((Q, rerank_k), np.float32)
+    stats = np.zeros((Q, 2), np.int64)
+    status = np.full(Q, -9, np.int32)
+    fp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    cb = np.ascontiguousarray(opq.codebooks, np.float32)
+    codes = np.ascontiguousarray(codes, np.uint8)
+    n = emu.gs_emu_search(L, nodes, nbrs, count, degree, entry, entry_level, fp(cb), fp(cq), fp(bmag), fp(codes),
+                          fp(code_norms), fp(blocks), fp(fnorms), D, M, deg0, Q, rerank_k, int(vsf), vcap_log2, spill_cap,
+                          cand_cap, workers, fp(out_ids), fp(out_sc), fp(stats), fp(status))
+    assert n >= 0
+    return out_ids, out_sc, stats, status, n
+
+
+def check(out_ids, out_sc, stats, status, want_ids, want_sc, want_stats, allow_overflow=False):
+    assert allow_overflow or (status == 0).all(), status
+    assert np.isin(status, (0, 1)).all()
+    for qi in range(out_ids.shape[0]):
+        if status[qi] != 0:
+            assert (out_ids[qi] == -1).all()
+            continue
+        assert np.array_equal(stats[qi], want_stats[qi])
+        got = sorted(zip(out_sc[qi].tolist(), (-out_ids[qi]).tolist()), reverse=True)
+        want = sorted(zip(want_sc[qi].tolist(), (-want_ids[qi]).tolist()), reverse=True)
+        assert got == want, qi
+
+
+def problem(seed, N, D, M, levels, deg=16, nq=10):
+    v, lv, entry, entry_level, cb, q = build_problem(seed, N=N, D=D, M=M, deg=deg, levels=levels)
+    opq = O.OraclePQ(D, M, cb)
+    codes = opq.encode_all(v)
+    return lv, entry, entry_level, opq, codes, q[:nq]
+
+
+def test_level_map_lookup(emu):
+    rng = np.random.default_rng(0)
+    nodes = np.sort(rng.choice(1 << 20, 5000, replace=False)).astype(np.int32)
+    p = nodes.ctypes.data_as(C.POINTER(C.c_int32))
+    for i in (0, 1, 77, 4999):
+        assert emu.gs_emu_level_lookup(p, 5000, int(nodes[i])) == i
+    missing = int(np.setdiff1d(np.arange(100), nodes)[0])
+    assert emu.gs_emu_level_lookup(p, 5000, missing) == -1
+
+
+@pytest.mark.parametrize("levels,fused,M", [(1, False, 16), (2, True, 16), (3, True, 32), (2, False, 48)])
+def test_emulated_kernel_matches_oracle(emu, levels, fused, M):
+    D = 8 * M
+    lv, entry, entry_level, opq, codes, q = problem(100 + levels + M, 2500, D, M, levels)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
+        for rk in (40, 1):
+            wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
+            ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused)
+            check(ids, sc, st, status, wi, ws, wst)
+
+
+def test_partition_and_spill_paths(emu):
+    """rerankK large enough that far more than cand_cap=256 candidates are alive: the LDS tier must spill (several
+    partitions per query) and results must not change."""
+    lv, entry, entry_level, opq, codes, q = problem(7, 4000, 128, 16, 2, deg=24, nq=6)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, None, q, O.COSINE, 400, 400, fused=True)
+    assert (wst[:, 0] - wst[:, 1]).min() > 2 * 256  # live candidates (pushed - popped) >> cand_cap: the tier must spill
+    ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.COSINE, 400, True, cand_cap=256)
+    check(ids, sc, st, status, wi, ws, wst)
+
+
+def test_exhaustive_search_pops_from_the_spill_tier(emu):
+    """rerankK >= N: the search never stops early, visits the whole component and pops every candidate — the LDS tier
+    drains and the remaining candidates come back out of the spill tier."""
+    lv, entry, entry_level, opq, codes, q = problem(11, 700, 128, 16, 2, deg=12, nq=4)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, None, q, O.EUCLIDEAN, 800, 800, fused=False)
+    assert (wst[:, 1] > 600).all()  # expanded (nearly) every node
+    ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.EUCLIDEAN, 800, False, cand_cap=256,
+                                     vcap_log2=12)
+    check(ids, sc, st, status, wi, ws, wst)
+
+
+def test_overflow_is_reported_not_hidden(emu):
+    lv, entry, entry_level, opq, codes, q = problem(13, 3000, 128, 16, 2, deg=24, nq=4)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, None, q, O.DOT_PRODUCT, 120, 120, fused=True)
+    # visited table too small for these searches: every query must say so
+    ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.DOT_PRODUCT, 120, True, vcap_log2=9)
+    assert (status == 1).all() and (ids == -1).all()
+    # spill tier too small
+    ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.DOT_PRODUCT, 120, True, spill_cap=32)
+    assert (status == 1).any()
+    check(ids, sc, st, status, wi, ws, wst, allow_overflow=True)  # queries that fitted are still exact
+    # and with room the same queries are fine
+    ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.DOT_PRODUCT, 120, True)
+    check(ids, sc, st, status, wi, ws, wst)
