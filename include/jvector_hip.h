@@ -251,6 +251,14 @@ JV_API int jv_hip_graph_set_level(jv_ctx *ctx, jv_graph *g, int level, int count
                                   const int32_t *neighbors, int degree);
 JV_API int jv_hip_graph_set_entry(jv_graph *g, int32_t node, int level);
 JV_API int jv_hip_graph_destroy(jv_graph *g);
+/* Where the traversal state (candidate / result queues, visited set) lives.
+ *   HOST   : the host batched searcher (C++ worker pool; the GPU scores each round's frontier).
+ *   DEVICE : one wavefront per query keeps the queues in LDS / L2 and runs the whole loop on the GPU (uniform 8-dim
+ *            sub-vectors, M a multiple of 16, degree <= 64); queries that outgrow its fixed-size structures are re-run
+ *            on the host.  Results, visitedCount and expandedCount are identical either way.
+ *   AUTO   : currently HOST.  The environment variable JVECTOR_HIP_GRAPH_TRAVERSAL=host|device overrides the setting. */
+enum { JV_TRAVERSAL_AUTO = 0, JV_TRAVERSAL_HOST = 1, JV_TRAVERSAL_DEVICE = 2 };
+JV_API int jv_hip_graph_set_traversal(jv_graph *g, int mode);
 JV_API int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *luts, const jv_codes *codes,
                                const jv_fused *fused, const jv_vectors *vectors, const float *queries, int Q,
                                jv_vsf vsf, int topK, int rerankK, int32_t *out_ids, float *out_scores, int64_t *stats);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "jv_hip_graph_set_level": (_i, [_p, _p, _i, _i, _p, _p, _i]),
     "jv_hip_graph_set_entry": (_i, [_p, C.c_int32, _i]),
     "jv_hip_graph_destroy": (_i, [_p]),
+    "jv_hip_graph_set_traversal": (_i, [_p, _i]),
     "jv_hip_graph_search": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
 }
 

@@ -249,6 +249,9 @@ int jv_hip_ctx_destroy(jv_ctx *ctx)
     ctx->d_scratch.release();
     ctx->d_scratch2.release();
     ctx->d_scratch3.release();
+    ctx->d_gs_visited.release();
+    ctx->d_gs_spill.release();
+    ctx->d_gs_out.release();
     for (auto &e : ctx->prof_pending) {
         (void)hipEventDestroy(e.start);
         (void)hipEventDestroy(e.stop);

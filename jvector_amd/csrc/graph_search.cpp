@@ -24,6 +24,8 @@
 #include <mutex>
 #include <thread>
 
+#include "gs_host.h"
+#include "gs_params.h"
 #include "jv_internal.h"
 
 namespace jv {
@@ -329,6 +331,27 @@ struct jv_graph {
         std::vector<int32_t> nbrs;    // count x degree, packed, -1 padded
     };
     std::vector<Level> levels;
+    // device mirror for the device-resident traversal (k_gsearch.hip), built on first use; immutable afterwards
+    struct DevLevel {
+        int32_t *nbrs = nullptr, *hkeys = nullptr, *hvals = nullptr;
+        uint32_t hmask = 0;
+        int32_t hshift = 32;
+    };
+    std::vector<DevLevel> dev;
+    std::mutex dev_mu;
+    bool dev_ready = false;
+    int dev_device = -1;
+    int traversal = JV_TRAVERSAL_AUTO;
+    ~jv_graph()
+    {
+        if (dev.empty()) return;
+        (void)hipSetDevice(dev_device);
+        for (DevLevel &d : dev) {
+            (void)hipFree(d.nbrs);
+            (void)hipFree(d.hkeys);
+            (void)hipFree(d.hvals);
+        }
+    }
     const int32_t *row(int level, int32_t node) const
     {
         const Level &L = levels[level];
@@ -391,7 +414,17 @@ int jv_hip_graph_destroy(jv_graph *g)
     return JV_OK;
 }
 
-int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
+int jv_hip_graph_set_traversal(jv_graph *g, int mode)
+{
+    clear_error();
+    JV_REQUIRE(g, "graph_set_traversal: NULL graph");
+    JV_REQUIRE(mode == JV_TRAVERSAL_AUTO || mode == JV_TRAVERSAL_HOST || mode == JV_TRAVERSAL_DEVICE,
+               "graph_set_traversal: unknown mode %d", mode);
+    g->traversal = mode;
+    return JV_OK;
+}
+
+static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
                         const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
                         int32_t *out_ids, float *out_scores, int64_t *stats)
 {
@@ -762,6 +795,242 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
         }
     }
     return JV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident traversal (k_gsearch.hip / gs_body.h): same search, the queues live on the GPU.
+// ---------------------------------------------------------------------------------------------
+static int ensure_device_graph(jv_ctx *ctx, jv_graph *g)
+{
+    std::lock_guard<std::mutex> lk(g->dev_mu);
+    if (g->dev_ready) {
+        JV_REQUIRE(g->dev_device == ctx->device, "graph: device mirror lives on device %d, search runs on device %d",
+                   g->dev_device, ctx->device);
+        return JV_OK;
+    }
+    g->dev_device = ctx->device;
+    g->dev.resize((size_t)g->entry_level + 1);
+    auto upload = [&](int32_t **dst, const int32_t *src, size_t n) -> int {
+        JV_HIP_CHECK(hipMalloc((void **)dst, sizeof(int32_t) * std::max<size_t>(n, 1)));
+        JV_HIP_CHECK(hipMemcpy(*dst, src, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        return JV_OK;
+    };
+    for (int lv = 0; lv <= g->entry_level; ++lv) {
+        const jv_graph::Level &L = g->levels[lv];
+        jv_graph::DevLevel &d = g->dev[lv];
+        JV_TRY(upload(&d.nbrs, L.nbrs.data(), L.nbrs.size()));
+        if (!L.nodes.empty()) {
+            const GsLevelMap m = gs_build_level_map(L.nodes.data(), L.count);
+            JV_TRY(upload(&d.hkeys, m.keys.data(), m.keys.size()));
+            JV_TRY(upload(&d.hvals, m.vals.data(), m.vals.size()));
+            d.hmask = m.mask;
+            d.hshift = m.shift;
+        }
+    }
+    g->dev_ready = true;
+    return JV_OK;
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
+                               const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
+                               int32_t *out_ids, float *out_scores, int64_t *stats)
+{
+    const jv_decoder_kind kind = fused ? JV_DECODER_FUSED : JV_DECODER_PQ;
+    JV_TRY(jv_hip_luts_build(ctx, l, queries, Q, vsf, kind));  // centred queries, query magnitudes, raw copy for the rerank
+    const int kvsf = to_kernel_vsf(vsf);
+    if (vsf == JV_COSINE) {
+        JV_TRY(ensure_code_norms(ctx, const_cast<jv_codes *>(codes)));
+        if (fused) JV_TRY(ensure_fused_norms(ctx, const_cast<jv_fused *>(fused)));
+    }
+    JV_TRY(ensure_device_graph(ctx, const_cast<jv_graph *>(g)));
+    const jv_pq *pq = l->pq;
+
+    // ---- sizing: LDS tier, workers, per-worker scratch ----
+    int cand_cap = std::max(256, env_int("JVECTOR_HIP_GS_CAND_CAP", 1024)) & ~63;
+    while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
+    const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap);
+    if (lds > ctx->lds_per_block) {
+        set_error("graph_search(device): rerankK %d needs %zu bytes of LDS per wave (limit %zu); use the host traversal", rerankK,
+                  lds, ctx->lds_per_block);
+        return JV_ERR_UNSUPPORTED;
+    }
+    int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / (lds + 256)));
+    per_cu = std::max(1, env_int("JVECTOR_HIP_GS_WAVES_PER_CU", per_cu));
+    const int workers = std::max(1, std::min(Q, ctx->num_cus * per_cu));
+    const int vcap_log2 = gs_vcap_log2(rerankK);
+    const size_t vcap = (size_t)1 << vcap_log2;
+    const int spill_cap = (int)(vcap / 2) + 64;  // pushes <= visited <= vcap / 2: the spill tier cannot overflow first
+    JV_TRY(ctx->d_gs_visited.reserve(sizeof(int32_t) * vcap * (size_t)workers));
+    JV_TRY(ctx->d_gs_spill.reserve(sizeof(long long) * (size_t)spill_cap * (size_t)workers));
+    // result staging: [ids Q*rk][scores Q*rk][qnorm Q][pad][stats Q*2 i64][status Q][counter]
+    const size_t c1 = (size_t)Q * rerankK;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t o = off;
+        off = (off + bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t o_ids = carve(sizeof(int32_t) * c1), o_sc = carve(sizeof(float) * c1), o_qn = carve(sizeof(float) * (size_t)Q);
+    const size_t o_stats = carve(sizeof(long long) * 2 * (size_t)Q), o_status = carve(sizeof(int32_t) * (size_t)Q);
+    const size_t o_counter = carve(sizeof(uint32_t));
+    JV_TRY(ctx->d_gs_out.reserve(off));
+    char *base = (char *)ctx->d_gs_out.ptr;
+    int32_t *d_cand = (int32_t *)(base + o_ids);
+    float *d_cand_sc = (float *)(base + o_sc);
+    float *d_qnorm = (float *)(base + o_qn);
+    long long *d_stats = (long long *)(base + o_stats);
+    int32_t *d_status = (int32_t *)(base + o_status);
+    uint32_t *d_counter = (uint32_t *)(base + o_counter);
+    JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
+
+    GsParams p{};
+    for (int lv = 0; lv <= g->entry_level; ++lv) {
+        const jv_graph::DevLevel &d = g->dev[lv];
+        p.lv[lv].nbrs = d.nbrs;
+        p.lv[lv].hkeys = d.hkeys;
+        p.lv[lv].hvals = d.hvals;
+        p.lv[lv].hmask = d.hmask;
+        p.lv[lv].hshift = d.hshift;
+        p.lv[lv].count = g->levels[lv].count;
+        p.lv[lv].degree = g->levels[lv].degree;
+    }
+    p.entry_node = g->entry_node;
+    p.entry_level = g->entry_level;
+    p.codebooks = pq->d_codebooks;
+    p.cq = l->d_queries;
+    p.bmag = l->d_bmag;
+    p.codes = codes->d_codes;
+    p.code_norms = codes->d_norms;
+    p.blocks = fused ? fused->d_blocks : nullptr;
+    p.fused_norms = fused ? fused->d_norms : nullptr;
+    p.D = pq->D;
+    p.M = pq->M;
+    p.deg0 = g->levels[0].degree;
+    p.Q = Q;
+    p.rerankK = rerankK;
+    p.visited = (int32_t *)ctx->d_gs_visited.ptr;
+    p.vcap_log2 = vcap_log2;
+    p.spill = (long long *)ctx->d_gs_spill.ptr;
+    p.spill_cap = spill_cap;
+    p.cand_cap = cand_cap;
+    p.out_ids = d_cand;
+    p.out_scores = d_cand_sc;
+    p.out_stats = d_stats;
+    p.out_status = d_status;
+    p.next_query = d_counter;
+    {
+        ProfScope ps(ctx, R_ADC);
+        JV_TRY(launch_graph_search(ctx->stream, kvsf, p, workers));
+    }
+
+    // ---- reranking :471-507 on the device-resident candidates ----
+    OutStage oi, osc;
+    JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_scratch2, &oi));
+    JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * topK, ctx->d_scratch3, &osc));
+    JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, topK)));
+    if (vectors) {
+        ProfScope ps(ctx, R_EXACT);
+        JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf, d_cand,
+                                   rerankK, d_cand_sc, d_qnorm));
+    }
+    {
+        ProfScope ps(ctx, R_TOPK);
+        JV_TRY(launch_topk(ctx->stream, ctx, d_cand_sc, d_cand, Q, rerankK, rerankK, 0, topK, (int32_t *)oi.dev,
+                           (float *)osc.dev, ctx->d_scratch.ptr));
+    }
+    JV_TRY(ctx->h_out.reserve(sizeof(long long) * 2 * (size_t)Q + sizeof(int32_t) * (size_t)Q));
+    long long *h_stats = (long long *)ctx->h_out.ptr;
+    int32_t *h_status = (int32_t *)(h_stats + 2 * (size_t)Q);
+    JV_HIP_CHECK(hipMemcpyAsync(h_stats, d_stats, sizeof(long long) * 2 * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+    JV_HIP_CHECK(hipMemcpyAsync(h_status, d_status, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+    JV_TRY(stage_out_end(ctx, oi));
+    JV_TRY(stage_out_end(ctx, osc));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::vector<int> redo;
+    for (int q = 0; q < Q; ++q) {
+        if (h_status[q] != GS_OK) redo.push_back(q);
+        if (stats) {
+            stats[2 * q] = h_stats[2 * q];
+            stats[2 * q + 1] = h_stats[2 * q + 1];
+        }
+    }
+    if (getenv("JVECTOR_HIP_GRAPH_TIMING"))
+        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU) lds=%zu cand_cap=%d vcap=%zu overflow=%zu\n", Q, workers,
+                per_cu, lds, cand_cap, vcap, redo.size());
+    if (redo.empty()) return JV_OK;
+
+    // ---- queries that outgrew the fixed-size device structures: same search on the host ----
+    const int D = pq->D, R = (int)redo.size();
+    std::vector<float> sub((size_t)R * D);
+    const bool q_dev = is_device_ptr(queries);
+    for (int i = 0; i < R; ++i) {
+        const float *src = queries + (size_t)redo[i] * D;
+        if (q_dev) JV_HIP_CHECK(hipMemcpy(sub.data() + (size_t)i * D, src, sizeof(float) * D, hipMemcpyDeviceToHost));
+        else memcpy(sub.data() + (size_t)i * D, src, sizeof(float) * D);
+    }
+    std::vector<int32_t> sub_ids((size_t)R * topK);
+    std::vector<float> sub_sc((size_t)R * topK);
+    std::vector<int64_t> sub_stats((size_t)R * 2);
+    JV_TRY(graph_search_host(ctx, g, l, codes, fused, vectors, sub.data(), R, vsf, topK, rerankK, sub_ids.data(), sub_sc.data(),
+                             sub_stats.data()));
+    const bool ids_dev = is_device_ptr(out_ids), sc_dev = is_device_ptr(out_scores);
+    for (int i = 0; i < R; ++i) {
+        const size_t dst = (size_t)redo[i] * topK, src = (size_t)i * topK;
+        if (ids_dev) JV_HIP_CHECK(hipMemcpy(out_ids + dst, sub_ids.data() + src, sizeof(int32_t) * topK, hipMemcpyHostToDevice));
+        else memcpy(out_ids + dst, sub_ids.data() + src, sizeof(int32_t) * topK);
+        if (sc_dev) JV_HIP_CHECK(hipMemcpy(out_scores + dst, sub_sc.data() + src, sizeof(float) * topK, hipMemcpyHostToDevice));
+        else memcpy(out_scores + dst, sub_sc.data() + src, sizeof(float) * topK);
+        if (stats) {
+            stats[2 * redo[i]] = sub_stats[2 * (size_t)i];
+            stats[2 * redo[i] + 1] = sub_stats[2 * (size_t)i + 1];
+        }
+    }
+    return JV_OK;
+}
+
+int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
+                        const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
+                        int32_t *out_ids, float *out_scores, int64_t *stats)
+{
+    clear_error();
+    JV_REQUIRE(ctx && g && l && codes, "graph_search: NULL argument");
+    // Traversal: the graph's setting, overridden by JVECTOR_HIP_GRAPH_TRAVERSAL=host|device.  AUTO is the host
+    // traversal until the device kernel has been validated on hardware (it was written after this round's GPU budget
+    // was spent; tests/test_gsearch_emulated.py checks its logic on a CPU lane emulator).
+    int mode = g->traversal;
+    if (const char *e = getenv("JVECTOR_HIP_GRAPH_TRAVERSAL")) {
+        if (!strcmp(e, "device")) mode = JV_TRAVERSAL_DEVICE;
+        else if (!strcmp(e, "host")) mode = JV_TRAVERSAL_HOST;
+    }
+    if (mode != JV_TRAVERSAL_DEVICE || Q == 0) return graph_search_host(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats);
+
+    JV_REQUIRE(topK > 0, "graph_search: topK must be positive");
+    JV_REQUIRE(rerankK >= topK, "rerankK %d must be >= topK %d", rerankK, topK);  // GraphSearcher.java:233
+    JV_REQUIRE(g->entry_node >= 0, "graph_search: the graph has no entry node");
+    JV_REQUIRE(codes->pq == l->pq && codes->count >= g->n_nodes, "graph_search: code store does not match the graph");
+    JV_REQUIRE(!fused || (fused->pq == l->pq && fused->count == g->n_nodes && fused->maxDegree == g->levels[0].degree),
+               "graph_search: fused blocks do not match the graph");
+    JV_REQUIRE(!vectors || (vectors->D == l->pq->D && vectors->count >= g->n_nodes), "graph_search: vectors mismatch");
+    JV_REQUIRE(Q <= l->capacity, "graph_search: Q=%d exceeds the LUT capacity %d", Q, l->capacity);
+    int W = 0;
+    for (int lv = 0; lv <= g->entry_level; ++lv) {
+        JV_REQUIRE(g->levels[lv].count > 0, "graph_search: level %d was never set", lv);
+        W = std::max(W, g->levels[lv].degree);
+    }
+    JV_REQUIRE(queries && out_ids && out_scores, "graph_search: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    if (!graph_search_device_supported(l->pq, codes, fused, W, g->entry_level + 1)) {
+        set_error("graph_search: the device traversal needs uniform 8-dim sub-vectors, M in {16,32,48,64,96,128,192}, degree <= 64 "
+                  "and <= %d levels; use the host traversal", GS_MAX_LEVELS);
+        return JV_ERR_UNSUPPORTED;
+    }
+    return graph_search_device(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats);
 }
 
 }  // extern "C"

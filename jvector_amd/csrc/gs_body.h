@@ -39,54 +39,9 @@
 
 #include <cstdint>
 
+#include "gs_params.h"
+
 namespace jv {
-
-constexpr int GS_MAX_LEVELS = 32;
-constexpr int GS_EVICT_CAP = 128;
-enum : int32_t { GS_OK = 0, GS_OVERFLOW = 1 };
-
-struct GsLevel {
-    const int32_t *nbrs;    // count x degree, packed rows padded with -1
-    const int32_t *hkeys;   // upper levels: open-addressing map node id -> row (keys, -1 = empty); level 0: nullptr
-    const int32_t *hvals;
-    uint32_t hmask;         // table size - 1
-    int32_t hshift;         // 32 - log2(table size)
-    int32_t count, degree;
-};
-
-struct GsParams {
-    GsLevel lv[GS_MAX_LEVELS];
-    int32_t entry_node, entry_level;
-    // scoring
-    const float *codebooks;   // [M][256][8]
-    const float *cq;          // [Q][D] centred queries
-    const float *bmag;        // [Q] query magnitude (cosine)
-    const uint8_t *codes;     // [n][M]
-    const float *code_norms;  // [n] decoded magnitudes (cosine)
-    const uint8_t *blocks;    // layer-0 FusedPQ blocks [n][deg0][M], or nullptr
-    const float *fused_norms; // [n][deg0] (cosine)
-    int32_t D, M, deg0;
-    // search
-    int32_t Q, rerankK;
-    // per-worker scratch
-    int32_t *visited;         // [workers][1 << vcap_log2]
-    int32_t vcap_log2;
-    long long *spill;         // [workers][spill_cap]
-    int32_t spill_cap;
-    int32_t cand_cap;         // LDS tier capacity (>= 256)
-    // outputs
-    int32_t *out_ids;         // [Q][rerankK] kept approximate results (unordered), -1 padded
-    float *out_scores;        // [Q][rerankK] their approximate scores, -inf padded
-    long long *out_stats;     // [Q][2] visitedCount, expandedCount
-    int32_t *out_status;      // [Q] GS_OK / GS_OVERFLOW
-    uint32_t *next_query;     // work counter (zeroed by the host before the launch)
-};
-
-// LDS bytes one worker needs
-inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap)
-{
-    return sizeof(float) * (size_t)D + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + GS_EVICT_CAP + 64);
-}
 
 struct alignas(16) gs_f4 { float x, y, z, w; };
 struct alignas(16) gs_u4 { uint32_t x, y, z, w; };

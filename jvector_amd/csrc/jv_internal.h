@@ -75,6 +75,8 @@ struct jv_ctx {
     size_t lds_per_block = 65536;  // hipDeviceProp_t.sharedMemPerBlock / maxSharedMemoryPerMultiProcessor
     // staging: host->device inputs, device->host outputs (pinned), device scratch
     jv::Buffer h_in, h_out, d_in, d_out, d_scratch, d_scratch2, d_scratch3;
+    // device-resident graph traversal: per-worker visited tables / spill tiers and the per-query result staging
+    jv::Buffer d_gs_visited, d_gs_spill, d_gs_out;
     // host batched graph searcher: worker pool (graph_search.cpp owns the type) and its destructor
     void *host_pool = nullptr;
     void (*host_pool_destroy)(void *) = nullptr;
@@ -216,6 +218,11 @@ int launch_frontier(hipStream_t s, int vsf, const float *d_luts, const float *d_
                     const int32_t *d_origins, const int32_t *d_ord_index, const int32_t *d_ords, const jv_fused *fused,
                     const jv_codes *codes, float *d_out, int S, int W, const jv_pq *pq = nullptr,
                     const float *d_cq = nullptr);
+// device-resident graph traversal (k_gsearch.hip; parameters in gs_params.h)
+struct GsParams;
+bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels);
+size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap);
+int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers);
 size_t topk_scratch_bytes(int Q, int k);
 int launch_topk(hipStream_t s, const jv_ctx *ctx, const float *d_scores, const int32_t *d_ids, int Q, int64_t n,
                 int64_t stride, int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, void *d_scratch,

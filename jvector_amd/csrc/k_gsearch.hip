@@ -1,0 +1,86 @@
+// k_gsearch.hip — device-resident graph traversal: the whole GraphSearcher loop of a query runs inside one
+// 64-lane wavefront (body: gs_body.h, which the CPU tests also compile for a lane emulator).
+//
+// Why: the host batched searcher (graph_search.cpp) is bound by the HOST — ~1.2 us of heap / hash work per
+// expansion per core, 68 k QPS on the 16-core box while its scoring kernels occupy the GPU for 18 % of the step.
+// Moving the three queues and the visited set next to the scoring removes the per-round PCIe exchange, the worker
+// pool and the dependence on host cores (which N > 1 ranks have to share).  Per expansion a wave reads one adjacency
+// row (128 B) and, with FusedPQ, one packed block (maxDegree x M = 3 KB) from HBM; everything else (candidate and
+// result arrays, the centred query) lives in LDS, the visited table and the rarely touched spill tier in L2/MALL, and
+// the codebook (768 KB) is shared by every wave through L2.  Launch: persistent waves, one per block, several
+// blocks per CU (LDS-limited), pulling queries from an atomic counter — queries differ 2-3x in length, and a
+// static split would leave CUs idle at the tail.  XCD placement needs no remapping: a worker touches only its own
+// scratch plus read-only data shared by all.
+#include "jv_device.h"
+#include "jv_internal.h"
+
+#define GS_FN __device__ __forceinline__
+__device__ __forceinline__ int gs_lane() { return (int)threadIdx.x; }
+__device__ __forceinline__ void gs_barrier() { __syncthreads(); }
+__device__ __forceinline__ uint64_t gs_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
+__device__ __forceinline__ long long gs_shfl(long long v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ long long gs_shfl_xor(long long v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired) { return atomicCAS(p, expect, desired); }
+__device__ __forceinline__ uint32_t gs_fetch_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ void gs_fence() { __threadfence(); }
+__device__ __forceinline__ double gs_sqrt(double x) { return sqrt(x); }
+
+#include "gs_body.h"
+
+namespace jv {
+
+static_assert(VSF_L2 == 0 && VSF_DOT == 1 && VSF_COS == 2, "gs_body.h hard-codes the kernel vsf numbering");
+
+template <int VSF, int CH16>
+__global__ __launch_bounds__(64) void graph_search_kernel(GsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char gs_lds[];
+    gs_worker<VSF, CH16>(p, (int)blockIdx.x, gs_lds);
+}
+
+template <int VSF>
+static int launch_gs_ch(hipStream_t s, const GsParams &p, int ch, int workers, size_t lds)
+{
+    dim3 grid(workers), block(64);
+#define JV_GS(CH) hipLaunchKernelGGL((graph_search_kernel<VSF, CH>), grid, block, lds, s, p)
+    switch (ch) {
+    case 1: JV_GS(1); break;
+    case 2: JV_GS(2); break;
+    case 3: JV_GS(3); break;
+    case 4: JV_GS(4); break;
+    case 6: JV_GS(6); break;
+    case 8: JV_GS(8); break;
+    case 12: JV_GS(12); break;
+    default:
+        set_error("graph search kernel: M = %d is not one of 16, 32, 48, 64, 96, 128, 192", ch * 16);
+        return JV_ERR_UNSUPPORTED;
+    }
+#undef JV_GS
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels)
+{
+    const int ch = pq->M / 16;
+    return pq->uniform && pq->max_size == 8 && pq->k == kClusters && pq->M % 16 == 0 &&
+           (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8 || ch == 12) && pq->D == 8 * pq->M &&
+           (reinterpret_cast<uintptr_t>(codes->d_codes) & 15) == 0 &&
+           (!fused || (reinterpret_cast<uintptr_t>(fused->d_blocks) & 15) == 0) && max_degree <= 64 &&
+           n_levels <= GS_MAX_LEVELS;
+}
+
+size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap) { return gs_lds_bytes(D, rerankK, cand_cap); }
+
+int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers)
+{
+    if (p.Q == 0) return JV_OK;
+    const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap);
+    switch (vsf) {
+    case VSF_L2: return launch_gs_ch<VSF_L2>(s, p, p.M / 16, workers, lds);
+    case VSF_DOT: return launch_gs_ch<VSF_DOT>(s, p, p.M / 16, workers, lds);
+    default: return launch_gs_ch<VSF_COS>(s, p, p.M / 16, workers, lds);
+    }
+}
+
+}  // namespace jv

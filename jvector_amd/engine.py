@@ -435,6 +435,14 @@ class GraphIndex:
                                                    nb.shape[1]))
         check(self._lib.jv_hip_graph_set_entry(h, int(entry_node), int(entry_level)))
 
+    TRAVERSAL = {"auto": 0, "host": 1, "device": 2}
+
+    def set_traversal(self, mode: str):
+        """Where the traversal state lives: "host" (worker pool + GPU frontier scoring), "device" (one wavefront per
+        query runs the whole loop on the GPU) or "auto" (currently host).  Results are identical."""
+        check(self._lib.jv_hip_graph_set_traversal(self._h, self.TRAVERSAL[mode]))
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.jv_hip_graph_destroy(self._h)
