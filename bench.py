@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95")
     ap.add_argument("--eval-queries", type=int, default=1024, help="timed queries with ground truth (recall)")
+    ap.add_argument("--traversal", choices=["host", "device"], default=os.environ.get("JVECTOR_BENCH_TRAVERSAL", "host"),
+                    help="graph mode: host batched searcher (default, hardware-verified) or the device-resident traversal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat", action="store_true", help="graph mode: skip the secondary flat-scan measurement")
     args = ap.parse_args()
@@ -156,7 +158,7 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     host_cores = max(1, effective_cpus() // max(1, local_world))
     if args.mode == "auto":
-        args.mode = "graph" if host_cores >= 8 else "flat"
+        args.mode = "graph" if (host_cores >= 8 or args.traversal == "device") else "flat"
     graph_mode = args.mode == "graph"
     Q = args.queries or (16384 if graph_mode else 256)
     t_setup = time.perf_counter()
@@ -180,7 +182,7 @@ def main():
         tb = time.perf_counter()
         levels, entry, entry_level, nbrs_dev = build_hier_graph(base, max_degree=args.degree)
         fused = J.FusedPQ(ctx, pq, fused_blocks_from(codes_t, nbrs_dev), nbrs_dev)
-        graph = J.GraphIndex(ctx, N, levels, entry, entry_level)
+        graph = J.GraphIndex(ctx, N, levels, entry, entry_level).set_traversal(args.traversal)
         searcher = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=Q)
         torch.cuda.synchronize()
         build_s = time.perf_counter() - tb
@@ -272,6 +274,12 @@ def main():
                 "launch scores only ~2k expansions x maxDegree candidates and overlaps the other slot group's host phase; "
                 "see kernel_ms_per_step vs ms_per_step and DESIGN.md §5")
         tfile = "graph_traffic_r1.json"
+        if args.traversal == "device":
+            kernel = "graph_search_kernel<COSINE,CH16=6> (device-resident traversal: one wavefront per query, queues in LDS, " \
+                     "table-free FusedPQ block scoring; one persistent launch per query batch)"
+            note = ("whole GraphSearcher loop on the GPU; algorithmic bytes = expansions x (maxDegree*M block bytes + "
+                    "4*maxDegree scores), the launch also carries the queue and visited-set work")
+            tfile = "gsearch_traffic.json"
     else:
         bytes_per_launch = float(Q) * N * (M + 4)
         kernel = "adc_mq_kernel<COSINE,SLCH=2,R=8,FILTER> (threshold-filtered multi-query ADC scan of all N codes; " \
@@ -343,10 +351,10 @@ def main():
             "config": {"workload": (f"synthetic {N}x{D} cosine (latent-32 mixture of 1000 clusters, unit norm), PQ-{M} (k=256, "
                                     f"Lloyd x6 on a 128k sample), " +
                                     (f"FusedADC graph search: synthetic kNN+robust-prune graph (maxDegree {args.degree}, {len(levels)} nested levels), "
-                                     f"host batched GraphSearcher, GPU fused-block scoring, rerankK {rerank_k} -> exact rerank -> top-{K}"
+                                     f"{'device-resident GraphSearcher (one wavefront per query)' if args.traversal == 'device' else 'host batched GraphSearcher, GPU fused-block scoring'}, rerankK {rerank_k} -> exact rerank -> top-{K}"
                                      if graph_mode else
                                      f"two-pass flat search: ADC scan of all codes -> top-{rerank_k} -> exact rerank -> top-{K}")),
-                       "mode": args.mode, "n_vectors": N, "dim": D, "pq_subspaces": M, "queries_per_step": Q, "topK": K,
+                       "mode": args.mode, "traversal": args.traversal if graph_mode else None, "n_vectors": N, "dim": D, "pq_subspaces": M, "queries_per_step": Q, "topK": K,
                        "rerankK": rerank_k, "similarity": "COSINE",
                        "parallelism": "1 GPU" if world == 1 else f"{world} replicas, queries sharded, no collective"},
             "recall_at_10": rec, "recall_ok": rec >= 0.95, "recall_eval_queries": n_eval,

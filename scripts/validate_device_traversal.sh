@@ -1,0 +1,21 @@
+#!/bin/bash
+# First hardware run of the device-resident graph traversal (k_gsearch.hip).  Run through gpurun, e.g.
+#   gpurun --timeout 1500 -- 'bash scripts/validate_device_traversal.sh'
+# Steps are ordered cheapest-first and each is bounded by its own timeout so that a hang costs minutes, not the box.
+set -u
+mkdir -p gpurun_out/gs
+export JVECTOR_TEST_DEVICE_TRAVERSAL=1
+# 1. parity on small graphs (5 shapes x 3 similarity functions, partitions/spills, refusal of unsupported shapes)
+timeout 600 python -m pytest tests/test_zz_device_traversal_gpu.py -x -q 2>&1 | tail -15 | tee gpurun_out/gs/pytest.log
+# 2. 1M-vector bench, both traversals, same index (about a minute each)
+for t in host device; do
+  JVECTOR_HIP_GRAPH_TIMING=1 timeout 600 python bench.py --n 1000000 --steps 5 --warmup 1 --no-flat --no-cpu-baseline \
+      --traversal $t > gpurun_out/gs/bench_1m_$t.json 2> gpurun_out/gs/bench_1m_$t.err
+  tail -c 600 gpurun_out/gs/bench_1m_$t.err; head -c 400 gpurun_out/gs/bench_1m_$t.json; echo
+done
+# 3. the headline configuration with the device traversal
+if [ "${GS_FULL:-1}" = "1" ]; then
+  JVECTOR_HIP_GRAPH_TIMING=1 timeout 900 python bench.py --traversal device > gpurun_out/gs/bench_10m_device.json \
+      2> gpurun_out/gs/bench_10m_device.err
+  tail -c 800 gpurun_out/gs/bench_10m_device.err; cat gpurun_out/gs/bench_10m_device.json
+fi
