@@ -140,8 +140,14 @@ static float rd_f32(const uint8_t *p)
     return f;
 }
 
+// The per-code cosine magnitudes are a lazily built, query-independent cache shared by every context that uses the
+// code store: build under a lock and drain the building stream before publishing, so a second context (another
+// host thread, another stream) never reads a half-written table.
+static std::mutex g_norms_mu;
+
 int ensure_code_norms(jv_ctx *ctx, jv_codes *codes)
 {
+    std::lock_guard<std::mutex> lk(g_norms_mu);
     if (codes->norms_valid) return JV_OK;
     if (!codes->d_norms) JV_HIP_CHECK(hipMalloc((void **)&codes->d_norms, sizeof(float) * (size_t)std::max<int64_t>(codes->count, 1)));
     {
@@ -149,16 +155,19 @@ int ensure_code_norms(jv_ctx *ctx, jv_codes *codes)
         JV_TRY(launch_code_norms(ctx->stream, ctx, codes->pq->d_self_mag, codes->M, codes->d_codes, codes->count,
                                  codes->d_norms));
     }
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     codes->norms_valid = true;
     return JV_OK;
 }
 
 int ensure_fused_norms(jv_ctx *ctx, jv_fused *f)
 {
+    std::lock_guard<std::mutex> lk(g_norms_mu);
     if (f->norms_valid) return JV_OK;
     const int64_t rows = f->count * f->maxDegree;
     if (!f->d_norms) JV_HIP_CHECK(hipMalloc((void **)&f->d_norms, sizeof(float) * (size_t)std::max<int64_t>(rows, 1)));
     JV_TRY(launch_code_norms(ctx->stream, ctx, f->pq->d_self_mag, f->M, f->d_blocks, rows, f->d_norms));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     f->norms_valid = true;
     return JV_OK;
 }

@@ -117,13 +117,18 @@ GS_FN long long gs_scan_extreme(const long long *a, int n, int *idx_out)
 // ---- table-free ADC row score: DefaultVectorUtilSupport.calculatePartialSums (:351-365) entry by entry, summed in
 //      ascending m (assembleAndSum :323-330).  qs = the centred query in LDS.  Same arithmetic as
 //      frontier_direct_kernel; -ffp-contract=off keeps every mul and add separate.
-template <int VSF, int CH16>
-GS_FN float gs_row_sum(const float *codebooks, const float *qs, const uint8_t *rp)
+// the M code bytes of one row as CH16 16-byte words (issued early: their latency hides behind the visited-set probes)
+template <int CH16>
+GS_FN void gs_load_row(const uint8_t *rp, gs_u4 (&w)[CH16])
 {
     const gs_u4 *r4 = reinterpret_cast<const gs_u4 *>(rp);
-    gs_u4 w[CH16];
 #pragma unroll
     for (int c = 0; c < CH16; ++c) w[c] = r4[c];
+}
+
+template <int VSF, int CH16>
+GS_FN float gs_row_sum(const float *codebooks, const float *qs, const gs_u4 (&w)[CH16])
+{
     float sum = 0.0f;
 #pragma unroll
     for (int c = 0; c < CH16; ++c) {
@@ -314,7 +319,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     {
         const int32_t e = p.entry_node;
         if (lane == 0) (void)gs_visit(vis, vmask, vshift, e);
-        float sc = gs_row_sum<VSF, CH16>(p.codebooks, qs, p.codes + (int64_t)e * p.M);
+        gs_u4 we[CH16];
+        gs_load_row<CH16>(p.codes + (int64_t)e * p.M, we);
+        float sc = gs_row_sum<VSF, CH16>(p.codebooks, qs, we);
         sc = gs_finish<VSF>(sc, (VSF == 2) ? p.code_norms[e] : 0.0f, query_mag);
         if (lane == 0) s.cand[0] = gs_key(e, sc);
         s.cand_n = 1;
@@ -380,8 +387,22 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             if (!row) continue;
             const int deg = L.degree;
             const int32_t nb = lane < deg ? row[lane] : -1;
+            // code bytes first, then the visited probes: the loads do not depend on the probes' outcome
+            gs_u4 w[CH16];
+            float node_mag = 0.0f;
+            const bool fused0 = lvl == 0 && p.blocks != nullptr;
+            if (fused0 && lane < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
+                const int64_t r = (int64_t)node * p.deg0 + lane;
+                gs_load_row<CH16>(p.blocks + r * p.M, w);
+                if (VSF == 2) node_mag = p.fused_norms[r];
+            }
             const int first_neg = gs_first(gs_ballot(nb < 0));  // rows are packed: the first -1 ends the row
-            const bool fresh = lane < first_neg && gs_visit(vis, vmask, vshift, nb);
+            const bool valid = lane < first_neg;
+            if (!fused0 && valid) {      // PQDecoder.similarityTo: the neighbour's own code
+                gs_load_row<CH16>(p.codes + (int64_t)nb * p.M, w);
+                if (VSF == 2) node_mag = p.code_norms[nb];
+            }
+            const bool fresh = valid && gs_visit(vis, vmask, vshift, nb);
             const uint64_t fm = gs_ballot(fresh);
             if (fm == 0) continue;
             n_visited += gs_popc(fm);
@@ -390,20 +411,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 break;
             }
             long long key = 0;
-            if (fresh) {
-                const uint8_t *rp;
-                float node_mag = 0.0f;
-                if (lvl == 0 && p.blocks) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block
-                    const int64_t r = (int64_t)node * p.deg0 + lane;
-                    rp = p.blocks + r * p.M;
-                    if (VSF == 2) node_mag = p.fused_norms[r];
-                } else {                     // PQDecoder.similarityTo: the neighbour's own code
-                    rp = p.codes + (int64_t)nb * p.M;
-                    if (VSF == 2) node_mag = p.code_norms[nb];
-                }
-                const float sum = gs_row_sum<VSF, CH16>(p.codebooks, qs, rp);
-                key = gs_key(nb, gs_finish<VSF>(sum, node_mag, query_mag));
-            }
+            if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CH16>(p.codebooks, qs, w), node_mag, query_mag));
             gs_push(s, p, key, fresh);
             if (s.status != GS_OK) break;
         }
