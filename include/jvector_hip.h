@@ -263,6 +263,35 @@ JV_API int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *luts, co
                                const jv_fused *fused, const jv_vectors *vectors, const float *queries, int Q,
                                jv_vsf vsf, int topK, int rerankK, int32_t *out_ids, float *out_scores, int64_t *stats);
 
+/* ---------------------------------------------------------------------------------------------
+ * Build-time scoring: the PQ-only score functions graph construction uses
+ * (BuildScoreProvider.pqBuildScoreProvider, B/graph/similarity/BuildScoreProvider.java:167-212), batched.
+ *   pair table   = ProductQuantization.createCodebookPartialSums(vsf) (ProductQuantization.java:609-628): per subspace
+ *                  the upper triangle of centroid x centroid dot products (DOT_PRODUCT, COSINE) or squared distances
+ *                  (EUCLIDEAN); M * k(k+1)/2 floats, built once per (pq, vsf) and kept on the device.
+ *   code_pair_scores[p][b] = ImmutablePQVectors.diversityFunctionFor(node1[p], vsf).similarityTo(node2[p*B + b])
+ *                  (ImmutablePQVectors.java:61-104 -> VectorUtil.assembleAndSumPQ, DefaultVectorUtilSupport.java:312-335,
+ *                  native jvector_simd_kernels.cpp:729-815): the candidate x selected score blocks of
+ *                  VamanaDiversityProvider.retainDiverse.  Ordinals outside [0, count) (e.g. -1 padding) give -inf.
+ *   pq_decode    = ProductQuantization.decode (ProductQuantization.java:454-471) of `count` codes (the rows `ordinals`
+ *                  lists, or first..first+count when ordinals is NULL): pqBuildScoreProvider.searchProviderFor(node1)
+ *                  searches from the DECODED vector (feed the result to jv_hip_luts_build).
+ *   direct_scores[q][b] = PQVectors.scoreFunctionFor(query q, vsf).similarityTo(ordinals[q*B + b])
+ *                  (PQVectors.java:223-281): query vs code without a look-up table.
+ * Pointers may be host or device memory, as everywhere in this header.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct jv_pair_table jv_pair_table;
+JV_API int jv_hip_pair_table_create(jv_ctx *ctx, const jv_pq *pq, jv_vsf vsf, jv_pair_table **out);
+JV_API int64_t jv_hip_pair_table_size(const jv_pair_table *t); /* number of floats */
+JV_API int jv_hip_pair_table_download(jv_ctx *ctx, const jv_pair_table *t, float *dst);
+JV_API int jv_hip_pair_table_destroy(jv_pair_table *t);
+JV_API int jv_hip_code_pair_scores(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *codes, const int32_t *node1, int P,
+                                   const int32_t *node2, int B, float *scores_out);
+JV_API int jv_hip_pq_decode(jv_ctx *ctx, const jv_codes *codes, const int32_t *ordinals, int64_t first, int64_t count,
+                            float *vectors_out);
+JV_API int jv_hip_direct_scores(jv_ctx *ctx, const jv_codes *codes, const float *queries, int Q, jv_vsf vsf,
+                                const int32_t *ordinals, int B, float *scores_out);
+
 #ifdef __cplusplus
 }
 #endif

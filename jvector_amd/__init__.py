@@ -13,6 +13,7 @@ from .engine import (  # noqa: F401
     GraphIndex,
     GraphSearcher,
     HipContext,
+    PQBuildScoreProvider,
     PQVectors,
     ProductQuantization,
     QueryTables,

@@ -81,6 +81,13 @@ SIGNATURES = {
     "jv_hip_graph_set_entry": (_i, [_p, C.c_int32, _i]),
     "jv_hip_graph_destroy": (_i, [_p]),
     "jv_hip_graph_set_traversal": (_i, [_p, _i]),
+    "jv_hip_pair_table_create": (_i, [_p, _p, _i, C.POINTER(_p)]),
+    "jv_hip_pair_table_size": (_i64, [_p]),
+    "jv_hip_pair_table_download": (_i, [_p, _p, _p]),
+    "jv_hip_pair_table_destroy": (_i, [_p]),
+    "jv_hip_code_pair_scores": (_i, [_p, _p, _p, _p, _i, _p, _i, _p]),
+    "jv_hip_pq_decode": (_i, [_p, _p, _p, _i64, _i64, _p]),
+    "jv_hip_direct_scores": (_i, [_p, _p, _p, _i, _i, _p, _i, _p]),
     "jv_hip_graph_search": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
 }
 

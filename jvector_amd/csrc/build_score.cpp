@@ -1,0 +1,138 @@
+// build_score.cpp — C ABI of the build-time scoring entry points (kernels in k_build_score.hip).
+#include "jv_internal.h"
+
+using namespace jv;
+
+struct jv_pair_table {
+    int device = 0;
+    const jv_pq *pq = nullptr;
+    jv_vsf vsf = JV_EUCLIDEAN;
+    float *d_tri = nullptr;
+    int64_t floats = 0;
+};
+
+extern "C" {
+
+int jv_hip_pair_table_create(jv_ctx *ctx, const jv_pq *pq, jv_vsf vsf, jv_pair_table **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && out, "pair_table_create: NULL argument");
+    JV_REQUIRE(vsf == JV_EUCLIDEAN || vsf == JV_DOT_PRODUCT || vsf == JV_COSINE, "Unsupported similarity function %d", (int)vsf);
+    JV_TRY(use_device(ctx->device));
+    jv_pair_table *t = new jv_pair_table();
+    t->device = ctx->device;
+    t->pq = pq;
+    t->vsf = vsf;
+    t->floats = (int64_t)pq->M * pq->k * (pq->k + 1) / 2;
+    hipError_t e = hipMalloc((void **)&t->d_tri, sizeof(float) * (size_t)t->floats);
+    if (e != hipSuccess) {
+        set_error("pair_table_create: hipMalloc of %lld floats failed: %s", (long long)t->floats, hipGetErrorString(e));
+        (void)hipGetLastError();
+        delete t;
+        return JV_ERR_OOM;
+    }
+    int st = launch_pair_table(ctx->stream, pq, to_kernel_vsf(vsf), t->d_tri);
+    if (st == JV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {  // shared by every context that uses the table
+        set_error("pair_table_create: kernel failed");
+        st = JV_ERR_HIP;
+    }
+    if (st != JV_OK) {
+        (void)hipFree(t->d_tri);
+        delete t;
+        return st;
+    }
+    *out = t;
+    return JV_OK;
+}
+
+int64_t jv_hip_pair_table_size(const jv_pair_table *t) { return t ? t->floats : 0; }
+
+int jv_hip_pair_table_download(jv_ctx *ctx, const jv_pair_table *t, float *dst)
+{
+    clear_error();
+    JV_REQUIRE(ctx && t && dst, "pair_table_download: NULL argument");
+    JV_TRY(use_device(ctx->device));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    JV_HIP_CHECK(hipMemcpy(dst, t->d_tri, sizeof(float) * (size_t)t->floats, hipMemcpyDefault));
+    return JV_OK;
+}
+
+int jv_hip_pair_table_destroy(jv_pair_table *t)
+{
+    if (!t) return JV_OK;
+    (void)hipSetDevice(t->device);
+    (void)hipFree(t->d_tri);
+    delete t;
+    return JV_OK;
+}
+
+int jv_hip_code_pair_scores(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *codes, const int32_t *node1, int P,
+                            const int32_t *node2, int B, float *scores_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && t && codes, "code_pair_scores: NULL argument");
+    JV_REQUIRE(codes->pq == t->pq, "code_pair_scores: the code store and the pair table use different codebooks");
+    JV_REQUIRE(P >= 0 && B >= 0, "code_pair_scores: negative sizes");
+    if (P == 0 || B == 0) return JV_OK;
+    JV_REQUIRE(node1 && node2 && scores_out, "code_pair_scores: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    const void *d_n1 = nullptr, *d_n2 = nullptr;
+    JV_TRY(stage_in(ctx, node1, sizeof(int32_t) * (size_t)P, ctx->h_in, ctx->d_in, &d_n1));
+    JV_TRY(stage_in(ctx, node2, sizeof(int32_t) * (size_t)P * B, ctx->h_in, ctx->d_scratch2, &d_n2));
+    OutStage os;
+    JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)P * B, ctx->d_out, &os));
+    {
+        ProfScope ps(ctx, R_ADC);
+        JV_TRY(launch_pair_scores(ctx->stream, t->d_tri, to_kernel_vsf(t->vsf), codes, (const int32_t *)d_n1, P,
+                                  (const int32_t *)d_n2, B, (float *)os.dev));
+    }
+    return stage_out_end(ctx, os);
+}
+
+int jv_hip_pq_decode(jv_ctx *ctx, const jv_codes *codes, const int32_t *ordinals, int64_t first, int64_t count, float *vectors_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && codes, "pq_decode: NULL argument");
+    JV_REQUIRE(count >= 0, "pq_decode: negative count");
+    JV_REQUIRE(ordinals || (first >= 0 && first + count <= codes->count), "Ordinal range out of bounds");
+    if (count == 0) return JV_OK;
+    JV_REQUIRE(vectors_out, "pq_decode: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    const void *d_ord = nullptr;
+    if (ordinals) JV_TRY(stage_in(ctx, ordinals, sizeof(int32_t) * (size_t)count, ctx->h_in, ctx->d_in, &d_ord));
+    OutStage os;
+    JV_TRY(stage_out_begin(ctx, vectors_out, sizeof(float) * (size_t)count * codes->pq->D, ctx->d_out, &os));
+    JV_TRY(launch_pq_decode(ctx->stream, codes, (const int32_t *)d_ord, first, count, (float *)os.dev));
+    return stage_out_end(ctx, os);
+}
+
+int jv_hip_direct_scores(jv_ctx *ctx, const jv_codes *codes, const float *queries, int Q, jv_vsf vsf, const int32_t *ordinals,
+                         int B, float *scores_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && codes, "direct_scores: NULL argument");
+    JV_REQUIRE(vsf == JV_EUCLIDEAN || vsf == JV_DOT_PRODUCT || vsf == JV_COSINE, "Unsupported similarity function %d", (int)vsf);
+    JV_REQUIRE(Q >= 0 && B >= 0, "direct_scores: negative sizes");
+    if (Q == 0 || B == 0) return JV_OK;
+    JV_REQUIRE(queries && ordinals && scores_out, "direct_scores: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    const jv_pq *pq = codes->pq;
+    const void *d_q = nullptr, *d_ord = nullptr;
+    JV_TRY(stage_in(ctx, queries, sizeof(float) * (size_t)Q * pq->D, ctx->h_in, ctx->d_in, &d_q));
+    JV_TRY(stage_in(ctx, ordinals, sizeof(int32_t) * (size_t)Q * B, ctx->h_in, ctx->d_scratch2, &d_ord));
+    // centred queries + their norms
+    JV_TRY(ctx->d_scratch3.reserve(sizeof(float) * ((size_t)Q * pq->D + (size_t)Q) + 256));
+    float *d_cq = (float *)ctx->d_scratch3.ptr;
+    float *d_qnorm = d_cq + (size_t)Q * pq->D;
+    JV_TRY(launch_center_queries(ctx->stream, pq, (const float *)d_q, Q, d_cq));
+    OutStage os;
+    JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)Q * B, ctx->d_out, &os));
+    {
+        ProfScope ps(ctx, R_ADC);
+        JV_TRY(launch_direct_scores(ctx->stream, codes, to_kernel_vsf(vsf), d_cq, Q, (const int32_t *)d_ord, B, d_qnorm,
+                                    (float *)os.dev));
+    }
+    return stage_out_end(ctx, os);
+}
+
+}  // extern "C"

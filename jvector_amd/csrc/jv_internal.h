@@ -218,6 +218,13 @@ int launch_frontier(hipStream_t s, int vsf, const float *d_luts, const float *d_
                     const int32_t *d_origins, const int32_t *d_ord_index, const int32_t *d_ords, const jv_fused *fused,
                     const jv_codes *codes, float *d_out, int S, int W, const jv_pq *pq = nullptr,
                     const float *d_cq = nullptr);
+// build-time scoring (k_build_score.hip)
+int launch_pair_table(hipStream_t s, const jv_pq *pq, int vsf, float *d_out);
+int launch_pair_scores(hipStream_t s, const float *d_tri, int vsf, const jv_codes *codes, const int32_t *d_node1, int P,
+                       const int32_t *d_node2, int B, float *d_out);
+int launch_pq_decode(hipStream_t s, const jv_codes *codes, const int32_t *d_ordinals, int64_t first, int64_t count, float *d_out);
+int launch_direct_scores(hipStream_t s, const jv_codes *codes, int vsf, const float *d_cq, int Q, const int32_t *d_ordinals, int B,
+                         float *d_qnorm, float *d_out);
 // device-resident graph traversal (k_gsearch.hip; parameters in gs_params.h)
 struct GsParams;
 bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels);

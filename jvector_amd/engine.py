@@ -266,6 +266,16 @@ class PQVectors:
         check(self._lib.jv_hip_codes_download(self.ctx._h, self._h, int(first), int(n), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def direct_scores(self, queries, vsf, ordinals):
+        """PQVectors.scoreFunctionFor(q, vsf).similarityTo(node) (:223-281) for ordinals[Q, B]: no look-up table."""
+        Q, B = int(ordinals.shape[0]), int(ordinals.shape[1])
+        q_p, kq = _ptr(queries, np.float32)
+        o_p, ko = _ptr(ordinals, np.int32)
+        out = _empty((Q, B), np.float32, ordinals)
+        s_p, ks = _ptr(out, np.float32)
+        check(self._lib.jv_hip_direct_scores(self.ctx._h, self._h, q_p, Q, int(vsf), o_p, B, s_p))
+        return out
+
     def precomputed_score_function_for(self, queries, vsf, luts=None):
         """PQVectors.precomputedScoreFunctionFor (:210-221), batched over Q queries."""
         luts = luts or QueryTables(self.ctx, self.pq, int(queries.shape[0]))
@@ -276,6 +286,49 @@ class PQVectors:
         if getattr(self, "_h", None):
             self._lib.jv_hip_codes_destroy(self._h)
             self._h = None
+
+
+class PQBuildScoreProvider:
+    """Batched BuildScoreProvider.pqBuildScoreProvider (B/graph/similarity/BuildScoreProvider.java:167-212): the PQ-only
+    score functions graph construction uses, over device-resident codes."""
+
+    def __init__(self, ctx, pq_vectors: "PQVectors", vsf):
+        self.ctx, self._lib, self.cv, self.vsf = ctx, ctx._lib, pq_vectors, vsf
+        h = C.c_void_p()
+        check(self._lib.jv_hip_pair_table_create(ctx._h, pq_vectors.pq._h, int(vsf), C.byref(h)))
+        self._h = h
+
+    def codebook_partial_sums(self):
+        """ProductQuantization.createCodebookPartialSums(vsf) (:609-628) as a host array."""
+        out = np.empty(int(self._lib.jv_hip_pair_table_size(self._h)), np.float32)
+        check(self._lib.jv_hip_pair_table_download(self.ctx._h, self._h, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def diversity_scores(self, node1, node2):
+        """scores[p, b] = diversityScoreFunctionFor(node1[p]).similarityTo(node2[p, b]); ordinals < 0 give -inf."""
+        P, B = int(node2.shape[0]), int(node2.shape[1])
+        n1_p, k1 = _ptr(node1, np.int32)
+        n2_p, k2 = _ptr(node2, np.int32)
+        out = _empty((P, B), np.float32, node2)
+        o_p, ko = _ptr(out, np.float32)
+        check(self._lib.jv_hip_code_pair_scores(self.ctx._h, self._h, self.cv._h, n1_p, P, n2_p, B, o_p))
+        return out
+
+    def decode(self, ordinals):
+        """ProductQuantization.decode of the listed codes (searchProviderFor(node1) searches from this vector)."""
+        n = int(ordinals.shape[0])
+        o_p, ko = _ptr(ordinals, np.int32)
+        out = _empty((n, self.cv.pq.original_dimension), np.float32, ordinals)
+        v_p, kv = _ptr(out, np.float32)
+        check(self._lib.jv_hip_pq_decode(self.ctx._h, self.cv._h, o_p, 0, n, v_p))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_pair_table_destroy(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 class QueryTables:

@@ -325,6 +325,45 @@ void jvo_pq_codebook_partial_sums(const jvo_pq *pq, int vsf, float *out)
     }
 }
 
+/* ImmutablePQVectors.diversityFunctionFor(node1, vsf).similarityTo(node2) :61-104 — via the triangular table
+ * (VectorUtil.assembleAndSumPQ); cosine: sum / (float) Math.sqrt(norm1 * norm2), a FLOAT division (:88). */
+float jvo_pq_diversity_score(const float *tri, int M, int k, int vsf, const uint8_t *code1, const uint8_t *code2)
+{
+    float sum = jvo_assemble_and_sum_pq(tri, M, code1, 0, code2, 0, k);
+    if (vsf == JVO_DOT_PRODUCT) return (1.0f + sum) / 2.0f;
+    if (vsf == JVO_EUCLIDEAN) return 1.0f / (1.0f + sum);
+    float norm1 = jvo_assemble_and_sum_pq(tri, M, code1, 0, code1, 0, k);
+    float norm2 = jvo_assemble_and_sum_pq(tri, M, code2, 0, code2, 0, k);
+    float prod = norm1 * norm2;
+    float cosine = sum / (float)sqrt((double)prod);
+    return (1.0f + cosine) / 2.0f;
+}
+
+/* PQVectors.diversityFunctionFor (the MutablePQVectors path) :284-345 — straight from the codebooks; must equal the
+ * table path bit for bit (same per-subspace dot / distance, same ascending-m sum). */
+float jvo_pq_diversity_score_direct(const jvo_pq *pq, int vsf, const uint8_t *code1, const uint8_t *code2)
+{
+    float sum = 0.0f, norm1 = 0.0f, norm2 = 0.0f;
+    size_t cboff = 0;
+    for (int m = 0; m < pq->M; m++) {
+        int len = pq->sizes[m];
+        const float *cb = pq->codebooks + cboff;
+        if (vsf == JVO_EUCLIDEAN) sum += jvo_l2_off(cb, code1[m] * len, cb, code2[m] * len, len);
+        else if (vsf == JVO_DOT_PRODUCT) sum += jvo_dot_off(cb, code1[m] * len, cb, code2[m] * len, len);
+        else {
+            sum += jvo_dot_off(cb, code2[m] * len, cb, code1[m] * len, len);
+            norm2 += jvo_dot_off(cb, code2[m] * len, cb, code2[m] * len, len);
+            norm1 += jvo_dot_off(cb, code1[m] * len, cb, code1[m] * len, len);
+        }
+        cboff += (size_t)pq->k * len;
+    }
+    if (vsf == JVO_DOT_PRODUCT) return (1.0f + sum) / 2.0f;
+    if (vsf == JVO_EUCLIDEAN) return 1.0f / (1.0f + sum);
+    float prod = norm1 * norm2;
+    float cosine = sum / (float)sqrt((double)prod);
+    return (1.0f + cosine) / 2.0f;
+}
+
 /* ------------------------------------------------------------------------------------------
  * PQDecoder / FusedPQDecoder set-up and per-node scores
  * ---------------------------------------------------------------------------------------- */

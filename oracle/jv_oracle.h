@@ -82,6 +82,8 @@ void jvo_pq_encode_all(const jvo_pq *pq, const float *vecs, int64_t n, uint8_t *
 void jvo_pq_decode(const jvo_pq *pq, const uint8_t *code, float *dst);
 /* createCodebookPartialSums: M*k*(k+1)/2 floats */
 void jvo_pq_codebook_partial_sums(const jvo_pq *pq, int vsf, float *out);
+float jvo_pq_diversity_score(const float *tri, int M, int k, int vsf, const uint8_t *code1, const uint8_t *code2);
+float jvo_pq_diversity_score_direct(const jvo_pq *pq, int vsf, const uint8_t *code1, const uint8_t *code2);
 
 /* PQDecoder (precomputedScoreFunctionFor): builds LUT (M*k floats), for cosine also the
  * aMagnitude table and bMagnitude.  lut/amag caller-allocated; amag/bmag may be NULL unless cosine. */

@@ -114,6 +114,8 @@ def lib():
         sig("jvo_adc_score", C.c_float, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, u8p)
         sig("jvo_adc_scores", None, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, u8p, i32p, C.c_int64, fp)
         sig("jvo_pq_direct_score", C.c_float, pqp, fp, C.c_int, u8p)
+        sig("jvo_pq_diversity_score", C.c_float, fp, C.c_int, C.c_int, C.c_int, u8p, u8p)
+        sig("jvo_pq_diversity_score_direct", C.c_float, pqp, C.c_int, u8p, u8p)
         sig("jvo_float_to_sortable_int", C.c_int32, C.c_float)
         sig("jvo_sortable_int_to_float", C.c_float, C.c_int32)
         sig("jvo_nodequeue_encode", C.c_int64, C.c_int32, C.c_float)
@@ -340,6 +342,16 @@ class OraclePQ:
     def direct_score(self, query, vsf, code):
         query, code = f32(query), np.ascontiguousarray(code, np.uint8)
         return float(lib().jvo_pq_direct_score(self.ref, _f(query), vsf, _u8(code)))
+
+    def diversity_score(self, tri, vsf, code1, code2):
+        """ImmutablePQVectors.diversityFunctionFor(node1, vsf).similarityTo(node2) on the triangular table `tri`."""
+        c1, c2 = np.ascontiguousarray(code1, np.uint8), np.ascontiguousarray(code2, np.uint8)
+        return float(lib().jvo_pq_diversity_score(_f(tri), self.M, self.k, vsf, _u8(c1), _u8(c2)))
+
+    def diversity_score_direct(self, vsf, code1, code2):
+        """PQVectors.diversityFunctionFor (MutablePQVectors path): straight from the codebooks."""
+        c1, c2 = np.ascontiguousarray(code1, np.uint8), np.ascontiguousarray(code2, np.uint8)
+        return float(lib().jvo_pq_diversity_score_direct(self.ref, vsf, _u8(c1), _u8(c2)))
 
     def codebook_partial_sums(self, vsf):
         out = np.empty(self.M * self.k * (self.k + 1) // 2, np.float32)
