@@ -41,7 +41,7 @@ typedef enum {
     JV_ERR_NO_DEVICE = -2,    /* no usable gfx950 device / HIP runtime */
     JV_ERR_HIP = -3,          /* a HIP runtime call failed; see jv_hip_last_error() */
     JV_ERR_OOM = -4,          /* device or pinned-host allocation failed */
-    JV_ERR_UNSUPPORTED = -5   /* e.g. clusterCount != 256, anisotropic PQ */
+    JV_ERR_UNSUPPORTED = -5   /* e.g. clusterCount != 256, NVQ features */
 } jv_status;
 
 /* VectorSimilarityFunction ordinals — B/vector/VectorSimilarityFunction.java:34-69 */
@@ -102,6 +102,12 @@ JV_API int jv_hip_pq_create(jv_ctx *ctx, int D, int M, int k, const int *sizes, 
                             const float *centroid, jv_pq **out);
 /* Parses the reference's big-endian wire format (ProductQuantization.load :649-693; v0..v6). */
 JV_API int jv_hip_pq_load(jv_ctx *ctx, const uint8_t *buf, size_t len, size_t *consumed, jv_pq **out);
+/* ProductQuantization.anisotropicThreshold (ProductQuantization.java:72; encodeTo :439-449): t > -1 makes every encode call
+ * use encodeAnisotropic (:269-306, coordinate descent on the parallel / perpendicular residual cost; vectors must be unit
+ * length); -1 (the default, UNWEIGHTED) is the plain nearest-centroid encode.  jv_hip_pq_load takes the threshold from the
+ * serialized form (version >= 3).  Valid range -1 <= t < 1 (KMeansPlusPlusClusterer.java:87-92). */
+JV_API int jv_hip_pq_set_anisotropic_threshold(jv_pq *pq, float threshold);
+JV_API float jv_hip_pq_anisotropic_threshold(const jv_pq *pq);
 JV_API int jv_hip_pq_destroy(jv_pq *pq);
 JV_API int jv_hip_pq_info(const jv_pq *pq, int *D, int *M, int *k, int *has_centroid);
 

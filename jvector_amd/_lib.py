@@ -46,6 +46,8 @@ SIGNATURES = {
     "jv_hip_ctx_profile_read": (_i, [_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "jv_hip_pq_create": (_i, [_p, _i, _i, _i, _p, _p, _p, C.POINTER(_p)]),
     "jv_hip_pq_load": (_i, [_p, _p, _sz, C.POINTER(_sz), C.POINTER(_p)]),
+    "jv_hip_pq_set_anisotropic_threshold": (_i, [_p, C.c_float]),
+    "jv_hip_pq_anisotropic_threshold": (C.c_float, [_p]),
     "jv_hip_pq_destroy": (_i, [_p]),
     "jv_hip_pq_info": (_i, [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "jv_hip_pq_self_magnitudes": (_i, [_p, _p, _p]),

@@ -460,10 +460,7 @@ int jv_hip_pq_load(jv_ctx *ctx, const uint8_t *buf, size_t len, size_t *consumed
         aniso = rd_f32(buf + p);
         p += 4;
     }
-    if (aniso > -1.0f) {
-        set_error("pq_load: anisotropic PQ (threshold %g) is not supported by the HIP encoder", (double)aniso);
-        return JV_ERR_UNSUPPORTED;
-    }
+    JV_REQUIRE(aniso == aniso && aniso >= -1.0f && aniso < 1.0f, "Valid range for anisotropic threshold T is -1.0 <= t < 1.0");
     NEED(4);
     int k = rd_i32(buf + p);
     p += 4;
@@ -475,8 +472,23 @@ int jv_hip_pq_load(jv_ctx *ctx, const uint8_t *buf, size_t len, size_t *consumed
 #undef NEED
     JV_REQUIRE(gcl == 0 || gcl == D, "Global centroid length %d does not match vector dimensionality %d", gcl, D);
     if (consumed) *consumed = p;
-    return jv_hip_pq_create(ctx, D, M, k, sizes.data(), cbs.data(), gcl ? centroid.data() : nullptr, out);
+    JV_TRY(jv_hip_pq_create(ctx, D, M, k, sizes.data(), cbs.data(), gcl ? centroid.data() : nullptr, out));
+    (*out)->aniso = aniso;  // > -1: encode with encodeAnisotropic (ProductQuantization.encodeTo :439-449)
+    return JV_OK;
 }
+
+int jv_hip_pq_set_anisotropic_threshold(jv_pq *pq, float threshold)
+{
+    clear_error();
+    JV_REQUIRE(pq, "pq is NULL");
+    // KMeansPlusPlusClusterer.java:87-92
+    JV_REQUIRE(threshold == threshold && threshold >= -1.0f && threshold < 1.0f,
+               "Valid range for anisotropic threshold T is -1.0 <= t < 1.0");
+    pq->aniso = threshold;
+    return JV_OK;
+}
+
+float jv_hip_pq_anisotropic_threshold(const jv_pq *pq) { return pq ? pq->aniso : -1.0f; }
 
 int jv_hip_pq_destroy(jv_pq *pq)
 {
@@ -673,7 +685,8 @@ int jv_hip_pq_encode(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t
     JV_TRY(stage_out_begin(ctx, codes_out, (size_t)count * pq->M, ctx->d_out, &os));
     {
         ProfScope ps(ctx, R_ENCODE);
-        JV_TRY(launch_pq_encode(ctx->stream, pq, (const float *)d_v, count, (uint8_t *)os.dev));
+        JV_TRY((pq->aniso > -1.0f ? launch_pq_encode_anisotropic : launch_pq_encode)(ctx->stream, pq, (const float *)d_v, count,
+                                                                                   (uint8_t *)os.dev));
     }
     return stage_out_end(ctx, os);
 }
@@ -690,7 +703,8 @@ int jv_hip_pq_encode_into(jv_ctx *ctx, const jv_pq *pq, const jv_vectors *v, int
     JV_TRY(use_device(ctx->device));
     {
         ProfScope ps(ctx, R_ENCODE);
-        JV_TRY(launch_pq_encode(ctx->stream, pq, v->d_vecs + first * v->D, count, codes->d_codes + first * codes->M));
+        JV_TRY((pq->aniso > -1.0f ? launch_pq_encode_anisotropic : launch_pq_encode)(ctx->stream, pq, v->d_vecs + first * v->D, count,
+                                                                                   codes->d_codes + first * codes->M));
     }
     codes->norms_valid = false;
     return JV_OK;

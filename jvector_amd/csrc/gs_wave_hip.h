@@ -1,0 +1,17 @@
+// gs_wave_hip.h — the wave API of gs_body.h / an_body.h on the GPU (wave64, one wavefront per block).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#define GS_FN __device__ __forceinline__
+__device__ __forceinline__ int gs_lane() { return (int)threadIdx.x; }
+__device__ __forceinline__ void gs_barrier() { __syncthreads(); }
+__device__ __forceinline__ uint64_t gs_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
+__device__ __forceinline__ long long gs_shfl(long long v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ long long gs_shfl_xor(long long v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired) { return atomicCAS(p, expect, desired); }
+__device__ __forceinline__ uint32_t gs_fetch_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ void gs_fence() { __threadfence(); }
+__device__ __forceinline__ double gs_sqrt(double x) { return sqrt(x); }

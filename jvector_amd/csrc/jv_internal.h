@@ -94,6 +94,7 @@ struct jv_pq {
     float *d_codebooks = nullptr;
     float *d_centroid = nullptr;   // nullable
     float *d_self_mag = nullptr;   // M*k floats, built at create (calculatePartialSelfMagnitudes)
+    float aniso = -1.0f;           // anisotropicThreshold; -1 = UNWEIGHTED (ProductQuantization.java:72)
 };
 
 struct jv_codes {
@@ -197,6 +198,7 @@ int launch_center_queries(hipStream_t s, const jv_pq *pq, const float *d_q, int 
 int launch_lut_build(hipStream_t s, const jv_pq *pq, const float *d_cq, int Q, int lut_vsf, float *d_luts);
 int launch_query_magnitudes(hipStream_t s, const jv_pq *pq, const float *d_cq, int Q, int kind, float *d_bmag);
 int launch_pq_encode(hipStream_t s, const jv_pq *pq, const float *d_vecs, int64_t count, uint8_t *d_codes);
+int launch_pq_encode_anisotropic(hipStream_t s, const jv_pq *pq, const float *d_vecs, int64_t count, uint8_t *d_codes);
 
 // raw table sums (used for the cosine norms): out[i] = sum_m table[m*256+code[m]]
 int launch_code_norms(hipStream_t s, const jv_ctx *ctx, const float *d_table, int M, const uint8_t *d_codes,

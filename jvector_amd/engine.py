@@ -155,6 +155,16 @@ class ProductQuantization:
         pq.bytes_consumed = consumed.value
         return pq
 
+    @property
+    def anisotropic_threshold(self) -> float:
+        """ProductQuantization.anisotropicThreshold; -1 = UNWEIGHTED."""
+        return float(self._lib.jv_hip_pq_anisotropic_threshold(self._h))
+
+    def set_anisotropic_threshold(self, t: float):
+        """t > -1: encode / encode_all / PQVectors.encode_and_build use encodeAnisotropic (:269-306); unit-length input."""
+        check(self._lib.jv_hip_pq_set_anisotropic_threshold(self._h, C.c_float(t)))
+        return self
+
     def get_subspace_count(self):
         return self.M
 

@@ -250,8 +250,8 @@ int jvo_closest_centroid(const jvo_pq *pq, const float *vec, int m)
     return closest_centroid(vec, pq->offsets[m], pq_codebook(pq, m), pq->sizes[m], pq->k);
 }
 
-/* encodeTo :439-449 (centre, then encodeUnweighted :422-426).  Anisotropic path is out of scope
- * (only when anisotropicThreshold > -1; default UNWEIGHTED). */
+/* encodeTo :439-449 (centre, then encodeUnweighted :422-426).  The anisotropic branch (anisotropicThreshold > -1,
+ * SURVEY §8a row 4) is jvo_pq_encode_anisotropic below. */
 void jvo_pq_encode(const jvo_pq *pq, const float *vec, uint8_t *dst)
 {
     float *tmp = NULL;
@@ -267,6 +267,80 @@ void jvo_pq_encode(const jvo_pq *pq, const float *vec, uint8_t *dst)
         cboff += (size_t)pq->k * pq->sizes[m];
     }
     free(tmp);
+}
+
+/* KMeansPlusPlusClusterer.computeParallelCostMultiplier :116-124 (double arithmetic, narrowed) */
+float jvo_parallel_cost_multiplier(float threshold, int dimensions)
+{
+    double t = (double)threshold;
+    double parallelCost = t * t;
+    double perpendicularCost = (1 - parallelCost) / (dimensions - 1);
+    double r = parallelCost / perpendicularCost;
+    return (float)(r > 1.0 ? r : 1.0);  /* Math.max(1.0, r) */
+}
+
+/* encodeTo :439-449 with anisotropicThreshold > UNWEIGHTED -> encodeAnisotropic :269-306
+ * (computeResiduals :384-399 + computeResidual :414-420, initializeToMinResidualNorms :364-379,
+ * optimizeSingleSubspace :308-349, <= 10 sweeps).  centroidNormsSquared as the constructor builds it (:241-248). */
+void jvo_pq_encode_anisotropic(const jvo_pq *pq, float threshold, const float *vec, uint8_t *dst)
+{
+    const int M = pq->M, k = pq->k;
+    float *v = (float *)malloc(sizeof(float) * (size_t)pq->D);
+    if (pq->centroid) jvo_sub(vec, pq->centroid, v, pq->D);
+    else memcpy(v, vec, sizeof(float) * (size_t)pq->D);
+    float *rns = (float *)malloc(sizeof(float) * (size_t)M * k);  /* residualNormSquared */
+    float *par = (float *)malloc(sizeof(float) * (size_t)M * k);  /* parallelResidualComponent */
+    const float inverseNorm = (float)(1.0 / sqrt((double)jvo_dot(v, v, pq->D)));
+    size_t cboff = 0;
+    for (int i = 0; i < M; i++) {
+        const int len = pq->sizes[i];
+        const float *x = v + pq->offsets[i];               /* getSubVector copies; same values */
+        const float xNormSquared = jvo_dot(x, x, len);     /* full-vector form on the copy */
+        const float *cb = pq->codebooks + cboff;
+        for (int j = 0; j < k; j++) {
+            const float cNormSquared = jvo_dot_off(cb, j * len, cb, j * len, len);
+            const float cDotX = jvo_dot_off(cb, j * len, x, 0, len);
+            const float two = 2 * cDotX;
+            const float residualNormSquared = cNormSquared - two + xNormSquared;
+            const float pes = cDotX - xNormSquared;
+            rns[(size_t)i * k + j] = residualNormSquared;
+            par[(size_t)i * k + j] = (pes * pes) * inverseNorm;
+        }
+        cboff += (size_t)k * len;
+    }
+    for (int i = 0; i < M; i++) {  /* initializeToMinResidualNorms: strict <, compared as double */
+        int minIndex = -1;
+        double minNormSquared = 1.7976931348623157e308;
+        for (int j = 0; j < k; j++)
+            if ((double)rns[(size_t)i * k + j] < minNormSquared) { minNormSquared = rns[(size_t)i * k + j]; minIndex = j; }
+        dst[i] = (uint8_t)minIndex;
+    }
+    float parSum = 0.0f;
+    for (int i = 0; i < M; i++) parSum += par[(size_t)i * k + dst[i]];
+    const float pcm = jvo_parallel_cost_multiplier(threshold, pq->D);
+    for (int iter = 0; iter < 10; iter++) {
+        int changed = 0;
+        for (int i = 0; i < M; i++) {
+            const int oldIdx = dst[i];
+            const float *R = rns + (size_t)i * k, *P = par + (size_t)i * k;
+            const float oldRns = R[oldIdx], oldPar = P[oldIdx];
+            float bestCostDelta = 0.0f, bestParSum = parSum;
+            int bestIndex = oldIdx;
+            for (int t = 0; t < k; t++) {
+                if (t == oldIdx) continue;
+                const float thisParSum = parSum - oldPar + P[t];
+                const float parallelNormDelta = thisParSum * thisParSum - parSum * parSum;
+                if (parallelNormDelta > 0) continue;
+                const float residualNormDelta = R[t] - oldRns;
+                const float perpendicularNormDelta = residualNormDelta - parallelNormDelta;
+                const float costDelta = pcm * parallelNormDelta + perpendicularNormDelta;
+                if (costDelta < bestCostDelta) { bestCostDelta = costDelta; bestIndex = t; bestParSum = thisParSum; }
+            }
+            if (bestIndex != oldIdx) { parSum = bestParSum; dst[i] = (uint8_t)bestIndex; changed = 1; }
+        }
+        if (!changed) break;
+    }
+    free(v); free(rns); free(par);
 }
 
 typedef struct { const jvo_pq *pq; const float *vecs; uint8_t *dst; int64_t lo, hi; } enc_job;

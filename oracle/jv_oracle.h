@@ -78,6 +78,8 @@ typedef struct {
 void jvo_subvector_sizes_offsets(int D, int M, int *sizes, int *offsets);
 int  jvo_closest_centroid(const jvo_pq *pq, const float *vec /*already centred*/, int m);
 void jvo_pq_encode(const jvo_pq *pq, const float *vec, uint8_t *dst);
+float jvo_parallel_cost_multiplier(float threshold, int dimensions);
+void jvo_pq_encode_anisotropic(const jvo_pq *pq, float threshold, const float *vec, uint8_t *dst);
 void jvo_pq_encode_all(const jvo_pq *pq, const float *vecs, int64_t n, uint8_t *dst, int nthreads);
 void jvo_pq_decode(const jvo_pq *pq, const uint8_t *code, float *dst);
 /* createCodebookPartialSums: M*k*(k+1)/2 floats */

@@ -114,6 +114,8 @@ def lib():
         sig("jvo_adc_score", C.c_float, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, u8p)
         sig("jvo_adc_scores", None, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, u8p, i32p, C.c_int64, fp)
         sig("jvo_pq_direct_score", C.c_float, pqp, fp, C.c_int, u8p)
+        sig("jvo_pq_encode_anisotropic", None, pqp, C.c_float, fp, u8p)
+        sig("jvo_parallel_cost_multiplier", C.c_float, C.c_float, C.c_int)
         sig("jvo_pq_diversity_score", C.c_float, fp, C.c_int, C.c_int, C.c_int, u8p, u8p)
         sig("jvo_pq_diversity_score_direct", C.c_float, pqp, C.c_int, u8p, u8p)
         sig("jvo_float_to_sortable_int", C.c_int32, C.c_float)
@@ -288,6 +290,13 @@ class OraclePQ:
         vec = f32(vec)
         out = np.empty(self.M, np.uint8)
         lib().jvo_pq_encode(self.ref, _f(vec), _u8(out))
+        return out
+
+    def encode_anisotropic(self, vec, threshold):
+        """ProductQuantization.encodeTo with anisotropicThreshold = threshold (> -1)."""
+        vec = f32(vec)
+        out = np.empty(self.M, np.uint8)
+        lib().jvo_pq_encode_anisotropic(self.ref, C.c_float(threshold), _f(vec), _u8(out))
         return out
 
     def encode_all(self, vecs, nthreads=8):
