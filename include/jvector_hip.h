@@ -108,6 +108,23 @@ JV_API int jv_hip_pq_load(jv_ctx *ctx, const uint8_t *buf, size_t len, size_t *c
  * serialized form (version >= 3).  Valid range -1 <= t < 1 (KMeansPlusPlusClusterer.java:87-92). */
 JV_API int jv_hip_pq_set_anisotropic_threshold(jv_pq *pq, float threshold);
 JV_API float jv_hip_pq_anisotropic_threshold(const jv_pq *pq);
+/* PQ training, unweighted k-means only.
+ *   pq_train  = ProductQuantization.compute(ravv, M, k, globallyCenter) (ProductQuantization.java:109-139): optional global
+ *               centring (centroidOf), per subspace k-means++ seeding + K_MEANS_ITERATIONS = 6 Lloyd rounds with the
+ *               reference's early stop (<= 1 % of the points moved).  `vectors` is the training set [n][D] the caller
+ *               sampled (the reference caps it at 128 000 vectors, extractTrainingVectors :141-175); n >= k.
+ *   pq_refine = ProductQuantization.refine(ravv, lloydsRounds) (:194-221): Lloyd rounds on new data from pq's codebooks.
+ * The reference draws from ThreadLocalRandom, so its codebooks are not reproducible; here a splitmix64 stream per subspace
+ * derived from `seed` replaces it and everything else — including the order of every float accumulation — is the
+ * reference's, so the result is a deterministic function of (vectors, seed).  Both return a NEW jv_pq. */
+JV_API int jv_hip_pq_train(jv_ctx *ctx, const float *vectors, int64_t n, int D, int M, int k, int globally_center,
+                           uint64_t seed, jv_pq **out);
+JV_API int jv_hip_pq_refine(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t n, int lloyds_rounds, uint64_t seed,
+                            jv_pq **out);
+/* ProductQuantization.write(out, version) (ProductQuantization.java:560-599; big-endian, versions 0..6): *len_out = bytes
+ * needed; the block is written only when buf != NULL and cap >= *len_out (call once with buf = NULL to size the buffer).
+ * jv_hip_pq_load / ProductQuantization.load read it back. */
+JV_API int jv_hip_pq_write(jv_ctx *ctx, const jv_pq *pq, int version, uint8_t *buf, size_t cap, size_t *len_out);
 JV_API int jv_hip_pq_destroy(jv_pq *pq);
 JV_API int jv_hip_pq_info(const jv_pq *pq, int *D, int *M, int *k, int *has_centroid);
 

@@ -220,6 +220,15 @@ int launch_frontier(hipStream_t s, int vsf, const float *d_luts, const float *d_
                     const int32_t *d_origins, const int32_t *d_ord_index, const int32_t *d_ords, const jv_fused *fused,
                     const jv_codes *codes, float *d_out, int S, int W, const jv_pq *pq = nullptr,
                     const float *d_cq = nullptr);
+// PQ training (k_pq_train.hip; parameters in km_body.h)
+struct KmParams;
+int launch_km_centroid(hipStream_t s, const float *d_X, int64_t n, int D, float *d_out);
+int launch_km_center(hipStream_t s, const float *d_X, const float *d_centroid, int64_t n, int D, float *d_Xc);
+int launch_km_pp_init(hipStream_t s, const KmParams &p);
+int launch_km_assign(hipStream_t s, const KmParams &p);
+int launch_km_replay(hipStream_t s, const KmParams &p, int first_pass);
+int launch_km_update_centroids(hipStream_t s, const KmParams &p);
+int launch_km_finish_round(hipStream_t s, const KmParams &p);
 // build-time scoring (k_build_score.hip)
 int launch_pair_table(hipStream_t s, const jv_pq *pq, int vsf, float *d_out);
 int launch_pair_scores(hipStream_t s, const float *d_tri, int vsf, const jv_codes *codes, const int32_t *d_node1, int P,

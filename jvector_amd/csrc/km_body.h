@@ -1,0 +1,232 @@
+// km_body.h — PQ training on the device: KMeansPlusPlusClusterer's unweighted path and
+// ProductQuantization.compute / refine (B/quantization/KMeansPlusPlusClusterer.java:131-150,171-272,330-372,437-446;
+// B/quantization/ProductQuantization.java:109-139,194-221,487-495).
+//
+// The reference's result depends on the ORDER of its float accumulations (centroidNums is updated point by point,
+// with subtractions when a point changes cluster), so a parallel reduction would only be "statistically" equal.
+// Instead every accumulator is owned by exactly one thread that replays ITS OWN history in point order:
+//   km_replay     thread (m, c) walks the points 0..n-1 and applies exactly the addInPlace / subInPlace calls
+//                 updateAssignedPointsUnweighted would apply to centroidNums[c] — same operands, same order, hence the
+//                 same bits; all M x k threads run concurrently, wavefront lanes = clusters of one subspace so the
+//                 assignment bytes they scan are broadcast loads.
+//   km_assign     thread (point, m): getNearestCluster (strict <, first minimum).
+//   km_centroids  thread (m, c): scale(centroidNums, 1.0f / denom).
+//   km_pp_init    one wavefront per subspace: k-means++ seeding; the distance refresh is lane-parallel, the
+//                 sequential prefix scan that picks the next centroid (sum, then r -= d[j] until r < 1e-6) is done by
+//                 lane 0 in the reference's order.
+// ThreadLocalRandom cannot be reproduced; a seeded splitmix64 stream per subspace replaces it (the CPU
+// checker under tests/ makes the same substitution), so both agree bit for bit for a given seed.
+// Per-thread bodies need KM_FN; km_pp_init additionally needs the wave API of gs_body.h (GS_FN, gs_lane, gs_barrier,
+// gs_shfl, gs_fence).  The anisotropic k-means variants are not built.
+#pragma once
+
+#include <cstdint>
+
+namespace jv {
+
+struct KmParams {
+    const float *X;            // [n][D] centred training vectors
+    float *C;                  // codebooks, concatenated [m][k][size_m] (in/out)
+    const int64_t *cb_offsets;
+    const int32_t *sizes, *offsets;
+    uint8_t *assign_old, *assign_new;  // [n][M]
+    float *nums;               // centroidNums, layout of C
+    int32_t *denoms;           // [M][k]
+    int32_t *active;           // [M] 1 while the subspace's clusterer is still iterating
+    int32_t *changed;          // [M]
+    uint64_t *rng;             // [M] splitmix64 state
+    float *dist;               // [M][n] k-means++ distances
+    int64_t n;
+    int32_t D, M, k;
+};
+
+constexpr float KM_FLT_MAX = 3.4028234663852886e38f;
+
+KM_FN uint64_t km_rng_next(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+KM_FN int64_t km_rng_int(uint64_t *s, int64_t bound) { return (int64_t)((km_rng_next(s) >> 33) % (uint64_t)bound); }
+KM_FN float km_rng_float(uint64_t *s) { return (float)(km_rng_next(s) >> 40) * (1.0f / 16777216.0f); }
+inline uint64_t km_stream(uint64_t seed, int m) { return seed * 0x9E3779B97F4A7C15ull + (uint64_t)m * 0xD1B54A32D192ED03ull + 1; }
+
+// centroidOf: thread d sums dimension d over the points in order, then scales by 1.0f / n
+KM_FN void km_centroid_dim(const float *X, int64_t n, int D, int64_t d, float *out)
+{
+    float s = 0.0f;
+    for (int64_t i = 0; i < n; ++i) s = s + X[i * D + d];
+    out[d] = s * (1.0f / (float)n);
+}
+
+// VectorUtil.sub(v, centroid): thread t over n*D
+KM_FN void km_center(const float *X, const float *centroid, int D, int64_t t, float *Xc)
+{
+    Xc[t] = centroid ? X[t] - centroid[t % D] : X[t];
+}
+
+// getNearestCluster :330-343 — thread t = i*M + m
+KM_FN void km_assign(const KmParams &p, int64_t t)
+{
+    const int m = (int)(t % p.M);
+    if (!p.active[m]) return;
+    const int64_t i = t / p.M;
+    const int len = p.sizes[m];
+    const float *x = p.X + i * p.D + p.offsets[m];
+    const float *C = p.C + p.cb_offsets[m];
+    float minDistance = KM_FLT_MAX;
+    int nearest = 0;
+    for (int c = 0; c < p.k; ++c) {
+        const float *cc = C + (int64_t)c * len;
+        float d = 0.0f;
+        for (int j = 0; j < len; ++j) {  // squareL2Distance offsets form, a = point, b = centroid
+            const float diff = x[j] - cc[j];
+            d += diff * diff;
+        }
+        if (d < minDistance) {
+            minDistance = d;
+            nearest = c;
+        }
+    }
+    p.assign_new[t] = (uint8_t)nearest;
+}
+
+// initializeAssignedPoints (first_pass) / updateAssignedPointsUnweighted: thread t = m*k + c replays cluster c's history
+KM_FN void km_replay(const KmParams &p, int first_pass, int64_t t)
+{
+    const int m = (int)(t / p.k), c = (int)(t % p.k);
+    if (m >= p.M || !p.active[m]) return;
+    const int len = p.sizes[m], off = p.offsets[m];
+    float *num = p.nums + p.cb_offsets[m] + (int64_t)c * len;
+    int32_t denom = first_pass ? 0 : p.denoms[t];
+    float acc[64];  // sub-vector length <= 64 (checked by the host)
+    for (int j = 0; j < len; ++j) acc[j] = first_pass ? 0.0f : num[j];
+    int32_t changed = 0;
+    for (int64_t i = 0; i < p.n; ++i) {
+        const int a = p.assign_new[i * p.M + m];
+        const int o = first_pass ? -1 : (int)p.assign_old[i * p.M + m];
+        if (a == o) continue;
+        ++changed;
+        const float *x = p.X + i * p.D + off;
+        if (o == c) {
+            --denom;
+            for (int j = 0; j < len; ++j) acc[j] = acc[j] - x[j];
+        }
+        if (a == c) {
+            ++denom;
+            for (int j = 0; j < len; ++j) acc[j] = acc[j] + x[j];
+        }
+    }
+    for (int j = 0; j < len; ++j) num[j] = acc[j];
+    p.denoms[t] = denom;
+    if (c == 0) p.changed[m] = changed;
+}
+
+// updateCentroidsUnweighted, non-empty clusters: thread t = m*k + c
+KM_FN void km_centroids(const KmParams &p, int64_t t)
+{
+    const int m = (int)(t / p.k), c = (int)(t % p.k);
+    if (m >= p.M || !p.active[m]) return;
+    const int32_t denom = p.denoms[t];
+    if (denom == 0) return;  // km_fill_empties
+    const int len = p.sizes[m];
+    const float inv = 1.0f / (float)denom;
+    const float *num = p.nums + p.cb_offsets[m] + (int64_t)c * len;
+    float *cc = p.C + p.cb_offsets[m] + (int64_t)c * len;
+    for (int j = 0; j < len; ++j) cc[j] = num[j] * inv;
+}
+
+// updateCentroidsUnweighted, empty clusters (initializeCentroidToRandomPoint) in cluster order: thread m
+KM_FN void km_fill_empties(const KmParams &p, int64_t m)
+{
+    if (!p.active[m]) return;
+    uint64_t s = p.rng[m];
+    const int len = p.sizes[m];
+    for (int c = 0; c < p.k; ++c) {
+        if (p.denoms[m * p.k + c] != 0) continue;
+        const float *x = p.X + km_rng_int(&s, p.n) * p.D + p.offsets[m];
+        float *cc = p.C + p.cb_offsets[m] + (int64_t)c * len;
+        for (int j = 0; j < len; ++j) cc[j] = x[j];
+    }
+    p.rng[m] = s;
+}
+
+// cluster() :131-150: stop iterating a subspace once <= 1 % of its points moved: thread m
+KM_FN void km_finish_round(const KmParams &p, int64_t m)
+{
+    if (p.active[m] && (double)p.changed[m] <= 0.01 * (double)p.n) p.active[m] = 0;
+}
+
+#ifdef GS_FN
+// VectorUtil.squareL2Distance(a, b) full-vector form: blocks of eight summed left to right, then the tail
+GS_FN float km_full_l2(const float *a, const float *b, int n)
+{
+    float sq = 0.0f;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const float d0 = a[i] - b[i], d1 = a[i + 1] - b[i + 1], d2 = a[i + 2] - b[i + 2], d3 = a[i + 3] - b[i + 3];
+        const float d4 = a[i + 4] - b[i + 4], d5 = a[i + 5] - b[i + 5], d6 = a[i + 6] - b[i + 6], d7 = a[i + 7] - b[i + 7];
+        float t = d0 * d0 + d1 * d1;
+        t = t + d2 * d2;
+        t = t + d3 * d3;
+        t = t + d4 * d4;
+        t = t + d5 * d5;
+        t = t + d6 * d6;
+        t = t + d7 * d7;
+        sq += t;
+    }
+    for (; i < n; ++i) {
+        const float d = a[i] - b[i];
+        sq += d * d;
+    }
+    return sq;
+}
+
+// chooseInitialCentroids :171-226 for subspace m, one wavefront
+GS_FN void km_pp_init(const KmParams &p, int m)
+{
+    const int lane = gs_lane();
+    const int len = p.sizes[m], off = p.offsets[m];
+    float *dist = p.dist + (int64_t)m * p.n;
+    float *C = p.C + p.cb_offsets[m];
+    for (int64_t j = lane; j < p.n; j += 64) dist[j] = KM_FLT_MAX;
+    uint64_t s = p.rng[m];
+    long long sel = 0;
+    if (lane == 0) sel = km_rng_int(&s, p.n);
+    for (int c = 0; c < p.k; ++c) {
+        gs_fence();
+        gs_barrier();
+        if (c > 0 && lane == 0) {
+            float total = 0.0f;
+            for (int64_t j = 0; j < p.n; ++j) total += dist[j];
+            float r = km_rng_float(&s) * total;
+            sel = -1;
+            for (int64_t j = 0; j < p.n; ++j) {
+                r -= dist[j];
+                if ((double)r < 1e-6) {
+                    sel = j;
+                    break;
+                }
+            }
+            if (sel == -1) sel = km_rng_int(&s, p.n);
+        }
+        sel = gs_shfl(sel, 0);
+        const float *x = p.X + sel * p.D + off;
+        float *cc = C + (int64_t)c * len;
+        for (int j = lane; j < len; j += 64) cc[j] = x[j];
+        gs_fence();
+        gs_barrier();
+        for (int64_t j = lane; j < p.n; j += 64) {
+            const float d = km_full_l2(p.X + j * p.D + off, cc, len);
+            if (d < dist[j]) dist[j] = d;
+        }
+    }
+    if (lane == 0) p.rng[m] = s;
+    gs_fence();
+    gs_barrier();
+}
+#endif
+
+}  // namespace jv

@@ -1,0 +1,188 @@
+// pq_train.cpp — C ABI of PQ training: ProductQuantization.compute / refine, unweighted
+// (B/quantization/ProductQuantization.java:109-139,194-221; kernels k_pq_train.hip, bodies km_body.h).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#define KM_FN static inline
+#include "km_body.h"
+
+#include "jv_internal.h"
+
+using namespace jv;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        JV_HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        return JV_OK;
+    }
+};
+
+// shared by train (init = k-means++) and refine (init = the given codebooks)
+int run_training(jv_ctx *ctx, jv_pq *work /* layout + d_codebooks in/out */, const float *vectors, int64_t n, const float *d_centroid,
+                 bool compute_centroid, float *d_centroid_out, bool seed_with_kmeans_pp, int rounds, uint64_t seed)
+{
+    const int D = work->D, M = work->M, k = work->k;
+    hipStream_t s = ctx->stream;
+    const void *d_X = nullptr;
+    JV_TRY(stage_in(ctx, vectors, sizeof(float) * (size_t)n * D, ctx->h_in, ctx->d_in, &d_X));
+    DevBuf Xc, A, B, nums, denoms, active, changed, rng, dist;
+    JV_TRY(Xc.alloc(sizeof(float) * (size_t)n * D));
+    JV_TRY(A.alloc((size_t)n * M));
+    JV_TRY(B.alloc((size_t)n * M));
+    JV_TRY(nums.alloc(sizeof(float) * (size_t)k * D));
+    JV_TRY(denoms.alloc(sizeof(int32_t) * (size_t)M * k));
+    JV_TRY(active.alloc(sizeof(int32_t) * (size_t)M));
+    JV_TRY(changed.alloc(sizeof(int32_t) * (size_t)M));
+    JV_TRY(rng.alloc(sizeof(uint64_t) * (size_t)M));
+    if (seed_with_kmeans_pp) JV_TRY(dist.alloc(sizeof(float) * (size_t)M * n));
+    if (compute_centroid) {
+        JV_TRY(launch_km_centroid(s, (const float *)d_X, n, D, d_centroid_out));
+        d_centroid = d_centroid_out;
+    }
+    JV_TRY(launch_km_center(s, (const float *)d_X, d_centroid, n, D, (float *)Xc.p));
+    std::vector<int32_t> ones((size_t)M, 1);
+    std::vector<uint64_t> streams((size_t)M);
+    for (int m = 0; m < M; ++m) streams[m] = km_stream(seed, m);
+    JV_HIP_CHECK(hipMemcpyAsync(active.p, ones.data(), sizeof(int32_t) * (size_t)M, hipMemcpyHostToDevice, s));
+    JV_HIP_CHECK(hipMemcpyAsync(rng.p, streams.data(), sizeof(uint64_t) * (size_t)M, hipMemcpyHostToDevice, s));
+    JV_HIP_CHECK(hipStreamSynchronize(s));  // the two host vectors above go out of scope with this frame: drain now
+    KmParams p{(const float *)Xc.p, work->d_codebooks, work->d_cb_offsets, work->d_sizes, work->d_offsets, (uint8_t *)A.p,
+               (uint8_t *)B.p, (float *)nums.p, (int32_t *)denoms.p, (int32_t *)active.p, (int32_t *)changed.p, (uint64_t *)rng.p,
+               (float *)dist.p, n, D, M, k};
+    if (seed_with_kmeans_pp) JV_TRY(launch_km_pp_init(s, p));
+    // KMeansPlusPlusClusterer constructor: initializeAssignedPoints
+    JV_TRY(launch_km_assign(s, p));
+    JV_TRY(launch_km_replay(s, p, 1));
+    for (int it = 0; it < rounds; ++it) {  // cluster(rounds, 0): subspaces that converged (<= 1 % moved) go inactive
+        std::swap(p.assign_old, p.assign_new);
+        JV_TRY(launch_km_update_centroids(s, p));
+        JV_TRY(launch_km_assign(s, p));
+        JV_TRY(launch_km_replay(s, p, 0));
+        JV_TRY(launch_km_finish_round(s, p));
+    }
+    JV_HIP_CHECK(hipStreamSynchronize(s));
+    return JV_OK;
+}
+
+int finish(jv_ctx *ctx, jv_pq *work, const float *d_centroid, float aniso, jv_pq **out)
+{
+    const int D = work->D, k = work->k;
+    std::vector<float> cb((size_t)k * D), cen;
+    JV_HIP_CHECK(hipMemcpy(cb.data(), work->d_codebooks, sizeof(float) * cb.size(), hipMemcpyDeviceToHost));
+    if (d_centroid) {
+        cen.resize((size_t)D);
+        JV_HIP_CHECK(hipMemcpy(cen.data(), d_centroid, sizeof(float) * (size_t)D, hipMemcpyDeviceToHost));
+    }
+    JV_TRY(jv_hip_pq_create(ctx, D, work->M, k, work->sizes.data(), cb.data(), d_centroid ? cen.data() : nullptr, out));
+    (*out)->aniso = aniso;
+    return JV_OK;
+}
+
+struct PqGuard {
+    jv_pq *pq = nullptr;
+    ~PqGuard() { if (pq) jv_hip_pq_destroy(pq); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int jv_hip_pq_train(jv_ctx *ctx, const float *vectors, int64_t n, int D, int M, int k, int globally_center, uint64_t seed, jv_pq **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && vectors && out, "pq_train: NULL argument");
+    *out = nullptr;
+    JV_REQUIRE(D > 0 && M > 0 && M <= D, "Number of subspaces must be less than or equal to the vector dimension");
+    // ProductQuantization.compute :119-121
+    JV_REQUIRE(n >= k, "Cannot train PQ with %d clusters on %lld points, supply more training vectors or lower cluster count.", k,
+               (long long)n);
+    JV_REQUIRE((D + M - 1) / M <= 64, "pq_train: sub-vectors longer than 64 dimensions are not supported");
+    JV_TRY(use_device(ctx->device));
+    PqGuard work;
+    std::vector<float> zeros((size_t)k * D, 0.0f);
+    JV_TRY(jv_hip_pq_create(ctx, D, M, k, nullptr, zeros.data(), nullptr, &work.pq));
+    DevBuf cen;
+    if (globally_center) JV_TRY(cen.alloc(sizeof(float) * (size_t)D));
+    JV_TRY(run_training(ctx, work.pq, vectors, n, nullptr, globally_center != 0, (float *)cen.p, true, 6 /* K_MEANS_ITERATIONS */, seed));
+    return finish(ctx, work.pq, globally_center ? (const float *)cen.p : nullptr, -1.0f, out);
+}
+
+int jv_hip_pq_refine(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t n, int lloyds_rounds, uint64_t seed, jv_pq **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && vectors && out, "pq_refine: NULL argument");
+    *out = nullptr;
+    JV_REQUIRE(lloyds_rounds >= 0, "lloydsRounds must be non-negative");  // ProductQuantization.refine :205-207
+    JV_REQUIRE(n > 0, "pq_refine: no training vectors");
+    JV_REQUIRE(pq->max_size <= 64, "pq_refine: sub-vectors longer than 64 dimensions are not supported");
+    if (pq->aniso > -1.0f) {
+        set_error("pq_refine: anisotropic k-means refinement is not built");
+        return JV_ERR_UNSUPPORTED;
+    }
+    JV_TRY(use_device(ctx->device));
+    PqGuard work;
+    std::vector<float> cb((size_t)pq->k * pq->D);
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    JV_HIP_CHECK(hipMemcpy(cb.data(), pq->d_codebooks, sizeof(float) * cb.size(), hipMemcpyDeviceToHost));
+    JV_TRY(jv_hip_pq_create(ctx, pq->D, pq->M, pq->k, pq->sizes.data(), cb.data(), nullptr, &work.pq));
+    JV_TRY(run_training(ctx, work.pq, vectors, n, pq->d_centroid, false, nullptr, false, lloyds_rounds, seed));
+    return finish(ctx, work.pq, pq->d_centroid, pq->aniso, out);
+}
+
+// ProductQuantization.write(out, version) :560-599, big-endian.  len_out = bytes needed; nothing is written when cap is
+// too small (query the size with buf = NULL, cap = 0).
+int jv_hip_pq_write(jv_ctx *ctx, const jv_pq *pq, int version, uint8_t *buf, size_t cap, size_t *len_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && len_out, "pq_write: NULL argument");
+    JV_REQUIRE(version >= 0 && version <= 6, "Unsupported serialization version %d", version);
+    JV_REQUIRE(version >= 3 || !(pq->aniso > -1.0f), "Anisotropic threshold is only supported in serialization version 3 and above");
+    const size_t total = (size_t)pq->k * pq->D;
+    const size_t need = (version >= 3 ? 8 : 0) + 4 + (pq->d_centroid ? (size_t)pq->D * 4 : 0) + 4 + (size_t)pq->M * 4 +
+                        (version >= 3 ? 4 : 0) + 4 + total * 4;
+    *len_out = need;
+    if (!buf || cap < need) return JV_OK;
+    JV_TRY(use_device(ctx->device));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::vector<float> cb(total), cen;
+    JV_HIP_CHECK(hipMemcpy(cb.data(), pq->d_codebooks, sizeof(float) * total, hipMemcpyDeviceToHost));
+    if (pq->d_centroid) {
+        cen.resize((size_t)pq->D);
+        JV_HIP_CHECK(hipMemcpy(cen.data(), pq->d_centroid, sizeof(float) * (size_t)pq->D, hipMemcpyDeviceToHost));
+    }
+    size_t p = 0;
+    auto wr_i32 = [&](int32_t v) {
+        buf[p++] = (uint8_t)((uint32_t)v >> 24);
+        buf[p++] = (uint8_t)((uint32_t)v >> 16);
+        buf[p++] = (uint8_t)((uint32_t)v >> 8);
+        buf[p++] = (uint8_t)(uint32_t)v;
+    };
+    auto wr_f32 = [&](float f) {
+        int32_t b;
+        memcpy(&b, &f, 4);
+        wr_i32(b);
+    };
+    if (version >= 3) {
+        wr_i32(0x75EC4012);
+        wr_i32(version);
+    }
+    if (cen.empty()) wr_i32(0);
+    else {
+        wr_i32(pq->D);
+        for (float f : cen) wr_f32(f);
+    }
+    wr_i32(pq->M);
+    for (int m = 0; m < pq->M; ++m) wr_i32(pq->sizes[m]);
+    if (version >= 3) wr_f32(pq->aniso);
+    wr_i32(pq->k);
+    for (float f : cb) wr_f32(f);
+    return JV_OK;
+}
+
+}  // extern "C"

@@ -155,6 +155,33 @@ class ProductQuantization:
         pq.bytes_consumed = consumed.value
         return pq
 
+    @classmethod
+    def compute(cls, ctx, vectors, M, cluster_count=256, globally_center=False, seed=1):
+        """ProductQuantization.compute (:109-139), unweighted: k-means++ + 6 Lloyd rounds per subspace on `vectors`
+        (the training sample, host or device [n, D]).  Deterministic in (vectors, seed)."""
+        n, D = int(vectors.shape[0]), int(vectors.shape[1])
+        v_p, keep = _ptr(vectors, np.float32)
+        h = C.c_void_p()
+        check(ctx._lib.jv_hip_pq_train(ctx._h, v_p, n, D, int(M), int(cluster_count), int(bool(globally_center)), int(seed),
+                                       C.byref(h)))
+        return cls(ctx, h)
+
+    def refine(self, vectors, lloyds_rounds=1, seed=1):
+        """ProductQuantization.refine (:194-221): a new PQ fine-tuned on `vectors`."""
+        n = int(vectors.shape[0])
+        v_p, keep = _ptr(vectors, np.float32)
+        h = C.c_void_p()
+        check(self._lib.jv_hip_pq_refine(self.ctx._h, self._h, v_p, n, int(lloyds_rounds), int(seed), C.byref(h)))
+        return ProductQuantization(self.ctx, h)
+
+    def write(self, version=6) -> bytes:
+        """ProductQuantization.write (:560-599): the reference's big-endian wire format."""
+        need = C.c_size_t()
+        check(self._lib.jv_hip_pq_write(self.ctx._h, self._h, int(version), None, 0, C.byref(need)))
+        buf = (C.c_ubyte * need.value)()
+        check(self._lib.jv_hip_pq_write(self.ctx._h, self._h, int(version), C.cast(buf, C.c_void_p), need.value, C.byref(need)))
+        return bytes(buf)
+
     @property
     def anisotropic_threshold(self) -> float:
         """ProductQuantization.anisotropicThreshold; -1 = UNWEIGHTED."""

@@ -439,6 +439,155 @@ float jvo_pq_diversity_score_direct(const jvo_pq *pq, int vsf, const uint8_t *co
 }
 
 /* ------------------------------------------------------------------------------------------
+ * PQ training: KMeansPlusPlusClusterer (unweighted path) + ProductQuantization.compute / refine.
+ * The reference draws from ThreadLocalRandom (unseedable), so its output is not reproducible; this restatement
+ * substitutes a seeded splitmix64 stream per subspace (jvo_rng) and is otherwise operation for operation:
+ *   chooseInitialCentroids :171-226, initializeAssignedPoints :232-240, updateAssignedPointsUnweighted :251-272,
+ *   getNearestCluster :330-343, updateCentroidsUnweighted :360-372, cluster :131-150 (stop when <= 1 % changed),
+ *   centroidOf :437-446, ProductQuantization.compute :109-139 / createCodebooks :487-495 (6 rounds) / refine :194-221.
+ * The anisotropic k-means variants (:274-320, :380-432) are not restated.
+ * ---------------------------------------------------------------------------------------- */
+static uint64_t rng_next(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static int rng_int(uint64_t *s, int64_t bound) { return (int)((rng_next(s) >> 33) % (uint64_t)bound); }
+static float rng_float(uint64_t *s) { return (float)(rng_next(s) >> 40) * (1.0f / 16777216.0f); }  /* 24 bits, as Random.nextFloat */
+uint64_t jvo_kmeans_stream(uint64_t seed, int m) { return seed * 0x9E3779B97F4A7C15ULL + (uint64_t)m * 0xD1B54A32D192ED03ULL + 1; }
+
+#define PT(i) (X + (size_t)(i) * stride + off)
+
+void jvo_kmeans_pp_init(const float *X, int64_t n, int stride, int off, int len, int k, uint64_t *rng, float *C)
+{
+    float *dist = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) dist[i] = 3.4028234663852886e38f;
+    int64_t sel = rng_int(rng, n);
+    for (int c = 0; c < k; c++) {
+        if (c > 0) {
+            float total = 0.0f;
+            for (int64_t j = 0; j < n; j++) total += dist[j];
+            float r = rng_float(rng) * total;
+            sel = -1;
+            for (int64_t j = 0; j < n; j++) {
+                r -= dist[j];
+                if ((double)r < 1e-6) { sel = j; break; }
+            }
+            if (sel == -1) sel = rng_int(rng, n);
+        }
+        memcpy(C + (size_t)c * len, PT(sel), sizeof(float) * (size_t)len);
+        for (int64_t j = 0; j < n; j++) {
+            float d = jvo_l2(PT(j), C + (size_t)c * len, len);  /* squareL2Distance(points[j], centroid): full-vector form */
+            if (d < dist[j]) dist[j] = d;                          /* minInPlace (Math.min; no NaNs here) */
+        }
+    }
+    free(dist);
+}
+
+static int km_nearest(const float *p, const float *C, int len, int k)
+{
+    float minDistance = 3.4028234663852886e38f;
+    int nearest = 0;
+    for (int i = 0; i < k; i++) {
+        float d = jvo_l2_off(p, 0, C, i * len, len);
+        if (d < minDistance) { minDistance = d; nearest = i; }
+    }
+    return nearest;
+}
+
+/* constructor (initializeAssignedPoints) + cluster(rounds, 0); returns the rounds actually run */
+int jvo_kmeans_lloyd(const float *X, int64_t n, int stride, int off, int len, int k, float *C, int rounds, uint64_t *rng)
+{
+    float *nums = (float *)calloc((size_t)k * len, sizeof(float));
+    int *denoms = (int *)calloc((size_t)k, sizeof(int));
+    int *assign = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        int a = km_nearest(PT(i), C, len, k);
+        denoms[a]++;
+        for (int d = 0; d < len; d++) nums[(size_t)a * len + d] = nums[(size_t)a * len + d] + PT(i)[d];
+        assign[i] = a;
+    }
+    int it = 0;
+    for (; it < rounds; it++) {
+        for (int c = 0; c < k; c++) {  /* updateCentroidsUnweighted */
+            if (denoms[c] == 0) memcpy(C + (size_t)c * len, PT(rng_int(rng, n)), sizeof(float) * (size_t)len);
+            else {
+                float inv = 1.0f / denoms[c];
+                for (int d = 0; d < len; d++) C[(size_t)c * len + d] = nums[(size_t)c * len + d] * inv;
+            }
+        }
+        int64_t changed = 0;
+        for (int64_t i = 0; i < n; i++) {  /* updateAssignedPointsUnweighted */
+            int o = assign[i], a = km_nearest(PT(i), C, len, k);
+            if (a != o) {
+                denoms[o]--;
+                for (int d = 0; d < len; d++) nums[(size_t)o * len + d] = nums[(size_t)o * len + d] - PT(i)[d];
+                denoms[a]++;
+                for (int d = 0; d < len; d++) nums[(size_t)a * len + d] = nums[(size_t)a * len + d] + PT(i)[d];
+                assign[i] = a;
+                changed++;
+            }
+        }
+        if ((double)changed <= 0.01 * (double)n) { it++; break; }
+    }
+    free(nums); free(denoms); free(assign);
+    return it;
+}
+#undef PT
+
+/* centroidOf: VectorUtil.sum(List) (point order) then scale(1.0f / n) */
+void jvo_centroid_of(const float *X, int64_t n, int D, float *out)
+{
+    for (int d = 0; d < D; d++) out[d] = 0.0f;
+    for (int64_t i = 0; i < n; i++)
+        for (int d = 0; d < D; d++) out[d] = out[d] + X[(size_t)i * D + d];
+    float inv = 1.0f / (float)n;
+    for (int d = 0; d < D; d++) out[d] = out[d] * inv;
+}
+
+/* ProductQuantization.compute (unweighted): codebooks [sum_m k*size_m], centroid [D] (written iff globallyCenter) */
+void jvo_pq_train(const float *X, int64_t n, int D, int M, int k, int globallyCenter, uint64_t seed, int rounds,
+                  float *codebooks, float *centroid, int *rounds_run /* [M] or NULL */)
+{
+    int *sizes = (int *)malloc(sizeof(int) * (size_t)M), *offs = (int *)malloc(sizeof(int) * (size_t)M);
+    jvo_subvector_sizes_offsets(D, M, sizes, offs);
+    float *Xc = (float *)malloc(sizeof(float) * (size_t)n * D);
+    if (globallyCenter) {
+        jvo_centroid_of(X, n, D, centroid);
+        for (int64_t i = 0; i < n; i++) jvo_sub(X + (size_t)i * D, centroid, Xc + (size_t)i * D, D);
+    } else memcpy(Xc, X, sizeof(float) * (size_t)n * D);
+    size_t cboff = 0;
+    for (int m = 0; m < M; m++) {
+        uint64_t rng = jvo_kmeans_stream(seed, m);
+        jvo_kmeans_pp_init(Xc, n, D, offs[m], sizes[m], k, &rng, codebooks + cboff);
+        int r = jvo_kmeans_lloyd(Xc, n, D, offs[m], sizes[m], k, codebooks + cboff, rounds, &rng);
+        if (rounds_run) rounds_run[m] = r;
+        cboff += (size_t)k * sizes[m];
+    }
+    free(Xc); free(sizes); free(offs);
+}
+
+/* ProductQuantization.refine (unweighted): starts from pq's codebooks, `rounds` Lloyd rounds on new data */
+void jvo_pq_refine(const jvo_pq *pq, const float *X, int64_t n, int rounds, uint64_t seed, float *codebooks)
+{
+    const int D = pq->D;
+    float *Xc = (float *)malloc(sizeof(float) * (size_t)n * D);
+    if (pq->centroid) for (int64_t i = 0; i < n; i++) jvo_sub(X + (size_t)i * D, pq->centroid, Xc + (size_t)i * D, D);
+    else memcpy(Xc, X, sizeof(float) * (size_t)n * D);
+    size_t cboff = 0;
+    for (int m = 0; m < pq->M; m++) {
+        size_t cnt = (size_t)pq->k * pq->sizes[m];
+        memcpy(codebooks + cboff, pq->codebooks + cboff, sizeof(float) * cnt);
+        uint64_t rng = jvo_kmeans_stream(seed, m);
+        jvo_kmeans_lloyd(Xc, n, D, pq->offsets[m], pq->sizes[m], pq->k, codebooks + cboff, rounds, &rng);
+        cboff += cnt;
+    }
+    free(Xc);
+}
+
+/* ------------------------------------------------------------------------------------------
  * PQDecoder / FusedPQDecoder set-up and per-node scores
  * ---------------------------------------------------------------------------------------- */
 

@@ -78,6 +78,14 @@ typedef struct {
 void jvo_subvector_sizes_offsets(int D, int M, int *sizes, int *offsets);
 int  jvo_closest_centroid(const jvo_pq *pq, const float *vec /*already centred*/, int m);
 void jvo_pq_encode(const jvo_pq *pq, const float *vec, uint8_t *dst);
+/* PQ training with a seeded RNG substituted for ThreadLocalRandom (see jv_oracle.c) */
+uint64_t jvo_kmeans_stream(uint64_t seed, int m);
+void jvo_kmeans_pp_init(const float *X, int64_t n, int stride, int off, int len, int k, uint64_t *rng, float *C);
+int  jvo_kmeans_lloyd(const float *X, int64_t n, int stride, int off, int len, int k, float *C, int rounds, uint64_t *rng);
+void jvo_centroid_of(const float *X, int64_t n, int D, float *out);
+void jvo_pq_train(const float *X, int64_t n, int D, int M, int k, int globallyCenter, uint64_t seed, int rounds,
+                  float *codebooks, float *centroid, int *rounds_run);
+void jvo_pq_refine(const jvo_pq *pq, const float *X, int64_t n, int rounds, uint64_t seed, float *codebooks);
 float jvo_parallel_cost_multiplier(float threshold, int dimensions);
 void jvo_pq_encode_anisotropic(const jvo_pq *pq, float threshold, const float *vec, uint8_t *dst);
 void jvo_pq_encode_all(const jvo_pq *pq, const float *vecs, int64_t n, uint8_t *dst, int nthreads);

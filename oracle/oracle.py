@@ -115,6 +115,8 @@ def lib():
         sig("jvo_adc_scores", None, C.c_int, C.c_int, C.c_int, fp, fp, C.c_float, u8p, i32p, C.c_int64, fp)
         sig("jvo_pq_direct_score", C.c_float, pqp, fp, C.c_int, u8p)
         sig("jvo_pq_encode_anisotropic", None, pqp, C.c_float, fp, u8p)
+        sig("jvo_pq_train", None, fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, fp, fp, C.POINTER(C.c_int))
+        sig("jvo_pq_refine", None, pqp, fp, C.c_int64, C.c_int, C.c_uint64, fp)
         sig("jvo_parallel_cost_multiplier", C.c_float, C.c_float, C.c_int)
         sig("jvo_pq_diversity_score", C.c_float, fp, C.c_int, C.c_int, C.c_int, u8p, u8p)
         sig("jvo_pq_diversity_score_direct", C.c_float, pqp, C.c_int, u8p, u8p)
@@ -262,6 +264,17 @@ def subvector_sizes_offsets(D, M):
     return s, o
 
 
+def pq_train(vecs, M, k=256, globally_center=False, seed=1, rounds=6):
+    """ProductQuantization.compute (unweighted) with a seeded RNG -> (OraclePQ, rounds_run[M])."""
+    vecs = f32(vecs)
+    n, D = vecs.shape
+    cb = np.empty(k * D, np.float32)
+    cen = np.zeros(D, np.float32)
+    rr = (C.c_int * M)()
+    lib().jvo_pq_train(_f(vecs), n, D, M, k, 1 if globally_center else 0, seed, rounds, _f(cb), _f(cen), rr)
+    return OraclePQ(D, M, cb, cen if globally_center else None, k), np.array(list(rr))
+
+
 class OraclePQ:
     """Flat-array ProductQuantization for the oracle (codebooks concatenated centroid-major)."""
 
@@ -291,6 +304,13 @@ class OraclePQ:
         out = np.empty(self.M, np.uint8)
         lib().jvo_pq_encode(self.ref, _f(vec), _u8(out))
         return out
+
+    def refine(self, vecs, rounds=1, seed=1):
+        """ProductQuantization.refine (unweighted) -> new OraclePQ."""
+        vecs = f32(vecs)
+        cb = np.empty_like(self.codebooks)
+        lib().jvo_pq_refine(self.ref, _f(vecs), vecs.shape[0], rounds, seed, _f(cb))
+        return OraclePQ(self.D, self.M, cb, self.centroid, self.k, sizes=self.sizes)
 
     def encode_anisotropic(self, vec, threshold):
         """ProductQuantization.encodeTo with anisotropicThreshold = threshold (> -1)."""

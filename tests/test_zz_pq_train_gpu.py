@@ -1,0 +1,49 @@
+"""PQ training on the GPU through the C ABI: ProductQuantization.compute / refine / write, bit-identical to
+the oracle's sequential restatement for the same seed.  Written after round 1's GPU budget was spent (bodies verified on the
+CPU, tests/test_pq_train_emulated.py); opt-in until its first hardware run (JVECTOR_TEST_PQ_TRAIN=1)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("JVECTOR_TEST_PQ_TRAIN") != "1",
+                                 reason="PQ training not yet validated on hardware; set JVECTOR_TEST_PQ_TRAIN=1")]
+
+import jvector_amd as J
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = J.HipContext(0)
+    yield c
+    c.close()
+
+
+def data(n, D, seed):
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((40, D)).astype(np.float32)
+    return (centers[rng.integers(0, 40, n)] + 0.3 * rng.standard_normal((n, D))).astype(np.float32)
+
+
+@pytest.mark.parametrize("D,M,center", [(32, 4, True), (26, 3, False), (128, 16, True)])
+def test_train_refine_write(ctx, D, M, center):
+    v = data(5000, D, D)
+    want, _ = O.pq_train(v, M, globally_center=center, seed=7)
+    pq = J.ProductQuantization.compute(ctx, v, M, globally_center=center, seed=7)
+    blob = pq.write(6)
+    got, ver, aniso, used = O.OraclePQ.parse(blob)
+    assert used == len(blob) and ver == 6 and aniso == -1.0
+    assert np.array_equal(got.codebooks, want.codebooks)
+    assert (got.centroid is None) == (want.centroid is None)
+    if center:
+        assert np.array_equal(got.centroid, want.centroid)
+    assert blob == want.serialize(6)                       # byte-identical wire form
+    assert np.array_equal(pq.encode_all(v[:200]), want.encode_all(v[:200]))
+    x = data(3000, D, D + 1)
+    want2 = want.refine(x, 2, seed=3)
+    got2, _, _, _ = O.OraclePQ.parse(pq.refine(x, 2, seed=3).write(0 if not center else 2))
+    assert np.array_equal(got2.codebooks, want2.codebooks)
+    with pytest.raises(ValueError):
+        J.ProductQuantization.compute(ctx, v[:100], M)   # fewer points than clusters
