@@ -53,6 +53,24 @@ class HipShardBackend:
         return self.J.topk(self.ctx, scores, k, ids=ids)
 
 
+class HipGraphShardBackend(HipShardBackend):
+    """One shard with its OWN graph index over ordinals [lo, hi) (the way JVector deployments shard: one segment index per
+    partition).  The partial result is the graph search's kept approximate top-rerankK (GraphSearcher without a reranker)
+    instead of the exhaustive ADC scan; merge, exact rerank by the owning shard and final top-K are unchanged, so the answer
+    equals "search every segment, merge under the NodeQueue order, rerank" computed on one device."""
+
+    def __init__(self, ctx, graph, pq, pq_vectors, fused, vectors, lo, max_queries=256):
+        import jvector_amd as J
+        self.J, self.ctx, self.lo, self.count = J, ctx, int(lo), pq_vectors.count()
+        self.vectors = vectors
+        self.searcher = J.GraphSearcher(ctx, graph, pq, pq_vectors, fused, None, max_queries=max_queries)
+
+    def adc_topk(self, queries, vsf, k):
+        ids, sc = self.searcher.search(queries, vsf, k, k)
+        ids = torch.as_tensor(ids)
+        return torch.where(ids >= 0, ids + self.lo, ids), torch.as_tensor(sc)
+
+
 class ShardedFlatSearcher:
     """local_shards: the shards living in THIS process (normally one: one process per GPU).
     group: a torch.distributed process group (None = default group when initialised, else single process)."""
@@ -100,3 +118,6 @@ class ShardedFlatSearcher:
         # 4. final top-K
         out_ids, out_sc = be.topk(exact, cand.contiguous(), top_k)
         return torch.as_tensor(out_ids), torch.as_tensor(out_sc)
+
+
+ShardedSearcher = ShardedFlatSearcher  # the merge does not care how a shard produced its partial top-k

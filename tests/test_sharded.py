@@ -132,6 +132,65 @@ def test_sharded_local_shards_cpu_checker():
         s.search(torch.from_numpy(queries), O.COSINE, 10, 5)
 
 
+class OracleGraphShardBackend(OracleShardBackend):
+    """CPU checker for HipGraphShardBackend: the partial top-k comes from the oracle's graph search over the shard's graph."""
+
+    def __init__(self, opq, codes, vecs, lo, graph, fused):
+        super().__init__(opq, codes, vecs, lo)
+        self.graph, self.fused = graph, fused
+
+    def adc_topk(self, queries, vsf, k):
+        ids, sc, _ = self.graph.search(self.opq, self.codes, None, queries.numpy(), int(vsf), k, k, fused=self.fused)
+        return torch.from_numpy(np.where(ids >= 0, ids + self.lo, ids).astype(np.int32)), torch.from_numpy(sc)
+
+
+def _graph_shards(seed, n_shards, N=1500, D=64, M=8):
+    from test_graph_search import build_problem
+    shards, lo = [], 0
+    for s in range(n_shards):
+        v, lv, entry, entry_level, cb, q = build_problem(seed + s, N=N, D=D, M=M, levels=2)
+        shards.append((v, lv, entry, entry_level, lo))
+        lo += N
+    return shards, cb, q[:6]
+
+
+def _manual_merge(opq, shard_results, shard_vecs, q, vsf, top_k, rerank_k):
+    """union of the per-shard kept results -> top-rerankK by NodeQueue key -> exact scores -> top-K"""
+    out_i, out_s = [], []
+    for qi in range(q.shape[0]):
+        ids = np.concatenate([r[0][qi] for r in shard_results])
+        sc = np.concatenate([r[1][qi] for r in shard_results])
+        keep = ids >= 0
+        ci, _ = O.topk(ids[keep], sc[keep], rerank_k)
+        ex = np.array([O.compare(int(vsf), q[qi], shard_vecs[g]) for g in ci], np.float32)
+        ti, ts = O.topk(ci, ex, top_k)
+        out_i.append(ti)
+        out_s.append(ts)
+    return np.stack(out_i), np.stack(out_s)
+
+
+def test_sharded_graph_backends_cpu_checker():
+    """segment indexes: three shards, each with its own graph; sharded result == manual merge of the per-shard searches"""
+    shards, cb, q = _graph_shards(40, 3)
+    opq = O.OraclePQ(64, 8, cb)
+    backends, results, allv = [], {}, {}
+    for v, lv, entry, entry_level, lo in shards:
+        codes = opq.encode_all(v, nthreads=1)
+        og = O.OracleGraph(len(v), lv, entry, entry_level)
+        backends.append(OracleGraphShardBackend(opq, codes, v, lo, og, True))
+        for i in range(len(v)):
+            allv[lo + i] = v[i]
+    s = ShardedFlatSearcher(backends)
+    for vsf in (O.EUCLIDEAN, O.COSINE):
+        per = []
+        for b in backends:
+            ids, sc = b.adc_topk(torch.from_numpy(q), vsf, 30)
+            per.append((ids.numpy(), sc.numpy()))
+        wi, ws = _manual_merge(opq, per, allv, q, vsf, 10, 30)
+        gi, gs = s.search(torch.from_numpy(q), vsf, 10, 30)
+        assert np.array_equal(gi.numpy(), wi) and np.array_equal(gs.numpy(), ws)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_hip_equals_single_gpu(world):
