@@ -852,7 +852,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const jv_pq *pq = l->pq;
 
     // ---- sizing: LDS tier, workers, per-worker scratch ----
-    int cand_cap = std::max(256, env_int("JVECTOR_HIP_GS_CAND_CAP", 1024)) & ~63;
+    // register-allocation variant: 2 waves/SIMD (default) or 4 (JVECTOR_HIP_GS_OCC=4: smaller LDS tier so 16 waves fit a CU)
+    const int occ = env_int("JVECTOR_HIP_GS_OCC", 2) >= 4 ? 4 : 2;
+    int cand_cap = std::max(256, env_int("JVECTOR_HIP_GS_CAND_CAP", occ == 4 ? 512 : 1024)) & ~63;
     while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
     const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap);
     if (lds > ctx->lds_per_block) {
@@ -860,7 +862,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
                   lds, ctx->lds_per_block);
         return JV_ERR_UNSUPPORTED;
     }
-    int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / (lds + 256)));
+    int per_cu = (int)std::min<size_t>((size_t)4 * occ, std::max<size_t>(1, (160 * 1024) / (lds + 256)));
     per_cu = std::max(1, env_int("JVECTOR_HIP_GS_WAVES_PER_CU", per_cu));
     const int workers = std::max(1, std::min(Q, ctx->num_cus * per_cu));
     const int vcap_log2 = gs_vcap_log2(rerankK);
@@ -926,7 +928,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.next_query = d_counter;
     {
         ProfScope ps(ctx, R_ADC);
-        JV_TRY(launch_graph_search(ctx->stream, kvsf, p, workers));
+        JV_TRY(launch_graph_search(ctx->stream, kvsf, p, workers, occ));
     }
 
     // ---- reranking :471-507 on the device-resident candidates ----
@@ -961,8 +963,8 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         }
     }
     if (getenv("JVECTOR_HIP_GRAPH_TIMING"))
-        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU) lds=%zu cand_cap=%d vcap=%zu overflow=%zu\n", Q, workers,
-                per_cu, lds, cand_cap, vcap, redo.size());
+        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d) lds=%zu cand_cap=%d vcap=%zu overflow=%zu\n", Q, workers,
+                per_cu, occ, lds, cand_cap, vcap, redo.size());
     if (redo.empty()) return JV_OK;
 
     // ---- queries that outgrew the fixed-size device structures: same search on the host ----

@@ -22,18 +22,21 @@ namespace jv {
 
 static_assert(VSF_L2 == 0 && VSF_DOT == 1 && VSF_COS == 2, "gs_body.h hard-codes the kernel vsf numbering");
 
-template <int VSF, int CH16>
-__global__ __launch_bounds__(64) void graph_search_kernel(GsParams p)
+// OCC = waves per SIMD the register allocation is held to: 2 (225 VGPRs: the unrolled scoring keeps ~100 codebook
+// loads in flight per wave) or 4 (128 VGPRs, no spills: twice the resident queries per CU to hide the
+// pop -> load -> probe -> score -> push dependency chain).  Which wins is a measurement; both are built.
+template <int VSF, int CH16, int OCC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void graph_search_kernel(GsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_lds[];
     gs_worker<VSF, CH16>(p, (int)blockIdx.x, gs_lds);
 }
 
-template <int VSF>
+template <int VSF, int OCC>
 static int launch_gs_ch(hipStream_t s, const GsParams &p, int ch, int workers, size_t lds)
 {
     dim3 grid(workers), block(64);
-#define JV_GS(CH) hipLaunchKernelGGL((graph_search_kernel<VSF, CH>), grid, block, lds, s, p)
+#define JV_GS(CH) hipLaunchKernelGGL((graph_search_kernel<VSF, CH, OCC>), grid, block, lds, s, p)
     switch (ch) {
     case 1: JV_GS(1); break;
     case 2: JV_GS(2); break;
@@ -63,14 +66,22 @@ bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const
 
 size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap) { return gs_lds_bytes(D, rerankK, cand_cap); }
 
-int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers)
+int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy)
 {
     if (p.Q == 0) return JV_OK;
     const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap);
+    const int ch = p.M / 16;
+    if (occupancy >= 4) {
+        switch (vsf) {
+        case VSF_L2: return launch_gs_ch<VSF_L2, 4>(s, p, ch, workers, lds);
+        case VSF_DOT: return launch_gs_ch<VSF_DOT, 4>(s, p, ch, workers, lds);
+        default: return launch_gs_ch<VSF_COS, 4>(s, p, ch, workers, lds);
+        }
+    }
     switch (vsf) {
-    case VSF_L2: return launch_gs_ch<VSF_L2>(s, p, p.M / 16, workers, lds);
-    case VSF_DOT: return launch_gs_ch<VSF_DOT>(s, p, p.M / 16, workers, lds);
-    default: return launch_gs_ch<VSF_COS>(s, p, p.M / 16, workers, lds);
+    case VSF_L2: return launch_gs_ch<VSF_L2, 2>(s, p, ch, workers, lds);
+    case VSF_DOT: return launch_gs_ch<VSF_DOT, 2>(s, p, ch, workers, lds);
+    default: return launch_gs_ch<VSF_COS, 2>(s, p, ch, workers, lds);
     }
 }
 

@@ -15,6 +15,10 @@ for t in host device; do
       --traversal $t > gpurun_out/gs/bench_1m_$t.json 2> gpurun_out/gs/bench_1m_$t.err
   tail -c 600 gpurun_out/gs/bench_1m_$t.err; head -c 400 gpurun_out/gs/bench_1m_$t.json; echo
 done
+# 2b. register-allocation variant: 4 waves/SIMD (128 VGPRs, 16 resident queries per CU)
+JVECTOR_HIP_GS_OCC=4 JVECTOR_HIP_GRAPH_TIMING=1 timeout 600 python bench.py --n 1000000 --steps 5 --warmup 1 --no-flat --no-cpu-baseline \
+    --traversal device > gpurun_out/gs/bench_1m_device_occ4.json 2> gpurun_out/gs/bench_1m_device_occ4.err
+tail -c 400 gpurun_out/gs/bench_1m_device_occ4.err; head -c 300 gpurun_out/gs/bench_1m_device_occ4.json; echo
 # 3. the headline configuration with the device traversal
 if [ "${GS_FULL:-1}" = "1" ]; then
   JVECTOR_HIP_GRAPH_TIMING=1 timeout 900 python bench.py --traversal device > gpurun_out/gs/bench_10m_device.json \
