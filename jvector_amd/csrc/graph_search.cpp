@@ -854,9 +854,14 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // ---- sizing: LDS tier, workers, per-worker scratch ----
     // register-allocation variant: 2 waves/SIMD (default) or 4 (JVECTOR_HIP_GS_OCC=4: smaller LDS tier so 16 waves fit a CU)
     const int occ = env_int("JVECTOR_HIP_GS_OCC", 2) >= 4 ? 4 : 2;
-    int cand_cap = std::max(256, env_int("JVECTOR_HIP_GS_CAND_CAP", occ == 4 ? 512 : 1024)) & ~63;
-    while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
-    const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap);
+    // pair-lane scoring (two lanes per neighbour) when no level has more than 32 neighbours; it needs an M/2 x 32 float
+    // exchange area in LDS, which only fits next to the queues at 2 waves/SIMD.  JVECTOR_HIP_GS_PAIR=0 turns it off.
+    bool pair = occ == 2 && env_int("JVECTOR_HIP_GS_PAIR", 1) != 0;
+    for (int lv = 0; lv <= g->entry_level; ++lv) pair = pair && g->levels[lv].degree <= 32;
+    const int pair_M = pair ? pq->M : 0;
+    int cand_cap = std::max(256, env_int("JVECTOR_HIP_GS_CAND_CAP", occ == 4 ? 512 : (pair ? 768 : 1024))) & ~63;
+    while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
+    const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M);
     if (lds > ctx->lds_per_block) {
         set_error("graph_search(device): rerankK %d needs %zu bytes of LDS per wave (limit %zu); use the host traversal", rerankK,
                   lds, ctx->lds_per_block);
@@ -921,6 +926,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.spill = (long long *)ctx->d_gs_spill.ptr;
     p.spill_cap = spill_cap;
     p.cand_cap = cand_cap;
+    p.pair = pair ? 1 : 0;
     p.out_ids = d_cand;
     p.out_scores = d_cand_sc;
     p.out_stats = d_stats;
@@ -963,8 +969,8 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         }
     }
     if (getenv("JVECTOR_HIP_GRAPH_TIMING"))
-        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d) lds=%zu cand_cap=%d vcap=%zu overflow=%zu\n", Q, workers,
-                per_cu, occ, lds, cand_cap, vcap, redo.size());
+        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d) lds=%zu cand_cap=%d vcap=%zu overflow=%zu\n", Q, workers,
+                per_cu, occ, (int)pair, lds, cand_cap, vcap, redo.size());
     if (redo.empty()) return JV_OK;
 
     // ---- queries that outgrew the fixed-size device structures: same search on the host ----

@@ -13,6 +13,7 @@
 //     gs_fetch_add(uint32_t *p, uint32_t v) -> old                    (device-scope atomic)
 //     gs_fence()                              device-scope memory fence
 //     gs_sqrt(double)
+//     GS_SCHED_FENCE()                        instruction-scheduling fence (may be empty)
 //
 // What it computes is GraphSearcher.search for threshold 0 / acceptOrds ALL (B/graph/GraphSearcher.java:222-243,
 // 263-282 internalSearch, 334-353 initializeInternal, 355-369 stopSearch, 406-457 searchOneLayer, 324-331
@@ -170,6 +171,67 @@ GS_FN float gs_row_sum(const float *codebooks, const float *qs, const gs_u4 (&w)
     return sum;
 }
 
+// ---- pair-lane scoring (maxDegree <= 32 leaves half the wave idle): lanes i and i + 32 share neighbour i.  Each
+//      computes the table entries of HALF the subspaces (entries are independent of one another); the low lane then forms
+//      the running sum in ascending m — its own entries first, the partner's after — so the f32 result is unchanged.
+struct alignas(8) gs_u2 { uint32_t x, y; };
+
+template <int HW>  // HW 8-byte words = M / 2 code bytes
+GS_FN void gs_load_half(const uint8_t *rp, gs_u2 (&w)[HW])
+{
+    const gs_u2 *r2 = reinterpret_cast<const gs_u2 *>(rp);
+#pragma unroll
+    for (int c = 0; c < HW; ++c) w[c] = r2[c];
+}
+
+// Entries of this lane's half of the subspaces.  Low lane (xw == nullptr): returns their running sum (ascending m).
+// High lane: writes entry j to xw[j * 32] (LDS exchange area, column = neighbour) for its partner and returns 0.
+template <int VSF, int HW>
+GS_FN float gs_half_entries(const float *codebooks, const float *qs, const gs_u2 (&w)[HW], int m_base, float *xw)
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < HW; ++c) {
+        const uint32_t d[2] = {w[c].x, w[c].y};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = c * 8 + e * 4 + b;
+                const int m = m_base + j;
+                const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
+                const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(codebooks + ((int64_t)m * 256 + code) * 8);
+                const gs_f4 c0 = cp[0], c1 = cp[1];
+                const float *q = qs + m * 8;
+                float v = 0.0f;
+                if (VSF == 0 /* L2 */) {
+                    float t;
+                    t = c0.x - q[0]; v += t * t;
+                    t = c0.y - q[1]; v += t * t;
+                    t = c0.z - q[2]; v += t * t;
+                    t = c0.w - q[3]; v += t * t;
+                    t = c1.x - q[4]; v += t * t;
+                    t = c1.y - q[5]; v += t * t;
+                    t = c1.z - q[6]; v += t * t;
+                    t = c1.w - q[7]; v += t * t;
+                } else {
+                    v += c0.x * q[0];
+                    v += c0.y * q[1];
+                    v += c0.z * q[2];
+                    v += c0.w * q[3];
+                    v += c1.x * q[4];
+                    v += c1.y * q[5];
+                    v += c1.z * q[6];
+                    v += c1.w * q[7];
+                }
+                if (xw) xw[j * 32] = v;
+                else sum += v;
+            }
+        }
+    }
+    return sum;
+}
+
 // raw table sum -> similarity (jv_device.h score_from_raw / cosine_finish; PQDecoder.java:68,79,126)
 template <int VSF>
 GS_FN float gs_finish(float sum, float node_mag, float query_mag)
@@ -280,7 +342,8 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 }
 
 // One query, start to finish.  lds: gs_lds_bytes() bytes, 16-byte aligned.
-template <int VSF, int CH16>
+// PAIR: every level's degree is <= 32 -> pair-lane scoring (decided by the host at launch)
+template <int VSF, int CH16, bool PAIR>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
     const int lane = gs_lane();
@@ -290,6 +353,8 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     s.cand = s.res + p.rerankK;
     s.evicted = s.cand + p.cand_cap;
     s.samp = s.evicted + GS_EVICT_CAP;
+    float *xchg = reinterpret_cast<float *>(s.samp + 64);  // [M/2][32] entries handed from high to low lanes (PAIR only)
+    (void)xchg;
     s.spill = p.spill + (int64_t)worker * p.spill_cap;
     s.cand_n = s.spill_n = s.res_n = s.ev_n = 0;
     s.res_min_idx = -1;
@@ -386,32 +451,71 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             const int32_t *row = gs_level_row(L, node);
             if (!row) continue;
             const int deg = L.degree;
-            const int32_t nb = lane < deg ? row[lane] : -1;
-            // code bytes first, then the visited probes: the loads do not depend on the probes' outcome
-            gs_u4 w[CH16];
-            float node_mag = 0.0f;
             const bool fused0 = lvl == 0 && p.blocks != nullptr;
-            if (fused0 && lane < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
-                const int64_t r = (int64_t)node * p.deg0 + lane;
-                gs_load_row<CH16>(p.blocks + r * p.M, w);
-                if (VSF == 2) node_mag = p.fused_norms[r];
-            }
-            const int first_neg = gs_first(gs_ballot(nb < 0));  // rows are packed: the first -1 ends the row
-            const bool valid = lane < first_neg;
-            if (!fused0 && valid) {      // PQDecoder.similarityTo: the neighbour's own code
-                gs_load_row<CH16>(p.codes + (int64_t)nb * p.M, w);
-                if (VSF == 2) node_mag = p.code_norms[nb];
-            }
-            const bool fresh = valid && gs_visit(vis, vmask, vshift, nb);
-            const uint64_t fm = gs_ballot(fresh);
-            if (fm == 0) continue;
-            n_visited += gs_popc(fm);
-            if ((n_visited + 1) * 2 > vcap) {
-                s.status = GS_OVERFLOW;
-                break;
-            }
             long long key = 0;
-            if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CH16>(p.codebooks, qs, w), node_mag, query_mag));
+            bool fresh;
+            if (PAIR) {
+                // ---- pair-lane form: neighbour i is handled by lanes i (low) and i + 32 (high) ----
+                const int ni = lane & 31;
+                const bool hi = lane >= 32;
+                const int m_base = hi ? p.M / 2 : 0;
+                const int32_t nb = ni < deg ? row[ni] : -1;
+                gs_u2 w[CH16];
+                float node_mag = 0.0f;
+                if (fused0 && ni < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
+                    const int64_t r = (int64_t)node * p.deg0 + ni;
+                    gs_load_half<CH16>(p.blocks + r * p.M + m_base, w);
+                    if (VSF == 2 && !hi) node_mag = p.fused_norms[r];
+                }
+                const int first_neg = gs_first(gs_ballot(!hi && nb < 0));  // rows are packed: the first -1 ends the row
+                const bool valid = ni < first_neg;
+                if (!fused0 && valid) {    // PQDecoder.similarityTo: the neighbour's own code
+                    gs_load_half<CH16>(p.codes + (int64_t)nb * p.M + m_base, w);
+                    if (VSF == 2 && !hi) node_mag = p.code_norms[nb];
+                }
+                fresh = !hi && valid && gs_visit(vis, vmask, vshift, nb);  // one probe per neighbour: the low lane's
+                const uint64_t fm = gs_ballot(fresh);
+                if (fm == 0) continue;
+                n_visited += gs_popc(fm);
+                if ((n_visited + 1) * 2 > vcap) {
+                    s.status = GS_OVERFLOW;
+                    break;
+                }
+                const bool work = ((fm >> ni) & 1ull) != 0;  // this lane's pair has a fresh neighbour
+                float sum = 0.0f;
+                if (work) sum = gs_half_entries<VSF, CH16>(p.codebooks, qs, w, m_base, hi ? xchg + ni : nullptr);
+                gs_barrier();
+                if (fresh) {  // low lane: its own subspaces [0, M/2) are summed; now the partner's [M/2, M) in order
+#pragma unroll
+                    for (int j = 0; j < CH16 * 8; ++j) sum += xchg[j * 32 + ni];
+                    key = gs_key(nb, gs_finish<VSF>(sum, node_mag, query_mag));
+                }
+            } else {
+                const int32_t nb = lane < deg ? row[lane] : -1;
+                // code bytes first, then the visited probes: the loads do not depend on the probes' outcome
+                gs_u4 w[CH16];
+                float node_mag = 0.0f;
+                if (fused0 && lane < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
+                    const int64_t r = (int64_t)node * p.deg0 + lane;
+                    gs_load_row<CH16>(p.blocks + r * p.M, w);
+                    if (VSF == 2) node_mag = p.fused_norms[r];
+                }
+                const int first_neg = gs_first(gs_ballot(nb < 0));  // rows are packed: the first -1 ends the row
+                const bool valid = lane < first_neg;
+                if (!fused0 && valid) {      // PQDecoder.similarityTo: the neighbour's own code
+                    gs_load_row<CH16>(p.codes + (int64_t)nb * p.M, w);
+                    if (VSF == 2) node_mag = p.code_norms[nb];
+                }
+                fresh = valid && gs_visit(vis, vmask, vshift, nb);
+                const uint64_t fm = gs_ballot(fresh);
+                if (fm == 0) continue;
+                n_visited += gs_popc(fm);
+                if ((n_visited + 1) * 2 > vcap) {
+                    s.status = GS_OVERFLOW;
+                    break;
+                }
+                if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CH16>(p.codebooks, qs, w), node_mag, query_mag));
+            }
             gs_push(s, p, key, fresh);
             if (s.status != GS_OK) break;
         }
@@ -449,7 +553,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 }
 
 // Persistent worker: pulls queries off the shared counter until none are left.
-template <int VSF, int CH16>
+template <int VSF, int CH16, bool PAIR>
 GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
 {
     for (;;) {
@@ -457,7 +561,7 @@ GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
         if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
         const int q = (int)gs_shfl(qv, 0);
         if (q >= p.Q) break;
-        gs_search_one<VSF, CH16>(p, q, worker, lds);
+        gs_search_one<VSF, CH16, PAIR>(p, q, worker, lds);
     }
 }
 

@@ -40,6 +40,7 @@ struct GsParams {
     long long *spill;         // [workers][spill_cap]
     int32_t spill_cap;
     int32_t cand_cap;         // LDS tier capacity (>= 256)
+    int32_t pair;             // 1: pair-lane scoring (every degree <= 32; LDS has the M/2 x 32 exchange area)
     // outputs
     int32_t *out_ids;         // [Q][rerankK] kept approximate results (unordered), -1 padded
     float *out_scores;        // [Q][rerankK] their approximate scores, -inf padded
@@ -49,9 +50,10 @@ struct GsParams {
 };
 
 // LDS bytes one worker needs
-inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap)
+inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M when pair-lane scoring is on, else 0 */)
 {
-    return sizeof(float) * (size_t)D + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + GS_EVICT_CAP + 64);
+    return sizeof(float) * (size_t)D + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + GS_EVICT_CAP + 64) +
+           sizeof(float) * 32 * (size_t)(pair_M / 2);
 }
 
 }  // namespace jv

@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #define GS_FN __device__ __forceinline__
+#define GS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ int gs_lane() { return (int)threadIdx.x; }
 __device__ __forceinline__ void gs_barrier() { __syncthreads(); }
 __device__ __forceinline__ uint64_t gs_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }

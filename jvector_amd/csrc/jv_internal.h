@@ -239,7 +239,7 @@ int launch_direct_scores(hipStream_t s, const jv_codes *codes, int vsf, const fl
 // device-resident graph traversal (k_gsearch.hip; parameters in gs_params.h)
 struct GsParams;
 bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels);
-size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap);
+size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M);
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy);
 size_t topk_scratch_bytes(int Q, int k);
 int launch_topk(hipStream_t s, const jv_ctx *ctx, const float *d_scores, const int32_t *d_ids, int Q, int64_t n,

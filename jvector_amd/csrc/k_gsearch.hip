@@ -25,18 +25,31 @@ static_assert(VSF_L2 == 0 && VSF_DOT == 1 && VSF_COS == 2, "gs_body.h hard-codes
 // OCC = waves per SIMD the register allocation is held to: 2 (225 VGPRs: the unrolled scoring keeps ~100 codebook
 // loads in flight per wave) or 4 (128 VGPRs, no spills: twice the resident queries per CU to hide the
 // pop -> load -> probe -> score -> push dependency chain).  Which wins is a measurement; both are built.
-template <int VSF, int CH16, int OCC>
+template <int VSF, int CH16, int OCC, bool PAIR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void graph_search_kernel(GsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_lds[];
-    gs_worker<VSF, CH16>(p, (int)blockIdx.x, gs_lds);
+    gs_worker<VSF, CH16, PAIR>(p, (int)blockIdx.x, gs_lds);
 }
 
 template <int VSF, int OCC>
 static int launch_gs_ch(hipStream_t s, const GsParams &p, int ch, int workers, size_t lds)
 {
     dim3 grid(workers), block(64);
-#define JV_GS(CH) hipLaunchKernelGGL((graph_search_kernel<VSF, CH, OCC>), grid, block, lds, s, p)
+    const bool pair = p.pair != 0;
+    if (pair && OCC != 2) {
+        set_error("graph search kernel: pair-lane scoring is only built for the 2-waves/SIMD variant");
+        return JV_ERR_INVALID;
+    }
+#define JV_GS(CH)                                                                                           \
+    do {                                                                                                    \
+        if constexpr (OCC == 2) {                                                                           \
+            if (pair) hipLaunchKernelGGL((graph_search_kernel<VSF, CH, OCC, true>), grid, block, lds, s, p); \
+            else hipLaunchKernelGGL((graph_search_kernel<VSF, CH, OCC, false>), grid, block, lds, s, p);     \
+        } else {                                                                                            \
+            hipLaunchKernelGGL((graph_search_kernel<VSF, CH, OCC, false>), grid, block, lds, s, p);          \
+        }                                                                                                   \
+    } while (0)
     switch (ch) {
     case 1: JV_GS(1); break;
     case 2: JV_GS(2); break;
@@ -64,12 +77,12 @@ bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const
            n_levels <= GS_MAX_LEVELS;
 }
 
-size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap) { return gs_lds_bytes(D, rerankK, cand_cap); }
+size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M) { return gs_lds_bytes(D, rerankK, cand_cap, pair_M); }
 
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy)
 {
     if (p.Q == 0) return JV_OK;
-    const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap);
+    const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0);
     const int ch = p.M / 16;
     if (occupancy >= 4) {
         switch (vsf) {

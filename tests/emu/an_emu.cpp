@@ -2,6 +2,7 @@
 #include "hip_emu.h"
 
 #define GS_FN inline
+#define GS_SCHED_FENCE() ((void)0)
 static inline int gs_lane() { return emu::lane(); }
 static inline void gs_barrier() { emu::barrier(); }
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }

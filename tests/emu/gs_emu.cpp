@@ -5,6 +5,7 @@
 #include "hip_emu.h"
 
 #define GS_FN inline
+#define GS_SCHED_FENCE() ((void)0)
 static inline int gs_lane() { return emu::lane(); }
 static inline void gs_barrier() { emu::barrier(); }
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
@@ -35,24 +36,30 @@ struct Launch {
     char *lds;
 };
 
-template <int VSF>
+template <int VSF, bool PAIR>
 void run_ch(const Launch &L)
 {
     switch (L.ch) {
-    case 1: jv::gs_worker<VSF, 1>(*L.p, L.worker, L.lds); break;
-    case 2: jv::gs_worker<VSF, 2>(*L.p, L.worker, L.lds); break;
-    case 3: jv::gs_worker<VSF, 3>(*L.p, L.worker, L.lds); break;
-    case 4: jv::gs_worker<VSF, 4>(*L.p, L.worker, L.lds); break;
-    case 6: jv::gs_worker<VSF, 6>(*L.p, L.worker, L.lds); break;
+    case 1: jv::gs_worker<VSF, 1, PAIR>(*L.p, L.worker, L.lds); break;
+    case 2: jv::gs_worker<VSF, 2, PAIR>(*L.p, L.worker, L.lds); break;
+    case 3: jv::gs_worker<VSF, 3, PAIR>(*L.p, L.worker, L.lds); break;
+    case 4: jv::gs_worker<VSF, 4, PAIR>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gs_worker<VSF, 6, PAIR>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
+}
+template <bool PAIR>
+void run_vsf(const Launch &L)
+{
+    if (L.vsf == 0) run_ch<0, PAIR>(L);
+    else if (L.vsf == 1) run_ch<1, PAIR>(L);
+    else run_ch<2, PAIR>(L);
 }
 void lane_main(void *arg)
 {
     const Launch &L = *(const Launch *)arg;
-    if (L.vsf == 0) run_ch<0>(L);
-    else if (L.vsf == 1) run_ch<1>(L);
-    else run_ch<2>(L);
+    if (L.p->pair) run_vsf<true>(L);
+    else run_vsf<false>(L);
 }
 }  // namespace
 
@@ -60,7 +67,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
                               const int32_t *lv_degree, int entry_node, int entry_level, const float *codebooks, const float *cq,
                               const float *bmag, const uint8_t *codes, const float *code_norms, const uint8_t *blocks,
                               const float *fused_norms, int D, int M, int deg0, int Q, int rerankK, int vsf, int vcap_log2,
-                              int spill_cap, int cand_cap, int workers, int32_t *out_ids, float *out_scores, long long *out_stats,
+                              int spill_cap, int cand_cap, int workers, int pair_mode /* 0 off, 1 when degrees allow */, int32_t *out_ids, float *out_scores, long long *out_stats,
                               int32_t *out_status)
 {
     if (n_levels < 1 || n_levels > jv::GS_MAX_LEVELS || M % 16 != 0 || D != 8 * M || cand_cap < 256) return -1;
@@ -87,6 +94,9 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     int32_t *visited = (int32_t *)aligned_alloc(64, sizeof(int32_t) * vcap * workers);
     long long *spill = (long long *)aligned_alloc(64, sizeof(long long) * (size_t)(spill_cap > 0 ? spill_cap : 1) * workers + 64);
     memset(visited, 0x5a, sizeof(int32_t) * vcap * workers);  // garbage: the kernel must clear it itself
+    bool pair = pair_mode != 0;  // same rule as graph_search.cpp
+    for (int l = 0; l < n_levels; ++l) pair = pair && lv_degree[l] <= 32;
+    p.pair = pair ? 1 : 0;
     p.visited = visited; p.vcap_log2 = vcap_log2; p.spill = spill; p.spill_cap = spill_cap; p.cand_cap = cand_cap;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_stats = out_stats; p.out_status = out_status;
     uint32_t next = 0;
@@ -97,8 +107,8 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     for (int w = 0; w < workers; ++w) {
         jv::GsParams pw = p;
         pw.Q = (int)((long long)Q * (w + 1) / workers);
-        char *lds = (char *)aligned_alloc(64, jv::gs_lds_bytes(D, rerankK, cand_cap) + 64);
-        memset(lds, 0xa5, jv::gs_lds_bytes(D, rerankK, cand_cap));
+        char *lds = (char *)aligned_alloc(64, jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0) + 64);
+        memset(lds, 0xa5, jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0));
         Launch L{&pw, vsf, M / 16, w, lds};
         collectives += emu::run_wave(lane_main, &L);
         next = (uint32_t)pw.Q;  // the drained worker overshot the counter by one

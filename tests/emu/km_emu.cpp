@@ -5,6 +5,7 @@
 #include "hip_emu.h"
 
 #define GS_FN inline
+#define GS_SCHED_FENCE() ((void)0)
 #define KM_FN static inline
 static inline int gs_lane() { return emu::lane(); }
 static inline void gs_barrier() { emu::barrier(); }

@@ -39,7 +39,7 @@ def seq_sum_f32(table, codes):
 
 
 def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vcap_log2=14, spill_cap=8192, cand_cap=256,
-            workers=2):
+            workers=2, pair=1):
     N, M, D = codes.shape[0], opq.M, opq.D
     Q = q.shape[0]
     deg0 = lv[0][1].shape[1]
@@ -72,7 +72,7 @@ def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vc
     codes = np.ascontiguousarray(codes, np.uint8)
     n = emu.gs_emu_search(L, nodes, nbrs, count, degree, entry, entry_level, fp(cb), fp(cq), fp(bmag), fp(codes),
                           fp(code_norms), fp(blocks), fp(fnorms), D, M, deg0, Q, rerank_k, int(vsf), vcap_log2, spill_cap,
-                          cand_cap, workers, fp(out_ids), fp(out_sc), fp(stats), fp(status))
+                          cand_cap, workers, pair, fp(out_ids), fp(out_sc), fp(stats), fp(status))
     assert n >= 0
     return out_ids, out_sc, stats, status, n
 
@@ -115,8 +115,20 @@ def test_emulated_kernel_matches_oracle(emu, levels, fused, M):
     for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
         for rk in (40, 1):
             wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
-            ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused)
-            check(ids, sc, st, status, wi, ws, wst)
+            for pair in (1, 0):  # two lanes per neighbour (degrees <= 32) and one lane per neighbour
+                ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, pair=pair)
+                check(ids, sc, st, status, wi, ws, wst)
+
+
+def test_degree_above_32_uses_one_lane_per_neighbour(emu):
+    """maxDegree 40 > 32: the pair-lane scoring does not apply; the one-lane-per-neighbour path must give the same answers"""
+    lv, entry, entry_level, opq, codes, q = problem(23, 2000, 128, 16, 2, deg=40, nq=6)
+    assert lv[0][1].shape[1] == 40
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    for vsf, fused in ((O.COSINE, True), (O.EUCLIDEAN, False)):
+        wi, ws, wst = og.search(opq, codes, None, q, vsf, 50, 50, fused=fused)
+        ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, 50, fused)
+        check(ids, sc, st, status, wi, ws, wst)
 
 
 def test_partition_and_spill_paths(emu):
