@@ -19,6 +19,10 @@ done
 JVECTOR_HIP_GS_OCC=4 JVECTOR_HIP_GRAPH_TIMING=1 timeout 600 python bench.py --n 1000000 --steps 5 --warmup 1 --no-flat --no-cpu-baseline \
     --traversal device > gpurun_out/gs/bench_1m_device_occ4.json 2> gpurun_out/gs/bench_1m_device_occ4.err
 tail -c 400 gpurun_out/gs/bench_1m_device_occ4.err; head -c 300 gpurun_out/gs/bench_1m_device_occ4.json; echo
+# 2c. one lane per neighbour instead of the pair-lane scoring
+JVECTOR_HIP_GS_PAIR=0 JVECTOR_HIP_GRAPH_TIMING=1 timeout 600 python bench.py --n 1000000 --steps 5 --warmup 1 --no-flat --no-cpu-baseline \
+    --traversal device > gpurun_out/gs/bench_1m_device_nopair.json 2> gpurun_out/gs/bench_1m_device_nopair.err
+tail -c 400 gpurun_out/gs/bench_1m_device_nopair.err; head -c 300 gpurun_out/gs/bench_1m_device_nopair.json; echo
 # 3. the headline configuration with the device traversal
 if [ "${GS_FULL:-1}" = "1" ]; then
   JVECTOR_HIP_GRAPH_TIMING=1 timeout 900 python bench.py --traversal device > gpurun_out/gs/bench_10m_device.json \
