@@ -952,13 +952,14 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         JV_TRY(launch_topk(ctx->stream, ctx, d_cand_sc, d_cand, Q, rerankK, rerankK, 0, topK, (int32_t *)oi.dev,
                            (float *)osc.dev, ctx->d_scratch.ptr));
     }
+    JV_TRY(stage_out_end(ctx, oi));
+    JV_TRY(stage_out_end(ctx, osc));
+    // stage_out_end stages through ctx->h_out: fetch the per-query status / counters only after it is done with it
     JV_TRY(ctx->h_out.reserve(sizeof(long long) * 2 * (size_t)Q + sizeof(int32_t) * (size_t)Q));
     long long *h_stats = (long long *)ctx->h_out.ptr;
     int32_t *h_status = (int32_t *)(h_stats + 2 * (size_t)Q);
     JV_HIP_CHECK(hipMemcpyAsync(h_stats, d_stats, sizeof(long long) * 2 * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
     JV_HIP_CHECK(hipMemcpyAsync(h_status, d_status, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
-    JV_TRY(stage_out_end(ctx, oi));
-    JV_TRY(stage_out_end(ctx, osc));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     std::vector<int> redo;
     for (int q = 0; q < Q; ++q) {
