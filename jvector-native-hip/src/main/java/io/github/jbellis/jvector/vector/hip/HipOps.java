@@ -79,6 +79,22 @@ public final class HipOps {
         static final MethodHandle graphSetEntry = h("jv_hip_graph_set_entry", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT));
         static final MethodHandle graphDestroy = h("jv_hip_graph_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
         static final MethodHandle graphSearch = h("jv_hip_graph_search", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle graphSetTraversal = h("jv_hip_graph_set_traversal", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT));
+        // build-time scoring (BuildScoreProvider.pqBuildScoreProvider), PQ training / serialization, anisotropic encode
+        static final MethodHandle pairTableCreate = h("jv_hip_pair_table_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS));
+        static final MethodHandle pairTableDestroy = h("jv_hip_pair_table_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle codePairScores = h("jv_hip_code_pair_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
+        static final MethodHandle pqDecode = h("jv_hip_pq_decode", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));
+        static final MethodHandle directScores = h("jv_hip_direct_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
+        static final MethodHandle pqTrain = h("jv_hip_pq_train", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_LONG, ADDRESS));
+        static final MethodHandle pqRefine = h("jv_hip_pq_refine", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, JAVA_INT, JAVA_LONG, ADDRESS));
+        static final MethodHandle pqWrite = h("jv_hip_pq_write", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS));
+        static final MethodHandle pqSetAnisotropicThreshold = h("jv_hip_pq_set_anisotropic_threshold", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_FLOAT));
+        // host-side readers of JVector's own byte formats (include/jvector_formats.h)
+        static final MethodHandle odgiDescribe = h("jv_fmt_odgi_describe", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS));
+        static final MethodHandle odgiReadL0 = h("jv_fmt_odgi_read_l0", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle odgiReadLevel = h("jv_fmt_odgi_read_level", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle pqvectorsDescribe = h("jv_fmt_pqvectors_describe", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle searchFlat = h("jv_hip_search_flat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
     }
 
