@@ -7,6 +7,9 @@ mkdir -p gpurun_out/gs
 export JVECTOR_TEST_DEVICE_TRAVERSAL=1 JVECTOR_TEST_BUILD_SCORE=1 JVECTOR_TEST_ANISOTROPIC=1 JVECTOR_TEST_PQ_TRAIN=1
 # 0. build-time scoring kernels (flat elementwise launches)
 timeout 300 python -m pytest tests/test_zz_build_score_gpu.py tests/test_zz_anisotropic_gpu.py tests/test_zz_pq_train_gpu.py -q 2>&1 | tail -8 | tee gpurun_out/gs/pytest_bs.log
+# 0b. canary: the smallest traversal case under a short timeout, so a hang in the new kernel costs 3 minutes, not 10
+timeout 180 python -m pytest tests/test_zz_device_traversal_gpu.py -x -q -k "test_device_traversal_matches_oracle and 1-False-128-16" 2>&1 | tail -5 | tee gpurun_out/gs/pytest_canary.log
+if ! grep -q " passed" gpurun_out/gs/pytest_canary.log; then echo "canary failed: stopping"; exit 1; fi
 # 1. parity on small graphs (5 shapes x 3 similarity functions, partitions/spills, refusal of unsupported shapes)
 timeout 600 python -m pytest tests/test_zz_device_traversal_gpu.py -x -q 2>&1 | tail -15 | tee gpurun_out/gs/pytest.log
 # 2. 1M-vector bench, both traversals, same index (about a minute each)
