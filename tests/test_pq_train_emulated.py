@@ -88,3 +88,18 @@ def test_refine_matches_oracle_bit_for_bit(emu, rounds, centroid):
     emu.km_emu_train(P(x), C.c_int64(len(x)), D, M, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(4), rounds, 1, P(cen), P(got), None)
     assert np.array_equal(got, want.codebooks)
     assert not np.array_equal(got, cb)
+
+
+def test_perfect_reconstruction_like_the_reference_test(emu):
+    """TestProductQuantization.testPerfectReconstruction (TS/quantization/TestProductQuantization.java:54-80): as many
+    distinct 3-d integer-valued vectors as clusters (then each repeated 10x): every vector must decode to itself."""
+    rng = np.random.default_rng(42)
+    v1 = rng.integers(0, 100000, (256, 3)).astype(np.float32)
+    for v in (v1, np.repeat(v1, 10, axis=0)):
+        sizes, offs, cbo = layout(3, 2)
+        want, _ = O.pq_train(v, 2, globally_center=False, seed=5)
+        codes = want.encode_all(v)
+        assert np.array_equal(np.stack([want.decode(c) for c in codes]), v)
+        got = np.empty(256 * 3, np.float32)
+        emu.km_emu_train(P(v), C.c_int64(len(v)), 3, 2, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(5), 6, 0, None, P(got), None)
+        assert np.array_equal(got, want.codebooks)
