@@ -8,10 +8,13 @@ import os
 import subprocess
 
 import numpy as np
+import platform
 import pytest
 
 from oracle import oracle as O
 from test_graph_search import build_problem, fused_blocks
+
+pytestmark = pytest.mark.skipif(platform.machine() != "x86_64", reason="the lane emulator's context switch is x86-64 assembly")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = [os.path.join(ROOT, "tests", "emu", "gs_emu.cpp"), os.path.join(ROOT, "tests", "emu", "hip_emu.h"),
