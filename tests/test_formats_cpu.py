@@ -222,3 +222,41 @@ def test_odgi_nvq_is_unsupported():
     hdr = W._common_header(6, 4, 0, [(1, 2)], 1) + W._i32(1, W.NVQ_VECTORS)
     with pytest.raises(J.UnsupportedError, match="NVQ"):
         F.describe_odgi(hdr + b"\0" * 64)
+
+
+def test_readers_survive_corrupted_input():
+    """The readers take bytes from files: random byte flips, planted extreme ints and truncations must end in a parse or
+    in ValueError / UnsupportedError — never in a crash or an out-of-bounds read (sizes are validated against the buffer)."""
+    import jvector_amd as J
+    rng = np.random.default_rng(0)
+    pq = _pq()
+    N, D, M, deg = 40, 16, 4, 5
+    nb = _graph(N, deg, rng)
+    vec = rng.standard_normal((N, D)).astype(np.float32)
+    codes = rng.integers(0, 256, (N, M), dtype=np.uint8)
+    l1 = {3: [9], 9: [3, 20], 20: [9]}
+    blobs = [W.write_odgi(6, D, nb, deg, 9, upper_levels=[(2, l1)], vectors=vec, codes=codes, pq_block=pq.serialize(6)),
+             W.write_odgi(6, D, nb, deg, 9, vectors=vec, separated=True, codes=codes, pq_block=pq.serialize(6)),
+             W.write_odgi(4, D, nb, deg, 9, upper_levels=[(2, l1)], vectors=vec), W.write_odgi(2, D, nb, deg, 9, vectors=vec)]
+    pqv = W.write_pqvectors(pq.serialize(6), codes)
+    parsed = rejected = 0
+    for it in range(1500):
+        b = bytearray(blobs[it % 4]) if it % 5 else bytearray(pqv)
+        for _ in range(int(rng.integers(1, 4))):
+            mode = rng.integers(0, 3)
+            pos = int(rng.integers(0, min(len(b), 700))) if rng.random() < 0.7 else int(rng.integers(0, len(b)))
+            if mode == 0:
+                b[pos] = int(rng.integers(0, 256))
+            elif mode == 1 and pos + 4 <= len(b):
+                struct.pack_into(">i", b, pos - pos % 4, int(rng.choice([-1, 0, 1, 2 ** 31 - 1, -2 ** 31, 255, 65536, 10 ** 6])))
+            else:
+                b = b[:max(1, pos)]
+        try:
+            if it % 5:
+                F.read_odgi(bytes(b))
+            else:
+                F.pqvectors_codes(bytes(b))
+            parsed += 1
+        except (ValueError, J.UnsupportedError):
+            rejected += 1
+    assert parsed > 100 and rejected > 100
