@@ -92,7 +92,11 @@ private:
     }
     void worker(int t)
     {
-        uint64_t seen = gen_.load(std::memory_order_acquire);
+        // The generation this worker has served.  It must start at the value gen_ had when the pool was BUILT (0), not at
+        // whatever the counter reads when the thread first gets to run: a thread that is scheduled late would otherwise
+        // adopt the generation of a parallel_for that is already waiting for it and never execute its chunk, leaving the
+        // caller spinning on done_ forever (seen with a mock device, where nothing delays the first parallel_for).
+        uint64_t seen = 0;
         for (;;) {
             {   // sleep while no search is running
                 std::unique_lock<std::mutex> lk(m_);
@@ -870,7 +874,8 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     int per_cu = (int)std::min<size_t>((size_t)4 * occ, std::max<size_t>(1, (160 * 1024) / (lds + 256)));
     per_cu = std::max(1, env_int("JVECTOR_HIP_GS_WAVES_PER_CU", per_cu));
     const int workers = std::max(1, std::min(Q, ctx->num_cus * per_cu));
-    const int vcap_log2 = gs_vcap_log2(rerankK);
+    // JVECTOR_HIP_GS_VCAP_LOG2 overrides the visited-table size (tests use a tiny table to drive the host fallback)
+    const int vcap_log2 = std::max(8, std::min(24, env_int("JVECTOR_HIP_GS_VCAP_LOG2", gs_vcap_log2(rerankK))));
     const size_t vcap = (size_t)1 << vcap_log2;
     const int spill_cap = (int)(vcap / 2) + 64;  // pushes <= visited <= vcap / 2: the spill tier cannot overflow first
     JV_TRY(ctx->d_gs_visited.reserve(sizeof(int32_t) * vcap * (size_t)workers));

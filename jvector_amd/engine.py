@@ -61,6 +61,17 @@ def _empty(shape, dtype, like):
     return np.empty(shape, dtype=dtype)
 
 
+def _finalizer(cls):
+    """Class decorator: release the device object when the wrapper is garbage collected (close() stays idempotent)."""
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the library may already be gone
+            pass
+    cls.__del__ = __del__
+    return cls
+
+
 def device_count() -> int:
     return int(_lib.load().jv_hip_device_count())
 
@@ -121,6 +132,7 @@ class HipContext:
             pass
 
 
+@_finalizer
 class ProductQuantization:
     """Device-resident codebooks (B/quantization/ProductQuantization.java)."""
 
@@ -224,6 +236,7 @@ class ProductQuantization:
             self._h = None
 
 
+@_finalizer
 class VectorSet:
     """Device-resident full-resolution vectors (RandomAccessVectorValues for the reranker)."""
 
@@ -270,6 +283,7 @@ class VectorSet:
             self._h = None
 
 
+@_finalizer
 class PQVectors:
     """Device-resident code store, ordinal-major (B/quantization/PQVectors.java)."""
 
@@ -368,6 +382,7 @@ class PQBuildScoreProvider:
     __del__ = close
 
 
+@_finalizer
 class QueryTables:
     """ADC look-up tables of a query batch (the state PQDecoder / FusedPQDecoder constructors compute)."""
 
@@ -425,6 +440,7 @@ class ApproximateScoreFunction:
         return out
 
 
+@_finalizer
 class FusedPQ:
     """Device-resident L0 fused blocks (B/graph/disk/feature/FusedPQ.java:146-161 layout)."""
 
@@ -504,6 +520,7 @@ class FlatSearcher:
         return out_ids, out_scores
 
 
+@_finalizer
 class GraphIndex:
     """Host-resident multi-level adjacency (the reference keeps the graph on the host: OnHeapGraphIndex /
     OnDiskGraphIndex.View).  levels[0] = (None, neighbors[n_nodes, maxDegree]); upper levels = (sorted node ids,

@@ -1,0 +1,131 @@
+// mock_hip.cpp — a CPU stand-in for the handful of HIP runtime calls the library's HOST code makes, so that the host
+// logic (staging, the graph searcher, the device-traversal driver and its fallback, training sequencing, error paths) can
+// run in the CPU test suite.  "Device" memory is malloc'ed memory remembered in a set (hipPointerGetAttributes answers
+// from it), streams and events are inert, copies are memcpy.  TEST HARNESS: linked only into build/mock/libjvector_hip_mock.so.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_set>
+
+namespace {
+std::mutex g_mu;
+std::unordered_set<const void *> g_dev;
+long g_dev_bytes_live = 0;
+}  // namespace
+
+extern "C" {
+
+long mock_hip_live_device_allocations()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (long)g_dev.size();
+}
+
+hipError_t hipGetDeviceCount(int *n)
+{
+    *n = 1;
+    return hipSuccess;
+}
+hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t *p, int d)
+{
+    if (d != 0) return hipErrorInvalidDevice;
+    memset(p, 0, sizeof(*p));
+    strcpy(p->name, "CPU mock device");
+    strcpy(p->gcnArchName, "gfx950:mock");
+    p->multiProcessorCount = 4;
+    p->sharedMemPerBlock = 65536;
+    p->maxSharedMemoryPerMultiProcessor = 163840;
+    return hipSuccess;
+}
+const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "mock HIP error"; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
+
+hipError_t hipMalloc(void **p, size_t bytes)
+{
+    void *m = aligned_alloc(256, (bytes + 255) & ~(size_t)255);
+    if (!m) return hipErrorOutOfMemory;
+    memset(m, 0xCD, bytes);  // device memory starts as garbage
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_dev.insert(m);
+    *p = m;
+    return hipSuccess;
+}
+hipError_t hipFree(void *p)
+{
+    if (!p) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_dev.erase(p)) return hipErrorInvalidValue;
+    }
+    free(p);
+    return hipSuccess;
+}
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned int)
+{
+    *p = aligned_alloc(256, (bytes + 255) & ~(size_t)255);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void *p)
+{
+    free(p);
+    return hipSuccess;
+}
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p)
+{
+    // device allocations are tracked by base address; an interior pointer counts if it lies inside one
+    std::lock_guard<std::mutex> lk(g_mu);
+    memset(a, 0, sizeof(*a));
+    if (g_dev.count(p)) {
+        a->type = hipMemoryTypeDevice;
+        return hipSuccess;
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind)
+{
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t)
+{
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t)
+{
+    memset(d, v, n);
+    return hipSuccess;
+}
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int)
+{
+    *s = (hipStream_t)malloc(8);
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s)
+{
+    free((void *)s);
+    return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t *e)
+{
+    *e = (hipEvent_t)malloc(8);
+    return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t e)
+{
+    free((void *)e);
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t)
+{
+    *ms = 0.0f;
+    return hipSuccess;
+}
+}

@@ -1,0 +1,401 @@
+// mock_kernels.cpp — CPU implementations of the library's kernel LAUNCHERS (namespace jv, declared in jv_internal.h) for
+// the mock device.  Arithmetic comes from the oracle's primitives (this is test infrastructure; the point of the mock is the
+// HOST code around the kernels, not the kernels), except where a kernel BODY is shared source: the device-resident graph
+// traversal runs gs_body.h on the 64-lane emulator, build-time scoring and training run bs_body.h / km_body.h as loops.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../emu/hip_emu.h"
+
+#define GS_FN inline
+#define GS_SCHED_FENCE() ((void)0)
+#define BS_FN static inline
+#define KM_FN static inline
+static inline int gs_lane() { return emu::lane(); }
+static inline void gs_barrier() { emu::barrier(); }
+static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
+static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
+static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
+static inline int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired)
+{
+    const int32_t old = *p;
+    if (old == expect) *p = desired;
+    return old;
+}
+static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
+{
+    const uint32_t old = *p;
+    *p = old + v;
+    return old;
+}
+static inline void gs_fence() {}
+static inline double gs_sqrt(double x) { return std::sqrt(x); }
+static inline double bs_sqrt(double x) { return std::sqrt(x); }
+
+#include "../../jvector_amd/csrc/jv_device.h"
+#include "../../jvector_amd/csrc/jv_internal.h"
+
+#include "../../jvector_amd/csrc/bs_body.h"
+#include "../../jvector_amd/csrc/gs_body.h"
+#include "../../jvector_amd/csrc/km_body.h"
+#include "../../oracle/jv_oracle.h"
+
+namespace jv {
+
+namespace {
+const float NEG_INF = -INFINITY;
+
+float finish(int vsf, float sum, float norm, float bmag)
+{
+    if (vsf == VSF_RAW) return sum;
+    if (vsf == VSF_L2) return 1.0f / (1.0f + sum);
+    if (vsf == VSF_COS) {
+        const float prod = norm * bmag;
+        sum = (float)((double)sum / std::sqrt((double)prod));
+    }
+    return (1.0f + sum) / 2.0f;
+}
+float row_sum(const float *lut, const uint8_t *row, int M)
+{
+    float s = 0.0f;
+    for (int m = 0; m < M; ++m) s += lut[m * kClusters + row[m]];
+    return s;
+}
+jvo_pq as_oracle(const jv_pq *pq)
+{
+    return jvo_pq{pq->D, pq->M, pq->k, pq->sizes.data(), pq->offsets.data(), pq->d_codebooks, pq->d_centroid};
+}
+}  // namespace
+
+int launch_self_magnitudes(hipStream_t, const jv_pq *pq)
+{
+    for (int m = 0; m < pq->M; ++m)
+        jvo_calculate_partial_self_magnitudes(pq->d_codebooks + pq->cb_offsets[m], m, pq->sizes[m], pq->k, pq->d_self_mag);
+    return JV_OK;
+}
+int launch_center_queries(hipStream_t, const jv_pq *pq, const float *d_q, int Q, float *d_cq)
+{
+    for (int64_t i = 0; i < (int64_t)Q * pq->D; ++i) d_cq[i] = pq->d_centroid ? d_q[i] - pq->d_centroid[i % pq->D] : d_q[i];
+    return JV_OK;
+}
+int launch_lut_build(hipStream_t, const jv_pq *pq, const float *d_cq, int Q, int lut_vsf, float *d_luts)
+{
+    for (int q = 0; q < Q; ++q)
+        for (int m = 0; m < pq->M; ++m)
+            jvo_calculate_partial_sums(pq->d_codebooks + pq->cb_offsets[m], m, pq->sizes[m], pq->k, d_cq + (size_t)q * pq->D,
+                                       pq->offsets[m], lut_vsf == VSF_L2 ? JVO_EUCLIDEAN : JVO_DOT_PRODUCT,
+                                       d_luts + (size_t)q * pq->M * pq->k);
+    return JV_OK;
+}
+int launch_query_magnitudes(hipStream_t, const jv_pq *pq, const float *d_cq, int Q, int kind, float *d_bmag)
+{
+    for (int q = 0; q < Q; ++q) {
+        const float *cq = d_cq + (size_t)q * pq->D;
+        if (kind == 0) d_bmag[q] = jvo_dot(cq, cq, pq->D);  // PQDecoder.CosineDecoder :121
+        else {                                              // FusedPQDecoder.CosineDecoder :188
+            float qm = 0.0f;
+            for (int m = 0; m < pq->M; ++m) qm += jvo_dot_off(cq, pq->offsets[m], cq, pq->offsets[m], pq->sizes[m]);
+            d_bmag[q] = qm;
+        }
+    }
+    return JV_OK;
+}
+int launch_pq_encode(hipStream_t, const jv_pq *pq, const float *d_vecs, int64_t count, uint8_t *d_codes)
+{
+    const jvo_pq o = as_oracle(pq);
+    for (int64_t i = 0; i < count; ++i) jvo_pq_encode(&o, d_vecs + i * pq->D, d_codes + i * pq->M);
+    return JV_OK;
+}
+int launch_pq_encode_anisotropic(hipStream_t, const jv_pq *pq, const float *d_vecs, int64_t count, uint8_t *d_codes)
+{
+    const jvo_pq o = as_oracle(pq);
+    for (int64_t i = 0; i < count; ++i) jvo_pq_encode_anisotropic(&o, pq->aniso, d_vecs + i * pq->D, d_codes + i * pq->M);
+    return JV_OK;
+}
+int launch_code_norms(hipStream_t, const jv_ctx *, const float *d_table, int M, const uint8_t *d_codes, int64_t count, float *d_out)
+{
+    for (int64_t i = 0; i < count; ++i) d_out[i] = row_sum(d_table, d_codes + i * M, M);
+    return JV_OK;
+}
+int launch_adc(hipStream_t, const jv_ctx *, const float *d_luts, const float *d_bmag, int Q, int M, int vsf, const uint8_t *d_codes,
+               const float *d_norms, int64_t n_codes, int64_t first, int64_t count, const int32_t *d_ordinals, float *d_out)
+{
+    for (int q = 0; q < Q; ++q)
+        for (int64_t i = 0; i < count; ++i) {
+            const int64_t row = d_ordinals ? (int64_t)d_ordinals[(int64_t)q * count + i] : first + i;
+            float *o = d_out + (int64_t)q * count + i;
+            if (d_ordinals && (row < 0 || row >= n_codes)) {
+                *o = NEG_INF;
+                continue;
+            }
+            const float s = row_sum(d_luts + (size_t)q * M * kClusters, d_codes + row * M, M);
+            *o = finish(vsf, s, vsf == VSF_COS ? d_norms[row] : 0.0f, vsf == VSF_COS ? d_bmag[q] : 0.0f);
+        }
+    return JV_OK;
+}
+int launch_fused(hipStream_t, const jv_ctx *, const float *d_luts, const float *d_bmag, int Q, int M, int vsf, const uint8_t *d_blocks,
+                 const int32_t *d_neighbors, const float *d_norms, int maxDegree, int64_t n_nodes, const int32_t *d_origins,
+                 float *d_out, int32_t *d_neighbors_out)
+{
+    for (int q = 0; q < Q; ++q)
+        for (int i = 0; i < maxDegree; ++i) {
+            const int64_t origin = d_origins[q], row = origin * maxDegree + i;
+            float *o = d_out + (int64_t)q * maxDegree + i;
+            const bool in = origin >= 0 && origin < n_nodes;
+            const int32_t nb = in ? d_neighbors[row] : -1;
+            if (d_neighbors_out) d_neighbors_out[(int64_t)q * maxDegree + i] = nb;
+            if (nb < 0) {
+                *o = NEG_INF;
+                continue;
+            }
+            const float s = row_sum(d_luts + (size_t)q * M * kClusters, d_blocks + row * M, M);
+            *o = finish(vsf, s, vsf == VSF_COS ? d_norms[row] : 0.0f, vsf == VSF_COS ? d_bmag[q] : 0.0f);
+        }
+    return JV_OK;
+}
+int launch_exact_gather(hipStream_t, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf, const int32_t *d_ord,
+                        int B, float *d_out, float *)
+{
+    for (int q = 0; q < Q; ++q)
+        for (int b = 0; b < B; ++b) {
+            const int64_t o = d_ord[(int64_t)q * B + b];
+            d_out[(int64_t)q * B + b] = (o < 0 || o >= n) ? NEG_INF : jvo_compare(vsf, d_q + (size_t)q * D, d_vecs + o * D, D);
+        }
+    return JV_OK;
+}
+int launch_exact_scan(hipStream_t, const jv_ctx *, const float *d_vecs, int D, const float *d_q, int Q, int vsf, int64_t first,
+                      int64_t count, float *d_out, float *)
+{
+    for (int q = 0; q < Q; ++q)
+        for (int64_t i = 0; i < count; ++i)
+            d_out[(int64_t)q * count + i] = jvo_compare(vsf, d_q + (size_t)q * D, d_vecs + (first + i) * D, D);
+    return JV_OK;
+}
+int launch_frontier(hipStream_t, int vsf, const float *d_luts, const float *d_bmag, const int32_t *d_slot_query, const int32_t *d_origins,
+                    const int32_t *d_ord_index, const int32_t *d_ords, const jv_fused *fused, const jv_codes *codes, float *d_out, int S,
+                    int W, const jv_pq *, const float *)
+{
+    const int M = codes->M;
+    for (int slot = 0; slot < S; ++slot)
+        for (int i = 0; i < W; ++i) {
+            float *o = d_out + (int64_t)slot * W + i;
+            *o = NEG_INF;
+            const int lq = d_slot_query[slot];
+            if (lq < 0) continue;
+            const int64_t origin = (fused && d_origins) ? d_origins[slot] : -1;
+            const uint8_t *rp;
+            float nrm = 0.0f;
+            if (origin >= 0) {
+                if (i >= fused->maxDegree || origin >= fused->count) continue;
+                const int64_t row = origin * fused->maxDegree + i;
+                if (fused->d_neighbors[row] < 0) continue;
+                rp = fused->d_blocks + row * M;
+                if (vsf == VSF_COS) nrm = fused->d_norms[row];
+            } else {
+                const int oi = d_ord_index[slot];
+                if (oi < 0) continue;
+                const int64_t ord = d_ords[(int64_t)oi * W + i];
+                if (ord < 0 || ord >= codes->count) continue;
+                rp = codes->d_codes + ord * M;
+                if (vsf == VSF_COS) nrm = codes->d_norms[ord];
+            }
+            *o = finish(vsf, row_sum(d_luts + (size_t)lq * M * kClusters, rp, M), nrm, vsf == VSF_COS ? d_bmag[lq] : 0.0f);
+        }
+    return JV_OK;
+}
+
+size_t topk_scratch_bytes(int, int) { return 256; }
+int launch_topk(hipStream_t, const jv_ctx *, const float *d_scores, const int32_t *d_ids, int Q, int64_t n, int64_t stride,
+                int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, void *, const unsigned int *d_row_counts)
+{
+    if (Q == 0 || k == 0) return JV_OK;
+    if (k > 8192) {
+        set_error("topk: k=%d exceeds the supported maximum %d", k, 8192);
+        return JV_ERR_UNSUPPORTED;
+    }
+    std::vector<int64_t> keys;
+    for (int q = 0; q < Q; ++q) {
+        keys.clear();
+        const int64_t row_n = d_row_counts ? std::min<int64_t>(n, d_row_counts[q]) : n;
+        for (int64_t c = 0; c < row_n; ++c) {
+            const int32_t id = d_ids ? d_ids[(int64_t)q * stride + c] : (int32_t)(id_base + c);
+            if (id < 0) continue;
+            keys.push_back(jvo_nodequeue_encode(id, d_scores[(int64_t)q * stride + c]));
+        }
+        std::sort(keys.begin(), keys.end(), std::greater<int64_t>());
+        for (int j = 0; j < k; ++j) {
+            const bool have = j < (int)keys.size();
+            d_out_ids[(int64_t)q * k + j] = have ? (int32_t)~(uint32_t)(keys[j] & 0xFFFFFFFFll) : -1;
+            d_out_scores[(int64_t)q * k + j] = have ? jvo_sortable_int_to_float((int32_t)(keys[j] >> 32)) : NEG_INF;
+        }
+    }
+    return JV_OK;
+}
+bool adc_mq_supported(int, const uint8_t *) { return false; }  // the multi-query scan kernels are not mocked
+int launch_adc_mq_store(hipStream_t, const jv_ctx *, const float *, const float *, int, int, int, const uint8_t *, const float *, int64_t,
+                        int64_t, int64_t, float *)
+{
+    set_error("mock device: adc_mq_store is not available");
+    return JV_ERR_UNSUPPORTED;
+}
+int launch_adc_mq_filter(hipStream_t, const jv_ctx *, const float *, const float *, int, int, int, const uint8_t *, const float *, int64_t,
+                         int64_t, const float *, int, int32_t *, float *, unsigned int *, int)
+{
+    set_error("mock device: adc_mq_filter is not available");
+    return JV_ERR_UNSUPPORTED;
+}
+int launch_add_id_base(hipStream_t, int32_t *d_ids, int64_t n, int32_t base)
+{
+    for (int64_t i = 0; i < n; ++i)
+        if (d_ids[i] >= 0) d_ids[i] += base;
+    return JV_OK;
+}
+
+// ---- build-time scoring: bs_body.h as loops ----
+static BsPq bs_pq_of(const jv_pq *pq)
+{
+    return BsPq{pq->d_codebooks, pq->d_cb_offsets, pq->d_sizes, pq->d_offsets, pq->d_centroid, pq->D, pq->M, pq->k};
+}
+int launch_pair_table(hipStream_t, const jv_pq *pq, int vsf, float *d_out)
+{
+    const BsPq b = bs_pq_of(pq);
+    for (int64_t t = 0; t < (int64_t)pq->M * pq->k; ++t) bs_pair_table_row(b, vsf, t, d_out);
+    return JV_OK;
+}
+int launch_pair_scores(hipStream_t, const float *d_tri, int vsf, const jv_codes *codes, const int32_t *d_node1, int P, const int32_t *d_node2,
+                       int B, float *d_out)
+{
+    for (int64_t t = 0; t < (int64_t)P * B; ++t)
+        bs_pair_score(d_tri, vsf, codes->M, codes->pq->k, codes->d_codes, codes->count, d_node1, d_node2, B, t, d_out);
+    return JV_OK;
+}
+int launch_pq_decode(hipStream_t, const jv_codes *codes, const int32_t *d_ordinals, int64_t first, int64_t count, float *d_out)
+{
+    const BsPq b = bs_pq_of(codes->pq);
+    for (int64_t t = 0; t < count * codes->pq->D; ++t) bs_decode(b, codes->d_codes, codes->count, d_ordinals, first, t, d_out);
+    return JV_OK;
+}
+int launch_direct_scores(hipStream_t, const jv_codes *codes, int vsf, const float *d_cq, int Q, const int32_t *d_ordinals, int B,
+                         float *d_qnorm, float *d_out)
+{
+    const BsPq b = bs_pq_of(codes->pq);
+    if (vsf == VSF_COS)
+        for (int64_t q = 0; q < Q; ++q) bs_query_norm(d_cq, codes->pq->D, q, d_qnorm);
+    for (int64_t t = 0; t < (int64_t)Q * B; ++t) bs_direct_score(b, vsf, codes->d_codes, codes->count, d_cq, d_qnorm, d_ordinals, B, t, d_out);
+    return JV_OK;
+}
+
+// ---- PQ training: km_body.h as loops, seeding on the lane emulator ----
+int launch_km_centroid(hipStream_t, const float *d_X, int64_t n, int D, float *d_out)
+{
+    for (int64_t d = 0; d < D; ++d) km_centroid_dim(d_X, n, D, d, d_out);
+    return JV_OK;
+}
+int launch_km_center(hipStream_t, const float *d_X, const float *d_centroid, int64_t n, int D, float *d_Xc)
+{
+    for (int64_t t = 0; t < n * D; ++t) km_center(d_X, d_centroid, D, t, d_Xc);
+    return JV_OK;
+}
+namespace {
+struct PP {
+    const KmParams *p;
+    int m;
+};
+void pp_main(void *a)
+{
+    const PP &x = *(const PP *)a;
+    km_pp_init(*x.p, x.m);
+}
+}  // namespace
+int launch_km_pp_init(hipStream_t, const KmParams &p)
+{
+    for (int m = 0; m < p.M; ++m) {
+        PP a{&p, m};
+        emu::run_wave(pp_main, &a);
+    }
+    return JV_OK;
+}
+int launch_km_assign(hipStream_t, const KmParams &p)
+{
+    for (int64_t t = 0; t < p.n * p.M; ++t) km_assign(p, t);
+    return JV_OK;
+}
+int launch_km_replay(hipStream_t, const KmParams &p, int first_pass)
+{
+    for (int64_t t = 0; t < (int64_t)p.M * p.k; ++t) km_replay(p, first_pass, t);
+    return JV_OK;
+}
+int launch_km_update_centroids(hipStream_t, const KmParams &p)
+{
+    for (int64_t t = 0; t < (int64_t)p.M * p.k; ++t) km_centroids(p, t);
+    for (int64_t m = 0; m < p.M; ++m) km_fill_empties(p, m);
+    return JV_OK;
+}
+int launch_km_finish_round(hipStream_t, const KmParams &p)
+{
+    for (int64_t m = 0; m < p.M; ++m) km_finish_round(p, m);
+    return JV_OK;
+}
+
+// ---- device-resident traversal: gs_body.h on the lane emulator ----
+bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels)
+{
+    const int ch = pq->M / 16;  // the same predicate as k_gsearch.hip (emulated instantiations: M in {16,...,96})
+    return pq->uniform && pq->max_size == 8 && pq->k == kClusters && pq->M % 16 == 0 && (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6) &&
+           pq->D == 8 * pq->M && (reinterpret_cast<uintptr_t>(codes->d_codes) & 15) == 0 &&
+           (!fused || (reinterpret_cast<uintptr_t>(fused->d_blocks) & 15) == 0) && max_degree <= 64 && n_levels <= GS_MAX_LEVELS;
+}
+size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M) { return gs_lds_bytes(D, rerankK, cand_cap, pair_M); }
+namespace {
+struct GsLaunch {
+    const GsParams *p;
+    int vsf, worker;
+    char *lds;
+};
+template <int VSF, bool PAIR>
+void gs_run_ch(const GsLaunch &L)
+{
+    switch (L.p->M / 16) {
+    case 1: gs_worker<VSF, 1, PAIR>(*L.p, L.worker, L.lds); break;
+    case 2: gs_worker<VSF, 2, PAIR>(*L.p, L.worker, L.lds); break;
+    case 3: gs_worker<VSF, 3, PAIR>(*L.p, L.worker, L.lds); break;
+    case 4: gs_worker<VSF, 4, PAIR>(*L.p, L.worker, L.lds); break;
+    case 6: gs_worker<VSF, 6, PAIR>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
+template <bool PAIR>
+void gs_run_vsf(const GsLaunch &L)
+{
+    if (L.vsf == VSF_L2) gs_run_ch<VSF_L2, PAIR>(L);
+    else if (L.vsf == VSF_DOT) gs_run_ch<VSF_DOT, PAIR>(L);
+    else gs_run_ch<VSF_COS, PAIR>(L);
+}
+void gs_main(void *a)
+{
+    const GsLaunch &L = *(const GsLaunch *)a;
+    if (L.p->pair) gs_run_vsf<true>(L);
+    else gs_run_vsf<false>(L);
+}
+}  // namespace
+int launch_graph_search(hipStream_t, int vsf, const GsParams &p, int workers, int /*occupancy*/)
+{
+    if (p.Q == 0) return JV_OK;
+    const size_t lds_bytes = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0);
+    // the waves of a persistent launch, one after another; wave w stops after its share so that several workers'
+    // scratch slices are exercised (a real launch interleaves them)
+    for (int w = 0; w < workers; ++w) {
+        GsParams pw = p;
+        pw.Q = (int)((long long)p.Q * (w + 1) / workers);
+        char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
+        memset(lds, 0xa5, lds_bytes);
+        GsLaunch L{&pw, vsf, w, lds};
+        emu::run_wave(gs_main, &L);
+        *p.next_query = (uint32_t)pw.Q;
+        free(lds);
+    }
+    return JV_OK;
+}
+
+}  // namespace jv

@@ -1,0 +1,191 @@
+"""The C ABI's HOST logic on the CPU: the library's host sources (cabi.cpp, graph_search.cpp, build_score.cpp, pq_train.cpp,
+formats.cpp) are built against a mock HIP runtime with CPU kernel launchers (tests/mock/) and the GPU test functions are
+re-run against that build.  The mock's arithmetic is the oracle's, so these runs say nothing about the kernels (the -m gpu
+tests and the lane-emulator tests do that); what they exercise is everything around them: argument validation and error
+mapping, host/"device" staging through the pinned buffers, the host batched graph searcher, the device-traversal DRIVER
+(scratch sizing, the emulated kernel, status read-back, host fallback for overflowed queries), index ingestion from bytes,
+the training launch sequence, and the Python mirror (jvector_amd/engine.py, formats.py) end to end."""
+import ctypes as C
+import os
+import platform
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.skipif(platform.machine() != "x86_64", reason="the lane emulator's context switch is x86-64 assembly")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "mock"))
+
+
+@pytest.fixture(scope="module")
+def J():
+    """jvector_amd bound to the mock library for the duration of this module."""
+    import build_mock
+    import jvector_amd
+    import jvector_amd._lib as L
+    lib = C.CDLL(build_mock.build())
+    for table in (L.SIGNATURES, L.COMPAT_SIGNATURES, L.FORMAT_SIGNATURES):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    saved, L._lib = L._lib, lib
+    # the host searcher's workers spin-wait; on a small shared CPU box that is slower than running the phases inline.
+    # One test below turns the pool back on.
+    saved_threads = os.environ.get("JVECTOR_HIP_HOST_THREADS")
+    os.environ["JVECTOR_HIP_HOST_THREADS"] = "1"
+    try:
+        assert b"mock" in lib.jv_hip_active_arch(0)
+        yield jvector_amd
+    finally:
+        L._lib = saved
+        if saved_threads is None:
+            os.environ.pop("JVECTOR_HIP_HOST_THREADS", None)
+        else:
+            os.environ["JVECTOR_HIP_HOST_THREADS"] = saved_threads
+
+
+@pytest.fixture()
+def ctx(J):
+    c = J.HipContext(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture()
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+# ---- the existing GPU parity tests, on the mock -----------------------------------------------------------------
+def test_parity_suite_host_logic(J, ctx, golden_dir):
+    import test_gpu_parity as T
+    T.test_encode_bit_exact(ctx, 10, 3, False)
+    T.test_encode_ties_and_nan(ctx)
+    T.test_perfect_reconstruction(ctx)
+    T.test_luts_bit_exact(ctx, 10, 3, True)
+    T.test_adc_scan_bit_exact(ctx, 128, 16, 20000)
+    for B in (1, 100):
+        T.test_adc_gather_bit_exact(ctx, B)
+    T.test_adc_precomputed_equals_direct(ctx)
+    T.test_fused_equals_unfused(ctx, 40, 10, 12)
+    for D in (7, 100):
+        T.test_exact_gather_and_scan_bit_exact(ctx, D)
+    T.test_exact_known_answers(ctx, golden_dir)
+    for n, k in ((10, 3), (1000, 10), (50, 64)):
+        T.test_topk_matches_nodequeue_order(ctx, n, k)
+    T.test_topk_explicit_ids_merge(ctx)
+    T.test_version0_pq_fixture_on_device(ctx, golden_dir)
+    T.test_siftsmall_plumbing(ctx, golden_dir)
+    T.test_error_behaviour(ctx)
+
+
+def test_search_flat_host_logic(J, ctx):
+    import test_gpu_parity as T
+    T.test_search_flat_matches_oracle(ctx, 128, 16, 20000)
+
+
+# ---- host batched graph searcher --------------------------------------------------------------------------------
+@pytest.mark.parametrize("levels,use_fused,D,M", [(2, True, 64, 8), (3, False, 64, 8)])
+def test_host_graph_searcher(J, ctx, levels, use_fused, D, M):
+    import test_graph_search as T
+    T.test_graph_search_matches_oracle(ctx, levels, use_fused, D, M)
+
+
+def test_host_graph_searcher_large_batch(J, ctx):
+    import test_graph_search as T
+    T.test_graph_search_large_batch_and_errors(ctx)
+
+
+def test_host_graph_searcher_worker_pool(J, monkeypatch):
+    """Three pool threads, first search issued right after the context exists: the workers must pick up the very first
+    parallel phase even if they are scheduled late (regression: a late worker adopted the pending generation and the caller
+    spun forever)."""
+    import test_graph_search as T
+    monkeypatch.setenv("JVECTOR_HIP_HOST_THREADS", "3")
+    for _ in range(3):  # a fresh pool each time
+        c = J.HipContext(0)
+        try:
+            T.test_graph_search_large_batch_and_errors(c)
+        finally:
+            c.close()
+
+
+# ---- device-traversal driver (emulated kernel) ------------------------------------------------------------------
+def _device_problem(J, ctx, seed, N, D, M, levels, use_fused, deg=16):
+    import test_zz_device_traversal_gpu as T
+    return T._setup(ctx, seed, N, D, M, levels, use_fused, deg=deg)
+
+
+@pytest.mark.parametrize("levels,use_fused", [(2, True), (1, False)])
+def test_device_traversal_driver(J, ctx, levels, use_fused):
+    from oracle import oracle as O
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _device_problem(J, ctx, 31 + levels, 2500, 128, 16, levels,
+                                                                                         use_fused)
+    q = q[:12]
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    for vsf in J.VectorSimilarityFunction:
+        for rerank, top_k, rk in ((True, 10, 40), (False, 5, 20)):
+            s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=64)
+            ids, sc, stats = s.search(q, vsf, top_k, rk, return_stats=True)
+            wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused)
+            assert np.array_equal(stats, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rerank)
+
+
+def test_device_traversal_overflow_falls_back_to_the_host(J, ctx, monkeypatch, capfd):
+    """A visited table far too small for the search: every query overflows on the device and is re-run by the host
+    searcher; the caller sees the same ids, scores and counters."""
+    from oracle import oracle as O
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _device_problem(J, ctx, 77, 2500, 128, 16, 2, True)
+    q = q[:10]
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, 60, fused=True)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+    monkeypatch.setenv("JVECTOR_HIP_GS_VCAP_LOG2", "8")
+    monkeypatch.setenv("JVECTOR_HIP_GRAPH_TIMING", "1")
+    ids, sc, stats = s.search(q, J.VectorSimilarityFunction.COSINE, 10, 60, return_stats=True)
+    assert "overflow=10" in capfd.readouterr().err          # all ten went through the fallback
+    assert np.array_equal(stats, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+    monkeypatch.setenv("JVECTOR_HIP_GS_VCAP_LOG2", "10")     # some fit, some do not: results still identical
+    ids, sc, stats = s.search(q, J.VectorSimilarityFunction.COSINE, 10, 60, return_stats=True)
+    assert np.array_equal(stats, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+
+
+def test_device_traversal_refuses_unsupported_shapes(J, ctx):
+    import test_zz_device_traversal_gpu as T
+    T.test_unsupported_shape_is_refused(ctx)
+
+
+# ---- ingestion, build-time scoring, anisotropic encode, training: the opt-in GPU tests ----------------------------
+@pytest.mark.parametrize("levels,separated,with_pqv", [(2, False, True), (1, True, False), (3, False, False)])
+def test_load_index_end_to_end(J, ctx, levels, separated, with_pqv):
+    import test_zz_load_index_gpu as T
+    T.test_loaded_index_searches_like_the_oracle(ctx, levels, separated, with_pqv)
+
+
+@pytest.mark.parametrize("D,M,centroid", [(64, 8, False), (50, 7, True)])
+def test_build_score_entry_points(J, ctx, D, M, centroid):
+    import test_zz_build_score_gpu as T
+    T.test_build_score_provider_matches_oracle(ctx, D, M, centroid)
+
+
+def test_anisotropic_entry_points(J, ctx):
+    import test_zz_anisotropic_gpu as T
+    T.test_anisotropic_encode_matches_oracle(ctx, 50, 7, True, 0.5)
+
+
+@pytest.mark.parametrize("D,M,center", [(32, 4, True), (26, 3, False)])
+def test_training_entry_points(J, ctx, D, M, center):
+    import test_zz_pq_train_gpu as T
+    T.test_train_refine_write(ctx, D, M, center)
+
+
+def test_no_device_memory_leaks(J):
+    """every jv_* object created by the tests above was destroyed: the mock runtime has no live device allocations left
+    except what lives in still-referenced Python wrappers (collected first)."""
+    import gc
+    import jvector_amd._lib as L
+    gc.collect()
+    live = L._lib.mock_hip_live_device_allocations()
+    assert live < 50, live
