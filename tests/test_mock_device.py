@@ -189,3 +189,46 @@ def test_no_device_memory_leaks(J):
     gc.collect()
     live = L._lib.mock_hip_live_device_allocations()
     assert live < 50, live
+
+
+# ---- edge cases of the searchers (cheap here, the same code runs on the GPU) -------------------------------------
+@pytest.mark.parametrize("traversal", ["host", "device"])
+def test_searcher_edge_cases(J, ctx, traversal):
+    """single query, rerankK > number of nodes (exhaustive), nodes without neighbours, an entry node that leads nowhere,
+    fewer reachable nodes than topK (padding with -1 / -inf)."""
+    from oracle import oracle as O
+    import test_graph_search as T
+    rng = np.random.default_rng(3)
+    D, M, N, deg = 128, 16, 300, 8
+    v = rng.standard_normal((N, D)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    sizes, offs = O.subvector_sizes_offsets(D, M)
+    cb = np.concatenate([v[rng.choice(N, 256, replace=False), offs[m]: offs[m] + sizes[m]].reshape(-1) for m in range(M)])
+    nb = np.full((N, deg), -1, np.int32)
+    for i in range(N):
+        d = int(rng.integers(0, deg + 1))           # some rows are empty
+        row = [int(x) for x in rng.permutation(N)[:d] if x != i]
+        nb[i, :len(row)] = row
+    nb[7] = -1                                      # node 7: no way out
+    nb[0, :3] = [7, 5, 9]
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    fused = J.FusedPQ(ctx, pq, T.fused_blocks(codes, nb), nb)
+    q = v[[11]] + 0.01
+    for entry in (0, 7):
+        lv = [(None, nb)]
+        graph = J.GraphIndex(ctx, N, lv, entry, 0).set_traversal(traversal)
+        og = O.OracleGraph(N, lv, entry, 0)
+        for top_k, rk in ((10, 10), (10, 400), (1, 1)):
+            s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=4)
+            ids, sc, st = s.search(q.astype(np.float32), J.VectorSimilarityFunction.COSINE, top_k, rk, return_stats=True)
+            wi, ws, wst = og.search(opq, codes, v, q.astype(np.float32), O.COSINE, top_k, rk, fused=True)
+            assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (entry, top_k, rk)
+        if entry == 7:
+            assert ids[0, 0] == 7 and (ids[0, 1:] == -1).all() if top_k > 1 else ids[0, 0] == 7
+    ids, sc = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=4).search(np.zeros((0, D), np.float32),
+                                                                                  J.VectorSimilarityFunction.COSINE, 5, 5)
+    assert ids.shape == (0, 5)
