@@ -232,3 +232,44 @@ def test_searcher_edge_cases(J, ctx, traversal):
     ids, sc = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=4).search(np.zeros((0, D), np.float32),
                                                                                   J.VectorSimilarityFunction.COSINE, 5, 5)
     assert ids.shape == (0, 5)
+
+
+def test_contexts_on_several_host_threads_share_device_objects(J):
+    """the SPI is called concurrently from many host threads.  One context per thread; codebooks, code store,
+    fused blocks, vectors and graph are shared; the lazily built cosine-magnitude caches are created under contention."""
+    import threading
+    from oracle import oracle as O
+    import test_graph_search as T
+    v, lv, entry, entry_level, cb, q = T.build_problem(91, N=3000, D=64, M=8, levels=2)
+    opq = O.OraclePQ(64, 8, cb)
+    main = J.HipContext(0)
+    pq = J.ProductQuantization.from_codebooks(main, 64, 8, cb)
+    vs = J.VectorSet(main, v)
+    cv = J.PQVectors.encode_and_build(main, pq, vs)
+    codes = cv.get(0, len(v))
+    graph = J.GraphIndex(main, len(v), lv, entry, entry_level)
+    fused = J.FusedPQ(main, pq, T.fused_blocks(codes, lv[0][1]), lv[0][1])
+    want = O.OracleGraph(len(v), lv, entry, entry_level).search(opq, codes, v, q, O.COSINE, 10, 40, fused=True)
+    want_adc = np.stack([opq.adc_scores(q[i], O.COSINE, codes[:500]) for i in range(4)])
+    errors = []
+
+    def work(tid):
+        try:
+            c = J.HipContext(0)
+            for _ in range(3):
+                s = J.GraphSearcher(c, graph, pq, cv, fused, vs, max_queries=64)
+                ids, sc, st = s.search(q, J.VectorSimilarityFunction.COSINE, 10, 40, return_stats=True)
+                assert np.array_equal(ids, want[0]) and np.array_equal(sc, want[1]) and np.array_equal(st, want[2])
+                sf = J.PQVectors(c, pq, codes[:500]).precomputed_score_function_for(q[:4], J.VectorSimilarityFunction.COSINE)
+                assert np.array_equal(sf.similarity_to_range(0, 500), want_adc)
+            c.close()
+        except BaseException as e:  # noqa: BLE001 - reported below
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    main.close()
+    assert not errors, errors
