@@ -1,0 +1,31 @@
+#!/bin/bash
+# AddressSanitizer pass over the library's HOST code (CPU only): builds the mock-device library (tests/mock/) with
+# -fsanitize=address and runs the mock tests that do not use the fiber-based lane emulator (ASan cannot follow its
+# stack switches) plus the corrupted-input fuzz of the format readers.  Last run (round 1): clean.
+set -eu
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${TMPDIR:-/tmp}/jv_asan; mkdir -p "$OUT"; cd "$OUT"
+CXXF="-std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -ffp-contract=off -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -include $ROOT/tests/mock/mock_prefix.h -fPIC -Wno-unknown-pragmas -Wno-unused-function"
+for f in cabi graph_search build_score pq_train formats compat_host; do g++ $CXXF -c "$ROOT/jvector_amd/csrc/$f.cpp" -o $f.o & done
+g++ $CXXF -c "$ROOT/tests/mock/mock_hip.cpp" -o mock_hip.o &
+g++ $CXXF -c "$ROOT/tests/mock/mock_kernels.cpp" -o mock_kernels.o &
+gcc -O1 -g -fsanitize=address -std=c11 -fPIC -ffp-contract=off -c "$ROOT/oracle/jv_oracle.c" -o jv_oracle.o &
+wait
+g++ -shared -fsanitize=address -Wl,-Bsymbolic -o libjvector_hip_mock_asan.so *.o -lpthread -lm
+cd "$ROOT"
+export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) JV_MOCK_LIBRARY="$OUT/libjvector_hip_mock_asan.so"
+python -m pytest tests/test_mock_device.py -x -q -p no:cacheprovider \
+  -k "parity_suite or search_flat or host_graph_searcher or load_index or build_score or (edge_cases and host) or several_host"
+python - <<'PY'
+import ctypes as C, os, sys
+sys.path.insert(0, "tests")
+import jvector_amd._lib as L
+lib = C.CDLL(os.environ["JV_MOCK_LIBRARY"])
+for table in (L.SIGNATURES, L.COMPAT_SIGNATURES, L.FORMAT_SIGNATURES):
+    for name, (res, args) in table.items():
+        fn = getattr(lib, name); fn.restype, fn.argtypes = res, args
+L._lib = lib
+import test_formats_cpu as T
+T.test_readers_survive_corrupted_input(); T.test_odgi_rejects_corruption(); T.test_odgi_v6_fused_multilayer(True)
+print("format readers under ASan: clean")
+PY

@@ -28,6 +28,8 @@ def _deps():
 
 
 def build():
+    if os.environ.get("JV_MOCK_LIBRARY"):  # a pre-built variant (scripts/asan_mock.sh)
+        return os.environ["JV_MOCK_LIBRARY"]
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in _deps()):
         return LIB
     os.makedirs(OUT, exist_ok=True)
