@@ -273,3 +273,16 @@ def test_contexts_on_several_host_threads_share_device_objects(J):
         t.join()
     main.close()
     assert not errors, errors
+
+
+def test_graft_entry_smoke_runs_on_the_mock(J, capsys):
+    """__graft_entry__.smoke() (the driver's GPU smoke test) end to end on the mock device, and nothing is left allocated."""
+    import gc
+    import __graft_entry__ as g
+    import jvector_amd._lib as L
+    gc.collect()
+    before = L._lib.mock_hip_live_device_allocations()
+    g.smoke()
+    gc.collect()
+    assert "smoke OK on gfx950:mock" in capsys.readouterr().out
+    assert L._lib.mock_hip_live_device_allocations() <= before
