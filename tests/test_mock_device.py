@@ -286,3 +286,9 @@ def test_graft_entry_smoke_runs_on_the_mock(J, capsys):
     gc.collect()
     assert "smoke OK on gfx950:mock" in capsys.readouterr().out
     assert L._lib.mock_hip_live_device_allocations() <= before
+
+
+def test_sharded_graph_backends_on_the_mock(J):
+    """HipGraphShardBackend + ShardedSearcher (three segment graphs in one process) with host tensors on the mock device."""
+    import test_zz_sharded_graph_gpu as T
+    T.run_sharded_graph_case(lambda t: t)

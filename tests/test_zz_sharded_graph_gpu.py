@@ -13,6 +13,11 @@ from test_sharded import _graph_shards, _manual_merge
 
 
 def test_sharded_graph_hip_equals_manual_merge():
+    run_sharded_graph_case(lambda t: t.cuda())
+
+
+def run_sharded_graph_case(to_device):
+    """to_device: where the query tensor lives (cuda on hardware; the CPU mock-device test passes the identity)"""
     import jvector_amd as J
     from jvector_amd.sharded import HipGraphShardBackend, ShardedSearcher
     shards, cb, q = _graph_shards(70, 3, N=3000)
@@ -33,7 +38,7 @@ def test_sharded_graph_hip_equals_manual_merge():
         for i in range(len(v)):
             allv[lo + i] = v[i]
     s = ShardedSearcher(backends)
-    tq = torch.from_numpy(q).cuda()
+    tq = to_device(torch.from_numpy(q))
     for vsf in J.VectorSimilarityFunction:
         per = []
         for og, codes, lo in oracle_shards:
