@@ -292,3 +292,62 @@ def test_sharded_graph_backends_on_the_mock(J):
     """HipGraphShardBackend + ShardedSearcher (three segment graphs in one process) with host tensors on the mock device."""
     import test_zz_sharded_graph_gpu as T
     T.run_sharded_graph_case(lambda t: t)
+
+
+@pytest.mark.parametrize("traversal", ["host", "device"])
+def test_searchers_on_random_irregular_graphs(J, ctx, traversal):
+    """Differential sweep against the oracle on graphs no builder would emit: self loops, duplicate neighbours inside a
+    row, a -1 in the middle of a row (ends it), rows of every length, 1-3 levels, random topK / rerankK, all three
+    similarity functions, with and without FusedPQ and reranking."""
+    from oracle import oracle as O
+    import test_graph_search as T
+    rng = np.random.default_rng(17)
+    D, M = 128, 16
+    for case in range(14):
+        N = int(rng.integers(40, 400))
+        deg = int(rng.choice([4, 9, 16, 32, 40]))
+        v = rng.standard_normal((N, D)).astype(np.float32)
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        sizes, offs = O.subvector_sizes_offsets(D, M)
+        cb = np.concatenate([v[rng.integers(0, N, 256), offs[m]: offs[m] + sizes[m]].reshape(-1) for m in range(M)])
+        nb = np.full((N, deg), -1, np.int32)
+        for i in range(N):
+            d = int(rng.integers(0, deg + 1))
+            row = rng.integers(0, N, d)                      # duplicates and self loops allowed
+            nb[i, :d] = row
+            if d > 2 and rng.random() < 0.15:
+                nb[i, int(rng.integers(1, d))] = -1           # everything after it is ignored
+        lv = [(None, nb)]
+        entry, entry_level = int(rng.integers(0, N)), 0
+        n_levels = int(rng.integers(1, 4))
+        prev = np.arange(N)
+        for _ in range(1, n_levels):
+            cnt = max(2, len(prev) // 6)
+            ids = np.sort(rng.choice(prev, cnt, replace=False)).astype(np.int32)
+            udeg = int(rng.choice([3, 8, 33]))
+            un = np.full((cnt, udeg), -1, np.int32)
+            for r in range(cnt):
+                d = int(rng.integers(0, min(udeg, cnt) + 1))
+                un[r, :d] = rng.choice(ids, d, replace=True)
+            lv.append((ids, un))
+            prev, entry, entry_level = ids, int(ids[rng.integers(0, cnt)]), len(lv) - 1
+        use_fused = bool(rng.random() < 0.6)
+        rerank = bool(rng.random() < 0.6)
+        top_k = int(rng.integers(1, 12))
+        rk = top_k + int(rng.integers(0, 60))
+        opq = O.OraclePQ(D, M, cb)
+        pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+        vs = J.VectorSet(ctx, v)
+        cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+        codes = cv.get(0, N)
+        graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal(traversal)
+        fused = J.FusedPQ(ctx, pq, T.fused_blocks(codes, nb), nb) if use_fused else None
+        q = (v[rng.integers(0, N, 5)] + 0.05 * rng.standard_normal((5, D))).astype(np.float32)
+        og = O.OracleGraph(N, lv, entry, entry_level)
+        s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=8)
+        for vsf in J.VectorSimilarityFunction:
+            ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True)
+            wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused)
+            tag = (case, N, deg, n_levels, use_fused, rerank, top_k, rk, vsf)
+            assert np.array_equal(st, wst), tag
+            assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag
