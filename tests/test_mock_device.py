@@ -351,3 +351,13 @@ def test_searchers_on_random_irregular_graphs(J, ctx, traversal):
             tag = (case, N, deg, n_levels, use_fused, rerank, top_k, rk, vsf)
             assert np.array_equal(st, wst), tag
             assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag
+
+
+@pytest.mark.parametrize("slots,groups", [(64, 1), (96, 3), (700, 2), (1, 1)])
+def test_host_searcher_continuous_batching(J, ctx, monkeypatch, slots, groups):
+    """more queries than traversal slots: finished queries hand their slot to the next one (and slot groups alternate);
+    per-query results and counters must not depend on the slot geometry"""
+    import test_graph_search as T
+    monkeypatch.setenv("JVECTOR_HIP_GRAPH_SLOTS", str(slots))
+    monkeypatch.setenv("JVECTOR_HIP_GRAPH_GROUPS", str(groups))
+    T.test_graph_search_large_batch_and_errors(ctx)
