@@ -4,6 +4,7 @@
 #   flat  : 10M flat mode, kernel-trace stats + FETCH_SIZE + WRITE_SIZE        (the ADC-scan kernel)
 #   graph : 1M graph mode, kernel-trace stats only                              (frontier kernel durations)
 #   fpmc  : frontier kernel FETCH_SIZE / WRITE_SIZE on a random 1M graph        (scripts/frontier_pmc.py)
+#   gsearch : device-resident traversal kernel on the same random 1M graph: kernel-trace stats, then FETCH/WRITE PMC
 set -u
 WHAT=${1:-flat}; TAG=${2:-r1}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -25,6 +26,14 @@ graph)
 fpmc)
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 150 rocprofv3 --pmc $C --output-format csv -d $O/$C -o fr -- python $R/scripts/frontier_pmc.py > $K/$C.log 2>&1
+    extract $C
+  done ;;
+gsearch)
+  export JVECTOR_HIP_GRAPH_TRAVERSAL=device
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o gs -- python $R/scripts/frontier_pmc.py > $K/stats.log 2>&1
+  cp $O/stats/*kernel_stats.csv $K/ 2>/dev/null
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 150 rocprofv3 --pmc $C --output-format csv -d $O/$C -o gs -- python $R/scripts/frontier_pmc.py > $K/$C.log 2>&1
     extract $C
   done ;;
 esac
