@@ -45,7 +45,12 @@ emu_switch:
 .size emu_switch,.-emu_switch
 )");
 
+// Lane scheduling order between collectives: lanes run one after another in the order order[0], order[1], ...
+// EMU_LANE_ORDER = "reverse" or "random[:seed]" changes it (default: ascending).  A kernel that is correct under every
+// order does not depend on which lane happens to run first inside a phase, i.e. every cross-lane hand-over goes through a
+// collective or barrier — the property the real wavefront needs.
 struct Wave {
+    int order[WAVE], pos_of[WAVE];
     void *sp[WAVE];
     char *stack[WAVE];
     bool done[WAVE];
@@ -65,18 +70,20 @@ inline Wave *&current()
 }
 inline int lane() { return current()->cur; }
 
+inline int next_live_after(const Wave &w, int me)
+{
+    for (int i = 1; i <= WAVE; ++i) {
+        const int c = w.order[(w.pos_of[me] + i) % WAVE];
+        if (!w.done[c]) return c;
+    }
+    return me;
+}
+
 inline void switch_to_next_live()
 {
     Wave &w = *current();
     const int me = w.cur;
-    int nx = me;
-    for (int i = 1; i <= WAVE; ++i) {
-        const int c = (me + i) % WAVE;
-        if (!w.done[c]) {
-            nx = c;
-            break;
-        }
-    }
+    const int nx = next_live_after(w, me);
     if (nx == me) return;
     w.cur = nx;
     emu_switch(&w.sp[me], w.sp[nx]);
@@ -110,14 +117,7 @@ inline void lane_exit()
         w.arrived = 0;
         w.gen++;
     }
-    int nx = me;
-    for (int i = 1; i <= WAVE; ++i) {
-        const int c = (me + i) % WAVE;
-        if (!w.done[c]) {
-            nx = c;
-            break;
-        }
-    }
+    const int nx = next_live_after(w, me);
     w.cur = nx;
     void *dummy;
     emu_switch(&dummy, w.sp[nx]);  // never returns
@@ -148,10 +148,30 @@ inline long run_wave(void (*fn)(void *), void *arg)
         for (int r = 0; r < 6; ++r) *--sp = nullptr;  // rbp rbx r12 r13 r14 r15
         w->sp[i] = (void *)sp;
     }
+    {
+        for (int i = 0; i < WAVE; ++i) w->order[i] = i;
+        const char *e = getenv("EMU_LANE_ORDER");
+        if (e && !strncmp(e, "reverse", 7)) {
+            for (int i = 0; i < WAVE; ++i) w->order[i] = WAVE - 1 - i;
+        } else if (e && !strncmp(e, "random", 6)) {
+            static unsigned long long state = 0;
+            if (!state) state = e[6] == ':' ? strtoull(e + 7, nullptr, 10) * 2654435761ull + 1 : 88172645463325252ull;
+            for (int i = WAVE - 1; i > 0; --i) {  // Fisher-Yates with xorshift64, a fresh permutation per wave
+                state ^= state << 13;
+                state ^= state >> 7;
+                state ^= state << 17;
+                const int j = (int)(state % (unsigned long long)(i + 1));
+                const int t = w->order[i];
+                w->order[i] = w->order[j];
+                w->order[j] = t;
+            }
+        }
+        for (int i = 0; i < WAVE; ++i) w->pos_of[w->order[i]] = i;
+    }
     Wave *prev = current();
     current() = w;
-    w->cur = 0;
-    emu_switch(&w->main_sp, w->sp[0]);
+    w->cur = w->order[0];
+    emu_switch(&w->main_sp, w->sp[w->order[0]]);
     current() = prev;
     const long n = w->collectives;
     for (int i = 0; i < WAVE; ++i) free(w->stack[i]);

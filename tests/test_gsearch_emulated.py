@@ -123,6 +123,19 @@ def test_emulated_kernel_matches_oracle(emu, levels, fused, M):
                 check(ids, sc, st, status, wi, ws, wst)
 
 
+@pytest.mark.parametrize("order", ["reverse", "random:7", "random:8"])
+def test_result_does_not_depend_on_lane_scheduling(emu, monkeypatch, order):
+    """The emulator runs the lanes of a phase one after another; under a reversed / shuffled order every cross-lane hand-over
+    that skipped a barrier or collective would read stale data (verified by deleting one barrier: this test fails)."""
+    monkeypatch.setenv("EMU_LANE_ORDER", order)
+    lv, entry, entry_level, opq, codes, q = problem(131, 3000, 128, 16, 2, deg=24, nq=6)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    for vsf, fused, rk, pair in ((O.COSINE, True, 300, 1), (O.EUCLIDEAN, False, 60, 0)):
+        wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
+        ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, cand_cap=256, pair=pair)
+        check(ids, sc, st, status, wi, ws, wst)
+
+
 def test_degree_above_32_uses_one_lane_per_neighbour(emu):
     """maxDegree 40 > 32: the pair-lane scoring does not apply; the one-lane-per-neighbour path must give the same answers"""
     lv, entry, entry_level, opq, codes, q = problem(23, 2000, 128, 16, 2, deg=40, nq=6)
