@@ -1065,6 +1065,42 @@ void jvo_rerank(const float *queries, const float *cand_vecs, const int32_t *can
  * the reference's membership for EXACT-score ties at the K-th place depends on heap array order (NodeQueue.java:
  * 197-214).  Distinct exact scores => identical results.
  * ---------------------------------------------------------------------------------------- */
+/* NodeQueue over a BoundedLongHeap / GrowableLongHeap (B/graph/NodeQueue.java:36-58,83-85,125-137; B/util/
+ * BoundedLongHeap.java:58-69): exported so that the reference's TestNodeQueue literals can pin it.
+ * order: 0 = MIN_HEAP (apply(v) = v), 1 = MAX_HEAP (apply(v) = -1 - v).  cap <= 0 = growable (caller provides room).
+ * heap[] is a binary min-heap of the order-applied keys.  Returns 1 if the value was added (BoundedLongHeap.push). */
+int jvo_nodequeue_push(int64_t *heap, int *size, int cap, int order, int32_t node, float score)
+{
+    int64_t v = jvo_nodequeue_encode(node, score);
+    if (order) v = -1 - v;
+    if (cap > 0 && *size >= cap) {
+        if (v < heap[0]) return 0;
+        heap[0] = v;                       /* updateTop */
+        heap_sift_down(heap, *size, 0);
+        return 1;
+    }
+    int i = (*size)++;
+    heap[i] = v;
+    while (i > 0 && heap[(i - 1) / 2] > heap[i]) {
+        int p = (i - 1) / 2;
+        int64_t t = heap[i]; heap[i] = heap[p]; heap[p] = t;
+        i = p;
+    }
+    return 1;
+}
+/* topNode / topScore / pop */
+void jvo_nodequeue_top(const int64_t *heap, int order, int32_t *node, float *score)
+{
+    int64_t v = order ? -1 - heap[0] : heap[0];
+    *node = (int32_t)~(uint32_t)(v & 0xFFFFFFFFLL);
+    *score = jvo_sortable_int_to_float((int32_t)(v >> 32));
+}
+void jvo_nodequeue_pop(int64_t *heap, int *size)
+{
+    heap[0] = heap[--(*size)];
+    heap_sift_down(heap, *size, 0);
+}
+
 typedef struct { int64_t *a; int n, cap; } lheap;  /* min-heap of keys */
 static void lh_push(lheap *h, int64_t v)
 {

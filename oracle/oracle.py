@@ -275,6 +275,33 @@ def pq_train(vecs, M, k=256, globally_center=False, seed=1, rounds=6):
     return OraclePQ(D, M, cb, cen if globally_center else None, k), np.array(list(rr))
 
 
+class OracleNodeQueue:
+    """NodeQueue over a Bounded/GrowableLongHeap (B/graph/NodeQueue.java); order "min" or "max"; max_size None = growable."""
+
+    def __init__(self, order, max_size=None, room=1024):
+        self.order = 1 if order == "max" else 0
+        self.cap = int(max_size) if max_size else 0
+        self.heap = np.zeros(max(room, self.cap), np.int64)
+        self.n = C.c_int(0)
+
+    def push(self, node, score):
+        return bool(lib().jvo_nodequeue_push(self.heap.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(self.n), self.cap,
+                                             self.order, int(node), C.c_float(score)))
+
+    def top(self):
+        node, score = C.c_int32(), C.c_float()
+        lib().jvo_nodequeue_top(self.heap.ctypes.data_as(C.POINTER(C.c_int64)), self.order, C.byref(node), C.byref(score))
+        return node.value, score.value
+
+    def pop(self):
+        node, _ = self.top()
+        lib().jvo_nodequeue_pop(self.heap.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(self.n))
+        return node
+
+    def size(self):
+        return self.n.value
+
+
 class OraclePQ:
     """Flat-array ProductQuantization for the oracle (codebooks concatenated centroid-major)."""
 

@@ -277,3 +277,39 @@ def test_siftsmall_query_fixture(golden_dir):
         sc = O.compare_many(O.EUCLIDEAN, q[i], q)
         ids, _ = O.topk(None, sc, 1)
         assert ids[0] == i
+
+
+# ---- NodeQueue / BoundedLongHeap: the reference's own literals (TS/graph/TestNodeQueue.java) ----
+def test_nodequeue_literals_from_the_reference():
+    nn = O.OracleNodeQueue("min", 2)                     # testNeighborsProduct :36-47
+    assert nn.push(2, 0.5) and nn.push(1, 0.2) and nn.push(3, 1.0)
+    assert nn.top()[1] == 0.5
+    nn.pop()
+    assert nn.top()[1] == 1.0
+    nn = O.OracleNodeQueue("max", 2)                     # testNeighborsMaxHeap :49-58
+    assert nn.push(2, 2) and nn.push(1, 1)
+    assert not nn.push(3, 3)
+    assert nn.top()[1] == 2.0
+    nn.pop()
+    assert nn.top()[1] == 1.0
+    nn = O.OracleNodeQueue("max")                        # testTopMaxHeap :60-68
+    nn.push(1, 2), nn.push(2, 1)
+    assert nn.top() == (1, 2.0)
+    nn = O.OracleNodeQueue("min")                        # testTopMinHeap :70-78
+    nn.push(1, 0.5), nn.push(2, -0.5)
+    assert nn.top() == (2, -0.5)
+    nn = O.OracleNodeQueue("min", 2)                     # testMaxSizeQueue :90-102
+    nn.push(1, 1), nn.push(2, 2)
+    assert nn.size() == 2 and nn.top()[0] == 1
+    nn.push(3, 3)
+    assert nn.size() == 2 and nn.top()[0] == 2
+    rng = np.random.default_rng(0)                       # testUnboundedQueue :104-120
+    nn = O.OracleNodeQueue("max")
+    scores = rng.random(256).astype(np.float32)
+    for i, s in enumerate(scores):
+        nn.push(i, float(s))
+    assert nn.top() == (int(np.argmax(scores)), float(scores.max()))
+    # equal scores: the smaller node id wins (NodeQueue.encode javadoc :104-124)
+    nn = O.OracleNodeQueue("max")
+    nn.push(7, 0.25), nn.push(3, 0.25), nn.push(9, 0.25)
+    assert [nn.pop() for _ in range(3)] == [3, 7, 9]
