@@ -614,7 +614,10 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
                     }
                     st.cand.pop();
                     const int32_t node = nq_node(top);
-                    if ((int)st.res.size() < rk) {  // addTopCandidate :515-530
+                    // threshold is 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the
+                    // results; the node is expanded all the same
+                    if (!(top_score >= 0.0f)) {
+                    } else if ((int)st.res.size() < rk) {  // addTopCandidate :515-530
                         st.res.push_back(top);
                         std::push_heap(st.res.begin(), st.res.end(), std::greater<int64_t>());
                     } else if (top_score > nq_score(st.res.front())) {

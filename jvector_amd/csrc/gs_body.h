@@ -420,8 +420,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 s.spill_max = top;  // still an upper bound of what is left
                 gs_fence();
             }
-            // addTopCandidate :515-530 (BoundedLongHeap.push / updateTop)
-            if (s.res_n < rk) {
+            // threshold 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the results (the
+            // node is expanded all the same); then addTopCandidate :515-530 (BoundedLongHeap.push / updateTop)
+            if (!(top_score >= 0.0f)) {
+                gs_barrier();
+            } else if (s.res_n < rk) {
                 if (lane == 0) s.res[s.res_n] = top;
                 if (top < s.res_min) {
                     s.res_min = top;

@@ -1161,8 +1161,10 @@ void jvo_graph_search(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes
             if (res.n >= rk && topScore < key_score(res.a[0])) break;  /* stopSearch */
             lh_pop(&cand);
             int32_t node = key_node(topKey);
-            /* addTopCandidate (acceptOrds = ALL, threshold = 0) */
-            if (res.n < rk) lh_push(&res, topKey);
+            /* acceptOrds = ALL, threshold = 0.0f: `topCandidateScore >= threshold` (:437) still keeps negative and NaN
+             * scores out of the results (they are expanded all the same); then addTopCandidate :515-530 */
+            if (!(topScore >= 0.0f)) { /* not a result */ }
+            else if (res.n < rk) lh_push(&res, topKey);
             else if (topScore > key_score(res.a[0])) {
                 lh_push(&evicted, res.a[0]);
                 res.a[0] = topKey;              /* BoundedLongHeap.updateTop */

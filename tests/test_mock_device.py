@@ -361,3 +361,33 @@ def test_host_searcher_continuous_batching(J, ctx, monkeypatch, slots, groups):
     monkeypatch.setenv("JVECTOR_HIP_GRAPH_SLOTS", str(slots))
     monkeypatch.setenv("JVECTOR_HIP_GRAPH_GROUPS", str(groups))
     T.test_graph_search_large_batch_and_errors(ctx)
+
+
+@pytest.mark.parametrize("traversal", ["host", "device"])
+def test_negative_scores_are_expanded_but_never_results(J, ctx, traversal):
+    """DOT_PRODUCT over unnormalised vectors: (1 + dot) / 2 < 0 for strongly opposed pairs.  With threshold 0.0f the reference
+    does not add such a candidate to the results (GraphSearcher.java:437) but still expands it."""
+    from oracle import oracle as O
+    import test_graph_search as T
+    rng = np.random.default_rng(8)
+    D, M, N, deg = 128, 16, 400, 8
+    v = (3.0 * rng.standard_normal((N, D))).astype(np.float32)          # norms ~ 34: dots reach +-hundreds
+    sizes, offs = O.subvector_sizes_offsets(D, M)
+    cb = np.concatenate([v[rng.integers(0, N, 256), offs[m]: offs[m] + sizes[m]].reshape(-1) for m in range(M)])
+    nb = np.stack([rng.permutation(N)[:deg] for _ in range(N)]).astype(np.int32)
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    lv = [(None, nb)]
+    graph = J.GraphIndex(ctx, N, lv, 0, 0).set_traversal(traversal)
+    fused = J.FusedPQ(ctx, pq, T.fused_blocks(codes, nb), nb)
+    q = (-v[rng.integers(0, N, 6)]).astype(np.float32)                    # opposed to some node: many negative scores
+    og = O.OracleGraph(N, lv, 0, 0)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, None, max_queries=8)
+    ids, sc, st = s.search(q, J.VectorSimilarityFunction.DOT_PRODUCT, 20, 500, return_stats=True)
+    wi, ws, wst = og.search(opq, codes, None, q, O.DOT_PRODUCT, 20, 500, fused=True)
+    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+    assert (st[:, 1] > (ids >= 0).sum(axis=1)).all()       # more nodes were expanded than became results
+    assert (sc[ids >= 0] >= 0).all()                       # and no negative score was kept
