@@ -310,6 +310,14 @@ JV_API int jv_hip_pair_table_download(jv_ctx *ctx, const jv_pair_table *t, float
 JV_API int jv_hip_pair_table_destroy(jv_pair_table *t);
 JV_API int jv_hip_code_pair_scores(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *codes, const int32_t *node1, int P,
                                    const int32_t *node2, int B, float *scores_out);
+/* FusedPQ.writeInline for nodes [first, first + count) (FusedPQ.java:146-161): stores the neighbour rows (count x maxDegree
+ * int32, -1 padded, host or device memory) and gathers each neighbour's code out of `codes` into the node's packed block,
+ * zero padded — the producer of the layout jv_hip_fused_scores / the graph searcher read.  Neighbour ids index `codes`. */
+JV_API int jv_hip_fused_build(jv_ctx *ctx, jv_fused *f, const jv_codes *codes, int64_t first, int64_t count,
+                              const int32_t *neighbors);
+/* copy blocks (count x maxDegree*M bytes) and / or neighbour rows back; either output may be NULL */
+JV_API int jv_hip_fused_download(jv_ctx *ctx, const jv_fused *f, int64_t first, int64_t count, uint8_t *blocks_out,
+                                 int32_t *neighbors_out);
 JV_API int jv_hip_pq_decode(jv_ctx *ctx, const jv_codes *codes, const int32_t *ordinals, int64_t first, int64_t count,
                             float *vectors_out);
 JV_API int jv_hip_direct_scores(jv_ctx *ctx, const jv_codes *codes, const float *queries, int Q, jv_vsf vsf,

@@ -91,6 +91,8 @@ SIGNATURES = {
     "jv_hip_pair_table_download": (_i, [_p, _p, _p]),
     "jv_hip_pair_table_destroy": (_i, [_p]),
     "jv_hip_code_pair_scores": (_i, [_p, _p, _p, _p, _i, _p, _i, _p]),
+    "jv_hip_fused_build": (_i, [_p, _p, _p, _i64, _i64, _p]),
+    "jv_hip_fused_download": (_i, [_p, _p, _i64, _i64, _p, _p]),
     "jv_hip_pq_decode": (_i, [_p, _p, _p, _i64, _i64, _p]),
     "jv_hip_direct_scores": (_i, [_p, _p, _p, _i, _i, _p, _i, _p]),
     "jv_hip_graph_search": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),

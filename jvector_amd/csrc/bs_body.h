@@ -112,6 +112,24 @@ BS_FN void bs_decode(const BsPq &pq, const uint8_t *codes, int64_t n, const int3
     out[t] = v;
 }
 
+// ---- FusedPQ.writeInline (B/graph/disk/feature/FusedPQ.java:146-161): block[node][j] = code of neighbour j, zero padded.
+//      thread t = (node, j, 16-byte chunk c) when M % 16 == 0 (chunk = 16), else (node, j, byte) (chunk = 1).
+BS_FN void bs_fused_gather(const uint8_t *codes, int64_t n_codes, const int32_t *neighbors, int maxDegree, int M, int chunk, int64_t t,
+                           uint8_t *blocks)
+{
+    const int per_row = M / chunk;
+    const int64_t row = t / per_row;  // node * maxDegree + j
+    const int c = (int)(t % per_row);
+    const int32_t nb = neighbors[row];
+    uint8_t *dst = blocks + row * M + (int64_t)c * chunk;
+    if (nb < 0 || nb >= n_codes) {
+        for (int b = 0; b < chunk; ++b) dst[b] = 0;
+        return;
+    }
+    const uint8_t *src = codes + (int64_t)nb * M + (int64_t)c * chunk;
+    for (int b = 0; b < chunk; ++b) dst[b] = src[b];
+}
+
 // VectorUtil.dotProduct(a, b) full-vector form (DefaultVectorUtilSupport.java:38-105): the FIRST len%8 elements one by
 // one, then blocks of eight whose products are summed left to right before joining the running sum (the 32-wide
 // unrolling of the reference is four such statements in sequence: same association).

@@ -89,6 +89,37 @@ int jv_hip_code_pair_scores(jv_ctx *ctx, const jv_pair_table *t, const jv_codes 
     return stage_out_end(ctx, os);
 }
 
+int jv_hip_fused_build(jv_ctx *ctx, jv_fused *f, const jv_codes *codes, int64_t first, int64_t count, const int32_t *neighbors)
+{
+    clear_error();
+    JV_REQUIRE(ctx && f && codes && neighbors, "fused_build: NULL argument");
+    JV_REQUIRE(codes->pq == f->pq, "fused_build: the code store and the fused blocks use different codebooks");
+    JV_REQUIRE(first >= 0 && count >= 0 && first + count <= f->count, "fused_build: range out of bounds");
+    if (count == 0) return JV_OK;
+    JV_TRY(use_device(ctx->device));
+    int32_t *d_nb = f->d_neighbors + first * f->maxDegree;
+    JV_HIP_CHECK(hipMemcpyAsync(d_nb, neighbors, sizeof(int32_t) * (size_t)count * f->maxDegree, hipMemcpyDefault, ctx->stream));
+    if (!is_device_ptr(neighbors)) JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the caller may reuse its buffer
+    JV_TRY(launch_fused_gather(ctx->stream, codes, d_nb, f->maxDegree, count, f->d_blocks + (size_t)first * f->maxDegree * f->M));
+    f->norms_valid = false;
+    return JV_OK;
+}
+
+int jv_hip_fused_download(jv_ctx *ctx, const jv_fused *f, int64_t first, int64_t count, uint8_t *blocks_out, int32_t *neighbors_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && f, "fused_download: NULL argument");
+    JV_REQUIRE(first >= 0 && count >= 0 && first + count <= f->count, "fused_download: range out of bounds");
+    JV_TRY(use_device(ctx->device));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const size_t bsz = (size_t)f->maxDegree * f->M;
+    if (blocks_out) JV_HIP_CHECK(hipMemcpy(blocks_out, f->d_blocks + (size_t)first * bsz, (size_t)count * bsz, hipMemcpyDefault));
+    if (neighbors_out)
+        JV_HIP_CHECK(hipMemcpy(neighbors_out, f->d_neighbors + first * f->maxDegree, sizeof(int32_t) * (size_t)count * f->maxDegree,
+                               hipMemcpyDefault));
+    return JV_OK;
+}
+
 int jv_hip_pq_decode(jv_ctx *ctx, const jv_codes *codes, const int32_t *ordinals, int64_t first, int64_t count, float *vectors_out)
 {
     clear_error();

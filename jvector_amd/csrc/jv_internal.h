@@ -233,6 +233,7 @@ int launch_km_finish_round(hipStream_t s, const KmParams &p);
 int launch_pair_table(hipStream_t s, const jv_pq *pq, int vsf, float *d_out);
 int launch_pair_scores(hipStream_t s, const float *d_tri, int vsf, const jv_codes *codes, const int32_t *d_node1, int P,
                        const int32_t *d_node2, int B, float *d_out);
+int launch_fused_gather(hipStream_t s, const jv_codes *codes, const int32_t *d_neighbors, int maxDegree, int64_t count, uint8_t *d_blocks);
 int launch_pq_decode(hipStream_t s, const jv_codes *codes, const int32_t *d_ordinals, int64_t first, int64_t count, float *d_out);
 int launch_direct_scores(hipStream_t s, const jv_codes *codes, int vsf, const float *d_cq, int Q, const int32_t *d_ordinals, int B,
                          float *d_qnorm, float *d_out);

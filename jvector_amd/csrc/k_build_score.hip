@@ -48,6 +48,13 @@ __global__ __launch_bounds__(256) void direct_scores_kernel(BsPq pq, int vsf, co
     if (t < total) bs_direct_score(pq, vsf, codes, n, cq, qnorm, ordinals, B, t, out);
 }
 
+__global__ __launch_bounds__(256) void fused_gather_kernel(const uint8_t *codes, int64_t n_codes, const int32_t *neighbors, int maxDegree,
+                                                           int M, int chunk, int64_t total, uint8_t *blocks)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) bs_fused_gather(codes, n_codes, neighbors, maxDegree, M, chunk, t, blocks);
+}
+
 static dim3 flat_grid(int64_t total) { return dim3((unsigned)((total + 255) / 256)); }
 
 int launch_pair_table(hipStream_t s, const jv_pq *pq, int vsf, float *d_out)
@@ -65,6 +72,20 @@ int launch_pair_scores(hipStream_t s, const float *d_tri, int vsf, const jv_code
     if (total == 0) return JV_OK;
     hipLaunchKernelGGL(pair_scores_kernel, flat_grid(total), dim3(256), 0, s, d_tri, vsf, codes->M, codes->pq->k, codes->d_codes,
                        codes->count, d_node1, d_node2, B, total, d_out);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+// HBM-bound copy: count * maxDegree * M bytes written (3 KB per node at C3), the reads are 96-byte gathers
+int launch_fused_gather(hipStream_t s, const jv_codes *codes, const int32_t *d_neighbors, int maxDegree, int64_t count, uint8_t *d_blocks)
+{
+    const int M = codes->M;
+    const bool wide = M % 16 == 0 && (reinterpret_cast<uintptr_t>(codes->d_codes) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_blocks) & 15) == 0;
+    const int chunk = wide ? 16 : 1;
+    const int64_t total = count * maxDegree * (M / chunk);
+    if (total == 0) return JV_OK;
+    hipLaunchKernelGGL(fused_gather_kernel, flat_grid(total), dim3(256), 0, s, codes->d_codes, codes->count, d_neighbors, maxDegree, M, chunk,
+                       total, d_blocks);
     JV_HIP_CHECK(hipGetLastError());
     return JV_OK;
 }

@@ -454,6 +454,28 @@ class FusedPQ:
         check(self._lib.jv_hip_fused_upload(ctx._h, h, 0, n, b_p, n_p))
         self._h, self.count, self.max_degree = h, n, max_degree
 
+    @classmethod
+    def build(cls, ctx, pq_vectors: "PQVectors", neighbors):
+        """FusedPQ.writeInline on the device: blocks gathered from `pq_vectors` for the given neighbour rows [n, maxDegree]."""
+        self = cls.__new__(cls)
+        self.ctx, self._lib, self.pq = ctx, ctx._lib, pq_vectors.pq
+        n, max_degree = int(neighbors.shape[0]), int(neighbors.shape[1])
+        h = C.c_void_p()
+        check(self._lib.jv_hip_fused_create(ctx._h, self.pq._h, n, max_degree, C.byref(h)))
+        self._h, self.count, self.max_degree = h, n, max_degree
+        n_p, nk = _ptr(neighbors, np.int32)
+        check(self._lib.jv_hip_fused_build(ctx._h, h, pq_vectors._h, 0, n, n_p))
+        return self
+
+    def get(self, first=0, n=None):
+        """(blocks[n, maxDegree*M] uint8, neighbors[n, maxDegree] int32) of nodes [first, first+n) as host arrays."""
+        n = self.count - first if n is None else n
+        blocks = np.empty((n, self.max_degree * self.pq.M), np.uint8)
+        nbrs = np.empty((n, self.max_degree), np.int32)
+        check(self._lib.jv_hip_fused_download(self.ctx._h, self._h, int(first), int(n), C.c_void_p(blocks.ctypes.data),
+                                              C.c_void_p(nbrs.ctypes.data)))
+        return blocks, nbrs
+
     def approximate_score_function_for(self, queries, vsf, luts=None):
         luts = luts or QueryTables(self.ctx, self.pq, int(queries.shape[0]))
         luts.build(queries, vsf, DecoderKind.FUSED)

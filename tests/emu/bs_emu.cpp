@@ -22,6 +22,12 @@ void bs_emu_pair_scores(const float *tri, int vsf, int M, int k, const uint8_t *
     for (int64_t t = 0; t < (int64_t)P * B; ++t) jv::bs_pair_score(tri, vsf, M, k, codes, n, node1, node2, B, t, out);
 }
 
+void bs_emu_fused_gather(const uint8_t *codes, int64_t n_codes, const int32_t *neighbors, int maxDegree, int M, int chunk, int64_t count,
+                         uint8_t *blocks)
+{
+    for (int64_t t = 0; t < count * maxDegree * (M / chunk); ++t) jv::bs_fused_gather(codes, n_codes, neighbors, maxDegree, M, chunk, t, blocks);
+}
+
 void bs_emu_decode(const float *codebooks, const int64_t *cb_offsets, const int32_t *sizes, const int32_t *offsets,
                    const float *centroid, int D, int M, int k, const uint8_t *codes, int64_t n, const int32_t *ordinals,
                    int64_t first, int64_t count, float *out)

@@ -270,6 +270,13 @@ int launch_pair_scores(hipStream_t, const float *d_tri, int vsf, const jv_codes 
         bs_pair_score(d_tri, vsf, codes->M, codes->pq->k, codes->d_codes, codes->count, d_node1, d_node2, B, t, d_out);
     return JV_OK;
 }
+int launch_fused_gather(hipStream_t, const jv_codes *codes, const int32_t *d_neighbors, int maxDegree, int64_t count, uint8_t *d_blocks)
+{
+    const int M = codes->M, chunk = M % 16 == 0 ? 16 : 1;
+    for (int64_t t = 0; t < count * maxDegree * (M / chunk); ++t)
+        bs_fused_gather(codes->d_codes, codes->count, d_neighbors, maxDegree, M, chunk, t, d_blocks);
+    return JV_OK;
+}
 int launch_pq_decode(hipStream_t, const jv_codes *codes, const int32_t *d_ordinals, int64_t first, int64_t count, float *d_out)
 {
     const BsPq b = bs_pq_of(codes->pq);

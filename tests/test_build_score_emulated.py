@@ -97,3 +97,20 @@ def test_decode_and_direct_scores(emu, D, M, centroid):
             for b in range(B):
                 want = -np.inf if o2[i, b] < 0 else np.float32(pq.direct_score(q[i], vsf, codes[o2[i, b]]))
                 assert sc[i, b] == want, (vsf, i, b)
+
+
+@pytest.mark.parametrize("M,chunk", [(16, 16), (96, 16), (7, 1)])
+def test_fused_block_gather(emu, M, chunk):
+    """FusedPQ.writeInline as a per-thread gather (bs_fused_gather): neighbour codes in neighbour order, zero padding."""
+    rng = np.random.default_rng(M)
+    n, deg = 50, 6
+    codes = rng.integers(1, 256, (n, M), dtype=np.uint8)
+    nb = np.full((n, deg), -1, np.int32)
+    for i in range(n):
+        d = int(rng.integers(0, deg + 1))
+        nb[i, :d] = rng.integers(0, n, d)
+    nb[3, 1] = n  # out of range id: treated like padding
+    blocks = np.full((n, deg, M), 0xEE, np.uint8)
+    emu.bs_emu_fused_gather(P(codes), C.c_int64(n), P(nb), deg, M, chunk, C.c_int64(n), P(blocks))
+    want = np.where(((nb >= 0) & (nb < n))[:, :, None], codes[np.clip(nb, 0, n - 1)], 0).astype(np.uint8)
+    assert np.array_equal(blocks, want)

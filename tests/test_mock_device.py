@@ -391,3 +391,22 @@ def test_negative_scores_are_expanded_but_never_results(J, ctx, traversal):
     assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
     assert (st[:, 1] > (ids >= 0).sum(axis=1)).all()       # more nodes were expanded than became results
     assert (sc[ids >= 0] >= 0).all()                       # and no negative score was kept
+
+
+def test_fused_build_entry_point(J, ctx):
+    """jv_hip_fused_build == uploading blocks assembled on the host (FusedPQ.writeInline), and it searches the same."""
+    from oracle import oracle as O
+    import test_graph_search as T
+    v, lv, entry, entry_level, cb, q = T.build_problem(5, N=1500, D=128, M=16, levels=2)
+    pq = J.ProductQuantization.from_codebooks(ctx, 128, 16, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, len(v))
+    built = J.FusedPQ.build(ctx, cv, lv[0][1])
+    blocks, nbrs = built.get()
+    assert np.array_equal(blocks, T.fused_blocks(codes, lv[0][1])) and np.array_equal(nbrs, lv[0][1])
+    graph = J.GraphIndex(ctx, len(v), lv, entry, entry_level)
+    got = J.GraphSearcher(ctx, graph, pq, cv, built, vs, max_queries=64).search(q, J.VectorSimilarityFunction.COSINE, 10, 40)
+    opq = O.OraclePQ(128, 16, cb)
+    wi, ws, _ = O.OracleGraph(len(v), lv, entry, entry_level).search(opq, codes, v, q, O.COSINE, 10, 40, fused=True)
+    assert np.array_equal(got[0], wi) and np.array_equal(got[1], ws)

@@ -57,3 +57,21 @@ def test_build_score_provider_matches_oracle(ctx, D, M, centroid):
             for b in range(0, 24, 5):
                 assert sc[i, b] == np.float32(opq.direct_score(q[i], int(vsf), codes[ords[i, b]])), (vsf, i, b)
         bsp.close()
+
+
+def test_fused_build_on_device(ctx):
+    """jv_hip_fused_build (FusedPQ.writeInline as a device gather) == blocks assembled on the host"""
+    rng = np.random.default_rng(3)
+    D, M, n, deg = 768, 96, 4000, 32
+    cb = rng.standard_normal(256 * D).astype(np.float32)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    codes = rng.integers(0, 256, (n, M), dtype=np.uint8)
+    cv = J.PQVectors(ctx, pq, codes)
+    nb = np.full((n, deg), -1, np.int32)
+    for i in range(n):
+        d = int(rng.integers(0, deg + 1))
+        nb[i, :d] = rng.integers(0, n, d)
+    blocks, nbrs = J.FusedPQ.build(ctx, cv, nb).get()
+    want = np.where((nb >= 0)[:, :, None], codes[np.clip(nb, 0, n - 1)], 0).astype(np.uint8).reshape(n, deg * M)
+    assert np.array_equal(blocks, want) and np.array_equal(nbrs, nb)
+
