@@ -1144,12 +1144,29 @@ void jvo_graph_search(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes
     if (fused) jvo_fuseddecoder_init(pq, query, vsf, lut, amag, &bmag);
     else jvo_pqdecoder_init(pq, query, vsf, lut, amag, &bmag);
 #define SCORE(node) jvo_adc_score(vsf, M, k, lut, amag, bmag, codes + (size_t)(node) * M)
-    uint8_t *visited = (uint8_t *)calloc((size_t)g->n_nodes, 1);
+    /* visited set: a per-thread array of epoch stamps reused from query to query (the reference clears a growable bit
+     * set per search; a fresh calloc of n_nodes bytes per query would make this baseline pay ~visited page faults each
+     * time, which the reference does not) */
+    static __thread uint32_t *tl_stamp = NULL;
+    static __thread int64_t tl_cap = 0;
+    static __thread uint32_t tl_epoch = 0;
+    if (tl_cap < g->n_nodes) {
+        free(tl_stamp);
+        tl_stamp = (uint32_t *)calloc((size_t)g->n_nodes, sizeof(uint32_t));
+        tl_cap = g->n_nodes;
+        tl_epoch = 0;
+    }
+    if (++tl_epoch == 0) {  /* wrapped: start over */
+        memset(tl_stamp, 0, sizeof(uint32_t) * (size_t)tl_cap);
+        tl_epoch = 1;
+    }
+    uint32_t *const stamp = tl_stamp;
+    const uint32_t epoch = tl_epoch;
     lheap cand = {0}, res = {0}, evicted = {0};
     int64_t n_visited = 0, n_expanded = 0;
 
     /* initializeInternal */
-    visited[g->entry_node] = 1;
+    stamp[g->entry_node] = epoch;
     lh_push(&cand, -1 - jvo_nodequeue_encode(g->entry_node, SCORE(g->entry_node)));  /* MAX_HEAP: -1 - v */
 
     for (int lvl = g->entry_level; lvl >= 0; lvl--) {
@@ -1176,8 +1193,8 @@ void jvo_graph_search(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes
             for (int i = 0; i < g->level_degree[lvl]; i++) {
                 int32_t nb = row[i];
                 if (nb < 0) break;  /* neighbour lists are packed: first -1 ends the row */
-                if (visited[nb]) continue;
-                visited[nb] = 1;
+                if (stamp[nb] == epoch) continue;
+                stamp[nb] = epoch;
                 lh_push(&cand, -1 - jvo_nodequeue_encode(nb, SCORE(nb)));
                 n_visited++;
             }
@@ -1207,5 +1224,5 @@ void jvo_graph_search(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes
     }
     if (stats) { stats[0] = n_visited; stats[1] = n_expanded; }
 #undef SCORE
-    free(fin); free(cand.a); free(res.a); free(evicted.a); free(visited); free(lut); free(amag);
+    free(fin); free(cand.a); free(res.a); free(evicted.a); free(lut); free(amag);
 }
