@@ -323,6 +323,17 @@ JV_API int jv_hip_pq_decode(jv_ctx *ctx, const jv_codes *codes, const int32_t *o
 JV_API int jv_hip_direct_scores(jv_ctx *ctx, const jv_codes *codes, const float *queries, int Q, jv_vsf vsf,
                                 const int32_t *ordinals, int B, float *scores_out);
 
+/* GraphSearcher.search(scoreProvider, topK, threshold = 0, acceptOrds) (GraphSearcher.java:222-243): the Bits filter as a
+ * little-endian bit array over node ids — bit n of 64-bit word n / 64 set = node n may be RETURNED.  Filtered-out nodes are
+ * still traversed (their neighbours are scored and expanded); only layer 0 consults the filter (upper layers run with
+ * Bits.ALL, :276).  accept_stride_words = 0: one mask for the whole batch; otherwise query q uses the words starting at
+ * accept_bits + q * accept_stride_words (>= ceil(n_nodes / 64)).  accept_bits may be host or device memory; NULL = Bits.ALL,
+ * i.e. jv_hip_graph_search. */
+JV_API int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *luts, const jv_codes *codes,
+                                        const jv_fused *fused, const jv_vectors *vectors, const float *queries, int Q,
+                                        jv_vsf vsf, int topK, int rerankK, const uint64_t *accept_bits,
+                                        int64_t accept_stride_words, int32_t *out_ids, float *out_scores, int64_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

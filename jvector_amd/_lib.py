@@ -96,6 +96,7 @@ SIGNATURES = {
     "jv_hip_pq_decode": (_i, [_p, _p, _p, _i64, _i64, _p]),
     "jv_hip_direct_scores": (_i, [_p, _p, _p, _i, _i, _p, _i, _p]),
     "jv_hip_graph_search": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "jv_hip_graph_search_filtered": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i64, _p, _p, _p]),
 }
 
 # the reference's per-pair SPI, exported unchanged (include/jvector_simd_compat.h)

@@ -261,6 +261,7 @@ int jv_hip_ctx_destroy(jv_ctx *ctx)
     ctx->d_gs_visited.release();
     ctx->d_gs_spill.release();
     ctx->d_gs_out.release();
+    ctx->d_gs_mask.release();
     for (auto &e : ctx->prof_pending) {
         (void)hipEventDestroy(e.start);
         (void)hipEventDestroy(e.stop);

@@ -428,9 +428,19 @@ int jv_hip_graph_set_traversal(jv_graph *g, int mode)
     return JV_OK;
 }
 
+// acceptOrds for a batch: a little-endian bit array over node ids per query (stride_words apart; 0 = one mask shared by all)
+struct AcceptMask {
+    const uint64_t *bits = nullptr;  // HOST memory for the host traversal, DEVICE memory for the device traversal
+    int64_t stride_words = 0;
+    bool accepts(int q, int32_t node) const
+    {
+        return !bits || ((bits[(int64_t)q * stride_words + (node >> 6)] >> (node & 63)) & 1ull);
+    }
+};
+
 static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
                         const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
-                        int32_t *out_ids, float *out_scores, int64_t *stats)
+                        int32_t *out_ids, float *out_scores, int64_t *stats, AcceptMask accept = AcceptMask())
 {
     clear_error();
     JV_REQUIRE(ctx && g && l && codes, "graph_search: NULL argument");
@@ -616,7 +626,8 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
                     const int32_t node = nq_node(top);
                     // threshold is 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the
                     // results; the node is expanded all the same
-                    if (!(top_score >= 0.0f)) {
+                    // and acceptOrds gates the same decision at layer 0 (upper layers run with Bits.ALL, :276)
+                    if (!(top_score >= 0.0f) || (s.lvl == 0 && !accept.accepts(s.query, node))) {
                     } else if ((int)st.res.size() < rk) {  // addTopCandidate :515-530
                         st.res.push_back(top);
                         std::push_heap(st.res.begin(), st.res.end(), std::greater<int64_t>());
@@ -846,7 +857,7 @@ static int env_int(const char *name, int dflt)
 
 static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
                                const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
-                               int32_t *out_ids, float *out_scores, int64_t *stats)
+                               int32_t *out_ids, float *out_scores, int64_t *stats, AcceptMask host_accept, AcceptMask dev_accept)
 {
     const jv_decoder_kind kind = fused ? JV_DECODER_FUSED : JV_DECODER_PQ;
     JV_TRY(jv_hip_luts_build(ctx, l, queries, Q, vsf, kind));  // centred queries, query magnitudes, raw copy for the rerank
@@ -929,6 +940,8 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.deg0 = g->levels[0].degree;
     p.Q = Q;
     p.rerankK = rerankK;
+    p.accept = (const unsigned long long *)dev_accept.bits;
+    p.accept_stride = dev_accept.stride_words;
     p.visited = (int32_t *)ctx->d_gs_visited.ptr;
     p.vcap_log2 = vcap_log2;
     p.spill = (long long *)ctx->d_gs_spill.ptr;
@@ -994,8 +1007,17 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     std::vector<int32_t> sub_ids((size_t)R * topK);
     std::vector<float> sub_sc((size_t)R * topK);
     std::vector<int64_t> sub_stats((size_t)R * 2);
+    std::vector<uint64_t> sub_mask;  // per-query masks of the redone queries, compacted like the queries themselves
+    AcceptMask sub_accept = host_accept;
+    if (host_accept.bits && host_accept.stride_words > 0) {
+        sub_mask.resize((size_t)R * host_accept.stride_words);
+        for (int i = 0; i < R; ++i)
+            memcpy(sub_mask.data() + (size_t)i * host_accept.stride_words, host_accept.bits + (size_t)redo[i] * host_accept.stride_words,
+                   sizeof(uint64_t) * (size_t)host_accept.stride_words);
+        sub_accept.bits = sub_mask.data();
+    }
     JV_TRY(graph_search_host(ctx, g, l, codes, fused, vectors, sub.data(), R, vsf, topK, rerankK, sub_ids.data(), sub_sc.data(),
-                             sub_stats.data()));
+                             sub_stats.data(), sub_accept));
     const bool ids_dev = is_device_ptr(out_ids), sc_dev = is_device_ptr(out_scores);
     for (int i = 0; i < R; ++i) {
         const size_t dst = (size_t)redo[i] * topK, src = (size_t)i * topK;
@@ -1015,6 +1037,15 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
                         const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
                         int32_t *out_ids, float *out_scores, int64_t *stats)
 {
+    return jv_hip_graph_search_filtered(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, nullptr, 0, out_ids, out_scores,
+                                        stats);
+}
+
+int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
+                                 const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
+                                 const uint64_t *accept_bits, int64_t accept_stride_words, int32_t *out_ids, float *out_scores,
+                                 int64_t *stats)
+{
     clear_error();
     JV_REQUIRE(ctx && g && l && codes, "graph_search: NULL argument");
     // Traversal: the graph's setting, overridden by JVECTOR_HIP_GRAPH_TRAVERSAL=host|device.  AUTO is the host
@@ -1025,7 +1056,28 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
         if (!strcmp(e, "device")) mode = JV_TRAVERSAL_DEVICE;
         else if (!strcmp(e, "host")) mode = JV_TRAVERSAL_HOST;
     }
-    if (mode != JV_TRAVERSAL_DEVICE || Q == 0) return graph_search_host(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats);
+    // acceptOrds: the host traversal reads the masks from host memory, the device traversal from device memory
+    const int64_t words = g->n_nodes > 0 ? (g->n_nodes + 63) / 64 : 0;
+    JV_REQUIRE(!accept_bits || accept_stride_words == 0 || accept_stride_words >= words,
+               "graph_search: accept_stride_words %lld is smaller than the %lld words one mask needs", (long long)accept_stride_words,
+               (long long)words);
+    const size_t mask_words = !accept_bits ? 0 : (accept_stride_words == 0 ? (size_t)words : (size_t)accept_stride_words * (size_t)std::max(Q, 0));
+    AcceptMask host_accept, dev_accept;
+    std::vector<uint64_t> host_copy;
+    if (accept_bits && Q > 0) {
+        JV_TRY(use_device(ctx->device));
+        host_accept.stride_words = dev_accept.stride_words = accept_stride_words;
+        if (is_device_ptr(accept_bits)) {
+            dev_accept.bits = accept_bits;
+            host_copy.resize(mask_words);
+            JV_HIP_CHECK(hipMemcpy(host_copy.data(), accept_bits, sizeof(uint64_t) * mask_words, hipMemcpyDeviceToHost));
+            host_accept.bits = host_copy.data();
+        } else {
+            host_accept.bits = accept_bits;
+        }
+    }
+    if (mode != JV_TRAVERSAL_DEVICE || Q == 0)
+        return graph_search_host(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats, host_accept);
 
     JV_REQUIRE(topK > 0, "graph_search: topK must be positive");
     JV_REQUIRE(rerankK >= topK, "rerankK %d must be >= topK %d", rerankK, topK);  // GraphSearcher.java:233
@@ -1047,7 +1099,13 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
                   "and <= %d levels; use the host traversal", GS_MAX_LEVELS);
         return JV_ERR_UNSUPPORTED;
     }
-    return graph_search_device(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats);
+    if (accept_bits && !dev_accept.bits) {  // host masks: the kernel needs a device copy
+        JV_TRY(ctx->d_gs_mask.reserve(sizeof(uint64_t) * mask_words));
+        JV_HIP_CHECK(hipMemcpy(ctx->d_gs_mask.ptr, accept_bits, sizeof(uint64_t) * mask_words, hipMemcpyHostToDevice));
+        dev_accept.bits = (const uint64_t *)ctx->d_gs_mask.ptr;
+    }
+    return graph_search_device(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats, host_accept,
+                               dev_accept);
 }
 
 }  // extern "C"

@@ -379,6 +379,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     gs_fence();
     gs_barrier();
     const float query_mag = (VSF == 2) ? p.bmag[q] : 0.0f;
+    const unsigned long long *acc = p.accept ? p.accept + (long long)q * p.accept_stride : nullptr;
 
     // ---- initializeInternal :334-353: mark and score the entry node ----
     {
@@ -422,7 +423,12 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             }
             // threshold 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the results (the
             // node is expanded all the same); then addTopCandidate :515-530 (BoundedLongHeap.push / updateTop)
-            if (!(top_score >= 0.0f)) {
+            bool result = top_score >= 0.0f;
+            if (result && lvl == 0 && acc) {  // acceptOrds: layer 0 only (upper layers run with Bits.ALL, :276)
+                const int32_t tn = gs_key_node(top);
+                result = ((acc[tn >> 6] >> (tn & 63)) & 1ull) != 0;
+            }
+            if (!result) {
                 gs_barrier();
             } else if (s.res_n < rk) {
                 if (lane == 0) s.res[s.res_n] = top;

@@ -34,6 +34,8 @@ struct GsParams {
     int32_t D, M, deg0;
     // search
     int32_t Q, rerankK;
+    const unsigned long long *accept;  // acceptOrds bit array (bit n of word n / 64) or nullptr = Bits.ALL; layer 0 only
+    long long accept_stride;           // words between the masks of consecutive queries; 0 = one mask for the batch
     // per-worker scratch
     int32_t *visited;         // [workers][1 << vcap_log2]
     int32_t vcap_log2;

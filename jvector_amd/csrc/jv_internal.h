@@ -76,7 +76,7 @@ struct jv_ctx {
     // staging: host->device inputs, device->host outputs (pinned), device scratch
     jv::Buffer h_in, h_out, d_in, d_out, d_scratch, d_scratch2, d_scratch3;
     // device-resident graph traversal: per-worker visited tables / spill tiers and the per-query result staging
-    jv::Buffer d_gs_visited, d_gs_spill, d_gs_out;
+    jv::Buffer d_gs_visited, d_gs_spill, d_gs_out, d_gs_mask;
     // host batched graph searcher: worker pool (graph_search.cpp owns the type) and its destructor
     void *host_pool = nullptr;
     void (*host_pool_destroy)(void *) = nullptr;

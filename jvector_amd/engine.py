@@ -72,6 +72,16 @@ def _finalizer(cls):
     return cls
 
 
+def pack_accept_bits(accept, n_nodes):
+    """bool [n_nodes] or [Q, n_nodes] -> uint64 words, bit n of word n // 64 (the layout jv_hip_graph_search_filtered takes)"""
+    a = np.asarray(accept.cpu().numpy() if _is_torch(accept) else accept, dtype=bool)
+    if a.shape[-1] != n_nodes:
+        raise ValueError(f"accept covers {a.shape[-1]} nodes, the graph has {n_nodes}")
+    pad = (-n_nodes) % 64
+    a = np.pad(a, [(0, 0)] * (a.ndim - 1) + [(0, pad)])
+    return np.ascontiguousarray(np.packbits(a, axis=-1, bitorder="little").view(np.uint64))
+
+
 def device_count() -> int:
     return int(_lib.load().jv_hip_device_count())
 
@@ -587,7 +597,9 @@ class GraphSearcher:
         self.ctx, self.graph, self.cv, self.fused, self.vectors = ctx, graph, pq_vectors, fused, vectors
         self.luts = QueryTables(ctx, pq, max_queries)
 
-    def search(self, queries, vsf, top_k, rerank_k, return_stats=False):
+    def search(self, queries, vsf, top_k, rerank_k, return_stats=False, accept=None):
+        """accept = acceptOrds (GraphSearcher.search's Bits filter): None, a bool array [n_nodes] shared by the batch, or
+        [Q, n_nodes] one filter per query; filtered-out nodes are traversed but never returned."""
         Q = int(queries.shape[0])
         q_p, qk = _ptr(queries, np.float32)
         out_ids = _empty((Q, top_k), np.int32, queries)
@@ -595,8 +607,16 @@ class GraphSearcher:
         oi_p, oik = _ptr(out_ids, np.int32)
         os_p, osk = _ptr(out_sc, np.float32)
         stats = np.zeros((Q, 2), np.int64)
-        check(self.ctx._lib.jv_hip_graph_search(
+        mask_p, stride, mask = None, 0, None
+        if accept is not None:
+            mask = pack_accept_bits(accept, self.graph.n_nodes)
+            if mask.ndim == 2:
+                if mask.shape[0] != Q:
+                    raise ValueError(f"accept has {mask.shape[0]} rows for {Q} queries")
+                stride = int(mask.shape[1])
+            mask_p = C.c_void_p(mask.ctypes.data)
+        check(self.ctx._lib.jv_hip_graph_search_filtered(
             self.ctx._h, self.graph._h, self.luts._h, self.cv._h, self.fused._h if self.fused is not None else None,
-            self.vectors._h if self.vectors is not None else None, q_p, Q, int(vsf), int(top_k), int(rerank_k), oi_p, os_p,
-            C.c_void_p(stats.ctypes.data) if return_stats else None))
+            self.vectors._h if self.vectors is not None else None, q_p, Q, int(vsf), int(top_k), int(rerank_k), mask_p, stride,
+            oi_p, os_p, C.c_void_p(stats.ctypes.data) if return_stats else None))
         return (out_ids, out_sc, stats) if return_stats else (out_ids, out_sc)

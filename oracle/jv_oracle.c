@@ -1137,6 +1137,16 @@ void jvo_graph_search(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes
                       const float *query, int vsf, int fused, int topK, int rerankK,
                       int32_t *out_ids, float *out_scores, int64_t *stats /* visited, expanded */)
 {
+    jvo_graph_search_filtered(g, pq, codes, vecs, query, vsf, fused, topK, rerankK, NULL, out_ids, out_scores, stats);
+}
+
+/* search(scoreProvider, topK, threshold = 0, acceptOrds): `accept` is the Bits filter as a little-endian bit array over node
+ * ids (bit n of word n / 64), NULL = Bits.ALL.  Only layer 0 consults it (upper layers run with Bits.ALL, :276), and only to
+ * decide whether the popped candidate becomes a RESULT (:437); traversal is unaffected. */
+void jvo_graph_search_filtered(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes, const float *vecs,
+                               const float *query, int vsf, int fused, int topK, int rerankK, const uint64_t *accept,
+                               int32_t *out_ids, float *out_scores, int64_t *stats /* visited, expanded */)
+{
     const int M = pq->M, k = pq->k;
     float *lut = (float *)malloc(sizeof(float) * (size_t)M * k);
     float *amag = (float *)malloc(sizeof(float) * (size_t)M * k);
@@ -1180,7 +1190,7 @@ void jvo_graph_search(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes
             int32_t node = key_node(topKey);
             /* acceptOrds = ALL, threshold = 0.0f: `topCandidateScore >= threshold` (:437) still keeps negative and NaN
              * scores out of the results (they are expanded all the same); then addTopCandidate :515-530 */
-            if (!(topScore >= 0.0f)) { /* not a result */ }
+            if (!(topScore >= 0.0f) || (lvl == 0 && accept && !((accept[node >> 6] >> (node & 63)) & 1))) { /* not a result */ }
             else if (res.n < rk) lh_push(&res, topKey);
             else if (topScore > key_score(res.a[0])) {
                 lh_push(&evicted, res.a[0]);

@@ -146,6 +146,9 @@ typedef struct {
 void jvo_graph_search(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes, const float *vecs,
                       const float *query, int vsf, int fused, int topK, int rerankK,
                       int32_t *out_ids, float *out_scores, int64_t *stats /* [visited, expanded] or NULL */);
+void jvo_graph_search_filtered(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes, const float *vecs,
+                               const float *query, int vsf, int fused, int topK, int rerankK, const uint64_t *accept,
+                               int32_t *out_ids, float *out_scores, int64_t *stats);
 
 /* exact rerank of pre-gathered candidate rows (Q x R x D), one query per worker thread */
 void jvo_rerank(const float *queries, const float *cand_vecs, const int32_t *cand_ids, int Q, int R, int D, int vsf,

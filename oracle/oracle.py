@@ -43,6 +43,15 @@ class _Graph(C.Structure):
                 ("level_nodes", C.POINTER(C.POINTER(C.c_int32))), ("level_neighbors", C.POINTER(C.POINTER(C.c_int32)))]
 
 
+def pack_accept_bits(accept):
+    """bool [N] or [Q, N] -> uint64 words, bit n of word n // 64 (little-endian bit order), rows padded to whole words"""
+    a = np.asarray(accept, bool)
+    n = a.shape[-1]
+    pad = (-n) % 64
+    a = np.pad(a, [(0, 0)] * (a.ndim - 1) + [(0, pad)])
+    return np.ascontiguousarray(np.packbits(a, axis=-1, bitorder="little").view(np.uint64))
+
+
 class OracleGraph:
     """levels: list of (node_ids | None, neighbors[n_l, degree_l] int32 packed, -1 padded); level 0 first."""
 
@@ -58,7 +67,8 @@ class OracleGraph:
         self._nbrs = (i32p * L)(*[nb.ctypes.data_as(i32p) for _, nb in self.levels])
         self._s = _Graph(n_nodes, L, entry_node, entry_level, self._count, self._deg, self._nodes, self._nbrs)
 
-    def search(self, pq, codes, vecs, queries, vsf, top_k, rerank_k, fused=False):
+    def search(self, pq, codes, vecs, queries, vsf, top_k, rerank_k, fused=False, accept=None):
+        """accept: None (Bits.ALL), a bool array [N] shared by all queries, or [Q, N] one filter per query."""
         codes = np.ascontiguousarray(codes, np.uint8)
         queries = f32(queries)
         vecs = None if vecs is None else f32(vecs)
@@ -67,10 +77,12 @@ class OracleGraph:
         sc = np.empty((Q, top_k), np.float32)
         stats = np.zeros((Q, 2), np.int64)
         L = lib()
+        masks = None if accept is None else pack_accept_bits(accept)
         for q in range(Q):
-            L.jvo_graph_search(C.byref(self._s), pq.ref, _u8(codes), None if vecs is None else _f(vecs), _f(queries[q]),
-                               vsf, 1 if fused else 0, top_k, rerank_k, _i32(ids[q]), _f(sc[q]),
-                               stats[q].ctypes.data_as(C.POINTER(C.c_int64)))
+            m = None if masks is None else (masks if masks.ndim == 1 else masks[q]).ctypes.data_as(C.POINTER(C.c_uint64))
+            L.jvo_graph_search_filtered(C.byref(self._s), pq.ref, _u8(codes), None if vecs is None else _f(vecs), _f(queries[q]),
+                                        vsf, 1 if fused else 0, top_k, rerank_k, m, _i32(ids[q]), _f(sc[q]),
+                                        stats[q].ctypes.data_as(C.POINTER(C.c_int64)))
         return ids, sc, stats
 
 
@@ -125,6 +137,8 @@ def lib():
         sig("jvo_nodequeue_encode", C.c_int64, C.c_int32, C.c_float)
         sig("jvo_topk", C.c_int, i32p, fp, C.c_int64, C.c_int, i32p, fp)
         sig("jvo_search_flat", None, pqp, u8p, fp, C.c_int64, fp, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp, C.c_int)
+        sig("jvo_graph_search_filtered", None, C.POINTER(_Graph), pqp, u8p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int,
+            C.POINTER(C.c_uint64), i32p, fp, C.POINTER(C.c_int64))
         sig("jvo_graph_search", None, C.POINTER(_Graph), pqp, u8p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp,
             C.POINTER(C.c_int64))
         sig("jvo_rerank", None, fp, fp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp, C.c_int)

@@ -133,3 +133,29 @@ def test_graph_search_continuous_batching(ctx, slots, groups, monkeypatch):
         ids, sc, stats = s.search(q, VSF.DOT_PRODUCT, 10, 30, return_stats=True)
         wi, ws, wst = og.search(opq, codes, v, q, O.DOT_PRODUCT, 10, 30, fused=use_fused)
         assert np.array_equal(stats, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+
+
+def test_graph_search_accept_ords(ctx):
+    """GraphSearcher.search(..., acceptOrds): filtered-out nodes are traversed but never returned; one mask for the batch
+    and one mask per query; identical to the oracle."""
+    v, lv, entry, entry_level, cb, q = build_problem(19, N=4000, D=128, M=16, levels=2)
+    N = v.shape[0]
+    opq = O.OraclePQ(128, 16, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, 128, 16, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+    fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1])
+    og = O.OracleGraph(N, lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+    rng = np.random.default_rng(2)
+    shared = rng.random(N) < 0.3
+    per_query = rng.random((len(q), N)) < 0.2
+    per_query[3] = False
+    for accept in (shared, per_query):
+        for vsf in VSF:
+            ids, sc, st = s.search(q, vsf, 10, 40, return_stats=True, accept=accept)
+            wi, ws, wst = og.search(opq, codes, v, q, int(vsf), 10, 40, fused=True, accept=accept)
+            assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), vsf
+    assert (ids[3] == -1).all()

@@ -96,6 +96,7 @@ def test_host_graph_searcher(J, ctx, levels, use_fused, D, M):
 def test_host_graph_searcher_large_batch(J, ctx):
     import test_graph_search as T
     T.test_graph_search_large_batch_and_errors(ctx)
+    T.test_graph_search_accept_ords(ctx)
 
 
 def test_host_graph_searcher_worker_pool(J, monkeypatch):
@@ -410,3 +411,44 @@ def test_fused_build_entry_point(J, ctx):
     opq = O.OraclePQ(128, 16, cb)
     wi, ws, _ = O.OracleGraph(len(v), lv, entry, entry_level).search(opq, codes, v, q, O.COSINE, 10, 40, fused=True)
     assert np.array_equal(got[0], wi) and np.array_equal(got[1], ws)
+
+
+@pytest.mark.parametrize("traversal", ["host", "device"])
+def test_filtered_search_accept_ords(J, ctx, traversal, monkeypatch):
+    """GraphSearcher.search(..., acceptOrds): one filter for the batch, one filter per query, and (device traversal) the
+    per-query masks of queries that fall back to the host."""
+    from oracle import oracle as O
+    import test_graph_search as T
+    v, lv, entry, entry_level, cb, q = T.build_problem(19, N=2500, D=128, M=16, levels=2)
+    q = q[:12]
+    N = len(v)
+    opq = O.OraclePQ(128, 16, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, 128, 16, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal(traversal)
+    fused = J.FusedPQ(ctx, pq, T.fused_blocks(codes, lv[0][1]), lv[0][1])
+    og = O.OracleGraph(N, lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=16)
+    rng = np.random.default_rng(2)
+    shared = rng.random(N) < 0.3
+    per_query = rng.random((len(q), N)) < 0.2
+    per_query[3] = False                                   # nothing acceptable: empty result, the whole component is searched
+    per_query[4] = True
+    for accept in (shared, per_query):
+        for vsf in J.VectorSimilarityFunction:
+            ids, sc, st = s.search(q, vsf, 10, 40, return_stats=True, accept=accept)
+            wi, ws, wst = og.search(opq, codes, v, q, int(vsf), 10, 40, fused=True, accept=accept)
+            assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), vsf
+            rows = accept if accept.ndim == 2 else np.broadcast_to(accept, (len(q), N))
+            for i in range(len(q)):
+                assert rows[i][ids[i][ids[i] >= 0]].all()
+    assert (ids[3] == -1).all() and st[3, 1] > 1000
+    if traversal == "device":                             # overflow -> host fallback must carry each query's own mask
+        monkeypatch.setenv("JVECTOR_HIP_GS_VCAP_LOG2", "9")
+        ids, sc, st = s.search(q, J.VectorSimilarityFunction.COSINE, 10, 40, return_stats=True, accept=per_query)
+        wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, 40, fused=True, accept=per_query)
+        assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+    with pytest.raises(ValueError):
+        s.search(q, J.VectorSimilarityFunction.COSINE, 10, 40, accept=np.ones(N - 1, bool))

@@ -78,3 +78,17 @@ def test_unsupported_shape_is_refused(ctx):
     s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
     with pytest.raises(J.UnsupportedError):
         s.search(q, VSF.COSINE, 10, 40)
+
+
+def test_device_traversal_accept_ords(ctx):
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 19, 4000, 128, 16, 2, True)
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+    rng = np.random.default_rng(2)
+    per_query = rng.random((len(q), len(v))) < 0.2
+    per_query[3] = False
+    for accept in (per_query[0], per_query):
+        ids, sc, st = s.search(q, VSF.COSINE, 10, 40, return_stats=True, accept=accept)
+        wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, 40, fused=True, accept=accept)
+        assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+
