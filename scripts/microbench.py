@@ -106,6 +106,35 @@ def main():
     res["exact_scan"] = {"ms": ms, "shape": f"16x{N}", "dist_per_s": 16 * N / ms * 1e3,
                          "hbm_GBps_rows_once": N * 4 * D / ms / 1e6, "frac_hbm_rows_once": N * 4 * D / ms / 1e6 / HBM,
                          "tflops_nonfused": 16 * N * 6 * D / ms / 1e9}
+    # --- measured HBM ceilings on this box (record them next to the 8 TB/s vendor peak): device-to-device
+    #     copy and a stream triad over 2 GiB operands, torch ops timed with events on the engine's stream
+    n_el = 1 << 29
+    a = torch.empty(n_el, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a).normal_()
+    c = torch.empty_like(a)
+
+    def ev_time(fn, iters=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    ms = ev_time(lambda: c.copy_(a))
+    res["hbm_copy_d2d"] = {"ms": ms, "bytes": 2 * 4 * n_el, "GBps": 2 * 4 * n_el / ms / 1e6, "frac_of_8TBps": 2 * 4 * n_el / ms / 1e6 / HBM}
+    ms = ev_time(lambda: torch.add(a, b, alpha=3.0, out=c))
+    res["hbm_stream_triad"] = {"ms": ms, "bytes": 3 * 4 * n_el, "GBps": 3 * 4 * n_el / ms / 1e6,
+                               "frac_of_8TBps": 3 * 4 * n_el / ms / 1e6 / HBM}
+    try:
+        props = torch.cuda.get_device_properties(0)
+        res["device"] = {"name": props.name, "gcn_arch": getattr(props, "gcnArchName", None), "cus": props.multi_processor_count,
+                         "hbm_GB": props.total_memory / 2 ** 30}
+    except Exception:
+        pass
     print(json.dumps(res, indent=1))
     if args.out:
         json.dump(res, open(args.out, "w"), indent=1)

@@ -32,3 +32,5 @@ if [ "${GS_FULL:-1}" = "1" ]; then
       2> gpurun_out/gs/bench_10m_device.err
   tail -c 800 gpurun_out/gs/bench_10m_device.err; cat gpurun_out/gs/bench_10m_device.json
 fi
+# 4. per-kernel micro-benchmarks incl. the measured HBM copy / triad ceilings of this box
+timeout 400 python scripts/microbench.py --out gpurun_out/gs/microbench.json > gpurun_out/gs/microbench.log 2>&1; tail -c 600 gpurun_out/gs/microbench.log
