@@ -112,6 +112,8 @@ BS_FN void bs_decode(const BsPq &pq, const uint8_t *codes, int64_t n, const int3
     out[t] = v;
 }
 
+struct alignas(16) bs_b16 { uint32_t w[4]; };
+
 // ---- FusedPQ.writeInline (B/graph/disk/feature/FusedPQ.java:146-161): block[node][j] = code of neighbour j, zero padded.
 //      thread t = (node, j, 16-byte chunk c) when M % 16 == 0 (chunk = 16), else (node, j, byte) (chunk = 1).
 BS_FN void bs_fused_gather(const uint8_t *codes, int64_t n_codes, const int32_t *neighbors, int maxDegree, int M, int chunk, int64_t t,
@@ -122,12 +124,15 @@ BS_FN void bs_fused_gather(const uint8_t *codes, int64_t n_codes, const int32_t 
     const int c = (int)(t % per_row);
     const int32_t nb = neighbors[row];
     uint8_t *dst = blocks + row * M + (int64_t)c * chunk;
-    if (nb < 0 || nb >= n_codes) {
-        for (int b = 0; b < chunk; ++b) dst[b] = 0;
+    const bool pad = nb < 0 || nb >= n_codes;
+    const uint8_t *src = pad ? nullptr : codes + (int64_t)nb * M + (int64_t)c * chunk;
+    if (chunk == 16) {  // one 16-byte move per thread (the launcher checked M % 16 == 0 and the base alignment)
+        bs_b16 v = {{0u, 0u, 0u, 0u}};
+        if (!pad) v = *reinterpret_cast<const bs_b16 *>(src);
+        *reinterpret_cast<bs_b16 *>(dst) = v;
         return;
     }
-    const uint8_t *src = codes + (int64_t)nb * M + (int64_t)c * chunk;
-    for (int b = 0; b < chunk; ++b) dst[b] = src[b];
+    for (int b = 0; b < chunk; ++b) dst[b] = pad ? (uint8_t)0 : src[b];
 }
 
 // VectorUtil.dotProduct(a, b) full-vector form (DefaultVectorUtilSupport.java:38-105): the FIRST len%8 elements one by
