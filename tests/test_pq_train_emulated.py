@@ -107,3 +107,28 @@ def test_perfect_reconstruction_like_the_reference_test(emu):
         got = np.empty(256 * 3, np.float32)
         emu.km_emu_train(P(v), C.c_int64(len(v)), 3, 2, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(5), 6, 0, None, P(got), None)
         assert np.array_equal(got, want.codebooks)
+
+
+def _loss(pq, v):
+    codes = pq.encode_all(v)
+    rec = np.stack([pq.decode(c) for c in codes])
+    return float(((v - rec) ** 2).sum())
+
+
+def test_reference_training_properties_hold_for_the_restatement():
+    """The reference's statistical tests of the clusterer, applied to the oracle restatement the device code is checked
+    against: one Lloyd round improves on the k-means++ seeds (testIterativeImprovementOnce, TestProductQuantization.java:
+    91-104) and refining on fresh data from the same distribution lowers the loss on that data (testRefine :107-131)."""
+    rng = np.random.default_rng(1)
+    for trial in range(3):
+        n = 256 + int(rng.integers(0, 2560))
+        D = 2 + int(rng.integers(0, 10))
+        centers = rng.standard_normal((20, D)).astype(np.float32)
+        v = (centers[rng.integers(0, 20, n)] + 0.3 * rng.standard_normal((n, D))).astype(np.float32)
+        seeds, _ = O.pq_train(v, 1, seed=trial, rounds=0)
+        once, _ = O.pq_train(v, 1, seed=trial, rounds=1)
+        assert _loss(once, v) < _loss(seeds, v)
+        half1, half2 = v[: n // 2], v[n // 2:]
+        if len(half1) >= 256:
+            pq1, _ = O.pq_train(half1, 1, seed=trial)
+            assert _loss(pq1.refine(half2, 1, seed=trial), half2) < _loss(pq1, half2)
