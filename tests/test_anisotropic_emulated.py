@@ -65,3 +65,30 @@ def test_anisotropic_encode_matches_oracle(emu, D, M, centroid, threshold, monke
     assert np.array_equal(got, want)
     plain = np.stack([pq.encode(x[i]) for i in range(n)])
     assert (want != plain).any()  # the case is not vacuous: anisotropy changed some codes
+
+
+def test_anisotropic_codes_never_cost_more_than_the_plain_codes():
+    """No reference test pins encodeAnisotropic; the algorithm's own contract does: it starts from the minimum-residual code
+    and only accepts moves that lower pcm * parallel^2 + perpendicular^2 (ProductQuantization.java:308-349), so its code
+    can not cost more than the plain nearest-centroid code under that loss."""
+    rng = np.random.default_rng(5)
+    D, M, T = 64, 8, 0.3
+    v = rng.standard_normal((600, D)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    sizes, offs = O.subvector_sizes_offsets(D, M)
+    cb = np.concatenate([v[rng.choice(600, 256, replace=False), offs[m]: offs[m] + sizes[m]].reshape(-1) for m in range(M)])
+    pq = O.OraclePQ(D, M, cb)
+    pcm = float(O.lib().jvo_parallel_cost_multiplier(C.c_float(T), D))
+
+    def cost(x, code):
+        r = (pq.decode(code) - x).astype(np.float64)
+        par = (r @ x.astype(np.float64)) ** 2 / float(x @ x)
+        return pcm * par + (r @ r - par)
+
+    better = 0
+    for x in v[:200]:
+        plain, aniso = pq.encode(x), pq.encode_anisotropic(x, T)
+        c0, c1 = cost(x, plain), cost(x, aniso)
+        assert c1 <= c0 * (1 + 1e-5) + 1e-9
+        better += c1 < c0 * (1 - 1e-6)
+    assert better > 0
