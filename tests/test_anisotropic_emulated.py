@@ -68,9 +68,10 @@ def test_anisotropic_encode_matches_oracle(emu, D, M, centroid, threshold, monke
 
 
 def test_anisotropic_codes_never_cost_more_than_the_plain_codes():
-    """No reference test pins encodeAnisotropic; the algorithm's own contract does: it starts from the minimum-residual code
-    and only accepts moves that lower pcm * parallel^2 + perpendicular^2 (ProductQuantization.java:308-349), so its code
-    can not cost more than the plain nearest-centroid code under that loss."""
+    """No reference test pins encodeAnisotropic.  Sanity check of the restatement's direction on fixed data: starting from
+    the minimum-residual code and accepting only moves its own cost model likes (ProductQuantization.java:308-349), the
+    result should not be worse than the plain code under the textbook loss pcm * parallel^2 + perpendicular^2 either
+    (the reference's running objective is its own variant of it; this is a plausibility check, not a proof)."""
     rng = np.random.default_rng(5)
     D, M, T = 64, 8, 0.3
     v = rng.standard_normal((600, D)).astype(np.float32)
