@@ -204,3 +204,107 @@ def load_index(ctx, odgi_data, pqvectors_data=None) -> LoadedIndex:
     vectors = VectorSet(ctx, g.vectors) if g.vectors is not None else None
     graph = GraphIndex(ctx, g.id_upper_bound, g.levels, g.entry_node, g.entry_level)
     return LoadedIndex(graph, pq, cv, fused, vectors, g)
+
+
+# ---- writers: the byte formats JVector reads back ---------------------------------------------------------------
+ODGI_MAGIC, FOOTER_MAGIC, V4_MAX_LAYERS = 0xFFFF0D61, 0x4A564244, 32
+FEATURE_ID = {name: i for i, name in enumerate(FEATURE_NAMES)}
+
+
+def _be_i32(values) -> bytes:
+    return np.asarray(values, dtype=np.int64).astype(np.uint32).astype(">u4").tobytes()
+
+
+def write_pqvectors(pq, pq_vectors, version=6) -> bytes:
+    """PQVectors.write (B/quantization/PQVectors.java:155-166): PQ block, count, M, then the codes ordinal-major
+    (chunk boundaries are invisible on disk).  pq: ProductQuantization, pq_vectors: PQVectors (device resident)."""
+    n = pq_vectors.count()
+    codes = pq_vectors.get(0, n) if n else np.zeros((0, pq.M), np.uint8)
+    return pq.write(version) + _be_i32([n, pq.M]) + np.ascontiguousarray(codes, np.uint8).tobytes()
+
+
+def write_odgi(dimension, levels, entry_node, vectors=None, separated=False, fused_blocks=None, pq_block=None,
+               hierarchy_codes=None, version=6) -> bytes:
+    """An OnDiskGraphIndex file (v6 layout; v4 / v5 without FusedPQ) from plain arrays — what OnDiskGraphIndexWriter /
+    OnDiskSequentialGraphIndexWriter emit (header CommonHeader.java:78-112 + Header.java:54-78; L0 records
+    OnDiskSequentialGraphIndexWriter.java:106-153; sparse levels and the v6 hierarchy block AbstractGraphIndexWriter.java:
+    209-282; separated vectors :284-309; footer :174-187).
+      levels          : [(None, nbrs0[N, deg0])] + [(ids_l[size_l], nbrs_l[size_l, deg_l]) ...], rows packed, -1 padded
+      vectors         : N x D float32 -> INLINE_VECTORS, or SEPARATED_VECTORS when `separated`
+      fused_blocks    : N x (deg0 * M) uint8 + pq_block (ProductQuantization.write bytes) -> FUSED_PQ (v6 only)
+      hierarchy_codes : codes of the level-1 nodes in levels[1] order (or of the entry node for a single-layer graph),
+                        required with FUSED_PQ
+    The writer does not reorder or validate the graph; it is the inverse of read_odgi."""
+    if version < 4 or version > 6:
+        raise ValueError("write_odgi supports versions 4..6")
+    nbrs0 = np.ascontiguousarray(levels[0][1], np.int32)
+    N, deg0 = nbrs0.shape
+    fused = fused_blocks is not None
+    if fused and version < 6:
+        raise ValueError("Fused features require version 6 or higher")  # AbstractGraphIndexWriter.java:97-99
+    if version < 5 and len(levels) > 1 and version < 4:
+        raise ValueError("Multilayer graphs must be written with version 4 or higher")
+    feats = []
+    if vectors is not None:
+        feats.append(FEATURE_ID["SEPARATED_VECTORS" if separated else "INLINE_VECTORS"])
+    if fused:
+        feats.append(FEATURE_ID["FUSED_PQ"])
+    feats.sort(key=(lambda f: (f == FEATURE_ID["FUSED_PQ"], f)) if version >= 6 else None)  # AbstractFeature.compareTo
+    layer_info = [(N, deg0)] + [(len(ids), nb.shape[1]) for ids, nb in levels[1:]]
+
+    def header(sep_off):
+        out = _be_i32([ODGI_MAGIC, version, N, dimension, entry_node, deg0, N, len(layer_info)])
+        out += _be_i32([x for li in layer_info for x in li]) + _be_i32([0, 0] * (V4_MAX_LAYERS - len(layer_info)))
+
+        def feature_header(fid):
+            if fid == FEATURE_ID["FUSED_PQ"]:
+                return pq_block
+            if fid == FEATURE_ID["SEPARATED_VECTORS"]:
+                return int(sep_off).to_bytes(8, "big")
+            return b""
+
+        if version >= 6:
+            out += _be_i32([len(feats)])
+            for fid in feats:
+                out += _be_i32([fid]) + feature_header(fid)
+        else:
+            out += _be_i32([sum(1 << f for f in feats)])
+            for fid in sorted(feats):
+                out += feature_header(fid)
+        return out
+
+    # L0 records, vectorised: [ordinal][inline features][degree][neighbours]
+    cols = [np.arange(N, dtype=">u4").view(np.uint8).reshape(N, 4)]
+    for fid in feats:
+        if fid == FEATURE_ID["INLINE_VECTORS"]:
+            cols.append(np.ascontiguousarray(vectors, np.float32).astype(">f4").view(np.uint8).reshape(N, 4 * dimension))
+        elif fid == FEATURE_ID["FUSED_PQ"]:
+            cols.append(np.ascontiguousarray(fused_blocks, np.uint8).reshape(N, -1))
+    degree = (nbrs0 >= 0).sum(axis=1).astype(np.int64)
+    cols.append(degree.astype(np.uint32).astype(">u4").view(np.uint8).reshape(N, 4))
+    cols.append(nbrs0.astype(np.int64).astype(np.uint32).astype(">u4").view(np.uint8).reshape(N, 4 * deg0))
+    out = bytearray(header(0))
+    out += np.concatenate(cols, axis=1).tobytes() if N else b""
+    for ids, nb in levels[1:]:
+        ids = np.asarray(ids, np.int64)
+        nb = np.asarray(nb, np.int64)
+        cnt = (nb >= 0).sum(axis=1)
+        rec = np.concatenate([ids[:, None], cnt[:, None], nb], axis=1)
+        out += rec.astype(np.uint32).astype(">u4").tobytes()
+    if version == 6 and fused:
+        if hierarchy_codes is None:
+            raise ValueError("FUSED_PQ needs the hierarchy source codes")
+        h_ids = np.asarray(levels[1][0] if len(levels) > 1 else [entry_node], np.int64)
+        hc = np.ascontiguousarray(hierarchy_codes, np.uint8).reshape(len(h_ids), -1)
+        out += np.concatenate([h_ids.astype(np.uint32).astype(">u4").view(np.uint8).reshape(len(h_ids), 4), hc], axis=1).tobytes()
+    sep_off = 0
+    if vectors is not None and separated:
+        sep_off = len(out)
+        out += np.ascontiguousarray(vectors, np.float32).astype(">f4").tobytes()
+    if version >= 5:
+        header_off = len(out)
+        out += header(sep_off) + int(header_off).to_bytes(8, "big") + _be_i32([FOOTER_MAGIC])
+    elif separated and vectors is not None:
+        h = header(sep_off)
+        out[:len(h)] = h
+    return bytes(out)

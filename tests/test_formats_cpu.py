@@ -260,3 +260,34 @@ def test_readers_survive_corrupted_input():
         except (ValueError, J.UnsupportedError):
             rejected += 1
     assert parsed > 100 and rejected > 100
+
+
+@pytest.mark.parametrize("version,fused,separated", [(6, True, False), (6, True, True), (6, False, False), (5, False, True),
+                                                     (4, False, False)])
+def test_product_writer_matches_the_writer_restatement_and_round_trips(version, fused, separated):
+    """jvector_amd.formats.write_odgi (vectorised) == oracle/jv_writers.py (the line-by-line restatement of the reference's
+    writers) byte for byte, and read_odgi(write_odgi(x)) == x."""
+    rng = np.random.default_rng(version * 7 + fused)
+    N, D, M, deg = 60, 16, 4, 6
+    pq = _pq(D, M, centroid=True)
+    nb = _graph(N, deg, rng)
+    vec = rng.standard_normal((N, D)).astype(np.float32)
+    codes = rng.integers(0, 256, (N, M), dtype=np.uint8)
+    l1 = {int(n): [int(x) for x in rng.choice([3, 9, 20, 41, 55], 2, replace=False) if x != n][:2] for n in [3, 9, 20, 41, 55]}
+    l2 = {9: [41], 41: [9]}
+    want = W.write_odgi(version, D, nb, deg, entry_node=41, upper_levels=[(3, l1), (2, l2)], vectors=vec, separated=separated,
+                        codes=codes if fused else None, pq_block=pq.serialize(6) if fused else None,
+                        level_file_order={1: [3, 9, 20, 41, 55], 2: [9, 41]})
+    nb0 = _packed(nb, deg)
+    lv1 = (np.array([3, 9, 20, 41, 55], np.int32), _packed([l1[k] for k in (3, 9, 20, 41, 55)], 3))
+    lv2 = (np.array([9, 41], np.int32), _packed([l2[9], l2[41]], 2))
+    blocks = np.where((nb0 >= 0)[:, :, None], codes[np.clip(nb0, 0, N - 1)], 0).astype(np.uint8).reshape(N, deg * M) if fused else None
+    got = F.write_odgi(D, [(None, nb0), lv1, lv2], 41, vectors=vec, separated=separated, fused_blocks=blocks,
+                       pq_block=pq.serialize(6) if fused else None, hierarchy_codes=codes[[3, 9, 20, 41, 55]] if fused else None,
+                       version=version)
+    assert got == want
+    g = F.read_odgi(got)
+    assert np.array_equal(g.levels[0][1], nb0) and np.array_equal(g.vectors, vec)
+    assert np.array_equal(g.levels[1][0], lv1[0]) and np.array_equal(g.levels[1][1], lv1[1])
+    if fused:
+        assert np.array_equal(g.fused_blocks.reshape(N, -1), blocks)

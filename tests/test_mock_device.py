@@ -452,3 +452,27 @@ def test_filtered_search_accept_ords(J, ctx, traversal, monkeypatch):
         assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
     with pytest.raises(ValueError):
         s.search(q, J.VectorSimilarityFunction.COSINE, 10, 40, accept=np.ones(N - 1, bool))
+
+
+def test_train_encode_build_write_load_search_pipeline(J, ctx):
+    """The whole artefact pipeline through the C ABI: train codebooks -> encode -> gather the FusedPQ blocks -> write an
+    OnDiskGraphIndex v6 file and a PQVectors blob -> load both back -> search; every stage equals the oracle's."""
+    import jvector_amd.formats as F
+    from oracle import oracle as O
+    import test_graph_search as T
+    v, lv, entry, entry_level, _, q = T.build_problem(123, N=2000, D=64, M=8, levels=2)
+    pq = J.ProductQuantization.compute(ctx, v, 8, globally_center=True, seed=11)
+    opq, _ = O.pq_train(v, 8, globally_center=True, seed=11)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, len(v))
+    assert np.array_equal(codes, opq.encode_all(v))
+    fused = J.FusedPQ.build(ctx, cv, lv[0][1])
+    blocks, _ = fused.get()
+    odgi = F.write_odgi(64, lv, entry, vectors=v, fused_blocks=blocks, pq_block=pq.write(6), hierarchy_codes=codes[lv[1][0]])
+    pqv = F.write_pqvectors(pq, cv)
+    assert pqv[:len(pq.write(6))] == opq.serialize(6)
+    idx = F.load_index(ctx, odgi, pqv)
+    ids, sc, st = idx.searcher(max_queries=64).search(q, J.VectorSimilarityFunction.COSINE, 10, 50, return_stats=True)
+    wi, ws, wst = O.OracleGraph(len(v), lv, entry, entry_level).search(opq, codes, v, q, O.COSINE, 10, 50, fused=True)
+    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
