@@ -476,3 +476,21 @@ def test_train_encode_build_write_load_search_pipeline(J, ctx):
     ids, sc, st = idx.searcher(max_queries=64).search(q, J.VectorSimilarityFunction.COSINE, 10, 50, return_stats=True)
     wi, ws, wst = O.OracleGraph(len(v), lv, entry, entry_level).search(opq, codes, v, q, O.COSINE, 10, 50, fused=True)
     assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+
+
+def test_standalone_canary_against_the_mock_library(J):
+    """tools/gs_canary.cpp (the first thing scripts/validate_device_traversal.sh runs on hardware) built against the mock
+    library: device traversal == host traversal, exit code 0, for the three similarity functions."""
+    import json
+    import subprocess
+    import build_mock
+    lib = build_mock.build()
+    exe = os.path.join(ROOT, "build", "mock", "gs_canary_mock")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "tools", "gs_canary.cpp"), "-o", exe,
+                           "-L" + os.path.dirname(lib), "-l:" + os.path.basename(lib), "-Wl,-rpath," + os.path.dirname(lib)])
+    env = dict(os.environ, JVECTOR_HIP_HOST_THREADS="1")
+    for vsf in (0, 1, 2):
+        out = subprocess.run([exe, "2500", "16", "32", "50", "1", str(vsf)], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["identical"] is True and line["avg_expanded"] >= 50
