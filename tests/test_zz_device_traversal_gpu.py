@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("JVECTOR_TEST_DEVICE_TRAVERSAL") != "1",
+              pytest.mark.skipif("1" not in (os.environ.get("JVECTOR_TEST_DEVICE_TRAVERSAL"), os.environ.get("JVECTOR_TEST_UNVERIFIED")),
                                  reason="device traversal not yet validated on hardware; set JVECTOR_TEST_DEVICE_TRAVERSAL=1")]
 
 import jvector_amd as J

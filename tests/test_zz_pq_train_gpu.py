@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("JVECTOR_TEST_PQ_TRAIN") != "1",
+              pytest.mark.skipif("1" not in (os.environ.get("JVECTOR_TEST_PQ_TRAIN"), os.environ.get("JVECTOR_TEST_UNVERIFIED")),
                                  reason="PQ training not yet validated on hardware; set JVECTOR_TEST_PQ_TRAIN=1")]
 
 import jvector_amd as J
