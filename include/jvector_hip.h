@@ -119,6 +119,13 @@ JV_API float jv_hip_pq_anisotropic_threshold(const jv_pq *pq);
  * reference's, so the result is a deterministic function of (vectors, seed).  Both return a NEW jv_pq. */
 JV_API int jv_hip_pq_train(jv_ctx *ctx, const float *vectors, int64_t n, int D, int M, int k, int globally_center,
                            uint64_t seed, jv_pq **out);
+/* ProductQuantization.compute(ravv, M, k, globallyCenter, anisotropicThreshold): after the unweighted rounds, 6 rounds of
+ * anisotropic k-means (KMeansPlusPlusClusterer.java:274-320,380-432: weighted reassignment; centroids from the per-cluster
+ * normalised outer-product sums through an explicit Gauss-Jordan inverse), sub-vectors of 2..16 dimensions, unit-length
+ * input.  The result carries the threshold (its encode calls are anisotropic).  jv_hip_pq_refine on such a PQ runs
+ * anisotropic rounds only, as the reference does (:212-214). */
+JV_API int jv_hip_pq_train_anisotropic(jv_ctx *ctx, const float *vectors, int64_t n, int D, int M, int k, int globally_center,
+                                       float anisotropic_threshold, uint64_t seed, jv_pq **out);
 JV_API int jv_hip_pq_refine(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t n, int lloyds_rounds, uint64_t seed,
                             jv_pq **out);
 /* ProductQuantization.write(out, version) (ProductQuantization.java:560-599; big-endian, versions 0..6): *len_out = bytes

@@ -49,6 +49,7 @@ SIGNATURES = {
     "jv_hip_pq_set_anisotropic_threshold": (_i, [_p, C.c_float]),
     "jv_hip_pq_anisotropic_threshold": (C.c_float, [_p]),
     "jv_hip_pq_train": (_i, [_p, _p, _i64, _i, _i, _i, _i, C.c_uint64, C.POINTER(_p)]),
+    "jv_hip_pq_train_anisotropic": (_i, [_p, _p, _i64, _i, _i, _i, _i, C.c_float, C.c_uint64, C.POINTER(_p)]),
     "jv_hip_pq_refine": (_i, [_p, _p, _p, _i64, _i, C.c_uint64, C.POINTER(_p)]),
     "jv_hip_pq_write": (_i, [_p, _p, _i, _p, _sz, C.POINTER(_sz)]),
     "jv_hip_pq_destroy": (_i, [_p]),

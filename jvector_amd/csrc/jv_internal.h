@@ -229,6 +229,8 @@ int launch_km_assign(hipStream_t s, const KmParams &p);
 int launch_km_replay(hipStream_t s, const KmParams &p, int first_pass);
 int launch_km_update_centroids(hipStream_t s, const KmParams &p);
 int launch_km_finish_round(hipStream_t s, const KmParams &p);
+int launch_km_aniso_round(hipStream_t s, const KmParams &p);
+int launch_km_reactivate(hipStream_t s, const KmParams &p);
 // build-time scoring (k_build_score.hip)
 int launch_pair_table(hipStream_t s, const jv_pq *pq, int vsf, float *d_out);
 int launch_pair_scores(hipStream_t s, const float *d_tri, int vsf, const jv_codes *codes, const int32_t *d_node1, int P,

@@ -47,6 +47,31 @@ __global__ __launch_bounds__(64) void km_finish_round_kernel(KmParams p)
     if (m < p.M) km_finish_round(p, m);
 }
 __global__ __launch_bounds__(64) void km_pp_init_kernel(KmParams p) { km_pp_init(p, (int)blockIdx.x); }
+__global__ __launch_bounds__(64) void km_centroids_aniso_kernel(KmParams p, int64_t total)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) km_centroids_aniso(p, t);
+}
+__global__ __launch_bounds__(256) void km_cnorm_kernel(KmParams p, int64_t total)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) km_cnorm(p, t);
+}
+__global__ __launch_bounds__(256) void km_assign_aniso_kernel(KmParams p, int64_t total)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) km_assign_aniso(p, t);
+}
+__global__ __launch_bounds__(64) void km_count_changed_kernel(KmParams p)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < p.M) km_count_changed(p, m);
+}
+__global__ __launch_bounds__(64) void km_reactivate_kernel(KmParams p)
+{
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < p.M) km_reactivate(p, m);
+}
 
 static dim3 grid_for(int64_t total, int block) { return dim3((unsigned)((total + block - 1) / block)); }
 
@@ -88,6 +113,24 @@ int launch_km_update_centroids(hipStream_t s, const KmParams &p)
     const int64_t total = (int64_t)p.M * p.k;
     hipLaunchKernelGGL(km_centroids_kernel, grid_for(total, 256), dim3(256), 0, s, p, total);
     hipLaunchKernelGGL(km_fill_empties_kernel, grid_for(p.M, 64), dim3(64), 0, s, p);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+// one anisotropic round: centroids (+ empty-cluster re-seeding) -> centroid norms -> weighted reassignment -> changed counts
+int launch_km_aniso_round(hipStream_t s, const KmParams &p)
+{
+    const int64_t mk = (int64_t)p.M * p.k, nm = p.n * p.M;
+    hipLaunchKernelGGL(km_centroids_aniso_kernel, grid_for(mk, 64), dim3(64), 0, s, p, mk);
+    hipLaunchKernelGGL(km_fill_empties_kernel, grid_for(p.M, 64), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(km_cnorm_kernel, grid_for(mk, 256), dim3(256), 0, s, p, mk);
+    hipLaunchKernelGGL(km_assign_aniso_kernel, grid_for(nm, 256), dim3(256), 0, s, p, nm);
+    hipLaunchKernelGGL(km_count_changed_kernel, grid_for(p.M, 64), dim3(64), 0, s, p);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+int launch_km_reactivate(hipStream_t s, const KmParams &p)
+{
+    hipLaunchKernelGGL(km_reactivate_kernel, grid_for(p.M, 64), dim3(64), 0, s, p);
     JV_HIP_CHECK(hipGetLastError());
     return JV_OK;
 }

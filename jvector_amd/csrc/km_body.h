@@ -36,6 +36,8 @@ struct KmParams {
     int32_t *changed;          // [M]
     uint64_t *rng;             // [M] splitmix64 state
     float *dist;               // [M][n] k-means++ distances
+    float *cnorm;              // [M][k] centroid norms (anisotropic rounds)
+    const float *pcm;          // [M] parallel cost multiplier per subspace (anisotropic rounds), computed on the host
     int64_t n;
     int32_t D, M, k;
 };
@@ -71,7 +73,10 @@ KM_FN void km_center(const float *X, const float *centroid, int D, int64_t t, fl
 KM_FN void km_assign(const KmParams &p, int64_t t)
 {
     const int m = (int)(t % p.M);
-    if (!p.active[m]) return;
+    if (!p.active[m]) {  // a converged subspace keeps its assignments current in both buffers (they alternate every round)
+        p.assign_new[t] = p.assign_old[t];
+        return;
+    }
     const int64_t i = t / p.M;
     const int len = p.sizes[m];
     const float *x = p.X + i * p.D + p.offsets[m];
@@ -158,6 +163,153 @@ KM_FN void km_finish_round(const KmParams &p, int64_t m)
 {
     if (p.active[m] && (double)p.changed[m] <= 0.01 * (double)p.n) p.active[m] = 0;
 }
+
+// ---- anisotropic rounds (clusterOnceAnisotropic :163-166), sub-vectors of at most KM_ANISO_MAX_LEN dimensions ----
+constexpr int KM_ANISO_MAX_LEN = 16;
+
+// VectorUtil.dotProduct(a, b) full-vector form
+KM_FN float km_full_dot(const float *a, const float *b, int n)
+{
+    float res = 0.0f;
+    int i = 0;
+    for (; i < n % 8; ++i) res += b[i] * a[i];
+    for (; i + 7 < n; i += 8) {
+        const float *x = a + i, *y = b + i;
+        float t = y[0] * x[0] + y[1] * x[1];
+        t = t + y[2] * x[2];
+        t = t + y[3] * x[3];
+        t = t + y[4] * x[4];
+        t = t + y[5] * x[5];
+        t = t + y[6] * x[6];
+        t = t + y[7] * x[7];
+        res += t;
+    }
+    return res;
+}
+
+// updateCentroidsAnisotropic :380-432 for cluster c of subspace m (thread t = m*k + c): mean and normalised outer-product
+// sum over the cluster's points in point order, (1 - ocm)/|L| scaling, + ocm on the diagonal, Matrix.invert
+// (B/vector/Matrix.java:70-118: Gauss-Jordan, partial pivoting), inverse x mean.  Writes the point count to denoms[t]
+// (0 = empty: km_fill_empties re-seeds it).
+KM_FN void km_centroids_aniso(const KmParams &p, int64_t t)
+{
+    const int m = (int)(t / p.k), c = (int)(t % p.k);
+    if (m >= p.M || !p.active[m]) return;
+    const int len = p.sizes[m], off = p.offsets[m];
+    const float pcm = p.pcm[m], ocm = 1.0f / pcm;
+    float mean[KM_ANISO_MAX_LEN], outer[KM_ANISO_MAX_LEN * KM_ANISO_MAX_LEN], aug[KM_ANISO_MAX_LEN * 2 * KM_ANISO_MAX_LEN];
+    for (int d = 0; d < len; ++d) mean[d] = 0.0f;
+    for (int d = 0; d < len * len; ++d) outer[d] = 0.0f;
+    int32_t cnt = 0;
+    for (int64_t i = 0; i < p.n; ++i) {
+        if (p.assign_old[i * p.M + m] != c) continue;  // the assignments of the previous round
+        const float *x = p.X + i * p.D + off;
+        ++cnt;
+        for (int d = 0; d < len; ++d) mean[d] = mean[d] + x[d];
+        const float denom = km_full_dot(x, x, len);
+        if (denom > 0) {
+            const float invd = 1.0f / denom;
+            for (int r = 0; r < len; ++r)
+                for (int d = 0; d < len; ++d) outer[r * len + d] = outer[r * len + d] + (x[d] * x[r]) * invd;
+        }
+    }
+    p.denoms[t] = cnt;
+    if (cnt == 0) return;
+    const float sc = (1 - ocm) / (float)cnt, invc = 1.0f / (float)cnt;
+    for (int d = 0; d < len * len; ++d) outer[d] = outer[d] * sc;
+    for (int d = 0; d < len; ++d) mean[d] = mean[d] * invc;
+    for (int d = 0; d < len; ++d) outer[d * len + d] = outer[d * len + d] + ocm;
+    const int W = 2 * len;
+    for (int i = 0; i < len; ++i)
+        for (int j = 0; j < len; ++j) {
+            aug[i * W + j] = outer[i * len + j];
+            aug[i * W + j + len] = (i == j) ? 1.0f : 0.0f;
+        }
+    for (int i = 0; i < len; ++i) {
+        int maxRow = i;
+        for (int r = i + 1; r < len; ++r) {
+            const float a = aug[r * W + i], b = aug[maxRow * W + i];
+            if ((a < 0 ? -a : a) > (b < 0 ? -b : b)) maxRow = r;
+        }
+        if (maxRow != i)
+            for (int j = 0; j < W; ++j) {
+                const float tmp = aug[i * W + j];
+                aug[i * W + j] = aug[maxRow * W + j];
+                aug[maxRow * W + j] = tmp;
+            }
+        const float s = 1 / aug[i * W + i];
+        for (int j = 0; j < W; ++j) aug[i * W + j] = aug[i * W + j] * s;
+        for (int r = 0; r < len; ++r) {
+            if (r == i) continue;
+            const float factor = aug[r * W + i];
+            for (int j = 0; j < W; ++j) aug[r * W + j] = aug[r * W + j] + (-factor * aug[i * W + j]);
+        }
+    }
+    float *cc = p.C + p.cb_offsets[m] + (int64_t)c * len;
+    for (int r = 0; r < len; ++r) {  // Matrix.multiply: dotProduct(inverse row, mean), full-vector form
+        float row[KM_ANISO_MAX_LEN];
+        for (int j = 0; j < len; ++j) row[j] = aug[r * W + j + len];
+        cc[r] = km_full_dot(row, mean, len);
+    }
+}
+
+// cNormSquared of updateAssignedPointsAnisotropic :279-285 — thread t = m*k + c
+KM_FN void km_cnorm(const KmParams &p, int64_t t)
+{
+    const int m = (int)(t / p.k), c = (int)(t % p.k);
+    if (m >= p.M || !p.active[m]) return;
+    const int len = p.sizes[m];
+    const float *cc = p.C + p.cb_offsets[m] + (int64_t)c * len;
+    float s = 0.0f;
+    for (int j = 0; j < len; ++j) s += cc[j] * cc[j];
+    p.cnorm[t] = s;
+}
+
+// updateAssignedPointsAnisotropic :274-306 + weightedDistance :311-320 — thread t = i*M + m
+KM_FN void km_assign_aniso(const KmParams &p, int64_t t)
+{
+    const int m = (int)(t % p.M);
+    if (!p.active[m]) {
+        p.assign_new[t] = p.assign_old[t];
+        return;
+    }
+    const int64_t i = t / p.M;
+    const int len = p.sizes[m];
+    const float *x = p.X + i * p.D + p.offsets[m];
+    const float *C = p.C + p.cb_offsets[m];
+    const float pcm = p.pcm[m];
+    const float xNorm = km_full_dot(x, x, len);
+    int index = p.assign_old[t];
+    float minDist = KM_FLT_MAX;
+    for (int j = 0; j < p.k; ++j) {
+        const float *cc = C + (int64_t)j * len;
+        float cDotX = 0.0f;
+        for (int d = 0; d < len; ++d) cDotX += cc[d] * x[d];
+        const float pes = cDotX - xNorm;
+        const float two = 2 * cDotX;
+        const float rsn = p.cnorm[m * p.k + j] - two + xNorm;
+        const float parErr = pes * pes;
+        const float perp = rsn - parErr;
+        const float dist = pcm * parErr + perp;
+        if (dist < minDist) {
+            minDist = dist;
+            index = j;
+        }
+    }
+    p.assign_new[t] = (uint8_t)index;
+}
+
+// changedCount of an anisotropic round — thread m
+KM_FN void km_count_changed(const KmParams &p, int64_t m)
+{
+    if (!p.active[m]) return;
+    int32_t changed = 0;
+    for (int64_t i = 0; i < p.n; ++i) changed += p.assign_new[i * p.M + m] != p.assign_old[i * p.M + m];
+    p.changed[m] = changed;
+}
+
+// every subspace iterates again when the anisotropic phase starts — thread m
+KM_FN void km_reactivate(const KmParams &p, int64_t m) { p.active[m] = 1; }
 
 #ifdef GS_FN
 // VectorUtil.squareL2Distance(a, b) full-vector form: blocks of eight summed left to right, then the tail

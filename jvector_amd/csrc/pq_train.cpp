@@ -24,14 +24,24 @@ struct DevBuf {
 };
 
 // shared by train (init = k-means++) and refine (init = the given codebooks)
+// KMeansPlusPlusClusterer.computeParallelCostMultiplier :116-124
+float parallel_cost_multiplier(float threshold, int dimensions)
+{
+    const double t = (double)threshold;
+    const double parallelCost = t * t;
+    const double perpendicularCost = (1 - parallelCost) / (dimensions - 1);
+    return (float)std::max(1.0, parallelCost / perpendicularCost);
+}
+
 int run_training(jv_ctx *ctx, jv_pq *work /* layout + d_codebooks in/out */, const float *vectors, int64_t n, const float *d_centroid,
-                 bool compute_centroid, float *d_centroid_out, bool seed_with_kmeans_pp, int rounds, uint64_t seed)
+                 bool compute_centroid, float *d_centroid_out, bool seed_with_kmeans_pp, int rounds, uint64_t seed,
+                 int aniso_rounds = 0, float aniso_threshold = -1.0f)
 {
     const int D = work->D, M = work->M, k = work->k;
     hipStream_t s = ctx->stream;
     const void *d_X = nullptr;
     JV_TRY(stage_in(ctx, vectors, sizeof(float) * (size_t)n * D, ctx->h_in, ctx->d_in, &d_X));
-    DevBuf Xc, A, B, nums, denoms, active, changed, rng, dist;
+    DevBuf Xc, A, B, nums, denoms, active, changed, rng, dist, cnorm, pcm;
     JV_TRY(Xc.alloc(sizeof(float) * (size_t)n * D));
     JV_TRY(A.alloc((size_t)n * M));
     JV_TRY(B.alloc((size_t)n * M));
@@ -41,6 +51,13 @@ int run_training(jv_ctx *ctx, jv_pq *work /* layout + d_codebooks in/out */, con
     JV_TRY(changed.alloc(sizeof(int32_t) * (size_t)M));
     JV_TRY(rng.alloc(sizeof(uint64_t) * (size_t)M));
     if (seed_with_kmeans_pp) JV_TRY(dist.alloc(sizeof(float) * (size_t)M * n));
+    std::vector<float> h_pcm((size_t)M, 1.0f);
+    if (aniso_rounds > 0) {
+        JV_TRY(cnorm.alloc(sizeof(float) * (size_t)M * k));
+        JV_TRY(pcm.alloc(sizeof(float) * (size_t)M));
+        for (int m = 0; m < M; ++m) h_pcm[m] = parallel_cost_multiplier(aniso_threshold, work->sizes[m]);
+        JV_HIP_CHECK(hipMemcpyAsync(pcm.p, h_pcm.data(), sizeof(float) * (size_t)M, hipMemcpyHostToDevice, s));
+    }
     if (compute_centroid) {
         JV_TRY(launch_km_centroid(s, (const float *)d_X, n, D, d_centroid_out));
         d_centroid = d_centroid_out;
@@ -54,7 +71,7 @@ int run_training(jv_ctx *ctx, jv_pq *work /* layout + d_codebooks in/out */, con
     JV_HIP_CHECK(hipStreamSynchronize(s));  // the two host vectors above go out of scope with this frame: drain now
     KmParams p{(const float *)Xc.p, work->d_codebooks, work->d_cb_offsets, work->d_sizes, work->d_offsets, (uint8_t *)A.p,
                (uint8_t *)B.p, (float *)nums.p, (int32_t *)denoms.p, (int32_t *)active.p, (int32_t *)changed.p, (uint64_t *)rng.p,
-               (float *)dist.p, n, D, M, k};
+               (float *)dist.p, (float *)cnorm.p, (const float *)pcm.p, n, D, M, k};
     if (seed_with_kmeans_pp) JV_TRY(launch_km_pp_init(s, p));
     // KMeansPlusPlusClusterer constructor: initializeAssignedPoints
     JV_TRY(launch_km_assign(s, p));
@@ -64,6 +81,12 @@ int run_training(jv_ctx *ctx, jv_pq *work /* layout + d_codebooks in/out */, con
         JV_TRY(launch_km_update_centroids(s, p));
         JV_TRY(launch_km_assign(s, p));
         JV_TRY(launch_km_replay(s, p, 0));
+        JV_TRY(launch_km_finish_round(s, p));
+    }
+    if (aniso_rounds > 0) JV_TRY(launch_km_reactivate(s, p));  // cluster() :141-147: a second loop with its own early stop
+    for (int it = 0; it < aniso_rounds; ++it) {
+        std::swap(p.assign_old, p.assign_new);
+        JV_TRY(launch_km_aniso_round(s, p));
         JV_TRY(launch_km_finish_round(s, p));
     }
     JV_HIP_CHECK(hipStreamSynchronize(s));
@@ -95,7 +118,19 @@ extern "C" {
 
 int jv_hip_pq_train(jv_ctx *ctx, const float *vectors, int64_t n, int D, int M, int k, int globally_center, uint64_t seed, jv_pq **out)
 {
+    return jv_hip_pq_train_anisotropic(ctx, vectors, n, D, M, k, globally_center, -1.0f, seed, out);
+}
+
+int jv_hip_pq_train_anisotropic(jv_ctx *ctx, const float *vectors, int64_t n, int D, int M, int k, int globally_center,
+                                float anisotropic_threshold, uint64_t seed, jv_pq **out)
+{
     clear_error();
+    const float T = anisotropic_threshold;
+    JV_REQUIRE(T == T && T >= -1.0f && T < 1.0f, "Valid range for anisotropic threshold T is -1.0 <= t < 1.0");
+    const bool aniso = T > -1.0f;
+    JV_REQUIRE(!aniso || (D + M - 1) / M <= KM_ANISO_MAX_LEN, "pq_train: anisotropic k-means supports sub-vectors of at most %d dimensions",
+               KM_ANISO_MAX_LEN);
+    JV_REQUIRE(!aniso || D / M >= 2, "pq_train: anisotropic k-means needs sub-vectors of at least 2 dimensions");
     JV_REQUIRE(ctx && vectors && out, "pq_train: NULL argument");
     *out = nullptr;
     JV_REQUIRE(D > 0 && M > 0 && M <= D, "Number of subspaces must be less than or equal to the vector dimension");
@@ -109,8 +144,9 @@ int jv_hip_pq_train(jv_ctx *ctx, const float *vectors, int64_t n, int D, int M, 
     JV_TRY(jv_hip_pq_create(ctx, D, M, k, nullptr, zeros.data(), nullptr, &work.pq));
     DevBuf cen;
     if (globally_center) JV_TRY(cen.alloc(sizeof(float) * (size_t)D));
-    JV_TRY(run_training(ctx, work.pq, vectors, n, nullptr, globally_center != 0, (float *)cen.p, true, 6 /* K_MEANS_ITERATIONS */, seed));
-    return finish(ctx, work.pq, globally_center ? (const float *)cen.p : nullptr, -1.0f, out);
+    JV_TRY(run_training(ctx, work.pq, vectors, n, nullptr, globally_center != 0, (float *)cen.p, true, 6 /* K_MEANS_ITERATIONS */, seed,
+                        aniso ? 6 : 0, T));
+    return finish(ctx, work.pq, globally_center ? (const float *)cen.p : nullptr, T, out);
 }
 
 int jv_hip_pq_refine(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t n, int lloyds_rounds, uint64_t seed, jv_pq **out)
@@ -121,17 +157,17 @@ int jv_hip_pq_refine(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t
     JV_REQUIRE(lloyds_rounds >= 0, "lloydsRounds must be non-negative");  // ProductQuantization.refine :205-207
     JV_REQUIRE(n > 0, "pq_refine: no training vectors");
     JV_REQUIRE(pq->max_size <= 64, "pq_refine: sub-vectors longer than 64 dimensions are not supported");
-    if (pq->aniso > -1.0f) {
-        set_error("pq_refine: anisotropic k-means refinement is not built");
-        return JV_ERR_UNSUPPORTED;
-    }
+    const bool aniso = pq->aniso > -1.0f;  // refine :212-214: cluster(aniso ? 0 : rounds, aniso ? rounds : 0)
+    JV_REQUIRE(!aniso || (pq->max_size <= KM_ANISO_MAX_LEN && pq->D / pq->M >= 2),
+               "pq_refine: anisotropic k-means supports sub-vectors of 2..%d dimensions", KM_ANISO_MAX_LEN);
     JV_TRY(use_device(ctx->device));
     PqGuard work;
     std::vector<float> cb((size_t)pq->k * pq->D);
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     JV_HIP_CHECK(hipMemcpy(cb.data(), pq->d_codebooks, sizeof(float) * cb.size(), hipMemcpyDeviceToHost));
     JV_TRY(jv_hip_pq_create(ctx, pq->D, pq->M, pq->k, pq->sizes.data(), cb.data(), nullptr, &work.pq));
-    JV_TRY(run_training(ctx, work.pq, vectors, n, pq->d_centroid, false, nullptr, false, lloyds_rounds, seed));
+    JV_TRY(run_training(ctx, work.pq, vectors, n, pq->d_centroid, false, nullptr, false, aniso ? 0 : lloyds_rounds, seed,
+                        aniso ? lloyds_rounds : 0, pq->aniso));
     return finish(ctx, work.pq, pq->d_centroid, pq->aniso, out);
 }
 

@@ -178,14 +178,14 @@ class ProductQuantization:
         return pq
 
     @classmethod
-    def compute(cls, ctx, vectors, M, cluster_count=256, globally_center=False, seed=1):
-        """ProductQuantization.compute (:109-139), unweighted: k-means++ + 6 Lloyd rounds per subspace on `vectors`
-        (the training sample, host or device [n, D]).  Deterministic in (vectors, seed)."""
+    def compute(cls, ctx, vectors, M, cluster_count=256, globally_center=False, seed=1, anisotropic_threshold=-1.0):
+        """ProductQuantization.compute (:109-139): k-means++ + 6 Lloyd rounds per subspace on `vectors` (the training sample,
+        host or device [n, D]), plus 6 anisotropic rounds when anisotropic_threshold > -1.  Deterministic in (vectors, seed)."""
         n, D = int(vectors.shape[0]), int(vectors.shape[1])
         v_p, keep = _ptr(vectors, np.float32)
         h = C.c_void_p()
-        check(ctx._lib.jv_hip_pq_train(ctx._h, v_p, n, D, int(M), int(cluster_count), int(bool(globally_center)), int(seed),
-                                       C.byref(h)))
+        check(ctx._lib.jv_hip_pq_train_anisotropic(ctx._h, v_p, n, D, int(M), int(cluster_count), int(bool(globally_center)),
+                                                   C.c_float(anisotropic_threshold), int(seed), C.byref(h)))
         return cls(ctx, h)
 
     def refine(self, vectors, lloyds_rounds=1, seed=1):

@@ -498,7 +498,103 @@ static int km_nearest(const float *p, const float *C, int len, int k)
 }
 
 /* constructor (initializeAssignedPoints) + cluster(rounds, 0); returns the rounds actually run */
+/* Matrix.invert (B/vector/Matrix.java:70-118): Gauss-Jordan with partial pivoting on an N x 2N augmented matrix, float */
+static void km_invert(const float *A, int N, float *inv /* N*N */, float *aug /* N*2N scratch */)
+{
+    const int W = 2 * N;
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) { aug[i * W + j] = A[i * N + j]; aug[i * W + j + N] = (i == j) ? 1.0f : 0.0f; }
+    for (int i = 0; i < N; i++) {
+        int maxRow = i;
+        for (int r = i + 1; r < N; r++)
+            if (fabsf(aug[r * W + i]) > fabsf(aug[maxRow * W + i])) maxRow = r;
+        if (maxRow != i)
+            for (int j = 0; j < W; j++) { float t = aug[i * W + j]; aug[i * W + j] = aug[maxRow * W + j]; aug[maxRow * W + j] = t; }
+        const float s = 1 / aug[i * W + i];
+        for (int j = 0; j < W; j++) aug[i * W + j] = aug[i * W + j] * s;
+        for (int r = 0; r < N; r++) {
+            if (r == i) continue;
+            const float factor = aug[r * W + i];
+            for (int j = 0; j < W; j++) aug[r * W + j] = aug[r * W + j] + (-factor * aug[i * W + j]);
+        }
+    }
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) inv[i * N + j] = aug[i * W + j + N];
+}
+
+/* clusterOnceAnisotropic (KMeansPlusPlusClusterer.java:163-166): updateCentroidsAnisotropic :380-432 then
+ * updateAssignedPointsAnisotropic :274-306 with weightedDistance :311-320.  Returns the number of points that moved. */
+static int64_t km_cluster_once_anisotropic(const float *X, int64_t n, int stride, int off, int len, int k, float *C, int *assign,
+                                           float threshold, uint64_t *rng)
+{
+    const float pcm = jvo_parallel_cost_multiplier(threshold, len);
+    const float ocm = 1.0f / pcm;
+    float *mean = (float *)malloc(sizeof(float) * (size_t)len);
+    float *outer = (float *)malloc(sizeof(float) * (size_t)len * len);
+    float *inv = (float *)malloc(sizeof(float) * (size_t)len * len);
+    float *aug = (float *)malloc(sizeof(float) * (size_t)len * 2 * len);
+    for (int c = 0; c < k; c++) {
+        int64_t cnt = 0;
+        for (int d = 0; d < len; d++) mean[d] = 0.0f;
+        for (int d = 0; d < len * len; d++) outer[d] = 0.0f;
+        for (int64_t j = 0; j < n; j++) {  /* pointsByCluster lists are in point order */
+            if (assign[j] != c) continue;
+            const float *p = PT(j);
+            cnt++;
+            for (int d = 0; d < len; d++) mean[d] = mean[d] + p[d];
+            const float denom = jvo_dot(p, p, len);
+            if (denom > 0) {
+                const float invd = 1.0f / denom;
+                for (int r = 0; r < len; r++)
+                    for (int d = 0; d < len; d++) outer[r * len + d] = outer[r * len + d] + (p[d] * p[r]) * invd;
+            }
+        }
+        if (cnt == 0) {
+            memcpy(C + (size_t)c * len, PT(rng_int(rng, n)), sizeof(float) * (size_t)len);
+            continue;
+        }
+        const float sc = (1 - ocm) / (float)cnt, invc = 1.0f / (float)cnt;
+        for (int d = 0; d < len * len; d++) outer[d] = outer[d] * sc;
+        for (int d = 0; d < len; d++) mean[d] = mean[d] * invc;
+        for (int d = 0; d < len; d++) outer[d * len + d] = outer[d * len + d] + ocm;
+        km_invert(outer, len, inv, aug);
+        for (int r = 0; r < len; r++) C[(size_t)c * len + r] = jvo_dot(inv + r * len, mean, len);  /* Matrix.multiply */
+    }
+    float *cnorm = (float *)malloc(sizeof(float) * (size_t)k);
+    for (int c = 0; c < k; c++) cnorm[c] = jvo_dot_off(C, c * len, C, c * len, len);
+    int64_t changed = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const float *x = PT(i);
+        const float xNorm = jvo_dot(x, x, len);
+        int index = assign[i];
+        float minDist = 3.4028234663852886e38f;
+        for (int j = 0; j < k; j++) {
+            const float cDotX = jvo_dot_off(C, j * len, x, 0, len);
+            const float pes = cDotX - xNorm;
+            const float two = 2 * cDotX;
+            const float rsn = cnorm[j] - two + xNorm;
+            const float parErr = pes * pes;
+            const float perp = rsn - parErr;
+            const float dist = pcm * parErr + perp;
+            if (dist < minDist) { minDist = dist; index = j; }
+        }
+        if (index != assign[i]) { changed++; assign[i] = index; }
+    }
+    free(mean); free(outer); free(inv); free(aug); free(cnorm);
+    return changed;
+}
+
+/* aniso_rounds > 0 with threshold > -1: cluster(rounds, aniso_rounds) :131-150 */
+int jvo_kmeans_lloyd_aniso(const float *X, int64_t n, int stride, int off, int len, int k, float *C, int rounds, int aniso_rounds,
+                           float threshold, uint64_t *rng);
+
 int jvo_kmeans_lloyd(const float *X, int64_t n, int stride, int off, int len, int k, float *C, int rounds, uint64_t *rng)
+{
+    return jvo_kmeans_lloyd_aniso(X, n, stride, off, len, k, C, rounds, 0, -1.0f, rng);
+}
+
+int jvo_kmeans_lloyd_aniso(const float *X, int64_t n, int stride, int off, int len, int k, float *C, int rounds, int aniso_rounds,
+                           float threshold, uint64_t *rng)
 {
     float *nums = (float *)calloc((size_t)k * len, sizeof(float));
     int *denoms = (int *)calloc((size_t)k, sizeof(int));
@@ -532,6 +628,10 @@ int jvo_kmeans_lloyd(const float *X, int64_t n, int stride, int off, int len, in
         }
         if ((double)changed <= 0.01 * (double)n) { it++; break; }
     }
+    for (int a = 0; a < aniso_rounds; a++) {  /* optionally refine with anisotropic clustering */
+        int64_t changed = km_cluster_once_anisotropic(X, n, stride, off, len, k, C, assign, threshold, rng);
+        if ((double)changed <= 0.01 * (double)n) break;
+    }
     free(nums); free(denoms); free(assign);
     return it;
 }
@@ -551,6 +651,13 @@ void jvo_centroid_of(const float *X, int64_t n, int D, float *out)
 void jvo_pq_train(const float *X, int64_t n, int D, int M, int k, int globallyCenter, uint64_t seed, int rounds,
                   float *codebooks, float *centroid, int *rounds_run /* [M] or NULL */)
 {
+    jvo_pq_train_aniso(X, n, D, M, k, globallyCenter, -1.0f, seed, rounds, codebooks, centroid, rounds_run);
+}
+
+/* ProductQuantization.compute with an anisotropic threshold: createCodebooks runs cluster(6, threshold > -1 ? 6 : 0) :487-495 */
+void jvo_pq_train_aniso(const float *X, int64_t n, int D, int M, int k, int globallyCenter, float threshold, uint64_t seed, int rounds,
+                        float *codebooks, float *centroid, int *rounds_run /* [M] or NULL */)
+{
     int *sizes = (int *)malloc(sizeof(int) * (size_t)M), *offs = (int *)malloc(sizeof(int) * (size_t)M);
     jvo_subvector_sizes_offsets(D, M, sizes, offs);
     float *Xc = (float *)malloc(sizeof(float) * (size_t)n * D);
@@ -562,7 +669,8 @@ void jvo_pq_train(const float *X, int64_t n, int D, int M, int k, int globallyCe
     for (int m = 0; m < M; m++) {
         uint64_t rng = jvo_kmeans_stream(seed, m);
         jvo_kmeans_pp_init(Xc, n, D, offs[m], sizes[m], k, &rng, codebooks + cboff);
-        int r = jvo_kmeans_lloyd(Xc, n, D, offs[m], sizes[m], k, codebooks + cboff, rounds, &rng);
+        int r = jvo_kmeans_lloyd_aniso(Xc, n, D, offs[m], sizes[m], k, codebooks + cboff, rounds, threshold > -1.0f ? rounds : 0,
+                                       threshold, &rng);
         if (rounds_run) rounds_run[m] = r;
         cboff += (size_t)k * sizes[m];
     }
@@ -571,6 +679,12 @@ void jvo_pq_train(const float *X, int64_t n, int D, int M, int k, int globallyCe
 
 /* ProductQuantization.refine (unweighted): starts from pq's codebooks, `rounds` Lloyd rounds on new data */
 void jvo_pq_refine(const jvo_pq *pq, const float *X, int64_t n, int rounds, uint64_t seed, float *codebooks)
+{
+    jvo_pq_refine_aniso(pq, -1.0f, X, n, rounds, seed, codebooks);
+}
+
+/* ProductQuantization.refine :194-221: cluster(threshold == UNWEIGHTED ? rounds : 0, threshold == UNWEIGHTED ? 0 : rounds) */
+void jvo_pq_refine_aniso(const jvo_pq *pq, float threshold, const float *X, int64_t n, int rounds, uint64_t seed, float *codebooks)
 {
     const int D = pq->D;
     float *Xc = (float *)malloc(sizeof(float) * (size_t)n * D);
@@ -581,7 +695,8 @@ void jvo_pq_refine(const jvo_pq *pq, const float *X, int64_t n, int rounds, uint
         size_t cnt = (size_t)pq->k * pq->sizes[m];
         memcpy(codebooks + cboff, pq->codebooks + cboff, sizeof(float) * cnt);
         uint64_t rng = jvo_kmeans_stream(seed, m);
-        jvo_kmeans_lloyd(Xc, n, D, pq->offsets[m], pq->sizes[m], pq->k, codebooks + cboff, rounds, &rng);
+        jvo_kmeans_lloyd_aniso(Xc, n, D, pq->offsets[m], pq->sizes[m], pq->k, codebooks + cboff, threshold > -1.0f ? 0 : rounds,
+                               threshold > -1.0f ? rounds : 0, threshold, &rng);
         cboff += cnt;
     }
     free(Xc);

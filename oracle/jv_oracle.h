@@ -86,6 +86,9 @@ void jvo_centroid_of(const float *X, int64_t n, int D, float *out);
 void jvo_pq_train(const float *X, int64_t n, int D, int M, int k, int globallyCenter, uint64_t seed, int rounds,
                   float *codebooks, float *centroid, int *rounds_run);
 void jvo_pq_refine(const jvo_pq *pq, const float *X, int64_t n, int rounds, uint64_t seed, float *codebooks);
+void jvo_pq_train_aniso(const float *X, int64_t n, int D, int M, int k, int globallyCenter, float threshold, uint64_t seed, int rounds,
+                        float *codebooks, float *centroid, int *rounds_run);
+void jvo_pq_refine_aniso(const jvo_pq *pq, float threshold, const float *X, int64_t n, int rounds, uint64_t seed, float *codebooks);
 int  jvo_nodequeue_push(int64_t *heap, int *size, int cap, int order, int32_t node, float score);
 void jvo_nodequeue_top(const int64_t *heap, int order, int32_t *node, float *score);
 void jvo_nodequeue_pop(int64_t *heap, int *size);

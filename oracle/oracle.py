@@ -129,6 +129,9 @@ def lib():
         sig("jvo_pq_encode_anisotropic", None, pqp, C.c_float, fp, u8p)
         sig("jvo_pq_train", None, fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, fp, fp, C.POINTER(C.c_int))
         sig("jvo_pq_refine", None, pqp, fp, C.c_int64, C.c_int, C.c_uint64, fp)
+        sig("jvo_pq_train_aniso", None, fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, fp, fp,
+            C.POINTER(C.c_int))
+        sig("jvo_pq_refine_aniso", None, pqp, C.c_float, fp, C.c_int64, C.c_int, C.c_uint64, fp)
         sig("jvo_parallel_cost_multiplier", C.c_float, C.c_float, C.c_int)
         sig("jvo_pq_diversity_score", C.c_float, fp, C.c_int, C.c_int, C.c_int, u8p, u8p)
         sig("jvo_pq_diversity_score_direct", C.c_float, pqp, C.c_int, u8p, u8p)
@@ -278,14 +281,16 @@ def subvector_sizes_offsets(D, M):
     return s, o
 
 
-def pq_train(vecs, M, k=256, globally_center=False, seed=1, rounds=6):
-    """ProductQuantization.compute (unweighted) with a seeded RNG -> (OraclePQ, rounds_run[M])."""
+def pq_train(vecs, M, k=256, globally_center=False, seed=1, rounds=6, anisotropic_threshold=-1.0):
+    """ProductQuantization.compute with a seeded RNG -> (OraclePQ, rounds_run[M]); anisotropic_threshold > -1 adds the
+    anisotropic k-means rounds (cluster(6, 6))."""
     vecs = f32(vecs)
     n, D = vecs.shape
     cb = np.empty(k * D, np.float32)
     cen = np.zeros(D, np.float32)
     rr = (C.c_int * M)()
-    lib().jvo_pq_train(_f(vecs), n, D, M, k, 1 if globally_center else 0, seed, rounds, _f(cb), _f(cen), rr)
+    lib().jvo_pq_train_aniso(_f(vecs), n, D, M, k, 1 if globally_center else 0, C.c_float(anisotropic_threshold), seed, rounds, _f(cb),
+                             _f(cen), rr)
     return OraclePQ(D, M, cb, cen if globally_center else None, k), np.array(list(rr))
 
 
@@ -346,11 +351,11 @@ class OraclePQ:
         lib().jvo_pq_encode(self.ref, _f(vec), _u8(out))
         return out
 
-    def refine(self, vecs, rounds=1, seed=1):
-        """ProductQuantization.refine (unweighted) -> new OraclePQ."""
+    def refine(self, vecs, rounds=1, seed=1, anisotropic_threshold=-1.0):
+        """ProductQuantization.refine -> new OraclePQ (anisotropic k-means rounds when anisotropic_threshold > -1)."""
         vecs = f32(vecs)
         cb = np.empty_like(self.codebooks)
-        lib().jvo_pq_refine(self.ref, _f(vecs), vecs.shape[0], rounds, seed, _f(cb))
+        lib().jvo_pq_refine_aniso(self.ref, C.c_float(anisotropic_threshold), _f(vecs), vecs.shape[0], rounds, seed, _f(cb))
         return OraclePQ(self.D, self.M, cb, self.centroid, self.k, sizes=self.sizes)
 
     def encode_anisotropic(self, vec, threshold):

@@ -29,7 +29,7 @@ void pp_main(void *arg)
 // mode 0: train from scratch (k-means++ then `rounds` Lloyd rounds); mode 1: refine the codebooks given in C
 extern "C" void km_emu_train(const float *X, int64_t n, int D, int M, int k, const int64_t *cb_offsets, const int32_t *sizes,
                              const int32_t *offsets, int globally_center, uint64_t seed, int rounds, int mode, const float *centroid_in,
-                             float *C, float *centroid_out)
+                             float *C, float *centroid_out, int aniso_rounds, const float *pcm)
 {
     std::vector<float> Xc((size_t)n * D), cen((size_t)D, 0.0f);
     const float *cptr = nullptr;
@@ -44,12 +44,12 @@ extern "C" void km_emu_train(const float *X, int64_t n, int D, int M, int k, con
     size_t total = 0;
     for (int m = 0; m < M; ++m) total += (size_t)k * sizes[m];
     std::vector<uint8_t> A((size_t)n * M), B((size_t)n * M);
-    std::vector<float> nums(total), dist((size_t)M * n);
+    std::vector<float> nums(total), dist((size_t)M * n), cnorm((size_t)M * k);
     std::vector<int32_t> denoms((size_t)M * k), active((size_t)M, 1), changed((size_t)M, 0);
     std::vector<uint64_t> rng((size_t)M);
     for (int m = 0; m < M; ++m) rng[m] = jv::km_stream(seed, m);
     jv::KmParams p{Xc.data(), C, cb_offsets, sizes, offsets, A.data(), B.data(), nums.data(), denoms.data(), active.data(),
-                   changed.data(), rng.data(), dist.data(), n, D, M, k};
+                   changed.data(), rng.data(), dist.data(), cnorm.data(), pcm, n, D, M, k};
     if (mode == 0)
         for (int m = 0; m < M; ++m) {
             PP a{&p, m};
@@ -64,6 +64,17 @@ extern "C" void km_emu_train(const float *X, int64_t n, int D, int M, int k, con
         for (int64_t m = 0; m < M; ++m) jv::km_fill_empties(p, m);
         for (int64_t t = 0; t < n * M; ++t) jv::km_assign(p, t);
         for (int64_t t = 0; t < (int64_t)M * k; ++t) jv::km_replay(p, 0, t);
+        for (int64_t m = 0; m < M; ++m) jv::km_finish_round(p, m);
+    }
+    if (aniso_rounds > 0)
+        for (int64_t m = 0; m < M; ++m) jv::km_reactivate(p, m);
+    for (int it = 0; it < aniso_rounds; ++it) {
+        std::swap(p.assign_old, p.assign_new);
+        for (int64_t t = 0; t < (int64_t)M * k; ++t) jv::km_centroids_aniso(p, t);
+        for (int64_t m = 0; m < M; ++m) jv::km_fill_empties(p, m);
+        for (int64_t t = 0; t < (int64_t)M * k; ++t) jv::km_cnorm(p, t);
+        for (int64_t t = 0; t < n * M; ++t) jv::km_assign_aniso(p, t);
+        for (int64_t m = 0; m < M; ++m) jv::km_count_changed(p, m);
         for (int64_t m = 0; m < M; ++m) jv::km_finish_round(p, m);
     }
 }

@@ -339,6 +339,20 @@ int launch_km_update_centroids(hipStream_t, const KmParams &p)
     for (int64_t m = 0; m < p.M; ++m) km_fill_empties(p, m);
     return JV_OK;
 }
+int launch_km_aniso_round(hipStream_t, const KmParams &p)
+{
+    for (int64_t t = 0; t < (int64_t)p.M * p.k; ++t) km_centroids_aniso(p, t);
+    for (int64_t m = 0; m < p.M; ++m) km_fill_empties(p, m);
+    for (int64_t t = 0; t < (int64_t)p.M * p.k; ++t) km_cnorm(p, t);
+    for (int64_t t = 0; t < p.n * p.M; ++t) km_assign_aniso(p, t);
+    for (int64_t m = 0; m < p.M; ++m) km_count_changed(p, m);
+    return JV_OK;
+}
+int launch_km_reactivate(hipStream_t, const KmParams &p)
+{
+    for (int64_t m = 0; m < p.M; ++m) km_reactivate(p, m);
+    return JV_OK;
+}
 int launch_km_finish_round(hipStream_t, const KmParams &p)
 {
     for (int64_t m = 0; m < p.M; ++m) km_finish_round(p, m);

@@ -182,6 +182,11 @@ def test_training_entry_points(J, ctx, D, M, center):
     T.test_train_refine_write(ctx, D, M, center)
 
 
+def test_anisotropic_training_entry_points(J, ctx):
+    import test_zz_pq_train_gpu as T
+    T.test_anisotropic_training(ctx)
+
+
 def test_no_device_memory_leaks(J):
     """every jv_* object created by the tests above was destroyed: the mock runtime has no live device allocations left
     except what lives in still-referenced Python wrappers (collected first)."""

@@ -50,7 +50,7 @@ def test_train_matches_oracle_bit_for_bit(emu, D, M, center, seed, monkeypatch):
     got = np.full(256 * D, np.nan, np.float32)
     cen = np.zeros(D, np.float32)
     emu.km_emu_train(P(v), C.c_int64(len(v)), D, M, 256, P(cbo), P(sizes), P(offs), int(center), C.c_uint64(seed), 6, 0, None,
-                     P(got), P(cen))
+                     P(got), P(cen), 0, None)
     assert np.array_equal(got, want.codebooks)
     if center:
         assert np.array_equal(cen, want.centroid)
@@ -71,7 +71,7 @@ def test_early_stop_per_subspace_and_empty_clusters(emu):
     assert rounds[0] < rounds[2] == 6
     assert len(np.unique(want.encode_all(v)[:, 1])) <= 100
     got = np.empty(256 * D, np.float32)
-    emu.km_emu_train(P(v), C.c_int64(len(v)), D, M, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(2), 6, 0, None, P(got), None)
+    emu.km_emu_train(P(v), C.c_int64(len(v)), D, M, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(2), 6, 0, None, P(got), None, 0, None)
     assert np.array_equal(got, want.codebooks)
 
 
@@ -89,7 +89,7 @@ def test_refine_matches_oracle_bit_for_bit(emu, rounds, centroid):
     want = pq.refine(data(2000, D, 12), rounds, seed=4)
     got = cb.copy()
     x = data(2000, D, 12)
-    emu.km_emu_train(P(x), C.c_int64(len(x)), D, M, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(4), rounds, 1, P(cen), P(got), None)
+    emu.km_emu_train(P(x), C.c_int64(len(x)), D, M, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(4), rounds, 1, P(cen), P(got), None, 0, None)
     assert np.array_equal(got, want.codebooks)
     assert not np.array_equal(got, cb)
 
@@ -105,7 +105,7 @@ def test_perfect_reconstruction_like_the_reference_test(emu):
         codes = want.encode_all(v)
         assert np.array_equal(np.stack([want.decode(c) for c in codes]), v)
         got = np.empty(256 * 3, np.float32)
-        emu.km_emu_train(P(v), C.c_int64(len(v)), 3, 2, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(5), 6, 0, None, P(got), None)
+        emu.km_emu_train(P(v), C.c_int64(len(v)), 3, 2, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(5), 6, 0, None, P(got), None, 0, None)
         assert np.array_equal(got, want.codebooks)
 
 
@@ -132,3 +132,31 @@ def test_reference_training_properties_hold_for_the_restatement():
         if len(half1) >= 256:
             pq1, _ = O.pq_train(half1, 1, seed=trial)
             assert _loss(pq1.refine(half2, 1, seed=trial), half2) < _loss(pq1, half2)
+
+
+@pytest.mark.parametrize("D,M,threshold,mode", [(32, 4, 0.2, "train"), (26, 3, 0.5, "train"), (32, 4, 0.3, "refine")])
+def test_anisotropic_kmeans_matches_oracle_bit_for_bit(emu, D, M, threshold, mode):
+    """cluster(6, 6) / refine with an anisotropic threshold: the anisotropic rounds (per-cluster outer-product sums,
+    8x8 Gauss-Jordan inverse, weighted reassignment) replayed per cluster in point order == the oracle's restatement."""
+    rng = np.random.default_rng(D)
+    v = data(2500, D, D + 3)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    sizes, offs, cbo = layout(D, M)
+    pcm = np.array([O.lib().jvo_parallel_cost_multiplier(C.c_float(threshold), int(s)) for s in sizes], np.float32)
+    if mode == "train":
+        want, _ = O.pq_train(v, M, seed=5, anisotropic_threshold=threshold)
+        plain, _ = O.pq_train(v, M, seed=5)
+        got = np.empty(256 * D, np.float32)
+        emu.km_emu_train(P(v), C.c_int64(len(v)), D, M, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(5), 6, 0, None, P(got), None, 6,
+                         P(pcm))
+        assert not np.array_equal(want.codebooks, plain.codebooks)
+    else:
+        pick = rng.choice(len(v), 256, replace=False)
+        cb = np.concatenate([v[pick, offs[m]: offs[m] + sizes[m]].reshape(-1) for m in range(M)]).astype(np.float32)
+        want = O.OraclePQ(D, M, cb).refine(v, 2, seed=5, anisotropic_threshold=threshold)
+        got = cb.copy()
+        emu.km_emu_train(P(v), C.c_int64(len(v)), D, M, 256, P(cbo), P(sizes), P(offs), 0, C.c_uint64(5), 0, 1, None, P(got), None, 2,
+                         P(pcm))
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, want.codebooks)
+

@@ -47,3 +47,21 @@ def test_train_refine_write(ctx, D, M, center):
     assert np.array_equal(got2.codebooks, want2.codebooks)
     with pytest.raises(ValueError):
         J.ProductQuantization.compute(ctx, v[:100], M)   # fewer points than clusters
+
+
+def test_anisotropic_training(ctx):
+    """compute / refine with an anisotropic threshold: unweighted + anisotropic k-means rounds == the oracle, bit for bit"""
+    v = data(4000, 32, 77)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    want, _ = O.pq_train(v, 4, seed=9, anisotropic_threshold=0.2)
+    pq = J.ProductQuantization.compute(ctx, v, 4, seed=9, anisotropic_threshold=0.2)
+    got, ver, aniso, _ = O.OraclePQ.parse(pq.write(6))
+    assert aniso == np.float32(0.2) and np.array_equal(got.codebooks, want.codebooks)
+    x = data(3000, 32, 78)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    want2 = want.refine(x, 2, seed=4, anisotropic_threshold=0.2)
+    got2, _, _, _ = O.OraclePQ.parse(pq.refine(x, 2, seed=4).write(6))
+    assert np.array_equal(got2.codebooks, want2.codebooks)
+    codes = pq.encode_all(v[:100])                      # the trained PQ encodes anisotropically
+    assert np.array_equal(codes, np.stack([want.encode_anisotropic(v[i], 0.2) for i in range(100)]))
+
