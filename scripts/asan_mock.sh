@@ -15,7 +15,7 @@ g++ -shared -fsanitize=address -Wl,-Bsymbolic -o libjvector_hip_mock_asan.so *.o
 cd "$ROOT"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) JV_MOCK_LIBRARY="$OUT/libjvector_hip_mock_asan.so"
 python -m pytest tests/test_mock_device.py -x -q -p no:cacheprovider \
-  -k "parity_suite or search_flat or host_graph_searcher or load_index or build_score or (edge_cases and host) or several_host"
+  -k "parity_suite or search_flat or host_graph_searcher or load_index or build_score or fused_build or continuous_batching or several_host or ((edge_cases or irregular or negative_scores or accept_ords) and host)"
 python - <<'PY'
 import ctypes as C, os, sys
 sys.path.insert(0, "tests")
