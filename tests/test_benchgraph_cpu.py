@@ -1,6 +1,8 @@
 """CPU checks of bench.py's synthetic input preparation (benchlib / benchgraph): structural invariants of the
 hierarchical graph and that the oracle's GraphSearcher restatement reaches a sane recall on it.  Not product code —
 this guards the bench's inputs."""
+import os
+
 import numpy as np
 import torch
 
@@ -45,3 +47,15 @@ def test_synthetic_graph_structure_and_recall():
     ids, _, stats = og.search(opq, codes, base.numpy(), q.numpy(), O.COSINE, 10, 200, fused=True)
     assert recall_at_k(ids, gt) >= 0.9
     assert stats[:, 0].mean() < N / 2          # a graph search, not a scan
+
+
+def test_bench_module_imports_and_parses_its_flags():
+    """bench.py cannot run without a GPU, but a syntax / import error or a broken flag table must not wait for the GPU box"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "--traversal" in out.stdout and "--gpus" in out.stdout
+    sys.path.insert(0, root)
+    import bench
+    assert bench.effective_cpus() >= 1
