@@ -67,7 +67,7 @@ def cpu_baseline_flat(cb, D, M, codes_h, base_dev, queries_dev, vsf, top_k, rera
     """CPU oracle on a bounded sample of the flat workload: one query per host thread."""
     from oracle import oracle as O
     threads = effective_cpus()
-    nq = min(threads, queries_dev.shape[0])
+    nq = min(threads, queries_dev.shape[0], gpu_ids.shape[0])
     opq = O.OraclePQ(D, M, cb)
     q = queries_dev[:nq].cpu().numpy()
     t0 = time.perf_counter()
@@ -94,7 +94,7 @@ def cpu_baseline_graph(cb, D, M, codes_h, levels, entry, entry_level, base_dev, 
 
     from oracle import oracle as O
     threads = effective_cpus()
-    nq = min(256 * threads, queries_dev.shape[0])
+    nq = min(256 * threads, queries_dev.shape[0], gpu_ids.shape[0])  # gpu_ids covers the first batch only
     opq = O.OraclePQ(D, M, cb)
     og = O.OracleGraph(codes_h.shape[0], levels, entry, entry_level)
     q = queries_dev[:nq].cpu().numpy()
@@ -178,6 +178,8 @@ def main():
     J._lib.check(ctx._lib.jv_hip_pq_encode_into(ctx._h, pq._h, vs._h, 0, N, cv._h))
     enc_ms, _ = ctx.profile_read("encode")
     ctx.profile(False)
+    if not codes_t.is_cuda:  # host tensors are copied, not wrapped (CPU dry run of this script against the mock device)
+        codes_t.copy_(torch.from_numpy(cv.get(0, N)))
 
     build_s = None
     if graph_mode:

@@ -54,7 +54,8 @@ def _ptr(x, dtype=None):
 
 
 def _empty(shape, dtype, like):
-    if like is not None and _is_torch(like) and like.is_cuda:
+    """output buffer of the caller's kind: torch tensor in (any device) -> torch tensor out on that device, else numpy"""
+    if like is not None and _is_torch(like):
         import torch
         tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32}[dtype]
         return torch.empty(shape, dtype=tdt, device=like.device)

@@ -499,3 +499,47 @@ def test_standalone_canary_against_the_mock_library(J):
         assert out.returncode == 0, out.stdout + out.stderr
         line = json.loads(out.stdout.strip().splitlines()[-1])
         assert line["identical"] is True and line["avg_expanded"] >= 50
+
+
+@pytest.mark.parametrize("mode,traversal", [("graph", "host"), ("graph", "device"), ("flat", "host")])
+def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal):
+    """bench.py end to end at toy size: torch runs on the CPU (a proxy maps the `cuda` device bench asks for to `cpu` and makes
+    the stream / synchronize calls inert) and the engine is the mock device.  Numbers are meaningless; what is checked is the
+    control flow — index build, rerankK calibration against exact ground truth, the timed loop, the secondary flat
+    measurement, the CPU-baseline leg and its top-K comparison — and the JSON contract of the one output line."""
+    import json
+    import types
+    import torch
+    import bench
+
+    class TorchProxy:
+        cuda = types.SimpleNamespace(set_device=lambda *_a: None, synchronize=lambda *_a: None,
+                                     current_stream=lambda *_a: types.SimpleNamespace(cuda_stream=0))
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def device(*_a, **_k):
+            return torch.device("cpu")
+
+    monkeypatch.setattr(bench, "torch", TorchProxy())
+    argv = ["bench.py", "--mode", mode, "--traversal", traversal, "--n", "6000", "--dim", "128", "--m", "16", "--degree", "16",
+            "--queries", "48", "--steps", "2", "--warmup", "1", "--eval-queries", "48"]
+    monkeypatch.setattr(sys, "argv", argv)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    bench.main()
+    out = capsys.readouterr().out.strip().splitlines()
+    line = json.loads(out[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["higher_is_better"] is True
+    assert line["config"]["mode"] == mode and line["config"]["n_vectors"] == 6000 and "workload" in line["config"]
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert line["cpu_baseline"]["matches_gpu_topk"] is True
+    assert 0.0 <= line["recall_at_10"] <= 1.0 and line["recall_at_10"] > 0.5
+    if mode == "graph":
+        assert line["config"]["traversal"] == traversal and line["avg_expanded"] > 0 and "flat_mode" in line
