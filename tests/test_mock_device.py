@@ -543,3 +543,68 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal):
     assert 0.0 <= line["recall_at_10"] <= 1.0 and line["recall_at_10"] > 0.5
     if mode == "graph":
         assert line["config"]["traversal"] == traversal and line["avg_expanded"] > 0 and "flat_mode" in line
+
+
+def _bench_rank(rank, world, port, mode, out_dir):
+    """one rank of a 2-process bench.py dry run: gloo instead of RCCL, CPU tensors, the mock device"""
+    import contextlib
+    import ctypes as C2
+    import types
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), JVECTOR_HIP_HOST_THREADS="1", OMP_NUM_THREADS="2", MKL_NUM_THREADS="2")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "mock"))
+    import build_mock
+    import jvector_amd._lib as L
+    lib = C2.CDLL(build_mock.build())
+    for table in (L.SIGNATURES, L.COMPAT_SIGNATURES, L.FORMAT_SIGNATURES):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    L._lib = lib
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(2)  # two ranks share this box: no oversubscription
+    import bench
+    real_init = dist.init_process_group
+    dist.init_process_group = lambda backend=None, **kw: real_init("gloo", rank=rank, world_size=world)
+
+    class TorchProxy:
+        cuda = types.SimpleNamespace(set_device=lambda *_a: None, synchronize=lambda *_a: None,
+                                     current_stream=lambda *_a: types.SimpleNamespace(cuda_stream=0))
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def device(*_a, **_k):
+            return torch.device("cpu")
+
+    bench.torch = TorchProxy()
+    sys.argv = ["bench.py", "--gpus", str(world), "--mode", mode, "--n", "5000", "--dim", "128", "--m", "16", "--degree", "16", "--queries",
+                "32", "--steps", "2", "--warmup", "1", "--eval-queries", "32"]
+    with open(os.path.join(out_dir, f"rank{rank}.out"), "w") as f, contextlib.redirect_stdout(f):
+        bench.main()
+
+
+@pytest.mark.parametrize("mode", ["graph", "flat"])
+def test_bench_two_rank_dry_run(tmp_path, mode):
+    """bench.py --gpus 2 as the driver launches it (one process per rank, RANK / WORLD_SIZE / LOCAL_WORLD_SIZE in the
+    environment), with gloo standing in for RCCL: rank 0 prints ONE line with n_gpus = 2, the aggregate over both ranks and the
+    max-over-ranks time; rank 1 prints nothing."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mp.spawn(_bench_rank, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    out0 = open(tmp_path / "rank0.out").read().strip().splitlines()
+    out1 = open(tmp_path / "rank1.out").read().strip()
+    assert out1 == "" and len(out0) == 1
+    line = json.loads(out0[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["mode"] == mode and "2 replicas" in line["config"]["parallelism"]
+    assert abs(line["value"] - 2 * 32 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]   # total queries / elapsed
+    assert "cpu_baseline" not in line                                                                # rank 0 at N = 1 only
