@@ -75,7 +75,8 @@ hipError_t hipHostFree(void *p)
 }
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p)
 {
-    // device allocations are tracked by base address; an interior pointer counts if it lies inside one
+    // device allocations are tracked by BASE address only (the library never asks about interior pointers of its own
+    // buffers; user pointers are either whole allocations or host memory)
     std::lock_guard<std::mutex> lk(g_mu);
     memset(a, 0, sizeof(*a));
     if (g_dev.count(p)) {
