@@ -876,6 +876,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // exchange area in LDS, which only fits next to the queues at 2 waves/SIMD.  JVECTOR_HIP_GS_PAIR=0 turns it off.
     bool pair = occ == 2 && env_int("JVECTOR_HIP_GS_PAIR", 1) != 0;
     for (int lv = 0; lv <= g->entry_level; ++lv) pair = pair && g->levels[lv].degree <= 32;
+    // M >= 128: the pair form's two half rows + exchange indices no longer fit 256 VGPRs (156 / 588 bytes of scratch per
+    // lane at M = 128 / 192, -Rpass-analysis=kernel-resource-usage) while the one-lane-per-neighbour form still does
+    pair = pair && pq->M <= 96;
     const int pair_M = pair ? pq->M : 0;
     int cand_cap = std::max(256, env_int("JVECTOR_HIP_GS_CAND_CAP", occ == 4 ? 512 : (pair ? 768 : 1024))) & ~63;
     while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;

@@ -98,15 +98,15 @@ KM_FN void km_assign(const KmParams &p, int64_t t)
     p.assign_new[t] = (uint8_t)nearest;
 }
 
-// initializeAssignedPoints (first_pass) / updateAssignedPointsUnweighted: thread t = m*k + c replays cluster c's history
-KM_FN void km_replay(const KmParams &p, int first_pass, int64_t t)
+// initializeAssignedPoints (first_pass) / updateAssignedPointsUnweighted: thread t = m*k + c replays cluster c's history.
+// LEN > 0: the sub-vector length is the compile-time LEN (accumulator in registers); LEN == 0: any length <= 64.
+template <int LEN>
+KM_FN void km_replay_len(const KmParams &p, int first_pass, int64_t t, int m, int c)
 {
-    const int m = (int)(t / p.k), c = (int)(t % p.k);
-    if (m >= p.M || !p.active[m]) return;
-    const int len = p.sizes[m], off = p.offsets[m];
+    const int len = LEN > 0 ? LEN : p.sizes[m], off = p.offsets[m];
     float *num = p.nums + p.cb_offsets[m] + (int64_t)c * len;
     int32_t denom = first_pass ? 0 : p.denoms[t];
-    float acc[64];  // sub-vector length <= 64 (checked by the host)
+    float acc[LEN > 0 ? LEN : 64];  // sub-vector length <= 64 (checked by the host)
     for (int j = 0; j < len; ++j) acc[j] = first_pass ? 0.0f : num[j];
     int32_t changed = 0;
     for (int64_t i = 0; i < p.n; ++i) {
@@ -127,6 +127,14 @@ KM_FN void km_replay(const KmParams &p, int first_pass, int64_t t)
     for (int j = 0; j < len; ++j) num[j] = acc[j];
     p.denoms[t] = denom;
     if (c == 0) p.changed[m] = changed;
+}
+
+KM_FN void km_replay(const KmParams &p, int first_pass, int64_t t)
+{
+    const int m = (int)(t / p.k), c = (int)(t % p.k);
+    if (m >= p.M || !p.active[m]) return;
+    if (p.sizes[m] == 8) km_replay_len<8>(p, first_pass, t, m, c);  // every BASELINE config: D / M = 8
+    else km_replay_len<0>(p, first_pass, t, m, c);
 }
 
 // updateCentroidsUnweighted, non-empty clusters: thread t = m*k + c
