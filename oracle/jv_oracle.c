@@ -706,12 +706,31 @@ void jvo_pq_refine_aniso(const jvo_pq *pq, float threshold, const float *X, int6
  * PQDecoder / FusedPQDecoder set-up and per-node scores
  * ---------------------------------------------------------------------------------------- */
 
+/* cpu_baseline switch (bench.py only): 0 = the scalar checker arithmetic of this file (default, what every parity test
+ * compares against); non-zero = the SIMD restatement of the reference's native kernels (jv_oracle_simd.c) inside the
+ * SEARCH entry points below (decoder tables, per-node ADC scores, exact rerank).  Set before any search thread starts. */
+static int g_simd = 0;
+int jvo_set_simd(int on)
+{
+    g_simd = on ? jvs_tier() : 0;
+    return g_simd;
+}
+static inline float adc_score_x(int vsf, int M, int k, const float *lut, const float *amag, float bmag, const uint8_t *code)
+{
+    return g_simd ? jvs_adc_score(vsf, M, k, lut, amag, bmag, code) : jvo_adc_score(vsf, M, k, lut, amag, bmag, code);
+}
+static inline float compare_x(int vsf, const float *a, const float *b, int n)
+{
+    return g_simd ? jvs_compare(vsf, a, b, n) : jvo_compare(vsf, a, b, n);
+}
+
 static void build_tables(const jvo_pq *pq, const float *cq, int lutVsf, float *lut, float *amag)
 {
     size_t cboff = 0;
     for (int m = 0; m < pq->M; m++) {
         int size = pq->sizes[m];
-        jvo_calculate_partial_sums(pq->codebooks + cboff, m, size, pq->k, cq, pq->offsets[m], lutVsf, lut);
+        if (g_simd) jvs_calculate_partial_sums(pq->codebooks + cboff, m, size, pq->k, cq, pq->offsets[m], lutVsf, lut);
+        else jvo_calculate_partial_sums(pq->codebooks + cboff, m, size, pq->k, cq, pq->offsets[m], lutVsf, lut);
         if (amag) jvo_calculate_partial_self_magnitudes(pq->codebooks + cboff, m, size, pq->k, amag);
         cboff += (size_t)pq->k * size;
     }
@@ -1065,10 +1084,12 @@ static void *flat_worker(void *arg)
     for (int q = j->q_lo; q < j->q_hi; q++) {
         const float *query = j->queries + (size_t)q * D;
         float bmag = 0.0f;
-        jvo_pqdecoder_init(pq, query, j->vsf, lut, amag, &bmag);
+        /* partialSquaredMagnitudes is cached per ProductQuantization (ProductQuantization.java:75,238) */
+        const float *am = (j->vsf == JVO_COSINE && pq->self_magnitudes) ? pq->self_magnitudes : amag;
+        jvo_pqdecoder_init(pq, query, j->vsf, lut, am == amag ? amag : NULL, &bmag);
         int size = 0;
         for (int64_t i = 0; i < j->n; i++) {
-            float s = jvo_adc_score(j->vsf, M, k, lut, amag, bmag, j->codes + i * M);
+            float s = adc_score_x(j->vsf, M, k, lut, am, bmag, j->codes + i * M);
             size = topk_heap_push(heap, size, k1, jvo_nodequeue_encode((int32_t)i, s));
         }
         int64_t *res = heap;
@@ -1077,7 +1098,7 @@ static void *flat_worker(void *arg)
             int s2 = 0;
             for (int c = 0; c < size; c++) {
                 int32_t id = (int32_t)~(uint32_t)(heap[c] & 0xFFFFFFFFLL);
-                float ex = jvo_compare(j->vsf, query, j->vecs + (size_t)id * D, D);
+                float ex = compare_x(j->vsf, query, j->vecs + (size_t)id * D, D);
                 s2 = topk_heap_push(heap2, s2, j->topK, jvo_nodequeue_encode(id, ex));
             }
             res = heap2;
@@ -1133,7 +1154,7 @@ static void *rr_worker(void *arg)
         for (int c = 0; c < j->R; c++) {
             int32_t id = j->cand_ids[(size_t)q * j->R + c];
             if (id < 0) continue;
-            float ex = jvo_compare(j->vsf, j->queries + (size_t)q * j->D,
+            float ex = compare_x(j->vsf, j->queries + (size_t)q * j->D,
                                    j->cand_vecs + ((size_t)q * j->R + c) * j->D, j->D);
             size = topk_heap_push(heap, size, j->topK, jvo_nodequeue_encode(id, ex));
         }
@@ -1266,9 +1287,12 @@ void jvo_graph_search_filtered(const jvo_graph *g, const jvo_pq *pq, const uint8
     float *lut = (float *)malloc(sizeof(float) * (size_t)M * k);
     float *amag = (float *)malloc(sizeof(float) * (size_t)M * k);
     float bmag = 0.0f;
-    if (fused) jvo_fuseddecoder_init(pq, query, vsf, lut, amag, &bmag);
-    else jvo_pqdecoder_init(pq, query, vsf, lut, amag, &bmag);
-#define SCORE(node) jvo_adc_score(vsf, M, k, lut, amag, bmag, codes + (size_t)(node) * M)
+    /* partialSquaredMagnitudes is query independent and cached per ProductQuantization (ProductQuantization.java:75,238):
+     * take the caller's copy when there is one instead of rebuilding it for every query */
+    const float *am = (vsf == JVO_COSINE && pq->self_magnitudes) ? pq->self_magnitudes : amag;
+    if (fused) jvo_fuseddecoder_init(pq, query, vsf, lut, am == amag ? amag : NULL, &bmag);
+    else jvo_pqdecoder_init(pq, query, vsf, lut, am == amag ? amag : NULL, &bmag);
+#define SCORE(node) adc_score_x(vsf, M, k, lut, am, bmag, codes + (size_t)(node) * M)
     /* visited set: a per-thread array of epoch stamps reused from query to query (the reference clears a growable bit
      * set per search; a fresh calloc of n_nodes bytes per query would make this baseline pay ~visited page faults each
      * time, which the reference does not) */
@@ -1337,7 +1361,7 @@ void jvo_graph_search_filtered(const jvo_graph *g, const jvo_pq *pq, const uint8
     if (vecs) {
         for (int i = 0; i < res.n; i++) {
             int32_t id = key_node(res.a[i]);
-            fin[nf++] = jvo_nodequeue_encode(id, jvo_compare(vsf, query, vecs + (size_t)id * pq->D, pq->D));
+            fin[nf++] = jvo_nodequeue_encode(id, compare_x(vsf, query, vecs + (size_t)id * pq->D, pq->D));
         }
     } else {
         for (int i = 0; i < res.n; i++) fin[nf++] = res.a[i];

@@ -73,6 +73,8 @@ typedef struct {
     const int *offsets;    /* [M] */
     const float *codebooks;/* [sum_m k*sizes[m]] */
     const float *centroid; /* [D] or NULL */
+    const float *self_magnitudes; /* optional [M*k]: the cached partialSquaredMagnitudes table (ProductQuantization.java:75,
+                                   * 238) for the SEARCH entry points; NULL = rebuild it per query (same values) */
 } jvo_pq;
 
 void jvo_subvector_sizes_offsets(int D, int M, int *sizes, int *offsets);
@@ -175,6 +177,23 @@ size_t jvo_pq_serialize(int version, int D, int M, int k, const int *sizes, cons
 
 /* ---- the reference's native known-answer generator: NC/tests/test_helpers.cpp:78-87 ---- */
 void jvo_make_vec(float *v, size_t n, float seed);
+
+/* ---- cpu_baseline only (jv_oracle_simd.c): x86 SIMD restatement of the reference's native kernels.  NOT the parity
+ * checker: results differ from the scalar functions above in the last bits (lane-wise FMA accumulation). ---- */
+int   jvs_tier(void);            /* 0 scalar, 2 avx2+fma, 3 avx512f; JVO_SIMD_TIER=avx2|scalar caps it */
+const char *jvs_tier_name(void);
+float jvs_dot(const float *a, const float *b, int n);
+float jvs_l2(const float *a, const float *b, int n);
+float jvs_cosine(const float *a, const float *b, int n);
+float jvs_compare(int vsf, const float *a, const float *b, int n);
+void  jvs_calculate_partial_sums(const float *codebook, int cbIndex, int size, int k, const float *query, int qoff, int vsf,
+                                 float *out);
+float jvs_assemble_and_sum(const float *data, int dataBase, const uint8_t *offs, int len);
+float jvs_pq_decoded_cosine(const uint8_t *offs, int len, int k, const float *lut, const float *amag, float bmag);
+float jvs_adc_score(int vsf, int M, int k, const float *lut, const float *amag, float bmag, const uint8_t *code);
+/* 0 = scalar arithmetic in jvo_search_flat / jvo_rerank / jvo_graph_search* (default; what parity tests use), non-zero =
+ * the SIMD kernels above.  Returns the tier in effect.  Process-wide: set it before starting search threads. */
+int   jvo_set_simd(int on);
 
 #ifdef __cplusplus
 }

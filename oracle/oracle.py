@@ -29,7 +29,8 @@ def build(force: bool = False) -> str:
 class _PQ(C.Structure):
     _fields_ = [("D", C.c_int), ("M", C.c_int), ("k", C.c_int),
                 ("sizes", C.POINTER(C.c_int)), ("offsets", C.POINTER(C.c_int)),
-                ("codebooks", C.POINTER(C.c_float)), ("centroid", C.POINTER(C.c_float))]
+                ("codebooks", C.POINTER(C.c_float)), ("centroid", C.POINTER(C.c_float)),
+                ("self_magnitudes", C.POINTER(C.c_float))]
 
 
 class _Layout(C.Structure):
@@ -151,8 +152,26 @@ def lib():
         sig("jvo_pq_serialize", C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp, C.c_float, fp,
             u8p, C.c_size_t)
         sig("jvo_make_vec", None, fp, C.c_size_t, C.c_float)
+        # cpu_baseline only: SIMD restatement of the reference's native kernels (jv_oracle_simd.c)
+        sig("jvs_tier", C.c_int)
+        sig("jvs_tier_name", C.c_char_p)
+        sig("jvs_dot", C.c_float, fp, fp, C.c_int)
+        sig("jvs_l2", C.c_float, fp, fp, C.c_int)
+        sig("jvs_cosine", C.c_float, fp, fp, C.c_int)
+        sig("jvs_calculate_partial_sums", None, fp, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp)
+        sig("jvs_assemble_and_sum", C.c_float, fp, C.c_int, u8p, C.c_int)
+        sig("jvs_pq_decoded_cosine", C.c_float, u8p, C.c_int, C.c_int, fp, fp, C.c_float)
+        sig("jvo_set_simd", C.c_int, C.c_int)
         _lib = L
     return _lib
+
+
+def set_simd(on):
+    """cpu_baseline only: switch the SEARCH entry points (search_flat / rerank / OracleGraph.search) between the scalar
+    checker arithmetic (False, the default) and the SIMD restatement of the reference's native kernels.  Returns the
+    ISA tier name in effect ("scalar" when off or unsupported).  Process-wide; callers must switch it back."""
+    tier = lib().jvo_set_simd(1 if on else 0)
+    return lib().jvs_tier_name().decode() if tier else "scalar"
 
 
 def _f(a):
@@ -335,11 +354,26 @@ class OraclePQ:
         assert self.codebooks.size == self.k * int(self.sizes.sum())
         self.centroid = None if centroid is None else f32(centroid)
         self._s = _PQ(self.D, self.M, self.k, _i32(self.sizes), _i32(self.offsets), _f(self.codebooks),
-                      None if self.centroid is None else _f(self.centroid))
+                      None if self.centroid is None else _f(self.centroid), None)
+        self._self_mag = None
 
     @property
     def ref(self):
         return C.byref(self._s)
+
+    def cache_self_magnitudes(self):
+        """Build partialSquaredMagnitudes once, like the reference's AtomicReference cache (ProductQuantization.java:75,
+        238); the search entry points then stop rebuilding it per query.  Same values either way."""
+        if self._self_mag is None:
+            out = np.empty(self.M * self.k, np.float32)
+            off = 0
+            for m in range(self.M):
+                cb = self.codebooks[off: off + self.k * int(self.sizes[m])]
+                lib().jvo_calculate_partial_self_magnitudes(_f(cb), m, int(self.sizes[m]), self.k, _f(out))
+                off += self.k * int(self.sizes[m])
+            self._self_mag = out
+            self._s.self_magnitudes = _f(out)
+        return self._self_mag
 
     def codebook(self, m):
         off = int(self.k * self.sizes[:m].sum())

@@ -9,7 +9,7 @@ CXXF="-std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -ffp-contract
 for f in cabi graph_search build_score pq_train formats compat_host; do g++ $CXXF -c "$ROOT/jvector_amd/csrc/$f.cpp" -o $f.o & done
 g++ $CXXF -c "$ROOT/tests/mock/mock_hip.cpp" -o mock_hip.o &
 g++ $CXXF -c "$ROOT/tests/mock/mock_kernels.cpp" -o mock_kernels.o &
-gcc -O1 -g -fsanitize=address -std=c11 -fPIC -ffp-contract=off -c "$ROOT/oracle/jv_oracle.c" -o jv_oracle.o &
+for f in jv_oracle jv_oracle_simd; do gcc -O1 -g -fsanitize=address -std=c11 -fPIC -ffp-contract=off -c "$ROOT/oracle/$f.c" -o $f.o & done
 wait
 g++ -shared -fsanitize=address -Wl,-Bsymbolic -o libjvector_hip_mock_asan.so *.o -lpthread -lm
 cd "$ROOT"

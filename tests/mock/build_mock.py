@@ -15,7 +15,7 @@ CXXF = ["-std=c++17", "-O2", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/
 def _sources():
     srcs = [os.path.join(ROOT, "jvector_amd", "csrc", f + ".cpp") for f in HOST]
     srcs += [os.path.join(ROOT, "tests", "mock", f) for f in ("mock_hip.cpp", "mock_kernels.cpp")]
-    srcs.append(os.path.join(ROOT, "oracle", "jv_oracle.c"))
+    srcs += [os.path.join(ROOT, "oracle", f) for f in ("jv_oracle.c", "jv_oracle_simd.c")]
     return srcs
 
 

@@ -539,7 +539,11 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal):
     assert line["config"]["mode"] == mode and line["config"]["n_vectors"] == 6000 and "workload" in line["config"]
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
-    assert line["cpu_baseline"]["matches_gpu_topk"] is True
+    assert line["cpu_baseline"]["matches_gpu_topk"] is True          # the scalar leg is the parity checker
+    cb = line["cpu_baseline"]
+    assert cb["isa"] in ("scalar", "avx2", "avx512") and cb["scalar_value"] > 0
+    if cb["isa"] != "scalar":                                         # SIMD leg: the reported value, ~the same top-k
+        assert cb["value"] != cb["scalar_value"] and cb["simd_topk_overlap_with_gpu"] >= 0.98
     assert 0.0 <= line["recall_at_10"] <= 1.0 and line["recall_at_10"] > 0.5
     if mode == "graph":
         assert line["config"]["traversal"] == traversal and line["avg_expanded"] > 0 and "flat_mode" in line
