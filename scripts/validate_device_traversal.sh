@@ -4,6 +4,8 @@
 # Steps are ordered cheapest-first and each is bounded by its own timeout so that a hang costs minutes, not the box.
 set -u
 mkdir -p gpurun_out/gs
+# device + host identification next to every number this run produces (record rocminfo beside the roofline peak)
+{ /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock|Name: +gfx" | sort | uniq -c; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Flags" | sed 's/Flags:.*avx512f.*/Flags: ... avx512f .../'; nproc; } > gpurun_out/gs/machine.txt 2>&1
 export JVECTOR_TEST_DEVICE_TRAVERSAL=1 JVECTOR_TEST_BUILD_SCORE=1 JVECTOR_TEST_ANISOTROPIC=1 JVECTOR_TEST_PQ_TRAIN=1
 # 0a. standalone canary (no Python / torch start-up): device traversal == host traversal on a random 200k-node graph, timed
 mkdir -p build && g++ -std=c++17 -O2 tools/gs_canary.cpp -o build/gs_canary -Ljvector_amd -ljvector_hip -Wl,-rpath,"$PWD/jvector_amd" > gpurun_out/gs/canary_build.log 2>&1  # (not `make canary`: no rebuild of the .so on the box)
