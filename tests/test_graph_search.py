@@ -159,3 +159,67 @@ def test_graph_search_accept_ords(ctx):
             wi, ws, wst = og.search(opq, codes, v, q, int(vsf), 10, 40, fused=True, accept=accept)
             assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), vsf
     assert (ids[3] == -1).all()
+
+
+def run_ties_cases(J, ctx, traversal, cases=6):
+    """Every base vector stored two or three times under different ordinals, coordinates on a coarse grid, queries that ARE
+    base vectors: ADC scores and exact scores tie constantly, so every queue decision falls to the NodeQueue order
+    (equal score -> smaller node id first, NodeQueue.java:125-129) — in the candidate queue, the bounded result heap,
+    the rerank and the final top-k, with and without an acceptOrds filter.  Shared with tests/test_mock_device.py."""
+    VSF = J.VectorSimilarityFunction
+    for case in range(cases):
+        rng = np.random.default_rng(1000 + case)
+        D, M = [(128, 16), (256, 32)][case % 2]
+        base = rng.standard_normal((int(rng.integers(150, 500)), D)).astype(np.float32)
+        if case % 3 == 0:
+            base = np.round(base * 2) / 2
+        v = np.repeat(base, int(rng.integers(2, 4)), axis=0)
+        v = v[rng.permutation(len(v))]
+        N, deg = len(v), int(rng.choice([8, 16, 32]))
+        nb = np.full((N, deg), -1, np.int32)
+        for i in range(N):
+            row = rng.choice(N, int(rng.integers(1, deg + 1)), replace=False)
+            row = row[row != i]
+            nb[i, :len(row)] = row
+        lv, entry, entry_level = [(None, nb)], int(rng.integers(0, N)), 0
+        if case % 2:
+            top = np.sort(rng.choice(N, 20, replace=False)).astype(np.int32)
+            nb2 = np.full((20, 4), -1, np.int32)
+            for i in range(20):
+                r = rng.choice(top, 3, replace=False)
+                r = r[r != top[i]]
+                nb2[i, :len(r)] = r
+            lv.append((top, nb2))
+            entry, entry_level = int(top[0]), 1
+        sizes, offs = O.subvector_sizes_offsets(D, M)
+        pick = rng.choice(N, 256, replace=True)               # duplicate centroids too: encode ties -> first index wins
+        cb = np.concatenate([v[pick, offs[m]: offs[m] + sizes[m]].reshape(-1) for m in range(M)])
+        q = np.concatenate([v[rng.integers(0, N, 10)], rng.standard_normal((4, D)).astype(np.float32)]).astype(np.float32)
+        opq = O.OraclePQ(D, M, cb)
+        pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+        vs = J.VectorSet(ctx, v)
+        cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+        codes = cv.get(0, N)
+        assert np.array_equal(codes, opq.encode_all(v))
+        og = O.OracleGraph(N, lv, entry, entry_level)
+        graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal(traversal)
+        use_fused = case % 2 == 0
+        fused = J.FusedPQ(ctx, pq, fused_blocks(codes, nb), nb) if use_fused else None
+        accept = None if case % 3 else (rng.random(N) < 0.6)
+        for vsf in VSF:
+            if vsf == VSF.COSINE and case % 3 == 0:
+                continue                                        # the grid holds zero vectors (NaN cosine; covered elsewhere)
+            for rerank, top_k, rk in ((True, 10, 30), (False, 7, 7)):
+                s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=16)
+                ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True, accept=accept)
+                wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused,
+                                        accept=accept)
+                tag = (case, N, deg, vsf, rerank)
+                assert np.array_equal(st, wst), tag
+                assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag
+                if rerank and accept is None:                   # the ties are really there: a query that is a base vector
+                    assert (np.diff(sc[:10], axis=1) == 0).any(), tag  # scores its copies identically
+
+
+def test_graph_search_engineered_ties(ctx):
+    run_ties_cases(J, ctx, "host")

@@ -359,6 +359,12 @@ def test_searchers_on_random_irregular_graphs(J, ctx, traversal):
             assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag
 
 
+@pytest.mark.parametrize("traversal", ["host", "device"])
+def test_searchers_with_engineered_score_ties(J, ctx, traversal):
+    import test_graph_search as T
+    T.run_ties_cases(J, ctx, traversal)
+
+
 @pytest.mark.parametrize("slots,groups", [(64, 1), (96, 3), (700, 2), (1, 1)])
 def test_host_searcher_continuous_batching(J, ctx, monkeypatch, slots, groups):
     """more queries than traversal slots: finished queries hand their slot to the next one (and slot groups alternate);

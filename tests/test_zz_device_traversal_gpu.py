@@ -92,3 +92,10 @@ def test_device_traversal_accept_ords(ctx):
         wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, 40, fused=True, accept=accept)
         assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
 
+
+
+def test_device_traversal_engineered_ties(ctx):
+    """duplicated base vectors, grid coordinates, queries that are base vectors: every decision falls to the NodeQueue
+    tie order (the CPU twin runs in tests/test_mock_device.py)"""
+    import test_graph_search as T
+    T.run_ties_cases(J, ctx, "device")
