@@ -130,7 +130,8 @@ def cpu_baseline_graph(cb, D, M, codes_h, levels, entry, entry_level, base_dev, 
 
     from oracle import oracle as O
     threads = effective_cpus()
-    nq = min(128 * threads, queries_dev.shape[0], gpu_ids.shape[0])  # gpu_ids covers the first batch only
+    # ~10-30 s of CPU work per leg at the headline shape (~1.6 CPU-ms per query, scalar); gpu_ids covers the first batch only
+    nq = min(1024 * threads, queries_dev.shape[0], gpu_ids.shape[0])
     opq = O.OraclePQ(D, M, cb)
     opq.cache_self_magnitudes()
     og = O.OracleGraph(codes_h.shape[0], levels, entry, entry_level)
