@@ -234,6 +234,15 @@ JV_API int jv_hip_exact_scores(jv_ctx *ctx, const jv_vectors *v, const float *qu
                                const int32_t *ordinals, int B, float *scores_out);
 JV_API int jv_hip_exact_scan(jv_ctx *ctx, const jv_vectors *v, const float *queries, int Q, jv_vsf vsf,
                              int64_t first, int64_t count, float *scores_out);
+/* MFMA tile form of the scan (north_star: "MFMA only for the batched query x candidates GEMM form of full-resolution
+ * rerank"; SURVEY §8d: the dense Q x N form of row 1 — brute force, ground truth).  Same arguments and output layout as
+ * jv_hip_exact_scan, but NOT bit-identical to it: dot products and norms are k-ascending f32 fused-multiply-add chains (what
+ * v_mfma_f32_32x32x2_f32 computes; the reference's native library fuses as well, jvector_simd_kernels.cpp:208-286), cosine
+ * finishes as jv_hip_exact_scan does, L2 uses |q|^2 + |v|^2 - 2 q.v.  Scores agree with jv_hip_exact_scan to 1e-5 relative
+ * and are themselves reproducible bit for bit (jvector_amd/csrc/ed_body.h states the order).  Use it for candidate
+ * generation / ground truth at Q >= ~32, and jv_hip_exact_scores / jv_hip_exact_scan where the bit-exact order matters. */
+JV_API int jv_hip_exact_scan_dense(jv_ctx *ctx, const jv_vectors *v, const float *queries, int Q, jv_vsf vsf,
+                                   int64_t first, int64_t count, float *scores_out);
 
 /* ---------------------------------------------------------------------------------------------
  * Top-k under the NodeQueue total order — SURVEY §8a row 9

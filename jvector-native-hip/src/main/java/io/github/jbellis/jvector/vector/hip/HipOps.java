@@ -74,6 +74,7 @@ public final class HipOps {
         static final MethodHandle fusedBuild = h("jv_hip_fused_build", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));
         static final MethodHandle fusedScores = h("jv_hip_fused_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle exactScores = h("jv_hip_exact_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
+        static final MethodHandle exactScanDense = h("jv_hip_exact_scan_dense", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_LONG, JAVA_LONG, ADDRESS));
         static final MethodHandle topk = h("jv_hip_topk", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_LONG, JAVA_LONG, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
         static final MethodHandle graphCreate = h("jv_hip_graph_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, JAVA_INT, ADDRESS));
         static final MethodHandle graphSetLevel = h("jv_hip_graph_set_level", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, JAVA_INT));
@@ -192,6 +193,13 @@ public final class HipOps {
 
     public static void exactScores(MemorySegment ctx, MemorySegment vectors, MemorySegment queries, int q, int vsf, MemorySegment ordinals, int b, MemorySegment out) {
         try { check((int) H.exactScores.invokeExact(ctx, vectors, queries, q, vsf, ordinals, b, out)); }
+        catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    /** MFMA tile form of the brute-force scan (ground truth / candidate generation over many queries): fused k-ascending
+     *  chains, within 1e-5 of {@link #exactScores}' scalar-order arithmetic; out is [q][count] row-major. */
+    public static void exactScanDense(MemorySegment ctx, MemorySegment vectors, MemorySegment queries, int q, int vsf, long first, long count, MemorySegment out) {
+        try { check((int) H.exactScanDense.invokeExact(ctx, vectors, queries, q, vsf, first, count, out)); }
         catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
     }
 }

@@ -985,6 +985,28 @@ int jv_hip_exact_scan(jv_ctx *ctx, const jv_vectors *v, const float *queries, in
     return stage_out_end(ctx, os);
 }
 
+int jv_hip_exact_scan_dense(jv_ctx *ctx, const jv_vectors *v, const float *queries, int Q, jv_vsf vsf, int64_t first,
+                            int64_t count, float *scores_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && v, "exact_scan_dense: NULL argument");
+    JV_REQUIRE(Q >= 0, "exact_scan_dense: negative query count");
+    JV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->count, "exact_scan_dense: range out of bounds");
+    if (Q == 0 || count == 0) return JV_OK;
+    JV_REQUIRE(queries && scores_out, "exact_scan_dense: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    const void *d_q = nullptr;
+    JV_TRY(stage_in(ctx, queries, sizeof(float) * (size_t)Q * v->D, ctx->h_in, ctx->d_in, &d_q));
+    OutStage os;
+    JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)Q * count, ctx->d_out, &os));
+    {
+        ProfScope ps(ctx, R_EXACT);
+        JV_TRY(launch_exact_scan_dense(ctx->stream, v->d_vecs, v->D, (const float *)d_q, Q, to_kernel_vsf(vsf), first, count,
+                                       (float *)os.dev));
+    }
+    return stage_out_end(ctx, os);
+}
+
 // ------------------------------------------------------------------------------------------------
 // top-k
 // ------------------------------------------------------------------------------------------------

@@ -16,3 +16,10 @@ __device__ __forceinline__ int32_t gs_cas(int32_t *p, int32_t expect, int32_t de
 __device__ __forceinline__ uint32_t gs_fetch_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void gs_fence() { __threadfence(); }
 __device__ __forceinline__ double gs_sqrt(double x) { return sqrt(x); }
+// ed_body.h: f32-input MFMA (bitwise a k-ordered fmaf chain; A: lane l holds A[l & 31][l >> 5], B: B[l >> 5][l & 31]) and fmaf
+typedef float gs_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ gs_f32x16 gs_mfma_32x32x2(float a, float b, gs_f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float gs_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

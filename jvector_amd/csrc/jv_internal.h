@@ -213,6 +213,9 @@ int launch_fused(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const fl
 
 int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf,
                         const int32_t *d_ord, int B, float *d_out, float *d_qnorm);
+// MFMA tile form (k_exact_dense.hip / ed_body.h): fused chains, not bit-identical to launch_exact_scan
+int launch_exact_scan_dense(hipStream_t s, const float *d_vecs, int D, const float *d_q, int Q, int vsf, int64_t first,
+                            int64_t count, float *d_out);
 int launch_exact_scan(hipStream_t s, const jv_ctx *ctx, const float *d_vecs, int D, const float *d_q, int Q, int vsf,
                       int64_t first, int64_t count, float *d_out, float *d_qnorm);
 

@@ -1,0 +1,45 @@
+// k_exact_dense.hip — MFMA tile form of full-resolution scoring (dense Q x N form).  Body and the
+// arithmetic contract in ed_body.h.  Roofline: MFMA f32 (157 TF peak; 2·Q·N·D flop) once Q >= ~64, HBM (4·D bytes per
+// vector, read once per 32-query tile row that misses L2) below that.  Launch: one wavefront per block, 21.7 KB LDS ->
+// 7 blocks per CU; four independent 32x32 accumulators per wave keep the 64-cycle MFMA issue slot full.
+#include "gs_wave_hip.h"
+#include "jv_internal.h"
+
+#include "ed_body.h"
+
+namespace jv {
+
+template <int VSF>
+__global__ __launch_bounds__(64, 2) void exact_dense_kernel(EdParams p, int64_t blocks_padded, int64_t n_tiles, int q_tiles)
+{
+    __shared__ float lds[ED_LDS_FLOATS];
+    int64_t n_tile;
+    int q_tile;
+    if (!ed_block_to_tile((int64_t)blockIdx.x, blocks_padded, n_tiles, q_tiles, &n_tile, &q_tile)) return;
+    ed_tile<VSF>(p, n_tile * ED_TN, q_tile * ED_TQ, lds);
+}
+
+int launch_exact_scan_dense(hipStream_t s, const float *d_vecs, int D, const float *d_q, int Q, int vsf, int64_t first,
+                            int64_t count, float *d_out)
+{
+    if (Q == 0 || count == 0) return JV_OK;
+    const EdParams p{d_vecs, d_q, d_out, first, count, D, Q};
+    const int64_t n_tiles = (count + ED_TN - 1) / ED_TN;
+    const int q_tiles = (Q + ED_TQ - 1) / ED_TQ;
+    const int64_t blocks_padded = (n_tiles * q_tiles + 7) / 8 * 8;
+    if (blocks_padded > 0x7fffffffLL) {
+        set_error("exact_scan_dense: %lld tiles exceed one launch; scan a smaller range", (long long)blocks_padded);
+        return JV_ERR_INVALID;
+    }
+    const dim3 grid((unsigned)blocks_padded), block(64);
+    switch (vsf) {
+    case 0: hipLaunchKernelGGL(exact_dense_kernel<0>, grid, block, 0, s, p, blocks_padded, n_tiles, q_tiles); break;
+    case 1: hipLaunchKernelGGL(exact_dense_kernel<1>, grid, block, 0, s, p, blocks_padded, n_tiles, q_tiles); break;
+    case 2: hipLaunchKernelGGL(exact_dense_kernel<2>, grid, block, 0, s, p, blocks_padded, n_tiles, q_tiles); break;
+    default: set_error("exact_scan_dense: unknown similarity %d", vsf); return JV_ERR_INVALID;
+    }
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+}  // namespace jv

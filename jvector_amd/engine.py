@@ -277,15 +277,18 @@ class VectorSet:
         check(self._lib.jv_hip_exact_scores(self.ctx._h, self._h, q_p, Q, int(vsf), o_p, B, out_p))
         return out
 
-    def scan(self, queries, vsf, first=0, count=None, out=None):
-        """brute-force form: out[q, i] = vsf.compare(queries[q], vectors[first + i])"""
+    def scan(self, queries, vsf, first=0, count=None, out=None, dense=False):
+        """brute-force form: out[q, i] = vsf.compare(queries[q], vectors[first + i]).
+        dense=True: the MFMA tile form (jv_hip_exact_scan_dense) — fused k-ascending chains, within 1e-5 of the default
+        bit-exact scalar-order scores, for ground truth / candidate generation over many queries."""
         Q = int(queries.shape[0])
         count = self.count - first if count is None else int(count)
         q_p, qk = _ptr(queries, np.float32)
         if out is None:
             out = _empty((Q, count), np.float32, queries)
         out_p, outk = _ptr(out, np.float32)
-        check(self._lib.jv_hip_exact_scan(self.ctx._h, self._h, q_p, Q, int(vsf), int(first), count, out_p))
+        fn = self._lib.jv_hip_exact_scan_dense if dense else self._lib.jv_hip_exact_scan
+        check(fn(self.ctx._h, self._h, q_p, Q, int(vsf), int(first), count, out_p))
         return out
 
     def close(self):

@@ -141,6 +141,38 @@ float jvo_compare(int vsf, const float *a, const float *b, int n)
 }
 
 /* DefaultVectorUtilSupport.sub(a, aOffset, b, bOffset, length) :282-288 */
+/* SPECIFICATION (not a restatement of reference code) of the engine's MFMA tile form of full-resolution scoring,
+ * jvector_amd/csrc/ed_body.h: fused multiply-adds in ascending k from +0 — what v_mfma_f32_32x32x2_f32 computes — for the
+ * dot product and both squared norms, then the finishes written out there.  The reference's counterpart is its native
+ * library's fused flavour (jvector_simd_kernels.cpp:208-286), which the reference itself only holds to 1e-4 of the scalar
+ * order; tests hold this form to 1e-5 of jvo_compare and to bit equality with this function. */
+float jvo_dense_compare(int vsf, const float *q, const float *v, int n)
+{
+    float dot = 0.0f, qn = 0.0f, vn = 0.0f;
+    for (int k = 0; k < n; k++) {
+        dot = fmaf(q[k], v[k], dot);
+        qn = fmaf(q[k], q[k], qn);
+        vn = fmaf(v[k], v[k], vn);
+    }
+    if (vsf == JVO_EUCLIDEAN) {
+        float d2 = fmaf(-2.0f, dot, qn + vn);
+        if (d2 < 0.0f) d2 = 0.0f;
+        return 1.0f / (1.0f + d2);
+    }
+    if (vsf == JVO_COSINE) {
+        float prod = qn * vn;
+        dot = (float)((double)dot / sqrt((double)prod));
+    }
+    return (1.0f + dot) / 2.0f;
+}
+
+void jvo_dense_scan(int vsf, const float *queries, int Q, const float *vecs, int64_t n, int D, float *out)
+{
+    for (int q = 0; q < Q; q++)
+        for (int64_t i = 0; i < n; i++)
+            out[(size_t)q * n + i] = jvo_dense_compare(vsf, queries + (size_t)q * D, vecs + (size_t)i * D, D);
+}
+
 void jvo_sub(const float *a, const float *b, float *out, int n)
 {
     for (int i = 0; i < n; i++) out[i] = a[i] - b[i];

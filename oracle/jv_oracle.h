@@ -195,6 +195,10 @@ float jvs_adc_score(int vsf, int M, int k, const float *lut, const float *amag, 
  * the SIMD kernels above.  Returns the tier in effect.  Process-wide: set it before starting search threads. */
 int   jvo_set_simd(int on);
 
+/* ---- specification of the engine's MFMA tile form (ed_body.h): k-ascending fmaf chains; see jv_oracle.c ---- */
+float jvo_dense_compare(int vsf, const float *q, const float *v, int n);
+void  jvo_dense_scan(int vsf, const float *queries, int Q, const float *vecs, int64_t n, int D, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,8 +162,18 @@ def lib():
         sig("jvs_assemble_and_sum", C.c_float, fp, C.c_int, u8p, C.c_int)
         sig("jvs_pq_decoded_cosine", C.c_float, u8p, C.c_int, C.c_int, fp, fp, C.c_float)
         sig("jvo_set_simd", C.c_int, C.c_int)
+        sig("jvo_dense_compare", C.c_float, C.c_int, fp, fp, C.c_int)
+        sig("jvo_dense_scan", None, C.c_int, fp, C.c_int, fp, C.c_int64, C.c_int, fp)
         _lib = L
     return _lib
+
+
+def dense_scan(vsf, queries, vecs):
+    """Specification of the engine's MFMA tile form (jv_hip_exact_scan_dense): [Q, N] similarities, fused chains."""
+    queries, vecs = f32(queries), f32(vecs)
+    out = np.empty((queries.shape[0], vecs.shape[0]), np.float32)
+    lib().jvo_dense_scan(int(vsf), _f(queries), queries.shape[0], _f(vecs), vecs.shape[0], vecs.shape[1], _f(out))
+    return out
 
 
 def set_simd(on):

@@ -6,13 +6,13 @@ set -u
 mkdir -p gpurun_out/gs
 # device + host identification next to every number this run produces (record rocminfo beside the roofline peak)
 { /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock|Name: +gfx" | sort | uniq -c; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Flags" | sed 's/Flags:.*avx512f.*/Flags: ... avx512f .../'; nproc; } > gpurun_out/gs/machine.txt 2>&1
-export JVECTOR_TEST_DEVICE_TRAVERSAL=1 JVECTOR_TEST_BUILD_SCORE=1 JVECTOR_TEST_ANISOTROPIC=1 JVECTOR_TEST_PQ_TRAIN=1
+export JVECTOR_TEST_DEVICE_TRAVERSAL=1 JVECTOR_TEST_BUILD_SCORE=1 JVECTOR_TEST_ANISOTROPIC=1 JVECTOR_TEST_PQ_TRAIN=1 JVECTOR_TEST_DENSE=1
 # 0a. standalone canary (no Python / torch start-up): device traversal == host traversal on a random 200k-node graph, timed
 mkdir -p build && g++ -std=c++17 -O2 tools/gs_canary.cpp -o build/gs_canary -Ljvector_amd -ljvector_hip -Wl,-rpath,"$PWD/jvector_amd" > gpurun_out/gs/canary_build.log 2>&1  # (not `make canary`: no rebuild of the .so on the box)
 for v in 2 0 1; do timeout 120 build/gs_canary 200000 2048 32 100 3 $v 2>&1 | tail -2 | tee -a gpurun_out/gs/canary.log; done
 if ! grep -q '"identical": true' gpurun_out/gs/canary.log; then echo "standalone canary failed or hung: stopping"; exit 1; fi
-# 0. build-time scoring kernels (flat elementwise launches)
-timeout 300 python -m pytest tests/test_zz_build_score_gpu.py tests/test_zz_anisotropic_gpu.py tests/test_zz_pq_train_gpu.py -q 2>&1 | tail -8 | tee gpurun_out/gs/pytest_bs.log
+# 0. MFMA dense scan + build-time scoring kernels (flat launches, no persistent loops: cannot hang)
+timeout 300 python -m pytest tests/test_zz_exact_dense_gpu.py tests/test_zz_build_score_gpu.py tests/test_zz_anisotropic_gpu.py tests/test_zz_pq_train_gpu.py -q 2>&1 | tail -8 | tee gpurun_out/gs/pytest_bs.log
 # 0b. canary: the smallest traversal case under a short timeout, so a hang in the new kernel costs 3 minutes, not 10
 timeout 180 python -m pytest tests/test_zz_device_traversal_gpu.py -x -q -k "test_device_traversal_matches_oracle and 1-False-128-16" 2>&1 | tail -5 | tee gpurun_out/gs/pytest_canary.log
 if ! grep -q " passed" gpurun_out/gs/pytest_canary.log; then echo "canary failed: stopping"; exit 1; fi

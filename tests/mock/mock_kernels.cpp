@@ -32,11 +32,15 @@ static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
 static inline void gs_fence() {}
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
 static inline double bs_sqrt(double x) { return std::sqrt(x); }
+static inline float gs_fmaf(float a, float b, float c) { return fmaf(a, b, c); }
+typedef emu::f32x16 gs_f32x16;
+static inline gs_f32x16 gs_mfma_32x32x2(float a, float b, gs_f32x16 c) { return emu::mfma_32x32x2(a, b, c); }
 
 #include "../../jvector_amd/csrc/jv_device.h"
 #include "../../jvector_amd/csrc/jv_internal.h"
 
 #include "../../jvector_amd/csrc/bs_body.h"
+#include "../../jvector_amd/csrc/ed_body.h"
 #include "../../jvector_amd/csrc/gs_body.h"
 #include "../../jvector_amd/csrc/km_body.h"
 #include "../../oracle/jv_oracle.h"
@@ -170,6 +174,42 @@ int launch_exact_scan(hipStream_t, const jv_ctx *, const float *d_vecs, int D, c
     for (int q = 0; q < Q; ++q)
         for (int64_t i = 0; i < count; ++i)
             d_out[(int64_t)q * count + i] = jvo_compare(vsf, d_q + (size_t)q * D, d_vecs + (first + i) * D, D);
+    return JV_OK;
+}
+namespace {
+struct EdLaunch {
+    const EdParams *p;
+    int vsf;
+    int64_t n_tile;
+    int q_tile;
+    float *lds;
+};
+void ed_main(void *a)
+{
+    const EdLaunch &L = *(const EdLaunch *)a;
+    if (L.vsf == VSF_L2) ed_tile<VSF_L2>(*L.p, L.n_tile * ED_TN, L.q_tile * ED_TQ, L.lds);
+    else if (L.vsf == VSF_DOT) ed_tile<VSF_DOT>(*L.p, L.n_tile * ED_TN, L.q_tile * ED_TQ, L.lds);
+    else ed_tile<VSF_COS>(*L.p, L.n_tile * ED_TN, L.q_tile * ED_TQ, L.lds);
+}
+}  // namespace
+// the shared kernel body (ed_body.h) on the lane emulator, launch geometry of k_exact_dense.hip
+int launch_exact_scan_dense(hipStream_t, const float *d_vecs, int D, const float *d_q, int Q, int vsf, int64_t first, int64_t count,
+                            float *d_out)
+{
+    if (Q == 0 || count == 0) return JV_OK;
+    const EdParams p{d_vecs, d_q, d_out, first, count, D, Q};
+    const int64_t n_tiles = (count + ED_TN - 1) / ED_TN;
+    const int q_tiles = (Q + ED_TQ - 1) / ED_TQ;
+    const int64_t blocks_padded = (n_tiles * q_tiles + 7) / 8 * 8;
+    std::vector<float> lds((size_t)ED_LDS_FLOATS);
+    for (int64_t b = 0; b < blocks_padded; ++b) {
+        int64_t nt;
+        int qt;
+        if (!ed_block_to_tile(b, blocks_padded, n_tiles, q_tiles, &nt, &qt)) continue;
+        std::fill(lds.begin(), lds.end(), NAN);
+        EdLaunch L{&p, vsf, nt, qt, lds.data()};
+        emu::run_wave(ed_main, &L);
+    }
     return JV_OK;
 }
 int launch_frontier(hipStream_t, int vsf, const float *d_luts, const float *d_bmag, const int32_t *d_slot_query, const int32_t *d_origins,

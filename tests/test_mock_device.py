@@ -359,6 +359,13 @@ def test_searchers_on_random_irregular_graphs(J, ctx, traversal):
             assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag
 
 
+def test_dense_mfma_scan_through_the_c_abi(J, ctx):
+    """jv_hip_exact_scan_dense end to end on the mock: the shared kernel body on the lane emulator (documented MFMA
+    semantics) behind the real host entry point, staging and Python wrapper"""
+    import test_zz_exact_dense_gpu as T
+    T.run_dense_cases(J, ctx, shapes=((1, 1, 1), (5, 130, 7), (33, 129, 100), (40, 300, 64)))
+
+
 @pytest.mark.parametrize("traversal", ["host", "device"])
 def test_searchers_with_engineered_score_ties(J, ctx, traversal):
     import test_graph_search as T
