@@ -5,6 +5,7 @@
 #   graph : 1M graph mode, kernel-trace stats only                              (frontier kernel durations)
 #   fpmc  : frontier kernel FETCH_SIZE / WRITE_SIZE on a random 1M graph        (scripts/frontier_pmc.py)
 #   gsearch : device-resident traversal kernel on the same random 1M graph: kernel-trace stats, then FETCH/WRITE PMC
+#   dense : MFMA tile form of the exact scan, 256 x 1M x 768 (scripts/dense_pmc.py): kernel-trace stats, FETCH/WRITE, MFMA busy
 set -u
 WHAT=${1:-flat}; TAG=${2:-r1}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -34,6 +35,13 @@ gsearch)
   cp $O/stats/*kernel_stats.csv $K/ 2>/dev/null
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 150 rocprofv3 --pmc $C --output-format csv -d $O/$C -o gs -- python $R/scripts/frontier_pmc.py > $K/$C.log 2>&1
+    extract $C
+  done ;;
+dense)
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o dense -- python $R/scripts/dense_pmc.py > $K/stats.log 2>&1
+  cp $O/stats/*kernel_stats.csv $K/ 2>/dev/null
+  for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES; do
+    timeout 150 rocprofv3 --pmc $C --output-format csv -d $O/$C -o dense -- python $R/scripts/dense_pmc.py 64 > $K/$C.log 2>&1
     extract $C
   done ;;
 esac
