@@ -182,6 +182,8 @@ def main():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95")
     ap.add_argument("--eval-queries", type=int, default=1024, help="timed queries with ground truth (recall)")
+    ap.add_argument("--gt-dense", action="store_true", help="ground truth candidates from the MFMA dense scan, rescored by the "
+                    "bit-exact kernel (opt-in until the dense kernel has been validated on hardware)")
     ap.add_argument("--traversal", choices=["host", "device"], default=os.environ.get("JVECTOR_BENCH_TRAVERSAL", "host"),
                     help="graph mode: host batched searcher (default, hardware-verified) or the device-resident traversal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -249,7 +251,7 @@ def main():
 
     timed_q = queries_all[args.warmup * Q:]
     n_eval = min(args.eval_queries, timed_q.shape[0])
-    gt = ground_truth(J, ctx, vs, timed_q[:n_eval].contiguous(), VSF, K).cpu().numpy()
+    gt = ground_truth(J, ctx, vs, timed_q[:n_eval].contiguous(), VSF, K, dense=args.gt_dense).cpu().numpy()
 
     # rerankK: smallest rung reaching recall@10 >= 0.95 on the evaluated timed queries (calibration is untimed)
     ladder = [args.rerank] if args.rerank > 0 else [50, 100, 150, 200, 300, 400, 600, 800, 1600]

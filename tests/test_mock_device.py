@@ -359,6 +359,20 @@ def test_searchers_on_random_irregular_graphs(J, ctx, traversal):
             assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag
 
 
+def test_ground_truth_from_dense_candidates_equals_the_exact_one(J, ctx):
+    """benchlib.ground_truth(dense=True): MFMA-scan candidates + bit-exact rescoring == the all-bit-exact ground truth"""
+    import torch
+    import benchlib
+    rng = np.random.default_rng(12)
+    v = rng.standard_normal((700, 40)).astype(np.float32)
+    q = (v[rng.integers(0, 700, 9)] + 0.1 * rng.standard_normal((9, 40))).astype(np.float32)
+    vs = J.VectorSet(ctx, v)
+    for vsf in J.VectorSimilarityFunction:
+        a = benchlib.ground_truth(J, ctx, vs, torch.from_numpy(q), vsf, 10, chunk=256)
+        b = benchlib.ground_truth(J, ctx, vs, torch.from_numpy(q), vsf, 10, chunk=256, dense=True)
+        assert np.array_equal(np.asarray(a), np.asarray(b)), vsf
+
+
 def test_dense_mfma_scan_through_the_c_abi(J, ctx):
     """jv_hip_exact_scan_dense end to end on the mock: the shared kernel body on the lane emulator (documented MFMA
     semantics) behind the real host entry point, staging and Python wrapper"""
