@@ -51,7 +51,27 @@ GS_FN float ed_finish(float dot, float qn, float vn)
     return (1.0f + dot) / 2.0f;
 }
 
+// Global loads of K columns kb .. kb + 32 of both tiles into registers (zero beyond D / Q / count: a zero product leaves a
+// chain as is).  Element (row = (lane >> 5) + 2 i, column = lane & 31): a half wave reads one 128-byte row segment; addresses
+// are a block-uniform base plus one 32-bit lane offset, and row pairs advance by a uniform 2 D.
+GS_FN void ed_load_chunk(const EdParams &p, int64_t n0, int q0, int kb, int lane, float (&ra)[16], float (&rb)[64])
+{
+    const int rl = lane >> 5, cl = lane & 31;
+    const bool k_ok = kb + cl < p.D;
+    const int lane_off = rl * p.D + cl;
+    const float *qbase = p.queries + (int64_t)q0 * p.D + kb;
+    const float *vbase = p.vecs + (p.first + n0) * p.D + kb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)  // query tile: 32 rows
+        ra[i] = (k_ok && q0 + rl + 2 * i < p.Q) ? (qbase + (int64_t)(2 * i) * p.D)[lane_off] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i)  // vector tile: 128 rows
+        rb[i] = (k_ok && n0 + rl + 2 * i < p.count) ? (vbase + (int64_t)(2 * i) * p.D)[lane_off] : 0.0f;
+}
+
 // tile (n0 .. n0 + 128) x (q0 .. q0 + 32); n0 is relative to p.first.  lds: ED_LDS_FLOATS floats.
+// Two-stage pipeline: the loads of chunk c + 1 are issued right after chunk c has been stored to LDS, so they are in flight
+// while chunk c's norms and 64 MFMAs run; one resident wave per SIMD already overlaps memory latency with the matrix pipe.
 template <int VSF>
 GS_FN void ed_tile(const EdParams &p, int64_t n0, int q0, float *lds)
 {
@@ -60,30 +80,19 @@ GS_FN void ed_tile(const EdParams &p, int64_t n0, int q0, float *lds)
     float *As = lds, *Bs = As + ED_TQ * ED_LD, *qn = Bs + ED_TN * ED_LD, *vn = qn + ED_TQ;
     gs_f32x16 acc[4] = {};
     float nq = 0.0f, nv0 = 0.0f, nv1 = 0.0f;  // |q|^2 of tile row `lane` (lanes < 32), |v|^2 of tile rows lane, lane + 64
+    float ra[16], rb[64];
+    ed_load_chunk(p, n0, q0, 0, lane, ra, rb);
 
     for (int kb = 0; kb < p.D; kb += ED_KB) {
-        // ---- stage K columns kb .. kb + 32 of both tiles (zero beyond D / Q / count: a zero product leaves a chain as is) ----
-        // Element e = lane + 64 i of a tile chunk is (row = (lane >> 5) + 2 i, column = lane & 31): a half wave reads one
-        // 128-byte row segment.  Addresses are a block-uniform base plus a 32-bit lane offset.
-        const int rl = lane >> 5, cl = lane & 31;
-        const bool k_ok = kb + cl < p.D;
-        const int lane_off = rl * p.D + cl;        // the only per-lane address term; row pairs advance by a uniform 2 D
         {
-            const float *qbase = p.queries + (int64_t)q0 * p.D + kb;
-            const float *vbase = p.vecs + (p.first + n0) * p.D + kb;
-            float ra[16], rb[64];           // all 80 loads of the chunk are issued before the first wait
-#pragma unroll
-            for (int i = 0; i < 16; ++i)    // query tile: 32 rows
-                ra[i] = (k_ok && q0 + rl + 2 * i < p.Q) ? (qbase + (int64_t)(2 * i) * p.D)[lane_off] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 64; ++i)    // vector tile: 128 rows
-                rb[i] = (k_ok && n0 + rl + 2 * i < p.count) ? (vbase + (int64_t)(2 * i) * p.D)[lane_off] : 0.0f;
+            const int rl = lane >> 5, cl = lane & 31;
 #pragma unroll
             for (int i = 0; i < 16; ++i) As[(rl + 2 * i) * ED_LD + cl] = ra[i];
 #pragma unroll
             for (int i = 0; i < 64; ++i) Bs[(rl + 2 * i) * ED_LD + cl] = rb[i];
         }
         gs_barrier();
+        if (kb + ED_KB < p.D) ed_load_chunk(p, n0, q0, kb + ED_KB, lane, ra, rb);  // prefetch: consumed after the MFMAs
         if (VSF != 1 /* not DOT: the norms */) {
 #pragma unroll 4
             for (int c = 0; c < ED_KB; ++c) {

@@ -1,7 +1,8 @@
 // k_exact_dense.hip — MFMA tile form of full-resolution scoring (dense Q x N form).  Body and the
 // arithmetic contract in ed_body.h.  Roofline: MFMA f32 (157 TF peak; 2·Q·N·D flop) once Q >= ~64, HBM (4·D bytes per
-// vector, read once per 32-query tile row that misses L2) below that.  Launch: one wavefront per block, 21.7 KB LDS ->
-// 7 blocks per CU; four independent 32x32 accumulators per wave keep the 64-cycle MFMA issue slot full.
+// vector, read once per 32-query tile row that misses L2) below that.  Launch: one wavefront per block, 21.7 KB LDS,
+// 202 VGPRs -> 2 waves per SIMD; four independent 32x32 accumulators per wave keep the 64-cycle MFMA issue slot full and
+// the next chunk's global loads are in flight under them (two-stage pipeline, ed_body.h).
 #include "gs_wave_hip.h"
 #include "jv_internal.h"
 
