@@ -45,6 +45,8 @@ void run_ch(const Launch &L)
     case 3: jv::gs_worker<VSF, 3, PAIR>(*L.p, L.worker, L.lds); break;
     case 4: jv::gs_worker<VSF, 4, PAIR>(*L.p, L.worker, L.lds); break;
     case 6: jv::gs_worker<VSF, 6, PAIR>(*L.p, L.worker, L.lds); break;
+    case 8: jv::gs_worker<VSF, 8, PAIR>(*L.p, L.worker, L.lds); break;
+    case 12: jv::gs_worker<VSF, 12, PAIR>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }

@@ -402,8 +402,9 @@ int launch_km_finish_round(hipStream_t, const KmParams &p)
 // ---- device-resident traversal: gs_body.h on the lane emulator ----
 bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels)
 {
-    const int ch = pq->M / 16;  // the same predicate as k_gsearch.hip (emulated instantiations: M in {16,...,96})
-    return pq->uniform && pq->max_size == 8 && pq->k == kClusters && pq->M % 16 == 0 && (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6) &&
+    const int ch = pq->M / 16;  // the same predicate as k_gsearch.hip
+    return pq->uniform && pq->max_size == 8 && pq->k == kClusters && pq->M % 16 == 0 &&
+           (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8 || ch == 12) &&
            pq->D == 8 * pq->M && (reinterpret_cast<uintptr_t>(codes->d_codes) & 15) == 0 &&
            (!fused || (reinterpret_cast<uintptr_t>(fused->d_blocks) & 15) == 0) && max_degree <= 64 && n_levels <= GS_MAX_LEVELS;
 }
@@ -423,6 +424,8 @@ void gs_run_ch(const GsLaunch &L)
     case 3: gs_worker<VSF, 3, PAIR>(*L.p, L.worker, L.lds); break;
     case 4: gs_worker<VSF, 4, PAIR>(*L.p, L.worker, L.lds); break;
     case 6: gs_worker<VSF, 6, PAIR>(*L.p, L.worker, L.lds); break;
+    case 8: gs_worker<VSF, 8, PAIR>(*L.p, L.worker, L.lds); break;
+    case 12: gs_worker<VSF, 12, PAIR>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }

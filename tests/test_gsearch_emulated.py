@@ -110,7 +110,8 @@ def test_level_map_lookup(emu):
     assert emu.gs_emu_level_lookup(p, 5000, missing) == -1
 
 
-@pytest.mark.parametrize("levels,fused,M", [(1, False, 16), (2, True, 16), (3, True, 32), (2, False, 48)])
+@pytest.mark.parametrize("levels,fused,M", [(1, False, 16), (2, True, 16), (3, True, 32), (2, False, 48), (2, True, 64),
+                                            (2, True, 96), (1, False, 128), (2, True, 192)])  # every CH16 the kernel is built for
 def test_emulated_kernel_matches_oracle(emu, levels, fused, M):
     D = 8 * M
     lv, entry, entry_level, opq, codes, q = problem(100 + levels + M, 2500, D, M, levels)

@@ -359,6 +359,28 @@ def test_searchers_on_random_irregular_graphs(J, ctx, traversal):
             assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag
 
 
+@pytest.mark.parametrize("M", [48, 64, 96, 128, 192])
+def test_device_traversal_driver_at_every_supported_M(J, ctx, M):
+    """the device-traversal DRIVER (LDS sizing with / without the pair-lane exchange area — pair form only up to M = 96 —
+    kernel instantiation per M / 16) through the C ABI, against the oracle, FusedPQ cosine as in the headline configuration"""
+    from oracle import oracle as O
+    import test_graph_search as T
+    D = 8 * M
+    v, lv, entry, entry_level, cb, q = T.build_problem(M, N=600, D=D, M=M, deg=32, levels=2)
+    N = v.shape[0]
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal("device")
+    fused = J.FusedPQ(ctx, pq, T.fused_blocks(codes, lv[0][1]), lv[0][1])
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=8)
+    ids, sc, st = s.search(q[:6], J.VectorSimilarityFunction.COSINE, 10, 50, return_stats=True)
+    wi, ws, wst = O.OracleGraph(N, lv, entry, entry_level).search(opq, codes, v, q[:6], O.COSINE, 10, 50, fused=True)
+    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+
+
 def test_ground_truth_from_dense_candidates_equals_the_exact_one(J, ctx):
     """benchlib.ground_truth(dense=True): MFMA-scan candidates + bit-exact rescoring == the all-bit-exact ground truth"""
     import torch
