@@ -39,7 +39,8 @@ def _setup(ctx, seed, N, D, M, levels, use_fused, deg=16):
 
 
 @pytest.mark.parametrize("levels,use_fused,D,M", [(1, False, 128, 16), (2, True, 128, 16), (3, True, 256, 32),
-                                                  (2, False, 384, 48), (2, True, 768, 96)])
+                                                  (2, False, 384, 48), (2, True, 512, 64), (2, True, 768, 96),
+                                                  (1, False, 1024, 128), (2, True, 1536, 192)])  # every built M
 def test_device_traversal_matches_oracle(ctx, levels, use_fused, D, M):
     v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 31 * levels + M, 5000, D, M, levels, use_fused)
     og = O.OracleGraph(len(v), lv, entry, entry_level)
