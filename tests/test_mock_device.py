@@ -381,6 +381,26 @@ def test_device_traversal_driver_at_every_supported_M(J, ctx, M):
     assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
 
 
+def test_device_traversal_refuses_a_rerank_k_that_does_not_fit_lds(J, ctx):
+    """the result heap lives in LDS: a rerankK whose queues exceed the per-block limit is refused (not silently truncated),
+    and the host traversal serves the same request"""
+    from oracle import oracle as O
+    import test_graph_search as T
+    import jvector_amd._lib as L
+    v, lv, entry, entry_level, cb, q = T.build_problem(77, N=400, D=128, M=16, deg=8, levels=1)
+    pq = J.ProductQuantization.from_codebooks(ctx, 128, 16, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    graph = J.GraphIndex(ctx, 400, lv, entry, entry_level).set_traversal("device")
+    s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=4)
+    with pytest.raises(L.UnsupportedError, match="LDS"):
+        s.search(q[:2], J.VectorSimilarityFunction.COSINE, 10, 30000)
+    graph.set_traversal("host")
+    ids, sc = s.search(q[:2], J.VectorSimilarityFunction.COSINE, 10, 30000)
+    wi, ws, _ = O.OracleGraph(400, lv, entry, entry_level).search(O.OraclePQ(128, 16, cb), cv.get(0, 400), v, q[:2], O.COSINE, 10, 30000)
+    assert np.array_equal(np.asarray(ids), wi) and np.array_equal(np.asarray(sc), ws)
+
+
 def test_ground_truth_from_dense_candidates_equals_the_exact_one(J, ctx):
     """benchlib.ground_truth(dense=True): MFMA-scan candidates + bit-exact rescoring == the all-bit-exact ground truth"""
     import torch
