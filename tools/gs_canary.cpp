@@ -87,12 +87,13 @@ int main(int argc, char **argv)
         const double ms = now_ms() - t0;
         if (ms < best) best = ms;
     }
+    if (iters <= 0) best = 0.0;
     const bool same = ids_h == ids_d && !memcmp(sc_h.data(), sc_d.data(), sizeof(float) * sc_h.size()) && st_h == st_d;
     double expanded = 0;
     for (int q = 0; q < Q; ++q) expanded += (double)st_h[2 * q + 1];
     printf("{\"identical\": %s, \"N\": %lld, \"Q\": %d, \"degree\": %d, \"rerankK\": %d, \"vsf\": %d, \"avg_expanded\": %.1f, "
            "\"host_ms\": %.2f, \"device_ms\": %.2f, \"host_qps\": %.0f, \"device_qps\": %.0f, \"arch\": \"%s\"}\n",
-           same ? "true" : "false", (long long)N, Q, deg, rerankK, (int)vsf, expanded / Q, host_ms, best, Q / host_ms * 1e3, Q / best * 1e3,
+           same ? "true" : "false", (long long)N, Q, deg, rerankK, (int)vsf, expanded / Q, host_ms, best, Q / host_ms * 1e3, best > 0 ? Q / best * 1e3 : 0.0,
            jv_hip_active_arch(0));
     jv_hip_luts_destroy(luts);
     jv_hip_graph_destroy(g);
