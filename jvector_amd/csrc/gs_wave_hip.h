@@ -23,3 +23,9 @@ __device__ __forceinline__ gs_f32x16 gs_mfma_32x32x2(float a, float b, gs_f32x16
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float gs_fmaf(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// km_body.h: every lane receives the 64 values of the wave (64 v_readlane_b32; the results are wave-uniform)
+__device__ __forceinline__ void gs_gather64(float v, float (&out)[64])
+{
+#pragma unroll
+    for (int i = 0; i < 64; ++i) out[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+}

@@ -12,12 +12,12 @@
 //   km_assign     thread (point, m): getNearestCluster (strict <, first minimum).
 //   km_centroids  thread (m, c): scale(centroidNums, 1.0f / denom).
 //   km_pp_init    one wavefront per subspace: k-means++ seeding; the distance refresh is lane-parallel, the
-//                 sequential prefix scan that picks the next centroid (sum, then r -= d[j] until r < 1e-6) is done by
-//                 lane 0 in the reference's order.
+//                 sequential prefix scan that picks the next centroid (sum, then r -= d[j] until r < 1e-6) is one chain in
+//                 the reference's order that every lane runs on values broadcast 64 at a time (gs_gather64).
 // ThreadLocalRandom cannot be reproduced; a seeded splitmix64 stream per subspace replaces it (the CPU
 // checker under tests/ makes the same substitution), so both agree bit for bit for a given seed.
 // Per-thread bodies need KM_FN; km_pp_init additionally needs the wave API of gs_body.h (GS_FN, gs_lane, gs_barrier,
-// gs_shfl, gs_fence).  The anisotropic k-means variants are not built.
+// gs_gather64, gs_fence).  The anisotropic k-means variants are not built.
 #pragma once
 
 #include <cstdint>
@@ -352,27 +352,41 @@ GS_FN void km_pp_init(const KmParams &p, int m)
     float *dist = p.dist + (int64_t)m * p.n;
     float *C = p.C + p.cb_offsets[m];
     for (int64_t j = lane; j < p.n; j += 64) dist[j] = KM_FLT_MAX;
+    // The sequential part (sum of the distances, then r -= d[j] until r < 1e-6, KMeansPlusPlusClusterer.java:139-156) is
+    // order dependent, so it stays one chain — but every lane runs the same chain on values broadcast 64 at a time
+    // (gs_gather64: one coalesced load per 64 distances instead of 64 dependent single-lane loads), which keeps all state
+    // wave-uniform: no lane 0 special case, no shuffle of the result.
     uint64_t s = p.rng[m];
-    long long sel = 0;
-    if (lane == 0) sel = km_rng_int(&s, p.n);
+    int64_t sel = km_rng_int(&s, p.n);
     for (int c = 0; c < p.k; ++c) {
         gs_fence();
         gs_barrier();
-        if (c > 0 && lane == 0) {
+        if (c > 0) {
             float total = 0.0f;
-            for (int64_t j = 0; j < p.n; ++j) total += dist[j];
+            for (int64_t base = 0; base < p.n; base += 64) {
+                float blk[64];
+                gs_gather64(base + lane < p.n ? dist[base + lane] : 0.0f, blk);
+                const int cnt = (int)(p.n - base < 64 ? p.n - base : 64);
+#pragma unroll
+                for (int i = 0; i < 64; ++i)
+                    if (i < cnt) total += blk[i];
+            }
             float r = km_rng_float(&s) * total;
             sel = -1;
-            for (int64_t j = 0; j < p.n; ++j) {
-                r -= dist[j];
-                if ((double)r < 1e-6) {
-                    sel = j;
-                    break;
+            for (int64_t base = 0; base < p.n && sel < 0; base += 64) {
+                float blk[64];
+                gs_gather64(base + lane < p.n ? dist[base + lane] : 0.0f, blk);
+                const int cnt = (int)(p.n - base < 64 ? p.n - base : 64);
+#pragma unroll
+                for (int i = 0; i < 64; ++i) {
+                    if (sel < 0 && i < cnt) {
+                        r -= blk[i];
+                        if ((double)r < 1e-6) sel = base + i;
+                    }
                 }
             }
             if (sel == -1) sel = km_rng_int(&s, p.n);
         }
-        sel = gs_shfl(sel, 0);
         const float *x = p.X + sel * p.D + off;
         float *cc = C + (int64_t)c * len;
         for (int j = lane; j < len; j += 64) cc[j] = x[j];

@@ -201,6 +201,17 @@ inline long long shfl(long long v, int src)
 }
 
 
+// every lane receives the 64 values of the wave (lanes that have exited contribute 0)
+inline void gather64(float v, float (&out)[WAVE])
+{
+    Wave &w = *current();
+    static float G[WAVE];  // one wave runs at a time
+    G[w.cur] = v;
+    barrier();
+    for (int i = 0; i < WAVE; ++i) out[i] = w.done[i] ? 0.0f : G[i];
+    barrier();
+}
+
 // v_mfma_f32_32x32x2_f32 as the hardware defines it (cdna_hip_programming.md §3): lane l supplies A[i = l & 31][k = l >> 5]
 // and B[k = l >> 5][j = l & 31]; lane l's accumulator register r holds D[i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][j = l & 31];
 // D = fma(A[i][1], B[1][j], fma(A[i][0], B[0][j], C)) — a k-ordered f32 fmaf chain, no wider internal accumulation.

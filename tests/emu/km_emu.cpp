@@ -11,6 +11,7 @@ static inline int gs_lane() { return emu::lane(); }
 static inline void gs_barrier() { emu::barrier(); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline void gs_fence() {}
+static inline void gs_gather64(float v, float (&out)[64]) { emu::gather64(v, out); }
 
 #include "../../jvector_amd/csrc/km_body.h"
 

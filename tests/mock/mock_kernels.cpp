@@ -30,6 +30,7 @@ static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
     return old;
 }
 static inline void gs_fence() {}
+static inline void gs_gather64(float v, float (&out)[64]) { emu::gather64(v, out); }
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
 static inline double bs_sqrt(double x) { return std::sqrt(x); }
 static inline float gs_fmaf(float a, float b, float c) { return fmaf(a, b, c); }
