@@ -184,8 +184,9 @@ def main():
     ap.add_argument("--eval-queries", type=int, default=1024, help="timed queries with ground truth (recall)")
     ap.add_argument("--gt-dense", action="store_true", help="ground truth candidates from the MFMA dense scan, rescored by the "
                     "bit-exact kernel (opt-in until the dense kernel has been validated on hardware)")
-    ap.add_argument("--traversal", choices=["host", "device"], default=os.environ.get("JVECTOR_BENCH_TRAVERSAL", "host"),
-                    help="graph mode: host batched searcher (default, hardware-verified) or the device-resident traversal")
+    ap.add_argument("--traversal", choices=["host", "device"], default=os.environ.get("JVECTOR_BENCH_TRAVERSAL", "device"),
+                    help="graph mode: device-resident traversal (default; what JV_TRAVERSAL_AUTO picks at this shape) or the "
+                         "host batched searcher")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat", action="store_true", help="graph mode: skip the secondary flat-scan measurement")
     args = ap.parse_args()

@@ -88,7 +88,10 @@ JV_API int jv_fmt_odgi_describe(const uint8_t *buf, size_t len, jv_odgi_info *in
  *   neighbors : id_upper_bound x degree0 int32, packed, padded with -1 (what jv_hip_graph_set_level takes)
  *   vectors   : id_upper_bound x D float32 (inline, else separated vectors; JV_ERR_INVALID if neither is present)
  *   fused     : id_upper_bound x degree0 x M bytes (what jv_hip_fused_upload takes)
- * Records whose stored ordinal differs from their position are rejected (the reference asserts the same). */
+ * The stored ordinal is a writer-side sanity value the reference's reader never reads: a record is accepted when it
+ * carries its own position (NodeRecordTask, and the sequential writer for live nodes) or -1, the sequential writer's
+ * placeholder for an ordinal its OrdinalMapper OMITTED (OnDiskGraphIndexWriter.java:101-110; the feature bytes of such a
+ * record are seek-skipped, i.e. unspecified) — a placeholder yields no neighbours and zeroed vector / fused bytes. */
 JV_API int jv_fmt_odgi_read_l0(const uint8_t *buf, size_t len, const jv_odgi_info *info, int32_t *neighbors,
                                float *vectors, uint8_t *fused);
 

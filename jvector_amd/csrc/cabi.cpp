@@ -9,6 +9,7 @@
 
 #include "jv_device.h"
 #include "jv_internal.h"
+#include "../../include/jvector_formats.h"
 
 namespace jv {
 
@@ -419,6 +420,14 @@ int jv_hip_pq_load(jv_ctx *ctx, const uint8_t *buf, size_t len, size_t *consumed
 {
     clear_error();
     JV_REQUIRE(ctx && buf && out, "pq_load: NULL argument");
+    // One validator for the format: jv_fmt_pq_describe (formats.cpp pq_walk) bounds version <= 6, every sub-vector size
+    // < 2^20, D < 2^24 (64-bit sum), k, and checks that every section lies inside the input; the walk below only copies.
+    {
+        size_t blk = 0;
+        int ver = 0, dD = 0, dM = 0, dk = 0, hc = 0;
+        float an = -1.0f;
+        JV_TRY(jv_fmt_pq_describe(buf, len, &blk, &ver, &dD, &dM, &dk, &hc, &an));
+    }
     // ProductQuantization.load :649-693
     size_t p = 0;
 #define NEED(nb) JV_REQUIRE(p + (size_t)(nb) <= len, "pq_load: truncated input at byte %zu", p)
@@ -895,6 +904,7 @@ int jv_hip_fused_upload(jv_ctx *ctx, jv_fused *f, int64_t first, int64_t count, 
                                 sizeof(int32_t) * (size_t)count * f->maxDegree, hipMemcpyDefault, ctx->stream));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     f->norms_valid = false;
+    f->generation++;
     return JV_OK;
 }
 

@@ -348,8 +348,18 @@ int jv_fmt_odgi_read_l0(const uint8_t *buf, size_t len, const jv_odgi_info *o, i
     const size_t fused_bytes = (size_t)deg * (size_t)o->pq_M;
     for (int64_t i = 0; i < N; ++i) {
         const uint8_t *rec = buf + o->l0_off + i * o->record_stride;
+        // The stored ordinal is a writer-side sanity value the reference's reader never looks at.  The sequential
+        // writer emits -1 for an ordinal the OrdinalMapper OMITTED (OnDiskGraphIndexWriter.java:101-110: feature bytes
+        // seek-skipped = unspecified, count 0, -1 padding): such a record is a hole — no neighbours, zeroed features.
         int32_t ord = be32(rec);
-        JV_REQUIRE(ord == (int32_t)i, "odgi_read_l0: record %lld carries ordinal %d", (long long)i, ord);
+        JV_REQUIRE(ord == (int32_t)i || ord == -1, "odgi_read_l0: record %lld carries ordinal %d", (long long)i, ord);
+        if (ord == -1) {
+            if (vectors && o->inline_vectors_off >= 0) memset(vectors + i * D, 0, (size_t)D * sizeof(float));
+            if (fused) memset(fused + (size_t)i * fused_bytes, 0, fused_bytes);
+            if (neighbors)
+                for (int j = 0; j < deg; ++j) neighbors[i * deg + j] = -1;
+            continue;
+        }
         if (vectors && o->inline_vectors_off >= 0) copy_be32(vectors + i * D, rec + o->inline_vectors_off, (size_t)D);
         if (fused) memcpy(fused + (size_t)i * fused_bytes, rec + o->fused_off, fused_bytes);
         if (neighbors) {

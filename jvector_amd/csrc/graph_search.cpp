@@ -346,16 +346,24 @@ struct jv_graph {
     bool dev_ready = false;
     int dev_device = -1;
     int traversal = JV_TRAVERSAL_AUTO;
-    ~jv_graph()
+    // drop the device mirror (graph mutated, upload failed midway, or destruction); caller holds dev_mu or owns the graph
+    void free_mirror()
     {
-        if (dev.empty()) return;
-        (void)hipSetDevice(dev_device);
-        for (DevLevel &d : dev) {
-            (void)hipFree(d.nbrs);
-            (void)hipFree(d.hkeys);
-            (void)hipFree(d.hvals);
+        if (!dev.empty() && dev_device >= 0) {
+            (void)hipSetDevice(dev_device);
+            for (DevLevel &d : dev) {
+                (void)hipFree(d.nbrs);
+                (void)hipFree(d.hkeys);
+                (void)hipFree(d.hvals);
+            }
         }
+        dev.clear();
+        dev_ready = false;
+        fused_checked = nullptr;
     }
+    const void *fused_checked = nullptr;  // the jv_fused whose neighbour table was last compared with level 0's adjacency
+    uint64_t fused_checked_gen = 0;
+    ~jv_graph() { free_mirror(); }
     const int32_t *row(int level, int32_t node) const
     {
         const Level &L = levels[level];
@@ -390,15 +398,22 @@ int jv_hip_graph_set_level(jv_ctx *ctx, jv_graph *g, int level, int count, const
     JV_REQUIRE(count > 0 && degree > 0 && degree < 2048, "graph_set_level: bad count/degree");
     JV_REQUIRE(level > 0 || (node_ids == nullptr && count == g->n_nodes), "graph_set_level: level 0 holds every node");
     JV_REQUIRE(!is_device_ptr(neighbors) && !is_device_ptr(node_ids), "graph_set_level: adjacency must be host memory");
+    // every kernel and the host searcher index code / vector / visited tables with these ids unchecked: validate once here
+    for (size_t i = 0, n = (size_t)count * degree; i < n; ++i)
+        JV_REQUIRE(neighbors[i] >= -1 && neighbors[i] < g->n_nodes, "graph_set_level: level %d row %zu holds neighbour id %d (n_nodes %lld)",
+                   level, i / degree, neighbors[i], (long long)g->n_nodes);
+    if (node_ids) {
+        JV_REQUIRE(std::is_sorted(node_ids, node_ids + count), "graph_set_level: node ids must be ascending");
+        JV_REQUIRE(node_ids[0] >= 0 && node_ids[count - 1] < g->n_nodes, "graph_set_level: node id out of range");
+    }
+    std::lock_guard<std::mutex> lk(g->dev_mu);
+    g->free_mirror();  // a search may already have built the device mirror: it is stale now
     jv_graph::Level &L = g->levels[level];
     L.count = count;
     L.degree = degree;
     L.nbrs.assign(neighbors, neighbors + (size_t)count * degree);
     L.nodes.clear();
-    if (node_ids) {
-        L.nodes.assign(node_ids, node_ids + count);
-        JV_REQUIRE(std::is_sorted(L.nodes.begin(), L.nodes.end()), "graph_set_level: node ids must be ascending");
-    }
+    if (node_ids) L.nodes.assign(node_ids, node_ids + count);
     return JV_OK;
 }
 
@@ -407,6 +422,8 @@ int jv_hip_graph_set_entry(jv_graph *g, int32_t node, int level)
     clear_error();
     JV_REQUIRE(g, "graph_set_entry: NULL graph");
     JV_REQUIRE(node >= 0 && node < g->n_nodes && level >= 0 && level < g->n_levels, "graph_set_entry: out of range");
+    std::lock_guard<std::mutex> lk(g->dev_mu);
+    g->free_mirror();  // the mirror covers levels 0..entry_level of the graph it was built from
     g->entry_node = node;
     g->entry_level = level;
     return JV_OK;
@@ -425,6 +442,33 @@ int jv_hip_graph_set_traversal(jv_graph *g, int mode)
     JV_REQUIRE(mode == JV_TRAVERSAL_AUTO || mode == JV_TRAVERSAL_HOST || mode == JV_TRAVERSAL_DEVICE,
                "graph_set_traversal: unknown mode %d", mode);
     g->traversal = mode;
+    return JV_OK;
+}
+
+// The fused layer-0 path takes neighbour IDS from the graph's level-0 adjacency and SCORES from slot i of the FusedPQ
+// block: a FusedPQ written from a different (or reordered) adjacency would silently pair the wrong score with each id.
+// Compared once per (graph, fused object, upload generation), in 16 MB pieces.
+static int check_fused_matches_graph(jv_ctx *ctx, jv_graph *g, const jv_fused *fused)
+{
+    std::lock_guard<std::mutex> lk(g->dev_mu);
+    if (g->fused_checked == (const void *)fused && g->fused_checked_gen == fused->generation) return JV_OK;
+    const std::vector<int32_t> &nb = g->levels[0].nbrs;
+    const size_t total = nb.size(), piece = (size_t)4 << 20;
+    std::vector<int32_t> tmp(std::min(total, piece));
+    for (size_t off = 0; off < total; off += piece) {
+        const size_t n = std::min(piece, total - off);
+        JV_HIP_CHECK(hipMemcpy(tmp.data(), fused->d_neighbors + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        if (memcmp(tmp.data(), nb.data() + off, sizeof(int32_t) * n) != 0) {
+            size_t i = 0;
+            while (tmp[i] == nb[off + i]) ++i;
+            const int deg = g->levels[0].degree;
+            set_error("graph_search: the FusedPQ blocks were written from a different adjacency than the graph's level 0 (node %zu slot %zu: "
+                      "fused %d, graph %d)", (off + i) / deg, (off + i) % deg, tmp[i], nb[off + i]);
+            return JV_ERR_INVALID;
+        }
+    }
+    g->fused_checked = fused;
+    g->fused_checked_gen = fused->generation;
     return JV_OK;
 }
 
@@ -826,6 +870,7 @@ static int ensure_device_graph(jv_ctx *ctx, jv_graph *g)
                    g->dev_device, ctx->device);
         return JV_OK;
     }
+    g->free_mirror();  // leftovers of an upload that failed midway
     g->dev_device = ctx->device;
     g->dev.resize((size_t)g->entry_level + 1);
     auto upload = [&](int32_t **dst, const int32_t *src, size_t n) -> int {
@@ -833,17 +878,25 @@ static int ensure_device_graph(jv_ctx *ctx, jv_graph *g)
         JV_HIP_CHECK(hipMemcpy(*dst, src, sizeof(int32_t) * n, hipMemcpyHostToDevice));
         return JV_OK;
     };
-    for (int lv = 0; lv <= g->entry_level; ++lv) {
-        const jv_graph::Level &L = g->levels[lv];
-        jv_graph::DevLevel &d = g->dev[lv];
-        JV_TRY(upload(&d.nbrs, L.nbrs.data(), L.nbrs.size()));
-        if (!L.nodes.empty()) {
-            const GsLevelMap m = gs_build_level_map(L.nodes.data(), L.count);
-            JV_TRY(upload(&d.hkeys, m.keys.data(), m.keys.size()));
-            JV_TRY(upload(&d.hvals, m.vals.data(), m.vals.size()));
-            d.hmask = m.mask;
-            d.hshift = m.shift;
+    auto build = [&]() -> int {
+        for (int lv = 0; lv <= g->entry_level; ++lv) {
+            const jv_graph::Level &L = g->levels[lv];
+            jv_graph::DevLevel &d = g->dev[lv];
+            JV_TRY(upload(&d.nbrs, L.nbrs.data(), L.nbrs.size()));
+            if (!L.nodes.empty()) {
+                const GsLevelMap m = gs_build_level_map(L.nodes.data(), L.count);
+                JV_TRY(upload(&d.hkeys, m.keys.data(), m.keys.size()));
+                JV_TRY(upload(&d.hvals, m.vals.data(), m.vals.size()));
+                d.hmask = m.mask;
+                d.hshift = m.shift;
+            }
         }
+        return JV_OK;
+    };
+    const int rc = build();
+    if (rc != JV_OK) {
+        g->free_mirror();
+        return rc;
     }
     g->dev_ready = true;
     return JV_OK;
@@ -1051,13 +1104,23 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
 {
     clear_error();
     JV_REQUIRE(ctx && g && l && codes, "graph_search: NULL argument");
-    // Traversal: the graph's setting, overridden by JVECTOR_HIP_GRAPH_TRAVERSAL=host|device.  AUTO is the host
-    // traversal until the device kernel has been validated on hardware (it was written after this round's GPU budget
-    // was spent; tests/test_gsearch_emulated.py checks its logic on a CPU lane emulator).
+    CtxBusy busy(ctx);
+    JV_REQUIRE(busy.ok, "graph_search: this jv_ctx is already inside a call on another thread (one context per host thread)");
+    // Traversal: the graph's setting, overridden by JVECTOR_HIP_GRAPH_TRAVERSAL=host|device.  AUTO = the device-resident
+    // traversal wherever it applies (uniform 8-dim sub-vectors, supported M / degree, queues fit LDS — validated on
+    // MI355X in round 2, 7-8x the host searcher's throughput), the host searcher for every other shape.
     int mode = g->traversal;
     if (const char *e = getenv("JVECTOR_HIP_GRAPH_TRAVERSAL")) {
         if (!strcmp(e, "device")) mode = JV_TRAVERSAL_DEVICE;
         else if (!strcmp(e, "host")) mode = JV_TRAVERSAL_HOST;
+    }
+    if (mode == JV_TRAVERSAL_AUTO) {
+        int Wd = 0;
+        for (int lv = 0; lv <= g->entry_level && lv < (int)g->levels.size(); ++lv) Wd = std::max(Wd, g->levels[lv].degree);
+        const bool fits = g->entry_node >= 0 && rerankK > 0 && l->pq && codes->pq == l->pq &&
+                          graph_search_device_supported(l->pq, codes, fused, Wd, g->entry_level + 1) &&
+                          graph_search_lds_bytes(l->pq->D, rerankK, 256, 0) <= std::min<size_t>(ctx->lds_per_block, 40 * 1024);
+        mode = fits ? JV_TRAVERSAL_DEVICE : JV_TRAVERSAL_HOST;
     }
     // acceptOrds: the host traversal reads the masks from host memory, the device traversal from device memory
     const int64_t words = g->n_nodes > 0 ? (g->n_nodes + 63) / 64 : 0;
@@ -1078,6 +1141,11 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
         } else {
             host_accept.bits = accept_bits;
         }
+    }
+    if (fused && Q > 0 && fused->count == g->n_nodes && fused->maxDegree == g->levels[0].degree &&
+        g->levels[0].nbrs.size() == (size_t)g->n_nodes * fused->maxDegree) {
+        JV_TRY(use_device(ctx->device));
+        JV_TRY(check_fused_matches_graph(ctx, const_cast<jv_graph *>(g), fused));
     }
     if (mode != JV_TRAVERSAL_DEVICE || Q == 0)
         return graph_search_host(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats, host_accept);

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -80,7 +81,22 @@ struct jv_ctx {
     // host batched graph searcher: worker pool (graph_search.cpp owns the type) and its destructor
     void *host_pool = nullptr;
     void (*host_pool_destroy)(void *) = nullptr;
+    // a context belongs to ONE host thread (jvector_hip.h); the long-running searches take this flag and refuse a second
+    // concurrent caller instead of corrupting the shared staging buffers / worker pool
+    std::atomic<int> busy{0};
 };
+
+namespace jv {
+struct CtxBusy {
+    jv_ctx *c;
+    bool ok;
+    explicit CtxBusy(jv_ctx *cc) : c(cc), ok(cc->busy.exchange(1, std::memory_order_acquire) == 0) {}
+    ~CtxBusy()
+    {
+        if (ok) c->busy.store(0, std::memory_order_release);
+    }
+};
+}  // namespace jv
 
 struct jv_pq {
     int device = 0;
@@ -127,6 +143,7 @@ struct jv_fused {
     int32_t *d_neighbors = nullptr; // count x maxDegree
     float *d_norms = nullptr;       // count x maxDegree (cosine), lazily built
     bool norms_valid = false;
+    uint64_t generation = 0;        // bumped by every upload (consumers that cached a consistency check compare it)
 };
 
 struct jv_luts {

@@ -582,7 +582,8 @@ class GraphIndex:
 
     def set_traversal(self, mode: str):
         """Where the traversal state lives: "host" (worker pool + GPU frontier scoring), "device" (one wavefront per
-        query runs the whole loop on the GPU) or "auto" (currently host).  Results are identical."""
+        query runs the whole loop on the GPU) or "auto" (device wherever the shape is supported — uniform 8-dim
+        sub-vectors, M in {16,32,48,64,96,128,192}, degree <= 64, queues fit LDS — else host).  Results are identical."""
         check(self._lib.jv_hip_graph_set_traversal(self._h, self.TRAVERSAL[mode]))
         return self
 

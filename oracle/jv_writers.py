@@ -90,10 +90,14 @@ def _header(version, dimension, entry_node, layers, id_upper_bound, feature_orde
 
 
 def write_odgi(version, dimension, l0_neighbors, degree0, entry_node, upper_levels=(), vectors=None, separated=False,
-               codes=None, pq_block=None, omitted=(), level_file_order=None) -> bytes:
+               codes=None, pq_block=None, omitted=(), level_file_order=None, sequential_placeholders=False,
+               placeholder_fill=0) -> bytes:
     """l0_neighbors: list (per ordinal) of neighbour-id lists;  upper_levels: [(degree, {node: [neighbours]}), ...] for
     levels 1..;  vectors: N x D float32 (inline, or separated when `separated`);  codes + pq_block: adds FUSED_PQ (v6);
-    omitted: ordinals written as placeholders;  level_file_order: optional {level: [node ids in file order]}."""
+    omitted: ordinals written as placeholders;  level_file_order: optional {level: [node ids in file order]}.
+    sequential_placeholders: write OMITTED ordinals the way the sequential OnDiskGraphIndexWriter does
+    (OnDiskGraphIndexWriter.java:101-110: ordinal -1, inline feature bytes seek-skipped — whatever the file held, modelled
+    by `placeholder_fill` — count 0, -1 padding) instead of NodeRecordTask's zero-feature record that keeps the ordinal."""
     N = len(l0_neighbors)
     layers = [(N - len(omitted), degree0)] + [(len(nodes), deg) for deg, nodes in upper_levels]
     fused = codes is not None
@@ -113,6 +117,15 @@ def write_odgi(version, dimension, l0_neighbors, degree0, entry_node, upper_leve
 
     out = bytearray(hdr(0))
     for i in range(N):
+        if sequential_placeholders and i in omitted:
+            out += _i32(-1)
+            for fid in feats:
+                if fid == INLINE_VECTORS:
+                    out += bytes([placeholder_fill]) * (4 * dimension)
+                elif fid == FUSED_PQ:
+                    out += bytes([placeholder_fill]) * (degree0 * M)
+            out += _i32(0) + _be_i32([-1] * degree0)
+            continue
         out += _i32(i)
         nb = [] if i in omitted else list(l0_neighbors[i])
         assert len(nb) <= degree0

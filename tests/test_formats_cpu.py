@@ -179,6 +179,38 @@ def test_odgi_v6_fused_single_layer_entry_code_and_omitted():
     assert F.read_odgi(blob, want_vectors=False).vectors is None
 
 
+@pytest.mark.parametrize("separated", [False, True])
+def test_odgi_sequential_writer_placeholders(separated):
+    """OnDiskGraphIndexWriter.writeL0Records :97-110 — an OMITTED ordinal is written as ordinal -1, its inline feature
+    bytes are seek-skipped (whatever the file held: modelled as 0xAB garbage), count 0, -1 padding.  The reference's
+    reader never looks at the stored ordinal; the record must load as a hole."""
+    rng = np.random.default_rng(10)
+    N, D, M, deg = 24, 8, 2, 4
+    pq = _pq(D, M)
+    holes = {3, 17, 23}
+    nb = [[int(x) for x in rng.choice([j for j in range(N) if j not in holes and j != i], deg, replace=False)] for i in range(N)]
+    codes = rng.integers(0, 256, (N, M), dtype=np.uint8)
+    vec = rng.standard_normal((N, D)).astype(np.float32)
+    blob = W.write_odgi(6, D, nb, deg, entry_node=5, vectors=vec, separated=separated, codes=codes, pq_block=pq.serialize(6),
+                        omitted=holes, sequential_placeholders=True, placeholder_fill=0xAB)
+    info = F.describe_odgi(blob)
+    assert struct.unpack_from(">i", blob, info.l0_off + 17 * info.record_stride)[0] == -1
+    g = F.read_odgi(blob)
+    assert g.info.layer_size[0] == N - len(holes) and g.id_upper_bound == N
+    for h in holes:
+        assert (g.levels[0][1][h] == -1).all() and not g.fused_blocks[h].any() and not g.vectors[h].any()
+    live = [i for i in range(N) if i not in holes]
+    assert np.array_equal(g.levels[0][1][live], _packed(nb, deg)[live])
+    assert np.array_equal(g.vectors[live], vec[live])
+    for i in live[:5]:
+        assert np.array_equal(g.fused_blocks[i], codes[nb[i]])
+    # same graph through NodeRecordTask's variant (ordinal kept, zero features): identical arrays
+    g2 = F.read_odgi(W.write_odgi(6, D, nb, deg, entry_node=5, vectors=vec, separated=separated, codes=codes,
+                                  pq_block=pq.serialize(6), omitted=holes))
+    assert np.array_equal(g.levels[0][1], g2.levels[0][1]) and np.array_equal(g.fused_blocks, g2.fused_blocks)
+    assert np.array_equal(g.vectors, g2.vectors)
+
+
 def test_odgi_no_vectors_and_empty():
     nb = [[1], [0]]
     g = F.read_odgi(W.write_odgi(6, 4, nb, 2, entry_node=0))

@@ -1,5 +1,8 @@
-"""Host batched graph searcher against the oracle's sequential GraphSearcher restatement:
-same graph, same queries -> identical result ids, scores, visitedCount and expandedCount per query."""
+"""Batched graph searcher against the oracle's sequential GraphSearcher restatement: same graph,
+same queries -> identical result ids, scores, visitedCount and expandedCount per query.  The host traversal
+(graph_search.cpp + frontier kernels) is pinned explicitly here; the device-resident traversal (the default wherever
+it applies) has its own file, tests/test_zz_device_traversal_gpu.py; the BASELINE shapes (C3: D=768 / M=96 /
+maxDegree 32, C5: D=1536 / M=192) run through BOTH at the bottom of this file."""
 import numpy as np
 import pytest
 
@@ -76,7 +79,7 @@ def test_graph_search_matches_oracle(ctx, levels, use_fused, D, M):
     codes = cv.get(0, N)
     assert np.array_equal(codes, opq.encode_all(v))
     og = O.OracleGraph(N, lv, entry, entry_level)
-    graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal("host")
     fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
     for vsf in VSF:
         for rerank, top_k, rk in ((True, 10, 40), (False, 5, 20), (True, 1, 1)):
@@ -98,7 +101,7 @@ def test_graph_search_large_batch_and_errors(ctx):
     vs = J.VectorSet(ctx, v)
     cv = J.PQVectors.encode_and_build(ctx, pq, vs)
     codes = cv.get(0, N)
-    graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal("host")
     fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1])
     s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=1024)
     ids, sc, stats = s.search(q, VSF.COSINE, 10, 60, return_stats=True)
@@ -123,7 +126,7 @@ def test_graph_search_continuous_batching(ctx, slots, groups, monkeypatch):
     vs = J.VectorSet(ctx, v)
     cv = J.PQVectors.encode_and_build(ctx, pq, vs)
     codes = cv.get(0, N)
-    graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal("host")
     og = O.OracleGraph(N, lv, entry, entry_level)
     monkeypatch.setenv("JVECTOR_HIP_GRAPH_SLOTS", str(slots))
     monkeypatch.setenv("JVECTOR_HIP_GRAPH_GROUPS", str(groups))
@@ -145,7 +148,7 @@ def test_graph_search_accept_ords(ctx):
     vs = J.VectorSet(ctx, v)
     cv = J.PQVectors.encode_and_build(ctx, pq, vs)
     codes = cv.get(0, N)
-    graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal("host")
     fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1])
     og = O.OracleGraph(N, lv, entry, entry_level)
     s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
@@ -223,3 +226,46 @@ def run_ties_cases(J, ctx, traversal, cases=6):
 
 def test_graph_search_engineered_ties(ctx):
     run_ties_cases(J, ctx, "host")
+
+
+# ---- BASELINE shapes: C3 = 10M x 768 cosine, PQ-96 + FusedADC, maxDegree 32 (the benched kernel instances:
+#      frontier_direct_kernel<.,CH16=6,TWO> / graph_search_kernel<.,6,.,PAIR>), C5 = 1536-d / PQ-192 (CH16=12) --------
+@pytest.fixture(scope="module")
+def baseline_problems():
+    cache = {}
+
+    def get(D, M, levels):
+        key = (D, M, levels)
+        if key not in cache:
+            N = 5000 if D <= 768 else 3000
+            cache[key] = build_problem(7 * levels + M, N=N, D=D, M=M, deg=32, top_n=80, top_deg=16, levels=levels)
+        return cache[key]
+    return get
+
+
+@pytest.mark.parametrize("traversal", ["host", "device", "auto"])
+@pytest.mark.parametrize("D,M,levels", [(768, 96, 2), (768, 96, 3), (1536, 192, 2)])
+def test_graph_search_baseline_shapes(ctx, baseline_problems, traversal, D, M, levels):
+    """ids, scores and visited / expanded counters == the oracle at the benched shapes, for both traversals, fused
+    (FusedPQDecoder.similarityToNeighbor) and unfused (PQDecoder.similarityTo), all three similarity functions."""
+    v, lv, entry, entry_level, cb, q = baseline_problems(D, M, levels)
+    N = v.shape[0]
+    assert lv[0][1].shape[1] == 32 and (lv[0][1] >= 0).sum(axis=1).max() == 32      # full-degree rows exist
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    assert np.array_equal(codes, opq.encode_all(v))
+    og = O.OracleGraph(N, lv, entry, entry_level)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal(traversal)
+    for use_fused in (True, False):
+        fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
+        for vsf in VSF:
+            for rerank, top_k, rk in ((True, 10, 150), (False, 10, 50)):
+                s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=64)
+                ids, sc, stats = s.search(q, vsf, top_k, rk, return_stats=True)
+                wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused)
+                tag = (traversal, use_fused, vsf, rerank)
+                assert np.array_equal(stats, wst), tag
+                assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag

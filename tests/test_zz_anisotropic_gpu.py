@@ -1,14 +1,12 @@
 """Anisotropic PQ encode on the GPU through the C ABI: codes byte-identical to the oracle's restatement
-of ProductQuantization.encodeAnisotropic.  Written after round 1's GPU budget was spent (logic verified on the CPU lane
-emulator, tests/test_anisotropic_emulated.py); opt-in until its first hardware run (JVECTOR_TEST_ANISOTROPIC=1)."""
+of ProductQuantization.encodeAnisotropic.  First run on MI355X in round 2 (green); the CPU lane-emulator twin is
+tests/test_anisotropic_emulated.py."""
 import os
 
 import numpy as np
 import pytest
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif("1" not in (os.environ.get("JVECTOR_TEST_ANISOTROPIC"), os.environ.get("JVECTOR_TEST_UNVERIFIED")),
-                                 reason="anisotropic encode not yet validated on hardware; set JVECTOR_TEST_ANISOTROPIC=1")]
+pytestmark = pytest.mark.gpu
 
 import jvector_amd as J
 from oracle import oracle as O

@@ -1,17 +1,14 @@
 """Device-resident graph traversal (k_gsearch.hip) on the GPU: identical ids, scores, visitedCount and expandedCount to
 the oracle's sequential GraphSearcher restatement, and to the host traversal.
 
-The kernel was written after round 1's GPU budget was spent: its logic is verified on the CPU lane emulator
-(tests/test_gsearch_emulated.py) but it has not yet run on hardware, so these tests are opt-in until it has
-(JVECTOR_TEST_DEVICE_TRAVERSAL=1); the default traversal stays the hardware-verified host searcher."""
+First run on MI355X in round 2 (green) — since then the default traversal wherever the shape is supported
+(JV_TRAVERSAL_AUTO); the CPU lane-emulator twin is tests/test_gsearch_emulated.py."""
 import os
 
 import numpy as np
 import pytest
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif("1" not in (os.environ.get("JVECTOR_TEST_DEVICE_TRAVERSAL"), os.environ.get("JVECTOR_TEST_UNVERIFIED")),
-                                 reason="device traversal not yet validated on hardware; set JVECTOR_TEST_DEVICE_TRAVERSAL=1")]
+pytestmark = pytest.mark.gpu
 
 import jvector_amd as J
 from jvector_amd import VectorSimilarityFunction as VSF

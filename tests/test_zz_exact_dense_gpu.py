@@ -2,17 +2,14 @@
 bit-equal to its k-ascending fmaf-chain specification (oracle.dense_scan), within 1e-5 of the bit-exact scalar-order scan,
 identity-times-asymmetric-matrix probe, sub-ranges, device-resident inputs / outputs.
 
-Written after round 1's GPU budget was spent: verified on the CPU lane emulator with the documented semantics of
-v_mfma_f32_32x32x2_f32 (tests/test_exact_dense_emulated.py) and through the mock device (tests/test_mock_device.py), not
-yet run on hardware — opt-in until it has (JVECTOR_TEST_DENSE=1 or JVECTOR_TEST_UNVERIFIED=1)."""
+First run on MI355X in round 2 (green); the CPU lane-emulator twin with the documented semantics of
+v_mfma_f32_32x32x2_f32 is tests/test_exact_dense_emulated.py."""
 import os
 
 import numpy as np
 import pytest
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif("1" not in (os.environ.get("JVECTOR_TEST_DENSE"), os.environ.get("JVECTOR_TEST_UNVERIFIED")),
-                                 reason="MFMA dense scan not yet validated on hardware; set JVECTOR_TEST_DENSE=1")]
+pytestmark = pytest.mark.gpu
 
 import jvector_amd as J
 from jvector_amd import VectorSimilarityFunction as VSF

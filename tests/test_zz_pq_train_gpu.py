@@ -1,14 +1,12 @@
 """PQ training on the GPU through the C ABI: ProductQuantization.compute / refine / write, bit-identical to
-the oracle's sequential restatement for the same seed.  Written after round 1's GPU budget was spent (bodies verified on the
-CPU, tests/test_pq_train_emulated.py); opt-in until its first hardware run (JVECTOR_TEST_PQ_TRAIN=1)."""
+the oracle's sequential restatement for the same seed.  First run on MI355X in round 2 (green); the CPU twin of the same
+kernel bodies is tests/test_pq_train_emulated.py."""
 import os
 
 import numpy as np
 import pytest
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif("1" not in (os.environ.get("JVECTOR_TEST_PQ_TRAIN"), os.environ.get("JVECTOR_TEST_UNVERIFIED")),
-                                 reason="PQ training not yet validated on hardware; set JVECTOR_TEST_PQ_TRAIN=1")]
+pytestmark = pytest.mark.gpu
 
 import jvector_amd as J
 from oracle import oracle as O
