@@ -2,33 +2,35 @@
 """bench.py — the hot path's headline benchmark on MI355X (contract: see the repo brief).
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic 10M x 768 cosine
-("ada-002-like"), PQ-96 (256 clusters, 8-dim sub-vectors), FusedADC graph blocks (maxDegree 32).
-One *step* = one batch of Q queries through the hot path, inputs resident in HBM.  Two search modes:
+("ada-002-like"), PQ-96 (256 clusters, 8-dim sub-vectors, trained by the engine's own ProductQuantization.compute),
+FusedADC graph blocks (maxDegree 32).  One *step* = one batch of Q queries through the hot path, inputs resident in HBM:
 
-  --mode graph            host batched GraphSearcher (lock-step traversal on the host cores, each round's frontier
-                          scored on the GPU from the FusedPQ neighbour blocks) -> exact rerank -> top-10
-                          [GraphSearcher.search + FusedPQDecoder + NodeQueue.rerank, batched]
+  --mode graph (default)  GraphSearcher.search batched: centre the queries -> graph traversal with FusedPQ neighbour-block
+                          scoring (device-resident traversal, one wavefront per query; --traversal host = the round-1
+                          host batched searcher) -> exact rerank of the kept rerankK (NodeQueue.rerank) -> top-10
   --mode flat             LUT build -> multi-query ADC scan of all N codes (threshold-filtered) -> top-rerankK
-                          -> exact rerank -> top-10   (no graph; the brute-force-over-codes path)
-  --mode auto (default)   graph when the rank has >= 3 host cores for the traversal (the graph path is host-bound),
-                          else flat (GPU-bound)
+                          -> exact rerank -> top-10   (no graph; the brute-force-over-codes path = the per-shard kernel of C4)
+  --workload c2           BASELINE.json configs[1]: SIFT-like 1M x 128, L2, PQ-16, flat two-pass ADC search
 
-value = whole-job queries/s at recall@10 >= 0.95; recall is measured against exact brute-force ground truth
-computed by the engine's bit-exact exact-scan kernel, outside the timed region, on (a subset of) the timed queries.
-`roofline` prices the mode's dominant kernel in algorithmic bytes against the 8 TB/s HBM peak from
-HIP events recorded on the engine's stream inside the timed region.  `cpu_baseline` times the CPU oracle ("port")
-on the host cores on a bounded sample of the same workload, same mode, twice: with the scalar reference arithmetic (the
-parity checker: its top-k must equal the GPU's bit for bit) and with the AVX2 / AVX-512 restatement of the reference's
-native kernels (`value`, when the host CPU has AVX2; `scalar_value` keeps the other).
+value = whole-job queries/s at recall@10 >= 0.95.  rerankK is calibrated on one query set (seed 7) and recall is then
+REPORTED on a disjoint evaluation set (seed 8, >= 10 000 queries, with its standard error) against exact brute-force
+ground truth (MFMA dense scan for candidates, rescored by the bit-exact kernel), all outside the timed region.
+`roofline` prices the dominant kernel in algorithmic bytes against the 8 TB/s HBM peak from HIP events
+recorded on the engine's stream inside the timed region; `traffic` is filled only from a rocprofv3 PMC summary of THIS
+configuration (profiles/traffic_r2.json, written by scripts/summarize_profile.py), else null.  `cpu_baseline` times the CPU
+oracle ("port") on the host cores on a bounded sample of the same workload: scalar reference arithmetic (the parity
+checker: its top-k must equal the GPU's bit for bit) and the AVX2 / AVX-512 restatement of the reference's native kernels.
 
-N > 1 (launched by torch.distributed.run): every rank holds a full replica of the index and serves its own
-query batches (10M x 768 fits one GPU); no data-path collective; scaling = weak.  The sharded 100M configuration
-(RCCL all-gather of partial top-k) is jvector_amd/sharded.py, covered by tests, not a bench line.
+N > 1 (launched by torch.distributed.run): every rank holds a full replica of the index and serves its own query
+batches (10M x 768 fits one GPU); no data-path collective; scaling = weak.  The traversal runs on the device, so ranks do
+not compete for host cores.  The sharded 100M configuration (all-gather of partial top-k) is jv_hip_sharded_* /
+jvector_amd/sharded.py, covered by tests, not a bench line.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -41,10 +43,15 @@ import numpy as np
 import torch
 
 from benchgraph import build_hier_graph  # noqa: E402
-from benchlib import (Mixture, fused_blocks_from, ground_truth, recall_at_k,  # noqa: E402
-                      train_codebooks)
+from benchlib import Mixture, ground_truth, recall_per_query, sift_like  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable copy)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec; measured on this pool: 5.15 TB/s d2d copy,
+                             # 6.0 TB/s stream triad — profiles/r2_validation/microbench.json)
+LDS_B128_PEAK_GBS = 256 * 256 * 2.4  # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 TB/s (MI355X_MICROARCH.md §LDS)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
 
 
 def effective_cpus():
@@ -65,6 +72,9 @@ def effective_cpus():
     return max(1, min(n, 64))
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# cpu_baseline legs (the oracle is the checker and the reported baseline here — never the thing measured as `value`)
+# ------------------------------------------------------------------------------------------------------------------
 def _simd_leg(run, gpu_ids, top_k):
     """Time `run()` once more with the oracle's SIMD kernels switched on (oracle/jv_oracle_simd.c: AVX2 / AVX-512
     restatement of the reference's native library).  Returns (isa, seconds, mean top-k overlap with the GPU's ids) or
@@ -94,11 +104,11 @@ def _baseline_line(nq, scalar_s, simd, threads, sample, matches):
     return line
 
 
-def cpu_baseline_flat(cb, D, M, codes_h, base_dev, queries_dev, vsf, top_k, rerank_k, gpu_ids):
-    """CPU oracle on a bounded sample of the flat workload: one query per host thread."""
+def cpu_baseline_flat(cb, D, M, codes_h, base_dev, queries_dev, vsf, top_k, rerank_k, gpu_ids, max_q=None):
+    """CPU oracle on a bounded sample of the flat workload: one query per host thread (more when the index is small)."""
     from oracle import oracle as O
     threads = effective_cpus()
-    nq = min(threads, queries_dev.shape[0], gpu_ids.shape[0])
+    nq = min(max_q or threads, queries_dev.shape[0], gpu_ids.shape[0])
     opq = O.OraclePQ(D, M, cb)
     opq.cache_self_magnitudes()
     q = queries_dev[:nq].cpu().numpy()
@@ -118,7 +128,7 @@ def cpu_baseline_flat(cb, D, M, codes_h, base_dev, queries_dev, vsf, top_k, rera
     simd = _simd_leg(run, gpu_ids, top_k)
     return _baseline_line(nq, scalar_s, simd, threads,
                           f"{nq} queries x {codes_h.shape[0]} codes, two-pass flat search (ADC scan + top-{rerank_k} + exact "
-                          f"rerank), one query per thread", bool(np.array_equal(ids, gpu_ids[:nq])))
+                          f"rerank), queries spread over {threads} threads", bool(np.array_equal(ids, gpu_ids[:nq])))
 
 
 def cpu_baseline_graph(cb, D, M, codes_h, levels, entry, entry_level, base_dev, queries_dev, vsf, top_k, rerank_k,
@@ -167,26 +177,171 @@ def cpu_baseline_graph(cb, D, M, codes_h, levels, entry, entry_level, base_dev, 
                           bool(np.array_equal(ids, gpu_ids[:nq])))
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------------------------
+def measured_traffic(kernel_key, cfg):
+    """HBM bytes per launch from the rocprofv3 PMC summary (profiles/traffic_r2.json) — only if it was collected on THIS
+    configuration (same kernel, N, D, M, queries per step, rerankK); else None."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic_r2.json")))
+    except Exception:
+        return None
+    for e in table.get("entries", []):
+        if e.get("kernel_key") == kernel_key and all(e.get("config", {}).get(k) == v for k, v in cfg.items()):
+            return e.get("hbm_bytes_per_launch")
+    return None
+
+
+def search_all(run, queries, Q, rk):
+    """ids of `queries` searched in batches of Q (untimed helper for calibration / evaluation)."""
+    out = []
+    for s in range(0, queries.shape[0], Q):
+        out.append(run(queries[s:s + Q].contiguous(), rk)[0].clone())
+    return torch.cat(out)
+
+
+def calibrate(run, ctx, ladder, cal_q, cal_gt, Q, tag):
+    """smallest rerankK of the ladder whose calibration recall clears 0.95 by two of its own standard errors — the margin
+    that makes the claim hold on the DISJOINT evaluation set too, not just on the queries it was tuned on"""
+    rerank_k, rec = ladder[-1], 0.0
+    for rk in ladder:
+        found = search_all(run, cal_q, Q, rk)
+        ctx.sync()
+        r = recall_per_query(found.cpu().numpy(), cal_gt)
+        rec, se = float(r.mean()), float(r.std(ddof=1) / math.sqrt(len(r))) if len(r) > 1 else 0.0
+        rerank_k = rk
+        log(f"[calibrate] {tag} rerankK={rk}: recall@{cal_gt.shape[1]} = {rec:.4f} +- {se:.4f} on {cal_q.shape[0]} calibration queries")
+        if rec - 2.0 * se >= 0.95:
+            break
+    return rerank_k, rec
+
+
+def evaluate(run, ctx, eval_q, eval_gt, Q, rk):
+    found = search_all(run, eval_q, Q, rk)
+    ctx.sync()
+    r = recall_per_query(found.cpu().numpy(), eval_gt)
+    return float(r.mean()), float(r.std(ddof=1) / math.sqrt(len(r))) if len(r) > 1 else 0.0
+
+
+def timed_steps(run, queries, Q, steps, rk, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        run(queries[s * Q:(s + 1) * Q], rk)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def flat_roofline(QF, N, M, f_ms, f_n, cfg, vsf_name="COSINE"):
+    """adc_mq_kernel: one (query, candidate) pair = M look-ups of 4 B served 4 queries at a time by ds_read_b128 from the
+    LDS-resident tables; the kernel's physical bound is the LDS gather rate, its HBM side is one pass over the codes."""
+    f_avg = f_ms / 1e3 / max(f_n, 1)
+    lds_bytes = float(QF) * N * M * 4.0            # bytes the ds_read_b128 stream delivers per launch
+    compulsory = float(N) * (M + 4)                # codes (+ code norms) read once
+    ach = lds_bytes / f_avg / 1e9 if f_avg > 0 else 0.0
+    traffic = measured_traffic("adc_mq", cfg)
+    return {"bound": "lds", "kernel": f"adc_mq_kernel<{vsf_name},M={M},R=8,FILTER> (threshold-filtered multi-query ADC scan of all N "
+            "codes; tables of 4 queries interleaved in LDS, one ds_read_b128 = 4 look-ups)",
+            "achieved": ach, "peak": LDS_B128_PEAK_GBS, "unit": "GB/s", "frac": ach / LDS_B128_PEAK_GBS,
+            "traffic": traffic, "hbm_compulsory_bytes": compulsory,
+            "hbm_traffic_over_compulsory": (traffic / compulsory) if traffic else None,
+            "pairs_per_launch": float(QF) * N, "avg_launch_ms": f_avg * 1e3, "launches": f_n,
+            "note": "bound = LDS gather rate (ds_read_b128 peak 256 B/clk/CU x 256 CUs x 2.4 GHz); HBM side: counter bytes vs the "
+                    "compulsory one pass over the codes"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# C2: SIFT-like 1M x 128, L2, PQ-16, flat two-pass ADC search
+# ------------------------------------------------------------------------------------------------------------------
+def run_c2(args, ctx, J, dev, world, rank, barrier):
+    VSF = J.VectorSimilarityFunction.EUCLIDEAN
+    N, D, M, K = (args.n if args.n != 10_000_000 else 1_000_000), 128, 16, args.topk
+    QF = args.queries or 1024
+    t_setup = time.perf_counter()
+    base = sift_like(N, D, seed=2, device=dev)
+    queries = sift_like(QF * (args.steps + args.warmup), D, seed=3 + 1000 * rank, device=dev)
+    cal_q, eval_q = sift_like(1024, D, seed=13, device=dev), sift_like(max(args.eval_queries, 1024), D, seed=14, device=dev)
+    g = torch.Generator(device=dev).manual_seed(4)
+    sample = base[torch.randperm(N, generator=g, device=dev)[:min(128_000, N)]].contiguous()
+    t0 = time.perf_counter()
+    pq = J.ProductQuantization.compute(ctx, sample, M, seed=4)
+    ctx.sync()
+    train_s = time.perf_counter() - t0
+    vs = J.VectorSet(ctx, base)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    flat = J.FlatSearcher(ctx, pq, cv, vs, max_queries=QF)
+
+    def run(qs, rk):
+        return flat.search(qs, VSF, K, rk)
+
+    cal_gt = ground_truth(J, ctx, vs, cal_q, VSF, K, dense=True).cpu().numpy()
+    eval_gt = ground_truth(J, ctx, vs, eval_q, VSF, K, dense=True).cpu().numpy()
+    ladder = [args.rerank] if args.rerank > 0 else [50, 100, 200, 400, 800, 1200, 1600, 2400, 3200, 4096]
+    rerank_k, cal_rec = calibrate(run, ctx, ladder, cal_q, cal_gt, QF, "c2 flat")
+    rec, rec_se = evaluate(run, ctx, eval_q, eval_gt, QF, rerank_k)
+    setup_s = time.perf_counter() - t_setup
+    for w in range(args.warmup):
+        run(queries[w * QF:(w + 1) * QF], rerank_k)
+    ctx.profile(True)
+    elapsed = timed_steps(run, queries[args.warmup * QF:], QF, args.steps, rerank_k, barrier)
+    prof = {r: ctx.profile_read(r) for r in ("adc", "sample", "topk", "exact", "lut")}
+    ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    cfg = {"n_vectors": N, "dim": D, "pq_subspaces": M, "queries_per_step": QF, "rerankK": rerank_k}
+    line = {"metric": "QPS@recall10>=0.95 (SIFT1M-like 1Mx128 L2, PQ-16 ADC search); distances/sec as % roofline",
+            "value": QF * args.steps * world / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE C2: synthetic SIFT-like {N}x{D} (clip(round(|N(0,1)|*40),0,218)), L2, PQ-{M} "
+                                   f"(engine-trained, k=256), two-pass flat search: ADC scan of all codes -> top-{rerank_k} -> exact "
+                                   f"rerank -> top-{K}", "mode": "flat", **cfg, "topK": K, "similarity": "EUCLIDEAN",
+                       "parallelism": "1 GPU" if world == 1 else f"{world} replicas"},
+            "recall_at_10": rec, "recall_se": rec_se, "recall_ok": rec >= 0.95, "recall_eval_queries": int(eval_q.shape[0]),
+            "recall_calibration": {"queries": int(cal_q.shape[0]), "recall": cal_rec, "disjoint_from_eval": True},
+            "roofline": flat_roofline(QF, N, M, prof["adc"][0], prof["adc"][1], cfg, "L2"),
+            "kernel_ms_per_step": {r: prof[r][0] / args.steps for r in prof},
+            "adc_distances_per_s": float(QF) * N * args.steps * world / elapsed, "pq_train_s": train_s, "setup_s": setup_s}
+    if world == 1 and not args.no_cpu_baseline:
+        tq = queries[args.warmup * QF:]
+        ids_gpu, _ = run(tq[:QF], rerank_k)
+        ctx.sync()
+        line["cpu_baseline"] = cpu_baseline_flat(pq.codebooks(), D, M, cv.get(0, N), base, tq, VSF, K, rerank_k,
+                                                 ids_gpu.cpu().numpy(), max_q=16 * effective_cpus())
+    return line
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=["auto", "graph", "flat"], default="auto",
-                    help="auto = graph when this rank has >= 3 host cores for the traversal, else flat")
+    ap.add_argument("--workload", choices=["c3", "c2"], default="c3", help="c3 = the headline 10Mx768 config; c2 = SIFT1M-like")
+    ap.add_argument("--mode", choices=["auto", "graph", "flat"], default="auto", help="auto = graph")
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--m", type=int, default=96)
     ap.add_argument("--degree", type=int, default=32)
-    ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 16384 graph / 256 flat)")
+    ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 16384 graph / 256 flat / 1024 c2)")
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95")
-    ap.add_argument("--eval-queries", type=int, default=1024, help="timed queries with ground truth (recall)")
-    ap.add_argument("--gt-dense", action="store_true", help="ground truth candidates from the MFMA dense scan, rescored by the "
-                    "bit-exact kernel (opt-in until the dense kernel has been validated on hardware)")
+    ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95 on the calibration set")
+    ap.add_argument("--cal-queries", type=int, default=2048, help="calibration queries (rerankK ladder)")
+    ap.add_argument("--eval-queries", type=int, default=10240, help="disjoint evaluation queries the reported recall is measured on")
+    ap.add_argument("--gt-exact", action="store_true", help="ground truth by the bit-exact scalar-order scan only (slower; the "
+                    "default takes 4k candidates from the MFMA dense scan and rescores them with the bit-exact kernel)")
     ap.add_argument("--traversal", choices=["host", "device"], default=os.environ.get("JVECTOR_BENCH_TRAVERSAL", "device"),
                     help="graph mode: device-resident traversal (default; what JV_TRAVERSAL_AUTO picks at this shape) or the "
                          "host batched searcher")
+    ap.add_argument("--torch-codebooks", action="store_true", help="codebooks from benchlib's torch Lloyd instead of the engine's "
+                    "ProductQuantization.compute (round-1 behaviour)")
+    ap.add_argument("--index-cache", default=os.environ.get("JVECTOR_BENCH_INDEX_CACHE", ""), help="npz file: synthetic graph + "
+                    "codebooks are loaded from it when it exists, else built and saved (lets rocprofv3 wrap search steps only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat", action="store_true", help="graph mode: skip the secondary flat-scan measurement")
     args = ap.parse_args()
@@ -202,24 +357,56 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import jvector_amd as J
-    VSF = J.VectorSimilarityFunction.COSINE
     ctx = J.HipContext(local, stream=torch.cuda.current_stream().cuda_stream)
 
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "c2":
+        line = run_c2(args, ctx, J, dev, world, rank, barrier)
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    VSF = J.VectorSimilarityFunction.COSINE
     N, D, M, K = args.n, args.dim, args.m, args.topk
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    host_cores = max(1, effective_cpus() // max(1, local_world))
     if args.mode == "auto":
-        # measured on MI355X: the host traversal serves ~4.25 k QPS per host thread (68 k with 16), the GPU-bound flat scan
-        # 9.7 k QPS per GPU: from 3 threads per rank upwards the graph path is the faster one
-        args.mode = "graph" if (host_cores >= 3 or args.traversal == "device") else "flat"
+        args.mode = "graph"
     graph_mode = args.mode == "graph"
     Q = args.queries or (16384 if graph_mode else 256)
     t_setup = time.perf_counter()
     mix = Mixture(D, seed=5, device=dev)
     base = mix.sample(N, seed=5)
     queries_all = mix.sample(Q * (args.steps + args.warmup), seed=6 + 1000 * rank)
-    cb = train_codebooks(base, M, seed=4)
-    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb.cpu().numpy())
+    cal_q = mix.sample(args.cal_queries, seed=7)
+    eval_q = mix.sample(args.eval_queries, seed=8)
+
+    cache = None
+    if args.index_cache and os.path.exists(args.index_cache):
+        cache = np.load(args.index_cache, allow_pickle=False)
+        if int(cache["n"]) != N or int(cache["dim"]) != D or int(cache["m"]) != M or int(cache["degree"]) != args.degree:
+            log(f"[bench] index cache {args.index_cache} was built for another shape: ignored")
+            cache = None
+
+    # ---- codebooks: the engine's ProductQuantization.compute on <= 128 000 sampled vectors (ProductQuantization.java:63-64,
+    #      109-139: k-means++ seeding + 6 Lloyd rounds), deterministic in (sample, seed)
+    t0 = time.perf_counter()
+    if cache is not None:
+        pq = J.ProductQuantization.load(ctx, cache["pq_bytes"].tobytes())
+    elif args.torch_codebooks:
+        from benchlib import train_codebooks
+        pq = J.ProductQuantization.from_codebooks(ctx, D, M, train_codebooks(base, M, seed=4).cpu().numpy())
+    else:
+        g = torch.Generator(device=dev).manual_seed(4)
+        sample = base[torch.randperm(N, generator=g, device=dev)[:min(128_000, N)]].contiguous()
+        pq = J.ProductQuantization.compute(ctx, sample, M, seed=4)
+        del sample
+    ctx.sync()
+    train_s = time.perf_counter() - t0
     vs = J.VectorSet(ctx, base)
 
     # PQ encode (row 3), timed with the engine's own events
@@ -232,169 +419,162 @@ def main():
     if not codes_t.is_cuda:  # host tensors are copied, not wrapped (CPU dry run of this script against the mock device)
         codes_t.copy_(torch.from_numpy(cv.get(0, N)))
 
-    build_s = None
+    build_s, levels = None, None
     if graph_mode:
         tb = time.perf_counter()
-        levels, entry, entry_level, nbrs_dev = build_hier_graph(base, max_degree=args.degree)
-        fused = J.FusedPQ(ctx, pq, fused_blocks_from(codes_t, nbrs_dev), nbrs_dev)
+        if cache is not None:
+            n_lv = int(cache["n_levels"])
+            levels = [(None if l == 0 else cache[f"nodes{l}"], cache[f"nbrs{l}"]) for l in range(n_lv)]
+            entry, entry_level = int(cache["entry"]), int(cache["entry_level"])
+            nbrs_dev = torch.from_numpy(levels[0][1]).to(dev)
+        else:
+            levels, entry, entry_level, nbrs_dev = build_hier_graph(base, max_degree=args.degree)
+            if args.index_cache and rank == 0:
+                arrs = {"n": N, "dim": D, "m": M, "degree": args.degree, "n_levels": len(levels), "entry": entry,
+                        "entry_level": entry_level, "pq_bytes": np.frombuffer(pq.write(6), dtype=np.uint8)}
+                for l, (nodes, nb) in enumerate(levels):
+                    arrs[f"nbrs{l}"] = nb
+                    if l > 0:
+                        arrs[f"nodes{l}"] = nodes
+                np.savez(args.index_cache, **arrs)
+        fused = J.FusedPQ.build(ctx, cv, nbrs_dev)          # FusedPQ.writeInline on the device (jv_hip_fused_build)
         graph = J.GraphIndex(ctx, N, levels, entry, entry_level).set_traversal(args.traversal)
         searcher = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=Q)
         torch.cuda.synchronize()
         build_s = time.perf_counter() - tb
 
-        def run(qs, rk):
-            return searcher.search(qs, VSF, K, rk)
+        def run(qs, rk, stats=False):
+            return searcher.search(qs, VSF, K, rk, return_stats=stats)
     else:
         flat = J.FlatSearcher(ctx, pq, cv, vs, max_queries=Q)
 
-        def run(qs, rk):
+        def run(qs, rk, stats=False):
             return flat.search(qs, VSF, K, rk)
 
-    timed_q = queries_all[args.warmup * Q:]
-    n_eval = min(args.eval_queries, timed_q.shape[0])
-    gt = ground_truth(J, ctx, vs, timed_q[:n_eval].contiguous(), VSF, K, dense=args.gt_dense).cpu().numpy()
+    # ---- ground truth (untimed): calibration and evaluation sets are disjoint from each other and from the timed queries
+    t0 = time.perf_counter()
+    cal_gt = ground_truth(J, ctx, vs, cal_q, VSF, K, dense=not args.gt_exact).cpu().numpy()
+    eval_gt = ground_truth(J, ctx, vs, eval_q, VSF, K, dense=not args.gt_exact).cpu().numpy()
+    gt_s = time.perf_counter() - t0
 
-    # rerankK: smallest rung reaching recall@10 >= 0.95 on the evaluated timed queries (calibration is untimed)
-    ladder = [args.rerank] if args.rerank > 0 else [50, 100, 150, 200, 300, 400, 600, 800, 1600]
-    rerank_k, rec = ladder[-1], 0.0
-    for rk in ladder:
-        found = [run(timed_q[s:s + Q], rk)[0].clone() for s in range(0, n_eval, Q)]
-        ctx.sync()
-        rec = recall_at_k(torch.cat(found)[:n_eval].cpu().numpy(), gt)
-        rerank_k = rk
-        print(f"[calibrate] mode={args.mode} rerankK={rk}: recall@{K} = {rec:.4f}", file=sys.stderr)
-        if rec >= 0.95:
-            break
+    ladder = [args.rerank] if args.rerank > 0 else [50, 75, 100, 125, 150, 175, 200, 250, 300, 400, 600, 800, 1600]
+    rerank_k, cal_rec = calibrate(run, ctx, ladder, cal_q, cal_gt, Q, f"mode={args.mode}")
     if world > 1:  # every rank serves with the same (largest calibrated) rerankK
         t_rk = torch.tensor([rerank_k], dtype=torch.int64, device=dev)
         torch.distributed.all_reduce(t_rk, op=torch.distributed.ReduceOp.MAX)
         rerank_k = int(t_rk.item())
+    rec, rec_se = evaluate(run, ctx, eval_q, eval_gt, Q, rerank_k)
+    log(f"[evaluate] rerankK={rerank_k}: recall@{K} = {rec:.4f} +- {rec_se:.4f} on {eval_q.shape[0]} evaluation queries")
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
+    timed_q = queries_all[args.warmup * Q:]
     for w in range(args.warmup):
         run(queries_all[w * Q:(w + 1) * Q], rerank_k)
-    barrier()
     ctx.profile(True)
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        run(timed_q[s * Q:(s + 1) * Q], rerank_k)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = {r: ctx.profile_read(r) for r in ("adc", "sample", "topk", "exact", "lut")}
+    elapsed = timed_steps(run, timed_q, Q, args.steps, rerank_k, barrier)
+    regions = ("gsearch", "adc", "sample", "topk", "exact", "lut")
+    prof = {r: ctx.profile_read(r) for r in regions}
     ctx.profile(False)
 
-    # developer aid: JVECTOR_BENCH_SWEEP="slots:groups,slots:groups,..." re-times the graph steps under other slot
-    # configurations (stderr only; the reported line is the default configuration above)
-    if graph_mode and os.environ.get("JVECTOR_BENCH_SWEEP"):
-        for cfg in os.environ["JVECTOR_BENCH_SWEEP"].split(","):
-            sl, gr = cfg.split(":")
-            os.environ["JVECTOR_HIP_GRAPH_SLOTS"], os.environ["JVECTOR_HIP_GRAPH_GROUPS"] = sl, gr
+    # developer aid: JVECTOR_BENCH_ENV_SWEEP="A=1,B=2;A=3" re-times the steps under other engine environment settings
+    # (stderr only; the reported line is the default configuration above)
+    if os.environ.get("JVECTOR_BENCH_ENV_SWEEP"):
+        for cfg in os.environ["JVECTOR_BENCH_ENV_SWEEP"].split(";"):
+            kv = dict(x.split("=", 1) for x in cfg.split(",") if x)
+            os.environ.update(kv)
             run(timed_q[:Q], rerank_k)
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for s in range(min(3, args.steps)):
-                run(timed_q[s * Q:(s + 1) * Q], rerank_k)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - ts) / min(3, args.steps)
-            print(f"[sweep] slots={sl} groups={gr}: {dt * 1e3:.1f} ms/step, {Q / dt:.0f} QPS", file=sys.stderr)
-        os.environ.pop("JVECTOR_HIP_GRAPH_SLOTS", None)
-        os.environ.pop("JVECTOR_HIP_GRAPH_GROUPS", None)
+            ctx.profile(True)
+            dt = timed_steps(run, timed_q, Q, min(3, args.steps), rerank_k, barrier) / min(3, args.steps)
+            pr = {r: ctx.profile_read(r)[0] / min(3, args.steps) for r in regions}
+            ctx.profile(False)
+            log(f"[sweep] {cfg}: {dt * 1e3:.2f} ms/step, {Q / dt:.0f} QPS, kernels " +
+                ", ".join(f"{r} {v:.2f}" for r, v in pr.items() if v > 0))
+            for k in kv:
+                os.environ.pop(k, None)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    adc_ms, adc_n = prof["adc"]
-    adc_avg_s = adc_ms / 1e3 / max(adc_n, 1)
-    graph_stats = None
+    cfg_key = {"n_vectors": N, "dim": D, "pq_subspaces": M, "queries_per_step": Q, "rerankK": rerank_k}
+    graph_stats, extra_roof = None, {}
     if graph_mode:
-        # dominant kernel: frontier scoring, one launch per traversal round of a slot group.
-        # algorithmic bytes per launch: expansions scored per launch x (maxDegree*M block bytes +
-        # 4*maxDegree scores out), with the expansion count measured (SearchResult.expandedCount).
-        _, _, graph_stats = searcher.search(timed_q[:Q], VSF, K, rerank_k, return_stats=True)
-        exp_per_step = float(graph_stats[:, 1].sum())
-        launches_per_step = max(adc_n / args.steps, 1.0)
-        bytes_per_launch = exp_per_step / launches_per_step * (args.degree * M + 4 * args.degree)
-        kernel = "frontier_direct_kernel<COSINE,CH16=6,two slots per wave> (table-free FusedPQ neighbour-block scoring: " \
-                 "the needed ADC entries are recomputed from the L2-resident codebook; one launch per traversal round of " \
-                 "a slot group)"
-        note = ("graph mode is bound by the HOST traversal (16-CPU cgroup quota on the GPU box), not by this kernel: each "
-                "launch scores only ~2k expansions x maxDegree candidates and overlaps the other slot group's host phase; "
-                "see kernel_ms_per_step vs ms_per_step and DESIGN.md §5")
-        tfile = "graph_traffic_r1.json"
+        # expansions / visited of exactly the timed steps (untimed repeat: the search is deterministic)
+        st = [run(timed_q[s * Q:(s + 1) * Q], rerank_k, stats=True)[2] for s in range(args.steps)]
+        graph_stats = np.concatenate(st)
+        expansions = float(graph_stats[:, 1].sum())
+        unit_bytes = args.degree * M + 4 * args.degree    # fused block (padding is read) + maxDegree scores
         if args.traversal == "device":
-            kernel = "graph_search_kernel<COSINE,CH16=6> (device-resident traversal: one wavefront per query, queues in LDS, " \
-                     "table-free FusedPQ block scoring; one persistent launch per query batch)"
-            note = ("whole GraphSearcher loop on the GPU; algorithmic bytes = expansions x (maxDegree*M block bytes + "
-                    "4*maxDegree scores), the launch also carries the queue and visited-set work")
-            tfile = "gsearch_traffic.json"
+            k_ms, k_n = prof["gsearch"]
+            kernel_key = "gsearch"
+            kernel = (f"graph_search_kernel<COSINE,CH16={M // 16},OCC=2,PAIR> (device-resident GraphSearcher: one wavefront per query, "
+                      "candidate / result queues in LDS, visited set in L2, table-free FusedPQ neighbour-block scoring; one "
+                      "persistent launch per query batch)")
+            note = (f"algorithmic bytes = expansions x {unit_bytes} B (SURVEY §8d row 7: maxDegree*M block bytes + 4*maxDegree "
+                    "scores); the kernel additionally reads the 132 B adjacency row per expansion and gathers 32 B of the "
+                    "L2-resident codebook per (fresh neighbour, subspace) — it is bound by those L2 gathers and the dependent "
+                    "pop -> load -> probe -> score -> push chain, not by HBM (DESIGN.md §4)")
+        else:
+            k_ms, k_n = prof["adc"]
+            kernel_key = "frontier"
+            kernel = (f"frontier_direct_kernel<COSINE,CH16={M // 16},two slots per wave> (table-free FusedPQ neighbour-block "
+                      "scoring; one launch per traversal round of a slot group; traversal on the host)")
+            note = "host traversal: bound by the host cores, not by this kernel"
+        bytes_total = expansions * unit_bytes
     else:
-        bytes_per_launch = float(Q) * N * (M + 4)
-        kernel = "adc_mq_kernel<COSINE,SLCH=2,R=8,FILTER> (threshold-filtered multi-query ADC scan of all N codes; " \
-                 "4 queries per ds_read_b128)"
-        note = ("algorithmic bytes = Q*N*(M+4) (SURVEY 8d: codes re-streamed per query); the kernel shares each code row "
-                "among 4 queries in registers and among query groups through L2/MALL, so frac can exceed 1 while HBM "
-                "traffic (PMC) stays far below peak; the physical bound is the LDS gather rate (DESIGN.md §4)")
-        tfile = "adc_traffic_r1.json"
-    achieved = bytes_per_launch / adc_avg_s / 1e9 if adc_avg_s > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", tfile)
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+        k_ms, k_n = prof["adc"]
+        kernel_key, kernel, note, bytes_total = "adc_mq", "", "", 0.0
+    k_avg_s = k_ms / 1e3 / max(k_n, 1)
+
+    # rerank kernel roofline (row 1): candidates x (4*D + 4) bytes over the exact kernel's time
+    e_ms, e_n = prof["exact"]
+    if e_n > 0 and e_ms > 0:
+        rr_bytes = float(Q) * rerank_k * args.steps * (4 * D + 4)
+        ach = rr_bytes / (e_ms / 1e3) / 1e9
+        extra_roof["rerank"] = {"bound": "hbm", "kernel": "exact_gather_kernel<COSINE> (NodeQueue.rerank: full-resolution cosine of the "
+                                "kept candidates, rows gathered by ordinal)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("exact_gather", cfg_key),
+                                "bytes_per_launch": rr_bytes / e_n, "avg_launch_ms": e_ms / e_n, "launches": e_n}
 
     # secondary measurement (single GPU, graph mode): the flat two-pass path on the same index, so that the ADC-scan
-    # kernel (the HBM/LDS-bound kernel of the engine) is priced in the same run.  Not part of `value`.
+    # kernel (the per-shard kernel of the sharded configuration) is priced in the same run.  Not part of `value`.
     flat_info = None
-    if graph_mode and world == 1 and not args.no_flat:
-        QF = 256
-        flat = J.FlatSearcher(ctx, pq, cv, vs, max_queries=QF)
-        f_rk, f_rec = ladder[-1], 0.0
-        for rk in ladder:
-            found = [flat.search(timed_q[s:s + QF], VSF, K, rk)[0].clone() for s in range(0, n_eval, QF)]
-            ctx.sync()
-            f_rec = recall_at_k(torch.cat(found)[:n_eval].cpu().numpy(), gt)
-            f_rk = rk
-            if f_rec >= 0.95:
-                break
-        f_steps = 5
-        flat.search(timed_q[:QF], VSF, K, f_rk)
-        torch.cuda.synchronize()
-        ctx.profile(True)
-        tf = time.perf_counter()
-        for s in range(f_steps):
-            flat.search(timed_q[s * QF:(s + 1) * QF], VSF, K, f_rk)
-        torch.cuda.synchronize()
-        f_el = time.perf_counter() - tf
-        f_ms, f_n = ctx.profile_read("adc")
-        ctx.profile(False)
-        f_avg = f_ms / 1e3 / max(f_n, 1)
-        f_bytes = float(QF) * N * (M + 4)
-        f_traffic = None
-        try:
-            f_traffic = json.load(open(os.path.join(ROOT, "profiles", "adc_traffic_r1.json"))).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+    if world == 1 and not (graph_mode and args.no_flat):
+        if graph_mode:
+            QF = 256
+            flat2 = J.FlatSearcher(ctx, pq, cv, vs, max_queries=QF)
+
+            def frun(qs, rk):
+                return flat2.search(qs, VSF, K, rk)
+            f_rk, _ = calibrate(frun, ctx, ladder, cal_q[:1024], cal_gt[:1024], QF, "mode=flat")
+            f_rec, f_se = evaluate(frun, ctx, eval_q[:2048], eval_gt[:2048], QF, f_rk)
+            f_steps = 5
+            frun(timed_q[:QF], f_rk)
+            ctx.profile(True)
+            f_el = timed_steps(frun, timed_q, QF, f_steps, f_rk, barrier)
+            f_ms, f_n = ctx.profile_read("adc")
+            ctx.profile(False)
+        else:
+            f_rk, f_rec, f_se, f_steps, f_el, (f_ms, f_n), QF = rerank_k, rec, rec_se, args.steps, elapsed, prof["adc"], Q
         flat_info = {"value": QF * f_steps / f_el, "unit": "queries/s", "ms_per_step": f_el / f_steps * 1e3,
-                     "queries_per_step": QF, "rerankK": f_rk, "recall_at_10": f_rec,
+                     "queries_per_step": QF, "rerankK": f_rk, "recall_at_10": f_rec, "recall_se": f_se,
                      "adc_distances_per_s": float(QF) * N * f_steps / f_el,
-                     "roofline": {"bound": "hbm", "kernel": "adc_mq_kernel<COSINE,SLCH=2,R=8,FILTER> (threshold-filtered "
-                                  "multi-query ADC scan of all N codes; 4 queries per ds_read_b128)",
-                                  "achieved": f_bytes / f_avg / 1e9 if f_avg > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": (f_bytes / f_avg / 1e9 / HBM_PEAK_GBS) if f_avg > 0 else 0.0, "traffic": f_traffic,
-                                  "bytes_per_launch": f_bytes, "avg_launch_ms": f_avg * 1e3, "launches": f_n}}
+                     "roofline": flat_roofline(QF, N, M, f_ms, f_n, {**cfg_key, "queries_per_step": QF, "rerankK": f_rk})}
 
     if rank == 0:
         total_queries = Q * args.steps * world
+        if graph_mode:
+            achieved = bytes_total / (k_ms / 1e3) / 1e9 if k_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel_key, cfg_key),
+                        "bytes_per_launch": bytes_total / max(k_n, 1), "avg_launch_ms": k_avg_s * 1e3, "launches": k_n,
+                        "expansions_per_launch": expansions / max(k_n, 1), "bytes_per_expansion": unit_bytes, "note": note}
+        elif flat_info is not None:
+            roofline = flat_info["roofline"]
+        else:
+            roofline = flat_roofline(Q, N, M, k_ms, k_n, cfg_key)
         line = {
             "metric": "QPS@recall10>=0.95 (10Mx768); distances/sec as % HBM roofline",
             "value": total_queries / elapsed,
@@ -403,8 +583,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"synthetic {N}x{D} cosine (latent-32 mixture of 1000 clusters, unit norm), PQ-{M} (k=256, "
-                                    f"Lloyd x6 on a 128k sample), " +
+            "config": {"workload": (f"synthetic {N}x{D} cosine (latent-32 mixture of 1000 clusters, unit norm), PQ-{M} (k=256, " +
+                                    ("torch Lloyd x6" if args.torch_codebooks else "engine ProductQuantization.compute: k-means++ + Lloyd x6") +
+                                    " on a 128k sample), " +
                                     (f"FusedADC graph search: synthetic kNN+robust-prune graph (maxDegree {args.degree}, {len(levels)} nested levels), "
                                      f"{'device-resident GraphSearcher (one wavefront per query)' if args.traversal == 'device' else 'host batched GraphSearcher, GPU fused-block scoring'}, rerankK {rerank_k} -> exact rerank -> top-{K}"
                                      if graph_mode else
@@ -412,33 +593,35 @@ def main():
                        "mode": args.mode, "traversal": args.traversal if graph_mode else None, "n_vectors": N, "dim": D, "pq_subspaces": M, "queries_per_step": Q, "topK": K,
                        "rerankK": rerank_k, "similarity": "COSINE",
                        "parallelism": "1 GPU" if world == 1 else f"{world} replicas, queries sharded, no collective"},
-            "recall_at_10": rec, "recall_ok": rec >= 0.95, "recall_eval_queries": n_eval,
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": bytes_per_launch,
-                         "avg_launch_ms": adc_avg_s * 1e3, "launches": adc_n, "note": note},
+            "recall_at_10": rec, "recall_se": rec_se, "recall_ok": rec >= 0.95, "recall_eval_queries": int(eval_q.shape[0]),
+            "recall_calibration": {"queries": int(cal_q.shape[0]), "recall": cal_rec, "disjoint_from_eval": True},
+            "roofline": roofline,
             "kernel_ms_per_step": {r: prof[r][0] / args.steps for r in prof},
+            "kernel_fraction_of_step": sum(prof[r][0] for r in prof) / (elapsed * 1e3) if world == 1 else None,
             "encode": {"vectors_per_s": N / (enc_ms / 1e3) if enc_ms > 0 else None, "ms": enc_ms},
-            "setup_s": setup_s, "graph_build_s": build_s,
+            "pq_train_s": train_s, "ground_truth_s": gt_s, "setup_s": setup_s, "graph_build_s": build_s,
         }
+        line.update(extra_roof)
         if graph_mode:
             st = graph_stats
             line["avg_visited"] = float(st[:, 0].mean())
             line["avg_expanded"] = float(st[:, 1].mean())
             line["adc_distances_per_s"] = float(st[:, 0].mean()) * total_queries / elapsed
-            line["host_threads"] = host_cores
+            line["expansions_per_s"] = float(st[:, 1].mean()) * total_queries / elapsed
             if flat_info is not None:
                 line["flat_mode"] = flat_info
         else:
             line["adc_distances_per_s"] = float(Q) * N * args.steps * world / elapsed
         if world == 1 and not args.no_cpu_baseline:
-            ids_gpu, _ = run(timed_q[:Q], rerank_k)
+            ids_gpu = run(timed_q[:Q], rerank_k)[0]
             ctx.sync()
             codes_h = codes_t.cpu().numpy()
+            cb = pq.codebooks()
             if graph_mode:
-                line["cpu_baseline"] = cpu_baseline_graph(cb.cpu().numpy(), D, M, codes_h, levels, entry, entry_level, base,
+                line["cpu_baseline"] = cpu_baseline_graph(cb, D, M, codes_h, levels, entry, entry_level, base,
                                                           timed_q, VSF, K, rerank_k, ids_gpu.cpu().numpy())
             else:
-                line["cpu_baseline"] = cpu_baseline_flat(cb.cpu().numpy(), D, M, codes_h, base, timed_q, VSF, K, rerank_k,
+                line["cpu_baseline"] = cpu_baseline_flat(cb, D, M, codes_h, base, timed_q, VSF, K, rerank_k,
                                                          ids_gpu.cpu().numpy())
         print(json.dumps(line))
     if world > 1:

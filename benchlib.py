@@ -66,6 +66,27 @@ def train_codebooks(base, M, seed, iters=6, sample=128_000, k=256):
     return cent.reshape(-1).contiguous()
 
 
+def sift_like(n, D, seed, device, chunk=1_000_000):
+    """SURVEY §8d C1/C2 generator: non-negative integers-as-float, clip(round(|N(0,1)| * 40), 0, 218) (SIFT descriptors are
+    byte-valued, mostly small)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = torch.empty(n, D, dtype=torch.float32, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        out[s:e] = (torch.randn(e - s, D, generator=g, device=device).abs() * 40.0).round().clamp_(0, 218)
+    return out
+
+
+def recall_per_query(found, truth):
+    """per-query |top-k ∩ gt-k| / k (AccuracyMetrics.recallFromSearchResults, EX/util/AccuracyMetrics.java:38-90, before the
+    average): the mean is the reported recall, std / sqrt(n) its standard error."""
+    k = truth.shape[1]
+    out = np.empty(truth.shape[0], np.float64)
+    for i, (f, t) in enumerate(zip(found, truth)):
+        out[i] = len(set(int(x) for x in f if x >= 0) & set(int(x) for x in t)) / float(k)
+    return out
+
+
 def recall_at_k(found, truth):
     """AccuracyMetrics.recallFromSearchResults (EX/util/AccuracyMetrics.java:38-90): |top-k ∩ gt-k| / k averaged."""
     hits = 0
@@ -74,28 +95,34 @@ def recall_at_k(found, truth):
     return hits / float(truth.shape[0] * truth.shape[1])
 
 
-def ground_truth(J, ctx, vs, queries, vsf, k, chunk=1_000_000, dense=False):
-    """Exact top-k by brute force with the engine's bit-exact exact-scan kernel + NodeQueue-order top-k.
+def ground_truth(J, ctx, vs, queries, vsf, k, chunk=1_000_000, dense=False, q_group=2048):
+    """Exact top-k by brute force with the engine's exact-scan kernels + NodeQueue-order top-k, query groups of <= q_group
+    (the score buffer is q_group x chunk floats).
     dense=True: candidates from the MFMA tile form of the scan (4k per query, fused-chain scores within 1e-5 of the exact
-    ones), then the bit-exact kernel rescores just those and picks the top k — the same ids as the default whenever the
-    k-th / 4k-th score gap exceeds the two forms' disagreement (~1e-7), at a fraction of the VALU work."""
-    Q, N = queries.shape[0], vs.count
+    ones), then the bit-exact kernel rescores just those and picks the top k — the same ids as the bit-exact scan whenever
+    the k-th / 4k-th score gap exceeds the two forms' disagreement (~1e-7), at a fraction of the VALU work."""
+    Qall, N = queries.shape[0], vs.count
     kc = min(4 * k, N) if dense else k
-    part_ids, part_sc = [], []
-    buf = torch.empty(Q, min(chunk, N), dtype=torch.float32, device=queries.device)
-    for s in range(0, N, chunk):
-        c = min(chunk, N - s)
-        out = buf[:, :c] if c == buf.shape[1] else torch.empty(Q, c, dtype=torch.float32, device=queries.device)
-        vs.scan(queries, vsf, first=s, count=c, out=out, dense=dense)
-        ids, sc = J.topk(ctx, out, min(kc, c), id_base=s)
-        part_ids.append(ids)
-        part_sc.append(sc)
-    ids, sc = J.topk(ctx, torch.cat(part_sc, 1).contiguous(), kc, ids=torch.cat(part_ids, 1).contiguous())
-    if dense:
-        exact = vs.scores(queries, vsf, ids.contiguous())
-        ids, sc = J.topk(ctx, exact, k, ids=ids.contiguous())
-    ctx.sync()
-    return ids
+    buf = torch.empty(min(q_group, Qall), min(chunk, N), dtype=torch.float32, device=queries.device)
+    result = []
+    for q0 in range(0, Qall, q_group):
+        qs = queries[q0:q0 + q_group].contiguous()
+        Q = qs.shape[0]
+        part_ids, part_sc = [], []
+        for s in range(0, N, chunk):
+            c = min(chunk, N - s)
+            out = buf[:Q, :c] if (c == buf.shape[1] and Q == buf.shape[0]) else torch.empty(Q, c, dtype=torch.float32, device=queries.device)
+            vs.scan(qs, vsf, first=s, count=c, out=out, dense=dense)
+            ids, sc = J.topk(ctx, out, min(kc, c), id_base=s)
+            part_ids.append(ids)
+            part_sc.append(sc)
+        ids, sc = J.topk(ctx, torch.cat(part_sc, 1).contiguous(), kc, ids=torch.cat(part_ids, 1).contiguous())
+        if dense:
+            exact = vs.scores(qs, vsf, ids.contiguous())
+            ids, sc = J.topk(ctx, exact, k, ids=ids.contiguous())
+        ctx.sync()
+        result.append(ids.clone())
+    return torch.cat(result)
 
 
 def fused_blocks_from(codes, nbrs):

@@ -295,7 +295,10 @@ JV_API int jv_hip_graph_destroy(jv_graph *g);
  *   DEVICE : one wavefront per query keeps the queues in LDS / L2 and runs the whole loop on the GPU (uniform 8-dim
  *            sub-vectors, M a multiple of 16, degree <= 64); queries that outgrow its fixed-size structures are re-run
  *            on the host.  Results, visitedCount and expandedCount are identical either way.
- *   AUTO   : currently HOST.  The environment variable JVECTOR_HIP_GRAPH_TRAVERSAL=host|device overrides the setting. */
+ *   AUTO   : DEVICE wherever that kernel applies (shape as above and the queues fit LDS), else HOST.
+ *            The environment variable JVECTOR_HIP_GRAPH_TRAVERSAL=host|device overrides the setting.
+ *   Queries that outgrow the device kernel's fixed-size structures are first retried on the device with an 8x / 64x
+ *   larger visited table; only what still overflows is re-run on the host. */
 enum { JV_TRAVERSAL_AUTO = 0, JV_TRAVERSAL_HOST = 1, JV_TRAVERSAL_DEVICE = 2 };
 JV_API int jv_hip_graph_set_traversal(jv_graph *g, int mode);
 JV_API int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *luts, const jv_codes *codes,
@@ -349,6 +352,39 @@ JV_API int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts 
                                         const jv_fused *fused, const jv_vectors *vectors, const float *queries, int Q,
                                         jv_vsf vsf, int topK, int rerankK, const uint64_t *accept_bits,
                                         int64_t accept_stride_words, int32_t *out_ids, float *out_scores, int64_t *stats);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sharded index (BASELINE config 4; SURVEY §8b "jv_hip_sharded_topk (RCCL)", §8e): PQ codes and base vectors are
+ * partitioned by contiguous ordinal range (the analogue of PQVectors' chunking, B/quantization/PQVectors.java:515-540),
+ * ONE RANK PER GPU — a process, or one host thread of a JVM, each with its own jv_ctx.  The reference has no sharded
+ * search; the contract is equality with the single index: ids and scores bit-identical to jv_hip_search_flat over the
+ * concatenated index, engineered score ties included (NodeQueue order, B/graph/NodeQueue.java:125-129).
+ * Collectives: one all-gather of the partial top-rerankK (Q x rerankK x (i32, f32) per shard) and one all-gather of the
+ * owners' exact scores — RCCL over xGMI, bound at run time (dlopen librccl.so; JVECTOR_HIP_RCCL_PATH overrides).
+ *
+ *   jv_hip_comm_unique_id : rank 0 makes the 128-byte rendezvous id (ncclGetUniqueId); the HOST distributes it to the other
+ *                           ranks by its own means (Java: a shared field; torch.distributed: a broadcast).
+ *   jv_hip_comm_create    : collective over all ranks (ncclCommInitRank) on ctx's device.  id == NULL with world == 1 makes a
+ *                           purely local communicator (no RCCL loaded): all shards live on this context.
+ *   jv_hip_sharded_topk   : every rank hands its partial list (Q x k_in scores + GLOBAL ids, host or device); every rank
+ *                           receives the same merged top-k_out (best first; (-1, -inf) padded).
+ *   jv_hip_sharded_search_flat : the whole two-pass search.  This rank holds n_local shards (normally 1; every rank the same
+ *                           number): codes[s] (+ vectors[s], or vectors == NULL for no rerank) own global ordinals
+ *                           [id_base[s], id_base[s] + count).  luts: capacity >= Q, same jv_pq on every rank.
+ *                           Every rank receives the identical Q x topK result.
+ * ------------------------------------------------------------------------------------------- */
+#define JV_COMM_ID_BYTES 128
+typedef struct jv_comm jv_comm;
+JV_API int jv_hip_comm_unique_id(uint8_t *id_out /* JV_COMM_ID_BYTES */);
+JV_API int jv_hip_comm_create(jv_ctx *ctx, const uint8_t *id, int rank, int world, jv_comm **out);
+JV_API int jv_hip_comm_destroy(jv_comm *comm);
+JV_API int jv_hip_comm_rank(const jv_comm *comm);
+JV_API int jv_hip_comm_world(const jv_comm *comm);
+JV_API int jv_hip_sharded_topk(jv_ctx *ctx, jv_comm *comm, const float *scores, const int32_t *ids, int Q, int k_in, int k_out,
+                               int32_t *out_ids, float *out_scores);
+JV_API int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts *luts, const jv_codes *const *codes,
+                                      const jv_vectors *const *vectors, const int64_t *id_base, const float *queries, int Q,
+                                      jv_vsf vsf, int topK, int rerankK, int32_t *out_ids, float *out_scores);
 
 #ifdef __cplusplus
 }

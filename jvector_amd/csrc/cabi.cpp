@@ -161,6 +161,20 @@ int ensure_code_norms(jv_ctx *ctx, jv_codes *codes)
     return JV_OK;
 }
 
+int ensure_vector_norms(jv_ctx *ctx, jv_vectors *v)
+{
+    std::lock_guard<std::mutex> lk(g_norms_mu);
+    if (v->sqnorm_valid) return JV_OK;
+    if (!v->d_sqnorm) JV_HIP_CHECK(hipMalloc((void **)&v->d_sqnorm, sizeof(float) * (size_t)std::max<int64_t>(v->count, 1)));
+    {
+        ProfScope ps(ctx, R_NORMS);
+        JV_TRY(launch_row_sqnorms(ctx->stream, v->d_vecs, v->count, v->D, v->d_sqnorm));
+    }
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    v->sqnorm_valid = true;
+    return JV_OK;
+}
+
 int ensure_fused_norms(jv_ctx *ctx, jv_fused *f)
 {
     std::lock_guard<std::mutex> lk(g_norms_mu);
@@ -319,7 +333,7 @@ int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, i
 {
     clear_error();
     JV_REQUIRE(ctx && region, "NULL argument");
-    static const char *names[R_COUNT] = {"adc", "topk", "exact", "lut", "encode", "norms", "sample"};
+    static const char *names[R_COUNT] = {"adc", "topk", "exact", "lut", "encode", "norms", "sample", "gsearch"};
     int r = -1;
     for (int i = 0; i < R_COUNT; ++i)
         if (strcmp(names[i], region) == 0) r = i;
@@ -666,6 +680,7 @@ int jv_hip_vectors_upload(jv_ctx *ctx, jv_vectors *v, int64_t first, int64_t cou
     JV_HIP_CHECK(hipMemcpyAsync(v->d_vecs + first * v->D, src, sizeof(float) * (size_t)count * v->D, hipMemcpyDefault,
                                 ctx->stream));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    v->sqnorm_valid = false;
     return JV_OK;
 }
 
@@ -674,6 +689,7 @@ int jv_hip_vectors_destroy(jv_vectors *v)
     if (!v) return JV_OK;
     (void)hipSetDevice(v->device);
     if (v->owns) (void)hipFree(v->d_vecs);
+    (void)hipFree(v->d_sqnorm);
     delete v;
     return JV_OK;
 }
@@ -760,9 +776,11 @@ int jv_hip_luts_destroy(jv_luts *l)
     return JV_OK;
 }
 
-int jv_hip_luts_build(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_vsf vsf, jv_decoder_kind kind)
+}  // extern "C"
+
+namespace jv {
+int luts_prepare(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_vsf vsf, jv_decoder_kind kind, bool with_tables)
 {
-    clear_error();
     JV_REQUIRE(ctx && l, "luts_build: NULL argument");
     JV_REQUIRE(Q >= 0 && Q <= l->capacity, "luts_build: Q=%d exceeds capacity %d", Q, l->capacity);
     JV_REQUIRE(vsf == JV_EUCLIDEAN || vsf == JV_DOT_PRODUCT || vsf == JV_COSINE, "Unsupported similarity function %d",
@@ -770,6 +788,7 @@ int jv_hip_luts_build(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_v
     l->Q = Q;
     l->vsf = vsf;
     l->kind = kind;
+    l->tables_valid = false;
     if (Q == 0) return JV_OK;
     JV_REQUIRE(queries, "luts_build: queries is NULL");
     JV_TRY(use_device(ctx->device));
@@ -785,12 +804,24 @@ int jv_hip_luts_build(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_v
     }
     ProfScope ps(ctx, R_LUT);
     JV_TRY(launch_center_queries(ctx->stream, pq, l->d_raw_queries, Q, l->d_queries));
-    // cosine numerator uses the DOT_PRODUCT partial sums (PQDecoder.java:117, FusedPQDecoder.java:187)
-    const int lut_vsf = (vsf == JV_EUCLIDEAN) ? VSF_L2 : VSF_DOT;
-    JV_TRY(launch_lut_build(ctx->stream, pq, l->d_queries, Q, lut_vsf, l->d_luts));
+    if (with_tables) {
+        // cosine numerator uses the DOT_PRODUCT partial sums (PQDecoder.java:117, FusedPQDecoder.java:187)
+        const int lut_vsf = (vsf == JV_EUCLIDEAN) ? VSF_L2 : VSF_DOT;
+        JV_TRY(launch_lut_build(ctx->stream, pq, l->d_queries, Q, lut_vsf, l->d_luts));
+        l->tables_valid = true;
+    }
     if (vsf == JV_COSINE)
         JV_TRY(launch_query_magnitudes(ctx->stream, pq, l->d_queries, Q, kind == JV_DECODER_FUSED ? 1 : 0, l->d_bmag));
     return JV_OK;
+}
+}  // namespace jv
+
+extern "C" {
+
+int jv_hip_luts_build(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_vsf vsf, jv_decoder_kind kind)
+{
+    clear_error();
+    return luts_prepare(ctx, l, queries, Q, vsf, kind, true);
 }
 
 int jv_hip_luts_download(jv_ctx *ctx, const jv_luts *l, int q, float *lut_out, float *bmag_out)
@@ -798,6 +829,7 @@ int jv_hip_luts_download(jv_ctx *ctx, const jv_luts *l, int q, float *lut_out, f
     clear_error();
     JV_REQUIRE(ctx && l, "luts_download: NULL argument");
     JV_REQUIRE(q >= 0 && q < l->Q, "luts_download: query %d out of range", q);
+    JV_REQUIRE(l->tables_valid || !lut_out, "luts_download: the tables were overwritten by a table-free graph search; call jv_hip_luts_build again");
     JV_TRY(use_device(ctx->device));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const size_t n = (size_t)l->pq->M * kClusters;
@@ -818,6 +850,7 @@ int jv_hip_adc_scan(jv_ctx *ctx, const jv_luts *l, const jv_codes *codes, int64_
     clear_error();
     JV_REQUIRE(ctx && l && codes, "adc_scan: NULL argument");
     JV_REQUIRE(codes->pq == l->pq, "adc_scan: LUTs and codes belong to different ProductQuantizations");
+    JV_REQUIRE(l->tables_valid || l->Q == 0, "adc_scan: no tables for the current queries; call jv_hip_luts_build first");
     JV_REQUIRE(first >= 0 && count >= 0 && first + count <= codes->count,
                "Ordinal range [%lld,%lld) out of bounds for vector count %lld", (long long)first,
                (long long)(first + count), (long long)codes->count);
@@ -846,6 +879,7 @@ int jv_hip_adc_scores(jv_ctx *ctx, const jv_luts *l, const jv_codes *codes, cons
     clear_error();
     JV_REQUIRE(ctx && l && codes, "adc_scores: NULL argument");
     JV_REQUIRE(codes->pq == l->pq, "adc_scores: LUTs and codes belong to different ProductQuantizations");
+    JV_REQUIRE(l->tables_valid || l->Q == 0, "adc_scores: no tables for the current queries; call jv_hip_luts_build first");
     JV_REQUIRE(B >= 0, "adc_scores: negative batch");
     if (l->Q == 0 || B == 0) return JV_OK;
     JV_REQUIRE(ordinals && scores_out, "adc_scores: NULL buffer");
@@ -925,6 +959,7 @@ int jv_hip_fused_scores(jv_ctx *ctx, const jv_luts *l, const jv_fused *f, const 
     clear_error();
     JV_REQUIRE(ctx && l && f, "fused_scores: NULL argument");
     JV_REQUIRE(f->pq == l->pq, "fused_scores: LUTs and fused blocks belong to different ProductQuantizations");
+    JV_REQUIRE(l->tables_valid || l->Q == 0, "fused_scores: no tables for the current queries; call jv_hip_luts_build first");
     if (l->Q == 0) return JV_OK;
     JV_REQUIRE(origins && scores_out, "fused_scores: NULL buffer");
     JV_TRY(use_device(ctx->device));
@@ -965,10 +1000,11 @@ int jv_hip_exact_scores(jv_ctx *ctx, const jv_vectors *v, const float *queries, 
     JV_TRY(ctx->d_scratch3.reserve(sizeof(float) * (size_t)Q));
     OutStage os;
     JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)Q * B, ctx->d_out, &os));
+    if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(v)));
     {
         ProfScope ps(ctx, R_EXACT);
         JV_TRY(launch_exact_gather(ctx->stream, v->d_vecs, v->count, v->D, (const float *)d_q, Q, to_kernel_vsf(vsf),
-                                   (const int32_t *)d_ord, B, (float *)os.dev, (float *)ctx->d_scratch3.ptr));
+                                   (const int32_t *)d_ord, B, (float *)os.dev, (float *)ctx->d_scratch3.ptr, v->d_sqnorm));
     }
     return stage_out_end(ctx, os);
 }
@@ -1173,10 +1209,11 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
 
     // ---------------- pass 2 ----------------
     if (rerank) {
+        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
         {
             ProfScope ps(ctx, R_EXACT);
             JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q,
-                                       kvsf, d_cand, k1, d_exact, d_qnorm));
+                                       kvsf, d_cand, k1, d_exact, d_qnorm, vectors->d_sqnorm));
         }
         ProfScope ps(ctx, R_TOPK);
         JV_TRY(launch_topk(ctx->stream, ctx, d_exact, d_cand, Q, k1, k1, 0, topK, (int32_t *)oi.dev, (float *)osc.dev,

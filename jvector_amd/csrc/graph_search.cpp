@@ -838,9 +838,10 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
                                 ctx->stream));
     JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, topK)));
     if (vectors) {
+        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
         ProfScope ps(ctx, R_EXACT);
         JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf,
-                                   d_cand, rerankK, d_cand_sc, d_qnorm));
+                                   d_cand, rerankK, d_cand_sc, d_qnorm, vectors->d_sqnorm));
     }
     {
         ProfScope ps(ctx, R_TOPK);
@@ -913,7 +914,8 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
                                int32_t *out_ids, float *out_scores, int64_t *stats, AcceptMask host_accept, AcceptMask dev_accept)
 {
     const jv_decoder_kind kind = fused ? JV_DECODER_FUSED : JV_DECODER_PQ;
-    JV_TRY(jv_hip_luts_build(ctx, l, queries, Q, vsf, kind));  // centred queries, query magnitudes, raw copy for the rerank
+    // centred queries, query magnitudes, raw copy for the rerank — NO look-up tables: the kernel scores table-free
+    JV_TRY(luts_prepare(ctx, l, queries, Q, vsf, kind, false));
     const int kvsf = to_kernel_vsf(vsf);
     if (vsf == JV_COSINE) {
         JV_TRY(ensure_code_norms(ctx, const_cast<jv_codes *>(codes)));
@@ -961,6 +963,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const size_t o_ids = carve(sizeof(int32_t) * c1), o_sc = carve(sizeof(float) * c1), o_qn = carve(sizeof(float) * (size_t)Q);
     const size_t o_stats = carve(sizeof(long long) * 2 * (size_t)Q), o_status = carve(sizeof(int32_t) * (size_t)Q);
     const size_t o_counter = carve(sizeof(uint32_t));
+    const size_t o_qmap = carve(sizeof(int32_t) * (size_t)Q);
+    const bool gs_prof = env_int("JVECTOR_HIP_GS_PROF", 0) != 0;
+    const size_t o_prof = carve(sizeof(unsigned long long) * 8);
     JV_TRY(ctx->d_gs_out.reserve(off));
     char *base = (char *)ctx->d_gs_out.ptr;
     int32_t *d_cand = (int32_t *)(base + o_ids);
@@ -970,6 +975,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     int32_t *d_status = (int32_t *)(base + o_status);
     uint32_t *d_counter = (uint32_t *)(base + o_counter);
     JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
+    if (gs_prof) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 8, ctx->stream));
 
     GsParams p{};
     for (int lv = 0; lv <= g->entry_level; ++lv) {
@@ -1009,9 +1015,70 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.out_stats = d_stats;
     p.out_status = d_status;
     p.next_query = d_counter;
+    p.prof = gs_prof ? (unsigned long long *)(base + o_prof) : nullptr;
     {
-        ProfScope ps(ctx, R_ADC);
+        ProfScope ps(ctx, R_GSEARCH);
         JV_TRY(launch_graph_search(ctx->stream, kvsf, p, workers, occ));
+    }
+    // ---- queries that outgrew the fixed-size structures (visited table half full, spill / evicted list full): run them
+    //      again on the device with a visited table 8x, then 64x the size (few queries -> few, roomy workers); whatever
+    //      still overflows goes to the host searcher below.  One 4-byte-per-query status read per batch.
+    std::vector<int32_t> status((size_t)Q);
+    std::vector<int> redo;
+    size_t n_overflow_first = 0;
+    {
+        JV_TRY(ctx->h_out.reserve(sizeof(int32_t) * (size_t)Q));
+        JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_status, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        memcpy(status.data(), ctx->h_out.ptr, sizeof(int32_t) * (size_t)Q);
+        for (int q = 0; q < Q; ++q)
+            if (status[q] != GS_OK) redo.push_back(q);
+        n_overflow_first = redo.size();
+    }
+    // JVECTOR_HIP_GS_VCAP_LOG2 pins a (tiny) table so that tests reach the host fallback: no retry then, unless
+    // JVECTOR_HIP_GS_RETRY=1 asks for it (the test of this very path)
+    const bool retry = getenv("JVECTOR_HIP_GS_RETRY") ? env_int("JVECTOR_HIP_GS_RETRY", 1) != 0 : getenv("JVECTOR_HIP_GS_VCAP_LOG2") == nullptr;
+    for (int attempt = 1; attempt <= 2 && !redo.empty() && retry; ++attempt) {
+        const int vlog2 = std::min(24, vcap_log2 + 3 * attempt);
+        if (vlog2 <= vcap_log2 + 3 * (attempt - 1)) break;
+        const size_t vcap2 = (size_t)1 << vlog2;
+        const int spill2 = (int)(vcap2 / 2) + 64;
+        const int R = (int)redo.size();
+        const int workers2 = std::max(1, std::min<int>({R, workers, (int)(((size_t)512 << 20) / (vcap2 * 12))}));
+        JV_TRY(ctx->d_gs_visited.reserve(sizeof(int32_t) * vcap2 * (size_t)workers2));
+        JV_TRY(ctx->d_gs_spill.reserve(sizeof(long long) * (size_t)spill2 * (size_t)workers2));
+        memcpy(ctx->h_out.ptr, redo.data(), sizeof(int32_t) * (size_t)R);
+        JV_HIP_CHECK(hipMemcpyAsync(base + o_qmap, ctx->h_out.ptr, sizeof(int32_t) * (size_t)R, hipMemcpyHostToDevice, ctx->stream));
+        JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
+        GsParams p2 = p;
+        p2.qmap = (const int32_t *)(base + o_qmap);
+        p2.Q = R;
+        p2.visited = (int32_t *)ctx->d_gs_visited.ptr;
+        p2.vcap_log2 = vlog2;
+        p2.spill = (long long *)ctx->d_gs_spill.ptr;
+        p2.spill_cap = spill2;
+        p2.prof = nullptr;
+        {
+            ProfScope ps(ctx, R_GSEARCH);
+            JV_TRY(launch_graph_search(ctx->stream, kvsf, p2, workers2, occ));
+        }
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // h_out is reused below
+        JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_status, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        memcpy(status.data(), ctx->h_out.ptr, sizeof(int32_t) * (size_t)Q);
+        std::vector<int> still;
+        for (int q : redo)
+            if (status[q] != GS_OK) still.push_back(q);
+        redo.swap(still);
+    }
+    if (gs_prof) {
+        unsigned long long h[8];
+        JV_HIP_CHECK(hipMemcpyAsync(h, base + o_prof, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const double e = (double)std::max<unsigned long long>(h[5], 1);
+        fprintf(stderr, "[jv gs prof] clocks/expansion: pop %.0f  result %.0f  row+block+visited %.0f  score %.0f  push %.0f | expansions %llu "
+                        "queries %llu  setup+epilogue clocks/query %.0f\n", h[0] / e, h[1] / e, h[2] / e, h[3] / e, h[4] / e, h[5], h[6],
+                (double)h[7] / (double)std::max<unsigned long long>(h[6], 1));
     }
 
     // ---- reranking :471-507 on the device-resident candidates ----
@@ -1020,9 +1087,10 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * topK, ctx->d_scratch3, &osc));
     JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, topK)));
     if (vectors) {
+        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
         ProfScope ps(ctx, R_EXACT);
         JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf, d_cand,
-                                   rerankK, d_cand_sc, d_qnorm));
+                                   rerankK, d_cand_sc, d_qnorm, vectors->d_sqnorm));
     }
     {
         ProfScope ps(ctx, R_TOPK);
@@ -1031,24 +1099,22 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     }
     JV_TRY(stage_out_end(ctx, oi));
     JV_TRY(stage_out_end(ctx, osc));
-    // stage_out_end stages through ctx->h_out: fetch the per-query status / counters only after it is done with it
-    JV_TRY(ctx->h_out.reserve(sizeof(long long) * 2 * (size_t)Q + sizeof(int32_t) * (size_t)Q));
-    long long *h_stats = (long long *)ctx->h_out.ptr;
-    int32_t *h_status = (int32_t *)(h_stats + 2 * (size_t)Q);
-    JV_HIP_CHECK(hipMemcpyAsync(h_stats, d_stats, sizeof(long long) * 2 * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
-    JV_HIP_CHECK(hipMemcpyAsync(h_status, d_status, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
-    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    std::vector<int> redo;
-    for (int q = 0; q < Q; ++q) {
-        if (h_status[q] != GS_OK) redo.push_back(q);
-        if (stats) {
+    // stage_out_end stages through ctx->h_out: fetch the per-query counters only after it is done with it
+    if (stats) {
+        JV_TRY(ctx->h_out.reserve(sizeof(long long) * 2 * (size_t)Q));
+        long long *h_stats = (long long *)ctx->h_out.ptr;
+        JV_HIP_CHECK(hipMemcpyAsync(h_stats, d_stats, sizeof(long long) * 2 * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int q = 0; q < Q; ++q) {
             stats[2 * q] = h_stats[2 * q];
             stats[2 * q + 1] = h_stats[2 * q + 1];
         }
+    } else {
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
     if (getenv("JVECTOR_HIP_GRAPH_TIMING"))
-        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d) lds=%zu cand_cap=%d vcap=%zu overflow=%zu\n", Q, workers,
-                per_cu, occ, (int)pair, lds, cand_cap, vcap, redo.size());
+        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d) lds=%zu cand_cap=%d vcap=%zu overflow=%zu -> host %zu\n", Q,
+                workers, per_cu, occ, (int)pair, lds, cand_cap, vcap, n_overflow_first, redo.size());
     if (redo.empty()) return JV_OK;
 
     // ---- queries that outgrew the fixed-size device structures: same search on the host ----

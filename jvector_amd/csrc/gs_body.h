@@ -11,6 +11,7 @@
 //     gs_shfl_xor(long long v, int laneMask)  butterfly exchange
 //     gs_cas(int32_t *p, int32_t expect, int32_t desired) -> old      (device-scope atomic)
 //     gs_fetch_add(uint32_t *p, uint32_t v) -> old                    (device-scope atomic)
+//     gs_fetch_add64(unsigned long long *p, unsigned long long v)     (device-scope atomic; profiling aid only)
 //     gs_fence()                              device-scope memory fence
 //     gs_sqrt(double)
 //     GS_SCHED_FENCE()                        instruction-scheduling fence (may be empty)
@@ -341,11 +342,28 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
     gs_barrier();
 }
 
+#ifndef GS_CLOCK
+#define GS_CLOCK() 0ull  // the GPU build maps it to the shader clock (gs_wave_hip.h); the emulator has no clock
+#endif
+
 // One query, start to finish.  lds: gs_lds_bytes() bytes, 16-byte aligned.
 // PAIR: every level's degree is <= 32 -> pair-lane scoring (decided by the host at launch)
-template <int VSF, int CH16, bool PAIR>
+// PROF: developer aid — per-phase shader-clock totals of the expansion loop are added to p.prof[0..7]
+//       (pop, result insert, row + block + visited probes, scoring, push, expansions, queries, setup + epilogue)
+template <int VSF, int CH16, bool PAIR, bool PROF = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
+    unsigned long long pf[5] = {0, 0, 0, 0, 0};
+    unsigned long long pt = 0, pq0 = 0;
+    if (PROF) pq0 = GS_CLOCK();
+#define GS_PHASE(i)                          \
+    do {                                     \
+        if (PROF) {                          \
+            const unsigned long long now_ = GS_CLOCK(); \
+            pf[i] += now_ - pt;              \
+            pt = now_;                       \
+        }                                    \
+    } while (0)
     const int lane = gs_lane();
     float *qs = reinterpret_cast<float *>(lds);
     GsState s;
@@ -400,6 +418,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         // ---- searchOneLayer :406-457 ----
         for (;;) {
             if (s.cand_n == 0 && s.spill_n == 0) break;
+            if (PROF) pt = GS_CLOCK();
             int idx;
             long long top;
             const bool from_lds = s.cand_n > 0;
@@ -421,6 +440,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 s.spill_max = top;  // still an upper bound of what is left
                 gs_fence();
             }
+            GS_PHASE(0);
             // threshold 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the results (the
             // node is expanded all the same); then addTopCandidate :515-530 (BoundedLongHeap.push / updateTop)
             bool result = top_score >= 0.0f;
@@ -454,6 +474,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 gs_barrier();
             }
             n_expanded++;
+            GS_PHASE(1);
 
             // ---- expand: visited.mark + score + candidates.push for every unvisited neighbour ----
             const int32_t node = gs_key_node(top);
@@ -490,6 +511,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     s.status = GS_OVERFLOW;
                     break;
                 }
+                GS_PHASE(2);
                 const bool work = ((fm >> ni) & 1ull) != 0;  // this lane's pair has a fresh neighbour
                 float sum = 0.0f;
                 if (work) sum = gs_half_entries<VSF, CH16>(p.codebooks, qs, w, m_base, hi ? xchg + ni : nullptr);
@@ -523,9 +545,16 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     s.status = GS_OVERFLOW;
                     break;
                 }
+                GS_PHASE(2);
                 if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CH16>(p.codebooks, qs, w), node_mag, query_mag));
             }
+            if (PROF) {  // the scores must have arrived before the phase is closed
+                const uint64_t done_ = gs_ballot(fresh && key != 0);
+                if (done_ == 0xdeadbeefdeadbeefull) n_visited++;
+            }
+            GS_PHASE(3);
             gs_push(s, p, key, fresh);
+            GS_PHASE(4);
             if (s.status != GS_OK) break;
         }
         if (s.status != GS_OK) break;
@@ -559,18 +588,29 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         p.out_status[q] = s.status;
     }
     gs_barrier();
+    if (PROF && p.prof && lane == 0) {
+        unsigned long long in_loop = 0;
+        for (int i = 0; i < 5; ++i) {
+            gs_fetch_add64(p.prof + i, pf[i]);
+            in_loop += pf[i];
+        }
+        gs_fetch_add64(p.prof + 5, (unsigned long long)n_expanded);
+        gs_fetch_add64(p.prof + 6, 1ull);
+        gs_fetch_add64(p.prof + 7, (GS_CLOCK() - pq0) - in_loop);
+    }
+#undef GS_PHASE
 }
 
 // Persistent worker: pulls queries off the shared counter until none are left.
-template <int VSF, int CH16, bool PAIR>
+template <int VSF, int CH16, bool PAIR, bool PROF = false>
 GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
 {
     for (;;) {
         long long qv = 0;
         if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
-        const int q = (int)gs_shfl(qv, 0);
-        if (q >= p.Q) break;
-        gs_search_one<VSF, CH16, PAIR>(p, q, worker, lds);
+        const int item = (int)gs_shfl(qv, 0);
+        if (item >= p.Q) break;
+        gs_search_one<VSF, CH16, PAIR, PROF>(p, p.qmap ? p.qmap[item] : item, worker, lds);
     }
 }
 

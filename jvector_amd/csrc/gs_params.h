@@ -34,6 +34,7 @@ struct GsParams {
     int32_t D, M, deg0;
     // search
     int32_t Q, rerankK;
+    const int32_t *qmap;      // nullptr: work items 0..Q-1 ARE the query indices; else item i runs query qmap[i] (retry pass)
     const unsigned long long *accept;  // acceptOrds bit array (bit n of word n / 64) or nullptr = Bits.ALL; layer 0 only
     long long accept_stride;           // words between the masks of consecutive queries; 0 = one mask for the batch
     // per-worker scratch
@@ -49,6 +50,7 @@ struct GsParams {
     long long *out_stats;     // [Q][2] visitedCount, expandedCount
     int32_t *out_status;      // [Q] GS_OK / GS_OVERFLOW
     uint32_t *next_query;     // work counter (zeroed by the host before the launch)
+    unsigned long long *prof; // developer aid (JVECTOR_HIP_GS_PROF=1): 8 phase counters, see gs_search_one; else nullptr
 };
 
 // LDS bytes one worker needs

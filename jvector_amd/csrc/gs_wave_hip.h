@@ -14,6 +14,8 @@ __device__ __forceinline__ long long gs_shfl(long long v, int src) { return __sh
 __device__ __forceinline__ long long gs_shfl_xor(long long v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired) { return atomicCAS(p, expect, desired); }
 __device__ __forceinline__ uint32_t gs_fetch_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ void gs_fetch_add64(unsigned long long *p, unsigned long long v) { (void)atomicAdd(p, v); }
+#define GS_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
 __device__ __forceinline__ void gs_fence() { __threadfence(); }
 __device__ __forceinline__ double gs_sqrt(double x) { return sqrt(x); }
 // ed_body.h: f32-input MFMA (bitwise a k-ordered fmaf chain; A: lane l holds A[l & 31][l >> 5], B: B[l >> 5][l & 31]) and fmaf

@@ -56,7 +56,7 @@ struct Buffer {
 }  // namespace jv
 
 namespace jv {
-enum Region : int { R_ADC = 0, R_TOPK, R_EXACT, R_LUT, R_ENCODE, R_NORMS, R_SAMPLE, R_COUNT };
+enum Region : int { R_ADC = 0, R_TOPK, R_EXACT, R_LUT, R_ENCODE, R_NORMS, R_SAMPLE, R_GSEARCH, R_COUNT };
 struct ProfEvent {
     int region;
     hipEvent_t start, stop;
@@ -132,6 +132,10 @@ struct jv_vectors {
     int D = 0;
     float *d_vecs = nullptr;
     bool owns = false;
+    // cosine rerank: per-row sum of squares (the query-independent norm2 accumulator), built lazily by
+    // ensure_vector_norms, invalidated by uploads
+    float *d_sqnorm = nullptr;
+    bool sqnorm_valid = false;
 };
 
 struct jv_fused {
@@ -157,6 +161,7 @@ struct jv_luts {
     float *d_bmag = nullptr;   // capacity
     float *d_queries = nullptr; // capacity x D : centred queries (cq = q - globalCentroid)
     float *d_raw_queries = nullptr; // capacity x D : un-centred copy (rerank)
+    bool tables_valid = false;  // d_luts holds the tables of the current queries (false after a queries-only prepare)
 };
 
 // ---- host helpers shared by cabi.cpp and graph_search.cpp ----
@@ -175,6 +180,7 @@ int stage_out_end(jv_ctx *ctx, const OutStage &st);
 int to_kernel_vsf(jv_vsf v);
 int use_device(int device);
 int ensure_code_norms(jv_ctx *ctx, jv_codes *codes);
+int ensure_vector_norms(jv_ctx *ctx, jv_vectors *v);
 int ensure_fused_norms(jv_ctx *ctx, jv_fused *f);
 
 // RAII region timer: two hipEventRecord calls on the context's stream when profiling is on, nothing otherwise.
@@ -229,7 +235,8 @@ int launch_fused(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const fl
                  int64_t n_nodes, const int32_t *d_origins, float *d_out, int32_t *d_neighbors_out);
 
 int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf,
-                        const int32_t *d_ord, int B, float *d_out, float *d_qnorm);
+                        const int32_t *d_ord, int B, float *d_out, float *d_qnorm, const float *d_vnorm);
+int launch_row_sqnorms(hipStream_t s, const float *d_vecs, int64_t n, int D, float *d_out);
 // MFMA tile form (k_exact_dense.hip / ed_body.h): fused chains, not bit-identical to launch_exact_scan
 int launch_exact_scan_dense(hipStream_t s, const float *d_vecs, int D, const float *d_q, int Q, int vsf, int64_t first,
                             int64_t count, float *d_out);
@@ -261,6 +268,9 @@ int launch_direct_scores(hipStream_t s, const jv_codes *codes, int vsf, const fl
                          float *d_qnorm, float *d_out);
 // device-resident graph traversal (k_gsearch.hip; parameters in gs_params.h)
 struct GsParams;
+// stage the queries of a batch (raw copy, centred copy, cosine query magnitudes); with_tables also builds the ADC look-up
+// tables (jv_hip_luts_build = with_tables true).  The table-free traversal kernels pass false: 96 KB per query saved.
+int luts_prepare(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_vsf vsf, jv_decoder_kind kind, bool with_tables);
 bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels);
 size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M);
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy);

@@ -9,6 +9,8 @@
 //
 //   gather form (rerank):  grid (Q, ceil(B/64)), block 64.  query in LDS (broadcast reads).
 //   scan form (brute force / ground truth): grid (ceil(count/256)), block 256, loops over query tiles.
+#include <cstdlib>
+
 #include "jv_device.h"
 #include "jv_internal.h"
 
@@ -163,14 +165,189 @@ __global__ __launch_bounds__(64) void exact_gather_kernel(const float *__restric
     *dst = score_from_raw(VSF, raw);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Transposing gather form (D % 8 == 0, 16-byte aligned rows): HBM is read with full-line coalescing and the per-lane
+// sequential chains run out of LDS.
+//
+// One wavefront = 64 candidates of one query.  A row is consumed in chunks of 64 floats: in the LOAD phase the wave
+// reads 4 rows x 256 B per instruction (16 lanes x 16 B per row: whole 128-byte lines, 16 instructions = 16 KB in
+// flight per wave) and parks the chunk in LDS as tile[row][64 + 4 pad]; in the COMPUTE phase lane j walks row j of the
+// tile with ds_read_b128 (row stride 68 dwords: the four 16-lane groups of a b128 read hit 64 distinct banks) and runs
+// the reference's chain against the query, which is wave-uniform and comes through scalar loads.  The loads of
+// chunk c+1 are issued before chunk c is computed, so HBM latency hides behind the chain.
+// The old lane-per-row kernels touched 64 different lines per wave-load and used 16 B of each (0.17 of HBM peak).
+// Cosine: norm2 = sum of e2*e2 (DefaultVectorUtilSupport.cosine :131-137) is query independent and a separate
+// accumulator, so it is read from a per-row table built once by row_sqnorm_kernel in the same order (same bits).
+// ------------------------------------------------------------------------------------------------
+constexpr int TR_CH = 64;          // floats of a row per chunk
+constexpr int TR_LS = TR_CH + 4;   // LDS row stride (dwords)
+
+// chain over one chunk of `len` floats (multiple of 8) of the lane's row in LDS against the uniform query slice a[]
+template <int VSF>
+__device__ __forceinline__ void tr_chunk(const float *__restrict__ row, const float *__restrict__ a, int len, float &acc)
+{
+    if (len == TR_CH) {
+#pragma unroll
+        for (int i = 0; i < TR_CH; i += 8) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(row + i);
+            const float4 v1 = *reinterpret_cast<const float4 *>(row + i + 4);
+            if (VSF == VSF_DOT) acc += dot8(a + i, v0, v1);
+            else if (VSF == VSF_L2) acc += l28(a + i, v0, v1);
+            else {
+                float s = acc;
+                s += a[i + 0] * v0.x; s += a[i + 1] * v0.y; s += a[i + 2] * v0.z; s += a[i + 3] * v0.w;
+                s += a[i + 4] * v1.x; s += a[i + 5] * v1.y; s += a[i + 6] * v1.z; s += a[i + 7] * v1.w;
+                acc = s;
+            }
+        }
+    } else {
+        for (int i = 0; i < len; i += 8) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(row + i);
+            const float4 v1 = *reinterpret_cast<const float4 *>(row + i + 4);
+            if (VSF == VSF_DOT) acc += dot8(a + i, v0, v1);
+            else if (VSF == VSF_L2) acc += l28(a + i, v0, v1);
+            else {
+                float s = acc;
+                s += a[i + 0] * v0.x; s += a[i + 1] * v0.y; s += a[i + 2] * v0.z; s += a[i + 3] * v0.w;
+                s += a[i + 4] * v1.x; s += a[i + 5] * v1.y; s += a[i + 6] * v1.z; s += a[i + 7] * v1.w;
+                acc = s;
+            }
+        }
+    }
+}
+
+// SQ = true: acc = sum of e*e over the row (no query) — builds the cosine norm table
+template <int VSF, bool SQ>
+__device__ __forceinline__ float tr_rows(const float *__restrict__ vecs, int D, int64_t my_row /* -1 = none */,
+                                         const float *__restrict__ a, float *tile)
+{
+    const int lane = threadIdx.x;
+    const int seg = (lane & 15) * 4;   // this lane's 16 bytes inside a row's 256-byte chunk
+    const int sub = lane >> 4;         // load instruction k fetches rows 4k + sub
+    const float *rp[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t ro = __shfl(my_row, 4 * k + sub, 64);
+        rp[k] = ro >= 0 ? vecs + ro * D + seg : nullptr;
+    }
+    const int nc = (D + TR_CH - 1) / TR_CH;
+    float4 r[16];
+    auto issue = [&](int c) {
+        const bool in = c * TR_CH + seg < D;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            r[k] = (rp[k] && in) ? *reinterpret_cast<const float4 *>(rp[k] + c * TR_CH) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    issue(0);
+    float acc = 0.0f;
+    for (int c = 0; c < nc; ++c) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<float4 *>(tile + (4 * k + sub) * TR_LS + seg) = r[k];
+        __syncthreads();
+        if (c + 1 < nc) issue(c + 1);
+        const int len = (D - c * TR_CH < TR_CH) ? (D - c * TR_CH) : TR_CH;
+        const float *row = tile + lane * TR_LS;
+        if (SQ) {
+            for (int i = 0; i < len; i += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + i);
+                acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
+            }
+        } else {
+            tr_chunk<VSF>(row, a + c * TR_CH, len, acc);
+        }
+        __syncthreads();
+    }
+    return acc;
+}
+
+template <int VSF>
+__global__ __launch_bounds__(64) void exact_gather_tr_kernel(const float *__restrict__ vecs, int64_t n, int D,
+                                                             const float *__restrict__ queries,
+                                                             const float *__restrict__ qnorm,
+                                                             const float *__restrict__ vnorm,
+                                                             const int32_t *__restrict__ ord, int B,
+                                                             float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float tile[64 * TR_LS];
+    const int q = blockIdx.x;
+    const int j = blockIdx.y * 64 + threadIdx.x;
+    int64_t o = -1;
+    if (j < B) {
+        o = ord[(int64_t)q * B + j];
+        if (o >= n) o = -1;
+    }
+    const float raw0 = tr_rows<VSF, false>(vecs, D, o, queries + (int64_t)q * D, tile);
+    if (j >= B) return;
+    float *dst = out + (int64_t)q * B + j;
+    if (o < 0) {
+        *dst = -INFINITY;
+        return;
+    }
+    const float raw = (VSF == VSF_COS) ? cosine_finish(raw0, qnorm[q], vnorm[o]) : raw0;
+    *dst = score_from_raw(VSF, raw);
+}
+
+// norm table: out[i] = sum_j v[i][j]^2, j ascending (the norm2 accumulator of DefaultVectorUtilSupport.cosine)
+__global__ __launch_bounds__(64) void row_sqnorm_tr_kernel(const float *__restrict__ vecs, int64_t n, int D,
+                                                           float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float tile[64 * TR_LS];
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const float s = tr_rows<VSF_COS, true>(vecs, D, i < n ? i : -1, nullptr, tile);
+    if (i < n) out[i] = s;
+}
+
+// generic-D fallback of the table: one thread per row
+__global__ void row_sqnorm_kernel(const float *__restrict__ vecs, int64_t n, int D, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *v = vecs + i * D;
+    float s = 0.0f;
+    for (int j = 0; j < D; ++j) s += v[j] * v[j];
+    out[i] = s;
+}
+
+bool exact_tr_supported(const float *d_vecs, int D) { return D % 8 == 0 && D >= 8 && (reinterpret_cast<uintptr_t>(d_vecs) & 15) == 0; }
+
+int launch_row_sqnorms(hipStream_t s, const float *d_vecs, int64_t n, int D, float *d_out)
+{
+    if (n == 0) return JV_OK;
+    if (exact_tr_supported(d_vecs, D))
+        hipLaunchKernelGGL(row_sqnorm_tr_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_vecs, n, D, d_out);
+    else
+        hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_vecs, n, D, d_out);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+// d_vnorm: per-row sum-of-squares table (launch_row_sqnorms) or nullptr.  With it (cosine) — and always for dot / L2 —
+// rows that allow it take the transposing kernel; anything else the lane-per-row kernel.
 int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf,
-                        const int32_t *d_ord, int B, float *d_out, float *d_qnorm)
+                        const int32_t *d_ord, int B, float *d_out, float *d_qnorm, const float *d_vnorm)
 {
     if (Q == 0 || B == 0) return JV_OK;
     // d_qnorm: caller-provided scratch of Q floats (query-side cosine norms)
     if (vsf == VSF_COS)
         hipLaunchKernelGGL(query_sqnorm_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, d_q, D, Q, d_qnorm);
     dim3 grid(Q, (B + 63) / 64), block(64);
+    if (exact_tr_supported(d_vecs, D) && (reinterpret_cast<uintptr_t>(d_q) & 15) == 0 && (vsf != VSF_COS || d_vnorm) &&
+        !getenv("JVECTOR_HIP_EXACT_LANE_ROWS")) {
+        switch (vsf) {
+        case VSF_L2:
+            hipLaunchKernelGGL(exact_gather_tr_kernel<VSF_L2>, grid, block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out);
+            break;
+        case VSF_DOT:
+            hipLaunchKernelGGL(exact_gather_tr_kernel<VSF_DOT>, grid, block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out);
+            break;
+        default:
+            hipLaunchKernelGGL(exact_gather_tr_kernel<VSF_COS>, grid, block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out);
+            break;
+        }
+        JV_HIP_CHECK(hipGetLastError());
+        return JV_OK;
+    }
     size_t lds = (size_t)D * sizeof(float);
     switch (vsf) {
     case VSF_L2:

@@ -32,6 +32,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     gs_worker<VSF, CH16, PAIR>(p, (int)blockIdx.x, gs_lds);
 }
 
+// developer aid (JVECTOR_HIP_GS_PROF=1): the benched instance with per-phase shader-clock counters (GsParams::prof)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_prof_kernel(GsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char gs_lds[];
+    gs_worker<VSF_COS, 6, true, true>(p, (int)blockIdx.x, gs_lds);
+}
+
 template <int VSF, int OCC>
 static int launch_gs_ch(hipStream_t s, const GsParams &p, int ch, int workers, size_t lds)
 {
@@ -84,6 +91,15 @@ int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, 
     if (p.Q == 0) return JV_OK;
     const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0);
     const int ch = p.M / 16;
+    if (p.prof) {
+        if (!(vsf == VSF_COS && ch == 6 && p.pair && occupancy < 4)) {
+            set_error("graph search kernel: the profiling variant is built for cosine, M = 96, pair-lane scoring only");
+            return JV_ERR_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL(graph_search_prof_kernel, dim3(workers), dim3(64), lds, s, p);
+        JV_HIP_CHECK(hipGetLastError());
+        return JV_OK;
+    }
     if (occupancy >= 4) {
         switch (vsf) {
         case VSF_L2: return launch_gs_ch<VSF_L2, 4>(s, p, ch, workers, lds);

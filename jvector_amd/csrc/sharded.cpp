@@ -1,0 +1,320 @@
+// sharded.cpp — the sharded-index search behind the C ABI (SURVEY §8b export list: jv_hip_sharded_topk; §8e).
+//
+// PQ codes and base vectors are partitioned by contiguous ordinal range over the GPUs of one node (the analogue of
+// PQVectors' chunking, B/quantization/PQVectors.java:515-540).  One RANK per GPU — a process (torch.distributed style) or
+// a host thread of one JVM, each with its own jv_ctx; the only data-path exchange is
+//   1. one all-gather of every shard's partial top-rerankK (Q x rerankK x (i32 global id, f32 score)) and
+//   2. one all-gather of the owners' exact scores (Q x rerankK x f32),
+// both latency-bound messages (Q = 1024, rerankK = 100: 0.8 MB per rank) that RCCL sends point-to-point over xGMI.
+// The merge is the NodeQueue-order top-k (k_topk.hip) over the union — keys are unique because global ids are disjoint —
+// so the result is bit-identical, ids and scores, to the single-index two-pass search (tests/test_sharded*.py).
+// Step 2 is a SELECTION of the owner's value, not a MAX all-reduce: NaN / -inf exact scores arrive unchanged.
+//
+// RCCL is bound at run time (dlopen of librccl.so, path override JVECTOR_HIP_RCCL_PATH): the library keeps no link-time
+// dependency on it, a process that never shards never loads it, and a host that already carries an RCCL (torch) shares it.
+// comm == NULL means "all shards are local to this context" (single rank): the same code path minus the collectives.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "jv_internal.h"
+
+namespace jv {
+
+int launch_shard_interleave(hipStream_t s, const int32_t *d_ids, const float *d_sc, int P, int Q, int k, int32_t *d_out_ids,
+                            float *d_out_sc);
+int launch_shard_localize(hipStream_t s, const int32_t *d_gids, int64_t n, int64_t base, int64_t count, int32_t *d_local);
+int launch_shard_select(hipStream_t s, const int32_t *d_gids, const float *d_exact, const long long *d_ranges, int P, int64_t n,
+                        float *d_out);
+
+namespace {
+
+// ---- the six RCCL entry points this file uses, declared here (rccl.h: ncclUniqueId is 128 opaque bytes passed BY VALUE;
+//      ncclInt32 = 2, ncclInt64 = 4, ncclFloat32 = 7) ----
+struct RcclId {
+    char internal[JV_COMM_ID_BYTES];
+};
+typedef void *RcclComm;
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(RcclId *) = nullptr;
+    int (*CommInitRank)(RcclComm *, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, RcclComm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclInt32 = 2, kNcclInt64 = 4, kNcclFloat32 = 7;
+
+std::mutex g_rccl_mu;
+Rccl g_rccl;
+
+int load_rccl(const Rccl **out)
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (!g_rccl.handle) {
+        const char *cands[] = {getenv("JVECTOR_HIP_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *h = nullptr;
+        for (const char *c : cands)
+            if (c && *c && (h = dlopen(c, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) {
+            set_error("sharded: cannot load RCCL (librccl.so; set JVECTOR_HIP_RCCL_PATH): %s", dlerror());
+            return JV_ERR_UNSUPPORTED;
+        }
+        Rccl r;
+        r.handle = h;
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+            set_error("sharded: the RCCL library lacks a required symbol");
+            dlclose(h);
+            return JV_ERR_UNSUPPORTED;
+        }
+        g_rccl = r;
+    }
+    *out = &g_rccl;
+    return JV_OK;
+}
+
+#define JV_RCCL_CHECK(r, expr)                                                                  \
+    do {                                                                                        \
+        const int _rc = (expr);                                                                 \
+        if (_rc != 0) {                                                                         \
+            set_error("RCCL: %s failed: %s", #expr, (r)->GetErrorString(_rc));                  \
+            return JV_ERR_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+}  // namespace
+}  // namespace jv
+
+using namespace jv;
+
+struct jv_comm {
+    const Rccl *rccl = nullptr;
+    RcclComm comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    // device staging owned by the communicator (jv_hip_search_flat uses the context's scratch for itself)
+    Buffer part_ids, part_sc, all_ids, all_sc, row_ids, row_sc, cand, cand_sc, local, exact, all_exact, ranges, all_ranges;
+    ~jv_comm()
+    {
+        for (Buffer *b : {&part_ids, &part_sc, &all_ids, &all_sc, &row_ids, &row_sc, &cand, &cand_sc, &local, &exact, &all_exact, &ranges,
+                          &all_ranges})
+            b->release();
+    }
+};
+
+namespace {
+
+// all-gather `count` elements of type `dt` per rank; local communicator: a device copy
+int all_gather(jv_ctx *ctx, jv_comm *c, const void *send, void *recv, size_t count, int dt, size_t elem)
+{
+    if (!c->comm) {  // local communicator; an RCCL communicator of one rank still goes through RCCL
+        if (send != recv) JV_HIP_CHECK(hipMemcpyAsync(recv, send, count * elem, hipMemcpyDeviceToDevice, ctx->stream));
+        return JV_OK;
+    }
+    JV_RCCL_CHECK(c->rccl, c->rccl->AllGather(send, recv, count, dt, c->comm, ctx->stream));
+    return JV_OK;
+}
+
+// merge the gathered pieces [P][Q][k] into [Q][k_out] under the NodeQueue order
+int merge_pieces(jv_ctx *ctx, jv_comm *c, const int32_t *all_ids, const float *all_sc, int P, int Q, int k, int k_out, int32_t *d_out_ids,
+                 float *d_out_sc)
+{
+    const size_t cells = (size_t)P * Q * k;
+    JV_TRY(c->row_ids.reserve(sizeof(int32_t) * cells));
+    JV_TRY(c->row_sc.reserve(sizeof(float) * cells));
+    JV_TRY(launch_shard_interleave(ctx->stream, all_ids, all_sc, P, Q, k, (int32_t *)c->row_ids.ptr, (float *)c->row_sc.ptr));
+    JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, k_out)));
+    ProfScope ps(ctx, R_TOPK);
+    return launch_topk(ctx->stream, ctx, (const float *)c->row_sc.ptr, (const int32_t *)c->row_ids.ptr, Q, (int64_t)P * k, (int64_t)P * k, 0,
+                       k_out, d_out_ids, d_out_sc, ctx->d_scratch.ptr);
+}
+
+}  // namespace
+
+extern "C" {
+
+int jv_hip_comm_unique_id(uint8_t *id_out)
+{
+    clear_error();
+    JV_REQUIRE(id_out, "comm_unique_id: NULL argument");
+    const Rccl *r;
+    JV_TRY(load_rccl(&r));
+    RcclId id;
+    JV_RCCL_CHECK(r, r->GetUniqueId(&id));
+    memcpy(id_out, id.internal, JV_COMM_ID_BYTES);
+    return JV_OK;
+}
+
+int jv_hip_comm_create(jv_ctx *ctx, const uint8_t *id, int rank, int world, jv_comm **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && out, "comm_create: NULL argument");
+    JV_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_create: rank %d outside world %d", rank, world);
+    JV_TRY(use_device(ctx->device));
+    jv_comm *c = new jv_comm();
+    c->rank = rank;
+    c->world = world;
+    c->device = ctx->device;
+    if (world > 1 || id) {  // world 1 without an id: purely local communicator, RCCL is not even loaded
+        JV_REQUIRE(id, "comm_create: a communicator of %d ranks needs the unique id of jv_hip_comm_unique_id", world);
+        int rc = load_rccl(&c->rccl);
+        if (rc != JV_OK) {
+            delete c;
+            return rc;
+        }
+        RcclId rid;
+        memcpy(rid.internal, id, JV_COMM_ID_BYTES);
+        const int nrc = c->rccl->CommInitRank(&c->comm, world, rid, rank);
+        if (nrc != 0) {
+            set_error("RCCL: ncclCommInitRank(rank %d of %d) failed: %s", rank, world, c->rccl->GetErrorString(nrc));
+            delete c;
+            return JV_ERR_HIP;
+        }
+    }
+    *out = c;
+    return JV_OK;
+}
+
+int jv_hip_comm_destroy(jv_comm *c)
+{
+    if (!c) return JV_OK;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)c->rccl->CommDestroy(c->comm);
+    delete c;
+    return JV_OK;
+}
+
+int jv_hip_comm_rank(const jv_comm *c) { return c ? c->rank : 0; }
+int jv_hip_comm_world(const jv_comm *c) { return c ? c->world : 1; }
+
+int jv_hip_sharded_topk(jv_ctx *ctx, jv_comm *comm, const float *scores, const int32_t *ids, int Q, int k_in, int k_out,
+                        int32_t *out_ids, float *out_scores)
+{
+    clear_error();
+    JV_REQUIRE(ctx && comm, "sharded_topk: NULL argument");
+    JV_REQUIRE(Q >= 0 && k_in > 0 && k_out > 0, "sharded_topk: bad sizes");
+    if (Q == 0) return JV_OK;
+    JV_REQUIRE(scores && ids && out_ids && out_scores, "sharded_topk: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    const size_t cells = (size_t)Q * k_in;
+    const void *d_sc = nullptr, *d_ids = nullptr;
+    JV_TRY(comm->part_sc.reserve(sizeof(float) * cells));
+    JV_TRY(comm->part_ids.reserve(sizeof(int32_t) * cells));
+    // host or device partial lists -> the communicator's send buffers
+    JV_HIP_CHECK(hipMemcpyAsync(comm->part_sc.ptr, scores, sizeof(float) * cells, hipMemcpyDefault, ctx->stream));
+    JV_HIP_CHECK(hipMemcpyAsync(comm->part_ids.ptr, ids, sizeof(int32_t) * cells, hipMemcpyDefault, ctx->stream));
+    d_sc = comm->part_sc.ptr;
+    d_ids = comm->part_ids.ptr;
+    const int W = comm->world;
+    JV_TRY(comm->all_sc.reserve(sizeof(float) * cells * W));
+    JV_TRY(comm->all_ids.reserve(sizeof(int32_t) * cells * W));
+    if (comm->comm) JV_RCCL_CHECK(comm->rccl, comm->rccl->GroupStart());
+    JV_TRY(all_gather(ctx, comm, d_ids, comm->all_ids.ptr, cells, kNcclInt32, 4));
+    JV_TRY(all_gather(ctx, comm, d_sc, comm->all_sc.ptr, cells, kNcclFloat32, 4));
+    if (comm->comm) JV_RCCL_CHECK(comm->rccl, comm->rccl->GroupEnd());
+    OutStage oi, os;
+    JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * k_out, ctx->d_scratch2, &oi));
+    JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * k_out, ctx->d_scratch3, &os));
+    JV_TRY(merge_pieces(ctx, comm, (const int32_t *)comm->all_ids.ptr, (const float *)comm->all_sc.ptr, W, Q, k_in, k_out, (int32_t *)oi.dev,
+                        (float *)os.dev));
+    JV_TRY(stage_out_end(ctx, oi));
+    return stage_out_end(ctx, os);
+}
+
+int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts *luts, const jv_codes *const *codes,
+                               const jv_vectors *const *vectors, const int64_t *id_base, const float *queries, int Q, jv_vsf vsf,
+                               int topK, int rerankK, int32_t *out_ids, float *out_scores)
+{
+    clear_error();
+    JV_REQUIRE(ctx && comm && luts && codes && id_base, "sharded_search_flat: NULL argument");
+    JV_REQUIRE(n_local >= 1 && n_local <= 64, "sharded_search_flat: %d local shards (1..64)", n_local);
+    JV_REQUIRE(topK > 0 && rerankK >= topK, "rerankK %d must be >= topK %d", rerankK, topK);  // GraphSearcher.java:233
+    if (Q == 0) return JV_OK;
+    JV_REQUIRE(queries && out_ids && out_scores, "sharded_search_flat: NULL buffer");
+    for (int s = 0; s < n_local; ++s) {
+        JV_REQUIRE(codes[s], "sharded_search_flat: shard %d has no codes", s);
+        JV_REQUIRE(id_base[s] >= 0 && id_base[s] + codes[s]->count <= 0x7fffffffLL, "sharded_search_flat: shard %d id range overflows int32", s);
+        JV_REQUIRE(!vectors || !vectors[s] || vectors[s]->count >= codes[s]->count, "sharded_search_flat: shard %d has fewer vectors than codes", s);
+    }
+    bool rerank = vectors != nullptr;
+    for (int s = 0; s < n_local && rerank; ++s) rerank = vectors[s] != nullptr;
+    JV_TRY(use_device(ctx->device));
+    const int W = comm->world, P = W * n_local, k = rerankK;
+    const size_t cells = (size_t)Q * k;
+    const bool grouped = comm->comm != nullptr;
+
+    // 1. every local shard's partial top-rerankK of the ADC scan, GLOBAL ids (jv_hip_search_flat without a reranker)
+    JV_TRY(comm->part_ids.reserve(sizeof(int32_t) * cells * n_local));
+    JV_TRY(comm->part_sc.reserve(sizeof(float) * cells * n_local));
+    JV_TRY(comm->ranges.reserve(sizeof(long long) * 2 * n_local));
+    std::vector<long long> h_ranges(2 * (size_t)n_local);
+    for (int s = 0; s < n_local; ++s) {
+        JV_TRY(jv_hip_search_flat(ctx, luts, codes[s], nullptr, queries, Q, vsf, k, 0, (int32_t)id_base[s],
+                                  (int32_t *)comm->part_ids.ptr + cells * s, (float *)comm->part_sc.ptr + cells * s));
+        h_ranges[2 * s] = id_base[s];
+        h_ranges[2 * s + 1] = codes[s]->count;
+    }
+    JV_HIP_CHECK(hipMemcpyAsync(comm->ranges.ptr, h_ranges.data(), sizeof(long long) * h_ranges.size(), hipMemcpyHostToDevice, ctx->stream));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // h_ranges is a stack object
+    // 2. all-gather (ids, scores, shard ranges), merge -> global top-rerankK
+    JV_TRY(comm->all_ids.reserve(sizeof(int32_t) * cells * P));
+    JV_TRY(comm->all_sc.reserve(sizeof(float) * cells * P));
+    JV_TRY(comm->all_ranges.reserve(sizeof(long long) * 2 * P));
+    if (grouped) JV_RCCL_CHECK(comm->rccl, comm->rccl->GroupStart());
+    JV_TRY(all_gather(ctx, comm, comm->part_ids.ptr, comm->all_ids.ptr, cells * n_local, kNcclInt32, 4));
+    JV_TRY(all_gather(ctx, comm, comm->part_sc.ptr, comm->all_sc.ptr, cells * n_local, kNcclFloat32, 4));
+    JV_TRY(all_gather(ctx, comm, comm->ranges.ptr, comm->all_ranges.ptr, 2 * (size_t)n_local, kNcclInt64, 8));
+    if (grouped) JV_RCCL_CHECK(comm->rccl, comm->rccl->GroupEnd());
+    JV_TRY(comm->cand.reserve(sizeof(int32_t) * cells));
+    JV_TRY(comm->cand_sc.reserve(sizeof(float) * cells));
+    OutStage oi, os;
+    JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_scratch2, &oi));
+    JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * topK, ctx->d_scratch3, &os));
+    if (!rerank) {  // no full-resolution vectors: the merged approximate top-K is the answer
+        JV_TRY(merge_pieces(ctx, comm, (const int32_t *)comm->all_ids.ptr, (const float *)comm->all_sc.ptr, P, Q, k, topK, (int32_t *)oi.dev,
+                            (float *)os.dev));
+        JV_TRY(stage_out_end(ctx, oi));
+        return stage_out_end(ctx, os);
+    }
+    JV_TRY(merge_pieces(ctx, comm, (const int32_t *)comm->all_ids.ptr, (const float *)comm->all_sc.ptr, P, Q, k, k, (int32_t *)comm->cand.ptr,
+                        (float *)comm->cand_sc.ptr));
+    // 3. exact scores by the owning shard (same kernel, same arithmetic as the single index), all-gather, owner selection
+    JV_TRY(comm->local.reserve(sizeof(int32_t) * cells));
+    JV_TRY(comm->exact.reserve(sizeof(float) * cells * n_local));
+    JV_TRY(comm->all_exact.reserve(sizeof(float) * cells * P));
+    JV_TRY(ctx->d_in.reserve(sizeof(float) * (size_t)Q));
+    const int kvsf = to_kernel_vsf(vsf);
+    for (int s = 0; s < n_local; ++s) {
+        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors[s])));
+        JV_TRY(launch_shard_localize(ctx->stream, (const int32_t *)comm->cand.ptr, (int64_t)cells, id_base[s], codes[s]->count,
+                                     (int32_t *)comm->local.ptr));
+        ProfScope ps(ctx, R_EXACT);
+        JV_TRY(launch_exact_gather(ctx->stream, vectors[s]->d_vecs, vectors[s]->count, vectors[s]->D, luts->d_raw_queries, Q, kvsf,
+                                   (const int32_t *)comm->local.ptr, k, (float *)comm->exact.ptr + cells * s, (float *)ctx->d_in.ptr,
+                                   vectors[s]->d_sqnorm));
+    }
+    JV_TRY(all_gather(ctx, comm, comm->exact.ptr, comm->all_exact.ptr, cells * n_local, kNcclFloat32, 4));
+    JV_TRY(launch_shard_select(ctx->stream, (const int32_t *)comm->cand.ptr, (const float *)comm->all_exact.ptr,
+                               (const long long *)comm->all_ranges.ptr, P, (int64_t)cells, (float *)comm->cand_sc.ptr));
+    // 4. final top-K under the NodeQueue order on the exact scores
+    JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, topK)));
+    {
+        ProfScope ps(ctx, R_TOPK);
+        JV_TRY(launch_topk(ctx->stream, ctx, (const float *)comm->cand_sc.ptr, (const int32_t *)comm->cand.ptr, Q, k, k, 0, topK,
+                           (int32_t *)oi.dev, (float *)os.dev, ctx->d_scratch.ptr));
+    }
+    JV_TRY(stage_out_end(ctx, oi));
+    return stage_out_end(ctx, os);
+}
+
+}  // extern "C"

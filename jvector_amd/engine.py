@@ -205,6 +205,20 @@ class ProductQuantization:
         check(self._lib.jv_hip_pq_write(self.ctx._h, self._h, int(version), C.cast(buf, C.c_void_p), need.value, C.byref(need)))
         return bytes(buf)
 
+    def codebooks(self) -> np.ndarray:
+        """The codebooks as one host float32 array (concatenation over m of k*size_m floats, centroid-major — what
+        from_codebooks takes), read back through the wire format (ProductQuantization.write v6: magic, version, centroid
+        length [+ centroid], M, M sizes, anisotropic threshold, k, codebooks; big-endian)."""
+        b = self.write(6)
+        gcl = int.from_bytes(b[8:12], "big", signed=True)
+        off = 12 + 4 * gcl
+        M = int.from_bytes(b[off:off + 4], "big", signed=True)
+        sizes = np.frombuffer(b, dtype=">i4", count=M, offset=off + 4)
+        off += 4 + 4 * M + 4          # sizes, anisotropic threshold
+        k = int.from_bytes(b[off:off + 4], "big", signed=True)
+        n = int(k) * int(sizes.sum())
+        return np.frombuffer(b, dtype=">f4", count=n, offset=off + 4).astype(np.float32)
+
     @property
     def anisotropic_threshold(self) -> float:
         """ProductQuantization.anisotropicThreshold; -1 = UNWEIGHTED."""

@@ -121,3 +121,89 @@ class ShardedFlatSearcher:
 
 
 ShardedSearcher = ShardedFlatSearcher  # the merge does not care how a shard produced its partial top-k
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The same search behind the C ABI (include/jvector_hip.h: jv_hip_comm_* / jv_hip_sharded_*): what a non-Python host (the
+# Java shim: one thread per GPU inside one JVM) calls.  RCCL is driven by the library itself, not by torch.distributed.
+# ----------------------------------------------------------------------------------------------------------------------
+class Communicator:
+    """jv_comm: one rank of an RCCL communicator bound to `ctx`'s device (world == 1 without an id: local, no RCCL)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, ctx, rank=0, world=1, unique_id: bytes | None = None):
+        import ctypes as C
+        from ._lib import check
+        self.ctx, self._lib = ctx, ctx._lib
+        h = C.c_void_p()
+        idbuf = (C.c_ubyte * self.ID_BYTES).from_buffer_copy(unique_id) if unique_id is not None else None
+        check(self._lib.jv_hip_comm_create(ctx._h, C.cast(idbuf, C.c_void_p) if idbuf is not None else None, int(rank), int(world),
+                                           C.byref(h)))
+        self._h, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def unique_id(ctx) -> bytes:
+        """ncclGetUniqueId: call on rank 0, hand the bytes to every other rank (the host's own rendezvous)."""
+        import ctypes as C
+        from ._lib import check
+        buf = (C.c_ubyte * Communicator.ID_BYTES)()
+        check(ctx._lib.jv_hip_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CShardedFlatSearcher:
+    """jv_hip_sharded_search_flat: `shards` = [(PQVectors, VectorSet | None, id_base), ...] resident on this rank's device
+    (normally one; every rank the same number)."""
+
+    def __init__(self, ctx, comm: Communicator, pq, shards, max_queries=256):
+        import jvector_amd as J
+        self.J, self.ctx, self.comm, self.shards = J, ctx, comm, list(shards)
+        self.luts = J.QueryTables(ctx, pq, max_queries)
+
+    def search(self, queries, vsf, top_k, rerank_k):
+        import ctypes as C
+        import numpy as np
+        from ._lib import check
+        from .engine import _empty, _ptr
+        Q, n = int(queries.shape[0]), len(self.shards)
+        codes = (C.c_void_p * n)(*[s[0]._h for s in self.shards])
+        rerank = all(s[1] is not None for s in self.shards)
+        vecs = (C.c_void_p * n)(*[s[1]._h for s in self.shards]) if rerank else None
+        bases = (C.c_int64 * n)(*[int(s[2]) for s in self.shards])
+        q_p, qk = _ptr(queries, np.float32)
+        out_ids = _empty((Q, top_k), np.int32, queries)
+        out_sc = _empty((Q, top_k), np.float32, queries)
+        oi_p, oik = _ptr(out_ids, np.int32)
+        os_p, osk = _ptr(out_sc, np.float32)
+        check(self.ctx._lib.jv_hip_sharded_search_flat(self.ctx._h, self.comm._h, n, self.luts._h, C.cast(codes, C.c_void_p),
+                                                       C.cast(vecs, C.c_void_p) if vecs is not None else None,
+                                                       C.cast(bases, C.c_void_p), q_p, Q, int(vsf), int(top_k), int(rerank_k), oi_p,
+                                                       os_p))
+        return out_ids, out_sc
+
+    def merge_topk(self, scores, ids, k_out):
+        """jv_hip_sharded_topk: this rank's partial list -> the merged top-k_out every rank receives."""
+        import numpy as np
+        from ._lib import check
+        from .engine import _empty, _ptr
+        Q, k_in = int(scores.shape[0]), int(scores.shape[1])
+        s_p, sk = _ptr(scores, np.float32)
+        i_p, ik = _ptr(ids, np.int32)
+        out_ids = _empty((Q, k_out), np.int32, scores)
+        out_sc = _empty((Q, k_out), np.float32, scores)
+        oi_p, oik = _ptr(out_ids, np.int32)
+        os_p, osk = _ptr(out_sc, np.float32)
+        check(self.ctx._lib.jv_hip_sharded_topk(self.ctx._h, self.comm._h, s_p, i_p, Q, k_in, int(k_out), oi_p, os_p))
+        return out_ids, out_sc

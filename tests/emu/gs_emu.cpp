@@ -23,6 +23,7 @@ static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
     *p = old + v;
     return old;
 }
+static inline void gs_fetch_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 static inline void gs_fence() {}
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
 

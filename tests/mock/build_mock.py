@@ -7,7 +7,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "build", "mock")
 LIB = os.path.join(OUT, "libjvector_hip_mock.so")
-HOST = ["cabi", "graph_search", "build_score", "pq_train", "formats", "compat_host"]
+HOST = ["cabi", "graph_search", "sharded", "build_score", "pq_train", "formats", "compat_host"]
 CXXF = ["-std=c++17", "-O2", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-include",
         os.path.join(ROOT, "tests", "mock", "mock_prefix.h"), "-fPIC", "-Wno-unknown-pragmas", "-Wno-unused-function"]
 
@@ -47,7 +47,7 @@ def build():
             raise RuntimeError("mock build failed: " + " ".join(cmd))
     # -Bsymbolic: calls between the library's own entry points must not be captured by a real HIP runtime / library that
     # another module (torch) may have put in the global symbol scope
-    subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", LIB] + objs + ["-lpthread", "-lm"])
+    subprocess.check_call(["g++", "-shared", "-Wl,-Bsymbolic", "-o", LIB] + objs + ["-lpthread", "-lm", "-ldl"])
     return LIB
 
 

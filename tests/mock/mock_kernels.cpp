@@ -29,6 +29,7 @@ static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
     *p = old + v;
     return old;
 }
+static inline void gs_fetch_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 static inline void gs_fence() {}
 static inline void gs_gather64(float v, float (&out)[64]) { emu::gather64(v, out); }
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
@@ -159,8 +160,46 @@ int launch_fused(hipStream_t, const jv_ctx *, const float *d_luts, const float *
         }
     return JV_OK;
 }
+int launch_shard_interleave(hipStream_t, const int32_t *d_ids, const float *d_sc, int P, int Q, int k, int32_t *d_out_ids, float *d_out_sc)
+{
+    for (int p = 0; p < P; ++p)
+        for (int q = 0; q < Q; ++q)
+            for (int j = 0; j < k; ++j) {
+                const int64_t src = ((int64_t)p * Q + q) * k + j, dst = ((int64_t)q * P + p) * k + j;
+                d_out_ids[dst] = d_ids[src];
+                d_out_sc[dst] = d_sc[src];
+            }
+    return JV_OK;
+}
+int launch_shard_localize(hipStream_t, const int32_t *d_gids, int64_t n, int64_t base, int64_t count, int32_t *d_local)
+{
+    for (int64_t i = 0; i < n; ++i) d_local[i] = (d_gids[i] >= base && d_gids[i] < base + count) ? (int32_t)(d_gids[i] - base) : -1;
+    return JV_OK;
+}
+int launch_shard_select(hipStream_t, const int32_t *d_gids, const float *d_exact, const long long *d_ranges, int P, int64_t n, float *d_out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float v = NEG_INF;
+        for (int p = 0; p < P && d_gids[i] >= 0; ++p)
+            if (d_gids[i] >= d_ranges[2 * p] && d_gids[i] < d_ranges[2 * p] + d_ranges[2 * p + 1]) {
+                v = d_exact[(int64_t)p * n + i];
+                break;
+            }
+        d_out[i] = v;
+    }
+    return JV_OK;
+}
+int launch_row_sqnorms(hipStream_t, const float *d_vecs, int64_t n, int D, float *d_out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float s = 0.0f;
+        for (int j = 0; j < D; ++j) s += d_vecs[i * D + j] * d_vecs[i * D + j];
+        d_out[i] = s;
+    }
+    return JV_OK;
+}
 int launch_exact_gather(hipStream_t, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf, const int32_t *d_ord,
-                        int B, float *d_out, float *)
+                        int B, float *d_out, float *, const float *)
 {
     for (int q = 0; q < Q; ++q)
         for (int b = 0; b < B; ++b) {

@@ -222,6 +222,45 @@ def test_exact_gather_and_scan_bit_exact(ctx, D):
             assert np.all(np.isneginf(g[q][~valid]))
 
 
+@pytest.mark.parametrize("D,B", [(768, 150), (1536, 150), (8, 1), (72, 64), (200, 65), (64, 129), (1024, 400)])
+def test_exact_gather_transposing_kernel(ctx, D, B, monkeypatch):
+    """NodeQueue.rerank's scoring at the benched shapes through the coalesced (LDS-transposing) kernel: ragged candidate
+    counts (not a multiple of the 64 rows a wave takes), chunk tails (D not a multiple of the 64-float chunk), -1 and
+    out-of-range ordinals, duplicate ordinals, zero rows (cosine NaN) — bit-identical to the oracle AND to the lane-per-row
+    kernel it replaces; then an upload invalidates the cosine norm table."""
+    rng = np.random.default_rng(D * 1000 + B)
+    N, Q = 2500, 23
+    vecs = rng.standard_normal((N, D)).astype(np.float32)
+    vecs[7] = 0.0
+    queries = rng.standard_normal((Q, D)).astype(np.float32)
+    vs = J.VectorSet(ctx, vecs)
+    ords = rng.integers(0, N, (Q, B)).astype(np.int32)
+    ords[0, 0] = -1
+    ords[1, B - 1] = N + 5                     # out of range -> -inf like -1
+    ords[2, :] = ords[2, 0]                    # one row 150 times
+    ords[3, B // 2] = 7                        # the zero vector
+    for vsf in ALL_VSF:
+        g = vs.scores(queries, vsf, ords)
+        monkeypatch.setenv("JVECTOR_HIP_EXACT_LANE_ROWS", "1")
+        g_old = vs.scores(queries, vsf, ords)
+        monkeypatch.delenv("JVECTOR_HIP_EXACT_LANE_ROWS")
+        assert np.array_equal(g, g_old, equal_nan=True), vsf
+        for q in range(Q):
+            valid = (ords[q] >= 0) & (ords[q] < N)
+            want = O.compare_many(int(vsf), queries[q], vecs[ords[q][valid]])
+            assert np.array_equal(g[q][valid], want, equal_nan=True), (vsf, q)
+            assert np.all(np.isneginf(g[q][~valid]))
+    # the cosine norm table follows uploads
+    vs2 = J.VectorSet(ctx, np.ascontiguousarray(vecs[:64]))           # host upload -> owned storage
+    a = vs2.scores(queries[:2], VSF.COSINE, np.arange(64, dtype=np.int32).reshape(1, 64).repeat(2, 0))
+    newrows = (3.0 * vecs[100:164]).astype(np.float32)
+    J._lib.check(ctx._lib.jv_hip_vectors_upload(ctx._h, vs2._h, 0, 64, J.engine._ptr(newrows, np.float32)[0]))
+    b = vs2.scores(queries[:2], VSF.COSINE, np.arange(64, dtype=np.int32).reshape(1, 64).repeat(2, 0))
+    for q in range(2):
+        assert np.array_equal(a[q], O.compare_many(int(VSF.COSINE), queries[q], vecs[:64]), equal_nan=True)
+        assert np.array_equal(b[q], O.compare_many(int(VSF.COSINE), queries[q], newrows))
+
+
 def test_exact_known_answers(ctx, golden_dir):
     """the reference's native KATs (test_similarity.cpp:92-219) through the HIP exact kernels"""
     import json

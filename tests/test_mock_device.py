@@ -594,7 +594,7 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal):
 
     monkeypatch.setattr(bench, "torch", TorchProxy())
     argv = ["bench.py", "--mode", mode, "--traversal", traversal, "--n", "6000", "--dim", "128", "--m", "16", "--degree", "16",
-            "--queries", "48", "--steps", "2", "--warmup", "1", "--eval-queries", "48"]
+            "--queries", "48", "--steps", "2", "--warmup", "1", "--eval-queries", "48", "--cal-queries", "48"]
     monkeypatch.setattr(sys, "argv", argv)
     monkeypatch.delenv("RANK", raising=False)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
@@ -655,7 +655,7 @@ def _bench_rank(rank, world, port, mode, out_dir):
 
     bench.torch = TorchProxy()
     sys.argv = ["bench.py", "--gpus", str(world), "--mode", mode, "--n", "5000", "--dim", "128", "--m", "16", "--degree", "16", "--queries",
-                "32", "--steps", "2", "--warmup", "1", "--eval-queries", "32"]
+                "32", "--steps", "2", "--warmup", "1", "--eval-queries", "32", "--cal-queries", "32"]
     with open(os.path.join(out_dir, f"rank{rank}.out"), "w") as f, contextlib.redirect_stdout(f):
         bench.main()
 

@@ -71,6 +71,24 @@ def test_device_equals_host_on_a_large_batch_with_spills_and_overflow(ctx, monke
         assert np.array_equal(a, b)
 
 
+def test_overflowed_queries_are_retried_on_the_device(ctx, monkeypatch, capfd):
+    """first pass with a 512-slot visited table overflows for most queries; the retry passes (8x, 64x the table) finish them
+    on the device — same ids / scores / counters as the oracle, nothing left for the host searcher"""
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 11, 5000, 128, 16, 2, True)
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+    monkeypatch.setenv("JVECTOR_HIP_GS_VCAP_LOG2", "9")
+    monkeypatch.setenv("JVECTOR_HIP_GS_RETRY", "1")
+    monkeypatch.setenv("JVECTOR_HIP_GRAPH_TIMING", "1")
+    ids, sc, st = s.search(q, VSF.COSINE, 10, 100, return_stats=True)
+    err = capfd.readouterr().err
+    wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, 100, fused=True)
+    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+    line = [x for x in err.splitlines() if "graph_search device" in x][-1]
+    first, host = int(line.split("overflow=")[1].split()[0]), int(line.rsplit("host ", 1)[1])
+    assert first > 0 and host == 0, line
+
+
 def test_unsupported_shape_is_refused(ctx):
     v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 9, 2000, 64, 8, 1, False)  # M = 8
     s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
