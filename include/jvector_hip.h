@@ -332,6 +332,21 @@ JV_API int jv_hip_code_pair_scores(jv_ctx *ctx, const jv_pair_table *t, const jv
 /* FusedPQ.writeInline for nodes [first, first + count) (FusedPQ.java:146-161): stores the neighbour rows (count x maxDegree
  * int32, -1 padded, host or device memory) and gathers each neighbour's code out of `codes` into the node's packed block,
  * zero padded — the producer of the layout jv_hip_fused_scores / the graph searcher read.  Neighbour ids index `codes`. */
+/* Batched robust prune — VamanaDiversityProvider.retainDiverse (B/graph/diversity/VamanaDiversityProvider.java:43-96) for P
+ * nodes at once with the PQ diversity score above as scoreProvider.diversityScoreFunctionFor (BuildScoreProvider.java:181-186):
+ * BASELINE config 5's "GPU-batched neighbor scoring".  Per node p: the NodeArray is cand_nodes / cand_scores[p*C .. p*C +
+ * cand_count[p]) (sorted by score descending by the caller, as NodeArray keeps it; cand_count NULL = C entries each);
+ * diverse_before[p] (NULL = 0) candidates at the front are taken as already diverse; alpha is GraphIndexBuilder's alpha
+ * (the prune ramps 1.0, 1.2, ... <= alpha + 1e-6).
+ *   selected_out   : P x maxDegree candidate INDICES (positions in the node's list) in ascending order, -1 padded — the set
+ *                    bits of the reference's `selected` BitSet
+ *   n_selected_out : P (nSelected)      short_edges_out : P floats or NULL (retainDiverse's return value; NaN if the loop never ran)
+ * maxDegree <= 64; C * M bytes of candidate codes must fit LDS next to the bookkeeping (C <= ~600 at M = 96), else
+ * JV_ERR_UNSUPPORTED.  Buffers may be host or device memory.  Selections are identical to the reference's sequential loop. */
+JV_API int jv_hip_retain_diverse(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *codes, int P, int C,
+                                 const int32_t *cand_nodes, const float *cand_scores, const int32_t *cand_count,
+                                 const int32_t *diverse_before, int maxDegree, float alpha, int32_t *selected_out,
+                                 int32_t *n_selected_out, float *short_edges_out);
 JV_API int jv_hip_fused_build(jv_ctx *ctx, jv_fused *f, const jv_codes *codes, int64_t first, int64_t count,
                               const int32_t *neighbors);
 /* copy blocks (count x maxDegree*M bytes) and / or neighbour rows back; either output may be NULL */

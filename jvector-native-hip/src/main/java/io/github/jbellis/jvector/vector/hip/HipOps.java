@@ -44,7 +44,14 @@ public final class HipOps {
     }
 
     private static MethodHandle h(String name, FunctionDescriptor d) {
-        return LINKER.downcallHandle(LOOKUP.find(name).orElseThrow(() -> new UnsatisfiedLinkError(name)), d);
+        return downcall(name, d);
+    }
+
+    /** Downcall handle for a symbol of libjvector_hip.so (HipCompatOps passes Linker.Option.critical(true), like the
+     *  reference's sed-patched jextract output, jvector-native/src/main/native/src/jextract_vector_simd.sh). */
+    static MethodHandle downcall(String name, FunctionDescriptor d, Linker.Option... options) {
+        if (LOOKUP == null && !load()) throw new UnsatisfiedLinkError("libjvector_hip");
+        return LINKER.downcallHandle(LOOKUP.find(name).orElseThrow(() -> new UnsatisfiedLinkError(name)), d, options);
     }
 
     private static final class H {
@@ -99,6 +106,12 @@ public final class HipOps {
         static final MethodHandle pqvectorsDescribe = h("jv_fmt_pqvectors_describe", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle graphSearchFiltered = h("jv_hip_graph_search_filtered", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle searchFlat = h("jv_hip_search_flat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+        // sharded index: one rank (thread + context) per GPU, RCCL inside the library
+        static final MethodHandle commUniqueId = h("jv_hip_comm_unique_id", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle commCreate = h("jv_hip_comm_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS));
+        static final MethodHandle commDestroy = h("jv_hip_comm_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle shardedTopk = h("jv_hip_sharded_topk", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle shardedSearchFlat = h("jv_hip_sharded_search_flat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
     }
 
     /** jv_status -> Java exception, mirroring the reference's exception types (include/jvector_hip.h:38-45). */
@@ -201,5 +214,107 @@ public final class HipOps {
     public static void exactScanDense(MemorySegment ctx, MemorySegment vectors, MemorySegment queries, int q, int vsf, long first, long count, MemorySegment out) {
         try { check((int) H.exactScanDense.invokeExact(ctx, vectors, queries, q, vsf, first, count, out)); }
         catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    // ---- the remaining entry points, same shape: status -> exception, out-pointers through a caller arena ----
+    private static MemorySegment outHandle(Arena arena, java.util.function.ToIntFunction<MemorySegment> call) {
+        MemorySegment out = arena.allocate(ADDRESS);
+        check(call.applyAsInt(out));
+        return out.get(ADDRESS, 0);
+    }
+    private interface Call { int run() throws Throwable; }
+    private static int st(Call c) {
+        try { return c.run(); } catch (RuntimeException | Error e) { throw e; } catch (Throwable t) { throw new AssertionError(t); }
+    }
+
+    public static void ctxSync(MemorySegment ctx) { check(st(() -> (int) H.ctxSync.invokeExact(ctx))); }
+    public static void pqDestroy(MemorySegment pq) { check(st(() -> (int) H.pqDestroy.invokeExact(pq))); }
+    public static void codesDestroy(MemorySegment c) { check(st(() -> (int) H.codesDestroy.invokeExact(c))); }
+    public static void lutsDestroy(MemorySegment l) { check(st(() -> (int) H.lutsDestroy.invokeExact(l))); }
+
+    public static MemorySegment vectorsCreate(Arena arena, MemorySegment ctx, long count, int dim) {
+        return outHandle(arena, out -> st(() -> (int) H.vectorsCreate.invokeExact(ctx, count, dim, out)));
+    }
+    public static void vectorsUpload(MemorySegment ctx, MemorySegment vectors, long first, long count, MemorySegment src) {
+        check(st(() -> (int) H.vectorsUpload.invokeExact(ctx, vectors, first, count, src)));
+    }
+    public static void vectorsDestroy(MemorySegment v) { check(st(() -> (int) H.vectorsDestroy.invokeExact(v))); }
+
+    /** ProductQuantization.encodeAll (PQVectors.encodeAndBuild, PQVectors.java:109-152): count x D floats -> count x M code bytes. */
+    public static void pqEncode(MemorySegment ctx, MemorySegment pq, MemorySegment vectors, long count, MemorySegment codesOut) {
+        check(st(() -> (int) H.pqEncode.invokeExact(ctx, pq, vectors, count, codesOut)));
+    }
+
+    public static MemorySegment fusedCreate(Arena arena, MemorySegment ctx, MemorySegment pq, long count, int maxDegree) {
+        return outHandle(arena, out -> st(() -> (int) H.fusedCreate.invokeExact(ctx, pq, count, maxDegree, out)));
+    }
+    public static void fusedUpload(MemorySegment ctx, MemorySegment fused, long first, long count, MemorySegment blocks, MemorySegment neighbors) {
+        check(st(() -> (int) H.fusedUpload.invokeExact(ctx, fused, first, count, blocks, neighbors)));
+    }
+    /** FusedPQ.writeInline on the device: blocks gathered from the code store for the given neighbour rows. */
+    public static void fusedBuild(MemorySegment ctx, MemorySegment fused, MemorySegment codes, long first, long count, MemorySegment neighbors) {
+        check(st(() -> (int) H.fusedBuild.invokeExact(ctx, fused, codes, first, count, neighbors)));
+    }
+
+    /** NodeQueue-order top-k (NodeQueue.java:125-129): ids may be NULL (id = idBase + column). */
+    public static void topk(MemorySegment ctx, MemorySegment scores, MemorySegment idsOrNull, int q, long n, long stride, int idBase, int k,
+                            MemorySegment outIds, MemorySegment outScores) {
+        check(st(() -> (int) H.topk.invokeExact(ctx, scores, idsOrNull, q, n, stride, idBase, k, outIds, outScores)));
+    }
+
+    public static MemorySegment graphCreate(Arena arena, MemorySegment ctx, long nNodes, int nLevels) {
+        return outHandle(arena, out -> st(() -> (int) H.graphCreate.invokeExact(ctx, nNodes, nLevels, out)));
+    }
+    public static void graphSetLevel(MemorySegment ctx, MemorySegment graph, int level, int count, MemorySegment nodeIdsOrNull, MemorySegment neighbors, int degree) {
+        check(st(() -> (int) H.graphSetLevel.invokeExact(ctx, graph, level, count, nodeIdsOrNull, neighbors, degree)));
+    }
+    public static void graphSetEntry(MemorySegment graph, int node, int level) { check(st(() -> (int) H.graphSetEntry.invokeExact(graph, node, level))); }
+    public static void graphSetTraversal(MemorySegment graph, int mode) { check(st(() -> (int) H.graphSetTraversal.invokeExact(graph, mode))); }
+    public static void graphDestroy(MemorySegment graph) { check(st(() -> (int) H.graphDestroy.invokeExact(graph))); }
+
+    /** GraphSearcher.search(scoreProvider, topK, rerankK, threshold = 0, rerankFloor = 0, acceptOrds) for a batch. */
+    public static void graphSearchFiltered(MemorySegment ctx, MemorySegment graph, MemorySegment luts, MemorySegment codes, MemorySegment fusedOrNull,
+                                           MemorySegment vectorsOrNull, MemorySegment queries, int q, int vsf, int topK, int rerankK,
+                                           MemorySegment acceptBitsOrNull, long acceptStrideWords, MemorySegment outIds, MemorySegment outScores,
+                                           MemorySegment statsOrNull) {
+        check(st(() -> (int) H.graphSearchFiltered.invokeExact(ctx, graph, luts, codes, fusedOrNull, vectorsOrNull, queries, q, vsf, topK, rerankK,
+                                                               acceptBitsOrNull, acceptStrideWords, outIds, outScores, statsOrNull)));
+    }
+
+    /** two-pass flat search over one shard (jv_hip_search_flat) */
+    public static void searchFlat(MemorySegment ctx, MemorySegment luts, MemorySegment codes, MemorySegment vectorsOrNull, MemorySegment queries,
+                                  int q, int vsf, int topK, int rerankK, int idBase, MemorySegment outIds, MemorySegment outScores) {
+        check(st(() -> (int) H.searchFlat.invokeExact(ctx, luts, codes, vectorsOrNull, queries, q, vsf, topK, rerankK, idBase, outIds, outScores)));
+    }
+
+    // build-time scoring (BuildScoreProvider.pqBuildScoreProvider, BuildScoreProvider.java:167-212)
+    public static MemorySegment pairTableCreate(Arena arena, MemorySegment ctx, MemorySegment pq, int vsf) {
+        return outHandle(arena, out -> st(() -> (int) H.pairTableCreate.invokeExact(ctx, pq, vsf, out)));
+    }
+    public static void pairTableDestroy(MemorySegment t) { check(st(() -> (int) H.pairTableDestroy.invokeExact(t))); }
+    /** diversityFunctionFor(node1).similarityTo(node2) for P x B candidate x selected blocks */
+    public static void codePairScores(MemorySegment ctx, MemorySegment table, MemorySegment codes, MemorySegment node1, int p, MemorySegment node2, int b, MemorySegment out) {
+        check(st(() -> (int) H.codePairScores.invokeExact(ctx, table, codes, node1, p, node2, b, out)));
+    }
+
+    // sharded index
+    public static MemorySegment commUniqueId(Arena arena) {
+        MemorySegment id = arena.allocate(128);
+        check(st(() -> (int) H.commUniqueId.invokeExact(id)));
+        return id;
+    }
+    public static MemorySegment commCreate(Arena arena, MemorySegment ctx, MemorySegment idOrNull, int rank, int world) {
+        return outHandle(arena, out -> st(() -> (int) H.commCreate.invokeExact(ctx, idOrNull, rank, world, out)));
+    }
+    public static void commDestroy(MemorySegment comm) { check(st(() -> (int) H.commDestroy.invokeExact(comm))); }
+    public static void shardedTopk(MemorySegment ctx, MemorySegment comm, MemorySegment scores, MemorySegment ids, int q, int kIn, int kOut,
+                                   MemorySegment outIds, MemorySegment outScores) {
+        check(st(() -> (int) H.shardedTopk.invokeExact(ctx, comm, scores, ids, q, kIn, kOut, outIds, outScores)));
+    }
+    public static void shardedSearchFlat(MemorySegment ctx, MemorySegment comm, int nLocal, MemorySegment luts, MemorySegment codesArray,
+                                         MemorySegment vectorsArrayOrNull, MemorySegment idBases, MemorySegment queries, int q, int vsf, int topK,
+                                         int rerankK, MemorySegment outIds, MemorySegment outScores) {
+        check(st(() -> (int) H.shardedSearchFlat.invokeExact(ctx, comm, nLocal, luts, codesArray, vectorsArrayOrNull, idBases, queries, q, vsf, topK,
+                                                             rerankK, outIds, outScores)));
     }
 }

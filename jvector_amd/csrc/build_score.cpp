@@ -1,5 +1,6 @@
 // build_score.cpp — C ABI of the build-time scoring entry points (kernels in k_build_score.hip).
 #include "jv_internal.h"
+#include "rd_params.h"
 
 using namespace jv;
 
@@ -87,6 +88,60 @@ int jv_hip_code_pair_scores(jv_ctx *ctx, const jv_pair_table *t, const jv_codes 
                                   (const int32_t *)d_n2, B, (float *)os.dev));
     }
     return stage_out_end(ctx, os);
+}
+
+int jv_hip_retain_diverse(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *codes, int P, int C, const int32_t *cand_nodes,
+                          const float *cand_scores, const int32_t *cand_count, const int32_t *diverse_before, int maxDegree, float alpha,
+                          int32_t *selected_out, int32_t *n_selected_out, float *short_edges_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && t && codes, "retain_diverse: NULL argument");
+    JV_REQUIRE(codes->pq == t->pq, "retain_diverse: the code store and the pair table use different codebooks");
+    JV_REQUIRE(P >= 0 && C >= 0, "retain_diverse: negative sizes");
+    JV_REQUIRE(maxDegree >= 1 && maxDegree <= 64, "retain_diverse: maxDegree %d outside 1..64", maxDegree);
+    JV_REQUIRE(alpha == alpha && alpha >= 1.0f && alpha <= 64.0f, "retain_diverse: alpha must lie in [1, 64]");
+    if (P == 0) return JV_OK;
+    JV_REQUIRE(C > 0 && cand_nodes && cand_scores && selected_out && n_selected_out, "retain_diverse: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    const size_t cells = (size_t)P * C;
+    const void *d_nodes = nullptr, *d_scores = nullptr, *d_count = nullptr, *d_before = nullptr;
+    // four inputs, one pinned staging buffer: stage them one after another into distinct device buffers
+    JV_TRY(stage_in(ctx, cand_nodes, sizeof(int32_t) * cells, ctx->h_in, ctx->d_in, &d_nodes));
+    JV_TRY(stage_in(ctx, cand_scores, sizeof(float) * cells, ctx->h_in, ctx->d_scratch2, &d_scores));
+    if (cand_count) JV_TRY(stage_in(ctx, cand_count, sizeof(int32_t) * (size_t)P, ctx->h_in, ctx->d_scratch3, &d_count));
+    if (diverse_before) JV_TRY(stage_in(ctx, diverse_before, sizeof(int32_t) * (size_t)P, ctx->h_in, ctx->d_gs_mask, &d_before));
+    // outputs: selected [P][maxDegree] + n_selected [P] + short_edges [P] in one device block
+    const size_t sel_bytes = sizeof(int32_t) * (size_t)P * maxDegree, cnt_bytes = sizeof(int32_t) * (size_t)P;
+    const size_t o_cnt = (sel_bytes + 255) & ~(size_t)255, o_se = (o_cnt + cnt_bytes + 255) & ~(size_t)255;
+    JV_TRY(ctx->d_out.reserve(o_se + sizeof(float) * (size_t)P));
+    char *base = (char *)ctx->d_out.ptr;
+    RdParams p{};
+    p.tri = t->d_tri;
+    p.codes = codes->d_codes;
+    p.n = codes->count;
+    p.cand_nodes = (const int32_t *)d_nodes;
+    p.cand_scores = (const float *)d_scores;
+    p.cand_count = (const int32_t *)d_count;
+    p.diverse_before = (const int32_t *)d_before;
+    p.P = P;
+    p.C = C;
+    p.M = codes->M;
+    p.k = t->pq->k;
+    p.vsf = to_kernel_vsf(t->vsf);
+    p.maxDegree = maxDegree;
+    p.alpha = alpha;
+    p.selected_out = (int32_t *)base;
+    p.n_selected_out = (int32_t *)(base + o_cnt);
+    p.short_edges_out = (float *)(base + o_se);
+    {
+        ProfScope ps(ctx, R_ADC);
+        JV_TRY(launch_retain_diverse(ctx->stream, ctx, p));
+    }
+    JV_HIP_CHECK(hipMemcpyAsync(selected_out, p.selected_out, sel_bytes, hipMemcpyDefault, ctx->stream));
+    JV_HIP_CHECK(hipMemcpyAsync(n_selected_out, p.n_selected_out, cnt_bytes, hipMemcpyDefault, ctx->stream));
+    if (short_edges_out) JV_HIP_CHECK(hipMemcpyAsync(short_edges_out, p.short_edges_out, sizeof(float) * (size_t)P, hipMemcpyDefault, ctx->stream));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return JV_OK;
 }
 
 int jv_hip_fused_build(jv_ctx *ctx, jv_fused *f, const jv_codes *codes, int64_t first, int64_t count, const int32_t *neighbors)

@@ -16,9 +16,17 @@
 //           precision in d2 for near-identical pairs, not in the similarity)
 // It agrees with the bit-exact path to ~1e-7 relative (f32 round-off class; tests hold it to 1e-5, the north_star bound).
 //
-// One wavefront per block computes a 32-query x 128-vector tile: 4 accumulators of 32x32 (64 VGPRs), K staged through
-// LDS 32 columns at a time (rows padded to 33 floats: the operand reads As[row][k] are bank-conflict free).
-// Wave API used: gs_lane, gs_barrier, gs_f32x16, gs_mfma_32x32x2, gs_fmaf, gs_sqrt.
+// A workgroup of 4 wavefronts computes a 128-query x 128-vector tile; wavefront w owns queries 32 w .. 32 w + 31 against all
+// 128 vectors (4 accumulators of 32x32 = 64 VGPRs).  K is staged through LDS 32 columns at a time, K-MAJOR: element (row, k)
+// of a tile lives at [k * 129 + row], so that
+//   * the MFMA operand reads (32 lanes = 32 consecutive rows at one k) are bank-conflict free,
+//   * the staging writes are too: a lane loads 4 consecutive k of one row with ONE 16-byte global load (8 lanes cover a row's
+//     128-byte segment: whole lines) and scatters them with 4 ds_write_b32 whose bank is (4 kq + c + row) mod 32 — distinct
+//     over the 32 lanes of a write group (rows 0..3 x kq 0..7).
+// Per 32-column chunk the block loads 32 KB for 1.05 Mflop (32 flop/B; round 1's one-wave 32 x 128 tile: 12.8 flop/B with
+// eighty 4-byte loads per lane — it reached 0.35 of the MFMA peak).  The next chunk's 8 loads per lane are in flight while
+// the 64 MFMAs of the current one run; ~120 VGPRs and 34 KB of LDS allow 4 blocks = 16 waves per CU.
+// Wave API used: gs_tid (0..255), gs_block_barrier, gs_f32x16, gs_mfma_32x32x2, gs_fmaf, gs_sqrt.
 #pragma once
 
 #include <cstdint>
@@ -33,8 +41,11 @@ struct EdParams {
     int D, Q;
 };
 
-constexpr int ED_TQ = 32, ED_TN = 128, ED_KB = 32, ED_LD = ED_KB + 1;
-constexpr int ED_LDS_FLOATS = (ED_TQ + ED_TN) * ED_LD + ED_TQ + ED_TN;  // staged tiles + the two norm arrays
+constexpr int ED_WAVES = 4, ED_THREADS = 64 * ED_WAVES;
+constexpr int ED_TQ = 32 * ED_WAVES, ED_TN = 128, ED_KB = 32, ED_LDW = 129;
+constexpr int ED_LDS_FLOATS = 2 * ED_KB * ED_LDW + ED_TQ + ED_TN;  // staged tiles (K-major) + the two norm arrays
+
+struct alignas(16) ed_f4 { float x, y, z, w; };
 
 template <int VSF>
 GS_FN float ed_finish(float dot, float qn, float vn)
@@ -51,85 +62,109 @@ GS_FN float ed_finish(float dot, float qn, float vn)
     return (1.0f + dot) / 2.0f;
 }
 
-// Global loads of K columns kb .. kb + 32 of both tiles into registers (zero beyond D / Q / count: a zero product leaves a
-// chain as is).  Element (row = (lane >> 5) + 2 i, column = lane & 31): a half wave reads one 128-byte row segment; addresses
-// are a block-uniform base plus one 32-bit lane offset, and row pairs advance by a uniform 2 D.
-GS_FN void ed_load_chunk(const EdParams &p, int64_t n0, int q0, int kb, int lane, float (&ra)[16], float (&rb)[64])
+// Global loads of K columns kb .. kb + 32 of both tiles into registers: thread t fetches columns 4 (t & 7) .. + 3 of rows
+// (t >> 3) + 32 i, i = 0..3, of each tile (zero beyond D / Q / count: a zero product leaves a chain as is).
+// vec4: rows are 16-byte aligned and D % 4 == 0, so the four columns are one 16-byte load.
+GS_FN void ed_load_chunk(const EdParams &p, int64_t n0, int q0, int kb, int tid, bool vec4, ed_f4 (&ra)[4], ed_f4 (&rb)[4])
 {
-    const int rl = lane >> 5, cl = lane & 31;
-    const bool k_ok = kb + cl < p.D;
-    const int lane_off = rl * p.D + cl;
-    const float *qbase = p.queries + (int64_t)q0 * p.D + kb;
-    const float *vbase = p.vecs + (p.first + n0) * p.D + kb;
+    const int r0 = tid >> 3, k = kb + 4 * (tid & 7);
 #pragma unroll
-    for (int i = 0; i < 16; ++i)  // query tile: 32 rows
-        ra[i] = (k_ok && q0 + rl + 2 * i < p.Q) ? (qbase + (int64_t)(2 * i) * p.D)[lane_off] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < 64; ++i)  // vector tile: 128 rows
-        rb[i] = (k_ok && n0 + rl + 2 * i < p.count) ? (vbase + (int64_t)(2 * i) * p.D)[lane_off] : 0.0f;
+    for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 32 * i;
+        ed_f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (q0 + row < p.Q && k < p.D) {
+            const float *src = p.queries + (int64_t)(q0 + row) * p.D + k;
+            if (vec4) a = *reinterpret_cast<const ed_f4 *>(src);
+            else {
+                a.x = src[0];
+                if (k + 1 < p.D) a.y = src[1];
+                if (k + 2 < p.D) a.z = src[2];
+                if (k + 3 < p.D) a.w = src[3];
+            }
+        }
+        if (n0 + row < p.count && k < p.D) {
+            const float *src = p.vecs + (p.first + n0 + row) * p.D + k;
+            if (vec4) b = *reinterpret_cast<const ed_f4 *>(src);
+            else {
+                b.x = src[0];
+                if (k + 1 < p.D) b.y = src[1];
+                if (k + 2 < p.D) b.z = src[2];
+                if (k + 3 < p.D) b.w = src[3];
+            }
+        }
+        ra[i] = a;
+        rb[i] = b;
+    }
 }
 
-// tile (n0 .. n0 + 128) x (q0 .. q0 + 32); n0 is relative to p.first.  lds: ED_LDS_FLOATS floats.
-// Two-stage pipeline: the loads of chunk c + 1 are issued right after chunk c has been stored to LDS, so they are in flight
-// while chunk c's norms and 64 MFMAs run; one resident wave per SIMD already overlaps memory latency with the matrix pipe.
+// tile (n0 .. n0 + 128) x (q0 .. q0 + 128); n0 is relative to p.first.  lds: ED_LDS_FLOATS floats.  Runs on ED_THREADS threads.
 template <int VSF>
 GS_FN void ed_tile(const EdParams &p, int64_t n0, int q0, float *lds)
 {
-    const int lane = gs_lane();
+    const int tid = gs_tid();
+    const int wave = tid >> 6, lane = tid & 63;
     const int lo = lane & 31, hi = lane >> 5;
-    float *As = lds, *Bs = As + ED_TQ * ED_LD, *qn = Bs + ED_TN * ED_LD, *vn = qn + ED_TQ;
+    float *As = lds, *Bs = As + ED_KB * ED_LDW, *qn = Bs + ED_KB * ED_LDW, *vn = qn + ED_TQ;
+    const bool vec4 = (p.D & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.vecs) | reinterpret_cast<uintptr_t>(p.queries)) & 15) == 0;
+    const bool wave_active = q0 + 32 * wave < p.Q;  // wave-uniform
     gs_f32x16 acc[4] = {};
-    float nq = 0.0f, nv0 = 0.0f, nv1 = 0.0f;  // |q|^2 of tile row `lane` (lanes < 32), |v|^2 of tile rows lane, lane + 64
-    float ra[16], rb[64];
-    ed_load_chunk(p, n0, q0, 0, lane, ra, rb);
+    float nrm = 0.0f;  // threads 0..127: |v|^2 of tile row tid; threads 128..255: |q|^2 of tile row tid - 128
+    ed_f4 ra[4], rb[4];
+    ed_load_chunk(p, n0, q0, 0, tid, vec4, ra, rb);
 
     for (int kb = 0; kb < p.D; kb += ED_KB) {
         {
-            const int rl = lane >> 5, cl = lane & 31;
+            const int r0 = tid >> 3, kq = 4 * (tid & 7);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) As[(rl + 2 * i) * ED_LD + cl] = ra[i];
-#pragma unroll
-            for (int i = 0; i < 64; ++i) Bs[(rl + 2 * i) * ED_LD + cl] = rb[i];
+            for (int i = 0; i < 4; ++i) {
+                const int row = r0 + 32 * i;
+                As[(kq + 0) * ED_LDW + row] = ra[i].x;
+                As[(kq + 1) * ED_LDW + row] = ra[i].y;
+                As[(kq + 2) * ED_LDW + row] = ra[i].z;
+                As[(kq + 3) * ED_LDW + row] = ra[i].w;
+                Bs[(kq + 0) * ED_LDW + row] = rb[i].x;
+                Bs[(kq + 1) * ED_LDW + row] = rb[i].y;
+                Bs[(kq + 2) * ED_LDW + row] = rb[i].z;
+                Bs[(kq + 3) * ED_LDW + row] = rb[i].w;
+            }
         }
-        gs_barrier();
-        if (kb + ED_KB < p.D) ed_load_chunk(p, n0, q0, kb + ED_KB, lane, ra, rb);  // prefetch: consumed after the MFMAs
-        if (VSF != 1 /* not DOT: the norms */) {
-#pragma unroll 4
+        gs_block_barrier();
+        if (kb + ED_KB < p.D) ed_load_chunk(p, n0, q0, kb + ED_KB, tid, vec4, ra, rb);  // prefetch: consumed after the MFMAs
+        if (VSF != 1 /* not DOT: the norms, k ascending */) {
+            const float *src = (tid < ED_TN) ? Bs + tid : As + (tid - ED_TN);
+#pragma unroll 8
             for (int c = 0; c < ED_KB; ++c) {
-                if (lane < ED_TQ) {
-                    const float a = As[lane * ED_LD + c];
-                    nq = gs_fmaf(a, a, nq);
-                }
-                const float b0 = Bs[lane * ED_LD + c], b1 = Bs[(lane + 64) * ED_LD + c];
-                nv0 = gs_fmaf(b0, b0, nv0);
-                nv1 = gs_fmaf(b1, b1, nv1);
+                const float x = src[c * ED_LDW];
+                nrm = gs_fmaf(x, x, nrm);
             }
         }
         // ---- 16 K-steps of 2: lane l supplies A[i = l & 31][k = 2s + (l >> 5)] and B[k][j = l & 31] of each column tile ----
+        const float *a_col = As + 32 * wave + lo;
+        if (wave_active)  // a wavefront whose 32 query rows lie beyond Q only helps with the staging (small batches)
 #pragma unroll 4
         for (int s = 0; s < ED_KB / 2; ++s) {
             const int k = 2 * s + hi;
-            const float a = As[lo * ED_LD + k];
+            const float a = a_col[k * ED_LDW];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = gs_mfma_32x32x2(a, Bs[(32 * t + lo) * ED_LD + k], acc[t]);
+            for (int t = 0; t < 4; ++t) acc[t] = gs_mfma_32x32x2(a, Bs[k * ED_LDW + 32 * t + lo], acc[t]);
         }
-        gs_barrier();
+        gs_block_barrier();
     }
 
     if (VSF != 1) {
-        if (lane < ED_TQ) qn[lane] = nq;
-        vn[lane] = nv0;
-        vn[lane + 64] = nv1;
-        gs_barrier();
+        if (tid < ED_TN) vn[tid] = nrm;
+        else qn[tid - ED_TN] = nrm;
+        gs_block_barrier();
     }
     // ---- C/D layout (dtype independent on gfx950): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) ----
+    if (!wave_active) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int j = 32 * t + lo;
         const int64_t n = n0 + j;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int i = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hi;
             const int q = q0 + i;
             if (q < p.Q && n < p.count)
                 p.out[(int64_t)q * p.count + n] = ed_finish<VSF>(acc[t][r], VSF != 1 ? qn[i] : 0.0f, VSF != 1 ? vn[j] : 0.0f);

@@ -1,8 +1,8 @@
 // k_exact_dense.hip — MFMA tile form of full-resolution scoring (dense Q x N form).  Body and the
 // arithmetic contract in ed_body.h.  Roofline: MFMA f32 (157 TF peak; 2·Q·N·D flop) once Q >= ~64, HBM (4·D bytes per
-// vector, read once per 32-query tile row that misses L2) below that.  Launch: one wavefront per block, 21.7 KB LDS,
-// 202 VGPRs -> 2 waves per SIMD; four independent 32x32 accumulators per wave keep the 64-cycle MFMA issue slot full and
-// the next chunk's global loads are in flight under them (two-stage pipeline, ed_body.h).
+// vector, read once per 128-query tile row that misses L2) below that.  Launch: 4 wavefronts per block sharing a
+// 128 x 128 tile staged K-major in 34 KB of LDS; four independent 32x32 accumulators per wave keep the 64-cycle MFMA issue
+// slot full and the next chunk's global loads are in flight under them (two-stage pipeline, ed_body.h).
 #include "gs_wave_hip.h"
 #include "jv_internal.h"
 
@@ -11,7 +11,7 @@
 namespace jv {
 
 template <int VSF>
-__global__ __launch_bounds__(64, 2) void exact_dense_kernel(EdParams p, int64_t blocks_padded, int64_t n_tiles, int q_tiles)
+__global__ __launch_bounds__(ED_THREADS) void exact_dense_kernel(EdParams p, int64_t blocks_padded, int64_t n_tiles, int q_tiles)
 {
     __shared__ float lds[ED_LDS_FLOATS];
     int64_t n_tile;
@@ -32,7 +32,7 @@ int launch_exact_scan_dense(hipStream_t s, const float *d_vecs, int D, const flo
         set_error("exact_scan_dense: %lld tiles exceed one launch; scan a smaller range", (long long)blocks_padded);
         return JV_ERR_INVALID;
     }
-    const dim3 grid((unsigned)blocks_padded), block(64);
+    const dim3 grid((unsigned)blocks_padded), block(ED_THREADS);
     switch (vsf) {
     case 0: hipLaunchKernelGGL(exact_dense_kernel<0>, grid, block, 0, s, p, blocks_padded, n_tiles, q_tiles); break;
     case 1: hipLaunchKernelGGL(exact_dense_kernel<1>, grid, block, 0, s, p, blocks_padded, n_tiles, q_tiles); break;

@@ -1,0 +1,31 @@
+// rd_params.h — launch parameters of the batched robust prune (rd_body.h / k_retain_diverse.hip), shared with the host
+// driver in build_score.cpp.  Plain data only.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+namespace jv {
+
+struct RdParams {
+    const float *tri;          // pair table: M x k(k+1)/2 floats
+    const uint8_t *codes;      // [n][M]
+    int64_t n;
+    const int32_t *cand_nodes; // [P][C] sorted by score descending; entries >= count are ignored
+    const float *cand_scores;  // [P][C]
+    const int32_t *cand_count; // [P] or nullptr (= C)
+    const int32_t *diverse_before;  // [P] or nullptr (= 0): the first diverse_before candidates are taken as already diverse
+    int32_t P, C, M, k, vsf, maxDegree;
+    float alpha;
+    int32_t *selected_out;     // [P][maxDegree] selected candidate INDICES in ascending order, -1 padded
+    int32_t *n_selected_out;   // [P]
+    float *short_edges_out;    // [P] or nullptr: nSelected after the alpha = 1.0 pass / maxDegree (NaN if the loop never ran)
+};
+
+// LDS bytes one wavefront needs: candidate code rows, transposed selected codes, self magnitudes, slot bookkeeping
+inline size_t rd_lds_bytes(int C, int M)
+{
+    return (size_t)C * M + (size_t)M * 64 + sizeof(float) * ((size_t)C + 64) + sizeof(int32_t) * 64 * 2 + 16;
+}
+
+}  // namespace jv

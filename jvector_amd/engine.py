@@ -393,6 +393,25 @@ class PQBuildScoreProvider:
         check(self._lib.jv_hip_code_pair_scores(self.ctx._h, self._h, self.cv._h, n1_p, P, n2_p, B, o_p))
         return out
 
+    def retain_diverse(self, cand_nodes, cand_scores, max_degree, alpha=1.2, cand_count=None, diverse_before=None):
+        """VamanaDiversityProvider.retainDiverse for P nodes at once (the robust prune of Vamana construction): cand_nodes /
+        cand_scores [P, C] sorted by score descending per row.  Returns (selected [P, max_degree] candidate indices ascending,
+        -1 padded; n_selected [P]; short_edges [P])."""
+        P, Cn = int(cand_nodes.shape[0]), int(cand_nodes.shape[1])
+        n_p, kn = _ptr(cand_nodes, np.int32)
+        s_p, ks = _ptr(cand_scores, np.float32)
+        c_p, kc = _ptr(cand_count, np.int32)
+        d_p, kd = _ptr(diverse_before, np.int32)
+        sel = _empty((P, max_degree), np.int32, cand_nodes)
+        cnt = _empty((P,), np.int32, cand_nodes)
+        se = _empty((P,), np.float32, cand_nodes)
+        sel_p, k1 = _ptr(sel, np.int32)
+        cnt_p, k2 = _ptr(cnt, np.int32)
+        se_p, k3 = _ptr(se, np.float32)
+        check(self._lib.jv_hip_retain_diverse(self.ctx._h, self._h, self.cv._h, P, Cn, n_p, s_p, c_p, d_p, int(max_degree),
+                                              C.c_float(alpha), sel_p, cnt_p, se_p))
+        return sel, cnt, se
+
     def decode(self, ordinals):
         """ProductQuantization.decode of the listed codes (searchProviderFor(node1) searches from this vector)."""
         n = int(ordinals.shape[0])

@@ -470,6 +470,48 @@ float jvo_pq_diversity_score_direct(const jvo_pq *pq, int vsf, const uint8_t *co
     return (1.0f + cosine) / 2.0f;
 }
 
+/* VamanaDiversityProvider.retainDiverse (B/graph/diversity/VamanaDiversityProvider.java:43-78) + isDiverse (:82-96) — the
+ * robust prune of Vamana construction — with the PQ diversity score above as scoreProvider.diversityScoreFunctionFor
+ * (BuildScoreProvider.pqBuildScoreProvider, BuildScoreProvider.java:181-186).
+ *   nodes / scores: the NodeArray (sorted by score descending by its owner), n entries;  selected: n bytes (the BitSet), cleared
+ *   here;  returns nSelected, *short_edges = the return value of retainDiverse (NaN when the loop never ran).
+ * Float details kept: `currentAlpha <= alpha + 1E-6` compares in double, `currentAlpha += 0.2f` and `score * alpha` are float,
+ * shortEdges = nSelected / (float) maxDegree. */
+int jvo_retain_diverse(const float *tri, int M, int k, int vsf, const uint8_t *codes, const int32_t *nodes, const float *scores,
+                       int n, int maxDegree, int diverseBefore, float alpha, uint8_t *selected, double *short_edges)
+{
+    memset(selected, 0, (size_t)(n > 0 ? n : 0));
+    for (int i = 0; i < (diverseBefore < maxDegree ? diverseBefore : maxDegree) && i < n; i++) selected[i] = 1;
+    int nSelected = diverseBefore;
+    double shortEdges = NAN;
+    float currentAlpha = 1.0f;
+    while ((double)currentAlpha <= (double)alpha + 1E-6 && nSelected < maxDegree) {
+        for (int i = diverseBefore; i < n && nSelected < maxDegree; i++) {
+            if (selected[i]) continue;
+            const int cNode = nodes[i];
+            const float cScore = scores[i];
+            int diverse = 1;
+            for (int j = 0; j < n; j++) {             /* selected.nextSetBit ascending */
+                if (!selected[j]) continue;
+                const int other = nodes[j];
+                if (cNode == other) break;
+                if (jvo_pq_diversity_score(tri, M, k, vsf, codes + (size_t)cNode * M, codes + (size_t)other * M) > cScore * currentAlpha) {
+                    diverse = 0;
+                    break;
+                }
+            }
+            if (diverse) {
+                selected[i] = 1;
+                nSelected++;
+            }
+        }
+        if (currentAlpha == 1.0f) shortEdges = nSelected / (float)maxDegree;
+        currentAlpha += 0.2f;
+    }
+    if (short_edges) *short_edges = shortEdges;
+    return nSelected;
+}
+
 /* ------------------------------------------------------------------------------------------
  * PQ training: KMeansPlusPlusClusterer (unweighted path) + ProductQuantization.compute / refine.
  * The reference draws from ThreadLocalRandom (unseedable), so its output is not reproducible; this restatement

@@ -102,6 +102,9 @@ void jvo_pq_decode(const jvo_pq *pq, const uint8_t *code, float *dst);
 void jvo_pq_codebook_partial_sums(const jvo_pq *pq, int vsf, float *out);
 float jvo_pq_diversity_score(const float *tri, int M, int k, int vsf, const uint8_t *code1, const uint8_t *code2);
 float jvo_pq_diversity_score_direct(const jvo_pq *pq, int vsf, const uint8_t *code1, const uint8_t *code2);
+/* VamanaDiversityProvider.retainDiverse with the PQ diversity score; selected: n bytes out; returns nSelected */
+int jvo_retain_diverse(const float *tri, int M, int k, int vsf, const uint8_t *codes, const int32_t *nodes, const float *scores,
+                       int n, int maxDegree, int diverseBefore, float alpha, uint8_t *selected, double *short_edges);
 
 /* PQDecoder (precomputedScoreFunctionFor): builds LUT (M*k floats), for cosine also the
  * aMagnitude table and bMagnitude.  lut/amag caller-allocated; amag/bmag may be NULL unless cosine. */

@@ -136,6 +136,8 @@ def lib():
         sig("jvo_parallel_cost_multiplier", C.c_float, C.c_float, C.c_int)
         sig("jvo_pq_diversity_score", C.c_float, fp, C.c_int, C.c_int, C.c_int, u8p, u8p)
         sig("jvo_pq_diversity_score_direct", C.c_float, pqp, C.c_int, u8p, u8p)
+        sig("jvo_retain_diverse", C.c_int, fp, C.c_int, C.c_int, C.c_int, u8p, C.POINTER(C.c_int32), fp, C.c_int, C.c_int, C.c_int,
+            C.c_float, u8p, C.POINTER(C.c_double))
         sig("jvo_float_to_sortable_int", C.c_int32, C.c_float)
         sig("jvo_sortable_int_to_float", C.c_float, C.c_int32)
         sig("jvo_nodequeue_encode", C.c_int64, C.c_int32, C.c_float)
@@ -466,6 +468,18 @@ class OraclePQ:
         """ImmutablePQVectors.diversityFunctionFor(node1, vsf).similarityTo(node2) on the triangular table `tri`."""
         c1, c2 = np.ascontiguousarray(code1, np.uint8), np.ascontiguousarray(code2, np.uint8)
         return float(lib().jvo_pq_diversity_score(_f(tri), self.M, self.k, vsf, _u8(c1), _u8(c2)))
+
+    def retain_diverse(self, tri, vsf, codes, nodes, scores, max_degree, diverse_before=0, alpha=1.2):
+        """VamanaDiversityProvider.retainDiverse over one NodeArray (nodes / scores sorted by score descending) with the PQ
+        diversity score: returns (selected bool[n], nSelected, shortEdges)."""
+        nodes = np.ascontiguousarray(nodes, np.int32)
+        scores = f32(scores)
+        codes = np.ascontiguousarray(codes, np.uint8)
+        sel = np.zeros(max(len(nodes), 1), np.uint8)
+        se = C.c_double()
+        n = lib().jvo_retain_diverse(_f(tri), self.M, self.k, int(vsf), _u8(codes), nodes.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     _f(scores), len(nodes), int(max_degree), int(diverse_before), C.c_float(alpha), _u8(sel), C.byref(se))
+        return sel[:len(nodes)].astype(bool), int(n), se.value
 
     def diversity_score_direct(self, vsf, code1, code2):
         """PQVectors.diversityFunctionFor (MutablePQVectors path): straight from the codebooks."""

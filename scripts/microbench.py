@@ -106,9 +106,9 @@ def main():
     res["exact_scan"] = {"ms": ms, "shape": f"16x{N}", "dist_per_s": 16 * N / ms * 1e3,
                          "hbm_GBps_rows_once": N * 4 * D / ms / 1e6, "frac_hbm_rows_once": N * 4 * D / ms / 1e6 / HBM,
                          "tflops_nonfused": 16 * N * 6 * D / ms / 1e9}
-    # --- MFMA tile form of the scan (k_exact_dense.hip; opt-in until it has been validated on hardware): f32 MFMA peak 157 TF
-    if os.environ.get("JVECTOR_TEST_DENSE") == "1" or os.environ.get("JVECTOR_TEST_UNVERIFIED") == "1":
-        for nq in (16, 64, 256):
+    # --- MFMA tile form of the scan (k_exact_dense.hip): f32 MFMA peak 157 TF (155 TF micro-benchmark ceiling)
+    if True:
+        for nq in (16, 64, 256, 1024):
             qd = queries[:nq].contiguous()
             od = torch.empty(nq, N, dtype=torch.float32, device=dev)
             ms = timed(ctx, "exact", lambda: vs.scan(qd, VSF, out=od, dense=True), 3)

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-2 profiling recipe (runs on the GPU box via gpurun): the DEFAULT 10M workload under rocprofv3, search steps only.
+# The synthetic index (graph + codebooks) is built once, untraced, and cached on the box's /tmp (bench.py --index-cache):
+# round 1 learnt that tracing the synthetic graph build (millions of tiny torch launches) makes rocprofv3 crawl.
+# Every traversal / rerank / scan launch of the traced runs has the benched shape (calibration and evaluation sets are sized
+# to whole 16384-query batches), so rocprofv3's per-kernel averages are directly comparable with bench.py's HIP events.
+#   1. kernel-trace + stats                      -> per-kernel time of the whole step
+#   2. --pmc FETCH_SIZE / --pmc WRITE_SIZE       -> HBM bytes per launch (separate passes, never combined with trace domains)
+#   3. --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_BUSY_CYCLES -> LDS conflict fraction of adc_mq_kernel
+#   4. --pmc TCC_HIT_sum TCC_MISS_sum            -> L2 hit rate of the traversal kernel's codebook gathers
+set -u
+TAG=${1:-r2_10m}; N=${2:-10000000}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=/tmp/prof_$TAG; K=$R/gpurun_out/prof_$TAG; C=/tmp/jv_index_$N.npz
+mkdir -p $O $K
+/opt/rocm/bin/rocminfo > $K/rocminfo.txt 2>&1
+ARGS="--n $N --index-cache $C --rerank 150 --cal-queries 16384 --eval-queries 16384 --no-cpu-baseline"
+cd /tmp && export TMPDIR=/tmp
+[ -f $C ] || timeout 900 python $R/bench.py --n $N --index-cache $C --steps 1 --warmup 1 --no-flat --no-cpu-baseline --cal-queries 256 --eval-queries 256 > $K/cache_build.log 2>&1
+ls -la $C >> $K/cache_build.log
+extract() { f=$(find $O/$1 -name "*counter_collection.csv" | head -1); [ -n "$f" ] && { head -1 $f > $K/$1_jv.csv; grep -E "jv::" $f >> $K/$1_jv.csv; }; }
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $R/bench.py $ARGS > $K/stats.log 2>&1
+cp $O/stats/*kernel_stats.csv $K/ 2>/dev/null
+f=$(find $O/stats -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && { head -1 $f > $K/kernel_trace_jv.csv; grep -E "jv::" $f >> $K/kernel_trace_jv.csv; }
+for CTR in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $CTR --output-format csv -d $O/$CTR -o bench -- python $R/bench.py $ARGS --steps 3 --warmup 1 > $K/$CTR.log 2>&1
+  extract $CTR
+done
+timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/LDS -o bench -- python $R/bench.py $ARGS --steps 3 --warmup 1 > $K/LDS.log 2>&1
+extract LDS
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/TCC -o bench -- python $R/bench.py $ARGS --steps 3 --warmup 1 --no-flat > $K/TCC.log 2>&1
+extract TCC
+ls -la $K; tail -3 $K/stats.log | cut -c1-600

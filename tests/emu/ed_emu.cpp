@@ -13,6 +13,8 @@
 #define GS_FN inline
 static inline int gs_lane() { return emu::lane(); }
 static inline void gs_barrier() { emu::barrier(); }
+static inline int gs_tid() { return emu::lane(); }
+static inline void gs_block_barrier() { emu::barrier(); }
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
 static inline float gs_fmaf(float a, float b, float c) { return fmaf(a, b, c); }
 typedef emu::f32x16 gs_f32x16;
@@ -56,7 +58,7 @@ extern "C" long ed_emu_scan(const float *vecs, const float *queries, float *out,
         if (nt < 0 || nt >= n_tiles || qt < 0 || qt >= q_tiles || seen[(size_t)(nt * q_tiles + qt)]++) return -1;
         for (int i = 0; i < jv::ED_LDS_FLOATS; ++i) lds[i] = NAN;  // stale LDS must never reach a result
         Launch L{&p, vsf, nt, qt, lds};
-        emu::run_wave(tile_main, &L);
+        emu::run_block(tile_main, &L, jv::ED_WAVES);
         ++ran;
     }
     free(lds);

@@ -1,6 +1,7 @@
 // hip_emu.h — a minimal lane-level emulator for wave-synchronous device code (TEST HARNESS, x86-64 only).
 //
-// It runs one 64-lane "wavefront" as 64 cooperatively scheduled fibers on one host thread.  A lane runs until it
+// It runs one workgroup of 1..4 64-lane "wavefronts" as cooperatively scheduled fibers on one host thread (run_wave = one
+// wavefront, run_block = several: barrier() is the workgroup barrier, ballot / shfl / gather64 / mfma are wave collectives).  A lane runs until it
 // reaches a collective (barrier / ballot / shuffle), then the next lane runs; when all live lanes have arrived the
 // collective completes.  That is enough to execute jvector_amd/csrc/gs_body.h — the body of the device-resident graph
 // search kernel — unchanged on the CPU and compare it with the oracle, lane divergence, in-place compaction and
@@ -18,6 +19,8 @@
 namespace emu {
 
 constexpr int WAVE = 64;
+constexpr int MAX_WAVES = 4;
+constexpr int MAXL = WAVE * MAX_WAVES;
 constexpr size_t STACK_BYTES = 256 * 1024;
 
 extern "C" void emu_switch(void **save_sp, void *next_sp);
@@ -49,15 +52,18 @@ emu_switch:
 // EMU_LANE_ORDER = "reverse" or "random[:seed]" changes it (default: ascending).  A kernel that is correct under every
 // order does not depend on which lane happens to run first inside a phase, i.e. every cross-lane hand-over goes through a
 // collective or barrier — the property the real wavefront needs.
-struct Wave {
-    int order[WAVE], pos_of[WAVE];
-    void *sp[WAVE];
-    char *stack[WAVE];
-    bool done[WAVE];
+struct Wave {  // (a workgroup: nl = 64 * waves lanes; the name predates multi-wave blocks)
+    int order[MAXL], pos_of[MAXL];
+    void *sp[MAXL];
+    char *stack[MAXL];
+    bool done[MAXL];
     void *main_sp;
+    int nl;
     int cur, live, arrived;
     unsigned gen;
-    long long xbuf[WAVE];
+    int wlive[MAX_WAVES], warrived[MAX_WAVES];  // wave-scope collectives
+    unsigned wgen[MAX_WAVES];
+    long long xbuf[MAXL];
     void (*fn)(void *);
     void *arg;
     long collectives;
@@ -68,12 +74,14 @@ inline Wave *&current()
     static Wave *w = nullptr;
     return w;
 }
-inline int lane() { return current()->cur; }
+inline int lane() { return current()->cur; }            // index inside the workgroup (threadIdx.x)
+inline int wave_id() { return current()->cur >> 6; }
+inline int wave_lane() { return current()->cur & 63; }
 
 inline int next_live_after(const Wave &w, int me)
 {
-    for (int i = 1; i <= WAVE; ++i) {
-        const int c = w.order[(w.pos_of[me] + i) % WAVE];
+    for (int i = 1; i <= w.nl; ++i) {
+        const int c = w.order[(w.pos_of[me] + i) % w.nl];
         if (!w.done[c]) return c;
     }
     return me;
@@ -102,6 +110,21 @@ inline void barrier()
     while (w.gen == g) switch_to_next_live();
 }
 
+// barrier among the live lanes of the calling lane's wavefront (the scope of ballot / shuffle / mfma)
+inline void wave_barrier()
+{
+    Wave &w = *current();
+    const int wv = w.cur >> 6;
+    const unsigned g = w.wgen[wv];
+    if (++w.warrived[wv] >= w.wlive[wv]) {
+        w.warrived[wv] = 0;
+        w.wgen[wv]++;
+        w.collectives++;
+        return;
+    }
+    while (w.wgen[wv] == g) switch_to_next_live();
+}
+
 inline void lane_exit()
 {
     Wave &w = *current();
@@ -109,6 +132,7 @@ inline void lane_exit()
     w.done[me] = true;
     w.xbuf[me] = 0;
     w.live--;
+    w.wlive[me >> 6]--;
     if (w.live == 0) {
         void *dummy;
         emu_switch(&dummy, w.main_sp);  // never returns
@@ -116,6 +140,10 @@ inline void lane_exit()
     if (w.arrived >= w.live) {  // the others were waiting for this lane only
         w.arrived = 0;
         w.gen++;
+    }
+    if (w.wlive[me >> 6] > 0 && w.warrived[me >> 6] >= w.wlive[me >> 6]) {
+        w.warrived[me >> 6] = 0;
+        w.wgen[me >> 6]++;
     }
     const int nx = next_live_after(w, me);
     w.cur = nx;
@@ -131,15 +159,18 @@ inline void lane_entry()
     abort();
 }
 
-// run fn(arg) on 64 lanes until every lane has returned
-inline long run_wave(void (*fn)(void *), void *arg)
+// run fn(arg) on a workgroup of `waves` wavefronts until every lane has returned
+inline long run_block(void (*fn)(void *), void *arg, int waves)
 {
     Wave *w = new Wave();
     memset(w, 0, sizeof(*w));
     w->fn = fn;
     w->arg = arg;
-    w->live = WAVE;
-    for (int i = 0; i < WAVE; ++i) {
+    const int NL = WAVE * waves;
+    w->nl = NL;
+    w->live = NL;
+    for (int v = 0; v < waves; ++v) w->wlive[v] = WAVE;
+    for (int i = 0; i < NL; ++i) {
         w->stack[i] = (char *)aligned_alloc(64, STACK_BYTES);
         uintptr_t top = ((uintptr_t)(w->stack[i] + STACK_BYTES)) & ~(uintptr_t)15;
         void **sp = (void **)top;
@@ -149,14 +180,14 @@ inline long run_wave(void (*fn)(void *), void *arg)
         w->sp[i] = (void *)sp;
     }
     {
-        for (int i = 0; i < WAVE; ++i) w->order[i] = i;
+        for (int i = 0; i < NL; ++i) w->order[i] = i;
         const char *e = getenv("EMU_LANE_ORDER");
         if (e && !strncmp(e, "reverse", 7)) {
-            for (int i = 0; i < WAVE; ++i) w->order[i] = WAVE - 1 - i;
+            for (int i = 0; i < NL; ++i) w->order[i] = NL - 1 - i;
         } else if (e && !strncmp(e, "random", 6)) {
             static unsigned long long state = 0;
             if (!state) state = e[6] == ':' ? strtoull(e + 7, nullptr, 10) * 2654435761ull + 1 : 88172645463325252ull;
-            for (int i = WAVE - 1; i > 0; --i) {  // Fisher-Yates with xorshift64, a fresh permutation per wave
+            for (int i = NL - 1; i > 0; --i) {  // Fisher-Yates with xorshift64, a fresh permutation per wave
                 state ^= state << 13;
                 state ^= state >> 7;
                 state ^= state << 17;
@@ -166,7 +197,7 @@ inline long run_wave(void (*fn)(void *), void *arg)
                 w->order[j] = t;
             }
         }
-        for (int i = 0; i < WAVE; ++i) w->pos_of[w->order[i]] = i;
+        for (int i = 0; i < NL; ++i) w->pos_of[w->order[i]] = i;
     }
     Wave *prev = current();
     current() = w;
@@ -174,29 +205,32 @@ inline long run_wave(void (*fn)(void *), void *arg)
     emu_switch(&w->main_sp, w->sp[w->order[0]]);
     current() = prev;
     const long n = w->collectives;
-    for (int i = 0; i < WAVE; ++i) free(w->stack[i]);
+    for (int i = 0; i < NL; ++i) free(w->stack[i]);
     delete w;
     return n;
 }
+inline long run_wave(void (*fn)(void *), void *arg) { return run_block(fn, arg, 1); }
 
 inline uint64_t ballot(bool p)
 {
     Wave &w = *current();
+    const int base = w.cur & ~63;
     w.xbuf[w.cur] = p ? 1 : 0;
-    barrier();
+    wave_barrier();
     uint64_t m = 0;
     for (int i = 0; i < WAVE; ++i)
-        if (!w.done[i] && w.xbuf[i]) m |= 1ull << i;
-    barrier();
+        if (!w.done[base + i] && w.xbuf[base + i]) m |= 1ull << i;
+    wave_barrier();
     return m;
 }
 inline long long shfl(long long v, int src)
 {
     Wave &w = *current();
+    const int base = w.cur & ~63;
     w.xbuf[w.cur] = v;
-    barrier();
-    const long long r = w.xbuf[src & 63];
-    barrier();
+    wave_barrier();
+    const long long r = w.xbuf[base + (src & 63)];
+    wave_barrier();
     return r;
 }
 
@@ -205,11 +239,12 @@ inline long long shfl(long long v, int src)
 inline void gather64(float v, float (&out)[WAVE])
 {
     Wave &w = *current();
-    static float G[WAVE];  // one wave runs at a time
+    static float G[MAXL];  // one workgroup runs at a time
+    const int base = w.cur & ~63;
     G[w.cur] = v;
-    barrier();
-    for (int i = 0; i < WAVE; ++i) out[i] = w.done[i] ? 0.0f : G[i];
-    barrier();
+    wave_barrier();
+    for (int i = 0; i < WAVE; ++i) out[i] = w.done[base + i] ? 0.0f : G[base + i];
+    wave_barrier();
 }
 
 // v_mfma_f32_32x32x2_f32 as the hardware defines it (cdna_hip_programming.md §3): lane l supplies A[i = l & 31][k = l >> 5]
@@ -223,16 +258,17 @@ struct f32x16 {
 inline f32x16 mfma_32x32x2(float a, float b, f32x16 c)
 {
     Wave &w = *current();
-    static float A[WAVE], B[WAVE];  // one wave runs at a time
+    static float A[MAXL], B[MAXL];  // one workgroup runs at a time; each wavefront uses its own 64 slots
+    const int base = w.cur & ~63;
     A[w.cur] = a;
     B[w.cur] = b;
-    barrier();
-    const int l = w.cur, j = l & 31;
+    wave_barrier();
+    const int l = w.cur & 63, j = l & 31;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        c.v[r] = fmaf(A[i + 32], B[j + 32], fmaf(A[i], B[j], c.v[r]));
+        c.v[r] = fmaf(A[base + i + 32], B[base + j + 32], fmaf(A[base + i], B[base + j], c.v[r]));
     }
-    barrier();
+    wave_barrier();
     return c;
 }
 

@@ -1,0 +1,49 @@
+// rd_emu.cpp — TEST HARNESS: runs the body of retain_diverse_kernel (jvector_amd/csrc/rd_body.h, unchanged) on the lane
+// emulator, one emulated wavefront per node.
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+
+#include "hip_emu.h"
+
+#define GS_FN inline
+static inline int gs_lane() { return emu::lane(); }
+static inline void gs_barrier() { emu::barrier(); }
+static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
+static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
+static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
+static inline double gs_sqrt(double x) { return std::sqrt(x); }
+
+#include "../../jvector_amd/csrc/rd_body.h"
+
+namespace {
+struct Launch {
+    const jv::RdParams *p;
+    int node;
+    char *lds;
+};
+void node_main(void *a)
+{
+    const Launch &L = *(const Launch *)a;
+    jv::rd_node(*L.p, L.node, L.lds);
+}
+}  // namespace
+
+extern "C" int rd_emu_run(const float *tri, const uint8_t *codes, int64_t n, const int32_t *cand_nodes, const float *cand_scores,
+                          const int32_t *cand_count, const int32_t *diverse_before, int P, int C, int M, int k, int vsf, int maxDegree,
+                          float alpha, int32_t *selected_out, int32_t *n_selected_out, float *short_edges_out)
+{
+    jv::RdParams p{};
+    p.tri = tri; p.codes = codes; p.n = n; p.cand_nodes = cand_nodes; p.cand_scores = cand_scores; p.cand_count = cand_count;
+    p.diverse_before = diverse_before; p.P = P; p.C = C; p.M = M; p.k = k; p.vsf = vsf; p.maxDegree = maxDegree; p.alpha = alpha;
+    p.selected_out = selected_out; p.n_selected_out = n_selected_out; p.short_edges_out = short_edges_out;
+    const size_t lds_bytes = jv::rd_lds_bytes(C, M);
+    char *lds = (char *)aligned_alloc(64, (lds_bytes + 63) & ~(size_t)63);
+    for (int node = 0; node < P; ++node) {
+        for (size_t i = 0; i < lds_bytes; ++i) lds[i] = (char)0xA5;  // stale LDS must never reach a result
+        Launch L{&p, node, lds};
+        emu::run_wave(node_main, &L);
+    }
+    free(lds);
+    return 0;
+}

@@ -14,6 +14,8 @@
 #define KM_FN static inline
 static inline int gs_lane() { return emu::lane(); }
 static inline void gs_barrier() { emu::barrier(); }
+static inline int gs_tid() { return emu::lane(); }
+static inline void gs_block_barrier() { emu::barrier(); }
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
@@ -45,6 +47,7 @@ static inline gs_f32x16 gs_mfma_32x32x2(float a, float b, gs_f32x16 c) { return 
 #include "../../jvector_amd/csrc/ed_body.h"
 #include "../../jvector_amd/csrc/gs_body.h"
 #include "../../jvector_amd/csrc/km_body.h"
+#include "../../jvector_amd/csrc/rd_body.h"
 #include "../../oracle/jv_oracle.h"
 
 namespace jv {
@@ -160,6 +163,35 @@ int launch_fused(hipStream_t, const jv_ctx *, const float *d_luts, const float *
         }
     return JV_OK;
 }
+namespace {
+struct RdLaunch {
+    const RdParams *p;
+    int node;
+    char *lds;
+};
+void rd_main(void *a)
+{
+    const RdLaunch &L = *(const RdLaunch *)a;
+    rd_node(*L.p, L.node, L.lds);
+}
+}  // namespace
+size_t retain_diverse_lds_bytes(int C, int M) { return rd_lds_bytes(C, M); }
+// the shared kernel body (rd_body.h) on the lane emulator, one wavefront per node
+int launch_retain_diverse(hipStream_t, const jv_ctx *ctx, const RdParams &p)
+{
+    const size_t lds_bytes = rd_lds_bytes(p.C, p.M);
+    if (lds_bytes > ctx->lds_per_block) {
+        set_error("retain_diverse: %d candidates x %d code bytes need %zu bytes of LDS (limit %zu)", p.C, p.M, lds_bytes, ctx->lds_per_block);
+        return JV_ERR_UNSUPPORTED;
+    }
+    std::vector<char> lds(lds_bytes + 64);
+    char *base = (char *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+    for (int node = 0; node < p.P; ++node) {
+        RdLaunch L{&p, node, base};
+        emu::run_wave(rd_main, &L);
+    }
+    return JV_OK;
+}
 int launch_shard_interleave(hipStream_t, const int32_t *d_ids, const float *d_sc, int P, int Q, int k, int32_t *d_out_ids, float *d_out_sc)
 {
     for (int p = 0; p < P; ++p)
@@ -248,7 +280,7 @@ int launch_exact_scan_dense(hipStream_t, const float *d_vecs, int D, const float
         if (!ed_block_to_tile(b, blocks_padded, n_tiles, q_tiles, &nt, &qt)) continue;
         std::fill(lds.begin(), lds.end(), NAN);
         EdLaunch L{&p, vsf, nt, qt, lds.data()};
-        emu::run_wave(ed_main, &L);
+        emu::run_block(ed_main, &L, jv::ED_WAVES);
     }
     return JV_OK;
 }

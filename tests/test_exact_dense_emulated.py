@@ -1,8 +1,8 @@
 """CPU check of the MFMA tile form of full-resolution scoring (jvector_amd/csrc/ed_body.h — the body of
-exact_dense_kernel): the kernel source is compiled unchanged for the 64-lane emulator, whose MFMA is the documented
+exact_dense_kernel): the kernel source is compiled unchanged for the lane emulator (a 4-wavefront workgroup), whose MFMA is the documented
 v_mfma_f32_32x32x2_f32 (lane -> operand / accumulator maps, k-ordered f32 fmaf chain), and must reproduce the
 k-ascending fmaf-chain specification (oracle.dense_scan) BIT FOR BIT on ragged shapes (Q, N, D not multiples of the
-32 x 128 x 32 tile), sit within 1e-5 of the bit-exact scalar-order scores, and pass the identity-times-asymmetric-matrix
+128 x 128 x 32 tile), sit within 1e-5 of the bit-exact scalar-order scores, and pass the identity-times-asymmetric-matrix
 probe that catches a transposed accumulator unpack.  The GPU twin is tests/test_zz_exact_dense_gpu.py."""
 import ctypes as C
 import os
@@ -40,11 +40,11 @@ def run(emu, vecs, queries, vsf, first=0, count=None):
     out = np.full((queries.shape[0], count), np.float32(-7.0))
     n = emu.ed_emu_scan(vecs.ctypes.data, queries.ctypes.data, out.ctypes.data, first, count, vecs.shape[1], queries.shape[0],
                         int(vsf))
-    assert n == -(-count // 128) * -(-queries.shape[0] // 32), "block -> tile map must cover every tile exactly once"
+    assert n == -(-count // 128) * -(-queries.shape[0] // 128), "block -> tile map must cover every tile exactly once"
     return out
 
 
-@pytest.mark.parametrize("Q,N,D", [(1, 1, 1), (5, 130, 7), (33, 129, 100), (40, 300, 64), (64, 256, 96), (3, 77, 129)])
+@pytest.mark.parametrize("Q,N,D", [(1, 1, 1), (5, 130, 7), (33, 129, 100), (40, 300, 64), (64, 256, 96), (3, 77, 129), (130, 140, 36), (257, 64, 8)])
 def test_dense_tile_equals_the_fma_chain_specification(emu, Q, N, D, monkeypatch):
     monkeypatch.setenv("EMU_LANE_ORDER", ["", "reverse", "random:5"][(Q + N) % 3])
     rng = np.random.default_rng(Q * 1000 + N)
