@@ -328,7 +328,7 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--m", type=int, default=96)
     ap.add_argument("--degree", type=int, default=32)
-    ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 16384 graph / 256 flat / 1024 c2)")
+    ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 65536 graph / 256 flat / 1024 c2)")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95 on the calibration set")
     ap.add_argument("--cal-queries", type=int, default=2048, help="calibration queries (rerankK ladder)")
@@ -377,7 +377,9 @@ def main():
     if args.mode == "auto":
         args.mode = "graph"
     graph_mode = args.mode == "graph"
-    Q = args.queries or (16384 if graph_mode else 256)
+    # graph mode: one persistent launch serves the whole batch and ends when its LAST query does (a long search takes 2-3 ms),
+    # so throughput grows with the batch until that tail is amortised: 775k / 868k / 938k QPS at 16k / 32k / 64k queries (1M run)
+    Q = args.queries or (65536 if graph_mode else 256)
     t_setup = time.perf_counter()
     mix = Mixture(D, seed=5, device=dev)
     base = mix.sample(N, seed=5)
@@ -608,6 +610,15 @@ def main():
             line["avg_expanded"] = float(st[:, 1].mean())
             line["adc_distances_per_s"] = float(st[:, 0].mean()) * total_queries / elapsed
             line["expansions_per_s"] = float(st[:, 1].mean()) * total_queries / elapsed
+            line["visited_percentiles"] = {k: float(np.percentile(st[:, 0], v)) for k, v in (("p50", 50), ("p99", 99), ("p99.9", 99.9), ("max", 100))}
+            # the kernel's physical bound: 32-byte codebook rows gathered from L2, one per (scored neighbour, subspace);
+            # ceiling = tools/gather_bench.hip on this GPU (profiles/r2_gather_bench.log: 396 G rows/s, 12.7 TB/s)
+            if args.traversal == "device" and k_ms > 0:
+                rows = float(st[:, 0].sum()) * M
+                line["l2_gather"] = {"rows_per_s": rows / (k_ms / 1e3), "ceiling_rows_per_s": 395.9e9,
+                                     "frac": rows / (k_ms / 1e3) / 395.9e9, "bytes_per_row": 32,
+                                     "note": "scored neighbours x M codebook rows of 32 B (L2-resident 768 KB table) over the traversal "
+                                             "kernel's time; ceiling measured by tools/gather_bench.hip (lane per row, 2 x dwordx4)"}
             if flat_info is not None:
                 line["flat_mode"] = flat_info
         else:

@@ -288,6 +288,12 @@ typedef struct jv_graph jv_graph;
 JV_API int jv_hip_graph_create(jv_ctx *ctx, int64_t n_nodes, int n_levels, jv_graph **out);
 JV_API int jv_hip_graph_set_level(jv_ctx *ctx, jv_graph *g, int level, int count, const int32_t *node_ids,
                                   const int32_t *neighbors, int degree);
+/* Level 0 in CALLER-owned device memory: n_nodes x degree int32, packed rows padded with -1, read in place by the device
+ * traversal on every search — the owner may rewrite rows between searches (incremental construction: search the partial
+ * graph, prune, write the new rows, search again).  No host copy is kept, so such a graph is searched by the device
+ * traversal only, without FusedPQ blocks (scores come from the code store: PQDecoder.similarityTo).  Upper levels, if any,
+ * are set with jv_hip_graph_set_level as usual.  Ids must stay inside [-1, n_nodes): the kernel does not check them. */
+JV_API int jv_hip_graph_set_level0_device(jv_ctx *ctx, jv_graph *g, const int32_t *d_neighbors, int degree);
 JV_API int jv_hip_graph_set_entry(jv_graph *g, int32_t node, int level);
 JV_API int jv_hip_graph_destroy(jv_graph *g);
 /* Where the traversal state (candidate / result queues, visited set) lives.

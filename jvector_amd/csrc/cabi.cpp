@@ -277,6 +277,7 @@ int jv_hip_ctx_destroy(jv_ctx *ctx)
     ctx->d_gs_spill.release();
     ctx->d_gs_out.release();
     ctx->d_gs_mask.release();
+    ctx->d_gs_big.release();
     for (auto &e : ctx->prof_pending) {
         (void)hipEventDestroy(e.start);
         (void)hipEventDestroy(e.stop);

@@ -352,7 +352,7 @@ struct jv_graph {
         if (!dev.empty() && dev_device >= 0) {
             (void)hipSetDevice(dev_device);
             for (DevLevel &d : dev) {
-                (void)hipFree(d.nbrs);
+                if (d.nbrs != dev_level0) (void)hipFree(d.nbrs);
                 (void)hipFree(d.hkeys);
                 (void)hipFree(d.hvals);
             }
@@ -361,6 +361,9 @@ struct jv_graph {
         dev_ready = false;
         fused_checked = nullptr;
     }
+    // level 0 living in CALLER-owned device memory (jv_hip_graph_set_level0_device): read in place by the device traversal,
+    // may be rewritten by its owner between searches (incremental construction); no host copy exists
+    const int32_t *dev_level0 = nullptr;
     const void *fused_checked = nullptr;  // the jv_fused whose neighbour table was last compared with level 0's adjacency
     uint64_t fused_checked_gen = 0;
     ~jv_graph() { free_mirror(); }
@@ -408,6 +411,7 @@ int jv_hip_graph_set_level(jv_ctx *ctx, jv_graph *g, int level, int count, const
     }
     std::lock_guard<std::mutex> lk(g->dev_mu);
     g->free_mirror();  // a search may already have built the device mirror: it is stale now
+    if (level == 0) g->dev_level0 = nullptr;
     jv_graph::Level &L = g->levels[level];
     L.count = count;
     L.degree = degree;
@@ -426,6 +430,23 @@ int jv_hip_graph_set_entry(jv_graph *g, int32_t node, int level)
     g->free_mirror();  // the mirror covers levels 0..entry_level of the graph it was built from
     g->entry_node = node;
     g->entry_level = level;
+    return JV_OK;
+}
+
+int jv_hip_graph_set_level0_device(jv_ctx *ctx, jv_graph *g, const int32_t *d_neighbors, int degree)
+{
+    clear_error();
+    JV_REQUIRE(ctx && g && d_neighbors, "graph_set_level0_device: NULL argument");
+    JV_REQUIRE(degree > 0 && degree <= 64, "graph_set_level0_device: degree %d outside 1..64", degree);
+    JV_REQUIRE(is_device_ptr(d_neighbors), "graph_set_level0_device: the adjacency must be device memory (use jv_hip_graph_set_level for host rows)");
+    std::lock_guard<std::mutex> lk(g->dev_mu);
+    g->free_mirror();
+    jv_graph::Level &L = g->levels[0];
+    L.count = (int)g->n_nodes;
+    L.degree = degree;
+    L.nbrs.clear();
+    L.nodes.clear();
+    g->dev_level0 = d_neighbors;
     return JV_OK;
 }
 
@@ -883,6 +904,10 @@ static int ensure_device_graph(jv_ctx *ctx, jv_graph *g)
         for (int lv = 0; lv <= g->entry_level; ++lv) {
             const jv_graph::Level &L = g->levels[lv];
             jv_graph::DevLevel &d = g->dev[lv];
+            if (lv == 0 && g->dev_level0) {
+                d.nbrs = const_cast<int32_t *>(g->dev_level0);  // caller-owned, read in place
+                continue;
+            }
             JV_TRY(upload(&d.nbrs, L.nbrs.data(), L.nbrs.size()));
             if (!L.nodes.empty()) {
                 const GsLevelMap m = gs_build_level_map(L.nodes.data(), L.count);
@@ -925,19 +950,23 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const jv_pq *pq = l->pq;
 
     // ---- sizing: LDS tier, workers, per-worker scratch ----
-    // register-allocation variant: 2 waves/SIMD (default) or 4 (JVECTOR_HIP_GS_OCC=4: smaller LDS tier so 16 waves fit a CU)
+    // register-allocation variant: waves per SIMD the kernel is compiled for — 2 (default: 225 VGPRs, the most codebook gathers
+    // in flight per wave) or 4 (JVECTOR_HIP_GS_OCC=4: 128 VGPRs, no pair-lane scoring).  Measured on MI355X at 1M x 768:
+    // 2 waves/SIMD + pair lanes 19.0 ms per 16384-query batch; 4 waves/SIMD 25.1 ms; a 3 waves/SIMD build (168 VGPRs, 12 waves
+    // per CU) 28.3 ms — fewer gathers in flight per wave cost more than the extra waves hide (profiles/r2_sweeps.md).
     const int occ = env_int("JVECTOR_HIP_GS_OCC", 2) >= 4 ? 4 : 2;
     // pair-lane scoring (two lanes per neighbour) when no level has more than 32 neighbours; it needs an M/2 x 32 float
-    // exchange area in LDS, which only fits next to the queues at 2 waves/SIMD.  JVECTOR_HIP_GS_PAIR=0 turns it off.
+    // exchange area in LDS.  JVECTOR_HIP_GS_PAIR=0 turns it off.
     bool pair = occ == 2 && env_int("JVECTOR_HIP_GS_PAIR", 1) != 0;
     for (int lv = 0; lv <= g->entry_level; ++lv) pair = pair && g->levels[lv].degree <= 32;
     // M >= 128: the pair form's two half rows + exchange indices no longer fit 256 VGPRs (156 / 588 bytes of scratch per
     // lane at M = 128 / 192, -Rpass-analysis=kernel-resource-usage) while the one-lane-per-neighbour form still does
     pair = pair && pq->M <= 96;
     const int pair_M = pair ? pq->M : 0;
-    int cand_cap = std::max(256, env_int("JVECTOR_HIP_GS_CAND_CAP", occ == 4 ? 512 : (pair ? 768 : 1024))) & ~63;
-    while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
-    const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M);
+    const int evict_cap = GS_EVICT_CAP;
+    int cand_cap = std::max(256, env_int("JVECTOR_HIP_GS_CAND_CAP", occ == 4 ? 512 : (pair ? 256 : 1024))) & ~63;
+    while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
+    const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap);
     if (lds > ctx->lds_per_block) {
         set_error("graph_search(device): rerankK %d needs %zu bytes of LDS per wave (limit %zu); use the host traversal", rerankK,
                   lds, ctx->lds_per_block);
@@ -952,6 +981,20 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const int spill_cap = (int)(vcap / 2) + 64;  // pushes <= visited <= vcap / 2: the spill tier cannot overflow first
     JV_TRY(ctx->d_gs_visited.reserve(sizeof(int32_t) * vcap * (size_t)workers));
     JV_TRY(ctx->d_gs_spill.reserve(sizeof(long long) * (size_t)spill_cap * (size_t)workers));
+    // growth pool: the few queries of a batch that outgrow the base table (a long search visits 3-6x the average) move to
+    // one of these 8x tables inside the kernel instead of costing a second launch; JVECTOR_HIP_GS_GROW=0 turns it off
+    const int big_log2 = std::min(24, vcap_log2 + 3);
+    // (a pinned JVECTOR_HIP_GS_VCAP_LOG2 is how tests reach the retry / host-fallback paths: no pool then unless asked for)
+    const bool grow_on = getenv("JVECTOR_HIP_GS_GROW") ? env_int("JVECTOR_HIP_GS_GROW", 1) != 0 : getenv("JVECTOR_HIP_GS_VCAP_LOG2") == nullptr;
+    const int big_count = (grow_on && big_log2 > vcap_log2) ? std::max(1, std::min(64, Q)) : 0;
+    const int big_spill_cap = (int)(((size_t)1 << big_log2) / 2) + 64;
+    const size_t big_vis_bytes = sizeof(int32_t) * ((size_t)1 << big_log2) * (size_t)big_count;
+    const size_t big_spill_off = (big_vis_bytes + 255) & ~(size_t)255;
+    const size_t big_ctr_off = (big_spill_off + sizeof(long long) * (size_t)big_spill_cap * (size_t)big_count + 255) & ~(size_t)255;
+    if (big_count > 0) {
+        JV_TRY(ctx->d_gs_big.reserve(big_ctr_off + 256));
+        JV_HIP_CHECK(hipMemsetAsync((char *)ctx->d_gs_big.ptr + big_ctr_off, 0, sizeof(uint32_t), ctx->stream));
+    }
     // result staging: [ids Q*rk][scores Q*rk][qnorm Q][pad][stats Q*2 i64][status Q][counter]
     const size_t c1 = (size_t)Q * rerankK;
     size_t off = 0;
@@ -1009,6 +1052,15 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.spill = (long long *)ctx->d_gs_spill.ptr;
     p.spill_cap = spill_cap;
     p.cand_cap = cand_cap;
+    p.evict_cap = evict_cap;
+    if (big_count > 0) {
+        p.big_visited = (int32_t *)ctx->d_gs_big.ptr;
+        p.big_spill = (long long *)((char *)ctx->d_gs_big.ptr + big_spill_off);
+        p.big_next = (uint32_t *)((char *)ctx->d_gs_big.ptr + big_ctr_off);
+        p.big_count = big_count;
+        p.big_log2 = big_log2;
+        p.big_spill_cap = big_spill_cap;
+    }
     p.pair = pair ? 1 : 0;
     p.out_ids = d_cand;
     p.out_scores = d_cand_sc;
@@ -1057,6 +1109,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p2.vcap_log2 = vlog2;
         p2.spill = (long long *)ctx->d_gs_spill.ptr;
         p2.spill_cap = spill2;
+        p2.big_visited = nullptr;  // the retry pass has roomy tables of its own
+        p2.big_count = 0;
+        p2.big_log2 = 0;
         p2.prof = nullptr;
         {
             ProfScope ps(ctx, R_GSEARCH);
@@ -1212,6 +1267,11 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
         g->levels[0].nbrs.size() == (size_t)g->n_nodes * fused->maxDegree) {
         JV_TRY(use_device(ctx->device));
         JV_TRY(check_fused_matches_graph(ctx, const_cast<jv_graph *>(g), fused));
+    }
+    if (g->dev_level0 && Q > 0) {
+        JV_REQUIRE(mode == JV_TRAVERSAL_DEVICE, "graph_search: a graph whose level 0 lives in device memory needs the device traversal "
+                                                "(shape unsupported by it, or JV_TRAVERSAL_HOST was requested)");
+        JV_REQUIRE(!fused, "graph_search: FusedPQ blocks cannot be checked against a device-resident, mutable adjacency; search it with the code store");
     }
     if (mode != JV_TRAVERSAL_DEVICE || Q == 0)
         return graph_search_host(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats, host_accept);

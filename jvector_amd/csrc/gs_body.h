@@ -274,7 +274,7 @@ GS_FN const int32_t *gs_level_row(const GsLevel &L, int32_t node)
 struct GsState {
     long long *cand, *res, *evicted, *samp;  // LDS
     long long *spill;                        // global
-    int cand_n, spill_n, res_n, ev_n, res_min_idx;
+    int cand_n, spill_n, res_n, ev_n, res_min_idx, spill_cap;
     long long spill_max, res_min;
     int32_t status;
 };
@@ -301,13 +301,13 @@ GS_FN void gs_partition(GsState &s, const GsParams &p)
         if (hi) s.cand[new_n + gs_popc(mh & lt)] = k;          // in place: target index <= i
         if (lo) {
             const int pos = s.spill_n + moved + gs_popc(ml & lt);
-            if (pos < p.spill_cap) s.spill[pos] = k;
+            if (pos < s.spill_cap) s.spill[pos] = k;
         }
         new_n += gs_popc(mh);
         moved += gs_popc(ml);
         gs_barrier();
     }
-    if (s.spill_n + moved > p.spill_cap) s.status = GS_OVERFLOW;
+    if (s.spill_n + moved > s.spill_cap) s.status = GS_OVERFLOW;
     s.spill_n += moved;
     s.cand_n = new_n;
     s.spill_max = pivot;  // the pivot itself moved, everything that stayed is larger
@@ -332,7 +332,7 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
     const bool to_sp = has && !to_lds;
     const uint64_t ms = gs_ballot(to_sp);
     if (ms) {
-        if (s.spill_n + gs_popc(ms) > p.spill_cap) {
+        if (s.spill_n + gs_popc(ms) > s.spill_cap) {
             s.status = GS_OVERFLOW;
             return;
         }
@@ -370,19 +370,61 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     s.res = reinterpret_cast<long long *>(lds + sizeof(float) * (size_t)p.D);
     s.cand = s.res + p.rerankK;
     s.evicted = s.cand + p.cand_cap;
-    s.samp = s.evicted + GS_EVICT_CAP;
-    float *xchg = reinterpret_cast<float *>(s.samp + 64);  // [M/2][32] entries handed from high to low lanes (PAIR only)
+    const int evict_cap = p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP;
+    // PAIR: [M/2][32] entries handed from high to low lanes; the partition step's 64-key sample buffer lives in the same
+    // bytes (it is only touched inside gs_push, after every lane has consumed the exchange area)
+    float *xchg = reinterpret_cast<float *>(s.evicted + evict_cap);
+    s.samp = s.evicted + evict_cap;
     (void)xchg;
     s.spill = p.spill + (int64_t)worker * p.spill_cap;
+    s.spill_cap = p.spill_cap;
     s.cand_n = s.spill_n = s.res_n = s.ev_n = 0;
     s.res_min_idx = -1;
     s.spill_max = GS_KEY_MIN;
     s.res_min = GS_KEY_MAX;
     s.status = GS_OK;
-    const int vcap = 1 << p.vcap_log2;
-    const uint32_t vmask = (uint32_t)vcap - 1u;
-    const int vshift = 32 - p.vcap_log2;
+    int vcap = 1 << p.vcap_log2;
+    uint32_t vmask = (uint32_t)vcap - 1u;
+    int vshift = 32 - p.vcap_log2;
     int32_t *vis = p.visited + (int64_t)worker * vcap;
+    bool grown = false;
+    // The visited table is half full: move to a table of the growth pool (once per query), or give up with GS_OVERFLOW.
+    // Wave-uniform.  The old table is read back with atomics (a CAS that can never succeed), like every other access to it.
+    auto grow = [&]() -> bool {
+        if (grown || !p.big_visited) return false;
+        long long sv = 0;
+        if (lane == 0) sv = (long long)gs_fetch_add(p.big_next, 1u);
+        const long long slot = gs_shfl(sv, 0);
+        if (slot >= p.big_count) return false;
+        const int bcap = 1 << p.big_log2;
+        int32_t *nvis = p.big_visited + slot * (long long)bcap;
+        {
+            gs_u4 *v4 = reinterpret_cast<gs_u4 *>(nvis);
+            const gs_u4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            for (int i = lane; i < bcap / 4; i += 64) v4[i] = ones;
+        }
+        gs_fence();
+        gs_barrier();
+        const uint32_t bmask = (uint32_t)bcap - 1u;
+        const int bshift = 32 - p.big_log2;
+        for (int i = lane; i < vcap; i += 64) {
+            const int32_t v = gs_cas(vis + i, -2, -2);
+            if (v >= 0) (void)gs_visit(nvis, bmask, bshift, v);
+        }
+        long long *nspill = p.big_spill + slot * (long long)p.big_spill_cap;
+        gs_fence();
+        for (int i = lane; i < s.spill_n; i += 64) nspill[i] = s.spill[i];
+        gs_fence();
+        gs_barrier();
+        vis = nvis;
+        vcap = bcap;
+        vmask = bmask;
+        vshift = bshift;
+        s.spill = nspill;
+        s.spill_cap = p.big_spill_cap;
+        grown = true;
+        return true;
+    };
     long long n_visited = 0, n_expanded = 0;
 
     // ---- per-query setup: clear the visited table, stage the centred query ----
@@ -460,7 +502,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 gs_barrier();
             } else if (top_score > gs_key_score(s.res_min)) {
                 if (lvl > 0) {
-                    if (s.ev_n >= GS_EVICT_CAP) {
+                    if (s.ev_n >= evict_cap) {
                         s.status = GS_OVERFLOW;
                         break;
                     }
@@ -507,7 +549,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 const uint64_t fm = gs_ballot(fresh);
                 if (fm == 0) continue;
                 n_visited += gs_popc(fm);
-                if ((n_visited + 1) * 2 > vcap) {
+                if ((n_visited + 1) * 2 > vcap && !((n_visited + 1) * 2 <= (1ll << p.big_log2) && grow())) {
                     s.status = GS_OVERFLOW;
                     break;
                 }
@@ -541,7 +583,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 const uint64_t fm = gs_ballot(fresh);
                 if (fm == 0) continue;
                 n_visited += gs_popc(fm);
-                if ((n_visited + 1) * 2 > vcap) {
+                if ((n_visited + 1) * 2 > vcap && !((n_visited + 1) * 2 <= (1ll << p.big_log2) && grow())) {
                     s.status = GS_OVERFLOW;
                     break;
                 }

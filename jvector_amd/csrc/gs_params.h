@@ -42,7 +42,14 @@ struct GsParams {
     int32_t vcap_log2;
     long long *spill;         // [workers][spill_cap]
     int32_t spill_cap;
+    // growth pool: a query whose visited table reaches half full claims one of big_count roomier tables (+ spill tier),
+    // re-inserts its visited set there and carries on; pool empty -> GS_OVERFLOW as before.  nullptr = no pool.
+    int32_t *big_visited;     // [big_count][1 << big_log2], claimed tables are cleared by their claimant
+    long long *big_spill;     // [big_count][big_spill_cap]
+    uint32_t *big_next;       // claim counter (zeroed by the host before the launch)
+    int32_t big_count, big_log2, big_spill_cap;
     int32_t cand_cap;         // LDS tier capacity (>= 256)
+    int32_t evict_cap;        // capacity of the upper-layer evicted list in LDS (0 = GS_EVICT_CAP)
     int32_t pair;             // 1: pair-lane scoring (every degree <= 32; LDS has the M/2 x 32 exchange area)
     // outputs
     int32_t *out_ids;         // [Q][rerankK] kept approximate results (unordered), -1 padded
@@ -54,9 +61,11 @@ struct GsParams {
 };
 
 // LDS bytes one worker needs
-inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M when pair-lane scoring is on, else 0 */)
+inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M when pair-lane scoring is on, else 0 */,
+                           int evict_cap = GS_EVICT_CAP)
 {
-    return sizeof(float) * (size_t)D + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + GS_EVICT_CAP + 64) +
+    // (the 64-key sample buffer of the partition step shares the pair-lane exchange area when there is one)
+    return sizeof(float) * (size_t)D + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + (size_t)evict_cap + (pair_M ? 0 : 64)) +
            sizeof(float) * 32 * (size_t)(pair_M / 2);
 }
 

@@ -77,7 +77,7 @@ struct jv_ctx {
     // staging: host->device inputs, device->host outputs (pinned), device scratch
     jv::Buffer h_in, h_out, d_in, d_out, d_scratch, d_scratch2, d_scratch3;
     // device-resident graph traversal: per-worker visited tables / spill tiers and the per-query result staging
-    jv::Buffer d_gs_visited, d_gs_spill, d_gs_out, d_gs_mask;
+    jv::Buffer d_gs_visited, d_gs_spill, d_gs_out, d_gs_mask, d_gs_big;
     // host batched graph searcher: worker pool (graph_search.cpp owns the type) and its destructor
     void *host_pool = nullptr;
     void (*host_pool_destroy)(void *) = nullptr;
@@ -275,7 +275,7 @@ struct GsParams;
 // tables (jv_hip_luts_build = with_tables true).  The table-free traversal kernels pass false: 96 KB per query saved.
 int luts_prepare(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_vsf vsf, jv_decoder_kind kind, bool with_tables);
 bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels);
-size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M);
+size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap = 0);
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy);
 size_t topk_scratch_bytes(int Q, int k);
 int launch_topk(hipStream_t s, const jv_ctx *ctx, const float *d_scores, const int32_t *d_ids, int Q, int64_t n,

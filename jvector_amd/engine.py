@@ -611,6 +611,26 @@ class GraphIndex:
                                                    nb.shape[1]))
         check(self._lib.jv_hip_graph_set_entry(h, int(entry_node), int(entry_level)))
 
+    @classmethod
+    def on_device(cls, ctx, neighbors, entry_node):
+        """Single-level graph whose adjacency [n_nodes, degree] int32 (-1 padded) lives in caller-owned DEVICE memory (a
+        torch.cuda tensor) and is read in place by the device traversal — the owner may rewrite rows between searches
+        (jvector_amd.builder uses this to search the graph it is building)."""
+        self = cls.__new__(cls)
+        self.ctx, self._lib = ctx, ctx._lib
+        n, deg = int(neighbors.shape[0]), int(neighbors.shape[1])
+        h = C.c_void_p()
+        check(self._lib.jv_hip_graph_create(ctx._h, n, 1, C.byref(h)))
+        self._h, self.n_nodes, self.max_degree = h, n, deg
+        p, self._keep = _ptr(neighbors, np.int32)
+        check(self._lib.jv_hip_graph_set_level0_device(ctx._h, h, p, deg))
+        check(self._lib.jv_hip_graph_set_entry(h, int(entry_node), 0))
+        return self
+
+    def set_entry(self, node, level=0):
+        check(self._lib.jv_hip_graph_set_entry(self._h, int(node), int(level)))
+        return self
+
     TRAVERSAL = {"auto": 0, "host": 1, "device": 2}
 
     def set_traversal(self, mode: str):

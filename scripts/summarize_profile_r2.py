@@ -29,13 +29,23 @@ def rows_of(name):
     return list(csv.DictReader(open(p))) if os.path.exists(p) else []
 
 
+def dur_ms(r):
+    return (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+
+
 def steady(rows, kern):
-    """dispatches of `kern` with the benched launch shape: the largest grid, and within it the longest-duration cluster"""
+    """dispatches of `kern` with the benched launch shape: the largest grid, and within it the longest-duration cluster
+    (>= 70 % of the longest launch: the timed 65536-query batches, not the shorter calibration / evaluation / retry launches)"""
     d = [r for r in rows if kern in r["Kernel_Name"]]
     if not d:
         return []
     g = max(int(r["Grid_Size"]) for r in d)
-    return [r for r in d if int(r["Grid_Size"]) == g]
+    d = [r for r in d if int(r["Grid_Size"]) == g]
+    names = {r["Counter_Name"] for r in d}
+    one = [r for r in d if r["Counter_Name"] == sorted(names)[0]]
+    top = max(dur_ms(r) for r in one)
+    keep = {r["Dispatch_Id"] for r in one if dur_ms(r) >= 0.7 * top}
+    return [r for r in d if r["Dispatch_Id"] in keep]
 
 
 def write_pmc(rows, out):
@@ -69,7 +79,8 @@ for key, kern in KEYS.items():
     if tr:
         gs = lambda r: int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])  # noqa: E731
         g = max(gs(r) for r in tr)
-        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr if gs(r) == g]
+        dur = [dur_ms(r) for r in tr if gs(r) == g]
+        dur = [x for x in dur if x >= 0.7 * max(dur)]
         e["rocprof_avg_ms"], e["rocprof_launches"] = statistics.mean(dur), len(dur)
     def ctr(table, name):
         v = [float(r["Counter_Value"]) for r in steady(pmc[table], kern) if r["Counter_Name"] == name]

@@ -23,6 +23,19 @@ long mock_hip_live_device_allocations()
     return (long)g_dev.size();
 }
 
+// test hook: treat a caller-owned buffer (numpy / torch CPU memory) as device memory, e.g. a mutable adjacency handed to
+// jv_hip_graph_set_level0_device
+void mock_hip_register_device(const void *p)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_dev.insert(p);
+}
+void mock_hip_unregister_device(const void *p)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_dev.erase(p);
+}
+
 hipError_t hipGetDeviceCount(int *n)
 {
     *n = 1;

@@ -1,0 +1,100 @@
+"""Batched Vamana construction (jvector_amd/builder.py: BASELINE config 5) — the engine searches the graph it is building
+(device traversal over a device-resident, mutable adjacency), prunes with jv_hip_retain_diverse and backlinks with the PQ
+diversity scores.  The reference's builder is concurrent and nondeterministic, so there is nothing to be bit-identical WITH;
+what is checked is the contract a Vamana graph has to meet: degrees within maxDegree, no self loops / duplicates / dangling
+ids, every node reachable from the entry point, and — the point of the exercise — a search over the built graph finds the
+true nearest neighbours (recall against brute force), while every call it is made of is separately parity-tested."""
+import ctypes as C
+import os
+import platform
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "mock"))
+
+from oracle import oracle as O
+
+
+def _data(N, D, seed):
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((40, D)).astype(np.float32)
+    v = (centers[rng.integers(0, 40, N)] + 0.6 * rng.standard_normal((N, D))).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    q = (v[rng.integers(0, N, 64)] + 0.1 * rng.standard_normal((64, D))).astype(np.float32)
+    return v, q
+
+
+def check_builder(J, ctx, dev, N, D, M, max_degree, beam, register=None, min_recall=0.85):
+    from jvector_amd.builder import build_vamana
+    VSF = J.VectorSimilarityFunction.COSINE
+    v, q = _data(N, D, 3)
+    tv = torch.from_numpy(v).to(dev)
+    pq = J.ProductQuantization.compute(ctx, tv, M, seed=2)
+    vs = J.VectorSet(ctx, tv)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    out = torch.empty((N, max_degree), dtype=torch.int32, device=dev)
+    if register:
+        register(out.data_ptr())
+    nbrs, entry, stats = build_vamana(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, alpha=1.2, max_batch=2048, out=out)
+    nb = nbrs.cpu().numpy().copy()        # (on the mock the "device" tensor is host memory: detach the view)
+    # ---- structural contract ----
+    assert nb.shape == (N, max_degree) and nb.min() >= -1 and nb.max() < N
+    deg = (nb >= 0).sum(axis=1)
+    assert deg.min() >= 1 and deg.max() <= max_degree and stats["avg_degree"] > max_degree / 4
+    for i in range(0, N, max(1, N // 200)):
+        row = nb[i][nb[i] >= 0]
+        assert i not in row and len(set(row.tolist())) == len(row)
+        assert (nb[i][:len(row)] >= 0).all()                                    # packed rows: -1 only at the end
+    seen = np.zeros(N, bool)
+    seen[entry] = True
+    frontier = [entry]
+    while frontier:
+        nxt = nb[frontier].reshape(-1)
+        nxt = np.unique(nxt[nxt >= 0])
+        nxt = nxt[~seen[nxt]]
+        seen[nxt] = True
+        frontier = nxt.tolist()
+    assert seen.mean() > 0.995, seen.mean()                                        # (almost) everything reachable from the entry
+    # ---- the graph serves searches: recall@10 against brute force, through the ordinary (host-adjacency) GraphIndex ----
+    graph = J.GraphIndex(ctx, N, [(None, nb)], entry, 0)
+    s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
+    ids, _ = s.search(q, VSF, 10, 4 * beam)
+    gt = np.argsort(-(q @ v.T), axis=1)[:, :10]
+    recall = np.mean([len(set(a.tolist()) & set(b.tolist())) / 10.0 for a, b in zip(np.asarray(ids), gt)])
+    assert recall >= min_recall, recall
+    return stats, recall
+
+
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+def test_builder_on_the_mock():
+    import build_mock
+    import jvector_amd
+    import jvector_amd._lib as L
+    lib = C.CDLL(build_mock.build())
+    for table in (L.SIGNATURES, L.COMPAT_SIGNATURES, L.FORMAT_SIGNATURES):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    saved, L._lib = L._lib, lib
+    os.environ["JVECTOR_HIP_HOST_THREADS"] = "1"
+    try:
+        ctx = jvector_amd.HipContext(0)
+        lib.mock_hip_register_device.argtypes = [C.c_void_p]
+        check_builder(jvector_amd, ctx, torch.device("cpu"), 700, 128, 16, 16, 24, register=lambda p: lib.mock_hip_register_device(C.c_void_p(p)))
+        ctx.close()
+    finally:
+        L._lib = saved
+        os.environ.pop("JVECTOR_HIP_HOST_THREADS", None)
+
+
+@pytest.mark.gpu
+def test_builder_gpu():
+    import jvector_amd as J
+    ctx = J.HipContext(0)
+    stats, recall = check_builder(J, ctx, torch.device("cuda", 0), 30000, 128, 16, 32, 100, min_recall=0.9)
+    print("builder:", dict(stats), "recall@10", recall)
+    ctx.close()

@@ -153,6 +153,14 @@ def test_device_traversal_overflow_falls_back_to_the_host(J, ctx, monkeypatch, c
     assert np.array_equal(stats, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
 
 
+def test_device_traversal_retry_and_growth_paths(J, ctx, monkeypatch, capfd):
+    """the two in-device answers to an outgrown visited table, driven on the mock: the retry pass with 8x / 64x tables and
+    the growth pool inside the kernel (the emulated kernel body does the re-insertion and the spill hand-over)"""
+    import test_zz_device_traversal_gpu as T
+    T.test_overflowed_queries_are_retried_on_the_device(ctx, monkeypatch, capfd)
+    T.test_visited_table_grows_inside_the_kernel(ctx, monkeypatch, capfd)
+
+
 def test_device_traversal_refuses_unsupported_shapes(J, ctx):
     import test_zz_device_traversal_gpu as T
     T.test_unsupported_shape_is_refused(ctx)

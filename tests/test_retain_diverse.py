@@ -131,8 +131,8 @@ def test_retain_diverse_gpu():
     import jvector_amd as J
     ctx = J.HipContext(0)
     run_through_cabi(J, ctx, CASES + [(5, 3000, 768, 96, 64, 100, 32, 1.2), (6, 1500, 1536, 192, 32, 100, 32, 1.2)])
-    # unsupported: candidate codes that do not fit LDS are refused, not truncated
-    opq, codes, tri, cand, sc, count, before = make_case(77, 900, 1536, 192, 2, 400, 0, 32)
+    # unsupported: candidate codes that do not fit LDS (1000 x 192 B > 160 KB) are refused, not truncated
+    opq, codes, tri, cand, sc, count, before = make_case(77, 1200, 1536, 192, 2, 1000, 0, 32)
     pq = J.ProductQuantization.from_codebooks(ctx, 1536, 192, opq.codebooks)
     bsp = J.PQBuildScoreProvider(ctx, J.PQVectors(ctx, pq, codes), J.VectorSimilarityFunction.EUCLIDEAN)
     with pytest.raises(J.UnsupportedError):

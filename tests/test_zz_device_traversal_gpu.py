@@ -89,6 +89,28 @@ def test_overflowed_queries_are_retried_on_the_device(ctx, monkeypatch, capfd):
     assert first > 0 and host == 0, line
 
 
+def test_visited_table_grows_inside_the_kernel(ctx, monkeypatch, capfd):
+    """a 512-slot base table with the growth pool on: queries that fill it half move to an 8x table inside the kernel
+    (re-inserting their visited set, carrying the spill tier over) and finish in the first launch — no retry pass, no host
+    fallback, same ids / scores / counters as the oracle; queries that outgrow even that are retried as before"""
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 13, 5000, 128, 16, 2, True)
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+    monkeypatch.setenv("JVECTOR_HIP_GS_VCAP_LOG2", "9")
+    monkeypatch.setenv("JVECTOR_HIP_GS_GROW", "1")
+    monkeypatch.setenv("JVECTOR_HIP_GS_CAND_CAP", "256")
+    monkeypatch.setenv("JVECTOR_HIP_GRAPH_TIMING", "1")
+    for rk, expect_clean in ((100, True), (600, False)):
+        ids, sc, st = s.search(q, VSF.COSINE, 10, rk, return_stats=True)
+        err = capfd.readouterr().err
+        wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, rk, fused=True)
+        assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), rk
+        assert (wst[:, 0] * 2 > 512).any()                        # the base table really was too small for some queries
+        line = [x for x in err.splitlines() if "graph_search device" in x][-1]
+        first = int(line.split("overflow=")[1].split()[0])
+        assert (first == 0) == expect_clean, line
+
+
 def test_unsupported_shape_is_refused(ctx):
     v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 9, 2000, 64, 8, 1, False)  # M = 8
     s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
