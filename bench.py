@@ -317,12 +317,73 @@ def run_c2(args, ctx, J, dev, world, rank, barrier):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# C5: index build — PQ training + encode + batched Vamana construction with the engine's scoring, N x 1536, PQ-192
+# ------------------------------------------------------------------------------------------------------------------
+def run_c5(args, ctx, J, dev, world, rank, barrier):
+    from jvector_amd.builder import build_vamana
+    VSF = J.VectorSimilarityFunction.COSINE
+    N, D, M, K = (args.n if args.n != 10_000_000 else 1_000_000), 1536, 192, args.topk
+    mix = Mixture(D, seed=7, device=dev)
+    base = mix.sample(N, seed=7 + 1000 * rank)
+    eval_q = mix.sample(min(args.eval_queries, 4096), seed=9)
+    g = torch.Generator(device=dev).manual_seed(4)
+    sample = base[torch.randperm(N, generator=g, device=dev)[:min(128_000, N)]].contiguous()
+    barrier()
+    t_all = time.perf_counter()
+    t0 = time.perf_counter()
+    pq = J.ProductQuantization.compute(ctx, sample, M, seed=4)
+    ctx.sync()
+    train_s = time.perf_counter() - t0
+    vs = J.VectorSet(ctx, base)
+    t0 = time.perf_counter()
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    ctx.sync()
+    encode_s = time.perf_counter() - t0
+    nbrs, entry, bstats = build_vamana(ctx, pq, cv, base, VSF, max_degree=args.degree, beam_width=100, alpha=1.2, log=log)
+    barrier()
+    total_s = time.perf_counter() - t_all
+    if world > 1:
+        t = torch.tensor([total_s], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        total_s = float(t.item())
+    # quality of what was built: recall@10 of a search over it (graph + exact rerank) against brute force
+    gt = ground_truth(J, ctx, vs, eval_q, VSF, K, dense=True).cpu().numpy()
+    graph = J.GraphIndex(ctx, N, [(None, nbrs.cpu().numpy())], entry, 0)
+    fused = J.FusedPQ.build(ctx, cv, nbrs)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=int(eval_q.shape[0]))
+    rec = {}
+    for rk in (50, 100, 200):
+        ids = s.search(eval_q, VSF, K, rk)[0]
+        ctx.sync()
+        rec[rk] = float(recall_per_query(ids.cpu().numpy(), gt).mean())
+    if rank != 0:
+        return None
+    return {"metric": "index build: nodes/s (batched Vamana, PQ-192 scoring) incl. PQ training + encode", "value": N * world / total_s,
+            "unit": "nodes/s", "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": total_s * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE C5: synthetic {N}x{D} cosine mixture, PQ-{M} trained + encoded by the engine, batched Vamana "
+                                   f"construction (maxDegree {args.degree}, beamWidth 100, alpha 1.2, prefix-doubling batches): candidates "
+                                   "from the engine's device-resident graph search over the partial graph, robust prune = "
+                                   "jv_hip_retain_diverse, backlink re-prune with PQ diversity scores", "n_vectors": N, "dim": D,
+                       "pq_subspaces": M, "max_degree": args.degree, "parallelism": "1 GPU" if world == 1 else f"{world} independent builds"},
+            "seconds": {"pq_train": train_s, "encode": encode_s, "search": bstats["search_s"], "prune": bstats["prune_s"],
+                        "backlink": bstats["backlink_s"], "total": total_s},
+            "build": {"batches": bstats["batches"], "reprunes": bstats["reprunes"], "avg_degree": bstats["avg_degree"]},
+            "recall_at_10_by_rerankK": rec, "recall_eval_queries": int(eval_q.shape[0]),
+            "roofline": None, "cpu_baseline": None}
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["c3", "c2"], default="c3", help="c3 = the headline 10Mx768 config; c2 = SIFT1M-like")
+    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3", help="c3 = the headline 10Mx768 config; c2 = SIFT1M-like; "
+                    "c5 = index build (batched Vamana with the engine's scoring) on Nx1536, PQ-192")
+    ap.add_argument("--graph", choices=["engine", "synthetic"], default="engine", help="c3 graph: jvector_amd.builder.build_vamana — "
+                    "batched Vamana construction with the engine's own search / robust-prune / backlink scoring (default; BASELINE "
+                    "config 5's path) — or benchgraph.py's synthetic kNN+prune graph (round 1's input preparation)")
     ap.add_argument("--mode", choices=["auto", "graph", "flat"], default="auto", help="auto = graph")
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
@@ -364,8 +425,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if args.workload == "c2":
-        line = run_c2(args, ctx, J, dev, world, rank, barrier)
+    if args.workload in ("c2", "c5"):
+        line = (run_c2 if args.workload == "c2" else run_c5)(args, ctx, J, dev, world, rank, barrier)
         if rank == 0:
             print(json.dumps(line))
         if world > 1:
@@ -421,7 +482,7 @@ def main():
     if not codes_t.is_cuda:  # host tensors are copied, not wrapped (CPU dry run of this script against the mock device)
         codes_t.copy_(torch.from_numpy(cv.get(0, N)))
 
-    build_s, levels = None, None
+    build_s, levels, build_info = None, None, None
     if graph_mode:
         tb = time.perf_counter()
         if cache is not None:
@@ -429,6 +490,20 @@ def main():
             levels = [(None if l == 0 else cache[f"nodes{l}"], cache[f"nbrs{l}"]) for l in range(n_lv)]
             entry, entry_level = int(cache["entry"]), int(cache["entry_level"])
             nbrs_dev = torch.from_numpy(levels[0][1]).to(dev)
+        elif args.graph == "engine":
+            from jvector_amd.builder import build_hierarchical
+            levels, entry, entry_level, nbrs_dev, bstats = build_hierarchical(ctx, pq, cv, base, VSF, max_degree=args.degree,
+                                                                                beam_width=100, alpha=1.2, log=log)
+            log(f"[build] {dict(bstats)}")
+            build_info = {k: (float(v) if isinstance(v, float) else v) for k, v in dict(bstats).items()}
+            if args.index_cache and rank == 0:
+                arrs = {"n": N, "dim": D, "m": M, "degree": args.degree, "n_levels": len(levels), "entry": entry,
+                        "entry_level": entry_level, "pq_bytes": np.frombuffer(pq.write(6), dtype=np.uint8)}
+                for l, (nodes, nb) in enumerate(levels):
+                    arrs[f"nbrs{l}"] = nb
+                    if l > 0:
+                        arrs[f"nodes{l}"] = nodes
+                np.savez(args.index_cache, **arrs)
         else:
             levels, entry, entry_level, nbrs_dev = build_hier_graph(base, max_degree=args.degree)
             if args.index_cache and rank == 0:
@@ -459,7 +534,7 @@ def main():
     eval_gt = ground_truth(J, ctx, vs, eval_q, VSF, K, dense=not args.gt_exact).cpu().numpy()
     gt_s = time.perf_counter() - t0
 
-    ladder = [args.rerank] if args.rerank > 0 else [50, 75, 100, 125, 150, 175, 200, 250, 300, 400, 600, 800, 1600]
+    ladder = [args.rerank] if args.rerank > 0 else [20, 30, 40, 50, 60, 75, 90, 100, 110, 125, 150, 175, 200, 250, 300, 400, 600, 800, 1600]
     rerank_k, cal_rec = calibrate(run, ctx, ladder, cal_q, cal_gt, Q, f"mode={args.mode}")
     if world > 1:  # every rank serves with the same (largest calibrated) rerankK
         t_rk = torch.tensor([rerank_k], dtype=torch.int64, device=dev)
@@ -588,7 +663,9 @@ def main():
             "config": {"workload": (f"synthetic {N}x{D} cosine (latent-32 mixture of 1000 clusters, unit norm), PQ-{M} (k=256, " +
                                     ("torch Lloyd x6" if args.torch_codebooks else "engine ProductQuantization.compute: k-means++ + Lloyd x6") +
                                     " on a 128k sample), " +
-                                    (f"FusedADC graph search: synthetic kNN+robust-prune graph (maxDegree {args.degree}, {len(levels)} nested levels), "
+                                    (f"FusedADC graph search: " + (f"layered Vamana graph built by the engine's batched builder (PQ scoring, beamWidth 100, alpha 1.2, neighborOverflow 1.25; maxDegree {args.degree}, {len(levels)} levels of N/{args.degree}^l nodes), "
+                                                                   if args.graph == "engine" else
+                                                                   f"synthetic kNN+robust-prune graph (maxDegree {args.degree}, {len(levels)} nested levels), ") +
                                      f"{'device-resident GraphSearcher (one wavefront per query)' if args.traversal == 'device' else 'host batched GraphSearcher, GPU fused-block scoring'}, rerankK {rerank_k} -> exact rerank -> top-{K}"
                                      if graph_mode else
                                      f"two-pass flat search: ADC scan of all codes -> top-{rerank_k} -> exact rerank -> top-{K}")),
@@ -602,6 +679,7 @@ def main():
             "kernel_fraction_of_step": sum(prof[r][0] for r in prof) / (elapsed * 1e3) if world == 1 else None,
             "encode": {"vectors_per_s": N / (enc_ms / 1e3) if enc_ms > 0 else None, "ms": enc_ms},
             "pq_train_s": train_s, "ground_truth_s": gt_s, "setup_s": setup_s, "graph_build_s": build_s,
+            "graph": args.graph, "graph_build": build_info,
         }
         line.update(extra_roof)
         if graph_mode:

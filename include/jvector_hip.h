@@ -288,6 +288,10 @@ typedef struct jv_graph jv_graph;
 JV_API int jv_hip_graph_create(jv_ctx *ctx, int64_t n_nodes, int n_levels, jv_graph **out);
 JV_API int jv_hip_graph_set_level(jv_ctx *ctx, jv_graph *g, int level, int count, const int32_t *node_ids,
                                   const int32_t *neighbors, int degree);
+/* Raw device memory for callers that have no allocator of their own (a Java host; torch users pass their tensors instead):
+ * e.g. the mutable adjacency of jv_hip_graph_set_level0_device.  Freed with jv_hip_device_free. */
+JV_API int jv_hip_device_alloc(jv_ctx *ctx, size_t bytes, void **out);
+JV_API int jv_hip_device_free(jv_ctx *ctx, void *ptr);
 /* Level 0 in CALLER-owned device memory: n_nodes x degree int32, packed rows padded with -1, read in place by the device
  * traversal on every search — the owner may rewrite rows between searches (incremental construction: search the partial
  * graph, prune, write the new rows, search again).  No host copy is kept, so such a graph is searched by the device

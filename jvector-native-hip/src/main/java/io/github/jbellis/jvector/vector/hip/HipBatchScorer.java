@@ -145,6 +145,11 @@ public final class HipBatchScorer implements AutoCloseable {
     public void close() {
         if (!pairTable.equals(MemorySegment.NULL)) HipOps.pairTableDestroy(pairTable);
         if (!graph.equals(MemorySegment.NULL)) HipOps.graphDestroy(graph);
+        if (!fused.equals(MemorySegment.NULL)) HipOps.fusedDestroy(fused);
+        if (!vectors.equals(MemorySegment.NULL)) HipOps.vectorsDestroy(vectors);
+        if (luts != null) HipOps.lutsDestroy(luts);
+        if (codes != null) HipOps.codesDestroy(codes);
+        if (pq != null) HipOps.pqDestroy(pq);
         HipOps.ctxDestroy(ctx);
         arena.close();
     }

@@ -78,6 +78,7 @@ public final class HipOps {
         static final MethodHandle adcScan = h("jv_hip_adc_scan", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));
         static final MethodHandle fusedCreate = h("jv_hip_fused_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_INT, ADDRESS));
         static final MethodHandle fusedUpload = h("jv_hip_fused_upload", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS, ADDRESS));
+        static final MethodHandle fusedDestroy = h("jv_hip_fused_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
         static final MethodHandle fusedBuild = h("jv_hip_fused_build", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS));
         static final MethodHandle fusedScores = h("jv_hip_fused_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle exactScores = h("jv_hip_exact_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
@@ -106,6 +107,11 @@ public final class HipOps {
         static final MethodHandle pqvectorsDescribe = h("jv_fmt_pqvectors_describe", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle graphSearchFiltered = h("jv_hip_graph_search_filtered", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle searchFlat = h("jv_hip_search_flat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+        // construction: batched robust prune, caller-owned mutable adjacency
+        static final MethodHandle retainDiverse = h("jv_hip_retain_diverse", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_FLOAT, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle deviceAlloc = h("jv_hip_device_alloc", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS));
+        static final MethodHandle deviceFree = h("jv_hip_device_free", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle graphSetLevel0Device = h("jv_hip_graph_set_level0_device", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT));
         // sharded index: one rank (thread + context) per GPU, RCCL inside the library
         static final MethodHandle commUniqueId = h("jv_hip_comm_unique_id", FunctionDescriptor.of(JAVA_INT, ADDRESS));
         static final MethodHandle commCreate = h("jv_hip_comm_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS));
@@ -256,6 +262,8 @@ public final class HipOps {
         check(st(() -> (int) H.fusedBuild.invokeExact(ctx, fused, codes, first, count, neighbors)));
     }
 
+    public static void fusedDestroy(MemorySegment fused) { check(st(() -> (int) H.fusedDestroy.invokeExact(fused))); }
+
     /** NodeQueue-order top-k (NodeQueue.java:125-129): ids may be NULL (id = idBase + column). */
     public static void topk(MemorySegment ctx, MemorySegment scores, MemorySegment idsOrNull, int q, long n, long stride, int idBase, int k,
                             MemorySegment outIds, MemorySegment outScores) {
@@ -295,6 +303,24 @@ public final class HipOps {
     /** diversityFunctionFor(node1).similarityTo(node2) for P x B candidate x selected blocks */
     public static void codePairScores(MemorySegment ctx, MemorySegment table, MemorySegment codes, MemorySegment node1, int p, MemorySegment node2, int b, MemorySegment out) {
         check(st(() -> (int) H.codePairScores.invokeExact(ctx, table, codes, node1, p, node2, b, out)));
+    }
+
+    /** VamanaDiversityProvider.retainDiverse for P NodeArrays at once (candidates sorted by score descending per row);
+     *  selectedOut: P x maxDegree candidate indices ascending, -1 padded — the set bits of the reference's BitSet. */
+    public static void retainDiverse(MemorySegment ctx, MemorySegment table, MemorySegment codes, int p, int c, MemorySegment candNodes,
+                                     MemorySegment candScores, MemorySegment candCountOrNull, MemorySegment diverseBeforeOrNull, int maxDegree,
+                                     float alpha, MemorySegment selectedOut, MemorySegment nSelectedOut, MemorySegment shortEdgesOutOrNull) {
+        check(st(() -> (int) H.retainDiverse.invokeExact(ctx, table, codes, p, c, candNodes, candScores, candCountOrNull, diverseBeforeOrNull,
+                                                         maxDegree, alpha, selectedOut, nSelectedOut, shortEdgesOutOrNull)));
+    }
+    /** raw device memory (e.g. the mutable adjacency of graphSetLevel0Device); a zero-length segment carrying the device address */
+    public static MemorySegment deviceAlloc(Arena arena, MemorySegment ctx, long bytes) {
+        return outHandle(arena, out -> st(() -> (int) H.deviceAlloc.invokeExact(ctx, bytes, out)));
+    }
+    public static void deviceFree(MemorySegment ctx, MemorySegment ptr) { check(st(() -> (int) H.deviceFree.invokeExact(ctx, ptr))); }
+    /** level 0 read in place from caller-owned device memory: the graph a builder is still writing can be searched */
+    public static void graphSetLevel0Device(MemorySegment ctx, MemorySegment graph, MemorySegment deviceNeighbors, int degree) {
+        check(st(() -> (int) H.graphSetLevel0Device.invokeExact(ctx, graph, deviceNeighbors, degree)));
     }
 
     // sharded index

@@ -43,16 +43,35 @@ def _sync(ctx, t):
 
 
 def build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=100, alpha=1.2, max_batch=131072, seed=11,
-                 search_batch=65536, log=None, out=None):
-    """vectors: [N, D] float32 torch tensor on the engine's device (the insert queries); pq_vectors: their PQ codes (PQVectors).
-    out: optional preallocated [N, max_degree] int32 tensor for the adjacency.
+                 search_batch=65536, log=None, out=None, overflow=1.25):
+    """One graph level.  vectors: [N, D] float32 torch tensor on the engine's device (the insert queries); pq_vectors: their PQ
+    codes (PQVectors).  out: optional preallocated [N, W] int32 tensor for the working adjacency, W = floor(overflow *
+    max_degree): like the reference's ConcurrentNeighborMap (neighborOverflow 1.2, :298-322) a neighbour list may run over
+    max_degree by that factor before a backlink forces a re-prune; a final pass prunes every list back to max_degree.
     Returns (neighbors [N, max_degree] int32 device tensor, -1 padded; entry_node; BuildStats)."""
     dev = vectors.device
     N = int(vectors.shape[0])
-    R = int(max_degree)
+    Rf = int(max_degree)                                   # final degree
+    R = max(Rf, min(64, int(Rf * overflow)))               # working width
     g = torch.Generator(device="cpu").manual_seed(seed)
     perm = torch.randperm(N, generator=g).to(dev)
-    nbrs = out if out is not None else torch.empty((N, R), dtype=torch.int32, device=dev)
+    owned = None
+    if out is not None:
+        nbrs = out
+        R = int(out.shape[1])
+        if R < Rf or R > 64:
+            raise ValueError(f"out has {R} columns; need max_degree {Rf} <= columns <= 64")
+    elif vectors.is_cuda:
+        nbrs = torch.empty((N, R), dtype=torch.int32, device=dev)
+    else:
+        # no CUDA tensors (the CPU dry run against the mock device): the adjacency must still be memory the library classifies
+        # as device memory -> allocate it through the C ABI and view it as a tensor
+        import ctypes as C
+        from ._lib import check
+        ptr = C.c_void_p()
+        check(ctx._lib.jv_hip_device_alloc(ctx._h, N * R * 4, C.byref(ptr)))
+        owned = ptr
+        nbrs = torch.frombuffer((C.c_byte * (N * R * 4)).from_address(ptr.value), dtype=torch.int32).view(N, R)
     nbrs.fill_(-1)
     bsp = PQBuildScoreProvider(ctx, pq_vectors, vsf)
     # entry point: the inserted node closest to the mean of a sample (the reference re-centres on the medoid at cleanup)
@@ -82,15 +101,15 @@ def build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=10
         # ---- 2. robust prune of every new node's candidates (sorted best first by the search) ----
         t0 = time.perf_counter()
         count = (cand >= 0).sum(dim=1).to(torch.int32)
-        sel, nsel, _ = bsp.retain_diverse(cand, csc, R, alpha, cand_count=count)
+        sel, nsel, _ = bsp.retain_diverse(cand, csc, Rf, alpha, cand_count=count)
         sel = torch.as_tensor(sel)
         chosen = torch.where(sel >= 0, torch.gather(cand, 1, sel.clamp(min=0).long()), torch.full_like(sel, -1))
-        nbrs[batch.long()] = chosen
+        nbrs[batch.long(), :Rf] = chosen
         _sync(ctx, nbrs)
         stats["prune_s"] += time.perf_counter() - t0
         # ---- 3. backlinks: v joins the list of each of its chosen neighbours s; lists that overflow are re-pruned ----
         t0 = time.perf_counter()
-        src = batch.view(-1, 1).expand(-1, R).reshape(-1)
+        src = batch.view(-1, 1).expand(-1, Rf).reshape(-1)
         dst = chosen.reshape(-1)
         ok = dst >= 0
         src, dst = src[ok].to(torch.int32), dst[ok].long()
@@ -119,9 +138,10 @@ def build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=10
                 o2 = torch.argsort(sc, dim=1, descending=True, stable=True)
                 lst, sc = torch.gather(lst, 1, o2).contiguous(), torch.gather(sc, 1, o2).contiguous()
                 cnt2 = (lst >= 0).sum(dim=1).to(torch.int32)
-                sel2, _, _ = bsp.retain_diverse(lst, sc, R, alpha, cand_count=cnt2)
+                sel2, _, _ = bsp.retain_diverse(lst, sc, Rf, alpha, cand_count=cnt2)
                 sel2 = torch.as_tensor(sel2)
-                nbrs[tgt.long()] = torch.where(sel2 >= 0, torch.gather(lst, 1, sel2.clamp(min=0).long()), torch.full_like(sel2, -1))
+                nbrs[tgt.long()] = -1
+                nbrs[tgt.long(), :Rf] = torch.where(sel2 >= 0, torch.gather(lst, 1, sel2.clamp(min=0).long()), torch.full_like(sel2, -1))
                 stats["reprunes"] += int(over.numel())
         _sync(ctx, nbrs)
         stats["backlink_s"] += time.perf_counter() - t0
@@ -130,8 +150,76 @@ def build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=10
             log(f"[build] inserted {hi}/{N} (batch {B}, beam {k}): search {stats['search_s']:.1f}s prune {stats['prune_s']:.1f}s "
                 f"backlink {stats['backlink_s']:.1f}s")
         lo = hi
+    # ---- final pass (the reference's cleanup: enforceDegree): lists still above max_degree are pruned back ----
+    t0 = time.perf_counter()
+    if R > Rf:
+        over_all = ((nbrs >= 0).sum(dim=1) > Rf).nonzero().squeeze(1)
+        for s0 in range(0, int(over_all.numel()), max_batch):
+            tgt = over_all[s0:s0 + max_batch].to(torch.int32)
+            lst = nbrs[tgt.long()].contiguous()
+            sc = torch.as_tensor(bsp.diversity_scores(tgt, lst))
+            o2 = torch.argsort(sc, dim=1, descending=True, stable=True)
+            lst, sc = torch.gather(lst, 1, o2).contiguous(), torch.gather(sc, 1, o2).contiguous()
+            sel2, _, _ = bsp.retain_diverse(lst, sc, Rf, alpha, cand_count=(lst >= 0).sum(dim=1).to(torch.int32))
+            sel2 = torch.as_tensor(sel2)
+            nbrs[tgt.long()] = -1
+            nbrs[tgt.long(), :Rf] = torch.where(sel2 >= 0, torch.gather(lst, 1, sel2.clamp(min=0).long()), torch.full_like(sel2, -1))
+            stats["reprunes"] += int(tgt.numel())
+        _sync(ctx, nbrs)
+    stats["backlink_s"] += time.perf_counter() - t0
+    final = nbrs[:, :Rf].contiguous() if R > Rf else nbrs
     stats["total_s"] = time.perf_counter() - t_all
     stats["nodes_per_s"] = N / stats["total_s"]
-    stats["avg_degree"] = float((nbrs >= 0).sum().item()) / N
+    stats["avg_degree"] = float((final >= 0).sum().item()) / N
     bsp.close()
-    return nbrs, entry, stats
+    if owned is not None:  # hand back an ordinary tensor and release the library allocation
+        graph.close()
+        final = final.clone()
+        del nbrs
+        ctx._lib.jv_hip_device_free(ctx._h, owned)
+    return final, entry, stats
+
+
+def build_hierarchical(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=100, alpha=1.2, seed=11, log=None, min_top=8,
+                       **kw):
+    """The reference's layered graph (GraphIndexBuilder with addHierarchy: a node reaches level >= l with probability
+    maxDegree^-l, :562-575 — ml = 1 / ln(degree)): nested random subsets of N / maxDegree^l nodes, each level a Vamana graph over
+    its own nodes built by build_vamana.  Returns (levels, entry_node, entry_level, level-0 neighbours on the device, stats) with
+    levels[l] = (None | sorted int32 node ids, int32 neighbour rows) as host arrays — what GraphIndex takes."""
+    from ._lib import check
+    from .engine import PQVectors, VectorSet
+    dev = vectors.device
+    N = int(vectors.shape[0])
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    perm = torch.randperm(N, generator=g).to(dev)
+    nb0, entry, stats = build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree, beam_width, alpha, seed=seed, log=log, **kw)
+    levels = [(None, nb0.cpu().numpy())]
+    entry_level = 0
+    n = N // max_degree
+    all_stats = {"level0": dict(stats)}
+    codes_all = torch.as_tensor(pq_vectors.get(0, N)) if not vectors.is_cuda else None
+    mean = vectors[perm[: min(N, 100000)]].mean(0)
+    while n >= min_top:
+        nodes = torch.sort(perm[:n]).values          # nested: perm[:n_{l+1}] is a subset of perm[:n_l]
+        sub_vec = vectors[nodes].contiguous()
+        if vectors.is_cuda:
+            codes_t = torch.empty((n, pq.M), dtype=torch.uint8, device=dev)
+            sub_cv = PQVectors(ctx, pq, codes_t)
+            sub_vs = VectorSet(ctx, sub_vec)
+            check(ctx._lib.jv_hip_pq_encode_into(ctx._h, pq._h, sub_vs._h, 0, n, sub_cv._h))   # same codes as level 0's rows
+        else:
+            sub_cv = PQVectors(ctx, pq, codes_all[nodes.cpu()].numpy())
+        nbl, _, st = build_vamana(ctx, pq, sub_cv, sub_vec, vsf, max_degree, beam_width, alpha, seed=seed + len(levels), log=log, **kw)
+        glob = torch.where(nbl >= 0, nodes[nbl.clamp(min=0).long()].to(torch.int32), nbl)
+        levels.append((nodes.to(torch.int32).cpu().numpy(), glob.cpu().numpy()))
+        all_stats[f"level{len(levels) - 1}"] = dict(st)
+        entry_level = len(levels) - 1
+        # entry point: the top level's node closest to the data mean (the reference re-centres on the medoid at cleanup)
+        entry = int(nodes[(sub_vec @ mean).argmax()])
+        n //= max_degree
+    total = BuildStats(stats)
+    for k in ("search_s", "prune_s", "backlink_s", "total_s", "reprunes", "batches"):
+        total[k] = sum(v[k] for v in all_stats.values())
+    total["nodes_per_s"] = N / total["total_s"]
+    total["levels"] = [int(N)] + [int(l[0].shape[0]) for l in levels[1:]]
+    return levels, entry, entry_level, nb0, total

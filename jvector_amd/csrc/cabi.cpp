@@ -685,6 +685,31 @@ int jv_hip_vectors_upload(jv_ctx *ctx, jv_vectors *v, int64_t first, int64_t cou
     return JV_OK;
 }
 
+int jv_hip_device_alloc(jv_ctx *ctx, size_t bytes, void **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && out, "device_alloc: NULL argument");
+    JV_TRY(use_device(ctx->device));
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("device_alloc: hipMalloc of %zu bytes failed", bytes);
+        return JV_ERR_OOM;
+    }
+    *out = p;
+    return JV_OK;
+}
+
+int jv_hip_device_free(jv_ctx *ctx, void *ptr)
+{
+    clear_error();
+    JV_REQUIRE(ctx, "device_free: NULL context");
+    if (!ptr) return JV_OK;
+    JV_TRY(use_device(ctx->device));
+    JV_HIP_CHECK(hipFree(ptr));
+    return JV_OK;
+}
+
 int jv_hip_vectors_destroy(jv_vectors *v)
 {
     if (!v) return JV_OK;

@@ -29,14 +29,14 @@ def _data(N, D, seed):
 
 
 def check_builder(J, ctx, dev, N, D, M, max_degree, beam, register=None, min_recall=0.85):
-    from jvector_amd.builder import build_vamana
+    from jvector_amd.builder import build_hierarchical, build_vamana
     VSF = J.VectorSimilarityFunction.COSINE
     v, q = _data(N, D, 3)
     tv = torch.from_numpy(v).to(dev)
     pq = J.ProductQuantization.compute(ctx, tv, M, seed=2)
     vs = J.VectorSet(ctx, tv)
     cv = J.PQVectors.encode_and_build(ctx, pq, vs)
-    out = torch.empty((N, max_degree), dtype=torch.int32, device=dev)
+    out = torch.empty((N, max_degree + max_degree // 4), dtype=torch.int32, device=dev)   # working width: overflow 1.25
     if register:
         register(out.data_ptr())
     nbrs, entry, stats = build_vamana(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, alpha=1.2, max_batch=2048, out=out)
@@ -66,6 +66,19 @@ def check_builder(J, ctx, dev, N, D, M, max_degree, beam, register=None, min_rec
     gt = np.argsort(-(q @ v.T), axis=1)[:, :10]
     recall = np.mean([len(set(a.tolist()) & set(b.tolist())) / 10.0 for a, b in zip(np.asarray(ids), gt)])
     assert recall >= min_recall, recall
+    # ---- layered variant (GraphIndexBuilder's hierarchy): nested levels of N / maxDegree^l nodes, searched top-down ----
+    if not register:
+        levels, e2, el2, nb0, st2 = build_hierarchical(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, max_batch=2048, min_top=4)
+        assert el2 == len(levels) - 1 >= 1 and st2["levels"][0] == N
+        for l in range(1, len(levels)):
+            ids_l, nb_l = levels[l]
+            assert (np.diff(ids_l) > 0).all() and set(nb_l[nb_l >= 0].tolist()) <= set(ids_l.tolist())
+            assert l == 1 or set(ids_l.tolist()) <= set(levels[l - 1][0].tolist())
+        assert e2 in set(levels[-1][0].tolist())
+        g2 = J.GraphIndex(ctx, N, levels, e2, el2)
+        ids2, _ = J.GraphSearcher(ctx, g2, pq, cv, None, vs, max_queries=64).search(q, VSF, 10, 4 * beam)
+        r2 = np.mean([len(set(a.tolist()) & set(b.tolist())) / 10.0 for a, b in zip(np.asarray(ids2), gt)])
+        assert r2 >= min_recall, r2
     return stats, recall
 
 

@@ -578,8 +578,9 @@ def test_standalone_canary_against_the_mock_library(J):
         assert line["identical"] is True and line["avg_expanded"] >= 50
 
 
-@pytest.mark.parametrize("mode,traversal", [("graph", "host"), ("graph", "device"), ("flat", "host")])
-def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal):
+@pytest.mark.parametrize("mode,traversal,graph,n", [("graph", "host", "synthetic", 6000), ("graph", "device", "engine", 2000),
+                                                   ("flat", "host", "synthetic", 6000)])
+def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, graph, n):
     """bench.py end to end at toy size: torch runs on the CPU (a proxy maps the `cuda` device bench asks for to `cpu` and makes
     the stream / synchronize calls inert) and the engine is the mock device.  Numbers are meaningless; what is checked is the
     control flow — index build, rerankK calibration against exact ground truth, the timed loop, the secondary flat
@@ -601,7 +602,7 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal):
             return torch.device("cpu")
 
     monkeypatch.setattr(bench, "torch", TorchProxy())
-    argv = ["bench.py", "--mode", mode, "--traversal", traversal, "--n", "6000", "--dim", "128", "--m", "16", "--degree", "16",
+    argv = ["bench.py", "--mode", mode, "--traversal", traversal, "--graph", graph, "--n", str(n), "--dim", "128", "--m", "16", "--degree", "16",
             "--queries", "48", "--steps", "2", "--warmup", "1", "--eval-queries", "48", "--cal-queries", "48"]
     monkeypatch.setattr(sys, "argv", argv)
     monkeypatch.delenv("RANK", raising=False)
@@ -613,7 +614,7 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal):
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["higher_is_better"] is True
-    assert line["config"]["mode"] == mode and line["config"]["n_vectors"] == 6000 and "workload" in line["config"]
+    assert line["config"]["mode"] == mode and line["config"]["n_vectors"] == n and "workload" in line["config"]
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
     assert line["cpu_baseline"]["matches_gpu_topk"] is True          # the scalar leg is the parity checker
@@ -624,6 +625,7 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal):
     assert 0.0 <= line["recall_at_10"] <= 1.0 and line["recall_at_10"] > 0.5
     if mode == "graph":
         assert line["config"]["traversal"] == traversal and line["avg_expanded"] > 0 and "flat_mode" in line
+        assert line["graph"] == graph and (graph != "engine" or line["graph_build"]["nodes_per_s"] > 0)
 
 
 def _bench_rank(rank, world, port, mode, out_dir):
@@ -662,7 +664,7 @@ def _bench_rank(rank, world, port, mode, out_dir):
             return torch.device("cpu")
 
     bench.torch = TorchProxy()
-    sys.argv = ["bench.py", "--gpus", str(world), "--mode", mode, "--n", "5000", "--dim", "128", "--m", "16", "--degree", "16", "--queries",
+    sys.argv = ["bench.py", "--gpus", str(world), "--mode", mode, "--graph", "synthetic", "--n", "5000", "--dim", "128", "--m", "16", "--degree", "16", "--queries",
                 "32", "--steps", "2", "--warmup", "1", "--eval-queries", "32", "--cal-queries", "32"]
     with open(os.path.join(out_dir, f"rank{rank}.out"), "w") as f, contextlib.redirect_stdout(f):
         bench.main()
