@@ -16,7 +16,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=/tmp/prof_$TAG; K=$R/gpurun_out/prof_$TAG; C=/tmp/jv_index_$N.npz
 mkdir -p $O $K
 /opt/rocm/bin/rocminfo > $K/rocminfo.txt 2>&1
-ARGS="--n $N --index-cache $C --rerank 150 --no-cpu-baseline"
+ARGS="--n $N --index-cache $C --no-cpu-baseline"
 cd /tmp && export TMPDIR=/tmp
 [ -f $C ] || timeout 900 python $R/bench.py --n $N --index-cache $C --steps 1 --warmup 1 --no-flat --no-cpu-baseline --cal-queries 256 --eval-queries 256 > $K/cache_build.log 2>&1
 ls -la $C >> $K/cache_build.log
