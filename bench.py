@@ -317,6 +317,61 @@ def run_c2(args, ctx, J, dev, world, rank, barrier):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# C4: sharded index — every rank owns one contiguous ordinal range; jv_hip_sharded_search_flat (RCCL inside the library)
+# ------------------------------------------------------------------------------------------------------------------
+def run_c4(args, ctx, J, dev, world, rank, barrier):
+    from jvector_amd.sharded import Communicator, CShardedFlatSearcher
+    VSF = J.VectorSimilarityFunction.COSINE
+    n_shard = args.n if args.n != 10_000_000 else 12_500_000
+    D, M, K, QF = args.dim, args.m, args.topk, (args.queries or 256)
+    rerank_k = args.rerank or 50
+    mix = Mixture(D, seed=5, device=dev)
+    base = mix.sample(n_shard, seed=5 + rank)                      # shard-local block (seeds 5 + i), never on the host
+    queries = mix.sample(QF * (args.steps + args.warmup), seed=6)   # the SAME queries on every rank: one sharded index, one answer
+    g = torch.Generator(device=dev).manual_seed(4)
+    pq_bytes = None
+    if rank == 0:
+        sample = base[torch.randperm(n_shard, generator=g, device=dev)[:128_000]].contiguous()
+        pq_bytes = J.ProductQuantization.compute(ctx, sample, M, seed=4).write(6)
+    uid = Communicator.unique_id(ctx) if rank == 0 else None
+    if world > 1:  # codebooks and the RCCL rendezvous id travel over the host's own channel
+        box = [pq_bytes, uid]
+        torch.distributed.broadcast_object_list(box, src=0)
+        pq_bytes, uid = box
+    pq = J.ProductQuantization.load(ctx, pq_bytes)
+    vs = J.VectorSet(ctx, base)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    comm = Communicator(ctx, rank, world, uid)
+    s = CShardedFlatSearcher(ctx, comm, pq, [(cv, vs, rank * n_shard)], max_queries=QF)
+    for w in range(args.warmup):
+        s.search(queries[w * QF:(w + 1) * QF], VSF, K, rerank_k)
+    barrier()
+    t0 = time.perf_counter()
+    for st in range(args.steps):
+        s.search(queries[(args.warmup + st) * QF:(args.warmup + st + 1) * QF], VSF, K, rerank_k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    comm.close()
+    if rank != 0:
+        return None
+    N = n_shard * world
+    return {"metric": "QPS, sharded flat search (ADC scan of every shard + RCCL partial-top-k all-gather + owner rerank)",
+            "value": QF * args.steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE C4: {N} x {D} cosine mixture in {world} shard(s) of {n_shard}, PQ-{M}; per query batch: per-shard "
+                                   f"ADC scan -> top-{rerank_k}, all-gather, NodeQueue-order merge, exact scores by the owning shard, all-gather + "
+                                   f"owner selection, top-{K} (jv_hip_sharded_search_flat)", "n_vectors": N, "shard": n_shard, "dim": D,
+                       "pq_subspaces": M, "queries_per_step": QF, "rerankK": rerank_k, "topK": K,
+                       "parallelism": f"{world} rank(s), one shard each, RCCL all-gather of Q x rerankK x 8 B per shard"},
+            "adc_distances_per_s": float(QF) * N * args.steps / elapsed, "roofline": None, "cpu_baseline": None}
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # C5: index build — PQ training + encode + batched Vamana construction with the engine's scoring, N x 1536, PQ-192
 # ------------------------------------------------------------------------------------------------------------------
 def run_c5(args, ctx, J, dev, world, rank, barrier):
@@ -379,8 +434,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3", help="c3 = the headline 10Mx768 config; c2 = SIFT1M-like; "
-                    "c5 = index build (batched Vamana with the engine's scoring) on Nx1536, PQ-192")
+    ap.add_argument("--workload", choices=["c3", "c2", "c4", "c5"], default="c3", help="c3 = the headline 10Mx768 config; c2 = SIFT1M-like; "
+                    "c4 = sharded flat search: every rank owns --n vectors (default 12.5M = 100M / 8) and the C ABI's RCCL exchange "
+                    "merges the partial top-k; c5 = index build (batched Vamana with the engine's scoring) on Nx1536, PQ-192")
     ap.add_argument("--graph", choices=["engine", "synthetic"], default="engine", help="c3 graph: jvector_amd.builder.build_vamana — "
                     "batched Vamana construction with the engine's own search / robust-prune / backlink scoring (default; BASELINE "
                     "config 5's path) — or benchgraph.py's synthetic kNN+prune graph (round 1's input preparation)")
@@ -399,6 +455,8 @@ def main():
     ap.add_argument("--traversal", choices=["host", "device"], default=os.environ.get("JVECTOR_BENCH_TRAVERSAL", "device"),
                     help="graph mode: device-resident traversal (default; what JV_TRAVERSAL_AUTO picks at this shape) or the "
                          "host batched searcher")
+    ap.add_argument("--build-beam", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_BEAM", "100")),
+                    help="engine graph: construction beam width (the reference's efConstruction / beamWidth, default 100)")
     ap.add_argument("--torch-codebooks", action="store_true", help="codebooks from benchlib's torch Lloyd instead of the engine's "
                     "ProductQuantization.compute (round-1 behaviour)")
     ap.add_argument("--index-cache", default=os.environ.get("JVECTOR_BENCH_INDEX_CACHE", ""), help="npz file: synthetic graph + "
@@ -425,8 +483,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    if args.workload in ("c2", "c5"):
-        line = (run_c2 if args.workload == "c2" else run_c5)(args, ctx, J, dev, world, rank, barrier)
+    if args.workload in ("c2", "c4", "c5"):
+        line = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[args.workload](args, ctx, J, dev, world, rank, barrier)
         if rank == 0:
             print(json.dumps(line))
         if world > 1:
@@ -493,7 +551,7 @@ def main():
         elif args.graph == "engine":
             from jvector_amd.builder import build_hierarchical
             levels, entry, entry_level, nbrs_dev, bstats = build_hierarchical(ctx, pq, cv, base, VSF, max_degree=args.degree,
-                                                                                beam_width=100, alpha=1.2, log=log)
+                                                                                beam_width=args.build_beam, alpha=1.2, log=log)
             log(f"[build] {dict(bstats)}")
             build_info = {k: (float(v) if isinstance(v, float) else v) for k, v in dict(bstats).items()}
             if args.index_cache and rank == 0:
@@ -663,7 +721,7 @@ def main():
             "config": {"workload": (f"synthetic {N}x{D} cosine (latent-32 mixture of 1000 clusters, unit norm), PQ-{M} (k=256, " +
                                     ("torch Lloyd x6" if args.torch_codebooks else "engine ProductQuantization.compute: k-means++ + Lloyd x6") +
                                     " on a 128k sample), " +
-                                    (f"FusedADC graph search: " + (f"layered Vamana graph built by the engine's batched builder (PQ scoring, beamWidth 100, alpha 1.2, neighborOverflow 1.25; maxDegree {args.degree}, {len(levels)} levels of N/{args.degree}^l nodes), "
+                                    (f"FusedADC graph search: " + (f"layered Vamana graph built by the engine's batched builder (PQ scoring, beamWidth {args.build_beam}, alpha 1.2, neighborOverflow 1.25; maxDegree {args.degree}, {len(levels)} levels of N/{args.degree}^l nodes), "
                                                                    if args.graph == "engine" else
                                                                    f"synthetic kNN+robust-prune graph (maxDegree {args.degree}, {len(levels)} nested levels), ") +
                                      f"{'device-resident GraphSearcher (one wavefront per query)' if args.traversal == 'device' else 'host batched GraphSearcher, GPU fused-block scoring'}, rerankK {rerank_k} -> exact rerank -> top-{K}"

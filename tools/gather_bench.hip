@@ -4,6 +4,9 @@
 //   1: two adjacent lanes per row, one dwordx4 each (the pair shares a 128-byte line)
 //   2: four adjacent lanes per row, one dwordx2 each
 //   3: one lane per row, rows forced to distinct lines but SAME row for all lanes of a quad (upper bound of coalescing)
+//   4: variant 0 with only 34 of the 64 lanes active (the traversal kernel's average: 17 fresh neighbours x 2 lanes) — is the
+//      cost per instruction or per active lane?
+//   5: variant 0 with 16 of 64 lanes active
 // build: hipcc --offload-arch=gfx950 -O3 tools/gather_bench.hip -o build/gather_bench ; run: build/gather_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -21,12 +24,16 @@ __global__ __launch_bounds__(64) void gather(const float *__restrict__ cb, const
     const int lane = threadIdx.x;
     const unsigned char *my = codes + ((size_t)blockIdx.x * 64 + (VAR == 1 ? (lane >> 1) : VAR == 2 ? (lane >> 2) : VAR == 3 ? (lane & ~3) : lane)) * M;
     float acc = 0.f;
+    if ((VAR == 4 && lane >= 34) || (VAR == 5 && lane >= 16)) {
+        out[(size_t)blockIdx.x * 64 + lane] = 0.f;
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll 8
         for (int m = 0; m < M; ++m) {
             const unsigned code = my[m] ^ (it & 255);
             const float *row = cb + ((size_t)m * K + (code & 255)) * 8;
-            if (VAR == 0 || VAR == 3) {
+            if (VAR == 0 || VAR == 3 || VAR == 4 || VAR == 5) {
                 const float4 a = *reinterpret_cast<const float4 *>(row);
                 const float4 b = *reinterpret_cast<const float4 *>(row + 4);
                 acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
@@ -57,7 +64,7 @@ void run(const float *cb, const unsigned char *codes, float *out, int blocks, in
     float ms;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double rows_per_lane_group = (double)M * iters;
-    const double groups = (double)blocks * (VAR == 1 ? 32 : VAR == 2 ? 16 : 64);
+    const double groups = (double)blocks * (VAR == 1 ? 32 : VAR == 2 ? 16 : VAR == 4 ? 34 : VAR == 5 ? 16 : 64);
     const double rows = rows_per_lane_group * groups;
     printf("%-44s %8.3f ms  %7.1f G rows/s  %6.2f TB/s  %6.3f rows/clk/CU (2.4 GHz, 256 CUs)\n", name, ms, rows / ms / 1e6,
            rows * 32 / ms / 1e9, rows / (ms * 1e-3) / 2.4e9 / 256);
@@ -81,5 +88,7 @@ int main()
     run<1>(cb, codes, out, blocks, iters, "1: lane PAIR per row, 1 x dwordx4 each");
     run<2>(cb, codes, out, blocks, iters, "2: lane QUAD per row, 1 x dwordx2 each");
     run<3>(cb, codes, out, blocks, iters, "3: quad reads the same row (2 x dwordx4)");
+    run<4>(cb, codes, out, blocks, iters, "4: variant 0, 34 of 64 lanes active");
+    run<5>(cb, codes, out, blocks, iters, "5: variant 0, 16 of 64 lanes active");
     return 0;
 }
