@@ -269,13 +269,15 @@ JV_API int jv_hip_search_flat(jv_ctx *ctx, jv_luts *luts, const jv_codes *codes,
                               int32_t *out_ids, float *out_scores);
 
 /* ---------------------------------------------------------------------------------------------
- * Host batched graph searcher — SURVEY §8f rank 1 ("next" row): a lock-step, multi-query restatement of
+ * Batched graph searcher — SURVEY §8f rank 1 ("next" row): a multi-query restatement of
  *   GraphSearcher.search / searchOneLayer / reranking (B/graph/GraphSearcher.java:222-507) +
  *   View.processNeighbors (B/graph/disk/OnDiskGraphIndex.java:639-661, B/graph/OnHeapGraphIndex.java:475-483).
- * The traversal (candidate heap, bounded result heap, visited set) stays on the HOST; every round ships one
- * expanded node per live query to the GPU: layer 0 with FusedPQ -> jv_fused block scores
- * (FusedPQDecoder.similarityToNeighbor), otherwise an ADC gather of the unvisited neighbours' codes.
- * Per query the visit order, scores and results equal the reference's sequential search on the same graph.
+ * Two traversals behind the same call (jv_hip_graph_set_traversal below).  DEVICE: one wavefront per query keeps the
+ * candidate / result queues in LDS and the visited set in device memory and runs the whole loop on the GPU.  HOST: the
+ * traversal state lives on the host and every round ships one expanded node per live query to the GPU.  Either way layer 0
+ * with FusedPQ scores the origin's packed block (FusedPQDecoder.similarityToNeighbor), otherwise the neighbours' own codes
+ * (PQDecoder.similarityTo), and per query the visit order, scores, results, visitedCount and expandedCount equal the
+ * reference's sequential search on the same graph.
  *
  * Graph: level 0 holds every node (count == n_nodes, node_ids == NULL); upper levels list their node ids in
  * ascending order.  neighbors: count x degree int32, packed, padded with -1 (the L0 record layout,

@@ -2,7 +2,8 @@
 // 64-lane wavefront (body: gs_body.h, which the CPU tests also compile for a lane emulator).
 //
 // Why: the host batched searcher (graph_search.cpp) is bound by the HOST — ~1.2 us of heap / hash work per
-// expansion per core, 68 k QPS on the 16-core box while its scoring kernels occupy the GPU for 18 % of the step.
+// expansion per core, 77-91 k QPS on the 16-core box while its scoring kernels occupy the GPU for 18 % of the step
+// (this kernel: 0.8-1.0 M QPS on the same 10M index).
 // Moving the three queues and the visited set next to the scoring removes the per-round PCIe exchange, the worker
 // pool and the dependence on host cores (which N > 1 ranks have to share).  Per expansion a wave reads one adjacency
 // row (128 B) and, with FusedPQ, one packed block (maxDegree x M = 3 KB) from HBM; everything else (candidate and
@@ -24,7 +25,10 @@ static_assert(VSF_L2 == 0 && VSF_DOT == 1 && VSF_COS == 2, "gs_body.h hard-codes
 
 // OCC = waves per SIMD the register allocation is held to: 2 (225 VGPRs: the unrolled scoring keeps ~100 codebook
 // loads in flight per wave) or 4 (128 VGPRs, no spills: twice the resident queries per CU to hide the
-// pop -> load -> probe -> score -> push dependency chain).  Which wins is a measurement; both are built.
+// pop -> load -> probe -> score -> push dependency chain).  Measured on MI355X (1M x 768, 16 384 queries per launch):
+// 2 waves/SIMD with pair-lane scoring 19.0 ms, 4 waves/SIMD 25.1 ms, 2 waves/SIMD without pair lanes 33.7 ms, a 3 waves/SIMD
+// build 28.3 ms: the kernel is bound by the rate at which a CU's texture path takes 16-byte gather requests
+// (tools/gather_bench.hip), and more gathers in flight per wave beat more waves.  2 is the default; 4 stays selectable.
 template <int VSF, int CH16, int OCC, bool PAIR>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void graph_search_kernel(GsParams p)
 {

@@ -647,8 +647,10 @@ class GraphIndex:
 
 
 class GraphSearcher:
-    """Batched GraphSearcher (B/graph/GraphSearcher.java): host traversal in lock-step over the query batch, GPU
-    scoring of each round's frontier (FusedPQ blocks at layer 0 when `fused` is given, ADC gathers otherwise)."""
+    """Batched GraphSearcher (B/graph/GraphSearcher.java): the whole search loop of every query of the batch runs on the GPU
+    (one wavefront per query; FusedPQ blocks at layer 0 when `fused` is given, the code store otherwise) or, for shapes the
+    kernel does not cover / on request, in the lock-step host searcher with GPU frontier scoring (GraphIndex.set_traversal).
+    Results, visitedCount and expandedCount equal the reference's sequential search either way."""
 
     def __init__(self, ctx, graph: GraphIndex, pq, pq_vectors: PQVectors, fused: FusedPQ | None = None,
                  vectors: VectorSet | None = None, max_queries=4096):
