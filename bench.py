@@ -377,7 +377,9 @@ def run_c4(args, ctx, J, dev, world, rank, barrier):
 def run_c5(args, ctx, J, dev, world, rank, barrier):
     from jvector_amd.builder import build_vamana
     VSF = J.VectorSimilarityFunction.COSINE
-    N, D, M, K = (args.n if args.n != 10_000_000 else 1_000_000), 1536, 192, args.topk
+    # BASELINE C5 shape unless --dim / --m were given explicitly (the CPU dry run uses a toy shape)
+    D, M = (1536, 192) if (args.dim, args.m) == (768, 96) else (args.dim, args.m)
+    N, K = (args.n if args.n != 10_000_000 else 1_000_000), args.topk
     mix = Mixture(D, seed=7, device=dev)
     base = mix.sample(N, seed=7 + 1000 * rank)
     eval_q = mix.sample(min(args.eval_queries, 4096), seed=9)

@@ -628,6 +628,45 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, grap
         assert line["graph"] == graph and (graph != "engine" or line["graph_build"]["nodes_per_s"] > 0)
 
 
+@pytest.mark.parametrize("workload,extra", [("c2", ["--n", "3000", "--queries", "32", "--eval-queries", "64", "--rerank", "100"]),
+                                            ("c4", ["--n", "3000", "--dim", "128", "--m", "16", "--queries", "16", "--rerank", "40"]),
+                                            ("c5", ["--n", "1500", "--dim", "128", "--m", "16", "--degree", "16", "--eval-queries", "32"])])
+def test_bench_other_workloads_dry_run(J, monkeypatch, capsys, workload, extra):
+    """the secondary workloads of bench.py (C2 flat SIFT-like, C4 sharded through the C ABI's communicator — here a one-rank
+    communicator on the shared-memory RCCL shim —, C5 index build) end to end at toy size on the mock: control flow + JSON contract"""
+    import json
+    import types
+    import torch
+    import bench
+    import test_sharded_cabi as TS
+    monkeypatch.setenv("JVECTOR_HIP_RCCL_PATH", TS.build_shim())
+
+    class TorchProxy:
+        cuda = types.SimpleNamespace(set_device=lambda *_a: None, synchronize=lambda *_a: None,
+                                     current_stream=lambda *_a: types.SimpleNamespace(cuda_stream=0))
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def device(*_a, **_k):
+            return torch.device("cpu")
+
+    monkeypatch.setattr(bench, "torch", TorchProxy())
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", workload, "--steps", "2", "--warmup", "1"] + extra)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    bench.main()
+    line = json.loads([x for x in capsys.readouterr().out.strip().splitlines() if x.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
+        assert key in line, key
+    assert line["value"] > 0 and "workload" in line["config"]
+    if workload == "c2":
+        assert line["roofline"]["bound"] == "lds" and line["cpu_baseline"]["matches_gpu_topk"] is True
+    if workload == "c5":
+        assert line["build"]["avg_degree"] > 4 and max(line["recall_at_10_by_rerankK"].values()) > 0.8
+
+
 def _bench_rank(rank, world, port, mode, out_dir):
     """one rank of a 2-process bench.py dry run: gloo instead of RCCL, CPU tensors, the mock device"""
     import contextlib
