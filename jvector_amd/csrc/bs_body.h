@@ -55,12 +55,25 @@ BS_FN void bs_pair_table_row(const BsPq &pq, int vsf, int64_t t, float *out)
     }
 }
 
-// VectorUtil.assembleAndSumPQ
+// VectorUtil.assembleAndSumPQ.  The table entries are independent loads feeding one sequential f32 sum: fetched 16 at a time,
+// then added in ascending m (same association, the load latency paid once per 16 entries).
 BS_FN float bs_assemble_pq(const float *tri, int M, int k, const uint8_t *c1v, const uint8_t *c2v)
 {
     const int64_t block = (int64_t)k * (k + 1) / 2;
     float res = 0.0f;
-    for (int m = 0; m < M; ++m) {
+    int m = 0;
+    for (; m + 16 <= M; m += 16) {
+        float e[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c1 = c1v[m + j], c2 = c2v[m + j];
+            const int r = c1 < c2 ? c1 : c2, c = c1 < c2 ? c2 : c1;
+            e[j] = tri[(int64_t)(m + j) * block + bs_tri_row(r, k) + (c - r)];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) res += e[j];
+    }
+    for (; m < M; ++m) {
         const int c1 = c1v[m], c2 = c2v[m];
         const int r = c1 < c2 ? c1 : c2, c = c1 < c2 ? c2 : c1;
         res += tri[(int64_t)m * block + bs_tri_row(r, k) + (c - r)];

@@ -23,12 +23,26 @@ namespace jv {
 
 GS_FN int64_t rd_tri_row(int r, int k) { return (int64_t)r * k - ((int64_t)r * (r - 1)) / 2; }
 
-// assembleAndSumPQ of (candidate row in LDS, this lane's selected slot column in LDS)
+// assembleAndSumPQ of (candidate row in LDS, this lane's selected slot column in LDS).  The M table entries are independent
+// loads (L2 / Infinity Cache latency each) feeding one sequential f32 sum: they are fetched 16 at a time and only then added,
+// in ascending m, so the latency is paid once per 16 entries instead of once per entry.
 GS_FN float rd_pair_sum(const float *tri, int M, int k, const uint8_t *crow, const uint8_t *scol /* stride 64 */)
 {
     const int64_t block = (int64_t)k * (k + 1) / 2;
     float res = 0.0f;
-    for (int m = 0; m < M; ++m) {
+    int m = 0;
+    for (; m + 16 <= M; m += 16) {
+        float e[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int c1 = crow[m + j], c2 = scol[(size_t)(m + j) * 64];
+            const int r = c1 < c2 ? c1 : c2, c = c1 < c2 ? c2 : c1;
+            e[j] = tri[(int64_t)(m + j) * block + rd_tri_row(r, k) + (c - r)];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) res += e[j];
+    }
+    for (; m < M; ++m) {
         const int c1 = crow[m], c2 = scol[(size_t)m * 64];
         const int r = c1 < c2 ? c1 : c2, c = c1 < c2 ? c2 : c1;
         res += tri[(int64_t)m * block + rd_tri_row(r, k) + (c - r)];
