@@ -1010,7 +1010,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const size_t o_counter = carve(sizeof(uint32_t));
     const size_t o_qmap = carve(sizeof(int32_t) * (size_t)Q);
     const bool gs_prof = env_int("JVECTOR_HIP_GS_PROF", 0) != 0;
-    const size_t o_prof = carve(sizeof(unsigned long long) * 8);
+    const size_t o_prof = carve(sizeof(unsigned long long) * 12);
     JV_TRY(ctx->d_gs_out.reserve(off));
     char *base = (char *)ctx->d_gs_out.ptr;
     int32_t *d_cand = (int32_t *)(base + o_ids);
@@ -1020,7 +1020,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     int32_t *d_status = (int32_t *)(base + o_status);
     uint32_t *d_counter = (uint32_t *)(base + o_counter);
     JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
-    if (gs_prof) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 8, ctx->stream));
+    if (gs_prof) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 12, ctx->stream));
 
     GsParams p{};
     for (int lv = 0; lv <= g->entry_level; ++lv) {
@@ -1129,13 +1129,16 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         redo.swap(still);
     }
     if (gs_prof) {
-        unsigned long long h[8];
+        unsigned long long h[12];
         JV_HIP_CHECK(hipMemcpyAsync(h, base + o_prof, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         const double e = (double)std::max<unsigned long long>(h[5], 1);
         fprintf(stderr, "[jv gs prof] clocks/expansion: pop %.0f  result %.0f  row+block+visited %.0f  score %.0f  push %.0f | expansions %llu "
                         "queries %llu  setup+epilogue clocks/query %.0f\n", h[0] / e, h[1] / e, h[2] / e, h[3] / e, h[4] / e, h[5], h[6],
                 (double)h[7] / (double)std::max<unsigned long long>(h[6], 1));
+        const double fs = (double)std::max<unsigned long long>(h[8] + h[9] + h[10] + h[11], 1);
+        fprintf(stderr, "[jv gs prof] scored neighbours by fresh count of their expansion: <=8 %.3f  <=16 %.3f  <=24 %.3f  <=32 %.3f\n", h[8] / fs,
+                h[9] / fs, h[10] / fs, h[11] / fs);
     }
 
     // ---- reranking :471-507 on the device-resident candidates ----

@@ -354,6 +354,7 @@ template <int VSF, int CH16, bool PAIR, bool PROF = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
     unsigned long long pf[5] = {0, 0, 0, 0, 0};
+    unsigned long long fh[4] = {0, 0, 0, 0};  // PROF: scored neighbours in expansions with <= 8 / <= 16 / <= 24 / <= 32 fresh ones
     unsigned long long pt = 0, pq0 = 0;
     if (PROF) pq0 = GS_CLOCK();
 #define GS_PHASE(i)                          \
@@ -554,6 +555,10 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     break;
                 }
                 GS_PHASE(2);
+                if (PROF) {
+                    const int f = gs_popc(fm);
+                    fh[f <= 8 ? 0 : (f <= 16 ? 1 : (f <= 24 ? 2 : 3))] += (unsigned long long)f;
+                }
                 const bool work = ((fm >> ni) & 1ull) != 0;  // this lane's pair has a fresh neighbour
                 float sum = 0.0f;
                 if (work) sum = gs_half_entries<VSF, CH16>(p.codebooks, qs, w, m_base, hi ? xchg + ni : nullptr);
@@ -639,6 +644,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         gs_fetch_add64(p.prof + 5, (unsigned long long)n_expanded);
         gs_fetch_add64(p.prof + 6, 1ull);
         gs_fetch_add64(p.prof + 7, (GS_CLOCK() - pq0) - in_loop);
+        for (int i = 0; i < 4; ++i) gs_fetch_add64(p.prof + 8 + i, fh[i]);
     }
 #undef GS_PHASE
 }
