@@ -380,6 +380,34 @@ JV_API int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts 
                                         jv_vsf vsf, int topK, int rerankK, const uint64_t *accept_bits,
                                         int64_t accept_stride_words, int32_t *out_ids, float *out_scores, int64_t *stats);
 
+/* GraphSearcher OBJECTS — every option of GraphSearcher.search(scoreProvider, topK, rerankK, threshold, rerankFloor, acceptOrds)
+ * (GraphSearcher.java:222-243) and resume(additionalK, rerankK) (:538-547), for a batch of Q independent searchers that keep
+ * their candidate queue, visited set, evictedResults and CachingReranker (:554-581) between calls.
+ *   threshold > 0   : layer 0 admits only nodes whose approximate similarity reaches it (:437) and stops early through
+ *                     ScoreTracker.TwoPhaseTracker (ScoreTracker.java:80-140; commons-math3 3.6.1's LEGACY percentile);
+ *                     typically used with a large topK = rerankK to find (approximately) everything above the threshold.
+ *   rerankFloor     : only approximate results >= rerankFloor are scored exactly (the best one if none is) and can be
+ *                     returned (NodeQueue.rerank, NodeQueue.java:160-230); the others wait in evictedResults for a resume.
+ *   resume          : continue layer 0 where the last search / resume of this object stopped and return the next
+ *                     additionalK results (never a node returned before); threshold = rerankFloor = 0 (:538-547).
+ * Outputs: out_ids / out_scores Q x topK best first, (-1, -inf) padded; out_counts (nullable) Q results per query;
+ * stats (nullable) Q x 4 int64 = {visitedCount, expandedCount, expandedCountBaseLayer, rerankedCount};
+ * worst_approx (nullable) Q floats = worstApproximateScoreInTopK (+inf when fewer than topK results or no reranker).
+ * Exact-score ties at the K-th place resolve as in the reference (its result heap's array order).
+ * These searches run on the host batched searcher (queues on the host, scoring on the GPU): the state they keep and rerankK
+ * = "all nodes" do not fit the device traversal's LDS-resident queues.  graph / luts / codes / fused / vectors must outlive
+ * the object; one object serves one batch at a time (a new search() discards the previous state).  accept_bits as in
+ * jv_hip_graph_search_filtered (copied: resume uses the same filter).  Buffers may be host or device memory. */
+typedef struct jv_searcher jv_searcher;
+JV_API int jv_hip_searcher_create(jv_ctx *ctx, const jv_graph *g, jv_luts *luts, const jv_codes *codes, const jv_fused *fused,
+                                  const jv_vectors *vectors, jv_searcher **out);
+JV_API int jv_hip_searcher_search(jv_ctx *ctx, jv_searcher *s, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
+                                  float threshold, float rerankFloor, const uint64_t *accept_bits, int64_t accept_stride_words,
+                                  int32_t *out_ids, float *out_scores, int32_t *out_counts, int64_t *stats, float *worst_approx);
+JV_API int jv_hip_searcher_resume(jv_ctx *ctx, jv_searcher *s, int additionalK, int rerankK, int32_t *out_ids, float *out_scores,
+                                  int32_t *out_counts, int64_t *stats, float *worst_approx);
+JV_API int jv_hip_searcher_destroy(jv_searcher *s);
+
 /* ---------------------------------------------------------------------------------------------
  * Sharded index (BASELINE config 4; SURVEY §8b "jv_hip_sharded_topk (RCCL)", §8e): PQ codes and base vectors are
  * partitioned by contiguous ordinal range (the analogue of PQVectors' chunking, B/quantization/PQVectors.java:515-540),

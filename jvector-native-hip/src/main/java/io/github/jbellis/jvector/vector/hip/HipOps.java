@@ -106,6 +106,11 @@ public final class HipOps {
         static final MethodHandle odgiReadLevel = h("jv_fmt_odgi_read_level", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, JAVA_INT, ADDRESS, ADDRESS));
         static final MethodHandle pqvectorsDescribe = h("jv_fmt_pqvectors_describe", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle graphSearchFiltered = h("jv_hip_graph_search_filtered", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS));
+        // GraphSearcher objects: threshold / rerankFloor / resume
+        static final MethodHandle searcherCreate = h("jv_hip_searcher_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle searcherSearch = h("jv_hip_searcher_search", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_FLOAT, JAVA_FLOAT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle searcherResume = h("jv_hip_searcher_resume", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle searcherDestroy = h("jv_hip_searcher_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
         static final MethodHandle searchFlat = h("jv_hip_search_flat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
         // construction: batched robust prune, caller-owned mutable adjacency
         static final MethodHandle retainDiverse = h("jv_hip_retain_diverse", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_FLOAT, ADDRESS, ADDRESS, ADDRESS));
@@ -288,6 +293,29 @@ public final class HipOps {
         check(st(() -> (int) H.graphSearchFiltered.invokeExact(ctx, graph, luts, codes, fusedOrNull, vectorsOrNull, queries, q, vsf, topK, rerankK,
                                                                acceptBitsOrNull, acceptStrideWords, outIds, outScores, statsOrNull)));
     }
+
+    /** Q GraphSearcher objects over one graph: search with every option, then resume (GraphSearcher.java:222-243,538-547). */
+    public static MemorySegment searcherCreate(Arena arena, MemorySegment ctx, MemorySegment graph, MemorySegment luts, MemorySegment codes,
+                                               MemorySegment fusedOrNull, MemorySegment vectorsOrNull) {
+        return outHandle(arena, out -> st(() -> (int) H.searcherCreate.invokeExact(ctx, graph, luts, codes, fusedOrNull, vectorsOrNull, out)));
+    }
+    /** search(scoreProvider, topK, rerankK, threshold, rerankFloor, acceptOrds) per query; outCounts Q, stats Q x 4
+     *  {visitedCount, expandedCount, expandedCountBaseLayer, rerankedCount}, worstApprox Q (all nullable). */
+    public static void searcherSearch(MemorySegment ctx, MemorySegment searcher, MemorySegment queries, int q, int vsf, int topK, int rerankK,
+                                      float threshold, float rerankFloor, MemorySegment acceptBitsOrNull, long acceptStrideWords,
+                                      MemorySegment outIds, MemorySegment outScores, MemorySegment outCountsOrNull, MemorySegment statsOrNull,
+                                      MemorySegment worstApproxOrNull) {
+        check(st(() -> (int) H.searcherSearch.invokeExact(ctx, searcher, queries, q, vsf, topK, rerankK, threshold, rerankFloor, acceptBitsOrNull,
+                                                          acceptStrideWords, outIds, outScores, outCountsOrNull, statsOrNull, worstApproxOrNull)));
+    }
+    /** resume(additionalK, rerankK) for every query of the last searcherSearch */
+    public static void searcherResume(MemorySegment ctx, MemorySegment searcher, int additionalK, int rerankK, MemorySegment outIds,
+                                      MemorySegment outScores, MemorySegment outCountsOrNull, MemorySegment statsOrNull,
+                                      MemorySegment worstApproxOrNull) {
+        check(st(() -> (int) H.searcherResume.invokeExact(ctx, searcher, additionalK, rerankK, outIds, outScores, outCountsOrNull, statsOrNull,
+                                                          worstApproxOrNull)));
+    }
+    public static void searcherDestroy(MemorySegment searcher) { check(st(() -> (int) H.searcherDestroy.invokeExact(searcher))); }
 
     /** two-pass flat search over one shard (jv_hip_search_flat) */
     public static void searchFlat(MemorySegment ctx, MemorySegment luts, MemorySegment codes, MemorySegment vectorsOrNull, MemorySegment queries,

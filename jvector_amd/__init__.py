@@ -12,6 +12,7 @@ from .engine import (  # noqa: F401
     FusedScoreFunction,
     GraphIndex,
     GraphSearcher,
+    SearchResult,
     HipContext,
     PQBuildScoreProvider,
     PQVectors,

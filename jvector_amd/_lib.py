@@ -99,6 +99,10 @@ SIGNATURES = {
     "jv_hip_direct_scores": (_i, [_p, _p, _p, _i, _i, _p, _i, _p]),
     "jv_hip_graph_search": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "jv_hip_graph_search_filtered": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i64, _p, _p, _p]),
+    "jv_hip_searcher_create": (_i, [_p, _p, _p, _p, _p, _p, C.POINTER(_p)]),
+    "jv_hip_searcher_search": (_i, [_p, _p, _p, _i, _i, _i, _i, C.c_float, C.c_float, _p, _i64, _p, _p, _p, _p, _p]),
+    "jv_hip_searcher_resume": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p]),
+    "jv_hip_searcher_destroy": (_i, [_p]),
     "jv_hip_device_alloc": (_i, [_p, C.c_size_t, C.POINTER(_p)]),
     "jv_hip_device_free": (_i, [_p, _p]),
     "jv_hip_graph_set_level0_device": (_i, [_p, _p, _p, _i]),

@@ -21,6 +21,8 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <functional>
+#include <memory>
+#include <unordered_map>
 #include <mutex>
 #include <thread>
 
@@ -308,16 +310,136 @@ struct MaxHeap8 {
     }
 };
 
+// approximateResults / rerankedResults: the reference's binary min-heap (AbstractLongHeap.java:77-85,136-146,158-187; 0-based
+// here).  NodeQueue keys are unique, so after the same push / updateTop / pop sequence the ARRAY holds the same order as
+// the reference's — and NodeQueue.rerank (:160-230) walks that array, which decides who survives an exact-score tie.
+struct JMinHeap {
+    std::vector<int64_t> a;
+    int size() const { return (int)a.size(); }
+    bool empty() const { return a.empty(); }
+    int64_t top() const { return a[0]; }
+    void clear() { a.clear(); }
+    void up(int i)
+    {
+        const int64_t v = a[i];
+        while (i > 0) {
+            const int p = (i - 1) >> 1;
+            if (!(v < a[p])) break;
+            a[i] = a[p];
+            i = p;
+        }
+        a[i] = v;
+    }
+    void down(int i)
+    {
+        const int n = (int)a.size();
+        const int64_t v = a[i];
+        for (;;) {
+            int j = 2 * i + 1;
+            if (j >= n) break;
+            if (j + 1 < n && a[j + 1] < a[j]) ++j;
+            if (!(a[j] < v)) break;
+            a[i] = a[j];
+            i = j;
+        }
+        a[i] = v;
+    }
+    void push(int64_t v) { a.push_back(v); up((int)a.size() - 1); }
+    void update_top(int64_t v) { a[0] = v; down(0); }
+    int64_t pop()
+    {
+        const int64_t r = a[0];
+        a[0] = a.back();
+        a.pop_back();
+        if (!a.empty()) down(0);
+        return r;
+    }
+};
+
+// ScoreTracker.TwoPhaseTracker (B/graph/ScoreTracker.java:80-140): threshold searches stop once the 99th percentile of the
+// last 500 scores falls below both the 100th best score seen and the threshold.  StatUtils.percentile = commons-math3's
+// Percentile, LEGACY estimation: pos = 0.99 * 501, linear interpolation between the order statistics around it, in double.
+struct TwoPhaseTracker {
+    static constexpr int kRecent = 500, kBest = 100;
+    double recent[kRecent];
+    int recent_idx = 0, obs = 0, n_best = 0;
+    int32_t best[kBest];  // min-heap of the best sortable-int scores (BoundedLongHeap :58-69)
+    double threshold = 0.0;
+    bool on = false;
+    void reset(float thr)
+    {
+        on = thr > 0;
+        n_best = 0;
+        obs = 0;
+        threshold = (double)thr;
+    }
+    static inline int32_t sortable(float f)
+    {
+        int32_t bits;
+        if (f != f) bits = 0x7fc00000;
+        else memcpy(&bits, &f, 4);
+        return bits ^ ((bits >> 31) & 0x7fffffff);
+    }
+    void track(float score)
+    {
+        if (!on) return;
+        const int32_t v = sortable(score);
+        if (n_best < kBest) {
+            int i = n_best++;
+            while (i > 0 && best[(i - 1) >> 1] > v) {
+                best[i] = best[(i - 1) >> 1];
+                i = (i - 1) >> 1;
+            }
+            best[i] = v;
+        } else if (!(v < best[0])) {
+            int i = 0;
+            for (;;) {
+                int j = 2 * i + 1;
+                if (j >= n_best) break;
+                if (j + 1 < n_best && best[j + 1] < best[j]) ++j;
+                if (!(best[j] < v)) break;
+                best[i] = best[j];
+                i = j;
+            }
+            best[i] = v;
+        }
+        recent[recent_idx] = (double)score;
+        recent_idx = (recent_idx + 1) % kRecent;
+        ++obs;
+    }
+    bool should_stop() const
+    {
+        if (!on || obs < kRecent || obs % 100 != 0) return false;
+        double w[kRecent];
+        memcpy(w, recent, sizeof(w));
+        const double pos = (99.0 / 100.0) * (double)(kRecent + 1);
+        const int ipos = (int)pos;  // floor: pos > 0
+        std::nth_element(w, w + ipos - 1, w + kRecent);
+        const double lower = w[ipos - 1];
+        const double upper = *std::min_element(w + ipos, w + kRecent);
+        const double window = lower + (pos - (double)ipos) * (upper - lower);
+        const int32_t e = best[0];
+        const int32_t bits = e ^ ((e >> 31) & 0x7fffffff);
+        float worst_best;
+        memcpy(&worst_best, &bits, 4);
+        return window < (double)worst_best && window < threshold;
+    }
+};
+
 struct QState {
     MaxHeap8 cand;                 // max-heap (best candidate on top)
-    std::vector<int64_t> res;      // min-heap (top = worst kept)
-    std::vector<int64_t> evicted;
+    JMinHeap res;                  // approximateResults (top = worst kept)
+    std::vector<int64_t> evicted;  // evictedResults (NodesUnsorted)
     IntSet visited;
+    std::unique_ptr<TwoPhaseTracker> tracker;  // layer 0 of a threshold > 0 search
     bool active = true;
     int32_t origin = -1;
     int n_pending = 0;
     uint64_t fresh_mask = 0;  // fused layer 0: neighbours newly marked visited in this round
-    int64_t n_visited = 0, n_expanded = 0;
+    int64_t n_visited = 0, n_expanded = 0, n_expanded_base = 0;
+    // CachingReranker (GraphSearcher.java:554-581): exact scores survive from search() to resume()
+    std::unordered_map<int32_t, float> exact_cache;
+    bool searched = false;
 };
 
 }  // namespace jv
@@ -503,9 +625,46 @@ struct AcceptMask {
     }
 };
 
+// One GraphSearcher per query, kept between search() and resume() (jv_hip_searcher_*)
+struct jv_searcher {
+    const jv_graph *g = nullptr;
+    jv_luts *luts = nullptr;
+    const jv_codes *codes = nullptr;
+    const jv_fused *fused = nullptr;
+    const jv_vectors *vectors = nullptr;
+    std::vector<std::unique_ptr<QState>> states;
+    std::vector<float> queries;     // the last search()'s queries: resume rebuilds their tables
+    std::vector<uint64_t> accept;   // this.acceptOrds (GraphSearcher.java:338), kept for resume
+    int64_t accept_stride = 0;
+    bool has_accept = false;
+    int Q = 0;
+    jv_vsf vsf = JV_DOT_PRODUCT;
+    bool searched = false;
+};
+
+// What the plain jv_hip_graph_search entry points leave at their defaults
+struct HostSearchOpts {
+    AcceptMask accept;
+    float threshold = 0.0f;      // search(..., threshold, ...) :222-243: TwoPhaseTracker + `score >= threshold` at layer 0
+    float rerank_floor = 0.0f;   // NodeQueue.rerank's floor
+    jv_searcher *session = nullptr;
+    bool resume = false;         // resume(additionalK, rerankK) :538-547: continue layer 0 from the kept state
+    int32_t *counts = nullptr;   // Q: results per query (host memory)
+    int64_t *stats4 = nullptr;   // Q x 4: visitedCount, expandedCount, expandedCountBaseLayer, rerankedCount (host memory)
+    float *worst = nullptr;      // Q: worstApproximateScoreInTopK (host memory)
+};
+
+static int copy_out(void *dst, const void *src_host, size_t bytes)
+{
+    if (bytes == 0) return JV_OK;
+    if (is_device_ptr(dst)) JV_HIP_CHECK(hipMemcpy(dst, src_host, bytes, hipMemcpyHostToDevice));
+    else memcpy(dst, src_host, bytes);
+    return JV_OK;
+}
+
 static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
                         const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
-                        int32_t *out_ids, float *out_scores, int64_t *stats, AcceptMask accept = AcceptMask())
+                        int32_t *out_ids, float *out_scores, int64_t *stats, const HostSearchOpts &opt = HostSearchOpts())
 {
     clear_error();
     JV_REQUIRE(ctx && g && l && codes, "graph_search: NULL argument");
@@ -517,11 +676,15 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
                "graph_search: fused blocks do not match the graph");
     JV_REQUIRE(!vectors || (vectors->D == l->pq->D && vectors->count >= g->n_nodes), "graph_search: vectors mismatch");
     JV_REQUIRE(Q <= l->capacity, "graph_search: Q=%d exceeds the LUT capacity %d", Q, l->capacity);
+    JV_REQUIRE(!(opt.threshold != opt.threshold) && !(opt.rerank_floor != opt.rerank_floor), "graph_search: NaN threshold / rerankFloor");
     for (int lv = 0; lv <= g->entry_level; ++lv)
         JV_REQUIRE(g->levels[lv].count > 0, "graph_search: level %d was never set", lv);
     if (Q == 0) return JV_OK;
     JV_REQUIRE(queries && out_ids && out_scores, "graph_search: NULL buffer");
     JV_TRY(use_device(ctx->device));
+    const AcceptMask &accept = opt.accept;
+    const float threshold = opt.threshold;
+    jv_searcher *const ses = opt.session;
 
     const jv_decoder_kind kind = fused ? JV_DECODER_FUSED : JV_DECODER_PQ;
     JV_TRY(jv_hip_luts_build(ctx, l, queries, Q, vsf, kind));
@@ -562,7 +725,7 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
 
     // initializeInternal for every query: score the entry node (one gather of Q x 1)
     std::vector<float> entry_score((size_t)Q);
-    {
+    if (!opt.resume) {
         int32_t *h = (int32_t *)ctx->h_in.ptr;
         for (int q = 0; q < Q; ++q) h[q] = g->entry_node;
         JV_HIP_CHECK(hipMemcpyAsync(ctx->d_in.ptr, h, sizeof(int32_t) * (size_t)Q, hipMemcpyHostToDevice, ctx->stream));
@@ -578,7 +741,8 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
     }
 
     struct Slot {
-        QState st;
+        QState own;           // a slot's own state, recycled from query to query ...
+        QState *st = nullptr; // ... or the session's state of the query the slot is running
         int query = -1;
         int lvl = 0;
     };
@@ -594,7 +758,8 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
     for (int gi = 0; gi < NG; ++gi) {
         Group &G = groups[gi];
         const int lo = gi * SG, hi = std::min(S_total, lo + SG);
-        G.slots.resize((size_t)std::max(0, hi - lo));
+        G.slots = std::vector<Slot>((size_t)std::max(0, hi - lo));
+        for (Slot &s : G.slots) s.st = &s.own;
         G.h_ctrl = (int32_t *)ctx->h_in.ptr + ctrl_ints * gi;
         G.d_ctrl = (int32_t *)ctx->d_in.ptr + ctrl_ints * gi;
         G.h_sc = (float *)ctx->h_out.ptr + sc_floats * gi;
@@ -606,8 +771,8 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
         ~EventGuard() { for (auto &G : gs) if (G.ev) (void)hipEventDestroy(G.ev); }
     } event_guard{groups};
 
-    std::vector<std::vector<int64_t>> fin((size_t)Q);       // per query: kept approximate results (keys)
-    std::vector<int64_t> q_visited((size_t)Q, 0), q_expanded((size_t)Q, 0);
+    std::vector<std::vector<int64_t>> fin((size_t)Q);       // per query: approximateResults' heap ARRAY at the end of the search
+    std::vector<int64_t> q_visited((size_t)Q, 0), q_expanded((size_t)Q, 0), q_expanded_base((size_t)Q, 0);
     std::atomic<int> next_q{0};
     const int deg0 = g->levels[0].degree;
 
@@ -615,6 +780,16 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
     // rehashes per query (~10 % of the host time at rerankK 150).  Growth stays automatic beyond the hint.
     int visited_cap = 1024;
     while (visited_cap < 32 * rerankK && visited_cap < (1 << 16)) visited_cap <<= 1;
+    // getScoreTracker (ScoreTracker.java:38-58): layer 0 of a threshold search gets the TwoPhaseTracker, everything else none
+    auto enter_layer = [&](Slot &s) {
+        QState &st = *s.st;
+        if (s.lvl == 0 && threshold > 0) {
+            if (!st.tracker) st.tracker.reset(new TwoPhaseTracker());
+            st.tracker->reset(threshold);
+        } else if (st.tracker) {
+            st.tracker->on = false;
+        }
+    };
     auto start_query = [&](Slot &s) -> bool {
         const int qi = next_q.fetch_add(1);
         if (qi >= Q) {
@@ -622,15 +797,26 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
             return false;
         }
         s.query = qi;
-        s.lvl = g->entry_level;
-        QState &st = s.st;
-        st.cand.clear();
-        st.res.clear();
-        st.evicted.clear();
-        st.visited.reset(visited_cap);
-        st.visited.add(g->entry_node);
-        st.cand.push(nq_encode(g->entry_node, entry_score[qi]));
-        st.n_visited = st.n_expanded = 0;
+        s.st = ses ? ses->states[(size_t)qi].get() : &s.own;
+        QState &st = *s.st;
+        st.n_visited = st.n_expanded = st.n_expanded_base = 0;
+        if (opt.resume) {  // searchLayer0 :459-469: the evicted results go back onto the candidate queue
+            s.lvl = 0;
+            for (int64_t k : st.evicted) st.cand.push(k);
+            st.evicted.clear();
+            st.res.clear();
+        } else {           // initializeInternal :334-353
+            s.lvl = g->entry_level;
+            st.cand.clear();
+            st.res.clear();
+            st.evicted.clear();
+            st.exact_cache.clear();
+            st.visited.reset(visited_cap);
+            st.visited.add(g->entry_node);
+            st.cand.push(nq_encode(g->entry_node, entry_score[qi]));
+            st.searched = true;
+        }
+        enter_layer(s);
         return true;
     };
 
@@ -650,58 +836,64 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
             int local_active = 0;
             for (int si = lo; si < hi; ++si) {
                 Slot &s = G.slots[si];
-                QState &st = s.st;
                 if (si + 1 < hi) {  // the next slot's heap roots have gone cold since the last round
-                    const QState &nx = G.slots[si + 1].st;
+                    const QState &nx = *G.slots[si + 1].st;
                     __builtin_prefetch(nx.cand.root_line());
-                    if (!nx.res.empty()) __builtin_prefetch(nx.res.data());
+                    if (!nx.res.empty()) __builtin_prefetch(nx.res.a.data());
                 }
-                st.origin = -1;
-                st.n_pending = 0;
+                s.st->origin = -1;
+                s.st->n_pending = 0;
                 slot_query[si] = -1;
                 origins[si] = -1;
                 ord_index[si] = -1;
                 if (s.query < 0 && !start_query(s)) continue;
                 for (;;) {
+                    QState &st = *s.st;
                     const int rk = s.lvl > 0 ? 1 : rerankK;
+                    const float thr = s.lvl > 0 ? 0.0f : threshold;  // upper layers run with threshold 0 (:276)
+                    const TwoPhaseTracker *trk = (st.tracker && st.tracker->on) ? st.tracker.get() : nullptr;
                     bool layer_done = st.cand.empty();
                     int64_t top = 0;
                     float top_score = 0.0f;
                     if (!layer_done) {
                         top = st.cand.top();
                         top_score = nq_score(top);
-                        layer_done = (int)st.res.size() >= rk && top_score < nq_score(st.res.front());  // stopSearch
+                        layer_done = st.res.size() >= rk && top_score < nq_score(st.res.top());  // stopSearch :358-361
+                        if (!layer_done && trk && trk->should_stop()) layer_done = true;          // :364-366
                     }
                     if (layer_done) {
                         if (s.lvl > 0) {  // setEntryPointsFromPreviousLayer :324-331
-                            for (int64_t k : st.res) st.cand.push(k);
+                            for (int64_t k : st.res.a) st.cand.push(k);
                             for (int64_t k : st.evicted) st.cand.push(k);
                             st.res.clear();
                             st.evicted.clear();
                             s.lvl--;
+                            enter_layer(s);
                             continue;
                         }
-                        fin[s.query].assign(st.res.begin(), st.res.end());
+                        fin[s.query].swap(st.res.a);
+                        st.res.clear();
                         q_visited[s.query] = st.n_visited;
                         q_expanded[s.query] = st.n_expanded;
+                        q_expanded_base[s.query] = st.n_expanded_base;
                         if (!start_query(s)) break;
                         continue;
                     }
                     st.cand.pop();
                     const int32_t node = nq_node(top);
-                    // threshold is 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the
-                    // results; the node is expanded all the same
-                    // and acceptOrds gates the same decision at layer 0 (upper layers run with Bits.ALL, :276)
-                    if (!(top_score >= 0.0f) || (s.lvl == 0 && !accept.accepts(s.query, node))) {
-                    } else if ((int)st.res.size() < rk) {  // addTopCandidate :515-530
-                        st.res.push_back(top);
-                        std::push_heap(st.res.begin(), st.res.end(), std::greater<int64_t>());
-                    } else if (top_score > nq_score(st.res.front())) {
-                        st.evicted.push_back(st.res.front());
-                        std::pop_heap(st.res.begin(), st.res.end(), std::greater<int64_t>());
-                        st.res.back() = top;
-                        std::push_heap(st.res.begin(), st.res.end(), std::greater<int64_t>());
+                    // `topCandidateScore >= threshold` (:437) keeps weaker (with threshold 0: negative / NaN) scores out of
+                    // the results; the node is expanded all the same.  acceptOrds gates the same decision at layer 0
+                    // (upper layers run with Bits.ALL, :276)
+                    if (!(top_score >= thr) || (s.lvl == 0 && !accept.accepts(s.query, node))) {
+                    } else if (st.res.size() < rk) {  // addTopCandidate :515-530
+                        st.res.push(top);
+                    } else if (top_score > nq_score(st.res.top())) {
+                        st.evicted.push_back(st.res.top());
+                        st.res.update_top(top);
                     }
+                    // "skip edge loading if we've found a local maximum and we have enough results" :441-444
+                    if (trk && trk->should_stop() && st.cand.n >= rk - st.res.size()) continue;
+                    if (s.lvl == 0) st.n_expanded_base++;
                     st.n_expanded++;
                     const int32_t *row = g->row(s.lvl, node);
                     if (!row) continue;  // node without a row at this level: nothing to score
@@ -770,9 +962,10 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
         pool->parallel_for(SGn, [&](int lo, int hi) {
             for (int si = lo; si < hi; ++si) {
                 Slot &s = G.slots[si];
-                QState &st = s.st;
+                QState &st = *s.st;
                 if (si + 1 < hi) __builtin_prefetch(G.h_sc + (size_t)(si + 1) * W);
                 if (st.origin < 0) continue;
+                TwoPhaseTracker *trk = (st.tracker && st.tracker->on) ? st.tracker.get() : nullptr;
                 const float *sc = G.h_sc + (size_t)si * W;
                 if (ord_index[si] < 0) {  // fused layer 0
                     const int32_t *row = g->row(0, st.origin);
@@ -780,12 +973,14 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
                     while (mask) {  // ascending bit order == neighbour order
                         const int i = __builtin_ctzll(mask);
                         mask &= mask - 1;
+                        if (trk) trk->track(sc[i]);
                         st.cand.push(nq_encode(row[i], sc[i]));
                         st.n_visited++;
                     }
                 } else {
                     const int32_t *o = ords + (size_t)ord_index[si] * W;
                     for (int j = 0; j < st.n_pending; ++j) {
+                        if (trk) trk->track(sc[j]);
                         st.cand.push(nq_encode(o[j], sc[j]));
                         st.n_visited++;
                     }
@@ -831,53 +1026,162 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
         fprintf(stderr, "[jv graph_search] Q=%d slots=%d groups=%d threads=%d rounds=%ld host %.2f ms, gpu-wait %.2f ms\n", Q,
                 S_total, NG, pool->size(), n_rounds, t_host, t_wait);
 
-    // ---- reranking :471-507 ----
+    // ---- reranking :471-507.  The exact scores come from the GPU (one gather over every position that needs one); the
+    //      selection itself is NodeQueue.rerank's loop (:160-230) over each query's heap ARRAY, on the host: an entry is kept
+    //      while the bounded queue has room or its exact score is STRICTLY better than the worst kept, so exact-score ties at
+    //      the K-th place resolve as in the reference. ----
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    OutStage oi, osc;
-    JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_scratch2, &oi));
-    JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * topK, ctx->d_scratch3, &osc));
-    const size_t c1 = (size_t)Q * rerankK;
-    JV_TRY(ctx->h_in.reserve(sizeof(int32_t) * c1 + sizeof(float) * c1));
-    int32_t *h_cand = (int32_t *)ctx->h_in.ptr;
-    float *h_cand_sc = (float *)(h_cand + c1);
-    pool->parallel_for(Q, [&](int lo, int hi) {
-        for (int q = lo; q < hi; ++q) {
-            const std::vector<int64_t> &r = fin[q];
-            for (int i = 0; i < rerankK; ++i) {
-                const bool have = i < (int)r.size();
-                h_cand[(size_t)q * rerankK + i] = have ? nq_node(r[i]) : -1;
-                h_cand_sc[(size_t)q * rerankK + i] = have ? nq_score(r[i]) : -INFINITY;
+    int Rmax = 0;
+    for (int q = 0; q < Q; ++q) Rmax = std::max(Rmax, (int)fin[q].size());
+    std::vector<float> h_exact;
+    std::vector<int32_t> need;  // Q x Rmax: node whose exact score the GPU computes for this position, -1 = none
+    if (vectors && Rmax > 0) {
+        const size_t c1 = (size_t)Q * Rmax;
+        need.assign(c1, -1);
+        pool->parallel_for(Q, [&](int lo, int hi) {
+            for (int q = lo; q < hi; ++q) {
+                const std::vector<int64_t> &r = fin[q];
+                const QState *st = ses ? ses->states[(size_t)q].get() : nullptr;
+                int above = 0, best = -1;
+                float best_score = -INFINITY;
+                for (int i = 0; i < (int)r.size(); ++i) {
+                    const float sc = nq_score(r[i]);
+                    if (sc > best_score) { best_score = sc; best = i; }
+                    if (sc >= opt.rerank_floor) {
+                        ++above;
+                        const int32_t id = nq_node(r[i]);
+                        if (!st || !st->exact_cache.count(id)) need[(size_t)q * Rmax + i] = id;
+                    }
+                }
+                if (above == 0 && best >= 0) {  // nothing above the floor: the best one is reranked (:186-191)
+                    const int32_t id = nq_node(r[best]);
+                    if (!st || !st->exact_cache.count(id)) need[(size_t)q * Rmax + best] = id;
+                }
             }
+        });
+        JV_TRY(ctx->h_in.reserve(sizeof(int32_t) * c1));
+        JV_TRY(ctx->d_in.reserve(sizeof(int32_t) * c1 + sizeof(float) * c1 + sizeof(float) * (size_t)Q + 256));
+        JV_TRY(ctx->h_out.reserve(sizeof(float) * c1));
+        memcpy(ctx->h_in.ptr, need.data(), sizeof(int32_t) * c1);
+        int32_t *d_cand = (int32_t *)ctx->d_in.ptr;
+        float *d_cand_sc = (float *)(d_cand + c1);
+        float *d_qnorm = d_cand_sc + c1;
+        JV_HIP_CHECK(hipMemcpyAsync(d_cand, ctx->h_in.ptr, sizeof(int32_t) * c1, hipMemcpyHostToDevice, ctx->stream));
+        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
+        {
+            ProfScope ps(ctx, R_EXACT);
+            JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf, d_cand, Rmax,
+                                       d_cand_sc, d_qnorm, vectors->d_sqnorm));
+        }
+        JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_cand_sc, sizeof(float) * c1, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        h_exact.assign((const float *)ctx->h_out.ptr, (const float *)ctx->h_out.ptr + c1);
+    }
+    std::vector<int32_t> r_ids((size_t)Q * topK, -1);
+    std::vector<float> r_sc((size_t)Q * topK, -INFINITY);
+    std::vector<int32_t> r_count((size_t)Q, 0);
+    std::vector<int64_t> r_reranked((size_t)Q, 0);
+    std::vector<float> r_worst((size_t)Q, INFINITY);
+    pool->parallel_for(Q, [&](int lo, int hi) {
+        JMinHeap rer;
+        std::vector<int32_t> ids;
+        std::vector<float> ex;
+        for (int q = lo; q < hi; ++q) {
+            std::vector<int64_t> &r = fin[q];
+            QState *st = ses ? ses->states[(size_t)q].get() : nullptr;
+            const int n = (int)r.size();
+            int32_t *oid = r_ids.data() + (size_t)q * topK;
+            float *osc = r_sc.data() + (size_t)q * topK;
+            JMinHeap *from = &rer;
+            JMinHeap approx;
+            rer.clear();
+            if (!vectors) {  // cachingReranker == null :478-487: the worst approximate results go to evictedResults
+                approx.a.swap(r);
+                while (approx.size() > topK) {
+                    const int64_t k = approx.pop();
+                    if (st) st->evicted.push_back(k);
+                }
+                from = &approx;
+            } else {
+                ids.assign((size_t)n, -1);
+                ex.assign((size_t)n, 0.0f);
+                int above = 0, best = -1;
+                float best_score = -INFINITY;
+                auto exact_of = [&](int i, int32_t id) {
+                    if (need[(size_t)q * Rmax + i] >= 0) {
+                        const float v = h_exact[(size_t)q * Rmax + i];
+                        r_reranked[q]++;
+                        if (st) st->exact_cache.emplace(id, v);
+                        return v;
+                    }
+                    return st->exact_cache.find(id)->second;  // only a session skips the GPU for a position
+                };
+                for (int i = 0; i < n; ++i) {
+                    const float sc = nq_score(r[i]);
+                    if (sc > best_score) { best_score = sc; best = i; }
+                    if (sc >= opt.rerank_floor) {
+                        ids[i] = nq_node(r[i]);
+                        ex[i] = exact_of(i, ids[i]);
+                        ++above;
+                    }
+                }
+                if (above == 0 && best >= 0) {
+                    ids[best] = nq_node(r[best]);
+                    ex[best] = exact_of(best, ids[best]);
+                }
+                auto approx_of = [&](int32_t node) {
+                    for (int j = 0; j < n; ++j)
+                        if (ids[j] == node) return nq_score(r[j]);
+                    return -INFINITY;
+                };
+                for (int i = 0; i < n; ++i) {
+                    if (ids[i] == -1) {
+                        if (st) st->evicted.push_back(r[i]);
+                        continue;
+                    }
+                    if (rer.size() < topK) {
+                        rer.push(nq_encode(ids[i], ex[i]));
+                    } else if (ex[i] > nq_score(rer.top())) {
+                        if (st) {
+                            const int32_t ev = nq_node(rer.top());
+                            st->evicted.push_back(nq_encode(ev, approx_of(ev)));
+                        }
+                        rer.update_top(nq_encode(ids[i], ex[i]));
+                    } else if (st) {
+                        st->evicted.push_back(r[i]);
+                    }
+                }
+                if (rer.size() >= topK)
+                    for (int64_t k : rer.a) r_worst[q] = std::min(r_worst[q], approx_of(nq_node(k)));
+            }
+            const int nres = from->size();
+            r_count[q] = nres;
+            for (int i = nres - 1; i >= 0; --i) {  // :497-502: the worst is popped first
+                const int64_t k = from->pop();
+                oid[i] = nq_node(k);
+                osc[i] = nq_score(k);
+            }
+            r.clear();
         }
     });
-    // device layout: [cand ids][approx or exact scores][qnorm]
-    JV_TRY(ctx->d_in.reserve(sizeof(int32_t) * c1 + sizeof(float) * c1 + sizeof(float) * (size_t)Q + 256));
-    int32_t *d_cand = (int32_t *)ctx->d_in.ptr;
-    float *d_cand_sc = (float *)(d_cand + c1);
-    float *d_qnorm = d_cand_sc + c1;
-    JV_HIP_CHECK(hipMemcpyAsync(d_cand, h_cand, sizeof(int32_t) * c1 + sizeof(float) * c1, hipMemcpyHostToDevice,
-                                ctx->stream));
-    JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, topK)));
-    if (vectors) {
-        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
-        ProfScope ps(ctx, R_EXACT);
-        JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf,
-                                   d_cand, rerankK, d_cand_sc, d_qnorm, vectors->d_sqnorm));
-    }
-    {
-        ProfScope ps(ctx, R_TOPK);
-        JV_TRY(launch_topk(ctx->stream, ctx, d_cand_sc, d_cand, Q, rerankK, rerankK, 0, topK, (int32_t *)oi.dev,
-                           (float *)osc.dev, ctx->d_scratch.ptr));
-    }
-    JV_TRY(stage_out_end(ctx, oi));
-    JV_TRY(stage_out_end(ctx, osc));
-    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    JV_TRY(copy_out(out_ids, r_ids.data(), sizeof(int32_t) * (size_t)Q * topK));
+    JV_TRY(copy_out(out_scores, r_sc.data(), sizeof(float) * (size_t)Q * topK));
     if (stats) {
         for (int q = 0; q < Q; ++q) {
             stats[2 * q] = q_visited[q];
             stats[2 * q + 1] = q_expanded[q];
         }
     }
+    if (opt.stats4) {
+        for (int q = 0; q < Q; ++q) {
+            opt.stats4[4 * q] = q_visited[q];
+            opt.stats4[4 * q + 1] = q_expanded[q];
+            opt.stats4[4 * q + 2] = q_expanded_base[q];
+            opt.stats4[4 * q + 3] = r_reranked[q];
+        }
+    }
+    if (opt.counts) memcpy(opt.counts, r_count.data(), sizeof(int32_t) * (size_t)Q);
+    if (opt.worst) memcpy(opt.worst, r_worst.data(), sizeof(float) * (size_t)Q);
     return JV_OK;
 }
 
@@ -1157,11 +1461,24 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         JV_TRY(launch_topk(ctx->stream, ctx, d_cand_sc, d_cand, Q, rerankK, rerankK, 0, topK, (int32_t *)oi.dev,
                            (float *)osc.dev, ctx->d_scratch.ptr));
     }
+    // exact-score ties across the K-th place are decided by the order of the reference's result heap array
+    // (NodeQueue.java:197-214), which only the host searcher holds: find those queries, re-run them there
+    const bool tie_check = vectors != nullptr && rerankK > topK && env_int("JVECTOR_HIP_GS_TIE_CHECK", 1) != 0;
+    if (tie_check) {
+        JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
+        ProfScope ps(ctx, R_TOPK);
+        JV_TRY(launch_rerank_ties(ctx->stream, d_cand_sc, d_cand, Q, rerankK, (const float *)osc.dev, (const int32_t *)oi.dev, topK, d_status,
+                                  GS_RERANK_TIE, d_counter));
+    }
     JV_TRY(stage_out_end(ctx, oi));
     JV_TRY(stage_out_end(ctx, osc));
     // stage_out_end stages through ctx->h_out: fetch the per-query counters only after it is done with it
+    const size_t stats_bytes = stats ? sizeof(long long) * 2 * (size_t)Q : 0;
+    JV_TRY(ctx->h_out.reserve(stats_bytes + 64));
+    unsigned int *h_ties = (unsigned int *)((char *)ctx->h_out.ptr + stats_bytes);
+    *h_ties = 0;
+    if (tie_check) JV_HIP_CHECK(hipMemcpyAsync(h_ties, d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     if (stats) {
-        JV_TRY(ctx->h_out.reserve(sizeof(long long) * 2 * (size_t)Q));
         long long *h_stats = (long long *)ctx->h_out.ptr;
         JV_HIP_CHECK(hipMemcpyAsync(h_stats, d_stats, sizeof(long long) * 2 * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1172,9 +1489,19 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     } else {
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
+    const size_t n_ties = *h_ties;
+    if (n_ties > 0) {
+        JV_TRY(ctx->h_out.reserve(sizeof(int32_t) * (size_t)Q));
+        JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_status, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const int32_t *hs = (const int32_t *)ctx->h_out.ptr;
+        for (int q = 0; q < Q; ++q)
+            if (hs[q] == GS_RERANK_TIE) redo.push_back(q);
+        std::sort(redo.begin(), redo.end());
+    }
     if (getenv("JVECTOR_HIP_GRAPH_TIMING"))
-        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d) lds=%zu cand_cap=%d vcap=%zu overflow=%zu -> host %zu\n", Q,
-                workers, per_cu, occ, (int)pair, lds, cand_cap, vcap, n_overflow_first, redo.size());
+        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d) lds=%zu cand_cap=%d vcap=%zu overflow=%zu rerank ties=%zu -> host %zu\n", Q,
+                workers, per_cu, occ, (int)pair, lds, cand_cap, vcap, n_overflow_first, n_ties, redo.size());
     if (redo.empty()) return JV_OK;
 
     // ---- queries that outgrew the fixed-size device structures: same search on the host ----
@@ -1198,8 +1525,10 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
                    sizeof(uint64_t) * (size_t)host_accept.stride_words);
         sub_accept.bits = sub_mask.data();
     }
+    HostSearchOpts sub_opt;
+    sub_opt.accept = sub_accept;
     JV_TRY(graph_search_host(ctx, g, l, codes, fused, vectors, sub.data(), R, vsf, topK, rerankK, sub_ids.data(), sub_sc.data(),
-                             sub_stats.data(), sub_accept));
+                             sub_stats.data(), sub_opt));
     const bool ids_dev = is_device_ptr(out_ids), sc_dev = is_device_ptr(out_scores);
     for (int i = 0; i < R; ++i) {
         const size_t dst = (size_t)redo[i] * topK, src = (size_t)i * topK;
@@ -1278,8 +1607,11 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
                                                 "(shape unsupported by it, or JV_TRAVERSAL_HOST was requested)");
         JV_REQUIRE(!fused, "graph_search: FusedPQ blocks cannot be checked against a device-resident, mutable adjacency; search it with the code store");
     }
-    if (mode != JV_TRAVERSAL_DEVICE || Q == 0)
-        return graph_search_host(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats, host_accept);
+    if (mode != JV_TRAVERSAL_DEVICE || Q == 0) {
+        HostSearchOpts opt;
+        opt.accept = host_accept;
+        return graph_search_host(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats, opt);
+    }
 
     JV_REQUIRE(topK > 0, "graph_search: topK must be positive");
     JV_REQUIRE(rerankK >= topK, "rerankK %d must be >= topK %d", rerankK, topK);  // GraphSearcher.java:233
@@ -1308,6 +1640,114 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
     }
     return graph_search_device(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats, host_accept,
                                dev_accept);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GraphSearcher objects: search with every option, then resume (jvector_hip.h)
+// ---------------------------------------------------------------------------------------------
+int jv_hip_searcher_create(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
+                           const jv_vectors *vectors, jv_searcher **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && g && l && codes && out, "searcher_create: NULL argument");
+    JV_REQUIRE(!g->dev_level0, "searcher_create: a graph whose level 0 lives in device memory has no host adjacency to walk");
+    jv_searcher *s = new jv_searcher();
+    s->g = g;
+    s->luts = l;
+    s->codes = codes;
+    s->fused = fused;
+    s->vectors = vectors;
+    *out = s;
+    return JV_OK;
+}
+
+int jv_hip_searcher_destroy(jv_searcher *s)
+{
+    delete s;
+    return JV_OK;
+}
+
+static int searcher_run(jv_ctx *ctx, jv_searcher *s, int Q, int topK, int rerankK, float threshold, float rerankFloor, bool resume,
+                        int32_t *out_ids, float *out_scores, int32_t *out_counts, int64_t *stats, float *worst)
+{
+    const jv_graph *g = s->g;
+    if (s->fused && Q > 0 && s->fused->count == g->n_nodes && s->fused->maxDegree == g->levels[0].degree &&
+        g->levels[0].nbrs.size() == (size_t)g->n_nodes * s->fused->maxDegree) {
+        JV_TRY(use_device(ctx->device));
+        JV_TRY(check_fused_matches_graph(ctx, const_cast<jv_graph *>(g), s->fused));
+    }
+    HostSearchOpts opt;
+    opt.threshold = threshold;
+    opt.rerank_floor = rerankFloor;
+    opt.session = s;
+    opt.resume = resume;
+    if (s->has_accept) {
+        opt.accept.bits = s->accept.data();
+        opt.accept.stride_words = s->accept_stride;
+    }
+    std::vector<int32_t> counts((size_t)Q);
+    std::vector<int64_t> st4((size_t)Q * 4);
+    std::vector<float> w((size_t)Q);
+    opt.counts = counts.data();
+    opt.stats4 = st4.data();
+    opt.worst = w.data();
+    JV_TRY(graph_search_host(ctx, g, s->luts, s->codes, s->fused, s->vectors, s->queries.data(), Q, s->vsf, topK, rerankK, out_ids,
+                             out_scores, nullptr, opt));
+    if (out_counts) JV_TRY(copy_out(out_counts, counts.data(), sizeof(int32_t) * (size_t)Q));
+    if (stats) JV_TRY(copy_out(stats, st4.data(), sizeof(int64_t) * 4 * (size_t)Q));
+    if (worst) JV_TRY(copy_out(worst, w.data(), sizeof(float) * (size_t)Q));
+    return JV_OK;
+}
+
+int jv_hip_searcher_search(jv_ctx *ctx, jv_searcher *s, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK, float threshold,
+                           float rerankFloor, const uint64_t *accept_bits, int64_t accept_stride_words, int32_t *out_ids,
+                           float *out_scores, int32_t *out_counts, int64_t *stats, float *worst)
+{
+    clear_error();
+    JV_REQUIRE(ctx && s, "searcher_search: NULL argument");
+    CtxBusy busy(ctx);
+    JV_REQUIRE(busy.ok, "searcher_search: this jv_ctx is already inside a call on another thread (one context per host thread)");
+    JV_REQUIRE(Q >= 0 && (Q == 0 || queries), "searcher_search: NULL queries");
+    JV_REQUIRE(s->luts->pq, "searcher_search: the look-up tables have no quantizer");
+    const jv_graph *g = s->g;
+    const int D = s->luts->pq->D;
+    const int64_t words = (g->n_nodes + 63) / 64;
+    JV_REQUIRE(!accept_bits || accept_stride_words == 0 || accept_stride_words >= words,
+               "searcher_search: accept_stride_words %lld is smaller than the %lld words one mask needs", (long long)accept_stride_words,
+               (long long)words);
+    JV_TRY(use_device(ctx->device));
+    s->searched = false;
+    s->Q = Q;
+    s->vsf = vsf;
+    s->queries.resize((size_t)Q * D);
+    if (Q > 0) {
+        if (is_device_ptr(queries)) JV_HIP_CHECK(hipMemcpy(s->queries.data(), queries, sizeof(float) * (size_t)Q * D, hipMemcpyDeviceToHost));
+        else memcpy(s->queries.data(), queries, sizeof(float) * (size_t)Q * D);
+    }
+    s->has_accept = accept_bits != nullptr;
+    s->accept_stride = accept_stride_words;
+    s->accept.clear();
+    if (accept_bits && Q > 0) {
+        const size_t mask_words = accept_stride_words == 0 ? (size_t)words : (size_t)accept_stride_words * (size_t)Q;
+        s->accept.resize(mask_words);
+        if (is_device_ptr(accept_bits)) JV_HIP_CHECK(hipMemcpy(s->accept.data(), accept_bits, sizeof(uint64_t) * mask_words, hipMemcpyDeviceToHost));
+        else memcpy(s->accept.data(), accept_bits, sizeof(uint64_t) * mask_words);
+    }
+    while ((int)s->states.size() < Q) s->states.emplace_back(new QState());
+    JV_TRY(searcher_run(ctx, s, Q, topK, rerankK, threshold, rerankFloor, false, out_ids, out_scores, out_counts, stats, worst));
+    s->searched = true;
+    return JV_OK;
+}
+
+int jv_hip_searcher_resume(jv_ctx *ctx, jv_searcher *s, int additionalK, int rerankK, int32_t *out_ids, float *out_scores,
+                           int32_t *out_counts, int64_t *stats, float *worst)
+{
+    clear_error();
+    JV_REQUIRE(ctx && s, "searcher_resume: NULL argument");
+    CtxBusy busy(ctx);
+    JV_REQUIRE(busy.ok, "searcher_resume: this jv_ctx is already inside a call on another thread (one context per host thread)");
+    JV_REQUIRE(s->searched, "searcher_resume: resume() is only valid after search() (GraphSearcher.java:533-536)");
+    return searcher_run(ctx, s, s->Q, additionalK, rerankK, 0.0f, 0.0f, true, out_ids, out_scores, out_counts, stats, worst);
 }
 
 }  // extern "C"

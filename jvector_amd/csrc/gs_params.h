@@ -9,7 +9,7 @@ namespace jv {
 
 constexpr int GS_MAX_LEVELS = 32;
 constexpr int GS_EVICT_CAP = 128;
-enum : int32_t { GS_OK = 0, GS_OVERFLOW = 1 };
+enum : int32_t { GS_OK = 0, GS_OVERFLOW = 1, GS_RERANK_TIE = 2 /* set by rerank_tie_kernel, not by the traversal */ };
 
 struct GsLevel {
     const int32_t *nbrs;    // count x degree, packed rows padded with -1

@@ -680,3 +680,66 @@ class GraphSearcher:
             self.vectors._h if self.vectors is not None else None, q_p, Q, int(vsf), int(top_k), int(rerank_k), mask_p, stride,
             oi_p, os_p, C.c_void_p(stats.ctypes.data) if return_stats else None))
         return (out_ids, out_sc, stats) if return_stats else (out_ids, out_sc)
+
+    def _session(self):
+        if getattr(self, "_s", None) is None:
+            h = C.c_void_p()
+            check(self.ctx._lib.jv_hip_searcher_create(
+                self.ctx._h, self.graph._h, self.luts._h, self.cv._h, self.fused._h if self.fused is not None else None,
+                self.vectors._h if self.vectors is not None else None, C.byref(h)))
+            self._s = h
+        return self._s
+
+    def _results(self, Q, top_k, call):
+        ids, sc = np.empty((Q, top_k), np.int32), np.empty((Q, top_k), np.float32)
+        counts, stats, worst = np.zeros(Q, np.int32), np.zeros((Q, 4), np.int64), np.zeros(Q, np.float32)
+        check(call(C.c_void_p(ids.ctypes.data), C.c_void_p(sc.ctypes.data), C.c_void_p(counts.ctypes.data),
+                   C.c_void_p(stats.ctypes.data), C.c_void_p(worst.ctypes.data)))
+        return [SearchResult(ids[q, : counts[q]].copy(), sc[q, : counts[q]].copy(), stats[q], worst[q]) for q in range(Q)]
+
+    def search_ex(self, queries, vsf, top_k, rerank_k, threshold=0.0, rerank_floor=0.0, accept=None):
+        """GraphSearcher.search(scoreProvider, topK, rerankK, threshold, rerankFloor, acceptOrds) (GraphSearcher.java:222-243)
+        for every query of the batch, as one GraphSearcher OBJECT per query: the state stays behind for resume().  Returns a
+        list of SearchResult (nodes best first, visited / expanded / expanded_base / reranked counts,
+        worst_approximate_in_topk).  threshold > 0 and rerank_floor behave as in the reference (TwoPhaseTracker,
+        NodeQueue.rerank); these searches run on the host batched searcher."""
+        Q = int(queries.shape[0])
+        q_p, qk = _ptr(queries, np.float32)
+        mask_p, stride, mask = None, 0, None
+        if accept is not None:
+            mask = pack_accept_bits(accept, self.graph.n_nodes)
+            if mask.ndim == 2:
+                if mask.shape[0] != Q:
+                    raise ValueError(f"accept has {mask.shape[0]} rows for {Q} queries")
+                stride = int(mask.shape[1])
+            mask_p = C.c_void_p(mask.ctypes.data)
+        s = self._session()
+        self._session_q = Q
+        return self._results(Q, int(top_k), lambda i, sc, c, st, w: self.ctx._lib.jv_hip_searcher_search(
+            self.ctx._h, s, q_p, Q, int(vsf), int(top_k), int(rerank_k), float(threshold), float(rerank_floor), mask_p, stride,
+            i, sc, c, st, w))
+
+    def resume(self, additional_k, rerank_k):
+        """GraphSearcher.resume(additionalK, rerankK) (:538-547) for every query of the last search_ex: the next
+        additional_k results, none of them returned before."""
+        s = self._session()
+        return self._results(int(getattr(self, "_session_q", 0)), int(additional_k),
+                             lambda i, sc, c, st, w: self.ctx._lib.jv_hip_searcher_resume(
+                                 self.ctx._h, s, int(additional_k), int(rerank_k), i, sc, c, st, w))
+
+    def close(self):
+        if getattr(self, "_s", None) is not None:
+            self.ctx._lib.jv_hip_searcher_destroy(self._s)
+            self._s = None
+
+
+class SearchResult:
+    """SearchResult (B/graph/SearchResult.java): getNodes() best first + the counters of the call that produced it."""
+
+    def __init__(self, ids, scores, stats, worst):
+        self.ids, self.scores = ids, scores
+        self.visited, self.expanded, self.expanded_base, self.reranked = (int(x) for x in stats)
+        self.worst_approximate_in_topk = float(worst)
+
+    def __len__(self):
+        return len(self.ids)

@@ -1271,9 +1271,9 @@ void jvo_rerank(const float *queries, const float *cand_vecs, const int32_t *can
  * Score functions: PQDecoder / FusedPQDecoder arithmetic (jvo_adc_score over the code of the node);
  * in fused mode layer-0 neighbour scores come from the origin's packed block
  * (FusedPQDecoder.similarityToNeighbor :104-111) — identical values by construction.
- * Deviation (documented): the final top-K after rerank is taken under the NodeQueue order on the exact scores;
- * the reference's membership for EXACT-score ties at the K-th place depends on heap array order (NodeQueue.java:
- * 197-214).  Distinct exact scores => identical results.
+ * The rerank walks the result heap in array order (NodeQueue.java:197-214), so membership for exact-score ties at the K-th
+ * place is the reference's too.  jvo_searcher_* below restates the remaining options: threshold > 0 (ScoreTracker.java:80-140),
+ * rerankFloor, resume() and the rerankedCount / worstApproximateInTopK outputs.
  * ---------------------------------------------------------------------------------------- */
 /* NodeQueue over a BoundedLongHeap / GrowableLongHeap (B/graph/NodeQueue.java:36-58,83-85,125-137; B/util/
  * BoundedLongHeap.java:58-69): exported so that the reference's TestNodeQueue literals can pin it.
@@ -1325,6 +1325,11 @@ static int64_t lh_pop(lheap *h)
     h->a[0] = h->a[--h->n];
     heap_sift_down(h->a, h->n, 0);
     return top;
+}
+static void jvo_nodequeue_push_lh(lheap *h, int order, int32_t node, float score)
+{
+    int64_t v = jvo_nodequeue_encode(node, score);
+    lh_push(h, order ? -1 - v : v);
 }
 static inline int32_t key_node(int64_t k) { return (int32_t)~(uint32_t)(k & 0xFFFFFFFFLL); }
 static inline float key_score(int64_t k) { return jvo_sortable_int_to_float((int32_t)(k >> 32)); }
@@ -1429,15 +1434,22 @@ void jvo_graph_search_filtered(const jvo_graph *g, const jvo_pq *pq, const uint8
             evicted.n = 0;
         }
     }
-    /* reranking */
+    /* reranking :471-507.  With a reranker: NodeQueue.rerank :160-230 walks approximateResults in HEAP ARRAY order (res.a is
+     * that array: the same push / updateTop sequence on the same binary heap, AbstractLongHeap.java:77-85,158-187) and keeps
+     * an entry only while the bounded queue has room or its exact score is STRICTLY better than the worst kept (:204-211), so
+     * which of several candidates tied on the exact score at the K-th place survives follows that order.  Without one
+     * (:478-487): the worst approximate results are popped until topK remain. */
     int64_t *fin = (int64_t *)malloc(sizeof(int64_t) * (size_t)(res.n > 0 ? res.n : 1));
     int nf = 0;
     if (vecs) {
         for (int i = 0; i < res.n; i++) {
             int32_t id = key_node(res.a[i]);
-            fin[nf++] = jvo_nodequeue_encode(id, compare_x(vsf, query, vecs + (size_t)id * pq->D, pq->D));
+            float ex = compare_x(vsf, query, vecs + (size_t)id * pq->D, pq->D);
+            if (nf < topK) jvo_nodequeue_push(fin, &nf, 0, 0, id, ex);
+            else if (ex > key_score(fin[0])) jvo_nodequeue_push(fin, &nf, topK, 0, id, ex);
         }
     } else {
+        while (res.n > topK) lh_pop(&res);
         for (int i = 0; i < res.n; i++) fin[nf++] = res.a[i];
     }
     qsort(fin, (size_t)nf, sizeof(int64_t), cmp_desc_i64);
@@ -1448,4 +1460,293 @@ void jvo_graph_search_filtered(const jvo_graph *g, const jvo_pq *pq, const uint8
     if (stats) { stats[0] = n_visited; stats[1] = n_expanded; }
 #undef SCORE
     free(fin); free(cand.a); free(res.a); free(evicted.a); free(lut); free(amag);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * GraphSearcher as an OBJECT — the options the one-shot function above leaves out:
+ *   threshold > 0 : ScoreTrackerFactory.getScoreTracker (B/graph/ScoreTracker.java:38-58) hands layer 0 a TwoPhaseTracker
+ *                   (:80-140); stopSearch (GraphSearcher.java:355-369) and the edge-loading skip (:441-444) consult it, and
+ *                   `topCandidateScore >= threshold` (:437) keeps weaker nodes out of the results.
+ *   rerankFloor   : NodeQueue.rerank (B/graph/NodeQueue.java:160-230) scores exactly only the entries whose approximate
+ *                   score reaches the floor (or the best one when none does); the rest go to evictedResults.
+ *   resume()      : GraphSearcher.java:459-469,509-513,538-547 — candidates, visited and evictedResults survive a search;
+ *                   resume pushes the evicted nodes back and continues layer 0.  CachingReranker (:554-581) remembers exact
+ *                   scores, rerankedCount counts the new ones.
+ * TwoPhaseTracker.shouldStop calls org.apache.commons.math3.stat.StatUtils.percentile(recentScores, 99) — commons-math3
+ * 3.6.1 (pom.xml:189-190), a dependency that is not in /root/reference.  Restated from its published algorithm (class
+ * Percentile, EstimationType.LEGACY, the default): pos = (p / 100) * (n + 1); pos < 1 -> min; pos >= n -> max; else with the
+ * sorted values, lower = x[floor(pos) - 1], upper = x[floor(pos)], result = lower + (pos - floor(pos)) * (upper - lower),
+ * all in double.  jvo_percentile_legacy exports it so the class' documented examples can pin it.
+ * ---------------------------------------------------------------------------------------- */
+static int cmp_asc_f64(const void *x, const void *y)
+{
+    double a = *(const double *)x, b = *(const double *)y;
+    return a < b ? -1 : (a > b ? 1 : 0);
+}
+double jvo_percentile_legacy(const double *values, int n, double p)
+{
+    if (n <= 0) return NAN;
+    if (n == 1) return values[0];
+    double *w = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(w, values, sizeof(double) * (size_t)n);
+    qsort(w, (size_t)n, sizeof(double), cmp_asc_f64);
+    const double q = p / 100.0;
+    const double pos = q == 1.0 ? (double)n : q * (double)(n + 1);
+    const double fpos = floor(pos);
+    const int ipos = (int)fpos;
+    const double dif = pos - fpos;
+    double r;
+    if (pos < 1.0) r = w[0];
+    else if (pos >= (double)n) r = w[n - 1];
+    else { const double lower = w[ipos - 1], upper = w[ipos]; r = lower + dif * (upper - lower); }
+    free(w);
+    return r;
+}
+
+#define JVO_RECENT_SCORES_TRACKED 500  /* ScoreTracker.java:81 */
+#define JVO_BEST_SCORES_TRACKED 100    /* :82 */
+struct jvo_searcher {
+    const jvo_graph *g; const jvo_pq *pq; const uint8_t *codes; const float *vecs; int vsf, fused;
+    float *lut, *amag, *query; const float *am; float bmag;
+    uint8_t *visited;                 /* IntHashSet visited (:64) */
+    lheap cand, res, evicted, rer;    /* candidates (keys stored as -1 - v: MAX_HEAP), approximateResults, evictedResults
+                                         (NodesUnsorted: plain list, `a` used as an array), rerankedResults */
+    uint64_t *accept; int has_accept; /* this.acceptOrds (:338), kept for resume */
+    uint8_t *cached; float *cache_val; int64_t rerank_calls; /* CachingReranker :554-581 */
+    int64_t visitedCount, expandedCount, expandedBase;
+    /* TwoPhaseTracker */
+    double recent[JVO_RECENT_SCORES_TRACKED]; int recent_idx; int obs; double thr; int tracking;
+    int32_t best[JVO_BEST_SCORES_TRACKED]; int n_best;
+    int searched;
+};
+
+jvo_searcher *jvo_searcher_new(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes, const float *vecs, int vsf,
+                               int fused)
+{
+    jvo_searcher *s = (jvo_searcher *)calloc(1, sizeof(jvo_searcher));
+    s->g = g; s->pq = pq; s->codes = codes; s->vecs = vecs; s->vsf = vsf; s->fused = fused;
+    s->lut = (float *)malloc(sizeof(float) * (size_t)pq->M * pq->k);
+    s->amag = (float *)malloc(sizeof(float) * (size_t)pq->M * pq->k);
+    s->query = (float *)malloc(sizeof(float) * (size_t)pq->D);
+    s->visited = (uint8_t *)calloc((size_t)g->n_nodes, 1);
+    s->accept = (uint64_t *)calloc((size_t)(g->n_nodes + 63) / 64, sizeof(uint64_t));
+    s->cached = (uint8_t *)calloc((size_t)g->n_nodes, 1);
+    s->cache_val = (float *)malloc(sizeof(float) * (size_t)g->n_nodes);
+    return s;
+}
+void jvo_searcher_free(jvo_searcher *s)
+{
+    if (!s) return;
+    free(s->lut); free(s->amag); free(s->query); free(s->visited); free(s->accept); free(s->cached); free(s->cache_val);
+    free(s->cand.a); free(s->res.a); free(s->evicted.a); free(s->rer.a);
+    free(s);
+}
+
+static void ev_add(lheap *h, int64_t key)  /* NodesUnsorted.add */
+{
+    if (h->n == h->cap) { h->cap = h->cap ? h->cap * 2 : 64; h->a = (int64_t *)realloc(h->a, sizeof(int64_t) * (size_t)h->cap); }
+    h->a[h->n++] = key;
+}
+static void tr_reset(jvo_searcher *s, float threshold)  /* getScoreTracker :38-58, TwoPhaseTracker.reset :104-108 */
+{
+    s->tracking = threshold > 0;
+    s->n_best = 0; s->obs = 0; s->thr = (double)threshold;
+}
+static void tr_track(jvo_searcher *s, float score)  /* :110-116 */
+{
+    if (!s->tracking) return;
+    int32_t v = jvo_float_to_sortable_int(score);
+    if (s->n_best < JVO_BEST_SCORES_TRACKED) {  /* BoundedLongHeap.push: min-heap of the best scores */
+        int i = s->n_best++;
+        s->best[i] = v;
+        while (i > 0 && s->best[(i - 1) / 2] > s->best[i]) { int p = (i - 1) / 2; int32_t t = s->best[i]; s->best[i] = s->best[p]; s->best[p] = t; i = p; }
+    } else if (!(v < s->best[0])) {
+        s->best[0] = v;
+        for (int i = 0;;) {
+            int l = 2 * i + 1, r = l + 1, m = i;
+            if (l < s->n_best && s->best[l] < s->best[m]) m = l;
+            if (r < s->n_best && s->best[r] < s->best[m]) m = r;
+            if (m == i) break;
+            int32_t t = s->best[i]; s->best[i] = s->best[m]; s->best[m] = t; i = m;
+        }
+    }
+    s->recent[s->recent_idx] = (double)score;
+    s->recent_idx = (s->recent_idx + 1) % JVO_RECENT_SCORES_TRACKED;
+    s->obs++;
+}
+static int tr_should_stop(const jvo_searcher *s)  /* :118-137 */
+{
+    if (!s->tracking) return 0;
+    if (s->obs < JVO_RECENT_SCORES_TRACKED) return 0;
+    if (s->obs % 100 != 0) return 0;
+    double windowMedian = jvo_percentile_legacy(s->recent, JVO_RECENT_SCORES_TRACKED, 99);
+    double worstBestScore = (double)jvo_sortable_int_to_float(s->best[0]);
+    return windowMedian < worstBestScore && windowMedian < s->thr;
+}
+
+static float searcher_score(const jvo_searcher *s, int32_t node)
+{
+    return adc_score_x(s->vsf, s->pq->M, s->pq->k, s->lut, s->am, s->bmag, s->codes + (size_t)node * s->pq->M);
+}
+
+/* searchOneLayer :406-457 */
+static void searcher_one_layer(jvo_searcher *s, int rk, float threshold, int level, int use_accept)
+{
+    const jvo_graph *g = s->g;
+    tr_reset(s, threshold);
+    while (s->cand.n > 0) {
+        int64_t topKey = -1 - s->cand.a[0];
+        float topScore = key_score(topKey);
+        if (s->res.n >= rk && topScore < key_score(s->res.a[0])) break;  /* stopSearch :358-361 */
+        if (threshold > 0 && tr_should_stop(s)) break;                     /* :364-366 */
+        lh_pop(&s->cand);
+        int32_t node = key_node(topKey);
+        int ok = !use_accept || !s->has_accept || ((s->accept[node >> 6] >> (node & 63)) & 1);
+        if (ok && topScore >= threshold) {  /* :437; addTopCandidate :515-530 */
+            if (s->res.n < rk) lh_push(&s->res, topKey);
+            else if (topScore > key_score(s->res.a[0])) {
+                ev_add(&s->evicted, s->res.a[0]);
+                s->res.a[0] = topKey;
+                heap_sift_down(s->res.a, s->res.n, 0);
+            }
+        }
+        if (tr_should_stop(s) && s->cand.n >= rk - s->res.n) continue;  /* :441-444 */
+        if (level == 0) s->expandedBase++;
+        s->expandedCount++;
+        const int32_t *row = level_row(g, level, node);
+        if (!row) continue;
+        for (int i = 0; i < g->level_degree[level]; i++) {
+            int32_t nb = row[i];
+            if (nb < 0) break;
+            if (s->visited[nb]) continue;
+            s->visited[nb] = 1;
+            float sc = searcher_score(s, nb);
+            tr_track(s, sc);
+            lh_push(&s->cand, -1 - jvo_nodequeue_encode(nb, sc));
+            s->visitedCount++;
+        }
+    }
+}
+
+static void searcher_layer0(jvo_searcher *s, int topK, int rerankK, float threshold)  /* searchLayer0 :459-469 */
+{
+    s->rer.n = 0;
+    for (int i = 0; i < s->evicted.n; i++) lh_push(&s->cand, -1 - s->evicted.a[i]);
+    s->evicted.n = 0;
+    searcher_one_layer(s, rerankK, threshold, 0, 1);
+    (void)topK;
+}
+
+static float searcher_exact(jvo_searcher *s, int32_t node)  /* CachingReranker.similarityTo :568-576 */
+{
+    if (s->cached[node]) return s->cache_val[node];
+    s->rerank_calls++;
+    float ex = compare_x(s->vsf, s->query, s->vecs + (size_t)node * s->pq->D, s->pq->D);
+    s->cached[node] = 1;
+    s->cache_val[node] = ex;
+    return ex;
+}
+
+/* reranking :471-507; returns the number of results */
+static int searcher_reranking(jvo_searcher *s, int topK, float rerankFloor, int32_t *out_ids, float *out_scores,
+                              int64_t *stats, float *worst_out)
+{
+    int64_t reranked = 0;
+    float worst = INFINITY;
+    lheap *from;
+    if (!s->vecs) {  /* cachingReranker == null :478-487 */
+        while (s->res.n > topK) ev_add(&s->evicted, lh_pop(&s->res));
+        from = &s->res;
+    } else {         /* NodeQueue.rerank :160-230 */
+        const int64_t before = s->rerank_calls;
+        const int n = s->res.n;
+        int32_t *ids = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+        float *ex = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+        float *approxById = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));  /* approximateScoresById, by position */
+        float bestScore = -INFINITY; int bestIndex = -1, above = 0;
+        for (int i = 0; i < n; i++) {
+            float sc = key_score(s->res.a[i]);
+            int32_t id = key_node(s->res.a[i]);
+            approxById[i] = sc;
+            if (sc > bestScore) { bestScore = sc; bestIndex = i; }
+            if (sc >= rerankFloor) { ids[i] = id; ex[i] = searcher_exact(s, id); above++; }
+            else ids[i] = -1;
+        }
+        if (above == 0 && bestIndex >= 0) { ids[bestIndex] = key_node(s->res.a[bestIndex]); ex[bestIndex] = searcher_exact(s, ids[bestIndex]); }
+        /* positions of the kept entries, parallel to s->rer (to find approximate scores again) */
+        for (int i = 0; i < n; i++) {
+            if (ids[i] == -1) { ev_add(&s->evicted, s->res.a[i]); continue; }
+            if (s->rer.n < topK) jvo_nodequeue_push_lh(&s->rer, 0, ids[i], ex[i]);
+            else if (ex[i] > key_score(s->rer.a[0])) {
+                int32_t evNode = key_node(s->rer.a[0]);
+                for (int j = 0; j < n; j++) if (ids[j] == evNode) { ev_add(&s->evicted, jvo_nodequeue_encode(evNode, approxById[j])); break; }
+                s->rer.a[0] = jvo_nodequeue_encode(ids[i], ex[i]);
+                heap_sift_down(s->rer.a, s->rer.n, 0);
+            } else ev_add(&s->evicted, s->res.a[i]);
+        }
+        if (s->rer.n >= topK) {
+            for (int i = 0; i < s->rer.n; i++) {
+                int32_t node = key_node(s->rer.a[i]);
+                for (int j = 0; j < n; j++) if (ids[j] == node) { if (approxById[j] < worst) worst = approxById[j]; break; }
+            }
+        }
+        reranked = s->rerank_calls - before;
+        s->res.n = 0;
+        from = &s->rer;
+        free(ids); free(ex); free(approxById);
+    }
+    const int nres = from->n;
+    for (int i = nres - 1; i >= 0; i--) {  /* :497-502: pop worst first */
+        int64_t k = lh_pop(from);
+        out_ids[i] = key_node(k);
+        out_scores[i] = key_score(k);
+    }
+    for (int i = nres; i < topK; i++) { out_ids[i] = -1; out_scores[i] = -INFINITY; }
+    if (stats) { stats[0] = s->visitedCount; stats[1] = s->expandedCount; stats[2] = s->expandedBase; stats[3] = reranked; }
+    if (worst_out) *worst_out = worst;
+    return nres;
+}
+
+/* search(scoreProvider, topK, rerankK, threshold, rerankFloor, acceptOrds) :222-243.  accept: bit array over node ids or NULL =
+ * Bits.ALL (copied).  out_*: topK entries, best first, (-1, -inf) padded.  stats (nullable): {visitedCount, expandedCount,
+ * expandedCountBaseLayer, rerankedCount}.  Returns the number of results, -1 on rerankK < topK (:233-235). */
+int jvo_searcher_search(jvo_searcher *s, const float *query, int topK, int rerankK, float threshold, float rerankFloor,
+                        const uint64_t *accept, int32_t *out_ids, float *out_scores, int64_t *stats, float *worst_out)
+{
+    const jvo_graph *g = s->g;
+    if (rerankK < topK) return -1;
+    /* initializeInternal :334-353 */
+    memcpy(s->query, query, sizeof(float) * (size_t)s->pq->D);
+    s->am = (s->vsf == JVO_COSINE && s->pq->self_magnitudes) ? s->pq->self_magnitudes : s->amag;
+    if (s->fused) jvo_fuseddecoder_init(s->pq, query, s->vsf, s->lut, s->am == s->amag ? s->amag : NULL, &s->bmag);
+    else jvo_pqdecoder_init(s->pq, query, s->vsf, s->lut, s->am == s->amag ? s->amag : NULL, &s->bmag);
+    s->has_accept = accept != NULL;
+    if (accept) memcpy(s->accept, accept, sizeof(uint64_t) * (size_t)((g->n_nodes + 63) / 64));
+    memset(s->cached, 0, (size_t)g->n_nodes);  /* a new CachingReranker per search :104-112 */
+    s->rerank_calls = 0;
+    s->res.n = s->evicted.n = s->cand.n = s->rer.n = 0;
+    memset(s->visited, 0, (size_t)g->n_nodes);
+    s->visited[g->entry_node] = 1;
+    lh_push(&s->cand, -1 - jvo_nodequeue_encode(g->entry_node, searcher_score(s, g->entry_node)));
+    s->visitedCount = s->expandedCount = s->expandedBase = 0;
+    s->searched = 1;
+    /* internalSearch :263-282 */
+    for (int lvl = g->entry_level; lvl > 0; lvl--) {
+        searcher_one_layer(s, 1, 0.0f, lvl, 0);
+        for (int i = 0; i < s->res.n; i++) lh_push(&s->cand, -1 - s->res.a[i]);  /* setEntryPointsFromPreviousLayer */
+        for (int i = 0; i < s->evicted.n; i++) lh_push(&s->cand, -1 - s->evicted.a[i]);
+        s->res.n = s->evicted.n = 0;
+    }
+    searcher_layer0(s, topK, rerankK, threshold);
+    return searcher_reranking(s, topK, rerankFloor, out_ids, out_scores, stats, worst_out);
+}
+
+/* resume(additionalK, rerankK) :538-547 (threshold = rerankFloor = 0).  -1 when no search came first. */
+int jvo_searcher_resume(jvo_searcher *s, int additionalK, int rerankK, int32_t *out_ids, float *out_scores, int64_t *stats,
+                        float *worst_out)
+{
+    if (!s->searched || rerankK < additionalK) return -1;
+    s->visitedCount = s->expandedCount = s->expandedBase = 0;
+    searcher_layer0(s, additionalK, rerankK, 0.0f);
+    return searcher_reranking(s, additionalK, 0.0f, out_ids, out_scores, stats, worst_out);
 }

@@ -158,6 +158,22 @@ void jvo_graph_search_filtered(const jvo_graph *g, const jvo_pq *pq, const uint8
                                const float *query, int vsf, int fused, int topK, int rerankK, const uint64_t *accept,
                                int32_t *out_ids, float *out_scores, int64_t *stats);
 
+/* GraphSearcher as an object: threshold > 0 (TwoPhaseTracker), rerankFloor, resume(), rerankedCount and
+ * worstApproximateInTopK (GraphSearcher.java:222-243,355-369,406-547; NodeQueue.java:160-230; ScoreTracker.java:38-140).
+ * The graph / pq / codes / vecs pointers must outlive the searcher.  stats (nullable): {visitedCount, expandedCount,
+ * expandedCountBaseLayer, rerankedCount}.  Both calls return the number of results written (<= topK; the rest of the topK
+ * output slots are (-1, -inf)), or -1 for an illegal argument (rerankK < topK; resume before search). */
+typedef struct jvo_searcher jvo_searcher;
+jvo_searcher *jvo_searcher_new(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes, const float *vecs, int vsf,
+                               int fused);
+void jvo_searcher_free(jvo_searcher *s);
+int jvo_searcher_search(jvo_searcher *s, const float *query, int topK, int rerankK, float threshold, float rerankFloor,
+                        const uint64_t *accept, int32_t *out_ids, float *out_scores, int64_t *stats, float *worst_out);
+int jvo_searcher_resume(jvo_searcher *s, int additionalK, int rerankK, int32_t *out_ids, float *out_scores, int64_t *stats,
+                        float *worst_out);
+/* org.apache.commons.math3 (3.6.1) StatUtils.percentile = Percentile, EstimationType.LEGACY, restated from its documentation */
+double jvo_percentile_legacy(const double *values, int n, double p);
+
 /* exact rerank of pre-gathered candidate rows (Q x R x D), one query per worker thread */
 void jvo_rerank(const float *queries, const float *cand_vecs, const int32_t *cand_ids, int Q, int R, int D, int vsf,
                 int topK, int32_t *out_ids, float *out_scores, int nthreads);

@@ -86,6 +86,65 @@ class OracleGraph:
                                         stats[q].ctypes.data_as(C.POINTER(C.c_int64)))
         return ids, sc, stats
 
+    def searcher(self, pq, codes, vecs, vsf, fused=False):
+        return OracleSearcher(self, pq, codes, vecs, vsf, fused)
+
+
+class SearchResult:
+    """SearchResult (B/graph/SearchResult.java): nodes best first, the counters, worstApproximateScoreInTopK."""
+
+    def __init__(self, ids, scores, stats, worst):
+        self.ids, self.scores = ids, scores
+        self.visited, self.expanded, self.expanded_base, self.reranked = (int(x) for x in stats)
+        self.worst_approximate_in_topk = float(worst)
+
+    def __len__(self):
+        return len(self.ids)
+
+
+class OracleSearcher:
+    """One GraphSearcher instance (jvo_searcher_*): search(...) then any number of resume(...)."""
+
+    def __init__(self, graph, pq, codes, vecs, vsf, fused=False):
+        self._keep = (graph, pq, np.ascontiguousarray(codes, np.uint8), None if vecs is None else f32(vecs))
+        _, _, c, v = self._keep
+        self._top = 0
+        self._h = lib().jvo_searcher_new(C.byref(graph._s), pq.ref, _u8(c), None if v is None else _f(v), vsf, 1 if fused else 0)
+
+    def close(self):
+        if self._h:
+            lib().jvo_searcher_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _result(self, n, top_k, ids, sc, stats, worst):
+        if n < 0:
+            raise ValueError("illegal argument (rerankK < topK, or resume before search)")
+        return SearchResult(ids[:n].copy(), sc[:n].copy(), stats, worst.value)
+
+    def search(self, query, top_k, rerank_k, threshold=0.0, rerank_floor=0.0, accept=None):
+        ids, sc = np.empty(max(top_k, 1), np.int32), np.empty(max(top_k, 1), np.float32)
+        stats, worst = np.zeros(4, np.int64), C.c_float(0)
+        m = None if accept is None else pack_accept_bits(accept)
+        n = lib().jvo_searcher_search(self._h, _f(f32(query)), top_k, rerank_k, threshold, rerank_floor,
+                                      None if m is None else m.ctypes.data_as(C.POINTER(C.c_uint64)), _i32(ids), _f(sc),
+                                      stats.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(worst))
+        return self._result(n, top_k, ids, sc, stats, worst)
+
+    def resume(self, additional_k, rerank_k):
+        ids, sc = np.empty(max(additional_k, 1), np.int32), np.empty(max(additional_k, 1), np.float32)
+        stats, worst = np.zeros(4, np.int64), C.c_float(0)
+        n = lib().jvo_searcher_resume(self._h, additional_k, rerank_k, _i32(ids), _f(sc),
+                                      stats.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(worst))
+        return self._result(n, additional_k, ids, sc, stats, worst)
+
+
+def percentile_legacy(values, p):
+    v = np.ascontiguousarray(values, np.float64)
+    return lib().jvo_percentile_legacy(v.ctypes.data_as(C.POINTER(C.c_double)), len(v), float(p))
+
 
 _lib = None
 
@@ -147,6 +206,12 @@ def lib():
             C.POINTER(C.c_uint64), i32p, fp, C.POINTER(C.c_int64))
         sig("jvo_graph_search", None, C.POINTER(_Graph), pqp, u8p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp,
             C.POINTER(C.c_int64))
+        sig("jvo_searcher_new", C.c_void_p, C.POINTER(_Graph), pqp, u8p, fp, C.c_int, C.c_int)
+        sig("jvo_searcher_free", None, C.c_void_p)
+        sig("jvo_searcher_search", C.c_int, C.c_void_p, fp, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64), i32p, fp,
+            C.POINTER(C.c_int64), C.POINTER(C.c_float))
+        sig("jvo_searcher_resume", C.c_int, C.c_void_p, C.c_int, C.c_int, i32p, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float))
+        sig("jvo_percentile_legacy", C.c_double, C.POINTER(C.c_double), C.c_int, C.c_double)
         sig("jvo_rerank", None, fp, fp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp, C.c_int)
         sig("jvo_pq_layout_compute", C.c_int, C.c_int, C.c_int, C.POINTER(_Layout))
         sig("jvo_pq_parse", C.c_int, u8p, C.c_size_t, i32p, i32p, i32p, i32p, i32p, fp, i32p, C.c_int,

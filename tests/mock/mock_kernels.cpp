@@ -344,6 +344,22 @@ int launch_topk(hipStream_t, const jv_ctx *, const float *d_scores, const int32_
     }
     return JV_OK;
 }
+int launch_rerank_ties(hipStream_t, const float *d_cand_sc, const int32_t *d_cand_ids, int Q, int R, const float *d_out_sc,
+                       const int32_t *d_out_ids, int K, int32_t *d_status, int32_t tie_code, unsigned int *d_count)
+{
+    for (int q = 0; q < Q; ++q) {
+        if (d_out_ids[(int64_t)q * K + K - 1] < 0) continue;
+        const float sk = d_out_sc[(int64_t)q * K + K - 1];
+        int all = 0, sel = 0;
+        for (int i = 0; i < R; ++i) all += d_cand_ids[(int64_t)q * R + i] >= 0 && d_cand_sc[(int64_t)q * R + i] == sk;
+        for (int i = 0; i < K; ++i) sel += d_out_sc[(int64_t)q * K + i] == sk;
+        if (all > sel && d_status[q] == 0) {
+            d_status[q] = tie_code;
+            ++*d_count;
+        }
+    }
+    return JV_OK;
+}
 bool adc_mq_supported(int, const uint8_t *) { return false; }  // the multi-query scan kernels are not mocked
 int launch_adc_mq_store(hipStream_t, const jv_ctx *, const float *, const float *, int, int, int, const uint8_t *, const float *, int64_t,
                         int64_t, int64_t, float *)

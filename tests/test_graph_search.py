@@ -269,3 +269,85 @@ def test_graph_search_baseline_shapes(ctx, baseline_problems, traversal, D, M, l
                 tag = (traversal, use_fused, vsf, rerank)
                 assert np.array_equal(stats, wst), tag
                 assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag
+
+
+# ---- GraphSearcher OBJECTS: threshold > 0, rerankFloor, resume() (jv_hip_searcher_*) ------------------------------------
+def _same(r, w, tag):
+    assert np.array_equal(r.ids, w.ids) and np.array_equal(r.scores, w.scores), tag
+    assert (r.visited, r.expanded, r.expanded_base, r.reranked) == (w.visited, w.expanded, w.expanded_base, w.reranked), tag
+    assert r.worst_approximate_in_topk == w.worst_approximate_in_topk, tag
+
+
+def run_searcher_object_cases(J, ctx, cases=4):
+    """search(topK, rerankK, threshold, rerankFloor, acceptOrds) followed by two resume() calls per query == the oracle's
+    jvo_searcher restatement: nodes, scores, the four counters and worstApproximateScoreInTopK.  Shared with the mock."""
+    VSF = J.VectorSimilarityFunction
+    early = 0
+    for case in range(cases):
+        levels = 1 + case % 3
+        D, M = [(64, 8), (128, 16)][case % 2]
+        v, lv, entry, entry_level, cb, q = build_problem(50 + case, N=3000, D=D, M=M, deg=16, levels=levels)
+        N = len(v)
+        rng = np.random.default_rng(case)
+        if case == 1:                                   # duplicates: exact ties for the heap-order rerank
+            v[1::2] = v[0:-1:2][: len(v[1::2])]
+        q = q[:12]
+        opq = O.OraclePQ(D, M, cb)
+        pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+        vs = J.VectorSet(ctx, v)
+        cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+        codes = cv.get(0, N)
+        og = O.OracleGraph(N, lv, entry, entry_level)
+        graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+        use_fused = case % 2 == 0
+        fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
+        accept = None if case % 2 else (rng.random((len(q), N)) < 0.7)
+        for vsf in VSF:
+            # approximate score levels of this query set, to place thresholds / floors where they bite
+            lvl = np.sort(np.stack([opq.adc_scores(q[i], int(vsf), codes, None, fused=use_fused) for i in range(len(q))]), axis=1)
+            settings = [(10, 40, 0.0, 0.0), (10, 40, 0.0, float(np.median(lvl[:, -15]))), (5, 25, 0.0, 9.0),
+                        (N, N, float(np.median(lvl[:, -120])), 0.0), (300, 300, float(np.median(lvl[:, -40])), float(np.median(lvl[:, -20])))]
+            for rerank in (True, False):
+                s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=16)
+                for top_k, rk, thr, floor in settings:
+                    got = s.search_ex(q, vsf, top_k, rk, threshold=thr, rerank_floor=floor, accept=accept)
+                    got1 = s.resume(7, 20)
+                    got2 = s.resume(30, 30)
+                    for i in range(len(q)):
+                        o = og.searcher(opq, codes, v if rerank else None, int(vsf), fused=use_fused)
+                        acc = None if accept is None else accept[i]
+                        tag = (case, vsf, rerank, top_k, rk, thr, floor, i)
+                        _same(got[i], o.search(q[i], top_k, rk, thr, floor, accept=acc), tag)
+                        _same(got1[i], o.resume(7, 20), tag + ("resume 1",))
+                        _same(got2[i], o.resume(30, 30), tag + ("resume 2",))
+                        o.close()
+                    if thr > 0 and top_k == N:
+                        early += sum(r.visited < N * 0.9 for r in got)
+                s.close()
+        graph.close()
+    # TwoPhaseTracker only answers when its observation count sits on a multiple of 100 (ScoreTracker.java:123-126), so an early
+    # stop is a matter of luck per search — but over all of these some must have stopped before crawling the whole graph
+    assert early > 0, "no threshold search ever stopped early: the tracker path was not exercised"
+
+
+def test_searcher_objects_threshold_floor_resume(ctx):
+    run_searcher_object_cases(J, ctx)
+
+
+def test_searcher_object_errors(ctx):
+    v, lv, entry, entry_level, cb, q = build_problem(3, N=500, D=64, M=8, deg=8, levels=1)
+    pq = J.ProductQuantization.from_codebooks(ctx, 64, 8, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    graph = J.GraphIndex(ctx, len(v), lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=8)
+    with pytest.raises(ValueError):
+        s.resume(5, 5)                                            # resume before search (GraphSearcher.java:533-536)
+    with pytest.raises(ValueError):
+        s.search_ex(q[:4], VSF.DOT_PRODUCT, 10, 5)                # rerankK < topK (:233)
+    with pytest.raises(ValueError):
+        s.search_ex(q[:4], VSF.DOT_PRODUCT, 5, 10, threshold=float("nan"))
+    r = s.search_ex(q[:4], VSF.DOT_PRODUCT, 5, 10)
+    assert all(len(x) == 5 for x in r)
+    with pytest.raises(ValueError):
+        s.resume(10, 5)

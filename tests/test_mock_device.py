@@ -436,6 +436,13 @@ def test_searchers_with_engineered_score_ties(J, ctx, traversal):
     T.run_ties_cases(J, ctx, traversal)
 
 
+def test_searcher_objects_on_the_mock(J, ctx):
+    """threshold > 0 / rerankFloor / resume(): the host searcher's session path against the oracle's GraphSearcher object"""
+    import test_graph_search as T
+    T.run_searcher_object_cases(J, ctx, cases=3)
+    T.test_searcher_object_errors(ctx)
+
+
 @pytest.mark.parametrize("slots,groups", [(64, 1), (96, 3), (700, 2), (1, 1)])
 def test_host_searcher_continuous_batching(J, ctx, monkeypatch, slots, groups):
     """more queries than traversal slots: finished queries hand their slot to the next one (and slot groups alternate);
