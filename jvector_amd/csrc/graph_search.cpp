@@ -1311,10 +1311,23 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     };
     const size_t o_ids = carve(sizeof(int32_t) * c1), o_sc = carve(sizeof(float) * c1), o_qn = carve(sizeof(float) * (size_t)Q);
     const size_t o_stats = carve(sizeof(long long) * 2 * (size_t)Q), o_status = carve(sizeof(int32_t) * (size_t)Q);
-    const size_t o_counter = carve(sizeof(uint32_t));
+    const size_t o_counter = carve(sizeof(uint32_t) * 2);
     const size_t o_qmap = carve(sizeof(int32_t) * (size_t)Q);
     const bool gs_prof = env_int("JVECTOR_HIP_GS_PROF", 0) != 0;
     const size_t o_prof = carve(sizeof(unsigned long long) * 12);
+    // exact-score ties across the K-th place of the rerank are decided by the order of the reference's result-heap array
+    // (NodeQueue.java:197-214): the traversal logs its addTopCandidate sequence (avg ~1 entry per expansion) and
+    // rerank_tie_kernel rebuilds the reference's answer for the (rare) tied queries; an overflowed log sends the query to
+    // the host searcher instead.  JVECTOR_HIP_GS_TIE_CHECK=0 turns the whole check off, JVECTOR_HIP_GS_PUSH_LOG=0 the log only.
+    const bool tie_check = vectors != nullptr && rerankK > topK && env_int("JVECTOR_HIP_GS_TIE_CHECK", 1) != 0;
+    int log_cap = 0;
+    if (tie_check && env_int("JVECTOR_HIP_GS_PUSH_LOG", 1) != 0) {
+        log_cap = std::max(256, 4 * rerankK);
+        const size_t budget = (size_t)1 << 30;
+        if ((size_t)Q * log_cap * sizeof(long long) > budget) log_cap = (int)std::max<size_t>(64, budget / ((size_t)Q * sizeof(long long)));
+        if (const char *e = getenv("JVECTOR_HIP_GS_PUSH_LOG_CAP")) log_cap = std::max(1, atoi(e));
+    }
+    const size_t o_log = carve(sizeof(long long) * (size_t)Q * (size_t)log_cap), o_log_n = carve(sizeof(int32_t) * (size_t)Q);
     JV_TRY(ctx->d_gs_out.reserve(off));
     char *base = (char *)ctx->d_gs_out.ptr;
     int32_t *d_cand = (int32_t *)(base + o_ids);
@@ -1373,6 +1386,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.out_stats = d_stats;
     p.out_status = d_status;
     p.next_query = d_counter;
+    if (log_cap > 0) {
+        p.push_log = (long long *)(base + o_log);
+        p.push_log_n = (int32_t *)(base + o_log_n);
+        p.push_log_cap = log_cap;
+    }
     p.prof = gs_prof ? (unsigned long long *)(base + o_prof) : nullptr;
     {
         ProfScope ps(ctx, R_GSEARCH);
@@ -1463,12 +1481,24 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     }
     // exact-score ties across the K-th place are decided by the order of the reference's result heap array
     // (NodeQueue.java:197-214), which only the host searcher holds: find those queries, re-run them there
-    const bool tie_check = vectors != nullptr && rerankK > topK && env_int("JVECTOR_HIP_GS_TIE_CHECK", 1) != 0;
     if (tie_check) {
-        JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
+        JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t) * 2, ctx->stream));
         ProfScope ps(ctx, R_TOPK);
-        JV_TRY(launch_rerank_ties(ctx->stream, d_cand_sc, d_cand, Q, rerankK, (const float *)osc.dev, (const int32_t *)oi.dev, topK, d_status,
-                                  GS_RERANK_TIE, d_counter));
+        RtParams rt{};
+        rt.cand_sc = d_cand_sc;
+        rt.cand_ids = d_cand;
+        rt.R = rerankK;
+        rt.out_sc = (float *)osc.dev;
+        rt.out_ids = (int32_t *)oi.dev;
+        rt.K = topK;
+        rt.Q = Q;
+        rt.push_log = p.push_log;
+        rt.push_log_n = p.push_log_n;
+        rt.log_cap = p.push_log_cap;
+        rt.rerankK = rerankK;
+        rt.status = d_status;
+        rt.count = d_counter;
+        JV_TRY(launch_rerank_ties(ctx->stream, rt));
     }
     JV_TRY(stage_out_end(ctx, oi));
     JV_TRY(stage_out_end(ctx, osc));
@@ -1476,8 +1506,8 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const size_t stats_bytes = stats ? sizeof(long long) * 2 * (size_t)Q : 0;
     JV_TRY(ctx->h_out.reserve(stats_bytes + 64));
     unsigned int *h_ties = (unsigned int *)((char *)ctx->h_out.ptr + stats_bytes);
-    *h_ties = 0;
-    if (tie_check) JV_HIP_CHECK(hipMemcpyAsync(h_ties, d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    h_ties[0] = h_ties[1] = 0;
+    if (tie_check) JV_HIP_CHECK(hipMemcpyAsync(h_ties, d_counter, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, ctx->stream));
     if (stats) {
         long long *h_stats = (long long *)ctx->h_out.ptr;
         JV_HIP_CHECK(hipMemcpyAsync(h_stats, d_stats, sizeof(long long) * 2 * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
@@ -1489,7 +1519,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     } else {
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     }
-    const size_t n_ties = *h_ties;
+    const size_t n_ties = h_ties[0], n_ties_resolved = h_ties[1];
     if (n_ties > 0) {
         JV_TRY(ctx->h_out.reserve(sizeof(int32_t) * (size_t)Q));
         JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_status, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
@@ -1500,8 +1530,8 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         std::sort(redo.begin(), redo.end());
     }
     if (getenv("JVECTOR_HIP_GRAPH_TIMING"))
-        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d) lds=%zu cand_cap=%d vcap=%zu overflow=%zu rerank ties=%zu -> host %zu\n", Q,
-                workers, per_cu, occ, (int)pair, lds, cand_cap, vcap, n_overflow_first, n_ties, redo.size());
+        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d) lds=%zu cand_cap=%d vcap=%zu overflow=%zu rerank ties=%zu (+%zu to the host) -> host %zu\n", Q,
+                workers, per_cu, occ, (int)pair, lds, cand_cap, vcap, n_overflow_first, n_ties_resolved, n_ties, redo.size());
     if (redo.empty()) return JV_OK;
 
     // ---- queries that outgrew the fixed-size device structures: same search on the host ----

@@ -458,6 +458,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     for (int lvl = p.entry_level; lvl >= 0 && s.status == GS_OK; --lvl) {
         const int rk = lvl > 0 ? 1 : p.rerankK;
         const GsLevel &L = p.lv[lvl];
+        // layer 0 evicts nothing, so the evicted area's first word counts the push-log entries there (lane 0 only: no
+        // register stays live across the loop for it)
+        if (lvl == 0 && p.push_log && lane == 0) *reinterpret_cast<int *>(s.evicted) = 0;
         // ---- searchOneLayer :406-457 ----
         for (;;) {
             if (s.cand_n == 0 && s.spill_n == 0) break;
@@ -490,6 +493,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             if (result && lvl == 0 && acc) {  // acceptOrds: layer 0 only (upper layers run with Bits.ALL, :276)
                 const int32_t tn = gs_key_node(top);
                 result = ((acc[tn >> 6] >> (tn & 63)) & 1ull) != 0;
+            }
+            if (result && lvl == 0 && p.push_log && lane == 0) {  // the addTopCandidate sequence, for rt_body.h's tie resolution
+                const int n_log = *reinterpret_cast<int *>(s.evicted);
+                if (n_log < p.push_log_cap) p.push_log[(int64_t)q * p.push_log_cap + n_log] = top;
+                *reinterpret_cast<int *>(s.evicted) = n_log + 1;
             }
             if (!result) {
                 gs_barrier();
@@ -633,6 +641,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         p.out_stats[2 * (int64_t)q] = n_visited;
         p.out_stats[2 * (int64_t)q + 1] = n_expanded;
         p.out_status[q] = s.status;
+        if (p.push_log) p.push_log_n[q] = s.status == GS_OK ? *reinterpret_cast<int *>(s.evicted) : -1;
     }
     gs_barrier();
     if (PROF && p.prof && lane == 0) {

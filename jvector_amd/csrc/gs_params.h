@@ -56,6 +56,11 @@ struct GsParams {
     float *out_scores;        // [Q][rerankK] their approximate scores, -inf padded
     long long *out_stats;     // [Q][2] visitedCount, expandedCount
     int32_t *out_status;      // [Q] GS_OK / GS_OVERFLOW
+    // the sequence of addTopCandidate calls at layer 0 (NodeQueue keys), kept so that rt_body.h can rebuild the reference's
+    // result-heap ARRAY for queries whose rerank ties on the exact score at the K-th place; nullptr = not recorded
+    long long *push_log;      // [Q][push_log_cap]
+    int32_t *push_log_n;      // [Q] entries offered (> push_log_cap: the log overflowed)
+    int push_log_cap;
     uint32_t *next_query;     // work counter (zeroed by the host before the launch)
     unsigned long long *prof; // developer aid (JVECTOR_HIP_GS_PROF=1): 8 phase counters, see gs_search_one; else nullptr
 };
@@ -68,5 +73,22 @@ inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M whe
     return sizeof(float) * (size_t)D + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + (size_t)evict_cap + (pair_M ? 0 : 64)) +
            sizeof(float) * 32 * (size_t)(pair_M / 2);
 }
+
+// rerank tie resolution (rt_body.h / rerank_tie_kernel)
+struct RtParams {
+    const float *cand_sc;       // [Q][R] exact scores of the kept approximate results (device order)
+    const int32_t *cand_ids;    // [Q][R], -1 = empty slot
+    int R;
+    float *out_sc;              // [Q][K] the selection's result, rewritten for tied queries
+    int32_t *out_ids;
+    int K, Q;
+    const long long *push_log;  // [Q][log_cap] NodeQueue keys in addTopCandidate order, nullptr = no log (mark only)
+    const int32_t *push_log_n;  // [Q] entries offered (may exceed log_cap: overflow)
+    int log_cap, rerankK;
+    int32_t *status;            // [Q] GS_OK -> stays GS_OK (resolved here) or becomes GS_RERANK_TIE (host searcher)
+    unsigned int *count;        // [2]: tied queries left for the host, tied queries resolved here
+};
+
+inline size_t rt_lds_bytes(int rerankK, int K) { return sizeof(long long) * ((size_t)rerankK + (size_t)K + 2); }
 
 }  // namespace jv

@@ -278,8 +278,8 @@ bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const
 size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap = 0);
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy);
 size_t topk_scratch_bytes(int Q, int k);
-int launch_rerank_ties(hipStream_t s, const float *d_cand_sc, const int32_t *d_cand_ids, int Q, int R, const float *d_out_sc,
-                       const int32_t *d_out_ids, int K, int32_t *d_status, int32_t tie_code, unsigned int *d_count);
+struct RtParams;
+int launch_rerank_ties(hipStream_t s, const RtParams &p);
 int launch_topk(hipStream_t s, const jv_ctx *ctx, const float *d_scores, const int32_t *d_ids, int Q, int64_t n,
                 int64_t stride, int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, void *d_scratch,
                 const unsigned int *d_row_counts = nullptr);

@@ -166,6 +166,12 @@ int launch_query_magnitudes(hipStream_t s, const jv_pq *pq, const float *d_cq, i
 // broadcasts; the thread's (centred) sub-vector lives in registers.  Roofline: FP32 VALU (non-fused
 // sub/mul/add, 3*256*SIZE flop per (vector, subspace)), not HBM — see DESIGN.md.
 // ------------------------------------------------------------------------------------------------
+// Two centroids per step: the codebook sits in LDS as PAIRS — entry (i/2, j) = {c[i][j], c[i+1][j]} — so that the two
+// centroids' chains run side by side in the halves of v_pk_add_f32 / v_pk_mul_f32 (each chain still adds its squares in
+// ascending j, the reference's order).  Per centroid 8 pk-sub + 8 pk-mul + 7 pk-add over two = 11.5 VALU slots + 3 for the
+// compare / selects, against 18 when only the subtractions and squares pack (the kernel is VALU-issue bound: r2 ISA count).
+typedef float jv_f2 __attribute__((ext_vector_type(2)));
+
 template <int SIZE>
 __global__ __launch_bounds__(256) void pq_encode_kernel(const float *__restrict__ vecs, int64_t count, int D, int M,
                                                         const float *__restrict__ codebooks,
@@ -174,10 +180,13 @@ __global__ __launch_bounds__(256) void pq_encode_kernel(const float *__restrict_
                                                         const float *__restrict__ centroid,
                                                         uint8_t *__restrict__ codes)
 {
-    __shared__ __attribute__((aligned(16))) float cb[kClusters * SIZE];
+    __shared__ __attribute__((aligned(16))) jv_f2 cb2[(kClusters / 2) * SIZE];
     const int m = blockIdx.y;
     const float *src = codebooks + cb_off[m];
-    for (int j = threadIdx.x; j < kClusters * SIZE; j += 256) cb[j] = src[j];
+    for (int j = threadIdx.x; j < kClusters * SIZE; j += 256) {
+        const int i = j / SIZE, d = j - i * SIZE;
+        reinterpret_cast<float *>(cb2)[((i >> 1) * SIZE + d) * 2 + (i & 1)] = src[j];
+    }
     __syncthreads();
 
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -193,17 +202,22 @@ __global__ __launch_bounds__(256) void pq_encode_kernel(const float *__restrict_
     }
     int best = 0;
     float minDist = 3.4028234663852886e+38f;  // Float.MAX_VALUE
-#pragma unroll 4
-    for (int i = 0; i < kClusters; ++i) {
-        float s = 0.0f;
+#pragma unroll 2
+    for (int i2 = 0; i2 < kClusters / 2; ++i2) {
+        jv_f2 s = {0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < SIZE; ++j) {
-            float d = v[j] - cb[i * SIZE + j];
+            const jv_f2 vv = {v[j], v[j]};
+            const jv_f2 d = vv - cb2[i2 * SIZE + j];
             s += d * d;
         }
-        if (s < minDist) {  // strict '<': first minimum wins; NaN never wins
-            minDist = s;
-            best = i;
+        if (s.x < minDist) {  // strict '<': first minimum wins; NaN never wins
+            minDist = s.x;
+            best = 2 * i2;
+        }
+        if (s.y < minDist) {
+            minDist = s.y;
+            best = 2 * i2 + 1;
         }
     }
     codes[n * M + m] = (uint8_t)best;

@@ -13,6 +13,8 @@
 // a one-workgroup bitonic sort orders them best-first.
 #include "jv_device.h"
 #include "jv_internal.h"
+#include "gs_wave_hip.h"
+#include "rt_body.h"
 
 namespace jv {
 
@@ -261,43 +263,23 @@ int launch_add_id_base(hipStream_t s, int32_t *d_ids, int64_t n, int32_t base)
 }
 
 // ------------------------------------------------------------------------------------------------
-// NodeQueue.rerank (B/graph/NodeQueue.java:197-214) keeps a reranked entry only while the bounded queue has room or its
-// exact score is STRICTLY better than the worst kept one, walking approximateResults' heap ARRAY: when more candidates
-// carry the K-th exact score than the selection returned, which of them the reference keeps follows that array order,
-// which the device traversal does not hold.  This kernel finds those queries (one wave each) and marks them
-// GS_RERANK_TIE; the caller re-runs them on the host searcher, whose result heap IS that array.  Float equality on
-// purpose: -0.0 and 0.0 are a tie for the reference's `>` although their NodeQueue keys differ.
+// Exact-score ties at the K-th place of the rerank (rt_body.h): one wavefront per query detects them and rebuilds the
+// reference's answer from the traversal's push log; what it cannot resolve is marked for the host searcher.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void rerank_tie_kernel(const float *cand_sc, const int32_t *cand_ids, int R, const float *out_sc,
-                                                        const int32_t *out_ids, int K, int Q, int32_t *status, int32_t tie_code,
-                                                        unsigned int *count)
+__global__ __launch_bounds__(64) void rerank_tie_kernel(RtParams p)
 {
+    extern __shared__ __attribute__((aligned(16))) char rt_lds[];
     const int q = blockIdx.x;
-    if (q >= Q) return;
-    const int lane = threadIdx.x;
-    if (out_ids[(int64_t)q * K + K - 1] < 0) return;  // fewer than K results: everything was kept
-    const float sk = out_sc[(int64_t)q * K + K - 1];
-    int all = 0, sel = 0;
-    for (int i = lane; i < R; i += 64)
-        if (cand_ids[(int64_t)q * R + i] >= 0 && cand_sc[(int64_t)q * R + i] == sk) ++all;
-    for (int i = lane; i < K; i += 64)
-        if (out_sc[(int64_t)q * K + i] == sk) ++sel;
-    for (int o = 32; o > 0; o >>= 1) {
-        all += __shfl_xor(all, o);
-        sel += __shfl_xor(sel, o);
-    }
-    if (lane == 0 && all > sel && status[q] == 0) {
-        status[q] = tie_code;
-        atomicAdd(count, 1u);
-    }
+    if (q < p.Q) rt_query(p, q, rt_lds);
 }
 
-int launch_rerank_ties(hipStream_t s, const float *d_cand_sc, const int32_t *d_cand_ids, int Q, int R, const float *d_out_sc,
-                       const int32_t *d_out_ids, int K, int32_t *d_status, int32_t tie_code, unsigned int *d_count)
+int launch_rerank_ties(hipStream_t s, const RtParams &p)
 {
-    if (Q == 0) return JV_OK;
-    hipLaunchKernelGGL(rerank_tie_kernel, dim3(Q), dim3(64), 0, s, d_cand_sc, d_cand_ids, R, d_out_sc, d_out_ids, K, Q, d_status,
-                       tie_code, d_count);
+    if (p.Q == 0) return JV_OK;
+    const size_t lds = rt_lds_bytes(p.rerankK, p.K);
+    if (lds > 64 * 1024)
+        JV_HIP_CHECK(hipFuncSetAttribute((const void *)rerank_tie_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(rerank_tie_kernel, dim3(p.Q), dim3(64), lds, s, p);
     JV_HIP_CHECK(hipGetLastError());
     return JV_OK;
 }

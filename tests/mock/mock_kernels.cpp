@@ -48,6 +48,7 @@ static inline gs_f32x16 gs_mfma_32x32x2(float a, float b, gs_f32x16 c) { return 
 #include "../../jvector_amd/csrc/gs_body.h"
 #include "../../jvector_amd/csrc/km_body.h"
 #include "../../jvector_amd/csrc/rd_body.h"
+#include "../../jvector_amd/csrc/rt_body.h"
 #include "../../oracle/jv_oracle.h"
 
 namespace jv {
@@ -344,20 +345,29 @@ int launch_topk(hipStream_t, const jv_ctx *, const float *d_scores, const int32_
     }
     return JV_OK;
 }
-int launch_rerank_ties(hipStream_t, const float *d_cand_sc, const int32_t *d_cand_ids, int Q, int R, const float *d_out_sc,
-                       const int32_t *d_out_ids, int K, int32_t *d_status, int32_t tie_code, unsigned int *d_count)
+// the shared kernel body (rt_body.h) on the lane emulator, one wavefront per query
+namespace {
+struct RtLaunch {
+    const jv::RtParams *p;
+    int q;
+    char *lds;
+};
+void rt_main(void *a)
 {
-    for (int q = 0; q < Q; ++q) {
-        if (d_out_ids[(int64_t)q * K + K - 1] < 0) continue;
-        const float sk = d_out_sc[(int64_t)q * K + K - 1];
-        int all = 0, sel = 0;
-        for (int i = 0; i < R; ++i) all += d_cand_ids[(int64_t)q * R + i] >= 0 && d_cand_sc[(int64_t)q * R + i] == sk;
-        for (int i = 0; i < K; ++i) sel += d_out_sc[(int64_t)q * K + i] == sk;
-        if (all > sel && d_status[q] == 0) {
-            d_status[q] = tie_code;
-            ++*d_count;
-        }
+    const RtLaunch &L = *(const RtLaunch *)a;
+    jv::rt_query(*L.p, L.q, L.lds);
+}
+}  // namespace
+int launch_rerank_ties(hipStream_t, const RtParams &p)
+{
+    const size_t lds_bytes = jv::rt_lds_bytes(p.rerankK, p.K);
+    char *lds = (char *)aligned_alloc(64, (lds_bytes + 63) & ~(size_t)63);
+    for (int q = 0; q < p.Q; ++q) {
+        memset(lds, 0xA5, lds_bytes);
+        RtLaunch L{&p, q, lds};
+        emu::run_wave(rt_main, &L);
     }
+    free(lds);
     return JV_OK;
 }
 bool adc_mq_supported(int, const uint8_t *) { return false; }  // the multi-query scan kernels are not mocked

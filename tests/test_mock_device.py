@@ -159,6 +159,7 @@ def test_device_traversal_retry_and_growth_paths(J, ctx, monkeypatch, capfd):
     import test_zz_device_traversal_gpu as T
     T.test_overflowed_queries_are_retried_on_the_device(ctx, monkeypatch, capfd)
     T.test_visited_table_grows_inside_the_kernel(ctx, monkeypatch, capfd)
+    T.test_exact_score_ties_are_resolved_on_the_device(ctx, monkeypatch, capfd)
 
 
 def test_device_traversal_refuses_unsupported_shapes(J, ctx):

@@ -111,6 +111,61 @@ def test_visited_table_grows_inside_the_kernel(ctx, monkeypatch, capfd):
         assert (first == 0) == expect_clean, line
 
 
+def test_exact_score_ties_are_resolved_on_the_device(ctx, monkeypatch, capfd):
+    """every base vector stored twice: the exact rerank ties at the K-th place for most queries.  The reference keeps whichever
+    copy comes first in its result heap's ARRAY (NodeQueue.java:197-214); the traversal's push log lets rerank_tie_kernel rebuild
+    that array on the device — nothing goes to the host searcher — and with a log too small to hold the sequence the same
+    queries are re-run on the host: both equal the oracle."""
+    rng = np.random.default_rng(77)
+    D, M, deg = 128, 16, 16
+    base = rng.standard_normal((1500, D)).astype(np.float32)
+    v = np.repeat(base, 2, axis=0)[rng.permutation(3000)]
+    N = len(v)
+    nb = np.full((N, deg), -1, np.int32)
+    sims = v @ v.T
+    np.fill_diagonal(sims, -np.inf)
+    order = np.argsort(-sims, axis=1)[:, :deg]
+    for i in range(N):
+        d = int(rng.integers(deg // 2, deg + 1))
+        nb[i, :d] = order[i, :d]
+    lv = [(None, nb)]
+    sizes, offs = O.subvector_sizes_offsets(D, M)
+    pick = rng.choice(N, 256, replace=False)
+    cb = np.concatenate([v[pick, offs[m]: offs[m] + sizes[m]].reshape(-1) for m in range(M)])
+    q = (v[rng.integers(0, N, 48)] + 0.01 * rng.standard_normal((48, D))).astype(np.float32)
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    og = O.OracleGraph(N, lv, 5, 0)
+    graph = J.GraphIndex(ctx, N, lv, 5, 0).set_traversal("device")
+    s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
+    monkeypatch.setenv("JVECTOR_HIP_GRAPH_TIMING", "1")
+    for top_k in (5, 7, 9):        # odd K: the boundary falls inside a pair of copies for nearly every query
+        wi, ws, wst = og.search(opq, codes, v, q, O.DOT_PRODUCT, top_k, 40)
+        for cap, on_device in ((None, True), ("8", False)):
+            if cap is None:
+                monkeypatch.delenv("JVECTOR_HIP_GS_PUSH_LOG_CAP", raising=False)
+            else:
+                monkeypatch.setenv("JVECTOR_HIP_GS_PUSH_LOG_CAP", cap)
+            ids, sc, st = s.search(q, VSF.DOT_PRODUCT, top_k, 40, return_stats=True)
+            err = capfd.readouterr().err
+            assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (top_k, cap)
+            line = [x for x in err.splitlines() if "graph_search device" in x][-1]
+            resolved = int(line.split("rerank ties=")[1].split()[0])
+            host = int(line.rsplit("host ", 1)[1])
+            assert (resolved > 0 and host == 0) if on_device else (resolved == 0 and host > 0), line
+    # and the membership really is order dependent: the (score desc, id asc) selection differs from the reference for some query
+    monkeypatch.setenv("JVECTOR_HIP_GS_TIE_CHECK", "0")
+    differs = 0
+    for top_k in (5, 7, 9):
+        wi, _, _ = og.search(opq, codes, v, q, O.DOT_PRODUCT, top_k, 40)
+        ids, _ = s.search(q, VSF.DOT_PRODUCT, top_k, 40)
+        differs += int((ids != wi).any())
+    assert differs > 0, "the tie cases never depended on the heap order: the test data lost its teeth"
+
+
 def test_unsupported_shape_is_refused(ctx):
     v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 9, 2000, 64, 8, 1, False)  # M = 8
     s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
