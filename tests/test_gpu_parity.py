@@ -282,8 +282,11 @@ def test_exact_known_answers(ctx, golden_dir):
 # ------------------------------------------------------------------------------------------------
 # row 9: top-k order
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,k", [(10, 3), (1000, 10), (100000, 100), (100000, 1000), (50, 64), (5000, 4096)])
+@pytest.mark.parametrize("n,k", [(10, 3), (1000, 10), (100000, 100), (100000, 1000), (50, 64), (5000, 4096),
+                                 (110, 10), (128, 1), (129, 64), (256, 17), (257, 10), (512, 64), (1024, 64), (1025, 64), (1024, 65)])
 def test_topk_matches_nodequeue_order(ctx, n, k):
+    """rows of <= 1024 with k <= 64 take the one-wavefront register kernel (2 / 4 / 8 / 16 keys per lane), everything else the
+    radix select; both must give the NodeQueue order"""
     rng = np.random.default_rng(n + k)
     Q = 5
     scores = rng.standard_normal((Q, n)).astype(np.float32)
@@ -298,6 +301,23 @@ def test_topk_matches_nodequeue_order(ctx, n, k):
         assert np.array_equal(ids[q][:cnt], wi), q
         assert np.array_equal(sc[q][:cnt], ws), q
         assert np.all(ids[q][cnt:] == -1) and np.all(np.isneginf(sc[q][cnt:]))
+
+
+def test_topk_short_rows_with_ids_and_padding(ctx):
+    """the rerank's shape: Q x rerankK candidate lists with -1 padded tails, engineered score ties, many rows"""
+    rng = np.random.default_rng(9)
+    Q, R, k = 300, 110, 10
+    ids = np.stack([rng.permutation(50_000)[:R] for _ in range(Q)]).astype(np.int32)
+    scores = (np.round(rng.standard_normal((Q, R)) * 16) / 16).astype(np.float32)
+    for q in range(Q):
+        ids[q, int(rng.integers(0, R + 1)):] = -1          # anything from an empty list to a full one
+    got_i, got_s = J.topk(ctx, scores, k, ids=ids)
+    for q in range(Q):
+        valid = ids[q] >= 0
+        wi, ws = O.topk(ids[q][valid], scores[q][valid], k)
+        cnt = len(wi)
+        assert np.array_equal(got_i[q][:cnt], wi) and np.array_equal(got_s[q][:cnt], ws), q
+        assert np.all(got_i[q][cnt:] == -1) and np.all(np.isneginf(got_s[q][cnt:])), q
 
 
 def test_topk_explicit_ids_merge(ctx):
