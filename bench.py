@@ -379,7 +379,8 @@ def run_c5(args, ctx, J, dev, world, rank, barrier):
     VSF = J.VectorSimilarityFunction.COSINE
     # BASELINE C5 shape unless --dim / --m were given explicitly (the CPU dry run uses a toy shape)
     D, M = (1536, 192) if (args.dim, args.m) == (768, 96) else (args.dim, args.m)
-    N, K = (args.n if args.n != 10_000_000 else 1_000_000), args.topk
+    # default 1M (a few seconds); `--n 10000000` given explicitly runs BASELINE's full 10M x 1536
+    N, K = (args.n if any(a == "--n" or a.startswith("--n=") for a in sys.argv) else 1_000_000), args.topk
     mix = Mixture(D, seed=7, device=dev)
     base = mix.sample(N, seed=7 + 1000 * rank)
     eval_q = mix.sample(min(args.eval_queries, 4096), seed=9)

@@ -412,6 +412,7 @@ int jv_hip_pq_create(jv_ctx *ctx, int D, int M, int k, const int *sizes, const f
     PQ_CHECK(hipMalloc((void **)&pq->d_cb_offsets, sizeof(int64_t) * M));
     PQ_CHECK(hipMalloc((void **)&pq->d_codebooks, sizeof(float) * (size_t)cbo));
     PQ_CHECK(hipMalloc((void **)&pq->d_self_mag, sizeof(float) * (size_t)M * k));
+    if (pq->uniform && k % 2 == 0) PQ_CHECK(hipMalloc((void **)&pq->d_cb_paired, sizeof(float) * (size_t)cbo));
     PQ_CHECK(hipMemcpy(pq->d_sizes, pq->sizes.data(), sizeof(int) * M, hipMemcpyHostToDevice));
     PQ_CHECK(hipMemcpy(pq->d_offsets, pq->offsets.data(), sizeof(int) * M, hipMemcpyHostToDevice));
     PQ_CHECK(hipMemcpy(pq->d_cb_offsets, pq->cb_offsets.data(), sizeof(int64_t) * M, hipMemcpyHostToDevice));
@@ -525,6 +526,7 @@ int jv_hip_pq_destroy(jv_pq *pq)
     (void)hipFree(pq->d_codebooks);
     (void)hipFree(pq->d_centroid);
     (void)hipFree(pq->d_self_mag);
+    (void)hipFree(pq->d_cb_paired);
     delete pq;
     return JV_OK;
 }

@@ -110,6 +110,9 @@ struct jv_pq {
     float *d_codebooks = nullptr;
     float *d_centroid = nullptr;   // nullable
     float *d_self_mag = nullptr;   // M*k floats, built at create (calculatePartialSelfMagnitudes)
+    // uniform sub-vector sizes: the codebooks once more with centroids PAIRED — entry (m, i/2, j) = {c[m][i][j], c[m][i+1][j]} —
+    // for pq_encode_kernel's packed two-centroid chains (scalar loads feed both halves of a v_pk operand); built at create
+    float *d_cb_paired = nullptr;
     float aniso = -1.0f;           // anisotropicThreshold; -1 = UNWEIGHTED (ProductQuantization.java:72)
 };
 

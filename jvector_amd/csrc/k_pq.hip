@@ -24,10 +24,26 @@ __global__ __launch_bounds__(256) void self_mag_kernel(const float *__restrict__
     out[m * kClusters + i] = sum;
 }
 
+// paired[m][i/2][j] = {c[m][i][j], c[m][i+1][j]} (uniform sizes only; see jv_pq::d_cb_paired)
+__global__ void pair_codebooks_kernel(const float *__restrict__ codebooks, int size, int64_t total, float *__restrict__ paired)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t per_m = (int64_t)kClusters * size;
+    const int64_t m = t / per_m, r = t - m * per_m;
+    const int i = (int)(r / size), j = (int)(r - (int64_t)i * size);
+    paired[m * per_m + ((int64_t)(i >> 1) * size + j) * 2 + (i & 1)] = codebooks[t];
+}
+
 int launch_self_magnitudes(hipStream_t s, const jv_pq *pq)
 {
     hipLaunchKernelGGL(self_mag_kernel, dim3(pq->M), dim3(256), 0, s, pq->d_codebooks, pq->d_cb_offsets, pq->d_sizes,
                        pq->d_self_mag);
+    if (pq->d_cb_paired) {
+        const int64_t total = (int64_t)pq->M * kClusters * pq->max_size;
+        hipLaunchKernelGGL(pair_codebooks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pq->d_codebooks, pq->max_size,
+                           total, pq->d_cb_paired);
+    }
     JV_HIP_CHECK(hipGetLastError());
     return JV_OK;
 }
@@ -223,6 +239,53 @@ __global__ __launch_bounds__(256) void pq_encode_kernel(const float *__restrict_
     codes[n * M + m] = (uint8_t)best;
 }
 
+// The same two-centroid chains with the pairs read through the SCALAR cache: centroid values are wave-uniform, so they can sit
+// in SGPR pairs and feed v_pk_add_f32 directly (one scalar operand per VALU instruction) — no LDS staging, no LDS reads in
+// the loop.  Blocks with consecutive blockIdx.x work on the same subspace, whose 256 * SIZE * 4 bytes (8 KB at SIZE 8) stay in
+// the scalar cache.  JVECTOR_HIP_ENCODE_LDS=1 selects the LDS form above.
+template <int SIZE>
+__global__ __launch_bounds__(256) void pq_encode_sgpr_kernel(const float *__restrict__ vecs, int64_t count, int D, int M,
+                                                             const jv_f2 *__restrict__ cb_paired,
+                                                             const int *__restrict__ offsets,
+                                                             const float *__restrict__ centroid,
+                                                             uint8_t *__restrict__ codes)
+{
+    const int m = blockIdx.y;
+    const jv_f2 *__restrict__ cb2 = cb_paired + (int64_t)m * (kClusters / 2) * SIZE;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= count) return;
+    const int off = offsets[m];
+    const float *vp = vecs + n * D + off;
+    float v[SIZE];
+#pragma unroll
+    for (int j = 0; j < SIZE; ++j) {
+        float x = vp[j];
+        if (centroid) x = x - centroid[off + j];  // VectorUtil.sub(vector, globalCentroid) :441-443
+        v[j] = x;
+    }
+    int best = 0;
+    float minDist = 3.4028234663852886e+38f;  // Float.MAX_VALUE
+#pragma unroll 2
+    for (int i2 = 0; i2 < kClusters / 2; ++i2) {
+        jv_f2 s = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < SIZE; ++j) {
+            const jv_f2 vv = {v[j], v[j]};
+            const jv_f2 d = vv - cb2[i2 * SIZE + j];
+            s += d * d;
+        }
+        if (s.x < minDist) {  // strict '<': first minimum wins; NaN never wins
+            minDist = s.x;
+            best = 2 * i2;
+        }
+        if (s.y < minDist) {
+            minDist = s.y;
+            best = 2 * i2 + 1;
+        }
+    }
+    codes[n * M + m] = (uint8_t)best;
+}
+
 // any sub-vector size (non-uniform splits when D % M != 0, or sizes without a specialisation):
 // sub-vector re-read from global/L1 per centroid — correct, slow, only a fallback.
 __global__ __launch_bounds__(256) void pq_encode_generic_kernel(const float *__restrict__ vecs, int64_t count, int D,
@@ -268,7 +331,23 @@ int launch_pq_encode(hipStream_t s, const jv_pq *pq, const float *d_vecs, int64_
     hipLaunchKernelGGL(pq_encode_kernel<SZ>, grid, block, 0, s, d_vecs, count, pq->D, pq->M, pq->d_codebooks,  \
                        pq->d_cb_offsets, pq->d_offsets, pq->d_centroid, d_codes)
     bool done = false;
-    if (pq->uniform) {
+#define JV_ENC_S(SZ)                                                                                                       \
+    hipLaunchKernelGGL(pq_encode_sgpr_kernel<SZ>, grid, block, 0, s, d_vecs, count, pq->D, pq->M, (const jv_f2 *)pq->d_cb_paired, \
+                       pq->d_offsets, pq->d_centroid, d_codes)
+    if (pq->uniform && pq->d_cb_paired && !getenv("JVECTOR_HIP_ENCODE_LDS")) {
+        done = true;
+        switch (pq->max_size) {
+        case 2: JV_ENC_S(2); break;
+        case 4: JV_ENC_S(4); break;
+        case 6: JV_ENC_S(6); break;
+        case 8: JV_ENC_S(8); break;
+        case 12: JV_ENC_S(12); break;
+        case 16: JV_ENC_S(16); break;
+        default: done = false;
+        }
+    }
+#undef JV_ENC_S
+    if (!done && pq->uniform) {
         done = true;
         switch (pq->max_size) {
         case 1: JV_ENC(1); break;
