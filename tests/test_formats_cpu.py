@@ -42,6 +42,19 @@ def test_fvecs_golden_fixture():
     assert v[0, 0] == struct.unpack_from("<f", data, 4)[0]
 
 
+def test_ivecs_golden_fixture():
+    """the repo-shipped siftsmall ground truth (SiftLoader.readIvecs, EX/util/SiftLoader.java:63-83): 100 queries x their 100
+    nearest base ordinals of the 10 000-vector siftsmall base set"""
+    data = open(os.path.join(GOLDEN, "siftsmall_groundtruth.ivecs"), "rb").read()
+    g = F.read_ivecs(data)
+    assert g.shape == (100, 100) and g.dtype == np.int32
+    raw = np.frombuffer(data, dtype="<i4").reshape(100, 101)
+    assert (raw[:, 0] == 100).all() and np.array_equal(g, raw[:, 1:])
+    assert g.min() >= 0 and g.max() < 10_000                       # ordinals of siftsmall_base (10 000 vectors)
+    assert all(len(set(row)) == 100 for row in g.tolist())         # a neighbour list holds no ordinal twice
+    assert len(np.unique(g[:, 0])) > 90                            # 100 different queries -> (almost) all different nearest neighbours
+
+
 def test_xvecs_round_trip_and_errors():
     rng = np.random.default_rng(1)
     f = rng.standard_normal((7, 5)).astype(np.float32)
