@@ -234,6 +234,13 @@ JV_API int jv_hip_exact_scores(jv_ctx *ctx, const jv_vectors *v, const float *qu
                                const int32_t *ordinals, int B, float *scores_out);
 JV_API int jv_hip_exact_scan(jv_ctx *ctx, const jv_vectors *v, const float *queries, int Q, jv_vsf vsf,
                              int64_t first, int64_t count, float *scores_out);
+/* The exact build-score provider — BuildScoreProvider.randomAccessScoreProvider (B/graph/similarity/BuildScoreProvider.java:
+ * 106-160): diversityScoreFunctionFor(node1).similarityTo(node2) = similarityFunction.compare(vectors[node1], vectors[node2])
+ * for P x B (node, candidate) blocks — the full-resolution counterpart of jv_hip_code_pair_scores, same arithmetic as
+ * jv_hip_exact_scores (searchProviderFor(node1) is jv_hip_exact_scores with the node's own row as the query).
+ * scores_out[p*B + b]; an ordinal outside [0, count) on either side gives -INFINITY.  Buffers: host or device memory. */
+JV_API int jv_hip_exact_pair_scores(jv_ctx *ctx, const jv_vectors *v, jv_vsf vsf, const int32_t *node1, int P, const int32_t *node2,
+                                    int B, float *scores_out);
 /* MFMA tile form of the scan (north_star: "MFMA only for the batched query x candidates GEMM form of full-resolution
  * rerank"; SURVEY §8d: the dense Q x N form of row 1 — brute force, ground truth).  Same arguments and output layout as
  * jv_hip_exact_scan, but NOT bit-identical to it: dot products and norms are k-ascending f32 fused-multiply-add chains (what

@@ -106,6 +106,7 @@ public final class HipOps {
         static final MethodHandle odgiReadLevel = h("jv_fmt_odgi_read_level", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, JAVA_INT, ADDRESS, ADDRESS));
         static final MethodHandle pqvectorsDescribe = h("jv_fmt_pqvectors_describe", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle graphSearchFiltered = h("jv_hip_graph_search_filtered", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle exactPairScores = h("jv_hip_exact_pair_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
         // GraphSearcher objects: threshold / rerankFloor / resume
         static final MethodHandle searcherCreate = h("jv_hip_searcher_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle searcherSearch = h("jv_hip_searcher_search", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_FLOAT, JAVA_FLOAT, ADDRESS, JAVA_LONG, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
@@ -331,6 +332,12 @@ public final class HipOps {
     /** diversityFunctionFor(node1).similarityTo(node2) for P x B candidate x selected blocks */
     public static void codePairScores(MemorySegment ctx, MemorySegment table, MemorySegment codes, MemorySegment node1, int p, MemorySegment node2, int b, MemorySegment out) {
         check(st(() -> (int) H.codePairScores.invokeExact(ctx, table, codes, node1, p, node2, b, out)));
+    }
+
+    /** randomAccessScoreProvider.diversityScoreFunctionFor(node1).similarityTo(node2) (BuildScoreProvider.java:151-157), P x B blocks */
+    public static void exactPairScores(MemorySegment ctx, MemorySegment vectors, int vsf, MemorySegment node1, int p, MemorySegment node2, int b,
+                                       MemorySegment out) {
+        check(st(() -> (int) H.exactPairScores.invokeExact(ctx, vectors, vsf, node1, p, node2, b, out)));
     }
 
     /** VamanaDiversityProvider.retainDiverse for P NodeArrays at once (candidates sorted by score descending per row);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "jv_hip_fused_scores": (_i, [_p, _p, _p, _p, _p, _p]),
     "jv_hip_exact_scores": (_i, [_p, _p, _p, _i, _i, _p, _i, _p]),
     "jv_hip_exact_scan": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _p]),
+    "jv_hip_exact_pair_scores": (_i, [_p, _p, _i, _p, _i, _p, _i, _p]),
     "jv_hip_exact_scan_dense": (_i, [_p, _p, _p, _i, _i, _i64, _i64, _p]),
     "jv_hip_topk": (_i, [_p, _p, _p, _i, _i64, _i64, C.c_int32, _i, _p, _p]),
     "jv_hip_search_flat": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.c_int32, _p, _p]),

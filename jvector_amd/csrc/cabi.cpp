@@ -1037,6 +1037,36 @@ int jv_hip_exact_scores(jv_ctx *ctx, const jv_vectors *v, const float *queries, 
     return stage_out_end(ctx, os);
 }
 
+int jv_hip_exact_pair_scores(jv_ctx *ctx, const jv_vectors *v, jv_vsf vsf, const int32_t *node1, int P, const int32_t *node2, int B,
+                             float *scores_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && v, "exact_pair_scores: NULL argument");
+    JV_REQUIRE(P >= 0 && B >= 0, "exact_pair_scores: negative sizes");
+    if (P == 0 || B == 0) return JV_OK;
+    JV_REQUIRE(node1 && node2 && scores_out, "exact_pair_scores: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    // node2 is copied: the gather step voids the lists of rows whose node1 is not a valid ordinal
+    const void *d_n1 = nullptr;
+    JV_TRY(stage_in(ctx, node1, sizeof(int32_t) * (size_t)P, ctx->h_in, ctx->d_in, &d_n1));
+    JV_TRY(ctx->d_scratch2.reserve(sizeof(int32_t) * (size_t)P * B));
+    JV_HIP_CHECK(hipMemcpyAsync(ctx->d_scratch2.ptr, node2, sizeof(int32_t) * (size_t)P * B, hipMemcpyDefault, ctx->stream));
+    if (!is_device_ptr(node2)) JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // pageable source: the copy must not outlive the call
+    JV_TRY(ctx->d_gs_out.reserve(sizeof(float) * (size_t)P * v->D));
+    JV_TRY(ctx->d_scratch3.reserve(sizeof(float) * (size_t)P));
+    OutStage os;
+    JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)P * B, ctx->d_out, &os));
+    if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(v)));
+    {
+        ProfScope ps(ctx, R_EXACT);
+        JV_TRY(launch_gather_rows(ctx->stream, v->d_vecs, v->count, v->D, (const int32_t *)d_n1, P, (float *)ctx->d_gs_out.ptr,
+                                  (int32_t *)ctx->d_scratch2.ptr, B));
+        JV_TRY(launch_exact_gather(ctx->stream, v->d_vecs, v->count, v->D, (const float *)ctx->d_gs_out.ptr, P, to_kernel_vsf(vsf),
+                                   (const int32_t *)ctx->d_scratch2.ptr, B, (float *)os.dev, (float *)ctx->d_scratch3.ptr, v->d_sqnorm));
+    }
+    return stage_out_end(ctx, os);
+}
+
 int jv_hip_exact_scan(jv_ctx *ctx, const jv_vectors *v, const float *queries, int Q, jv_vsf vsf, int64_t first,
                       int64_t count, float *scores_out)
 {

@@ -237,6 +237,8 @@ int launch_fused(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const fl
                  const uint8_t *d_blocks, const int32_t *d_neighbors, const float *d_norms, int maxDegree,
                  int64_t n_nodes, const int32_t *d_origins, float *d_out, int32_t *d_neighbors_out);
 
+int launch_gather_rows(hipStream_t s, const float *d_vecs, int64_t n, int D, const int32_t *d_ord, int P, float *d_out, int32_t *d_cand,
+                       int B);
 int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf,
                         const int32_t *d_ord, int B, float *d_out, float *d_qnorm, const float *d_vnorm);
 int launch_row_sqnorms(hipStream_t s, const float *d_vecs, int64_t n, int D, float *d_out);

@@ -364,6 +364,29 @@ int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, co
     return JV_OK;
 }
 
+// rows of the vector set as a query batch (the exact build-score provider scores node against node): out[p] = vecs[ord[p]];
+// an ordinal outside [0, n) gives a zero row and voids that row's candidate list (ids -> -1, i.e. -inf scores downstream)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ vecs, int64_t n, int D, const int32_t *__restrict__ ord,
+                                                          int P, float *__restrict__ out, int32_t *__restrict__ cand, int B)
+{
+    const int p = blockIdx.x;
+    if (p >= P) return;
+    const int64_t o = ord[p];
+    const bool ok = o >= 0 && o < n;
+    for (int j = threadIdx.x; j < D; j += 256) out[(int64_t)p * D + j] = ok ? vecs[o * D + j] : 0.0f;
+    if (!ok)
+        for (int j = threadIdx.x; j < B; j += 256) cand[(int64_t)p * B + j] = -1;
+}
+
+int launch_gather_rows(hipStream_t s, const float *d_vecs, int64_t n, int D, const int32_t *d_ord, int P, float *d_out, int32_t *d_cand,
+                       int B)
+{
+    if (P == 0) return JV_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(P), dim3(256), 0, s, d_vecs, n, D, d_ord, P, d_out, d_cand, B);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // scan form: every candidate in [first, first+count) against all Q queries.
 // block 256 lanes = 256 candidates; queries are processed in tiles of QB staged in LDS; each lane keeps

@@ -291,6 +291,17 @@ class VectorSet:
         check(self._lib.jv_hip_exact_scores(self.ctx._h, self._h, q_p, Q, int(vsf), o_p, B, out_p))
         return out
 
+    def pair_scores(self, vsf, node1, node2):
+        """BuildScoreProvider.randomAccessScoreProvider's diversity function (BuildScoreProvider.java:151-157) for P nodes at once:
+        out[p, b] = vsf.compare(vectors[node1[p]], vectors[node2[p, b]]); an ordinal outside the set gives -inf."""
+        P, B = int(node2.shape[0]), int(node2.shape[1])
+        a_p, ak = _ptr(node1, np.int32)
+        b_p, bk = _ptr(node2, np.int32)
+        out = _empty((P, B), np.float32, node2)
+        out_p, outk = _ptr(out, np.float32)
+        check(self._lib.jv_hip_exact_pair_scores(self.ctx._h, self._h, int(vsf), a_p, P, b_p, B, out_p))
+        return out
+
     def scan(self, queries, vsf, first=0, count=None, out=None, dense=False):
         """brute-force form: out[q, i] = vsf.compare(queries[q], vectors[first + i]).
         dense=True: the MFMA tile form (jv_hip_exact_scan_dense) — fused k-ascending chains, within 1e-5 of the default

@@ -231,6 +231,17 @@ int launch_row_sqnorms(hipStream_t, const float *d_vecs, int64_t n, int D, float
     }
     return JV_OK;
 }
+int launch_gather_rows(hipStream_t, const float *d_vecs, int64_t n, int D, const int32_t *d_ord, int P, float *d_out, int32_t *d_cand, int B)
+{
+    for (int p = 0; p < P; ++p) {
+        const int64_t o = d_ord[p];
+        const bool ok = o >= 0 && o < n;
+        for (int j = 0; j < D; ++j) d_out[(int64_t)p * D + j] = ok ? d_vecs[o * D + j] : 0.0f;
+        if (!ok)
+            for (int j = 0; j < B; ++j) d_cand[(int64_t)p * B + j] = -1;
+    }
+    return JV_OK;
+}
 int launch_exact_gather(hipStream_t, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf, const int32_t *d_ord,
                         int B, float *d_out, float *, const float *)
 {

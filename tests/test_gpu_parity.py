@@ -303,6 +303,27 @@ def test_topk_matches_nodequeue_order(ctx, n, k):
         assert np.all(ids[q][cnt:] == -1) and np.all(np.isneginf(sc[q][cnt:]))
 
 
+def test_exact_pair_scores_bit_exact(ctx):
+    """the exact build-score provider (BuildScoreProvider.randomAccessScoreProvider :106-160): node-vs-node full-resolution
+    similarity for P x B blocks == the scalar compare of the two rows, -inf for ordinals outside the set on either side"""
+    rng = np.random.default_rng(21)
+    for D in (24, 768):
+        N, P, B = 500, 37, 19
+        v = rng.standard_normal((N, D)).astype(np.float32)
+        vs = J.VectorSet(ctx, v)
+        n1 = rng.integers(0, N, P).astype(np.int32)
+        n2 = rng.integers(0, N, (P, B)).astype(np.int32)
+        n1[3], n1[7] = -1, N + 5
+        n2[0, 2], n2[5, 0] = -1, N
+        for vsf in VSF:
+            got = vs.pair_scores(vsf, n1, n2)
+            for p in range(P):
+                for b in range(B):
+                    bad = not (0 <= n1[p] < N and 0 <= n2[p, b] < N)
+                    want = -np.inf if bad else O.compare(int(vsf), v[n1[p]], v[n2[p, b]])
+                    assert got[p, b] == want or (np.isnan(got[p, b]) and np.isnan(want)), (D, vsf, p, b)
+
+
 def test_topk_short_rows_with_ids_and_padding(ctx):
     """the rerank's shape: Q x rerankK candidate lists with -1 padded tails, engineered score ties, many rows"""
     rng = np.random.default_rng(9)

@@ -77,6 +77,7 @@ def test_parity_suite_host_logic(J, ctx, golden_dir):
         T.test_topk_matches_nodequeue_order(ctx, n, k)
     T.test_topk_explicit_ids_merge(ctx)
     T.test_topk_short_rows_with_ids_and_padding(ctx)
+    T.test_exact_pair_scores_bit_exact(ctx)
     T.test_version0_pq_fixture_on_device(ctx, golden_dir)
     T.test_siftsmall_plumbing(ctx, golden_dir)
     T.test_error_behaviour(ctx)
