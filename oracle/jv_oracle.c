@@ -1348,6 +1348,12 @@ static const int32_t *level_row(const jvo_graph *g, int level, int32_t node)
     return NULL;
 }
 
+/* analysis aid (scripts/lut_cache_study.py): the calling thread's next jvo_graph_search* records the scored node ids in order */
+static __thread int32_t *tl_visit_log = NULL;
+static __thread int64_t tl_visit_cap = 0, tl_visit_n = 0;
+void jvo_set_visit_log(int32_t *buf, int64_t cap) { tl_visit_log = buf; tl_visit_cap = cap; tl_visit_n = 0; }
+int64_t jvo_visit_log_count(void) { return tl_visit_n; }
+
 void jvo_graph_search(const jvo_graph *g, const jvo_pq *pq, const uint8_t *codes, const float *vecs,
                       const float *query, int vsf, int fused, int topK, int rerankK,
                       int32_t *out_ids, float *out_scores, int64_t *stats /* visited, expanded */)
@@ -1424,6 +1430,8 @@ void jvo_graph_search_filtered(const jvo_graph *g, const jvo_pq *pq, const uint8
                 if (stamp[nb] == epoch) continue;
                 stamp[nb] = epoch;
                 lh_push(&cand, -1 - jvo_nodequeue_encode(nb, SCORE(nb)));
+                if (tl_visit_log && tl_visit_n < tl_visit_cap) tl_visit_log[tl_visit_n] = nb;
+                tl_visit_n++;
                 n_visited++;
             }
         }

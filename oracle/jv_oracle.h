@@ -158,6 +158,10 @@ void jvo_graph_search_filtered(const jvo_graph *g, const jvo_pq *pq, const uint8
                                const float *query, int vsf, int fused, int topK, int rerankK, const uint64_t *accept,
                                int32_t *out_ids, float *out_scores, int64_t *stats);
 
+/* analysis aid: the calling thread's next jvo_graph_search* call records the ids of the nodes it scores, in order */
+void jvo_set_visit_log(int32_t *buf, int64_t cap);
+int64_t jvo_visit_log_count(void);
+
 /* GraphSearcher as an object: threshold > 0 (TwoPhaseTracker), rerankFloor, resume(), rerankedCount and
  * worstApproximateInTopK (GraphSearcher.java:222-243,355-369,406-547; NodeQueue.java:160-230; ScoreTracker.java:38-140).
  * The graph / pq / codes / vecs pointers must outlive the searcher.  stats (nullable): {visitedCount, expandedCount,

@@ -212,6 +212,8 @@ def lib():
             C.POINTER(C.c_int64), C.POINTER(C.c_float))
         sig("jvo_searcher_resume", C.c_int, C.c_void_p, C.c_int, C.c_int, i32p, fp, C.POINTER(C.c_int64), C.POINTER(C.c_float))
         sig("jvo_percentile_legacy", C.c_double, C.POINTER(C.c_double), C.c_int, C.c_double)
+        sig("jvo_set_visit_log", None, i32p, C.c_int64)
+        sig("jvo_visit_log_count", C.c_int64)
         sig("jvo_rerank", None, fp, fp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, fp, C.c_int)
         sig("jvo_pq_layout_compute", C.c_int, C.c_int, C.c_int, C.POINTER(_Layout))
         sig("jvo_pq_parse", C.c_int, u8p, C.c_size_t, i32p, i32p, i32p, i32p, i32p, fp, i32p, C.c_int,
