@@ -1,0 +1,121 @@
+"""One-off validation aid: a time-boxed differential sweep of the device traversal (and the host searcher) against the oracle's
+GraphSearcher restatement on random problems — shapes, degrees, level counts, similarity functions, fused / unfused, rerank /
+no rerank, acceptOrds filters, duplicated vectors (exact-score ties), tiny visited tables (growth / retry / host fallback).
+Every case must agree bit for bit on ids, scores and the visited / expanded counters.
+usage (GPU box): python scripts/fuzz_traversal.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import jvector_amd as J  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from test_graph_search import fused_blocks  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ctx = J.HipContext(0)
+VSF = J.VectorSimilarityFunction
+t_end = time.time() + budget
+cases = searches = 0
+knobs = ("JVECTOR_HIP_GS_VCAP_LOG2", "JVECTOR_HIP_GS_GROW", "JVECTOR_HIP_GS_RETRY", "JVECTOR_HIP_GS_CAND_CAP", "JVECTOR_HIP_GS_PUSH_LOG_CAP")
+while time.time() < t_end:
+    D = int(rng.choice([128, 256, 384, 512, 768]))
+    M = D // 8
+    N = int(rng.integers(200, 6000))
+    deg = int(rng.choice([8, 16, 24, 32, 48, 64]))
+    n_levels = int(rng.integers(1, 4))
+    base = rng.standard_normal((N, D)).astype(np.float32)
+    if rng.random() < 0.3:                                   # duplicates: exact-score ties
+        base[N // 2:] = base[: N - N // 2]
+    if rng.random() < 0.5:
+        base /= np.linalg.norm(base, axis=1, keepdims=True)
+    perm = rng.permutation(N)
+    v = np.ascontiguousarray(base[perm])
+    # neighbour rows: mostly near vectors of a random projection bucket + random long edges, ragged, packed
+    key = v @ rng.standard_normal((D, 3)).astype(np.float32)
+    order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))
+    pos = np.empty(N, np.int64)
+    pos[order] = np.arange(N)
+    nb = np.full((N, deg), -1, np.int32)
+    for i in range(N):
+        d = int(rng.integers(1, deg + 1))
+        near = order[np.clip(pos[i] + rng.integers(-deg, deg + 1, d), 0, N - 1)]
+        far = rng.integers(0, N, max(1, d // 4))
+        row = np.concatenate([near[: d - len(far)], far])
+        row = row[row != i]
+        _, first = np.unique(row, return_index=True)
+        row = row[np.sort(first)]
+        nb[i, : len(row)] = row
+    lv = [(None, nb)]
+    entry, entry_level = int(rng.integers(0, N)), 0
+    prev = np.arange(N)
+    for _ in range(1, n_levels):
+        cnt = max(3, len(prev) // int(rng.integers(4, 20)))
+        ids = np.sort(rng.choice(prev, cnt, replace=False)).astype(np.int32)
+        udeg = int(rng.choice([4, 8, 16, 32]))
+        un = np.full((cnt, udeg), -1, np.int32)
+        for i in range(cnt):
+            r = rng.choice(ids, int(rng.integers(1, min(udeg, cnt - 1) + 1)), replace=False)
+            r = r[r != ids[i]]
+            un[i, : len(r)] = r
+        lv.append((ids, un))
+        entry, entry_level, prev = int(ids[rng.integers(0, cnt)]), len(lv) - 1, ids
+    sizes, offs = O.subvector_sizes_offsets(D, M)
+    pick = rng.integers(0, N, 256)
+    cb = np.concatenate([v[pick, offs[m]: offs[m] + sizes[m]].reshape(-1) for m in range(M)])
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    og = O.OracleGraph(N, lv, entry, entry_level)
+    use_fused = bool(rng.random() < 0.6)
+    fused = J.FusedPQ(ctx, pq, fused_blocks(codes, nb), nb) if use_fused else None
+    Q = int(rng.integers(1, 48))
+    q = (v[rng.integers(0, N, Q)] + rng.choice([0.0, 0.02, 0.3]) * rng.standard_normal((Q, D))).astype(np.float32)
+    for trial in range(3):
+        vsf = VSF(int(rng.integers(0, 3)))
+        rk = int(rng.choice([1, 5, 20, 60, 150, 300]))
+        top_k = int(rng.integers(1, min(rk, 20) + 1))
+        rerank = bool(rng.random() < 0.7)
+        accept = None if rng.random() < 0.6 else (rng.random(N) < 0.7 if rng.random() < 0.5 else rng.random((Q, N)) < 0.5)
+        traversal = "device" if (deg <= 64 and rng.random() < 0.85) else "host"
+        env = {}
+        if traversal == "device" and rng.random() < 0.4:
+            env["JVECTOR_HIP_GS_VCAP_LOG2"] = str(int(rng.integers(8, 11)))
+            env["JVECTOR_HIP_GS_GROW"] = str(int(rng.integers(0, 2)))
+            env["JVECTOR_HIP_GS_RETRY"] = str(int(rng.integers(0, 2)))
+        if traversal == "device" and rng.random() < 0.3:
+            env["JVECTOR_HIP_GS_CAND_CAP"] = "256"
+        if traversal == "device" and rng.random() < 0.2:
+            env["JVECTOR_HIP_GS_PUSH_LOG_CAP"] = str(int(rng.choice([4, 16, 64])))
+        for k in knobs:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal(traversal)
+        s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=64)
+        try:
+            ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True, accept=accept)
+        except J.UnsupportedError:
+            graph.close()
+            continue
+        wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused, accept=accept)
+        ok = np.array_equal(st, wst) and np.array_equal(ids, wi) and (np.array_equal(sc, ws) or np.array_equal(np.nan_to_num(sc, nan=-7.0), np.nan_to_num(ws, nan=-7.0)))
+        if not ok:
+            print("MISMATCH", dict(seed=seed, case=cases, D=D, N=N, deg=deg, levels=n_levels, vsf=str(vsf), rk=rk, top_k=top_k, rerank=rerank,
+                                   fused=use_fused, traversal=traversal, accept=None if accept is None else accept.shape, env=env))
+            bad = np.where((ids != wi).any(axis=1) | (st != wst).any(axis=1))[0]
+            print(" queries", bad[:5], "\n got", ids[bad[:2]], "\n want", wi[bad[:2]], "\n stats", st[bad[:2]], wst[bad[:2]])
+            sys.exit(1)
+        searches += 1
+        graph.close()
+    cases += 1
+for k in knobs:
+    os.environ.pop(k, None)
+print(f"fuzz: {cases} random problems, {searches} searches, all bit-identical to the oracle (seed {seed}, {budget:.0f} s)")
