@@ -323,6 +323,40 @@ __global__ __launch_bounds__(256) void pq_encode_generic_kernel(const float *__r
     codes[n * M + m] = (uint8_t)best;
 }
 
+// sub-vectors too long for the codebook of one subspace to fit LDS (256 * size * 4 B > 128 KB, i.e. size > 128 — e.g. M = 1
+// over a 1000-dimensional vector): the same loop reading the centroids from global memory (L2-resident across the block)
+__global__ __launch_bounds__(256) void pq_encode_global_kernel(const float *__restrict__ vecs, int64_t count, int D, int M,
+                                                               const float *__restrict__ codebooks,
+                                                               const int64_t *__restrict__ cb_off,
+                                                               const int *__restrict__ sizes,
+                                                               const int *__restrict__ offsets,
+                                                               const float *__restrict__ centroid,
+                                                               uint8_t *__restrict__ codes)
+{
+    const int m = blockIdx.y;
+    const int size = sizes[m], off = offsets[m];
+    const float *cbg = codebooks + cb_off[m];
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= count) return;
+    const float *vp = vecs + n * D + off;
+    int best = 0;
+    float minDist = 3.4028234663852886e+38f;
+    for (int i = 0; i < kClusters; ++i) {
+        float s = 0.0f;
+        for (int j = 0; j < size; ++j) {
+            float x = vp[j];
+            if (centroid) x = x - centroid[off + j];
+            float d = x - cbg[(int64_t)i * size + j];
+            s += d * d;
+        }
+        if (s < minDist) {
+            minDist = s;
+            best = i;
+        }
+    }
+    codes[n * M + m] = (uint8_t)best;
+}
+
 int launch_pq_encode(hipStream_t s, const jv_pq *pq, const float *d_vecs, int64_t count, uint8_t *d_codes)
 {
     if (count == 0) return JV_OK;
@@ -362,6 +396,11 @@ int launch_pq_encode(hipStream_t s, const jv_pq *pq, const float *d_vecs, int64_
         }
     }
 #undef JV_ENC
+    if (!done && (size_t)kClusters * pq->max_size * sizeof(float) > 128 * 1024) {
+        hipLaunchKernelGGL(pq_encode_global_kernel, grid, block, 0, s, d_vecs, count, pq->D, pq->M, pq->d_codebooks, pq->d_cb_offsets,
+                           pq->d_sizes, pq->d_offsets, pq->d_centroid, d_codes);
+        done = true;
+    }
     if (!done) {
         size_t lds = (size_t)kClusters * pq->max_size * sizeof(float);
         if (lds > 64 * 1024) {

@@ -37,7 +37,8 @@ def make_pq(ctx, rng, D, M, center=False, scale=1.0):
 # row 3: encode
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("D,M,center", [(128, 16, False), (768, 96, True), (64, 8, True), (10, 3, False),
-                                        (100, 7, True), (32, 32, False), (48, 4, False), (6, 6, True)])
+                                        (100, 7, True), (32, 32, False), (48, 4, False), (6, 6, True),
+                                        (1021, 1, False), (300, 2, True), (250, 2, False)])  # codebook of a subspace beyond LDS / at its edge
 def test_encode_bit_exact(ctx, D, M, center):
     rng = np.random.default_rng(D * 1000 + M)
     pq, opq = make_pq(ctx, rng, D, M, center)
