@@ -451,7 +451,7 @@ def main():
     ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 65536 graph / 256 flat / 1024 c2)")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95 on the calibration set")
-    ap.add_argument("--cal-queries", type=int, default=2048, help="calibration queries (rerankK ladder)")
+    ap.add_argument("--cal-queries", type=int, default=4096, help="calibration queries (rerankK ladder)")
     ap.add_argument("--eval-queries", type=int, default=10240, help="disjoint evaluation queries the reported recall is measured on")
     ap.add_argument("--gt-exact", action="store_true", help="ground truth by the bit-exact scalar-order scan only (slower; the "
                     "default takes 4k candidates from the MFMA dense scan and rescores them with the bit-exact kernel)")
@@ -595,7 +595,7 @@ def main():
     eval_gt = ground_truth(J, ctx, vs, eval_q, VSF, K, dense=not args.gt_exact).cpu().numpy()
     gt_s = time.perf_counter() - t0
 
-    ladder = [args.rerank] if args.rerank > 0 else [20, 30, 40, 50, 60, 75, 90, 100, 110, 125, 150, 175, 200, 250, 300, 400, 600, 800, 1600]
+    ladder = [args.rerank] if args.rerank > 0 else [20, 30, 40, 50, 60, 70, 80, 90, 95, 100, 105, 110, 115, 120, 125, 135, 150, 175, 200, 250, 300, 400, 600, 800, 1600]
     rerank_k, cal_rec = calibrate(run, ctx, ladder, cal_q, cal_gt, Q, f"mode={args.mode}")
     if world > 1:  # every rank serves with the same (largest calibrated) rerankK
         t_rk = torch.tensor([rerank_k], dtype=torch.int64, device=dev)
