@@ -94,12 +94,23 @@ def test_builder_on_the_mock():
             fn.restype, fn.argtypes = res, args
     saved, L._lib = L._lib, lib
     os.environ["JVECTOR_HIP_HOST_THREADS"] = "1"
+    registered = []
+
+    def register(ptr):
+        registered.append(ptr)
+        lib.mock_hip_register_device(C.c_void_p(ptr))
+
     try:
         ctx = jvector_amd.HipContext(0)
         lib.mock_hip_register_device.argtypes = [C.c_void_p]
-        check_builder(jvector_amd, ctx, torch.device("cpu"), 700, 128, 16, 16, 24, register=lambda p: lib.mock_hip_register_device(C.c_void_p(p)))
+        lib.mock_hip_unregister_device.argtypes = [C.c_void_p]
+        check_builder(jvector_amd, ctx, torch.device("cpu"), 700, 128, 16, 16, 24, register=register)
         ctx.close()
     finally:
+        # the buffers die with this test: a later test's numpy array that lands on one of these addresses must not be taken
+        # for device memory by the mock (seen once as a failure of an unrelated test in a whole-suite run)
+        for ptr in registered:
+            lib.mock_hip_unregister_device(C.c_void_p(ptr))
         L._lib = saved
         os.environ.pop("JVECTOR_HIP_HOST_THREADS", None)
 
