@@ -31,6 +31,7 @@ struct AdcMqParams {
     float *cand_scores;    // filter mode: [Q][cap]
     unsigned int *cand_count;  // filter mode: [Q]
     int cap;
+    int staged;            // filter mode: collect survivors per workgroup in LDS first (pays when a workgroup keeps dozens per query)
     int64_t first, count, row_stride;
     int Q, M_total;
 };
@@ -99,6 +100,22 @@ __global__ __launch_bounds__(1024) void adc_mq_kernel(AdcMqParams p)
     }
 
     // epilogue
+    // FILTER: survivors are collected per workgroup — in the LDS the table slices no longer need — and handed to the query's
+    // global list with ONE reservation per (workgroup, query) instead of one global atomic per survivor (at rerankK 3200 over 1M
+    // codes 2.5 % of all pairs survive: the per-survivor atomics cost 1.6 of the scan's 4.7 ms).  A workgroup's share that does
+    // not fit the staging area falls back to the per-survivor form; the list's order is immaterial (it feeds a top-k).  With few
+    // survivors per workgroup (C3's rerankK 50 over 10M codes: ~3 per query) the extra barriers cost more than the atomics:
+    // the host turns staging on from the expected count (AdcMqParams::staged).
+    constexpr int STAGE = (SL * kClusters * (int)sizeof(float4)) / (P * 8);  // (id, score) pairs per query
+    __shared__ unsigned int s_cnt[P], s_base[P];
+    int32_t *st_ids = reinterpret_cast<int32_t *>(lds4);
+    float *st_sc = reinterpret_cast<float *>(lds4) + (size_t)P * STAGE;
+    const bool staged = FILTER && p.staged != 0;
+    if (staged) {
+        __syncthreads();  // every lane is done with the last table slice
+        if (tid < P) s_cnt[tid] = 0u;
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t i = tile_base + (int64_t)r * 1024 + tid;
@@ -114,14 +131,41 @@ __global__ __launch_bounds__(1024) void adc_mq_kernel(AdcMqParams p)
             else sc = score_from_raw(VSF, acc[r][j]);
             if (FILTER) {
                 if (sc >= p.tau[(int64_t)q * p.tau_stride]) {
-                    const unsigned int pos = atomicAdd(&p.cand_count[q], 1u);
-                    if (pos < (unsigned int)p.cap) {
-                        p.cand_ids[(int64_t)q * p.cap + pos] = (int32_t)row;
-                        p.cand_scores[(int64_t)q * p.cap + pos] = sc;
+                    const unsigned int sp = staged ? atomicAdd(&s_cnt[j], 1u) : (unsigned int)STAGE;
+                    if (sp < (unsigned int)STAGE) {
+                        st_ids[j * STAGE + sp] = (int32_t)row;
+                        st_sc[j * STAGE + sp] = sc;
+                    } else {  // staging area full: straight to the global list
+                        const unsigned int pos = atomicAdd(&p.cand_count[q], 1u);
+                        if (pos < (unsigned int)p.cap) {
+                            p.cand_ids[(int64_t)q * p.cap + pos] = (int32_t)row;
+                            p.cand_scores[(int64_t)q * p.cap + pos] = sc;
+                        }
                     }
                 }
             } else {
                 p.out[(int64_t)q * p.count + i] = sc;
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        if (tid < P && q0 + tid < p.Q) {
+            const unsigned int n = s_cnt[tid] < (unsigned int)STAGE ? s_cnt[tid] : (unsigned int)STAGE;
+            s_base[tid] = n ? atomicAdd(&p.cand_count[q0 + tid], n) : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int q = q0 + j;
+            if (q >= p.Q) continue;
+            const unsigned int n = s_cnt[j] < (unsigned int)STAGE ? s_cnt[j] : (unsigned int)STAGE, base = s_base[j];
+            for (unsigned int t = tid; t < n; t += 1024) {
+                const unsigned int pos = base + t;
+                if (pos < (unsigned int)p.cap) {
+                    p.cand_ids[(int64_t)q * p.cap + pos] = st_ids[j * STAGE + t];
+                    p.cand_scores[(int64_t)q * p.cap + pos] = st_sc[j * STAGE + t];
+                }
             }
         }
     }
@@ -195,6 +239,11 @@ int launch_adc_mq_filter(hipStream_t s, const jv_ctx *ctx, const float *d_luts, 
     AdcMqParams p{};
     p.luts = d_luts; p.bmag = d_bmag; p.codes = d_codes; p.norms = d_norms;
     p.tau = d_tau; p.tau_stride = tau_stride; p.cand_ids = d_cand_ids; p.cand_scores = d_cand_scores; p.cand_count = d_cand_count; p.cap = cap;
+    {   // expected survivors per (workgroup, query): the filter aims at cap / 4 per query over `count` candidates
+        const int R0 = mq_R(ctx, Q, count);
+        const double per_wg = (double)cap / 4.0 * (1024.0 * R0) / (double)count;
+        p.staged = (per_wg >= 16.0 && !getenv("JVECTOR_HIP_ADC_NO_STAGING")) ? 1 : 0;
+    }
     p.first = first; p.count = count; p.row_stride = 1; p.Q = Q; p.M_total = M;
     const int slch = mq_slch(M), R = mq_R(ctx, Q, count);
     switch (vsf) {
