@@ -195,7 +195,7 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(const SelState *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// Short rows (n <= 1024, k <= 64 — the rerank's "top 10 of rerankK"): one wavefront per row keeps the keys in registers
+// Short rows (n <= 4096, k <= 64 — the rerank's "top 10 of rerankK"): one wavefront per row keeps the keys in registers
 // (NPL per lane, coalesced loads) and extracts the k best one at a time: lane-local max, 6-step wave max, the owning lane
 // retires its key.  Keys are unique, 0 = empty.  65 536 rows x 110 -> top 10 took 1.9 ms through the six-pass radix
 // select above (built for rows of millions); this form is launch-latency sized.
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void topk_small_kernel(const float *__restrict
 static bool launch_topk_small(hipStream_t s, const float *d_scores, const int32_t *d_ids, int Q, int64_t n, int64_t stride,
                               int32_t id_base, int k, int32_t *d_out_ids, float *d_out_scores, const unsigned int *d_row_counts)
 {
-    if (n > 1024 || k > 64 || getenv("JVECTOR_HIP_TOPK_RADIX")) return false;
+    if (n > 4096 || k > 64 || getenv("JVECTOR_HIP_TOPK_RADIX")) return false;
     const dim3 grid((unsigned)((Q + 3) / 4)), block(256);
 #define JV_TS(NPL)                                                                                                        \
     hipLaunchKernelGGL(topk_small_kernel<NPL>, grid, block, 0, s, d_scores, d_ids, (int)n, stride, id_base, d_row_counts, k, Q, \
@@ -252,7 +252,9 @@ static bool launch_topk_small(hipStream_t s, const float *d_scores, const int32_
     if (n <= 128) JV_TS(2);
     else if (n <= 256) JV_TS(4);
     else if (n <= 512) JV_TS(8);
-    else JV_TS(16);
+    else if (n <= 1024) JV_TS(16);
+    else if (n <= 2048) JV_TS(32);
+    else JV_TS(64);
 #undef JV_TS
     return true;
 }

@@ -284,9 +284,10 @@ def test_exact_known_answers(ctx, golden_dir):
 # row 9: top-k order
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,k", [(10, 3), (1000, 10), (100000, 100), (100000, 1000), (50, 64), (5000, 4096),
-                                 (110, 10), (128, 1), (129, 64), (256, 17), (257, 10), (512, 64), (1024, 64), (1025, 64), (1024, 65)])
+                                 (110, 10), (128, 1), (129, 64), (256, 17), (257, 10), (512, 64), (1024, 64), (1025, 64), (1024, 65),
+                                 (2048, 10), (2049, 64), (3200, 10), (4096, 64), (4097, 64)])
 def test_topk_matches_nodequeue_order(ctx, n, k):
-    """rows of <= 1024 with k <= 64 take the one-wavefront register kernel (2 / 4 / 8 / 16 keys per lane), everything else the
+    """rows of <= 4096 with k <= 64 take the one-wavefront register kernel (2 ... 64 keys per lane), everything else the
     radix select; both must give the NodeQueue order"""
     rng = np.random.default_rng(n + k)
     Q = 5
