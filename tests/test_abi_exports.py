@@ -79,3 +79,15 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower().replace("nothing here imports oracle/", "").replace(
                     "imports oracle", ""), f
+
+
+def test_integration_doc_lists_every_entry_point():
+    """INTEGRATION.md's appendix is the complete list: a symbol added to the headers must show up there too"""
+    import re
+    text = ""
+    for f in ("jvector_hip.h", "jvector_formats.h"):
+        text += re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", f)).read(), flags=re.S)
+    names = re.findall(r"JV_API\s+[\w\s\*]+?\b(jv_\w+)\s*\(", text)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in names if f"`{n}`" not in doc and n not in doc]
+    assert len(names) > 80 and not missing, missing
