@@ -1,19 +1,22 @@
 #!/bin/bash
 # AddressSanitizer pass over the library's HOST code (CPU only): builds the mock-device library (tests/mock/) with
-# -fsanitize=address and runs the mock tests that do not use the fiber-based lane emulator (ASan cannot follow its
+# -fsanitize=$SAN and runs the mock tests that do not use the fiber-based lane emulator (ASan cannot follow its
 # stack switches) plus the corrupted-input fuzz of the format readers.  Last run (round 2, incl. the GraphSearcher-object sessions and the sharded C ABI): clean.
 set -eu
+# SAN=undefined scripts/asan_mock.sh runs the same pass under UndefinedBehaviorSanitizer (round 2: clean as well)
+SAN=${SAN:-address}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/jv_asan; mkdir -p "$OUT"; cd "$OUT"
-CXXF="-std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -ffp-contract=off -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -include $ROOT/tests/mock/mock_prefix.h -fPIC -Wno-unknown-pragmas -Wno-unused-function"
+CXXF="-std=c++17 -O1 -g -fsanitize=$SAN -fno-omit-frame-pointer -ffp-contract=off -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -include $ROOT/tests/mock/mock_prefix.h -fPIC -Wno-unknown-pragmas -Wno-unused-function"
 for f in cabi graph_search sharded build_score pq_train formats compat_host; do g++ $CXXF -c "$ROOT/jvector_amd/csrc/$f.cpp" -o $f.o & done
 g++ $CXXF -c "$ROOT/tests/mock/mock_hip.cpp" -o mock_hip.o &
 g++ $CXXF -c "$ROOT/tests/mock/mock_kernels.cpp" -o mock_kernels.o &
-for f in jv_oracle jv_oracle_simd; do gcc -O1 -g -fsanitize=address -std=c11 -fPIC -ffp-contract=off -c "$ROOT/oracle/$f.c" -o $f.o & done
+for f in jv_oracle jv_oracle_simd; do gcc -O1 -g -fsanitize=$SAN -std=c11 -fPIC -ffp-contract=off -c "$ROOT/oracle/$f.c" -o $f.o & done
 wait
-g++ -shared -fsanitize=address -Wl,-Bsymbolic -o libjvector_hip_mock_asan.so *.o -lpthread -lm -ldl
+g++ -shared -fsanitize=$SAN -Wl,-Bsymbolic -o libjvector_hip_mock_asan.so *.o -lpthread -lm -ldl
 cd "$ROOT"
-export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) JV_MOCK_LIBRARY="$OUT/libjvector_hip_mock_asan.so"
+RT=libasan.so; [ "$SAN" = undefined ] && RT=libubsan.so
+export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=$RT) JV_MOCK_LIBRARY="$OUT/libjvector_hip_mock_asan.so"
 python -m pytest tests/test_mock_device.py -x -q -p no:cacheprovider \
   -k "parity_suite or search_flat or host_graph_searcher or load_index or build_score or fused_build or continuous_batching or several_host or searcher_objects or sharded_cabi_local or ((edge_cases or irregular or negative_scores or accept_ords or ties) and host)"
 python -m pytest tests/test_sharded_cabi.py -x -q -p no:cacheprovider -k "local_shards"
@@ -28,5 +31,5 @@ for table in (L.SIGNATURES, L.COMPAT_SIGNATURES, L.FORMAT_SIGNATURES):
 L._lib = lib
 import test_formats_cpu as T
 T.test_readers_survive_corrupted_input(); T.test_odgi_rejects_corruption(); T.test_odgi_v6_fused_multilayer(True)
-print("format readers under ASan: clean")
+print("format readers under the sanitizer: clean")
 PY
