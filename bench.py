@@ -21,10 +21,13 @@ configuration (profiles/traffic_r2.json, written by scripts/summarize_profile.py
 oracle ("port") on the host cores on a bounded sample of the same workload: scalar reference arithmetic (the parity
 checker: its top-k must equal the GPU's bit for bit) and the AVX2 / AVX-512 restatement of the reference's native kernels.
 
-N > 1 (launched by torch.distributed.run): every rank holds a full replica of the index and serves its own query
-batches (10M x 768 fits one GPU); no data-path collective; scaling = weak.  The traversal runs on the device, so ranks do
-not compete for host cores.  The sharded 100M configuration (all-gather of partial top-k) is jv_hip_sharded_* /
-jvector_amd/sharded.py, covered by tests, not a bench line.
+N > 1: one process per GPU.  The driver launches the ranks through torch.distributed.run; a bare `python bench.py --gpus N`
+re-executes itself under the same launcher (self_spawn_if_needed), and a launcher whose WORLD_SIZE disagrees with --gpus is
+refused — the flag can never yield an N = 1 line.  Default workload: every rank holds a full replica of the index and serves
+its own query batches (10M x 768 fits one GPU); no data-path collective; scaling = weak.  `--workload c4 --gpus 8` is the
+sharded 100M configuration (every rank one 12.5M shard, RCCL all-gather of the partial top-k inside
+jv_hip_sharded_search_flat).  Every N > 1 line carries `rccl_ranks` (ncclCommCount of the ENGINE's own RCCL communicator,
+created for the run) and `per_rank_qps` (all-gathered through that communicator).
 """
 from __future__ import annotations
 
@@ -251,10 +254,81 @@ def flat_roofline(QF, N, M, f_ms, f_n, cfg, vsf_name="COSINE"):
                     "compulsory one pass over the codes"}
 
 
+
+# ------------------------------------------------------------------------------------------------------------------
+# multi-GPU launch: one process per GPU.  The driver starts the ranks itself (torch.distributed.run exports RANK /
+# WORLD_SIZE / LOCAL_RANK); a bare `python bench.py --gpus N` re-executes itself under the same launcher, so the flag alone
+# is enough and can never silently produce an N = 1 line.
+# ------------------------------------------------------------------------------------------------------------------
+def self_spawn_if_needed(args):
+    """--gpus N > 1 without a launcher environment: re-exec this very command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` and exit with
+    its status (rank 0's JSON line goes to our stdout unchanged)."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "--", os.path.abspath(sys.argv[0])] + sys.argv[1:]   # `--`: the launcher's argparse would
+    # otherwise try to complete our own flags (`--n` is an ambiguous prefix of its --nnodes / --nproc-per-node)
+    log(f"[bench] --gpus {args.gpus}: no launcher environment, starting {args.gpus} ranks: {' '.join(cmd)}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def launcher_world(args):
+    """(rank, world, local_rank) from the launcher's environment; --gpus must agree with it."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks — refusing to print a line whose "
+                         f"n_gpus would not be what was asked for")
+    return rank, world, local
+
+
+class RankSet:
+    """The ranks of this run as the ENGINE sees them: for world > 1 the library's own RCCL communicator (jv_hip_comm_create,
+    the rendezvous id travels over torch.distributed) — `rccl_ranks` is what ncclCommCount says about it, and the per-rank
+    timings are all-gathered through it (jv_hip_comm_all_gather), so an N-GPU line is evidence that N RCCL ranks ran."""
+
+    def __init__(self, ctx, rank, world):
+        self.rank, self.world, self.comm = rank, world, None
+        if world > 1:
+            from jvector_amd.sharded import Communicator
+            box = [Communicator.unique_id(ctx) if rank == 0 else None]
+            torch.distributed.broadcast_object_list(box, src=0)
+            self.comm = Communicator(ctx, rank, world, box[0])
+
+    def rccl_ranks(self):
+        return self.comm.count() if self.comm is not None else 1
+
+    def gather(self, values):
+        """[world, len(values)] float64, every rank gets the same table"""
+        if self.comm is None:
+            return np.asarray([list(values)], dtype=np.float64)
+        return self.comm.all_gather_f64(values)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+
+def aggregate(ranks, elapsed, units_this_rank):
+    """contract timing: max over ranks of the barrier-bracketed time; per-rank throughput for the record"""
+    table = ranks.gather([elapsed, units_this_rank])
+    per_rank = [float(u / t) if t > 0 else 0.0 for t, u in table]
+    return float(table[:, 0].max()), float(table[:, 1].sum()), per_rank
+
 # ------------------------------------------------------------------------------------------------------------------
 # C2: SIFT-like 1M x 128, L2, PQ-16, flat two-pass ADC search
 # ------------------------------------------------------------------------------------------------------------------
-def run_c2(args, ctx, J, dev, world, rank, barrier):
+def run_c2(args, ctx, J, dev, world, rank, barrier, ranks):
     VSF = J.VectorSimilarityFunction.EUCLIDEAN
     N, D, M, K = (args.n if args.n != 10_000_000 else 1_000_000), 128, 16, args.topk
     QF = args.queries or 1024
@@ -287,15 +361,14 @@ def run_c2(args, ctx, J, dev, world, rank, barrier):
     elapsed = timed_steps(run, queries[args.warmup * QF:], QF, args.steps, rerank_k, barrier)
     prof = {r: ctx.profile_read(r) for r in ("adc", "sample", "topk", "exact", "lut")}
     ctx.profile(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rccl_ranks = ranks.rccl_ranks()
+    elapsed, total_q, per_rank = aggregate(ranks, elapsed, QF * args.steps)
     if rank != 0:
         return None
     cfg = {"n_vectors": N, "dim": D, "pq_subspaces": M, "queries_per_step": QF, "rerankK": rerank_k}
     line = {"metric": "QPS@recall10>=0.95 (SIFT1M-like 1Mx128 L2, PQ-16 ADC search); distances/sec as % roofline",
-            "value": QF * args.steps * world / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "value": total_q / elapsed, "unit": "queries/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "per_rank_qps": per_rank,
+            "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE C2: synthetic SIFT-like {N}x{D} (clip(round(|N(0,1)|*40),0,218)), L2, PQ-{M} "
@@ -319,62 +392,110 @@ def run_c2(args, ctx, J, dev, world, rank, barrier):
 # ------------------------------------------------------------------------------------------------------------------
 # C4: sharded index — every rank owns one contiguous ordinal range; jv_hip_sharded_search_flat (RCCL inside the library)
 # ------------------------------------------------------------------------------------------------------------------
-def run_c4(args, ctx, J, dev, world, rank, barrier):
+def sharded_ground_truth(J, ctx, vs, queries, vsf, k, id_base, world):
+    """exact global top-k of a sharded index: every rank's exact top-k over its own shard (dense MFMA candidates rescored
+    bit-exactly, benchlib.ground_truth), GLOBAL ids, all-gathered over torch.distributed and merged by score (untimed)"""
+    ids = ground_truth(J, ctx, vs, queries, vsf, k, dense=True)
+    sc = vs.scores(queries, vsf, ids.contiguous())
+    ctx.sync()
+    ids = ids.to(torch.int64) + int(id_base)
+    if world == 1:
+        return ids.cpu().numpy()
+    all_ids = [torch.empty_like(ids) for _ in range(world)]
+    all_sc = [torch.empty_like(sc) for _ in range(world)]
+    torch.distributed.all_gather(all_ids, ids.contiguous())
+    torch.distributed.all_gather(all_sc, sc.contiguous())
+    ids_c, sc_c = torch.cat(all_ids, 1), torch.cat(all_sc, 1)
+    top = torch.topk(sc_c, k, dim=1).indices
+    return torch.gather(ids_c, 1, top).cpu().numpy()
+
+
+def run_c4(args, ctx, J, dev, world, rank, barrier, ranks):
     from jvector_amd.sharded import Communicator, CShardedFlatSearcher
     VSF = J.VectorSimilarityFunction.COSINE
     n_shard = args.n if args.n != 10_000_000 else 12_500_000
     D, M, K, QF = args.dim, args.m, args.topk, (args.queries or 256)
-    rerank_k = args.rerank or 50
-    mix = Mixture(D, seed=5, device=dev)
+    mix = Mixture(D, seed=5, device=dev, latent=args.latent)
     base = mix.sample(n_shard, seed=5 + rank)                      # shard-local block (SURVEY §8d C4: seeds 5 + i), never on the host
     queries = mix.sample(QF * (args.steps + args.warmup), seed=6)   # the SAME queries on every rank: one sharded index, one answer
+    eval_q = mix.sample(min(args.eval_queries, 2048), seed=8)
     g = torch.Generator(device=dev).manual_seed(4)
     pq_bytes = None
     if rank == 0:
         sample = base[torch.randperm(n_shard, generator=g, device=dev)[:128_000]].contiguous()
         pq_bytes = J.ProductQuantization.compute(ctx, sample, M, seed=4).write(6)
-    uid = Communicator.unique_id(ctx) if rank == 0 else None
-    if world > 1:  # codebooks and the RCCL rendezvous id travel over the host's own channel
-        box = [pq_bytes, uid]
+    if world > 1:  # codebooks travel over the host's own channel
+        box = [pq_bytes]
         torch.distributed.broadcast_object_list(box, src=0)
-        pq_bytes, uid = box
+        pq_bytes = box[0]
     pq = J.ProductQuantization.load(ctx, pq_bytes)
     vs = J.VectorSet(ctx, base)
     cv = J.PQVectors.encode_and_build(ctx, pq, vs)
-    comm = Communicator(ctx, rank, world, uid)
-    s = CShardedFlatSearcher(ctx, comm, pq, [(cv, vs, rank * n_shard)], max_queries=QF)
+    # the library's communicator: the N-rank one of this run, or (N = 1) a real RCCL communicator of one rank
+    comm = ranks.comm if ranks.comm is not None else Communicator(ctx, 0, 1, Communicator.unique_id(ctx))
+    rccl_ranks = comm.count()
+    s = CShardedFlatSearcher(ctx, comm, pq, [(cv, vs, rank * n_shard)], max_queries=max(QF, 256))
+
+    def run(qs, rk):
+        return s.search(qs, VSF, K, rk)
+
+    # recall of the sharded search against the exact global top-K (every rank computes the same numbers)
+    gt = sharded_ground_truth(J, ctx, vs, eval_q, VSF, K, rank * n_shard, world)
+    ladder = [args.rerank] if args.rerank > 0 else [30, 40, 50, 60, 80, 100, 150, 200, 400]
+    rerank_k, rec, rec_se = ladder[-1], 0.0, 0.0
+    for rk in ladder:
+        found = torch.cat([run(eval_q[i:i + 256].contiguous(), rk)[0].clone() for i in range(0, eval_q.shape[0], 256)])
+        ctx.sync()
+        r = recall_per_query(found.cpu().numpy(), gt)
+        rerank_k, rec, rec_se = rk, float(r.mean()), float(r.std(ddof=1) / math.sqrt(len(r))) if len(r) > 1 else 0.0
+        log(f"[c4] rerankK={rk}: recall@{K} = {rec:.4f} +- {rec_se:.4f} on {len(r)} queries over {n_shard * world} vectors")
+        if rec - 2.0 * rec_se >= 0.95:
+            break
     for w in range(args.warmup):
-        s.search(queries[w * QF:(w + 1) * QF], VSF, K, rerank_k)
-    barrier()
-    t0 = time.perf_counter()
-    for st in range(args.steps):
-        s.search(queries[(args.warmup + st) * QF:(args.warmup + st + 1) * QF], VSF, K, rerank_k)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    comm.close()
+        run(queries[w * QF:(w + 1) * QF], rerank_k)
+    ctx.profile(True)
+    elapsed = timed_steps(run, queries[args.warmup * QF:], QF, args.steps, rerank_k, barrier)
+    prof = {r: ctx.profile_read(r) for r in ("adc", "sample", "topk", "exact", "lut")}
+    ctx.profile(False)
+    # every rank answers every query (one index, one answer): the job's throughput is queries / max-over-ranks time
+    elapsed, _, per_rank = aggregate(ranks, elapsed, QF * args.steps)
     if rank != 0:
+        if ranks.comm is None:
+            comm.close()
         return None
     N = n_shard * world
-    return {"metric": "QPS, sharded flat search (ADC scan of every shard + RCCL partial-top-k all-gather + owner rerank)",
+    cfg = {"n_vectors": n_shard, "dim": D, "pq_subspaces": M, "queries_per_step": QF, "rerankK": rerank_k}
+    gather_bytes = QF * rerank_k * 8 + QF * rerank_k * 4 + 136 * 8   # per rank per step: (ids, scores) + exact scores + the agreement header
+    line = {"metric": "QPS@recall10>=0.95, sharded flat search (ADC scan of every shard + RCCL partial-top-k all-gather + owner rerank)",
             "value": QF * args.steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"BASELINE C4: {N} x {D} cosine mixture in {world} shard(s) of {n_shard}, PQ-{M}; per query batch: per-shard "
-                                   f"ADC scan -> top-{rerank_k}, all-gather, NodeQueue-order merge, exact scores by the owning shard, all-gather + "
-                                   f"owner selection, top-{K} (jv_hip_sharded_search_flat)", "n_vectors": N, "shard": n_shard, "dim": D,
-                       "pq_subspaces": M, "queries_per_step": QF, "rerankK": rerank_k, "topK": K,
-                       "parallelism": f"{world} rank(s), one shard each, RCCL all-gather of Q x rerankK x 8 B per shard"},
-            "adc_distances_per_s": float(QF) * N * args.steps / elapsed, "roofline": None, "cpu_baseline": None}
+            "data": "synthetic", "rccl_ranks": rccl_ranks, "per_rank_qps": per_rank,
+            "config": {"workload": f"BASELINE C4: {N} x {D} cosine mixture (latent {args.latent}) in {world} shard(s) of {n_shard}, PQ-{M}; per query "
+                                   f"batch: per-shard ADC scan -> top-{rerank_k}, all-gather, NodeQueue-order merge, exact scores by the owning "
+                                   f"shard, all-gather + owner selection, top-{K} (jv_hip_sharded_search_flat)", "n_vectors": N,
+                       "shard": n_shard, "dim": D, "pq_subspaces": M, "queries_per_step": QF, "rerankK": rerank_k, "topK": K,
+                       "parallelism": f"{world} rank(s), one shard each, RCCL all-gather of Q x rerankK x 8 B per shard",
+                       "rccl_bytes_per_rank_per_step": gather_bytes},
+            "recall_at_10": rec, "recall_se": rec_se, "recall_ok": rec >= 0.95, "recall_eval_queries": int(eval_q.shape[0]),
+            "adc_distances_per_s": float(QF) * N * args.steps / elapsed,
+            "kernel_ms_per_step": {r: prof[r][0] / args.steps for r in prof},
+            # the per-shard kernel: every rank scans ITS shard for every query, so the kernel roofline is per GPU
+            "roofline": flat_roofline(QF, n_shard, M, prof["adc"][0], prof["adc"][1], cfg), "cpu_baseline": None}
+    if world == 1 and not args.no_cpu_baseline:
+        tq = queries[args.warmup * QF:]
+        ids_gpu, _ = run(tq[:QF], rerank_k)
+        ctx.sync()
+        line["cpu_baseline"] = cpu_baseline_flat(pq.codebooks(), D, M, cv.get(0, n_shard), base, tq, VSF, K, rerank_k,
+                                                 ids_gpu.cpu().numpy())
+    if ranks.comm is None:
+        comm.close()
+    return line
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # C5: index build — PQ training + encode + batched Vamana construction with the engine's scoring, N x 1536, PQ-192
 # ------------------------------------------------------------------------------------------------------------------
-def run_c5(args, ctx, J, dev, world, rank, barrier):
+def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
     from jvector_amd.builder import build_vamana
     VSF = J.VectorSimilarityFunction.COSINE
     # BASELINE C5 shape unless --dim / --m were given explicitly (the CPU dry run uses a toy shape)
@@ -400,10 +521,8 @@ def run_c5(args, ctx, J, dev, world, rank, barrier):
     nbrs, entry, bstats = build_vamana(ctx, pq, cv, base, VSF, max_degree=args.degree, beam_width=100, alpha=1.2, log=log)
     barrier()
     total_s = time.perf_counter() - t_all
-    if world > 1:
-        t = torch.tensor([total_s], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        total_s = float(t.item())
+    rccl_ranks = ranks.rccl_ranks()
+    total_s, _, per_rank = aggregate(ranks, total_s, N)
     # quality of what was built: recall@10 of a search over it (graph + exact rerank) against brute force
     gt = ground_truth(J, ctx, vs, eval_q, VSF, K, dense=True).cpu().numpy()
     graph = J.GraphIndex(ctx, N, [(None, nbrs.cpu().numpy())], entry, 0)
@@ -417,7 +536,7 @@ def run_c5(args, ctx, J, dev, world, rank, barrier):
     if rank != 0:
         return None
     return {"metric": "index build: nodes/s (batched Vamana, PQ-192 scoring) incl. PQ training + encode", "value": N * world / total_s,
-            "unit": "nodes/s", "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": total_s * 1e3, "higher_is_better": True,
+            "unit": "nodes/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "per_rank_nodes_per_s": per_rank, "steps": 1, "warmup": 0, "ms_per_step": total_s * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE C5: synthetic {N}x{D} cosine mixture, PQ-{M} trained + encoded by the engine, batched Vamana "
                                    f"construction (maxDegree {args.degree}, beamWidth 100, alpha 1.2, prefix-doubling batches): candidates "
@@ -464,13 +583,14 @@ def main():
                     "ProductQuantization.compute (round-1 behaviour)")
     ap.add_argument("--index-cache", default=os.environ.get("JVECTOR_BENCH_INDEX_CACHE", ""), help="npz file: synthetic graph + "
                     "codebooks are loaded from it when it exists, else built and saved (lets rocprofv3 wrap search steps only)")
+    ap.add_argument("--latent", type=int, default=32, help="intrinsic dimension of the synthetic mixture (benchlib.Mixture: latent-L clusters "
+                    "embedded in D dims + isotropic noise); QPS@recall is a strong function of it — 64 / 128 are the sensitivity points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat", action="store_true", help="graph mode: skip the secondary flat-scan measurement")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    self_spawn_if_needed(args)
+    rank, world, local = launcher_world(args)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -486,10 +606,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    ranks = RankSet(ctx, rank, world)
     if args.workload in ("c2", "c4", "c5"):
-        line = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[args.workload](args, ctx, J, dev, world, rank, barrier)
+        line = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[args.workload](args, ctx, J, dev, world, rank, barrier, ranks)
         if rank == 0:
             print(json.dumps(line))
+        ranks.close()
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -503,7 +625,7 @@ def main():
     # so throughput grows with the batch until that tail is amortised: 775k / 868k / 938k QPS at 16k / 32k / 64k queries (1M run)
     Q = args.queries or (65536 if graph_mode else 256)
     t_setup = time.perf_counter()
-    mix = Mixture(D, seed=5, device=dev)
+    mix = Mixture(D, seed=5, device=dev, latent=args.latent)
     base = mix.sample(N, seed=5)
     queries_all = mix.sample(Q * (args.steps + args.warmup), seed=6 + 1000 * rank)
     cal_q = mix.sample(args.cal_queries, seed=7)
@@ -631,10 +753,8 @@ def main():
             for k in kv:
                 os.environ.pop(k, None)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rccl_ranks = ranks.rccl_ranks()
+    elapsed, total_queries, per_rank = aggregate(ranks, elapsed, Q * args.steps)
 
     cfg_key = {"n_vectors": N, "dim": D, "pq_subspaces": M, "queries_per_step": Q, "rerankK": rerank_k}
     graph_stats, extra_roof = None, {}
@@ -671,8 +791,8 @@ def main():
     if e_n > 0 and e_ms > 0:
         rr_bytes = float(Q) * rerank_k * args.steps * (4 * D + 4)
         ach = rr_bytes / (e_ms / 1e3) / 1e9
-        extra_roof["rerank"] = {"bound": "hbm", "kernel": "exact_gather_kernel<COSINE> (NodeQueue.rerank: full-resolution cosine of the "
-                                "kept candidates, rows gathered by ordinal)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        extra_roof["rerank"] = {"bound": "hbm", "kernel": "exact_gather_tr_kernel<COSINE> (NodeQueue.rerank: full-resolution cosine of the "
+                                "kept candidates; rows gathered by ordinal in coalesced 256-byte pieces and transposed through LDS)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("exact_gather", cfg_key),
                                 "bytes_per_launch": rr_bytes / e_n, "avg_launch_ms": e_ms / e_n, "launches": e_n}
 
@@ -702,7 +822,6 @@ def main():
                      "roofline": flat_roofline(QF, N, M, f_ms, f_n, {**cfg_key, "queries_per_step": QF, "rerankK": f_rk})}
 
     if rank == 0:
-        total_queries = Q * args.steps * world
         if graph_mode:
             achieved = bytes_total / (k_ms / 1e3) / 1e9 if k_ms > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -717,11 +836,11 @@ def main():
             "metric": "QPS@recall10>=0.95 (10Mx768); distances/sec as % HBM roofline",
             "value": total_queries / elapsed,
             "unit": "queries/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "per_rank_qps": per_rank, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"synthetic {N}x{D} cosine (latent-32 mixture of 1000 clusters, unit norm), PQ-{M} (k=256, " +
+            "config": {"workload": (f"synthetic {N}x{D} cosine (latent-{args.latent} mixture of 1000 clusters, unit norm), PQ-{M} (k=256, " +
                                     ("torch Lloyd x6" if args.torch_codebooks else "engine ProductQuantization.compute: k-means++ + Lloyd x6") +
                                     " on a 128k sample), " +
                                     (f"FusedADC graph search: " + (f"layered Vamana graph built by the engine's batched builder (PQ scoring, beamWidth {args.build_beam}, alpha 1.2, neighborOverflow 1.25; maxDegree {args.degree}, {len(levels)} levels of N/{args.degree}^l nodes), "
@@ -761,7 +880,7 @@ def main():
             if flat_info is not None:
                 line["flat_mode"] = flat_info
         else:
-            line["adc_distances_per_s"] = float(Q) * N * args.steps * world / elapsed
+            line["adc_distances_per_s"] = float(N) * total_queries / elapsed
         if world == 1 and not args.no_cpu_baseline:
             ids_gpu = run(timed_q[:Q], rerank_k)[0]
             ctx.sync()
@@ -774,6 +893,7 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_flat(cb, D, M, codes_h, base, timed_q, VSF, K, rerank_k,
                                                          ids_gpu.cpu().numpy())
         print(json.dumps(line))
+    ranks.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -428,12 +428,21 @@ JV_API int jv_hip_searcher_destroy(jv_searcher *s);
  *                           ranks by its own means (Java: a shared field; torch.distributed: a broadcast).
  *   jv_hip_comm_create    : collective over all ranks (ncclCommInitRank) on ctx's device.  id == NULL with world == 1 makes a
  *                           purely local communicator (no RCCL loaded): all shards live on this context.
+ *   jv_hip_comm_count     : ncclCommCount of the communicator's RCCL object — how many ranks RCCL itself says it joined (1 for a
+ *                           local communicator).  A launcher uses it to verify that an N-GPU job really is N RCCL ranks.
+ *   jv_hip_comm_all_gather: all-gather of `bytes` opaque bytes per rank (host or device buffers; recv holds world x bytes,
+ *                           rank-major) over the communicator, blocking — for small host-side records (per-rank timings,
+ *                           shard tables), not a data-path primitive.
  *   jv_hip_sharded_topk   : every rank hands its partial list (Q x k_in scores + GLOBAL ids, host or device); every rank
  *                           receives the same merged top-k_out (best first; (-1, -inf) padded).
  *   jv_hip_sharded_search_flat : the whole two-pass search.  This rank holds n_local shards (normally 1; every rank the same
  *                           number): codes[s] (+ vectors[s], or vectors == NULL for no rerank) own global ordinals
  *                           [id_base[s], id_base[s] + count).  luts: capacity >= Q, same jv_pq on every rank.
- *                           Every rank receives the identical Q x topK result.
+ *                           Every rank receives the identical Q x topK result.  The call opens with one small all-gather
+ *                           of {n_local, Q, topK, rerankK, rerank?, vsf, D, argument status, shard ranges}: every rank takes
+ *                           the same decisions from the same table, so ranks that disagree (one shard without vectors, a
+ *                           different Q, a rejected argument) make EVERY rank return an error instead of hanging in a
+ *                           collective the others never issue.  (A HIP failure inside one rank's scan is not covered.)
  * ------------------------------------------------------------------------------------------- */
 #define JV_COMM_ID_BYTES 128
 typedef struct jv_comm jv_comm;
@@ -442,6 +451,8 @@ JV_API int jv_hip_comm_create(jv_ctx *ctx, const uint8_t *id, int rank, int worl
 JV_API int jv_hip_comm_destroy(jv_comm *comm);
 JV_API int jv_hip_comm_rank(const jv_comm *comm);
 JV_API int jv_hip_comm_world(const jv_comm *comm);
+JV_API int jv_hip_comm_count(const jv_comm *comm, int *out);
+JV_API int jv_hip_comm_all_gather(jv_ctx *ctx, jv_comm *comm, const void *send, size_t bytes, void *recv);
 JV_API int jv_hip_sharded_topk(jv_ctx *ctx, jv_comm *comm, const float *scores, const int32_t *ids, int Q, int k_in, int k_out,
                                int32_t *out_ids, float *out_scores);
 JV_API int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts *luts, const jv_codes *const *codes,

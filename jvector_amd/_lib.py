@@ -113,6 +113,8 @@ SIGNATURES = {
     "jv_hip_comm_destroy": (_i, [_p]),
     "jv_hip_comm_rank": (_i, [_p]),
     "jv_hip_comm_world": (_i, [_p]),
+    "jv_hip_comm_count": (_i, [_p, C.POINTER(_i)]),
+    "jv_hip_comm_all_gather": (_i, [_p, _p, _p, _sz, _p]),
     "jv_hip_sharded_topk": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "jv_hip_sharded_search_flat": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
 }

@@ -31,7 +31,7 @@ int launch_shard_select(hipStream_t s, const int32_t *d_gids, const float *d_exa
 
 namespace {
 
-// ---- the six RCCL entry points this file uses, declared here (rccl.h: ncclUniqueId is 128 opaque bytes passed BY VALUE;
+// ---- the eight RCCL entry points this file uses, declared here (rccl.h: ncclUniqueId is 128 opaque bytes passed BY VALUE;
 //      ncclInt32 = 2, ncclInt64 = 4, ncclFloat32 = 7) ----
 struct RcclId {
     char internal[JV_COMM_ID_BYTES];
@@ -42,12 +42,13 @@ struct Rccl {
     int (*GetUniqueId)(RcclId *) = nullptr;
     int (*CommInitRank)(RcclComm *, int, RcclId, int) = nullptr;
     int (*CommDestroy)(RcclComm) = nullptr;
+    int (*CommCount)(RcclComm, int *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, RcclComm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
-constexpr int kNcclInt32 = 2, kNcclInt64 = 4, kNcclFloat32 = 7;
+constexpr int kNcclInt8 = 0, kNcclInt32 = 2, kNcclInt64 = 4, kNcclFloat32 = 7;
 
 std::mutex g_rccl_mu;
 Rccl g_rccl;
@@ -69,11 +70,12 @@ int load_rccl(const Rccl **out)
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
         r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
         r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.AllGather || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
             set_error("sharded: the RCCL library lacks a required symbol");
             dlclose(h);
             return JV_ERR_UNSUPPORTED;
@@ -102,12 +104,14 @@ struct jv_comm {
     const Rccl *rccl = nullptr;
     RcclComm comm = nullptr;
     int rank = 0, world = 1, device = 0;
+    std::vector<long long> h_ranges;  // host copy of the shard table (source of an async upload: must outlive the call)
     // device staging owned by the communicator (jv_hip_search_flat uses the context's scratch for itself)
-    Buffer part_ids, part_sc, all_ids, all_sc, row_ids, row_sc, cand, cand_sc, local, exact, all_exact, ranges, all_ranges;
+    Buffer part_ids, part_sc, all_ids, all_sc, row_ids, row_sc, cand, cand_sc, local, exact, all_exact, ranges, all_ranges, bytes_in,
+        bytes_out;
     ~jv_comm()
     {
         for (Buffer *b : {&part_ids, &part_sc, &all_ids, &all_sc, &row_ids, &row_sc, &cand, &cand_sc, &local, &exact, &all_exact, &ranges,
-                          &all_ranges})
+                          &all_ranges, &bytes_in, &bytes_out})
             b->release();
     }
 };
@@ -160,13 +164,13 @@ int jv_hip_comm_create(jv_ctx *ctx, const uint8_t *id, int rank, int world, jv_c
     clear_error();
     JV_REQUIRE(ctx && out, "comm_create: NULL argument");
     JV_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_create: rank %d outside world %d", rank, world);
+    JV_REQUIRE(world == 1 || id, "comm_create: a communicator of %d ranks needs the unique id of jv_hip_comm_unique_id", world);
     JV_TRY(use_device(ctx->device));
     jv_comm *c = new jv_comm();
     c->rank = rank;
     c->world = world;
     c->device = ctx->device;
-    if (world > 1 || id) {  // world 1 without an id: purely local communicator, RCCL is not even loaded
-        JV_REQUIRE(id, "comm_create: a communicator of %d ranks needs the unique id of jv_hip_comm_unique_id", world);
+    if (id) {  // world 1 without an id: purely local communicator, RCCL is not even loaded
         int rc = load_rccl(&c->rccl);
         if (rc != JV_OK) {
             delete c;
@@ -196,6 +200,37 @@ int jv_hip_comm_destroy(jv_comm *c)
 
 int jv_hip_comm_rank(const jv_comm *c) { return c ? c->rank : 0; }
 int jv_hip_comm_world(const jv_comm *c) { return c ? c->world : 1; }
+
+int jv_hip_comm_count(const jv_comm *c, int *out)
+{
+    clear_error();
+    JV_REQUIRE(c && out, "comm_count: NULL argument");
+    if (!c->comm) {  // local communicator: no RCCL object behind it
+        *out = 1;
+        return JV_OK;
+    }
+    int n = 0;
+    JV_RCCL_CHECK(c->rccl, c->rccl->CommCount(c->comm, &n));
+    *out = n;
+    return JV_OK;
+}
+
+int jv_hip_comm_all_gather(jv_ctx *ctx, jv_comm *comm, const void *send, size_t bytes, void *recv)
+{
+    clear_error();
+    JV_REQUIRE(ctx && comm, "comm_all_gather: NULL argument");
+    if (bytes == 0) return JV_OK;
+    JV_REQUIRE(send && recv, "comm_all_gather: NULL buffer");
+    JV_TRY(use_device(ctx->device));
+    const size_t W = (size_t)comm->world;
+    JV_TRY(comm->bytes_in.reserve(bytes));
+    JV_TRY(comm->bytes_out.reserve(bytes * W));
+    JV_HIP_CHECK(hipMemcpyAsync(comm->bytes_in.ptr, send, bytes, hipMemcpyDefault, ctx->stream));
+    JV_TRY(all_gather(ctx, comm, comm->bytes_in.ptr, comm->bytes_out.ptr, bytes, kNcclInt8, 1));
+    JV_HIP_CHECK(hipMemcpyAsync(recv, comm->bytes_out.ptr, bytes * W, hipMemcpyDefault, ctx->stream));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return JV_OK;
+}
 
 int jv_hip_sharded_topk(jv_ctx *ctx, jv_comm *comm, const float *scores, const int32_t *ids, int Q, int k_in, int k_out,
                         int32_t *out_ids, float *out_scores)
@@ -237,43 +272,104 @@ int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts 
 {
     clear_error();
     JV_REQUIRE(ctx && comm && luts && codes && id_base, "sharded_search_flat: NULL argument");
-    JV_REQUIRE(n_local >= 1 && n_local <= 64, "sharded_search_flat: %d local shards (1..64)", n_local);
-    JV_REQUIRE(topK > 0 && rerankK >= topK, "rerankK %d must be >= topK %d", rerankK, topK);  // GraphSearcher.java:233
-    if (Q == 0) return JV_OK;
-    JV_REQUIRE(queries && out_ids && out_scores, "sharded_search_flat: NULL buffer");
-    for (int s = 0; s < n_local; ++s) {
-        JV_REQUIRE(codes[s], "sharded_search_flat: shard %d has no codes", s);
-        JV_REQUIRE(id_base[s] >= 0 && id_base[s] + codes[s]->count <= 0x7fffffffLL, "sharded_search_flat: shard %d id range overflows int32", s);
-        JV_REQUIRE(!vectors || !vectors[s] || vectors[s]->count >= codes[s]->count, "sharded_search_flat: shard %d has fewer vectors than codes", s);
-    }
-    bool rerank = vectors != nullptr;
-    for (int s = 0; s < n_local && rerank; ++s) rerank = vectors[s] != nullptr;
     JV_TRY(use_device(ctx->device));
-    const int W = comm->world, P = W * n_local, k = rerankK;
+    // ---- 0. agreement.  The collectives below must be issued by every rank the same number of times with the same sizes, so
+    //      nothing rank-local may decide whether a rank takes part: each rank validates its own arguments into a status word,
+    //      all ranks exchange one fixed-size header {n_local, Q, topK, rerankK, rerank?, vsf, D, status, ranges...} and then take
+    //      the SAME decision from the same table (a rank whose arguments are bad makes every rank fail, none hang).
+    constexpr int kHdr = 8, kMaxLocal = 64, kRec = kHdr + 2 * kMaxLocal;
+    char local_msg[256] = {0};
+    int local_status = 0;
+    auto fail_local = [&](const char *fmt, auto... a) {
+        if (local_status == 0) {
+            if constexpr (sizeof...(a) == 0) snprintf(local_msg, sizeof(local_msg), "%s", fmt);
+            else snprintf(local_msg, sizeof(local_msg), fmt, a...);
+            local_status = 1;
+        }
+    };
+    if (n_local < 1 || n_local > kMaxLocal) fail_local("sharded_search_flat: %d local shards (1..64)", n_local);
+    if (!(topK > 0 && rerankK >= topK)) fail_local("rerankK %d must be >= topK %d", rerankK, topK);  // GraphSearcher.java:233
+    if (Q < 0 || (Q > 0 && !(queries && out_ids && out_scores))) fail_local("sharded_search_flat: NULL buffer");
+    bool rerank = vectors != nullptr;
+    for (int s = 0; s < n_local && local_status == 0; ++s) {
+        if (!codes[s]) {
+            fail_local("sharded_search_flat: shard %d has no codes", s);
+            break;
+        }
+        if (!(id_base[s] >= 0 && id_base[s] + codes[s]->count <= 0x7fffffffLL)) fail_local("sharded_search_flat: shard %d id range overflows int32", s);
+        if (codes[s]->M != luts->pq->M) fail_local("sharded_search_flat: shard %d codes have M = %d, the tables M = %d", s, codes[s]->M, luts->pq->M);
+        if (vectors && vectors[s]) {
+            if (vectors[s]->count < codes[s]->count) fail_local("sharded_search_flat: shard %d has fewer vectors than codes", s);
+            if (vectors[s]->D != luts->pq->D) fail_local("sharded_search_flat: shard %d vectors have D = %d, the quantizer D = %d", s, vectors[s]->D, luts->pq->D);
+        } else {
+            rerank = false;
+        }
+    }
+    const int W = comm->world;
+    std::vector<long long> h_rec(kRec, 0), h_all((size_t)kRec * W, 0);
+    h_rec[0] = n_local;
+    h_rec[1] = Q;
+    h_rec[2] = topK;
+    h_rec[3] = rerankK;
+    h_rec[4] = rerank ? 1 : 0;
+    h_rec[5] = (long long)vsf;
+    h_rec[6] = luts->pq->D;
+    h_rec[7] = local_status;
+    for (int s = 0; s < n_local && s < kMaxLocal && local_status == 0; ++s) {
+        h_rec[kHdr + 2 * s] = id_base[s];
+        h_rec[kHdr + 2 * s + 1] = codes[s]->count;
+    }
+    if (comm->comm) {
+        JV_TRY(comm->ranges.reserve(sizeof(long long) * kRec));
+        JV_TRY(comm->all_ranges.reserve(sizeof(long long) * (size_t)kRec * W));
+        JV_HIP_CHECK(hipMemcpyAsync(comm->ranges.ptr, h_rec.data(), sizeof(long long) * kRec, hipMemcpyHostToDevice, ctx->stream));
+        JV_TRY(all_gather(ctx, comm, comm->ranges.ptr, comm->all_ranges.ptr, kRec, kNcclInt64, 8));
+        JV_HIP_CHECK(hipMemcpyAsync(h_all.data(), comm->all_ranges.ptr, sizeof(long long) * h_all.size(), hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    } else {
+        h_all = h_rec;
+    }
+    if (local_status != 0) {
+        set_error("%s", local_msg);
+        return JV_ERR_INVALID;
+    }
+    for (int r = 0; r < W; ++r) {
+        const long long *o = h_all.data() + (size_t)kRec * r;
+        JV_REQUIRE(o[7] == 0, "sharded_search_flat: rank %d rejected its arguments (see that rank's error)", r);
+        JV_REQUIRE(o[0] == h_rec[0] && o[1] == h_rec[1] && o[2] == h_rec[2] && o[3] == h_rec[3] && o[5] == h_rec[5] && o[6] == h_rec[6],
+                   "sharded_search_flat: rank %d disagrees with rank %d on (n_local, Q, topK, rerankK, vsf, D) = (%lld, %lld, %lld, %lld, %lld, %lld) "
+                   "vs (%lld, %lld, %lld, %lld, %lld, %lld)", r, comm->rank, o[0], o[1], o[2], o[3], o[5], o[6], h_rec[0], h_rec[1], h_rec[2],
+                   h_rec[3], h_rec[5], h_rec[6]);
+        JV_REQUIRE(o[4] == h_rec[4], "sharded_search_flat: rank %d %s full-resolution vectors for every shard, rank %d %s — either every "
+                   "rank reranks or none", r, o[4] ? "has" : "lacks", comm->rank, h_rec[4] ? "has" : "lacks");
+    }
+    if (Q == 0) return JV_OK;
+    const int P = W * n_local, k = rerankK;
     const size_t cells = (size_t)Q * k;
     const bool grouped = comm->comm != nullptr;
+    // the shard table [P][2] = {first global ordinal, count} in rank-major order, for the owner selection of step 3
+    comm->h_ranges.assign(2 * (size_t)P, 0);
+    for (int r = 0; r < W; ++r)
+        for (int s = 0; s < n_local; ++s) {
+            comm->h_ranges[2 * ((size_t)r * n_local + s)] = h_all[(size_t)kRec * r + kHdr + 2 * s];
+            comm->h_ranges[2 * ((size_t)r * n_local + s) + 1] = h_all[(size_t)kRec * r + kHdr + 2 * s + 1];
+        }
+    JV_TRY(comm->all_ranges.reserve(sizeof(long long) * std::max<size_t>(2 * (size_t)P, (size_t)kRec * W)));
+    JV_HIP_CHECK(hipMemcpyAsync(comm->all_ranges.ptr, comm->h_ranges.data(), sizeof(long long) * 2 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
 
     // 1. every local shard's partial top-rerankK of the ADC scan, GLOBAL ids (jv_hip_search_flat without a reranker)
     JV_TRY(comm->part_ids.reserve(sizeof(int32_t) * cells * n_local));
     JV_TRY(comm->part_sc.reserve(sizeof(float) * cells * n_local));
-    JV_TRY(comm->ranges.reserve(sizeof(long long) * 2 * n_local));
-    std::vector<long long> h_ranges(2 * (size_t)n_local);
     for (int s = 0; s < n_local; ++s) {
         JV_TRY(jv_hip_search_flat(ctx, luts, codes[s], nullptr, queries, Q, vsf, k, 0, (int32_t)id_base[s],
                                   (int32_t *)comm->part_ids.ptr + cells * s, (float *)comm->part_sc.ptr + cells * s));
-        h_ranges[2 * s] = id_base[s];
-        h_ranges[2 * s + 1] = codes[s]->count;
     }
-    JV_HIP_CHECK(hipMemcpyAsync(comm->ranges.ptr, h_ranges.data(), sizeof(long long) * h_ranges.size(), hipMemcpyHostToDevice, ctx->stream));
-    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // h_ranges is a stack object
-    // 2. all-gather (ids, scores, shard ranges), merge -> global top-rerankK
+    // 2. all-gather (ids, scores), merge -> global top-rerankK
     JV_TRY(comm->all_ids.reserve(sizeof(int32_t) * cells * P));
     JV_TRY(comm->all_sc.reserve(sizeof(float) * cells * P));
-    JV_TRY(comm->all_ranges.reserve(sizeof(long long) * 2 * P));
     if (grouped) JV_RCCL_CHECK(comm->rccl, comm->rccl->GroupStart());
     JV_TRY(all_gather(ctx, comm, comm->part_ids.ptr, comm->all_ids.ptr, cells * n_local, kNcclInt32, 4));
     JV_TRY(all_gather(ctx, comm, comm->part_sc.ptr, comm->all_sc.ptr, cells * n_local, kNcclFloat32, 4));
-    JV_TRY(all_gather(ctx, comm, comm->ranges.ptr, comm->all_ranges.ptr, 2 * (size_t)n_local, kNcclInt64, 8));
     if (grouped) JV_RCCL_CHECK(comm->rccl, comm->rccl->GroupEnd());
     JV_TRY(comm->cand.reserve(sizeof(int32_t) * cells));
     JV_TRY(comm->cand_sc.reserve(sizeof(float) * cells));

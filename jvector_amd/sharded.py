@@ -151,6 +151,25 @@ class Communicator:
         check(ctx._lib.jv_hip_comm_unique_id(C.cast(buf, C.c_void_p)))
         return bytes(buf)
 
+    def count(self) -> int:
+        """ncclCommCount of the RCCL object behind this communicator (1 for a local communicator): what RCCL itself says."""
+        import ctypes as C
+        from ._lib import check
+        n = C.c_int(0)
+        check(self._lib.jv_hip_comm_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def all_gather_f64(self, values):
+        """jv_hip_comm_all_gather of a few float64 per rank -> numpy [world, len(values)] (host records, e.g. per-rank timings)"""
+        import ctypes as C
+        import numpy as np
+        from ._lib import check
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1))
+        out = np.zeros((self.world, v.size), dtype=np.float64)
+        check(self._lib.jv_hip_comm_all_gather(self.ctx._h, self._h, v.ctypes.data_as(C.c_void_p), v.nbytes,
+                                               out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.jv_hip_comm_destroy(self._h)

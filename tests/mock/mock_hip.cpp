@@ -36,15 +36,22 @@ void mock_hip_unregister_device(const void *p)
     g_dev.erase(p);
 }
 
+// JV_MOCK_DEVICES=n: the mock box has n (identical, independent) devices — one per rank of a multi-process dry run
+static int mock_device_count()
+{
+    const char *e = getenv("JV_MOCK_DEVICES");
+    const int n = e ? atoi(e) : 1;
+    return n >= 1 && n <= 64 ? n : 1;
+}
 hipError_t hipGetDeviceCount(int *n)
 {
-    *n = 1;
+    *n = mock_device_count();
     return hipSuccess;
 }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+hipError_t hipSetDevice(int d) { return d >= 0 && d < mock_device_count() ? hipSuccess : hipErrorInvalidDevice; }
 hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t *p, int d)
 {
-    if (d != 0) return hipErrorInvalidDevice;
+    if (d < 0 || d >= mock_device_count()) return hipErrorInvalidDevice;
     memset(p, 0, sizeof(*p));
     strcpy(p->name, "CPU mock device");
     strcpy(p->gcnArchName, "gfx950:mock");

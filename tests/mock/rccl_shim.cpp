@@ -1,4 +1,4 @@
-// rccl_shim.cpp — TEST HARNESS: the seven RCCL entry points sharded.cpp binds (dlopen via JVECTOR_HIP_RCCL_PATH),
+// rccl_shim.cpp — TEST HARNESS: the eight RCCL entry points sharded.cpp binds (dlopen via JVECTOR_HIP_RCCL_PATH),
 // implemented over POSIX shared memory for `world` PROCESSES on one host whose "device memory" is host memory (the mock
 // HIP runtime of tests/mock).  It lets the world_size-2 CPU test drive the C ABI's multi-rank path — rendezvous by unique id,
 // grouped all-gathers, the gathered layout — without a GPU.  Never loaded by the product.
@@ -101,6 +101,12 @@ int ncclAllGather(const void *send, void *recv, size_t count, int dt, void *comm
     pthread_barrier_wait(&c->sh->barrier);
     for (int r = 0; r < c->world; ++r) memcpy((char *)recv + bytes * (size_t)r, c->sh->data + kSlot * (size_t)r, bytes);
     pthread_barrier_wait(&c->sh->barrier);
+    return 0;
+}
+
+int ncclCommCount(void *comm, int *count)
+{
+    *count = ((Comm *)comm)->world;
     return 0;
 }
 

@@ -686,6 +686,9 @@ def _bench_rank(rank, world, port, mode, out_dir):
                       MASTER_PORT=str(port), JVECTOR_HIP_HOST_THREADS="1", OMP_NUM_THREADS="2", MKL_NUM_THREADS="2")
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests", "mock"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_sharded_cabi as TS
+    os.environ["JVECTOR_HIP_RCCL_PATH"] = TS.build_shim()   # the engine's own communicator (rccl_ranks) lands in the shared-memory shim
     import build_mock
     import jvector_amd._lib as L
     lib = C2.CDLL(build_mock.build())
@@ -736,7 +739,55 @@ def test_bench_two_rank_dry_run(tmp_path, mode):
     out1 = open(tmp_path / "rank1.out").read().strip()
     assert out1 == "" and len(out0) == 1
     line = json.loads(out0[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["config"]["mode"] == mode and "2 replicas" in line["config"]["parallelism"]
     assert abs(line["value"] - 2 * 32 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]   # total queries / elapsed
     assert "cpu_baseline" not in line                                                                # rank 0 at N = 1 only
+
+
+def _run_bench_on_mock(argv, timeout=900):
+    """`python tests/mock/bench_on_mock.py <argv>` as ONE process, no launcher environment: returns (returncode, JSON lines, stderr)"""
+    import json
+    import subprocess
+    import test_sharded_cabi as TS
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(JVECTOR_HIP_RCCL_PATH=TS.build_shim(), JVECTOR_HIP_HOST_THREADS="1", OMP_NUM_THREADS="2", MKL_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock", "bench_on_mock.py")] + argv, env=env, capture_output=True,
+                         text=True, timeout=timeout)
+    lines = [json.loads(x) for x in out.stdout.splitlines() if x.startswith("{")]
+    return out.returncode, lines, out.stderr
+
+
+@pytest.mark.parametrize("workload", ["c3", "c4"])
+def test_bench_gpus_flag_spawns_its_own_ranks(J, workload):
+    """`bench.py --gpus 2` given to ONE process (no RANK / WORLD_SIZE in its environment) must start two ranks itself and print
+    ONE line with n_gpus == 2 and rccl_ranks == 2 — the engine's own communicator (here on the shared-memory RCCL shim) joined
+    by both.  c3 = replicas (weak scaling line), c4 = the sharded index through jv_hip_sharded_search_flat."""
+    if workload == "c3":
+        argv = ["--gpus", "2", "--mode", "graph", "--graph", "synthetic", "--n", "4000", "--dim", "128", "--m", "16", "--degree", "16",
+                "--queries", "32", "--steps", "2", "--warmup", "1", "--eval-queries", "32", "--cal-queries", "32"]
+    else:
+        argv = ["--gpus", "2", "--workload", "c4", "--n", "3000", "--dim", "128", "--m", "16", "--queries", "16", "--steps", "2",
+                "--warmup", "1", "--eval-queries", "32", "--rerank", "40"]
+    rc, lines, err = _run_bench_on_mock(argv)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, (lines, err[-2000:])
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["per_rank_qps"]) == 2 and all(v > 0 for v in line["per_rank_qps"])
+    assert line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    if workload == "c3":
+        assert "2 replicas" in line["config"]["parallelism"]
+        assert abs(line["value"] - 2 * 32 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]
+    else:
+        assert line["config"]["n_vectors"] == 6000 and line["config"]["shard"] == 3000 and line["recall_at_10"] > 0.8
+        assert line["roofline"]["bound"] == "lds" and set(line["roofline"]) >= {"achieved", "peak", "unit", "frac", "traffic"}
+        assert abs(line["value"] - 16 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]   # every rank answers every query
+
+
+def test_bench_refuses_a_launcher_that_disagrees_with_gpus(J):
+    """WORLD_SIZE from the launcher != --gpus: no line at all rather than one with the wrong n_gpus"""
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock", "bench_on_mock.py"), "--gpus", "2", "--n", "2000"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "--gpus 2" in out.stderr and not [x for x in out.stdout.splitlines() if x.startswith("{")]
