@@ -88,6 +88,27 @@ JV_API void *jv_hip_ctx_stream(jv_ctx *ctx);
  * profile(ctx, 1) clears the counters and starts recording; profile_read synchronises the stream and returns
  * the summed elapsed milliseconds and the number of recorded regions (one per API-level launch group). */
 JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
+/* Per-context tuning options and event counters.  Every option also has a process-wide default in the environment variable
+ * JVECTOR_HIP_<NAME IN CAPITALS>; a value set here wins for this context (a JVM cannot change its environment, and two
+ * contexts may want different settings).  Options (all integers):
+ *   graph_traversal  0 auto / 1 host / 2 device — overrides jv_hip_graph_set_traversal for searches on this context
+ *   gs_vcap_log2     log2 of the device traversal's per-worker visited table (tier 2); pinning it also turns the in-kernel
+ *                    growth pool and the retry passes off unless gs_grow / gs_retry = 1 ask for them
+ *   gs_v1_log2       log2(slots) of the visited set's LDS tier; 0 = off, unset = the largest that keeps 8 waves per CU
+ *   gs_grow, gs_retry, gs_tie_check, gs_push_log, gs_push_log_cap, gs_occ, gs_pair, gs_cand_cap, gs_waves_per_cu
+ *                    device-traversal internals
+ *   gs_prof, graph_timing   1 = developer diagnostics on stderr
+ *   no_filter        1 = jv_hip_search_flat materialises all scores instead of threshold-filtering them
+ *   quiet            1 = no one-line notices on stderr (e.g. when AUTO traversal takes the host searcher)
+ * Counters (jv_hip_ctx_get_stat; unknown names read 0), accumulated over the graph searches of this context:
+ *   gs_calls_device, gs_calls_host, gs_calls_host_auto (AUTO fell back to the host searcher: the shape is outside the device
+ *   traversal's coverage), gs_queries_device, gs_queries_retried (re-run on the device with a bigger visited table),
+ *   gs_queries_host_fallback (finished by the host searcher after the device passes), gs_ties_resolved_device,
+ *   gs_ties_to_host, gs_last_v1_log2, gs_last_workers_per_cu. */
+JV_API int jv_hip_ctx_set_option(jv_ctx *ctx, const char *name, int64_t value);
+JV_API int jv_hip_ctx_clear_option(jv_ctx *ctx, const char *name);
+JV_API int jv_hip_ctx_get_stat(jv_ctx *ctx, const char *name, int64_t *out);
+JV_API int jv_hip_ctx_reset_stats(jv_ctx *ctx);
 JV_API int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, int64_t *count);
 
 /* ---------------------------------------------------------------------------------------------

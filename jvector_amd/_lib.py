@@ -43,6 +43,10 @@ SIGNATURES = {
     "jv_hip_ctx_sync": (_i, [_p]),
     "jv_hip_ctx_stream": (_p, [_p]),
     "jv_hip_ctx_profile": (_i, [_p, _i]),
+    "jv_hip_ctx_set_option": (_i, [_p, C.c_char_p, _i64]),
+    "jv_hip_ctx_clear_option": (_i, [_p, C.c_char_p]),
+    "jv_hip_ctx_get_stat": (_i, [_p, C.c_char_p, C.POINTER(_i64)]),
+    "jv_hip_ctx_reset_stats": (_i, [_p]),
     "jv_hip_ctx_profile_read": (_i, [_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "jv_hip_pq_create": (_i, [_p, _i, _i, _i, _p, _p, _p, C.POINTER(_p)]),
     "jv_hip_pq_load": (_i, [_p, _p, _sz, C.POINTER(_sz), C.POINTER(_p)]),

@@ -346,6 +346,78 @@ int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, i
     return JV_OK;
 }
 
+// ---- per-context options and counters ----
+}  // extern "C"
+namespace jv {
+namespace {
+// every option a context understands; the environment default of option x is JVECTOR_HIP_<X>
+const char *const kOptions[] = {"graph_traversal", "gs_occ", "gs_pair", "gs_cand_cap", "gs_waves_per_cu", "gs_vcap_log2", "gs_v1_log2",
+                                "gs_grow", "gs_retry", "gs_prof", "gs_tie_check", "gs_push_log", "gs_push_log_cap", "graph_timing",
+                                "no_filter", "quiet"};
+std::string env_name(const char *name)
+{
+    std::string e = "JVECTOR_HIP_";
+    for (const char *c = name; *c; ++c) e.push_back((char)toupper((unsigned char)*c));
+    return e;
+}
+}  // namespace
+bool ctx_opt_is_set(const jv_ctx *ctx, const char *name)
+{
+    if (ctx && ctx->opts.count(name)) return true;
+    return getenv(env_name(name).c_str()) != nullptr;
+}
+long long ctx_opt(const jv_ctx *ctx, const char *name, long long dflt)
+{
+    if (ctx) {
+        auto it = ctx->opts.find(name);
+        if (it != ctx->opts.end()) return it->second;
+    }
+    const char *e = getenv(env_name(name).c_str());
+    if (!e) return dflt;
+    if (!strcmp(name, "graph_traversal")) return !strcmp(e, "host") ? JV_TRAVERSAL_HOST : (!strcmp(e, "device") ? JV_TRAVERSAL_DEVICE : dflt);
+    return atoll(e);
+}
+}  // namespace jv
+extern "C" {
+
+int jv_hip_ctx_set_option(jv_ctx *ctx, const char *name, int64_t value)
+{
+    clear_error();
+    JV_REQUIRE(ctx && name, "ctx_set_option: NULL argument");
+    for (const char *k : kOptions)
+        if (!strcmp(k, name)) {
+            ctx->opts[name] = (long long)value;
+            return JV_OK;
+        }
+    set_error("ctx_set_option: unknown option '%s'", name);
+    return JV_ERR_INVALID;
+}
+
+int jv_hip_ctx_clear_option(jv_ctx *ctx, const char *name)
+{
+    clear_error();
+    JV_REQUIRE(ctx && name, "ctx_clear_option: NULL argument");
+    ctx->opts.erase(name);
+    return JV_OK;
+}
+
+int jv_hip_ctx_get_stat(jv_ctx *ctx, const char *name, int64_t *out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && name && out, "ctx_get_stat: NULL argument");
+    auto it = ctx->stats.find(name);
+    *out = it == ctx->stats.end() ? 0 : (int64_t)it->second;
+    return JV_OK;
+}
+
+int jv_hip_ctx_reset_stats(jv_ctx *ctx)
+{
+    clear_error();
+    JV_REQUIRE(ctx, "ctx_reset_stats: NULL argument");
+    ctx->stats.clear();
+    return JV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // ProductQuantization
 // ------------------------------------------------------------------------------------------------
@@ -1197,7 +1269,7 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
     // ---------------- pass 1 ----------------
     bool done1 = false;
     const bool mq = adc_mq_supported(codes->M, codes->d_codes) && Q >= 2;
-    if (mq && N >= (1 << 18) && (int64_t)k1 * 64 <= N && getenv("JVECTOR_HIP_NO_FILTER") == nullptr) {
+    if (mq && N >= (1 << 18) && (int64_t)k1 * 64 <= N && ctx_opt(ctx, "no_filter", 0) == 0) {
         const int64_t c_target = std::max<int64_t>(8 * (int64_t)k1, 4096);
         int64_t S_target = std::max<int64_t>(16384, next_pow2_i64(32 * N / c_target));
         const int64_t stride = std::max<int64_t>(1, N / S_target);

@@ -1232,12 +1232,6 @@ static int ensure_device_graph(jv_ctx *ctx, jv_graph *g)
     return JV_OK;
 }
 
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
                                const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
                                int32_t *out_ids, float *out_scores, int64_t *stats, AcceptMask host_accept, AcceptMask dev_accept)
@@ -1258,29 +1252,59 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // in flight per wave) or 4 (JVECTOR_HIP_GS_OCC=4: 128 VGPRs, no pair-lane scoring).  Measured on MI355X at 1M x 768:
     // 2 waves/SIMD + pair lanes 19.0 ms per 16384-query batch; 4 waves/SIMD 25.1 ms; a 3 waves/SIMD build (168 VGPRs, 12 waves
     // per CU) 28.3 ms — fewer gathers in flight per wave cost more than the extra waves hide (profiles/r2_sweeps.md).
-    const int occ = env_int("JVECTOR_HIP_GS_OCC", 2) >= 4 ? 4 : 2;
+    const int occ = ctx_opt(ctx, "gs_occ", 2) >= 4 ? 4 : 2;
     // pair-lane scoring (two lanes per neighbour) when no level has more than 32 neighbours; it needs an M/2 x 32 float
-    // exchange area in LDS.  JVECTOR_HIP_GS_PAIR=0 turns it off.
-    bool pair = occ == 2 && env_int("JVECTOR_HIP_GS_PAIR", 1) != 0;
+    // exchange area in LDS.  gs_pair = 0 turns it off.
+    bool pair = occ == 2 && ctx_opt(ctx, "gs_pair", 1) != 0;
     for (int lv = 0; lv <= g->entry_level; ++lv) pair = pair && g->levels[lv].degree <= 32;
     // M >= 128: the pair form's two half rows + exchange indices no longer fit 256 VGPRs (156 / 588 bytes of scratch per
     // lane at M = 128 / 192, -Rpass-analysis=kernel-resource-usage) while the one-lane-per-neighbour form still does
     pair = pair && pq->M <= 96;
     const int pair_M = pair ? pq->M : 0;
-    const int evict_cap = GS_EVICT_CAP;
-    int cand_cap = std::max(256, env_int("JVECTOR_HIP_GS_CAND_CAP", occ == 4 ? 512 : (pair ? 256 : 1024))) & ~63;
+    int evict_cap = GS_EVICT_CAP;
+    int cand_cap = std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", occ == 4 ? 512 : (pair ? 256 : 1024))) & ~63;
     while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
-    const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap);
+    // Visited set, tier 1 (gs_body.h gs_visit1): an LDS table of 16-bit entries in whatever the other per-worker structures
+    // leave of 160 KB / (4 x occ workers per CU).  Preference: the largest table first (4096 slots = 8 KB hold the median
+    // search of the headline workload: ~2200 visited nodes), giving up candidate-tier / evicted-list capacity before table size
+    // (LDS tier sizes 256 / 512 / 768 measured within 3 % of each other in round 2; a full evicted list only costs a retry);
+    // gs_v1_log2 = 0 turns the tier off, a positive value pins it.  Graphs too large for the entry format (more than 13
+    // remainder bits) get a bigger table or none.
+    const int idbits = gs_idbits(g->n_nodes);
+    const int want_per_cu = 4 * occ;
+    const size_t lds_budget = (160 * 1024) / (size_t)want_per_cu - 256;
+    int v1_log2 = 0;
+    {
+        // (a pinned gs_vcap_log2 is how tests drive the overflow paths of tier 2: no LDS tier in front of it then, unless asked for)
+        const long long pin = ctx_opt(ctx, "gs_v1_log2", ctx_opt_is_set(ctx, "gs_vcap_log2") ? 0 : -1);
+        struct Caps { int cand, evict; };
+        const Caps caps[3] = {{cand_cap, evict_cap}, {std::min(cand_cap, 128), evict_cap}, {std::min(cand_cap, 128), 64}};
+        bool done = false;
+        for (int lg = pin > 0 ? (int)pin : 12; lg >= (pin > 0 ? (int)pin : 10) && !done && pin != 0; --lg) {
+            if (!gs_v1_fits(lg, idbits)) continue;
+            for (const Caps &c : caps) {
+                if (ctx_opt_is_set(ctx, "gs_cand_cap") && c.cand != cand_cap) continue;
+                if (graph_search_lds_bytes(pq->D, rerankK, c.cand, pair_M, c.evict, lg) <= lds_budget || (pin > 0 && &c == &caps[2])) {
+                    v1_log2 = lg;
+                    cand_cap = c.cand;
+                    evict_cap = c.evict;
+                    done = true;
+                    break;
+                }
+            }
+        }
+    }
+    const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap, v1_log2);
     if (lds > ctx->lds_per_block) {
         set_error("graph_search(device): rerankK %d needs %zu bytes of LDS per wave (limit %zu); use the host traversal", rerankK,
                   lds, ctx->lds_per_block);
         return JV_ERR_UNSUPPORTED;
     }
     int per_cu = (int)std::min<size_t>((size_t)4 * occ, std::max<size_t>(1, (160 * 1024) / (lds + 256)));
-    per_cu = std::max(1, env_int("JVECTOR_HIP_GS_WAVES_PER_CU", per_cu));
+    per_cu = std::max(1, (int)ctx_opt(ctx, "gs_waves_per_cu", per_cu));
     const int workers = std::max(1, std::min(Q, ctx->num_cus * per_cu));
     // JVECTOR_HIP_GS_VCAP_LOG2 overrides the visited-table size (tests use a tiny table to drive the host fallback)
-    const int vcap_log2 = std::max(8, std::min(24, env_int("JVECTOR_HIP_GS_VCAP_LOG2", gs_vcap_log2(rerankK))));
+    const int vcap_log2 = std::max(8, std::min(24, (int)ctx_opt(ctx, "gs_vcap_log2", gs_vcap_log2(rerankK))));
     const size_t vcap = (size_t)1 << vcap_log2;
     const int spill_cap = (int)(vcap / 2) + 64;  // pushes <= visited <= vcap / 2: the spill tier cannot overflow first
     JV_TRY(ctx->d_gs_visited.reserve(sizeof(int32_t) * vcap * (size_t)workers));
@@ -1289,7 +1313,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // one of these 8x tables inside the kernel instead of costing a second launch; JVECTOR_HIP_GS_GROW=0 turns it off
     const int big_log2 = std::min(24, vcap_log2 + 3);
     // (a pinned JVECTOR_HIP_GS_VCAP_LOG2 is how tests reach the retry / host-fallback paths: no pool then unless asked for)
-    const bool grow_on = getenv("JVECTOR_HIP_GS_GROW") ? env_int("JVECTOR_HIP_GS_GROW", 1) != 0 : getenv("JVECTOR_HIP_GS_VCAP_LOG2") == nullptr;
+    const bool grow_on = ctx_opt_is_set(ctx, "gs_grow") ? ctx_opt(ctx, "gs_grow", 1) != 0 : !ctx_opt_is_set(ctx, "gs_vcap_log2");
     // pool size: ~3 % of the batch (p99.9 of the visited count is 2.2x the median on the benched graphs, so well under 1 % of
     // the queries outgrow a base table sized at 64 x rerankK), at least 64, at most 2048 tables (1 GB at rerankK 110)
     const int big_count = (grow_on && big_log2 > vcap_log2) ? std::max(1, std::min(Q, std::max(64, std::min(2048, Q / 32)))) : 0;
@@ -1313,19 +1337,19 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const size_t o_stats = carve(sizeof(long long) * 2 * (size_t)Q), o_status = carve(sizeof(int32_t) * (size_t)Q);
     const size_t o_counter = carve(sizeof(uint32_t) * 2);
     const size_t o_qmap = carve(sizeof(int32_t) * (size_t)Q);
-    const bool gs_prof = env_int("JVECTOR_HIP_GS_PROF", 0) != 0;
+    const bool gs_prof = ctx_opt(ctx, "gs_prof", 0) != 0;
     const size_t o_prof = carve(sizeof(unsigned long long) * 12);
     // exact-score ties across the K-th place of the rerank are decided by the order of the reference's result-heap array
     // (NodeQueue.java:197-214): the traversal logs its addTopCandidate sequence (avg ~1 entry per expansion) and
     // rerank_tie_kernel rebuilds the reference's answer for the (rare) tied queries; an overflowed log sends the query to
     // the host searcher instead.  JVECTOR_HIP_GS_TIE_CHECK=0 turns the whole check off, JVECTOR_HIP_GS_PUSH_LOG=0 the log only.
-    const bool tie_check = vectors != nullptr && rerankK > topK && env_int("JVECTOR_HIP_GS_TIE_CHECK", 1) != 0;
+    const bool tie_check = vectors != nullptr && rerankK > topK && ctx_opt(ctx, "gs_tie_check", 1) != 0;
     int log_cap = 0;
-    if (tie_check && env_int("JVECTOR_HIP_GS_PUSH_LOG", 1) != 0) {
+    if (tie_check && ctx_opt(ctx, "gs_push_log", 1) != 0) {
         log_cap = std::max(256, 4 * rerankK);
         const size_t budget = (size_t)1 << 30;
         if ((size_t)Q * log_cap * sizeof(long long) > budget) log_cap = (int)std::max<size_t>(64, budget / ((size_t)Q * sizeof(long long)));
-        if (const char *e = getenv("JVECTOR_HIP_GS_PUSH_LOG_CAP")) log_cap = std::max(1, atoi(e));
+        if (ctx_opt_is_set(ctx, "gs_push_log_cap")) log_cap = std::max(1, (int)ctx_opt(ctx, "gs_push_log_cap", log_cap));
     }
     const size_t o_log = carve(sizeof(long long) * (size_t)Q * (size_t)log_cap), o_log_n = carve(sizeof(int32_t) * (size_t)Q);
     JV_TRY(ctx->d_gs_out.reserve(off));
@@ -1372,6 +1396,8 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.spill_cap = spill_cap;
     p.cand_cap = cand_cap;
     p.evict_cap = evict_cap;
+    p.v1_log2 = v1_log2;
+    p.v1_idbits = idbits;
     if (big_count > 0) {
         p.big_visited = (int32_t *)ctx->d_gs_big.ptr;
         p.big_spill = (long long *)((char *)ctx->d_gs_big.ptr + big_spill_off);
@@ -1413,7 +1439,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     }
     // JVECTOR_HIP_GS_VCAP_LOG2 pins a (tiny) table so that tests reach the host fallback: no retry then, unless
     // JVECTOR_HIP_GS_RETRY=1 asks for it (the test of this very path)
-    const bool retry = getenv("JVECTOR_HIP_GS_RETRY") ? env_int("JVECTOR_HIP_GS_RETRY", 1) != 0 : getenv("JVECTOR_HIP_GS_VCAP_LOG2") == nullptr;
+    const bool retry = ctx_opt_is_set(ctx, "gs_retry") ? ctx_opt(ctx, "gs_retry", 1) != 0 : !ctx_opt_is_set(ctx, "gs_vcap_log2");
     for (int attempt = 1; attempt <= 2 && !redo.empty() && retry; ++attempt) {
         const int vlog2 = std::min(24, vcap_log2 + 3 * attempt);
         if (vlog2 <= vcap_log2 + 3 * (attempt - 1)) break;
@@ -1529,12 +1555,48 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
             if (hs[q] == GS_RERANK_TIE) redo.push_back(q);
         std::sort(redo.begin(), redo.end());
     }
-    if (getenv("JVECTOR_HIP_GRAPH_TIMING"))
-        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d) lds=%zu cand_cap=%d vcap=%zu overflow=%zu rerank ties=%zu (+%zu to the host) -> host %zu\n", Q,
-                workers, per_cu, occ, (int)pair, lds, cand_cap, vcap, n_overflow_first, n_ties_resolved, n_ties, redo.size());
+    ctx_stat_add(ctx, "gs_calls_device", 1);
+    ctx_stat_add(ctx, "gs_queries_device", Q);
+    ctx_stat_add(ctx, "gs_queries_retried", (long long)n_overflow_first);
+    ctx_stat_add(ctx, "gs_ties_resolved_device", (long long)n_ties_resolved);
+    ctx_stat_add(ctx, "gs_ties_to_host", (long long)n_ties);
+    ctx_stat_add(ctx, "gs_queries_host_fallback", (long long)redo.size());
+    ctx_stat_set(ctx, "gs_last_v1_log2", v1_log2);
+    ctx_stat_set(ctx, "gs_last_workers_per_cu", per_cu);
+    if (ctx_opt(ctx, "graph_timing", 0) != 0)
+        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d) lds=%zu cand_cap=%d evict_cap=%d v1_log2=%d vcap=%zu overflow=%zu rerank ties=%zu (+%zu to the host) -> host %zu\n", Q,
+                workers, per_cu, occ, (int)pair, lds, cand_cap, evict_cap, v1_log2, vcap, n_overflow_first, n_ties_resolved, n_ties, redo.size());
     if (redo.empty()) return JV_OK;
 
     // ---- queries that outgrew the fixed-size device structures: same search on the host ----
+    // A graph whose level 0 lives in caller-owned device memory (jv_hip_graph_set_level0_device) has no host adjacency: the
+    // host searcher walks a temporary copy of it (a build-time graph is small next to its vectors; the case is rare: a query
+    // that overflowed the 64x visited table, or an exact-score tie whose push log overflowed).
+    jv_graph *gm = const_cast<jv_graph *>(g);
+    std::unique_lock<std::mutex> loan_lock(gm->dev_mu, std::defer_lock);  // two contexts falling back at once: one copy at a time
+    if (g->dev_level0) loan_lock.lock();
+    struct Level0Loan {  // (declared after the lock: the copy is dropped before the lock is released)
+        jv_graph *g;
+        bool active = false;
+        ~Level0Loan()
+        {
+            if (active) {
+                g->levels[0].nbrs.clear();
+                g->levels[0].nbrs.shrink_to_fit();
+            }
+        }
+    } loan{gm};
+    if (g->dev_level0 && g->levels[0].nbrs.empty()) {
+        const size_t cells = (size_t)g->n_nodes * (size_t)g->levels[0].degree;
+        try {
+            gm->levels[0].nbrs.resize(cells);
+        } catch (const std::bad_alloc &) {
+            set_error("graph_search: %zu queries need the host searcher but the device-resident level 0 (%zu ids) cannot be copied to the host", redo.size(), cells);
+            return JV_ERR_OOM;
+        }
+        loan.active = true;
+        JV_HIP_CHECK(hipMemcpy(gm->levels[0].nbrs.data(), g->dev_level0, sizeof(int32_t) * cells, hipMemcpyDeviceToHost));
+    }
     const int D = pq->D, R = (int)redo.size();
     std::vector<float> sub((size_t)R * D);
     const bool q_dev = is_device_ptr(queries);
@@ -1594,11 +1656,9 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
     // Traversal: the graph's setting, overridden by JVECTOR_HIP_GRAPH_TRAVERSAL=host|device.  AUTO = the device-resident
     // traversal wherever it applies (uniform 8-dim sub-vectors, supported M / degree, queues fit LDS — validated on
     // MI355X in round 2, 7-8x the host searcher's throughput), the host searcher for every other shape.
-    int mode = g->traversal;
-    if (const char *e = getenv("JVECTOR_HIP_GRAPH_TRAVERSAL")) {
-        if (!strcmp(e, "device")) mode = JV_TRAVERSAL_DEVICE;
-        else if (!strcmp(e, "host")) mode = JV_TRAVERSAL_HOST;
-    }
+    int mode = (int)ctx_opt(ctx, "graph_traversal", g->traversal);
+    if (mode != JV_TRAVERSAL_HOST && mode != JV_TRAVERSAL_DEVICE) mode = JV_TRAVERSAL_AUTO;
+    const bool was_auto = mode == JV_TRAVERSAL_AUTO;
     if (mode == JV_TRAVERSAL_AUTO) {
         int Wd = 0;
         for (int lv = 0; lv <= g->entry_level && lv < (int)g->levels.size(); ++lv) Wd = std::max(Wd, g->levels[lv].degree);
@@ -1638,6 +1698,18 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
         JV_REQUIRE(!fused, "graph_search: FusedPQ blocks cannot be checked against a device-resident, mutable adjacency; search it with the code store");
     }
     if (mode != JV_TRAVERSAL_DEVICE || Q == 0) {
+        if (Q > 0) {
+            ctx_stat_add(ctx, "gs_calls_host", 1);
+            if (was_auto) {  // say so: the host searcher is ~13x slower than the device traversal
+                ctx_stat_add(ctx, "gs_calls_host_auto", 1);
+                int64_t n_auto = 0;
+                (void)jv_hip_ctx_get_stat(ctx, "gs_calls_host_auto", &n_auto);
+                if (n_auto == 1 && ctx_opt(ctx, "quiet", 0) == 0)
+                    fprintf(stderr, "[jvector_hip] graph_search: JV_TRAVERSAL_AUTO takes the HOST searcher for this shape (the device traversal needs "
+                                    "uniform 8-dim sub-vectors, M in {16,32,48,64,96,128,192}, degree <= 64, queues that fit LDS); counter "
+                                    "gs_calls_host_auto counts further calls\n");
+            }
+        }
         HostSearchOpts opt;
         opt.accept = host_accept;
         return graph_search_host(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, out_ids, out_scores, stats, opt);

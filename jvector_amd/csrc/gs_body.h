@@ -12,6 +12,7 @@
 //     gs_cas(int32_t *p, int32_t expect, int32_t desired) -> old      (device-scope atomic)
 //     gs_fetch_add(uint32_t *p, uint32_t v) -> old                    (device-scope atomic)
 //     gs_fetch_add64(unsigned long long *p, unsigned long long v)     (device-scope atomic; profiling aid only)
+//     gs_lds_cas(uint32_t *p, uint32_t expect, uint32_t desired) -> old    (LDS atomic, workgroup scope)
 //     gs_fence()                              device-scope memory fence
 //     gs_sqrt(double)
 //     GS_SCHED_FENCE()                        instruction-scheduling fence (may be empty)
@@ -30,8 +31,10 @@
 //               stops long before it has to pop from the spill tier; that path exists but is a plain scan.
 //   results     (BoundedLongHeap(rerankK), MIN_HEAP)  LDS array + cached minimum; replace-min = rescan.
 //   evicted     (upper layers, rk = 1)               LDS array.
-//   visited     open-addressing hash table of node ids in global memory (one per worker, cleared per query);
-//               the <= 64 neighbours of an expansion are inserted by their lanes concurrently with CAS.
+//   visited     two-tier open-addressing set, the <= 64 neighbours of an expansion inserted by their lanes concurrently
+//               with CAS.  Tier 1: 16-bit entries in LDS (gs_visit1).  Tier 2: node ids in global memory (one table per
+//               worker), touched — and only then cleared — by the queries whose tier 1 fills up (or by all of them when
+//               the launch has no LDS tier, GsParams::v1_log2 == 0).
 // Scores: table-free ADC (k_frontier.hip's direct variant): lane i recomputes the look-up entries its neighbour's
 // code selects from the L2-resident codebook, summing in ascending m into one f32 — bit-identical to
 // assembleAndSum / pqDecodedCosineSimilarity on the decoder's tables (uniform 8-dim sub-vectors only).
@@ -257,6 +260,48 @@ GS_FN bool gs_visit(int32_t *tab, uint32_t mask, int shift, int32_t node)
     }
 }
 
+// ---- two-tier visited set, tier 1 (LDS) ----
+// Node ids are < 2^idbits.  h = node * odd mod 2^idbits is a bijection on them; its top bits pick the home slot, the
+// remaining rbits = idbits - log2(slots) bits are the remainder r.  An entry sits at most dmax slots past its home
+// (linear probing) and is stored as 16 bits (d << rbits | r): (slot - d, r) identify h and therefore the node EXACTLY, at
+// half the bytes of a node id — 4096 slots are 8 KB, which is what 8 waves per CU leave free in LDS at the headline shape.
+// 0xFFFF = empty (d <= dmax = 2^(16 - rbits) - 2 keeps real entries away from it).
+// Returns 0: already in the set; 1: inserted here (fresh); 2: cannot live in this tier — no free slot within dmax of its
+// home, or the tier is frozen.  Both conditions are permanent for that node (slots are never freed, a frozen tier never
+// thaws), so a node answered 2 once is answered 2 on every later probe and tier 2 alone decides about it: a node is in
+// exactly one tier.
+struct GsVis1 {
+    uint32_t *w;       // LDS words, two entries each
+    uint32_t smask;    // slots - 1
+    uint32_t idmask;   // 2^idbits - 1
+    int rbits, dmax;
+};
+
+GS_FN int gs_visit1(const GsVis1 &t, bool frozen, int32_t node)
+{
+    const uint32_t h = ((uint32_t)node * 0x9E3779B1u) & t.idmask;
+    const uint32_t home = (h >> t.rbits) & t.smask;
+    const uint32_t r = h & ((1u << t.rbits) - 1u);
+    for (int d = 0; d <= t.dmax; ++d) {
+        const uint32_t slot = (home + (uint32_t)d) & t.smask;
+        uint32_t *wp = t.w + (slot >> 1);
+        const int sh = (int)(slot & 1u) * 16;
+        const uint32_t mine = ((uint32_t)d << t.rbits) | r;
+        uint32_t w = *wp;
+        for (;;) {
+            const uint32_t cur = (w >> sh) & 0xFFFFu;
+            if (cur == mine) return 0;
+            if (cur != 0xFFFFu) break;  // another node's entry: next slot
+            if (frozen) return 2;
+            const uint32_t want = (w & ~(0xFFFFu << sh)) | (mine << sh);
+            const uint32_t old = gs_lds_cas(wp, w, want);
+            if (old == w) return 1;
+            w = old;  // a neighbouring lane changed the word (this slot or its twin): look again
+        }
+    }
+    return 2;
+}
+
 // upper-level adjacency row of `node`, or nullptr (uniform: every lane probes the same slots)
 GS_FN const int32_t *gs_level_row(const GsLevel &L, int32_t node)
 {
@@ -389,6 +434,25 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     int vshift = 32 - p.vcap_log2;
     int32_t *vis = p.visited + (int64_t)worker * vcap;
     bool grown = false;
+    // tier 1 of the visited set (LDS), behind everything else in the worker's LDS block.  Its geometry is re-derived from the
+    // launch parameters at every use (gs_v1_of) instead of living in registers across the scoring loop.
+    const bool has_v1 = p.v1_log2 > 0;
+    auto gs_v1_of = [&]() -> GsVis1 {
+        GsVis1 t;
+        const size_t base = ((size_t)((char *)(xchg + 32 * (PAIR ? p.M / 2 : 0)) - lds) + (PAIR ? 0 : sizeof(long long) * 64) + 15) & ~(size_t)15;
+        t.w = reinterpret_cast<uint32_t *>(lds + base);
+        t.smask = (1u << p.v1_log2) - 1u;
+        t.idmask = (p.v1_idbits >= 32) ? 0xFFFFFFFFu : ((1u << p.v1_idbits) - 1u);
+        t.rbits = p.v1_idbits > p.v1_log2 ? p.v1_idbits - p.v1_log2 : 0;
+        const int dlim = (1 << (16 - t.rbits)) - 2;
+        t.dmax = dlim < 30 ? dlim : 30;
+        return t;
+    };
+    const int v1_cap = has_v1 ? (3 << p.v1_log2) >> 2 : 0;  // freeze at 3/4 full: misses then cost <= ~8 LDS probes
+    int n1 = 0;
+    long long n2 = 0;            // nodes in tier 2
+    bool frozen = false;
+    bool t2_ready = !has_v1;     // tier 2 cleared for this query (eagerly below when there is no LDS tier)
     // The visited table is half full: move to a table of the growth pool (once per query), or give up with GS_OVERFLOW.
     // Wave-uniform.  The old table is read back with atomics (a CAS that can never succeed), like every other access to it.
     auto grow = [&]() -> bool {
@@ -428,11 +492,45 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     };
     long long n_visited = 0, n_expanded = 0;
 
-    // ---- per-query setup: clear the visited table, stage the centred query ----
-    {
+    // tier 2 is cleared by the first probe that needs it (wave-uniform call)
+    auto t2_init = [&]() {
         gs_u4 *v4 = reinterpret_cast<gs_u4 *>(vis);
         const gs_u4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
         for (int i = lane; i < vcap / 4; i += 64) v4[i] = ones;
+        gs_fence();
+        gs_barrier();
+        t2_ready = true;
+    };
+    // visited.add for one node per participating lane; true = the node was not in the set.  Wave-uniform call (every lane
+    // enters, `act` says whether it carries a node).  Sets s.status on table overflow.
+    auto visit = [&](bool act, int32_t nb) -> bool {
+        int r1 = act ? 2 : 0;
+        if (has_v1) {
+            if (act) r1 = gs_visit1(gs_v1_of(), frozen, nb);
+            n1 += gs_popc(gs_ballot(r1 == 1));
+            if (n1 >= v1_cap) frozen = true;
+        }
+        bool fr = r1 == 1;
+        if (gs_ballot(r1 == 2)) {
+            if (!t2_ready) t2_init();
+            const bool f2 = r1 == 2 && gs_visit(vis, vmask, vshift, nb);
+            fr = fr || f2;
+            n2 += gs_popc(gs_ballot(f2));
+            if ((n2 + 1) * 2 > vcap && !((n2 + 1) * 2 <= (1ll << p.big_log2) && grow())) s.status = GS_OVERFLOW;
+        }
+        return fr;
+    };
+
+    // ---- per-query setup: clear the visited set, stage the centred query ----
+    {
+        const gs_u4 ones = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        if (has_v1) {
+            gs_u4 *t4 = reinterpret_cast<gs_u4 *>(gs_v1_of().w);
+            for (int i = lane; i < (int)((2u << p.v1_log2) / 16u); i += 64) t4[i] = ones;
+        } else {
+            gs_u4 *v4 = reinterpret_cast<gs_u4 *>(vis);
+            for (int i = lane; i < vcap / 4; i += 64) v4[i] = ones;
+        }
         const gs_f4 *src = reinterpret_cast<const gs_f4 *>(p.cq + (int64_t)q * p.D);
         gs_f4 *dst = reinterpret_cast<gs_f4 *>(qs);
         for (int i = lane; i < p.D / 4; i += 64) dst[i] = src[i];
@@ -445,7 +543,14 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     // ---- initializeInternal :334-353: mark and score the entry node ----
     {
         const int32_t e = p.entry_node;
-        if (lane == 0) (void)gs_visit(vis, vmask, vshift, e);
+        // first insertion into an empty set: no probing conflicts, no growth check
+        if (has_v1) {
+            if (lane == 0) (void)gs_visit1(gs_v1_of(), false, e);
+            n1 = 1;
+        } else {
+            if (lane == 0) (void)gs_visit(vis, vmask, vshift, e);
+            n2 = 1;
+        }
         gs_u4 we[CH16];
         gs_load_row<CH16>(p.codes + (int64_t)e * p.M, we);
         float sc = gs_row_sum<VSF, CH16>(p.codebooks, qs, we);
@@ -554,14 +659,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     gs_load_half<CH16>(p.codes + (int64_t)nb * p.M + m_base, w);
                     if (VSF == 2 && !hi) node_mag = p.code_norms[nb];
                 }
-                fresh = !hi && valid && gs_visit(vis, vmask, vshift, nb);  // one probe per neighbour: the low lane's
+                fresh = visit(!hi && valid, nb);  // one probe per neighbour: the low lane's
+                if (s.status != GS_OK) break;
                 const uint64_t fm = gs_ballot(fresh);
                 if (fm == 0) continue;
                 n_visited += gs_popc(fm);
-                if ((n_visited + 1) * 2 > vcap && !((n_visited + 1) * 2 <= (1ll << p.big_log2) && grow())) {
-                    s.status = GS_OVERFLOW;
-                    break;
-                }
                 GS_PHASE(2);
                 if (PROF) {
                     const int f = gs_popc(fm);
@@ -592,14 +694,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     gs_load_row<CH16>(p.codes + (int64_t)nb * p.M, w);
                     if (VSF == 2) node_mag = p.code_norms[nb];
                 }
-                fresh = valid && gs_visit(vis, vmask, vshift, nb);
+                fresh = visit(valid, nb);
+                if (s.status != GS_OK) break;
                 const uint64_t fm = gs_ballot(fresh);
                 if (fm == 0) continue;
                 n_visited += gs_popc(fm);
-                if ((n_visited + 1) * 2 > vcap && !((n_visited + 1) * 2 <= (1ll << p.big_log2) && grow())) {
-                    s.status = GS_OVERFLOW;
-                    break;
-                }
                 GS_PHASE(2);
                 if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CH16>(p.codebooks, qs, w), node_mag, query_mag));
             }

@@ -51,6 +51,10 @@ struct GsParams {
     int32_t cand_cap;         // LDS tier capacity (>= 256)
     int32_t evict_cap;        // capacity of the upper-layer evicted list in LDS (0 = GS_EVICT_CAP)
     int32_t pair;             // 1: pair-lane scoring (every degree <= 32; LDS has the M/2 x 32 exchange area)
+    // visited set, tier 1: an open-addressing table of 16-bit entries in LDS (gs_body.h "two-tier visited set"); the global
+    // table above is tier 2 and is only touched (and only then cleared) by a query whose tier 1 fills up.
+    int32_t v1_log2;          // log2(slots) of the LDS tier, 0 = no LDS tier (every probe goes to the global table)
+    int32_t v1_idbits;        // node ids are < 1 << v1_idbits; v1_idbits - v1_log2 remainder bits + displacement bits = 16
     // outputs
     int32_t *out_ids;         // [Q][rerankK] kept approximate results (unordered), -1 padded
     float *out_scores;        // [Q][rerankK] their approximate scores, -inf padded
@@ -67,11 +71,21 @@ struct GsParams {
 
 // LDS bytes one worker needs
 inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M when pair-lane scoring is on, else 0 */,
-                           int evict_cap = GS_EVICT_CAP)
+                           int evict_cap = GS_EVICT_CAP, int v1_log2 = 0)
 {
     // (the 64-key sample buffer of the partition step shares the pair-lane exchange area when there is one)
-    return sizeof(float) * (size_t)D + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + (size_t)evict_cap + (pair_M ? 0 : 64)) +
-           sizeof(float) * 32 * (size_t)(pair_M / 2);
+    const size_t base = sizeof(float) * (size_t)D + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + (size_t)evict_cap + (pair_M ? 0 : 64)) +
+                        sizeof(float) * 32 * (size_t)(pair_M / 2);
+    return v1_log2 > 0 ? ((base + 15) & ~(size_t)15) + ((size_t)2 << v1_log2) : base;
+}
+
+// The LDS tier's entry format needs >= 3 displacement bits: 16 - (idbits - v1_log2) >= 3.
+inline bool gs_v1_fits(int v1_log2, int idbits) { return v1_log2 >= 6 && v1_log2 <= 15 && idbits - v1_log2 <= 13 && idbits <= 31; }
+inline int gs_idbits(long long n_nodes)
+{
+    int b = 1;
+    while ((1ll << b) < n_nodes && b < 31) ++b;
+    return b;
 }
 
 // rerank tie resolution (rt_body.h / rerank_tie_kernel)

@@ -16,6 +16,14 @@ __device__ __forceinline__ uint64_t gs_ballot(bool p) { return (uint64_t)__ballo
 __device__ __forceinline__ long long gs_shfl(long long v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ long long gs_shfl_xor(long long v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired) { return atomicCAS(p, expect, desired); }
+// LDS atomic (ds_cmpst_rtn_b32): p points into the workgroup's LDS block
+__device__ __forceinline__ uint32_t gs_lds_cas(uint32_t *p, uint32_t expect, uint32_t desired)
+{
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32 *lp = (lds_u32 *)p;
+    __hip_atomic_compare_exchange_strong(lp, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return expect;
+}
 __device__ __forceinline__ uint32_t gs_fetch_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void gs_fetch_add64(unsigned long long *p, unsigned long long v) { (void)atomicAdd(p, v); }
 #define GS_CLOCK() ((unsigned long long)__builtin_readcyclecounter())

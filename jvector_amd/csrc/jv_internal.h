@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "../../include/jvector_hip.h"
@@ -84,9 +86,18 @@ struct jv_ctx {
     // a context belongs to ONE host thread (jvector_hip.h); the long-running searches take this flag and refuse a second
     // concurrent caller instead of corrupting the shared staging buffers / worker pool
     std::atomic<int> busy{0};
+    // jv_hip_ctx_set_option / jv_hip_ctx_get_stat (jvector_hip.h): per-context tuning options (they win over the process-wide
+    // JVECTOR_HIP_* environment defaults) and event counters of the searches that ran on this context
+    std::map<std::string, long long> opts, stats;
 };
 
 namespace jv {
+// option `name` of this context: set by jv_hip_ctx_set_option, else the environment variable JVECTOR_HIP_<NAME>, else dflt
+long long ctx_opt(const jv_ctx *ctx, const char *name, long long dflt);
+bool ctx_opt_is_set(const jv_ctx *ctx, const char *name);
+inline void ctx_stat_add(jv_ctx *ctx, const char *name, long long v) { ctx->stats[name] += v; }
+inline void ctx_stat_set(jv_ctx *ctx, const char *name, long long v) { ctx->stats[name] = v; }
+
 struct CtxBusy {
     jv_ctx *c;
     bool ok;
@@ -280,7 +291,7 @@ struct GsParams;
 // tables (jv_hip_luts_build = with_tables true).  The table-free traversal kernels pass false: 96 KB per query saved.
 int luts_prepare(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_vsf vsf, jv_decoder_kind kind, bool with_tables);
 bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels);
-size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap = 0);
+size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap = 0, int v1_log2 = 0);
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy);
 size_t topk_scratch_bytes(int Q, int k);
 struct RtParams;

@@ -88,15 +88,15 @@ bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const
            n_levels <= GS_MAX_LEVELS;
 }
 
-size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap)
+size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap, int v1_log2)
 {
-    return gs_lds_bytes(D, rerankK, cand_cap, pair_M, evict_cap > 0 ? evict_cap : GS_EVICT_CAP);
+    return gs_lds_bytes(D, rerankK, cand_cap, pair_M, evict_cap > 0 ? evict_cap : GS_EVICT_CAP, v1_log2);
 }
 
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy)
 {
     if (p.Q == 0) return JV_OK;
-    const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP);
+    const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2);
     const int ch = p.M / 16;
     if (p.prof) {
         if (!(vsf == VSF_COS && ch == 6 && p.pair && occupancy < 4)) {

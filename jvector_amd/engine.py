@@ -125,6 +125,24 @@ class HipContext:
         """Start (and reset) / stop HIP-event timing of the kernel regions on this context's stream."""
         check(self._lib.jv_hip_ctx_profile(self._h, 1 if enable else 0))
 
+    def set_option(self, name, value):
+        """jv_hip_ctx_set_option: a tuning option of THIS context (wins over the JVECTOR_HIP_<NAME> environment default);
+        value None clears it"""
+        if value is None:
+            check(self._lib.jv_hip_ctx_clear_option(self._h, name.encode()))
+        else:
+            check(self._lib.jv_hip_ctx_set_option(self._h, name.encode(), int(value)))
+        return self
+
+    def stat(self, name):
+        """jv_hip_ctx_get_stat: event counter of the searches that ran on this context (0 for names never counted)"""
+        v = C.c_int64()
+        check(self._lib.jv_hip_ctx_get_stat(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def reset_stats(self):
+        check(self._lib.jv_hip_ctx_reset_stats(self._h))
+
     def profile_read(self, region):
         """(total_ms, count) of a region: 'adc', 'topk', 'exact', 'lut', 'encode', 'norms'. Synchronises."""
         ms, cnt = C.c_double(), C.c_int64()

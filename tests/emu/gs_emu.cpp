@@ -17,6 +17,12 @@ static inline int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired)
     if (old == expect) *p = desired;
     return old;
 }
+static inline uint32_t gs_lds_cas(uint32_t *p, uint32_t expect, uint32_t desired)
+{
+    const uint32_t old = *p;
+    if (old == expect) *p = desired;
+    return old;
+}
 static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
 {
     const uint32_t old = *p;
@@ -71,9 +77,11 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
                               const float *bmag, const uint8_t *codes, const float *code_norms, const uint8_t *blocks,
                               const float *fused_norms, int D, int M, int deg0, int Q, int rerankK, int vsf, int vcap_log2,
                               int spill_cap, int cand_cap, int workers, int pair_mode /* 0 off, 1 when degrees allow */, int32_t *out_ids, float *out_scores, long long *out_stats,
-                              int32_t *out_status)
+                              int32_t *out_status, int v1_log2 /* LDS tier of the visited set: log2(slots), 0 = none */, int v1_idbits,
+                              int evict_cap /* 0 = GS_EVICT_CAP */)
 {
-    if (n_levels < 1 || n_levels > jv::GS_MAX_LEVELS || M % 16 != 0 || D != 8 * M || cand_cap < 256) return -1;
+    if (n_levels < 1 || n_levels > jv::GS_MAX_LEVELS || M % 16 != 0 || D != 8 * M || cand_cap < 128) return -1;
+    if (v1_log2 > 0 && !jv::gs_v1_fits(v1_log2, v1_idbits)) return -2;
     jv::GsParams p{};
     std::vector<jv::GsLevelMap> maps((size_t)n_levels);
     for (int l = 0; l < n_levels; ++l) {
@@ -100,6 +108,8 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     bool pair = pair_mode != 0;  // same rule as graph_search.cpp
     for (int l = 0; l < n_levels; ++l) pair = pair && lv_degree[l] <= 32;
     p.pair = pair ? 1 : 0;
+    p.v1_log2 = v1_log2; p.v1_idbits = v1_idbits; p.evict_cap = evict_cap;
+    const int ecap = evict_cap > 0 ? evict_cap : jv::GS_EVICT_CAP;
     p.visited = visited; p.vcap_log2 = vcap_log2; p.spill = spill; p.spill_cap = spill_cap; p.cand_cap = cand_cap;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_stats = out_stats; p.out_status = out_status;
     uint32_t next = 0;
@@ -110,11 +120,15 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     for (int w = 0; w < workers; ++w) {
         jv::GsParams pw = p;
         pw.Q = (int)((long long)Q * (w + 1) / workers);
-        char *lds = (char *)aligned_alloc(64, jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0) + 64);
-        memset(lds, 0xa5, jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0));
+        const size_t lds_bytes = jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0, ecap, v1_log2);
+        char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
+        memset(lds, 0xa5, lds_bytes);
+        memset(lds + lds_bytes, 0x3c, 64);  // canary behind the block
         Launch L{&pw, vsf, M / 16, w, lds};
         collectives += emu::run_wave(lane_main, &L);
         next = (uint32_t)pw.Q;  // the drained worker overshot the counter by one
+        for (int i = 0; i < 64; ++i)
+            if (lds[lds_bytes + i] != 0x3c) return -3;  // the worker wrote past its LDS block
         free(lds);
     }
     free(visited);

@@ -25,6 +25,12 @@ static inline int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired)
     if (old == expect) *p = desired;
     return old;
 }
+static inline uint32_t gs_lds_cas(uint32_t *p, uint32_t expect, uint32_t desired)
+{
+    const uint32_t old = *p;
+    if (old == expect) *p = desired;
+    return old;
+}
 static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
 {
     const uint32_t old = *p;
@@ -517,9 +523,9 @@ bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const
            pq->D == 8 * pq->M && (reinterpret_cast<uintptr_t>(codes->d_codes) & 15) == 0 &&
            (!fused || (reinterpret_cast<uintptr_t>(fused->d_blocks) & 15) == 0) && max_degree <= 64 && n_levels <= GS_MAX_LEVELS;
 }
-size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap)
+size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap, int v1_log2)
 {
-    return gs_lds_bytes(D, rerankK, cand_cap, pair_M, evict_cap > 0 ? evict_cap : GS_EVICT_CAP);
+    return gs_lds_bytes(D, rerankK, cand_cap, pair_M, evict_cap > 0 ? evict_cap : GS_EVICT_CAP, v1_log2);
 }
 namespace {
 struct GsLaunch {
@@ -558,7 +564,7 @@ void gs_main(void *a)
 int launch_graph_search(hipStream_t, int vsf, const GsParams &p, int workers, int /*occupancy*/)
 {
     if (p.Q == 0) return JV_OK;
-    const size_t lds_bytes = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP);
+    const size_t lds_bytes = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2);
     // the waves of a persistent launch, one after another; wave w stops after its share so that several workers'
     // scratch slices are exercised (a real launch interleaves them)
     for (int w = 0; w < workers; ++w) {

@@ -42,7 +42,9 @@ def seq_sum_f32(table, codes):
 
 
 def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vcap_log2=14, spill_cap=8192, cand_cap=256,
-            workers=2, pair=1):
+            workers=2, pair=1, v1_log2=9, v1_idbits=None, evict_cap=0):
+    """v1_log2: slots of the visited set's LDS tier (default 512: small enough that the toy searches fill it, freeze it and go
+    on in tier 2, so both tiers and the hand-over are exercised by every test); 0 = no LDS tier"""
     N, M, D = codes.shape[0], opq.M, opq.D
     Q = q.shape[0]
     deg0 = lv[0][1].shape[1]
@@ -73,10 +75,12 @@ def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vc
     fp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     cb = np.ascontiguousarray(opq.codebooks, np.float32)
     codes = np.ascontiguousarray(codes, np.uint8)
+    if v1_idbits is None:
+        v1_idbits = max(1, int(N - 1).bit_length())
     n = emu.gs_emu_search(L, nodes, nbrs, count, degree, entry, entry_level, fp(cb), fp(cq), fp(bmag), fp(codes),
                           fp(code_norms), fp(blocks), fp(fnorms), D, M, deg0, Q, rerank_k, int(vsf), vcap_log2, spill_cap,
-                          cand_cap, workers, pair, fp(out_ids), fp(out_sc), fp(stats), fp(status))
-    assert n >= 0
+                          cand_cap, workers, pair, fp(out_ids), fp(out_sc), fp(stats), fp(status), v1_log2, v1_idbits, evict_cap)
+    assert n >= 0, n
     return out_ids, out_sc, stats, status, n
 
 
@@ -171,13 +175,42 @@ def test_exhaustive_search_pops_from_the_spill_tier(emu):
     check(ids, sc, st, status, wi, ws, wst)
 
 
+@pytest.mark.parametrize("v1_log2,idbits_extra", [(0, 0), (6, 0), (8, 0), (10, 0), (12, 0), (12, 12), (9, 4), (15, 0)])
+def test_two_tier_visited_set(emu, v1_log2, idbits_extra):
+    """the visited set's LDS tier at every size class: absent; tiny (64 / 256 slots: frozen after a few expansions, nearly
+    everything lives in tier 2); medium (some queries stay inside it, others freeze it); large (tier 2 is never touched: its
+    garbage-filled table must not matter); with more id bits than the graph needs (12 slot bits + 12 remainder bits = the
+    headline shape's entry format: 4 displacement bits, so probes run out of displacement long before the tier is full)"""
+    lv, entry, entry_level, opq, codes, q = problem(29, 3000, 128, 16, 2, deg=24, nq=8)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    idbits = max(1, int(codes.shape[0] - 1).bit_length()) + idbits_extra
+    for vsf, fused, rk, pair in ((O.COSINE, True, 120, 1), (O.EUCLIDEAN, False, 60, 0), (O.DOT_PRODUCT, True, 1, 1)):
+        wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
+        ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, pair=pair, v1_log2=v1_log2,
+                                         v1_idbits=idbits, cand_cap=128, evict_cap=64)
+        check(ids, sc, st, status, wi, ws, wst)
+
+
+def test_two_tier_visited_set_under_lane_reordering(emu, monkeypatch):
+    """the LDS tier's CAS loop (two 16-bit entries share a word) under reversed / shuffled lane schedules"""
+    lv, entry, entry_level, opq, codes, q = problem(31, 2500, 128, 16, 2, deg=32, nq=5)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, None, q, O.COSINE, 80, 80, fused=True)
+    for order in ("reverse", "random:3", "random:4"):
+        monkeypatch.setenv("EMU_LANE_ORDER", order)
+        for v1 in (7, 11):
+            ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.COSINE, 80, True, v1_log2=v1)
+            check(ids, sc, st, status, wi, ws, wst)
+
+
 def test_overflow_is_reported_not_hidden(emu):
     lv, entry, entry_level, opq, codes, q = problem(13, 3000, 128, 16, 2, deg=24, nq=4)
     og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
     wi, ws, wst = og.search(opq, codes, None, q, O.DOT_PRODUCT, 120, 120, fused=True)
     # visited table too small for these searches: every query must say so
-    ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.DOT_PRODUCT, 120, True, vcap_log2=9)
-    assert (status == 1).all() and (ids == -1).all()
+    for v1 in (0, 6):  # (a 64-slot LDS tier holds 48 of them; the rest still overflows tier 2)
+        ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.DOT_PRODUCT, 120, True, vcap_log2=9, v1_log2=v1)
+        assert (status == 1).all() and (ids == -1).all()
     # spill tier too small
     ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.DOT_PRODUCT, 120, True, spill_cap=32)
     assert (status == 1).any()

@@ -164,6 +164,23 @@ def test_device_traversal_retry_and_growth_paths(J, ctx, monkeypatch, capfd):
     T.test_exact_score_ties_are_resolved_on_the_device(ctx, monkeypatch, capfd)
 
 
+def test_device_traversal_tiers_fallbacks_and_counters(J, ctx, capfd):
+    """the two-tier visited set at pinned sizes, the host fallback of a graph whose level 0 is device-resident and
+    the AUTO-took-the-host notice, driven on the mock through the same functions the GPU suite runs"""
+    import test_zz_device_traversal_gpu as T
+    T.test_two_tier_visited_set_sizes(ctx)
+    lib = ctx._lib
+    lib.mock_hip_register_device.argtypes = [C.c_void_p]
+    lib.mock_hip_unregister_device.argtypes = [C.c_void_p]
+    ptrs = []
+    try:
+        T.test_host_fallback_with_a_device_resident_level0(ctx, register=lambda p: (ptrs.append(p), lib.mock_hip_register_device(C.c_void_p(p))))
+    finally:
+        for p in ptrs:
+            lib.mock_hip_unregister_device(C.c_void_p(p))
+    T.test_auto_traversal_reports_the_host_fallback(ctx, capfd)
+
+
 def test_device_traversal_refuses_unsupported_shapes(J, ctx):
     import test_zz_device_traversal_gpu as T
     T.test_unsupported_shape_is_refused(ctx)

@@ -192,3 +192,75 @@ def test_device_traversal_engineered_ties(ctx):
     tie order (the CPU twin runs in tests/test_mock_device.py)"""
     import test_graph_search as T
     T.run_ties_cases(J, ctx, "device")
+
+
+def test_two_tier_visited_set_sizes(ctx):
+    """the visited set's LDS tier (gs_visit1) at several pinned sizes, with a tier-2 table small enough that the frozen tier
+    hands over to it, grows it inside the kernel and still finishes: ids / scores / counters equal the oracle's, and the
+    context's counters say what ran"""
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 17, 6000, 128, 16, 2, True, deg=24)
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, 150, fused=True)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+    try:
+        for v1, vcap in ((None, None), (0, None), (6, None), (9, None), (12, None), (7, 9)):
+            ctx.set_option("gs_v1_log2", v1).set_option("gs_vcap_log2", vcap)
+            if vcap is not None:
+                ctx.set_option("gs_grow", 1).set_option("gs_retry", 1)
+            ctx.reset_stats()
+            ids, sc, st = s.search(q, VSF.COSINE, 10, 150, return_stats=True)
+            assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (v1, vcap)
+            assert ctx.stat("gs_calls_device") == 1 and ctx.stat("gs_queries_device") == len(q) and ctx.stat("gs_calls_host") == 0
+            assert ctx.stat("gs_queries_host_fallback") == 0
+            assert ctx.stat("gs_last_v1_log2") == (v1 if v1 is not None else 12), (v1, ctx.stat("gs_last_v1_log2"))
+    finally:
+        for k in ("gs_v1_log2", "gs_vcap_log2", "gs_grow", "gs_retry"):
+            ctx.set_option(k, None)
+
+
+def test_host_fallback_with_a_device_resident_level0(ctx, register=None):
+    """a graph whose level 0 lives in caller-owned device memory has no host adjacency; queries that overflow the
+    (pinned, tiny) visited table used to reach the host searcher with an empty row table.  They now walk a temporary copy:
+    same answers as the oracle, the fallback counted."""
+    import torch
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 19, 3000, 128, 16, 1, False)
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, 80, fused=False)
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    nb = torch.from_numpy(np.ascontiguousarray(lv[0][1], np.int32)).to(dev)
+    if register is not None:  # the CPU run against the mock device: declare the tensor's bytes "device memory"
+        register(nb.data_ptr())
+    g = J.GraphIndex.on_device(ctx, nb, entry)
+    s = J.GraphSearcher(ctx, g, pq, cv, None, vs, max_queries=64)
+    try:
+        ctx.set_option("gs_vcap_log2", 8)          # 256 slots, no LDS tier, no growth, no retry: every query overflows
+        ctx.reset_stats()
+        ids, sc, st = s.search(q, VSF.COSINE, 10, 80, return_stats=True)
+        assert ctx.stat("gs_queries_host_fallback") == len(q)
+        assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+        ctx.set_option("gs_vcap_log2", None)
+        ids, sc, st = s.search(q, VSF.COSINE, 10, 80, return_stats=True)   # and the graph still serves the device traversal
+        assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+    finally:
+        ctx.set_option("gs_vcap_log2", None)
+
+
+def test_auto_traversal_reports_the_host_fallback(ctx, capfd):
+    """JV_TRAVERSAL_AUTO on a shape the device traversal does not cover (12-dim sub-vectors) takes the host searcher — and says
+    so: one stderr notice per context, and the gs_calls_host_auto counter"""
+    v, lv, entry, entry_level, cb, q = build_problem(23, N=1500, D=96, M=8, deg=12, levels=1)
+    opq = O.OraclePQ(96, 8, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, 96, 8, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    graph = J.GraphIndex(ctx, len(v), lv, entry, entry_level).set_traversal("auto")
+    s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
+    ctx.reset_stats()
+    capfd.readouterr()
+    ids, sc, st = s.search(q, VSF.EUCLIDEAN, 10, 40, return_stats=True)
+    ids2, _, _ = s.search(q, VSF.EUCLIDEAN, 10, 40, return_stats=True)
+    err = capfd.readouterr().err
+    wi, ws, wst = O.OracleGraph(len(v), lv, entry, entry_level).search(opq, cv.get(0, len(v)), v, q, O.EUCLIDEAN, 10, 40, fused=False)
+    assert np.array_equal(ids, wi) and np.array_equal(sc, ws) and np.array_equal(st, wst) and np.array_equal(ids2, wi)
+    assert ctx.stat("gs_calls_host_auto") == 2 and ctx.stat("gs_calls_device") == 0
+    assert err.count("JV_TRAVERSAL_AUTO takes the HOST searcher") == 1
