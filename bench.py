@@ -180,6 +180,54 @@ def cpu_baseline_graph(cb, D, M, codes_h, levels, entry, entry_level, base_dev, 
                           bool(np.array_equal(ids, gpu_ids[:nq])))
 
 
+def cpu_baseline_build(cb, D, M, codes_h, nbrs_h, entry, base_dev, vsf, max_degree, beam, alpha, per_thread=24):
+    """CPU oracle on a bounded sample of the BUILD workload: what one insert costs the reference's per-node path — a sequential
+    GraphSearcher over the (finished) graph for the node's vector, topK = rerankK = beamWidth, PQ scores — and
+    VamanaDiversityProvider.retainDiverse of its candidates with the PQ diversity function (oracle restatements, the parity
+    checkers of the two kernels), spread over the host cores.  Backlinks are not charged to the CPU side."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+    threads = effective_cpus()
+    N = codes_h.shape[0]
+    nq = min(per_thread * threads, N)
+    opq = O.OraclePQ(D, M, cb)
+    opq.cache_self_magnitudes()
+    tri = opq.codebook_partial_sums(int(vsf))
+    og = O.OracleGraph(N, [(None, nbrs_h)], entry, 0)
+    nodes = np.random.default_rng(1).choice(N, nq, replace=False)
+    q = base_dev[torch.from_numpy(nodes).to(base_dev.device)].cpu().numpy()
+
+    def one(lo):
+        ids, sc, _ = og.search(opq, codes_h, None, q[lo:lo + 4], int(vsf), beam, beam, fused=False)
+        kept = 0
+        for r in range(ids.shape[0]):
+            ok = ids[r] >= 0
+            sel = opq.retain_diverse(tri, int(vsf), codes_h, ids[r][ok], sc[r][ok], max_degree, 0, alpha)
+            kept += int(sel[1])
+        return kept
+
+    def run():
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            kept = sum(ex.map(one, range(0, nq, 4)))
+        return kept, time.perf_counter() - t0
+
+    kept, scalar_s = run()
+    line = {"value": nq / scalar_s, "unit": "nodes/s", "cores": threads, "kind": "port", "isa": "scalar", "scalar_value": nq / scalar_s,
+            "sample": f"{nq} inserts replayed against the finished graph: GraphSearcher (beam {beam}, PQ scores) + retainDiverse (alpha {alpha}, "
+                      f"maxDegree {max_degree}), 4 nodes per task on {threads} threads; scalar oracle {scalar_s:.1f}s wall; backlinks not charged",
+            "avg_selected": kept / float(nq)}
+    try:
+        isa = O.set_simd(True)
+        if isa != "scalar":
+            _, simd_s = run()
+            line.update({"value": nq / simd_s, "isa": isa, "sample": line["sample"] + f", {isa} restatement of the reference's native kernels {simd_s:.1f}s wall"})
+    finally:
+        O.set_simd(False)
+    return line
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # helpers
 # ------------------------------------------------------------------------------------------------------------------
@@ -518,14 +566,18 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
     cv = J.PQVectors.encode_and_build(ctx, pq, vs)
     ctx.sync()
     encode_s = time.perf_counter() - t0
-    nbrs, entry, bstats = build_vamana(ctx, pq, cv, base, VSF, max_degree=args.degree, beam_width=100, alpha=1.2, log=log)
+    ctx.profile(True)
+    nbrs, entry, bstats = build_vamana(ctx, pq, cv, base, VSF, max_degree=args.degree, beam_width=args.build_beam, alpha=1.2, log=log, vector_set=vs)
+    prof = {r: ctx.profile_read(r) for r in ("gsearch", "adc")}
+    ctx.profile(False)
     barrier()
     total_s = time.perf_counter() - t_all
     rccl_ranks = ranks.rccl_ranks()
     total_s, _, per_rank = aggregate(ranks, total_s, N)
     # quality of what was built: recall@10 of a search over it (graph + exact rerank) against brute force
     gt = ground_truth(J, ctx, vs, eval_q, VSF, K, dense=True).cpu().numpy()
-    graph = J.GraphIndex(ctx, N, [(None, nbrs.cpu().numpy())], entry, 0)
+    nbrs_h = nbrs.cpu().numpy()
+    graph = J.GraphIndex(ctx, N, [(None, nbrs_h)], entry, 0)
     fused = J.FusedPQ.build(ctx, cv, nbrs)
     s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=int(eval_q.shape[0]))
     rec = {}
@@ -535,19 +587,35 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
         rec[rk] = float(recall_per_query(ids.cpu().numpy(), gt).mean())
     if rank != 0:
         return None
-    return {"metric": "index build: nodes/s (batched Vamana, PQ-192 scoring) incl. PQ training + encode", "value": N * world / total_s,
-            "unit": "nodes/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "per_rank_nodes_per_s": per_rank, "steps": 1, "warmup": 0, "ms_per_step": total_s * 1e3, "higher_is_better": True,
+    # dominant kernel: the construction-time graph search (device traversal over the growing adjacency, the neighbours' own
+    # codes — no fused blocks exist yet).  SURVEY §8d rows 5/6: M code bytes + 4 B ordinal + 4 B score per scored node.
+    g_ms, g_n = prof["gsearch"]
+    unit = M + 8
+    ach = bstats["visited"] * unit / (g_ms / 1e3) / 1e9 if g_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": f"graph_search_kernel<COSINE,CH16={M // 16}> over the builder's device-resident adjacency (PQDecoder.similarityTo on the "
+                "neighbours' own codes, table-free)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "scored_nodes": bstats["visited"], "expansions": bstats["expanded"], "bytes_per_scored_node": unit, "kernel_ms": g_ms,
+                "launches": g_n, "prune_and_pair_score_kernel_ms": prof["adc"][0],
+                "note": "algorithmic bytes = scored nodes x (M + 8) (SURVEY §8d: ADC gather by ordinal); physically the kernel is bound by the L2 "
+                        "gather rate of its table-free scoring, like the search kernel of the headline (DESIGN.md §4); the robust-prune / pair-score "
+                        "kernels gather M pair-table entries of 4 B per (candidate, selected) pair from L2 / MALL"}
+    line = {"metric": "index build: nodes/s (batched Vamana, PQ scoring) incl. PQ training + encode", "value": N * world / total_s,
+            "unit": "nodes/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "per_rank_nodes_per_s": per_rank, "steps": 1, "warmup": 0,
+            "ms_per_step": total_s * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE C5: synthetic {N}x{D} cosine mixture, PQ-{M} trained + encoded by the engine, batched Vamana "
-                                   f"construction (maxDegree {args.degree}, beamWidth 100, alpha 1.2, prefix-doubling batches): candidates "
-                                   "from the engine's device-resident graph search over the partial graph, robust prune = "
-                                   "jv_hip_retain_diverse, backlink re-prune with PQ diversity scores", "n_vectors": N, "dim": D,
-                       "pq_subspaces": M, "max_degree": args.degree, "parallelism": "1 GPU" if world == 1 else f"{world} independent builds"},
+                                   f"construction behind jv_hip_builder_* (maxDegree {args.degree}, beamWidth {args.build_beam}, alpha 1.2, neighborOverflow "
+                                   "1.25, prefix-doubling batches): candidates from the engine's device-resident graph search over the partial "
+                                   "graph, robust prune = the retain_diverse kernel, backlinks + re-prune with PQ diversity scores", "n_vectors": N,
+                       "dim": D, "pq_subspaces": M, "max_degree": args.degree, "parallelism": "1 GPU" if world == 1 else f"{world} independent builds"},
             "seconds": {"pq_train": train_s, "encode": encode_s, "search": bstats["search_s"], "prune": bstats["prune_s"],
                         "backlink": bstats["backlink_s"], "total": total_s},
             "build": {"batches": bstats["batches"], "reprunes": bstats["reprunes"], "avg_degree": bstats["avg_degree"]},
             "recall_at_10_by_rerankK": rec, "recall_eval_queries": int(eval_q.shape[0]),
-            "roofline": None, "cpu_baseline": None}
+            "roofline": roofline, "cpu_baseline": None}
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_build(pq.codebooks(), D, M, cv.get(0, N), nbrs_h, entry, base, VSF, args.degree, args.build_beam, 1.2)
+    return line
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -178,6 +178,9 @@ JV_API void *jv_hip_codes_device_ptr(const jv_codes *codes);
 JV_API int jv_hip_vectors_create(jv_ctx *ctx, int64_t count, int D, jv_vectors **out);
 JV_API int jv_hip_vectors_wrap(jv_ctx *ctx, int64_t count, int D, void *device_vectors, jv_vectors **out);
 JV_API int jv_hip_vectors_upload(jv_ctx *ctx, jv_vectors *v, int64_t first, int64_t count, const float *src);
+/* Wrapped (caller-owned) vectors edited in place: the engine caches one float per row for the cosine rerank (the reference's
+ * norm2 accumulator, DefaultVectorUtilSupport.java:131-137); tell it that the rows changed.  jv_hip_vectors_upload does this itself. */
+JV_API int jv_hip_vectors_invalidate(jv_vectors *v);
 JV_API int jv_hip_vectors_destroy(jv_vectors *v);
 
 /* ---------------------------------------------------------------------------------------------
@@ -389,6 +392,35 @@ JV_API int jv_hip_retain_diverse(jv_ctx *ctx, const jv_pair_table *t, const jv_c
                                  int32_t *n_selected_out, float *short_edges_out);
 JV_API int jv_hip_fused_build(jv_ctx *ctx, jv_fused *f, const jv_codes *codes, int64_t first, int64_t count,
                               const int32_t *neighbors);
+
+/* Batched Vamana construction of one graph level (BASELINE config 5) — the driver of the calls above, so that a host needs no
+ * array plumbing of its own:  replaces the per-node GraphIndexBuilder.addGraphNode loop (B/graph/GraphIndexBuilder.java:605-659:
+ * search -> VamanaDiversityProvider.retainDiverse -> ConcurrentNeighborMap.insertDiverse / backlink, :104-163) and
+ * cleanup()'s enforceDegree (:472-508) with batch calls.  Scores are the PQ build-score provider's (BuildScoreProvider.java:
+ * 167-212) except that the insert query is the node's full-resolution vector, not its decoded code.
+ *   create       : nodes = the `codes->count` ordinals of `codes` / `vectors`; the adjacency (count x floor(maxDegree *
+ *                  neighborOverflow) int32, device memory owned by the builder) starts empty.  beamWidth = candidates per
+ *                  insert; alpha = the robust prune's relaxation (the prune ramps 1.0, 1.2, ... <= alpha).
+ *   seed         : the first node (entry point of the construction-time searches)
+ *   insert_batch : inserts `nodes[0..B)` (host or device memory; none of them inserted before) as B concurrent inserts that
+ *                  do not see each other: candidate search over the graph so far (device traversal), robust prune, rows,
+ *                  backlinks, re-prune of the lists that outgrow the working width.  Callers grow the batch with the graph
+ *                  (prefix doubling: batch <= nodes already inserted).
+ *   finish       : enforceDegree on every list; neighbors_out (nullable; host or device) receives count x maxDegree int32,
+ *                  rows packed, -1 padded.  The builder can keep inserting afterwards.
+ *   stats        : seconds3 = {search, prune, backlink}; counts5 = {batches, re-pruned lists, inserted nodes, visitedCount and
+ *                  expandedCount summed over the construction-time searches}
+ *   neighbors_device : the working adjacency in place (row width in *row_width) — e.g. for jv_hip_fused_build.
+ * The result depends on the insertion order and batch boundaries only (no atomics decide an edge), so a build is reproducible. */
+typedef struct jv_builder jv_builder;
+JV_API int jv_hip_builder_create(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, const jv_vectors *vectors, jv_vsf vsf,
+                                 int max_degree, int beam_width, float alpha, float neighbor_overflow, jv_builder **out);
+JV_API int jv_hip_builder_seed(jv_ctx *ctx, jv_builder *b, int32_t node);
+JV_API int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes, int B);
+JV_API int jv_hip_builder_finish(jv_ctx *ctx, jv_builder *b, int32_t *neighbors_out);
+JV_API int jv_hip_builder_stats(const jv_builder *b, double *seconds3, int64_t *counts5);
+JV_API const int32_t *jv_hip_builder_neighbors_device(const jv_builder *b, int *row_width);
+JV_API int jv_hip_builder_destroy(jv_builder *b);
 /* copy blocks (count x maxDegree*M bytes) and / or neighbour rows back; either output may be NULL */
 JV_API int jv_hip_fused_download(jv_ctx *ctx, const jv_fused *f, int64_t first, int64_t count, uint8_t *blocks_out,
                                  int32_t *neighbors_out);

@@ -123,6 +123,22 @@ public final class HipOps {
         static final MethodHandle commCreate = h("jv_hip_comm_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS));
         static final MethodHandle commDestroy = h("jv_hip_comm_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
         static final MethodHandle shardedTopk = h("jv_hip_sharded_topk", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle commCount = h("jv_hip_comm_count", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle commAllGather = h("jv_hip_comm_all_gather", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS));
+        // batched Vamana construction of one level (GraphIndexBuilder.addGraphNode / cleanup as batch calls)
+        static final MethodHandle builderCreate = h("jv_hip_builder_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_FLOAT, JAVA_FLOAT, ADDRESS));
+        static final MethodHandle builderSeed = h("jv_hip_builder_seed", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT));
+        static final MethodHandle builderInsertBatch = h("jv_hip_builder_insert_batch", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT));
+        static final MethodHandle builderFinish = h("jv_hip_builder_finish", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle builderStats = h("jv_hip_builder_stats", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle builderNeighborsDevice = h("jv_hip_builder_neighbors_device", FunctionDescriptor.of(ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle builderDestroy = h("jv_hip_builder_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        // per-context options (a JVM cannot set the JVECTOR_HIP_* environment per context) and counters
+        static final MethodHandle ctxSetOption = h("jv_hip_ctx_set_option", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG));
+        static final MethodHandle ctxClearOption = h("jv_hip_ctx_clear_option", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle ctxGetStat = h("jv_hip_ctx_get_stat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle ctxResetStats = h("jv_hip_ctx_reset_stats", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle vectorsInvalidate = h("jv_hip_vectors_invalidate", FunctionDescriptor.of(JAVA_INT, ADDRESS));
         static final MethodHandle shardedSearchFlat = h("jv_hip_sharded_search_flat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
     }
 
@@ -348,6 +364,59 @@ public final class HipOps {
         check(st(() -> (int) H.retainDiverse.invokeExact(ctx, table, codes, p, c, candNodes, candScores, candCountOrNull, diverseBeforeOrNull,
                                                          maxDegree, alpha, selectedOut, nSelectedOut, shortEdgesOutOrNull)));
     }
+    // ---- batched construction: the GraphIndexBuilder.addGraphNode loop (GraphIndexBuilder.java:605-659) as batch calls ----
+    /** one graph level over the nodes of `codes` / `vectors`; alpha / neighborOverflow as GraphIndexBuilder's constructor takes them */
+    public static MemorySegment builderCreate(Arena arena, MemorySegment ctx, MemorySegment pq, MemorySegment codes, MemorySegment vectors, int vsf,
+                                              int maxDegree, int beamWidth, float alpha, float neighborOverflow) {
+        return outHandle(arena, out -> st(() -> (int) H.builderCreate.invokeExact(ctx, pq, codes, vectors, vsf, maxDegree, beamWidth, alpha, neighborOverflow, out)));
+    }
+    public static void builderSeed(MemorySegment ctx, MemorySegment builder, int node) { check(st(() -> (int) H.builderSeed.invokeExact(ctx, builder, node))); }
+    /** B concurrent inserts that do not see each other (nodes: int32 ordinals, off-heap or device memory); callers grow the batch with the graph */
+    public static void builderInsertBatch(MemorySegment ctx, MemorySegment builder, MemorySegment nodes, int b) {
+        check(st(() -> (int) H.builderInsertBatch.invokeExact(ctx, builder, nodes, b)));
+    }
+    /** cleanup(): enforceDegree on every list; neighborsOutOrNull receives count x maxDegree int32, rows packed, -1 padded */
+    public static void builderFinish(MemorySegment ctx, MemorySegment builder, MemorySegment neighborsOutOrNull) {
+        check(st(() -> (int) H.builderFinish.invokeExact(ctx, builder, neighborsOutOrNull)));
+    }
+    /** seconds3 = {search, prune, backlink}; counts5 = {batches, re-pruned lists, inserted, visitedCount, expandedCount} */
+    public static void builderStats(MemorySegment builder, MemorySegment seconds3, MemorySegment counts5) {
+        check(st(() -> (int) H.builderStats.invokeExact(builder, seconds3, counts5)));
+    }
+    public static MemorySegment builderNeighborsDevice(MemorySegment builder, MemorySegment rowWidthOutOrNull) {
+        try { return (MemorySegment) H.builderNeighborsDevice.invokeExact(builder, rowWidthOutOrNull); } catch (Throwable t) { throw new AssertionError(t); }
+    }
+    public static void builderDestroy(MemorySegment builder) { check(st(() -> (int) H.builderDestroy.invokeExact(builder))); }
+
+    // ---- per-context options / counters, communicator introspection ----
+    public static void ctxSetOption(Arena arena, MemorySegment ctx, String name, long value) {
+        MemorySegment n = arena.allocateFrom(name);
+        check(st(() -> (int) H.ctxSetOption.invokeExact(ctx, n, value)));
+    }
+    public static void ctxClearOption(Arena arena, MemorySegment ctx, String name) {
+        MemorySegment n = arena.allocateFrom(name);
+        check(st(() -> (int) H.ctxClearOption.invokeExact(ctx, n)));
+    }
+    /** e.g. "gs_calls_host_auto": how often JV_TRAVERSAL_AUTO fell back to the (13x slower) host searcher on this context */
+    public static long ctxGetStat(Arena arena, MemorySegment ctx, String name) {
+        MemorySegment n = arena.allocateFrom(name), out = arena.allocate(JAVA_LONG);
+        check(st(() -> (int) H.ctxGetStat.invokeExact(ctx, n, out)));
+        return out.get(JAVA_LONG, 0);
+    }
+    public static void ctxResetStats(MemorySegment ctx) { check(st(() -> (int) H.ctxResetStats.invokeExact(ctx))); }
+    /** wrapped vectors edited in place: drop the cached cosine norms */
+    public static void vectorsInvalidate(MemorySegment vectors) { check(st(() -> (int) H.vectorsInvalidate.invokeExact(vectors))); }
+    /** ncclCommCount of the communicator's RCCL object (1 for a local communicator) */
+    public static int commCount(Arena arena, MemorySegment comm) {
+        MemorySegment out = arena.allocate(JAVA_INT);
+        check(st(() -> (int) H.commCount.invokeExact(comm, out)));
+        return out.get(JAVA_INT, 0);
+    }
+    /** all-gather of `bytes` opaque bytes per rank (small host records); recv holds world x bytes, rank-major */
+    public static void commAllGather(MemorySegment ctx, MemorySegment comm, MemorySegment send, long bytes, MemorySegment recv) {
+        check(st(() -> (int) H.commAllGather.invokeExact(ctx, comm, send, bytes, recv)));
+    }
+
     /** raw device memory (e.g. the mutable adjacency of graphSetLevel0Device); a zero-length segment carrying the device address */
     public static MemorySegment deviceAlloc(Arena arena, MemorySegment ctx, long bytes) {
         return outHandle(arena, out -> st(() -> (int) H.deviceAlloc.invokeExact(ctx, bytes, out)));

@@ -69,6 +69,7 @@ SIGNATURES = {
     "jv_hip_vectors_create": (_i, [_p, _i64, _i, C.POINTER(_p)]),
     "jv_hip_vectors_wrap": (_i, [_p, _i64, _i, _p, C.POINTER(_p)]),
     "jv_hip_vectors_upload": (_i, [_p, _p, _i64, _i64, _p]),
+    "jv_hip_vectors_invalidate": (_i, [_p]),
     "jv_hip_vectors_destroy": (_i, [_p]),
     "jv_hip_pq_encode": (_i, [_p, _p, _p, _i64, _p]),
     "jv_hip_pq_encode_into": (_i, [_p, _p, _p, _i64, _i64, _p]),
@@ -112,6 +113,13 @@ SIGNATURES = {
     "jv_hip_device_free": (_i, [_p, _p]),
     "jv_hip_graph_set_level0_device": (_i, [_p, _p, _p, _i]),
     "jv_hip_retain_diverse": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _i, C.c_float, _p, _p, _p]),
+    "jv_hip_builder_create": (_i, [_p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, C.POINTER(_p)]),
+    "jv_hip_builder_seed": (_i, [_p, _p, C.c_int32]),
+    "jv_hip_builder_insert_batch": (_i, [_p, _p, _p, _i]),
+    "jv_hip_builder_finish": (_i, [_p, _p, _p]),
+    "jv_hip_builder_stats": (_i, [_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "jv_hip_builder_neighbors_device": (_p, [_p, C.POINTER(_i)]),
+    "jv_hip_builder_destroy": (_i, [_p]),
     "jv_hip_comm_unique_id": (_i, [_p]),
     "jv_hip_comm_create": (_i, [_p, _p, _i, _i, _p]),
     "jv_hip_comm_destroy": (_i, [_p]),

@@ -1,0 +1,209 @@
+// bl_body.h — the array plumbing of batched graph construction (builder.cpp): what sits between the engine's scoring calls when
+// a batch of nodes is inserted into a Vamana level.  Each function is the body of ONE work item (an inserted node, a back edge, a
+// list element), written as plain C++ so that k_builder.hip runs it one item per GPU thread and the CPU mock
+// (tests/mock/mock_kernels.cpp) runs the very same code in a loop.  No floating-point arithmetic lives here except the order
+// comparison of scores (NodeQueue's total order, NodeQueue.java:125-129 / NumericUtils.java:49-65).
+//
+// Reference behaviour restated (host code there, batched here):
+//   GraphIndexBuilder.updateNeighbors / ConcurrentNeighborMap.insertDiverse (B/graph/GraphIndexBuilder.java:644-659,
+//   B/graph/ConcurrentNeighborMap.java:104-163): a new node's pruned candidate list becomes its neighbour list; every chosen
+//   neighbour s gets the BACKLINK s -> node appended to its list (insertEdgeNotDiverse / backlink); a list that outgrows
+//   maxDegree x neighborOverflow is re-pruned with retainDiverse over the merged list (existing + appended, by score).
+#pragma once
+
+#include <cstdint>
+
+#ifndef BL_FN
+#define BL_FN inline
+#endif
+
+namespace jv {
+
+struct BlApplyParams {
+    const int32_t *nodes;     // [B] inserted nodes (rows to write)
+    const int32_t *cand;      // [B][C] candidate ids, best first, -1 padded
+    const int32_t *sel;       // [B][Rf] selected candidate positions, ascending, -1 padded (retain_diverse output)
+    int B, C, Rf, R;
+    int32_t *nbrs;            // [N][R] adjacency, rows packed, -1 padded
+    unsigned long long *edge_keys;  // [B*Rf] (target << 32 | edge index), or ~0 for "no edge"; nullptr = rows only
+    int32_t *edge_src;        // [B*Rf]
+};
+
+// item = b * Rf + j  (one selected slot of one inserted node)
+BL_FN void bl_apply_selection(const BlApplyParams &p, long long item)
+{
+    const int b = (int)(item / p.Rf), j = (int)(item % p.Rf);
+    const int32_t v = p.nodes[b];
+    const int32_t s = p.sel[(long long)b * p.Rf + j];
+    int32_t chosen = s >= 0 && s < p.C ? p.cand[(long long)b * p.C + s] : -1;
+    if (chosen == v) chosen = -1;  // never link a node to itself (re-insertion passes search a graph that already holds it)
+    p.nbrs[(long long)v * p.R + j] = chosen;
+    if (j == 0)
+        for (int t = p.Rf; t < p.R; ++t) p.nbrs[(long long)v * p.R + t] = -1;
+    if (p.edge_keys) {
+        p.edge_keys[item] = chosen >= 0 ? (((unsigned long long)(uint32_t)chosen) << 32) | (unsigned long long)(uint32_t)item : ~0ull;
+        p.edge_src[item] = v;
+    }
+}
+
+// A row written by bl_apply_selection may have holes (a dropped self link): close them.  item = b.
+BL_FN void bl_pack_row(const BlApplyParams &p, long long b)
+{
+    int32_t *row = p.nbrs + (long long)p.nodes[b] * p.R;
+    int w = 0;
+    for (int t = 0; t < p.Rf; ++t) {
+        const int32_t x = row[t];
+        if (x >= 0) row[w++] = x;
+    }
+    for (; w < p.Rf; ++w) row[w] = -1;
+}
+
+struct BlMergeParams {
+    const unsigned long long *keys;  // [E] sorted ascending: edges of one target are consecutive, in edge-index order
+    const int32_t *src;              // [E] sorted along
+    long long E;
+    int R, Knew;                     // row width; at most Knew appended ids are kept for a re-prune
+    int32_t *nbrs;                   // [N][R]
+    int32_t *over_tgt;               // [cap] targets whose list overflowed
+    int32_t *over_list;              // [cap][R + Knew] merged list: existing row, then the appended ids, -1 padded
+    unsigned int *over_count;        // atomic slot counter
+    unsigned int over_cap;
+};
+
+#ifndef BL_ATOMIC_INC
+#define BL_ATOMIC_INC(p) ((*(p))++)
+#endif
+
+// item = index into the sorted edge array; only the first edge of each target's run does the work
+BL_FN void bl_backlink_merge(const BlMergeParams &p, long long i)
+{
+    const unsigned long long k = p.keys[i];
+    if (k == ~0ull) return;
+    const int32_t tgt = (int32_t)(k >> 32);
+    if (i > 0 && (int32_t)(p.keys[i - 1] >> 32) == tgt) return;
+    int32_t *row = p.nbrs + (long long)tgt * p.R;
+    int deg = 0;
+    while (deg < p.R && row[deg] >= 0) ++deg;
+    long long e = i;
+    // append while the row has room (duplicates of an existing neighbour are dropped: s may already point at the new node when a
+    // re-insertion pass runs)
+    for (; e < p.E && (int32_t)(p.keys[e] >> 32) == tgt; ++e) {
+        const int32_t s = p.src[e];
+        bool dup = false;
+        for (int t = 0; t < deg; ++t) dup = dup || row[t] == s;
+        if (dup) continue;
+        if (deg == p.R) break;
+        row[deg++] = s;
+    }
+    if (e >= p.E || (int32_t)(p.keys[e] >> 32) != tgt) return;  // everything fitted
+    // overflow: hand the merged list to the re-prune
+    const unsigned int slot = BL_ATOMIC_INC(p.over_count);
+    if (slot >= p.over_cap) return;  // cannot happen (cap = number of targets); the row simply keeps what fitted
+    const int L = p.R + p.Knew;
+    int32_t *lst = p.over_list + (long long)slot * L;
+    p.over_tgt[slot] = tgt;
+    for (int t = 0; t < p.R; ++t) lst[t] = row[t];
+    int n = p.R;
+    for (; e < p.E && (int32_t)(p.keys[e] >> 32) == tgt && n < L; ++e) {
+        const int32_t s = p.src[e];
+        bool dup = false;
+        for (int t = 0; t < n; ++t) dup = dup || lst[t] == s;
+        if (!dup) lst[n++] = s;
+    }
+    for (; n < L; ++n) lst[n] = -1;
+}
+
+// NodeQueue's order on scores (NumericUtils.floatToSortableInt), as a sortable 32-bit key
+BL_FN int32_t bl_sortable(float f)
+{
+    int32_t b;
+    __builtin_memcpy(&b, &f, 4);
+    if (f != f) b = 0x7fc00000;
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+
+struct BlSortParams {
+    const int32_t *ids;     // [P][L]
+    const float *scores;    // [P][L]  (-inf for the -1 padding)
+    int P, L;
+    int32_t *out_ids;       // [P][L] best first; equal scores keep their input order; -1 ids last
+    float *out_scores;
+    int32_t *out_count;     // [P] ids >= 0
+};
+
+// item = p * L + i: the element finds its rank among the L of its row (NodeArray order: score descending, stable)
+BL_FN void bl_rank_sort(const BlSortParams &p, long long item)
+{
+    const long long row = item / p.L;
+    const int i = (int)(item % p.L);
+    const int32_t *ids = p.ids + row * p.L;
+    const float *sc = p.scores + row * p.L;
+    const int32_t my_id = ids[i];
+    const int32_t mine = bl_sortable(sc[i]);
+    int rank = 0, valid = 0;
+    for (int j = 0; j < p.L; ++j) {
+        const int32_t oid = ids[j];
+        valid += oid >= 0 ? 1 : 0;
+        if (j == i) continue;
+        const int32_t other = bl_sortable(sc[j]);
+        bool before;
+        if ((oid >= 0) != (my_id >= 0)) before = oid >= 0;            // padding goes last
+        else before = other > mine || (other == mine && j < i);
+        rank += before ? 1 : 0;
+    }
+    p.out_ids[row * p.L + rank] = my_id;
+    p.out_scores[row * p.L + rank] = sc[i];
+    if (i == 0) p.out_count[row] = valid;
+}
+
+struct BlRowsParams {
+    const int32_t *tgt;     // [P] rows to rewrite
+    const int32_t *lst;     // [P][L] sorted merged lists
+    const int32_t *sel;     // [P][Rf] selected positions
+    int P, L, Rf, R;
+    int32_t *nbrs;          // [N][R]
+};
+
+// item = p: the re-pruned list replaces the row
+BL_FN void bl_rewrite_row(const BlRowsParams &p, long long r)
+{
+    int32_t *row = p.nbrs + (long long)p.tgt[r] * p.R;
+    int w = 0;
+    for (int j = 0; j < p.Rf; ++j) {
+        const int32_t s = p.sel[r * p.Rf + j];
+        if (s >= 0 && s < p.L) {
+            const int32_t x = p.lst[r * p.L + s];
+            if (x >= 0) row[w++] = x;
+        }
+    }
+    for (; w < p.R; ++w) row[w] = -1;
+}
+
+struct BlOverParams {
+    const int32_t *nbrs;    // [N][R]
+    long long N;
+    int R, Rf;
+    int32_t *over_tgt;      // [cap]
+    unsigned int *over_count;
+    unsigned int over_cap;
+};
+
+// final pass (GraphIndexBuilder.cleanup -> enforceDegree): item = node; rows longer than Rf are listed for a re-prune
+BL_FN void bl_list_over_degree(const BlOverParams &p, long long v)
+{
+    const int32_t *row = p.nbrs + v * p.R;
+    if (p.R > p.Rf && row[p.Rf] >= 0) {
+        const unsigned int slot = BL_ATOMIC_INC(p.over_count);
+        if (slot < p.over_cap) p.over_tgt[slot] = (int32_t)v;
+    }
+}
+
+// candidates per row = ids >= 0 (the search pads with -1); item = b
+BL_FN void bl_count_valid(const int32_t *cand, int C, int32_t *count, long long b)
+{
+    int n = 0;
+    for (int j = 0; j < C; ++j) n += cand[b * C + j] >= 0 ? 1 : 0;
+    count[b] = n;
+}
+
+}  // namespace jv

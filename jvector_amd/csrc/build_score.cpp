@@ -4,14 +4,6 @@
 
 using namespace jv;
 
-struct jv_pair_table {
-    int device = 0;
-    const jv_pq *pq = nullptr;
-    jv_vsf vsf = JV_EUCLIDEAN;
-    float *d_tri = nullptr;
-    int64_t floats = 0;
-};
-
 extern "C" {
 
 int jv_hip_pair_table_create(jv_ctx *ctx, const jv_pq *pq, jv_vsf vsf, jv_pair_table **out)
@@ -157,6 +149,7 @@ int jv_hip_fused_build(jv_ctx *ctx, jv_fused *f, const jv_codes *codes, int64_t 
     if (!is_device_ptr(neighbors)) JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the caller may reuse its buffer
     JV_TRY(launch_fused_gather(ctx->stream, codes, d_nb, f->maxDegree, count, f->d_blocks + (size_t)first * f->maxDegree * f->M));
     f->norms_valid = false;
+    f->generation = next_fused_generation();
     return JV_OK;
 }
 

@@ -1,0 +1,387 @@
+// builder.cpp — batched Vamana construction behind the C ABI (jv_hip_builder_*; BASELINE config 5: "GPU-batched neighbor
+// scoring + PQ encode", SURVEY §8 f.2 + Appendix C).
+//
+// The reference inserts nodes one by one from many threads (GraphIndexBuilder.addGraphNode, B/graph/GraphIndexBuilder.java:
+// 605-659): search the current graph for the new node with the BuildScoreProvider's PQ score function (beamWidth candidates),
+// robust-prune them (VamanaDiversityProvider.retainDiverse, B/graph/diversity/VamanaDiversityProvider.java:43-96), link, and
+// backlink with a re-prune when a neighbour's list outgrows maxDegree x neighborOverflow (ConcurrentNeighborMap.insertDiverse /
+// backlink, B/graph/ConcurrentNeighborMap.java:104-163, :298-322); cleanup() finally trims every list to maxDegree
+// (enforceDegree, GraphIndexBuilder.java:472-508).  Its result depends on thread interleaving, so the contract here is the
+// structure of the result (degree <= maxDegree, packed rows, no self loops / duplicates) and the recall of a search over it —
+// not a bit-level trace.  What IS bit-exact is every score it consumes: the candidate search is the engine's GraphSearcher
+// (device traversal over the builder's own mutable adjacency), the prune is jv_hip_retain_diverse's kernel, the backlink
+// re-prune scores with the PQ pair table (ImmutablePQVectors.diversityFunctionFor).
+//
+// One insert_batch = the batch analogue of B concurrent addGraphNode calls that do not see each other:
+//   1. queries = the batch's full-resolution vectors (gathered on the device)            launch_gather_rows
+//   2. candidates = GraphSearcher.search(topK = rerankK = beam) on the graph so far       jv_hip_graph_search (device pointers)
+//   3. robust prune of every candidate list                                              launch_retain_diverse
+//   4. rows of the new nodes <- selection; back edges (target, source) emitted           bl_apply_selection
+//   5. back edges sorted by (target, edge index)                                         launch_bl_sort_edges
+//   6. per target: append while the row has room, else hand the merged list over          bl_backlink_merge
+//   7. overflowed lists: PQ diversity scores, NodeArray order, robust prune, row rewrite  launch_pair_scores, bl_rank_sort,
+//                                                                                        launch_retain_diverse, bl_rewrite_row
+// Everything stays on the context's stream; the host reads back one counter per batch (how many lists overflowed).
+#include <chrono>
+
+#include "bl_body.h"
+#include "jv_internal.h"
+#include "rd_params.h"
+
+using namespace jv;
+
+struct jv_builder {
+    int device = 0;
+    const jv_pq *pq = nullptr;
+    const jv_codes *codes = nullptr;
+    const jv_vectors *vectors = nullptr;
+    jv_vsf vsf = JV_EUCLIDEAN;
+    int64_t n = 0;
+    int Rf = 32, R = 40, beam = 100;
+    float alpha = 1.2f;
+    int32_t *d_nbrs = nullptr;       // [n][R]
+    jv_graph *graph = nullptr;       // level 0 = d_nbrs, read in place by the device traversal
+    jv_luts *luts = nullptr;
+    int luts_cap = 0;
+    jv_pair_table *tri = nullptr;
+    int64_t inserted = 0;            // nodes that have a row (the search cannot return more than that)
+    int32_t entry = -1;
+    Buffer d_nodes, d_q, d_cand, d_csc, d_count, d_sel, d_nsel, d_keys, d_keys2, d_src, d_src2, d_sort_tmp, d_over_tgt, d_over_list, d_over_sc,
+        d_sorted_ids, d_sorted_sc, d_ctr;
+    double search_s = 0, prune_s = 0, backlink_s = 0;
+    int64_t reprunes = 0, batches = 0, visited = 0, expanded = 0;  // (visited / expanded: SearchResult counters summed over the inserts)
+    std::vector<int64_t> h_stats;
+    ~jv_builder()
+    {
+        for (Buffer *b : {&d_nodes, &d_q, &d_cand, &d_csc, &d_count, &d_sel, &d_nsel, &d_keys, &d_keys2, &d_src, &d_src2, &d_sort_tmp, &d_over_tgt,
+                          &d_over_list, &d_over_sc, &d_sorted_ids, &d_sorted_sc, &d_ctr})
+            b->release();
+    }
+};
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int run_retain(jv_ctx *ctx, jv_builder *b, const int32_t *d_cand, const float *d_sc, const int32_t *d_count, int P, int C, int32_t *d_sel,
+               int32_t *d_nsel)
+{
+    RdParams p{};
+    p.tri = b->tri->d_tri;
+    p.codes = b->codes->d_codes;
+    p.n = b->codes->count;
+    p.cand_nodes = d_cand;
+    p.cand_scores = d_sc;
+    p.cand_count = d_count;
+    p.diverse_before = nullptr;
+    p.P = P;
+    p.C = C;
+    p.M = b->codes->M;
+    p.k = b->pq->k;
+    p.vsf = to_kernel_vsf(b->vsf);
+    p.maxDegree = b->Rf;
+    p.alpha = b->alpha;
+    p.selected_out = d_sel;
+    p.n_selected_out = d_nsel;
+    p.short_edges_out = nullptr;
+    ProfScope ps(ctx, R_ADC);
+    return launch_retain_diverse(ctx->stream, ctx, p);
+}
+
+// lists d_list [P][L] of targets d_tgt: score against the target (PQ diversity function), NodeArray order, robust prune, rewrite
+int reprune_lists(jv_ctx *ctx, jv_builder *b, const int32_t *d_tgt, const int32_t *d_list, int P, int L)
+{
+    if (P == 0) return JV_OK;
+    const size_t cells = (size_t)P * L;
+    JV_TRY(b->d_over_sc.reserve(sizeof(float) * cells));
+    JV_TRY(b->d_sorted_ids.reserve(sizeof(int32_t) * cells));
+    JV_TRY(b->d_sorted_sc.reserve(sizeof(float) * cells));
+    JV_TRY(b->d_count.reserve(sizeof(int32_t) * (size_t)P));
+    JV_TRY(b->d_sel.reserve(sizeof(int32_t) * (size_t)P * b->Rf));
+    JV_TRY(b->d_nsel.reserve(sizeof(int32_t) * (size_t)P));
+    {
+        ProfScope ps(ctx, R_ADC);
+        JV_TRY(launch_pair_scores(ctx->stream, b->tri->d_tri, to_kernel_vsf(b->vsf), b->codes, d_tgt, P, d_list, L, (float *)b->d_over_sc.ptr));
+    }
+    BlSortParams sp{};
+    sp.ids = d_list;
+    sp.scores = (const float *)b->d_over_sc.ptr;
+    sp.P = P;
+    sp.L = L;
+    sp.out_ids = (int32_t *)b->d_sorted_ids.ptr;
+    sp.out_scores = (float *)b->d_sorted_sc.ptr;
+    sp.out_count = (int32_t *)b->d_count.ptr;
+    JV_TRY(launch_bl_rank_sort(ctx->stream, sp));
+    JV_TRY(run_retain(ctx, b, sp.out_ids, sp.out_scores, sp.out_count, P, L, (int32_t *)b->d_sel.ptr, (int32_t *)b->d_nsel.ptr));
+    BlRowsParams rp{};
+    rp.tgt = d_tgt;
+    rp.lst = sp.out_ids;
+    rp.sel = (const int32_t *)b->d_sel.ptr;
+    rp.P = P;
+    rp.L = L;
+    rp.Rf = b->Rf;
+    rp.R = b->R;
+    rp.nbrs = b->d_nbrs;
+    JV_TRY(launch_bl_rewrite_rows(ctx->stream, rp));
+    b->reprunes += P;
+    return JV_OK;
+}
+
+int read_counter(jv_ctx *ctx, jv_builder *b, unsigned int *out)
+{
+    JV_TRY(ctx->h_out.reserve(64));
+    JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, b->d_ctr.ptr, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = *(const unsigned int *)ctx->h_out.ptr;
+    return JV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jv_hip_builder_create(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, const jv_vectors *vectors, jv_vsf vsf, int max_degree,
+                          int beam_width, float alpha, float neighbor_overflow, jv_builder **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && codes && vectors && out, "builder_create: NULL argument");
+    *out = nullptr;
+    JV_REQUIRE(vsf == JV_EUCLIDEAN || vsf == JV_DOT_PRODUCT || vsf == JV_COSINE, "Unsupported similarity function %d", (int)vsf);
+    JV_REQUIRE(codes->pq == pq, "builder_create: the code store belongs to another quantizer");
+    JV_REQUIRE(vectors->D == pq->D && vectors->count >= codes->count, "builder_create: vectors do not match the codes (%lld x %d vs %lld x %d)",
+               (long long)vectors->count, vectors->D, (long long)codes->count, pq->D);
+    JV_REQUIRE(codes->count >= 1 && codes->count <= 0x7fffffffLL, "builder_create: %lld nodes", (long long)codes->count);
+    JV_REQUIRE(max_degree >= 2 && max_degree <= 64, "builder_create: maxDegree %d outside 2..64", max_degree);
+    JV_REQUIRE(beam_width >= 1 && beam_width <= 4096, "builder_create: beamWidth %d outside 1..4096", beam_width);
+    JV_REQUIRE(alpha == alpha && alpha >= 1.0f && alpha <= 64.0f, "builder_create: alpha must lie in [1, 64]");
+    JV_REQUIRE(neighbor_overflow == neighbor_overflow && neighbor_overflow >= 1.0f && neighbor_overflow <= 8.0f, "builder_create: neighborOverflow must lie in [1, 8]");
+    JV_TRY(use_device(ctx->device));
+    jv_builder *b = new jv_builder();
+    b->device = ctx->device;
+    b->pq = pq;
+    b->codes = codes;
+    b->vectors = vectors;
+    b->vsf = vsf;
+    b->n = codes->count;
+    b->Rf = max_degree;
+    b->R = std::max(max_degree, std::min(64, (int)(max_degree * neighbor_overflow)));  // the working row width (ConcurrentNeighborMap.java:298-322)
+    b->beam = beam_width;
+    b->alpha = alpha;
+    auto fail = [&](int rc) {
+        jv_hip_builder_destroy(b);
+        return rc;
+    };
+    if (hipMalloc((void **)&b->d_nbrs, sizeof(int32_t) * (size_t)b->n * b->R) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("builder_create: cannot allocate the %lld x %d adjacency", (long long)b->n, b->R);
+        return fail(JV_ERR_OOM);
+    }
+    if (hipMemsetAsync(b->d_nbrs, 0xFF, sizeof(int32_t) * (size_t)b->n * b->R, ctx->stream) != hipSuccess) return fail(JV_ERR_HIP);
+    int rc = jv_hip_graph_create(ctx, b->n, 1, &b->graph);
+    if (rc == JV_OK) rc = jv_hip_graph_set_level0_device(ctx, b->graph, b->d_nbrs, b->R);
+    if (rc == JV_OK) rc = jv_hip_graph_set_traversal(b->graph, JV_TRAVERSAL_DEVICE);
+    if (rc == JV_OK) rc = jv_hip_pair_table_create(ctx, pq, vsf, &b->tri);
+    if (rc == JV_OK) rc = b->d_ctr.reserve(256);
+    if (rc != JV_OK) return fail(rc);
+    *out = b;
+    return JV_OK;
+}
+
+int jv_hip_builder_destroy(jv_builder *b)
+{
+    if (!b) return JV_OK;
+    (void)hipSetDevice(b->device);
+    if (b->luts) jv_hip_luts_destroy(b->luts);
+    if (b->graph) jv_hip_graph_destroy(b->graph);
+    if (b->tri) jv_hip_pair_table_destroy(b->tri);
+    if (b->d_nbrs) (void)hipFree(b->d_nbrs);
+    delete b;
+    return JV_OK;
+}
+
+int jv_hip_builder_seed(jv_ctx *ctx, jv_builder *b, int32_t node)
+{
+    clear_error();
+    JV_REQUIRE(ctx && b, "builder_seed: NULL argument");
+    JV_REQUIRE(node >= 0 && node < b->n, "builder_seed: node %d outside [0, %lld)", node, (long long)b->n);
+    JV_REQUIRE(b->inserted == 0, "builder_seed: the graph already has nodes");
+    b->entry = node;
+    b->inserted = 1;  // its (empty) row exists; the first batch links to it
+    return jv_hip_graph_set_entry(b->graph, node, 0);
+}
+
+int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes, int B)
+{
+    clear_error();
+    JV_REQUIRE(ctx && b, "builder_insert_batch: NULL argument");
+    JV_REQUIRE(B >= 0, "builder_insert_batch: negative batch");
+    if (B == 0) return JV_OK;
+    JV_REQUIRE(nodes, "builder_insert_batch: NULL nodes");
+    JV_REQUIRE(b->entry >= 0, "builder_insert_batch: seed the graph first (jv_hip_builder_seed)");
+    JV_REQUIRE(ctx->device == b->device, "builder_insert_batch: the builder lives on device %d", b->device);
+    JV_TRY(use_device(ctx->device));
+    const int D = b->pq->D, Rf = b->Rf, R = b->R;
+    const int k = (int)std::min<int64_t>(b->beam, b->inserted);  // cannot ask for more candidates than the graph holds
+    const int search_chunk = 65536;
+    if (!b->luts || b->luts_cap < std::min(B, search_chunk)) {
+        if (b->luts) jv_hip_luts_destroy(b->luts);
+        b->luts = nullptr;
+        b->luts_cap = std::min(search_chunk, std::max(1024, 2 * B));
+        JV_TRY(jv_hip_luts_create(ctx, b->pq, b->luts_cap, &b->luts));
+    }
+    JV_TRY(b->d_nodes.reserve(sizeof(int32_t) * (size_t)B));
+    JV_HIP_CHECK(hipMemcpyAsync(b->d_nodes.ptr, nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));
+    if (!is_device_ptr(nodes)) JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the caller may reuse its buffer
+    const int32_t *d_nodes = (const int32_t *)b->d_nodes.ptr;
+    JV_TRY(b->d_cand.reserve(sizeof(int32_t) * (size_t)B * k));
+    JV_TRY(b->d_csc.reserve(sizeof(float) * (size_t)B * k));
+    JV_TRY(b->d_q.reserve(sizeof(float) * (size_t)std::min(B, search_chunk) * D));
+    int32_t *d_cand = (int32_t *)b->d_cand.ptr;
+    float *d_csc = (float *)b->d_csc.ptr;
+
+    // ---- 1 + 2. candidate search on the graph built so far ----
+    double t0 = now_s();
+    for (int s = 0; s < B; s += search_chunk) {
+        const int bc = std::min(search_chunk, B - s);
+        JV_TRY(launch_gather_rows(ctx->stream, b->vectors->d_vecs, b->vectors->count, D, d_nodes + s, bc, (float *)b->d_q.ptr, nullptr, 0));
+        b->h_stats.resize(2 * (size_t)bc);
+        JV_TRY(jv_hip_graph_search(ctx, b->graph, b->luts, b->codes, nullptr, nullptr, (const float *)b->d_q.ptr, bc, b->vsf, k, k,
+                                   d_cand + (size_t)s * k, d_csc + (size_t)s * k, b->h_stats.data()));
+        for (int q = 0; q < bc; ++q) {
+            b->visited += b->h_stats[2 * (size_t)q];
+            b->expanded += b->h_stats[2 * (size_t)q + 1];
+        }
+    }
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    b->search_s += now_s() - t0;
+
+    // ---- 3 + 4. robust prune of every new node's candidates (best first), rows + back edges ----
+    t0 = now_s();
+    JV_TRY(b->d_count.reserve(sizeof(int32_t) * (size_t)B));
+    JV_TRY(b->d_sel.reserve(sizeof(int32_t) * (size_t)B * Rf));
+    JV_TRY(b->d_nsel.reserve(sizeof(int32_t) * (size_t)B));
+    JV_TRY(launch_bl_count_valid(ctx->stream, d_cand, k, (int32_t *)b->d_count.ptr, B));
+    JV_TRY(run_retain(ctx, b, d_cand, d_csc, (const int32_t *)b->d_count.ptr, B, k, (int32_t *)b->d_sel.ptr, (int32_t *)b->d_nsel.ptr));
+    const long long E = (long long)B * Rf;
+    JV_TRY(b->d_keys.reserve(sizeof(unsigned long long) * (size_t)E));
+    JV_TRY(b->d_keys2.reserve(sizeof(unsigned long long) * (size_t)E));
+    JV_TRY(b->d_src.reserve(sizeof(int32_t) * (size_t)E));
+    JV_TRY(b->d_src2.reserve(sizeof(int32_t) * (size_t)E));
+    BlApplyParams ap{};
+    ap.nodes = d_nodes;
+    ap.cand = d_cand;
+    ap.sel = (const int32_t *)b->d_sel.ptr;
+    ap.B = B;
+    ap.C = k;
+    ap.Rf = Rf;
+    ap.R = R;
+    ap.nbrs = b->d_nbrs;
+    ap.edge_keys = (unsigned long long *)b->d_keys.ptr;
+    ap.edge_src = (int32_t *)b->d_src.ptr;
+    JV_TRY(launch_bl_apply_selection(ctx->stream, ap));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    b->prune_s += now_s() - t0;
+
+    // ---- 5 - 7. backlinks ----
+    t0 = now_s();
+    size_t tmp_bytes = 0;
+    JV_TRY(launch_bl_sort_edges(ctx->stream, nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, E, 64));
+    JV_TRY(b->d_sort_tmp.reserve(tmp_bytes + 256));
+    JV_TRY(launch_bl_sort_edges(ctx->stream, b->d_sort_tmp.ptr, &tmp_bytes, (const unsigned long long *)b->d_keys.ptr,
+                                (unsigned long long *)b->d_keys2.ptr, (const int32_t *)b->d_src.ptr, (int32_t *)b->d_src2.ptr, E, 64));
+    const int Knew = 2 * R, L = R + Knew;
+    const unsigned int over_cap = (unsigned int)std::min<long long>(E, b->n);  // at most one overflow per distinct target
+    JV_TRY(b->d_over_tgt.reserve(sizeof(int32_t) * (size_t)over_cap));
+    JV_TRY(b->d_over_list.reserve(sizeof(int32_t) * (size_t)over_cap * L));
+    JV_HIP_CHECK(hipMemsetAsync(b->d_ctr.ptr, 0, sizeof(unsigned int), ctx->stream));
+    BlMergeParams mp{};
+    mp.keys = (const unsigned long long *)b->d_keys2.ptr;
+    mp.src = (const int32_t *)b->d_src2.ptr;
+    mp.E = E;
+    mp.R = R;
+    mp.Knew = Knew;
+    mp.nbrs = b->d_nbrs;
+    mp.over_tgt = (int32_t *)b->d_over_tgt.ptr;
+    mp.over_list = (int32_t *)b->d_over_list.ptr;
+    mp.over_count = (unsigned int *)b->d_ctr.ptr;
+    mp.over_cap = over_cap;
+    JV_TRY(launch_bl_backlink_merge(ctx->stream, mp));
+    unsigned int n_over = 0;
+    JV_TRY(read_counter(ctx, b, &n_over));
+    n_over = std::min(n_over, over_cap);
+    JV_TRY(reprune_lists(ctx, b, mp.over_tgt, mp.over_list, (int)n_over, L));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    b->backlink_s += now_s() - t0;
+    b->inserted += B;
+    b->batches += 1;
+    return JV_OK;
+}
+
+int jv_hip_builder_finish(jv_ctx *ctx, jv_builder *b, int32_t *neighbors_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && b, "builder_finish: NULL argument");
+    JV_REQUIRE(ctx->device == b->device, "builder_finish: the builder lives on device %d", b->device);
+    JV_TRY(use_device(ctx->device));
+    const double t0 = now_s();
+    if (b->R > b->Rf) {  // GraphIndexBuilder.cleanup -> enforceDegree: lists still above maxDegree are pruned back
+        JV_TRY(b->d_over_tgt.reserve(sizeof(int32_t) * (size_t)b->n));
+        JV_HIP_CHECK(hipMemsetAsync(b->d_ctr.ptr, 0, sizeof(unsigned int), ctx->stream));
+        BlOverParams op{};
+        op.nbrs = b->d_nbrs;
+        op.N = b->n;
+        op.R = b->R;
+        op.Rf = b->Rf;
+        op.over_tgt = (int32_t *)b->d_over_tgt.ptr;
+        op.over_count = (unsigned int *)b->d_ctr.ptr;
+        op.over_cap = (unsigned int)b->n;
+        JV_TRY(launch_bl_list_over_degree(ctx->stream, op));
+        unsigned int n_over = 0;
+        JV_TRY(read_counter(ctx, b, &n_over));
+        const int piece = 1 << 20;
+        JV_TRY(b->d_over_list.reserve(sizeof(int32_t) * (size_t)std::min<unsigned int>(n_over, piece) * b->R));
+        for (unsigned int s = 0; s < n_over; s += piece) {
+            const int P = (int)std::min<unsigned int>(piece, n_over - s);
+            const int32_t *tgt = (const int32_t *)b->d_over_tgt.ptr + s;
+            JV_TRY(launch_bl_copy_rows(ctx->stream, b->d_nbrs, b->R, tgt, P, (int32_t *)b->d_over_list.ptr));
+            JV_TRY(reprune_lists(ctx, b, tgt, (const int32_t *)b->d_over_list.ptr, P, b->R));
+        }
+    }
+    if (neighbors_out) {
+        OutStage os;
+        JV_TRY(stage_out_begin(ctx, neighbors_out, sizeof(int32_t) * (size_t)b->n * b->Rf, ctx->d_out, &os));
+        JV_TRY(launch_bl_strided_copy(ctx->stream, b->d_nbrs, b->R, b->Rf, b->n, (int32_t *)os.dev));
+        JV_TRY(stage_out_end(ctx, os));
+    }
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    b->backlink_s += now_s() - t0;
+    return JV_OK;
+}
+
+int jv_hip_builder_stats(const jv_builder *b, double *seconds3, int64_t *counts5)
+{
+    clear_error();
+    JV_REQUIRE(b, "builder_stats: NULL argument");
+    if (seconds3) {
+        seconds3[0] = b->search_s;
+        seconds3[1] = b->prune_s;
+        seconds3[2] = b->backlink_s;
+    }
+    if (counts5) {
+        counts5[0] = b->batches;
+        counts5[1] = b->reprunes;
+        counts5[2] = b->inserted;
+        counts5[3] = b->visited;
+        counts5[4] = b->expanded;
+    }
+    return JV_OK;
+}
+
+const int32_t *jv_hip_builder_neighbors_device(const jv_builder *b, int *row_width)
+{
+    if (!b) return nullptr;
+    if (row_width) *row_width = b->R;
+    return b->d_nbrs;
+}
+
+}  // extern "C"

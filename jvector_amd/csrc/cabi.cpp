@@ -746,6 +746,14 @@ int jv_hip_vectors_wrap(jv_ctx *ctx, int64_t count, int D, void *device_vectors,
     return JV_OK;
 }
 
+int jv_hip_vectors_invalidate(jv_vectors *v)
+{
+    clear_error();
+    JV_REQUIRE(v, "vectors_invalidate: NULL argument");
+    v->sqnorm_valid = false;  // the cosine rerank's per-row sum-of-squares table is rebuilt on next use
+    return JV_OK;
+}
+
 int jv_hip_vectors_upload(jv_ctx *ctx, jv_vectors *v, int64_t first, int64_t count, const float *src)
 {
     clear_error();
@@ -1038,7 +1046,7 @@ int jv_hip_fused_upload(jv_ctx *ctx, jv_fused *f, int64_t first, int64_t count, 
                                 sizeof(int32_t) * (size_t)count * f->maxDegree, hipMemcpyDefault, ctx->stream));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     f->norms_valid = false;
-    f->generation++;
+    f->generation = next_fused_generation();  // process-wide, never reused: a recycled jv_fused address cannot alias a cached check
     return JV_OK;
 }
 

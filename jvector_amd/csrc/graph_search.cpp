@@ -1264,12 +1264,12 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     int evict_cap = GS_EVICT_CAP;
     int cand_cap = std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", occ == 4 ? 512 : (pair ? 256 : 1024))) & ~63;
     while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
-    // Visited set, tier 1 (gs_body.h gs_visit1): an LDS table of 16-bit entries in whatever the other per-worker structures
-    // leave of 160 KB / (4 x occ workers per CU).  Preference: the largest table first (4096 slots = 8 KB hold the median
-    // search of the headline workload: ~2200 visited nodes), giving up candidate-tier / evicted-list capacity before table size
-    // (LDS tier sizes 256 / 512 / 768 measured within 3 % of each other in round 2; a full evicted list only costs a retry);
-    // gs_v1_log2 = 0 turns the tier off, a positive value pins it.  Graphs too large for the entry format (more than 13
-    // remainder bits) get a bigger table or none.
+    // Visited set, tier 1 (gs_body.h gs_visit1): a two-choice bucketed LDS table of 16-bit entries in whatever the other
+    // per-worker structures leave of 160 KB / (4 x occ workers per CU).  Preference: the largest table first (4096 slots = 8 KB
+    // hold ~3900 nodes: all but the longest searches of the headline workload, median ~2200 visited nodes), giving up
+    // candidate-tier capacity before table size (LDS tier sizes 256 / 512 / 768 measured within 3 % of each other in round 2);
+    // gs_v1_log2 = 0 turns the tier off, a positive value pins it.  Graphs too large for the entry format (more than 14
+    // remainder bits) get none.
     const int idbits = gs_idbits(g->n_nodes);
     const int want_per_cu = 4 * occ;
     const size_t lds_budget = (160 * 1024) / (size_t)want_per_cu - 256;
@@ -1278,7 +1278,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         // (a pinned gs_vcap_log2 is how tests drive the overflow paths of tier 2: no LDS tier in front of it then, unless asked for)
         const long long pin = ctx_opt(ctx, "gs_v1_log2", ctx_opt_is_set(ctx, "gs_vcap_log2") ? 0 : -1);
         struct Caps { int cand, evict; };
-        const Caps caps[3] = {{cand_cap, evict_cap}, {std::min(cand_cap, 128), evict_cap}, {std::min(cand_cap, 128), 64}};
+        // (third choice: the evicted list takes what is left, but no less than 96 entries — round 3's first hardware run used 64
+        // and sent 0.3 % of the 10M queries through a retry launch that cost 7 % of the step)
+        const int cand_small = std::min(cand_cap, 128);
+        const long long left = (long long)lds_budget - (long long)graph_search_lds_bytes(pq->D, rerankK, cand_small, pair_M, 1, 12) + 8;
+        const Caps caps[3] = {{cand_cap, evict_cap}, {cand_small, evict_cap}, {cand_small, (int)std::max<long long>(96, std::min<long long>(evict_cap, left / 8))}};
         bool done = false;
         for (int lg = pin > 0 ? (int)pin : 12; lg >= (pin > 0 ? (int)pin : 10) && !done && pin != 0; --lg) {
             if (!gs_v1_fits(lg, idbits)) continue;

@@ -261,45 +261,49 @@ GS_FN bool gs_visit(int32_t *tab, uint32_t mask, int shift, int32_t node)
 }
 
 // ---- two-tier visited set, tier 1 (LDS) ----
-// Node ids are < 2^idbits.  h = node * odd mod 2^idbits is a bijection on them; its top bits pick the home slot, the
-// remaining rbits = idbits - log2(slots) bits are the remainder r.  An entry sits at most dmax slots past its home
-// (linear probing) and is stored as 16 bits (d << rbits | r): (slot - d, r) identify h and therefore the node EXACTLY, at
-// half the bytes of a node id — 4096 slots are 8 KB, which is what 8 waves per CU leave free in LDS at the headline shape.
-// 0xFFFF = empty (d <= dmax = 2^(16 - rbits) - 2 keeps real entries away from it).
-// Returns 0: already in the set; 1: inserted here (fresh); 2: cannot live in this tier — no free slot within dmax of its
-// home, or the tier is frozen.  Both conditions are permanent for that node (slots are never freed, a frozen tier never
-// thaws), so a node answered 2 once is answered 2 on every later probe and tier 2 alone decides about it: a node is in
-// exactly one tier.
+// A two-choice bucketed hash set of 16-bit entries: slots / 4 buckets of four entries (8 bytes, one ds_read_b64).  Node ids
+// are < 2^idbits; h_c = node * odd_c mod 2^idbits (c = 0, 1) are two bijections on them.  The top bits of h_c pick bucket
+// b_c, the remaining rbits = idbits - log2(buckets) bits are the remainder, and the entry stored in bucket b_c is
+// (c << rbits | remainder): (bucket, entry) give h_c back and therefore the node EXACTLY, at half the bytes of a node id —
+// 4096 slots are 8 KB, what 8 waves per CU leave free in LDS at the headline shape, and hold the visited set of all but the
+// longest searches.  0xFFFF = empty (rbits <= 14 keeps real entries away from it).  A probe reads bucket b_0 and, only if
+// that is full, bucket b_1: one or two LDS reads whatever the load (linear probing, the first version, cost the wave the
+// LONGEST of its 32 lanes' probe sequences: slower than the global-memory CAS it replaced once the table filled up).
+// Returns 0: already in the set; 1: inserted (fresh); 2: both buckets are full of other nodes.  Buckets never lose entries,
+// so a node answered 2 once is answered 2 on every later probe and tier 2 alone decides about it; and a node is inserted into
+// b_1 only while b_0 is full, i.e. it can never sit in b_1 while b_0 has room: a node lives in exactly one place.
 struct GsVis1 {
-    uint32_t *w;       // LDS words, two entries each
-    uint32_t smask;    // slots - 1
+    uint32_t *w;       // LDS words, two entries each; bucket b = words 2b, 2b + 1
+    uint32_t bmask;    // buckets - 1
     uint32_t idmask;   // 2^idbits - 1
-    int rbits, dmax;
+    int rbits;
 };
 
-GS_FN int gs_visit1(const GsVis1 &t, bool frozen, int32_t node)
+// 0 found / 1 inserted / 2 bucket full of other entries
+GS_FN int gs_v1_bucket(uint32_t *bw, uint32_t mine)
 {
-    const uint32_t h = ((uint32_t)node * 0x9E3779B1u) & t.idmask;
-    const uint32_t home = (h >> t.rbits) & t.smask;
-    const uint32_t r = h & ((1u << t.rbits) - 1u);
-    for (int d = 0; d <= t.dmax; ++d) {
-        const uint32_t slot = (home + (uint32_t)d) & t.smask;
-        uint32_t *wp = t.w + (slot >> 1);
-        const int sh = (int)(slot & 1u) * 16;
-        const uint32_t mine = ((uint32_t)d << t.rbits) | r;
-        uint32_t w = *wp;
-        for (;;) {
-            const uint32_t cur = (w >> sh) & 0xFFFFu;
-            if (cur == mine) return 0;
-            if (cur != 0xFFFFu) break;  // another node's entry: next slot
-            if (frozen) return 2;
-            const uint32_t want = (w & ~(0xFFFFu << sh)) | (mine << sh);
-            const uint32_t old = gs_lds_cas(wp, w, want);
-            if (old == w) return 1;
-            w = old;  // a neighbouring lane changed the word (this slot or its twin): look again
-        }
+    for (;;) {
+        const uint32_t w0 = bw[0], w1 = bw[1];
+        const uint32_t e0 = w0 & 0xFFFFu, e1 = w0 >> 16, e2 = w1 & 0xFFFFu, e3 = w1 >> 16;
+        if (e0 == mine || e1 == mine || e2 == mine || e3 == mine) return 0;
+        const int slot = e0 == 0xFFFFu ? 0 : (e1 == 0xFFFFu ? 1 : (e2 == 0xFFFFu ? 2 : (e3 == 0xFFFFu ? 3 : -1)));
+        if (slot < 0) return 2;
+        const uint32_t w = slot < 2 ? w0 : w1;
+        const int sh = (slot & 1) * 16;
+        const uint32_t want = (w & ~(0xFFFFu << sh)) | (mine << sh);
+        if (gs_lds_cas(bw + (slot >> 1), w, want) == w) return 1;
+        // a neighbouring lane changed the word first: look again (its entry may have taken the slot)
     }
-    return 2;
+}
+
+GS_FN int gs_visit1(const GsVis1 &t, int32_t node)
+{
+    const uint32_t rmask = (1u << t.rbits) - 1u;
+    const uint32_t h0 = ((uint32_t)node * 0x9E3779B1u) & t.idmask;
+    const int r = gs_v1_bucket(t.w + 2u * ((h0 >> t.rbits) & t.bmask), h0 & rmask);
+    if (r != 2) return r;
+    const uint32_t h1 = ((uint32_t)node * 0x85EBCA6Bu) & t.idmask;
+    return gs_v1_bucket(t.w + 2u * ((h1 >> t.rbits) & t.bmask), (1u << t.rbits) | (h1 & rmask));
 }
 
 // upper-level adjacency row of `node`, or nullptr (uniform: every lane probes the same slots)
@@ -441,17 +445,12 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         GsVis1 t;
         const size_t base = ((size_t)((char *)(xchg + 32 * (PAIR ? p.M / 2 : 0)) - lds) + (PAIR ? 0 : sizeof(long long) * 64) + 15) & ~(size_t)15;
         t.w = reinterpret_cast<uint32_t *>(lds + base);
-        t.smask = (1u << p.v1_log2) - 1u;
+        t.bmask = (1u << (p.v1_log2 - 2)) - 1u;
         t.idmask = (p.v1_idbits >= 32) ? 0xFFFFFFFFu : ((1u << p.v1_idbits) - 1u);
-        t.rbits = p.v1_idbits > p.v1_log2 ? p.v1_idbits - p.v1_log2 : 0;
-        const int dlim = (1 << (16 - t.rbits)) - 2;
-        t.dmax = dlim < 30 ? dlim : 30;
+        t.rbits = p.v1_idbits > p.v1_log2 - 2 ? p.v1_idbits - (p.v1_log2 - 2) : 0;
         return t;
     };
-    const int v1_cap = has_v1 ? (3 << p.v1_log2) >> 2 : 0;  // freeze at 3/4 full: misses then cost <= ~8 LDS probes
-    int n1 = 0;
     long long n2 = 0;            // nodes in tier 2
-    bool frozen = false;
     bool t2_ready = !has_v1;     // tier 2 cleared for this query (eagerly below when there is no LDS tier)
     // The visited table is half full: move to a table of the growth pool (once per query), or give up with GS_OVERFLOW.
     // Wave-uniform.  The old table is read back with atomics (a CAS that can never succeed), like every other access to it.
@@ -505,11 +504,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     // enters, `act` says whether it carries a node).  Sets s.status on table overflow.
     auto visit = [&](bool act, int32_t nb) -> bool {
         int r1 = act ? 2 : 0;
-        if (has_v1) {
-            if (act) r1 = gs_visit1(gs_v1_of(), frozen, nb);
-            n1 += gs_popc(gs_ballot(r1 == 1));
-            if (n1 >= v1_cap) frozen = true;
-        }
+        if (has_v1 && act) r1 = gs_visit1(gs_v1_of(), nb);
         bool fr = r1 == 1;
         if (gs_ballot(r1 == 2)) {
             if (!t2_ready) t2_init();
@@ -545,8 +540,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         const int32_t e = p.entry_node;
         // first insertion into an empty set: no probing conflicts, no growth check
         if (has_v1) {
-            if (lane == 0) (void)gs_visit1(gs_v1_of(), false, e);
-            n1 = 1;
+            if (lane == 0) (void)gs_visit1(gs_v1_of(), e);
         } else {
             if (lane == 0) (void)gs_visit(vis, vmask, vshift, e);
             n2 = 1;

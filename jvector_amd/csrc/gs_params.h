@@ -53,8 +53,8 @@ struct GsParams {
     int32_t pair;             // 1: pair-lane scoring (every degree <= 32; LDS has the M/2 x 32 exchange area)
     // visited set, tier 1: an open-addressing table of 16-bit entries in LDS (gs_body.h "two-tier visited set"); the global
     // table above is tier 2 and is only touched (and only then cleared) by a query whose tier 1 fills up.
-    int32_t v1_log2;          // log2(slots) of the LDS tier, 0 = no LDS tier (every probe goes to the global table)
-    int32_t v1_idbits;        // node ids are < 1 << v1_idbits; v1_idbits - v1_log2 remainder bits + displacement bits = 16
+    int32_t v1_log2;          // log2(slots) of the LDS tier (slots / 4 buckets of four 16-bit entries), 0 = no LDS tier
+    int32_t v1_idbits;        // node ids are < 1 << v1_idbits; v1_idbits - (v1_log2 - 2) <= 14 remainder bits + the choice bit
     // outputs
     int32_t *out_ids;         // [Q][rerankK] kept approximate results (unordered), -1 padded
     float *out_scores;        // [Q][rerankK] their approximate scores, -inf padded
@@ -79,8 +79,8 @@ inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M whe
     return v1_log2 > 0 ? ((base + 15) & ~(size_t)15) + ((size_t)2 << v1_log2) : base;
 }
 
-// The LDS tier's entry format needs >= 3 displacement bits: 16 - (idbits - v1_log2) >= 3.
-inline bool gs_v1_fits(int v1_log2, int idbits) { return v1_log2 >= 6 && v1_log2 <= 15 && idbits - v1_log2 <= 13 && idbits <= 31; }
+// The LDS tier's 16-bit entry = choice bit + remainder: idbits - log2(buckets) <= 14 (0xFFFF stays free for "empty").
+inline bool gs_v1_fits(int v1_log2, int idbits) { return v1_log2 >= 4 && v1_log2 <= 15 && idbits - (v1_log2 - 2) <= 14 && idbits <= 31; }
 inline int gs_idbits(long long n_nodes)
 {
     int b = 1;

@@ -92,6 +92,11 @@ struct jv_ctx {
 };
 
 namespace jv {
+inline uint64_t next_fused_generation()
+{
+    static std::atomic<uint64_t> g{1};
+    return g.fetch_add(1, std::memory_order_relaxed);
+}
 // option `name` of this context: set by jv_hip_ctx_set_option, else the environment variable JVECTOR_HIP_<NAME>, else dflt
 long long ctx_opt(const jv_ctx *ctx, const char *name, long long dflt);
 bool ctx_opt_is_set(const jv_ctx *ctx, const char *name);
@@ -152,6 +157,14 @@ struct jv_vectors {
     bool sqnorm_valid = false;
 };
 
+struct jv_pair_table {   // ProductQuantization.createCodebookPartialSums on the device (build_score.cpp)
+    int device = 0;
+    const jv_pq *pq = nullptr;
+    jv_vsf vsf = JV_EUCLIDEAN;
+    float *d_tri = nullptr;
+    int64_t floats = 0;
+};
+
 struct jv_fused {
     int device = 0;
     const jv_pq *pq = nullptr;
@@ -161,7 +174,7 @@ struct jv_fused {
     int32_t *d_neighbors = nullptr; // count x maxDegree
     float *d_norms = nullptr;       // count x maxDegree (cosine), lazily built
     bool norms_valid = false;
-    uint64_t generation = 0;        // bumped by every upload (consumers that cached a consistency check compare it)
+    uint64_t generation = 0;        // set from a process-wide counter by every upload / build (consumers that cached a consistency check compare it)
 };
 
 struct jv_luts {
@@ -285,6 +298,22 @@ int launch_fused_gather(hipStream_t s, const jv_codes *codes, const int32_t *d_n
 int launch_pq_decode(hipStream_t s, const jv_codes *codes, const int32_t *d_ordinals, int64_t first, int64_t count, float *d_out);
 int launch_direct_scores(hipStream_t s, const jv_codes *codes, int vsf, const float *d_cq, int Q, const int32_t *d_ordinals, int B,
                          float *d_qnorm, float *d_out);
+// batched graph construction (k_builder.hip; bodies and parameters in bl_body.h)
+struct BlApplyParams;
+struct BlMergeParams;
+struct BlSortParams;
+struct BlRowsParams;
+struct BlOverParams;
+int launch_bl_apply_selection(hipStream_t s, const BlApplyParams &p);
+int launch_bl_backlink_merge(hipStream_t s, const BlMergeParams &p);
+int launch_bl_rank_sort(hipStream_t s, const BlSortParams &p);
+int launch_bl_rewrite_rows(hipStream_t s, const BlRowsParams &p);
+int launch_bl_list_over_degree(hipStream_t s, const BlOverParams &p);
+int launch_bl_count_valid(hipStream_t s, const int32_t *cand, int C, int32_t *count, long long B);
+int launch_bl_copy_rows(hipStream_t s, const int32_t *nbrs, int R, const int32_t *tgt, long long P, int32_t *out);
+int launch_bl_strided_copy(hipStream_t s, const int32_t *src, int R, int Rf, long long N, int32_t *dst);
+int launch_bl_sort_edges(hipStream_t s, void *temp, size_t *temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
+                         const int32_t *vals_in, int32_t *vals_out, long long n, int end_bit);
 // device-resident graph traversal (k_gsearch.hip; parameters in gs_params.h)
 struct GsParams;
 // stage the queries of a batch (raw copy, centred copy, cosine query magnitudes); with_tables also builds the ADC look-up

@@ -299,6 +299,11 @@ class VectorSet:
     def size(self):
         return self.count
 
+    def invalidate(self):
+        """the wrapped tensor was edited in place: drop the cached per-row norms of the cosine rerank (jv_hip_vectors_invalidate)"""
+        check(self._lib.jv_hip_vectors_invalidate(self._h))
+        return self
+
     def scores(self, queries, vsf, ordinals):
         """rerank form: out[q, j] = vsf.compare(queries[q], vectors[ordinals[q, j]])"""
         Q, B = int(ordinals.shape[0]), int(ordinals.shape[1])

@@ -7,7 +7,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "build", "mock")
 LIB = os.path.join(OUT, "libjvector_hip_mock.so")
-HOST = ["cabi", "graph_search", "sharded", "build_score", "pq_train", "formats", "compat_host"]
+HOST = ["cabi", "graph_search", "sharded", "build_score", "builder", "pq_train", "formats", "compat_host"]
 CXXF = ["-std=c++17", "-O2", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-include",
         os.path.join(ROOT, "tests", "mock", "mock_prefix.h"), "-fPIC", "-Wno-unknown-pragmas", "-Wno-unused-function"]
 

@@ -49,6 +49,7 @@ static inline gs_f32x16 gs_mfma_32x32x2(float a, float b, gs_f32x16 c) { return 
 #include "../../jvector_amd/csrc/jv_device.h"
 #include "../../jvector_amd/csrc/jv_internal.h"
 
+#include "../../jvector_amd/csrc/bl_body.h"
 #include "../../jvector_amd/csrc/bs_body.h"
 #include "../../jvector_amd/csrc/ed_body.h"
 #include "../../jvector_amd/csrc/gs_body.h"
@@ -511,6 +512,66 @@ int launch_km_reactivate(hipStream_t, const KmParams &p)
 int launch_km_finish_round(hipStream_t, const KmParams &p)
 {
     for (int64_t m = 0; m < p.M; ++m) km_finish_round(p, m);
+    return JV_OK;
+}
+
+// ---- batched graph construction: bl_body.h's per-item bodies as loops (in REVERSE item order where the GPU's order is
+//      unspecified, so that nothing silently depends on ascending execution) ----
+int launch_bl_apply_selection(hipStream_t, const BlApplyParams &p)
+{
+    for (long long i = (long long)p.B * p.Rf - 1; i >= 0; --i) bl_apply_selection(p, i);
+    for (long long b = p.B - 1; b >= 0; --b) bl_pack_row(p, b);
+    return JV_OK;
+}
+int launch_bl_backlink_merge(hipStream_t, const BlMergeParams &p)
+{
+    for (long long i = p.E - 1; i >= 0; --i) bl_backlink_merge(p, i);
+    return JV_OK;
+}
+int launch_bl_rank_sort(hipStream_t, const BlSortParams &p)
+{
+    for (long long i = (long long)p.P * p.L - 1; i >= 0; --i) bl_rank_sort(p, i);
+    return JV_OK;
+}
+int launch_bl_rewrite_rows(hipStream_t, const BlRowsParams &p)
+{
+    for (long long i = p.P - 1; i >= 0; --i) bl_rewrite_row(p, i);
+    return JV_OK;
+}
+int launch_bl_list_over_degree(hipStream_t, const BlOverParams &p)
+{
+    for (long long i = p.N - 1; i >= 0; --i) bl_list_over_degree(p, i);
+    return JV_OK;
+}
+int launch_bl_count_valid(hipStream_t, const int32_t *cand, int C, int32_t *count, long long B)
+{
+    for (long long b = 0; b < B; ++b) bl_count_valid(cand, C, count, b);
+    return JV_OK;
+}
+int launch_bl_copy_rows(hipStream_t, const int32_t *nbrs, int R, const int32_t *tgt, long long P, int32_t *out)
+{
+    for (long long i = 0; i < P * R; ++i) out[i] = nbrs[(long long)tgt[i / R] * R + (i % R)];
+    return JV_OK;
+}
+int launch_bl_strided_copy(hipStream_t, const int32_t *src, int R, int Rf, long long N, int32_t *dst)
+{
+    for (long long i = 0; i < N * Rf; ++i) dst[i] = src[(i / Rf) * R + (i % Rf)];
+    return JV_OK;
+}
+int launch_bl_sort_edges(hipStream_t, void *temp, size_t *temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
+                         const int32_t *vals_in, int32_t *vals_out, long long n, int)
+{
+    if (!temp) {
+        *temp_bytes = 64;
+        return JV_OK;
+    }
+    std::vector<long long> idx((size_t)n);
+    for (long long i = 0; i < n; ++i) idx[(size_t)i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](long long a, long long b) { return keys_in[a] < keys_in[b]; });
+    for (long long i = 0; i < n; ++i) {
+        keys_out[i] = keys_in[idx[(size_t)i]];
+        vals_out[i] = vals_in[idx[(size_t)i]];
+    }
     return JV_OK;
 }
 

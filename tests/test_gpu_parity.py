@@ -223,6 +223,32 @@ def test_exact_gather_and_scan_bit_exact(ctx, D):
             assert np.all(np.isneginf(g[q][~valid]))
 
 
+def test_wrapped_vectors_edited_in_place_need_invalidate(ctx):
+    """a VectorSet that WRAPS caller-owned device memory caches one float per row for the cosine rerank; after the
+    caller rewrites rows in place, jv_hip_vectors_invalidate makes the next cosine score see the new rows (== the oracle)"""
+    import torch
+    rng = np.random.default_rng(5)
+    N, D, Q = 500, 128, 7
+    vecs = rng.standard_normal((N, D)).astype(np.float32)
+    queries = rng.standard_normal((Q, D)).astype(np.float32)
+    ords = rng.integers(0, N, (Q, 70)).astype(np.int32)
+    t = torch.from_numpy(vecs.copy())
+    if torch.cuda.is_available():
+        t = t.cuda()
+    vs = J.VectorSet(ctx, t)
+    g0 = np.asarray(torch.as_tensor(vs.scores(queries, VSF.COSINE, ords)).cpu())
+    for q in range(Q):
+        assert np.array_equal(g0[q], O.compare_many(int(VSF.COSINE), queries[q], vecs)[ords[q]])
+    t.mul_(3.0)                                   # cosine is scale invariant in exact arithmetic, not in f32 bits ...
+    t[11] = torch.from_numpy(queries[0]).to(t.device)   # ... and one row changes outright
+    vecs2 = np.asarray(t.cpu())
+    vs.invalidate()
+    ctx.sync()
+    g1 = np.asarray(torch.as_tensor(vs.scores(queries, VSF.COSINE, ords)).cpu())
+    for q in range(Q):
+        assert np.array_equal(g1[q], O.compare_many(int(VSF.COSINE), queries[q], vecs2)[ords[q]])
+
+
 @pytest.mark.parametrize("D,B", [(768, 150), (1536, 150), (8, 1), (72, 64), (200, 65), (64, 129), (1024, 400)])
 def test_exact_gather_transposing_kernel(ctx, D, B, monkeypatch):
     """NodeQueue.rerank's scoring at the benched shapes through the coalesced (LDS-transposing) kernel: ragged candidate

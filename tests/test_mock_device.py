@@ -808,3 +808,11 @@ def test_bench_refuses_a_launcher_that_disagrees_with_gpus(J):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mock", "bench_on_mock.py"), "--gpus", "2", "--n", "2000"], env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "--gpus 2" in out.stderr and not [x for x in out.stdout.splitlines() if x.startswith("{")]
+
+
+def test_golden_checker_through_the_c_abi_on_the_mock(J):
+    """tests/test_reference_goldens.py's HIP-side adapter (every quantity GoldenDump.java records, fetched through the C ABI)
+    against the oracle-made golden file, on the mock device: keeps the adapter's API usage compiling until a GPU run does it for real"""
+    import test_reference_goldens as T
+    g = T.oracle_made_goldens()
+    T.check_goldens(g, T.HipSide(g), exact=True)
