@@ -647,6 +647,11 @@ def main():
                          "host batched searcher")
     ap.add_argument("--build-beam", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_BEAM", "100")),
                     help="engine graph: construction beam width (the reference's efConstruction / beamWidth, default 100)")
+    ap.add_argument("--build-alpha", type=float, default=float(os.environ.get("JVECTOR_BENCH_BUILD_ALPHA", "1.2")), help="engine graph: robust-prune alpha")
+    ap.add_argument("--build-overflow", type=float, default=float(os.environ.get("JVECTOR_BENCH_BUILD_OVERFLOW", "1.25")),
+                    help="engine graph: neighborOverflow (working row width = maxDegree x overflow, <= 64)")
+    ap.add_argument("--build-max-batch", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_MAX_BATCH", "131072")),
+                    help="engine graph: largest insert batch (inserts of one batch do not see each other)")
     ap.add_argument("--torch-codebooks", action="store_true", help="codebooks from benchlib's torch Lloyd instead of the engine's "
                     "ProductQuantization.compute (round-1 behaviour)")
     ap.add_argument("--index-cache", default=os.environ.get("JVECTOR_BENCH_INDEX_CACHE", ""), help="npz file: synthetic graph + "
@@ -744,7 +749,8 @@ def main():
         elif args.graph == "engine":
             from jvector_amd.builder import build_hierarchical
             levels, entry, entry_level, nbrs_dev, bstats = build_hierarchical(ctx, pq, cv, base, VSF, max_degree=args.degree,
-                                                                                beam_width=args.build_beam, alpha=1.2, log=log)
+                                                                                beam_width=args.build_beam, alpha=args.build_alpha, log=log,
+                                                                                overflow=args.build_overflow, max_batch=args.build_max_batch)
             log(f"[build] {dict(bstats)}")
             build_info = {k: (float(v) if isinstance(v, float) else v) for k, v in dict(bstats).items()}
             if args.index_cache and rank == 0:
@@ -911,7 +917,7 @@ def main():
             "config": {"workload": (f"synthetic {N}x{D} cosine (latent-{args.latent} mixture of 1000 clusters, unit norm), PQ-{M} (k=256, " +
                                     ("torch Lloyd x6" if args.torch_codebooks else "engine ProductQuantization.compute: k-means++ + Lloyd x6") +
                                     " on a 128k sample), " +
-                                    (f"FusedADC graph search: " + (f"layered Vamana graph built by the engine's batched builder (PQ scoring, beamWidth {args.build_beam}, alpha 1.2, neighborOverflow 1.25; maxDegree {args.degree}, {len(levels)} levels of N/{args.degree}^l nodes), "
+                                    (f"FusedADC graph search: " + (f"layered Vamana graph built by the engine's batched builder (jv_hip_builder_*: PQ scoring, beamWidth {args.build_beam}, alpha {args.build_alpha}, neighborOverflow {args.build_overflow}; maxDegree {args.degree}, {len(levels)} levels of N/{args.degree}^l nodes), "
                                                                    if args.graph == "engine" else
                                                                    f"synthetic kNN+robust-prune graph (maxDegree {args.degree}, {len(levels)} nested levels), ") +
                                      f"{'device-resident GraphSearcher (one wavefront per query)' if args.traversal == 'device' else 'host batched GraphSearcher, GPU fused-block scoring'}, rerankK {rerank_k} -> exact rerank -> top-{K}"

@@ -1402,6 +1402,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.evict_cap = evict_cap;
     p.v1_log2 = v1_log2;
     p.v1_idbits = idbits;
+    p.prefetch = (ctx_opt(ctx, "gs_prefetch", 0) != 0 && evict_cap >= 48) ? 1 : 0;
     if (big_count > 0) {
         p.big_visited = (int32_t *)ctx->d_gs_big.ptr;
         p.big_spill = (long long *)((char *)ctx->d_gs_big.ptr + big_spill_off);

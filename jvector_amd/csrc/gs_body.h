@@ -13,6 +13,8 @@
 //     gs_fetch_add(uint32_t *p, uint32_t v) -> old                    (device-scope atomic)
 //     gs_fetch_add64(unsigned long long *p, unsigned long long v)     (device-scope atomic; profiling aid only)
 //     gs_lds_cas(uint32_t *p, uint32_t expect, uint32_t desired) -> old    (LDS atomic, workgroup scope)
+//     gs_prefetch_lds(const void *g, void *lds)  speculative touch: every active lane starts a 4-byte load of ITS address g whose
+//                                             result lands (whenever) at lds + 4 * lane and is never read — no register waits for it
 //     gs_fence()                              device-scope memory fence
 //     gs_sqrt(double)
 //     GS_SCHED_FENCE()                        instruction-scheduling fence (may be empty)
@@ -116,6 +118,29 @@ GS_FN long long gs_scan_extreme(const long long *a, int n, int *idx_out)
     const long long m = MAX ? gs_wave_max(best) : gs_wave_min(best);
     const uint64_t who = gs_ballot(bi >= 0 && best == m);
     *idx_out = (int)gs_shfl((long long)bi, gs_first(who));
+    return m;
+}
+
+// max key of a[0..n), its index, and the runner-up key (GS_KEY_MIN when n < 2); results uniform across the wave
+GS_FN long long gs_scan_top2(const long long *a, int n, int *idx_out, long long *second_out)
+{
+    const int lane = gs_lane();
+    long long best = GS_KEY_MIN, second = GS_KEY_MIN;
+    int bi = -1;
+    for (int i = lane; i < n; i += 64) {
+        const long long k = a[i];
+        if (k > best) {
+            second = best;
+            best = k;
+            bi = i;
+        } else if (k > second) {
+            second = k;
+        }
+    }
+    const long long m = gs_wave_max(best);
+    const int w = gs_first(gs_ballot(bi >= 0 && best == m));  // keys are unique: exactly one lane holds the maximum
+    *idx_out = (int)gs_shfl((long long)bi, w);
+    *second_out = gs_wave_max(lane == w ? second : best);
     return m;
 }
 
@@ -565,10 +590,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             if (s.cand_n == 0 && s.spill_n == 0) break;
             if (PROF) pt = GS_CLOCK();
             int idx;
-            long long top;
+            long long top, runner_up = GS_KEY_MIN;
             const bool from_lds = s.cand_n > 0;
             if (from_lds) {
-                top = gs_scan_extreme<true>(s.cand, s.cand_n, &idx);
+                if (p.prefetch && lvl == 0) top = gs_scan_top2(s.cand, s.cand_n, &idx, &runner_up);
+                else top = gs_scan_extreme<true>(s.cand, s.cand_n, &idx);
             } else {  // the LDS tier ran dry: the best candidate is somewhere in the spill tier
                 gs_fence();
                 top = gs_scan_extreme<true>(s.spill, s.spill_n, &idx);
@@ -584,6 +610,22 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 s.spill_n--;
                 s.spill_max = top;  // still an upper bound of what is left
                 gs_fence();
+            }
+            // Speculative touch of the NEXT expansion's data: unless one of the neighbours scored below beats it, the runner-up
+            // is popped next, and its adjacency row + FusedPQ block (3.2 KB of HBM, the head of that expansion's dependent chain)
+            // can be on their way into L2 while this expansion is scored.  Lanes 0..n-1 each touch one 128-byte line; the loaded
+            // words land in the evicted list's (unused at layer 0) LDS bytes and are never read.  Results cannot change.
+            if (p.prefetch && lvl == 0 && runner_up != GS_KEY_MIN &&
+                !(s.res_n >= rk && gs_key_score(runner_up) < gs_key_score(s.res_min))) {
+                const int32_t rn = gs_key_node(runner_up);
+                const char *row_b = reinterpret_cast<const char *>(L.nbrs + (int64_t)rn * L.degree);
+                const int row_lines = (L.degree * 4 + 127) / 128;
+                const int blk_lines = p.blocks ? (p.deg0 * p.M + 127) / 128 : 0;
+                const char *addr = nullptr;
+                if (lane < row_lines) addr = row_b + lane * 128;
+                else if (lane < row_lines + blk_lines) addr = reinterpret_cast<const char *>(p.blocks + (int64_t)rn * p.deg0 * p.M) + (lane - row_lines) * 128;
+                else if (VSF == 2 && p.blocks && lane == row_lines + blk_lines) addr = reinterpret_cast<const char *>(p.fused_norms + (int64_t)rn * p.deg0);
+                if (addr) gs_prefetch_lds(addr, reinterpret_cast<char *>(s.evicted) + 64);
             }
             GS_PHASE(0);
             // threshold 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the results (the

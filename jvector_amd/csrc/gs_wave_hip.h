@@ -24,6 +24,14 @@ __device__ __forceinline__ uint32_t gs_lds_cas(uint32_t *p, uint32_t expect, uin
     __hip_atomic_compare_exchange_strong(lp, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return expect;
 }
+// LDS-DMA load (global_load_lds_dword): 4 bytes per active lane from its own global address straight into LDS at
+// lds + 4 * lane — no destination register, so nothing in the wave ever waits for it explicitly
+__device__ __forceinline__ void gs_prefetch_lds(const void *g, void *lds)
+{
+    typedef __attribute__((address_space(1))) const void gptr;
+    typedef __attribute__((address_space(3))) void lptr;
+    __builtin_amdgcn_global_load_lds((gptr *)g, (lptr *)lds, 4, 0, 0);
+}
 __device__ __forceinline__ uint32_t gs_fetch_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void gs_fetch_add64(unsigned long long *p, unsigned long long v) { (void)atomicAdd(p, v); }
 #define GS_CLOCK() ((unsigned long long)__builtin_readcyclecounter())

@@ -23,6 +23,12 @@ static inline uint32_t gs_lds_cas(uint32_t *p, uint32_t expect, uint32_t desired
     if (old == expect) *p = desired;
     return old;
 }
+static inline void gs_prefetch_lds(const void *g, void *lds)
+{
+    // the emulated lane really performs the touch: an address outside the arrays it names would fault here, and the landing
+    // bytes are scribbled so that any read of them shows up as a wrong result
+    ((volatile uint32_t *)lds)[emu::lane() & 63] = *(const volatile uint32_t *)g ^ 0xA5A5A5A5u;
+}
 static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
 {
     const uint32_t old = *p;
@@ -109,6 +115,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     for (int l = 0; l < n_levels; ++l) pair = pair && lv_degree[l] <= 32;
     p.pair = pair ? 1 : 0;
     p.v1_log2 = v1_log2; p.v1_idbits = v1_idbits; p.evict_cap = evict_cap;
+    p.prefetch = getenv("GS_EMU_PREFETCH") ? atoi(getenv("GS_EMU_PREFETCH")) : 1;  // on by default in the emulator: more code under test
     const int ecap = evict_cap > 0 ? evict_cap : jv::GS_EVICT_CAP;
     p.visited = visited; p.vcap_log2 = vcap_log2; p.spill = spill; p.spill_cap = spill_cap; p.cand_cap = cand_cap;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_stats = out_stats; p.out_status = out_status;

@@ -31,6 +31,12 @@ static inline uint32_t gs_lds_cas(uint32_t *p, uint32_t expect, uint32_t desired
     if (old == expect) *p = desired;
     return old;
 }
+static inline void gs_prefetch_lds(const void *g, void *lds)
+{
+    // the emulated lane really performs the touch: an address outside the arrays it names would fault here, and the landing
+    // bytes are scribbled so that any read of them shows up as a wrong result
+    ((volatile uint32_t *)lds)[emu::lane() & 63] = *(const volatile uint32_t *)g ^ 0xA5A5A5A5u;
+}
 static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
 {
     const uint32_t old = *p;
