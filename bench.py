@@ -180,7 +180,7 @@ def cpu_baseline_graph(cb, D, M, codes_h, levels, entry, entry_level, base_dev, 
                           bool(np.array_equal(ids, gpu_ids[:nq])))
 
 
-def cpu_baseline_build(cb, D, M, codes_h, nbrs_h, entry, base_dev, vsf, max_degree, beam, alpha, per_thread=24):
+def cpu_baseline_build(cb, D, M, codes_h, nbrs_h, entry, base_dev, vsf, max_degree, beam, alpha, per_thread=4096):
     """CPU oracle on a bounded sample of the BUILD workload: what one insert costs the reference's per-node path — a sequential
     GraphSearcher over the (finished) graph for the node's vector, topK = rerankK = beamWidth, PQ scores — and
     VamanaDiversityProvider.retainDiverse of its candidates with the PQ diversity function (oracle restatements, the parity
@@ -232,15 +232,16 @@ def cpu_baseline_build(cb, D, M, codes_h, nbrs_h, entry, base_dev, vsf, max_degr
 # helpers
 # ------------------------------------------------------------------------------------------------------------------
 def measured_traffic(kernel_key, cfg):
-    """HBM bytes per launch from the rocprofv3 PMC summary (profiles/traffic_r2.json) — only if it was collected on THIS
+    """HBM bytes per launch from the rocprofv3 PMC summary (profiles/traffic_r3.json, else traffic_r2.json) — only if it was collected on THIS
     configuration (same kernel, N, D, M, queries per step, rerankK); else None."""
-    try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "traffic_r2.json")))
-    except Exception:
-        return None
-    for e in table.get("entries", []):
-        if e.get("kernel_key") == kernel_key and all(e.get("config", {}).get(k) == v for k, v in cfg.items()):
-            return e.get("hbm_bytes_per_launch")
+    for name in ("traffic_r3.json", "traffic_r2.json"):   # the newest summary whose configuration matches
+        try:
+            table = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        for e in table.get("entries", []):
+            if e.get("kernel_key") == kernel_key and all(e.get("config", {}).get(k) == v for k, v in cfg.items()):
+                return e.get("hbm_bytes_per_launch")
     return None
 
 
@@ -567,7 +568,8 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
     ctx.sync()
     encode_s = time.perf_counter() - t0
     ctx.profile(True)
-    nbrs, entry, bstats = build_vamana(ctx, pq, cv, base, VSF, max_degree=args.degree, beam_width=args.build_beam, alpha=1.2, log=log, vector_set=vs)
+    nbrs, entry, bstats = build_vamana(ctx, pq, cv, base, VSF, max_degree=args.degree, beam_width=args.build_beam, alpha=args.build_alpha, log=log,
+                                       vector_set=vs, overflow=args.build_overflow, max_batch=args.build_max_batch)
     prof = {r: ctx.profile_read(r) for r in ("gsearch", "adc")}
     ctx.profile(False)
     barrier()
@@ -604,8 +606,8 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
             "ms_per_step": total_s * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE C5: synthetic {N}x{D} cosine mixture, PQ-{M} trained + encoded by the engine, batched Vamana "
-                                   f"construction behind jv_hip_builder_* (maxDegree {args.degree}, beamWidth {args.build_beam}, alpha 1.2, neighborOverflow "
-                                   "1.25, prefix-doubling batches): candidates from the engine's device-resident graph search over the partial "
+                                   f"construction behind jv_hip_builder_* (maxDegree {args.degree}, beamWidth {args.build_beam}, alpha {args.build_alpha}, neighborOverflow "
+                                   f"{args.build_overflow}, prefix-doubling batches): candidates from the engine's device-resident graph search over the partial "
                                    "graph, robust prune = the retain_diverse kernel, backlinks + re-prune with PQ diversity scores", "n_vectors": N,
                        "dim": D, "pq_subspaces": M, "max_degree": args.degree, "parallelism": "1 GPU" if world == 1 else f"{world} independent builds"},
             "seconds": {"pq_train": train_s, "encode": encode_s, "search": bstats["search_s"], "prune": bstats["prune_s"],
@@ -648,8 +650,9 @@ def main():
     ap.add_argument("--build-beam", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_BEAM", "100")),
                     help="engine graph: construction beam width (the reference's efConstruction / beamWidth, default 100)")
     ap.add_argument("--build-alpha", type=float, default=float(os.environ.get("JVECTOR_BENCH_BUILD_ALPHA", "1.2")), help="engine graph: robust-prune alpha")
-    ap.add_argument("--build-overflow", type=float, default=float(os.environ.get("JVECTOR_BENCH_BUILD_OVERFLOW", "1.25")),
-                    help="engine graph: neighborOverflow (working row width = maxDegree x overflow, <= 64)")
+    ap.add_argument("--build-overflow", type=float, default=float(os.environ.get("JVECTOR_BENCH_BUILD_OVERFLOW", "2.0")),
+                    help="engine graph: neighborOverflow (working row width = maxDegree x overflow, <= 64).  Measured at 10M (profiles/r3_c): "
+                         "2.0 builds faster (15.6M re-pruned lists instead of 36.6M) AND yields a graph that needs rerankK 95 instead of 105")
     ap.add_argument("--build-max-batch", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_MAX_BATCH", "131072")),
                     help="engine graph: largest insert batch (inserts of one batch do not see each other)")
     ap.add_argument("--torch-codebooks", action="store_true", help="codebooks from benchlib's torch Lloyd instead of the engine's "
