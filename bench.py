@@ -939,6 +939,16 @@ def main():
             "graph": args.graph, "graph_build": build_info,
         }
         line.update(extra_roof)
+        # QPS@recall is a strong function of the data's intrinsic dimension: the same run at other latent dimensions, measured
+        # separately on the same code (scripts/gpu_sessions/r3_run_d.sh -> profiles/sensitivity_r3.json), is attached for context
+        try:
+            sens = json.load(open(os.path.join(ROOT, "profiles", "sensitivity_r3.json")))
+            pts = [e for e in sens.get("entries", []) if e.get("n_vectors") == N and e.get("dim") == D and e.get("pq_subspaces") == M
+                   and e.get("latent") != args.latent]
+            if pts and graph_mode:
+                line["sensitivity"] = {"note": sens.get("note"), "points": pts}
+        except Exception:
+            pass
         if graph_mode:
             st = graph_stats
             line["avg_visited"] = float(st[:, 0].mean())

@@ -1253,16 +1253,20 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // 2 waves/SIMD + pair lanes 19.0 ms per 16384-query batch; 4 waves/SIMD 25.1 ms; a 3 waves/SIMD build (168 VGPRs, 12 waves
     // per CU) 28.3 ms — fewer gathers in flight per wave cost more than the extra waves hide (profiles/r2_sweeps.md).
     const int occ = ctx_opt(ctx, "gs_occ", 2) >= 4 ? 4 : 2;
+    // gs_lutr = 1: the query's ADC table lives in the wave's registers (64 subspaces, cross-lane reads) + LDS (the rest) instead
+    // of being recomputed from the L2-resident codebook per scored neighbour; one wave per SIMD (4 workers per CU), one lane per
+    // neighbour (k_gsearch.hip graph_search_lutr_kernel).  M <= 96 only.
+    const bool lutr = ctx_opt(ctx, "gs_lutr", 0) != 0 && graph_search_lutr_supported(pq->M);
     // pair-lane scoring (two lanes per neighbour) when no level has more than 32 neighbours; it needs an M/2 x 32 float
     // exchange area in LDS.  gs_pair = 0 turns it off.
-    bool pair = occ == 2 && ctx_opt(ctx, "gs_pair", 1) != 0;
+    bool pair = occ == 2 && !lutr && ctx_opt(ctx, "gs_pair", 1) != 0;
     for (int lv = 0; lv <= g->entry_level; ++lv) pair = pair && g->levels[lv].degree <= 32;
     // M >= 128: the pair form's two half rows + exchange indices no longer fit 256 VGPRs (156 / 588 bytes of scratch per
     // lane at M = 128 / 192, -Rpass-analysis=kernel-resource-usage) while the one-lane-per-neighbour form still does
     pair = pair && pq->M <= 96;
     const int pair_M = pair ? pq->M : 0;
     int evict_cap = GS_EVICT_CAP;
-    int cand_cap = std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", occ == 4 ? 512 : (pair ? 256 : 1024))) & ~63;
+    int cand_cap = std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", lutr ? 256 : (occ == 4 ? 512 : (pair ? 256 : 1024)))) & ~63;
     while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
     // Visited set, tier 1 (gs_body.h gs_visit1): a two-choice bucketed LDS table of 16-bit entries in whatever the other
     // per-worker structures leave of 160 KB / (4 x occ workers per CU).  Preference: the largest table first (4096 slots = 8 KB
@@ -1271,8 +1275,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // gs_v1_log2 = 0 turns the tier off, a positive value pins it.  Graphs too large for the entry format (more than 14
     // remainder bits) get none.
     const int idbits = gs_idbits(g->n_nodes);
-    const int want_per_cu = 4 * occ;
-    const size_t lds_budget = (160 * 1024) / (size_t)want_per_cu - 256;
+    const int want_per_cu = lutr ? 4 : 4 * occ;
+    const size_t lut_lds = lutr ? gs_lutr_lds_bytes(pq->M) : 0;
+    const size_t lds_budget = (160 * 1024) / (size_t)want_per_cu - 256 - lut_lds;
     int v1_log2 = 0;
     {
         // (a pinned gs_vcap_log2 is how tests drive the overflow paths of tier 2: no LDS tier in front of it then, unless asked for)
@@ -1298,13 +1303,13 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
             }
         }
     }
-    const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap, v1_log2);
+    const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap, v1_log2) + lut_lds;
     if (lds > ctx->lds_per_block) {
         set_error("graph_search(device): rerankK %d needs %zu bytes of LDS per wave (limit %zu); use the host traversal", rerankK,
                   lds, ctx->lds_per_block);
         return JV_ERR_UNSUPPORTED;
     }
-    int per_cu = (int)std::min<size_t>((size_t)4 * occ, std::max<size_t>(1, (160 * 1024) / (lds + 256)));
+    int per_cu = (int)std::min<size_t>((size_t)want_per_cu, std::max<size_t>(1, (160 * 1024) / (lds + 256)));
     per_cu = std::max(1, (int)ctx_opt(ctx, "gs_waves_per_cu", per_cu));
     const int workers = std::max(1, std::min(Q, ctx->num_cus * per_cu));
     // JVECTOR_HIP_GS_VCAP_LOG2 overrides the visited-table size (tests use a tiny table to drive the host fallback)
@@ -1403,6 +1408,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.v1_log2 = v1_log2;
     p.v1_idbits = idbits;
     p.prefetch = (ctx_opt(ctx, "gs_prefetch", 0) != 0 && evict_cap >= 48) ? 1 : 0;
+    p.lutr = lutr ? 1 : 0;
     if (big_count > 0) {
         p.big_visited = (int32_t *)ctx->d_gs_big.ptr;
         p.big_spill = (long long *)((char *)ctx->d_gs_big.ptr + big_spill_off);

@@ -8,6 +8,7 @@
 //     gs_barrier()                            block barrier (the block IS one wavefront)
 //     gs_ballot(bool) -> uint64_t             wave vote
 //     gs_shfl(long long v, int src)           read lane src's v
+//     gs_shfl32(int32_t v, int src)           the same for 32 bits (one ds_bpermute_b32)
 //     gs_shfl_xor(long long v, int laneMask)  butterfly exchange
 //     gs_cas(int32_t *p, int32_t expect, int32_t desired) -> old      (device-scope atomic)
 //     gs_fetch_add(uint32_t *p, uint32_t v) -> old                    (device-scope atomic)
@@ -194,6 +195,94 @@ GS_FN float gs_row_sum(const float *codebooks, const float *qs, const gs_u4 (&w)
                     ent += c1.w * q[7];
                 }
                 sum += ent;
+            }
+        }
+    }
+    return sum;
+}
+
+// ---- the query's ADC table held by the wave itself (M <= 96): M x 256 f32 = 96 KB at PQ-96 — too large for a wave's LDS
+//      share — split between the wave's VECTOR REGISTERS and LDS.  Subspaces m < GS_LUT_REG_SUB (64): entry (m, code) lives in
+//      lane code & 63, register 4 m + (code >> 6) — 256 registers per lane, half of the 512 a wave owns at one wave per SIMD — and
+//      a look-up is a cross-lane read (gs_shfl32 -> ds_bpermute_b32: the LDS crossbar, no storage, no bank conflicts): the four
+//      registers of subspace m are fetched from lane code & 63 and code >> 6 picks one.  Subspaces m >= 64 (32 of them at
+//      PQ-96): a plain [m - 64][256] f32 table in LDS (32 KB).  This replaces the table-free form's 2 x 16-byte gathers per
+//      (neighbour, subspace) from the L2-resident codebook — the traffic that saturates a CU's vector-memory path.
+//      The entries are computed ONCE per query by the very arithmetic of gs_row_sum (calculatePartialSums entry by entry) and
+//      summed in ascending m, so scores keep their bits.  Every lane must execute the cross-lane reads (a lane's registers are
+//      only readable while it is active): callers do not branch around gs_row_sum_lut.
+constexpr int GS_LUT_REG_SUB = 64;
+
+template <int VSF>
+GS_FN float gs_lut_entry(const float *codebooks, const float *qs, int m, int code)
+{
+    const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(codebooks + ((int64_t)(m * 256) + code) * 8);
+    const gs_f4 c0 = cp[0], c1 = cp[1];
+    const float *q = qs + m * 8;
+    float ent = 0.0f;
+    if (VSF == 0 /* L2 */) {
+        float t;
+        t = c0.x - q[0]; ent += t * t;
+        t = c0.y - q[1]; ent += t * t;
+        t = c0.z - q[2]; ent += t * t;
+        t = c0.w - q[3]; ent += t * t;
+        t = c1.x - q[4]; ent += t * t;
+        t = c1.y - q[5]; ent += t * t;
+        t = c1.z - q[6]; ent += t * t;
+        t = c1.w - q[7]; ent += t * t;
+    } else {
+        ent += c0.x * q[0];
+        ent += c0.y * q[1];
+        ent += c0.z * q[2];
+        ent += c0.w * q[3];
+        ent += c1.x * q[4];
+        ent += c1.y * q[5];
+        ent += c1.z * q[6];
+        ent += c1.w * q[7];
+    }
+    return ent;
+}
+
+template <int VSF, int CH16>
+GS_FN void gs_lut_build(const float *codebooks, const float *qs, float (&lut)[(CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB) * 4],
+                        float *lut_lds)
+{
+    constexpr int M = CH16 * 16, MR = M < GS_LUT_REG_SUB ? M : GS_LUT_REG_SUB;
+    const int lane = gs_lane();
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lut[m * 4 + r] = gs_lut_entry<VSF>(codebooks, qs, m, r * 64 + lane);
+    }
+    for (int m = MR; m < M; ++m)   // the LDS part: coalesced stores, lane = code & 63
+        for (int r = 0; r < 4; ++r) lut_lds[(m - MR) * 256 + r * 64 + lane] = gs_lut_entry<VSF>(codebooks, qs, m, r * 64 + lane);
+}
+
+template <int CH16>
+GS_FN float gs_row_sum_lut(const float (&lut)[(CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB) * 4], const float *lut_lds,
+                           const gs_u4 (&w)[CH16])
+{
+    constexpr int M = CH16 * 16, MR = M < GS_LUT_REG_SUB ? M : GS_LUT_REG_SUB;
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH16; ++c) {
+        const uint32_t d[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int m = c * 16 + e * 4 + b;
+                const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
+                if (m < MR) {
+                    const int src = (int)(code & 63u);
+                    const int mr = m < MR ? m : 0;
+                    const int32_t v0 = gs_shfl32(gs_float_bits(lut[mr * 4 + 0]), src), v1 = gs_shfl32(gs_float_bits(lut[mr * 4 + 1]), src);
+                    const int32_t v2 = gs_shfl32(gs_float_bits(lut[mr * 4 + 2]), src), v3 = gs_shfl32(gs_float_bits(lut[mr * 4 + 3]), src);
+                    const uint32_t r = code >> 6;
+                    sum += gs_bits_float(r < 2u ? (r == 0u ? v0 : v1) : (r == 2u ? v2 : v3));
+                } else {
+                    sum += lut_lds[(m - MR) * 256 + (int)code];
+                }
             }
         }
     }
@@ -424,9 +513,14 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 // PAIR: every level's degree is <= 32 -> pair-lane scoring (decided by the host at launch)
 // PROF: developer aid — per-phase shader-clock totals of the expansion loop are added to p.prof[0..7]
 //       (pop, result insert, row + block + visited probes, scoring, push, expansions, queries, setup + epilogue)
-template <int VSF, int CH16, bool PAIR, bool PROF = false>
+// LUTR: the query's ADC table lives in registers (gs_lut_build / gs_row_sum_lut; one lane per neighbour, PAIR must be false)
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
+    static_assert(!(LUTR && PAIR), "the register-resident table serves the one-lane-per-neighbour form");
+    constexpr int LUT_MR = CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB;
+    float lut[LUTR ? LUT_MR * 4 : 1];
+    float *lut_lds = nullptr;  // LUTR: the table of subspaces >= GS_LUT_REG_SUB, at the very end of the worker's LDS block
     unsigned long long pf[5] = {0, 0, 0, 0, 0};
     unsigned long long fh[4] = {0, 0, 0, 0};  // PROF: scored neighbours in expansions with <= 8 / <= 16 / <= 24 / <= 32 fresh ones
     unsigned long long pt = 0, pq0 = 0;
@@ -557,6 +651,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     }
     gs_fence();
     gs_barrier();
+    if constexpr (LUTR) {
+        lut_lds = reinterpret_cast<float *>(lds + gs_lds_bytes(p.D, p.rerankK, p.cand_cap, 0, evict_cap, p.v1_log2));
+        gs_lut_build<VSF, CH16>(p.codebooks, qs, reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds);
+        gs_barrier();
+    }
     const float query_mag = (VSF == 2) ? p.bmag[q] : 0.0f;
     const unsigned long long *acc = p.accept ? p.accept + (long long)q * p.accept_stride : nullptr;
 
@@ -572,7 +671,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         }
         gs_u4 we[CH16];
         gs_load_row<CH16>(p.codes + (int64_t)e * p.M, we);
-        float sc = gs_row_sum<VSF, CH16>(p.codebooks, qs, we);
+        float sc;
+        if constexpr (LUTR) sc = gs_row_sum_lut<CH16>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, we);
+        else sc = gs_row_sum<VSF, CH16>(p.codebooks, qs, we);
         sc = gs_finish<VSF>(sc, (VSF == 2) ? p.code_norms[e] : 0.0f, query_mag);
         if (lane == 0) s.cand[0] = gs_key(e, sc);
         s.cand_n = 1;
@@ -718,6 +819,10 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 const int32_t nb = lane < deg ? row[lane] : -1;
                 // code bytes first, then the visited probes: the loads do not depend on the probes' outcome
                 gs_u4 w[CH16];
+                if constexpr (LUTR) {  // every lane takes part in the cross-lane reads below: no uninitialised code words
+#pragma unroll
+                    for (int c = 0; c < CH16; ++c) w[c] = gs_u4{0u, 0u, 0u, 0u};
+                }
                 float node_mag = 0.0f;
                 if (fused0 && lane < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
                     const int64_t r = (int64_t)node * p.deg0 + lane;
@@ -736,7 +841,12 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 if (fm == 0) continue;
                 n_visited += gs_popc(fm);
                 GS_PHASE(2);
-                if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CH16>(p.codebooks, qs, w), node_mag, query_mag));
+                if constexpr (LUTR) {
+                    const float raw = gs_row_sum_lut<CH16>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, w);  // all lanes
+                    if (fresh) key = gs_key(nb, gs_finish<VSF>(raw, node_mag, query_mag));
+                } else {
+                    if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CH16>(p.codebooks, qs, w), node_mag, query_mag));
+                }
             }
             if (PROF) {  // the scores must have arrived before the phase is closed
                 const uint64_t done_ = gs_ballot(fresh && key != 0);
@@ -794,7 +904,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 }
 
 // Persistent worker: pulls queries off the shared counter until none are left.
-template <int VSF, int CH16, bool PAIR, bool PROF = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false>
 GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
 {
     for (;;) {
@@ -802,7 +912,7 @@ GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
         if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
         const int item = (int)gs_shfl(qv, 0);
         if (item >= p.Q) break;
-        gs_search_one<VSF, CH16, PAIR, PROF>(p, p.qmap ? p.qmap[item] : item, worker, lds);
+        gs_search_one<VSF, CH16, PAIR, PROF, LUTR>(p, p.qmap ? p.qmap[item] : item, worker, lds);
     }
 }
 

@@ -53,6 +53,7 @@ struct GsParams {
     int32_t pair;             // 1: pair-lane scoring (every degree <= 32; LDS has the M/2 x 32 exchange area)
     // visited set, tier 1: an open-addressing table of 16-bit entries in LDS (gs_body.h "two-tier visited set"); the global
     // table above is tier 2 and is only touched (and only then cleared) by a query whose tier 1 fills up.
+    int32_t lutr;             // 1: the query's ADC table lives in the wave's registers (M <= 96; one wave per SIMD; no pair lanes)
     int32_t prefetch;         // 1: touch the runner-up candidate's adjacency row + fused block while the popped one is scored (layer 0)
     int32_t v1_log2;          // log2(slots) of the LDS tier (slots / 4 buckets of four 16-bit entries), 0 = no LDS tier
     int32_t v1_idbits;        // node ids are < 1 << v1_idbits; v1_idbits - (v1_log2 - 2) <= 14 remainder bits + the choice bit
@@ -71,7 +72,7 @@ struct GsParams {
 };
 
 // LDS bytes one worker needs
-inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M when pair-lane scoring is on, else 0 */,
+constexpr size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M when pair-lane scoring is on, else 0 */,
                            int evict_cap = GS_EVICT_CAP, int v1_log2 = 0)
 {
     // (the 64-key sample buffer of the partition step shares the pair-lane exchange area when there is one)
@@ -79,6 +80,9 @@ inline size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M whe
                         sizeof(float) * 32 * (size_t)(pair_M / 2);
     return v1_log2 > 0 ? ((base + 15) & ~(size_t)15) + ((size_t)2 << v1_log2) : base;
 }
+
+// LDS bytes of the register/LDS split ADC table (gs_body.h gs_lut_build): the subspaces past the 64 held in registers
+constexpr size_t gs_lutr_lds_bytes(int M) { return M > 64 ? (size_t)(M - 64) * 256 * sizeof(float) : 0; }
 
 // The LDS tier's 16-bit entry = choice bit + remainder: idbits - log2(buckets) <= 14 (0xFFFF stays free for "empty").
 inline bool gs_v1_fits(int v1_log2, int idbits) { return v1_log2 >= 4 && v1_log2 <= 15 && idbits - (v1_log2 - 2) <= 14 && idbits <= 31; }

@@ -15,6 +15,7 @@ __device__ __forceinline__ void gs_block_barrier() { __syncthreads(); }
 __device__ __forceinline__ uint64_t gs_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
 __device__ __forceinline__ long long gs_shfl(long long v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ long long gs_shfl_xor(long long v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ int32_t gs_shfl32(int32_t v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
 __device__ __forceinline__ int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired) { return atomicCAS(p, expect, desired); }
 // LDS atomic (ds_cmpst_rtn_b32): p points into the workgroup's LDS block
 __device__ __forceinline__ uint32_t gs_lds_cas(uint32_t *p, uint32_t expect, uint32_t desired)

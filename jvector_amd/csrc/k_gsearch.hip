@@ -36,6 +36,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     gs_worker<VSF, CH16, PAIR>(p, (int)blockIdx.x, gs_lds);
 }
 
+// The register-resident-table form (gs_body.h gs_lut_build / gs_row_sum_lut): ONE wave per SIMD owns all 512 vector registers,
+// 4 M of them hold the query's ADC table, look-ups are ds_bpermute reads.  4 workers per CU instead of 8, but an expansion no
+// longer issues ~190 divergent 16-byte gathers into the CU's vector-memory path.
+template <int VSF, int CH16, bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void graph_search_lutr_kernel(GsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char gs_lds[];
+    gs_worker<VSF, CH16, false, PROF, true>(p, (int)blockIdx.x, gs_lds);
+}
+
 // developer aid (JVECTOR_HIP_GS_PROF=1): the benched instance with per-phase shader-clock counters (GsParams::prof)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_prof_kernel(GsParams p)
 {
@@ -93,11 +103,60 @@ size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int 
     return gs_lds_bytes(D, rerankK, cand_cap, pair_M, evict_cap > 0 ? evict_cap : GS_EVICT_CAP, v1_log2);
 }
 
+// Built for the headline shape only (PQ-96 and PQ-32 x the three similarity functions; the phase-clock variant for cosine / 96):
+// every further (M, similarity) instance costs minutes of compile time for its fully unrolled table code.
+template <int VSF>
+static int launch_gs_lutr(hipStream_t s, const GsParams &p, int ch, int workers, size_t lds)
+{
+    dim3 grid(workers), block(64);
+#define JV_LUTR(CH, PROFV)                                                                                     \
+    do {                                                                                                        \
+        auto kfn = graph_search_lutr_kernel<VSF, CH, PROFV>;                                                    \
+        JV_HIP_CHECK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                        \
+    } while (0)
+    if (p.prof) {
+        if constexpr (VSF == VSF_COS) {
+            if (ch == 6) {
+                JV_LUTR(6, true);
+                JV_HIP_CHECK(hipGetLastError());
+                return JV_OK;
+            }
+        }
+        set_error("graph search kernel: the phase-clock variant of the register-resident table form is built for cosine, M = 96 only");
+        return JV_ERR_UNSUPPORTED;
+    }
+    switch (ch) {
+    case 2: JV_LUTR(2, false); break;
+    case 6: JV_LUTR(6, false); break;
+    default:
+        set_error("graph search kernel: the register-resident table form is built for M = 32 and M = 96 (M = %d)", ch * 16);
+        return JV_ERR_UNSUPPORTED;
+    }
+#undef JV_LUTR
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+bool graph_search_lutr_supported(int M) { return M == 32 || M == 96; }
+
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy)
 {
     if (p.Q == 0) return JV_OK;
-    const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2);
+    const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2) +
+                       (p.lutr ? gs_lutr_lds_bytes(p.M) : 0);
     const int ch = p.M / 16;
+    if (p.lutr) {
+        if (p.pair) {
+            set_error("graph search kernel: the register-resident table form has no pair-lane scoring");
+            return JV_ERR_INVALID;
+        }
+        switch (vsf) {
+        case VSF_L2: return launch_gs_lutr<VSF_L2>(s, p, ch, workers, lds);
+        case VSF_DOT: return launch_gs_lutr<VSF_DOT>(s, p, ch, workers, lds);
+        default: return launch_gs_lutr<VSF_COS>(s, p, ch, workers, lds);
+        }
+    }
     if (p.prof) {
         if (!(vsf == VSF_COS && ch == 6 && p.pair && occupancy < 4)) {
             set_error("graph search kernel: the profiling variant is built for cosine, M = 96, pair-lane scoring only");

@@ -11,6 +11,7 @@ static inline void gs_barrier() { emu::barrier(); }
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
+static inline int32_t gs_shfl32(int32_t v, int src) { return (int32_t)emu::shfl((long long)v, src); }
 static inline int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired)
 {
     const int32_t old = *p;
@@ -70,10 +71,26 @@ void run_vsf(const Launch &L)
     else if (L.vsf == 1) run_ch<1, PAIR>(L);
     else run_ch<2, PAIR>(L);
 }
+template <int VSF>
+void run_lutr(const Launch &L)
+{
+    switch (L.ch) {
+    case 1: jv::gs_worker<VSF, 1, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 2: jv::gs_worker<VSF, 2, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 3: jv::gs_worker<VSF, 3, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 4: jv::gs_worker<VSF, 4, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gs_worker<VSF, 6, false, false, true>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
 void lane_main(void *arg)
 {
     const Launch &L = *(const Launch *)arg;
-    if (L.p->pair) run_vsf<true>(L);
+    if (L.p->lutr) {
+        if (L.vsf == 0) run_lutr<0>(L);
+        else if (L.vsf == 1) run_lutr<1>(L);
+        else run_lutr<2>(L);
+    } else if (L.p->pair) run_vsf<true>(L);
     else run_vsf<false>(L);
 }
 }  // namespace
@@ -84,8 +101,9 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
                               const float *fused_norms, int D, int M, int deg0, int Q, int rerankK, int vsf, int vcap_log2,
                               int spill_cap, int cand_cap, int workers, int pair_mode /* 0 off, 1 when degrees allow */, int32_t *out_ids, float *out_scores, long long *out_stats,
                               int32_t *out_status, int v1_log2 /* LDS tier of the visited set: log2(slots), 0 = none */, int v1_idbits,
-                              int evict_cap /* 0 = GS_EVICT_CAP */)
+                              int evict_cap /* 0 = GS_EVICT_CAP */, int lutr /* 1: ADC table in registers + LDS (M <= 96) */)
 {
+    if (lutr && M > 96) return -4;
     if (n_levels < 1 || n_levels > jv::GS_MAX_LEVELS || M % 16 != 0 || D != 8 * M || cand_cap < 128) return -1;
     if (v1_log2 > 0 && !jv::gs_v1_fits(v1_log2, v1_idbits)) return -2;
     jv::GsParams p{};
@@ -111,8 +129,9 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     int32_t *visited = (int32_t *)aligned_alloc(64, sizeof(int32_t) * vcap * workers);
     long long *spill = (long long *)aligned_alloc(64, sizeof(long long) * (size_t)(spill_cap > 0 ? spill_cap : 1) * workers + 64);
     memset(visited, 0x5a, sizeof(int32_t) * vcap * workers);  // garbage: the kernel must clear it itself
-    bool pair = pair_mode != 0;  // same rule as graph_search.cpp
+    bool pair = pair_mode != 0 && !lutr;  // same rule as graph_search.cpp
     for (int l = 0; l < n_levels; ++l) pair = pair && lv_degree[l] <= 32;
+    p.lutr = lutr ? 1 : 0;
     p.pair = pair ? 1 : 0;
     p.v1_log2 = v1_log2; p.v1_idbits = v1_idbits; p.evict_cap = evict_cap;
     p.prefetch = getenv("GS_EMU_PREFETCH") ? atoi(getenv("GS_EMU_PREFETCH")) : 1;  // on by default in the emulator: more code under test
@@ -127,7 +146,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     for (int w = 0; w < workers; ++w) {
         jv::GsParams pw = p;
         pw.Q = (int)((long long)Q * (w + 1) / workers);
-        const size_t lds_bytes = jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0, ecap, v1_log2);
+        const size_t lds_bytes = jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0);
         char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
         memset(lds, 0xa5, lds_bytes);
         memset(lds + lds_bytes, 0x3c, 64);  // canary behind the block

@@ -19,6 +19,7 @@ static inline void gs_block_barrier() { emu::barrier(); }
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
+static inline int32_t gs_shfl32(int32_t v, int src) { return (int32_t)emu::shfl((long long)v, src); }
 static inline int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired)
 {
     const int32_t old = *p;
@@ -582,6 +583,7 @@ int launch_bl_sort_edges(hipStream_t, void *temp, size_t *temp_bytes, const unsi
 }
 
 // ---- device-resident traversal: gs_body.h on the lane emulator ----
+bool graph_search_lutr_supported(int M) { return M == 32 || M == 96; }  // (the shapes k_gsearch.hip builds)
 bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels)
 {
     const int ch = pq->M / 16;  // the same predicate as k_gsearch.hip
@@ -600,6 +602,18 @@ struct GsLaunch {
     int vsf, worker;
     char *lds;
 };
+template <int VSF>
+void gs_run_lutr(const GsLaunch &L)
+{
+    switch (L.p->M / 16) {
+    case 1: gs_worker<VSF, 1, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 2: gs_worker<VSF, 2, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 3: gs_worker<VSF, 3, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 4: gs_worker<VSF, 4, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: gs_worker<VSF, 6, false, false, true>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
 template <int VSF, bool PAIR>
 void gs_run_ch(const GsLaunch &L)
 {
@@ -624,14 +638,19 @@ void gs_run_vsf(const GsLaunch &L)
 void gs_main(void *a)
 {
     const GsLaunch &L = *(const GsLaunch *)a;
-    if (L.p->pair) gs_run_vsf<true>(L);
+    if (L.p->lutr) {
+        if (L.vsf == VSF_L2) gs_run_lutr<VSF_L2>(L);
+        else if (L.vsf == VSF_DOT) gs_run_lutr<VSF_DOT>(L);
+        else gs_run_lutr<VSF_COS>(L);
+    } else if (L.p->pair) gs_run_vsf<true>(L);
     else gs_run_vsf<false>(L);
 }
 }  // namespace
 int launch_graph_search(hipStream_t, int vsf, const GsParams &p, int workers, int /*occupancy*/)
 {
     if (p.Q == 0) return JV_OK;
-    const size_t lds_bytes = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2);
+    const size_t lds_bytes = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2) +
+                             (p.lutr ? gs_lutr_lds_bytes(p.M) : 0);
     // the waves of a persistent launch, one after another; wave w stops after its share so that several workers'
     // scratch slices are exercised (a real launch interleaves them)
     for (int w = 0; w < workers; ++w) {

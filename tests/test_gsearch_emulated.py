@@ -42,7 +42,7 @@ def seq_sum_f32(table, codes):
 
 
 def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vcap_log2=14, spill_cap=8192, cand_cap=256,
-            workers=2, pair=1, v1_log2=9, v1_idbits=None, evict_cap=0):
+            workers=2, pair=1, v1_log2=9, v1_idbits=None, evict_cap=0, lutr=0):
     """v1_log2: slots of the visited set's LDS tier (default 512: small enough that the toy searches fill it, freeze it and go
     on in tier 2, so both tiers and the hand-over are exercised by every test); 0 = no LDS tier"""
     N, M, D = codes.shape[0], opq.M, opq.D
@@ -79,7 +79,7 @@ def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vc
         v1_idbits = max(1, int(N - 1).bit_length())
     n = emu.gs_emu_search(L, nodes, nbrs, count, degree, entry, entry_level, fp(cb), fp(cq), fp(bmag), fp(codes),
                           fp(code_norms), fp(blocks), fp(fnorms), D, M, deg0, Q, rerank_k, int(vsf), vcap_log2, spill_cap,
-                          cand_cap, workers, pair, fp(out_ids), fp(out_sc), fp(stats), fp(status), v1_log2, v1_idbits, evict_cap)
+                          cand_cap, workers, pair, fp(out_ids), fp(out_sc), fp(stats), fp(status), v1_log2, v1_idbits, evict_cap, lutr)
     assert n >= 0, n
     return out_ids, out_sc, stats, status, n
 
@@ -126,6 +126,31 @@ def test_emulated_kernel_matches_oracle(emu, levels, fused, M):
             for pair in (1, 0):  # two lanes per neighbour (degrees <= 32) and one lane per neighbour
                 ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, pair=pair)
                 check(ids, sc, st, status, wi, ws, wst)
+
+
+@pytest.mark.parametrize("levels,fused,M,deg", [(1, False, 16, 16), (2, True, 32, 16), (2, False, 48, 40), (2, True, 64, 24), (2, True, 96, 32),
+                                                (3, False, 96, 16)])
+def test_register_resident_table_matches_oracle(emu, levels, fused, M, deg):
+    """LUTR: the query's ADC table split between the wave's registers (cross-lane reads) and LDS — every M it is built for,
+    degrees up to 64 (one lane per neighbour), all three similarity functions: bit-identical to the oracle like the table-free form"""
+    D = 8 * M
+    lv, entry, entry_level, opq, codes, q = problem(300 + levels + M, 2000, D, M, levels, deg=deg, nq=6)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
+        for rk in (40, 1):
+            wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
+            ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, lutr=1)
+            check(ids, sc, st, status, wi, ws, wst)
+
+
+def test_register_resident_table_under_lane_reordering(emu, monkeypatch):
+    lv, entry, entry_level, opq, codes, q = problem(41, 2000, 768, 96, 2, deg=24, nq=3)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, None, q, O.COSINE, 60, 60, fused=True)
+    for order in ("reverse", "random:5"):
+        monkeypatch.setenv("EMU_LANE_ORDER", order)
+        ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.COSINE, 60, True, lutr=1, v1_log2=10)
+        check(ids, sc, st, status, wi, ws, wst)
 
 
 @pytest.mark.parametrize("order", ["reverse", "random:7", "random:8"])

@@ -264,3 +264,21 @@ def test_auto_traversal_reports_the_host_fallback(ctx, capfd):
     assert np.array_equal(ids, wi) and np.array_equal(sc, ws) and np.array_equal(st, wst) and np.array_equal(ids2, wi)
     assert ctx.stat("gs_calls_host_auto") == 2 and ctx.stat("gs_calls_device") == 0
     assert err.count("JV_TRAVERSAL_AUTO takes the HOST searcher") == 1
+
+
+@pytest.mark.parametrize("levels,use_fused,D,M,deg", [(2, True, 768, 96, 32), (2, False, 256, 32, 16), (3, True, 256, 32, 24), (1, False, 768, 96, 40)])
+def test_register_resident_table_kernel(ctx, levels, use_fused, D, M, deg):
+    """gs_lutr = 1: the traversal kernel whose ADC table lives in the wave's registers + LDS (graph_search_lutr_kernel) — ids,
+    scores and counters equal the oracle's (and therefore the table-free kernel's) for every similarity function"""
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 7 * levels + M, 4000, D, M, levels, use_fused, deg=deg)
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+    try:
+        ctx.set_option("gs_lutr", 1)
+        for vsf in VSF:
+            for top_k, rk in ((10, 80), (1, 1)):
+                ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True)
+                wi, ws, wst = og.search(opq, codes, v, q, int(vsf), top_k, rk, fused=use_fused)
+                assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rk)
+    finally:
+        ctx.set_option("gs_lutr", None)
