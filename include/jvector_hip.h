@@ -454,9 +454,14 @@ JV_API int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts 
  * stats (nullable) Q x 4 int64 = {visitedCount, expandedCount, expandedCountBaseLayer, rerankedCount};
  * worst_approx (nullable) Q floats = worstApproximateScoreInTopK (+inf when fewer than topK results or no reranker).
  * Exact-score ties at the K-th place resolve as in the reference (its result heap's array order).
- * These searches run on the host batched searcher (queues on the host, scoring on the GPU): the state they keep and rerankK
- * = "all nodes" do not fit the device traversal's LDS-resident queues.  graph / luts / codes / fused / vectors must outlive
- * the object; one object serves one batch at a time (a new search() discards the previous state).  accept_bits as in
+ * Where they run: search() runs on the DEVICE traversal wherever its session kernels apply (uniform 8-dim sub-vectors, M = 16 or
+ * 96, degree <= 64, the rerankK results fit LDS; graph traversal not pinned to the host): threshold admission, the
+ * TwoPhaseTracker stop and acceptOrds inside the kernel, then the host rebuilds approximateResults' heap array from the kernel's
+ * addTopCandidate log and runs the reference's rerank (floor, caching reranker, worst approximate score).  resume() needs the
+ * candidate queue / visited set of every searcher, which never left the device: it first replays the search on the host
+ * batched searcher (deterministic, same state) and continues there.  Every other shape runs both calls on the host searcher.
+ * Counters: gs_session_calls_device / gs_session_resume_replays / gs_session_calls_host_overflow / _unsupported.
+ * graph / luts / codes / fused / vectors must outlive the object; one object serves one batch at a time (a new search() discards the previous state).  accept_bits as in
  * jv_hip_graph_search_filtered (copied: resume uses the same filter).  Buffers may be host or device memory. */
 typedef struct jv_searcher jv_searcher;
 JV_API int jv_hip_searcher_create(jv_ctx *ctx, const jv_graph *g, jv_luts *luts, const jv_codes *codes, const jv_fused *fused,

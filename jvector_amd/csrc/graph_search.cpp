@@ -640,6 +640,11 @@ struct jv_searcher {
     int Q = 0;
     jv_vsf vsf = JV_DOT_PRODUCT;
     bool searched = false;
+    // the last search() ran on the device traversal: the per-query candidate queues / visited sets were never brought to the
+    // host, so a resume() first replays that search on the host searcher (deterministic: the same state the device left)
+    bool device_searched = false;
+    int last_topK = 0, last_rerankK = 0;
+    float last_threshold = 0.0f, last_floor = 0.0f;
 };
 
 // What the plain jv_hip_graph_search entry points leave at their defaults
@@ -659,6 +664,173 @@ static int copy_out(void *dst, const void *src_host, size_t bytes)
     if (bytes == 0) return JV_OK;
     if (is_device_ptr(dst)) JV_HIP_CHECK(hipMemcpy(dst, src_host, bytes, hipMemcpyHostToDevice));
     else memcpy(dst, src_host, bytes);
+    return JV_OK;
+}
+
+// ---- reranking (GraphSearcher.reranking :471-507 + NodeQueue.rerank :160-230) over every query's approximateResults heap ARRAY
+//      (`fin`): shared by the host traversal and by the device traversal of GraphSearcher objects (which rebuilds the array from
+//      the kernel's addTopCandidate log).  Fills the outputs and, with a session, its evictedResults / CachingReranker state.
+static int rerank_stage(jv_ctx *ctx, HostPool *pool, jv_luts *l, const jv_vectors *vectors, jv_vsf vsf, int kvsf, int Q, int topK,
+                        const HostSearchOpts &opt, jv_searcher *ses, std::vector<std::vector<int64_t>> &fin,
+                        const std::vector<int64_t> &q_visited, const std::vector<int64_t> &q_expanded,
+                        const std::vector<int64_t> &q_expanded_base, int32_t *out_ids, float *out_scores, int64_t *stats)
+{
+    // ---- reranking :471-507.  The exact scores come from the GPU (one gather over every position that needs one); the
+    //      selection itself is NodeQueue.rerank's loop (:160-230) over each query's heap ARRAY, on the host: an entry is kept
+    //      while the bounded queue has room or its exact score is STRICTLY better than the worst kept, so exact-score ties at
+    //      the K-th place resolve as in the reference. ----
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    int Rmax = 0;
+    for (int q = 0; q < Q; ++q) Rmax = std::max(Rmax, (int)fin[q].size());
+    std::vector<float> h_exact;
+    std::vector<int32_t> need;  // Q x Rmax: node whose exact score the GPU computes for this position, -1 = none
+    if (vectors && Rmax > 0) {
+        const size_t c1 = (size_t)Q * Rmax;
+        need.assign(c1, -1);
+        pool->parallel_for(Q, [&](int lo, int hi) {
+            for (int q = lo; q < hi; ++q) {
+                const std::vector<int64_t> &r = fin[q];
+                const QState *st = ses ? ses->states[(size_t)q].get() : nullptr;
+                int above = 0, best = -1;
+                float best_score = -INFINITY;
+                for (int i = 0; i < (int)r.size(); ++i) {
+                    const float sc = nq_score(r[i]);
+                    if (sc > best_score) { best_score = sc; best = i; }
+                    if (sc >= opt.rerank_floor) {
+                        ++above;
+                        const int32_t id = nq_node(r[i]);
+                        if (!st || !st->exact_cache.count(id)) need[(size_t)q * Rmax + i] = id;
+                    }
+                }
+                if (above == 0 && best >= 0) {  // nothing above the floor: the best one is reranked (:186-191)
+                    const int32_t id = nq_node(r[best]);
+                    if (!st || !st->exact_cache.count(id)) need[(size_t)q * Rmax + best] = id;
+                }
+            }
+        });
+        JV_TRY(ctx->h_in.reserve(sizeof(int32_t) * c1));
+        JV_TRY(ctx->d_in.reserve(sizeof(int32_t) * c1 + sizeof(float) * c1 + sizeof(float) * (size_t)Q + 256));
+        JV_TRY(ctx->h_out.reserve(sizeof(float) * c1));
+        memcpy(ctx->h_in.ptr, need.data(), sizeof(int32_t) * c1);
+        int32_t *d_cand = (int32_t *)ctx->d_in.ptr;
+        float *d_cand_sc = (float *)(d_cand + c1);
+        float *d_qnorm = d_cand_sc + c1;
+        JV_HIP_CHECK(hipMemcpyAsync(d_cand, ctx->h_in.ptr, sizeof(int32_t) * c1, hipMemcpyHostToDevice, ctx->stream));
+        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
+        {
+            ProfScope ps(ctx, R_EXACT);
+            JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf, d_cand, Rmax,
+                                       d_cand_sc, d_qnorm, vectors->d_sqnorm));
+        }
+        JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_cand_sc, sizeof(float) * c1, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        h_exact.assign((const float *)ctx->h_out.ptr, (const float *)ctx->h_out.ptr + c1);
+    }
+    std::vector<int32_t> r_ids((size_t)Q * topK, -1);
+    std::vector<float> r_sc((size_t)Q * topK, -INFINITY);
+    std::vector<int32_t> r_count((size_t)Q, 0);
+    std::vector<int64_t> r_reranked((size_t)Q, 0);
+    std::vector<float> r_worst((size_t)Q, INFINITY);
+    pool->parallel_for(Q, [&](int lo, int hi) {
+        JMinHeap rer;
+        std::vector<int32_t> ids;
+        std::vector<float> ex;
+        for (int q = lo; q < hi; ++q) {
+            std::vector<int64_t> &r = fin[q];
+            QState *st = ses ? ses->states[(size_t)q].get() : nullptr;
+            const int n = (int)r.size();
+            int32_t *oid = r_ids.data() + (size_t)q * topK;
+            float *osc = r_sc.data() + (size_t)q * topK;
+            JMinHeap *from = &rer;
+            JMinHeap approx;
+            rer.clear();
+            if (!vectors) {  // cachingReranker == null :478-487: the worst approximate results go to evictedResults
+                approx.a.swap(r);
+                while (approx.size() > topK) {
+                    const int64_t k = approx.pop();
+                    if (st) st->evicted.push_back(k);
+                }
+                from = &approx;
+            } else {
+                ids.assign((size_t)n, -1);
+                ex.assign((size_t)n, 0.0f);
+                int above = 0, best = -1;
+                float best_score = -INFINITY;
+                auto exact_of = [&](int i, int32_t id) {
+                    if (need[(size_t)q * Rmax + i] >= 0) {
+                        const float v = h_exact[(size_t)q * Rmax + i];
+                        r_reranked[q]++;
+                        if (st) st->exact_cache.emplace(id, v);
+                        return v;
+                    }
+                    return st->exact_cache.find(id)->second;  // only a session skips the GPU for a position
+                };
+                for (int i = 0; i < n; ++i) {
+                    const float sc = nq_score(r[i]);
+                    if (sc > best_score) { best_score = sc; best = i; }
+                    if (sc >= opt.rerank_floor) {
+                        ids[i] = nq_node(r[i]);
+                        ex[i] = exact_of(i, ids[i]);
+                        ++above;
+                    }
+                }
+                if (above == 0 && best >= 0) {
+                    ids[best] = nq_node(r[best]);
+                    ex[best] = exact_of(best, ids[best]);
+                }
+                auto approx_of = [&](int32_t node) {
+                    for (int j = 0; j < n; ++j)
+                        if (ids[j] == node) return nq_score(r[j]);
+                    return -INFINITY;
+                };
+                for (int i = 0; i < n; ++i) {
+                    if (ids[i] == -1) {
+                        if (st) st->evicted.push_back(r[i]);
+                        continue;
+                    }
+                    if (rer.size() < topK) {
+                        rer.push(nq_encode(ids[i], ex[i]));
+                    } else if (ex[i] > nq_score(rer.top())) {
+                        if (st) {
+                            const int32_t ev = nq_node(rer.top());
+                            st->evicted.push_back(nq_encode(ev, approx_of(ev)));
+                        }
+                        rer.update_top(nq_encode(ids[i], ex[i]));
+                    } else if (st) {
+                        st->evicted.push_back(r[i]);
+                    }
+                }
+                if (rer.size() >= topK)
+                    for (int64_t k : rer.a) r_worst[q] = std::min(r_worst[q], approx_of(nq_node(k)));
+            }
+            const int nres = from->size();
+            r_count[q] = nres;
+            for (int i = nres - 1; i >= 0; --i) {  // :497-502: the worst is popped first
+                const int64_t k = from->pop();
+                oid[i] = nq_node(k);
+                osc[i] = nq_score(k);
+            }
+            r.clear();
+        }
+    });
+    JV_TRY(copy_out(out_ids, r_ids.data(), sizeof(int32_t) * (size_t)Q * topK));
+    JV_TRY(copy_out(out_scores, r_sc.data(), sizeof(float) * (size_t)Q * topK));
+    if (stats) {
+        for (int q = 0; q < Q; ++q) {
+            stats[2 * q] = q_visited[q];
+            stats[2 * q + 1] = q_expanded[q];
+        }
+    }
+    if (opt.stats4) {
+        for (int q = 0; q < Q; ++q) {
+            opt.stats4[4 * q] = q_visited[q];
+            opt.stats4[4 * q + 1] = q_expanded[q];
+            opt.stats4[4 * q + 2] = q_expanded_base[q];
+            opt.stats4[4 * q + 3] = r_reranked[q];
+        }
+    }
+    if (opt.counts) memcpy(opt.counts, r_count.data(), sizeof(int32_t) * (size_t)Q);
+    if (opt.worst) memcpy(opt.worst, r_worst.data(), sizeof(float) * (size_t)Q);
     return JV_OK;
 }
 
@@ -1026,163 +1198,7 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
         fprintf(stderr, "[jv graph_search] Q=%d slots=%d groups=%d threads=%d rounds=%ld host %.2f ms, gpu-wait %.2f ms\n", Q,
                 S_total, NG, pool->size(), n_rounds, t_host, t_wait);
 
-    // ---- reranking :471-507.  The exact scores come from the GPU (one gather over every position that needs one); the
-    //      selection itself is NodeQueue.rerank's loop (:160-230) over each query's heap ARRAY, on the host: an entry is kept
-    //      while the bounded queue has room or its exact score is STRICTLY better than the worst kept, so exact-score ties at
-    //      the K-th place resolve as in the reference. ----
-    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    int Rmax = 0;
-    for (int q = 0; q < Q; ++q) Rmax = std::max(Rmax, (int)fin[q].size());
-    std::vector<float> h_exact;
-    std::vector<int32_t> need;  // Q x Rmax: node whose exact score the GPU computes for this position, -1 = none
-    if (vectors && Rmax > 0) {
-        const size_t c1 = (size_t)Q * Rmax;
-        need.assign(c1, -1);
-        pool->parallel_for(Q, [&](int lo, int hi) {
-            for (int q = lo; q < hi; ++q) {
-                const std::vector<int64_t> &r = fin[q];
-                const QState *st = ses ? ses->states[(size_t)q].get() : nullptr;
-                int above = 0, best = -1;
-                float best_score = -INFINITY;
-                for (int i = 0; i < (int)r.size(); ++i) {
-                    const float sc = nq_score(r[i]);
-                    if (sc > best_score) { best_score = sc; best = i; }
-                    if (sc >= opt.rerank_floor) {
-                        ++above;
-                        const int32_t id = nq_node(r[i]);
-                        if (!st || !st->exact_cache.count(id)) need[(size_t)q * Rmax + i] = id;
-                    }
-                }
-                if (above == 0 && best >= 0) {  // nothing above the floor: the best one is reranked (:186-191)
-                    const int32_t id = nq_node(r[best]);
-                    if (!st || !st->exact_cache.count(id)) need[(size_t)q * Rmax + best] = id;
-                }
-            }
-        });
-        JV_TRY(ctx->h_in.reserve(sizeof(int32_t) * c1));
-        JV_TRY(ctx->d_in.reserve(sizeof(int32_t) * c1 + sizeof(float) * c1 + sizeof(float) * (size_t)Q + 256));
-        JV_TRY(ctx->h_out.reserve(sizeof(float) * c1));
-        memcpy(ctx->h_in.ptr, need.data(), sizeof(int32_t) * c1);
-        int32_t *d_cand = (int32_t *)ctx->d_in.ptr;
-        float *d_cand_sc = (float *)(d_cand + c1);
-        float *d_qnorm = d_cand_sc + c1;
-        JV_HIP_CHECK(hipMemcpyAsync(d_cand, ctx->h_in.ptr, sizeof(int32_t) * c1, hipMemcpyHostToDevice, ctx->stream));
-        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
-        {
-            ProfScope ps(ctx, R_EXACT);
-            JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf, d_cand, Rmax,
-                                       d_cand_sc, d_qnorm, vectors->d_sqnorm));
-        }
-        JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_cand_sc, sizeof(float) * c1, hipMemcpyDeviceToHost, ctx->stream));
-        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        h_exact.assign((const float *)ctx->h_out.ptr, (const float *)ctx->h_out.ptr + c1);
-    }
-    std::vector<int32_t> r_ids((size_t)Q * topK, -1);
-    std::vector<float> r_sc((size_t)Q * topK, -INFINITY);
-    std::vector<int32_t> r_count((size_t)Q, 0);
-    std::vector<int64_t> r_reranked((size_t)Q, 0);
-    std::vector<float> r_worst((size_t)Q, INFINITY);
-    pool->parallel_for(Q, [&](int lo, int hi) {
-        JMinHeap rer;
-        std::vector<int32_t> ids;
-        std::vector<float> ex;
-        for (int q = lo; q < hi; ++q) {
-            std::vector<int64_t> &r = fin[q];
-            QState *st = ses ? ses->states[(size_t)q].get() : nullptr;
-            const int n = (int)r.size();
-            int32_t *oid = r_ids.data() + (size_t)q * topK;
-            float *osc = r_sc.data() + (size_t)q * topK;
-            JMinHeap *from = &rer;
-            JMinHeap approx;
-            rer.clear();
-            if (!vectors) {  // cachingReranker == null :478-487: the worst approximate results go to evictedResults
-                approx.a.swap(r);
-                while (approx.size() > topK) {
-                    const int64_t k = approx.pop();
-                    if (st) st->evicted.push_back(k);
-                }
-                from = &approx;
-            } else {
-                ids.assign((size_t)n, -1);
-                ex.assign((size_t)n, 0.0f);
-                int above = 0, best = -1;
-                float best_score = -INFINITY;
-                auto exact_of = [&](int i, int32_t id) {
-                    if (need[(size_t)q * Rmax + i] >= 0) {
-                        const float v = h_exact[(size_t)q * Rmax + i];
-                        r_reranked[q]++;
-                        if (st) st->exact_cache.emplace(id, v);
-                        return v;
-                    }
-                    return st->exact_cache.find(id)->second;  // only a session skips the GPU for a position
-                };
-                for (int i = 0; i < n; ++i) {
-                    const float sc = nq_score(r[i]);
-                    if (sc > best_score) { best_score = sc; best = i; }
-                    if (sc >= opt.rerank_floor) {
-                        ids[i] = nq_node(r[i]);
-                        ex[i] = exact_of(i, ids[i]);
-                        ++above;
-                    }
-                }
-                if (above == 0 && best >= 0) {
-                    ids[best] = nq_node(r[best]);
-                    ex[best] = exact_of(best, ids[best]);
-                }
-                auto approx_of = [&](int32_t node) {
-                    for (int j = 0; j < n; ++j)
-                        if (ids[j] == node) return nq_score(r[j]);
-                    return -INFINITY;
-                };
-                for (int i = 0; i < n; ++i) {
-                    if (ids[i] == -1) {
-                        if (st) st->evicted.push_back(r[i]);
-                        continue;
-                    }
-                    if (rer.size() < topK) {
-                        rer.push(nq_encode(ids[i], ex[i]));
-                    } else if (ex[i] > nq_score(rer.top())) {
-                        if (st) {
-                            const int32_t ev = nq_node(rer.top());
-                            st->evicted.push_back(nq_encode(ev, approx_of(ev)));
-                        }
-                        rer.update_top(nq_encode(ids[i], ex[i]));
-                    } else if (st) {
-                        st->evicted.push_back(r[i]);
-                    }
-                }
-                if (rer.size() >= topK)
-                    for (int64_t k : rer.a) r_worst[q] = std::min(r_worst[q], approx_of(nq_node(k)));
-            }
-            const int nres = from->size();
-            r_count[q] = nres;
-            for (int i = nres - 1; i >= 0; --i) {  // :497-502: the worst is popped first
-                const int64_t k = from->pop();
-                oid[i] = nq_node(k);
-                osc[i] = nq_score(k);
-            }
-            r.clear();
-        }
-    });
-    JV_TRY(copy_out(out_ids, r_ids.data(), sizeof(int32_t) * (size_t)Q * topK));
-    JV_TRY(copy_out(out_scores, r_sc.data(), sizeof(float) * (size_t)Q * topK));
-    if (stats) {
-        for (int q = 0; q < Q; ++q) {
-            stats[2 * q] = q_visited[q];
-            stats[2 * q + 1] = q_expanded[q];
-        }
-    }
-    if (opt.stats4) {
-        for (int q = 0; q < Q; ++q) {
-            opt.stats4[4 * q] = q_visited[q];
-            opt.stats4[4 * q + 1] = q_expanded[q];
-            opt.stats4[4 * q + 2] = q_expanded_base[q];
-            opt.stats4[4 * q + 3] = r_reranked[q];
-        }
-    }
-    if (opt.counts) memcpy(opt.counts, r_count.data(), sizeof(int32_t) * (size_t)Q);
-    if (opt.worst) memcpy(opt.worst, r_worst.data(), sizeof(float) * (size_t)Q);
-    return JV_OK;
+    return rerank_stage(ctx, pool, l, vectors, vsf, kvsf, Q, topK, opt, ses, fin, q_visited, q_expanded, q_expanded_base, out_ids, out_scores, stats);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1232,9 +1248,21 @@ static int ensure_device_graph(jv_ctx *ctx, jv_graph *g)
     return JV_OK;
 }
 
+// What a GraphSearcher-object search (jv_hip_searcher_search) takes from the device traversal instead of final results: the
+// per-query addTopCandidate log (from which the host rebuilds approximateResults' heap array and the layer-0 evictedResults),
+// the counters, and which queries could not be finished on the device.
+struct DeviceSessionOut {
+    float threshold = 0.0f;
+    int log_cap = 0;
+    std::vector<int32_t> status, base, log_n;
+    std::vector<int64_t> stats;      // Q x 2
+    std::vector<long long> log;      // Q x log_cap
+};
+
 static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
                                const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
-                               int32_t *out_ids, float *out_scores, int64_t *stats, AcceptMask host_accept, AcceptMask dev_accept)
+                               int32_t *out_ids, float *out_scores, int64_t *stats, AcceptMask host_accept, AcceptMask dev_accept,
+                               DeviceSessionOut *so = nullptr)
 {
     const jv_decoder_kind kind = fused ? JV_DECODER_FUSED : JV_DECODER_PQ;
     // centred queries, query magnitudes, raw copy for the rerank — NO look-up tables: the kernel scores table-free
@@ -1256,7 +1284,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // gs_lutr = 1: the query's ADC table lives in the wave's registers (64 subspaces, cross-lane reads) + LDS (the rest) instead
     // of being recomputed from the L2-resident codebook per scored neighbour; one wave per SIMD (4 workers per CU), one lane per
     // neighbour (k_gsearch.hip graph_search_lutr_kernel).  M <= 96 only.
-    const bool lutr = ctx_opt(ctx, "gs_lutr", 0) != 0 && graph_search_lutr_supported(pq->M);
+    const bool lutr = !so && ctx_opt(ctx, "gs_lutr", 0) != 0 && graph_search_lutr_supported(pq->M);
     // pair-lane scoring (two lanes per neighbour) when no level has more than 32 neighbours; it needs an M/2 x 32 float
     // exchange area in LDS.  gs_pair = 0 turns it off.
     bool pair = occ == 2 && !lutr && ctx_opt(ctx, "gs_pair", 1) != 0;
@@ -1276,7 +1304,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // remainder bits) get none.
     const int idbits = gs_idbits(g->n_nodes);
     const int want_per_cu = lutr ? 4 : 4 * occ;
-    const size_t lut_lds = lutr ? gs_lutr_lds_bytes(pq->M) : 0;
+    const size_t lut_lds = lutr ? gs_lutr_lds_bytes(pq->M) : (so ? gs_session_lds_bytes() : 0);  // (session kernels: the tracker's arrays)
     const size_t lds_budget = (160 * 1024) / (size_t)want_per_cu - 256 - lut_lds;
     int v1_log2 = 0;
     {
@@ -1346,21 +1374,23 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const size_t o_stats = carve(sizeof(long long) * 2 * (size_t)Q), o_status = carve(sizeof(int32_t) * (size_t)Q);
     const size_t o_counter = carve(sizeof(uint32_t) * 2);
     const size_t o_qmap = carve(sizeof(int32_t) * (size_t)Q);
-    const bool gs_prof = ctx_opt(ctx, "gs_prof", 0) != 0;
+    const bool gs_prof = !so && ctx_opt(ctx, "gs_prof", 0) != 0;
     const size_t o_prof = carve(sizeof(unsigned long long) * 12);
     // exact-score ties across the K-th place of the rerank are decided by the order of the reference's result-heap array
     // (NodeQueue.java:197-214): the traversal logs its addTopCandidate sequence (avg ~1 entry per expansion) and
     // rerank_tie_kernel rebuilds the reference's answer for the (rare) tied queries; an overflowed log sends the query to
     // the host searcher instead.  JVECTOR_HIP_GS_TIE_CHECK=0 turns the whole check off, JVECTOR_HIP_GS_PUSH_LOG=0 the log only.
-    const bool tie_check = vectors != nullptr && rerankK > topK && ctx_opt(ctx, "gs_tie_check", 1) != 0;
+    const bool tie_check = !so && vectors != nullptr && rerankK > topK && ctx_opt(ctx, "gs_tie_check", 1) != 0;
     int log_cap = 0;
-    if (tie_check && ctx_opt(ctx, "gs_push_log", 1) != 0) {
-        log_cap = std::max(256, 4 * rerankK);
+    if (so || (tie_check && ctx_opt(ctx, "gs_push_log", 1) != 0)) {
+        // (a session needs the whole addTopCandidate sequence: threshold searches accept far more candidates than they keep)
+        log_cap = so ? std::max(4096, 8 * rerankK) : std::max(256, 4 * rerankK);
         const size_t budget = (size_t)1 << 30;
         if ((size_t)Q * log_cap * sizeof(long long) > budget) log_cap = (int)std::max<size_t>(64, budget / ((size_t)Q * sizeof(long long)));
         if (ctx_opt_is_set(ctx, "gs_push_log_cap")) log_cap = std::max(1, (int)ctx_opt(ctx, "gs_push_log_cap", log_cap));
     }
     const size_t o_log = carve(sizeof(long long) * (size_t)Q * (size_t)log_cap), o_log_n = carve(sizeof(int32_t) * (size_t)Q);
+    const size_t o_base = carve(sizeof(int32_t) * (size_t)Q);
     JV_TRY(ctx->d_gs_out.reserve(off));
     char *base = (char *)ctx->d_gs_out.ptr;
     int32_t *d_cand = (int32_t *)(base + o_ids);
@@ -1409,6 +1439,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.v1_idbits = idbits;
     p.prefetch = (ctx_opt(ctx, "gs_prefetch", 0) != 0 && evict_cap >= 48) ? 1 : 0;
     p.lutr = lutr ? 1 : 0;
+    if (so) {
+        p.session = 1;
+        p.threshold = so->threshold;
+        p.out_base = (int32_t *)(base + o_base);
+    }
     if (big_count > 0) {
         p.big_visited = (int32_t *)ctx->d_gs_big.ptr;
         p.big_spill = (long long *)((char *)ctx->d_gs_big.ptr + big_spill_off);
@@ -1500,6 +1535,23 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
                 h[9] / fs, h[10] / fs, h[11] / fs);
     }
 
+    if (so) {  // GraphSearcher objects: the host finishes (searcher_search_device) from the log and the counters
+        so->log_cap = log_cap;
+        so->status.assign(status.begin(), status.end());
+        so->base.resize((size_t)Q);
+        so->log_n.resize((size_t)Q);
+        so->stats.resize(2 * (size_t)Q);
+        so->log.resize((size_t)Q * (size_t)log_cap);
+        JV_HIP_CHECK(hipMemcpyAsync(so->base.data(), base + o_base, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipMemcpyAsync(so->log_n.data(), base + o_log_n, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipMemcpyAsync(so->stats.data(), d_stats, sizeof(long long) * 2 * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipMemcpyAsync(so->log.data(), base + o_log, sizeof(long long) * (size_t)Q * (size_t)log_cap, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx_stat_add(ctx, "gs_calls_device", 1);
+        ctx_stat_add(ctx, "gs_queries_device", Q);
+        ctx_stat_add(ctx, "gs_session_calls_device", 1);
+        return JV_OK;
+    }
     // ---- reranking :471-507 on the device-resident candidates ----
     OutStage oi, osc;
     JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_scratch2, &oi));
@@ -1780,6 +1832,110 @@ int jv_hip_searcher_destroy(jv_searcher *s)
     return JV_OK;
 }
 
+// search() of Q GraphSearcher objects on the DEVICE traversal (session kernels, gs_body.h SES): threshold admission, the
+// TwoPhaseTracker stop and acceptOrds run inside the kernel; the host then rebuilds every query's approximateResults heap ARRAY
+// by replaying the kernel's addTopCandidate log through the reference's own push / updateTop sequence (:515-530) — which also
+// yields the layer-0 evictedResults — and runs the shared rerank stage (rerankFloor, CachingReranker, worstApproximateScoreInTopK).
+// *done = false: the shape is outside the session kernels' coverage, the traversal is pinned to the host, or some query
+// outgrew the device structures / its log — the caller runs the whole batch on the host searcher instead (same answers).
+static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, int rerankK, float threshold, float rerankFloor,
+                                  int32_t *out_ids, float *out_scores, int32_t *out_counts, int64_t *stats, float *worst, bool *done)
+{
+    *done = false;
+    const jv_graph *g = s->g;
+    jv_luts *l = s->luts;
+    const jv_pq *pq = l->pq;
+    if (Q == 0 || !pq) return JV_OK;
+    int mode = (int)ctx_opt(ctx, "graph_traversal", g->traversal);
+    if (mode == JV_TRAVERSAL_HOST) return JV_OK;
+    int Wd = 0;
+    for (int lv = 0; lv <= g->entry_level && lv < (int)g->levels.size(); ++lv) {
+        if (g->levels[lv].count <= 0) return JV_OK;
+        Wd = std::max(Wd, g->levels[lv].degree);
+    }
+    const bool fits = g->entry_node >= 0 && topK > 0 && rerankK >= topK && s->codes->pq == pq && s->codes->count >= g->n_nodes &&
+                      Q <= l->capacity && graph_search_device_supported(pq, s->codes, s->fused, Wd, g->entry_level + 1) &&
+                      graph_search_session_supported(pq->M) &&
+                      (!s->fused || (s->fused->pq == pq && s->fused->count == g->n_nodes && s->fused->maxDegree == g->levels[0].degree)) &&
+                      (!s->vectors || (s->vectors->D == pq->D && s->vectors->count >= g->n_nodes)) &&
+                      graph_search_lds_bytes(pq->D, rerankK, 256, 0) + gs_session_lds_bytes() <= std::min<size_t>(ctx->lds_per_block, 40 * 1024);
+    if (!fits) {
+        if (mode == JV_TRAVERSAL_DEVICE) ctx_stat_add(ctx, "gs_session_calls_host_unsupported", 1);
+        return JV_OK;
+    }
+    JV_TRY(use_device(ctx->device));
+    AcceptMask host_accept, dev_accept;
+    if (s->has_accept) {
+        host_accept.bits = s->accept.data();
+        host_accept.stride_words = s->accept_stride;
+        JV_TRY(ctx->d_gs_mask.reserve(sizeof(uint64_t) * s->accept.size()));
+        JV_HIP_CHECK(hipMemcpy(ctx->d_gs_mask.ptr, s->accept.data(), sizeof(uint64_t) * s->accept.size(), hipMemcpyHostToDevice));
+        dev_accept.bits = (const uint64_t *)ctx->d_gs_mask.ptr;
+        dev_accept.stride_words = s->accept_stride;
+    }
+    DeviceSessionOut so;
+    so.threshold = threshold;
+    JV_TRY(graph_search_device(ctx, g, l, s->codes, s->fused, s->vectors, s->queries.data(), Q, s->vsf, topK, rerankK, nullptr, nullptr, nullptr,
+                               host_accept, dev_accept, &so));
+    for (int q = 0; q < Q; ++q)
+        if (so.status[(size_t)q] != GS_OK || so.log_n[(size_t)q] < 0 || so.log_n[(size_t)q] > so.log_cap) {
+            ctx_stat_add(ctx, "gs_session_calls_host_overflow", 1);
+            return JV_OK;  // (rare: one query outgrew the device structures or its log) -> the whole batch on the host
+        }
+    // approximateResults + layer-0 evictedResults of every query from its addTopCandidate sequence
+    std::vector<std::vector<int64_t>> fin((size_t)Q);
+    std::vector<int64_t> q_visited((size_t)Q), q_expanded((size_t)Q), q_expanded_base((size_t)Q);
+    HostPool *pool = get_pool(ctx);
+    pool->begin();
+    pool->parallel_for(Q, [&](int lo, int hi) {
+        JMinHeap res;
+        for (int q = lo; q < hi; ++q) {
+            QState &st = *s->states[(size_t)q];
+            st.cand.clear();
+            st.res.clear();
+            st.evicted.clear();
+            st.exact_cache.clear();
+            st.searched = true;
+            res.clear();
+            const long long *log = so.log.data() + (size_t)q * (size_t)so.log_cap;
+            for (int i = 0; i < so.log_n[(size_t)q]; ++i) {
+                const int64_t top = (int64_t)log[i];
+                if (res.size() < rerankK) {
+                    res.push(top);
+                } else if (nq_score(top) > nq_score(res.top())) {
+                    st.evicted.push_back(res.top());
+                    res.update_top(top);
+                }
+            }
+            fin[(size_t)q] = res.a;
+            st.n_visited = q_visited[(size_t)q] = so.stats[2 * (size_t)q];
+            st.n_expanded = q_expanded[(size_t)q] = so.stats[2 * (size_t)q + 1];
+            st.n_expanded_base = q_expanded_base[(size_t)q] = so.base[(size_t)q];
+        }
+    });
+    pool->end();
+    HostSearchOpts opt;
+    opt.threshold = threshold;
+    opt.rerank_floor = rerankFloor;
+    opt.session = s;
+    std::vector<int32_t> counts((size_t)Q);
+    std::vector<int64_t> st4((size_t)Q * 4);
+    std::vector<float> w((size_t)Q);
+    opt.counts = counts.data();
+    opt.stats4 = st4.data();
+    opt.worst = w.data();
+    pool->begin();
+    const int rc = rerank_stage(ctx, pool, l, s->vectors, s->vsf, to_kernel_vsf(s->vsf), Q, topK, opt, s, fin, q_visited, q_expanded, q_expanded_base,
+                                out_ids, out_scores, nullptr);
+    pool->end();
+    JV_TRY(rc);
+    if (out_counts) JV_TRY(copy_out(out_counts, counts.data(), sizeof(int32_t) * (size_t)Q));
+    if (stats) JV_TRY(copy_out(stats, st4.data(), sizeof(int64_t) * 4 * (size_t)Q));
+    if (worst) JV_TRY(copy_out(worst, w.data(), sizeof(float) * (size_t)Q));
+    *done = true;
+    return JV_OK;
+}
+
 static int searcher_run(jv_ctx *ctx, jv_searcher *s, int Q, int topK, int rerankK, float threshold, float rerankFloor, bool resume,
                         int32_t *out_ids, float *out_scores, int32_t *out_counts, int64_t *stats, float *worst)
 {
@@ -1788,6 +1944,35 @@ static int searcher_run(jv_ctx *ctx, jv_searcher *s, int Q, int topK, int rerank
         g->levels[0].nbrs.size() == (size_t)g->n_nodes * s->fused->maxDegree) {
         JV_TRY(use_device(ctx->device));
         JV_TRY(check_fused_matches_graph(ctx, const_cast<jv_graph *>(g), s->fused));
+    }
+    if (!resume) {
+        s->device_searched = false;
+        s->last_topK = topK;
+        s->last_rerankK = rerankK;
+        s->last_threshold = threshold;
+        s->last_floor = rerankFloor;
+        bool done = false;
+        JV_TRY(searcher_search_device(ctx, s, Q, topK, rerankK, threshold, rerankFloor, out_ids, out_scores, out_counts, stats, worst, &done));
+        if (done) {
+            s->device_searched = true;
+            return JV_OK;
+        }
+    } else if (s->device_searched) {
+        // resume() after a device search: rebuild the per-query state by replaying that search on the host searcher
+        HostSearchOpts ro;
+        ro.threshold = s->last_threshold;
+        ro.rerank_floor = s->last_floor;
+        ro.session = s;
+        if (s->has_accept) {
+            ro.accept.bits = s->accept.data();
+            ro.accept.stride_words = s->accept_stride;
+        }
+        std::vector<int32_t> ids((size_t)Q * s->last_topK);
+        std::vector<float> sc((size_t)Q * s->last_topK);
+        JV_TRY(graph_search_host(ctx, g, s->luts, s->codes, s->fused, s->vectors, s->queries.data(), Q, s->vsf, s->last_topK, s->last_rerankK,
+                                 ids.data(), sc.data(), nullptr, ro));
+        s->device_searched = false;
+        ctx_stat_add(ctx, "gs_session_resume_replays", 1);
     }
     HostSearchOpts opt;
     opt.threshold = threshold;

@@ -514,7 +514,11 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 // PROF: developer aid — per-phase shader-clock totals of the expansion loop are added to p.prof[0..7]
 //       (pop, result insert, row + block + visited probes, scoring, push, expansions, queries, setup + epilogue)
 // LUTR: the query's ADC table lives in registers (gs_lut_build / gs_row_sum_lut; one lane per neighbour, PAIR must be false)
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false>
+// SES:  GraphSearcher OBJECTS (jv_hip_searcher_*): layer 0 admits `score >= p.threshold` (:437) and, for threshold > 0, stops
+//       through ScoreTracker.TwoPhaseTracker (ScoreTracker.java:80-140: a 500-score window + the 100 best scores, both in LDS);
+//       expandedCountBaseLayer is reported.  What reranking / resume need beyond that is rebuilt by the host from the
+//       addTopCandidate log (graph_search.cpp searcher_search_device).
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
     static_assert(!(LUTR && PAIR), "the register-resident table serves the one-lane-per-neighbour form");
@@ -680,9 +684,101 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         gs_barrier();
     }
 
+    // ---- SES: ScoreTracker.TwoPhaseTracker (ScoreTracker.java:80-140), wave-uniform state + two LDS arrays behind the worker's block
+    constexpr int TRK_RECENT = 500, TRK_BEST = 100;
+    float *trk_recent = nullptr;
+    int32_t *trk_best = nullptr;
+    int trk_obs = 0, trk_ridx = 0, trk_nbest = 0, trk_min_idx = -1;
+    int32_t trk_min = 0x7fffffff;
+    bool thr_on = false;
+    long long n_expanded_base = 0;
+    if constexpr (SES) {
+        trk_recent = reinterpret_cast<float *>(lds + gs_lds_bytes(p.D, p.rerankK, p.cand_cap, PAIR ? p.M : 0, evict_cap, p.v1_log2));
+        trk_best = reinterpret_cast<int32_t *>(trk_recent + TRK_RECENT);
+    }
+    auto trk_sortable = [](float f) -> int32_t {   // NumericUtils.floatToSortableInt
+        const int32_t b = (f != f) ? 0x7fc00000 : gs_float_bits(f);
+        return b ^ ((b >> 31) & 0x7fffffff);
+    };
+    // track(score) for every lane with `has` (order inside one expansion is immaterial: the window and the best-100 set are sets)
+    auto trk_track = [&](bool has, float sc) {
+        const uint64_t fm = gs_ballot(has);
+        if (fm == 0) return;
+        const uint64_t lt = (1ull << lane) - 1ull;
+        if (has) trk_recent[(trk_ridx + gs_popc(fm & lt)) % TRK_RECENT] = sc;
+        trk_ridx = (trk_ridx + gs_popc(fm)) % TRK_RECENT;
+        const long long mine = (long long)trk_sortable(sc);
+        for (uint64_t rest = fm; rest; rest &= rest - 1) {   // BoundedLongHeap(100).push :59-69, one score at a time
+            const int32_t v = (int32_t)gs_shfl(mine, gs_first(rest));
+            if (trk_nbest < TRK_BEST) {
+                if (lane == 0) trk_best[trk_nbest] = v;
+                if (v < trk_min) {
+                    trk_min = v;
+                    trk_min_idx = trk_nbest;
+                }
+                trk_nbest++;
+            } else if (!(v < trk_min)) {                     // rejects value < top; an equal value replaces it
+                if (lane == 0) trk_best[trk_min_idx] = v;
+                gs_barrier();
+                long long best = GS_KEY_MAX;
+                for (int i = lane; i < TRK_BEST; i += 64) {
+                    const long long k = ((long long)trk_best[i] << 32) | (long long)(uint32_t)i;
+                    best = k < best ? k : best;
+                }
+                best = gs_wave_min(best);
+                trk_min = (int32_t)(best >> 32);
+                trk_min_idx = (int)(best & 0xFFFFFFFFll);
+            }
+        }
+        trk_obs += gs_popc(fm);
+        gs_barrier();
+    };
+    // shouldStop(): only looked at when 500 scores have been seen and the count is a multiple of 100; the 99th percentile of the
+    // window is commons-math3's LEGACY estimate: pos = 0.99 * 501 = 495.99 -> sorted[494] + 0.99 * (sorted[495] - sorted[494]),
+    // i.e. the 6th and the 5th largest of the 500 (in double, like the reference)
+    auto trk_should_stop = [&]() -> bool {
+        if (!thr_on || trk_obs < TRK_RECENT || trk_obs % 100 != 0) return false;
+        long long loc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane + 64 * j;
+            loc[j] = i < TRK_RECENT ? (((long long)trk_sortable(trk_recent[i]) << 32) | (long long)(uint32_t)i) : GS_KEY_MIN;
+        }
+        long long fifth = GS_KEY_MIN, sixth = GS_KEY_MIN;
+        for (int round = 0; round < 6; ++round) {
+            long long m = GS_KEY_MIN;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = loc[j] > m ? loc[j] : m;
+            const long long w = gs_wave_max(m);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (loc[j] == w) loc[j] = GS_KEY_MIN;   // keys are unique (index in the low word): exactly one lane drops it
+            if (round == 4) fifth = w;
+            if (round == 5) sixth = w;
+        }
+        auto val = [](long long k) -> double {
+            const int32_t e = (int32_t)(k >> 32);
+            return (double)gs_bits_float(e ^ ((e >> 31) & 0x7fffffff));
+        };
+        const double pos = (99.0 / 100.0) * (double)(TRK_RECENT + 1);
+        const double lower = val(sixth), upper = val(fifth);
+        const double window = lower + (pos - (double)(int)pos) * (upper - lower);
+        const int32_t e = trk_min;
+        const double worst_best = (double)gs_bits_float(e ^ ((e >> 31) & 0x7fffffff));
+        return window < worst_best && window < (double)p.threshold;
+    };
+
     for (int lvl = p.entry_level; lvl >= 0 && s.status == GS_OK; --lvl) {
         const int rk = lvl > 0 ? 1 : p.rerankK;
         const GsLevel &L = p.lv[lvl];
+        const float thr = (SES && lvl == 0) ? p.threshold : 0.0f;
+        if constexpr (SES) {   // getScoreTracker (ScoreTracker.java:38-58): layer 0 of a threshold search, reset per layer entry
+            thr_on = lvl == 0 && p.threshold > 0.0f;
+            trk_obs = 0;
+            trk_nbest = 0;
+            trk_min = 0x7fffffff;
+            trk_min_idx = -1;
+        }
         // layer 0 evicts nothing, so the evicted area's first word counts the push-log entries there (lane 0 only: no
         // register stays live across the loop for it)
         if (lvl == 0 && p.push_log && lane == 0) *reinterpret_cast<int *>(s.evicted) = 0;
@@ -702,6 +798,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             }
             const float top_score = gs_key_score(top);
             if (s.res_n >= rk && top_score < gs_key_score(s.res_min)) break;  // stopSearch :355-369
+            if constexpr (SES) {
+                if (trk_should_stop()) break;                                 // "preserve legacy threshold early termination"
+            }
             // candidates.pop()
             if (from_lds) {
                 if (lane == 0) s.cand[idx] = s.cand[s.cand_n - 1];
@@ -731,7 +830,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             GS_PHASE(0);
             // threshold 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the results (the
             // node is expanded all the same); then addTopCandidate :515-530 (BoundedLongHeap.push / updateTop)
-            bool result = top_score >= 0.0f;
+            bool result = top_score >= thr;
             if (result && lvl == 0 && acc) {  // acceptOrds: layer 0 only (upper layers run with Bits.ALL, :276)
                 const int32_t tn = gs_key_node(top);
                 result = ((acc[tn >> 6] >> (tn & 63)) & 1ull) != 0;
@@ -765,6 +864,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 s.res_min = gs_scan_extreme<false>(s.res, s.res_n, &s.res_min_idx);
             } else {
                 gs_barrier();
+            }
+            if constexpr (SES) {
+                // "skip edge loading if we've found a local maximum and we have enough results" (:441-444)
+                if (trk_should_stop() && (long long)s.cand_n + s.spill_n >= (long long)rk - s.res_n) continue;
+                if (lvl == 0) n_expanded_base++;
             }
             n_expanded++;
             GS_PHASE(1);
@@ -853,6 +957,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 if (done_ == 0xdeadbeefdeadbeefull) n_visited++;
             }
             GS_PHASE(3);
+            if constexpr (SES) {
+                if (thr_on) trk_track(fresh, gs_key_score(key));
+            }
             gs_push(s, p, key, fresh);
             GS_PHASE(4);
             if (s.status != GS_OK) break;
@@ -886,6 +993,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         p.out_stats[2 * (int64_t)q] = n_visited;
         p.out_stats[2 * (int64_t)q + 1] = n_expanded;
         p.out_status[q] = s.status;
+        if (SES && p.out_base) p.out_base[q] = (int32_t)n_expanded_base;
         if (p.push_log) p.push_log_n[q] = s.status == GS_OK ? *reinterpret_cast<int *>(s.evicted) : -1;
     }
     gs_barrier();
@@ -904,7 +1012,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 }
 
 // Persistent worker: pulls queries off the shared counter until none are left.
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false>
 GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
 {
     for (;;) {
@@ -912,7 +1020,7 @@ GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
         if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
         const int item = (int)gs_shfl(qv, 0);
         if (item >= p.Q) break;
-        gs_search_one<VSF, CH16, PAIR, PROF, LUTR>(p, p.qmap ? p.qmap[item] : item, worker, lds);
+        gs_search_one<VSF, CH16, PAIR, PROF, LUTR, SES>(p, p.qmap ? p.qmap[item] : item, worker, lds);
     }
 }
 

@@ -53,6 +53,10 @@ struct GsParams {
     int32_t pair;             // 1: pair-lane scoring (every degree <= 32; LDS has the M/2 x 32 exchange area)
     // visited set, tier 1: an open-addressing table of 16-bit entries in LDS (gs_body.h "two-tier visited set"); the global
     // table above is tier 2 and is only touched (and only then cleared) by a query whose tier 1 fills up.
+    // GraphSearcher objects (session kernels, gs_body.h SES)
+    int32_t session;          // 1: launch the session kernel (SES = true)
+    float threshold;          // layer-0 admission `score >= threshold` (:437); > 0 also arms the TwoPhaseTracker
+    int32_t *out_base;        // [Q] expandedCountBaseLayer, or nullptr
     int32_t lutr;             // 1: the query's ADC table lives in the wave's registers (M <= 96; one wave per SIMD; no pair lanes)
     int32_t prefetch;         // 1: touch the runner-up candidate's adjacency row + fused block while the popped one is scored (layer 0)
     int32_t v1_log2;          // log2(slots) of the LDS tier (slots / 4 buckets of four 16-bit entries), 0 = no LDS tier
@@ -83,6 +87,9 @@ constexpr size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M 
 
 // LDS bytes of the register/LDS split ADC table (gs_body.h gs_lut_build): the subspaces past the 64 held in registers
 constexpr size_t gs_lutr_lds_bytes(int M) { return M > 64 ? (size_t)(M - 64) * 256 * sizeof(float) : 0; }
+
+// LDS bytes of the session kernels' TwoPhaseTracker state (500 recent scores + the 100 best)
+constexpr size_t gs_session_lds_bytes() { return sizeof(float) * 500 + sizeof(int32_t) * 100; }
 
 // The LDS tier's 16-bit entry = choice bit + remainder: idbits - log2(buckets) <= 14 (0xFFFF stays free for "empty").
 inline bool gs_v1_fits(int v1_log2, int idbits) { return v1_log2 >= 4 && v1_log2 <= 15 && idbits - (v1_log2 - 2) <= 14 && idbits <= 31; }

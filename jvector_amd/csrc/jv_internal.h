@@ -323,6 +323,8 @@ bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const
 size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap = 0, int v1_log2 = 0);
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy);
 bool graph_search_lutr_supported(int M);
+bool graph_search_session_supported(int M);
+int launch_graph_search_session(hipStream_t s, int vsf, const GsParams &p, int workers, size_t lds);
 size_t topk_scratch_bytes(int Q, int k);
 struct RtParams;
 int launch_rerank_ties(hipStream_t s, const RtParams &p);

@@ -103,8 +103,8 @@ size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int 
     return gs_lds_bytes(D, rerankK, cand_cap, pair_M, evict_cap > 0 ? evict_cap : GS_EVICT_CAP, v1_log2);
 }
 
-// Built for the headline shape only (PQ-96 and PQ-32 x the three similarity functions; the phase-clock variant for cosine / 96):
-// every further (M, similarity) instance costs minutes of compile time for its fully unrolled table code.
+// Built for the headline shape only (PQ-96 x the three similarity functions; the phase-clock variant for cosine): an experiment
+// kept selectable (option gs_lutr), measured SLOWER than the table-free form — other M would only cost compile time.
 template <int VSF>
 static int launch_gs_lutr(hipStream_t s, const GsParams &p, int ch, int workers, size_t lds)
 {
@@ -127,10 +127,9 @@ static int launch_gs_lutr(hipStream_t s, const GsParams &p, int ch, int workers,
         return JV_ERR_UNSUPPORTED;
     }
     switch (ch) {
-    case 2: JV_LUTR(2, false); break;
     case 6: JV_LUTR(6, false); break;
     default:
-        set_error("graph search kernel: the register-resident table form is built for M = 32 and M = 96 (M = %d)", ch * 16);
+        set_error("graph search kernel: the register-resident table form is built for M = 96 (M = %d)", ch * 16);
         return JV_ERR_UNSUPPORTED;
     }
 #undef JV_LUTR
@@ -138,7 +137,7 @@ static int launch_gs_lutr(hipStream_t s, const GsParams &p, int ch, int workers,
     return JV_OK;
 }
 
-bool graph_search_lutr_supported(int M) { return M == 32 || M == 96; }
+bool graph_search_lutr_supported(int M) { return M == 96; }
 
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy)
 {
@@ -146,6 +145,13 @@ int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, 
     const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2) +
                        (p.lutr ? gs_lutr_lds_bytes(p.M) : 0);
     const int ch = p.M / 16;
+    if (p.session) {
+        if (p.lutr || p.prof) {
+            set_error("graph search kernel: the GraphSearcher-object form has no register-table / phase-clock variant");
+            return JV_ERR_INVALID;
+        }
+        return launch_graph_search_session(s, vsf, p, workers, lds + gs_session_lds_bytes());
+    }
     if (p.lutr) {
         if (p.pair) {
             set_error("graph search kernel: the register-resident table form has no pair-lane scoring");

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""GraphSearcher OBJECTS on the device traversal (round 3): QPS of search_ex — plain, with a rerank floor, with a threshold —
+next to the plain batched search, on a 1M x 768 / PQ-96 index the engine builds itself; and the cost of resume() (host replay).
+Prints one JSON object.   usage: python scripts/searcher_bench.py [--n 1000000] [--queries 4096]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import jvector_amd as J
+from benchlib import Mixture
+from jvector_amd.builder import build_hierarchical
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--queries", type=int, default=4096)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    ctx = J.HipContext(0, stream=torch.cuda.current_stream().cuda_stream)
+    VSF = J.VectorSimilarityFunction.COSINE
+    D, M, N, Q = 768, 96, args.n, args.queries
+    mix = Mixture(D, seed=5, device=dev)
+    base = mix.sample(N, seed=5)
+    q = mix.sample(Q, seed=6)
+    g = torch.Generator(device=dev).manual_seed(4)
+    pq = J.ProductQuantization.compute(ctx, base[torch.randperm(N, generator=g, device=dev)[:128_000]].contiguous(), M, seed=4)
+    vs = J.VectorSet(ctx, base)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    levels, entry, entry_level, nb0, _ = build_hierarchical(ctx, pq, cv, base, VSF, overflow=2.0)
+    fused = J.FusedPQ.build(ctx, cv, nb0)
+    graph = J.GraphIndex(ctx, N, levels, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=Q)
+    qh = q.cpu().numpy()
+
+    def timed(fn, reps=3):
+        fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        ctx.sync()
+        return (time.perf_counter() - t0) / reps, r
+
+    out = {"n": N, "queries": Q}
+    t, _ = timed(lambda: s.search(q, VSF, 10, 100))
+    out["plain_search_qps"] = Q / t
+    # a score level ~ the 60th best approximate neighbour of a typical query: the threshold search returns "everything above it"
+    ids, sc = s.search(q[:256], VSF, 100, 100)
+    thr = float(np.median(np.asarray(torch.as_tensor(sc).cpu())[:, 59]))
+    for name, kw in (("objects_plain", dict(top_k=10, rerank_k=100)), ("objects_floor", dict(top_k=10, rerank_k=100, rerank_floor=thr)),
+                     ("objects_threshold", dict(top_k=200, rerank_k=200, threshold=thr))):
+        ctx.reset_stats()
+        t, res = timed(lambda: s.search_ex(qh, VSF, **kw))
+        out[name] = {"qps": Q / t, "device_calls": ctx.stat("gs_session_calls_device"), "host_overflow_calls": ctx.stat("gs_session_calls_host_overflow"),
+                     "avg_results": float(np.mean([len(r) for r in res])), "avg_visited": float(np.mean([r.visited for r in res]))}
+    t0 = time.perf_counter()
+    s.resume(10, 100)
+    out["resume_after_device_search_s"] = time.perf_counter() - t0
+    ctx.set_option("graph_traversal", 1)   # the same threshold search on the host searcher
+    t, res = timed(lambda: s.search_ex(qh, VSF, top_k=200, rerank_k=200, threshold=thr), reps=1)
+    out["objects_threshold_host"] = {"qps": Q / t}
+    ctx.set_option("graph_traversal", None)
+    out["threshold"] = thr
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -583,7 +583,8 @@ int launch_bl_sort_edges(hipStream_t, void *temp, size_t *temp_bytes, const unsi
 }
 
 // ---- device-resident traversal: gs_body.h on the lane emulator ----
-bool graph_search_lutr_supported(int M) { return M == 32 || M == 96; }  // (the shapes k_gsearch.hip builds)
+bool graph_search_lutr_supported(int M) { return M == 96; }  // (the shape k_gsearch.hip builds)
+bool graph_search_session_supported(int M) { return M == 16 || M == 96; }
 bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels)
 {
     const int ch = pq->M / 16;  // the same predicate as k_gsearch.hip
@@ -615,6 +616,15 @@ void gs_run_lutr(const GsLaunch &L)
     }
 }
 template <int VSF, bool PAIR>
+void gs_run_session(const GsLaunch &L)
+{
+    switch (L.p->M / 16) {
+    case 1: gs_worker<VSF, 1, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: gs_worker<VSF, 6, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
+template <int VSF, bool PAIR>
 void gs_run_ch(const GsLaunch &L)
 {
     switch (L.p->M / 16) {
@@ -638,7 +648,17 @@ void gs_run_vsf(const GsLaunch &L)
 void gs_main(void *a)
 {
     const GsLaunch &L = *(const GsLaunch *)a;
-    if (L.p->lutr) {
+    if (L.p->session) {
+        if (L.p->pair) {
+            if (L.vsf == VSF_L2) gs_run_session<VSF_L2, true>(L);
+            else if (L.vsf == VSF_DOT) gs_run_session<VSF_DOT, true>(L);
+            else gs_run_session<VSF_COS, true>(L);
+        } else {
+            if (L.vsf == VSF_L2) gs_run_session<VSF_L2, false>(L);
+            else if (L.vsf == VSF_DOT) gs_run_session<VSF_DOT, false>(L);
+            else gs_run_session<VSF_COS, false>(L);
+        }
+    } else if (L.p->lutr) {
         if (L.vsf == VSF_L2) gs_run_lutr<VSF_L2>(L);
         else if (L.vsf == VSF_DOT) gs_run_lutr<VSF_DOT>(L);
         else gs_run_lutr<VSF_COS>(L);
@@ -650,7 +670,7 @@ int launch_graph_search(hipStream_t, int vsf, const GsParams &p, int workers, in
 {
     if (p.Q == 0) return JV_OK;
     const size_t lds_bytes = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2) +
-                             (p.lutr ? gs_lutr_lds_bytes(p.M) : 0);
+                             (p.lutr ? gs_lutr_lds_bytes(p.M) : 0) + (p.session ? gs_session_lds_bytes() : 0);
     // the waves of a persistent launch, one after another; wave w stops after its share so that several workers'
     // scratch slices are exercised (a real launch interleaves them)
     for (int w = 0; w < workers; ++w) {

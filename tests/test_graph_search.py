@@ -278,11 +278,16 @@ def _same(r, w, tag):
     assert r.worst_approximate_in_topk == w.worst_approximate_in_topk, tag
 
 
-def run_searcher_object_cases(J, ctx, cases=4):
+def run_searcher_object_cases(J, ctx, cases=4, traversal=None):
     """search(topK, rerankK, threshold, rerankFloor, acceptOrds) followed by two resume() calls per query == the oracle's
-    jvo_searcher restatement: nodes, scores, the four counters and worstApproximateScoreInTopK.  Shared with the mock."""
+    jvo_searcher restatement: nodes, scores, the four counters and worstApproximateScoreInTopK.  Shared with the mock.
+    traversal: None = the graph's default (AUTO: search() of the M = 16 cases runs on the DEVICE traversal's session kernels —
+    threshold admission, TwoPhaseTracker stop, acceptOrds in the kernel; resume() replays on the host searcher — the M = 8 cases
+    on the host searcher), "host" / "device" pin it."""
     VSF = J.VectorSimilarityFunction
     early = 0
+    ctx.reset_stats()
+    dev_expected = 0
     for case in range(cases):
         levels = 1 + case % 3
         D, M = [(64, 8), (128, 16)][case % 2]
@@ -299,9 +304,13 @@ def run_searcher_object_cases(J, ctx, cases=4):
         codes = cv.get(0, N)
         og = O.OracleGraph(N, lv, entry, entry_level)
         graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+        if traversal:
+            graph.set_traversal(traversal)
         use_fused = case % 2 == 0
         fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
         accept = None if case % 2 else (rng.random((len(q), N)) < 0.7)
+        if M == 16 and traversal != "host":
+            dev_expected += 1
         for vsf in VSF:
             # approximate score levels of this query set, to place thresholds / floors where they bite
             lvl = np.sort(np.stack([opq.adc_scores(q[i], int(vsf), codes, None, fused=use_fused) for i in range(len(q))]), axis=1)
@@ -328,10 +337,19 @@ def run_searcher_object_cases(J, ctx, cases=4):
     # TwoPhaseTracker only answers when its observation count sits on a multiple of 100 (ScoreTracker.java:123-126), so an early
     # stop is a matter of luck per search — but over all of these some must have stopped before crawling the whole graph
     assert early > 0, "no threshold search ever stopped early: the tracker path was not exercised"
+    if dev_expected:   # the M = 16 cases really went through the session kernels (and their resumes through the host replay)
+        assert ctx.stat("gs_session_calls_device") >= dev_expected * 3 * 2 * 3, ctx.stat("gs_session_calls_device")
+        assert ctx.stat("gs_session_resume_replays") > 0
+    else:
+        assert ctx.stat("gs_session_calls_device") == 0
 
 
 def test_searcher_objects_threshold_floor_resume(ctx):
     run_searcher_object_cases(J, ctx)
+
+
+def test_searcher_objects_on_the_host_searcher(ctx):
+    run_searcher_object_cases(J, ctx, cases=2, traversal="host")
 
 
 def test_searcher_object_errors(ctx):

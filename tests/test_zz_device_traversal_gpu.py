@@ -266,7 +266,7 @@ def test_auto_traversal_reports_the_host_fallback(ctx, capfd):
     assert err.count("JV_TRAVERSAL_AUTO takes the HOST searcher") == 1
 
 
-@pytest.mark.parametrize("levels,use_fused,D,M,deg", [(2, True, 768, 96, 32), (2, False, 256, 32, 16), (3, True, 256, 32, 24), (1, False, 768, 96, 40)])
+@pytest.mark.parametrize("levels,use_fused,D,M,deg", [(2, True, 768, 96, 32), (3, True, 768, 96, 24), (1, False, 768, 96, 40)])
 def test_register_resident_table_kernel(ctx, levels, use_fused, D, M, deg):
     """gs_lutr = 1: the traversal kernel whose ADC table lives in the wave's registers + LDS (graph_search_lutr_kernel) — ids,
     scores and counters equal the oracle's (and therefore the table-free kernel's) for every similarity function"""
