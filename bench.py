@@ -637,7 +637,7 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--m", type=int, default=96)
     ap.add_argument("--degree", type=int, default=32)
-    ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 65536 graph / 256 flat / 1024 c2)")
+    ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 131072 graph / 256 flat / 1024 c2)")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95 on the calibration set")
     ap.add_argument("--cal-queries", type=int, default=4096, help="calibration queries (rerankK ladder)")
@@ -698,8 +698,9 @@ def main():
         args.mode = "graph"
     graph_mode = args.mode == "graph"
     # graph mode: one persistent launch serves the whole batch and ends when its LAST query does (a long search takes 2-3 ms),
-    # so throughput grows with the batch until that tail is amortised: 775k / 868k / 938k QPS at 16k / 32k / 64k queries (1M run)
-    Q = args.queries or (65536 if graph_mode else 256)
+    # so throughput grows with the batch until that tail is amortised: 775k / 868k / 938k QPS at 16k / 32k / 64k queries (1M run);
+    # at 10M: 1.132 M QPS at 65536, 1.183 M at 131072 (profiles/r3_f) — the default
+    Q = args.queries or (131072 if graph_mode else 256)
     t_setup = time.perf_counter()
     mix = Mixture(D, seed=5, device=dev, latent=args.latent)
     base = mix.sample(N, seed=5)

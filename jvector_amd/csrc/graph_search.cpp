@@ -1536,17 +1536,28 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     }
 
     if (so) {  // GraphSearcher objects: the host finishes (searcher_search_device) from the log and the counters
-        so->log_cap = log_cap;
         so->status.assign(status.begin(), status.end());
         so->base.resize((size_t)Q);
         so->log_n.resize((size_t)Q);
         so->stats.resize(2 * (size_t)Q);
-        so->log.resize((size_t)Q * (size_t)log_cap);
         JV_HIP_CHECK(hipMemcpyAsync(so->base.data(), base + o_base, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipMemcpyAsync(so->log_n.data(), base + o_log_n, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipMemcpyAsync(so->stats.data(), d_stats, sizeof(long long) * 2 * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
-        JV_HIP_CHECK(hipMemcpyAsync(so->log.data(), base + o_log, sizeof(long long) * (size_t)Q * (size_t)log_cap, hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        // only the used prefix of every query's log crosses PCIe: [Q][longest log] instead of [Q][log_cap]
+        int longest = 0;
+        bool overflowed = false;
+        for (int q = 0; q < Q; ++q) {
+            overflowed = overflowed || so->log_n[(size_t)q] > log_cap;
+            longest = std::max(longest, std::min(so->log_n[(size_t)q], log_cap));
+        }
+        so->log_cap = overflowed ? -1 : std::max(longest, 1);   // -1: some log overflowed -> the caller falls back
+        if (!overflowed) {
+            so->log.resize((size_t)Q * (size_t)so->log_cap);
+            JV_HIP_CHECK(hipMemcpy2DAsync(so->log.data(), sizeof(long long) * (size_t)so->log_cap, base + o_log, sizeof(long long) * (size_t)log_cap,
+                                          sizeof(long long) * (size_t)so->log_cap, (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+            JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
         ctx_stat_add(ctx, "gs_calls_device", 1);
         ctx_stat_add(ctx, "gs_queries_device", Q);
         ctx_stat_add(ctx, "gs_session_calls_device", 1);
@@ -1878,7 +1889,7 @@ static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, 
     JV_TRY(graph_search_device(ctx, g, l, s->codes, s->fused, s->vectors, s->queries.data(), Q, s->vsf, topK, rerankK, nullptr, nullptr, nullptr,
                                host_accept, dev_accept, &so));
     for (int q = 0; q < Q; ++q)
-        if (so.status[(size_t)q] != GS_OK || so.log_n[(size_t)q] < 0 || so.log_n[(size_t)q] > so.log_cap) {
+        if (so.log_cap < 0 || so.status[(size_t)q] != GS_OK || so.log_n[(size_t)q] < 0 || so.log_n[(size_t)q] > so.log_cap) {
             ctx_stat_add(ctx, "gs_session_calls_host_overflow", 1);
             return JV_OK;  // (rare: one query outgrew the device structures or its log) -> the whole batch on the host
         }

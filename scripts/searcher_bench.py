@@ -52,20 +52,39 @@ def main():
     t, _ = timed(lambda: s.search(q, VSF, 10, 100))
     out["plain_search_qps"] = Q / t
     # a score level ~ the 60th best approximate neighbour of a typical query: the threshold search returns "everything above it"
-    ids, sc = s.search(q[:256], VSF, 100, 100)
-    thr = float(np.median(np.asarray(torch.as_tensor(sc).cpu())[:, 59]))
+    import ctypes as C
+    ses = s._session()
+
+    def c_call(top_k, rerank_k, threshold=0.0, rerank_floor=0.0):
+        """jv_hip_searcher_search straight through ctypes (outputs into preallocated numpy buffers): what a Java caller pays —
+        search_ex additionally builds one Python SearchResult object per query"""
+        ids, sc = np.empty((Q, top_k), np.int32), np.empty((Q, top_k), np.float32)
+        cnt, st, w = np.empty(Q, np.int32), np.empty((Q, 4), np.int64), np.empty(Q, np.float32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        def run():
+            J._lib.check(ctx._lib.jv_hip_searcher_search(ctx._h, ses, p(qh), Q, int(VSF), top_k, rerank_k, float(threshold), float(rerank_floor), None, 0,
+                                                         p(ids), p(sc), p(cnt), p(st), p(w)))
+            return cnt, st
+        return run
+
+    # the approximate-score level of the ~60th neighbour (thresholds act on APPROXIMATE scores)
+    thr = float(np.median([r.worst_approximate_in_topk for r in s.search_ex(qh[:256], VSF, 60, 60)]))
     for name, kw in (("objects_plain", dict(top_k=10, rerank_k=100)), ("objects_floor", dict(top_k=10, rerank_k=100, rerank_floor=thr)),
                      ("objects_threshold", dict(top_k=200, rerank_k=200, threshold=thr))):
         ctx.reset_stats()
-        t, res = timed(lambda: s.search_ex(qh, VSF, **kw))
+        t, (cnt, st) = timed(c_call(**kw))
         out[name] = {"qps": Q / t, "device_calls": ctx.stat("gs_session_calls_device"), "host_overflow_calls": ctx.stat("gs_session_calls_host_overflow"),
-                     "avg_results": float(np.mean([len(r) for r in res])), "avg_visited": float(np.mean([r.visited for r in res]))}
+                     "avg_results": float(cnt.mean()), "avg_visited": float(st[:, 0].mean())}
+    t, _ = timed(lambda: s.search_ex(qh, VSF, top_k=10, rerank_k=100), reps=2)
+    out["objects_plain_through_python_search_ex_qps"] = Q / t
     t0 = time.perf_counter()
     s.resume(10, 100)
     out["resume_after_device_search_s"] = time.perf_counter() - t0
-    ctx.set_option("graph_traversal", 1)   # the same threshold search on the host searcher
-    t, res = timed(lambda: s.search_ex(qh, VSF, top_k=200, rerank_k=200, threshold=thr), reps=1)
+    ctx.set_option("graph_traversal", 1)   # the same searches on the host searcher
+    t, _ = timed(c_call(top_k=200, rerank_k=200, threshold=thr), reps=1)
     out["objects_threshold_host"] = {"qps": Q / t}
+    t, _ = timed(c_call(top_k=10, rerank_k=100), reps=1)
+    out["objects_plain_host"] = {"qps": Q / t}
     ctx.set_option("graph_traversal", None)
     out["threshold"] = thr
     print(json.dumps(out))

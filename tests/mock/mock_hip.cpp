@@ -110,6 +110,11 @@ hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind)
     memcpy(d, s, n);
     return hipSuccess;
 }
+hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t)
+{
+    for (size_t r = 0; r < height; ++r) memcpy((char *)d + r * dpitch, (const char *)s + r * spitch, width);
+    return hipSuccess;
+}
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t)
 {
     memcpy(d, s, n);
