@@ -952,6 +952,11 @@ def main():
             pass
         if graph_mode:
             st = graph_stats
+            # which traversal served the queries of this process (jv_hip_ctx_get_stat): device-resident, re-run on the device with a
+            # bigger visited table, finished by the host searcher, AUTO falling back to the host searcher altogether
+            line["traversal_stats"] = {k: ctx.stat(k) for k in ("gs_calls_device", "gs_calls_host", "gs_calls_host_auto", "gs_queries_device",
+                                                                "gs_queries_retried", "gs_queries_host_fallback", "gs_ties_resolved_device",
+                                                                "gs_ties_to_host", "gs_last_v1_log2", "gs_last_workers_per_cu")}
             line["avg_visited"] = float(st[:, 0].mean())
             line["avg_expanded"] = float(st[:, 1].mean())
             line["adc_distances_per_s"] = float(st[:, 0].mean()) * total_queries / elapsed

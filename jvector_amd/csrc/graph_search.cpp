@@ -1343,7 +1343,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // JVECTOR_HIP_GS_VCAP_LOG2 overrides the visited-table size (tests use a tiny table to drive the host fallback)
     const int vcap_log2 = std::max(8, std::min(24, (int)ctx_opt(ctx, "gs_vcap_log2", gs_vcap_log2(rerankK))));
     const size_t vcap = (size_t)1 << vcap_log2;
-    const int spill_cap = (int)(vcap / 2) + 64;  // pushes <= visited <= vcap / 2: the spill tier cannot overflow first
+    // pushes <= visited <= (tier-2 capacity vcap / 2) + (tier-1 capacity 1 << v1_log2): the spill tier cannot overflow first.
+    // (Round 3's first builds sized it for tier 2 alone: the 0.24 % longest searches of every 10M batch overflowed it and went
+    // through a 3.5 ms retry launch — found in the closing profile's kernel trace.)
+    const size_t v1_slots = v1_log2 > 0 ? ((size_t)1 << v1_log2) : 0;
+    const int spill_cap = (int)(vcap / 2 + v1_slots) + 64;
     JV_TRY(ctx->d_gs_visited.reserve(sizeof(int32_t) * vcap * (size_t)workers));
     JV_TRY(ctx->d_gs_spill.reserve(sizeof(long long) * (size_t)spill_cap * (size_t)workers));
     // growth pool: the few queries of a batch that outgrow the base table (a long search visits 3-6x the average) move to
@@ -1354,7 +1358,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // pool size: ~3 % of the batch (p99.9 of the visited count is 2.2x the median on the benched graphs, so well under 1 % of
     // the queries outgrow a base table sized at 64 x rerankK), at least 64, at most 2048 tables (1 GB at rerankK 110)
     const int big_count = (grow_on && big_log2 > vcap_log2) ? std::max(1, std::min(Q, std::max(64, std::min(2048, Q / 32)))) : 0;
-    const int big_spill_cap = (int)(((size_t)1 << big_log2) / 2) + 64;
+    const int big_spill_cap = (int)(((size_t)1 << big_log2) / 2 + v1_slots) + 64;
     const size_t big_vis_bytes = sizeof(int32_t) * ((size_t)1 << big_log2) * (size_t)big_count;
     const size_t big_spill_off = (big_vis_bytes + 255) & ~(size_t)255;
     const size_t big_ctr_off = (big_spill_off + sizeof(long long) * (size_t)big_spill_cap * (size_t)big_count + 255) & ~(size_t)255;
@@ -1490,7 +1494,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         const int vlog2 = std::min(24, vcap_log2 + 3 * attempt);
         if (vlog2 <= vcap_log2 + 3 * (attempt - 1)) break;
         const size_t vcap2 = (size_t)1 << vlog2;
-        const int spill2 = (int)(vcap2 / 2) + 64;
+        const int spill2 = (int)(vcap2 / 2 + v1_slots) + 64;
         const int R = (int)redo.size();
         const int workers2 = std::max(1, std::min<int>({R, workers, (int)(((size_t)512 << 20) / (vcap2 * 12))}));
         JV_TRY(ctx->d_gs_visited.reserve(sizeof(int32_t) * vcap2 * (size_t)workers2));
