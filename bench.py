@@ -655,6 +655,8 @@ def main():
                          "2.0 builds faster (15.6M re-pruned lists instead of 36.6M) AND yields a graph that needs rerankK 95 instead of 105")
     ap.add_argument("--build-max-batch", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_MAX_BATCH", "131072")),
                     help="engine graph: largest insert batch (inserts of one batch do not see each other)")
+    ap.add_argument("--build-passes", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_PASSES", "1")),
+                    help="engine graph: 2 = re-insert every level-0 node against the finished graph (improveConnections for all nodes)")
     ap.add_argument("--torch-codebooks", action="store_true", help="codebooks from benchlib's torch Lloyd instead of the engine's "
                     "ProductQuantization.compute (round-1 behaviour)")
     ap.add_argument("--index-cache", default=os.environ.get("JVECTOR_BENCH_INDEX_CACHE", ""), help="npz file: synthetic graph + "
@@ -754,7 +756,8 @@ def main():
             from jvector_amd.builder import build_hierarchical
             levels, entry, entry_level, nbrs_dev, bstats = build_hierarchical(ctx, pq, cv, base, VSF, max_degree=args.degree,
                                                                                 beam_width=args.build_beam, alpha=args.build_alpha, log=log,
-                                                                                overflow=args.build_overflow, max_batch=args.build_max_batch)
+                                                                                overflow=args.build_overflow, max_batch=args.build_max_batch,
+                                                                                passes=args.build_passes)
             log(f"[build] {dict(bstats)}")
             build_info = {k: (float(v) if isinstance(v, float) else v) for k, v in dict(bstats).items()}
             if args.index_cache and rank == 0:

@@ -63,7 +63,7 @@ class GraphBuilder:
 
 
 def build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=100, alpha=1.2, max_batch=131072, seed=11, log=None,
-                 overflow=1.25, vector_set=None):
+                 overflow=1.25, vector_set=None, passes=1):
     """One graph level.  vectors: [N, D] float32 tensor on the engine's device (the insert queries).  Prefix-doubling batches: a
     batch never exceeds what the graph already holds.  Returns (neighbors [N, max_degree] int32 tensor, entry_node, BuildStats)."""
     N = int(vectors.shape[0])
@@ -81,6 +81,12 @@ def build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=10
             st = b.stats()
             log(f"[build] inserted {hi}/{N}: search {st['search_s']:.1f}s prune {st['prune_s']:.1f}s backlink {st['backlink_s']:.1f}s")
         lo = hi
+    for extra in range(1, passes):   # improveConnections for every node (GraphIndexBuilder.java:510-540): re-insert against the finished graph
+        for lo in range(0, N, max_batch):
+            b.insert_batch(perm[lo:lo + max_batch].contiguous())
+        if log:
+            st = b.stats()
+            log(f"[build] pass {extra + 1} done: search {st['search_s']:.1f}s prune {st['prune_s']:.1f}s backlink {st['backlink_s']:.1f}s")
     out = b.finish(torch.empty((N, max_degree), dtype=torch.int32, device=vectors.device))
     stats = b.stats()
     stats["total_s"] = time.perf_counter() - t0

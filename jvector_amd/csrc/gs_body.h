@@ -708,7 +708,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         if (has) trk_recent[(trk_ridx + gs_popc(fm & lt)) % TRK_RECENT] = sc;
         trk_ridx = (trk_ridx + gs_popc(fm)) % TRK_RECENT;
         const long long mine = (long long)trk_sortable(sc);
-        for (uint64_t rest = fm; rest; rest &= rest - 1) {   // BoundedLongHeap(100).push :59-69, one score at a time
+        // a FULL heap rejects a score below its minimum, and the minimum only grows: such lanes need no turn
+        const uint64_t turns = gs_ballot(has && (trk_nbest < TRK_BEST || !((int32_t)mine < trk_min)));
+        for (uint64_t rest = turns; rest; rest &= rest - 1) {   // BoundedLongHeap(100).push :59-69, one score at a time
             const int32_t v = (int32_t)gs_shfl(mine, gs_first(rest));
             if (trk_nbest < TRK_BEST) {
                 if (lane == 0) trk_best[trk_nbest] = v;

@@ -64,6 +64,18 @@ def check_builder(J, ctx, dev, N, D, M, max_degree, beam, register=None, min_rec
     gt = np.argsort(-(q @ v.T), axis=1)[:, :10]
     recall = np.mean([len(set(a.tolist()) & set(b.tolist())) / 10.0 for a, b in zip(np.asarray(ids), gt)])
     assert recall >= min_recall, recall
+    # ---- a second pass (improveConnections for every node: re-insertion against the finished graph) keeps the contract ----
+    nb2, entry2, st2p = build_vamana(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, alpha=1.2, max_batch=2048, passes=2, overflow=2.0)
+    nb2 = nb2.cpu().numpy()
+    assert st2p["inserted"] >= 2 * N - 1 and nb2.shape == (N, max_degree) and nb2.max() < N
+    for i in range(0, N, max(1, N // 100)):
+        row = nb2[i][nb2[i] >= 0]
+        assert i not in row and len(set(row.tolist())) == len(row) and (nb2[i][:len(row)] >= 0).all()
+    g2p = J.GraphIndex(ctx, N, [(None, nb2)], entry2, 0)
+    ids2p, _ = J.GraphSearcher(ctx, g2p, pq, cv, None, vs, max_queries=64).search(q, VSF, 10, 4 * beam)
+    gt2p = np.argsort(-(q @ v.T), axis=1)[:, :10]
+    r2p = np.mean([len(set(a.tolist()) & set(b.tolist())) / 10.0 for a, b in zip(np.asarray(ids2p), gt2p)])
+    assert r2p >= min_recall, r2p
     # ---- layered variant (GraphIndexBuilder's hierarchy): nested levels of N / maxDegree^l nodes, searched top-down ----
     if True:
         levels, e2, el2, nb0, st2 = build_hierarchical(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, max_batch=2048, min_top=4)
