@@ -663,6 +663,10 @@ def main():
                     "codebooks are loaded from it when it exists, else built and saved (lets rocprofv3 wrap search steps only)")
     ap.add_argument("--latent", type=int, default=32, help="intrinsic dimension of the synthetic mixture (benchlib.Mixture: latent-L clusters "
                     "embedded in D dims + isotropic noise); QPS@recall is a strong function of it — 64 / 128 are the sensitivity points")
+    ap.add_argument("--reranker", choices=["full", "nvq"], default="full", help="c3: what NodeQueue.rerank scores the kept candidates with — "
+                    "full = the float32 rows (INLINE_VECTORS, the headline), nvq = NVQ rows encoded by the engine (the reference's NVQ_VECTORS "
+                    "feature: D + 16 S bytes per candidate instead of 4 D); recall is measured against the exact ground truth either way")
+    ap.add_argument("--nvq-subvectors", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat", action="store_true", help="graph mode: skip the secondary flat-scan measurement")
     args = ap.parse_args()
@@ -744,6 +748,23 @@ def main():
     if not codes_t.is_cuda:  # host tensors are copied, not wrapped (CPU dry run of this script against the mock device)
         codes_t.copy_(torch.from_numpy(cv.get(0, N)))
 
+    rerank_vs, nvq_info = vs, None
+    if args.reranker == "nvq":   # NVQuantization.compute + encodeAll on the device (EX/Grid.java:508-514 builds the same feature)
+        tn = time.perf_counter()
+        nvq = J.NVQuantization.compute(ctx, vs, args.nvq_subvectors)
+        ctx.sync()
+        mean_s = time.perf_counter() - tn
+        ctx.profile(True)
+        nvq_rows = nvq.encode_all(vs)
+        nenc_ms, _ = ctx.profile_read("encode")
+        ctx.profile(False)
+        rerank_vs = nvq_rows.as_vector_set()
+        nvq_info = {"subvectors": args.nvq_subvectors, "global_mean_s": mean_s, "encode_ms": nenc_ms,
+                    "encode_vectors_per_s": N / (nenc_ms / 1e3) if nenc_ms > 0 else None,
+                    "bytes_per_row": D + 16 * args.nvq_subvectors, "bytes_per_row_full": 4 * D}
+        log(f"[nvq] global mean {mean_s:.2f} s, encode {nenc_ms:.1f} ms ({N / max(nenc_ms, 1e-9) / 1e3:.2f} M vectors/s), "
+            f"{D + 16 * args.nvq_subvectors} B per row instead of {4 * D}")
+
     build_s, levels, build_info = None, None, None
     if graph_mode:
         tb = time.perf_counter()
@@ -780,14 +801,14 @@ def main():
                 np.savez(args.index_cache, **arrs)
         fused = J.FusedPQ.build(ctx, cv, nbrs_dev)          # FusedPQ.writeInline on the device (jv_hip_fused_build)
         graph = J.GraphIndex(ctx, N, levels, entry, entry_level).set_traversal(args.traversal)
-        searcher = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=Q)
+        searcher = J.GraphSearcher(ctx, graph, pq, cv, fused, rerank_vs, max_queries=Q)
         torch.cuda.synchronize()
         build_s = time.perf_counter() - tb
 
         def run(qs, rk, stats=False):
             return searcher.search(qs, VSF, K, rk, return_stats=stats)
     else:
-        flat = J.FlatSearcher(ctx, pq, cv, vs, max_queries=Q)
+        flat = J.FlatSearcher(ctx, pq, cv, rerank_vs, max_queries=Q)
 
         def run(qs, rk, stats=False):
             return flat.search(qs, VSF, K, rk)
@@ -870,10 +891,16 @@ def main():
     # rerank kernel roofline (row 1): candidates x (4*D + 4) bytes over the exact kernel's time
     e_ms, e_n = prof["exact"]
     if e_n > 0 and e_ms > 0:
-        rr_bytes = float(Q) * rerank_k * args.steps * (4 * D + 4)
+        row_bytes = (D + 16 * args.nvq_subvectors + 4 + 4) if args.reranker == "nvq" else (4 * D + 4)
+        rr_bytes = float(Q) * rerank_k * args.steps * row_bytes
         ach = rr_bytes / (e_ms / 1e3) / 1e9
-        extra_roof["rerank"] = {"bound": "hbm", "kernel": "exact_gather_tr_kernel<COSINE> (NodeQueue.rerank: full-resolution cosine of the "
-                                "kept candidates; rows gathered by ordinal in coalesced 256-byte pieces and transposed through LDS)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        rr_kernel = ("nvq_gather_kernel<COSINE> (NVQ.rerankerFor: NVQ rows of the kept candidates — one byte per dimension + 16 B per "
+                     "sub-vector + the row's normalisation sum — de-quantised and chained in the scalar provider's order; VALU-bound "
+                     "(~26 instructions per dimension incl. an IEEE divide), priced against HBM for comparability)"
+                     if args.reranker == "nvq" else
+                     "exact_gather_tr_kernel<COSINE> (NodeQueue.rerank: full-resolution cosine of the "
+                     "kept candidates; rows gathered by ordinal in coalesced 256-byte pieces and transposed through LDS)")
+        extra_roof["rerank"] = {"bound": "hbm", "kernel": rr_kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("exact_gather", cfg_key),
                                 "bytes_per_launch": rr_bytes / e_n, "avg_launch_ms": e_ms / e_n, "launches": e_n}
 
@@ -941,6 +968,7 @@ def main():
             "encode": {"vectors_per_s": N / (enc_ms / 1e3) if enc_ms > 0 else None, "ms": enc_ms},
             "pq_train_s": train_s, "ground_truth_s": gt_s, "setup_s": setup_s, "graph_build_s": build_s,
             "graph": args.graph, "graph_build": build_info,
+            "reranker": args.reranker, "nvq": nvq_info,
         }
         line.update(extra_roof)
         # QPS@recall is a strong function of the data's intrinsic dimension: the same run at other latent dimensions, measured
@@ -988,6 +1016,9 @@ def main():
             else:
                 line["cpu_baseline"] = cpu_baseline_flat(cb, D, M, codes_h, base, timed_q, VSF, K, rerank_k,
                                                          ids_gpu.cpu().numpy())
+            if args.reranker == "nvq" and line.get("cpu_baseline"):
+                line["cpu_baseline"]["note"] = ("the CPU leg reranks with the float32 rows (the headline's reranker): its top-k differs from the "
+                                                "NVQ-reranked GPU top-k by design, so the identical-results flag does not apply to this line")
         print(json.dumps(line))
     ranks.close()
     if world > 1:

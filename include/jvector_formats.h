@@ -41,6 +41,23 @@ JV_API int jv_fmt_pq_describe(const uint8_t *buf, size_t len, size_t *block_len,
 JV_API int jv_fmt_pqvectors_describe(const uint8_t *buf, size_t len, size_t *pq_block_len, int64_t *count, int *M,
                                      size_t *codes_off);
 
+/* ---- NVQuantization / NVQVectors ---------------------------------------------------------------------------- */
+/* NVQuantization.write (B/quantization/NVQuantization.java:260-277): [int version][int D][D floats][int bitsPerDimension = 8]
+ * [int S][S ints].  vector_stride = NVQuantization.compressedVectorSize (:357-363), the bytes of one serialised
+ * QuantizedVector.  The stored sub-vector sizes must be the split NVQuantization.create(D, S) makes, else
+ * JV_ERR_UNSUPPORTED.  Any out pointer may be NULL. */
+JV_API int jv_fmt_nvq_describe(const uint8_t *buf, size_t len, size_t *block_len, int *version, int *D, int *n_subvectors,
+                               size_t *mean_off, int64_t *vector_stride);
+JV_API int jv_fmt_nvq_read_mean(const uint8_t *buf, size_t len, float *global_mean /* D floats, host order */);
+/* NVQVectors.write (B/quantization/NVQVectors.java:50-62): [NVQuantization block][int count][count QuantizedVectors]. */
+JV_API int jv_fmt_nvqvectors_describe(const uint8_t *buf, size_t len, size_t *nvq_block_len, int64_t *count, size_t *vectors_off,
+                                      int64_t *vector_stride);
+/* Decode `count` serialised QuantizedVectors (QuantizedVector.write :437-443, QuantizedSubVector.write :577-587), record r at
+ * src + r * stride, into what jv_hip_nvq_vectors_upload takes:
+ *   bytes  : count x D (the sub-vectors' bytes concatenated);  params : count x S x {minValue, maxValue, growthRate, midpoint} */
+JV_API int jv_fmt_nvq_unpack(const uint8_t *src, size_t len, int64_t stride, int64_t count, int D, int n_subvectors, uint8_t *bytes,
+                             float *params);
+
 /* ---- OnDiskGraphIndex --------------------------------------------------------------------------------------- */
 #define JV_ODGI_MAX_LAYERS 32 /* CommonHeader.V4_MAX_LAYERS */
 #define JV_ODGI_MAX_FEATURES 8
@@ -77,11 +94,17 @@ typedef struct jv_odgi_info {
     int64_t hierarchy_off;       /* v6 + FusedPQ: (int node, M code bytes) x hierarchy_count; -1 if absent */
     int32_t hierarchy_count;     /* layer_size[1], or 1 (the entry node) for a single-layer graph */
     int64_t separated_vectors_off; /* SEPARATED_VECTORS: id_upper_bound x D floats; -1 if absent */
+    int64_t nvq_off, nvq_len;    /* NVQ_VECTORS / SEPARATED_NVQ header = an NVQuantization block inside buf; -1/0 if absent */
+    int32_t nvq_S;               /* its sub-vector count, 0 if absent */
+    int32_t reserved0;
+    int64_t nvq_stride;          /* bytes of one serialised QuantizedVector (NVQuantization.compressedVectorSize) */
+    int64_t nvq_inline_off;      /* NVQ_VECTORS: offset of the QuantizedVector inside a record, -1 if absent */
+    int64_t separated_nvq_off;   /* SEPARATED_NVQ: id_upper_bound x nvq_stride bytes; -1 if absent */
 } jv_odgi_info;
 
 /* Parse the header(s) of the index that starts at buf[0] and spans len bytes (a slice that holds the index and nothing
  * else, as OnDiskGraphIndex.loadFromFooter requires) and validate every section against len.
- * NVQ features are recognised but not decoded: JV_ERR_UNSUPPORTED. */
+ * NVQ features: header and offsets are reported here, rows come out of jv_fmt_odgi_read_nvq. */
 JV_API int jv_fmt_odgi_describe(const uint8_t *buf, size_t len, jv_odgi_info *info);
 
 /* Unpack layer 0. Any output may be NULL.
@@ -105,6 +128,10 @@ JV_API int jv_fmt_odgi_read_level(const uint8_t *buf, size_t len, const jv_odgi_
  *   node_ids : hierarchy_count int32;  codes : hierarchy_count x M bytes */
 JV_API int jv_fmt_odgi_read_hierarchy_codes(const uint8_t *buf, size_t len, const jv_odgi_info *info, int32_t *node_ids,
                                             uint8_t *codes);
+
+/* NVQ_VECTORS (inline) or SEPARATED_NVQ rows of every L0 node: bytes id_upper_bound x D, params id_upper_bound x S x 4
+ * (either may be NULL); a placeholder record yields a zeroed row. */
+JV_API int jv_fmt_odgi_read_nvq(const uint8_t *buf, size_t len, const jv_odgi_info *info, uint8_t *bytes, float *params);
 
 /* ---- fvecs / ivecs ------------------------------------------------------------------------------------------ */
 /* Little-endian rows of [int32 dim][dim x 4-byte element]; every row must carry the same dim. */

@@ -276,6 +276,57 @@ JV_API int jv_hip_exact_scan_dense(jv_ctx *ctx, const jv_vectors *v, const float
                                    int64_t first, int64_t count, float *scores_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * NVQ ("NuVeQ", non-uniform vector quantization) — the reference's compressed RERANK codec; SURVEY 8 f.4 names it as what
+ * follows the format readers.  One byte per dimension plus four floats per sub-vector: a reranked candidate costs
+ * D + 16 S bytes of HBM instead of 4 D.
+ *   replaces: NVQuantization.compute / create / encodeAll / encode (B/quantization/NVQuantization.java:153-216,
+ *             QuantizedSubVector.quantizeTo :508-557 incl. the growth-rate search over nvqLoss / nvqUniformLoss),
+ *             NVQVectors.scoreFunctionFor / NVQScorer (B/quantization/NVQScorer.java:33-137),
+ *             NVQ.rerankerFor / SeparatedNVQ.rerankerFor (B/graph/disk/feature/NVQ.java:96-110),
+ *             VectorUtilSupport.nvqQuantize8bit / nvqLoss / nvqUniformLoss / nvqDotProduct8bit / nvqSquareL2Distance8bit /
+ *             nvqCosine8bit / nvqShuffleQueryInPlace8bit (B/vector/VectorUtilSupport.java; scalar bodies
+ *             DefaultVectorUtilSupport.java:385-548, native NC/src/jvector_simd_kernels.cpp:1029-1643).
+ * Arithmetic = the scalar provider's (Math.fma chains over each sub-vector in dimension order); encoded bytes, parameters
+ * and scores are bit-identical to it.  The query is NOT shuffled (DefaultVectorUtilSupport's no-op): callers hand over
+ * plain queries.
+ *   params   : per vector S x 4 floats {minValue, maxValue, growthRate, midpoint} — the order QuantizedSubVector.write
+ *              serialises them (:577-587)
+ *   bytes    : per vector D bytes, the sub-vectors' bytes concatenated (sub-vector split = getSubvectorSizesAndOffsets)
+ * jv_hip_vectors_from_nvq wraps NVQ rows as a jv_vectors: every search entry point that takes `vectors` for its rerank
+ * (jv_hip_search_flat, jv_hip_graph_search, jv_hip_searcher_*, jv_hip_sharded_search, jv_hip_exact_scores) then reranks
+ * with the NVQ score function, as a graph whose features are FUSED_PQ + NVQ_VECTORS does; entry points that need the
+ * float rows themselves (encode, scans, construction) return JV_ERR_UNSUPPORTED for such a set.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct jv_nvq jv_nvq;
+typedef struct jv_nvq_vectors jv_nvq_vectors;
+/* NVQuantization.create(globalMean, nSubVectors); global_mean: D floats (host or device) */
+JV_API int jv_hip_nvq_create(jv_ctx *ctx, int D, int n_subvectors, const float *global_mean, jv_nvq **out);
+/* NVQuantization.compute(ravv, nSubVectors): the mean is accumulated over the rows in order, on the device */
+JV_API int jv_hip_nvq_compute(jv_ctx *ctx, const jv_vectors *v, int n_subvectors, jv_nvq **out);
+JV_API int jv_hip_nvq_set_learn(jv_nvq *nvq, int learn); /* NVQuantization.learn (default 1) */
+JV_API int jv_hip_nvq_dimension(const jv_nvq *nvq);
+JV_API int jv_hip_nvq_subvectors(const jv_nvq *nvq);
+JV_API int jv_hip_nvq_global_mean(jv_ctx *ctx, const jv_nvq *nvq, float *dst);
+JV_API int jv_hip_nvq_destroy(jv_nvq *nvq);
+JV_API int jv_hip_nvq_vectors_create(jv_ctx *ctx, const jv_nvq *nvq, int64_t count, jv_nvq_vectors **out);
+/* encodeAll: rows [first, first + count) of v into rows [dst_first, ...) of dst */
+JV_API int jv_hip_nvq_encode(jv_ctx *ctx, const jv_nvq *nvq, const jv_vectors *v, int64_t first, int64_t count,
+                             jv_nvq_vectors *dst, int64_t dst_first);
+/* rows decoded from a file (jv_fmt_nvq_unpack); bytes: count x D, params: count x S x 4 (host or device) */
+JV_API int jv_hip_nvq_vectors_upload(jv_ctx *ctx, jv_nvq_vectors *nv, int64_t first, int64_t count, const uint8_t *bytes,
+                                     const float *params);
+JV_API int jv_hip_nvq_vectors_download(jv_ctx *ctx, const jv_nvq_vectors *nv, int64_t first, int64_t count, uint8_t *bytes,
+                                       float *params);
+JV_API int64_t jv_hip_nvq_vectors_count(const jv_nvq_vectors *nv);
+JV_API int jv_hip_nvq_vectors_destroy(jv_nvq_vectors *nv);
+/* scores_out[q][b] = NVQVectors.scoreFunctionFor(query q, vsf).similarityTo(ordinals[q*B + b]); ordinals outside
+ * [0, count) give -inf */
+JV_API int jv_hip_nvq_scores(jv_ctx *ctx, const jv_nvq_vectors *nv, const float *queries, int Q, jv_vsf vsf,
+                             const int32_t *ordinals, int B, float *scores_out);
+/* a jv_vectors whose rows are `nv` (which must outlive it); destroy with jv_hip_vectors_destroy */
+JV_API int jv_hip_vectors_from_nvq(jv_ctx *ctx, jv_nvq_vectors *nv, jv_vectors **out);
+
+/* ---------------------------------------------------------------------------------------------
  * Top-k under the NodeQueue total order — SURVEY §8a row 9
  *   replaces: NodeQueue.encode + BoundedLongHeap.push (B/graph/NodeQueue.java:125-129,
  *   B/util/BoundedLongHeap.java:59-69, B/util/NumericUtils.java:49-65): higher score first, ties -> smaller id.

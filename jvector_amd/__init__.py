@@ -14,6 +14,8 @@ from .engine import (  # noqa: F401
     GraphSearcher,
     SearchResult,
     HipContext,
+    NVQuantization,
+    NVQVectors,
     PQBuildScoreProvider,
     PQVectors,
     ProductQuantization,

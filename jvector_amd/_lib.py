@@ -129,6 +129,21 @@ SIGNATURES = {
     "jv_hip_comm_all_gather": (_i, [_p, _p, _p, _sz, _p]),
     "jv_hip_sharded_topk": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "jv_hip_sharded_search_flat": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "jv_hip_nvq_create": (_i, [_p, _i, _i, _p, C.POINTER(_p)]),
+    "jv_hip_nvq_compute": (_i, [_p, _p, _i, C.POINTER(_p)]),
+    "jv_hip_nvq_set_learn": (_i, [_p, _i]),
+    "jv_hip_nvq_dimension": (_i, [_p]),
+    "jv_hip_nvq_subvectors": (_i, [_p]),
+    "jv_hip_nvq_global_mean": (_i, [_p, _p, _p]),
+    "jv_hip_nvq_destroy": (_i, [_p]),
+    "jv_hip_nvq_vectors_create": (_i, [_p, _p, _i64, C.POINTER(_p)]),
+    "jv_hip_nvq_encode": (_i, [_p, _p, _p, _i64, _i64, _p, _i64]),
+    "jv_hip_nvq_vectors_upload": (_i, [_p, _p, _i64, _i64, _p, _p]),
+    "jv_hip_nvq_vectors_download": (_i, [_p, _p, _i64, _i64, _p, _p]),
+    "jv_hip_nvq_vectors_count": (_i64, [_p]),
+    "jv_hip_nvq_vectors_destroy": (_i, [_p]),
+    "jv_hip_nvq_scores": (_i, [_p, _p, _p, _i, _i, _p, _i, _p]),
+    "jv_hip_vectors_from_nvq": (_i, [_p, _p, C.POINTER(_p)]),
 }
 
 # the reference's per-pair SPI, exported unchanged (include/jvector_simd_compat.h)
@@ -179,6 +194,8 @@ class OdgiInfo(C.Structure):
         ("pq_off", C.c_int64), ("pq_len", C.c_int64), ("pq_M", C.c_int32),
         ("upper_off", C.c_int64), ("hierarchy_off", C.c_int64), ("hierarchy_count", C.c_int32),
         ("separated_vectors_off", C.c_int64),
+        ("nvq_off", C.c_int64), ("nvq_len", C.c_int64), ("nvq_S", C.c_int32), ("reserved0", C.c_int32),
+        ("nvq_stride", C.c_int64), ("nvq_inline_off", C.c_int64), ("separated_nvq_off", C.c_int64),
     ]
 
 
@@ -190,6 +207,11 @@ FORMAT_SIGNATURES = {
     "jv_fmt_odgi_read_l0": (_i, [_p, _sz, C.POINTER(OdgiInfo), _p, _p, _p]),
     "jv_fmt_odgi_read_level": (_i, [_p, _sz, C.POINTER(OdgiInfo), _i, _p, _p]),
     "jv_fmt_odgi_read_hierarchy_codes": (_i, [_p, _sz, C.POINTER(OdgiInfo), _p, _p]),
+    "jv_fmt_nvq_describe": (_i, [_p, _sz, C.POINTER(_sz), _ip, _ip, _ip, C.POINTER(_sz), C.POINTER(_i64)]),
+    "jv_fmt_nvq_read_mean": (_i, [_p, _sz, _p]),
+    "jv_fmt_nvqvectors_describe": (_i, [_p, _sz, C.POINTER(_sz), C.POINTER(_i64), C.POINTER(_sz), C.POINTER(_i64)]),
+    "jv_fmt_nvq_unpack": (_i, [_p, _sz, _i64, _i64, _i, _i, _p, _p]),
+    "jv_fmt_odgi_read_nvq": (_i, [_p, _sz, C.POINTER(OdgiInfo), _p, _p]),
     "jv_fmt_xvecs_describe": (_i, [_p, _sz, C.POINTER(_i64), _ip]),
     "jv_fmt_xvecs_read": (_i, [_p, _sz, _p]),
 }

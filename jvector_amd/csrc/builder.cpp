@@ -146,6 +146,7 @@ int jv_hip_builder_create(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, c
     clear_error();
     JV_REQUIRE(ctx && pq && codes && vectors && out, "builder_create: NULL argument");
     *out = nullptr;
+    JV_FLOAT_ROWS(vectors, "builder_create");
     JV_REQUIRE(vsf == JV_EUCLIDEAN || vsf == JV_DOT_PRODUCT || vsf == JV_COSINE, "Unsupported similarity function %d", (int)vsf);
     JV_REQUIRE(codes->pq == pq, "builder_create: the code store belongs to another quantizer");
     JV_REQUIRE(vectors->D == pq->D && vectors->count >= codes->count, "builder_create: vectors do not match the codes (%lld x %d vs %lld x %d)",

@@ -278,6 +278,7 @@ int jv_hip_ctx_destroy(jv_ctx *ctx)
     ctx->d_gs_out.release();
     ctx->d_gs_mask.release();
     ctx->d_gs_big.release();
+    ctx->d_nvq_q.release();
     for (auto &e : ctx->prof_pending) {
         (void)hipEventDestroy(e.start);
         (void)hipEventDestroy(e.stop);
@@ -758,6 +759,7 @@ int jv_hip_vectors_upload(jv_ctx *ctx, jv_vectors *v, int64_t first, int64_t cou
 {
     clear_error();
     JV_REQUIRE(ctx && v && src, "vectors_upload: NULL argument");
+    JV_FLOAT_ROWS(v, "vectors_upload");
     JV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->count, "vectors_upload: range out of bounds");
     JV_TRY(use_device(ctx->device));
     JV_HIP_CHECK(hipMemcpyAsync(v->d_vecs + first * v->D, src, sizeof(float) * (size_t)count * v->D, hipMemcpyDefault,
@@ -830,6 +832,7 @@ int jv_hip_pq_encode_into(jv_ctx *ctx, const jv_pq *pq, const jv_vectors *v, int
 {
     clear_error();
     JV_REQUIRE(ctx && pq && v && codes, "pq_encode_into: NULL argument");
+    JV_FLOAT_ROWS(v, "pq_encode_into");
     JV_REQUIRE(v->D == pq->D, "vector dimension %d does not match PQ dimension %d", v->D, pq->D);
     JV_REQUIRE(codes->M == pq->M, "code store M %d does not match PQ M %d", codes->M, pq->M);
     JV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->count && first + count <= codes->count,
@@ -1108,12 +1111,7 @@ int jv_hip_exact_scores(jv_ctx *ctx, const jv_vectors *v, const float *queries, 
     JV_TRY(ctx->d_scratch3.reserve(sizeof(float) * (size_t)Q));
     OutStage os;
     JV_TRY(stage_out_begin(ctx, scores_out, sizeof(float) * (size_t)Q * B, ctx->d_out, &os));
-    if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(v)));
-    {
-        ProfScope ps(ctx, R_EXACT);
-        JV_TRY(launch_exact_gather(ctx->stream, v->d_vecs, v->count, v->D, (const float *)d_q, Q, to_kernel_vsf(vsf),
-                                   (const int32_t *)d_ord, B, (float *)os.dev, (float *)ctx->d_scratch3.ptr, v->d_sqnorm));
-    }
+    JV_TRY(rerank_gather(ctx, v, (const float *)d_q, Q, vsf, (const int32_t *)d_ord, B, (float *)os.dev, (float *)ctx->d_scratch3.ptr));
     return stage_out_end(ctx, os);
 }
 
@@ -1122,6 +1120,7 @@ int jv_hip_exact_pair_scores(jv_ctx *ctx, const jv_vectors *v, jv_vsf vsf, const
 {
     clear_error();
     JV_REQUIRE(ctx && v, "exact_pair_scores: NULL argument");
+    JV_FLOAT_ROWS(v, "exact_pair_scores");
     JV_REQUIRE(P >= 0 && B >= 0, "exact_pair_scores: negative sizes");
     if (P == 0 || B == 0) return JV_OK;
     JV_REQUIRE(node1 && node2 && scores_out, "exact_pair_scores: NULL buffer");
@@ -1152,6 +1151,7 @@ int jv_hip_exact_scan(jv_ctx *ctx, const jv_vectors *v, const float *queries, in
 {
     clear_error();
     JV_REQUIRE(ctx && v, "exact_scan: NULL argument");
+    JV_FLOAT_ROWS(v, "exact_scan");
     JV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->count, "exact_scan: range out of bounds");
     if (Q == 0 || count == 0) return JV_OK;
     JV_REQUIRE(queries && scores_out, "exact_scan: NULL buffer");
@@ -1174,6 +1174,7 @@ int jv_hip_exact_scan_dense(jv_ctx *ctx, const jv_vectors *v, const float *queri
 {
     clear_error();
     JV_REQUIRE(ctx && v, "exact_scan_dense: NULL argument");
+    JV_FLOAT_ROWS(v, "exact_scan_dense");
     JV_REQUIRE(Q >= 0, "exact_scan_dense: negative query count");
     JV_REQUIRE(first >= 0 && count >= 0 && first + count <= v->count, "exact_scan_dense: range out of bounds");
     if (Q == 0 || count == 0) return JV_OK;
@@ -1347,12 +1348,7 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
 
     // ---------------- pass 2 ----------------
     if (rerank) {
-        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
-        {
-            ProfScope ps(ctx, R_EXACT);
-            JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q,
-                                       kvsf, d_cand, k1, d_exact, d_qnorm, vectors->d_sqnorm));
-        }
+        JV_TRY(rerank_gather(ctx, vectors, l->d_raw_queries, Q, vsf, d_cand, k1, d_exact, d_qnorm));
         ProfScope ps(ctx, R_TOPK);
         JV_TRY(launch_topk(ctx->stream, ctx, d_exact, d_cand, Q, k1, k1, 0, topK, (int32_t *)oi.dev, (float *)osc.dev,
                            ctx->d_scratch.ptr));

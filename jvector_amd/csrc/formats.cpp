@@ -103,6 +103,88 @@ int pq_walk(const uint8_t *buf, size_t len, PqShape *s)
     return JV_OK;
 }
 
+struct NvqShape {
+    size_t block_len, mean_off, sizes_off;
+    int version, D, S;
+    int64_t vector_stride;   // NVQuantization.compressedVectorSize :357-363
+};
+
+// NVQuantization.load :322-344 — [int version][int D][D floats][int bitsPerDimension][int S][S ints].  The device layout
+// derives the sub-vector split from (D, S) as NVQuantization.create does (getSubvectorSizesAndOffsets :236-252, the only way
+// the reference makes one); a file whose stored sizes differ from that split is refused.
+int nvq_walk(const uint8_t *buf, size_t len, NvqShape *s)
+{
+    Cursor c{buf, len, 0};
+    RD_NEED(c, 8, "nvq");
+    s->version = be32(buf);
+    const int D = be32(buf + 4);
+    c.pos = 8;
+    JV_REQUIRE(s->version >= 0 && s->version <= 6, "nvq: unsupported version %d", s->version);
+    JV_REQUIRE(D > 0 && D < (1 << 24), "nvq: implausible global mean length %d", D);
+    s->mean_off = c.pos;
+    RD_NEED(c, (size_t)D * 4, "nvq");
+    c.pos += (size_t)D * 4;
+    RD_NEED(c, 8, "nvq");
+    const int bits = be32(buf + c.pos), S = be32(buf + c.pos + 4);
+    c.pos += 8;
+    if (bits != 8) {   // BitsPerDimension.load :96-103
+        set_error("Unsupported BitsPerDimension %d", bits);
+        return JV_ERR_UNSUPPORTED;
+    }
+    JV_REQUIRE(S > 0 && S <= D, "nvq: %d sub-vectors for %d dimensions", S, D);
+    s->sizes_off = c.pos;
+    RD_NEED(c, (size_t)S * 4, "nvq");
+    int64_t total = 0;
+    s->vector_stride = 4;
+    for (int i = 0; i < S; ++i, c.pos += 4) {
+        const int sz = be32(buf + c.pos), want = D / S + (i < D % S ? 1 : 0);
+        if (sz != want) {
+            set_error("nvq: sub-vector %d has %d dimensions, NVQuantization.create(%d, %d) gives %d", i, sz, D, S, want);
+            return JV_ERR_UNSUPPORTED;
+        }
+        total += sz;
+        s->vector_stride += (int64_t)sz + 4 * 4 + 3 * 4;   // QuantizedSubVector.compressedVectorSize :497-503
+    }
+    JV_REQUIRE(total == D, "Global mean length %d does not match vector dimensionality %lld", D, (long long)total);
+    s->D = D;
+    s->S = S;
+    s->block_len = c.pos;
+    return JV_OK;
+}
+
+// QuantizedVector.load :449-458 / QuantizedSubVector.load :605-617 for `count` records `stride` bytes apart
+int nvq_unpack(const uint8_t *src, size_t len, int64_t stride, int64_t count, int D, int S, uint8_t *bytes, float *params)
+{
+    JV_REQUIRE(stride > 0 && count >= 0 && (count == 0 || ((uint64_t)(count - 1) * (uint64_t)stride <= len)), "nvq_unpack: records out of range");
+    for (int64_t r = 0; r < count; ++r) {
+        Cursor c{src, len, (size_t)(r * stride)};
+        RD_NEED(c, 4, "nvq vector");
+        const int ns = be32(src + c.pos);
+        c.pos += 4;
+        JV_REQUIRE(ns == S, "nvq vector %lld has %d sub-vectors, the quantizer %d", (long long)r, ns, S);
+        int off = 0;
+        for (int i = 0; i < S; ++i) {
+            const int want = D / S + (i < D % S ? 1 : 0);
+            RD_NEED(c, 28, "nvq vector");
+            const int bits = be32(src + c.pos);
+            if (bits != 8) {
+                set_error("Unsupported BitsPerDimension %d", bits);
+                return JV_ERR_UNSUPPORTED;
+            }
+            if (params) copy_be32(params + (r * S + i) * 4, src + c.pos + 4, 4);   // minValue, maxValue, growthRate, midpoint
+            const int od = be32(src + c.pos + 20), nb = be32(src + c.pos + 24);
+            c.pos += 28;
+            JV_REQUIRE(od == want && nb == want, "nvq vector %lld sub-vector %d: %d dimensions in %d bytes, expected %d", (long long)r, i, od,
+                       nb, want);
+            RD_NEED(c, (size_t)nb, "nvq vector");
+            if (bytes) memcpy(bytes + r * D + off, src + c.pos, (size_t)nb);
+            c.pos += (size_t)nb;
+            off += nb;
+        }
+    }
+    return JV_OK;
+}
+
 // CommonHeader.load :116-152
 int common_header(Cursor &c, jv_odgi_info *o)
 {
@@ -182,6 +264,9 @@ int full_header(Cursor &c, jv_odgi_info *o)
     o->pq_len = 0;
     o->pq_M = 0;
     o->separated_vectors_off = -1;
+    o->nvq_off = o->nvq_inline_off = o->separated_nvq_off = -1;
+    o->nvq_len = o->nvq_stride = 0;
+    o->nvq_S = 0;
     for (int i = 0; i < o->n_features; ++i) {
         if (o->version >= 6) {
             RD_NEED(c, 4, "odgi features");
@@ -212,10 +297,27 @@ int full_header(Cursor &c, jv_odgi_info *o)
             o->separated_vectors_off = be64(c.buf + c.pos);
             c.pos += 8;
             break;
-        case JV_FEATURE_NVQ_VECTORS:
-        case JV_FEATURE_SEPARATED_NVQ:
-            set_error("odgi: NVQ features are not decoded by this reader");
-            return JV_ERR_UNSUPPORTED;
+        case JV_FEATURE_NVQ_VECTORS:      // header = the NVQuantization block (NVQ.java:64-76), inline = one QuantizedVector
+        case JV_FEATURE_SEPARATED_NVQ: {  // header = the block + long offset (SeparatedNVQ.java:78-82,100-108)
+            JV_REQUIRE(o->nvq_off < 0, "odgi: more than one NVQ feature");
+            NvqShape ns;
+            JV_TRY(nvq_walk(c.buf + c.pos, c.len - c.pos, &ns));
+            JV_REQUIRE(ns.D == o->dimension, "odgi: NVQ dimension %d != index dimension %d", ns.D, o->dimension);
+            o->nvq_off = (int64_t)c.pos;
+            o->nvq_len = (int64_t)ns.block_len;
+            o->nvq_S = ns.S;
+            o->nvq_stride = ns.vector_stride;
+            c.pos += ns.block_len;
+            if (o->feature_id[i] == JV_FEATURE_NVQ_VECTORS) {
+                o->nvq_inline_off = 4 + inline_bytes;
+                inline_bytes += ns.vector_stride;
+            } else {
+                RD_NEED(c, 8, "odgi features");
+                o->separated_nvq_off = be64(c.buf + c.pos);
+                c.pos += 8;
+            }
+            break;
+        }
         default:
             JV_REQUIRE(false, "odgi: unknown feature id %d", o->feature_id[i]);
         }
@@ -329,6 +431,90 @@ int jv_fmt_odgi_describe(const uint8_t *buf, size_t len, jv_odgi_info *info)
     if (o->separated_vectors_off >= 0)
         JV_REQUIRE(range_ok(o->separated_vectors_off, (int64_t)o->id_upper_bound * o->dimension * 4, len),
                    "odgi: separated vectors run past the end of the input");
+    if (o->separated_nvq_off >= 0)
+        JV_REQUIRE(range_ok(o->separated_nvq_off, (int64_t)o->id_upper_bound * o->nvq_stride, len),
+                   "odgi: separated NVQ vectors run past the end of the input");
+    return JV_OK;
+}
+
+int jv_fmt_nvq_describe(const uint8_t *buf, size_t len, size_t *block_len, int *version, int *D, int *n_subvectors, size_t *mean_off,
+                        int64_t *vector_stride)
+{
+    clear_error();
+    JV_REQUIRE(buf, "nvq_describe: NULL buffer");
+    NvqShape s;
+    JV_TRY(nvq_walk(buf, len, &s));
+    if (block_len) *block_len = s.block_len;
+    if (version) *version = s.version;
+    if (D) *D = s.D;
+    if (n_subvectors) *n_subvectors = s.S;
+    if (mean_off) *mean_off = s.mean_off;
+    if (vector_stride) *vector_stride = s.vector_stride;
+    return JV_OK;
+}
+
+int jv_fmt_nvq_read_mean(const uint8_t *buf, size_t len, float *global_mean)
+{
+    clear_error();
+    JV_REQUIRE(buf && global_mean, "nvq_read_mean: NULL argument");
+    NvqShape s;
+    JV_TRY(nvq_walk(buf, len, &s));
+    copy_be32(global_mean, buf + s.mean_off, (size_t)s.D);
+    return JV_OK;
+}
+
+int jv_fmt_nvqvectors_describe(const uint8_t *buf, size_t len, size_t *nvq_block_len, int64_t *count, size_t *vectors_off,
+                               int64_t *vector_stride)
+{
+    clear_error();
+    JV_REQUIRE(buf, "nvqvectors_describe: NULL buffer");
+    NvqShape s;
+    JV_TRY(nvq_walk(buf, len, &s));
+    Cursor c{buf, len, s.block_len};
+    RD_NEED(c, 4, "nvqvectors");
+    const int32_t n = be32(buf + c.pos);   // NVQVectors.load :73-77
+    c.pos += 4;
+    JV_REQUIRE(n >= 0, "Invalid compressed vector count %d", n);
+    JV_REQUIRE(range_ok((int64_t)c.pos, (int64_t)n * s.vector_stride, len), "nvqvectors: %d vectors of %lld bytes run past the end of the input",
+               n, (long long)s.vector_stride);
+    if (nvq_block_len) *nvq_block_len = s.block_len;
+    if (count) *count = n;
+    if (vectors_off) *vectors_off = c.pos;
+    if (vector_stride) *vector_stride = s.vector_stride;
+    return JV_OK;
+}
+
+int jv_fmt_nvq_unpack(const uint8_t *src, size_t len, int64_t stride, int64_t count, int D, int n_subvectors, uint8_t *bytes, float *params)
+{
+    clear_error();
+    JV_REQUIRE(src, "nvq_unpack: NULL buffer");
+    JV_REQUIRE(D > 0 && n_subvectors > 0 && n_subvectors <= D, "nvq_unpack: bad shape %d / %d", D, n_subvectors);
+    return nvq_unpack(src, len, stride, count, D, n_subvectors, bytes, params);
+}
+
+int jv_fmt_odgi_read_nvq(const uint8_t *buf, size_t len, const jv_odgi_info *o, uint8_t *bytes, float *params)
+{
+    clear_error();
+    JV_TRY(check_info(buf, len, o, "odgi_read_nvq"));
+    JV_REQUIRE(o->nvq_off >= 0 && (o->nvq_inline_off >= 0 || o->separated_nvq_off >= 0), "odgi_read_nvq: the index has no NVQ feature");
+    const int64_t N = o->id_upper_bound;
+    if (o->nvq_inline_off < 0) {
+        JV_REQUIRE(range_ok(o->separated_nvq_off, N * o->nvq_stride, len), "odgi_read_nvq: separated NVQ vectors out of range");
+        return nvq_unpack(buf + o->separated_nvq_off, len - (size_t)o->separated_nvq_off, o->nvq_stride, N, o->dimension, o->nvq_S, bytes,
+                          params);
+    }
+    // inline: a placeholder record (ordinal -1, jv_fmt_odgi_read_l0) carries unspecified feature bytes -> zeroed row
+    const int D = o->dimension, S = o->nvq_S;
+    for (int64_t i = 0; i < N; ++i) {
+        const uint8_t *rec = buf + o->l0_off + i * o->record_stride;
+        if (be32(rec) == -1) {
+            if (bytes) memset(bytes + i * D, 0, (size_t)D);
+            if (params) memset(params + i * 4 * S, 0, sizeof(float) * 4 * (size_t)S);
+            continue;
+        }
+        JV_TRY(nvq_unpack(rec + o->nvq_inline_off, (size_t)o->nvq_stride, o->nvq_stride, 1, D, S, bytes ? bytes + i * D : nullptr,
+                          params ? params + i * 4 * S : nullptr));
+    }
     return JV_OK;
 }
 

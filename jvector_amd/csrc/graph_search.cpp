@@ -716,12 +716,7 @@ static int rerank_stage(jv_ctx *ctx, HostPool *pool, jv_luts *l, const jv_vector
         float *d_cand_sc = (float *)(d_cand + c1);
         float *d_qnorm = d_cand_sc + c1;
         JV_HIP_CHECK(hipMemcpyAsync(d_cand, ctx->h_in.ptr, sizeof(int32_t) * c1, hipMemcpyHostToDevice, ctx->stream));
-        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
-        {
-            ProfScope ps(ctx, R_EXACT);
-            JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf, d_cand, Rmax,
-                                       d_cand_sc, d_qnorm, vectors->d_sqnorm));
-        }
+        JV_TRY(rerank_gather(ctx, vectors, l->d_raw_queries, Q, vsf, d_cand, Rmax, d_cand_sc, d_qnorm));
         JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_cand_sc, sizeof(float) * c1, hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         h_exact.assign((const float *)ctx->h_out.ptr, (const float *)ctx->h_out.ptr + c1);
@@ -1572,12 +1567,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_scratch2, &oi));
     JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * topK, ctx->d_scratch3, &osc));
     JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, topK)));
-    if (vectors) {
-        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
-        ProfScope ps(ctx, R_EXACT);
-        JV_TRY(launch_exact_gather(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf, d_cand,
-                                   rerankK, d_cand_sc, d_qnorm, vectors->d_sqnorm));
-    }
+    if (vectors) JV_TRY(rerank_gather(ctx, vectors, l->d_raw_queries, Q, vsf, d_cand, rerankK, d_cand_sc, d_qnorm));
     {
         ProfScope ps(ctx, R_TOPK);
         JV_TRY(launch_topk(ctx->stream, ctx, d_cand_sc, d_cand, Q, rerankK, rerankK, 0, topK, (int32_t *)oi.dev,

@@ -40,6 +40,15 @@ void clear_error();
         }                                \
     } while (0)
 
+// entry points that read the float rows of a jv_vectors refuse a set made by jv_hip_vectors_from_nvq
+#define JV_FLOAT_ROWS(v, what)                                                       \
+    do {                                                                             \
+        if ((v)->nvq) {                                                              \
+            jv::set_error("%s: the vector set holds NVQ rows, not floats", what);   \
+            return JV_ERR_UNSUPPORTED;                                               \
+        }                                                                            \
+    } while (0)
+
 #define JV_TRY(expr)                 \
     do {                             \
         int _s = (expr);             \
@@ -80,6 +89,7 @@ struct jv_ctx {
     jv::Buffer h_in, h_out, d_in, d_out, d_scratch, d_scratch2, d_scratch3;
     // device-resident graph traversal: per-worker visited tables / spill tiers and the per-query result staging
     jv::Buffer d_gs_visited, d_gs_spill, d_gs_out, d_gs_mask, d_gs_big;
+    jv::Buffer d_nvq_q;   // NVQ rerank: shifted queries + per-query scalars (nvq.cpp)
     // host batched graph searcher: worker pool (graph_search.cpp owns the type) and its destructor
     void *host_pool = nullptr;
     void (*host_pool_destroy)(void *) = nullptr;
@@ -155,6 +165,31 @@ struct jv_vectors {
     // ensure_vector_norms, invalidated by uploads
     float *d_sqnorm = nullptr;
     bool sqnorm_valid = false;
+    // jv_hip_vectors_from_nvq: no float rows at all (d_vecs == nullptr) — every rerank through this set scores the NVQ rows
+    // (NVQ.rerankerFor, B/graph/disk/feature/NVQ.java:96-110); calls that need the floats themselves refuse it
+    struct jv_nvq_vectors *nvq = nullptr;
+};
+
+// NVQuantization (B/quantization/NVQuantization.java): the global mean and the sub-vector split
+struct jv_nvq {
+    int device = 0;
+    int D = 0, S = 0;
+    bool learn = true;           // NVQuantization.learn (:129): false = growthRate 1e-2f without the search
+    float *d_mean = nullptr;     // D
+    float *d_grid = nullptr;     // growth-rate candidates of quantizeTo's two loops (k_nvq.hip nvq_encode_kernel)
+};
+
+// NVQVectors on the device (layout: k_nvq.hip header)
+struct jv_nvq_vectors {
+    int device = 0;
+    const jv_nvq *nvq = nullptr;
+    int64_t count = 0;
+    int ld = 0;                  // row stride of d_bytes: D rounded up to 16
+    uint8_t *d_bytes = nullptr;
+    float *d_params = nullptr;   // count x S x {min, max, growthRate, midpoint}
+    float *d_derived = nullptr;  // count x S x {1/scaledGrowthRate, scaledMidpoint, logisticScale, logisticBias}
+    float *d_cosnorm = nullptr;  // count (cosine only, lazily)
+    bool derived_valid = false, cosnorm_valid = false;
 };
 
 struct jv_pair_table {   // ProductQuantization.createCodebookPartialSums on the device (build_score.cpp)
@@ -266,6 +301,21 @@ int launch_gather_rows(hipStream_t s, const float *d_vecs, int64_t n, int D, con
 int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf,
                         const int32_t *d_ord, int B, float *d_out, float *d_qnorm, const float *d_vnorm);
 int launch_row_sqnorms(hipStream_t s, const float *d_vecs, int64_t n, int D, float *d_out);
+// NVQ (k_nvq.hip)
+int launch_nvq_mean(hipStream_t s, const float *d_vecs, int64_t n, int D, float *d_mean);
+size_t nvq_encode_lds_bytes(int D, int S);
+int launch_nvq_encode(hipStream_t s, const jv_ctx *ctx, const float *d_vecs, int64_t count, int D, int S, const float *d_mean, int learn,
+                      const float *d_grid, uint8_t *d_bytes, int ld, float *d_params);
+int launch_nvq_derive(hipStream_t s, const float *d_params, int64_t units, float *d_derived);
+int launch_nvq_cosnorm(hipStream_t s, const uint8_t *d_bytes, int ld, int64_t n, int D, int S, const float *d_derived, const float *d_mean,
+                       float *d_out);
+int launch_nvq_gather(hipStream_t s, const uint8_t *d_bytes, int ld, int64_t n, int D, int S, const float *d_derived, const float *d_cosnorm,
+                      const float *d_mean, const float *d_q, int Q, int vsf, const int32_t *d_ord, int B, float *d_out, float *d_qwork,
+                      float *d_qaux);
+// the reranker of a vector set (nvq.cpp): full-resolution rows through launch_exact_gather (cosine: the norm table is
+// made first), NVQ rows for a set made by jv_hip_vectors_from_nvq.  d_qnorm: Q floats of scratch.
+int rerank_gather(jv_ctx *ctx, const jv_vectors *v, const float *d_q, int Q, jv_vsf vsf, const int32_t *d_ord, int B, float *d_out,
+                  float *d_qnorm);
 // MFMA tile form (k_exact_dense.hip / ed_body.h): fused chains, not bit-identical to launch_exact_scan
 int launch_exact_scan_dense(hipStream_t s, const float *d_vecs, int D, const float *d_q, int Q, int vsf, int64_t first,
                             int64_t count, float *d_out);

@@ -389,15 +389,11 @@ int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts 
     JV_TRY(comm->exact.reserve(sizeof(float) * cells * n_local));
     JV_TRY(comm->all_exact.reserve(sizeof(float) * cells * P));
     JV_TRY(ctx->d_in.reserve(sizeof(float) * (size_t)Q));
-    const int kvsf = to_kernel_vsf(vsf);
     for (int s = 0; s < n_local; ++s) {
-        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors[s])));
         JV_TRY(launch_shard_localize(ctx->stream, (const int32_t *)comm->cand.ptr, (int64_t)cells, id_base[s], codes[s]->count,
                                      (int32_t *)comm->local.ptr));
-        ProfScope ps(ctx, R_EXACT);
-        JV_TRY(launch_exact_gather(ctx->stream, vectors[s]->d_vecs, vectors[s]->count, vectors[s]->D, luts->d_raw_queries, Q, kvsf,
-                                   (const int32_t *)comm->local.ptr, k, (float *)comm->exact.ptr + cells * s, (float *)ctx->d_in.ptr,
-                                   vectors[s]->d_sqnorm));
+        JV_TRY(rerank_gather(ctx, vectors[s], luts->d_raw_queries, Q, vsf, (const int32_t *)comm->local.ptr, k,
+                             (float *)comm->exact.ptr + cells * s, (float *)ctx->d_in.ptr));
     }
     JV_TRY(all_gather(ctx, comm, comm->exact.ptr, comm->all_exact.ptr, cells * n_local, kNcclFloat32, 4));
     JV_TRY(launch_shard_select(ctx->stream, (const int32_t *)comm->cand.ptr, (const float *)comm->all_exact.ptr,

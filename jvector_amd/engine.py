@@ -296,6 +296,16 @@ class VectorSet:
             check(self._lib.jv_hip_vectors_upload(ctx._h, h, 0, n, p))
         self._h, self.count, self.dimension = h, n, D
 
+    @classmethod
+    def _from_nvq(cls, nvq_vectors):
+        self = cls.__new__(cls)
+        self.ctx, self._lib = nvq_vectors.ctx, nvq_vectors._lib
+        h = C.c_void_p()
+        check(self._lib.jv_hip_vectors_from_nvq(self.ctx._h, nvq_vectors._h, C.byref(h)))
+        self._h, self.count, self.dimension = h, nvq_vectors.count(), nvq_vectors.nvq.dimension
+        self._keep = nvq_vectors   # the rows must outlive the handle
+        return self
+
     def size(self):
         return self.count
 
@@ -342,6 +352,134 @@ class VectorSet:
     def close(self):
         if getattr(self, "_h", None):
             self._lib.jv_hip_vectors_destroy(self._h)
+            self._h = None
+
+
+@_finalizer
+class NVQuantization:
+    """NVQuantization (B/quantization/NVQuantization.java): the global mean + the split into sub-vectors; encodes on the GPU."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._lib, self._h = ctx, ctx._lib, handle
+        self.dimension = int(self._lib.jv_hip_nvq_dimension(handle))
+        self.subvectors = int(self._lib.jv_hip_nvq_subvectors(handle))
+        self.learn = True
+
+    @classmethod
+    def create(cls, ctx, global_mean, n_subvectors):
+        """NVQuantization.create(globalMean, nSubVectors) :170-173"""
+        h = C.c_void_p()
+        p, keep = _ptr(global_mean, np.float32)
+        check(ctx._lib.jv_hip_nvq_create(ctx._h, int(global_mean.shape[0]), int(n_subvectors), p, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def compute(cls, ctx, vectors: "VectorSet", n_subvectors):
+        """NVQuantization.compute(ravv, nSubVectors) :153-163 — the mean is accumulated on the device, rows in order"""
+        h = C.c_void_p()
+        check(ctx._lib.jv_hip_nvq_compute(ctx._h, vectors._h, int(n_subvectors), C.byref(h)))
+        return cls(ctx, h)
+
+    def set_learn(self, learn):
+        check(self._lib.jv_hip_nvq_set_learn(self._h, int(bool(learn))))
+        self.learn = bool(learn)
+        return self
+
+    def global_mean(self):
+        out = np.empty(self.dimension, np.float32)
+        check(self._lib.jv_hip_nvq_global_mean(self.ctx._h, self._h, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def subvector_sizes(self):
+        """getSubvectorSizesAndOffsets :236-252 -> sizes"""
+        base, rem = divmod(self.dimension, self.subvectors)
+        return [base + (1 if i < rem else 0) for i in range(self.subvectors)]
+
+    def encode_all(self, vectors: "VectorSet", first=0, count=None) -> "NVQVectors":
+        """encodeAll :182-195"""
+        count = vectors.count - first if count is None else int(count)
+        out = NVQVectors(self.ctx, self, count=count)
+        check(self._lib.jv_hip_nvq_encode(self.ctx._h, self._h, vectors._h, int(first), count, out._h, 0))
+        return out
+
+    def write(self, version=6) -> bytes:
+        """NVQuantization.write :260-277"""
+        be = lambda v: np.asarray(v, np.int64).astype(np.uint32).astype(">u4").tobytes()  # noqa: E731
+        return (be([version, self.dimension]) + self.global_mean().astype(">f4").tobytes() + be([8, self.subvectors])
+                + be(self.subvector_sizes()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_nvq_destroy(self._h)
+            self._h = None
+
+
+@_finalizer
+class NVQVectors:
+    """NVQVectors (B/quantization/NVQVectors.java) resident on the device: one byte per dimension + four floats per
+    sub-vector.  `as_vector_set()` is the reranker a graph with the NVQ_VECTORS feature uses (NVQ.rerankerFor)."""
+
+    def __init__(self, ctx, nvq: NVQuantization, bytes_=None, params=None, count=None):
+        self.ctx, self._lib, self.nvq = ctx, ctx._lib, nvq
+        n = int(count if bytes_ is None else bytes_.shape[0])
+        h = C.c_void_p()
+        check(self._lib.jv_hip_nvq_vectors_create(ctx._h, nvq._h, n, C.byref(h)))
+        self._h, self._count = h, n
+        if bytes_ is not None:
+            self.upload(0, bytes_, params)
+
+    def count(self):
+        return self._count
+
+    def upload(self, first, bytes_, params):
+        n = int(bytes_.shape[0])
+        if tuple(bytes_.shape) != (n, self.nvq.dimension) or int(np.prod(params.shape)) != n * self.nvq.subvectors * 4:
+            raise ValueError("NVQ rows: bytes must be count x D and params count x S x 4")
+        b_p, bk = _ptr(bytes_, np.uint8)
+        p_p, pk = _ptr(params, np.float32)
+        check(self._lib.jv_hip_nvq_vectors_upload(self.ctx._h, self._h, int(first), n, b_p, p_p))
+
+    def get(self, first=0, count=None):
+        """-> (bytes[count, D] uint8, params[count, S, 4] float32 = {minValue, maxValue, growthRate, midpoint})"""
+        count = self._count - first if count is None else int(count)
+        b = np.empty((count, self.nvq.dimension), np.uint8)
+        p = np.empty((count, self.nvq.subvectors, 4), np.float32)
+        check(self._lib.jv_hip_nvq_vectors_download(self.ctx._h, self._h, int(first), count, C.c_void_p(b.ctypes.data),
+                                                    C.c_void_p(p.ctypes.data)))
+        return b, p
+
+    def scores(self, queries, vsf, ordinals):
+        """out[q, j] = scoreFunctionFor(queries[q], vsf).similarityTo(ordinals[q, j]) (NVQVectors.java:110-113)"""
+        Q, B = int(ordinals.shape[0]), int(ordinals.shape[1])
+        q_p, qk = _ptr(queries, np.float32)
+        o_p, ok = _ptr(ordinals, np.int32)
+        out = _empty((Q, B), np.float32, ordinals)
+        out_p, outk = _ptr(out, np.float32)
+        check(self._lib.jv_hip_nvq_scores(self.ctx._h, self._h, q_p, Q, int(vsf), o_p, B, out_p))
+        return out
+
+    def as_vector_set(self) -> "VectorSet":
+        """a VectorSet whose rerank goes through these rows (jv_hip_vectors_from_nvq); pass it wherever `vectors` goes"""
+        return VectorSet._from_nvq(self)
+
+    def write(self, version=6) -> bytes:
+        """NVQVectors.write :50-62 (QuantizedVector.write :437-443, QuantizedSubVector.write :577-587)"""
+        b, p = self.get()
+        n, S = self._count, self.nvq.subvectors
+        be32 = lambda v: np.asarray(v, np.int64).astype(np.uint32).astype(">u4")  # noqa: E731
+        cols = [np.broadcast_to(be32([S]).view(np.uint8), (n, 4))]
+        off = 0
+        for s, size in enumerate(self.nvq.subvector_sizes()):
+            cols.append(np.broadcast_to(be32([8]).view(np.uint8), (n, 4)))
+            cols.append(np.ascontiguousarray(p[:, s, :]).astype(">f4").view(np.uint8).reshape(n, 16))
+            cols.append(np.broadcast_to(be32([size, size]).view(np.uint8), (n, 8)))
+            cols.append(b[:, off:off + size])
+            off += size
+        return self.nvq.write(version) + be32([n]).tobytes() + np.concatenate(cols, axis=1).tobytes()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.jv_hip_nvq_vectors_destroy(self._h)
             self._h = None
 
 

@@ -92,6 +92,49 @@ def load_pqvectors(ctx, data):
     return pq, PQVectors(ctx, pq, np.ascontiguousarray(a[off:off + cnt * M].reshape(cnt, M)))
 
 
+# ---- NVQuantization / NVQVectors -------------------------------------------------------------------------------
+def describe_nvq(data):
+    """-> (block_len, version, D, S, vector_stride) of an NVQuantization.write block"""
+    lib = load()
+    a, p, n = _buf(data)
+    bl, ver, D, S, mo, st = C.c_size_t(), C.c_int(), C.c_int(), C.c_int(), C.c_size_t(), C.c_int64()
+    check(lib.jv_fmt_nvq_describe(p, n, C.byref(bl), C.byref(ver), C.byref(D), C.byref(S), C.byref(mo), C.byref(st)))
+    return bl.value, ver.value, D.value, S.value, st.value
+
+
+def read_nvq_mean(data) -> np.ndarray:
+    lib = load()
+    a, p, n = _buf(data)
+    _, _, D, _, _ = describe_nvq(a)
+    mean = np.empty(D, np.float32)
+    check(lib.jv_fmt_nvq_read_mean(p, n, C.c_void_p(mean.ctypes.data)))
+    return mean
+
+
+def read_nvqvectors(data):
+    """NVQVectors.load (B/quantization/NVQVectors.java:64-84), host only: -> (mean[D], S, bytes[count, D], params[count, S, 4])"""
+    lib = load()
+    a, p, n = _buf(data)
+    bl, cnt, off, st = C.c_size_t(), C.c_int64(), C.c_size_t(), C.c_int64()
+    check(lib.jv_fmt_nvqvectors_describe(p, n, C.byref(bl), C.byref(cnt), C.byref(off), C.byref(st)))
+    _, _, D, S, _ = describe_nvq(a[:bl.value])
+    mean = read_nvq_mean(a[:bl.value])
+    b = np.empty((cnt.value, D), np.uint8)
+    prm = np.empty((cnt.value, S, 4), np.float32)
+    body = a[off.value:]
+    check(lib.jv_fmt_nvq_unpack(C.c_void_p(body.ctypes.data if body.size else None), body.size, st.value, cnt.value, D, S,
+                                C.c_void_p(b.ctypes.data), C.c_void_p(prm.ctypes.data)))
+    return mean, S, b, prm
+
+
+def load_nvqvectors(ctx, data):
+    """NVQVectors.load -> (NVQuantization, NVQVectors) resident on ctx's device"""
+    from .engine import NVQuantization, NVQVectors
+    mean, S, b, prm = read_nvqvectors(data)
+    nvq = NVQuantization.create(ctx, mean, S)
+    return nvq, NVQVectors(ctx, nvq, b, prm)
+
+
 # ---- OnDiskGraphIndex ------------------------------------------------------------------------------------------
 @dataclass
 class OnDiskGraph:
@@ -109,6 +152,9 @@ class OnDiskGraph:
     hierarchy_nodes: np.ndarray | None = None
     hierarchy_codes: np.ndarray | None = None
     info: OdgiInfo = field(default=None, repr=False)
+    nvq_block: bytes | None = None          # NVQ_VECTORS / SEPARATED_NVQ header: the NVQuantization block
+    nvq_bytes: np.ndarray | None = None     # N x D uint8
+    nvq_params: np.ndarray | None = None    # N x S x 4 float32 {minValue, maxValue, growthRate, midpoint}
 
     def codes_from_fused(self) -> np.ndarray:
         """Rebuild the N x M code table from the fused blocks (+ hierarchy source codes): a node's code sits in the
@@ -163,8 +209,14 @@ def read_odgi(data, want_vectors=True) -> OnDiskGraph:
                                                    C.c_void_p(h_codes.ctypes.data)))
     pq_bytes = a[info.pq_off:info.pq_off + info.pq_len].tobytes() if info.pq_off >= 0 else None
     feats = tuple(FEATURE_NAMES[info.feature_id[i]] for i in range(info.n_features))
+    nvq_block = nvq_b = nvq_p = None
+    if info.nvq_off >= 0:
+        nvq_block = a[info.nvq_off:info.nvq_off + info.nvq_len].tobytes()
+        nvq_b = np.empty((N, D), dtype=np.uint8)
+        nvq_p = np.empty((N, info.nvq_S, 4), dtype=np.float32)
+        check(lib.jv_fmt_odgi_read_nvq(p, n, C.byref(info), C.c_void_p(nvq_b.ctypes.data), C.c_void_p(nvq_p.ctypes.data)))
     return OnDiskGraph(info.version, D, info.entry_node, info.entry_level, N, feats, levels, vectors, fused, pq_bytes,
-                       h_nodes, h_codes, info)
+                       h_nodes, h_codes, info, nvq_block, nvq_b, nvq_p)
 
 
 @dataclass
@@ -176,6 +228,8 @@ class LoadedIndex:
     fused: object
     vectors: object
     host: OnDiskGraph
+    nvq: object = None
+    nvq_vectors: object = None
 
     def searcher(self, max_queries=4096):
         from .engine import GraphSearcher
@@ -202,8 +256,17 @@ def load_index(ctx, odgi_data, pqvectors_data=None) -> LoadedIndex:
         raise ValueError("no PQ codes: the index has no FUSED_PQ feature and no PQVectors blob was given")
     fused = FusedPQ(ctx, pq, g.fused_blocks.reshape(g.id_upper_bound, -1), g.levels[0][1]) if g.fused_blocks is not None else None
     vectors = VectorSet(ctx, g.vectors) if g.vectors is not None else None
+    nvq = nvq_vectors = None
+    if g.nvq_block is not None:
+        # NVQ_VECTORS / SEPARATED_NVQ: the reranker is the NVQ score function; View.rerankerFor (OnDiskGraphIndex.java:705-713)
+        # prefers INLINE_VECTORS when the index carries both
+        from .engine import NVQuantization, NVQVectors
+        nvq = NVQuantization.create(ctx, read_nvq_mean(g.nvq_block), g.nvq_params.shape[1])
+        nvq_vectors = NVQVectors(ctx, nvq, g.nvq_bytes, g.nvq_params)
+        if vectors is None:
+            vectors = nvq_vectors.as_vector_set()
     graph = GraphIndex(ctx, g.id_upper_bound, g.levels, g.entry_node, g.entry_level)
-    return LoadedIndex(graph, pq, cv, fused, vectors, g)
+    return LoadedIndex(graph, pq, cv, fused, vectors, g, nvq, nvq_vectors)
 
 
 # ---- writers: the byte formats JVector reads back ---------------------------------------------------------------

@@ -797,6 +797,14 @@ static inline float compare_x(int vsf, const float *a, const float *b, int n)
 {
     return g_simd ? jvs_compare(vsf, a, b, n) : jvo_compare(vsf, a, b, n);
 }
+/* the reranker of the search entry points: full-resolution rows (view.rerankerFor with INLINE_VECTORS) or, after
+ * jvo_set_nvq_reranker (jv_nvq.c), the NVQ feature's score function (B/graph/disk/feature/NVQ.java:96-110); `vecs` is then
+ * only the "rerank at all" flag */
+static inline float rerank_x(int vsf, const float *query, const float *vecs, int32_t id, int D)
+{
+    if (jvo_nvq_reranker_active()) return jvo_nvq_rerank_score(vsf, query, id);
+    return compare_x(vsf, query, vecs + (size_t)id * D, D);
+}
 
 static void build_tables(const jvo_pq *pq, const float *cq, int lutVsf, float *lut, float *amag)
 {
@@ -1172,7 +1180,7 @@ static void *flat_worker(void *arg)
             int s2 = 0;
             for (int c = 0; c < size; c++) {
                 int32_t id = (int32_t)~(uint32_t)(heap[c] & 0xFFFFFFFFLL);
-                float ex = compare_x(j->vsf, query, j->vecs + (size_t)id * D, D);
+                float ex = rerank_x(j->vsf, query, j->vecs, id, D);
                 s2 = topk_heap_push(heap2, s2, j->topK, jvo_nodequeue_encode(id, ex));
             }
             res = heap2;
@@ -1452,7 +1460,7 @@ void jvo_graph_search_filtered(const jvo_graph *g, const jvo_pq *pq, const uint8
     if (vecs) {
         for (int i = 0; i < res.n; i++) {
             int32_t id = key_node(res.a[i]);
-            float ex = compare_x(vsf, query, vecs + (size_t)id * pq->D, pq->D);
+            float ex = rerank_x(vsf, query, vecs, id, pq->D);
             if (nf < topK) jvo_nodequeue_push(fin, &nf, 0, 0, id, ex);
             else if (ex > key_score(fin[0])) jvo_nodequeue_push(fin, &nf, topK, 0, id, ex);
         }
@@ -1649,7 +1657,7 @@ static float searcher_exact(jvo_searcher *s, int32_t node)  /* CachingReranker.s
 {
     if (s->cached[node]) return s->cache_val[node];
     s->rerank_calls++;
-    float ex = compare_x(s->vsf, s->query, s->vecs + (size_t)node * s->pq->D, s->pq->D);
+    float ex = rerank_x(s->vsf, s->query, s->vecs, node, s->pq->D);
     s->cached[node] = 1;
     s->cache_val[node] = ex;
     return ex;

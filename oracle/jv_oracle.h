@@ -222,6 +222,34 @@ int   jvo_set_simd(int on);
 float jvo_dense_compare(int vsf, const float *q, const float *v, int n);
 void  jvo_dense_scan(int vsf, const float *queries, int Q, const float *vecs, int64_t n, int D, float *out);
 
+/* ---- NVQ (jv_nvq.c): the reference's compressed rerank codec — B/quantization/NVQuantization.java, NVQScorer.java,
+ * DefaultVectorUtilSupport.java:385-548.  params per sub-vector = {minValue, maxValue, growthRate, midpoint} (the order
+ * QuantizedSubVector.write serialises them); bytes = the sub-vectors' bytes concatenated (D per vector). ---- */
+void  jvo_nvq_derive(float growthRate, float midpoint, float minValue, float maxValue, float levels, float *out5);
+float jvo_nvq_min(const float *v, int n);
+float jvo_nvq_max(const float *v, int n);
+void  jvo_nvq_quantize_8bit(const float *v, int n, float growthRate, float midpoint, float minValue, float maxValue, uint8_t *dst);
+float jvo_nvq_loss(const float *v, int n, float growthRate, float midpoint, float minValue, float maxValue, int nBits);
+float jvo_nvq_uniform_loss(const float *v, int n, float minValue, float maxValue, int nBits);
+float jvo_nvq_dot_8bit(const float *q, const uint8_t *bytes, int n, float growthRate, float midpoint, float minValue, float maxValue);
+float jvo_nvq_l2_8bit(const float *q, const uint8_t *bytes, int n, float growthRate, float midpoint, float minValue, float maxValue);
+void  jvo_nvq_cosine_8bit(const float *q, const uint8_t *bytes, int n, float growthRate, float midpoint, float minValue, float maxValue,
+                          const float *centroid, float *out2);
+float jvo_nvq_dequantize(uint8_t b, float growthRate, float midpoint, float minValue, float maxValue);
+void  jvo_nvq_global_mean(const float *X, int64_t n, int D, float *out);
+void  jvo_nvq_encode_sub(const float *v, int n, int learn, uint8_t *bytes, float *params);
+int   jvo_nvq_growth_grid(float *coarse, float *fine, int *fine_n, int fine_stride);
+void  jvo_nvq_encode(const float *mean, int D, int S, const float *vec, int learn, uint8_t *bytes, float *params);
+void  jvo_nvq_encode_all(const float *mean, int D, int S, const float *X, int64_t n, int learn, uint8_t *bytes, float *params, int nthreads);
+float jvo_nvq_score(int vsf, const float *mean, int D, int S, const float *query, const uint8_t *bytes, const float *params);
+void  jvo_nvq_scores(int vsf, const float *mean, int D, int S, const float *queries, int Q, const uint8_t *bytes, const float *params,
+                     int64_t n, const int32_t *ids, int B, float *out);
+double jvo_nvq_reconstruction_error(const float *mean, int D, int S, const float *vec, int learn);
+/* search entry points rerank with NVQ rows instead of `vecs` while this is set (bytes == NULL clears it) */
+void  jvo_set_nvq_reranker(const uint8_t *bytes, const float *params, const float *mean, int D, int S);
+int   jvo_nvq_reranker_active(void);
+float jvo_nvq_rerank_score(int vsf, const float *query, int32_t node);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,10 @@ directories with a JVM, which is absent here), so these writers are checked only
   footer                        B/graph/disk/AbstractGraphIndexWriter.java:174-187
   FusedPQ.writeInline           B/graph/disk/feature/FusedPQ.java:146-161  (neighbour codes in neighbour order, zero padded)
   PQVectors.write               B/quantization/PQVectors.java:155-166
+  NVQuantization.write          B/quantization/NVQuantization.java:260-277
+  QuantizedVector.write         B/quantization/NVQuantization.java:437-443, QuantizedSubVector.write :577-587
+  NVQVectors.write              B/quantization/NVQVectors.java:50-62
+  NVQ / SeparatedNVQ headers    B/graph/disk/feature/NVQ.java:64-76, SeparatedNVQ.java:78-95
   fvecs / ivecs                 EX/util/SiftLoader.java:37-83 (little-endian)
 The ProductQuantization block itself IS pinned (tests/golden/version0.pq, oracle.OraclePQ.serialize/parse).
 All JVector output is big-endian (B/disk/IndexWriter.java:36-42).
@@ -43,6 +47,34 @@ def write_pqvectors(pq_block: bytes, codes: np.ndarray) -> bytes:
     return pq_block + _i32(n, M) + np.ascontiguousarray(codes, dtype=np.uint8).tobytes()
 
 
+def nvq_sizes(D, S):
+    """NVQuantization.getSubvectorSizesAndOffsets :236-252"""
+    return [D // S + (1 if i < D % S else 0) for i in range(S)]
+
+
+def write_nvq_block(mean: np.ndarray, S: int, version=6) -> bytes:
+    D = len(mean)
+    return _i32(version, D) + _be_f32(mean) + _i32(8, S) + _i32(*nvq_sizes(D, S))
+
+
+def write_quantized_vector(sizes, row_bytes: np.ndarray, row_params: np.ndarray) -> bytes:
+    """row_params: S x {minValue, maxValue, growthRate, midpoint}"""
+    out = _i32(len(sizes))
+    off = 0
+    for s, size in enumerate(sizes):
+        out += _i32(8) + _be_f32(row_params[s]) + _i32(size, size) + np.ascontiguousarray(row_bytes[off:off + size], np.uint8).tobytes()
+        off += size
+    return out
+
+
+def write_nvqvectors(mean, S, bytes_, params, version=6) -> bytes:
+    sizes = nvq_sizes(len(mean), S)
+    out = bytearray(write_nvq_block(mean, S, version) + _i32(len(bytes_)))
+    for r in range(len(bytes_)):
+        out += write_quantized_vector(sizes, bytes_[r], params[r])
+    return bytes(out)
+
+
 def write_xvecs(rows: np.ndarray) -> bytes:
     rows = np.ascontiguousarray(rows)
     assert rows.dtype in (np.float32, np.int32)
@@ -67,7 +99,7 @@ def _common_header(version, dimension, entry_node, layers, id_upper_bound):
     return out
 
 
-def _header(version, dimension, entry_node, layers, id_upper_bound, feature_order, pq_block, sep_offset):
+def _header(version, dimension, entry_node, layers, id_upper_bound, feature_order, pq_block, sep_offset, nvq_block=None):
     out = _common_header(version, dimension, entry_node, layers, id_upper_bound)
 
     def feature_header(fid):
@@ -75,6 +107,10 @@ def _header(version, dimension, entry_node, layers, id_upper_bound, feature_orde
             return pq_block
         if fid == SEPARATED_VECTORS:
             return struct.pack(">q", sep_offset)
+        if fid == NVQ_VECTORS:
+            return nvq_block
+        if fid == SEPARATED_NVQ:
+            return nvq_block + struct.pack(">q", sep_offset)
         return b""
 
     if version >= 6:
@@ -91,14 +127,26 @@ def _header(version, dimension, entry_node, layers, id_upper_bound, feature_orde
 
 def write_odgi(version, dimension, l0_neighbors, degree0, entry_node, upper_levels=(), vectors=None, separated=False,
                codes=None, pq_block=None, omitted=(), level_file_order=None, sequential_placeholders=False,
-               placeholder_fill=0) -> bytes:
+               placeholder_fill=0, nvq=None, nvq_separated=False) -> bytes:
     """l0_neighbors: list (per ordinal) of neighbour-id lists;  upper_levels: [(degree, {node: [neighbours]}), ...] for
     levels 1..;  vectors: N x D float32 (inline, or separated when `separated`);  codes + pq_block: adds FUSED_PQ (v6);
     omitted: ordinals written as placeholders;  level_file_order: optional {level: [node ids in file order]}.
     sequential_placeholders: write OMITTED ordinals the way the sequential OnDiskGraphIndexWriter does
     (OnDiskGraphIndexWriter.java:101-110: ordinal -1, inline feature bytes seek-skipped — whatever the file held, modelled
-    by `placeholder_fill` — count 0, -1 padding) instead of NodeRecordTask's zero-feature record that keeps the ordinal."""
+    by `placeholder_fill` — count 0, -1 padding) instead of NodeRecordTask's zero-feature record that keeps the ordinal.
+    nvq: (mean[D], S, bytes[N, D], params[N, S, 4]) adds NVQ_VECTORS (inline) or, with nvq_separated, SEPARATED_NVQ (an
+    omitted ordinal gets QuantizedVector.createEmpty: zero bytes and parameters, SeparatedNVQ.java:86-94)."""
     N = len(l0_neighbors)
+    assert not (nvq is not None and nvq_separated and vectors is not None and separated), "one separated feature at a time"
+    nvq_block = write_nvq_block(nvq[0], nvq[1], version) if nvq is not None else None
+    nsizes = nvq_sizes(dimension, nvq[1]) if nvq is not None else None
+    nvq_stride = 4 + sum(28 + z for z in nsizes) if nvq is not None else 0
+
+    def nvq_record(i, empty):
+        if empty:
+            return write_quantized_vector(nsizes, np.zeros(dimension, np.uint8), np.zeros((nvq[1], 4), np.float32))
+        return write_quantized_vector(nsizes, nvq[2][i], nvq[3][i])
+
     layers = [(N - len(omitted), degree0)] + [(len(nodes), deg) for deg, nodes in upper_levels]
     fused = codes is not None
     assert not fused or version >= 6
@@ -107,13 +155,15 @@ def write_odgi(version, dimension, l0_neighbors, degree0, entry_node, upper_leve
         feats.append(SEPARATED_VECTORS if separated else INLINE_VECTORS)
     if fused:
         feats.append(FUSED_PQ)
+    if nvq is not None:
+        feats.append(SEPARATED_NVQ if nvq_separated else NVQ_VECTORS)
     # v6 orders features with fused ones last, then by id (AbstractFeature.compareTo :20-25, AbstractGraphIndexWriter
     # :83-90); <= v5 uses FeatureId order.
     feats.sort(key=(lambda f: (f == FUSED_PQ, f)) if version >= 6 else None)
     M = codes.shape[1] if fused else 0
 
     def hdr(sep_off):
-        return _header(version, dimension, entry_node, layers, N, feats, pq_block, sep_off)
+        return _header(version, dimension, entry_node, layers, N, feats, pq_block, sep_off, nvq_block)
 
     out = bytearray(hdr(0))
     for i in range(N):
@@ -124,6 +174,8 @@ def write_odgi(version, dimension, l0_neighbors, degree0, entry_node, upper_leve
                     out += bytes([placeholder_fill]) * (4 * dimension)
                 elif fid == FUSED_PQ:
                     out += bytes([placeholder_fill]) * (degree0 * M)
+                elif fid == NVQ_VECTORS:
+                    out += bytes([placeholder_fill]) * nvq_stride
             out += _i32(0) + _be_i32([-1] * degree0)
             continue
         out += _i32(i)
@@ -137,6 +189,8 @@ def write_odgi(version, dimension, l0_neighbors, degree0, entry_node, upper_leve
                 if nb:
                     blk[:len(nb)] = codes[nb]
                 out += blk.tobytes()
+            elif fid == NVQ_VECTORS:
+                out += nvq_record(i, i in omitted)
         out += _i32(len(nb)) + _be_i32(nb + [-1] * (degree0 - len(nb)))
     for lvl, (deg, nodes) in enumerate(upper_levels, start=1):
         order = (level_file_order or {}).get(lvl, list(nodes.keys()))
@@ -158,10 +212,14 @@ def write_odgi(version, dimension, l0_neighbors, degree0, entry_node, upper_leve
         for i in omitted:
             vv[i] = 0
         out += _be_f32(vv)
+    if nvq is not None and nvq_separated:
+        sep_off = len(out)
+        for i in range(N):
+            out += nvq_record(i, i in omitted)
     if version >= 5:
         header_off = len(out)
         out += hdr(sep_off) + struct.pack(">q", header_off) + _i32(FOOTER_MAGIC)
-    elif separated and vectors is not None:
+    elif (separated and vectors is not None) or (nvq is not None and nvq_separated):
         # pre-footer versions rewrite the leading header in place once the offset is known
         h = hdr(sep_off)
         out[:len(h)] = h

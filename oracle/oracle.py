@@ -19,7 +19,7 @@ VSF_NAMES = {EUCLIDEAN: "EUCLIDEAN", DOT_PRODUCT: "DOT_PRODUCT", COSINE: "COSINE
 
 
 def build(force: bool = False) -> str:
-    src = [os.path.join(_HERE, f) for f in ("jv_oracle.c", "jv_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("jv_oracle.c", "jv_oracle_simd.c", "jv_nvq.c", "jv_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "libjv_oracle.so"], stdout=subprocess.DEVNULL)
@@ -233,8 +233,103 @@ def lib():
         sig("jvo_set_simd", C.c_int, C.c_int)
         sig("jvo_dense_compare", C.c_float, C.c_int, fp, fp, C.c_int)
         sig("jvo_dense_scan", None, C.c_int, fp, C.c_int, fp, C.c_int64, C.c_int, fp)
+        # NVQ (jv_nvq.c)
+        F = C.c_float
+        sig("jvo_nvq_derive", None, F, F, F, F, F, fp)
+        sig("jvo_nvq_min", F, fp, C.c_int)
+        sig("jvo_nvq_max", F, fp, C.c_int)
+        sig("jvo_nvq_quantize_8bit", None, fp, C.c_int, F, F, F, F, u8p)
+        sig("jvo_nvq_loss", F, fp, C.c_int, F, F, F, F, C.c_int)
+        sig("jvo_nvq_uniform_loss", F, fp, C.c_int, F, F, C.c_int)
+        sig("jvo_nvq_dot_8bit", F, fp, u8p, C.c_int, F, F, F, F)
+        sig("jvo_nvq_l2_8bit", F, fp, u8p, C.c_int, F, F, F, F)
+        sig("jvo_nvq_cosine_8bit", None, fp, u8p, C.c_int, F, F, F, F, fp, fp)
+        sig("jvo_nvq_dequantize", F, C.c_uint8, F, F, F, F)
+        sig("jvo_nvq_global_mean", None, fp, C.c_int64, C.c_int, fp)
+        sig("jvo_nvq_encode_sub", None, fp, C.c_int, C.c_int, u8p, fp)
+        sig("jvo_nvq_growth_grid", C.c_int, fp, fp, i32p, C.c_int)
+        sig("jvo_nvq_encode", None, fp, C.c_int, C.c_int, fp, C.c_int, u8p, fp)
+        sig("jvo_nvq_encode_all", None, fp, C.c_int, C.c_int, fp, C.c_int64, C.c_int, u8p, fp, C.c_int)
+        sig("jvo_nvq_score", F, C.c_int, fp, C.c_int, C.c_int, fp, u8p, fp)
+        sig("jvo_nvq_scores", None, C.c_int, fp, C.c_int, C.c_int, fp, C.c_int, u8p, fp, C.c_int64, i32p, C.c_int, fp)
+        sig("jvo_nvq_reconstruction_error", C.c_double, fp, C.c_int, C.c_int, fp, C.c_int)
+        sig("jvo_set_nvq_reranker", None, u8p, fp, fp, C.c_int, C.c_int)
+        sig("jvo_nvq_reranker_active", C.c_int)
         _lib = L
     return _lib
+
+
+class OracleNVQ:
+    """NVQuantization + NVQVectors + NVQScorer of the scalar reference path (jv_nvq.c).  params[i, s] = {minValue, maxValue,
+    growthRate, midpoint}; bytes[i] = the sub-vectors' bytes concatenated."""
+
+    def __init__(self, mean, n_subvectors, learn=True):
+        self.mean = f32(mean).copy()
+        self.D, self.S, self.learn = int(self.mean.shape[0]), int(n_subvectors), bool(learn)
+        self.bytes = self.params = None
+
+    @classmethod
+    def compute(cls, vecs, n_subvectors, learn=True):
+        """NVQuantization.compute :153-163"""
+        vecs = f32(vecs)
+        mean = np.empty(vecs.shape[1], np.float32)
+        lib().jvo_nvq_global_mean(_f(vecs), vecs.shape[0], vecs.shape[1], _f(mean))
+        return cls(mean, n_subvectors, learn)
+
+    def sizes(self):
+        return [self.D // self.S + (1 if i < self.D % self.S else 0) for i in range(self.S)]
+
+    def encode_all(self, vecs, nthreads=16):
+        vecs = f32(vecs)
+        n = vecs.shape[0]
+        self.bytes = np.zeros((n, self.D), np.uint8)
+        self.params = np.zeros((n, self.S, 4), np.float32)
+        lib().jvo_nvq_encode_all(_f(self.mean), self.D, self.S, _f(vecs), n, int(self.learn), _u8(self.bytes), _f(self.params), nthreads)
+        return self.bytes, self.params
+
+    def set_rows(self, bytes_, params):
+        self.bytes = np.ascontiguousarray(bytes_, np.uint8)
+        self.params = np.ascontiguousarray(params, np.float32).reshape(len(self.bytes), self.S, 4)
+        return self
+
+    def scores(self, queries, vsf, ordinals):
+        queries, ordinals = f32(queries), np.ascontiguousarray(ordinals, np.int32)
+        Q, B = ordinals.shape
+        out = np.empty((Q, B), np.float32)
+        lib().jvo_nvq_scores(vsf, _f(self.mean), self.D, self.S, _f(queries), Q, _u8(self.bytes), _f(self.params), self.bytes.shape[0],
+                             _i32(ordinals), B, _f(out))
+        return out
+
+    def reconstruction_error(self, vec):
+        return float(lib().jvo_nvq_reconstruction_error(_f(self.mean), self.D, self.S, _f(f32(vec)), int(self.learn)))
+
+    def as_reranker(self):
+        """context manager: the oracle's search entry points rerank with these rows (NVQ.rerankerFor) while it is active;
+        their `vecs` argument must still be non-None (any N x D float array) — it only says "rerank at all" """
+        return _NVQReranker(self)
+
+
+class _NVQReranker:
+    def __init__(self, o):
+        self.o = o
+
+    def __enter__(self):
+        o = self.o
+        lib().jvo_set_nvq_reranker(_u8(o.bytes), _f(o.params), _f(o.mean), o.D, o.S)
+        return o
+
+    def __exit__(self, *a):
+        lib().jvo_set_nvq_reranker(None, None, None, 0, 0)
+        return False
+
+
+def nvq_growth_grid():
+    """-> (coarse[20], [fine values of coarse c])"""
+    co = np.zeros(32, np.float32)
+    fi = np.zeros((32, 32), np.float32)
+    fn = np.zeros(32, np.int32)
+    nc = lib().jvo_nvq_growth_grid(_f(co), _f(fi), _i32(fn), 32)
+    return co[:nc].copy(), [fi[c, :fn[c]].copy() for c in range(nc)]
 
 
 def dense_scan(vsf, queries, vecs):

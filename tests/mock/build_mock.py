@@ -7,7 +7,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "build", "mock")
 LIB = os.path.join(OUT, "libjvector_hip_mock.so")
-HOST = ["cabi", "graph_search", "sharded", "build_score", "builder", "pq_train", "formats", "compat_host"]
+HOST = ["cabi", "graph_search", "sharded", "build_score", "builder", "nvq", "pq_train", "formats", "compat_host"]
 CXXF = ["-std=c++17", "-O2", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-include",
         os.path.join(ROOT, "tests", "mock", "mock_prefix.h"), "-fPIC", "-Wno-unknown-pragmas", "-Wno-unused-function"]
 
@@ -15,7 +15,7 @@ CXXF = ["-std=c++17", "-O2", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I/
 def _sources():
     srcs = [os.path.join(ROOT, "jvector_amd", "csrc", f + ".cpp") for f in HOST]
     srcs += [os.path.join(ROOT, "tests", "mock", f) for f in ("mock_hip.cpp", "mock_kernels.cpp")]
-    srcs += [os.path.join(ROOT, "oracle", f) for f in ("jv_oracle.c", "jv_oracle_simd.c")]
+    srcs += [os.path.join(ROOT, "oracle", f) for f in ("jv_oracle.c", "jv_oracle_simd.c", "jv_nvq.c")]
     return srcs
 
 

@@ -266,6 +266,44 @@ int launch_exact_gather(hipStream_t, const float *d_vecs, int64_t n, int D, cons
         }
     return JV_OK;
 }
+// ---- NVQ (k_nvq.hip): the oracle's restatement; the mock's "derived" array simply carries the raw parameters ----
+int launch_nvq_mean(hipStream_t, const float *d_vecs, int64_t n, int D, float *d_mean)
+{
+    jvo_nvq_global_mean(d_vecs, n, D, d_mean);
+    return JV_OK;
+}
+size_t nvq_encode_lds_bytes(int D, int S) { return sizeof(float) * (3 * (size_t)(D / S + 1) + 96); }
+int launch_nvq_encode(hipStream_t, const jv_ctx *ctx, const float *d_vecs, int64_t count, int D, int S, const float *d_mean, int learn,
+                      const float *, uint8_t *d_bytes, int ld, float *d_params)
+{
+    if (nvq_encode_lds_bytes(D, S) > ctx->lds_per_block) {
+        set_error("nvq_encode: sub-vector too long for LDS");
+        return JV_ERR_UNSUPPORTED;
+    }
+    for (int64_t i = 0; i < count; ++i) jvo_nvq_encode(d_mean, D, S, d_vecs + i * D, learn, d_bytes + i * ld, d_params + i * 4 * S);
+    return JV_OK;
+}
+int launch_nvq_derive(hipStream_t, const float *d_params, int64_t units, float *d_derived)
+{
+    memcpy(d_derived, d_params, sizeof(float) * 4 * (size_t)units);
+    return JV_OK;
+}
+int launch_nvq_cosnorm(hipStream_t, const uint8_t *, int, int64_t n, int, int, const float *, const float *, float *d_out)
+{
+    for (int64_t i = 0; i < n; ++i) d_out[i] = 0.0f;   // the mock's gather recomputes the sum
+    return JV_OK;
+}
+int launch_nvq_gather(hipStream_t, const uint8_t *d_bytes, int ld, int64_t n, int D, int S, const float *d_derived, const float *,
+                      const float *d_mean, const float *d_q, int Q, int vsf, const int32_t *d_ord, int B, float *d_out, float *, float *)
+{
+    for (int q = 0; q < Q; ++q)
+        for (int b = 0; b < B; ++b) {
+            const int64_t o = d_ord[(int64_t)q * B + b];
+            d_out[(int64_t)q * B + b] = (o < 0 || o >= n) ? NEG_INF
+                : jvo_nvq_score(vsf, d_mean, D, S, d_q + (size_t)q * D, d_bytes + o * ld, d_derived + o * 4 * S);
+        }
+    return JV_OK;
+}
 int launch_exact_scan(hipStream_t, const jv_ctx *, const float *d_vecs, int D, const float *d_q, int Q, int vsf, int64_t first,
                       int64_t count, float *d_out, float *)
 {

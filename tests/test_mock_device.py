@@ -606,9 +606,10 @@ def test_standalone_canary_against_the_mock_library(J):
         assert line["identical"] is True and line["avg_expanded"] >= 50
 
 
-@pytest.mark.parametrize("mode,traversal,graph,n", [("graph", "host", "synthetic", 6000), ("graph", "device", "engine", 2000),
-                                                   ("flat", "host", "synthetic", 6000)])
-def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, graph, n):
+@pytest.mark.parametrize("mode,traversal,graph,n,extra", [("graph", "host", "synthetic", 6000, []), ("graph", "device", "engine", 2000, []),
+                                                         ("flat", "host", "synthetic", 6000, []),
+                                                         ("graph", "device", "engine", 2000, ["--reranker", "nvq"])])
+def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, graph, n, extra):
     """bench.py end to end at toy size: torch runs on the CPU (a proxy maps the `cuda` device bench asks for to `cpu` and makes
     the stream / synchronize calls inert) and the engine is the mock device.  Numbers are meaningless; what is checked is the
     control flow — index build, rerankK calibration against exact ground truth, the timed loop, the secondary flat
@@ -631,7 +632,7 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, grap
 
     monkeypatch.setattr(bench, "torch", TorchProxy())
     argv = ["bench.py", "--mode", mode, "--traversal", traversal, "--graph", graph, "--n", str(n), "--dim", "128", "--m", "16", "--degree", "16",
-            "--queries", "48", "--steps", "2", "--warmup", "1", "--eval-queries", "48", "--cal-queries", "48"]
+            "--queries", "48", "--steps", "2", "--warmup", "1", "--eval-queries", "48", "--cal-queries", "48"] + extra
     monkeypatch.setattr(sys, "argv", argv)
     monkeypatch.delenv("RANK", raising=False)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
@@ -645,10 +646,14 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, grap
     assert line["config"]["mode"] == mode and line["config"]["n_vectors"] == n and "workload" in line["config"]
     assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
-    assert line["cpu_baseline"]["matches_gpu_topk"] is True          # the scalar leg is the parity checker
     cb = line["cpu_baseline"]
+    if "nvq" in extra:   # NVQ rows rerank on the GPU, float rows on the CPU leg: the line says so instead of claiming equality
+        assert line["reranker"] == "nvq" and line["nvq"]["bytes_per_row"] == 128 + 32 and "note" in cb
+        assert "rerank" not in line or "nvq_gather_kernel" in line["rerank"]["kernel"]   # (the mock's events measure no time)
+    else:
+        assert cb["matches_gpu_topk"] is True                        # the scalar leg is the parity checker
     assert cb["isa"] in ("scalar", "avx2", "avx512") and cb["scalar_value"] > 0
-    if cb["isa"] != "scalar":                                         # SIMD leg: the reported value, ~the same top-k
+    if cb["isa"] != "scalar" and "nvq" not in extra:                  # SIMD leg: the reported value, ~the same top-k
         assert cb["value"] != cb["scalar_value"] and cb["simd_topk_overlap_with_gpu"] >= 0.98
     assert 0.0 <= line["recall_at_10"] <= 1.0 and line["recall_at_10"] > 0.5
     if mode == "graph":
