@@ -139,6 +139,19 @@ public final class HipOps {
         static final MethodHandle ctxGetStat = h("jv_hip_ctx_get_stat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle ctxResetStats = h("jv_hip_ctx_reset_stats", FunctionDescriptor.of(JAVA_INT, ADDRESS));
         static final MethodHandle vectorsInvalidate = h("jv_hip_vectors_invalidate", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        // NVQ: NVQuantization / NVQVectors / NVQScorer and the graph's NVQ reranker
+        static final MethodHandle nvqCreate = h("jv_hip_nvq_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle nvqCompute = h("jv_hip_nvq_compute", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS));
+        static final MethodHandle nvqSetLearn = h("jv_hip_nvq_set_learn", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT));
+        static final MethodHandle nvqGlobalMean = h("jv_hip_nvq_global_mean", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle nvqDestroy = h("jv_hip_nvq_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle nvqVectorsCreate = h("jv_hip_nvq_vectors_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, ADDRESS));
+        static final MethodHandle nvqEncode = h("jv_hip_nvq_encode", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS, JAVA_LONG));
+        static final MethodHandle nvqVectorsUpload = h("jv_hip_nvq_vectors_upload", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS, ADDRESS));
+        static final MethodHandle nvqVectorsDownload = h("jv_hip_nvq_vectors_download", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG, JAVA_LONG, ADDRESS, ADDRESS));
+        static final MethodHandle nvqVectorsDestroy = h("jv_hip_nvq_vectors_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle nvqScores = h("jv_hip_nvq_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
+        static final MethodHandle vectorsFromNvq = h("jv_hip_vectors_from_nvq", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle shardedSearchFlat = h("jv_hip_sharded_search_flat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
     }
 
@@ -363,6 +376,42 @@ public final class HipOps {
                                      float alpha, MemorySegment selectedOut, MemorySegment nSelectedOut, MemorySegment shortEdgesOutOrNull) {
         check(st(() -> (int) H.retainDiverse.invokeExact(ctx, table, codes, p, c, candNodes, candScores, candCountOrNull, diverseBeforeOrNull,
                                                          maxDegree, alpha, selectedOut, nSelectedOut, shortEdgesOutOrNull)));
+    }
+    // ---- NVQ: NVQuantization.compute / encodeAll (NVQuantization.java:153-216), NVQScorer (NVQScorer.java:33-137) and
+    //      NVQ.rerankerFor (graph/disk/feature/NVQ.java:96-110) as batch calls ----
+    /** NVQuantization.create(globalMean, nSubVectors) */
+    public static MemorySegment nvqCreate(Arena arena, MemorySegment ctx, int dimension, int nSubVectors, MemorySegment globalMean) {
+        return outHandle(arena, out -> st(() -> (int) H.nvqCreate.invokeExact(ctx, dimension, nSubVectors, globalMean, out)));
+    }
+    /** NVQuantization.compute(ravv, nSubVectors): the mean is accumulated over the device-resident rows in order */
+    public static MemorySegment nvqCompute(Arena arena, MemorySegment ctx, MemorySegment vectors, int nSubVectors) {
+        return outHandle(arena, out -> st(() -> (int) H.nvqCompute.invokeExact(ctx, vectors, nSubVectors, out)));
+    }
+    public static void nvqSetLearn(MemorySegment nvq, boolean learn) { check(st(() -> (int) H.nvqSetLearn.invokeExact(nvq, learn ? 1 : 0))); }
+    public static void nvqGlobalMean(MemorySegment ctx, MemorySegment nvq, MemorySegment dst) { check(st(() -> (int) H.nvqGlobalMean.invokeExact(ctx, nvq, dst))); }
+    public static void nvqDestroy(MemorySegment nvq) { check(st(() -> (int) H.nvqDestroy.invokeExact(nvq))); }
+    public static MemorySegment nvqVectorsCreate(Arena arena, MemorySegment ctx, MemorySegment nvq, long count) {
+        return outHandle(arena, out -> st(() -> (int) H.nvqVectorsCreate.invokeExact(ctx, nvq, count, out)));
+    }
+    /** encodeAll: rows [first, first + count) of `vectors` into rows [dstFirst, ...) of `rows` */
+    public static void nvqEncode(MemorySegment ctx, MemorySegment nvq, MemorySegment vectors, long first, long count, MemorySegment rows, long dstFirst) {
+        check(st(() -> (int) H.nvqEncode.invokeExact(ctx, nvq, vectors, first, count, rows, dstFirst)));
+    }
+    /** bytes: count x D; params: count x S x {minValue, maxValue, growthRate, midpoint} (QuantizedSubVector.write order) */
+    public static void nvqVectorsUpload(MemorySegment ctx, MemorySegment rows, long first, long count, MemorySegment bytes, MemorySegment params) {
+        check(st(() -> (int) H.nvqVectorsUpload.invokeExact(ctx, rows, first, count, bytes, params)));
+    }
+    public static void nvqVectorsDownload(MemorySegment ctx, MemorySegment rows, long first, long count, MemorySegment bytes, MemorySegment params) {
+        check(st(() -> (int) H.nvqVectorsDownload.invokeExact(ctx, rows, first, count, bytes, params)));
+    }
+    public static void nvqVectorsDestroy(MemorySegment rows) { check(st(() -> (int) H.nvqVectorsDestroy.invokeExact(rows))); }
+    /** scores[q][b] = NVQVectors.scoreFunctionFor(query q, vsf).similarityTo(ordinals[q*B + b]) */
+    public static void nvqScores(MemorySegment ctx, MemorySegment rows, MemorySegment queries, int q, int vsf, MemorySegment ordinals, int b, MemorySegment scores) {
+        check(st(() -> (int) H.nvqScores.invokeExact(ctx, rows, queries, q, vsf, ordinals, b, scores)));
+    }
+    /** a jv_vectors whose rerank scores the NVQ rows: pass it wherever a search takes `vectors` */
+    public static MemorySegment vectorsFromNvq(Arena arena, MemorySegment ctx, MemorySegment rows) {
+        return outHandle(arena, out -> st(() -> (int) H.vectorsFromNvq.invokeExact(ctx, rows, out)));
     }
     // ---- batched construction: the GraphIndexBuilder.addGraphNode loop (GraphIndexBuilder.java:605-659) as batch calls ----
     /** one graph level over the nodes of `codes` / `vectors`; alpha / neighborOverflow as GraphIndexBuilder's constructor takes them */

@@ -63,16 +63,29 @@ inline float l2_seq(const float *a, const float *b, size_t n)  // :195-208
 }
 
 // NVQ helpers — DefaultVectorUtilSupport.java:441-474 (logistic / logit "NQT" approximations, Math.fma)
-inline int java_round(float x) { return (int)std::floor((double)x + 0.5); }
+inline int java_round(float x)   // Math.round(float): floor(x + 1/2), NaN -> 0, saturating
+{
+    if (x != x) return 0;
+    const double r = std::floor((double)x + 0.5);
+    if (r <= -2147483648.0) return INT32_MIN;
+    if (r >= 2147483647.0) return INT32_MAX;
+    return (int)r;
+}
 inline float bits_to_float(int32_t b) { float f; std::memcpy(&f, &b, 4); return f; }
-inline int32_t float_to_bits(float f) { int32_t b; std::memcpy(&b, &f, 4); return b; }
+inline int32_t float_to_bits(float f)   // Float.floatToIntBits: NaN canonical
+{
+    if (f != f) return 0x7fc00000;
+    int32_t b;
+    std::memcpy(&b, &f, 4);
+    return b;
+}
 
 inline float logistic_nqt(float value, float alpha, float x0)
 {
     float temp = std::fmaf(value, alpha, -alpha * x0);
     int p = java_round(temp + 0.5f);
     int32_t m = float_to_bits(std::fmaf(temp - (float)p, 0.5f, 1.0f));
-    temp = bits_to_float(m + (int32_t)((uint32_t)p << 23));
+    temp = bits_to_float((int32_t)((uint32_t)m + ((uint32_t)p << 23)));
     return temp / (temp + 1.0f);
 }
 inline float logit_nqt(float value, float inverseAlpha, float x0)

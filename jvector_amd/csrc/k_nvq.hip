@@ -279,20 +279,102 @@ __global__ __launch_bounds__(256) void nvq_derive_kernel(const float4 *__restric
 // ------------------------------------------------------------------------------------------------
 // gather form: score[q][b] = NVQScorer...similarityTo(row ord[q][b]).
 // Same structure as exact_gather_tr_kernel (k_exact.hip): one wavefront = 64 candidates of one query; a row is consumed
-// in chunks of 256 bytes — the wave loads 4 rows x 256 B per instruction (whole lines) and parks the chunk in LDS as
-// tile[row][256 + 16 pad]; lane j then walks row j with ds_read_b128 (16 dimensions per read, row stride 68 dwords) and
-// runs the reference's chain: de-quantise, fma into the accumulator.  The query slice is wave-uniform (scalar loads).
+// in chunks of 128 bytes — the wave loads 8 rows x 128 B per instruction (whole lines) and parks the chunk in LDS as
+// tile[row][128 + 16 pad]; lane j then walks row j with ds_read_b128 (16 dimensions per read; row stride 36 dwords: the
+// 16 lanes of a b128 phase start at 16 distinct multiples of 4 banks) and runs the reference's chain: de-quantise, fma
+// into the accumulator.  The query slice is wave-uniform (scalar loads).  The kernel is VALU-bound (the de-quantisation is
+// ~26 instructions per dimension, half of them the IEEE divide), so the tile is kept small: 9 KB of LDS per wave lets
+// 16 waves share a CU (the 256-byte chunks of the float kernel would cap it at 9).
 // Sub-vector boundaries are wave-uniform too: at each one the chain's value is added to the running total
 // (`nvqDot += ...` :66) and the lane fetches its row's next derived quadruple.
 // NORM = true builds the cosine table instead: cosnorm[row] = sum over sub-vectors of normDQ (:448, NVQScorer :127).
 // ------------------------------------------------------------------------------------------------
-constexpr int NQ_CH = 256;           // bytes of a row per chunk
+constexpr int NQ_CH = 128;           // bytes of a row per chunk
 constexpr int NQ_LS = NQ_CH + 16;    // LDS row stride (bytes)
+constexpr int NQ_LPR = NQ_CH / 16;   // lanes that cover one row's chunk with 16 bytes each (8)
+constexpr int NQ_RPI = 64 / NQ_LPR;  // rows fetched per load instruction (8)
+constexpr int NQ_NI = 64 / NQ_RPI;   // load instructions per chunk (8)
+
+// a / b for operands well inside the normal range: the fma sequence the compiler's IEEE division is made of (reciprocal
+// estimate, one Newton step on it, quotient with two residual corrections — correctly rounded) without the v_div_scale /
+// v_div_fmas / v_div_fixup wrapping that only matters at the ends of the exponent range.  Plain fma chains also let the
+// compiler pair two dimensions per v_pk_fma_f32.
+__device__ __forceinline__ float nq_div_fast(float a, float b)
+{
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = a * r;
+    float t = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(t, r, q);
+}
+// is every byte of a sub-vector with these derived numbers safe for nq_div_fast?  sv = fma(byte, scale, bias) is monotone in
+// the byte, so both ends inside [2^-40, 1 - 2^-20] put every sv there, 1 - sv inside [2^-20, 1) and the quotient inside
+// [2^-41, 2^20]: finite, normal, never NaN.  (Comparisons are false for NaN parameters -> the IEEE path.)
+__device__ __forceinline__ bool nq_fast_ok(const float4 prm)
+{
+    const float s0 = prm.w, s1 = __builtin_fmaf(255.0f, prm.z, prm.w);
+    const float lo = s0 < s1 ? s0 : s1, hi = s0 < s1 ? s1 : s0;
+    return lo >= 9.094947017729282e-13f && hi <= 0.99999905f;
+}
+
+// two dimensions at a time through the short division, on packed f32 operations (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+// are full rate: half the issue slots of the fma chain); only the two reciprocal estimates, the exponent / mantissa splits
+// and the two chain steps (sequential by definition) stay scalar.  Same operations per lane as nq_elem<.., FAST = true>.
+typedef float nq_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ nq_f2 nq_fma2(nq_f2 a, nq_f2 b, nq_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 template <int VSF, bool NORM>
+__device__ __forceinline__ void nq_pair(uint32_t b0, uint32_t b1, const float4 prm, float qa0, float qa1, float ca0, float ca1, float &acc)
+{
+    const nq_f2 x = {(float)b0, (float)b1};
+    const nq_f2 sv = nq_fma2(x, nq_f2{prm.z, prm.z}, nq_f2{prm.w, prm.w});
+    const nq_f2 den = nq_f2{1.0f, 1.0f} - sv;
+    nq_f2 r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const nq_f2 e = nq_fma2(-den, r, nq_f2{1.0f, 1.0f});
+    r = nq_fma2(e, r, r);
+    nq_f2 q = sv * r;
+    nq_f2 t = nq_fma2(-den, q, sv);
+    q = nq_fma2(t, r, q);
+    t = nq_fma2(-den, q, sv);
+    const nq_f2 z = nq_fma2(t, r, q);
+    const int z0 = __float_as_int(z.x), z1 = __float_as_int(z.y);
+    const nq_f2 pe = {(float)(((z0 & 0x7f800000) >> 23) - 128), (float)(((z1 & 0x7f800000) >> 23) - 128)};
+    const nq_f2 mn = {__int_as_float((z0 & 0x007fffff) + 0x3f800000), __int_as_float((z1 & 0x007fffff) + 0x3f800000)};
+    nq_f2 val = nq_fma2(mn + pe, nq_f2{prm.x, prm.x}, nq_f2{prm.y, prm.y});
+    if (NORM) {
+        val = val + nq_f2{ca0, ca1};
+        acc = __builtin_fmaf(val.x, val.x, acc);
+        acc = __builtin_fmaf(val.y, val.y, acc);
+    } else if (VSF == VSF_DOT) {
+        acc = __builtin_fmaf(qa0, val.x, acc);
+        acc = __builtin_fmaf(qa1, val.y, acc);
+    } else if (VSF == VSF_L2) {
+        const nq_f2 d = val - nq_f2{qa0, qa1};
+        acc = __builtin_fmaf(d.x, d.x, acc);
+        acc = __builtin_fmaf(d.y, d.y, acc);
+    } else {
+        val = val + nq_f2{ca0, ca1};
+        acc = __builtin_fmaf(qa0, val.x, acc);
+        acc = __builtin_fmaf(qa1, val.y, acc);
+    }
+}
+
+template <int VSF, bool NORM, bool FAST>
 __device__ __forceinline__ void nq_elem(uint32_t byte, const float4 prm, float qa, float ca, float &acc)
 {
-    float val = nq_scaled_logit((float)byte, prm.x, prm.y, prm.z, prm.w);
+    float val;
+    if (FAST) {   // nq_scaled_logit with the division above; the quotient is a positive normal number: its bits are Java's bits
+        const float sv = __builtin_fmaf((float)byte, prm.z, prm.w);
+        const int zb = __float_as_int(nq_div_fast(sv, 1.0f - sv));
+        const float p = (float)(((zb & 0x7f800000) >> 23) - 128);
+        const float m = __int_as_float((zb & 0x007fffff) + 0x3f800000);
+        val = __builtin_fmaf(m + p, prm.x, prm.y);
+    } else {
+        val = nq_scaled_logit((float)byte, prm.x, prm.y, prm.z, prm.w);
+    }
     if (NORM) {
         val += ca;
         acc = __builtin_fmaf(val, val, acc);
@@ -307,37 +389,62 @@ __device__ __forceinline__ void nq_elem(uint32_t byte, const float4 prm, float q
     }
 }
 
+// dimensions [i, iend) of the lane's row in the LDS tile (offsets inside the chunk; a / cen point at the chunk's first dimension)
+template <int VSF, bool NORM, bool FAST>
+__device__ __forceinline__ void nq_segment(const uint8_t *__restrict__ row, int i, int iend, const float4 prm, const float *__restrict__ a,
+                                           const float *__restrict__ cen, float &acc)
+{
+    constexpr bool CEN = NORM || VSF == VSF_COS;
+    for (; i < iend && (i & 15); ++i) nq_elem<VSF, NORM, FAST>(row[i], prm, NORM ? 0.0f : a[i], CEN ? cen[i] : 0.0f, acc);
+    for (; i + 16 <= iend; i += 16) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(row + i);
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+        if (FAST) {
+#pragma unroll
+            for (int t = 0; t < 16; t += 2)
+                nq_pair<VSF, NORM>((ws[t >> 2] >> (8 * (t & 3))) & 0xffu, (ws[t >> 2] >> (8 * ((t + 1) & 3))) & 0xffu, prm,
+                                   NORM ? 0.0f : a[i + t], NORM ? 0.0f : a[i + t + 1], CEN ? cen[i + t] : 0.0f, CEN ? cen[i + t + 1] : 0.0f, acc);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                nq_elem<VSF, NORM, FAST>((ws[t >> 2] >> (8 * (t & 3))) & 0xffu, prm, NORM ? 0.0f : a[i + t], CEN ? cen[i + t] : 0.0f, acc);
+        }
+    }
+    for (; i < iend; ++i) nq_elem<VSF, NORM, FAST>(row[i], prm, NORM ? 0.0f : a[i], CEN ? cen[i] : 0.0f, acc);
+}
+
 template <int VSF, bool NORM>
 __device__ __forceinline__ float nq_rows(const uint8_t *__restrict__ bytes, int ld, int D, int S, int64_t my_row /* -1 = none */,
                                          const float4 *__restrict__ derived, const float *__restrict__ a,
                                          const float *__restrict__ cen, uint8_t *tile)
 {
     const int lane = threadIdx.x;
-    const int seg = (lane & 15) * 16;   // this lane's 16 bytes inside a row's 256-byte chunk
-    const int sub = lane >> 4;          // load instruction k fetches rows 4k + sub
-    const uint8_t *rp[16];
+    const int seg = (lane % NQ_LPR) * 16;   // this lane's 16 bytes inside a row's chunk
+    const int sub = lane / NQ_LPR;          // load instruction k fetches rows NQ_RPI * k + sub
+    const uint8_t *rp[NQ_NI];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int64_t ro = __shfl(my_row, 4 * k + sub, 64);
+    for (int k = 0; k < NQ_NI; ++k) {
+        const int64_t ro = __shfl(my_row, NQ_RPI * k + sub, 64);
         rp[k] = ro >= 0 ? bytes + ro * ld + seg : nullptr;
     }
     const int nc = (D + NQ_CH - 1) / NQ_CH;
-    uint4 r[16];
+    uint4 r[NQ_NI];
     auto issue = [&](int c) {
         const bool in = c * NQ_CH + seg < ld;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
+        for (int k = 0; k < NQ_NI; ++k)
             r[k] = (rp[k] && in) ? *reinterpret_cast<const uint4 *>(rp[k] + c * NQ_CH) : make_uint4(0u, 0u, 0u, 0u);
     };
     issue(0);
     const int base = D / S, rem = D % S;
     int s = 0, sub_end = base + (rem ? 1 : 0);
     const float4 *dp = derived + (my_row >= 0 ? my_row : 0) * S;
-    float4 prm = dp[0];
+    const float4 none = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 prm = my_row >= 0 ? dp[0] : none;
     float total = 0.0f, acc = 0.0f;
     for (int c = 0; c < nc; ++c) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) *reinterpret_cast<uint4 *>(tile + (4 * k + sub) * NQ_LS + seg) = r[k];
+        for (int k = 0; k < NQ_NI; ++k) *reinterpret_cast<uint4 *>(tile + (NQ_RPI * k + sub) * NQ_LS + seg) = r[k];
         __syncthreads();
         if (c + 1 < nc) issue(c + 1);
         const uint8_t *row = tile + lane * NQ_LS;
@@ -346,18 +453,10 @@ __device__ __forceinline__ float nq_rows(const uint8_t *__restrict__ bytes, int 
         const int dend = (D - c0 < NQ_CH) ? D : c0 + NQ_CH;
         while (d < dend) {
             const int seg_end = sub_end < dend ? sub_end : dend;
-            int i = d - c0;
-            const int iend = seg_end - c0;
-            for (; i < iend && (i & 15); ++i) nq_elem<VSF, NORM>(row[i], prm, NORM ? 0.0f : a[c0 + i], (NORM || VSF == VSF_COS) ? cen[c0 + i] : 0.0f, acc);
-            for (; i + 16 <= iend; i += 16) {
-                const uint4 w = *reinterpret_cast<const uint4 *>(row + i);
-                const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    nq_elem<VSF, NORM>((ws[t >> 2] >> (8 * (t & 3))) & 0xffu, prm, NORM ? 0.0f : a[c0 + i + t],
-                                       (NORM || VSF == VSF_COS) ? cen[c0 + i + t] : 0.0f, acc);
-            }
-            for (; i < iend; ++i) nq_elem<VSF, NORM>(row[i], prm, NORM ? 0.0f : a[c0 + i], (NORM || VSF == VSF_COS) ? cen[c0 + i] : 0.0f, acc);
+            const int ibeg = d - c0, iend = seg_end - c0;
+            // wave-uniform choice: every lane's row allows the short division for this sub-vector (almost always)
+            if (__all(my_row < 0 || nq_fast_ok(prm))) nq_segment<VSF, NORM, true>(row, ibeg, iend, prm, a + c0, cen + c0, acc);
+            else nq_segment<VSF, NORM, false>(row, ibeg, iend, prm, a + c0, cen + c0, acc);
             d = seg_end;
             if (d == sub_end) {
                 total += acc;
@@ -365,7 +464,7 @@ __device__ __forceinline__ float nq_rows(const uint8_t *__restrict__ bytes, int 
                 ++s;
                 if (s < S) {
                     sub_end += base + (s < rem ? 1 : 0);
-                    prm = dp[s];
+                    prm = my_row >= 0 ? dp[s] : none;
                 }
             }
         }
@@ -446,9 +545,10 @@ int launch_nvq_encode(hipStream_t s, const jv_ctx *ctx, const float *d_vecs, int
 {
     if (count == 0) return JV_OK;
     const size_t lds = nvq_encode_lds_bytes(D, S);
-    if (lds > ctx->lds_per_block) {
+    const size_t lds_max = ctx->lds_per_block < 65536 ? ctx->lds_per_block : 65536;   // dynamic LDS without a per-function opt-in
+    if (lds > lds_max) {
         set_error("nvq_encode: a sub-vector of %d dimensions needs %zu bytes of LDS (limit %zu); use more sub-vectors", D / S + 1, lds,
-                  ctx->lds_per_block);
+                  lds_max);
         return JV_ERR_UNSUPPORTED;
     }
     const int64_t units = count * S, blocks = (units + 2) / 3;

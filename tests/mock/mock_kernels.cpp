@@ -276,7 +276,7 @@ size_t nvq_encode_lds_bytes(int D, int S) { return sizeof(float) * (3 * (size_t)
 int launch_nvq_encode(hipStream_t, const jv_ctx *ctx, const float *d_vecs, int64_t count, int D, int S, const float *d_mean, int learn,
                       const float *, uint8_t *d_bytes, int ld, float *d_params)
 {
-    if (nvq_encode_lds_bytes(D, S) > ctx->lds_per_block) {
+    if (nvq_encode_lds_bytes(D, S) > 65536) {
         set_error("nvq_encode: sub-vector too long for LDS");
         return JV_ERR_UNSUPPORTED;
     }

@@ -40,7 +40,7 @@ def test_python_signature_table_matches_header():
     compat = set(declared_symbols("jvector_simd_compat.h", "JVC_API"))
     assert compat == set(L.COMPAT_SIGNATURES), compat ^ set(L.COMPAT_SIGNATURES)
     fmt = set(declared_symbols("jvector_formats.h", "JV_API"))
-    assert fmt == set(L.FORMAT_SIGNATURES) and len(fmt) == 8, fmt ^ set(L.FORMAT_SIGNATURES)
+    assert fmt == set(L.FORMAT_SIGNATURES) and len(fmt) == 13, fmt ^ set(L.FORMAT_SIGNATURES)
     # the reference's own kernel list: 22 kernels + 2 getters (jvector_simd_kernel_list.h:36-62, jvector_simd.h:47,53)
     assert len(compat) == 24
 
