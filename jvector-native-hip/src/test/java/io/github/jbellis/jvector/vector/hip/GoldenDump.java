@@ -5,7 +5,8 @@
  * reference, pinned only where the reference ships literal fixtures.  This program produces the missing literals with the
  * reference's own classes under the scalar provider (-Djvector.vectorization_provider=default ... or simply no Panama/native
  * modules on the class path): PQ code bytes, ADC / direct / diversity scores as raw float bits, robust-prune selections, a built
- * graph with search results and counters, and an on-disk index (v6, FusedPQ + inline vectors) plus a PQVectors blob.
+ * graph with search results and counters, an on-disk index (v6, FusedPQ + inline vectors) plus a PQVectors blob, and NVQ (global
+ * mean, encoded bytes + the four parameters per sub-vector, NVQScorer scores, the NVQVectors blob) for 1 and 3 sub-vectors.
  * tests/test_reference_goldens.py consumes the file (tests/golden/ref/jvector_goldens.bin) and checks BOTH the oracle and the
  * HIP library against it.
  *
@@ -35,6 +36,8 @@ import io.github.jbellis.jvector.graph.disk.feature.InlineVectors;
 import io.github.jbellis.jvector.graph.diversity.VamanaDiversityProvider;
 import io.github.jbellis.jvector.graph.similarity.BuildScoreProvider;
 import io.github.jbellis.jvector.graph.similarity.DefaultSearchScoreProvider;
+import io.github.jbellis.jvector.quantization.NVQVectors;
+import io.github.jbellis.jvector.quantization.NVQuantization;
 import io.github.jbellis.jvector.quantization.PQVectors;
 import io.github.jbellis.jvector.quantization.ProductQuantization;
 import io.github.jbellis.jvector.util.BitSet;
@@ -201,6 +204,42 @@ public final class GoldenDump {
                 g.floats("rd_scores_" + vsf.name(), candSc, node1.length, C);
                 g.bytes("rd_selected_" + vsf.name(), selected, node1.length, C);
                 g.floats("rd_short_edges_" + vsf.name(), shortEdges);
+            }
+
+            // ---- NVQ: NVQuantization.compute / encodeAll (deterministic: a grid search, no RNG) and NVQScorer, 1 and 3 sub-vectors ----
+            for (int S : new int[]{1, 3}) {
+                NVQuantization nvq = NVQuantization.compute(ravv, S);
+                float[] mean = new float[D];
+                for (int j = 0; j < D; j++) mean[j] = nvq.globalMean.get(j);
+                g.floats("nvq_mean_s" + S, mean);
+                NVQVectors nv = (NVQVectors) nvq.encodeAll(ravv);
+                byte[] nb = new byte[N * D];
+                float[] np = new float[N * S * 4];
+                for (int i = 0; i < N; i++) {
+                    var qvec = nv.get(i);
+                    int off = 0;
+                    for (int sv = 0; sv < S; sv++) {
+                        var sub = qvec.subVectors[sv];
+                        for (int d = 0; d < sub.bytes.length(); d++) nb[i * D + off + d] = sub.bytes.get(d);
+                        off += sub.bytes.length();
+                        np[(i * S + sv) * 4] = sub.minValue;               // the order QuantizedSubVector.write serialises them
+                        np[(i * S + sv) * 4 + 1] = sub.maxValue;
+                        np[(i * S + sv) * 4 + 2] = sub.growthRate;
+                        np[(i * S + sv) * 4 + 3] = sub.midpoint;
+                    }
+                }
+                g.bytes("nvq_bytes_s" + S, nb, N, D);
+                g.floats("nvq_params_s" + S, np, N, S, 4);
+                for (var vsf : VectorSimilarityFunction.values()) {
+                    float[] sc = new float[Q * N];
+                    for (int q = 0; q < Q; q++) {
+                        var f = nv.scoreFunctionFor(qv.get(q), vsf);
+                        for (int i = 0; i < N; i++) sc[q * N + i] = f.similarityTo(i);
+                    }
+                    g.floats("nvq_scores_" + vsf.name() + "_s" + S, sc, Q, N);
+                }
+                try (var w = new SimpleWriter(tmp)) { nv.write(w, OnDiskGraphIndex.CURRENT_VERSION); }
+                g.bytes("nvqvectors_bytes_s" + S, Files.readAllBytes(tmp));
             }
 
             // ---- a graph built by the reference (hierarchy on), dumped level by level; searches over it with the PQ score

@@ -121,6 +121,15 @@ class OracleSide:
         """blocks_codes [n, M]: the codes a fused block holds for its neighbour slots -> FusedPQDecoder arithmetic"""
         return np.stack([self.pq.adc_scores(qq, vsf, blocks_codes, fused=True) for qq in q])
 
+    def nvq_encode(self, vectors, S):
+        o = O.OracleNVQ.compute(vectors, S)
+        b, p = o.encode_all(vectors)
+        return o.mean, b, p
+
+    def nvq_scores(self, mean, S, b, p, q, vsf):
+        ords = np.tile(np.arange(len(b), dtype=np.int32), (len(q), 1))
+        return O.OracleNVQ(mean, S).set_rows(b, p).scores(q, vsf, ords)
+
 
 def check_goldens(g, side, exact):
     N, D, M, Q, DEG, BEAM, TOPK, RERANK = (int(x) for x in g["shape"])
@@ -162,6 +171,23 @@ def check_goldens(g, side, exact):
             got = side.fused_scores(queries, vsf, od.fused_blocks[o][:d])
             _same_floats(got, want[:, oi, :d], exact, f"FusedPQDecoder.similarityToNeighbor {name} origin {o}")          # row 7
             assert np.all(np.isneginf(want[:, oi, d:]))
+    # NVQ (records added in round 3; a file dumped before that simply lacks them): mean, bytes + parameters, NVQScorer scores, blob
+    for S in (1, 3):
+        if f"nvq_mean_s{S}" not in g:
+            continue
+        mean, b, p = side.nvq_encode(vectors, S)
+        _same_floats(mean, g[f"nvq_mean_s{S}"], exact, f"NVQuantization.compute global mean S={S}")
+        if exact:
+            assert np.array_equal(b, g[f"nvq_bytes_s{S}"]), f"NVQ bytes S={S}"
+        else:
+            assert (np.asarray(b) != g[f"nvq_bytes_s{S}"]).mean() < 1e-2, f"NVQ bytes S={S}"
+        _same_floats(np.asarray(p).reshape(N, S, 4), g[f"nvq_params_s{S}"], exact, f"NVQ parameters S={S}")
+        for name, vsf in VSFS:   # scored from the REFERENCE's rows, so that a byte that differs above does not cascade
+            got = side.nvq_scores(g[f"nvq_mean_s{S}"], S, g[f"nvq_bytes_s{S}"], g[f"nvq_params_s{S}"], queries, vsf)
+            _same_floats(got, g[f"nvq_scores_{name}_s{S}"], exact, f"NVQScorer {name} S={S}")
+        m2, S2, b2, p2 = F.read_nvqvectors(g[f"nvqvectors_bytes_s{S}"].tobytes())
+        assert S2 == S and np.array_equal(b2, g[f"nvq_bytes_s{S}"]) and np.array_equal(_bits(p2), _bits(g[f"nvq_params_s{S}"]))
+        assert np.array_equal(_bits(m2), _bits(g[f"nvq_mean_s{S}"]))
 
 
 # ---- an oracle-made file with GoldenDump's records: keeps the checker honest without a JDK ----------------------------------
@@ -219,6 +245,12 @@ def oracle_made_goldens(seed=5):
             d = int((lv[0][1][o] >= 0).sum())
             fs[:, oi, :d] = side.fused_scores(q, vsf, blocks[o][:d])
         rec[f"fused_scores_{name}"] = fs
+    for S in (1, 3):
+        mean, b, p = side.nvq_encode(v, S)
+        rec[f"nvq_mean_s{S}"], rec[f"nvq_bytes_s{S}"], rec[f"nvq_params_s{S}"] = mean, b, np.asarray(p, np.float32).reshape(N, S, 4)
+        for name, vsf in VSFS:
+            rec[f"nvq_scores_{name}_s{S}"] = side.nvq_scores(mean, S, b, p, q, vsf)
+        rec[f"nvqvectors_bytes_s{S}"] = np.frombuffer(W.write_nvqvectors(mean, S, b, np.asarray(p).reshape(N, S, 4)), np.uint8)
     return rec
 
 
@@ -303,6 +335,19 @@ class HipSide:
 
     def fused_scores(self, q, vsf, blocks_codes):
         return self._scan(q, vsf, blocks_codes, self.J.DecoderKind.FUSED)
+
+    def nvq_encode(self, vectors, S):
+        J = self.J
+        vs = J.VectorSet(self.ctx, vectors)
+        nvq = J.NVQuantization.compute(self.ctx, vs, S)
+        b, p = nvq.encode_all(vs).get()
+        return nvq.global_mean(), b, p
+
+    def nvq_scores(self, mean, S, b, p, q, vsf):
+        J = self.J
+        nv = J.NVQVectors(self.ctx, J.NVQuantization.create(self.ctx, np.ascontiguousarray(mean), S), np.ascontiguousarray(b), np.ascontiguousarray(p))
+        ords = np.tile(np.arange(len(b), dtype=np.int32), (len(q), 1))
+        return np.asarray(nv.scores(np.ascontiguousarray(q), J.VectorSimilarityFunction(vsf), ords))
 
 
 @pytest.mark.gpu
