@@ -26,7 +26,7 @@
 // Per 32-column chunk the block loads 32 KB for 1.05 Mflop (32 flop/B; round 1's one-wave 32 x 128 tile: 12.8 flop/B with
 // eighty 4-byte loads per lane — it reached 0.35 of the MFMA peak).  The next chunk's 8 loads per lane are in flight while
 // the 64 MFMAs of the current one run; ~120 VGPRs and 34 KB of LDS allow 4 blocks = 16 waves per CU.
-// Wave API used: gs_tid (0..255), gs_block_barrier, gs_f32x16, gs_mfma_32x32x2, gs_fmaf, gs_sqrt.
+// Wave API used: gs_tid (0..255), gs_block_barrier, gs_sched_fence, gs_f32x16, gs_mfma_32x32x2, gs_fmaf, gs_sqrt.
 #pragma once
 
 #include <cstdint>
@@ -68,6 +68,18 @@ GS_FN float ed_finish(float dot, float qn, float vn)
 GS_FN void ed_load_chunk(const EdParams &p, int64_t n0, int q0, int kb, int tid, bool vec4, ed_f4 (&ra)[4], ed_f4 (&rb)[4])
 {
     const int r0 = tid >> 3, k = kb + 4 * (tid & 7);
+    // interior tile and chunk (block-uniform; all but the edge tiles): eight unconditional 16-byte loads, no per-row branches
+    if (vec4 && q0 + ED_TQ <= p.Q && n0 + ED_TN <= p.count && kb + ED_KB <= p.D) {
+        const float *qa = p.queries + (int64_t)(q0 + r0) * p.D + k;
+        const float *vb = p.vecs + (p.first + n0 + r0) * p.D + k;
+        const int64_t step = (int64_t)32 * p.D;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const ed_f4 *>(qa + i * step);
+            rb[i] = *reinterpret_cast<const ed_f4 *>(vb + i * step);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = r0 + 32 * i;
@@ -139,14 +151,31 @@ GS_FN void ed_tile(const EdParams &p, int64_t n0, int q0, float *lds)
             }
         }
         // ---- 16 K-steps of 2: lane l supplies A[i = l & 31][k = 2s + (l >> 5)] and B[k][j = l & 31] of each column tile ----
-        const float *a_col = As + 32 * wave + lo;
-        if (wave_active)  // a wavefront whose 32 query rows lie beyond Q only helps with the staging (small batches)
-#pragma unroll 4
-        for (int s = 0; s < ED_KB / 2; ++s) {
-            const int k = 2 * s + hi;
-            const float a = a_col[k * ED_LDW];
+        // Operands of step s + 1 are read from LDS BEFORE the four MFMAs of step s are issued (two register sets), so that an
+        // MFMA never waits for the read issued right in front of it: with reads and MFMAs back to back the matrix pipe idled
+        // ~27 % of the time on LDS latency (SQ_WAIT_INST_LDS, profiles/r3_m).
+        const float *a_col = As + 32 * wave + lo + hi * ED_LDW;   // k = 2 s + hi
+        const float *b_col = Bs + lo + hi * ED_LDW;
+        if (wave_active) {  // a wavefront whose 32 query rows lie beyond Q only helps with the staging (small batches)
+            float a_cur = a_col[0], b_cur[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = gs_mfma_32x32x2(a, Bs[k * ED_LDW + 32 * t + lo], acc[t]);
+            for (int t = 0; t < 4; ++t) b_cur[t] = b_col[32 * t];
+#pragma unroll
+            for (int s = 0; s < ED_KB / 2; ++s) {
+                float a_nxt = 0.0f, b_nxt[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (s + 1 < ED_KB / 2) {
+                    a_nxt = a_col[(2 * s + 2) * ED_LDW];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b_nxt[t] = b_col[(2 * s + 2) * ED_LDW + 32 * t];
+                }
+                gs_sched_fence();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = gs_mfma_32x32x2(a_cur, b_cur[t], acc[t]);
+                gs_sched_fence();
+                a_cur = a_nxt;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b_cur[t] = b_nxt[t];
+            }
         }
         gs_block_barrier();
     }

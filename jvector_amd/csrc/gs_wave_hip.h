@@ -12,6 +12,8 @@ __device__ __forceinline__ void gs_barrier() { __syncthreads(); }
 // multi-wave workgroups (ed_body.h): thread index inside the block and the workgroup barrier
 __device__ __forceinline__ int gs_tid() { return (int)threadIdx.x; }
 __device__ __forceinline__ void gs_block_barrier() { __syncthreads(); }
+// keeps the instruction scheduler from moving anything across this point (software pipelines written in source order)
+__device__ __forceinline__ void gs_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ uint64_t gs_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
 __device__ __forceinline__ long long gs_shfl(long long v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ long long gs_shfl_xor(long long v, int m) { return __shfl_xor(v, m, 64); }

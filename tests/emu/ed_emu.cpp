@@ -15,6 +15,7 @@ static inline int gs_lane() { return emu::lane(); }
 static inline void gs_barrier() { emu::barrier(); }
 static inline int gs_tid() { return emu::lane(); }
 static inline void gs_block_barrier() { emu::barrier(); }
+static inline void gs_sched_fence() {}
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
 static inline float gs_fmaf(float a, float b, float c) { return fmaf(a, b, c); }
 typedef emu::f32x16 gs_f32x16;

@@ -16,6 +16,7 @@ static inline int gs_lane() { return emu::lane(); }
 static inline void gs_barrier() { emu::barrier(); }
 static inline int gs_tid() { return emu::lane(); }
 static inline void gs_block_barrier() { emu::barrier(); }
+static inline void gs_sched_fence() {}
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
