@@ -464,18 +464,10 @@ class NVQVectors:
 
     def write(self, version=6) -> bytes:
         """NVQVectors.write :50-62 (QuantizedVector.write :437-443, QuantizedSubVector.write :577-587)"""
+        from .formats import nvq_records
         b, p = self.get()
-        n, S = self._count, self.nvq.subvectors
-        be32 = lambda v: np.asarray(v, np.int64).astype(np.uint32).astype(">u4")  # noqa: E731
-        cols = [np.broadcast_to(be32([S]).view(np.uint8), (n, 4))]
-        off = 0
-        for s, size in enumerate(self.nvq.subvector_sizes()):
-            cols.append(np.broadcast_to(be32([8]).view(np.uint8), (n, 4)))
-            cols.append(np.ascontiguousarray(p[:, s, :]).astype(">f4").view(np.uint8).reshape(n, 16))
-            cols.append(np.broadcast_to(be32([size, size]).view(np.uint8), (n, 8)))
-            cols.append(b[:, off:off + size])
-            off += size
-        return self.nvq.write(version) + be32([n]).tobytes() + np.concatenate(cols, axis=1).tobytes()
+        n = np.asarray([self._count], np.int64).astype(np.uint32).astype(">u4").tobytes()
+        return self.nvq.write(version) + n + nvq_records(self.nvq.subvector_sizes(), b, p).tobytes()
 
     def close(self):
         if getattr(self, "_h", None):

@@ -286,8 +286,25 @@ def write_pqvectors(pq, pq_vectors, version=6) -> bytes:
     return pq.write(version) + _be_i32([n, pq.M]) + np.ascontiguousarray(codes, np.uint8).tobytes()
 
 
+def nvq_records(sizes, bytes_, params) -> np.ndarray:
+    """count x stride uint8: QuantizedVector.write (B/quantization/NVQuantization.java:437-443; QuantizedSubVector.write :577-587)
+    for every row.  bytes_: count x D uint8; params: count x S x 4 float32 {minValue, maxValue, growthRate, midpoint}"""
+    b = np.ascontiguousarray(bytes_, np.uint8)
+    n, S = b.shape[0], len(sizes)
+    p = np.ascontiguousarray(params, np.float32).reshape(n, S, 4)
+    be32 = lambda v: np.asarray(v, np.int64).astype(np.uint32).astype(">u4").view(np.uint8)  # noqa: E731
+    cols, off = [np.broadcast_to(be32([S]), (n, 4))], 0
+    for s_, size in enumerate(sizes):
+        cols.append(np.broadcast_to(be32([8]), (n, 4)))
+        cols.append(np.ascontiguousarray(p[:, s_, :]).astype(">f4").view(np.uint8).reshape(n, 16))
+        cols.append(np.broadcast_to(be32([size, size]), (n, 8)))
+        cols.append(b[:, off:off + size])
+        off += size
+    return np.concatenate(cols, axis=1)
+
+
 def write_odgi(dimension, levels, entry_node, vectors=None, separated=False, fused_blocks=None, pq_block=None,
-               hierarchy_codes=None, version=6) -> bytes:
+               hierarchy_codes=None, version=6, nvq=None, nvq_separated=False) -> bytes:
     """An OnDiskGraphIndex file (v6 layout; v4 / v5 without FusedPQ) from plain arrays — what OnDiskGraphIndexWriter /
     OnDiskSequentialGraphIndexWriter emit (header CommonHeader.java:78-112 + Header.java:54-78; L0 records
     OnDiskSequentialGraphIndexWriter.java:106-153; sparse levels and the v6 hierarchy block AbstractGraphIndexWriter.java:
@@ -297,6 +314,8 @@ def write_odgi(dimension, levels, entry_node, vectors=None, separated=False, fus
       fused_blocks    : N x (deg0 * M) uint8 + pq_block (ProductQuantization.write bytes) -> FUSED_PQ (v6 only)
       hierarchy_codes : codes of the level-1 nodes in levels[1] order (or of the entry node for a single-layer graph),
                         required with FUSED_PQ
+      nvq             : (NVQuantization.write bytes, bytes[N, D] uint8, params[N, S, 4]) -> NVQ_VECTORS, or SEPARATED_NVQ when
+                        `nvq_separated` (NVQ.java:64-82, SeparatedNVQ.java:78-95); at most one separated feature per file here
     The writer does not reorder or validate the graph; it is the inverse of read_odgi."""
     if version < 4 or version > 6:
         raise ValueError("write_odgi supports versions 4..6")
@@ -312,6 +331,14 @@ def write_odgi(dimension, levels, entry_node, vectors=None, separated=False, fus
         feats.append(FEATURE_ID["SEPARATED_VECTORS" if separated else "INLINE_VECTORS"])
     if fused:
         feats.append(FEATURE_ID["FUSED_PQ"])
+    nvq_rows = None
+    if nvq is not None:
+        if nvq_separated and separated and vectors is not None:
+            raise ValueError("write_odgi writes one separated feature per file")
+        S_nvq = describe_nvq(nvq[0])[3]
+        base_, rem_ = divmod(dimension, S_nvq)
+        nvq_rows = nvq_records([base_ + (1 if i < rem_ else 0) for i in range(S_nvq)], nvq[1], nvq[2])
+        feats.append(FEATURE_ID["SEPARATED_NVQ" if nvq_separated else "NVQ_VECTORS"])
     feats.sort(key=(lambda f: (f == FEATURE_ID["FUSED_PQ"], f)) if version >= 6 else None)  # AbstractFeature.compareTo
     layer_info = [(N, deg0)] + [(len(ids), nb.shape[1]) for ids, nb in levels[1:]]
 
@@ -324,6 +351,10 @@ def write_odgi(dimension, levels, entry_node, vectors=None, separated=False, fus
                 return pq_block
             if fid == FEATURE_ID["SEPARATED_VECTORS"]:
                 return int(sep_off).to_bytes(8, "big")
+            if fid == FEATURE_ID["NVQ_VECTORS"]:
+                return bytes(nvq[0])
+            if fid == FEATURE_ID["SEPARATED_NVQ"]:
+                return bytes(nvq[0]) + int(sep_off).to_bytes(8, "big")
             return b""
 
         if version >= 6:
@@ -343,6 +374,8 @@ def write_odgi(dimension, levels, entry_node, vectors=None, separated=False, fus
             cols.append(np.ascontiguousarray(vectors, np.float32).astype(">f4").view(np.uint8).reshape(N, 4 * dimension))
         elif fid == FEATURE_ID["FUSED_PQ"]:
             cols.append(np.ascontiguousarray(fused_blocks, np.uint8).reshape(N, -1))
+        elif fid == FEATURE_ID["NVQ_VECTORS"]:
+            cols.append(nvq_rows)
     degree = (nbrs0 >= 0).sum(axis=1).astype(np.int64)
     cols.append(degree.astype(np.uint32).astype(">u4").view(np.uint8).reshape(N, 4))
     cols.append(nbrs0.astype(np.int64).astype(np.uint32).astype(">u4").view(np.uint8).reshape(N, 4 * deg0))
@@ -364,10 +397,13 @@ def write_odgi(dimension, levels, entry_node, vectors=None, separated=False, fus
     if vectors is not None and separated:
         sep_off = len(out)
         out += np.ascontiguousarray(vectors, np.float32).astype(">f4").tobytes()
+    if nvq is not None and nvq_separated:
+        sep_off = len(out)
+        out += nvq_rows.tobytes()
     if version >= 5:
         header_off = len(out)
         out += header(sep_off) + int(header_off).to_bytes(8, "big") + _be_i32([FOOTER_MAGIC])
-    elif separated and vectors is not None:
+    elif (separated and vectors is not None) or (nvq is not None and nvq_separated):
         h = header(sep_off)
         out[:len(h)] = h
     return bytes(out)

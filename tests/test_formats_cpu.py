@@ -261,12 +261,17 @@ def test_odgi_rejects_corruption():
         F.describe_odgi(bytes(bad))
 
 
-def test_odgi_nvq_is_unsupported():
+def test_odgi_nvq_header_is_validated():
+    """NVQ features are decoded since round 3 (tests/test_nvq_cpu.py); what stays refused: a feature header that is not an
+    NVQuantization block, and bit depths the reference's own loader rejects (BitsPerDimension.load)"""
     import jvector_amd as J
-    # v6 header listing NVQ_VECTORS (feature ordinal 2)
+    # v6 header listing NVQ_VECTORS (feature ordinal 2) followed by zeros instead of an NVQuantization block
     hdr = W._common_header(6, 4, 0, [(1, 2)], 1) + W._i32(1, W.NVQ_VECTORS)
-    with pytest.raises(J.UnsupportedError, match="NVQ"):
+    with pytest.raises(ValueError, match="nvq"):
         F.describe_odgi(hdr + b"\0" * 64)
+    four_bits = W._i32(6, 4) + W._be_f32(np.zeros(4, np.float32)) + W._i32(4, 1) + W._i32(4)
+    with pytest.raises(J.UnsupportedError, match="Unsupported BitsPerDimension 4"):
+        F.describe_odgi(hdr + four_bits + b"\0" * 64)
 
 
 def test_readers_survive_corrupted_input():

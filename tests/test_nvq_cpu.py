@@ -131,11 +131,12 @@ def test_nvqvectors_reader_round_trip():
         F.read_nvqvectors(blob[:-3])
     bad = bytearray(blob)
     bad[8 + 4 * 50: 8 + 4 * 50 + 4] = (4).to_bytes(4, "big")              # bitsPerDimension = 4: BitsPerDimension.load throws
-    with pytest.raises(F.UnsupportedError if hasattr(F, "UnsupportedError") else Exception, match="Unsupported BitsPerDimension 4"):
+    from jvector_amd import UnsupportedError
+    with pytest.raises(UnsupportedError, match="Unsupported BitsPerDimension 4"):
         F.describe_nvq(bytes(bad))
     odd = bytearray(blob)
     odd[8 + 4 * 50 + 8: 8 + 4 * 50 + 12] = (16).to_bytes(4, "big")        # sizes that NVQuantization.create would not make
-    with pytest.raises(Exception, match="NVQuantization.create"):
+    with pytest.raises(UnsupportedError, match="NVQuantization.create"):
         F.describe_nvq(bytes(odd))
 
 
@@ -166,6 +167,24 @@ def test_odgi_with_nvq_features(separated, version):
                              placeholder_fill=0xAB)
         g2 = F.read_odgi(data2)
         assert np.array_equal(g2.nvq_bytes, want_b) and np.array_equal(g2.nvq_params.view(np.uint32), want_p.view(np.uint32))
+
+
+def test_product_odgi_writer_with_nvq_matches_the_oracle_writer():
+    """formats.write_odgi(nvq=...) (the product's writer) emits the bytes the oracle's restatement of the reference's writers does"""
+    from jvector_amd import formats as F
+    N, D, S, deg = 23, 12, 2, 4
+    X, o = _rows(6, N, D, S)
+    rng = np.random.default_rng(7)
+    l0 = [list(rng.choice(N, int(rng.integers(1, deg + 1)), replace=False)) for _ in range(N)]
+    nb = np.full((N, deg), -1, np.int32)
+    for i, r in enumerate(l0):
+        nb[i, :len(r)] = r
+    blk = W.write_nvq_block(o.mean, S)
+    for sep in (False, True):
+        want = W.write_odgi(6, D, l0, deg, 0, nvq=(o.mean, S, o.bytes, o.params), nvq_separated=sep)
+        assert F.write_odgi(D, [(None, nb)], 0, nvq=(blk, o.bytes, o.params), nvq_separated=sep) == want
+        g = F.read_odgi(want)
+        assert np.array_equal(g.nvq_bytes, o.bytes) and g.nvq_block == blk
 
 
 # ---- (4) host logic on the mock device -------------------------------------------------------------------------------
