@@ -219,7 +219,6 @@ __global__ __launch_bounds__(64) void nvq_encode_kernel(const float *__restrict_
         // coarse pass :523-531
         float loss = 0.0f;
         if (valid && l < 20) loss = baseline / nq_loss_chain(v, n, nloop, grid[l], mn, mx);
-        else (void)nq_loss_chain(v, 0, 0, 1.0f, 0.0f, 1.0f);
         if (valid) scr[l] = loss;
         __syncthreads();
         float best = 1.401298464324817e-45f;   // Float.MIN_VALUE

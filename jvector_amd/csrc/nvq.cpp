@@ -93,8 +93,10 @@ int nvq_gather(jv_ctx *ctx, jv_nvq_vectors *nv, const float *d_q, int Q, jv_vsf 
 {
     const jv_nvq *q = nv->nvq;
     JV_TRY(ensure_nvq_tables(ctx, nv, vsf == JV_COSINE));
-    JV_TRY(ctx->d_nvq_q.reserve(sizeof(float) * ((size_t)Q * q->D + (size_t)Q)));
-    float *qwork = (float *)ctx->d_nvq_q.ptr, *qaux = qwork + (size_t)Q * q->D;
+    // per-query scalars (dot product with the mean / query norm), and for EUCLIDEAN only the shifted queries
+    const size_t work = vsf == JV_EUCLIDEAN ? (size_t)Q * q->D : 0;
+    JV_TRY(ctx->d_nvq_q.reserve(sizeof(float) * (work + (size_t)Q)));
+    float *qwork = (float *)ctx->d_nvq_q.ptr, *qaux = qwork + work;
     ProfScope ps(ctx, R_EXACT);
     return launch_nvq_gather(ctx->stream, nv->d_bytes, nv->ld, nv->count, q->D, q->S, nv->d_derived, nv->d_cosnorm, q->d_mean, d_q, Q,
                              to_kernel_vsf(vsf), d_ord, B, d_out, qwork, qaux);
