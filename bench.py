@@ -855,6 +855,36 @@ def main():
             for k in kv:
                 os.environ.pop(k, None)
 
+    # developer aid: JVECTOR_BENCH_IN_FLIGHT=n re-times the steps with n batches in flight — n host threads, each with its own
+    # context (= its own HIP stream and scratch) and searcher over the SAME index, taking the steps round-robin — so that one
+    # batch's HBM-bound rerank can overlap another's gather-bound traversal.  stderr only; the reported line stays one batch at a time.
+    if graph_mode and int(os.environ.get("JVECTOR_BENCH_IN_FLIGHT", "1")) > 1:
+        import threading
+        nfl = int(os.environ["JVECTOR_BENCH_IN_FLIGHT"])
+        ctxs = [ctx] + [J.HipContext(dev.index or 0) for _ in range(nfl - 1)]
+        srs = [searcher] + [J.GraphSearcher(c, graph, pq, cv, fused, rerank_vs, max_queries=Q) for c in ctxs[1:]]
+        for sr in srs:
+            sr.search(timed_q[:Q], VSF, K, rerank_k)
+
+        def worker(t):
+            for s_ in range(t, args.steps, nfl):
+                srs[t].search(timed_q[s_ * Q:(s_ + 1) * Q], VSF, K, rerank_k)
+
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(nfl)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        log(f"[in-flight] {nfl} batches in flight: {dt * 1e3:.2f} ms/step, {Q / dt:.0f} QPS (one at a time: {elapsed / args.steps * 1e3:.2f} ms/step)")
+        for sr in srs[1:]:
+            sr.close()
+        for c in ctxs[1:]:
+            c.close()
+
     rccl_ranks = ranks.rccl_ranks()
     elapsed, total_queries, per_rank = aggregate(ranks, elapsed, Q * args.steps)
 
