@@ -279,6 +279,7 @@ int jv_hip_ctx_destroy(jv_ctx *ctx)
     ctx->d_gs_mask.release();
     ctx->d_gs_big.release();
     ctx->d_nvq_q.release();
+    ctx->d_gs_extra.release();
     for (auto &e : ctx->prof_pending) {
         (void)hipEventDestroy(e.start);
         (void)hipEventDestroy(e.stop);

@@ -640,11 +640,18 @@ struct jv_searcher {
     int Q = 0;
     jv_vsf vsf = JV_DOT_PRODUCT;
     bool searched = false;
-    // the last search() ran on the device traversal: the per-query candidate queues / visited sets were never brought to the
-    // host, so a resume() first replays that search on the host searcher (deterministic: the same state the device left)
+    // the calls since the last search() ran on the device traversal: the per-query candidate queues / visited sets were never
+    // brought to the host.  resume() replays them (the traversal is deterministic): inside the session kernel (GsParams::n_phases)
+    // while the history is short, else on the host searcher.  One record per call — its parameters and the evictedResults every
+    // query held when it returned (what the next resume() pushes back into the candidates)
     bool device_searched = false;
-    int last_topK = 0, last_rerankK = 0;
-    float last_threshold = 0.0f, last_floor = 0.0f;
+    struct Call {
+        int topK = 0, rerankK = 0;
+        float threshold = 0.0f, floor = 0.0f;
+        std::vector<int32_t> ev_off;     // Q + 1
+        std::vector<long long> ev_keys;  // evictedResults of every query, query-major
+    };
+    std::vector<Call> history;
 };
 
 // What the plain jv_hip_graph_search entry points leave at their defaults
@@ -1248,6 +1255,9 @@ static int ensure_device_graph(jv_ctx *ctx, jv_graph *g)
 // the counters, and which queries could not be finished on the device.
 struct DeviceSessionOut {
     float threshold = 0.0f;
+    // resume(): the calls to replay before the one being served (jv_searcher::history) and the new call's parameters
+    const std::vector<jv_searcher::Call> *history = nullptr;
+    int new_rerankK = 0;
     int log_cap = 0;
     std::vector<int32_t> status, base, log_n;
     std::vector<int64_t> stats;      // Q x 2
@@ -1442,6 +1452,38 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p.session = 1;
         p.threshold = so->threshold;
         p.out_base = (int32_t *)(base + o_base);
+        if (so->history && !so->history->empty()) {   // resume(): search() + the earlier resume() calls + this one, in one launch
+            const std::vector<jv_searcher::Call> &h = *so->history;
+            const int np = (int)h.size() + 1;
+            std::vector<int32_t> off((size_t)(np - 1) * Q + 1);
+            size_t total = 0;
+            for (int t = 0; t < np - 1; ++t) {
+                p.ph_rerankK[t] = h[(size_t)t].rerankK;
+                p.ph_threshold[t] = h[(size_t)t].threshold;
+                for (int q = 0; q < Q; ++q) {
+                    off[(size_t)t * Q + q] = (int32_t)total;
+                    total += (size_t)(h[(size_t)t].ev_off[(size_t)q + 1] - h[(size_t)t].ev_off[(size_t)q]);
+                }
+            }
+            off.back() = (int32_t)total;
+            p.ph_rerankK[np - 1] = so->new_rerankK;
+            p.ph_threshold[np - 1] = so->threshold;
+            p.n_phases = np;
+            p.ph_Q = Q;
+            const size_t off_bytes = (sizeof(int32_t) * off.size() + 15) & ~(size_t)15;
+            JV_TRY(ctx->d_gs_extra.reserve(off_bytes + sizeof(long long) * std::max<size_t>(total, 1)));
+            JV_HIP_CHECK(hipMemcpyAsync(ctx->d_gs_extra.ptr, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice, ctx->stream));
+            size_t at = 0;
+            for (int t = 0; t < np - 1; ++t) {
+                const size_t n = h[(size_t)t].ev_keys.size();
+                if (n) JV_HIP_CHECK(hipMemcpyAsync((char *)ctx->d_gs_extra.ptr + off_bytes + sizeof(long long) * at, h[(size_t)t].ev_keys.data(),
+                                                   sizeof(long long) * n, hipMemcpyHostToDevice, ctx->stream));
+                at += n;
+            }
+            JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // `off` goes out of scope with this block
+            p.ph_extra_off = (const int32_t *)ctx->d_gs_extra.ptr;
+            p.ph_extra = (const long long *)((const char *)ctx->d_gs_extra.ptr + off_bytes);
+        }
     }
     if (big_count > 0) {
         p.big_visited = (int32_t *)ctx->d_gs_big.ptr;
@@ -1843,10 +1885,15 @@ int jv_hip_searcher_destroy(jv_searcher *s)
 // yields the layer-0 evictedResults — and runs the shared rerank stage (rerankFloor, CachingReranker, worstApproximateScoreInTopK).
 // *done = false: the shape is outside the session kernels' coverage, the traversal is pinned to the host, or some query
 // outgrew the device structures / its log — the caller runs the whole batch on the host searcher instead (same answers).
-static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, int rerankK, float threshold, float rerankFloor,
+// search() — or, with `resume`, resume() after calls that all ran here (s->history): the session kernel replays them and goes on
+static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, int rerankK, float threshold, float rerankFloor, bool resume,
                                   int32_t *out_ids, float *out_scores, int32_t *out_counts, int64_t *stats, float *worst, bool *done)
 {
     *done = false;
+    if (resume && (s->history.empty() || (int)s->history.size() >= GS_MAX_PHASES)) return JV_OK;
+    int rk_max = rerankK;   // LDS result array / output stride of the launch: the largest rerankK of the replayed calls
+    if (resume)
+        for (const jv_searcher::Call &c : s->history) rk_max = std::max(rk_max, c.rerankK);
     const jv_graph *g = s->g;
     jv_luts *l = s->luts;
     const jv_pq *pq = l->pq;
@@ -1863,7 +1910,7 @@ static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, 
                       graph_search_session_supported(pq->M) &&
                       (!s->fused || (s->fused->pq == pq && s->fused->count == g->n_nodes && s->fused->maxDegree == g->levels[0].degree)) &&
                       (!s->vectors || (s->vectors->D == pq->D && s->vectors->count >= g->n_nodes)) &&
-                      graph_search_lds_bytes(pq->D, rerankK, 256, 0) + gs_session_lds_bytes() <= std::min<size_t>(ctx->lds_per_block, 40 * 1024);
+                      graph_search_lds_bytes(pq->D, rk_max, 256, 0) + gs_session_lds_bytes() <= std::min<size_t>(ctx->lds_per_block, 40 * 1024);
     if (!fits) {
         if (mode == JV_TRAVERSAL_DEVICE) ctx_stat_add(ctx, "gs_session_calls_host_unsupported", 1);
         return JV_OK;
@@ -1880,8 +1927,12 @@ static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, 
     }
     DeviceSessionOut so;
     so.threshold = threshold;
-    JV_TRY(graph_search_device(ctx, g, l, s->codes, s->fused, s->vectors, s->queries.data(), Q, s->vsf, topK, rerankK, nullptr, nullptr, nullptr,
-                               host_accept, dev_accept, &so));
+    if (resume) {
+        so.history = &s->history;
+        so.new_rerankK = rerankK;
+    }
+    JV_TRY(graph_search_device(ctx, g, l, s->codes, s->fused, s->vectors, s->queries.data(), Q, s->vsf, std::min(topK, rk_max), rk_max, nullptr,
+                               nullptr, nullptr, host_accept, dev_accept, &so));
     for (int q = 0; q < Q; ++q)
         if (so.log_cap < 0 || so.status[(size_t)q] != GS_OK || so.log_n[(size_t)q] < 0 || so.log_n[(size_t)q] > so.log_cap) {
             ctx_stat_add(ctx, "gs_session_calls_host_overflow", 1);
@@ -1898,8 +1949,8 @@ static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, 
             QState &st = *s->states[(size_t)q];
             st.cand.clear();
             st.res.clear();
-            st.evicted.clear();
-            st.exact_cache.clear();
+            st.evicted.clear();                       // search(): initializeInternal; resume(): searchLayer0 moved it to the candidates
+            if (!resume) st.exact_cache.clear();      // the CachingReranker lives as long as the search does (:568-576)
             st.searched = true;
             res.clear();
             const long long *log = so.log.data() + (size_t)q * (size_t)so.log_cap;
@@ -1937,6 +1988,28 @@ static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, 
     if (out_counts) JV_TRY(copy_out(out_counts, counts.data(), sizeof(int32_t) * (size_t)Q));
     if (stats) JV_TRY(copy_out(stats, st4.data(), sizeof(int64_t) * 4 * (size_t)Q));
     if (worst) JV_TRY(copy_out(worst, w.data(), sizeof(float) * (size_t)Q));
+    // this call joins the history: its parameters and what every query's evictedResults holds now
+    if (!resume) s->history.clear();
+    s->history.emplace_back();
+    jv_searcher::Call &c = s->history.back();
+    c.topK = topK;
+    c.rerankK = rerankK;
+    c.threshold = threshold;
+    c.floor = rerankFloor;
+    c.ev_off.resize((size_t)Q + 1);
+    size_t total = 0;
+    for (int q = 0; q < Q; ++q) {
+        c.ev_off[(size_t)q] = (int32_t)total;
+        total += s->states[(size_t)q]->evicted.size();
+    }
+    c.ev_off[(size_t)Q] = (int32_t)total;
+    c.ev_keys.resize(total);
+    static_assert(sizeof(long long) == sizeof(int64_t), "NodeQueue keys are 64-bit");
+    for (int q = 0; q < Q; ++q) {
+        const std::vector<int64_t> &ev = s->states[(size_t)q]->evicted;
+        if (!ev.empty()) memcpy(c.ev_keys.data() + c.ev_off[(size_t)q], ev.data(), sizeof(int64_t) * ev.size());
+    }
+    if (resume) ctx_stat_add(ctx, "gs_session_resume_device", 1);
     *done = true;
     return JV_OK;
 }
@@ -1952,30 +2025,37 @@ static int searcher_run(jv_ctx *ctx, jv_searcher *s, int Q, int topK, int rerank
     }
     if (!resume) {
         s->device_searched = false;
-        s->last_topK = topK;
-        s->last_rerankK = rerankK;
-        s->last_threshold = threshold;
-        s->last_floor = rerankFloor;
+        s->history.clear();
         bool done = false;
-        JV_TRY(searcher_search_device(ctx, s, Q, topK, rerankK, threshold, rerankFloor, out_ids, out_scores, out_counts, stats, worst, &done));
+        JV_TRY(searcher_search_device(ctx, s, Q, topK, rerankK, threshold, rerankFloor, false, out_ids, out_scores, out_counts, stats, worst, &done));
         if (done) {
             s->device_searched = true;
             return JV_OK;
         }
     } else if (s->device_searched) {
-        // resume() after a device search: rebuild the per-query state by replaying that search on the host searcher
-        HostSearchOpts ro;
-        ro.threshold = s->last_threshold;
-        ro.rerank_floor = s->last_floor;
-        ro.session = s;
-        if (s->has_accept) {
-            ro.accept.bits = s->accept.data();
-            ro.accept.stride_words = s->accept_stride;
+        // resume() after calls that ran on the device: the candidate queues / visited sets never left it.  The session kernel
+        // replays those calls and continues (one launch); if it cannot (history too long, a structure or the log overflowed),
+        // the same history is replayed on the host searcher instead and the searcher stays there.
+        bool done = false;
+        JV_TRY(searcher_search_device(ctx, s, Q, topK, rerankK, threshold, rerankFloor, true, out_ids, out_scores, out_counts, stats, worst, &done));
+        if (done) return JV_OK;
+        const std::vector<jv_searcher::Call> calls = std::move(s->history);
+        s->history.clear();
+        for (size_t i = 0; i < calls.size(); ++i) {
+            HostSearchOpts ro;
+            ro.threshold = calls[i].threshold;
+            ro.rerank_floor = calls[i].floor;
+            ro.session = s;
+            ro.resume = i > 0;
+            if (s->has_accept) {
+                ro.accept.bits = s->accept.data();
+                ro.accept.stride_words = s->accept_stride;
+            }
+            std::vector<int32_t> ids((size_t)Q * calls[i].topK);
+            std::vector<float> sc((size_t)Q * calls[i].topK);
+            JV_TRY(graph_search_host(ctx, g, s->luts, s->codes, s->fused, s->vectors, s->queries.data(), Q, s->vsf, calls[i].topK, calls[i].rerankK,
+                                     ids.data(), sc.data(), nullptr, ro));
         }
-        std::vector<int32_t> ids((size_t)Q * s->last_topK);
-        std::vector<float> sc((size_t)Q * s->last_topK);
-        JV_TRY(graph_search_host(ctx, g, s->luts, s->codes, s->fused, s->vectors, s->queries.data(), Q, s->vsf, s->last_topK, s->last_rerankK,
-                                 ids.data(), sc.data(), nullptr, ro));
         s->device_searched = false;
         ctx_stat_add(ctx, "gs_session_resume_replays", 1);
     }

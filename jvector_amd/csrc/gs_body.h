@@ -692,6 +692,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     int32_t trk_min = 0x7fffffff;
     bool thr_on = false;
     long long n_expanded_base = 0;
+    float cur_thr = p.threshold;   // the running phase's threshold (SES with n_phases > 1: ph_threshold[phase])
     if constexpr (SES) {
         trk_recent = reinterpret_cast<float *>(lds + gs_lds_bytes(p.D, p.rerankK, p.cand_cap, PAIR ? p.M : 0, evict_cap, p.v1_log2));
         trk_best = reinterpret_cast<int32_t *>(trk_recent + TRK_RECENT);
@@ -767,15 +768,20 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         const double window = lower + (pos - (double)(int)pos) * (upper - lower);
         const int32_t e = trk_min;
         const double worst_best = (double)gs_bits_float(e ^ ((e >> 31) & 0x7fffffff));
-        return window < worst_best && window < (double)p.threshold;
+        return window < worst_best && window < (double)cur_thr;
     };
 
     for (int lvl = p.entry_level; lvl >= 0 && s.status == GS_OK; --lvl) {
-        const int rk = lvl > 0 ? 1 : p.rerankK;
+        int rk = lvl > 0 ? 1 : p.rerankK;
         const GsLevel &L = p.lv[lvl];
-        const float thr = (SES && lvl == 0) ? p.threshold : 0.0f;
+        int phase = 0;
+        if (SES && lvl == 0 && p.n_phases > 1) {
+            rk = p.ph_rerankK[0];
+            cur_thr = p.ph_threshold[0];
+        }
+        float thr = (SES && lvl == 0) ? cur_thr : 0.0f;
         if constexpr (SES) {   // getScoreTracker (ScoreTracker.java:38-58): layer 0 of a threshold search, reset per layer entry
-            thr_on = lvl == 0 && p.threshold > 0.0f;
+            thr_on = lvl == 0 && cur_thr > 0.0f;
             trk_obs = 0;
             trk_nbest = 0;
             trk_min = 0x7fffffff;
@@ -784,7 +790,8 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         // layer 0 evicts nothing, so the evicted area's first word counts the push-log entries there (lane 0 only: no
         // register stays live across the loop for it)
         if (lvl == 0 && p.push_log && lane == 0) *reinterpret_cast<int *>(s.evicted) = 0;
-        // ---- searchOneLayer :406-457 ----
+        // ---- searchOneLayer :406-457 (layer 0 of a session with a history: once per phase) ----
+        for (;;) {
         for (;;) {
             if (s.cand_n == 0 && s.spill_n == 0) break;
             if (PROF) pt = GS_CLOCK();
@@ -965,6 +972,35 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             gs_push(s, p, key, fresh);
             GS_PHASE(4);
             if (s.status != GS_OK) break;
+        }
+        if (!(SES && lvl == 0 && s.status == GS_OK && phase + 1 < p.n_phases)) break;
+        if constexpr (SES) {
+            // ---- the call returned and resume() was called: reranking() drained approximateResults (:471-507), searchLayer0 puts
+            //      evictedResults back into the candidates (:459-469), the counters of SearchResult restart (:541-545) ----
+            s.res_n = 0;
+            s.res_min = GS_KEY_MAX;
+            s.res_min_idx = -1;
+            const int32_t *off = p.ph_extra_off + (int64_t)phase * p.ph_Q + q;
+            const int e0 = off[0], e1 = off[1];
+            for (int base = e0; base < e1 && s.status == GS_OK; base += 64) {
+                const bool has = base + lane < e1;
+                gs_push(s, p, has ? p.ph_extra[base + lane] : 0, has);
+            }
+            phase++;
+            rk = p.ph_rerankK[phase];
+            cur_thr = p.ph_threshold[phase];
+            thr = cur_thr;
+            thr_on = cur_thr > 0.0f;
+            trk_obs = 0;
+            trk_nbest = 0;
+            trk_min = 0x7fffffff;
+            trk_min_idx = -1;
+            n_visited = 0;
+            n_expanded = 0;
+            n_expanded_base = 0;
+            if (p.push_log && lane == 0) *reinterpret_cast<int *>(s.evicted) = 0;
+            gs_barrier();
+        }
         }
         if (s.status != GS_OK) break;
         if (lvl > 0) {  // setEntryPointsFromPreviousLayer :324-331

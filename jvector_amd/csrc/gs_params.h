@@ -9,6 +9,7 @@ namespace jv {
 
 constexpr int GS_MAX_LEVELS = 32;
 constexpr int GS_EVICT_CAP = 128;
+constexpr int GS_MAX_PHASES = 8;   // session kernels: a search() and up to 7 resume() calls replayed in one launch
 enum : int32_t { GS_OK = 0, GS_OVERFLOW = 1, GS_RERANK_TIE = 2 /* set by rerank_tie_kernel, not by the traversal */ };
 
 struct GsLevel {
@@ -57,6 +58,17 @@ struct GsParams {
     int32_t session;          // 1: launch the session kernel (SES = true)
     float threshold;          // layer-0 admission `score >= threshold` (:437); > 0 also arms the TwoPhaseTracker
     int32_t *out_base;        // [Q] expandedCountBaseLayer, or nullptr
+    // resume() on the device = the whole history of the searcher in ONE launch: phase 0 is the original search(), phase i > 0 the
+    // i-th resume().  Between two phases the kernel does what reranking() + searchLayer0() do to the traversal state
+    // (GraphSearcher.java:459-507): approximateResults is empty, evictedResults — ph_extra, the keys the host kept from that
+    // call — goes back to the candidates, the counters restart.  Candidates and the visited set simply live on.  n_phases <= 1:
+    // a plain search (ph_* unused, rerankK / threshold above apply).
+    int32_t n_phases;
+    int32_t ph_rerankK[GS_MAX_PHASES];
+    float ph_threshold[GS_MAX_PHASES];
+    const long long *ph_extra;      // keys of all transitions, query-major inside a phase
+    const int32_t *ph_extra_off;    // (n_phases - 1) * ph_Q + 1 offsets into ph_extra: transition t of query q = [t * ph_Q + q, t * ph_Q + q + 1)
+    int32_t ph_Q;                   // queries of the searcher (a launch may cover a part of them: Q / qmap above)
     int32_t lutr;             // 1: the query's ADC table lives in the wave's registers (M <= 96; one wave per SIMD; no pair lanes)
     int32_t prefetch;         // 1: touch the runner-up candidate's adjacency row + fused block while the popped one is scored (layer 0)
     int32_t v1_log2;          // log2(slots) of the LDS tier (slots / 4 buckets of four 16-bit entries), 0 = no LDS tier

@@ -89,6 +89,7 @@ struct jv_ctx {
     jv::Buffer h_in, h_out, d_in, d_out, d_scratch, d_scratch2, d_scratch3;
     // device-resident graph traversal: per-worker visited tables / spill tiers and the per-query result staging
     jv::Buffer d_gs_visited, d_gs_spill, d_gs_out, d_gs_mask, d_gs_big;
+    jv::Buffer d_gs_extra;   // session kernels: the evictedResults a resume() pushes back (graph_search.cpp)
     jv::Buffer d_nvq_q;   // NVQ rerank: shifted queries + per-query scalars (nvq.cpp)
     // host batched graph searcher: worker pool (graph_search.cpp owns the type) and its destructor
     void *host_pool = nullptr;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GraphSearcher OBJECTS on the device traversal (round 3): QPS of search_ex — plain, with a rerank floor, with a threshold —
-next to the plain batched search, on a 1M x 768 / PQ-96 index the engine builds itself; and the cost of resume() (host replay).
+next to the plain batched search, on a 1M x 768 / PQ-96 index the engine builds itself; and the cost of resume() (the session
+kernel replays the searcher's earlier calls and goes on: one launch).
 Prints one JSON object.   usage: python scripts/searcher_bench.py [--n 1000000] [--queries 4096]"""
 import argparse
 import json
@@ -77,9 +78,15 @@ def main():
                      "avg_results": float(cnt.mean()), "avg_visited": float(st[:, 0].mean())}
     t, _ = timed(lambda: s.search_ex(qh, VSF, top_k=10, rerank_k=100), reps=2)
     out["objects_plain_through_python_search_ex_qps"] = Q / t
+    ctx.reset_stats()
     t0 = time.perf_counter()
     s.resume(10, 100)
     out["resume_after_device_search_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    s.resume(10, 100)
+    out["second_resume_s"] = time.perf_counter() - t0
+    out["resume_device_calls"] = ctx.stat("gs_session_resume_device")
+    out["resume_host_replays"] = ctx.stat("gs_session_resume_replays")
     ctx.set_option("graph_traversal", 1)   # the same searches on the host searcher
     t, _ = timed(c_call(top_k=200, rerank_k=200, threshold=thr), reps=1)
     out["objects_threshold_host"] = {"qps": Q / t}
