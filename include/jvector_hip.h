@@ -509,9 +509,11 @@ JV_API int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts 
  * 96, degree <= 64, the rerankK results fit LDS; graph traversal not pinned to the host): threshold admission, the
  * TwoPhaseTracker stop and acceptOrds inside the kernel, then the host rebuilds approximateResults' heap array from the kernel's
  * addTopCandidate log and runs the reference's rerank (floor, caching reranker, worst approximate score).  resume() needs the
- * candidate queue / visited set of every searcher, which never left the device: it first replays the search on the host
- * batched searcher (deterministic, same state) and continues there.  Every other shape runs both calls on the host searcher.
- * Counters: gs_session_calls_device / gs_session_resume_replays / gs_session_calls_host_overflow / _unsupported.
+ * candidate queue / visited set of every searcher, which never left the device: the session kernel replays the searcher's earlier
+ * calls (the traversal is deterministic; up to 7 of them) and continues in the same launch; a longer history, or a query that
+ * outgrows the device structures, replays on the host batched searcher instead.  Every other shape runs both calls on the host
+ * searcher.  Counters: gs_session_calls_device / gs_session_resume_device / gs_session_resume_replays /
+ * gs_session_calls_host_overflow / _unsupported.
  * graph / luts / codes / fused / vectors must outlive the object; one object serves one batch at a time (a new search() discards the previous state).  accept_bits as in
  * jv_hip_graph_search_filtered (copied: resume uses the same filter).  Buffers may be host or device memory. */
 typedef struct jv_searcher jv_searcher;
