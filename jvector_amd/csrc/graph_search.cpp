@@ -1931,6 +1931,8 @@ static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, 
         so.history = &s->history;
         so.new_rerankK = rerankK;
     }
+    const bool timing = ctx_opt(ctx, "graph_timing", 0) != 0;
+    const auto t_start = std::chrono::steady_clock::now();
     JV_TRY(graph_search_device(ctx, g, l, s->codes, s->fused, s->vectors, s->queries.data(), Q, s->vsf, std::min(topK, rk_max), rk_max, nullptr,
                                nullptr, nullptr, host_accept, dev_accept, &so));
     for (int q = 0; q < Q; ++q)
@@ -1938,6 +1940,7 @@ static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, 
             ctx_stat_add(ctx, "gs_session_calls_host_overflow", 1);
             return JV_OK;  // (rare: one query outgrew the device structures or its log) -> the whole batch on the host
         }
+    const auto t_kernel = std::chrono::steady_clock::now();
     // approximateResults + layer-0 evictedResults of every query from its addTopCandidate sequence
     std::vector<std::vector<int64_t>> fin((size_t)Q);
     std::vector<int64_t> q_visited((size_t)Q), q_expanded((size_t)Q), q_expanded_base((size_t)Q);
@@ -1970,6 +1973,7 @@ static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, 
         }
     });
     pool->end();
+    const auto t_replay = std::chrono::steady_clock::now();
     HostSearchOpts opt;
     opt.threshold = threshold;
     opt.rerank_floor = rerankFloor;
@@ -1985,6 +1989,16 @@ static int searcher_search_device(jv_ctx *ctx, jv_searcher *s, int Q, int topK, 
                                 out_ids, out_scores, nullptr);
     pool->end();
     JV_TRY(rc);
+    if (timing) {
+        const auto t_end = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        long long log_total = 0;
+        for (int q = 0; q < Q; ++q) log_total += so.log_n[(size_t)q];
+        fprintf(stderr, "[jv searcher objects] Q=%d %s: tables + traversal + log download %.2f ms, log replay %.2f ms (%.0f entries per query), rerank stage %.2f ms\n",
+                Q, resume ? "resume" : "search", ms(t_start, t_kernel), ms(t_kernel, t_replay), (double)log_total / Q, ms(t_replay, t_end));
+    }
     if (out_counts) JV_TRY(copy_out(out_counts, counts.data(), sizeof(int32_t) * (size_t)Q));
     if (stats) JV_TRY(copy_out(stats, st4.data(), sizeof(int64_t) * 4 * (size_t)Q));
     if (worst) JV_TRY(copy_out(worst, w.data(), sizeof(float) * (size_t)Q));

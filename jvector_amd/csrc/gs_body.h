@@ -476,6 +476,67 @@ GS_FN void gs_partition(GsState &s, const GsParams &p)
     s.spill_max = pivot;  // the pivot itself moved, everything that stayed is larger
 }
 
+// The LDS tier ran dry while keys wait in the spill tier: bring the BEST of them back (all of them if they fit in half the
+// tier; else those above a pivot taken from 64 samples, aimed at a quarter of the tier), so that the pops that follow scan LDS
+// again instead of the whole spill tier in global memory — one pass over the tier per ~cand_cap / 4 pops instead of one per pop
+// (a threshold search that waits for the TwoPhaseTracker drains hundreds of candidates this way: 12x the time of a plain
+// search before this existed).  The invariant of the two tiers holds afterwards (every LDS key > spill_max >= every spilled
+// key), so the pop order — always the global maximum — is unchanged.  Leaves cand_n == 0 only if no pivot separates anything
+// (the caller then pops from the spill tier directly, as before).
+GS_FN void gs_refill(GsState &s, const GsParams &p)
+{
+    const int lane = gs_lane();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    gs_fence();
+    const int n = s.spill_n;
+    if (n <= p.cand_cap / 2) {
+        for (int base = 0; base < n; base += 64)
+            if (base + lane < n) s.cand[base + lane] = s.spill[base + lane];
+        s.cand_n = n;
+        s.spill_n = 0;
+        s.spill_max = GS_KEY_MIN;
+        gs_barrier();
+        return;
+    }
+    const long long mine = s.spill[(int)(((long long)lane * n) >> 6)];
+    s.samp[lane] = mine;
+    gs_barrier();
+    int rank = 0;
+    for (int j = 0; j < 64; ++j) rank += (s.samp[j] < mine) ? 1 : 0;   // keys are unique: the ranks are 0..63, each once
+    int r = 63 - (int)(((long long)(p.cand_cap / 4) * 64) / n);           // ~cand_cap / 4 keys expected above the rank-r sample
+    r = r < 1 ? 1 : (r > 62 ? 62 : r);
+    long long pivot = 0;
+    int above = 0;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        pivot = gs_shfl(mine, gs_first(gs_ballot(rank == r)));
+        above = 0;
+        for (int base = 0; base < n; base += 64) above += gs_popc(gs_ballot(base + lane < n && s.spill[base + lane] > pivot));
+        if (above <= p.cand_cap - 64 || r >= 62) break;   // (r <= 62: at least the largest sample lies above the pivot)
+        r += (64 - r) / 2;                                  // too many for the tier: a higher pivot
+        if (r > 62) r = 62;
+    }
+    gs_barrier();
+    if (above == 0 || above > p.cand_cap - 64) return;
+    int nc = 0, ns = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool in = i < n;
+        const long long k = in ? s.spill[i] : 0;
+        const bool hi = in && k > pivot;
+        const bool lo = in && !hi;
+        const uint64_t mh = gs_ballot(hi), ml = gs_ballot(lo);  // every lane has read its key before any lane writes
+        if (hi) s.cand[nc + gs_popc(mh & lt)] = k;
+        if (lo) s.spill[ns + gs_popc(ml & lt)] = k;             // in place: target index <= i
+        nc += gs_popc(mh);
+        ns += gs_popc(ml);
+        gs_barrier();
+    }
+    s.cand_n = nc;
+    s.spill_n = ns;
+    s.spill_max = pivot;   // the pivot itself stayed behind; everything that moved is larger
+    gs_fence();
+}
+
 // candidates.push for up to one key per lane
 GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 {
@@ -794,6 +855,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         for (;;) {
         for (;;) {
             if (s.cand_n == 0 && s.spill_n == 0) break;
+            if (s.cand_n == 0) gs_refill(s, p);
             if (PROF) pt = GS_CLOCK();
             int idx;
             long long top, runner_up = GS_KEY_MIN;

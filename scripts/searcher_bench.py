@@ -70,11 +70,16 @@ def main():
 
     # the approximate-score level of the ~60th neighbour (thresholds act on APPROXIMATE scores)
     thr = float(np.median([r.worst_approximate_in_topk for r in s.search_ex(qh[:256], VSF, 60, 60)]))
+    if os.environ.get("SEARCHER_BENCH_TIMING"):
+        ctx.set_option("graph_timing", 1)
     for name, kw in (("objects_plain", dict(top_k=10, rerank_k=100)), ("objects_floor", dict(top_k=10, rerank_k=100, rerank_floor=thr)),
-                     ("objects_threshold", dict(top_k=200, rerank_k=200, threshold=thr))):
+                     ("objects_threshold", dict(top_k=200, rerank_k=200, threshold=thr)),
+                     ("objects_top200_no_threshold", dict(top_k=200, rerank_k=200)),
+                     ("objects_threshold_top10", dict(top_k=10, rerank_k=100, threshold=thr))):
         ctx.reset_stats()
         t, (cnt, st) = timed(c_call(**kw))
         out[name] = {"qps": Q / t, "device_calls": ctx.stat("gs_session_calls_device"), "host_overflow_calls": ctx.stat("gs_session_calls_host_overflow"),
+                     "queries_retried": ctx.stat("gs_queries_retried"), "workers_per_cu": ctx.stat("gs_last_workers_per_cu"),
                      "avg_results": float(cnt.mean()), "avg_visited": float(st[:, 0].mean())}
     t, _ = timed(lambda: s.search_ex(qh, VSF, top_k=10, rerank_k=100), reps=2)
     out["objects_plain_through_python_search_ex_qps"] = Q / t
