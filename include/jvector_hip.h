@@ -505,8 +505,7 @@ JV_API int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts 
  * stats (nullable) Q x 4 int64 = {visitedCount, expandedCount, expandedCountBaseLayer, rerankedCount};
  * worst_approx (nullable) Q floats = worstApproximateScoreInTopK (+inf when fewer than topK results or no reranker).
  * Exact-score ties at the K-th place resolve as in the reference (its result heap's array order).
- * Where they run: search() runs on the DEVICE traversal wherever its session kernels apply (uniform 8-dim sub-vectors, M = 16 or
- * 96, degree <= 64, the rerankK results fit LDS; graph traversal not pinned to the host): threshold admission, the
+ * Where they run: search() runs on the DEVICE traversal wherever its session kernels apply (uniform 8-dim sub-vectors, M = 16 … 192, degree <= 64, the rerankK results fit LDS; graph traversal not pinned to the host): threshold admission, the
  * TwoPhaseTracker stop and acceptOrds inside the kernel, then the host rebuilds approximateResults' heap array from the kernel's
  * addTopCandidate log and runs the reference's rerank (floor, caching reranker, worst approximate score).  resume() needs the
  * candidate queue / visited set of every searcher, which never left the device: the session kernel replays the searcher's earlier

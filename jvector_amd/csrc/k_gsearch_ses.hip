@@ -10,9 +10,11 @@
 
 namespace jv {
 
-// Built for M = 16 and M = 96 (the test shape and the headline shape); other shapes stay on the host searcher.
+// Built for every M the plain kernels are built for (16, 32, 48, 64, 96, 128, 192): 2 waves per SIMD, except the lane-per-neighbour
+// form at M >= 96 (degrees above 32), whose code words do not fit 256 registers (the plain kernels' OCC = 1 build).
 template <int VSF, int CH16, bool PAIR>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_session_kernel(GsParams p)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((PAIR || CH16 < 6) ? 2 : 1, (PAIR || CH16 < 6) ? 2 : 1)))
+void graph_search_session_kernel(GsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_lds[];
     gs_worker<VSF, CH16, PAIR, false, false, true>(p, (int)blockIdx.x, gs_lds);
@@ -30,9 +32,14 @@ static int launch_gs_session(hipStream_t s, const GsParams &p, int ch, int worke
     } while (0)
     switch (ch) {
     case 1: JV_SES(1); break;
+    case 2: JV_SES(2); break;
+    case 3: JV_SES(3); break;
+    case 4: JV_SES(4); break;
     case 6: JV_SES(6); break;
+    case 8: JV_SES(8); break;
+    case 12: JV_SES(12); break;
     default:
-        set_error("graph search kernel: the GraphSearcher-object form is built for M = 16 and M = 96 (M = %d)", ch * 16);
+        set_error("graph search kernel: M = %d is not one of 16, 32, 48, 64, 96, 128, 192", ch * 16);
         return JV_ERR_UNSUPPORTED;
     }
 #undef JV_SES
@@ -41,7 +48,11 @@ static int launch_gs_session(hipStream_t s, const GsParams &p, int ch, int worke
 }
 
 
-bool graph_search_session_supported(int M) { return M == 16 || M == 96; }
+bool graph_search_session_supported(int M)
+{
+    const int ch = M / 16;
+    return M % 16 == 0 && (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8 || ch == 12);
+}
 
 int launch_graph_search_session(hipStream_t s, int vsf, const GsParams &p, int workers, size_t lds)
 {

@@ -866,7 +866,7 @@ class GraphSearcher:
         for every query of the batch, as one GraphSearcher OBJECT per query: the state stays behind for resume().  Returns a
         list of SearchResult (nodes best first, visited / expanded / expanded_base / reranked counts,
         worst_approximate_in_topk).  threshold > 0 and rerank_floor behave as in the reference (TwoPhaseTracker,
-        NodeQueue.rerank).  search() runs on the device traversal where its session kernels apply (M = 16 / 96), else on the host
+        NodeQueue.rerank).  search() runs on the device traversal where its session kernels apply (M = 16 … 192), else on the host
         batched searcher; resume() likewise (the session kernel replays the searcher's earlier calls and continues)."""
         Q = int(queries.shape[0])
         q_p, qk = _ptr(queries, np.float32)

@@ -623,7 +623,11 @@ int launch_bl_sort_edges(hipStream_t, void *temp, size_t *temp_bytes, const unsi
 
 // ---- device-resident traversal: gs_body.h on the lane emulator ----
 bool graph_search_lutr_supported(int M) { return M == 96; }  // (the shape k_gsearch.hip builds)
-bool graph_search_session_supported(int M) { return M == 16 || M == 96; }
+bool graph_search_session_supported(int M)
+{
+    const int ch = M / 16;
+    return M % 16 == 0 && (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8 || ch == 12);
+}
 bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels)
 {
     const int ch = pq->M / 16;  // the same predicate as k_gsearch.hip
@@ -659,7 +663,12 @@ void gs_run_session(const GsLaunch &L)
 {
     switch (L.p->M / 16) {
     case 1: gs_worker<VSF, 1, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 2: gs_worker<VSF, 2, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 3: gs_worker<VSF, 3, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 4: gs_worker<VSF, 4, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
     case 6: gs_worker<VSF, 6, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 8: gs_worker<VSF, 8, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 12: gs_worker<VSF, 12, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }

@@ -352,6 +352,47 @@ def test_searcher_objects_on_the_host_searcher(ctx):
     run_searcher_object_cases(J, ctx, cases=2, traversal="host")
 
 
+def run_searcher_objects_other_shapes(J, ctx, shapes=((256, 32, 16), (384, 48, 40), (1536, 192, 24))):
+    """session kernels at the other subspace counts the device traversal is built for (M = 32, 48, 192; degrees <= 32 take the
+    pair-lane form, 40 the lane-per-neighbour form): search with a threshold + two resumes == the oracle, all on the device"""
+    VSF = J.VectorSimilarityFunction
+    for D, M, deg in shapes:
+        v, lv, entry, entry_level, cb, q = build_problem(D + deg, N=1500, D=D, M=M, deg=deg, top_deg=8, levels=2)
+        q = q[:6]
+        N = len(v)
+        opq = O.OraclePQ(D, M, cb)
+        pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+        vs = J.VectorSet(ctx, v)
+        cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+        codes = cv.get(0, N)
+        og = O.OracleGraph(N, lv, entry, entry_level)
+        graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
+        fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1])
+        ctx.reset_stats()
+        for vsf in (VSF.COSINE, VSF.EUCLIDEAN):
+            lvl = np.sort(np.stack([opq.adc_scores(q[i], int(vsf), codes, None, fused=True) for i in range(len(q))]), axis=1)
+            thr = float(np.median(lvl[:, -60]))
+            s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=8)
+            for top_k, rk, t in ((10, 40, 0.0), (N, N, thr)):
+                got = s.search_ex(q, vsf, top_k, rk, threshold=t)
+                got1 = s.resume(7, 20)
+                got2 = s.resume(20, 30)
+                for i in range(len(q)):
+                    o = og.searcher(opq, codes, v, int(vsf), fused=True)
+                    tag = (D, M, deg, vsf, top_k, i)
+                    _same(got[i], o.search(q[i], top_k, rk, t, 0.0), tag)
+                    _same(got1[i], o.resume(7, 20), tag + ("resume 1",))
+                    _same(got2[i], o.resume(20, 30), tag + ("resume 2",))
+                    o.close()
+            s.close()
+        assert ctx.stat("gs_session_calls_device") >= 4 and ctx.stat("gs_session_resume_device") >= 8, (D, M, ctx.stat("gs_session_calls_device"))
+        graph.close()
+
+
+def test_searcher_objects_other_shapes(ctx):
+    run_searcher_objects_other_shapes(J, ctx)
+
+
 def test_searcher_object_errors(ctx):
     v, lv, entry, entry_level, cb, q = build_problem(3, N=500, D=64, M=8, deg=8, levels=1)
     pq = J.ProductQuantization.from_codebooks(ctx, 64, 8, cb)
