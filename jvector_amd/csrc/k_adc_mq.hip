@@ -116,6 +116,25 @@ __global__ __launch_bounds__(1024) void adc_mq_kernel(AdcMqParams p)
         if (tid < P) s_cnt[tid] = 0u;
         __syncthreads();
     }
+    // the sure-reject bounds of the four queries (see the loop below), once per lane
+    float cut[P], bm[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        cut[j] = (VSF == VSF_L2) ? __builtin_inff() : -__builtin_inff();   // never rejects
+        bm[j] = 0.0f;
+        if (FILTER && q0 + j < p.Q) {
+            const float tq = p.tau[(int64_t)(q0 + j) * p.tau_stride];
+            if (VSF == VSF_L2) {
+                if (tq > 1e-6f) cut[j] = (1.0f / tq - 1.0f) * 1.000002f + 4e-6f;
+            } else if (VSF == VSF_DOT) {
+                cut[j] = (2.0f * tq - 1.0f) - 4e-6f * (fabsf(2.0f * tq - 1.0f) + 1.0f);
+            } else {
+                cut[j] = 2.0f * tq - 1.0f;
+                bm[j] = p.bmag[q0 + j];
+            }
+            if (!(tq == tq)) cut[j] = (VSF == VSF_L2) ? __builtin_inff() : -__builtin_inff();
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t i = tile_base + (int64_t)r * 1024 + tid;
@@ -126,6 +145,22 @@ __global__ __launch_bounds__(1024) void adc_mq_kernel(AdcMqParams p)
         for (int j = 0; j < P; ++j) {
             const int q = q0 + j;
             if (q >= p.Q) continue;
+            if (FILTER) {
+                // Cheap sure-reject before the similarity transform (an IEEE divide for EUCLIDEAN, a double sqrt + divide for COSINE:
+                // a third of this kernel's arithmetic at M = 16, and all but a few pairs in a thousand fail the threshold anyway).
+                // The test is conservative by a relative 2e-6 / absolute 4e-6 — orders of magnitude above the transform's rounding —
+                // so it only drops pairs the exact comparison below would drop too; the survivor set is unchanged.
+                const float raw = acc[r][j];
+                bool sure_fail;
+                if (VSF == VSF_L2) sure_fail = raw > cut[j];                                          // 1 / (1 + raw) < tau
+                else if (VSF == VSF_DOT) sure_fail = raw < cut[j];                                     // (1 + raw) / 2 < tau
+                else {
+                    const float prod = nrm * bm[j];
+                    const float c = raw * __builtin_amdgcn_rsqf(prod);                                  // ~cosine, few ulps
+                    sure_fail = prod > 1e-30f && prod < 1e30f && c < cut[j] - 8e-6f * (fabsf(c) + 1.0f);
+                }
+                if (sure_fail) continue;
+            }
             float sc;
             if (VSF == VSF_COS) sc = score_from_raw(VSF_COS, cosine_finish(acc[r][j], nrm, p.bmag[q]));
             else sc = score_from_raw(VSF, acc[r][j]);

@@ -352,13 +352,13 @@ def test_searcher_objects_on_the_host_searcher(ctx):
     run_searcher_object_cases(J, ctx, cases=2, traversal="host")
 
 
-def run_searcher_objects_other_shapes(J, ctx, shapes=((256, 32, 16), (384, 48, 40), (1536, 192, 24))):
+def run_searcher_objects_other_shapes(J, ctx, shapes=((256, 32, 16), (384, 48, 40), (1536, 192, 24)), N=1500, nq=6, vsfs=None):
     """session kernels at the other subspace counts the device traversal is built for (M = 32, 48, 192; degrees <= 32 take the
     pair-lane form, 40 the lane-per-neighbour form): search with a threshold + two resumes == the oracle, all on the device"""
     VSF = J.VectorSimilarityFunction
     for D, M, deg in shapes:
-        v, lv, entry, entry_level, cb, q = build_problem(D + deg, N=1500, D=D, M=M, deg=deg, top_deg=8, levels=2)
-        q = q[:6]
+        v, lv, entry, entry_level, cb, q = build_problem(D + deg, N=N, D=D, M=M, deg=deg, top_deg=8, levels=2)
+        q = q[:nq]
         N = len(v)
         opq = O.OraclePQ(D, M, cb)
         pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
@@ -369,7 +369,7 @@ def run_searcher_objects_other_shapes(J, ctx, shapes=((256, 32, 16), (384, 48, 4
         graph = J.GraphIndex(ctx, N, lv, entry, entry_level)
         fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1])
         ctx.reset_stats()
-        for vsf in (VSF.COSINE, VSF.EUCLIDEAN):
+        for vsf in (vsfs or (VSF.COSINE, VSF.EUCLIDEAN)):
             lvl = np.sort(np.stack([opq.adc_scores(q[i], int(vsf), codes, None, fused=True) for i in range(len(q))]), axis=1)
             thr = float(np.median(lvl[:, -60]))
             s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=8)
@@ -385,7 +385,8 @@ def run_searcher_objects_other_shapes(J, ctx, shapes=((256, 32, 16), (384, 48, 4
                     _same(got2[i], o.resume(20, 30), tag + ("resume 2",))
                     o.close()
             s.close()
-        assert ctx.stat("gs_session_calls_device") >= 4 and ctx.stat("gs_session_resume_device") >= 8, (D, M, ctx.stat("gs_session_calls_device"))
+        n_vsf = len(vsfs) if vsfs else 2
+        assert ctx.stat("gs_session_calls_device") >= 2 * n_vsf and ctx.stat("gs_session_resume_device") >= 4 * n_vsf, (D, M, ctx.stat("gs_session_calls_device"))
         graph.close()
 
 

@@ -460,7 +460,7 @@ def test_searchers_with_engineered_score_ties(J, ctx, traversal):
 def test_searcher_objects_other_shapes_on_the_mock(J, ctx):
     """the session kernels at M = 32 (pair-lane form) and M = 48 at degree 40 (lane-per-neighbour form) on the lane emulator"""
     import test_graph_search as T
-    T.run_searcher_objects_other_shapes(J, ctx, shapes=((256, 32, 16), (384, 48, 40)))
+    T.run_searcher_objects_other_shapes(J, ctx, shapes=((256, 32, 16), (384, 48, 40)), N=600, nq=3, vsfs=(J.VectorSimilarityFunction.COSINE,))
 
 
 def test_searcher_objects_on_the_mock(J, ctx):
