@@ -612,7 +612,7 @@ def test_standalone_canary_against_the_mock_library(J):
         assert line["identical"] is True and line["avg_expanded"] >= 50
 
 
-@pytest.mark.parametrize("mode,traversal,graph,n,extra", [("graph", "host", "synthetic", 6000, []), ("graph", "device", "engine", 2000, []),
+@pytest.mark.parametrize("mode,traversal,graph,n,extra", [("graph", "host", "synthetic", 3000, []), ("graph", "device", "engine", 2000, []),
                                                          ("flat", "host", "synthetic", 6000, []),
                                                          ("graph", "device", "engine", 2000, ["--reranker", "nvq"])])
 def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, graph, n, extra):
