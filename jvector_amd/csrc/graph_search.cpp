@@ -1285,14 +1285,19 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // in flight per wave) or 4 (JVECTOR_HIP_GS_OCC=4: 128 VGPRs, no pair-lane scoring).  Measured on MI355X at 1M x 768:
     // 2 waves/SIMD + pair lanes 19.0 ms per 16384-query batch; 4 waves/SIMD 25.1 ms; a 3 waves/SIMD build (168 VGPRs, 12 waves
     // per CU) 28.3 ms — fewer gathers in flight per wave cost more than the extra waves hide (profiles/r2_sweeps.md).
-    const int occ = ctx_opt(ctx, "gs_occ", 2) >= 4 ? 4 : 2;
     // gs_lutr = 1: the query's ADC table lives in the wave's registers (64 subspaces, cross-lane reads) + LDS (the rest) instead
     // of being recomputed from the L2-resident codebook per scored neighbour; one wave per SIMD (4 workers per CU), one lane per
     // neighbour (k_gsearch.hip graph_search_lutr_kernel).  M <= 96 only.
-    const bool lutr = !so && ctx_opt(ctx, "gs_lutr", 0) != 0 && graph_search_lutr_supported(pq->M);
+    // PQ shapes outside the specialised builds (ragged / non-8 sub-vectors, other M) run the generic kernels: one lane per
+    // neighbour, the per-subspace geometry read from the quantizer's device tables
+    const bool generic = !graph_search_device_specialised(pq, codes, fused) || ctx_opt(ctx, "gs_generic", 0) != 0;  // (option: tests / benches)
+    // (the generic kernels need 113 VGPRs: 4 waves per SIMD by default — their byte-wise code reads and short gathers are
+    // latency-bound, more resident queries hide more of it)
+    const int occ = ctx_opt(ctx, "gs_occ", generic ? 4 : 2) >= 4 ? 4 : 2;
+    const bool lutr = !so && !generic && ctx_opt(ctx, "gs_lutr", 0) != 0 && graph_search_lutr_supported(pq->M);
     // pair-lane scoring (two lanes per neighbour) when no level has more than 32 neighbours; it needs an M/2 x 32 float
     // exchange area in LDS.  gs_pair = 0 turns it off.
-    bool pair = occ == 2 && !lutr && ctx_opt(ctx, "gs_pair", 1) != 0;
+    bool pair = occ == 2 && !lutr && !generic && ctx_opt(ctx, "gs_pair", 1) != 0;
     for (int lv = 0; lv <= g->entry_level; ++lv) pair = pair && g->levels[lv].degree <= 32;
     // M >= 128: the pair form's two half rows + exchange indices no longer fit 256 VGPRs (156 / 588 bytes of scratch per
     // lane at M = 128 / 192, -Rpass-analysis=kernel-resource-usage) while the one-lane-per-neighbour form still does
@@ -1434,6 +1439,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.D = pq->D;
     p.M = pq->M;
     p.deg0 = g->levels[0].degree;
+    p.generic = generic ? 1 : 0;
+    p.sub_uniform4 = (generic && pq->uniform && pq->max_size % 4 == 0) ? pq->max_size : 0;
+    p.sub_sizes = pq->d_sizes;
+    p.sub_offsets = pq->d_offsets;
+    p.cb_offsets = reinterpret_cast<const long long *>(pq->d_cb_offsets);
     p.Q = Q;
     p.rerankK = rerankK;
     p.accept = (const unsigned long long *)dev_accept.bits;
@@ -1446,7 +1456,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.evict_cap = evict_cap;
     p.v1_log2 = v1_log2;
     p.v1_idbits = idbits;
-    p.prefetch = (ctx_opt(ctx, "gs_prefetch", 0) != 0 && evict_cap >= 48) ? 1 : 0;
+    p.prefetch = (ctx_opt(ctx, "gs_prefetch", 0) != 0 && evict_cap >= 48 && !generic) ? 1 : 0;  // (dword touches: aligned rows only)
     p.lutr = lutr ? 1 : 0;
     if (so) {
         p.session = 1;
@@ -1764,8 +1774,8 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
     CtxBusy busy(ctx);
     JV_REQUIRE(busy.ok, "graph_search: this jv_ctx is already inside a call on another thread (one context per host thread)");
     // Traversal: the graph's setting, overridden by JVECTOR_HIP_GRAPH_TRAVERSAL=host|device.  AUTO = the device-resident
-    // traversal wherever it applies (uniform 8-dim sub-vectors, supported M / degree, queues fit LDS — validated on
-    // MI355X in round 2, 7-8x the host searcher's throughput), the host searcher for every other shape.
+    // traversal wherever it applies (256-cluster codebooks, degree <= 64, queues fit LDS: specialised kernels for uniform 8-dim
+    // sub-vectors at M = 16 ... 192, the generic form for every other quantizer), the host searcher otherwise.
     int mode = (int)ctx_opt(ctx, "graph_traversal", g->traversal);
     if (mode != JV_TRAVERSAL_HOST && mode != JV_TRAVERSAL_DEVICE) mode = JV_TRAVERSAL_AUTO;
     const bool was_auto = mode == JV_TRAVERSAL_AUTO;
@@ -1815,9 +1825,9 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
                 int64_t n_auto = 0;
                 (void)jv_hip_ctx_get_stat(ctx, "gs_calls_host_auto", &n_auto);
                 if (n_auto == 1 && ctx_opt(ctx, "quiet", 0) == 0)
-                    fprintf(stderr, "[jvector_hip] graph_search: JV_TRAVERSAL_AUTO takes the HOST searcher for this shape (the device traversal needs "
-                                    "uniform 8-dim sub-vectors, M in {16,32,48,64,96,128,192}, degree <= 64, queues that fit LDS); counter "
-                                    "gs_calls_host_auto counts further calls\n");
+                    fprintf(stderr, "[jvector_hip] graph_search: JV_TRAVERSAL_AUTO takes the HOST searcher for this search (the device traversal needs "
+                                    "256-cluster codebooks, degree <= 64, <= %d levels and queues that fit LDS); counter "
+                                    "gs_calls_host_auto counts further calls\n", GS_MAX_LEVELS);
             }
         }
         HostSearchOpts opt;
@@ -1841,8 +1851,8 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
     JV_REQUIRE(queries && out_ids && out_scores, "graph_search: NULL buffer");
     JV_TRY(use_device(ctx->device));
     if (!graph_search_device_supported(l->pq, codes, fused, W, g->entry_level + 1)) {
-        set_error("graph_search: the device traversal needs uniform 8-dim sub-vectors, M in {16,32,48,64,96,128,192}, degree <= 64 "
-                  "and <= %d levels; use the host traversal", GS_MAX_LEVELS);
+        set_error("graph_search: the device traversal needs 256-cluster codebooks, degree <= 64 and <= %d levels; use the host traversal",
+                  GS_MAX_LEVELS);
         return JV_ERR_UNSUPPORTED;
     }
     if (accept_bits && !dev_accept.bits) {  // host masks: the kernel needs a device copy
@@ -2032,6 +2042,8 @@ static int searcher_run(jv_ctx *ctx, jv_searcher *s, int Q, int topK, int rerank
                         int32_t *out_ids, float *out_scores, int32_t *out_counts, int64_t *stats, float *worst)
 {
     const jv_graph *g = s->g;
+    // (whatever traversal serves the call: the host searcher has the same check, the session kernels would not stop on a NaN)
+    JV_REQUIRE(!(threshold != threshold) && !(rerankFloor != rerankFloor), "graph_search: NaN threshold / rerankFloor");
     if (s->fused && Q > 0 && s->fused->count == g->n_nodes && s->fused->maxDegree == g->levels[0].degree &&
         g->levels[0].nbrs.size() == (size_t)g->n_nodes * s->fused->maxDegree) {
         JV_TRY(use_device(ctx->device));

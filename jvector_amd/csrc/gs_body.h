@@ -201,6 +201,60 @@ GS_FN float gs_row_sum(const float *codebooks, const float *qs, const gs_u4 (&w)
     return sum;
 }
 
+// ---- the same score for ANY product quantizer (CH16 = 0 kernels: ragged sub-vectors, sizes other than 8, M not a multiple of 16):
+//      entry (m, code) = calculatePartialSums' chain over the sub-vector's own length (j ascending, mul and add separate), entries
+//      summed in ascending m — what lut_build_kernel (k_pq.hip) writes into the tables of the flat path, so the bits agree with
+//      every other scoring form.  The code bytes are read one at a time straight from the row (no alignment to rely on).
+template <int VSF>
+GS_FN float gs_row_sum_any(const GsParams &p, const float *qs, const uint8_t *rp)
+{
+    float sum = 0.0f;
+    const int M = p.M;
+    if (p.sub_uniform4 > 0) {  // uniform sizes, a multiple of 4: codebook rows are 16-byte aligned
+        const int S = p.sub_uniform4;
+#pragma unroll 4
+        for (int m = 0; m < M; ++m) {
+            const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(p.codebooks + ((int64_t)m * 256 + rp[m]) * S);
+            const float *q = qs + m * S;
+            float ent = 0.0f;
+            for (int j = 0; j < S; j += 4) {
+                const gs_f4 c = cp[j >> 2];
+                if (VSF == 0 /* L2 */) {
+                    float t;
+                    t = c.x - q[j]; ent += t * t;
+                    t = c.y - q[j + 1]; ent += t * t;
+                    t = c.z - q[j + 2]; ent += t * t;
+                    t = c.w - q[j + 3]; ent += t * t;
+                } else {
+                    ent += c.x * q[j];
+                    ent += c.y * q[j + 1];
+                    ent += c.z * q[j + 2];
+                    ent += c.w * q[j + 3];
+                }
+            }
+            sum += ent;
+        }
+        return sum;
+    }
+#pragma unroll 2
+    for (int m = 0; m < M; ++m) {
+        const int S = p.sub_sizes[m];
+        const float *cb = p.codebooks + p.cb_offsets[m] + (int64_t)rp[m] * S;
+        const float *q = qs + p.sub_offsets[m];
+        float ent = 0.0f;
+        for (int j = 0; j < S; ++j) {
+            if (VSF == 0 /* L2 */) {
+                const float t = cb[j] - q[j];
+                ent += t * t;
+            } else {
+                ent += cb[j] * q[j];
+            }
+        }
+        sum += ent;
+    }
+    return sum;
+}
+
 // ---- the query's ADC table held by the wave itself (M <= 96): M x 256 f32 = 96 KB at PQ-96 — too large for a wave's LDS
 //      share — split between the wave's VECTOR REGISTERS and LDS.  Subspaces m < GS_LUT_REG_SUB (64): entry (m, code) lives in
 //      lane code & 63, register 4 m + (code >> 6) — 256 registers per lane, half of the 512 a wave owns at one wave per SIMD — and
@@ -583,6 +637,8 @@ template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bo
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
     static_assert(!(LUTR && PAIR), "the register-resident table serves the one-lane-per-neighbour form");
+    static_assert(CH16 > 0 || !(LUTR || PAIR), "the generic form (CH16 = 0) is one lane per neighbour, table-free");
+    constexpr int CW = CH16 > 0 ? CH16 : 1;  // code words a lane holds (the generic form reads its row from memory instead)
     constexpr int LUT_MR = CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB;
     float lut[LUTR ? LUT_MR * 4 : 1];
     float *lut_lds = nullptr;  // LUTR: the table of subspaces >= GS_LUT_REG_SUB, at the very end of the worker's LDS block
@@ -601,7 +657,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     const int lane = gs_lane();
     float *qs = reinterpret_cast<float *>(lds);
     GsState s;
-    s.res = reinterpret_cast<long long *>(lds + sizeof(float) * (size_t)p.D);
+    s.res = reinterpret_cast<long long *>(lds + gs_q_bytes(p.D));
     s.cand = s.res + p.rerankK;
     s.evicted = s.cand + p.cand_cap;
     const int evict_cap = p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP;
@@ -710,9 +766,14 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             gs_u4 *v4 = reinterpret_cast<gs_u4 *>(vis);
             for (int i = lane; i < vcap / 4; i += 64) v4[i] = ones;
         }
-        const gs_f4 *src = reinterpret_cast<const gs_f4 *>(p.cq + (int64_t)q * p.D);
-        gs_f4 *dst = reinterpret_cast<gs_f4 *>(qs);
-        for (int i = lane; i < p.D / 4; i += 64) dst[i] = src[i];
+        if constexpr (CH16 == 0) {  // any D: rows of the query matrix need not be 16-byte aligned
+            const float *src = p.cq + (int64_t)q * p.D;
+            for (int i = lane; i < p.D; i += 64) qs[i] = src[i];
+        } else {
+            const gs_f4 *src = reinterpret_cast<const gs_f4 *>(p.cq + (int64_t)q * p.D);
+            gs_f4 *dst = reinterpret_cast<gs_f4 *>(qs);
+            for (int i = lane; i < p.D / 4; i += 64) dst[i] = src[i];
+        }
     }
     gs_fence();
     gs_barrier();
@@ -734,11 +795,15 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             if (lane == 0) (void)gs_visit(vis, vmask, vshift, e);
             n2 = 1;
         }
-        gs_u4 we[CH16];
-        gs_load_row<CH16>(p.codes + (int64_t)e * p.M, we);
         float sc;
-        if constexpr (LUTR) sc = gs_row_sum_lut<CH16>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, we);
-        else sc = gs_row_sum<VSF, CH16>(p.codebooks, qs, we);
+        if constexpr (CH16 == 0) {
+            sc = gs_row_sum_any<VSF>(p, qs, p.codes + (int64_t)e * p.M);
+        } else {
+            gs_u4 we[CW];
+            gs_load_row<CW>(p.codes + (int64_t)e * p.M, we);
+            if constexpr (LUTR) sc = gs_row_sum_lut<CW>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, we);
+            else sc = gs_row_sum<VSF, CW>(p.codebooks, qs, we);
+        }
         sc = gs_finish<VSF>(sc, (VSF == 2) ? p.code_norms[e] : 0.0f, query_mag);
         if (lane == 0) s.cand[0] = gs_key(e, sc);
         s.cand_n = 1;
@@ -952,7 +1017,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             const bool fused0 = lvl == 0 && p.blocks != nullptr;
             long long key = 0;
             bool fresh;
-            if (PAIR) {
+            if constexpr (PAIR) {
                 // ---- pair-lane form: neighbour i is handled by lanes i (low) and i + 32 (high) ----
                 const int ni = lane & 31;
                 const bool hi = lane >= 32;
@@ -993,21 +1058,26 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             } else {
                 const int32_t nb = lane < deg ? row[lane] : -1;
                 // code bytes first, then the visited probes: the loads do not depend on the probes' outcome
-                gs_u4 w[CH16];
+                gs_u4 w[CW];
+                const uint8_t *rp = nullptr;  // generic form: where the lane's code row lives
+                (void)w;
+                (void)rp;
                 if constexpr (LUTR) {  // every lane takes part in the cross-lane reads below: no uninitialised code words
 #pragma unroll
-                    for (int c = 0; c < CH16; ++c) w[c] = gs_u4{0u, 0u, 0u, 0u};
+                    for (int c = 0; c < CW; ++c) w[c] = gs_u4{0u, 0u, 0u, 0u};
                 }
                 float node_mag = 0.0f;
                 if (fused0 && lane < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
                     const int64_t r = (int64_t)node * p.deg0 + lane;
-                    gs_load_row<CH16>(p.blocks + r * p.M, w);
+                    if constexpr (CH16 == 0) rp = p.blocks + r * p.M;
+                    else gs_load_row<CW>(p.blocks + r * p.M, w);
                     if (VSF == 2) node_mag = p.fused_norms[r];
                 }
                 const int first_neg = gs_first(gs_ballot(nb < 0));  // rows are packed: the first -1 ends the row
                 const bool valid = lane < first_neg;
                 if (!fused0 && valid) {      // PQDecoder.similarityTo: the neighbour's own code
-                    gs_load_row<CH16>(p.codes + (int64_t)nb * p.M, w);
+                    if constexpr (CH16 == 0) rp = p.codes + (int64_t)nb * p.M;
+                    else gs_load_row<CW>(p.codes + (int64_t)nb * p.M, w);
                     if (VSF == 2) node_mag = p.code_norms[nb];
                 }
                 fresh = visit(valid, nb);
@@ -1016,11 +1086,13 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 if (fm == 0) continue;
                 n_visited += gs_popc(fm);
                 GS_PHASE(2);
-                if constexpr (LUTR) {
-                    const float raw = gs_row_sum_lut<CH16>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, w);  // all lanes
+                if constexpr (CH16 == 0) {
+                    if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum_any<VSF>(p, qs, rp), node_mag, query_mag));
+                } else if constexpr (LUTR) {
+                    const float raw = gs_row_sum_lut<CW>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, w);  // all lanes
                     if (fresh) key = gs_key(nb, gs_finish<VSF>(raw, node_mag, query_mag));
                 } else {
-                    if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CH16>(p.codebooks, qs, w), node_mag, query_mag));
+                    if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CW>(p.codebooks, qs, w), node_mag, query_mag));
                 }
             }
             if (PROF) {  // the scores must have arrived before the phase is closed

@@ -33,6 +33,13 @@ struct GsParams {
     const uint8_t *blocks;    // layer-0 FusedPQ blocks [n][deg0][M], or nullptr
     const float *fused_norms; // [n][deg0] (cosine)
     int32_t D, M, deg0;
+    // every other PQ shape (the GENERIC kernels, CH16 = 0 in gs_body.h: ragged sub-vectors, sizes other than 8, any M): the
+    // per-subspace geometry replaces the [M][256][8] assumption; one lane per neighbour, no register table
+    int32_t generic;              // 1: sub_sizes / sub_offsets / cb_offsets describe `codebooks`
+    int32_t sub_uniform4;         // > 0: every sub-vector has this size, a multiple of 4 (codebook rows are read as 16-byte words)
+    const int32_t *sub_sizes;     // [M]
+    const int32_t *sub_offsets;   // [M] offset of sub-vector m inside a vector
+    const long long *cb_offsets;  // [M] float offset of codebook m inside `codebooks`
     // search
     int32_t Q, rerankK;
     const int32_t *qmap;      // nullptr: work items 0..Q-1 ARE the query indices; else item i runs query qmap[i] (retry pass)
@@ -87,12 +94,15 @@ struct GsParams {
     unsigned long long *prof; // developer aid (JVECTOR_HIP_GS_PROF=1): 8 phase counters, see gs_search_one; else nullptr
 };
 
+// the centred query at the head of a worker's LDS block, padded so that the 8-byte arrays behind it stay aligned for any D
+constexpr size_t gs_q_bytes(int D) { return (sizeof(float) * (size_t)D + 15) & ~(size_t)15; }
+
 // LDS bytes one worker needs
 constexpr size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M when pair-lane scoring is on, else 0 */,
                            int evict_cap = GS_EVICT_CAP, int v1_log2 = 0)
 {
     // (the 64-key sample buffer of the partition step shares the pair-lane exchange area when there is one)
-    const size_t base = sizeof(float) * (size_t)D + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + (size_t)evict_cap + (pair_M ? 0 : 64)) +
+    const size_t base = gs_q_bytes(D) + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + (size_t)evict_cap + (pair_M ? 0 : 64)) +
                         sizeof(float) * 32 * (size_t)(pair_M / 2);
     return v1_log2 > 0 ? ((base + 15) & ~(size_t)15) + ((size_t)2 << v1_log2) : base;
 }

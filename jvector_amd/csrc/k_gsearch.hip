@@ -72,6 +72,13 @@ static int launch_gs_ch(hipStream_t s, const GsParams &p, int ch, int workers, s
         }                                                                                                   \
     } while (0)
     switch (ch) {
+    case 0:  // the generic form (any sub-vector geometry): one lane per neighbour
+        if (pair) {
+            set_error("graph search kernel: the generic form has no pair-lane scoring");
+            return JV_ERR_INVALID;
+        }
+        hipLaunchKernelGGL((graph_search_kernel<VSF, 0, OCC, false>), grid, block, lds, s, p);
+        break;
     case 1: JV_GS(1); break;
     case 2: JV_GS(2); break;
     case 3: JV_GS(3); break;
@@ -80,7 +87,7 @@ static int launch_gs_ch(hipStream_t s, const GsParams &p, int ch, int workers, s
     case 8: JV_GS(8); break;
     case 12: JV_GS(12); break;
     default:
-        set_error("graph search kernel: M = %d is not one of 16, 32, 48, 64, 96, 128, 192", ch * 16);
+        set_error("graph search kernel: M = %d has no specialised build (16, 32, 48, 64, 96, 128, 192) and the launch did not ask for the generic one", ch * 16);
         return JV_ERR_UNSUPPORTED;
     }
 #undef JV_GS
@@ -88,14 +95,22 @@ static int launch_gs_ch(hipStream_t s, const GsParams &p, int ch, int workers, s
     return JV_OK;
 }
 
-bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels)
+// The specialised kernels: uniform 8-dim sub-vectors, M one of 16 ... 192, 16-byte aligned code rows.
+bool graph_search_device_specialised(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused)
 {
     const int ch = pq->M / 16;
     return pq->uniform && pq->max_size == 8 && pq->k == kClusters && pq->M % 16 == 0 &&
            (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8 || ch == 12) && pq->D == 8 * pq->M &&
            (reinterpret_cast<uintptr_t>(codes->d_codes) & 15) == 0 &&
-           (!fused || (reinterpret_cast<uintptr_t>(fused->d_blocks) & 15) == 0) && max_degree <= 64 &&
-           n_levels <= GS_MAX_LEVELS;
+           (!fused || (reinterpret_cast<uintptr_t>(fused->d_blocks) & 15) == 0);
+}
+
+// Every 256-cluster quantizer has a device traversal: the specialised kernels where they apply, the generic form otherwise.
+bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels)
+{
+    (void)codes;
+    (void)fused;
+    return pq->k == kClusters && pq->M >= 1 && max_degree <= 64 && n_levels <= GS_MAX_LEVELS;
 }
 
 size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap, int v1_log2)
@@ -144,7 +159,11 @@ int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, 
     if (p.Q == 0) return JV_OK;
     const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2) +
                        (p.lutr ? gs_lutr_lds_bytes(p.M) : 0);
-    const int ch = p.M / 16;
+    const int ch = p.generic ? 0 : p.M / 16;
+    if (p.generic && (p.lutr || p.prof || p.pair)) {
+        set_error("graph search kernel: the generic form has no register-table / phase-clock / pair-lane variant");
+        return JV_ERR_INVALID;
+    }
     if (p.session) {
         if (p.lutr || p.prof) {
             set_error("graph search kernel: the GraphSearcher-object form has no register-table / phase-clock variant");

@@ -10,10 +10,11 @@
 
 namespace jv {
 
-// Built for every M the plain kernels are built for (16, 32, 48, 64, 96, 128, 192): 2 waves per SIMD, except the lane-per-neighbour
-// form at M >= 96 (degrees above 32), whose code words do not fit 256 registers (the plain kernels' OCC = 1 build).
+// Built for every M the plain kernels are built for (16, 32, 48, 64, 96, 128, 192) + the generic form (CH16 = 0): 2 waves per SIMD, except the lane-per-neighbour
+// form at M >= 96 (degrees above 32), whose code words do not fit 256 registers (the plain kernels' OCC = 1 build); the generic form
+// holds no code words at all and runs at 4 waves per SIMD.
 template <int VSF, int CH16, bool PAIR>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((PAIR || CH16 < 6) ? 2 : 1, (PAIR || CH16 < 6) ? 2 : 1)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH16 == 0 ? 4 : ((PAIR || CH16 < 6) ? 2 : 1), CH16 == 0 ? 4 : ((PAIR || CH16 < 6) ? 2 : 1))))
 void graph_search_session_kernel(GsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_lds[];
@@ -31,6 +32,13 @@ static int launch_gs_session(hipStream_t s, const GsParams &p, int ch, int worke
         else hipLaunchKernelGGL((graph_search_session_kernel<VSF, CH, false>), grid, block, lds, s, p);          \
     } while (0)
     switch (ch) {
+    case 0:  // the generic form (any sub-vector geometry): one lane per neighbour
+        if (pair) {
+            set_error("graph search kernel: the generic form has no pair-lane scoring");
+            return JV_ERR_INVALID;
+        }
+        hipLaunchKernelGGL((graph_search_session_kernel<VSF, 0, false>), grid, block, lds, s, p);
+        break;
     case 1: JV_SES(1); break;
     case 2: JV_SES(2); break;
     case 3: JV_SES(3); break;
@@ -39,7 +47,7 @@ static int launch_gs_session(hipStream_t s, const GsParams &p, int ch, int worke
     case 8: JV_SES(8); break;
     case 12: JV_SES(12); break;
     default:
-        set_error("graph search kernel: M = %d is not one of 16, 32, 48, 64, 96, 128, 192", ch * 16);
+        set_error("graph search kernel: M = %d has no specialised build (16, 32, 48, 64, 96, 128, 192) and the launch did not ask for the generic one", ch * 16);
         return JV_ERR_UNSUPPORTED;
     }
 #undef JV_SES
@@ -48,15 +56,11 @@ static int launch_gs_session(hipStream_t s, const GsParams &p, int ch, int worke
 }
 
 
-bool graph_search_session_supported(int M)
-{
-    const int ch = M / 16;
-    return M % 16 == 0 && (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8 || ch == 12);
-}
+bool graph_search_session_supported(int M) { return M >= 1; }  // (specialised builds for M = 16 ... 192, the generic form otherwise)
 
 int launch_graph_search_session(hipStream_t s, int vsf, const GsParams &p, int workers, size_t lds)
 {
-    const int ch = p.M / 16;
+    const int ch = p.generic ? 0 : p.M / 16;
     switch (vsf) {
     case VSF_L2: return launch_gs_session<VSF_L2>(s, p, ch, workers, lds);
     case VSF_DOT: return launch_gs_session<VSF_DOT>(s, p, ch, workers, lds);

@@ -1,6 +1,6 @@
 """One-off validation aid: a time-boxed differential sweep of GraphSearcher OBJECTS (jv_hip_searcher_*: search with threshold /
 rerankFloor / acceptOrds, then a random chain of resume() calls) against the oracle's jvo_searcher restatement.  Random shapes
-(every subspace count the session kernels are built for + shapes that go to the host searcher), degrees, level counts, fused /
+(every subspace count the session kernels have a specialised build for + arbitrary quantizers, which take the generic build), degrees, level counts, fused /
 unfused, reranker / none, similarity functions, call chains long enough to leave the in-kernel replay (GS_MAX_PHASES) for the host
 replay, and small candidate / push-log capacities so that spills, refills, retries and host fallbacks all occur.
 Every result must agree bit for bit: nodes, scores, the four counters, worstApproximateScoreInTopK.
@@ -41,7 +41,7 @@ VSF = list(J.VectorSimilarityFunction)
 t_end = time.time() + budget
 cases = calls = checks = 0
 dev_calls = dev_resumes = host_calls = 0
-OPTS = ("gs_cand_cap", "gs_push_log_cap", "gs_vcap_log2", "gs_v1_log2")
+OPTS = ("gs_cand_cap", "gs_push_log_cap", "gs_vcap_log2", "gs_v1_log2", "gs_generic")
 
 
 def same(r, w, tag):
@@ -58,6 +58,9 @@ def same(r, w, tag):
 while time.time() < t_end:
     M = int(rng.choice([8, 16, 16, 32, 48, 64, 96, 128, 192] if not MOCK else [8, 16, 16, 32, 48]))
     D = 8 * M
+    if rng.random() < 0.3:                                   # any other quantizer: ragged / small / odd geometries (generic kernels)
+        D = int(rng.integers(6, 260))
+        M = int(rng.integers(1, min(D, 40) + 1))
     N = int(rng.integers(260, 700 if MOCK else 2500))
     deg = int(rng.choice([8, 16, 24, 32, 40, 64]))
     levels = int(rng.integers(1, 4))
@@ -79,6 +82,8 @@ while time.time() < t_end:
         opts["gs_vcap_log2"] = int(rng.choice([8, 9, 10, 12]))
     if rng.random() < 0.2:
         opts["gs_v1_log2"] = int(rng.choice([0, 8, 10]))
+    if rng.random() < 0.3:                                   # the generic kernels on a shape that has a specialised build
+        opts["gs_generic"] = 1
     for name in OPTS:
         ctx.set_option(name, opts.get(name))
     opq = O.OraclePQ(D, M, cb)

@@ -1,5 +1,5 @@
 """One-off validation aid: a time-boxed differential sweep of the device traversal (and the host searcher) against the oracle's
-GraphSearcher restatement on random problems — shapes, degrees, level counts, similarity functions, fused / unfused, rerank /
+GraphSearcher restatement on random problems — shapes (specialised and generic kernels), degrees, level counts, similarity functions, fused / unfused, rerank /
 no rerank, acceptOrds filters, duplicated vectors (exact-score ties), tiny visited tables (growth / retry / host fallback).
 Every case must agree bit for bit on ids, scores and the visited / expanded counters.
 usage (GPU box): python scripts/fuzz_traversal.py [seconds] [seed]"""
@@ -23,10 +23,14 @@ ctx = J.HipContext(0)
 VSF = J.VectorSimilarityFunction
 t_end = time.time() + budget
 cases = searches = 0
-knobs = ("JVECTOR_HIP_GS_VCAP_LOG2", "JVECTOR_HIP_GS_GROW", "JVECTOR_HIP_GS_RETRY", "JVECTOR_HIP_GS_CAND_CAP", "JVECTOR_HIP_GS_PUSH_LOG_CAP")
+knobs = ("JVECTOR_HIP_GS_VCAP_LOG2", "JVECTOR_HIP_GS_GROW", "JVECTOR_HIP_GS_RETRY", "JVECTOR_HIP_GS_CAND_CAP", "JVECTOR_HIP_GS_PUSH_LOG_CAP",
+         "JVECTOR_HIP_GS_GENERIC")
 while time.time() < t_end:
     D = int(rng.choice([128, 256, 384, 512, 768]))
     M = D // 8
+    if rng.random() < 0.3:                                   # any other quantizer (ragged / small / odd): the generic kernels
+        D = int(rng.integers(6, 260))
+        M = int(rng.integers(1, min(D, 40) + 1))
     N = int(rng.integers(200, 6000))
     deg = int(rng.choice([8, 16, 24, 32, 48, 64]))
     n_levels = int(rng.integers(1, 4))
@@ -93,6 +97,8 @@ while time.time() < t_end:
             env["JVECTOR_HIP_GS_RETRY"] = str(int(rng.integers(0, 2)))
         if traversal == "device" and rng.random() < 0.3:
             env["JVECTOR_HIP_GS_CAND_CAP"] = "256"
+        if traversal == "device" and rng.random() < 0.25:   # the generic kernels on a shape that has a specialised build
+            env["JVECTOR_HIP_GS_GENERIC"] = "1"
         if traversal == "device" and rng.random() < 0.2:
             env["JVECTOR_HIP_GS_PUSH_LOG_CAP"] = str(int(rng.choice([4, 16, 64])))
         for k in knobs:

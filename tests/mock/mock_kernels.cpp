@@ -4,6 +4,7 @@
 // traversal runs gs_body.h on the 64-lane emulator, build-time scoring and training run bs_body.h / km_body.h as loops.
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "../emu/hip_emu.h"
@@ -65,6 +66,15 @@ static inline gs_f32x16 gs_mfma_32x32x2(float a, float b, gs_f32x16 c) { return 
 #include "../../jvector_amd/csrc/rd_body.h"
 #include "../../jvector_amd/csrc/rt_body.h"
 #include "../../oracle/jv_oracle.h"
+
+// The lane emulator keeps the running wave's context in statics: emulated launches from several host threads take turns.
+static std::mutex g_emu_mu;
+template <typename Arg>
+static void run_wave_locked(void (*fn)(void *), Arg *arg)
+{
+    std::lock_guard<std::mutex> lock(g_emu_mu);
+    emu::run_wave(fn, (void *)arg);
+}
 
 namespace jv {
 
@@ -204,7 +214,7 @@ int launch_retain_diverse(hipStream_t, const jv_ctx *ctx, const RdParams &p)
     char *base = (char *)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
     for (int node = 0; node < p.P; ++node) {
         RdLaunch L{&p, node, base};
-        emu::run_wave(rd_main, &L);
+        run_wave_locked(rd_main, &L);
     }
     return JV_OK;
 }
@@ -429,7 +439,7 @@ int launch_rerank_ties(hipStream_t, const RtParams &p)
     for (int q = 0; q < p.Q; ++q) {
         memset(lds, 0xA5, lds_bytes);
         RtLaunch L{&p, q, lds};
-        emu::run_wave(rt_main, &L);
+        run_wave_locked(rt_main, &L);
     }
     free(lds);
     return JV_OK;
@@ -521,7 +531,7 @@ int launch_km_pp_init(hipStream_t, const KmParams &p)
 {
     for (int m = 0; m < p.M; ++m) {
         PP a{&p, m};
-        emu::run_wave(pp_main, &a);
+        run_wave_locked(pp_main, &a);
     }
     return JV_OK;
 }
@@ -623,18 +633,18 @@ int launch_bl_sort_edges(hipStream_t, void *temp, size_t *temp_bytes, const unsi
 
 // ---- device-resident traversal: gs_body.h on the lane emulator ----
 bool graph_search_lutr_supported(int M) { return M == 96; }  // (the shape k_gsearch.hip builds)
-bool graph_search_session_supported(int M)
+bool graph_search_session_supported(int M) { return M >= 1; }
+bool graph_search_device_specialised(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused)
 {
-    const int ch = M / 16;
-    return M % 16 == 0 && (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8 || ch == 12);
-}
-bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels)
-{
-    const int ch = pq->M / 16;  // the same predicate as k_gsearch.hip
+    const int ch = pq->M / 16;  // the same predicates as k_gsearch.hip
     return pq->uniform && pq->max_size == 8 && pq->k == kClusters && pq->M % 16 == 0 &&
            (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8 || ch == 12) &&
            pq->D == 8 * pq->M && (reinterpret_cast<uintptr_t>(codes->d_codes) & 15) == 0 &&
-           (!fused || (reinterpret_cast<uintptr_t>(fused->d_blocks) & 15) == 0) && max_degree <= 64 && n_levels <= GS_MAX_LEVELS;
+           (!fused || (reinterpret_cast<uintptr_t>(fused->d_blocks) & 15) == 0);
+}
+bool graph_search_device_supported(const jv_pq *pq, const jv_codes *, const jv_fused *, int max_degree, int n_levels)
+{
+    return pq->k == kClusters && pq->M >= 1 && max_degree <= 64 && n_levels <= GS_MAX_LEVELS;
 }
 size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap, int v1_log2)
 {
@@ -661,6 +671,11 @@ void gs_run_lutr(const GsLaunch &L)
 template <int VSF, bool PAIR>
 void gs_run_session(const GsLaunch &L)
 {
+    if (L.p->generic) {
+        if constexpr (!PAIR) gs_worker<VSF, 0, false, false, false, true>(*L.p, L.worker, L.lds);
+        else abort();
+        return;
+    }
     switch (L.p->M / 16) {
     case 1: gs_worker<VSF, 1, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
     case 2: gs_worker<VSF, 2, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
@@ -675,6 +690,11 @@ void gs_run_session(const GsLaunch &L)
 template <int VSF, bool PAIR>
 void gs_run_ch(const GsLaunch &L)
 {
+    if (L.p->generic) {
+        if constexpr (!PAIR) gs_worker<VSF, 0, false>(*L.p, L.worker, L.lds);
+        else abort();
+        return;
+    }
     switch (L.p->M / 16) {
     case 1: gs_worker<VSF, 1, PAIR>(*L.p, L.worker, L.lds); break;
     case 2: gs_worker<VSF, 2, PAIR>(*L.p, L.worker, L.lds); break;
@@ -720,14 +740,15 @@ int launch_graph_search(hipStream_t, int vsf, const GsParams &p, int workers, in
     const size_t lds_bytes = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2) +
                              (p.lutr ? gs_lutr_lds_bytes(p.M) : 0) + (p.session ? gs_session_lds_bytes() : 0);
     // the waves of a persistent launch, one after another; wave w stops after its share so that several workers'
-    // scratch slices are exercised (a real launch interleaves them)
+    // scratch slices are exercised (a real launch interleaves them).  The lane emulator keeps one wave's context in statics:
+    // launches from several host threads (one context each) take turns (run_wave_locked).
     for (int w = 0; w < workers; ++w) {
         GsParams pw = p;
         pw.Q = (int)((long long)p.Q * (w + 1) / workers);
         char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
         memset(lds, 0xa5, lds_bytes);
         GsLaunch L{&pw, vsf, w, lds};
-        emu::run_wave(gs_main, &L);
+        run_wave_locked(gs_main, &L);
         *p.next_query = (uint32_t)pw.Q;
         free(lds);
     }

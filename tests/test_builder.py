@@ -95,16 +95,16 @@ def check_builder(J, ctx, dev, N, D, M, max_degree, beam, register=None, min_rec
     return stats, recall
 
 
-@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
-def test_builder_on_the_mock():
+def _on_the_mock(fn):
+    """run fn(jvector_amd, ctx, register) with the package bound to the mock library"""
     import build_mock
     import jvector_amd
     import jvector_amd._lib as L
     lib = C.CDLL(build_mock.build())
     for table in (L.SIGNATURES, L.COMPAT_SIGNATURES, L.FORMAT_SIGNATURES):
         for name, (res, args) in table.items():
-            fn = getattr(lib, name)
-            fn.restype, fn.argtypes = res, args
+            f = getattr(lib, name)
+            f.restype, f.argtypes = res, args
     saved, L._lib = L._lib, lib
     os.environ["JVECTOR_HIP_HOST_THREADS"] = "1"
     registered = []
@@ -117,7 +117,7 @@ def test_builder_on_the_mock():
         ctx = jvector_amd.HipContext(0)
         lib.mock_hip_register_device.argtypes = [C.c_void_p]
         lib.mock_hip_unregister_device.argtypes = [C.c_void_p]
-        check_builder(jvector_amd, ctx, torch.device("cpu"), 700, 128, 16, 16, 24, register=register)
+        fn(jvector_amd, ctx, register)
         ctx.close()
     finally:
         # the buffers die with this test: a later test's numpy array that lands on one of these addresses must not be taken
@@ -128,10 +128,34 @@ def test_builder_on_the_mock():
         os.environ.pop("JVECTOR_HIP_HOST_THREADS", None)
 
 
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+def test_builder_on_the_mock():
+    _on_the_mock(lambda J, ctx, register: check_builder(J, ctx, torch.device("cpu"), 700, 128, 16, 16, 24, register=register))
+
+
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+def test_builder_on_the_mock_ragged_quantizer():
+    """100 dimensions in 12 sub-vectors (9 9 9 9 8 ...): the builder's searches run on the traversal's generic kernels"""
+    _on_the_mock(lambda J, ctx, register: check_builder(J, ctx, torch.device("cpu"), 500, 100, 12, 16, 24, register=register))
+
+
 @pytest.mark.gpu
 def test_builder_gpu():
     import jvector_amd as J
     ctx = J.HipContext(0)
     stats, recall = check_builder(J, ctx, torch.device("cuda", 0), 30000, 128, 16, 32, 100, min_recall=0.9)
     print("builder:", dict(stats), "recall@10", recall)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_builder_gpu_ragged_quantizer():
+    """a quantizer outside the specialised traversal builds (100-d, PQ-12, ragged sub-vectors): built and searched on the device
+    through the generic kernels"""
+    import jvector_amd as J
+    ctx = J.HipContext(0)
+    ctx.reset_stats()
+    stats, recall = check_builder(J, ctx, torch.device("cuda", 0), 12000, 100, 12, 16, 60, min_recall=0.85)
+    assert ctx.stat("gs_calls_host") == 0
+    print("builder (ragged PQ):", dict(stats), "recall@10", recall)
     ctx.close()

@@ -278,12 +278,12 @@ def _same(r, w, tag):
     assert r.worst_approximate_in_topk == w.worst_approximate_in_topk, tag
 
 
-def run_searcher_object_cases(J, ctx, cases=4, traversal=None):
+def run_searcher_object_cases(J, ctx, cases=4, traversal=None, n_nodes=3000, nq=12):
     """search(topK, rerankK, threshold, rerankFloor, acceptOrds) followed by two resume() calls per query == the oracle's
     jvo_searcher restatement: nodes, scores, the four counters and worstApproximateScoreInTopK.  Shared with the mock.
-    traversal: None = the graph's default (AUTO: search() AND resume() of the M = 16 cases run on the DEVICE traversal's session
-    kernels — threshold admission, TwoPhaseTracker stop, acceptOrds in the kernel; a resume() replays the earlier calls of the
-    searcher in the same launch — the M = 8 cases on the host searcher), "host" / "device" pin it."""
+    traversal: None = the graph's default (AUTO: search() AND resume() run on the DEVICE traversal's session kernels — threshold
+    admission, TwoPhaseTracker stop, acceptOrds in the kernel; a resume() replays the earlier calls of the searcher in the same
+    launch — the M = 16 cases on the specialised build, the M = 8 cases on the generic one), "host" / "device" pin it."""
     VSF = J.VectorSimilarityFunction
     early = 0
     ctx.reset_stats()
@@ -291,12 +291,12 @@ def run_searcher_object_cases(J, ctx, cases=4, traversal=None):
     for case in range(cases):
         levels = 1 + case % 3
         D, M = [(64, 8), (128, 16)][case % 2]
-        v, lv, entry, entry_level, cb, q = build_problem(50 + case, N=3000, D=D, M=M, deg=16, levels=levels)
+        v, lv, entry, entry_level, cb, q = build_problem(50 + case, N=n_nodes, D=D, M=M, deg=16, levels=levels)
         N = len(v)
         rng = np.random.default_rng(case)
         if case == 1:                                   # duplicates: exact ties for the heap-order rerank
             v[1::2] = v[0:-1:2][: len(v[1::2])]
-        q = q[:12]
+        q = q[:nq]
         opq = O.OraclePQ(D, M, cb)
         pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
         vs = J.VectorSet(ctx, v)
@@ -309,7 +309,7 @@ def run_searcher_object_cases(J, ctx, cases=4, traversal=None):
         use_fused = case % 2 == 0
         fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
         accept = None if case % 2 else (rng.random((len(q), N)) < 0.7)
-        if M == 16 and traversal != "host":
+        if traversal != "host":
             dev_expected += 1
         for vsf in VSF:
             # approximate score levels of this query set, to place thresholds / floors where they bite
@@ -337,7 +337,7 @@ def run_searcher_object_cases(J, ctx, cases=4, traversal=None):
     # TwoPhaseTracker only answers when its observation count sits on a multiple of 100 (ScoreTracker.java:123-126), so an early
     # stop is a matter of luck per search — but over all of these some must have stopped before crawling the whole graph
     assert early > 0, "no threshold search ever stopped early: the tracker path was not exercised"
-    if dev_expected:   # the M = 16 cases really went through the session kernels, their resume() calls included (replayed in-kernel)
+    if dev_expected:   # the cases really went through the session kernels, their resume() calls included (replayed in-kernel)
         assert ctx.stat("gs_session_calls_device") >= dev_expected * 3 * 2 * 3, ctx.stat("gs_session_calls_device")
         assert ctx.stat("gs_session_resume_device") >= dev_expected * 3 * 2 * 2, ctx.stat("gs_session_resume_device")
     else:
@@ -392,6 +392,62 @@ def run_searcher_objects_other_shapes(J, ctx, shapes=((256, 32, 16), (384, 48, 4
 
 def test_searcher_objects_other_shapes(ctx):
     run_searcher_objects_other_shapes(J, ctx)
+
+
+def run_generic_shapes(J, ctx, shapes=((100, 12, 16), (200, 25, 40), (64, 8, 16), (50, 6, 24), (96, 24, 16), (120, 10, 40), (25, 3, 8), (30, 30, 16)),
+                       N=1200, nq=10):
+    """the device traversal's GENERIC kernels (gs_body.h CH16 = 0): every quantizer outside the specialised builds — ragged
+    sub-vectors (100 / 12, 50 / 6, 25 / 3), 8-dim sub-vectors at other M (200 / 25, 64 / 8), 4- and 12-dim ones read as 16-byte words
+    (96 / 24, 120 / 10), 1-dim ones (30 / 30), odd D — pinned to the device: plain searches (fused and not, reranked and not) and a
+    GraphSearcher object with a threshold + resume, all equal to the oracle bit for bit"""
+    VSF = J.VectorSimilarityFunction
+    for D, M, deg in shapes:
+        levels = 1 + (D + M) % 3
+        v, lv, entry, entry_level, cb, q = build_problem(D * 7 + M, N=N, D=D, M=M, deg=deg, top_deg=min(8, deg), levels=levels)
+        q = q[:nq]
+        n = len(v)
+        opq = O.OraclePQ(D, M, cb)
+        pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+        vs = J.VectorSet(ctx, v)
+        cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+        codes = cv.get(0, n)
+        og = O.OracleGraph(n, lv, entry, entry_level)
+        graph = J.GraphIndex(ctx, n, lv, entry, entry_level).set_traversal("device")
+        ctx.reset_stats()
+        for use_fused in (True, False):
+            fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
+            for vsf in VSF:
+                for rerank, top_k, rk in ((True, 10, 40), (False, 5, 20)):
+                    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=16)
+                    ids, sc, stats = s.search(q, vsf, top_k, rk, return_stats=True)
+                    wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused)
+                    tag = (D, M, deg, use_fused, vsf, rerank)
+                    assert np.array_equal(stats, wst), tag
+                    assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag
+                    s.close()
+            # GraphSearcher object: threshold search + two resumes through the generic session kernel
+            vsf = VSF.COSINE if D % 2 else VSF.EUCLIDEAN
+            lvl = np.sort(np.stack([opq.adc_scores(q[i], int(vsf), codes, None, fused=use_fused) for i in range(len(q))]), axis=1)
+            thr = float(np.median(lvl[:, -50]))
+            s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=16)
+            got = s.search_ex(q, vsf, n, n, threshold=thr)
+            got1 = s.resume(7, 20)
+            got2 = s.resume(20, 30)
+            for i in range(len(q)):
+                o = og.searcher(opq, codes, v, int(vsf), fused=use_fused)
+                tag = (D, M, deg, use_fused, "object", i)
+                _same(got[i], o.search(q[i], n, n, thr, 0.0), tag)
+                _same(got1[i], o.resume(7, 20), tag + ("resume 1",))
+                _same(got2[i], o.resume(20, 30), tag + ("resume 2",))
+                o.close()
+            s.close()
+        assert ctx.stat("gs_calls_device") >= 12 and ctx.stat("gs_calls_host") == 0, (D, M, ctx.stat("gs_calls_device"), ctx.stat("gs_calls_host"))
+        assert ctx.stat("gs_session_calls_device") >= 6 and ctx.stat("gs_session_resume_device") >= 4, (D, M)
+        graph.close()
+
+
+def test_generic_pq_shapes_on_the_device_traversal(ctx):
+    run_generic_shapes(J, ctx)
 
 
 def test_searcher_object_errors(ctx):

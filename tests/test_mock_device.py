@@ -464,10 +464,18 @@ def test_searcher_objects_other_shapes_on_the_mock(J, ctx):
 
 
 def test_searcher_objects_on_the_mock(J, ctx):
-    """threshold > 0 / rerankFloor / resume(): the host searcher's session path against the oracle's GraphSearcher object"""
+    """threshold > 0 / rerankFloor / resume() against the oracle's GraphSearcher object: the session kernels on the lane emulator
+    (generic build at M = 8, specialised at M = 16) and the host searcher's session path"""
     import test_graph_search as T
-    T.run_searcher_object_cases(J, ctx, cases=3)
+    T.run_searcher_object_cases(J, ctx, cases=2, n_nodes=1200, nq=8)
+    T.run_searcher_object_cases(J, ctx, cases=1, traversal="host")
     T.test_searcher_object_errors(ctx)
+
+
+def test_generic_pq_shapes_on_the_mock(J, ctx):
+    """the device traversal's generic kernels (any sub-vector geometry) on the lane emulator: searches + GraphSearcher objects"""
+    import test_graph_search as T
+    T.run_generic_shapes(J, ctx, N=500, nq=4)
 
 
 @pytest.mark.parametrize("slots,groups", [(64, 1), (96, 3), (700, 2), (1, 1)])

@@ -167,10 +167,15 @@ def test_exact_score_ties_are_resolved_on_the_device(ctx, monkeypatch, capfd):
 
 
 def test_unsupported_shape_is_refused(ctx):
+    """M = 8 has no specialised build: the pinned device traversal serves it through the generic kernels (== the oracle); what it
+    refuses is a search whose queues do not fit a wave's LDS"""
     v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 9, 2000, 64, 8, 1, False)  # M = 8
     s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
+    ids, sc, st = s.search(q, VSF.COSINE, 10, 40, return_stats=True)
+    wi, ws, wst = O.OracleGraph(len(v), lv, entry, entry_level).search(opq, codes, v, q, O.COSINE, 10, 40, fused=False)
+    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
     with pytest.raises(J.UnsupportedError):
-        s.search(q, VSF.COSINE, 10, 40)
+        s.search(q, VSF.COSINE, 10, 30000)
 
 
 def test_device_traversal_accept_ords(ctx):
@@ -246,9 +251,10 @@ def test_host_fallback_with_a_device_resident_level0(ctx, register=None):
 
 
 def test_auto_traversal_reports_the_host_fallback(ctx, capfd):
-    """JV_TRAVERSAL_AUTO on a shape the device traversal does not cover (12-dim sub-vectors) takes the host searcher — and says
-    so: one stderr notice per context, and the gs_calls_host_auto counter"""
+    """JV_TRAVERSAL_AUTO on a search the device traversal does not cover (a rerankK whose result queue does not fit a wave's LDS
+    share) takes the host searcher — and says so: one stderr notice per context, and the gs_calls_host_auto counter"""
     v, lv, entry, entry_level, cb, q = build_problem(23, N=1500, D=96, M=8, deg=12, levels=1)
+    RK = 6000
     opq = O.OraclePQ(96, 8, cb)
     pq = J.ProductQuantization.from_codebooks(ctx, 96, 8, cb)
     vs = J.VectorSet(ctx, v)
@@ -257,10 +263,10 @@ def test_auto_traversal_reports_the_host_fallback(ctx, capfd):
     s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
     ctx.reset_stats()
     capfd.readouterr()
-    ids, sc, st = s.search(q, VSF.EUCLIDEAN, 10, 40, return_stats=True)
-    ids2, _, _ = s.search(q, VSF.EUCLIDEAN, 10, 40, return_stats=True)
+    ids, sc, st = s.search(q, VSF.EUCLIDEAN, 10, RK, return_stats=True)
+    ids2, _, _ = s.search(q, VSF.EUCLIDEAN, 10, RK, return_stats=True)
     err = capfd.readouterr().err
-    wi, ws, wst = O.OracleGraph(len(v), lv, entry, entry_level).search(opq, cv.get(0, len(v)), v, q, O.EUCLIDEAN, 10, 40, fused=False)
+    wi, ws, wst = O.OracleGraph(len(v), lv, entry, entry_level).search(opq, cv.get(0, len(v)), v, q, O.EUCLIDEAN, 10, RK, fused=False)
     assert np.array_equal(ids, wi) and np.array_equal(sc, ws) and np.array_equal(st, wst) and np.array_equal(ids2, wi)
     assert ctx.stat("gs_calls_host_auto") == 2 and ctx.stat("gs_calls_device") == 0
     assert err.count("JV_TRAVERSAL_AUTO takes the HOST searcher") == 1
