@@ -435,7 +435,7 @@ struct QState {
     bool active = true;
     int32_t origin = -1;
     int n_pending = 0;
-    uint64_t fresh_mask = 0;  // fused layer 0: neighbours newly marked visited in this round
+    uint64_t fresh_mask[kMaxGraphDegree / 64] = {};  // fused layer 0: neighbours newly marked visited in this round (bit i = neighbour i)
     int64_t n_visited = 0, n_expanded = 0, n_expanded_base = 0;
     // CachingReranker (GraphSearcher.java:554-581): exact scores survive from search() to resume()
     std::unordered_map<int32_t, float> exact_cache;
@@ -875,7 +875,7 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
     } pool_session(pool);
     int W = 0;
     for (int lv = 0; lv <= g->entry_level; ++lv) W = std::max(W, g->levels[lv].degree);
-    JV_REQUIRE(W <= 64, "graph_search: degree %d > 64 is not supported", W);
+    JV_REQUIRE(W <= kMaxGraphDegree, "graph_search: degree %d > %d is not supported", W, kMaxGraphDegree);
 
     // ---- slots: queries stream through a fixed number of traversal slots (continuous batching), in NG groups that
     //      alternate between the host phase and the GPU phase so that one group's scoring overlaps the other's
@@ -1075,20 +1075,23 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
                         // scored from the packed block.  visited.mark happens here (the reference marks before it
                         // scores, OnDiskGraphIndex.java:646-650); the bitmask of newly marked neighbours tells the
                         // push phase which block scores to use.  No unvisited neighbour => no GPU round needed.
-                        uint64_t mask = 0;
+                        uint64_t any = 0;
+                        for (int wd = 0; wd < (deg0 + 63) / 64; ++wd) st.fresh_mask[wd] = 0;
                         // the <= maxDegree probes are independent: issue their cache misses together
                         for (int i = 0; i < deg0 && row[i] >= 0; ++i) st.visited.prefetch(row[i]);
                         for (int i = 0; i < deg0; ++i) {
                             const int32_t nb = row[i];
                             if (nb < 0) break;
-                            if (st.visited.add(nb)) mask |= (1ull << i);
+                            if (st.visited.add(nb)) {
+                                st.fresh_mask[i >> 6] |= (1ull << (i & 63));
+                                any = 1;
+                            }
                         }
-                        if (mask == 0) continue;
-                        st.fresh_mask = mask;
+                        if (any == 0) continue;
                         origins[si] = node;
                     } else {
                         const int deg = g->levels[s.lvl].degree;
-                        int32_t tmp[64];
+                        int32_t tmp[kMaxGraphDegree];
                         int np = 0;
                         for (int i = 0; i < deg; ++i) {
                             const int32_t nb = row[i];
@@ -1143,13 +1146,15 @@ static int graph_search_host(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const j
                 const float *sc = G.h_sc + (size_t)si * W;
                 if (ord_index[si] < 0) {  // fused layer 0
                     const int32_t *row = g->row(0, st.origin);
-                    uint64_t mask = st.fresh_mask;
-                    while (mask) {  // ascending bit order == neighbour order
-                        const int i = __builtin_ctzll(mask);
-                        mask &= mask - 1;
-                        if (trk) trk->track(sc[i]);
-                        st.cand.push(nq_encode(row[i], sc[i]));
-                        st.n_visited++;
+                    for (int wd = 0; wd < (deg0 + 63) / 64; ++wd) {
+                        uint64_t mask = st.fresh_mask[wd];
+                        while (mask) {  // ascending bit order == neighbour order
+                            const int i = wd * 64 + __builtin_ctzll(mask);
+                            mask &= mask - 1;
+                            if (trk) trk->track(sc[i]);
+                            st.cand.push(nq_encode(row[i], sc[i]));
+                            st.n_visited++;
+                        }
                     }
                 } else {
                     const int32_t *o = ords + (size_t)ord_index[si] * W;

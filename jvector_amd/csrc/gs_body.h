@@ -1016,7 +1016,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             const int deg = L.degree;
             const bool fused0 = lvl == 0 && p.blocks != nullptr;
             long long key = 0;
-            bool fresh;
+            bool fresh = false;
             if constexpr (PAIR) {
                 // ---- pair-lane form: neighbour i is handled by lanes i (low) and i + 32 (high) ----
                 const int ni = lane & 31;
@@ -1056,44 +1056,70 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     key = gs_key(nb, gs_finish<VSF>(sum, node_mag, query_mag));
                 }
             } else {
-                const int32_t nb = lane < deg ? row[lane] : -1;
-                // code bytes first, then the visited probes: the loads do not depend on the probes' outcome
-                gs_u4 w[CW];
-                const uint8_t *rp = nullptr;  // generic form: where the lane's code row lives
-                (void)w;
-                (void)rp;
-                if constexpr (LUTR) {  // every lane takes part in the cross-lane reads below: no uninitialised code words
+                // ---- one lane per neighbour, 64 neighbours at a time (degrees above 64: the next chunk of the row; inside an
+                //      expansion the order of visited.mark / push / track calls is immaterial — sets and a priority queue) ----
+                bool give_up = false;
+                for (int c0 = 0; c0 < deg; c0 += 64) {
+                    const int li = c0 + lane;
+                    const int32_t nb = li < deg ? row[li] : -1;
+                    // code bytes first, then the visited probes: the loads do not depend on the probes' outcome
+                    gs_u4 w[CW];
+                    const uint8_t *rp = nullptr;  // generic form: where the lane's code row lives
+                    (void)w;
+                    (void)rp;
+                    if constexpr (LUTR) {  // every lane takes part in the cross-lane reads below: no uninitialised code words
 #pragma unroll
-                    for (int c = 0; c < CW; ++c) w[c] = gs_u4{0u, 0u, 0u, 0u};
+                        for (int c = 0; c < CW; ++c) w[c] = gs_u4{0u, 0u, 0u, 0u};
+                    }
+                    float node_mag = 0.0f;
+                    if (fused0 && li < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
+                        const int64_t r = (int64_t)node * p.deg0 + li;
+                        if constexpr (CH16 == 0) rp = p.blocks + r * p.M;
+                        else gs_load_row<CW>(p.blocks + r * p.M, w);
+                        if (VSF == 2) node_mag = p.fused_norms[r];
+                    }
+                    const int first_neg = gs_first(gs_ballot(nb < 0));  // rows are packed: the first -1 ends the row
+                    const bool valid = lane < first_neg;
+                    if (!fused0 && valid) {      // PQDecoder.similarityTo: the neighbour's own code
+                        if constexpr (CH16 == 0) rp = p.codes + (int64_t)nb * p.M;
+                        else gs_load_row<CW>(p.codes + (int64_t)nb * p.M, w);
+                        if (VSF == 2) node_mag = p.code_norms[nb];
+                    }
+                    fresh = visit(valid, nb);
+                    if (s.status != GS_OK) {
+                        give_up = true;
+                        break;
+                    }
+                    const uint64_t fm = gs_ballot(fresh);
+                    const bool last = first_neg < 64 || c0 + 64 >= deg;  // the row ends inside this chunk
+                    if (fm == 0) {
+                        if (last) break;
+                        continue;
+                    }
+                    n_visited += gs_popc(fm);
+                    GS_PHASE(2);
+                    key = 0;
+                    if constexpr (CH16 == 0) {
+                        if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum_any<VSF>(p, qs, rp), node_mag, query_mag));
+                    } else if constexpr (LUTR) {
+                        const float raw = gs_row_sum_lut<CW>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, w);  // all lanes
+                        if (fresh) key = gs_key(nb, gs_finish<VSF>(raw, node_mag, query_mag));
+                    } else {
+                        if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CW>(p.codebooks, qs, w), node_mag, query_mag));
+                    }
+                    if (last) break;  // (the common case, every degree <= 64: the shared tail below pushes this chunk)
+                    if constexpr (SES) {
+                        if (thr_on) trk_track(fresh, gs_key_score(key));
+                    }
+                    gs_push(s, p, key, fresh);
+                    fresh = false;
+                    if (s.status != GS_OK) {
+                        give_up = true;
+                        break;
+                    }
                 }
-                float node_mag = 0.0f;
-                if (fused0 && lane < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
-                    const int64_t r = (int64_t)node * p.deg0 + lane;
-                    if constexpr (CH16 == 0) rp = p.blocks + r * p.M;
-                    else gs_load_row<CW>(p.blocks + r * p.M, w);
-                    if (VSF == 2) node_mag = p.fused_norms[r];
-                }
-                const int first_neg = gs_first(gs_ballot(nb < 0));  // rows are packed: the first -1 ends the row
-                const bool valid = lane < first_neg;
-                if (!fused0 && valid) {      // PQDecoder.similarityTo: the neighbour's own code
-                    if constexpr (CH16 == 0) rp = p.codes + (int64_t)nb * p.M;
-                    else gs_load_row<CW>(p.codes + (int64_t)nb * p.M, w);
-                    if (VSF == 2) node_mag = p.code_norms[nb];
-                }
-                fresh = visit(valid, nb);
-                if (s.status != GS_OK) break;
-                const uint64_t fm = gs_ballot(fresh);
-                if (fm == 0) continue;
-                n_visited += gs_popc(fm);
-                GS_PHASE(2);
-                if constexpr (CH16 == 0) {
-                    if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum_any<VSF>(p, qs, rp), node_mag, query_mag));
-                } else if constexpr (LUTR) {
-                    const float raw = gs_row_sum_lut<CW>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, w);  // all lanes
-                    if (fresh) key = gs_key(nb, gs_finish<VSF>(raw, node_mag, query_mag));
-                } else {
-                    if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CW>(p.codebooks, qs, w), node_mag, query_mag));
-                }
+                if (give_up) break;
+                if (gs_ballot(fresh) == 0) continue;  // nothing left for the tail (no fresh neighbour in the last chunk)
             }
             if (PROF) {  // the scores must have arrived before the phase is closed
                 const uint64_t done_ = gs_ballot(fresh && key != 0);

@@ -18,6 +18,9 @@
 namespace jv {
 
 constexpr int kClusters = 256;  // ProductQuantization.DEFAULT_CLUSTERS (ProductQuantization.java:62)
+// widest adjacency row the searchers take (the traversal kernels and the frontier kernels walk a row 64 neighbours at a time; the
+// builder and the diversity kernel keep their own limit of 64)
+constexpr int kMaxGraphDegree = 512;
 
 void set_error(const char *fmt, ...);
 void clear_error();

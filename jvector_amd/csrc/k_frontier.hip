@@ -63,13 +63,14 @@ __device__ __forceinline__ float frontier_row_sum(const float *lut, const uint8_
     return sum;
 }
 
-// block = 64 lanes.  W <= 32: two slots per wave (lane>>5 picks the slot); W <= 64: one slot per wave.
+// block = 64 lanes.  W <= 32: two slots per wave (lane>>5 picks the slot); W <= 64: one slot per wave; wider rows: blockIdx.y
+// picks the 64-neighbour chunk.
 template <int VSF, int CH16, bool TWO>
 __global__ __launch_bounds__(64) void frontier_kernel(FrontierParams p)
 {
     const int lane = threadIdx.x;
     const int slot = TWO ? (blockIdx.x * 2 + (lane >> 5)) : blockIdx.x;
-    const int i = TWO ? (lane & 31) : lane;
+    const int i = TWO ? (lane & 31) : (int)blockIdx.y * 64 + lane;
     if (slot >= p.S || i >= p.W) return;
     float *o = p.out + (int64_t)slot * p.W + i;
     const int lq = p.slot_query[slot];
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(64) void frontier_kernel(FrontierParams p)
 template <int VSF, bool TWO>
 static int launch_frontier_ch(hipStream_t s, const FrontierParams &p, int ch)
 {
-    dim3 grid(TWO ? (p.S + 1) / 2 : p.S), block(64);
+    dim3 grid(TWO ? (p.S + 1) / 2 : p.S, TWO ? 1 : (p.W + 63) / 64), block(64);
 #define JV_FR(CH) hipLaunchKernelGGL((frontier_kernel<VSF, CH, TWO>), grid, block, 0, s, p)
     switch (ch) {
     case 1: JV_FR(1); break;
@@ -138,16 +139,17 @@ __global__ __launch_bounds__(64) void frontier_direct_kernel(FrontierParams p)
     const int lane = threadIdx.x;
     const int half = TWO ? (lane >> 5) : 0;
     const int slot = TWO ? (blockIdx.x * 2 + half) : blockIdx.x;
-    const int i = TWO ? (lane & 31) : lane;
+    const int li = TWO ? (lane & 31) : lane;
     const int lanes_per_slot = TWO ? 32 : 64;
     const int lq = slot < p.S ? p.slot_query[slot] : -1;
     float *qs = qlds + half * p.D;
     if (lq >= 0) {
         const float4 *src = reinterpret_cast<const float4 *>(p.cq + (int64_t)lq * p.D);
         float4 *dst = reinterpret_cast<float4 *>(qs);
-        for (int j = i; j < p.D / 4; j += lanes_per_slot) dst[j] = src[j];
+        for (int j = li; j < p.D / 4; j += lanes_per_slot) dst[j] = src[j];
     }
     __syncthreads();
+    const int i = TWO ? li : (int)blockIdx.y * 64 + li;  // rows wider than 64: blockIdx.y picks the chunk
     if (slot >= p.S || i >= p.W) return;
     float *o = p.out + (int64_t)slot * p.W + i;
     if (lq < 0) { *o = -INFINITY; return; }
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(64) void frontier_direct_kernel(FrontierParams p)
 template <int VSF, bool TWO>
 static int launch_frontier_direct_ch(hipStream_t s, const FrontierParams &p, int ch)
 {
-    dim3 grid(TWO ? (p.S + 1) / 2 : p.S), block(64);
+    dim3 grid(TWO ? (p.S + 1) / 2 : p.S, TWO ? 1 : (p.W + 63) / 64), block(64);
     const size_t lds = sizeof(float) * (size_t)p.D * (TWO ? 2 : 1);
 #define JV_FD(CH) hipLaunchKernelGGL((frontier_direct_kernel<VSF, CH, TWO>), grid, block, lds, s, p)
     switch (ch) {
@@ -241,8 +243,8 @@ int launch_frontier(hipStream_t s, int vsf, const float *d_luts, const float *d_
                     const jv_codes *codes, float *d_out, int S, int W, const jv_pq *pq, const float *d_cq)
 {
     if (S == 0 || W == 0) return JV_OK;
-    if (W > 64) {
-        set_error("frontier: degree %d > 64 is not supported", W);
+    if (W > kMaxGraphDegree) {
+        set_error("frontier: degree %d > %d is not supported", W, kMaxGraphDegree);
         return JV_ERR_UNSUPPORTED;
     }
     FrontierParams p{};

@@ -110,7 +110,7 @@ bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const
 {
     (void)codes;
     (void)fused;
-    return pq->k == kClusters && pq->M >= 1 && max_degree <= 64 && n_levels <= GS_MAX_LEVELS;
+    return pq->k == kClusters && pq->M >= 1 && max_degree <= kMaxGraphDegree && n_levels <= GS_MAX_LEVELS;
 }
 
 size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap, int v1_log2)

@@ -450,6 +450,53 @@ def test_generic_pq_shapes_on_the_device_traversal(ctx):
     run_generic_shapes(J, ctx)
 
 
+def run_wide_rows(J, ctx, shapes=((128, 16, 72), (64, 8, 130), (100, 12, 96)), N=900, nq=8):
+    """adjacency rows wider than a wavefront (the reference's M grid goes to 128): the traversal kernels and the frontier kernels
+    walk such a row 64 neighbours at a time.  Host and device traversal, fused and not, plain searches and a GraphSearcher object
+    with a threshold + resume == the oracle"""
+    VSF = J.VectorSimilarityFunction
+    for D, M, deg in shapes:
+        v, lv, entry, entry_level, cb, q = build_problem(D + deg, N=N, D=D, M=M, deg=deg, top_n=max(80, deg + 10), top_deg=min(deg, 70), levels=2)
+        q = q[:nq]
+        n = len(v)
+        opq = O.OraclePQ(D, M, cb)
+        pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+        vs = J.VectorSet(ctx, v)
+        cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+        codes = cv.get(0, n)
+        og = O.OracleGraph(n, lv, entry, entry_level)
+        for traversal in ("device", "host"):
+            graph = J.GraphIndex(ctx, n, lv, entry, entry_level).set_traversal(traversal)
+            for use_fused in (True, False):
+                fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
+                for vsf in VSF:
+                    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=16)
+                    ids, sc, stats = s.search(q, vsf, 10, 30, return_stats=True)
+                    wi, ws, wst = og.search(opq, codes, v, q, int(vsf), 10, 30, fused=use_fused)
+                    tag = (D, M, deg, traversal, use_fused, vsf)
+                    assert np.array_equal(stats, wst), tag
+                    assert np.array_equal(ids, wi) and np.array_equal(sc, ws), tag
+                    s.close()
+                vsf = VSF.COSINE
+                lvl = np.sort(np.stack([opq.adc_scores(q[i], int(vsf), codes, None, fused=use_fused) for i in range(len(q))]), axis=1)
+                thr = float(np.median(lvl[:, -50]))
+                s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=16)
+                got = s.search_ex(q, vsf, n, n, threshold=thr)
+                got1 = s.resume(9, 25)
+                for i in range(len(q)):
+                    o = og.searcher(opq, codes, v, int(vsf), fused=use_fused)
+                    tag = (D, M, deg, traversal, use_fused, "object", i)
+                    _same(got[i], o.search(q[i], n, n, thr, 0.0), tag)
+                    _same(got1[i], o.resume(9, 25), tag + ("resume",))
+                    o.close()
+                s.close()
+            graph.close()
+
+
+def test_rows_wider_than_a_wavefront(ctx):
+    run_wide_rows(J, ctx)
+
+
 def test_searcher_object_errors(ctx):
     v, lv, entry, entry_level, cb, q = build_problem(3, N=500, D=64, M=8, deg=8, levels=1)
     pq = J.ProductQuantization.from_codebooks(ctx, 64, 8, cb)

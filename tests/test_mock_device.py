@@ -472,6 +472,12 @@ def test_searcher_objects_on_the_mock(J, ctx):
     T.test_searcher_object_errors(ctx)
 
 
+def test_rows_wider_than_a_wavefront_on_the_mock(J, ctx):
+    """degree 72 / 96 / 130 graphs: the traversal body's chunk loop on the lane emulator, the host searcher's multi-word masks"""
+    import test_graph_search as T
+    T.run_wide_rows(J, ctx, N=500, nq=4)
+
+
 def test_generic_pq_shapes_on_the_mock(J, ctx):
     """the device traversal's generic kernels (any sub-vector geometry) on the lane emulator: searches + GraphSearcher objects"""
     import test_graph_search as T
