@@ -387,7 +387,7 @@ JV_API int jv_hip_graph_destroy(jv_graph *g);
 /* Where the traversal state (candidate / result queues, visited set) lives.
  *   HOST   : the host batched searcher (C++ worker pool; the GPU scores each round's frontier).
  *   DEVICE : one wavefront per query keeps the queues in LDS / L2 and runs the whole loop on the GPU (256-cluster codebooks,
- *            degree <= 64: kernels specialised for uniform 8-dim sub-vectors at M = 16, 32, 48, 64, 96, 128, 192, a generic
+ *            degree <= 512 — rows wider than 64 are walked 64 neighbours at a time —: kernels specialised for uniform 8-dim sub-vectors at M = 16, 32, 48, 64, 96, 128, 192, a generic
  *            build for every other quantizer — ragged or other sub-vector sizes, any M); queries that outgrow its
  *            fixed-size structures are re-run on the host.  Results, visitedCount and expandedCount are identical either way.
  *   AUTO   : DEVICE wherever it applies (as above and the queues fit LDS), else HOST.
@@ -506,7 +506,7 @@ JV_API int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts 
  * stats (nullable) Q x 4 int64 = {visitedCount, expandedCount, expandedCountBaseLayer, rerankedCount};
  * worst_approx (nullable) Q floats = worstApproximateScoreInTopK (+inf when fewer than topK results or no reranker).
  * Exact-score ties at the K-th place resolve as in the reference (its result heap's array order).
- * Where they run: search() runs on the DEVICE traversal wherever its session kernels apply (256-cluster codebooks — specialised builds at M = 16 … 192, a generic one otherwise —, degree <= 64, the rerankK results fit LDS; graph traversal not pinned to the host): threshold admission, the
+ * Where they run: search() runs on the DEVICE traversal wherever its session kernels apply (256-cluster codebooks — specialised builds at M = 16 … 192, a generic one otherwise —, degree <= 512, the rerankK results fit LDS; graph traversal not pinned to the host): threshold admission, the
  * TwoPhaseTracker stop and acceptOrds inside the kernel, then the host rebuilds approximateResults' heap array from the kernel's
  * addTopCandidate log and runs the reference's rerank (floor, caching reranker, worst approximate score).  resume() needs the
  * candidate queue / visited set of every searcher, which never left the device: the session kernel replays the searcher's earlier

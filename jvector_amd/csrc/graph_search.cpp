@@ -1779,7 +1779,7 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
     CtxBusy busy(ctx);
     JV_REQUIRE(busy.ok, "graph_search: this jv_ctx is already inside a call on another thread (one context per host thread)");
     // Traversal: the graph's setting, overridden by JVECTOR_HIP_GRAPH_TRAVERSAL=host|device.  AUTO = the device-resident
-    // traversal wherever it applies (256-cluster codebooks, degree <= 64, queues fit LDS: specialised kernels for uniform 8-dim
+    // traversal wherever it applies (256-cluster codebooks, degree <= 512, queues fit LDS: specialised kernels for uniform 8-dim
     // sub-vectors at M = 16 ... 192, the generic form for every other quantizer), the host searcher otherwise.
     int mode = (int)ctx_opt(ctx, "graph_traversal", g->traversal);
     if (mode != JV_TRAVERSAL_HOST && mode != JV_TRAVERSAL_DEVICE) mode = JV_TRAVERSAL_AUTO;
@@ -1831,7 +1831,7 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
                 (void)jv_hip_ctx_get_stat(ctx, "gs_calls_host_auto", &n_auto);
                 if (n_auto == 1 && ctx_opt(ctx, "quiet", 0) == 0)
                     fprintf(stderr, "[jvector_hip] graph_search: JV_TRAVERSAL_AUTO takes the HOST searcher for this search (the device traversal needs "
-                                    "256-cluster codebooks, degree <= 64, <= %d levels and queues that fit LDS); counter "
+                                    "256-cluster codebooks, degree <= 512, <= %d levels and queues that fit LDS); counter "
                                     "gs_calls_host_auto counts further calls\n", GS_MAX_LEVELS);
             }
         }
@@ -1856,7 +1856,7 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
     JV_REQUIRE(queries && out_ids && out_scores, "graph_search: NULL buffer");
     JV_TRY(use_device(ctx->device));
     if (!graph_search_device_supported(l->pq, codes, fused, W, g->entry_level + 1)) {
-        set_error("graph_search: the device traversal needs 256-cluster codebooks, degree <= 64 and <= %d levels; use the host traversal",
+        set_error("graph_search: the device traversal needs 256-cluster codebooks, degree <= 512 and <= %d levels; use the host traversal",
                   GS_MAX_LEVELS);
         return JV_ERR_UNSUPPORTED;
     }

@@ -799,7 +799,7 @@ class GraphIndex:
 
     def set_traversal(self, mode: str):
         """Where the traversal state lives: "host" (worker pool + GPU frontier scoring), "device" (one wavefront per
-        query runs the whole loop on the GPU) or "auto" (device wherever it applies — 256-cluster codebooks, degree <= 64,
+        query runs the whole loop on the GPU) or "auto" (device wherever it applies — 256-cluster codebooks, degree <= 512,
         queues fit LDS; kernels specialised for uniform 8-dim sub-vectors at M in {16,32,48,64,96,128,192}, a generic build for
         every other quantizer — else host).  Results are identical."""
         check(self._lib.jv_hip_graph_set_traversal(self._h, self.TRAVERSAL[mode]))
@@ -867,7 +867,7 @@ class GraphSearcher:
         for every query of the batch, as one GraphSearcher OBJECT per query: the state stays behind for resume().  Returns a
         list of SearchResult (nodes best first, visited / expanded / expanded_base / reranked counts,
         worst_approximate_in_topk).  threshold > 0 and rerank_floor behave as in the reference (TwoPhaseTracker,
-        NodeQueue.rerank).  search() runs on the device traversal where its session kernels apply (any 256-cluster quantizer, degree <= 64), else on the host
+        NodeQueue.rerank).  search() runs on the device traversal where its session kernels apply (any 256-cluster quantizer, degree <= 512), else on the host
         batched searcher; resume() likewise (the session kernel replays the searcher's earlier calls and continues)."""
         Q = int(queries.shape[0])
         q_p, qk = _ptr(queries, np.float32)

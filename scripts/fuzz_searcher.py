@@ -62,7 +62,7 @@ while time.time() < t_end:
         D = int(rng.integers(6, 260))
         M = int(rng.integers(1, min(D, 40) + 1))
     N = int(rng.integers(260, 700 if MOCK else 2500))
-    deg = int(rng.choice([8, 16, 24, 32, 40, 64]))
+    deg = int(rng.choice([8, 16, 24, 32, 40, 64, 80, 130]))
     levels = int(rng.integers(1, 4))
     v, lv, entry, entry_level, cb, q = build_problem(int(rng.integers(1 << 30)), N=N, D=D, M=M, deg=deg, top_n=max(12, N // 20), top_deg=min(8, deg),
                                                      levels=levels)

@@ -2,7 +2,7 @@
 GraphSearcher restatement on random problems — shapes (specialised and generic kernels), degrees, level counts, similarity functions, fused / unfused, rerank /
 no rerank, acceptOrds filters, duplicated vectors (exact-score ties), tiny visited tables (growth / retry / host fallback).
 Every case must agree bit for bit on ids, scores and the visited / expanded counters.
-usage (GPU box): python scripts/fuzz_traversal.py [seconds] [seed]"""
+usage (GPU box): python scripts/fuzz_traversal.py [seconds] [seed]     (here: FUZZ_MOCK=1 python scripts/fuzz_traversal.py 60)"""
 import os
 import sys
 import time
@@ -12,6 +12,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+MOCK = os.environ.get("FUZZ_MOCK") == "1"       # the same sweep on the CPU mock + lane emulator (slow: small problems)
+if MOCK:
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests", "mock"))
+    os.environ.setdefault("JVECTOR_HIP_HOST_THREADS", "1")
+    import build_mock
+    import jvector_amd._lib as L
+    lib = C.CDLL(build_mock.build())
+    for table in (L.SIGNATURES, L.COMPAT_SIGNATURES, L.FORMAT_SIGNATURES):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    L._lib = lib
 import jvector_amd as J  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from test_graph_search import fused_blocks  # noqa: E402
@@ -26,13 +39,13 @@ cases = searches = 0
 knobs = ("JVECTOR_HIP_GS_VCAP_LOG2", "JVECTOR_HIP_GS_GROW", "JVECTOR_HIP_GS_RETRY", "JVECTOR_HIP_GS_CAND_CAP", "JVECTOR_HIP_GS_PUSH_LOG_CAP",
          "JVECTOR_HIP_GS_GENERIC")
 while time.time() < t_end:
-    D = int(rng.choice([128, 256, 384, 512, 768]))
+    D = int(rng.choice([128, 256, 384, 512, 768] if not MOCK else [128, 256]))
     M = D // 8
     if rng.random() < 0.3:                                   # any other quantizer (ragged / small / odd): the generic kernels
         D = int(rng.integers(6, 260))
         M = int(rng.integers(1, min(D, 40) + 1))
-    N = int(rng.integers(200, 6000))
-    deg = int(rng.choice([8, 16, 24, 32, 48, 64]))
+    N = int(rng.integers(200, 900 if MOCK else 6000))
+    deg = int(rng.choice([8, 16, 24, 32, 48, 64, 72, 100, 130]))   # (> 64: rows walked 64 neighbours at a time)
     n_levels = int(rng.integers(1, 4))
     base = rng.standard_normal((N, D)).astype(np.float32)
     if rng.random() < 0.3:                                   # duplicates: exact-score ties
@@ -89,7 +102,7 @@ while time.time() < t_end:
         top_k = int(rng.integers(1, min(rk, 20) + 1))
         rerank = bool(rng.random() < 0.7)
         accept = None if rng.random() < 0.6 else (rng.random(N) < 0.7 if rng.random() < 0.5 else rng.random((Q, N)) < 0.5)
-        traversal = "device" if (deg <= 64 and rng.random() < 0.85) else "host"
+        traversal = "device" if rng.random() < 0.85 else "host"
         env = {}
         if traversal == "device" and rng.random() < 0.4:
             env["JVECTOR_HIP_GS_VCAP_LOG2"] = str(int(rng.integers(8, 11)))
