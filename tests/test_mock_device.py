@@ -759,7 +759,7 @@ def _bench_rank(rank, world, port, mode, out_dir):
             return torch.device("cpu")
 
     bench.torch = TorchProxy()
-    sys.argv = ["bench.py", "--gpus", str(world), "--mode", mode, "--graph", "synthetic", "--n", "5000", "--dim", "128", "--m", "16", "--degree", "16", "--queries",
+    sys.argv = ["bench.py", "--gpus", str(world), "--mode", mode, "--graph", "synthetic", "--n", "2500", "--dim", "128", "--m", "16", "--degree", "16", "--queries",
                 "32", "--steps", "2", "--warmup", "1", "--eval-queries", "32", "--cal-queries", "32"]
     with open(os.path.join(out_dir, f"rank{rank}.out"), "w") as f, contextlib.redirect_stdout(f):
         bench.main()
@@ -807,7 +807,7 @@ def test_bench_gpus_flag_spawns_its_own_ranks(J, workload):
     ONE line with n_gpus == 2 and rccl_ranks == 2 — the engine's own communicator (here on the shared-memory RCCL shim) joined
     by both.  c3 = replicas (weak scaling line), c4 = the sharded index through jv_hip_sharded_search_flat."""
     if workload == "c3":
-        argv = ["--gpus", "2", "--mode", "graph", "--graph", "synthetic", "--n", "4000", "--dim", "128", "--m", "16", "--degree", "16",
+        argv = ["--gpus", "2", "--mode", "graph", "--graph", "synthetic", "--n", "2500", "--dim", "128", "--m", "16", "--degree", "16",
                 "--queries", "32", "--steps", "2", "--warmup", "1", "--eval-queries", "32", "--cal-queries", "32"]
     else:
         argv = ["--gpus", "2", "--workload", "c4", "--n", "3000", "--dim", "128", "--m", "16", "--queries", "16", "--steps", "2",
