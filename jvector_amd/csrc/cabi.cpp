@@ -432,16 +432,44 @@ int jv_hip_pq_create(jv_ctx *ctx, int D, int M, int k, const int *sizes, const f
     JV_REQUIRE(D > 0 && M > 0, "pq_create: D and M must be positive");
     // ProductQuantization.getSubvectorSizesAndOffsets :536-538
     JV_REQUIRE(M <= D, "Number of subspaces must be less than or equal to the vector dimension");
-    if (k != kClusters) {
-        set_error("pq_create: clusterCount %d unsupported (codes are one byte: k must be 256)", k);
+    // ProductQuantization.checkClusterCount: 1..256 (codes are one byte).  Fewer than 256: padded below.
+    if (k < 1 || k > kClusters) {
+        set_error("pq_create: clusterCount %d outside 1..256 (codes are one byte)", k);
         return JV_ERR_UNSUPPORTED;
     }
     JV_TRY(use_device(ctx->device));
+    const int k_user = k;
+    std::vector<float> padded;
+    if (k_user < kClusters) {
+        // rows k_user..255 of every codebook = copies of its row 0 (jv_pq::k_user): the device side only ever sees 256-row codebooks
+        std::vector<int> sz((size_t)M);
+        size_t total = 0;
+        for (int m = 0; m < M; ++m) {
+            sz[(size_t)m] = sizes ? sizes[m] : (D / M + (m < D % M ? 1 : 0));
+            JV_REQUIRE(sz[(size_t)m] > 0, "pq_create: subvector size %d at m=%d", sz[(size_t)m], m);
+            total += (size_t)sz[(size_t)m];
+        }
+        JV_REQUIRE(total == (size_t)D, "pq_create: subvector sizes sum to %zu, expected D=%d", total, D);
+        std::vector<float> src((size_t)k_user * (size_t)D);
+        JV_HIP_CHECK(hipMemcpy(src.data(), codebooks, sizeof(float) * src.size(), hipMemcpyDefault));
+        padded.resize((size_t)kClusters * (size_t)D);
+        size_t so = 0, po = 0;
+        for (int m = 0; m < M; ++m) {
+            const size_t S = (size_t)sz[(size_t)m];
+            memcpy(padded.data() + po, src.data() + so, sizeof(float) * S * (size_t)k_user);
+            for (int c = k_user; c < kClusters; ++c) memcpy(padded.data() + po + (size_t)c * S, src.data() + so, sizeof(float) * S);
+            so += S * (size_t)k_user;
+            po += S * (size_t)kClusters;
+        }
+        codebooks = padded.data();
+        k = kClusters;
+    }
     jv_pq *pq = new jv_pq();
     pq->device = ctx->device;
     pq->D = D;
     pq->M = M;
     pq->k = k;
+    pq->k_user = k_user;
     pq->sizes.resize(M);
     pq->offsets.resize(M);
     pq->cb_offsets.resize(M);
@@ -572,6 +600,11 @@ int jv_hip_pq_load(jv_ctx *ctx, const uint8_t *buf, size_t len, size_t *consumed
 #undef NEED
     JV_REQUIRE(gcl == 0 || gcl == D, "Global centroid length %d does not match vector dimensionality %d", gcl, D);
     if (consumed) *consumed = p;
+    JV_REQUIRE(k <= kClusters, "pq_load: clusterCount %d > 256 (codes are one byte)", k);
+    if (aniso > -1.0f && k != kClusters) {
+        set_error("pq_load: an anisotropic PQ with clusterCount %d != 256 is not supported", k);
+        return JV_ERR_UNSUPPORTED;
+    }
     JV_TRY(jv_hip_pq_create(ctx, D, M, k, sizes.data(), cbs.data(), gcl ? centroid.data() : nullptr, out));
     (*out)->aniso = aniso;  // > -1: encode with encodeAnisotropic (ProductQuantization.encodeTo :439-449)
     return JV_OK;
@@ -584,6 +617,10 @@ int jv_hip_pq_set_anisotropic_threshold(jv_pq *pq, float threshold)
     // KMeansPlusPlusClusterer.java:87-92
     JV_REQUIRE(threshold == threshold && threshold >= -1.0f && threshold < 1.0f,
                "Valid range for anisotropic threshold T is -1.0 <= t < 1.0");
+    if (threshold > -1.0f && pq->k_user != kClusters) {  // (the padded rows would take part in the coordinate descent)
+        set_error("anisotropic encoding needs a 256-cluster PQ here (clusterCount %d)", pq->k_user);
+        return JV_ERR_UNSUPPORTED;
+    }
     pq->aniso = threshold;
     return JV_OK;
 }
@@ -610,7 +647,7 @@ int jv_hip_pq_info(const jv_pq *pq, int *D, int *M, int *k, int *has_centroid)
     JV_REQUIRE(pq, "pq is NULL");
     if (D) *D = pq->D;
     if (M) *M = pq->M;
-    if (k) *k = pq->k;
+    if (k) *k = pq->k_user;   // the caller's clusterCount (the device side holds 256 rows per sub-space whatever it is)
     if (has_centroid) *has_centroid = pq->d_centroid != nullptr;
     return JV_OK;
 }
@@ -621,7 +658,14 @@ int jv_hip_pq_self_magnitudes(jv_ctx *ctx, const jv_pq *pq, float *out)
     JV_REQUIRE(ctx && pq && out, "NULL argument");
     JV_TRY(use_device(ctx->device));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    JV_HIP_CHECK(hipMemcpy(out, pq->d_self_mag, sizeof(float) * (size_t)pq->M * pq->k, hipMemcpyDefault));
+    // [M][clusterCount]: rows of the caller's cluster count out of the 256-row device table
+    if (pq->k_user == pq->k) {
+        JV_HIP_CHECK(hipMemcpy(out, pq->d_self_mag, sizeof(float) * (size_t)pq->M * pq->k, hipMemcpyDefault));
+    } else {
+        for (int m = 0; m < pq->M; ++m)
+            JV_HIP_CHECK(hipMemcpy(out + (size_t)m * pq->k_user, pq->d_self_mag + (size_t)m * pq->k, sizeof(float) * (size_t)pq->k_user,
+                                   hipMemcpyDefault));
+    }
     return JV_OK;
 }
 
@@ -1017,7 +1061,8 @@ int jv_hip_fused_create(jv_ctx *ctx, const jv_pq *pq, int64_t count, int maxDegr
     clear_error();
     JV_REQUIRE(ctx && pq && out, "fused_create: NULL argument");
     JV_REQUIRE(count > 0 && maxDegree > 0 && maxDegree < 2048, "fused_create: bad count/maxDegree");
-    // FusedPQ requires a 256-cluster PQ (FusedPQ.java:57-59) — already guaranteed by pq_create
+    // FusedPQ requires a 256-cluster PQ (FusedPQ.java:57-59)
+    JV_REQUIRE(pq->k_user == kClusters, "FusedPQ requires a 256-cluster PQ");
     JV_TRY(use_device(ctx->device));
     jv_fused *f = new jv_fused();
     f->device = ctx->device;

@@ -130,7 +130,11 @@ struct CtxBusy {
 
 struct jv_pq {
     int device = 0;
-    int D = 0, M = 0, k = 0;
+    int D = 0, M = 0, k = 0;   // k: rows per codebook in device memory — always kClusters (see k_user)
+    // clusterCount the caller gave (ProductQuantization allows 1..256).  A smaller count is stored PADDED to 256 rows per
+    // sub-space with copies of centroid 0: closestCentroidIndex keeps the FIRST minimum (ProductQuantization.java:507-520: strict
+    // `<`), so a copy of row 0 is never chosen, every code stays < k_user, and every kernel keeps its 256-row table stride
+    int k_user = 0;
     bool uniform = false;      // all subvector sizes equal
     int max_size = 0;
     std::vector<int> sizes, offsets;

@@ -138,6 +138,10 @@ int jv_hip_pq_train_anisotropic(jv_ctx *ctx, const float *vectors, int64_t n, in
     JV_REQUIRE(n >= k, "Cannot train PQ with %d clusters on %lld points, supply more training vectors or lower cluster count.", k,
                (long long)n);
     JV_REQUIRE((D + M - 1) / M <= 64, "pq_train: sub-vectors longer than 64 dimensions are not supported");
+    if (k != kClusters) {  // (a PQ with fewer clusters can be LOADED / created from codebooks and used; it is not trained here)
+        set_error("pq_train: clusterCount %d unsupported by the training kernels (256 only)", k);
+        return JV_ERR_UNSUPPORTED;
+    }
     JV_TRY(use_device(ctx->device));
     PqGuard work;
     std::vector<float> zeros((size_t)k * D, 0.0f);
@@ -155,6 +159,10 @@ int jv_hip_pq_refine(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t
     JV_REQUIRE(ctx && pq && vectors && out, "pq_refine: NULL argument");
     *out = nullptr;
     JV_REQUIRE(lloyds_rounds >= 0, "lloydsRounds must be non-negative");  // ProductQuantization.refine :205-207
+    if (pq->k_user != kClusters) {
+        set_error("pq_refine: clusterCount %d != 256 is not supported by the training kernels", pq->k_user);
+        return JV_ERR_UNSUPPORTED;
+    }
     JV_REQUIRE(n > 0, "pq_refine: no training vectors");
     JV_REQUIRE(pq->max_size <= 64, "pq_refine: sub-vectors longer than 64 dimensions are not supported");
     const bool aniso = pq->aniso > -1.0f;  // refine :212-214: cluster(aniso ? 0 : rounds, aniso ? rounds : 0)
@@ -179,7 +187,7 @@ int jv_hip_pq_write(jv_ctx *ctx, const jv_pq *pq, int version, uint8_t *buf, siz
     JV_REQUIRE(ctx && pq && len_out, "pq_write: NULL argument");
     JV_REQUIRE(version >= 0 && version <= 6, "Unsupported serialization version %d", version);
     JV_REQUIRE(version >= 3 || !(pq->aniso > -1.0f), "Anisotropic threshold is only supported in serialization version 3 and above");
-    const size_t total = (size_t)pq->k * pq->D;
+    const size_t total = (size_t)pq->k_user * pq->D;   // the caller's clusterCount: padded rows are not part of the format
     const size_t need = (version >= 3 ? 8 : 0) + 4 + (pq->d_centroid ? (size_t)pq->D * 4 : 0) + 4 + (size_t)pq->M * 4 +
                         (version >= 3 ? 4 : 0) + 4 + total * 4;
     *len_out = need;
@@ -187,7 +195,15 @@ int jv_hip_pq_write(jv_ctx *ctx, const jv_pq *pq, int version, uint8_t *buf, siz
     JV_TRY(use_device(ctx->device));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     std::vector<float> cb(total), cen;
-    JV_HIP_CHECK(hipMemcpy(cb.data(), pq->d_codebooks, sizeof(float) * total, hipMemcpyDeviceToHost));
+    {
+        size_t so = 0, po = 0;
+        for (int m = 0; m < pq->M; ++m) {  // codebook m: the first k_user of its 256 device rows
+            const size_t S = (size_t)pq->sizes[(size_t)m];
+            JV_HIP_CHECK(hipMemcpy(cb.data() + so, pq->d_codebooks + po, sizeof(float) * S * (size_t)pq->k_user, hipMemcpyDeviceToHost));
+            so += S * (size_t)pq->k_user;
+            po += S * (size_t)pq->k;
+        }
+    }
     if (pq->d_centroid) {
         cen.resize((size_t)pq->D);
         JV_HIP_CHECK(hipMemcpy(cen.data(), pq->d_centroid, sizeof(float) * (size_t)pq->D, hipMemcpyDeviceToHost));
@@ -216,7 +232,7 @@ int jv_hip_pq_write(jv_ctx *ctx, const jv_pq *pq, int version, uint8_t *buf, siz
     wr_i32(pq->M);
     for (int m = 0; m < pq->M; ++m) wr_i32(pq->sizes[m]);
     if (version >= 3) wr_f32(pq->aniso);
-    wr_i32(pq->k);
+    wr_i32(pq->k_user);
     for (float f : cb) wr_f32(f);
     return JV_OK;
 }

@@ -48,6 +48,40 @@ def test_encode_bit_exact(ctx, D, M, center):
     assert got.dtype == np.uint8 and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("D,M,k", [(64, 8, 16), (100, 7, 50), (128, 16, 255), (24, 3, 1)])
+def test_cluster_counts_below_256(ctx, D, M, k):
+    """ProductQuantization allows 1..256 clusters (the reference's own tests train 16 and 50).  The engine stores such a quantizer
+    padded to 256 rows per sub-space with copies of centroid 0 — never chosen, closestCentroidIndex keeps the FIRST minimum — so
+    codes, table scores, magnitudes and the wire format must equal the oracle's, which works with the true cluster count"""
+    rng = np.random.default_rng(D + k)
+    cb = rng.standard_normal(k * D).astype(np.float32)
+    centroid = (rng.standard_normal(D) * 0.1).astype(np.float32)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb, centroid, cluster_count=k)
+    opq = O.OraclePQ(D, M, cb, centroid, k=k)
+    assert pq.get_cluster_count() == k
+    vecs = rng.standard_normal((2000, D)).astype(np.float32)
+    hit = rng.integers(0, k, (50, M)).astype(np.uint8)
+    hit[:, 0] = 0                                        # sub-vector 0 = centroid 0 exactly: ties with every padded copy of it
+    vecs[:50] = np.stack([opq.decode(c) for c in hit])
+    got = pq.encode_all(vecs)
+    assert np.array_equal(got, opq.encode_all(vecs)) and int(got.max()) < k
+    codes = rng.integers(0, k, (3000, M)).astype(np.uint8)
+    queries = rng.standard_normal((3, D)).astype(np.float32)
+    cv = J.PQVectors(ctx, pq, codes)
+    for vsf in ALL_VSF:
+        sf = cv.precomputed_score_function_for(queries, vsf)
+        got_sc = sf.similarity_to_range(0, len(codes))
+        for q in range(3):
+            assert np.array_equal(got_sc[q], opq.adc_scores(queries[q], int(vsf), codes)), (vsf, q)
+    # the wire format carries the caller's cluster count and codebooks, not the padding
+    blob = pq.write()
+    pq2 = J.ProductQuantization.load(ctx, blob)
+    assert pq2.get_cluster_count() == k and np.array_equal(pq2.encode_all(vecs[:300]), got[:300])
+    assert np.array_equal(pq.self_magnitudes(), opq.cache_self_magnitudes())
+    with pytest.raises(ValueError):           # FusedPQ requires 256 clusters: IllegalArgumentException (FusedPQ.java:57-59)
+        J.FusedPQ(ctx, pq, np.zeros((4, 2 * M), np.uint8), np.zeros((4, 2), np.int32))
+
+
 def test_encode_ties_and_nan(ctx):
     # strict '<' keeps the FIRST minimum; NaN distances never win (ProductQuantization.java:507-520)
     cb = np.full((256, 2), 5.0, np.float32)
@@ -460,8 +494,8 @@ def test_error_behaviour(ctx):
     rng = np.random.default_rng(1)
     with pytest.raises(ValueError):  # M > D: IllegalArgumentException (ProductQuantization.java:536-538)
         J.ProductQuantization.from_codebooks(ctx, 4, 5, np.zeros(256 * 4, np.float32))
-    with pytest.raises(J.UnsupportedError):
-        J.ProductQuantization.from_codebooks(ctx, 8, 2, np.zeros(128 * 8, np.float32), cluster_count=128)
+    with pytest.raises(J.UnsupportedError):  # more than one byte's worth of clusters (ProductQuantization.checkClusterCount)
+        J.ProductQuantization.from_codebooks(ctx, 8, 2, np.zeros(300 * 8, np.float32), cluster_count=300)
     pq, _ = make_pq(ctx, rng, 16, 4)
     with pytest.raises(ValueError):  # dimension mismatch (VectorUtil.java:46-48)
         pq.encode_all(np.zeros((3, 15), np.float32))

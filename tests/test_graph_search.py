@@ -497,6 +497,35 @@ def test_rows_wider_than_a_wavefront(ctx):
     run_wide_rows(J, ctx)
 
 
+def run_small_cluster_count(J, ctx, D=64, M=8, k=40, N=1500):
+    """a quantizer with fewer than 256 clusters (kept padded on the device side) under the graph searchers: host and device
+    traversal, PQVectors codes (FusedPQ needs 256 clusters, as in the reference) == the oracle working with the true count"""
+    VSF = J.VectorSimilarityFunction
+    v, lv, entry, entry_level, cb256, q = build_problem(k + D, N=N, D=D, M=M, deg=16, levels=2)
+    sizes, _ = O.subvector_sizes_offsets(D, M)
+    cb = np.concatenate([cb256[256 * int(sizes[:m].sum()): 256 * int(sizes[:m].sum()) + k * int(sizes[m])] for m in range(M)])
+    opq = O.OraclePQ(D, M, cb, k=k)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb, cluster_count=k)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, len(v))
+    assert np.array_equal(codes, opq.encode_all(v)) and int(codes.max()) < k
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    for traversal in ("host", "device"):
+        graph = J.GraphIndex(ctx, len(v), lv, entry, entry_level).set_traversal(traversal)
+        for vsf in VSF:
+            s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
+            ids, sc, stats = s.search(q, vsf, 10, 40, return_stats=True)
+            wi, ws, wst = og.search(opq, codes, v, q, int(vsf), 10, 40, fused=False)
+            assert np.array_equal(stats, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (traversal, vsf)
+            s.close()
+        graph.close()
+
+
+def test_graph_search_with_fewer_than_256_clusters(ctx):
+    run_small_cluster_count(J, ctx)
+
+
 def test_searcher_object_errors(ctx):
     v, lv, entry, entry_level, cb, q = build_problem(3, N=500, D=64, M=8, deg=8, levels=1)
     pq = J.ProductQuantization.from_codebooks(ctx, 64, 8, cb)

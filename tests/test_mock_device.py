@@ -63,6 +63,8 @@ def test_parity_suite_host_logic(J, ctx, golden_dir):
     import test_gpu_parity as T
     T.test_encode_bit_exact(ctx, 10, 3, False)
     T.test_encode_ties_and_nan(ctx)
+    T.test_cluster_counts_below_256(ctx, 64, 8, 16)
+    T.test_cluster_counts_below_256(ctx, 100, 7, 50)
     T.test_perfect_reconstruction(ctx)
     T.test_luts_bit_exact(ctx, 10, 3, True)
     T.test_adc_scan_bit_exact(ctx, 128, 16, 20000)
@@ -476,6 +478,11 @@ def test_rows_wider_than_a_wavefront_on_the_mock(J, ctx):
     """degree 72 / 96 / 130 graphs: the traversal body's chunk loop on the lane emulator, the host searcher's multi-word masks"""
     import test_graph_search as T
     T.run_wide_rows(J, ctx, N=500, nq=4)
+
+
+def test_small_cluster_count_on_the_mock(J, ctx):
+    import test_graph_search as T
+    T.run_small_cluster_count(J, ctx, N=600)
 
 
 def test_generic_pq_shapes_on_the_mock(J, ctx):
