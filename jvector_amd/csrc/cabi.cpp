@@ -423,8 +423,23 @@ int jv_hip_ctx_reset_stats(jv_ctx *ctx)
 // ------------------------------------------------------------------------------------------------
 // ProductQuantization
 // ------------------------------------------------------------------------------------------------
+}  // extern "C"
+namespace jv {
+// jv_hip_pq_create with the choice of keeping a quantizer of fewer than 256 clusters UNPADDED: the training kernels (KmParams::k)
+// work on such a k-row layout; everything else needs the padded form (pad = true, what the C entry point does)
+int pq_create_impl(jv_ctx *ctx, int D, int M, int k, const int *sizes, const float *codebooks, const float *centroid, bool pad,
+                   jv_pq **out);
+}  // namespace jv
+extern "C" {
 int jv_hip_pq_create(jv_ctx *ctx, int D, int M, int k, const int *sizes, const float *codebooks, const float *centroid,
                      jv_pq **out)
+{
+    return jv::pq_create_impl(ctx, D, M, k, sizes, codebooks, centroid, true, out);
+}
+}  // extern "C"
+namespace jv {
+int pq_create_impl(jv_ctx *ctx, int D, int M, int k, const int *sizes, const float *codebooks, const float *centroid, bool pad,
+                   jv_pq **out)
 {
     clear_error();
     JV_REQUIRE(ctx && out && codebooks, "pq_create: NULL argument");
@@ -440,7 +455,7 @@ int jv_hip_pq_create(jv_ctx *ctx, int D, int M, int k, const int *sizes, const f
     JV_TRY(use_device(ctx->device));
     const int k_user = k;
     std::vector<float> padded;
-    if (k_user < kClusters) {
+    if (k_user < kClusters && pad) {
         // rows k_user..255 of every codebook = copies of its row 0 (jv_pq::k_user): the device side only ever sees 256-row codebooks
         std::vector<int> sz((size_t)M);
         size_t total = 0;
@@ -533,6 +548,8 @@ int jv_hip_pq_create(jv_ctx *ctx, int D, int M, int k, const int *sizes, const f
     *out = pq;
     return JV_OK;
 }
+}  // namespace jv
+extern "C" {
 
 int jv_hip_pq_load(jv_ctx *ctx, const uint8_t *buf, size_t len, size_t *consumed, jv_pq **out)
 {

@@ -377,6 +377,8 @@ struct GsParams;
 // stage the queries of a batch (raw copy, centred copy, cosine query magnitudes); with_tables also builds the ADC look-up
 // tables (jv_hip_luts_build = with_tables true).  The table-free traversal kernels pass false: 96 KB per query saved.
 int luts_prepare(jv_ctx *ctx, jv_luts *l, const float *queries, int Q, jv_vsf vsf, jv_decoder_kind kind, bool with_tables);
+// jv_hip_pq_create; pad = false keeps a quantizer of fewer than 256 clusters in its k-row layout (training work objects only)
+int pq_create_impl(jv_ctx *ctx, int D, int M, int k, const int *sizes, const float *codebooks, const float *centroid, bool pad, jv_pq **out);
 bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused, int max_degree, int n_levels);
 bool graph_search_device_specialised(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused);  // else: the generic kernels
 size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap = 0, int v1_log2 = 0);

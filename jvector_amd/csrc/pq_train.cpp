@@ -138,14 +138,15 @@ int jv_hip_pq_train_anisotropic(jv_ctx *ctx, const float *vectors, int64_t n, in
     JV_REQUIRE(n >= k, "Cannot train PQ with %d clusters on %lld points, supply more training vectors or lower cluster count.", k,
                (long long)n);
     JV_REQUIRE((D + M - 1) / M <= 64, "pq_train: sub-vectors longer than 64 dimensions are not supported");
-    if (k != kClusters) {  // (a PQ with fewer clusters can be LOADED / created from codebooks and used; it is not trained here)
-        set_error("pq_train: clusterCount %d unsupported by the training kernels (256 only)", k);
+    JV_REQUIRE(k >= 1 && k <= kClusters, "pq_train: clusterCount %d outside 1..256", k);  // ProductQuantization.checkClusterCount
+    if (aniso && k != kClusters) {  // (the padded rows of the finished quantizer would take part in anisotropic encoding)
+        set_error("pq_train: anisotropic training needs 256 clusters here (clusterCount %d)", k);
         return JV_ERR_UNSUPPORTED;
     }
     JV_TRY(use_device(ctx->device));
     PqGuard work;
     std::vector<float> zeros((size_t)k * D, 0.0f);
-    JV_TRY(jv_hip_pq_create(ctx, D, M, k, nullptr, zeros.data(), nullptr, &work.pq));
+    JV_TRY(pq_create_impl(ctx, D, M, k, nullptr, zeros.data(), nullptr, false, &work.pq));  // (k-row work layout: KmParams::k)
     DevBuf cen;
     if (globally_center) JV_TRY(cen.alloc(sizeof(float) * (size_t)D));
     JV_TRY(run_training(ctx, work.pq, vectors, n, nullptr, globally_center != 0, (float *)cen.p, true, 6 /* K_MEANS_ITERATIONS */, seed,
@@ -159,10 +160,7 @@ int jv_hip_pq_refine(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t
     JV_REQUIRE(ctx && pq && vectors && out, "pq_refine: NULL argument");
     *out = nullptr;
     JV_REQUIRE(lloyds_rounds >= 0, "lloydsRounds must be non-negative");  // ProductQuantization.refine :205-207
-    if (pq->k_user != kClusters) {
-        set_error("pq_refine: clusterCount %d != 256 is not supported by the training kernels", pq->k_user);
-        return JV_ERR_UNSUPPORTED;
-    }
+
     JV_REQUIRE(n > 0, "pq_refine: no training vectors");
     JV_REQUIRE(pq->max_size <= 64, "pq_refine: sub-vectors longer than 64 dimensions are not supported");
     const bool aniso = pq->aniso > -1.0f;  // refine :212-214: cluster(aniso ? 0 : rounds, aniso ? rounds : 0)
@@ -170,10 +168,18 @@ int jv_hip_pq_refine(jv_ctx *ctx, const jv_pq *pq, const float *vectors, int64_t
                "pq_refine: anisotropic k-means supports sub-vectors of 2..%d dimensions", KM_ANISO_MAX_LEN);
     JV_TRY(use_device(ctx->device));
     PqGuard work;
-    std::vector<float> cb((size_t)pq->k * pq->D);
+    std::vector<float> cb((size_t)pq->k_user * pq->D);
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    JV_HIP_CHECK(hipMemcpy(cb.data(), pq->d_codebooks, sizeof(float) * cb.size(), hipMemcpyDeviceToHost));
-    JV_TRY(jv_hip_pq_create(ctx, pq->D, pq->M, pq->k, pq->sizes.data(), cb.data(), nullptr, &work.pq));
+    {
+        size_t so = 0, po = 0;
+        for (int m = 0; m < pq->M; ++m) {  // the caller's clusters: the first k_user of every codebook's 256 device rows
+            const size_t S = (size_t)pq->sizes[(size_t)m];
+            JV_HIP_CHECK(hipMemcpy(cb.data() + so, pq->d_codebooks + po, sizeof(float) * S * (size_t)pq->k_user, hipMemcpyDeviceToHost));
+            so += S * (size_t)pq->k_user;
+            po += S * (size_t)pq->k;
+        }
+    }
+    JV_TRY(pq_create_impl(ctx, pq->D, pq->M, pq->k_user, pq->sizes.data(), cb.data(), nullptr, false, &work.pq));
     JV_TRY(run_training(ctx, work.pq, vectors, n, pq->d_centroid, false, nullptr, false, aniso ? 0 : lloyds_rounds, seed,
                         aniso ? lloyds_rounds : 0, pq->aniso));
     return finish(ctx, work.pq, pq->d_centroid, pq->aniso, out);

@@ -213,6 +213,12 @@ def test_training_entry_points(J, ctx, D, M, center):
     T.test_train_refine_write(ctx, D, M, center)
 
 
+def test_training_with_fewer_clusters_on_the_mock(J, ctx):
+    import test_zz_pq_train_gpu as T
+    T.test_train_with_fewer_than_256_clusters(ctx, 32, 4, 16, True)
+    T.test_train_with_fewer_than_256_clusters(ctx, 26, 3, 50, False)
+
+
 def test_anisotropic_training_entry_points(J, ctx):
     import test_zz_pq_train_gpu as T
     T.test_anisotropic_training(ctx)

@@ -47,6 +47,29 @@ def test_train_refine_write(ctx, D, M, center):
         J.ProductQuantization.compute(ctx, v[:100], M)   # fewer points than clusters
 
 
+@pytest.mark.parametrize("D,M,k,center", [(32, 4, 16, True), (26, 3, 50, False), (64, 8, 255, False)])
+def test_train_with_fewer_than_256_clusters(ctx, D, M, k, center):
+    """ProductQuantization.compute / refine with clusterCount < 256 (the reference's own tests train 16 and 50 clusters): the
+    training kernels work on a k-row layout, the finished quantizer is padded on the device side; codebooks, wire form and codes ==
+    the oracle trained with the same count"""
+    v = data(4000, D, D + k)
+    want, _ = O.pq_train(v, M, k=k, globally_center=center, seed=5)
+    pq = J.ProductQuantization.compute(ctx, v, M, cluster_count=k, globally_center=center, seed=5)
+    assert pq.get_cluster_count() == k
+    blob = pq.write(6)
+    assert blob == want.serialize(6)
+    codes = pq.encode_all(v[:300])
+    assert np.array_equal(codes, want.encode_all(v[:300])) and int(codes.max()) < k
+    x = data(2500, D, D + k + 1)
+    want2 = want.refine(x, 2, seed=3)
+    pq2 = pq.refine(x, 2, seed=3)
+    assert pq2.get_cluster_count() == k and pq2.write(6) == want2.serialize(6)
+    with pytest.raises(ValueError):
+        J.ProductQuantization.compute(ctx, v[: k - 1], M, cluster_count=k)   # fewer points than clusters (:119-121)
+    with pytest.raises(J.UnsupportedError):
+        J.ProductQuantization.compute(ctx, v, M, cluster_count=k, anisotropic_threshold=0.2)
+
+
 def test_anisotropic_training(ctx):
     """compute / refine with an anisotropic threshold: unweighted + anisotropic k-means rounds == the oracle, bit for bit"""
     v = data(4000, 32, 77)
