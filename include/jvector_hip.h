@@ -41,7 +41,7 @@ typedef enum {
     JV_ERR_NO_DEVICE = -2,    /* no usable gfx950 device / HIP runtime */
     JV_ERR_HIP = -3,          /* a HIP runtime call failed; see jv_hip_last_error() */
     JV_ERR_OOM = -4,          /* device or pinned-host allocation failed */
-    JV_ERR_UNSUPPORTED = -5   /* e.g. clusterCount > 256, training with clusterCount != 256, NVQ bit widths other than 8 */
+    JV_ERR_UNSUPPORTED = -5   /* e.g. clusterCount > 256, anisotropic PQ with clusterCount != 256, NVQ bit widths other than 8 */
 } jv_status;
 
 /* VectorSimilarityFunction ordinals — B/vector/VectorSimilarityFunction.java:34-69 */
@@ -120,7 +120,8 @@ JV_API int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *tota
  * centroid: globalCentroid (D floats) or NULL.  k = clusterCount, 1..256 (ProductQuantization.checkClusterCount; one code byte).
  * A quantizer with fewer than 256 clusters is kept padded to 256 rows per sub-space with copies of centroid 0 (never chosen:
  * closestCentroidIndex keeps the first minimum), so every kernel keeps its table stride; jv_hip_pq_info / _write /
- * _self_magnitudes speak the caller's count.  FusedPQ (FusedPQ.java:57-59), anisotropic encoding and training need 256.
+ * _self_magnitudes speak the caller's count.  jv_hip_pq_train / _refine train with the caller's count; FusedPQ
+ * (FusedPQ.java:57-59) and anisotropic training / encoding need 256.
  * ------------------------------------------------------------------------------------------- */
 JV_API int jv_hip_pq_create(jv_ctx *ctx, int D, int M, int k, const int *sizes, const float *codebooks,
                             const float *centroid, jv_pq **out);
