@@ -450,7 +450,7 @@ def test_generic_pq_shapes_on_the_device_traversal(ctx):
     run_generic_shapes(J, ctx)
 
 
-def run_wide_rows(J, ctx, shapes=((128, 16, 72), (64, 8, 130), (100, 12, 96)), N=900, nq=8):
+def run_wide_rows(J, ctx, shapes=((128, 16, 72), (64, 8, 130), (100, 12, 96)), N=900, nq=8, traversals=("device", "host")):
     """adjacency rows wider than a wavefront (the reference's M grid goes to 128): the traversal kernels and the frontier kernels
     walk such a row 64 neighbours at a time.  Host and device traversal, fused and not, plain searches and a GraphSearcher object
     with a threshold + resume == the oracle"""
@@ -465,7 +465,7 @@ def run_wide_rows(J, ctx, shapes=((128, 16, 72), (64, 8, 130), (100, 12, 96)), N
         cv = J.PQVectors.encode_and_build(ctx, pq, vs)
         codes = cv.get(0, n)
         og = O.OracleGraph(n, lv, entry, entry_level)
-        for traversal in ("device", "host"):
+        for traversal in traversals:
             graph = J.GraphIndex(ctx, n, lv, entry, entry_level).set_traversal(traversal)
             for use_fused in (True, False):
                 fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
@@ -497,7 +497,7 @@ def test_rows_wider_than_a_wavefront(ctx):
     run_wide_rows(J, ctx)
 
 
-def run_small_cluster_count(J, ctx, D=64, M=8, k=40, N=1500):
+def run_small_cluster_count(J, ctx, D=64, M=8, k=40, N=1500, traversals=("host", "device")):
     """a quantizer with fewer than 256 clusters (kept padded on the device side) under the graph searchers: host and device
     traversal, PQVectors codes (FusedPQ needs 256 clusters, as in the reference) == the oracle working with the true count"""
     VSF = J.VectorSimilarityFunction
@@ -511,7 +511,7 @@ def run_small_cluster_count(J, ctx, D=64, M=8, k=40, N=1500):
     codes = cv.get(0, len(v))
     assert np.array_equal(codes, opq.encode_all(v)) and int(codes.max()) < k
     og = O.OracleGraph(len(v), lv, entry, entry_level)
-    for traversal in ("host", "device"):
+    for traversal in traversals:
         graph = J.GraphIndex(ctx, len(v), lv, entry, entry_level).set_traversal(traversal)
         for vsf in VSF:
             s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
