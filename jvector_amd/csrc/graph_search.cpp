@@ -1307,10 +1307,26 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // M >= 128: the pair form's two half rows + exchange indices no longer fit 256 VGPRs (156 / 588 bytes of scratch per
     // lane at M = 128 / 192, -Rpass-analysis=kernel-resource-usage) while the one-lane-per-neighbour form still does
     pair = pair && pq->M <= 96;
-    const int pair_M = pair ? pq->M : 0;
+    // gs_wgx = 1: the WORKGROUP form (gx_body.h, k_gsearch_wgx.hip) — one query per workgroup / CU, the query's ADC table in LDS
+    // (M <= 128), a control wave + expander waves that score adjacency rows ahead of time; plain searches, degrees <= 64
+    bool wgx = !so && !generic && !lutr && ctx_opt(ctx, "gs_wgx", 0) != 0 && graph_search_wgx_supported(pq->M);
+    for (int lv = 0; lv <= g->entry_level; ++lv) wgx = wgx && g->levels[lv].degree <= 64;
+    int wgx_kps = 32;
+    for (int lv = 0; lv <= g->entry_level; ++lv)
+        if (g->levels[lv].degree > 32) wgx_kps = 64;
+    const int wgx_waves = std::max(2, std::min(8, (int)ctx_opt(ctx, "gs_wgx_waves", 8)));
+    const int wgx_slots = std::max(2, std::min((int)GX_MAX_SLOTS, (int)ctx_opt(ctx, "gs_wgx_slots", 16)));
     int evict_cap = GS_EVICT_CAP;
-    int cand_cap = std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", lutr ? 256 : (occ == 4 ? 512 : (pair ? 256 : 1024)))) & ~63;
-    while (cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
+    int wgx_cand_cap = std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", 512)) & ~63;
+    if (wgx) {   // the table + the queues must fit the CU's LDS (a large rerankK or M = 128 may need the smaller candidate tier)
+        auto fits = [&](int cc) { return graph_search_wgx_lds_bytes(pq->D, rerankK, cc, evict_cap, 0, wgx_slots, wgx_kps, pq->M) + 2048 <= ctx->lds_per_block; };
+        if (!fits(wgx_cand_cap) && !ctx_opt_is_set(ctx, "gs_cand_cap")) wgx_cand_cap = 256;
+        wgx = fits(wgx_cand_cap);
+    }
+    if (wgx) pair = false;
+    const int pair_M = pair ? pq->M : 0;
+    int cand_cap = wgx ? wgx_cand_cap : std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", lutr ? 256 : (occ == 4 ? 512 : (pair ? 256 : 1024)))) & ~63;
+    while (!wgx && cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
     // Visited set, tier 1 (gs_body.h gs_visit1): a two-choice bucketed LDS table of 16-bit entries in whatever the other
     // per-worker structures leave of 160 KB / (4 x occ workers per CU).  Preference: the largest table first (4096 slots = 8 KB
     // hold ~3900 nodes: all but the longest searches of the headline workload, median ~2200 visited nodes), giving up
@@ -1322,7 +1338,18 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const size_t lut_lds = lutr ? gs_lutr_lds_bytes(pq->M) : (so ? gs_session_lds_bytes() : 0);  // (session kernels: the tracker's arrays)
     const size_t lds_budget = (160 * 1024) / (size_t)want_per_cu - 256 - lut_lds;
     int v1_log2 = 0;
-    {
+    if (wgx) {
+        // the workgroup owns the CU's LDS: the largest tier that fits next to the table (16384 slots hold every search of the
+        // headline workload: p99.9 of the visited count is 4.8 k)
+        const long long pin = ctx_opt(ctx, "gs_v1_log2", ctx_opt_is_set(ctx, "gs_vcap_log2") ? 0 : -1);
+        for (int lg = pin > 0 ? (int)pin : 14; lg >= (pin > 0 ? (int)pin : 8) && pin != 0; --lg) {
+            if (!gs_v1_fits(lg, idbits)) continue;
+            if (graph_search_wgx_lds_bytes(pq->D, rerankK, cand_cap, evict_cap, lg, wgx_slots, wgx_kps, pq->M) + 512 <= ctx->lds_per_block) {
+                v1_log2 = lg;
+                break;
+            }
+        }
+    } else {
         // (a pinned gs_vcap_log2 is how tests drive the overflow paths of tier 2: no LDS tier in front of it then, unless asked for)
         const long long pin = ctx_opt(ctx, "gs_v1_log2", ctx_opt_is_set(ctx, "gs_vcap_log2") ? 0 : -1);
         struct Caps { int cand, evict; };
@@ -1346,7 +1373,8 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
             }
         }
     }
-    const size_t lds = graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap, v1_log2) + lut_lds;
+    const size_t lds = wgx ? graph_search_wgx_lds_bytes(pq->D, rerankK, cand_cap, evict_cap, v1_log2, wgx_slots, wgx_kps, pq->M)
+                           : graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap, v1_log2) + lut_lds;
     if (lds > ctx->lds_per_block) {
         set_error("graph_search(device): rerankK %d needs %zu bytes of LDS per wave (limit %zu); use the host traversal", rerankK,
                   lds, ctx->lds_per_block);
@@ -1354,6 +1382,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     }
     int per_cu = (int)std::min<size_t>((size_t)want_per_cu, std::max<size_t>(1, (160 * 1024) / (lds + 256)));
     per_cu = std::max(1, (int)ctx_opt(ctx, "gs_waves_per_cu", per_cu));
+    if (wgx) per_cu = 1;
     const int workers = std::max(1, std::min(Q, ctx->num_cus * per_cu));
     // JVECTOR_HIP_GS_VCAP_LOG2 overrides the visited-table size (tests use a tiny table to drive the host fallback)
     const int vcap_log2 = std::max(8, std::min(24, (int)ctx_opt(ctx, "gs_vcap_log2", gs_vcap_log2(rerankK))));
@@ -1463,6 +1492,16 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.v1_idbits = idbits;
     p.prefetch = (ctx_opt(ctx, "gs_prefetch", 0) != 0 && evict_cap >= 48 && !generic) ? 1 : 0;  // (dword touches: aligned rows only)
     p.lutr = lutr ? 1 : 0;
+    if (wgx) {
+        p.prefetch = 0;
+        p.wgx = 1;
+        p.wgx_slots = wgx_slots;
+        p.wgx_kps = wgx_kps;
+        p.wgx_depth = (int)ctx_opt(ctx, "gs_wgx_depth", 1);
+    }
+    auto launch = [&](const GsParams &pp, int w) -> int {
+        return wgx ? launch_graph_search_wgx(ctx->stream, kvsf, pp, w, 64 * wgx_waves) : launch_graph_search(ctx->stream, kvsf, pp, w, occ);
+    };
     if (so) {
         p.session = 1;
         p.threshold = so->threshold;
@@ -1522,7 +1561,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.prof = gs_prof ? (unsigned long long *)(base + o_prof) : nullptr;
     {
         ProfScope ps(ctx, R_GSEARCH);
-        JV_TRY(launch_graph_search(ctx->stream, kvsf, p, workers, occ));
+        JV_TRY(launch(p, workers));
     }
     // ---- queries that outgrew the fixed-size structures (visited table half full, spill / evicted list full): run them
     //      again on the device with a visited table 8x, then 64x the size (few queries -> few, roomy workers); whatever
@@ -1567,7 +1606,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p2.prof = nullptr;
         {
             ProfScope ps(ctx, R_GSEARCH);
-            JV_TRY(launch_graph_search(ctx->stream, kvsf, p2, workers2, occ));
+            JV_TRY(launch(p2, workers2));
         }
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // h_out is reused below
         JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_status, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
@@ -1587,6 +1626,10 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
                         "queries %llu  setup+epilogue clocks/query %.0f\n", h[0] / e, h[1] / e, h[2] / e, h[3] / e, h[4] / e, h[5], h[6],
                 (double)h[7] / (double)std::max<unsigned long long>(h[6], 1));
         const double fs = (double)std::max<unsigned long long>(h[8] + h[9] + h[10] + h[11], 1);
+        if (wgx)
+            fprintf(stderr, "[jv gs prof] workgroup form, per expansion: row found in a slot %.3f (of those still being scored at use: %.3f of all)  "
+                            "requested at the pop %.3f  rows requested ahead %.3f\n", h[8] / e, h[9] / e, h[10] / e, h[11] / e);
+        else
         fprintf(stderr, "[jv gs prof] scored neighbours by fresh count of their expansion: <=8 %.3f  <=16 %.3f  <=24 %.3f  <=32 %.3f\n", h[8] / fs,
                 h[9] / fs, h[10] / fs, h[11] / fs);
     }
@@ -1688,9 +1731,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     ctx_stat_add(ctx, "gs_queries_host_fallback", (long long)redo.size());
     ctx_stat_set(ctx, "gs_last_v1_log2", v1_log2);
     ctx_stat_set(ctx, "gs_last_workers_per_cu", per_cu);
+    ctx_stat_set(ctx, "gs_last_wgx", wgx ? 1 : 0);
+    if (wgx) ctx_stat_add(ctx, "gs_calls_wgx", 1);
     if (ctx_opt(ctx, "graph_timing", 0) != 0)
-        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d) lds=%zu cand_cap=%d evict_cap=%d v1_log2=%d vcap=%zu overflow=%zu rerank ties=%zu (+%zu to the host) -> host %zu\n", Q,
-                workers, per_cu, occ, (int)pair, lds, cand_cap, evict_cap, v1_log2, vcap, n_overflow_first, n_ties_resolved, n_ties, redo.size());
+        fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d, wgx %d) lds=%zu cand_cap=%d evict_cap=%d v1_log2=%d vcap=%zu overflow=%zu rerank ties=%zu (+%zu to the host) -> host %zu\n", Q,
+                workers, per_cu, occ, (int)pair, wgx ? wgx_waves : 0, lds, cand_cap, evict_cap, v1_log2, vcap, n_overflow_first, n_ties_resolved, n_ties, redo.size());
     if (redo.empty()) return JV_OK;
 
     // ---- queries that outgrew the fixed-size device structures: same search on the host ----

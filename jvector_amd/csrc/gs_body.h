@@ -19,6 +19,13 @@
 //     gs_fence()                              device-scope memory fence
 //     gs_sqrt(double)
 //     GS_SCHED_FENCE()                        instruction-scheduling fence (may be empty)
+// and, for the workgroup form (WGX, gx_body.h — several wavefronts per query; gs_barrier() is then a WAVE-scope sync point):
+//     gs_tid()                                thread index inside the workgroup
+//     gs_block_barrier()                      workgroup barrier
+//     gs_lds_load(const int32_t *p)           LDS flag read, acquire at workgroup scope
+//     gs_lds_store(int32_t *p, int32_t v)     LDS flag write, release at workgroup scope
+//     gs_lds_add(int32_t *p, int32_t v) -> old   LDS atomic add
+//     gs_spin_pause()                         inside a spin-wait on an LDS flag (s_sleep / a scheduling point of the emulator)
 //
 // What it computes is GraphSearcher.search for threshold 0 / acceptOrds ALL (B/graph/GraphSearcher.java:222-243,
 // 263-282 internalSearch, 334-353 initializeInternal, 355-369 stopSearch, 406-457 searchOneLayer, 324-331
@@ -82,6 +89,8 @@ GS_FN float gs_key_score(long long k)
 
 constexpr long long GS_KEY_MIN = (long long)0x8000000000000000ull;
 constexpr long long GS_KEY_MAX = (long long)0x7fffffffffffffffull;
+// "no neighbour in this lane" in a scored row of the workgroup form: a real key's low word is ~node with node >= 0, never 0
+constexpr long long GX_KEY_NONE = 0;
 
 GS_FN long long gs_wave_max(long long v)
 {
@@ -337,6 +346,29 @@ GS_FN float gs_row_sum_lut(const float (&lut)[(CH16 * 16 < GS_LUT_REG_SUB ? CH16
                 } else {
                     sum += lut_lds[(m - MR) * 256 + (int)code];
                 }
+            }
+        }
+    }
+    return sum;
+}
+
+// ---- the workgroup form's score: the query's whole ADC table [M][256] f32 sits in LDS (gx_body.h gx_lut_build wrote it with
+//      gs_lut_entry's arithmetic: calculatePartialSums entry by entry); a row's score is assembleAndSum (:323-330): the entries
+//      its code bytes select, added in ascending m into one f32.
+template <int CH16>
+GS_FN float gx_row_sum(const float *lut, const gs_u4 (&w)[CH16])
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CH16; ++c) {
+        const uint32_t d[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int m = c * 16 + e * 4 + b;
+                const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
+                sum += lut[m * 256 + (int)code];
             }
         }
     }
@@ -629,14 +661,20 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 // PROF: developer aid — per-phase shader-clock totals of the expansion loop are added to p.prof[0..7]
 //       (pop, result insert, row + block + visited probes, scoring, push, expansions, queries, setup + epilogue)
 // LUTR: the query's ADC table lives in registers (gs_lut_build / gs_row_sum_lut; one lane per neighbour, PAIR must be false)
+// WGX:  the workgroup form (gx_body.h): this function is the CONTROL wave (wave 0 of the workgroup).  The query's ADC table is in
+//       LDS (built by all waves before the call); an expansion does not score anything itself — it takes the popped node's
+//       scored adjacency row (one NodeQueue key per neighbour) from a slot an expander wave filled, requested right after the pop
+//       or, for the likely next candidates, one or more iterations ahead.  A scored row is a pure function of (node, level), so
+//       requesting rows that are never consumed cannot change a result.  gs_barrier() is a wave-scope sync point in this form.
 // SES:  GraphSearcher OBJECTS (jv_hip_searcher_*): layer 0 admits `score >= p.threshold` (:437) and, for threshold > 0, stops
 //       through ScoreTracker.TwoPhaseTracker (ScoreTracker.java:80-140: a 500-score window + the 100 best scores, both in LDS);
 //       expandedCountBaseLayer is reported.  What reranking / resume need beyond that is rebuilt by the host from the
 //       addTopCandidate log (graph_search.cpp searcher_search_device).
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool WGX = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
     static_assert(!(LUTR && PAIR), "the register-resident table serves the one-lane-per-neighbour form");
+    static_assert(!WGX || (CH16 > 0 && !PAIR && !LUTR && !SES), "the workgroup form: specialised shapes, plain searches");
     static_assert(CH16 > 0 || !(LUTR || PAIR), "the generic form (CH16 = 0) is one lane per neighbour, table-free");
     constexpr int CW = CH16 > 0 ? CH16 : 1;  // code words a lane holds (the generic form reads its row from memory instead)
     constexpr int LUT_MR = CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB;
@@ -731,6 +769,68 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     };
     long long n_visited = 0, n_expanded = 0;
 
+    // ---- WGX: the scored-row slots shared with the expander waves (layout: gs_params.h gx_off_*).  Slot t is managed by lane t:
+    //      gx_node / gx_lvl / gx_ckey are PER-LANE registers (the (node, level) slot t holds, -1 = free; the candidate key it was
+    //      requested for, which decides evictions); everything else here is wave-uniform.
+    int32_t *gx_hdr = nullptr, *gx_ring = nullptr, *gx_slot_node = nullptr, *gx_slot_lvl = nullptr, *gx_slot_state = nullptr;
+    long long *gx_keys = nullptr;
+    const float *gx_lut = nullptr;
+    int32_t gx_node = -1, gx_lvl = 0;
+    long long gx_ckey = 0;
+    int gx_tail = 0;
+    if constexpr (WGX) {
+        char *sh = lds + gx_ctl_bytes(p.D, p.rerankK, p.cand_cap, evict_cap, p.v1_log2);
+        gx_hdr = reinterpret_cast<int32_t *>(sh);
+        gx_ring = reinterpret_cast<int32_t *>(sh + gx_off_ring());
+        gx_slot_node = reinterpret_cast<int32_t *>(sh + gx_off_slot_node());
+        gx_slot_lvl = reinterpret_cast<int32_t *>(sh + gx_off_slot_lvl());
+        gx_slot_state = reinterpret_cast<int32_t *>(sh + gx_off_slot_state());
+        gx_keys = reinterpret_cast<long long *>(sh + gx_off_keys());
+        gx_lut = reinterpret_cast<const float *>(sh + gx_off_lut(p.wgx_slots, p.wgx_kps));
+    }
+    // slot holding (node, level), or -1
+    auto gx_find = [&](int32_t node, int lvl) -> int {
+        const uint64_t m = gs_ballot(lane < p.wgx_slots && gx_node == node && gx_lvl == lvl);
+        return m ? gs_first(m) : -1;
+    };
+    // Ask the expanders for the scored row of (node, level).  Returns the slot, or -1 when every slot is taken and the request is
+    // only speculative (!must).  must: the popped node itself — evicts the READY slot whose candidate is the worst (its row is
+    // simply requested again should that candidate ever be popped).
+    auto gx_post = [&](int32_t node, int lvl, long long ckey, bool must) -> int {
+        const uint64_t fm = gs_ballot(lane < p.wgx_slots && gx_node == -1);
+        int slot;
+        if (fm) {
+            slot = gs_first(fm);
+        } else if (!must) {
+            return -1;
+        } else {
+            uint64_t rm;
+            for (;;) {
+                rm = gs_ballot(lane < p.wgx_slots && gs_lds_load(gx_slot_state + lane) == GX_READY);
+                if (rm) break;
+                gs_spin_pause();
+            }
+            const bool mine = ((rm >> lane) & 1ull) != 0;
+            const long long mn = gs_wave_min(mine ? gx_ckey : GS_KEY_MAX);
+            slot = gs_first(gs_ballot(mine && gx_ckey == mn));
+        }
+        if (lane == slot) {
+            gx_node = node;
+            gx_lvl = lvl;
+            gx_ckey = ckey;
+        }
+        if (lane == 0) {
+            gx_slot_node[slot] = node;
+            gx_slot_lvl[slot] = lvl;
+            gx_slot_state[slot] = GX_REQUESTED;
+            gx_ring[gx_tail & (GX_RING - 1)] = slot;
+        }
+        gs_barrier();
+        gx_tail++;
+        if (lane == 0) gs_lds_store(gx_hdr + GX_REQ_TAIL, gx_tail);   // release: the expander that sees it sees the slot's fields
+        return slot;
+    };
+
     // tier 2 is cleared by the first probe that needs it (wave-uniform call)
     auto t2_init = [&]() {
         gs_u4 *v4 = reinterpret_cast<gs_u4 *>(vis);
@@ -766,7 +866,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             gs_u4 *v4 = reinterpret_cast<gs_u4 *>(vis);
             for (int i = lane; i < vcap / 4; i += 64) v4[i] = ones;
         }
-        if constexpr (CH16 == 0) {  // any D: rows of the query matrix need not be 16-byte aligned
+        if constexpr (WGX) {
+            // (gx_worker staged the query and built the table from it before this call)
+        } else if constexpr (CH16 == 0) {  // any D: rows of the query matrix need not be 16-byte aligned
             const float *src = p.cq + (int64_t)q * p.D;
             for (int i = lane; i < p.D; i += 64) qs[i] = src[i];
         } else {
@@ -802,6 +904,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             gs_u4 we[CW];
             gs_load_row<CW>(p.codes + (int64_t)e * p.M, we);
             if constexpr (LUTR) sc = gs_row_sum_lut<CW>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, we);
+            else if constexpr (WGX) sc = gx_row_sum<CW>(gx_lut, we);
             else sc = gs_row_sum<VSF, CW>(p.codebooks, qs, we);
         }
         sc = gs_finish<VSF>(sc, (VSF == 2) ? p.code_norms[e] : 0.0f, query_mag);
@@ -926,7 +1029,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             long long top, runner_up = GS_KEY_MIN;
             const bool from_lds = s.cand_n > 0;
             if (from_lds) {
-                if (p.prefetch && lvl == 0) top = gs_scan_top2(s.cand, s.cand_n, &idx, &runner_up);
+                if (WGX || (p.prefetch && lvl == 0)) top = gs_scan_top2(s.cand, s.cand_n, &idx, &runner_up);
                 else top = gs_scan_extreme<true>(s.cand, s.cand_n, &idx);
             } else {  // the LDS tier ran dry: the best candidate is somewhere in the spill tier
                 gs_fence();
@@ -962,6 +1065,20 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 else if (lane < row_lines + blk_lines) addr = reinterpret_cast<const char *>(p.blocks + (int64_t)rn * p.deg0 * p.M) + (lane - row_lines) * 128;
                 else if (VSF == 2 && p.blocks && lane == row_lines + blk_lines) addr = reinterpret_cast<const char *>(p.fused_norms + (int64_t)rn * p.deg0);
                 if (addr) gs_prefetch_lds(addr, reinterpret_cast<char *>(s.evicted) + 64);
+            }
+            // WGX: the popped node's scored row — normally requested one or more iterations ago; if not, now.  Then the row of the
+            // best remaining candidate (popped next unless a neighbour scored below beats it), so that the expanders work on it
+            // while this expansion's probes and pushes run.
+            int gx_slot = -1;
+            if constexpr (WGX) {
+                const int32_t tn = gs_key_node(top);
+                gx_slot = gx_find(tn, lvl);
+                if (PROF) fh[gx_slot < 0 ? 2 : 0] += 1;
+                if (gx_slot < 0) gx_slot = gx_post(tn, lvl, top, true);
+                if (p.wgx_depth > 0 && runner_up != GS_KEY_MIN && !(s.res_n >= rk && gs_key_score(runner_up) < gs_key_score(s.res_min))) {
+                    const int32_t rn = gs_key_node(runner_up);
+                    if (gx_find(rn, lvl) < 0 && gx_post(rn, lvl, runner_up, false) >= 0 && PROF) fh[3] += 1;
+                }
             }
             GS_PHASE(0);
             // threshold 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the results (the
@@ -1011,13 +1128,37 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 
             // ---- expand: visited.mark + score + candidates.push for every unvisited neighbour ----
             const int32_t node = gs_key_node(top);
-            const int32_t *row = gs_level_row(L, node);
+            // (WGX: the expander looks the row up — a node without one gets a row of GX_KEY_NONE)
+            const int32_t *row = WGX ? L.nbrs : gs_level_row(L, node);
             if (!row) continue;
             const int deg = L.degree;
             const bool fused0 = lvl == 0 && p.blocks != nullptr;
             long long key = 0;
             bool fresh = false;
-            if constexpr (PAIR) {
+            if constexpr (WGX) {
+                (void)row;
+                (void)deg;
+                (void)fused0;
+                // wait for the expander (no spin at all when the row was requested early enough)
+                if (PROF && gs_ballot(lane == 0 && gs_lds_load(gx_slot_state + gx_slot) != GX_READY)) fh[1] += 1;
+                while (!gs_ballot(lane == 0 && gs_lds_load(gx_slot_state + gx_slot) == GX_READY)) gs_spin_pause();
+                key = lane < p.wgx_kps ? gx_keys[gx_slot * p.wgx_kps + lane] : GX_KEY_NONE;
+                if (lane == gx_slot) gx_node = -1;   // the slot is free again (its keys are in registers now)
+                const bool valid = key != GX_KEY_NONE;
+                fresh = visit(valid, gs_key_node(key));
+                if (s.status != GS_OK) break;
+                const uint64_t fm = gs_ballot(fresh);
+                if (fm == 0) continue;
+                n_visited += gs_popc(fm);
+                GS_PHASE(2);
+                // the best fresh neighbour beats everything that is queued: it is popped next — its row cannot be asked for earlier
+                if (p.wgx_depth > 0) {
+                    const long long bf = gs_wave_max(fresh ? key : GS_KEY_MIN);
+                    if ((runner_up == GS_KEY_MIN || bf > runner_up) && !(s.res_n >= rk && gs_key_score(bf) < gs_key_score(s.res_min))) {
+                        if (gx_post(gs_key_node(bf), lvl, bf, false) >= 0 && PROF) fh[3] += 1;
+                    }
+                }
+            } else if constexpr (PAIR) {
                 // ---- pair-lane form: neighbour i is handled by lanes i (low) and i + 32 (high) ----
                 const int ni = lane & 31;
                 const bool hi = lane >= 32;
@@ -1163,6 +1304,13 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         }
         }
         if (s.status != GS_OK) break;
+        if constexpr (WGX) {
+            // rows requested for this level are of no use on the next one: let the expanders finish them, then free every slot
+            if (lvl > 0) {
+                while (gs_ballot(lane < p.wgx_slots && gx_node != -1 && gs_lds_load(gx_slot_state + lane) != GX_READY)) gs_spin_pause();
+                gx_node = -1;
+            }
+        }
         if (lvl > 0) {  // setEntryPointsFromPreviousLayer :324-331
             for (int base = 0; base < s.res_n && s.status == GS_OK; base += 64) {
                 const bool has = base + lane < s.res_n;
@@ -1179,6 +1327,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         }
     }
 
+    if constexpr (WGX) {   // the expanders leave their service loop (a request in flight is finished first; gx_worker's barrier waits)
+        if (lane == 0) gs_lds_store(gx_hdr + GX_QUIT, 1);
+    }
     // ---- hand the kept approximate results to the rerank stage ----
     gs_barrier();
     for (int i = lane; i < p.rerankK; i += 64) {

@@ -80,6 +80,12 @@ struct GsParams {
     int32_t prefetch;         // 1: touch the runner-up candidate's adjacency row + fused block while the popped one is scored (layer 0)
     int32_t v1_log2;          // log2(slots) of the LDS tier (slots / 4 buckets of four 16-bit entries), 0 = no LDS tier
     int32_t v1_idbits;        // node ids are < 1 << v1_idbits; v1_idbits - (v1_log2 - 2) <= 14 remainder bits + the choice bit
+    // the workgroup form (gx_body.h, k_gsearch_wgx.hip): ONE query per workgroup — the query's ADC table (M x 256 f32) lives in LDS,
+    // wave 0 runs the GraphSearcher loop and the other waves ("expanders") score whole adjacency rows it asks for ahead of time
+    int32_t wgx;              // 1: launch the workgroup form
+    int32_t wgx_slots;        // scored-row slots in LDS (<= 64)
+    int32_t wgx_kps;          // keys per slot: 32 or 64 (>= every level's degree)
+    int32_t wgx_depth;        // candidates below the popped one whose rows are requested ahead of time (0..3)
     // outputs
     int32_t *out_ids;         // [Q][rerankK] kept approximate results (unordered), -1 padded
     float *out_scores;        // [Q][rerankK] their approximate scores, -inf padded
@@ -120,6 +126,29 @@ inline int gs_idbits(long long n_nodes)
     int b = 1;
     while ((1ll << b) < n_nodes && b < 31) ++b;
     return b;
+}
+
+// ---- the workgroup form's LDS block: [the control wave's block = gs_lds_bytes(..., pair_M = 0, ...)] [header + ring + slot
+//      tables] [slot keys] [the ADC table].  Offsets in bytes from the start of the header.
+constexpr int GX_RING = 64;                 // request ring entries (>= slots: every request owns a slot)
+constexpr int GX_MAX_SLOTS = 64;
+enum : int32_t { GX_ITEM = 0, GX_REQ_HEAD = 1, GX_REQ_TAIL = 2, GX_QUIT = 3, GX_HDR_INTS = 8 };
+enum : int32_t { GX_FREE = 0, GX_REQUESTED = 1, GX_READY = 2 };
+constexpr size_t gx_off_ring() { return sizeof(int32_t) * GX_HDR_INTS; }
+constexpr size_t gx_off_slot_node() { return gx_off_ring() + sizeof(int32_t) * GX_RING; }
+constexpr size_t gx_off_slot_lvl() { return gx_off_slot_node() + sizeof(int32_t) * GX_MAX_SLOTS; }
+constexpr size_t gx_off_slot_state() { return gx_off_slot_lvl() + sizeof(int32_t) * GX_MAX_SLOTS; }
+constexpr size_t gx_off_keys() { return (gx_off_slot_state() + sizeof(int32_t) * GX_MAX_SLOTS + 15) & ~(size_t)15; }
+constexpr size_t gx_off_lut(int slots, int kps) { return (gx_off_keys() + sizeof(long long) * (size_t)slots * (size_t)kps + 15) & ~(size_t)15; }
+constexpr size_t gx_shared_bytes(int slots, int kps, int M) { return gx_off_lut(slots, kps) + sizeof(float) * 256 * (size_t)M; }
+// where the header starts inside the workgroup's LDS block
+constexpr size_t gx_ctl_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2)
+{
+    return (gs_lds_bytes(D, rerankK, cand_cap, 0, evict_cap, v1_log2) + 15) & ~(size_t)15;
+}
+constexpr size_t gx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int M)
+{
+    return gx_ctl_bytes(D, rerankK, cand_cap, evict_cap, v1_log2) + gx_shared_bytes(slots, kps, M);
 }
 
 // rerank tie resolution (rt_body.h / rerank_tie_kernel)

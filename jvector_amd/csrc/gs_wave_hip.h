@@ -8,10 +8,38 @@
 #define GS_FN __device__ __forceinline__
 #define GS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ int gs_lane() { return (int)threadIdx.x; }
+#ifdef GS_WAVE_SCOPE_BARRIER
+// the workgroup form (gx_body.h): gs_body.h runs in ONE wave of a larger workgroup, so its sync points are wave-scope — LDS
+// operations of a wave are performed in program order, what is needed is that the compiler neither moves nor caches accesses
+// across the point (the fences emit no instruction at this scope) and that the lanes have reconverged
+__device__ __forceinline__ void gs_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#else
 __device__ __forceinline__ void gs_barrier() { __syncthreads(); }
+#endif
 // multi-wave workgroups (ed_body.h): thread index inside the block and the workgroup barrier
 __device__ __forceinline__ int gs_tid() { return (int)threadIdx.x; }
 __device__ __forceinline__ void gs_block_barrier() { __syncthreads(); }
+__device__ __forceinline__ int gs_block_threads() { return (int)blockDim.x; }
+// LDS flags between the waves of a workgroup (gx_body.h): acquire / release at workgroup scope, an LDS atomic add, and the pause
+// inside a spin-wait (the waiting wave gives its issue slots to the others)
+__device__ __forceinline__ int32_t gs_lds_load(const int32_t *p)
+{
+    return __hip_atomic_load((const __attribute__((address_space(3))) int32_t *)p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void gs_lds_store(int32_t *p, int32_t v)
+{
+    __hip_atomic_store((__attribute__((address_space(3))) int32_t *)p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int32_t gs_lds_add(int32_t *p, int32_t v)
+{
+    return __hip_atomic_fetch_add((__attribute__((address_space(3))) int32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void gs_spin_pause() { __builtin_amdgcn_s_sleep(1); }
 // keeps the instruction scheduler from moving anything across this point (software pipelines written in source order)
 __device__ __forceinline__ void gs_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ uint64_t gs_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }

@@ -7,7 +7,22 @@
 #define GS_FN inline
 #define GS_SCHED_FENCE() ((void)0)
 static inline int gs_lane() { return emu::lane(); }
-static inline void gs_barrier() { emu::barrier(); }
+// gs_body.h's sync point is wave-scope here: in a one-wave block (every form but WGX) that IS the block barrier, and in the
+// workgroup form (gx_body.h) the control wave must not wait for the expander waves
+static inline void gs_barrier() { emu::wave_barrier(); }
+static inline int gs_tid() { return emu::lane(); }
+static inline int gs_block_threads() { return emu::current()->nl; }
+static inline void gs_block_barrier() { emu::barrier(); }
+// LDS flags between waves: plain accesses (one host thread runs all lanes); a spin-wait must let the other lanes run
+static inline int32_t gs_lds_load(const int32_t *p) { return *(const volatile int32_t *)p; }
+static inline void gs_lds_store(int32_t *p, int32_t v) { *(volatile int32_t *)p = v; }
+static inline int32_t gs_lds_add(int32_t *p, int32_t v)
+{
+    const int32_t old = *p;
+    *p = old + v;
+    return old;
+}
+static inline void gs_spin_pause() { emu::switch_to_next_live(); }
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
@@ -41,6 +56,7 @@ static inline void gs_fence() {}
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
 
 #include "../../jvector_amd/csrc/gs_body.h"
+#include "../../jvector_amd/csrc/gx_body.h"
 #include "../../jvector_amd/csrc/gs_host.h"
 
 namespace {
@@ -83,10 +99,27 @@ void run_lutr(const Launch &L)
     default: abort();
     }
 }
+template <int VSF>
+void run_wgx(const Launch &L)
+{
+    switch (L.ch) {
+    case 1: jv::gx_worker<VSF, 1>(*L.p, L.worker, L.lds); break;
+    case 2: jv::gx_worker<VSF, 2>(*L.p, L.worker, L.lds); break;
+    case 3: jv::gx_worker<VSF, 3>(*L.p, L.worker, L.lds); break;
+    case 4: jv::gx_worker<VSF, 4>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gx_worker<VSF, 6>(*L.p, L.worker, L.lds); break;
+    case 8: jv::gx_worker<VSF, 8>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
 void lane_main(void *arg)
 {
     const Launch &L = *(const Launch *)arg;
-    if (L.p->lutr) {
+    if (L.p->wgx) {
+        if (L.vsf == 0) run_wgx<0>(L);
+        else if (L.vsf == 1) run_wgx<1>(L);
+        else run_wgx<2>(L);
+    } else if (L.p->lutr) {
         if (L.vsf == 0) run_lutr<0>(L);
         else if (L.vsf == 1) run_lutr<1>(L);
         else run_lutr<2>(L);
@@ -101,9 +134,12 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
                               const float *fused_norms, int D, int M, int deg0, int Q, int rerankK, int vsf, int vcap_log2,
                               int spill_cap, int cand_cap, int workers, int pair_mode /* 0 off, 1 when degrees allow */, int32_t *out_ids, float *out_scores, long long *out_stats,
                               int32_t *out_status, int v1_log2 /* LDS tier of the visited set: log2(slots), 0 = none */, int v1_idbits,
-                              int evict_cap /* 0 = GS_EVICT_CAP */, int lutr /* 1: ADC table in registers + LDS (M <= 96) */)
+                              int evict_cap /* 0 = GS_EVICT_CAP */, int lutr /* 1: ADC table in registers + LDS (M <= 96) */,
+                              int wgx_waves /* > 0: the workgroup form (gx_body.h) with this many waves (2..4 here), M <= 128 */,
+                              int wgx_slots, int wgx_depth)
 {
     if (lutr && M > 96) return -4;
+    if (wgx_waves && (M > 128 || M == 80 || M == 112 || wgx_waves < 2 || wgx_waves > emu::MAX_WAVES || lutr)) return -5;
     if (n_levels < 1 || n_levels > jv::GS_MAX_LEVELS || M % 16 != 0 || D != 8 * M || cand_cap < 128) return -1;
     if (v1_log2 > 0 && !jv::gs_v1_fits(v1_log2, v1_idbits)) return -2;
     jv::GsParams p{};
@@ -129,12 +165,24 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     int32_t *visited = (int32_t *)aligned_alloc(64, sizeof(int32_t) * vcap * workers);
     long long *spill = (long long *)aligned_alloc(64, sizeof(long long) * (size_t)(spill_cap > 0 ? spill_cap : 1) * workers + 64);
     memset(visited, 0x5a, sizeof(int32_t) * vcap * workers);  // garbage: the kernel must clear it itself
-    bool pair = pair_mode != 0 && !lutr;  // same rule as graph_search.cpp
+    bool pair = pair_mode != 0 && !lutr && !wgx_waves;  // same rule as graph_search.cpp
     for (int l = 0; l < n_levels; ++l) pair = pair && lv_degree[l] <= 32;
     p.lutr = lutr ? 1 : 0;
     p.pair = pair ? 1 : 0;
     p.v1_log2 = v1_log2; p.v1_idbits = v1_idbits; p.evict_cap = evict_cap;
     p.prefetch = getenv("GS_EMU_PREFETCH") ? atoi(getenv("GS_EMU_PREFETCH")) : 1;  // on by default in the emulator: more code under test
+    int kps = 32;
+    for (int l = 0; l < n_levels; ++l)
+        if (lv_degree[l] > 32) kps = 64;
+    if (wgx_waves) {
+        for (int l = 0; l < n_levels; ++l)
+            if (lv_degree[l] > 64) return -6;
+        p.wgx = 1;
+        p.wgx_slots = wgx_slots;
+        p.wgx_kps = kps;
+        p.wgx_depth = wgx_depth;
+        p.prefetch = 0;
+    }
     const int ecap = evict_cap > 0 ? evict_cap : jv::GS_EVICT_CAP;
     p.visited = visited; p.vcap_log2 = vcap_log2; p.spill = spill; p.spill_cap = spill_cap; p.cand_cap = cand_cap;
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_stats = out_stats; p.out_status = out_status;
@@ -146,12 +194,13 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     for (int w = 0; w < workers; ++w) {
         jv::GsParams pw = p;
         pw.Q = (int)((long long)Q * (w + 1) / workers);
-        const size_t lds_bytes = jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0);
+        const size_t lds_bytes = wgx_waves ? jv::gx_lds_bytes(D, rerankK, cand_cap, ecap, v1_log2, wgx_slots, kps, M)
+                                           : jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0);
         char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
         memset(lds, 0xa5, lds_bytes);
         memset(lds + lds_bytes, 0x3c, 64);  // canary behind the block
         Launch L{&pw, vsf, M / 16, w, lds};
-        collectives += emu::run_wave(lane_main, &L);
+        collectives += wgx_waves ? emu::run_block(lane_main, &L, wgx_waves) : emu::run_wave(lane_main, &L);
         next = (uint32_t)pw.Q;  // the drained worker overshot the counter by one
         for (int i = 0; i < 64; ++i)
             if (lds[lds_bytes + i] != 0x3c) return -3;  // the worker wrote past its LDS block

@@ -14,9 +14,21 @@
 #define BS_FN static inline
 #define KM_FN static inline
 static inline int gs_lane() { return emu::lane(); }
-static inline void gs_barrier() { emu::barrier(); }
+// gs_body.h's sync point: wave scope (= the block barrier in a one-wave block; the control wave of the workgroup form must not
+// wait for the expanders).  Bodies written for several waves use gs_block_barrier().
+static inline void gs_barrier() { emu::wave_barrier(); }
 static inline int gs_tid() { return emu::lane(); }
+static inline int gs_block_threads() { return emu::current()->nl; }
 static inline void gs_block_barrier() { emu::barrier(); }
+static inline int32_t gs_lds_load(const int32_t *p) { return *(const volatile int32_t *)p; }
+static inline void gs_lds_store(int32_t *p, int32_t v) { *(volatile int32_t *)p = v; }
+static inline int32_t gs_lds_add(int32_t *p, int32_t v)
+{
+    const int32_t old = *p;
+    *p = old + v;
+    return old;
+}
+static inline void gs_spin_pause() { emu::switch_to_next_live(); }
 static inline void gs_sched_fence() {}
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
@@ -62,6 +74,7 @@ static inline gs_f32x16 gs_mfma_32x32x2(float a, float b, gs_f32x16 c) { return 
 #include "../../jvector_amd/csrc/bs_body.h"
 #include "../../jvector_amd/csrc/ed_body.h"
 #include "../../jvector_amd/csrc/gs_body.h"
+#include "../../jvector_amd/csrc/gx_body.h"
 #include "../../jvector_amd/csrc/km_body.h"
 #include "../../jvector_amd/csrc/rd_body.h"
 #include "../../jvector_amd/csrc/rt_body.h"
@@ -74,6 +87,12 @@ static void run_wave_locked(void (*fn)(void *), Arg *arg)
 {
     std::lock_guard<std::mutex> lock(g_emu_mu);
     emu::run_wave(fn, (void *)arg);
+}
+template <typename Arg>
+static void run_block_locked(void (*fn)(void *), Arg *arg, int waves)
+{
+    std::lock_guard<std::mutex> lock(g_emu_mu);
+    emu::run_block(fn, (void *)arg, waves);
 }
 
 namespace jv {
@@ -734,6 +753,56 @@ void gs_main(void *a)
     else gs_run_vsf<false>(L);
 }
 }  // namespace
+// ---- the workgroup form (gx_body.h): up to emu::MAX_WAVES waves per workgroup on the emulator ----
+bool graph_search_wgx_supported(int M)
+{
+    const int ch = M / 16;
+    return M % 16 == 0 && (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8);
+}
+size_t graph_search_wgx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int M)
+{
+    return gx_lds_bytes(D, rerankK, cand_cap, evict_cap > 0 ? evict_cap : GS_EVICT_CAP, v1_log2, slots, kps, M);
+}
+namespace {
+template <int VSF>
+void gx_run_ch(const GsLaunch &L)
+{
+    switch (L.p->M / 16) {
+    case 1: gx_worker<VSF, 1>(*L.p, L.worker, L.lds); break;
+    case 2: gx_worker<VSF, 2>(*L.p, L.worker, L.lds); break;
+    case 3: gx_worker<VSF, 3>(*L.p, L.worker, L.lds); break;
+    case 4: gx_worker<VSF, 4>(*L.p, L.worker, L.lds); break;
+    case 6: gx_worker<VSF, 6>(*L.p, L.worker, L.lds); break;
+    case 8: gx_worker<VSF, 8>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
+void gx_main(void *a)
+{
+    const GsLaunch &L = *(const GsLaunch *)a;
+    if (L.vsf == VSF_L2) gx_run_ch<VSF_L2>(L);
+    else if (L.vsf == VSF_DOT) gx_run_ch<VSF_DOT>(L);
+    else gx_run_ch<VSF_COS>(L);
+}
+}  // namespace
+int launch_graph_search_wgx(hipStream_t, int vsf, const GsParams &p, int workgroups, int threads)
+{
+    if (p.Q == 0) return JV_OK;
+    const int waves = std::min(emu::MAX_WAVES, std::max(2, threads / 64));   // (the emulator runs up to 4 waves per block)
+    const size_t lds_bytes = gx_lds_bytes(p.D, p.rerankK, p.cand_cap, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2, p.wgx_slots, p.wgx_kps, p.M);
+    for (int w = 0; w < workgroups; ++w) {
+        GsParams pw = p;
+        pw.Q = (int)((long long)p.Q * (w + 1) / workgroups);
+        char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
+        memset(lds, 0xa5, lds_bytes);
+        GsLaunch L{&pw, vsf, w, lds};
+        run_block_locked(gx_main, &L, waves);
+        *p.next_query = (uint32_t)pw.Q;
+        free(lds);
+    }
+    return JV_OK;
+}
+
 int launch_graph_search(hipStream_t, int vsf, const GsParams &p, int workers, int /*occupancy*/)
 {
     if (p.Q == 0) return JV_OK;

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.skipif(platform.machine() != "x86_64", reason="the lane
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = [os.path.join(ROOT, "tests", "emu", "gs_emu.cpp"), os.path.join(ROOT, "tests", "emu", "hip_emu.h"),
-       os.path.join(ROOT, "jvector_amd", "csrc", "gs_body.h"), os.path.join(ROOT, "jvector_amd", "csrc", "gs_host.h")]
+       os.path.join(ROOT, "jvector_amd", "csrc", "gs_body.h"), os.path.join(ROOT, "jvector_amd", "csrc", "gs_host.h"),
+       os.path.join(ROOT, "jvector_amd", "csrc", "gx_body.h"), os.path.join(ROOT, "jvector_amd", "csrc", "gs_params.h")]
 LIB = os.path.join(ROOT, "build", "emu", "libgs_emu.so")
 
 
@@ -42,7 +43,7 @@ def seq_sum_f32(table, codes):
 
 
 def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vcap_log2=14, spill_cap=8192, cand_cap=256,
-            workers=2, pair=1, v1_log2=9, v1_idbits=None, evict_cap=0, lutr=0):
+            workers=2, pair=1, v1_log2=9, v1_idbits=None, evict_cap=0, lutr=0, wgx_waves=0, wgx_slots=4, wgx_depth=1):
     """v1_log2: slots of the visited set's LDS tier (default 512: small enough that the toy searches fill it, freeze it and go
     on in tier 2, so both tiers and the hand-over are exercised by every test); 0 = no LDS tier"""
     N, M, D = codes.shape[0], opq.M, opq.D
@@ -79,7 +80,8 @@ def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vc
         v1_idbits = max(1, int(N - 1).bit_length())
     n = emu.gs_emu_search(L, nodes, nbrs, count, degree, entry, entry_level, fp(cb), fp(cq), fp(bmag), fp(codes),
                           fp(code_norms), fp(blocks), fp(fnorms), D, M, deg0, Q, rerank_k, int(vsf), vcap_log2, spill_cap,
-                          cand_cap, workers, pair, fp(out_ids), fp(out_sc), fp(stats), fp(status), v1_log2, v1_idbits, evict_cap, lutr)
+                          cand_cap, workers, pair, fp(out_ids), fp(out_sc), fp(stats), fp(status), v1_log2, v1_idbits, evict_cap, lutr,
+                          wgx_waves, wgx_slots, wgx_depth)
     assert n >= 0, n
     return out_ids, out_sc, stats, status, n
 
@@ -126,6 +128,38 @@ def test_emulated_kernel_matches_oracle(emu, levels, fused, M):
             for pair in (1, 0):  # two lanes per neighbour (degrees <= 32) and one lane per neighbour
                 ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, pair=pair)
                 check(ids, sc, st, status, wi, ws, wst)
+
+
+@pytest.mark.parametrize("levels,fused,M,deg", [(1, False, 16, 16), (2, True, 32, 16), (2, False, 48, 40), (2, True, 64, 24), (2, True, 96, 32),
+                                                (3, False, 96, 16), (2, True, 128, 64)])
+def test_workgroup_form_matches_oracle(emu, levels, fused, M, deg):
+    """WGX (gx_body.h): one query per workgroup, the ADC table in LDS, a control wave + expander waves that score rows ahead of
+    time — every M it is built for, degrees up to 64, all three similarity functions, 2..4 waves, 2..8 slots, with and without
+    requests ahead: results, scores and both counters bit-identical to the oracle"""
+    D = 8 * M
+    lv, entry, entry_level, opq, codes, q = problem(500 + levels + M, 2000, D, M, levels, deg=deg, nq=6)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
+        for rk in (40, 1):
+            wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
+            for waves, slots, depth in ((4, 8, 1), (2, 2, 1), (3, 4, 0)):
+                ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, wgx_waves=waves,
+                                                 wgx_slots=slots, wgx_depth=depth)
+                check(ids, sc, st, status, wi, ws, wst)
+
+
+@pytest.mark.parametrize("order", ["reverse", "random:5", "random:6"])
+def test_workgroup_form_under_lane_reordering(emu, monkeypatch, order):
+    """the control wave and the expanders hand rows over through LDS flags: any schedule of the lanes must give the same answer
+    (also the spill tier, both visited tiers and the eviction of scored rows: 2 slots, rerankK 300)"""
+    monkeypatch.setenv("EMU_LANE_ORDER", order)
+    lv, entry, entry_level, opq, codes, q = problem(141, 3000, 128, 16, 2, deg=24, nq=5)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    for vsf, fused, rk, slots in ((O.COSINE, True, 300, 2), (O.EUCLIDEAN, False, 60, 5)):
+        wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
+        ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, cand_cap=256, wgx_waves=4,
+                                         wgx_slots=slots)
+        check(ids, sc, st, status, wi, ws, wst)
 
 
 @pytest.mark.parametrize("levels,fused,M,deg", [(1, False, 16, 16), (2, True, 32, 16), (2, False, 48, 40), (2, True, 64, 24), (2, True, 96, 32),

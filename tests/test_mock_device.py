@@ -184,6 +184,16 @@ def test_device_traversal_tiers_fallbacks_and_counters(J, ctx, capfd):
     T.test_register_resident_table_kernel(ctx, 2, False, 768, 96, 40)
 
 
+def test_workgroup_form_driver_on_the_mock(J, ctx):
+    """gs_wgx = 1 through the C ABI on the mock: LDS sizing next to the table, one workgroup per "CU", the emulated control +
+    expander waves, candidate-tier spills, the tier-2 table with the growth pool and the retry launches — the functions the GPU
+    suite runs"""
+    import test_zz_device_traversal_gpu as T
+    T.test_workgroup_form_kernel(ctx, 2, True, 128, 16, 16)
+    T.test_workgroup_form_kernel(ctx, 1, False, 768, 96, 40)
+    T.test_workgroup_form_large_batch_with_spills_and_overflow(ctx, n_queries=60)
+
+
 def test_device_traversal_refuses_unsupported_shapes(J, ctx):
     import test_zz_device_traversal_gpu as T
     T.test_unsupported_shape_is_refused(ctx)

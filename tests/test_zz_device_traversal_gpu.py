@@ -288,3 +288,60 @@ def test_register_resident_table_kernel(ctx, levels, use_fused, D, M, deg):
                 assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rk)
     finally:
         ctx.set_option("gs_lutr", None)
+
+
+@pytest.mark.parametrize("levels,use_fused,D,M,deg", [(2, True, 768, 96, 32), (3, True, 768, 96, 24), (1, False, 768, 96, 40),
+                                                      (2, True, 128, 16, 16), (2, False, 256, 32, 64), (2, True, 384, 48, 32),
+                                                      (2, True, 512, 64, 32), (2, True, 1024, 128, 32)])
+def test_workgroup_form_kernel(ctx, levels, use_fused, D, M, deg):
+    """gs_wgx = 1: the workgroup form (k_gsearch_wgx.hip — one query per workgroup, the ADC table in LDS, expander waves scoring
+    adjacency rows ahead of the control wave): ids, scores and both counters equal the oracle's for every similarity function,
+    every M it is built for, 2 / 4 / 8 waves, few and many slots, with and without requests ahead"""
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 9 * levels + M, 4000, D, M, levels, use_fused, deg=deg)
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+    try:
+        ctx.set_option("gs_wgx", 1)
+        for vsf in VSF:
+            for top_k, rk in ((10, 80), (1, 1)):
+                wi, ws, wst = og.search(opq, codes, v, q, int(vsf), top_k, rk, fused=use_fused)
+                for waves, slots, depth in ((8, 16, 1), (4, 4, 1), (2, 2, 0)):
+                    ctx.set_option("gs_wgx_waves", waves)
+                    ctx.set_option("gs_wgx_slots", slots)
+                    ctx.set_option("gs_wgx_depth", depth)
+                    before = ctx.stat("gs_calls_wgx")
+                    ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True)
+                    assert ctx.stat("gs_calls_wgx") == before + 1
+                    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rk, waves, slots, depth)
+    finally:
+        for k in ("gs_wgx", "gs_wgx_waves", "gs_wgx_slots", "gs_wgx_depth"):
+            ctx.set_option(k, None)
+
+
+def test_workgroup_form_large_batch_with_spills_and_overflow(ctx, n_queries=1500):
+    """1500 queries over 256 workgroups (every CU serves several queries one after another: the per-query LDS state is rebuilt),
+    rerankK 400 with a 256-key candidate tier (partitions + spill tier), and a 512-slot tier-2 table without an LDS tier
+    (growth pool / retry launches): equal to the host searcher"""
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, _ = _setup(ctx, 5, 8000, 128, 16, 2, True, deg=24)
+    rng = np.random.default_rng(1)
+    q = (v[rng.integers(0, len(v), n_queries)] + 0.1 * rng.standard_normal((n_queries, 128))).astype(np.float32)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=2048)
+    host = J.GraphIndex(ctx, len(v), lv, entry, entry_level).set_traversal("host")
+    sh = J.GraphSearcher(ctx, host, pq, cv, fused, vs, max_queries=2048)
+    want = sh.search(q, VSF.COSINE, 10, 400, return_stats=True)
+    try:
+        ctx.set_option("gs_wgx", 1)
+        ctx.set_option("gs_cand_cap", 256)
+        got = s.search(q, VSF.COSINE, 10, 400, return_stats=True)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        ctx.set_option("gs_vcap_log2", 9)
+        ctx.set_option("gs_retry", 1)
+        ctx.set_option("gs_grow", 1)
+        got = s.search(q, VSF.COSINE, 10, 400, return_stats=True)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        assert ctx.stat("gs_last_wgx") == 1
+    finally:
+        for k in ("gs_wgx", "gs_cand_cap", "gs_vcap_log2", "gs_retry", "gs_grow"):
+            ctx.set_option(k, None)
