@@ -1311,6 +1311,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // (M <= 128), a control wave + expander waves that score adjacency rows ahead of time; plain searches, degrees <= 64
     bool wgx = !so && !generic && !lutr && ctx_opt(ctx, "gs_wgx", 0) != 0 && graph_search_wgx_supported(pq->M);
     for (int lv = 0; lv <= g->entry_level; ++lv) wgx = wgx && g->levels[lv].degree <= 64;
+    const int wgx_log = std::min(512, std::max(256, 4 * rerankK));   // push-log entries buffered in LDS (8 bytes each)
     int wgx_kps = 32;
     for (int lv = 0; lv <= g->entry_level; ++lv)
         if (g->levels[lv].degree > 32) wgx_kps = 64;
@@ -1319,7 +1320,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     int evict_cap = GS_EVICT_CAP;
     int wgx_cand_cap = std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", 512)) & ~63;
     if (wgx) {   // the table + the queues must fit the CU's LDS (a large rerankK or M = 128 may need the smaller candidate tier)
-        auto fits = [&](int cc) { return graph_search_wgx_lds_bytes(pq->D, rerankK, cc, evict_cap, 0, wgx_slots, wgx_kps, pq->M) + 2048 <= ctx->lds_per_block; };
+        auto fits = [&](int cc) { return graph_search_wgx_lds_bytes(pq->D, rerankK, cc, evict_cap, 0, wgx_slots, wgx_kps, wgx_log, pq->M) + 2048 <= ctx->lds_per_block; };
         if (!fits(wgx_cand_cap) && !ctx_opt_is_set(ctx, "gs_cand_cap")) wgx_cand_cap = 256;
         wgx = fits(wgx_cand_cap);
     }
@@ -1344,7 +1345,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         const long long pin = ctx_opt(ctx, "gs_v1_log2", ctx_opt_is_set(ctx, "gs_vcap_log2") ? 0 : -1);
         for (int lg = pin > 0 ? (int)pin : 14; lg >= (pin > 0 ? (int)pin : 8) && pin != 0; --lg) {
             if (!gs_v1_fits(lg, idbits)) continue;
-            if (graph_search_wgx_lds_bytes(pq->D, rerankK, cand_cap, evict_cap, lg, wgx_slots, wgx_kps, pq->M) + 512 <= ctx->lds_per_block) {
+            if (graph_search_wgx_lds_bytes(pq->D, rerankK, cand_cap, evict_cap, lg, wgx_slots, wgx_kps, wgx_log, pq->M) + 512 <= ctx->lds_per_block) {
                 v1_log2 = lg;
                 break;
             }
@@ -1373,7 +1374,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
             }
         }
     }
-    const size_t lds = wgx ? graph_search_wgx_lds_bytes(pq->D, rerankK, cand_cap, evict_cap, v1_log2, wgx_slots, wgx_kps, pq->M)
+    const size_t lds = wgx ? graph_search_wgx_lds_bytes(pq->D, rerankK, cand_cap, evict_cap, v1_log2, wgx_slots, wgx_kps, wgx_log, pq->M)
                            : graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap, v1_log2) + lut_lds;
     if (lds > ctx->lds_per_block) {
         set_error("graph_search(device): rerankK %d needs %zu bytes of LDS per wave (limit %zu); use the host traversal", rerankK,
@@ -1423,7 +1424,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const size_t o_counter = carve(sizeof(uint32_t) * 2);
     const size_t o_qmap = carve(sizeof(int32_t) * (size_t)Q);
     const bool gs_prof = !so && ctx_opt(ctx, "gs_prof", 0) != 0;
-    const size_t o_prof = carve(sizeof(unsigned long long) * 12);
+    const size_t o_prof = carve(sizeof(unsigned long long) * 16);
     // exact-score ties across the K-th place of the rerank are decided by the order of the reference's result-heap array
     // (NodeQueue.java:197-214): the traversal logs its addTopCandidate sequence (avg ~1 entry per expansion) and
     // rerank_tie_kernel rebuilds the reference's answer for the (rare) tied queries; an overflowed log sends the query to
@@ -1448,7 +1449,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     int32_t *d_status = (int32_t *)(base + o_status);
     uint32_t *d_counter = (uint32_t *)(base + o_counter);
     JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
-    if (gs_prof) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 12, ctx->stream));
+    if (gs_prof) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 16, ctx->stream));
 
     GsParams p{};
     for (int lv = 0; lv <= g->entry_level; ++lv) {
@@ -1497,6 +1498,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p.wgx = 1;
         p.wgx_slots = wgx_slots;
         p.wgx_kps = wgx_kps;
+        p.wgx_log = wgx_log;
         p.wgx_depth = (int)ctx_opt(ctx, "gs_wgx_depth", 1);
     }
     auto launch = [&](const GsParams &pp, int w) -> int {
@@ -1618,7 +1620,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         redo.swap(still);
     }
     if (gs_prof) {
-        unsigned long long h[12];
+        unsigned long long h[16];
         JV_HIP_CHECK(hipMemcpyAsync(h, base + o_prof, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         const double e = (double)std::max<unsigned long long>(h[5], 1);
@@ -1626,6 +1628,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
                         "queries %llu  setup+epilogue clocks/query %.0f\n", h[0] / e, h[1] / e, h[2] / e, h[3] / e, h[4] / e, h[5], h[6],
                 (double)h[7] / (double)std::max<unsigned long long>(h[6], 1));
         const double fs = (double)std::max<unsigned long long>(h[8] + h[9] + h[10] + h[11], 1);
+        {
+            const double nq = (double)std::max<unsigned long long>(h[6], 1);
+            fprintf(stderr, "[jv gs prof] clocks/query outside the expansion loop: setup %.0f  level transitions %.0f  epilogue %.0f  table build %.0f\n",
+                    h[12] / nq, h[13] / nq, h[14] / nq, h[15] / nq);
+        }
         if (wgx)
             fprintf(stderr, "[jv gs prof] workgroup form, per expansion: row found in a slot %.3f (of those still being scored at use: %.3f of all)  "
                             "requested at the pop %.3f  rows requested ahead %.3f\n", h[8] / e, h[9] / e, h[10] / e, h[11] / e);

@@ -92,6 +92,7 @@ constexpr long long GS_KEY_MAX = (long long)0x7fffffffffffffffull;
 // "no neighbour in this lane" in a scored row of the workgroup form: a real key's low word is ~node with node >= 0, never 0
 constexpr long long GX_KEY_NONE = 0;
 
+#ifndef GS_HAVE_WAVE_REDUCE   // (gs_wave_hip.h supplies DPP forms under GS_UNIFORM_SHFL)
 GS_FN long long gs_wave_max(long long v)
 {
     for (int o = 32; o > 0; o >>= 1) {
@@ -108,6 +109,7 @@ GS_FN long long gs_wave_min(long long v)
     }
     return v;
 }
+#endif
 GS_FN int gs_popc(uint64_t m) { return __builtin_popcountll(m); }
 GS_FN int gs_first(uint64_t m) { return m ? __builtin_ctzll(m) : 64; }
 
@@ -118,11 +120,16 @@ GS_FN long long gs_scan_extreme(const long long *a, int n, int *idx_out)
     const int lane = gs_lane();
     long long best = MAX ? GS_KEY_MIN : GS_KEY_MAX;
     int bi = -1;
-    for (int i = lane; i < n; i += 64) {
-        const long long k = a[i];
-        if (MAX ? (k > best) : (k < best)) {
-            best = k;
-            bi = i;
+    for (int i = lane; i < n; i += 256) {   // four keys per lane and pass, read before any of them is compared
+        long long k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = (i + 64 * u < n) ? a[i + 64 * u] : (MAX ? GS_KEY_MIN : GS_KEY_MAX);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (MAX ? (k[u] > best) : (k[u] < best)) {
+                best = k[u];
+                bi = i + 64 * u;
+            }
         }
     }
     const long long m = MAX ? gs_wave_max(best) : gs_wave_min(best);
@@ -137,14 +144,20 @@ GS_FN long long gs_scan_top2(const long long *a, int n, int *idx_out, long long 
     const int lane = gs_lane();
     long long best = GS_KEY_MIN, second = GS_KEY_MIN;
     int bi = -1;
-    for (int i = lane; i < n; i += 64) {
-        const long long k = a[i];
-        if (k > best) {
-            second = best;
-            best = k;
-            bi = i;
-        } else if (k > second) {
-            second = k;
+    // four keys per lane and pass, read before any of them is compared (one LDS round trip per 256 keys)
+    for (int i = lane; i < n; i += 256) {
+        long long k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = (i + 64 * u < n) ? a[i + 64 * u] : GS_KEY_MIN;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k[u] > best) {
+                second = best;
+                best = k[u];
+                bi = i + 64 * u;
+            } else if (k[u] > second) {
+                second = k[u];
+            }
         }
     }
     const long long m = gs_wave_max(best);
@@ -277,11 +290,17 @@ GS_FN float gs_row_sum_any(const GsParams &p, const float *qs, const uint8_t *rp
 constexpr int GS_LUT_REG_SUB = 64;
 
 template <int VSF>
+GS_FN float gs_lut_entry_from(const gs_f4 c0, const gs_f4 c1, const float *q);
+template <int VSF>
 GS_FN float gs_lut_entry(const float *codebooks, const float *qs, int m, int code)
 {
     const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(codebooks + ((int64_t)(m * 256) + code) * 8);
-    const gs_f4 c0 = cp[0], c1 = cp[1];
-    const float *q = qs + m * 8;
+    return gs_lut_entry_from<VSF>(cp[0], cp[1], qs + m * 8);
+}
+// one table entry from its codebook row (c0, c1) and the query's sub-vector q: calculatePartialSums' chain
+template <int VSF>
+GS_FN float gs_lut_entry_from(const gs_f4 c0, const gs_f4 c1, const float *q)
+{
     float ent = 0.0f;
     if (VSF == 0 /* L2 */) {
         float t;
@@ -683,6 +702,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     unsigned long long pf[5] = {0, 0, 0, 0, 0};
     unsigned long long fh[4] = {0, 0, 0, 0};  // PROF: scored neighbours in expansions with <= 8 / <= 16 / <= 24 / <= 32 fresh ones
     unsigned long long pt = 0, pq0 = 0;
+    unsigned long long px[3] = {0, 0, 0};   // PROF: setup (entry -> first pop), level transitions, epilogue
     if (PROF) pq0 = GS_CLOCK();
 #define GS_PHASE(i)                          \
     do {                                     \
@@ -733,6 +753,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     // The visited table is half full: move to a table of the growth pool (once per query), or give up with GS_OVERFLOW.
     // Wave-uniform.  The old table is read back with atomics (a CAS that can never succeed), like every other access to it.
     auto grow = [&]() -> bool {
+        if constexpr (WGX) return false;   // (the workgroup form leaves an outgrown tier 2 to the retry launch)
         if (grown || !p.big_visited) return false;
         long long sv = 0;
         if (lane == 0) sv = (long long)gs_fetch_add(p.big_next, 1u);
@@ -775,6 +796,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     int32_t *gx_hdr = nullptr, *gx_ring = nullptr, *gx_slot_node = nullptr, *gx_slot_lvl = nullptr, *gx_slot_state = nullptr;
     long long *gx_keys = nullptr;
     const float *gx_lut = nullptr;
+    long long *gx_log = nullptr;    // the first wgx_log entries of the push log wait in LDS until the query ends (no global store per expansion)
     int32_t gx_node = -1, gx_lvl = 0;
     long long gx_ckey = 0;
     int gx_tail = 0;
@@ -786,7 +808,8 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         gx_slot_lvl = reinterpret_cast<int32_t *>(sh + gx_off_slot_lvl());
         gx_slot_state = reinterpret_cast<int32_t *>(sh + gx_off_slot_state());
         gx_keys = reinterpret_cast<long long *>(sh + gx_off_keys());
-        gx_lut = reinterpret_cast<const float *>(sh + gx_off_lut(p.wgx_slots, p.wgx_kps));
+        gx_lut = reinterpret_cast<const float *>(sh + gx_off_lut(p.wgx_slots, p.wgx_kps, p.wgx_log));
+        gx_log = reinterpret_cast<long long *>(sh + gx_off_log(p.wgx_slots, p.wgx_kps));
     }
     // slot holding (node, level), or -1
     auto gx_find = [&](int32_t node, int lvl) -> int {
@@ -1000,6 +1023,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         return window < worst_best && window < (double)cur_thr;
     };
 
+    if (PROF) px[0] = GS_CLOCK() - pq0;
     for (int lvl = p.entry_level; lvl >= 0 && s.status == GS_OK; --lvl) {
         int rk = lvl > 0 ? 1 : p.rerankK;
         const GsLevel &L = p.lv[lvl];
@@ -1090,7 +1114,8 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             }
             if (result && lvl == 0 && p.push_log && lane == 0) {  // the addTopCandidate sequence, for rt_body.h's tie resolution
                 const int n_log = *reinterpret_cast<int *>(s.evicted);
-                if (n_log < p.push_log_cap) p.push_log[(int64_t)q * p.push_log_cap + n_log] = top;
+                if (WGX && n_log < p.wgx_log) gx_log[n_log] = top;
+                else if (n_log < p.push_log_cap) p.push_log[(int64_t)q * p.push_log_cap + n_log] = top;
                 *reinterpret_cast<int *>(s.evicted) = n_log + 1;
             }
             if (!result) {
@@ -1304,6 +1329,8 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         }
         }
         if (s.status != GS_OK) break;
+        unsigned long long ptr0 = 0;
+        if (PROF) ptr0 = GS_CLOCK();
         if constexpr (WGX) {
             // rows requested for this level are of no use on the next one: let the expanders finish them, then free every slot
             if (lvl > 0) {
@@ -1325,13 +1352,24 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             s.res_min = GS_KEY_MAX;
             s.res_min_idx = -1;
         }
+        if (PROF) px[1] += GS_CLOCK() - ptr0;
     }
+    unsigned long long pep0 = 0;
+    if (PROF) pep0 = GS_CLOCK();
 
     if constexpr (WGX) {   // the expanders leave their service loop (a request in flight is finished first; gx_worker's barrier waits)
         if (lane == 0) gs_lds_store(gx_hdr + GX_QUIT, 1);
     }
     // ---- hand the kept approximate results to the rerank stage ----
     gs_barrier();
+    if constexpr (WGX) {
+        if (p.push_log && s.status == GS_OK) {
+            int n_log = *reinterpret_cast<int *>(s.evicted);
+            n_log = n_log < p.wgx_log ? n_log : p.wgx_log;
+            n_log = n_log < p.push_log_cap ? n_log : p.push_log_cap;
+            for (int i = lane; i < n_log; i += 64) p.push_log[(int64_t)q * p.push_log_cap + i] = gx_log[i];
+        }
+    }
     for (int i = lane; i < p.rerankK; i += 64) {
         const bool have = s.status == GS_OK && i < s.res_n;
         const long long k = have ? s.res[i] : 0;
@@ -1356,6 +1394,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         gs_fetch_add64(p.prof + 6, 1ull);
         gs_fetch_add64(p.prof + 7, (GS_CLOCK() - pq0) - in_loop);
         for (int i = 0; i < 4; ++i) gs_fetch_add64(p.prof + 8 + i, fh[i]);
+        gs_fetch_add64(p.prof + 12, px[0]);
+        gs_fetch_add64(p.prof + 13, px[1]);
+        gs_fetch_add64(p.prof + 14, GS_CLOCK() - pep0);
     }
 #undef GS_PHASE
 }

@@ -86,6 +86,7 @@ struct GsParams {
     int32_t wgx_slots;        // scored-row slots in LDS (<= 64)
     int32_t wgx_kps;          // keys per slot: 32 or 64 (>= every level's degree)
     int32_t wgx_depth;        // candidates below the popped one whose rows are requested ahead of time (0..3)
+    int32_t wgx_log;          // addTopCandidate keys buffered in LDS and written to push_log when the query ends (0 = straight to push_log)
     // outputs
     int32_t *out_ids;         // [Q][rerankK] kept approximate results (unordered), -1 padded
     float *out_scores;        // [Q][rerankK] their approximate scores, -inf padded
@@ -139,16 +140,17 @@ constexpr size_t gx_off_slot_node() { return gx_off_ring() + sizeof(int32_t) * G
 constexpr size_t gx_off_slot_lvl() { return gx_off_slot_node() + sizeof(int32_t) * GX_MAX_SLOTS; }
 constexpr size_t gx_off_slot_state() { return gx_off_slot_lvl() + sizeof(int32_t) * GX_MAX_SLOTS; }
 constexpr size_t gx_off_keys() { return (gx_off_slot_state() + sizeof(int32_t) * GX_MAX_SLOTS + 15) & ~(size_t)15; }
-constexpr size_t gx_off_lut(int slots, int kps) { return (gx_off_keys() + sizeof(long long) * (size_t)slots * (size_t)kps + 15) & ~(size_t)15; }
-constexpr size_t gx_shared_bytes(int slots, int kps, int M) { return gx_off_lut(slots, kps) + sizeof(float) * 256 * (size_t)M; }
+constexpr size_t gx_off_log(int slots, int kps) { return (gx_off_keys() + sizeof(long long) * (size_t)slots * (size_t)kps + 15) & ~(size_t)15; }
+constexpr size_t gx_off_lut(int slots, int kps, int logcap) { return (gx_off_log(slots, kps) + sizeof(long long) * (size_t)logcap + 15) & ~(size_t)15; }
+constexpr size_t gx_shared_bytes(int slots, int kps, int logcap, int M) { return gx_off_lut(slots, kps, logcap) + sizeof(float) * 256 * (size_t)M; }
 // where the header starts inside the workgroup's LDS block
 constexpr size_t gx_ctl_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2)
 {
     return (gs_lds_bytes(D, rerankK, cand_cap, 0, evict_cap, v1_log2) + 15) & ~(size_t)15;
 }
-constexpr size_t gx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int M)
+constexpr size_t gx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int logcap, int M)
 {
-    return gx_ctl_bytes(D, rerankK, cand_cap, evict_cap, v1_log2) + gx_shared_bytes(slots, kps, M);
+    return gx_ctl_bytes(D, rerankK, cand_cap, evict_cap, v1_log2) + gx_shared_bytes(slots, kps, logcap, M);
 }
 
 // rerank tie resolution (rt_body.h / rerank_tie_kernel)

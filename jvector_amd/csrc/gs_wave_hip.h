@@ -27,13 +27,21 @@ __device__ __forceinline__ void gs_block_barrier() { __syncthreads(); }
 __device__ __forceinline__ int gs_block_threads() { return (int)blockDim.x; }
 // LDS flags between the waves of a workgroup (gx_body.h): acquire / release at workgroup scope, an LDS atomic add, and the pause
 // inside a spin-wait (the waiting wave gives its issue slots to the others)
+// (The flags order LDS accesses only — a slot's keys against its READY flag, a request's fields against the ring tail.  LDS
+// operations of one wave are performed in issue order, so "every earlier LDS operation has been issued and the compiler moves nothing
+// across" is all a release / acquire needs here; the workgroup-scope atomics of the memory model would also wait for the wave's
+// outstanding GLOBAL accesses — s_waitcnt vmcnt(0) — which costs an expander nothing but stalls the control wave behind its
+// fire-and-forget stores.)
 __device__ __forceinline__ int32_t gs_lds_load(const int32_t *p)
 {
-    return __hip_atomic_load((const __attribute__((address_space(3))) int32_t *)p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int32_t v = *(const volatile __attribute__((address_space(3))) int32_t *)p;
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return v;
 }
 __device__ __forceinline__ void gs_lds_store(int32_t *p, int32_t v)
 {
-    __hip_atomic_store((__attribute__((address_space(3))) int32_t *)p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    *(volatile __attribute__((address_space(3))) int32_t *)p = v;
 }
 __device__ __forceinline__ int32_t gs_lds_add(int32_t *p, int32_t v)
 {
@@ -43,7 +51,43 @@ __device__ __forceinline__ void gs_spin_pause() { __builtin_amdgcn_s_sleep(1); }
 // keeps the instruction scheduler from moving anything across this point (software pipelines written in source order)
 __device__ __forceinline__ void gs_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ uint64_t gs_ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
+#ifdef GS_UNIFORM_SHFL
+// every gs_shfl of gs_body.h / gx_body.h reads ONE lane for the whole wave (src is wave-uniform): v_readlane_b32 through the scalar
+// unit instead of two ds_bpermute_b32 round trips through the LDS crossbar
+__device__ __forceinline__ long long gs_shfl(long long v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned long long)v, src), hi = __builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), src);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+// max / min of a 64-bit key over the wave in DPP steps (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, row_bcast15 / row_bcast31
+// across them; lane 63 ends up with the result): 6 steps of two v_mov_dpp + compare + select instead of 12 dependent ds_bpermute
+// round trips.  All 64 lanes must be active (every call site of gs_body.h is wave-uniform).
+#define GS_HAVE_WAVE_REDUCE 1
+template <bool MAX>
+__device__ __forceinline__ long long gs_wave_reduce64(long long v)
+{
+#define JV_DPP_STEP(CTRL, ROWS)                                                                                       \
+    do {                                                                                                              \
+        const int lo_ = __builtin_amdgcn_update_dpp((int)(unsigned long long)v, (int)(unsigned long long)v, CTRL, ROWS, 0xf, false);              \
+        const int hi_ = __builtin_amdgcn_update_dpp((int)((unsigned long long)v >> 32), (int)((unsigned long long)v >> 32), CTRL, ROWS, 0xf, false); \
+        const long long o_ = (long long)(((unsigned long long)(unsigned)hi_ << 32) | (unsigned long long)(unsigned)lo_);                          \
+        v = MAX ? (o_ > v ? o_ : v) : (o_ < v ? o_ : v);                                                              \
+    } while (0)
+    JV_DPP_STEP(0x111, 0xf);  // row_shr:1
+    JV_DPP_STEP(0x112, 0xf);  // row_shr:2
+    JV_DPP_STEP(0x114, 0xf);  // row_shr:4
+    JV_DPP_STEP(0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds its row's result
+    JV_DPP_STEP(0x142, 0xa);  // row_bcast15 -> rows 1 and 3 take in rows 0 and 2
+    JV_DPP_STEP(0x143, 0xc);  // row_bcast31 -> rows 2 and 3 take in lane 31: lane 63 holds the wave's result
+#undef JV_DPP_STEP
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned long long)v, 63), hi = __builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), 63);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ long long gs_wave_max(long long v) { return gs_wave_reduce64<true>(v); }
+__device__ __forceinline__ long long gs_wave_min(long long v) { return gs_wave_reduce64<false>(v); }
+#else
 __device__ __forceinline__ long long gs_shfl(long long v, int src) { return __shfl(v, src, 64); }
+#endif
 __device__ __forceinline__ long long gs_shfl_xor(long long v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ int32_t gs_shfl32(int32_t v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
 __device__ __forceinline__ int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired) { return atomicCAS(p, expect, desired); }

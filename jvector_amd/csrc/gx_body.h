@@ -35,8 +35,26 @@ GS_FN void gx_lut_build(const GsParams &p, int q, float *qs, float *lut, int tid
         for (int i = tid; i < p.D / 4; i += nthreads) dst[i] = src[i];
     }
     gs_block_barrier();
+    // eight entries per thread and pass, their codebook rows (32 B each, consecutive threads -> consecutive rows) loaded before the
+    // first one is used: the build is bound by the L2 -> CU stream of the 768 KB codebook, not by one load's latency
     const int total = p.M * 256;
-    for (int i = tid; i < total; i += nthreads) lut[i] = gs_lut_entry<VSF>(p.codebooks, qs, i >> 8, i & 255);
+    for (int base = tid; base < total; base += 8 * nthreads) {
+        gs_f4 c0[8], c1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * nthreads;
+            if (i < total) {
+                const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(p.codebooks + (int64_t)i * 8);
+                c0[u] = cp[0];
+                c1[u] = cp[1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * nthreads;
+            if (i < total) lut[i] = gs_lut_entry_from<VSF>(c0[u], c1[u], qs + (i >> 8) * 8);
+        }
+    }
 }
 
 // An expander wave's service loop for one query.  lane = 0..63 inside the wave.
@@ -49,7 +67,7 @@ GS_FN void gx_expander(const GsParams &p, int q, char *sh, int lane)
     int32_t *slot_lvl = reinterpret_cast<int32_t *>(sh + gx_off_slot_lvl());
     int32_t *slot_state = reinterpret_cast<int32_t *>(sh + gx_off_slot_state());
     long long *keys = reinterpret_cast<long long *>(sh + gx_off_keys());
-    const float *lut = reinterpret_cast<const float *>(sh + gx_off_lut(p.wgx_slots, p.wgx_kps));
+    const float *lut = reinterpret_cast<const float *>(sh + gx_off_lut(p.wgx_slots, p.wgx_kps, p.wgx_log));
     const float query_mag = (VSF == 2) ? p.bmag[q] : 0.0f;
     for (;;) {
         // take a ticket; wait until the control wave has posted that many requests (or the query is over)
@@ -101,7 +119,7 @@ GS_FN void gx_worker(const GsParams &p, int worker, char *lds)
     const int evict_cap = p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP;
     char *sh = lds + gx_ctl_bytes(p.D, p.rerankK, p.cand_cap, evict_cap, p.v1_log2);
     int32_t *hdr = reinterpret_cast<int32_t *>(sh);
-    float *lut = reinterpret_cast<float *>(sh + gx_off_lut(p.wgx_slots, p.wgx_kps));
+    float *lut = reinterpret_cast<float *>(sh + gx_off_lut(p.wgx_slots, p.wgx_kps, p.wgx_log));
     for (;;) {
         if (tid == 0) {
             hdr[GX_ITEM] = (int32_t)gs_fetch_add(p.next_query, 1u);
@@ -113,8 +131,11 @@ GS_FN void gx_worker(const GsParams &p, int worker, char *lds)
         const int item = hdr[GX_ITEM];
         if (item >= p.Q) break;
         const int q = p.qmap ? p.qmap[item] : item;
+        unsigned long long t0 = 0;
+        if (PROF) t0 = GS_CLOCK();
         gx_lut_build<VSF>(p, q, reinterpret_cast<float *>(lds), lut, tid, nthreads);
         gs_block_barrier();
+        if (PROF && p.prof && tid == 0) gs_fetch_add64(p.prof + 15, GS_CLOCK() - t0);
         if (tid < 64) gs_search_one<VSF, CH16, false, PROF, false, false, true>(p, q, worker, lds);
         else gx_expander<VSF, CH16>(p, q, sh, tid & 63);
         gs_block_barrier();   // nobody is inside this query's LDS state any more

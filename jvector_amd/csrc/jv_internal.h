@@ -386,7 +386,7 @@ int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, 
 bool graph_search_lutr_supported(int M);
 // the workgroup form (k_gsearch_wgx.hip): one query per workgroup, the ADC table in LDS
 bool graph_search_wgx_supported(int M);
-size_t graph_search_wgx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int M);
+size_t graph_search_wgx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int logcap, int M);
 int launch_graph_search_wgx(hipStream_t s, int vsf, const GsParams &p, int workgroups, int threads);
 bool graph_search_session_supported(int M);
 int launch_graph_search_session(hipStream_t s, int vsf, const GsParams &p, int workers, size_t lds);

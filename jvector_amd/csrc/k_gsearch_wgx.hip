@@ -6,6 +6,7 @@
 #include "jv_internal.h"
 
 #define GS_WAVE_SCOPE_BARRIER 1
+#define GS_UNIFORM_SHFL 1
 #include "gs_wave_hip.h"
 
 #include "gx_body.h"
@@ -56,9 +57,9 @@ bool graph_search_wgx_supported(int M)
     return M % 16 == 0 && (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8);
 }
 
-size_t graph_search_wgx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int M)
+size_t graph_search_wgx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int logcap, int M)
 {
-    return gx_lds_bytes(D, rerankK, cand_cap, evict_cap > 0 ? evict_cap : GS_EVICT_CAP, v1_log2, slots, kps, M);
+    return gx_lds_bytes(D, rerankK, cand_cap, evict_cap > 0 ? evict_cap : GS_EVICT_CAP, v1_log2, slots, kps, logcap, M);
 }
 
 int launch_graph_search_wgx(hipStream_t s, int vsf, const GsParams &p, int workgroups, int threads)
@@ -72,7 +73,7 @@ int launch_graph_search_wgx(hipStream_t s, int vsf, const GsParams &p, int workg
         set_error("graph search kernel (workgroup form): bad launch shape (threads %d, slots %d, keys per slot %d)", threads, p.wgx_slots, p.wgx_kps);
         return JV_ERR_INVALID;
     }
-    const size_t lds = gx_lds_bytes(p.D, p.rerankK, p.cand_cap, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2, p.wgx_slots, p.wgx_kps, p.M);
+    const size_t lds = gx_lds_bytes(p.D, p.rerankK, p.cand_cap, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2, p.wgx_slots, p.wgx_kps, p.wgx_log, p.M);
     const int ch = p.M / 16;
     if (p.prof) {
         if (vsf != VSF_COS) {

@@ -181,6 +181,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
         p.wgx_slots = wgx_slots;
         p.wgx_kps = kps;
         p.wgx_depth = wgx_depth;
+        p.wgx_log = 16;
         p.prefetch = 0;
     }
     const int ecap = evict_cap > 0 ? evict_cap : jv::GS_EVICT_CAP;
@@ -194,7 +195,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     for (int w = 0; w < workers; ++w) {
         jv::GsParams pw = p;
         pw.Q = (int)((long long)Q * (w + 1) / workers);
-        const size_t lds_bytes = wgx_waves ? jv::gx_lds_bytes(D, rerankK, cand_cap, ecap, v1_log2, wgx_slots, kps, M)
+        const size_t lds_bytes = wgx_waves ? jv::gx_lds_bytes(D, rerankK, cand_cap, ecap, v1_log2, wgx_slots, kps, p.wgx_log, M)
                                            : jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0);
         char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
         memset(lds, 0xa5, lds_bytes);
