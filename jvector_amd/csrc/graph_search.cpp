@@ -1307,9 +1307,17 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // M >= 128: the pair form's two half rows + exchange indices no longer fit 256 VGPRs (156 / 588 bytes of scratch per
     // lane at M = 128 / 192, -Rpass-analysis=kernel-resource-usage) while the one-lane-per-neighbour form still does
     pair = pair && pq->M <= 96;
-    // gs_wgx = 1: the WORKGROUP form (gx_body.h, k_gsearch_wgx.hip) — one query per workgroup / CU, the query's ADC table in LDS
-    // (M <= 128), a control wave + expander waves that score adjacency rows ahead of time; plain searches, degrees <= 64
-    bool wgx = !so && !generic && !lutr && ctx_opt(ctx, "gs_wgx", 0) != 0 && graph_search_wgx_supported(pq->M);
+    // The WORKGROUP form (gx_body.h, k_gsearch_wgx.hip) — one query per workgroup / CU, the query's ADC table in LDS, a control wave
+    // + expander waves that score adjacency rows ahead of time; plain searches, degrees <= 64.  A query takes ~0.3 ms in it against
+    // ~1.5 ms in the one-wave form (10M x 768, rerankK 95), but a CU serves one query at a time instead of eight: it is the form
+    // for SMALL batches — gs_wgx unset: batches of up to 4 queries per CU; 1 / 0: always / never.
+    const long long wgx_opt = ctx_opt(ctx, "gs_wgx", -1);
+    // (AUTO leaves a launch alone that carries tuning options of the one-wave form: tests and benches that pin them mean that form)
+    bool one_wave_tuned = false;
+    for (const char *o : {"gs_vcap_log2", "gs_v1_log2", "gs_grow", "gs_retry", "gs_occ", "gs_pair", "gs_cand_cap", "gs_waves_per_cu", "gs_prefetch", "gs_prof"})
+        one_wave_tuned = one_wave_tuned || ctx_opt_is_set(ctx, o);
+    bool wgx = !so && !generic && !lutr && graph_search_wgx_supported(pq->M) &&
+               (wgx_opt > 0 || (wgx_opt < 0 && !one_wave_tuned && Q <= 4 * ctx->num_cus));
     for (int lv = 0; lv <= g->entry_level; ++lv) wgx = wgx && g->levels[lv].degree <= 64;
     const int wgx_log = std::min(512, std::max(256, 4 * rerankK));   // push-log entries buffered in LDS (8 bytes each)
     int wgx_kps = 32;
@@ -1318,11 +1326,24 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const int wgx_waves = std::max(2, std::min(8, (int)ctx_opt(ctx, "gs_wgx_waves", 8)));
     const int wgx_slots = std::max(2, std::min((int)GX_MAX_SLOTS, (int)ctx_opt(ctx, "gs_wgx_slots", 16)));
     int evict_cap = GS_EVICT_CAP;
-    int wgx_cand_cap = std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", 512)) & ~63;
-    if (wgx) {   // the table + the queues must fit the CU's LDS (a large rerankK or M = 128 may need the smaller candidate tier)
-        auto fits = [&](int cc) { return graph_search_wgx_lds_bytes(pq->D, rerankK, cc, evict_cap, 0, wgx_slots, wgx_kps, wgx_log, pq->M) + 2048 <= ctx->lds_per_block; };
-        if (!fits(wgx_cand_cap) && !ctx_opt_is_set(ctx, "gs_cand_cap")) wgx_cand_cap = 256;
-        wgx = fits(wgx_cand_cap);
+    const int wgx_cand_cap = 256;   // (gx_body.h GX_HOT: the control wave scans its candidate tier from registers, four keys per lane)
+    // LDS of one workgroup: gs_wgx_per_cu workgroups (= control waves = queries in flight) share a CU; the table covers the first
+    // gs_wgx_lut_m subspaces (default: as many as fit), the others are scored table-free by the expanders
+    const int wgx_per_cu = std::max(1, std::min(4, (int)ctx_opt(ctx, "gs_wgx_per_cu", 1)));
+    const size_t wgx_budget = ctx->lds_per_block / (size_t)wgx_per_cu - (wgx_per_cu > 1 ? 256 : 512);
+    auto wgx_bytes = [&](int lg, int lm) { return graph_search_wgx_lds_bytes(pq->D, rerankK, wgx_cand_cap, evict_cap, lg, wgx_slots, wgx_kps, wgx_log, lm); };
+    int wgx_lut_m = (int)ctx_opt(ctx, "gs_wgx_lut_m", 0);
+    if (wgx) {
+        const int idb = gs_idbits(g->n_nodes);
+        int min_v1 = 0;   // room for an LDS tier of the visited set is set aside before the table takes the rest
+        for (int lg = 12; lg >= 8 && min_v1 == 0; --lg)
+            if (gs_v1_fits(lg, idb)) min_v1 = lg;
+        if (wgx_lut_m <= 0) {
+            wgx_lut_m = pq->M;
+            while (wgx_lut_m > 16 && wgx_bytes(min_v1, wgx_lut_m) > wgx_budget) wgx_lut_m -= 16;
+        }
+        wgx_lut_m = std::max(16, std::min(pq->M, wgx_lut_m / 16 * 16));
+        wgx = wgx_bytes(0, wgx_lut_m) <= wgx_budget;
     }
     if (wgx) pair = false;
     const int pair_M = pair ? pq->M : 0;
@@ -1345,7 +1366,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         const long long pin = ctx_opt(ctx, "gs_v1_log2", ctx_opt_is_set(ctx, "gs_vcap_log2") ? 0 : -1);
         for (int lg = pin > 0 ? (int)pin : 14; lg >= (pin > 0 ? (int)pin : 8) && pin != 0; --lg) {
             if (!gs_v1_fits(lg, idbits)) continue;
-            if (graph_search_wgx_lds_bytes(pq->D, rerankK, cand_cap, evict_cap, lg, wgx_slots, wgx_kps, wgx_log, pq->M) + 512 <= ctx->lds_per_block) {
+            if (wgx_bytes(lg, wgx_lut_m) <= wgx_budget) {
                 v1_log2 = lg;
                 break;
             }
@@ -1374,7 +1395,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
             }
         }
     }
-    const size_t lds = wgx ? graph_search_wgx_lds_bytes(pq->D, rerankK, cand_cap, evict_cap, v1_log2, wgx_slots, wgx_kps, wgx_log, pq->M)
+    const size_t lds = wgx ? wgx_bytes(v1_log2, wgx_lut_m)
                            : graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap, v1_log2) + lut_lds;
     if (lds > ctx->lds_per_block) {
         set_error("graph_search(device): rerankK %d needs %zu bytes of LDS per wave (limit %zu); use the host traversal", rerankK,
@@ -1383,7 +1404,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     }
     int per_cu = (int)std::min<size_t>((size_t)want_per_cu, std::max<size_t>(1, (160 * 1024) / (lds + 256)));
     per_cu = std::max(1, (int)ctx_opt(ctx, "gs_waves_per_cu", per_cu));
-    if (wgx) per_cu = 1;
+    if (wgx) per_cu = wgx_per_cu;
     const int workers = std::max(1, std::min(Q, ctx->num_cus * per_cu));
     // JVECTOR_HIP_GS_VCAP_LOG2 overrides the visited-table size (tests use a tiny table to drive the host fallback)
     const int vcap_log2 = std::max(8, std::min(24, (int)ctx_opt(ctx, "gs_vcap_log2", gs_vcap_log2(rerankK))));
@@ -1499,6 +1520,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p.wgx_slots = wgx_slots;
         p.wgx_kps = wgx_kps;
         p.wgx_log = wgx_log;
+        p.wgx_lut_m = wgx_lut_m;
         p.wgx_depth = (int)ctx_opt(ctx, "gs_wgx_depth", 1);
     }
     auto launch = [&](const GsParams &pp, int w) -> int {

@@ -374,20 +374,34 @@ GS_FN float gs_row_sum_lut(const float (&lut)[(CH16 * 16 < GS_LUT_REG_SUB ? CH16
 // ---- the workgroup form's score: the query's whole ADC table [M][256] f32 sits in LDS (gx_body.h gx_lut_build wrote it with
 //      gs_lut_entry's arithmetic: calculatePartialSums entry by entry); a row's score is assembleAndSum (:323-330): the entries
 //      its code bytes select, added in ascending m into one f32.
-template <int CH16>
-GS_FN float gx_row_sum(const float *lut, const gs_u4 (&w)[CH16])
+//      The table may cover only the subspaces [0, lut_m) (a multiple of 16): the entries of the others are recomputed from the
+//      codebook like gs_row_sum does — the same bits, in the same ascending-m sum.
+template <int VSF, int CH16, bool FULL = false>   // FULL: the table covers every subspace (lut_m == M, no table-free code at all)
+GS_FN float gx_row_sum(const float *lut, int lut_m, const float *codebooks, const float *qs, const gs_u4 (&w)[CH16])
 {
     float sum = 0.0f;
 #pragma unroll
     for (int c = 0; c < CH16; ++c) {
         const uint32_t d[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
+        if (FULL || c * 16 < lut_m) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int m = c * 16 + e * 4 + b;
-                const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
-                sum += lut[m * 256 + (int)code];
+                for (int b = 0; b < 4; ++b) {
+                    const int m = c * 16 + e * 4 + b;
+                    const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
+                    sum += lut[m * 256 + (int)code];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int m = c * 16 + e * 4 + b;
+                    const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
+                    sum += gs_lut_entry<VSF>(codebooks, qs, m, (int)code);
+                }
             }
         }
     }
@@ -680,20 +694,14 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 // PROF: developer aid — per-phase shader-clock totals of the expansion loop are added to p.prof[0..7]
 //       (pop, result insert, row + block + visited probes, scoring, push, expansions, queries, setup + epilogue)
 // LUTR: the query's ADC table lives in registers (gs_lut_build / gs_row_sum_lut; one lane per neighbour, PAIR must be false)
-// WGX:  the workgroup form (gx_body.h): this function is the CONTROL wave (wave 0 of the workgroup).  The query's ADC table is in
-//       LDS (built by all waves before the call); an expansion does not score anything itself — it takes the popped node's
-//       scored adjacency row (one NodeQueue key per neighbour) from a slot an expander wave filled, requested right after the pop
-//       or, for the likely next candidates, one or more iterations ahead.  A scored row is a pure function of (node, level), so
-//       requesting rows that are never consumed cannot change a result.  gs_barrier() is a wave-scope sync point in this form.
 // SES:  GraphSearcher OBJECTS (jv_hip_searcher_*): layer 0 admits `score >= p.threshold` (:437) and, for threshold > 0, stops
 //       through ScoreTracker.TwoPhaseTracker (ScoreTracker.java:80-140: a 500-score window + the 100 best scores, both in LDS);
 //       expandedCountBaseLayer is reported.  What reranking / resume need beyond that is rebuilt by the host from the
 //       addTopCandidate log (graph_search.cpp searcher_search_device).
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool WGX = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
     static_assert(!(LUTR && PAIR), "the register-resident table serves the one-lane-per-neighbour form");
-    static_assert(!WGX || (CH16 > 0 && !PAIR && !LUTR && !SES), "the workgroup form: specialised shapes, plain searches");
     static_assert(CH16 > 0 || !(LUTR || PAIR), "the generic form (CH16 = 0) is one lane per neighbour, table-free");
     constexpr int CW = CH16 > 0 ? CH16 : 1;  // code words a lane holds (the generic form reads its row from memory instead)
     constexpr int LUT_MR = CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB;
@@ -753,7 +761,6 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     // The visited table is half full: move to a table of the growth pool (once per query), or give up with GS_OVERFLOW.
     // Wave-uniform.  The old table is read back with atomics (a CAS that can never succeed), like every other access to it.
     auto grow = [&]() -> bool {
-        if constexpr (WGX) return false;   // (the workgroup form leaves an outgrown tier 2 to the retry launch)
         if (grown || !p.big_visited) return false;
         long long sv = 0;
         if (lane == 0) sv = (long long)gs_fetch_add(p.big_next, 1u);
@@ -790,70 +797,6 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     };
     long long n_visited = 0, n_expanded = 0;
 
-    // ---- WGX: the scored-row slots shared with the expander waves (layout: gs_params.h gx_off_*).  Slot t is managed by lane t:
-    //      gx_node / gx_lvl / gx_ckey are PER-LANE registers (the (node, level) slot t holds, -1 = free; the candidate key it was
-    //      requested for, which decides evictions); everything else here is wave-uniform.
-    int32_t *gx_hdr = nullptr, *gx_ring = nullptr, *gx_slot_node = nullptr, *gx_slot_lvl = nullptr, *gx_slot_state = nullptr;
-    long long *gx_keys = nullptr;
-    const float *gx_lut = nullptr;
-    long long *gx_log = nullptr;    // the first wgx_log entries of the push log wait in LDS until the query ends (no global store per expansion)
-    int32_t gx_node = -1, gx_lvl = 0;
-    long long gx_ckey = 0;
-    int gx_tail = 0;
-    if constexpr (WGX) {
-        char *sh = lds + gx_ctl_bytes(p.D, p.rerankK, p.cand_cap, evict_cap, p.v1_log2);
-        gx_hdr = reinterpret_cast<int32_t *>(sh);
-        gx_ring = reinterpret_cast<int32_t *>(sh + gx_off_ring());
-        gx_slot_node = reinterpret_cast<int32_t *>(sh + gx_off_slot_node());
-        gx_slot_lvl = reinterpret_cast<int32_t *>(sh + gx_off_slot_lvl());
-        gx_slot_state = reinterpret_cast<int32_t *>(sh + gx_off_slot_state());
-        gx_keys = reinterpret_cast<long long *>(sh + gx_off_keys());
-        gx_lut = reinterpret_cast<const float *>(sh + gx_off_lut(p.wgx_slots, p.wgx_kps, p.wgx_log));
-        gx_log = reinterpret_cast<long long *>(sh + gx_off_log(p.wgx_slots, p.wgx_kps));
-    }
-    // slot holding (node, level), or -1
-    auto gx_find = [&](int32_t node, int lvl) -> int {
-        const uint64_t m = gs_ballot(lane < p.wgx_slots && gx_node == node && gx_lvl == lvl);
-        return m ? gs_first(m) : -1;
-    };
-    // Ask the expanders for the scored row of (node, level).  Returns the slot, or -1 when every slot is taken and the request is
-    // only speculative (!must).  must: the popped node itself — evicts the READY slot whose candidate is the worst (its row is
-    // simply requested again should that candidate ever be popped).
-    auto gx_post = [&](int32_t node, int lvl, long long ckey, bool must) -> int {
-        const uint64_t fm = gs_ballot(lane < p.wgx_slots && gx_node == -1);
-        int slot;
-        if (fm) {
-            slot = gs_first(fm);
-        } else if (!must) {
-            return -1;
-        } else {
-            uint64_t rm;
-            for (;;) {
-                rm = gs_ballot(lane < p.wgx_slots && gs_lds_load(gx_slot_state + lane) == GX_READY);
-                if (rm) break;
-                gs_spin_pause();
-            }
-            const bool mine = ((rm >> lane) & 1ull) != 0;
-            const long long mn = gs_wave_min(mine ? gx_ckey : GS_KEY_MAX);
-            slot = gs_first(gs_ballot(mine && gx_ckey == mn));
-        }
-        if (lane == slot) {
-            gx_node = node;
-            gx_lvl = lvl;
-            gx_ckey = ckey;
-        }
-        if (lane == 0) {
-            gx_slot_node[slot] = node;
-            gx_slot_lvl[slot] = lvl;
-            gx_slot_state[slot] = GX_REQUESTED;
-            gx_ring[gx_tail & (GX_RING - 1)] = slot;
-        }
-        gs_barrier();
-        gx_tail++;
-        if (lane == 0) gs_lds_store(gx_hdr + GX_REQ_TAIL, gx_tail);   // release: the expander that sees it sees the slot's fields
-        return slot;
-    };
-
     // tier 2 is cleared by the first probe that needs it (wave-uniform call)
     auto t2_init = [&]() {
         gs_u4 *v4 = reinterpret_cast<gs_u4 *>(vis);
@@ -889,9 +832,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             gs_u4 *v4 = reinterpret_cast<gs_u4 *>(vis);
             for (int i = lane; i < vcap / 4; i += 64) v4[i] = ones;
         }
-        if constexpr (WGX) {
-            // (gx_worker staged the query and built the table from it before this call)
-        } else if constexpr (CH16 == 0) {  // any D: rows of the query matrix need not be 16-byte aligned
+        if constexpr (CH16 == 0) {  // any D: rows of the query matrix need not be 16-byte aligned
             const float *src = p.cq + (int64_t)q * p.D;
             for (int i = lane; i < p.D; i += 64) qs[i] = src[i];
         } else {
@@ -927,7 +868,6 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             gs_u4 we[CW];
             gs_load_row<CW>(p.codes + (int64_t)e * p.M, we);
             if constexpr (LUTR) sc = gs_row_sum_lut<CW>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, we);
-            else if constexpr (WGX) sc = gx_row_sum<CW>(gx_lut, we);
             else sc = gs_row_sum<VSF, CW>(p.codebooks, qs, we);
         }
         sc = gs_finish<VSF>(sc, (VSF == 2) ? p.code_norms[e] : 0.0f, query_mag);
@@ -1053,7 +993,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             long long top, runner_up = GS_KEY_MIN;
             const bool from_lds = s.cand_n > 0;
             if (from_lds) {
-                if (WGX || (p.prefetch && lvl == 0)) top = gs_scan_top2(s.cand, s.cand_n, &idx, &runner_up);
+                if (p.prefetch && lvl == 0) top = gs_scan_top2(s.cand, s.cand_n, &idx, &runner_up);
                 else top = gs_scan_extreme<true>(s.cand, s.cand_n, &idx);
             } else {  // the LDS tier ran dry: the best candidate is somewhere in the spill tier
                 gs_fence();
@@ -1090,20 +1030,6 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 else if (VSF == 2 && p.blocks && lane == row_lines + blk_lines) addr = reinterpret_cast<const char *>(p.fused_norms + (int64_t)rn * p.deg0);
                 if (addr) gs_prefetch_lds(addr, reinterpret_cast<char *>(s.evicted) + 64);
             }
-            // WGX: the popped node's scored row — normally requested one or more iterations ago; if not, now.  Then the row of the
-            // best remaining candidate (popped next unless a neighbour scored below beats it), so that the expanders work on it
-            // while this expansion's probes and pushes run.
-            int gx_slot = -1;
-            if constexpr (WGX) {
-                const int32_t tn = gs_key_node(top);
-                gx_slot = gx_find(tn, lvl);
-                if (PROF) fh[gx_slot < 0 ? 2 : 0] += 1;
-                if (gx_slot < 0) gx_slot = gx_post(tn, lvl, top, true);
-                if (p.wgx_depth > 0 && runner_up != GS_KEY_MIN && !(s.res_n >= rk && gs_key_score(runner_up) < gs_key_score(s.res_min))) {
-                    const int32_t rn = gs_key_node(runner_up);
-                    if (gx_find(rn, lvl) < 0 && gx_post(rn, lvl, runner_up, false) >= 0 && PROF) fh[3] += 1;
-                }
-            }
             GS_PHASE(0);
             // threshold 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the results (the
             // node is expanded all the same); then addTopCandidate :515-530 (BoundedLongHeap.push / updateTop)
@@ -1114,8 +1040,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             }
             if (result && lvl == 0 && p.push_log && lane == 0) {  // the addTopCandidate sequence, for rt_body.h's tie resolution
                 const int n_log = *reinterpret_cast<int *>(s.evicted);
-                if (WGX && n_log < p.wgx_log) gx_log[n_log] = top;
-                else if (n_log < p.push_log_cap) p.push_log[(int64_t)q * p.push_log_cap + n_log] = top;
+                if (n_log < p.push_log_cap) p.push_log[(int64_t)q * p.push_log_cap + n_log] = top;
                 *reinterpret_cast<int *>(s.evicted) = n_log + 1;
             }
             if (!result) {
@@ -1153,37 +1078,13 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 
             // ---- expand: visited.mark + score + candidates.push for every unvisited neighbour ----
             const int32_t node = gs_key_node(top);
-            // (WGX: the expander looks the row up — a node without one gets a row of GX_KEY_NONE)
-            const int32_t *row = WGX ? L.nbrs : gs_level_row(L, node);
+            const int32_t *row = gs_level_row(L, node);
             if (!row) continue;
             const int deg = L.degree;
             const bool fused0 = lvl == 0 && p.blocks != nullptr;
             long long key = 0;
             bool fresh = false;
-            if constexpr (WGX) {
-                (void)row;
-                (void)deg;
-                (void)fused0;
-                // wait for the expander (no spin at all when the row was requested early enough)
-                if (PROF && gs_ballot(lane == 0 && gs_lds_load(gx_slot_state + gx_slot) != GX_READY)) fh[1] += 1;
-                while (!gs_ballot(lane == 0 && gs_lds_load(gx_slot_state + gx_slot) == GX_READY)) gs_spin_pause();
-                key = lane < p.wgx_kps ? gx_keys[gx_slot * p.wgx_kps + lane] : GX_KEY_NONE;
-                if (lane == gx_slot) gx_node = -1;   // the slot is free again (its keys are in registers now)
-                const bool valid = key != GX_KEY_NONE;
-                fresh = visit(valid, gs_key_node(key));
-                if (s.status != GS_OK) break;
-                const uint64_t fm = gs_ballot(fresh);
-                if (fm == 0) continue;
-                n_visited += gs_popc(fm);
-                GS_PHASE(2);
-                // the best fresh neighbour beats everything that is queued: it is popped next — its row cannot be asked for earlier
-                if (p.wgx_depth > 0) {
-                    const long long bf = gs_wave_max(fresh ? key : GS_KEY_MIN);
-                    if ((runner_up == GS_KEY_MIN || bf > runner_up) && !(s.res_n >= rk && gs_key_score(bf) < gs_key_score(s.res_min))) {
-                        if (gx_post(gs_key_node(bf), lvl, bf, false) >= 0 && PROF) fh[3] += 1;
-                    }
-                }
-            } else if constexpr (PAIR) {
+            if constexpr (PAIR) {
                 // ---- pair-lane form: neighbour i is handled by lanes i (low) and i + 32 (high) ----
                 const int ni = lane & 31;
                 const bool hi = lane >= 32;
@@ -1331,13 +1232,6 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         if (s.status != GS_OK) break;
         unsigned long long ptr0 = 0;
         if (PROF) ptr0 = GS_CLOCK();
-        if constexpr (WGX) {
-            // rows requested for this level are of no use on the next one: let the expanders finish them, then free every slot
-            if (lvl > 0) {
-                while (gs_ballot(lane < p.wgx_slots && gx_node != -1 && gs_lds_load(gx_slot_state + lane) != GX_READY)) gs_spin_pause();
-                gx_node = -1;
-            }
-        }
         if (lvl > 0) {  // setEntryPointsFromPreviousLayer :324-331
             for (int base = 0; base < s.res_n && s.status == GS_OK; base += 64) {
                 const bool has = base + lane < s.res_n;
@@ -1357,19 +1251,8 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     unsigned long long pep0 = 0;
     if (PROF) pep0 = GS_CLOCK();
 
-    if constexpr (WGX) {   // the expanders leave their service loop (a request in flight is finished first; gx_worker's barrier waits)
-        if (lane == 0) gs_lds_store(gx_hdr + GX_QUIT, 1);
-    }
     // ---- hand the kept approximate results to the rerank stage ----
     gs_barrier();
-    if constexpr (WGX) {
-        if (p.push_log && s.status == GS_OK) {
-            int n_log = *reinterpret_cast<int *>(s.evicted);
-            n_log = n_log < p.wgx_log ? n_log : p.wgx_log;
-            n_log = n_log < p.push_log_cap ? n_log : p.push_log_cap;
-            for (int i = lane; i < n_log; i += 64) p.push_log[(int64_t)q * p.push_log_cap + i] = gx_log[i];
-        }
-    }
     for (int i = lane; i < p.rerankK; i += 64) {
         const bool have = s.status == GS_OK && i < s.res_n;
         const long long k = have ? s.res[i] : 0;

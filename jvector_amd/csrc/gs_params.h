@@ -86,6 +86,8 @@ struct GsParams {
     int32_t wgx_slots;        // scored-row slots in LDS (<= 64)
     int32_t wgx_kps;          // keys per slot: 32 or 64 (>= every level's degree)
     int32_t wgx_depth;        // candidates below the popped one whose rows are requested ahead of time (0..3)
+    int32_t wgx_lut_m;        // subspaces [0, wgx_lut_m) are scored from the LDS table, the rest table-free from the codebook (a multiple
+                              // of 16, <= M): a shorter table lets two or three workgroups — control waves — share a CU
     int32_t wgx_log;          // addTopCandidate keys buffered in LDS and written to push_log when the query ends (0 = straight to push_log)
     // outputs
     int32_t *out_ids;         // [Q][rerankK] kept approximate results (unordered), -1 padded

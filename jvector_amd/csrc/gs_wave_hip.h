@@ -85,6 +85,31 @@ __device__ __forceinline__ long long gs_wave_reduce64(long long v)
 }
 __device__ __forceinline__ long long gs_wave_max(long long v) { return gs_wave_reduce64<true>(v); }
 __device__ __forceinline__ long long gs_wave_min(long long v) { return gs_wave_reduce64<false>(v); }
+// the same over 32-bit values: one v_max / v_min with a DPP operand per step
+#define GS_HAVE_WAVE_REDUCE32 1
+#define JV_DPP_RED32(T, NAME, EXPR)                                                                  \
+    __device__ __forceinline__ T NAME(T v)                                                           \
+    {                                                                                                \
+        _Pragma("unroll") for (int s_ = 0; s_ < 6; ++s_)                                             \
+        {                                                                                            \
+            T o_;                                                                                    \
+            switch (s_) {                                                                            \
+            case 0: o_ = (T)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false); break; \
+            case 1: o_ = (T)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false); break; \
+            case 2: o_ = (T)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false); break; \
+            case 3: o_ = (T)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false); break; \
+            case 4: o_ = (T)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false); break; \
+            default: o_ = (T)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false); break; \
+            }                                                                                        \
+            v = EXPR;                                                                                \
+        }                                                                                            \
+        return (T)__builtin_amdgcn_readlane((int)v, 63);                                             \
+    }
+JV_DPP_RED32(int32_t, gs_wave_max_i32, (o_ > v ? o_ : v))
+JV_DPP_RED32(int32_t, gs_wave_min_i32, (o_ < v ? o_ : v))
+JV_DPP_RED32(uint32_t, gs_wave_max_u32, (o_ > v ? o_ : v))
+#undef JV_DPP_RED32
+__device__ __forceinline__ int32_t gs_uniform(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 #else
 __device__ __forceinline__ long long gs_shfl(long long v, int src) { return __shfl(v, src, 64); }
 #endif

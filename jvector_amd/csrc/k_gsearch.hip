@@ -15,6 +15,11 @@
 #include "jv_device.h"
 #include "jv_internal.h"
 
+// one wavefront per block: gs_barrier() only has to order the wave's own LDS accesses (a WAVE-scope sync point: no s_barrier and,
+// above all, no s_waitcnt vmcnt(0) behind every fire-and-forget global store), broadcasts go through v_readlane, and the 64-bit
+// max / min reductions of the queue scans through DPP steps instead of ds_bpermute round trips (gs_wave_hip.h)
+#define GS_WAVE_SCOPE_BARRIER 1
+#define GS_UNIFORM_SHFL 1
 #include "gs_wave_hip.h"
 
 #include "gs_body.h"

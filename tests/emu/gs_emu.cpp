@@ -109,6 +109,7 @@ void run_wgx(const Launch &L)
     case 4: jv::gx_worker<VSF, 4>(*L.p, L.worker, L.lds); break;
     case 6: jv::gx_worker<VSF, 6>(*L.p, L.worker, L.lds); break;
     case 8: jv::gx_worker<VSF, 8>(*L.p, L.worker, L.lds); break;
+    case 12: jv::gx_worker<VSF, 12>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }
@@ -136,10 +137,10 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
                               int32_t *out_status, int v1_log2 /* LDS tier of the visited set: log2(slots), 0 = none */, int v1_idbits,
                               int evict_cap /* 0 = GS_EVICT_CAP */, int lutr /* 1: ADC table in registers + LDS (M <= 96) */,
                               int wgx_waves /* > 0: the workgroup form (gx_body.h) with this many waves (2..4 here), M <= 128 */,
-                              int wgx_slots, int wgx_depth)
+                              int wgx_slots, int wgx_depth, int wgx_lut_m /* 0 = M */)
 {
     if (lutr && M > 96) return -4;
-    if (wgx_waves && (M > 128 || M == 80 || M == 112 || wgx_waves < 2 || wgx_waves > emu::MAX_WAVES || lutr)) return -5;
+    if (wgx_waves && (M == 80 || M == 112 || wgx_waves < 2 || wgx_waves > emu::MAX_WAVES || lutr)) return -5;
     if (n_levels < 1 || n_levels > jv::GS_MAX_LEVELS || M % 16 != 0 || D != 8 * M || cand_cap < 128) return -1;
     if (v1_log2 > 0 && !jv::gs_v1_fits(v1_log2, v1_idbits)) return -2;
     jv::GsParams p{};
@@ -182,6 +183,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
         p.wgx_kps = kps;
         p.wgx_depth = wgx_depth;
         p.wgx_log = 16;
+        p.wgx_lut_m = wgx_lut_m > 0 ? wgx_lut_m : M;
         p.prefetch = 0;
     }
     const int ecap = evict_cap > 0 ? evict_cap : jv::GS_EVICT_CAP;
@@ -195,7 +197,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     for (int w = 0; w < workers; ++w) {
         jv::GsParams pw = p;
         pw.Q = (int)((long long)Q * (w + 1) / workers);
-        const size_t lds_bytes = wgx_waves ? jv::gx_lds_bytes(D, rerankK, cand_cap, ecap, v1_log2, wgx_slots, kps, p.wgx_log, M)
+        const size_t lds_bytes = wgx_waves ? jv::gx_lds_bytes(D, rerankK, cand_cap, ecap, v1_log2, wgx_slots, kps, p.wgx_log, p.wgx_lut_m)
                                            : jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0);
         char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
         memset(lds, 0xa5, lds_bytes);

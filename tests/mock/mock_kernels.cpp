@@ -757,7 +757,7 @@ void gs_main(void *a)
 bool graph_search_wgx_supported(int M)
 {
     const int ch = M / 16;
-    return M % 16 == 0 && (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8);
+    return M % 16 == 0 && (ch == 1 || ch == 2 || ch == 3 || ch == 4 || ch == 6 || ch == 8 || ch == 12);
 }
 size_t graph_search_wgx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int logcap, int M)
 {
@@ -774,6 +774,7 @@ void gx_run_ch(const GsLaunch &L)
     case 4: gx_worker<VSF, 4>(*L.p, L.worker, L.lds); break;
     case 6: gx_worker<VSF, 6>(*L.p, L.worker, L.lds); break;
     case 8: gx_worker<VSF, 8>(*L.p, L.worker, L.lds); break;
+    case 12: gx_worker<VSF, 12>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }
@@ -789,7 +790,7 @@ int launch_graph_search_wgx(hipStream_t, int vsf, const GsParams &p, int workgro
 {
     if (p.Q == 0) return JV_OK;
     const int waves = std::min(emu::MAX_WAVES, std::max(2, threads / 64));   // (the emulator runs up to 4 waves per block)
-    const size_t lds_bytes = gx_lds_bytes(p.D, p.rerankK, p.cand_cap, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2, p.wgx_slots, p.wgx_kps, p.wgx_log, p.M);
+    const size_t lds_bytes = gx_lds_bytes(p.D, p.rerankK, p.cand_cap, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2, p.wgx_slots, p.wgx_kps, p.wgx_log, p.wgx_lut_m);
     for (int w = 0; w < workgroups; ++w) {
         GsParams pw = p;
         pw.Q = (int)((long long)p.Q * (w + 1) / workgroups);

@@ -43,7 +43,7 @@ def seq_sum_f32(table, codes):
 
 
 def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vcap_log2=14, spill_cap=8192, cand_cap=256,
-            workers=2, pair=1, v1_log2=9, v1_idbits=None, evict_cap=0, lutr=0, wgx_waves=0, wgx_slots=4, wgx_depth=1):
+            workers=2, pair=1, v1_log2=9, v1_idbits=None, evict_cap=0, lutr=0, wgx_waves=0, wgx_slots=4, wgx_depth=1, wgx_lut_m=0):
     """v1_log2: slots of the visited set's LDS tier (default 512: small enough that the toy searches fill it, freeze it and go
     on in tier 2, so both tiers and the hand-over are exercised by every test); 0 = no LDS tier"""
     N, M, D = codes.shape[0], opq.M, opq.D
@@ -81,7 +81,7 @@ def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vc
     n = emu.gs_emu_search(L, nodes, nbrs, count, degree, entry, entry_level, fp(cb), fp(cq), fp(bmag), fp(codes),
                           fp(code_norms), fp(blocks), fp(fnorms), D, M, deg0, Q, rerank_k, int(vsf), vcap_log2, spill_cap,
                           cand_cap, workers, pair, fp(out_ids), fp(out_sc), fp(stats), fp(status), v1_log2, v1_idbits, evict_cap, lutr,
-                          wgx_waves, wgx_slots, wgx_depth)
+                          wgx_waves, wgx_slots, wgx_depth, wgx_lut_m)
     assert n >= 0, n
     return out_ids, out_sc, stats, status, n
 
@@ -131,7 +131,7 @@ def test_emulated_kernel_matches_oracle(emu, levels, fused, M):
 
 
 @pytest.mark.parametrize("levels,fused,M,deg", [(1, False, 16, 16), (2, True, 32, 16), (2, False, 48, 40), (2, True, 64, 24), (2, True, 96, 32),
-                                                (3, False, 96, 16), (2, True, 128, 64)])
+                                                (3, False, 96, 16), (2, True, 128, 64), (2, True, 192, 32)])
 def test_workgroup_form_matches_oracle(emu, levels, fused, M, deg):
     """WGX (gx_body.h): one query per workgroup, the ADC table in LDS, a control wave + expander waves that score rows ahead of
     time — every M it is built for, degrees up to 64, all three similarity functions, 2..4 waves, 2..8 slots, with and without
@@ -142,9 +142,9 @@ def test_workgroup_form_matches_oracle(emu, levels, fused, M, deg):
     for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
         for rk in (40, 1):
             wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
-            for waves, slots, depth in ((4, 8, 1), (2, 2, 1), (3, 4, 0)):
+            for waves, slots, depth, lut_m in ((4, 8, 1, 0), (2, 2, 1, 16), (3, 4, 0, max(16, (M // 2) // 16 * 16))):
                 ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, wgx_waves=waves,
-                                                 wgx_slots=slots, wgx_depth=depth)
+                                                 wgx_slots=slots, wgx_depth=depth, wgx_lut_m=lut_m)
                 check(ids, sc, st, status, wi, ws, wst)
 
 
@@ -159,6 +159,57 @@ def test_workgroup_form_under_lane_reordering(emu, monkeypatch, order):
         wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
         ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, cand_cap=256, wgx_waves=4,
                                          wgx_slots=slots)
+        check(ids, sc, st, status, wi, ws, wst)
+
+
+def test_workgroup_form_rare_paths(emu):
+    """the control wave's own queue code (gx_body.h gx_control): candidate-tier partitions into the spill tier, an exhaustive search
+    that drains the LDS tier and refills it from the spill tier again and again, every size class of the visited set's LDS tier
+    (absent / tiny / large), overflow reporting"""
+    lv, entry, entry_level, opq, codes, q = problem(7, 4000, 128, 16, 2, deg=24, nq=6)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, None, q, O.COSINE, 400, 400, fused=True)
+    assert (wst[:, 0] - wst[:, 1]).min() > 2 * 256
+    ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.COSINE, 400, True, wgx_waves=4, wgx_slots=6)
+    check(ids, sc, st, status, wi, ws, wst)
+    # exhaustive: rerankK >= N
+    lv, entry, entry_level, opq, codes, q = problem(11, 700, 128, 16, 2, deg=12, nq=4)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, None, q, O.EUCLIDEAN, 800, 800, fused=False)
+    assert (wst[:, 1] > 600).all()
+    ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.EUCLIDEAN, 800, False, vcap_log2=12, wgx_waves=3)
+    check(ids, sc, st, status, wi, ws, wst)
+    # visited tiers
+    lv, entry, entry_level, opq, codes, q = problem(29, 3000, 128, 16, 2, deg=24, nq=8)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    for v1 in (0, 6, 10, 15):
+        for vsf, fused, rk in ((O.COSINE, True, 120), (O.EUCLIDEAN, False, 60), (O.DOT_PRODUCT, True, 1)):
+            wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
+            ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, v1_log2=v1, evict_cap=64,
+                                             wgx_waves=4, wgx_slots=8)
+            check(ids, sc, st, status, wi, ws, wst)
+    # overflow is reported, not hidden
+    lv, entry, entry_level, opq, codes, q = problem(13, 3000, 128, 16, 2, deg=24, nq=4)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    wi, ws, wst = og.search(opq, codes, None, q, O.DOT_PRODUCT, 120, 120, fused=True)
+    for v1 in (0, 6):
+        ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.DOT_PRODUCT, 120, True, vcap_log2=9, v1_log2=v1, wgx_waves=4)
+        assert (status == 1).all() and (ids == -1).all()
+    ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.DOT_PRODUCT, 120, True, spill_cap=32, wgx_waves=4)
+    assert (status == 1).any()
+    check(ids, sc, st, status, wi, ws, wst, allow_overflow=True)
+
+
+def test_workgroup_form_equal_scores(emu):
+    """every vector stored three times: equal PQ codes, equal scores — the pop's tie path (node words decide, NodeQueue.java:125-129)"""
+    lv, entry, entry_level, opq, codes, q = problem(17, 1500, 128, 16, 2, deg=16, nq=6)
+    codes = codes.copy()
+    codes[1::3] = codes[0:-1:3][: len(codes[1::3])]
+    codes[2::3] = codes[0:-2:3][: len(codes[2::3])]
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    for vsf, fused in ((O.COSINE, True), (O.EUCLIDEAN, False)):
+        wi, ws, wst = og.search(opq, codes, None, q, vsf, 60, 60, fused=fused)
+        ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, 60, fused, wgx_waves=4)
         check(ids, sc, st, status, wi, ws, wst)
 
 

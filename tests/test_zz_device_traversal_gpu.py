@@ -41,14 +41,21 @@ def _setup(ctx, seed, N, D, M, levels, use_fused, deg=16):
 def test_device_traversal_matches_oracle(ctx, levels, use_fused, D, M):
     v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 31 * levels + M, 5000, D, M, levels, use_fused)
     og = O.OracleGraph(len(v), lv, entry, entry_level)
-    for vsf in VSF:
-        for rerank, top_k, rk in ((True, 10, 60), (False, 5, 20), (True, 1, 1)):
-            s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=64)
-            ids, sc, stats = s.search(q, vsf, top_k, rk, return_stats=True)
-            wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused)
-            assert np.array_equal(stats, wst), (vsf, rerank)
-            assert np.array_equal(ids, wi), (vsf, rerank, top_k)
-            assert np.array_equal(sc, ws), (vsf, rerank, top_k)
+    try:
+        for vsf in VSF:
+            for rerank, top_k, rk in ((True, 10, 60), (False, 5, 20), (True, 1, 1)):
+                s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=64)
+                wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused)
+                # the one-wave kernels, the workgroup form, and what AUTO picks for a batch this small (the workgroup form)
+                for form in (0, 1, None):
+                    ctx.set_option("gs_wgx", form)
+                    ids, sc, stats = s.search(q, vsf, top_k, rk, return_stats=True)
+                    assert ctx.stat("gs_last_wgx") == (0 if form == 0 else 1)
+                    assert np.array_equal(stats, wst), (vsf, rerank, form)
+                    assert np.array_equal(ids, wi), (vsf, rerank, top_k, form)
+                    assert np.array_equal(sc, ws), (vsf, rerank, top_k, form)
+    finally:
+        ctx.set_option("gs_wgx", None)
 
 
 def test_device_equals_host_on_a_large_batch_with_spills_and_overflow(ctx, monkeypatch):
