@@ -35,6 +35,7 @@ import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -621,6 +622,82 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def batch_sweep(run, ctx, queries, rerank_k, sizes=(1, 16, 256, 4096, 131072)):
+    """End-to-end search time (traversal + rerank + top-k, inputs resident) as a function of the batch size: the engine picks the
+    workgroup form of the traversal (one query per CU, ADC table in LDS) for small batches and the one-wave form (eight queries
+    per CU, table-free) for large ones; each small size is also timed with the other form forced, so the line shows what the choice
+    buys.  Reference harness: jvector-examples/.../benchmarks/LatencyBenchmark.java."""
+    out = []
+    for qb in sizes:
+        if qb > queries.shape[0]:
+            continue
+        qs = queries[:qb]
+        entry = {"queries": qb}
+        for label, opt in (("auto", None), ("one_wave", 0), ("workgroup", 1)):
+            if label != "auto" and qb > 4096:
+                continue
+            ctx.set_option("gs_wgx", opt)
+            try:
+                run(qs, rerank_k)
+                ctx.sync()
+                t0 = time.perf_counter()
+                run(qs, rerank_k)
+                ctx.sync()
+                one = max(time.perf_counter() - t0, 1e-6)
+                reps = max(2, min(100, int(0.4 / one)))
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    run(qs, rerank_k)
+                ctx.sync()
+                dt = (time.perf_counter() - t0) / reps
+                entry[label] = {"ms_per_batch": dt * 1e3, "qps": qb / dt, "form": "workgroup" if ctx.stat("gs_last_wgx") else "one-wave"}
+            finally:
+                ctx.set_option("gs_wgx", None)
+        log(f"[batch sweep] Q={qb}: " + ", ".join(f"{k} {v['ms_per_batch']:.3f} ms ({v['form']})" for k, v in entry.items() if isinstance(v, dict)))
+        out.append(entry)
+    return out
+
+
+SUB_RUNS = (
+    # key, argv, what it is
+    ("hard_case", ["--latent", "64", "--queries", "65536", "--steps", "3", "--warmup", "1", "--no-flat", "--no-cpu-baseline"],
+     "the headline pipeline on a HARDER distribution (intrinsic dimension 64 instead of 32): same code, same builder, same calibration rule"),
+    ("literal_c3", ["--generator", "literal", "--n", "1000000", "--queries", "16384", "--steps", "3", "--warmup", "1", "--cal-queries", "1024",
+                    "--eval-queries", "2048", "--no-flat", "--no-cpu-baseline"],
+     "SURVEY §8d's literal C3 generator (sigma 0.1 per coordinate in all 768 dimensions) at 1M vectors: an isotropic cloud"),
+    ("c2", ["--workload", "c2"], "BASELINE config 2"),
+    ("c5", ["--workload", "c5"], "BASELINE config 5"),
+    ("c4_one_shard", ["--workload", "c4"], "BASELINE config 4, one of its eight 12.5M shards on one GPU"),
+)
+
+
+def run_sub_workloads(keys=None):
+    """The other single-GPU BASELINE configurations and the data-sensitivity points, each as its own process of this script (its
+    own device memory, its own calibration), timed inside the same driver run.  Returns {key: line or {"error": ...}}."""
+    out = {}
+    for key, argv, what in SUB_RUNS:
+        if keys is not None and key not in keys:
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sub-line"] + argv
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env={k: v for k, v in os.environ.items()
+                                                                                                      if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+            lines = [x for x in p.stdout.decode(errors="replace").splitlines() if x.startswith("{")]
+            if p.returncode != 0 or not lines:
+                out[key] = {"error": f"rc {p.returncode}", "stderr_tail": p.stderr.decode(errors="replace")[-600:]}
+            else:
+                sub = json.loads(lines[-1])
+                sub["what"] = what
+                sub["wall_s"] = time.perf_counter() - t0
+                out[key] = sub
+        except Exception as e:  # a sub-run must never take the headline line with it
+            out[key] = {"error": repr(e)}
+        log(f"[sub-run] {key}: " + (f"{out[key].get('value')} {out[key].get('unit')} recall {out[key].get('recall_at_10')} in {time.perf_counter() - t0:.0f} s"
+                                    if "error" not in out[key] else str(out[key])[:300]))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -667,6 +744,11 @@ def main():
                     "full = the float32 rows (INLINE_VECTORS, the headline), nvq = NVQ rows encoded by the engine (the reference's NVQ_VECTORS "
                     "feature: D + 16 S bytes per candidate instead of 4 D); recall is measured against the exact ground truth either way")
     ap.add_argument("--nvq-subvectors", type=int, default=2)
+    ap.add_argument("--generator", choices=["mixture", "literal"], default="mixture", help="c3 data: benchlib.Mixture (latent-L clusters, the "
+                    "headline) or SURVEY §8d's literal generator (1000 Gaussian clusters, sigma 0.1 per coordinate in all D dimensions)")
+    ap.add_argument("--no-sub-workloads", action="store_true", help="default c3 run on one GPU: do not append the other single-GPU BASELINE "
+                    "configs (c2, c5, one c4 shard), the latent-64 hard case, the literal-generator point and the batch-size sweep")
+    ap.add_argument("--sub-line", action="store_true", help="(internal) this process is one of those sub-runs: a lean line, no sub-runs of its own")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-flat", action="store_true", help="graph mode: skip the secondary flat-scan measurement")
     args = ap.parse_args()
@@ -708,7 +790,11 @@ def main():
     # at 10M: 1.132 M QPS at 65536, 1.183 M at 131072 (profiles/r3_f) — the default
     Q = args.queries or (131072 if graph_mode else 256)
     t_setup = time.perf_counter()
-    mix = Mixture(D, seed=5, device=dev, latent=args.latent)
+    if args.generator == "literal":
+        from benchlib import LiteralMixture
+        mix = LiteralMixture(D, seed=5, device=dev)
+    else:
+        mix = Mixture(D, seed=5, device=dev, latent=args.latent)
     base = mix.sample(N, seed=5)
     queries_all = mix.sample(Q * (args.steps + args.warmup), seed=6 + 1000 * rank)
     cal_q = mix.sample(args.cal_queries, seed=7)
@@ -819,7 +905,7 @@ def main():
     eval_gt = ground_truth(J, ctx, vs, eval_q, VSF, K, dense=not args.gt_exact).cpu().numpy()
     gt_s = time.perf_counter() - t0
 
-    ladder = [args.rerank] if args.rerank > 0 else [20, 30, 40, 50, 60, 70, 80, 90, 95, 100, 105, 110, 115, 120, 125, 135, 150, 175, 200, 250, 300, 400, 600, 800, 1600]
+    ladder = [args.rerank] if args.rerank > 0 else [20, 30, 40, 50, 60, 70, 75, 80, 85, 90, 95, 100, 105, 110, 115, 120, 125, 135, 150, 175, 200, 250, 300, 400, 600, 800, 1600]
     rerank_k, cal_rec = calibrate(run, ctx, ladder, cal_q, cal_gt, Q, f"mode={args.mode}")
     if world > 1:  # every rank serves with the same (largest calibrated) rerankK
         t_rk = torch.tensor([rerank_k], dtype=torch.int64, device=dev)
@@ -887,6 +973,9 @@ def main():
 
     rccl_ranks = ranks.rccl_ranks()
     elapsed, total_queries, per_rank = aggregate(ranks, elapsed, Q * args.steps)
+    # the driver's default command (the headline configuration itself) also carries the batch-size sweep and the sub-runs
+    headline_run = (not args.sub_line and not args.no_sub_workloads and N == 10_000_000 and D == 768 and M == 96 and args.latent == 32 and
+                    args.generator == "mixture" and args.rerank == 0 and args.graph == "engine" and args.reranker == "full")
 
     cfg_key = {"n_vectors": N, "dim": D, "pq_subspaces": M, "queries_per_step": Q, "rerankK": rerank_k}
     graph_stats, extra_roof = None, {}
@@ -964,6 +1053,8 @@ def main():
             achieved = bytes_total / (k_ms / 1e3) / 1e9 if k_ms > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel_key, cfg_key),
+                        "traffic_source": ("profiles/traffic_r*.json: rocprofv3 PMC passes of this configuration collected by the builder "
+                                           "(replayed, not measured by this run)") if measured_traffic(kernel_key, cfg_key) is not None else None,
                         "bytes_per_launch": bytes_total / max(k_n, 1), "avg_launch_ms": k_avg_s * 1e3, "launches": k_n,
                         "expansions_per_launch": expansions / max(k_n, 1), "bytes_per_expansion": unit_bytes, "note": note}
         elif flat_info is not None:
@@ -1001,16 +1092,6 @@ def main():
             "reranker": args.reranker, "nvq": nvq_info,
         }
         line.update(extra_roof)
-        # QPS@recall is a strong function of the data's intrinsic dimension: the same run at other latent dimensions, measured
-        # separately on the same code (scripts/gpu_sessions/r3_run_d.sh -> profiles/sensitivity_r3.json), is attached for context
-        try:
-            sens = json.load(open(os.path.join(ROOT, "profiles", "sensitivity_r3.json")))
-            pts = [e for e in sens.get("entries", []) if e.get("n_vectors") == N and e.get("dim") == D and e.get("pq_subspaces") == M
-                   and e.get("latent") != args.latent]
-            if pts and graph_mode:
-                line["sensitivity"] = {"note": sens.get("note"), "points": pts}
-        except Exception:
-            pass
         if graph_mode:
             st = graph_stats
             # which traversal served the queries of this process (jv_hip_ctx_get_stat): device-resident, re-run on the device with a
@@ -1033,6 +1114,8 @@ def main():
                                              "kernel's time; ceiling measured by tools/gather_bench.hip (lane per row, 2 x dwordx4)"}
             if flat_info is not None:
                 line["flat_mode"] = flat_info
+            if world == 1 and args.traversal == "device" and headline_run:
+                line["batch_sweep"] = batch_sweep(run, ctx, timed_q, rerank_k)
         else:
             line["adc_distances_per_s"] = float(N) * total_queries / elapsed
         if world == 1 and not args.no_cpu_baseline:
@@ -1049,6 +1132,18 @@ def main():
             if args.reranker == "nvq" and line.get("cpu_baseline"):
                 line["cpu_baseline"]["note"] = ("the CPU leg reranks with the float32 rows (the headline's reranker): its top-k differs from the "
                                                 "NVQ-reranked GPU top-k by design, so the identical-results flag does not apply to this line")
+        if world == 1 and graph_mode and headline_run:
+            # the headline's own index is released first: the sub-runs are processes of their own on the same GPU
+            for obj in ("searcher", "fused", "graph", "flat2", "rerank_vs", "cv", "vs"):
+                o = locals().get(obj)
+                try:
+                    if o is not None and hasattr(o, "close"):
+                        o.close()
+                except Exception:
+                    pass
+            del base, codes_t
+            torch.cuda.empty_cache()
+            line.update(run_sub_workloads())
         print(json.dumps(line))
     ranks.close()
     if world > 1:

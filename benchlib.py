@@ -42,6 +42,31 @@ class Mixture:
         return out
 
 
+class LiteralMixture:
+    """SURVEY §8d's C3 generator taken literally: 1 000 Gaussian clusters, sigma = 0.1 PER COORDINATE around unit-norm centres in all D
+    dimensions, then L2-normalised.  In 768 dimensions the noise vector has norm 0.1 * sqrt(768) = 2.8 against a centre of norm 1: the
+    result is an isotropic 768-dimensional cloud in which nearest neighbours are barely closer than random pairs — bench.py measures
+    it as `literal_c3` so that the record shows why the headline uses the low-intrinsic-dimension Mixture instead."""
+
+    def __init__(self, D, seed, device, n_clusters=1000, sigma=0.1):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.D, self.device, self.sigma = D, device, sigma
+        self.centers = torch.randn(n_clusters, D, generator=g).to(device)
+        self.centers /= self.centers.norm(dim=1, keepdim=True)
+
+    def sample(self, n, seed, chunk=1_000_000, out=None):
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        if out is None:
+            out = torch.empty(n, self.D, dtype=torch.float32, device=self.device)
+        for s in range(0, n, chunk):
+            e = min(n, s + chunk)
+            cid = torch.randint(0, self.centers.shape[0], (e - s,), generator=g, device=self.device)
+            x = self.centers[cid] + self.sigma * torch.randn(e - s, self.D, generator=g, device=self.device)
+            x /= x.norm(dim=1, keepdim=True)
+            out[s:e] = x
+        return out
+
+
 def train_codebooks(base, M, seed, iters=6, sample=128_000, k=256):
     """Fixed synthetic codebooks: Lloyd iterations per subspace on a sample (the reference trains on <= 128k
     vectors for 6 iterations, ProductQuantization.java:63-64).  Input preparation only — PQ training is a

@@ -22,7 +22,9 @@
 //   7. overflowed lists: PQ diversity scores, NodeArray order, robust prune, row rewrite  launch_pair_scores, bl_rank_sort,
 //                                                                                        launch_retain_diverse, bl_rewrite_row
 // Everything stays on the context's stream; the host reads back one counter per batch (how many lists overflowed).
+#include <algorithm>
 #include <chrono>
+#include <vector>
 
 #include "bl_body.h"
 #include "jv_internal.h"
@@ -229,6 +231,22 @@ int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes
         b->luts = nullptr;
         b->luts_cap = std::min(search_chunk, std::max(1024, 2 * B));
         JV_TRY(jv_hip_luts_create(ctx, b->pq, b->luts_cap, &b->luts));
+    }
+    // The caller's ids index the adjacency rows, the code rows and the vector rows unguarded further down (bl_apply_selection,
+    // bl_pack_row, the back-edge emission) and two inserts of one id would race on one row: an id outside every one of them, or
+    // listed twice, is refused here.  A batch is at most a few hundred KB: a host copy and a sort cost nothing next
+    // to the batch's searches.
+    JV_REQUIRE((long long)B * b->Rf <= 0x7fffffffll, "builder_insert_batch: %d nodes x %d working slots exceed the edge sorter's 32-bit count; split the batch", B, b->Rf);
+    {
+        std::vector<int32_t> h((size_t)B);
+        JV_HIP_CHECK(hipMemcpyAsync(h.data(), nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const long long limit = std::min<long long>({(long long)b->n, (long long)b->codes->count, (long long)b->vectors->count});
+        for (int i = 0; i < B; ++i)
+            JV_REQUIRE(h[(size_t)i] >= 0 && h[(size_t)i] < limit, "builder_insert_batch: node id %d (position %d) outside [0, %lld)", h[(size_t)i], i, limit);
+        std::sort(h.begin(), h.end());
+        for (int i = 1; i < B; ++i)
+            JV_REQUIRE(h[(size_t)i] != h[(size_t)i - 1], "builder_insert_batch: node id %d appears twice in the batch", h[(size_t)i]);
     }
     JV_TRY(b->d_nodes.reserve(sizeof(int32_t) * (size_t)B));
     JV_HIP_CHECK(hipMemcpyAsync(b->d_nodes.ptr, nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));

@@ -500,8 +500,26 @@ int jv_fmt_odgi_read_nvq(const uint8_t *buf, size_t len, const jv_odgi_info *o, 
     const int64_t N = o->id_upper_bound;
     if (o->nvq_inline_off < 0) {
         JV_REQUIRE(range_ok(o->separated_nvq_off, N * o->nvq_stride, len), "odgi_read_nvq: separated NVQ vectors out of range");
-        return nvq_unpack(buf + o->separated_nvq_off, len - (size_t)o->separated_nvq_off, o->nvq_stride, N, o->dimension, o->nvq_S, bytes,
-                          params);
+        // AbstractGraphIndexWriter.writeSeparatedFeatures writes featureSize ZERO bytes for every ordinal the OrdinalMapper omitted:
+        // such a record (its level-0 record is the -1 placeholder, or — whatever the writer — every byte is zero, i.e. a sub-vector
+        // count of 0) is a hole, not a damaged vector: zeroed row, like the inline branch below
+        const int D = o->dimension, S = o->nvq_S;
+        for (int64_t i = 0; i < N; ++i) {
+            const uint8_t *rec = buf + o->separated_nvq_off + i * o->nvq_stride;
+            bool hole = be32(buf + o->l0_off + i * o->record_stride) == -1;
+            if (!hole) {
+                hole = true;
+                for (int64_t b = 0; b < o->nvq_stride && hole; ++b) hole = rec[b] == 0;
+            }
+            if (hole) {
+                if (bytes) memset(bytes + i * D, 0, (size_t)D);
+                if (params) memset(params + i * 4 * S, 0, sizeof(float) * 4 * (size_t)S);
+                continue;
+            }
+            JV_TRY(nvq_unpack(rec, (size_t)o->nvq_stride, o->nvq_stride, 1, D, S, bytes ? bytes + i * D : nullptr,
+                              params ? params + i * 4 * S : nullptr));
+        }
+        return JV_OK;
     }
     // inline: a placeholder record (ordinal -1, jv_fmt_odgi_read_l0) carries unspecified feature bytes -> zeroed row
     const int D = o->dimension, S = o->nvq_S;

@@ -126,7 +126,7 @@ def _header(version, dimension, entry_node, layers, id_upper_bound, feature_orde
 
 
 def write_odgi(version, dimension, l0_neighbors, degree0, entry_node, upper_levels=(), vectors=None, separated=False,
-               codes=None, pq_block=None, omitted=(), level_file_order=None, sequential_placeholders=False,
+               codes=None, pq_block=None, omitted=(), level_file_order=None, sequential_placeholders=False, separated_holes_as_zero_bytes=True,
                placeholder_fill=0, nvq=None, nvq_separated=False) -> bytes:
     """l0_neighbors: list (per ordinal) of neighbour-id lists;  upper_levels: [(degree, {node: [neighbours]}), ...] for
     levels 1..;  vectors: N x D float32 (inline, or separated when `separated`);  codes + pq_block: adds FUSED_PQ (v6);
@@ -215,7 +215,10 @@ def write_odgi(version, dimension, l0_neighbors, degree0, entry_node, upper_leve
     if nvq is not None and nvq_separated:
         sep_off = len(out)
         for i in range(N):
-            out += nvq_record(i, i in omitted)
+            rec = nvq_record(i, i in omitted)
+            # an OMITTED ordinal gets featureSize ZERO bytes (AbstractGraphIndexWriter.writeSeparatedFeatures :298-307), not an empty
+            # QuantizedVector (SeparatedNVQ.writeSeparately :86-94 does that for a present ordinal whose state carries no vector)
+            out += bytes(len(rec)) if (i in omitted and separated_holes_as_zero_bytes) else rec
     if version >= 5:
         header_off = len(out)
         out += hdr(sep_off) + struct.pack(">q", header_off) + _i32(FOOTER_MAGIC)

@@ -161,6 +161,20 @@ def test_odgi_with_nvq_features(separated, version):
     assert np.array_equal(g.nvq_bytes, want_b) and np.array_equal(g.nvq_params.view(np.uint32), want_p.view(np.uint32))
     for i in range(N):
         assert list(g.levels[0][1][i][: len(l0[i])]) == ([] if i in omitted else l0[i])
+    if separated:
+        # both shapes of a hole in the separated block: featureSize zero bytes (an OMITTED ordinal, AbstractGraphIndexWriter
+        # :298-307 — ADVICE r3: the reader used to refuse it) and an empty QuantizedVector (a present ordinal without a vector,
+        # SeparatedNVQ.java:86-94); and a zero record whose level-0 record is NOT a placeholder
+        for kw in (dict(separated_holes_as_zero_bytes=False), dict(sequential_placeholders=True)):
+            gk = F.read_odgi(W.write_odgi(version, D, l0, deg, 0, nvq=(o.mean, S, o.bytes, o.params), nvq_separated=True, omitted=omitted, **kw))
+            assert np.array_equal(gk.nvq_bytes, want_b) and np.array_equal(gk.nvq_params.view(np.uint32), want_p.view(np.uint32))
+        blob = bytearray(W.write_odgi(version, D, l0, deg, 0, nvq=(o.mean, S, o.bytes, o.params), nvq_separated=True))
+        stride = info.nvq_stride
+        blob[info.separated_nvq_off + 7 * stride: info.separated_nvq_off + 8 * stride] = bytes(stride)
+        g7 = F.read_odgi(bytes(blob))
+        w7b, w7p = o.bytes.copy(), o.params.copy()
+        w7b[7], w7p[7] = 0, 0
+        assert np.array_equal(g7.nvq_bytes, w7b) and np.array_equal(g7.nvq_params.view(np.uint32), w7p.view(np.uint32))
     # sequential-writer placeholders carry unspecified inline bytes: the reader hands back a zeroed row
     if not separated:
         data2 = W.write_odgi(version, D, l0, deg, 0, nvq=(o.mean, S, o.bytes, o.params), omitted=omitted, sequential_placeholders=True,
