@@ -666,7 +666,7 @@ SUB_RUNS = (
                     "--eval-queries", "2048", "--no-flat", "--no-cpu-baseline"],
      "SURVEY §8d's literal C3 generator (sigma 0.1 per coordinate in all 768 dimensions) at 1M vectors: an isotropic cloud"),
     ("c2", ["--workload", "c2"], "BASELINE config 2"),
-    ("c5", ["--workload", "c5"], "BASELINE config 5"),
+    ("c5", ["--workload", "c5", "--n", "10000000"], "BASELINE config 5 at its full size (10M x 1536)"),
     ("c4_one_shard", ["--workload", "c4"], "BASELINE config 4, one of its eight 12.5M shards on one GPU"),
 )
 

@@ -215,6 +215,7 @@ def test_two_tier_visited_set_sizes(ctx):
     wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, 150, fused=True)
     s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
     try:
+        ctx.set_option("gs_wgx", 0)   # (the one-wave kernels' tiers; unpinned, a batch this small would go to the workgroup form)
         for v1, vcap in ((None, None), (0, None), (6, None), (9, None), (12, None), (7, 9)):
             ctx.set_option("gs_v1_log2", v1).set_option("gs_vcap_log2", vcap)
             if vcap is not None:
@@ -226,7 +227,7 @@ def test_two_tier_visited_set_sizes(ctx):
             assert ctx.stat("gs_queries_host_fallback") == 0
             assert ctx.stat("gs_last_v1_log2") == (v1 if v1 is not None else 12), (v1, ctx.stat("gs_last_v1_log2"))
     finally:
-        for k in ("gs_v1_log2", "gs_vcap_log2", "gs_grow", "gs_retry"):
+        for k in ("gs_v1_log2", "gs_vcap_log2", "gs_grow", "gs_retry", "gs_wgx"):
             ctx.set_option(k, None)
 
 
