@@ -734,6 +734,9 @@ def main():
                     help="engine graph: largest insert batch (inserts of one batch do not see each other)")
     ap.add_argument("--build-passes", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_PASSES", "1")),
                     help="engine graph: 2 = re-insert every level-0 node against the finished graph (improveConnections for all nodes)")
+    ap.add_argument("--build-improve", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_IMPROVE", "0")),
+                    help="engine graph: passes of improveConnections over every node of a level after its last insert (search the finished "
+                         "graph, MERGE with the node's neighbours, prune, backlink: jv_hip_builder_improve_batch)")
     ap.add_argument("--torch-codebooks", action="store_true", help="codebooks from benchlib's torch Lloyd instead of the engine's "
                     "ProductQuantization.compute (round-1 behaviour)")
     ap.add_argument("--index-cache", default=os.environ.get("JVECTOR_BENCH_INDEX_CACHE", ""), help="npz file: synthetic graph + "
@@ -864,7 +867,7 @@ def main():
             levels, entry, entry_level, nbrs_dev, bstats = build_hierarchical(ctx, pq, cv, base, VSF, max_degree=args.degree,
                                                                                 beam_width=args.build_beam, alpha=args.build_alpha, log=log,
                                                                                 overflow=args.build_overflow, max_batch=args.build_max_batch,
-                                                                                passes=args.build_passes)
+                                                                                passes=args.build_passes, improve=args.build_improve)
             log(f"[build] {dict(bstats)}")
             build_info = {k: (float(v) if isinstance(v, float) else v) for k, v in dict(bstats).items()}
             if args.index_cache and rank == 0:

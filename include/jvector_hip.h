@@ -462,6 +462,11 @@ JV_API int jv_hip_fused_build(jv_ctx *ctx, jv_fused *f, const jv_codes *codes, i
  *                  do not see each other: candidate search over the graph so far (device traversal), robust prune, rows,
  *                  backlinks, re-prune of the lists that outgrow the working width.  Callers grow the batch with the graph
  *                  (prefix doubling: batch <= nodes already inserted).
+ *   improve_batch: improveConnections (GraphIndexBuilder.java:510-560, what cleanup() :472-508 runs before enforceDegree) for
+ *                  `nodes[0..B)`, all of them IN the graph: search the graph as it stands for each node, MERGE the results with the
+ *                  neighbours the node has (ConcurrentNeighborMap.insertDiverse), robust-prune the merged list scored with the PQ
+ *                  diversity function, rewrite the row, backlink its members.  A pass over every level-0 node after the last
+ *                  insert is what the bench's --build-improve does.
  *   finish       : enforceDegree on every list; neighbors_out (nullable; host or device) receives count x maxDegree int32,
  *                  rows packed, -1 padded.  The builder can keep inserting afterwards.
  *   stats        : seconds3 = {search, prune, backlink}; counts5 = {batches, re-pruned lists, inserted nodes, visitedCount and
@@ -473,6 +478,7 @@ JV_API int jv_hip_builder_create(jv_ctx *ctx, const jv_pq *pq, const jv_codes *c
                                  int max_degree, int beam_width, float alpha, float neighbor_overflow, jv_builder **out);
 JV_API int jv_hip_builder_seed(jv_ctx *ctx, jv_builder *b, int32_t node);
 JV_API int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes, int B);
+JV_API int jv_hip_builder_improve_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes, int B);
 JV_API int jv_hip_builder_finish(jv_ctx *ctx, jv_builder *b, int32_t *neighbors_out);
 JV_API int jv_hip_builder_stats(const jv_builder *b, double *seconds3, int64_t *counts5);
 JV_API const int32_t *jv_hip_builder_neighbors_device(const jv_builder *b, int *row_width);

@@ -129,6 +129,7 @@ public final class HipOps {
         static final MethodHandle builderCreate = h("jv_hip_builder_create", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_FLOAT, JAVA_FLOAT, ADDRESS));
         static final MethodHandle builderSeed = h("jv_hip_builder_seed", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT));
         static final MethodHandle builderInsertBatch = h("jv_hip_builder_insert_batch", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT));
+        static final MethodHandle builderImproveBatch = h("jv_hip_builder_improve_batch", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT));
         static final MethodHandle builderFinish = h("jv_hip_builder_finish", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle builderStats = h("jv_hip_builder_stats", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle builderNeighborsDevice = h("jv_hip_builder_neighbors_device", FunctionDescriptor.of(ADDRESS, ADDRESS, ADDRESS));
@@ -423,6 +424,10 @@ public final class HipOps {
     /** B concurrent inserts that do not see each other (nodes: int32 ordinals, off-heap or device memory); callers grow the batch with the graph */
     public static void builderInsertBatch(MemorySegment ctx, MemorySegment builder, MemorySegment nodes, int b) {
         check(st(() -> (int) H.builderInsertBatch.invokeExact(ctx, builder, nodes, b)));
+    }
+    /** improveConnections for nodes already in the graph: search, merge with the node's neighbours, robust prune, backlink */
+    public static void builderImproveBatch(MemorySegment ctx, MemorySegment builder, MemorySegment nodes, int b) {
+        check(st(() -> (int) H.builderImproveBatch.invokeExact(ctx, builder, nodes, b)));
     }
     /** cleanup(): enforceDegree on every list; neighborsOutOrNull receives count x maxDegree int32, rows packed, -1 padded */
     public static void builderFinish(MemorySegment ctx, MemorySegment builder, MemorySegment neighborsOutOrNull) {

@@ -116,6 +116,7 @@ SIGNATURES = {
     "jv_hip_builder_create": (_i, [_p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, C.POINTER(_p)]),
     "jv_hip_builder_seed": (_i, [_p, _p, C.c_int32]),
     "jv_hip_builder_insert_batch": (_i, [_p, _p, _p, _i]),
+    "jv_hip_builder_improve_batch": (_i, [_p, _p, _p, _i]),
     "jv_hip_builder_finish": (_i, [_p, _p, _p]),
     "jv_hip_builder_stats": (_i, [_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "jv_hip_builder_neighbors_device": (_p, [_p, C.POINTER(_i)]),

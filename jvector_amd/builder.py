@@ -38,6 +38,11 @@ class GraphBuilder:
         p, _k = _ptr(nodes, np.int32)
         check(self._lib.jv_hip_builder_insert_batch(self.ctx._h, self._h, p, int(nodes.shape[0])))
 
+    def improve_batch(self, nodes):
+        """improveConnections for nodes that are in the graph: search, merge with the node's neighbours, robust prune, backlink"""
+        p, _k = _ptr(nodes, np.int32)
+        check(self._lib.jv_hip_builder_improve_batch(self.ctx._h, self._h, p, int(nodes.shape[0])))
+
     def finish(self, out):
         """enforceDegree; `out` [n, max_degree] int32 (torch / numpy) receives the packed, -1 padded rows"""
         p, _k = _ptr(out, np.int32)
@@ -63,7 +68,7 @@ class GraphBuilder:
 
 
 def build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=100, alpha=1.2, max_batch=131072, seed=11, log=None,
-                 overflow=1.25, vector_set=None, passes=1):
+                 overflow=1.25, vector_set=None, passes=1, improve=0):
     """One graph level.  vectors: [N, D] float32 tensor on the engine's device (the insert queries).  Prefix-doubling batches: a
     batch never exceeds what the graph already holds.  Returns (neighbors [N, max_degree] int32 tensor, entry_node, BuildStats)."""
     N = int(vectors.shape[0])
@@ -87,6 +92,12 @@ def build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=10
         if log:
             st = b.stats()
             log(f"[build] pass {extra + 1} done: search {st['search_s']:.1f}s prune {st['prune_s']:.1f}s backlink {st['backlink_s']:.1f}s")
+    for extra in range(improve):   # cleanup()'s improveConnections, for every node: search + MERGE with the node's row + prune + backlink
+        for lo in range(0, N, max_batch):
+            b.improve_batch(perm[lo:lo + max_batch].contiguous())
+        if log:
+            st = b.stats()
+            log(f"[build] improve pass {extra + 1} done: search {st['search_s']:.1f}s prune {st['prune_s']:.1f}s backlink {st['backlink_s']:.1f}s")
     out = b.finish(torch.empty((N, max_degree), dtype=torch.int32, device=vectors.device))
     stats = b.stats()
     stats["total_s"] = time.perf_counter() - t0

@@ -58,6 +58,54 @@ BL_FN void bl_pack_row(const BlApplyParams &p, long long b)
     for (; w < p.Rf; ++w) row[w] = -1;
 }
 
+// ---- improveConnections (GraphIndexBuilder.java:510-560: search the FINISHED graph for a node and merge what the search found
+//      with the neighbours the node already has — ConcurrentNeighborMap.insertDiverse, :104-163 — then prune): the merged list ----
+struct BlImproveParams {
+    const int32_t *nodes;   // [B] nodes being improved (each has a row)
+    const int32_t *cand;    // [B][C] search results, best first, -1 padded
+    int B, C, R;
+    const int32_t *nbrs;    // [N][R]
+    int32_t *list;          // [B][R + C]: the node's current row, then the candidates it does not hold yet (never the node itself), -1 padded
+};
+
+// item = b
+BL_FN void bl_improve_list(const BlImproveParams &p, long long b)
+{
+    const int32_t v = p.nodes[b];
+    const int32_t *row = p.nbrs + (long long)v * p.R;
+    int32_t *out = p.list + b * (long long)(p.R + p.C);
+    int w = 0;
+    for (int t = 0; t < p.R && row[t] >= 0; ++t) out[w++] = row[t];
+    const int have = w;
+    for (int c = 0; c < p.C; ++c) {
+        const int32_t x = p.cand[b * (long long)p.C + c];
+        if (x < 0 || x == v) continue;
+        bool dup = false;
+        for (int t = 0; t < have && !dup; ++t) dup = out[t] == x;
+        if (!dup) out[w++] = x;
+    }
+    for (; w < p.R + p.C; ++w) out[w] = -1;
+}
+
+// back edges of rows that were just rewritten: item = b * Rf + j -> edge (row[j] <- nodes[b]); the merge step drops an edge its target
+// already holds
+struct BlRowEdgesParams {
+    const int32_t *nodes;   // [B]
+    int B, Rf, R;
+    const int32_t *nbrs;    // [N][R]
+    unsigned long long *edge_keys;   // [B * Rf]
+    int32_t *edge_src;               // [B * Rf]
+};
+
+BL_FN void bl_row_edges(const BlRowEdgesParams &p, long long item)
+{
+    const int b = (int)(item / p.Rf), j = (int)(item % p.Rf);
+    const int32_t v = p.nodes[b];
+    const int32_t u = p.nbrs[(long long)v * p.R + j];
+    p.edge_keys[item] = u >= 0 ? (((unsigned long long)(uint32_t)u) << 32) | (unsigned long long)(uint32_t)item : ~0ull;
+    p.edge_src[item] = v;
+}
+
 struct BlMergeParams {
     const unsigned long long *keys;  // [E] sorted ascending: edges of one target are consecutive, in edge-index order
     const int32_t *src;              // [E] sorted along

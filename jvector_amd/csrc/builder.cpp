@@ -49,14 +49,14 @@ struct jv_builder {
     int64_t inserted = 0;            // nodes that have a row (the search cannot return more than that)
     int32_t entry = -1;
     Buffer d_nodes, d_q, d_cand, d_csc, d_count, d_sel, d_nsel, d_keys, d_keys2, d_src, d_src2, d_sort_tmp, d_over_tgt, d_over_list, d_over_sc,
-        d_sorted_ids, d_sorted_sc, d_ctr;
+        d_sorted_ids, d_sorted_sc, d_ctr, d_imp_list;
     double search_s = 0, prune_s = 0, backlink_s = 0;
-    int64_t reprunes = 0, batches = 0, visited = 0, expanded = 0;  // (visited / expanded: SearchResult counters summed over the inserts)
+    int64_t reprunes = 0, batches = 0, visited = 0, expanded = 0, improved = 0;  // (visited / expanded: SearchResult counters summed over the inserts)
     std::vector<int64_t> h_stats;
     ~jv_builder()
     {
         for (Buffer *b : {&d_nodes, &d_q, &d_cand, &d_csc, &d_count, &d_sel, &d_nsel, &d_keys, &d_keys2, &d_src, &d_src2, &d_sort_tmp, &d_over_tgt,
-                          &d_over_list, &d_over_sc, &d_sorted_ids, &d_sorted_sc, &d_ctr})
+                          &d_over_list, &d_over_sc, &d_sorted_ids, &d_sorted_sc, &d_ctr, &d_imp_list})
             b->release();
     }
 };
@@ -213,18 +213,29 @@ int jv_hip_builder_seed(jv_ctx *ctx, jv_builder *b, int32_t node)
     return jv_hip_graph_set_entry(b->graph, node, 0);
 }
 
-int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes, int B)
+// ---- shared steps of insert_batch / improve_batch ----
+static int check_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes, int B, const char *what)
 {
-    clear_error();
-    JV_REQUIRE(ctx && b, "builder_insert_batch: NULL argument");
-    JV_REQUIRE(B >= 0, "builder_insert_batch: negative batch");
-    if (B == 0) return JV_OK;
-    JV_REQUIRE(nodes, "builder_insert_batch: NULL nodes");
-    JV_REQUIRE(b->entry >= 0, "builder_insert_batch: seed the graph first (jv_hip_builder_seed)");
-    JV_REQUIRE(ctx->device == b->device, "builder_insert_batch: the builder lives on device %d", b->device);
-    JV_TRY(use_device(ctx->device));
-    const int D = b->pq->D, Rf = b->Rf, R = b->R;
-    const int k = (int)std::min<int64_t>(b->beam, b->inserted);  // cannot ask for more candidates than the graph holds
+    // The caller's ids index the adjacency rows, the code rows and the vector rows unguarded further down (bl_apply_selection,
+    // bl_pack_row, the back-edge emission) and two inserts of one id would race on one row: an id outside every one of them, or
+    // listed twice, is refused here (ADVICE r3).  A batch is at most a few hundred KB: a host copy and a sort cost nothing next
+    // to the batch's searches.
+    JV_REQUIRE((long long)B * b->Rf <= 0x7fffffffll, "%s: %d nodes x %d working slots exceed the edge sorter's 32-bit count; split the batch", what, B, b->Rf);
+    std::vector<int32_t> h((size_t)B);
+    JV_HIP_CHECK(hipMemcpyAsync(h.data(), nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const long long limit = std::min<long long>({(long long)b->n, (long long)b->codes->count, (long long)b->vectors->count});
+    for (int i = 0; i < B; ++i)
+        JV_REQUIRE(h[(size_t)i] >= 0 && h[(size_t)i] < limit, "%s: node id %d (position %d) outside [0, %lld)", what, h[(size_t)i], i, limit);
+    std::sort(h.begin(), h.end());
+    for (int i = 1; i < B; ++i) JV_REQUIRE(h[(size_t)i] != h[(size_t)i - 1], "%s: node id %d appears twice in the batch", what, h[(size_t)i]);
+    return JV_OK;
+}
+
+// 1 + 2: the batch's vectors as queries, GraphSearcher.search(topK = rerankK = k) over the graph built so far -> d_cand / d_csc [B][k]
+static int search_candidates(jv_ctx *ctx, jv_builder *b, const int32_t *d_nodes, int B, int k)
+{
+    const int D = b->pq->D;
     const int search_chunk = 65536;
     if (!b->luts || b->luts_cap < std::min(B, search_chunk)) {
         if (b->luts) jv_hip_luts_destroy(b->luts);
@@ -232,34 +243,12 @@ int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes
         b->luts_cap = std::min(search_chunk, std::max(1024, 2 * B));
         JV_TRY(jv_hip_luts_create(ctx, b->pq, b->luts_cap, &b->luts));
     }
-    // The caller's ids index the adjacency rows, the code rows and the vector rows unguarded further down (bl_apply_selection,
-    // bl_pack_row, the back-edge emission) and two inserts of one id would race on one row: an id outside every one of them, or
-    // listed twice, is refused here (ADVICE r3).  A batch is at most a few hundred KB: a host copy and a sort cost nothing next
-    // to the batch's searches.
-    JV_REQUIRE((long long)B * b->Rf <= 0x7fffffffll, "builder_insert_batch: %d nodes x %d working slots exceed the edge sorter's 32-bit count; split the batch", B, b->Rf);
-    {
-        std::vector<int32_t> h((size_t)B);
-        JV_HIP_CHECK(hipMemcpyAsync(h.data(), nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));
-        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        const long long limit = std::min<long long>({(long long)b->n, (long long)b->codes->count, (long long)b->vectors->count});
-        for (int i = 0; i < B; ++i)
-            JV_REQUIRE(h[(size_t)i] >= 0 && h[(size_t)i] < limit, "builder_insert_batch: node id %d (position %d) outside [0, %lld)", h[(size_t)i], i, limit);
-        std::sort(h.begin(), h.end());
-        for (int i = 1; i < B; ++i)
-            JV_REQUIRE(h[(size_t)i] != h[(size_t)i - 1], "builder_insert_batch: node id %d appears twice in the batch", h[(size_t)i]);
-    }
-    JV_TRY(b->d_nodes.reserve(sizeof(int32_t) * (size_t)B));
-    JV_HIP_CHECK(hipMemcpyAsync(b->d_nodes.ptr, nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));
-    if (!is_device_ptr(nodes)) JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the caller may reuse its buffer
-    const int32_t *d_nodes = (const int32_t *)b->d_nodes.ptr;
     JV_TRY(b->d_cand.reserve(sizeof(int32_t) * (size_t)B * k));
     JV_TRY(b->d_csc.reserve(sizeof(float) * (size_t)B * k));
     JV_TRY(b->d_q.reserve(sizeof(float) * (size_t)std::min(B, search_chunk) * D));
     int32_t *d_cand = (int32_t *)b->d_cand.ptr;
     float *d_csc = (float *)b->d_csc.ptr;
-
-    // ---- 1 + 2. candidate search on the graph built so far ----
-    double t0 = now_s();
+    const double t0 = now_s();
     for (int s = 0; s < B; s += search_chunk) {
         const int bc = std::min(search_chunk, B - s);
         JV_TRY(launch_gather_rows(ctx->stream, b->vectors->d_vecs, b->vectors->count, D, d_nodes + s, bc, (float *)b->d_q.ptr, nullptr, 0));
@@ -273,36 +262,14 @@ int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes
     }
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     b->search_s += now_s() - t0;
+    return JV_OK;
+}
 
-    // ---- 3 + 4. robust prune of every new node's candidates (best first), rows + back edges ----
-    t0 = now_s();
-    JV_TRY(b->d_count.reserve(sizeof(int32_t) * (size_t)B));
-    JV_TRY(b->d_sel.reserve(sizeof(int32_t) * (size_t)B * Rf));
-    JV_TRY(b->d_nsel.reserve(sizeof(int32_t) * (size_t)B));
-    JV_TRY(launch_bl_count_valid(ctx->stream, d_cand, k, (int32_t *)b->d_count.ptr, B));
-    JV_TRY(run_retain(ctx, b, d_cand, d_csc, (const int32_t *)b->d_count.ptr, B, k, (int32_t *)b->d_sel.ptr, (int32_t *)b->d_nsel.ptr));
-    const long long E = (long long)B * Rf;
-    JV_TRY(b->d_keys.reserve(sizeof(unsigned long long) * (size_t)E));
-    JV_TRY(b->d_keys2.reserve(sizeof(unsigned long long) * (size_t)E));
-    JV_TRY(b->d_src.reserve(sizeof(int32_t) * (size_t)E));
-    JV_TRY(b->d_src2.reserve(sizeof(int32_t) * (size_t)E));
-    BlApplyParams ap{};
-    ap.nodes = d_nodes;
-    ap.cand = d_cand;
-    ap.sel = (const int32_t *)b->d_sel.ptr;
-    ap.B = B;
-    ap.C = k;
-    ap.Rf = Rf;
-    ap.R = R;
-    ap.nbrs = b->d_nbrs;
-    ap.edge_keys = (unsigned long long *)b->d_keys.ptr;
-    ap.edge_src = (int32_t *)b->d_src.ptr;
-    JV_TRY(launch_bl_apply_selection(ctx->stream, ap));
-    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    b->prune_s += now_s() - t0;
-
-    // ---- 5 - 7. backlinks ----
-    t0 = now_s();
+// 5 - 7: the E back edges in d_keys / d_src: sorted by (target, edge index), appended while rows have room, overflowed lists re-pruned
+static int link_back_edges(jv_ctx *ctx, jv_builder *b, long long E)
+{
+    const int R = b->R;
+    const double t0 = now_s();
     size_t tmp_bytes = 0;
     JV_TRY(launch_bl_sort_edges(ctx->stream, nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, E, 64));
     JV_TRY(b->d_sort_tmp.reserve(tmp_bytes + 256));
@@ -331,8 +298,126 @@ int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes
     JV_TRY(reprune_lists(ctx, b, mp.over_tgt, mp.over_list, (int)n_over, L));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     b->backlink_s += now_s() - t0;
+    return JV_OK;
+}
+
+static int reserve_edges(jv_builder *b, long long E)
+{
+    JV_TRY(b->d_keys.reserve(sizeof(unsigned long long) * (size_t)E));
+    JV_TRY(b->d_keys2.reserve(sizeof(unsigned long long) * (size_t)E));
+    JV_TRY(b->d_src.reserve(sizeof(int32_t) * (size_t)E));
+    JV_TRY(b->d_src2.reserve(sizeof(int32_t) * (size_t)E));
+    return JV_OK;
+}
+
+int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes, int B)
+{
+    clear_error();
+    JV_REQUIRE(ctx && b, "builder_insert_batch: NULL argument");
+    JV_REQUIRE(B >= 0, "builder_insert_batch: negative batch");
+    if (B == 0) return JV_OK;
+    JV_REQUIRE(nodes, "builder_insert_batch: NULL nodes");
+    JV_REQUIRE(b->entry >= 0, "builder_insert_batch: seed the graph first (jv_hip_builder_seed)");
+    JV_REQUIRE(ctx->device == b->device, "builder_insert_batch: the builder lives on device %d", b->device);
+    JV_TRY(use_device(ctx->device));
+    const int Rf = b->Rf, R = b->R;
+    const int k = (int)std::min<int64_t>(b->beam, b->inserted);  // cannot ask for more candidates than the graph holds
+    JV_TRY(check_batch(ctx, b, nodes, B, "builder_insert_batch"));
+    JV_TRY(b->d_nodes.reserve(sizeof(int32_t) * (size_t)B));
+    JV_HIP_CHECK(hipMemcpyAsync(b->d_nodes.ptr, nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));
+    if (!is_device_ptr(nodes)) JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // the caller may reuse its buffer
+    const int32_t *d_nodes = (const int32_t *)b->d_nodes.ptr;
+
+    // ---- 1 + 2. candidate search on the graph built so far ----
+    JV_TRY(search_candidates(ctx, b, d_nodes, B, k));
+    const int32_t *d_cand = (const int32_t *)b->d_cand.ptr;
+    const float *d_csc = (const float *)b->d_csc.ptr;
+
+    // ---- 3 + 4. robust prune of every new node's candidates (best first), rows + back edges ----
+    double t0 = now_s();
+    JV_TRY(b->d_count.reserve(sizeof(int32_t) * (size_t)B));
+    JV_TRY(b->d_sel.reserve(sizeof(int32_t) * (size_t)B * Rf));
+    JV_TRY(b->d_nsel.reserve(sizeof(int32_t) * (size_t)B));
+    JV_TRY(launch_bl_count_valid(ctx->stream, d_cand, k, (int32_t *)b->d_count.ptr, B));
+    JV_TRY(run_retain(ctx, b, d_cand, d_csc, (const int32_t *)b->d_count.ptr, B, k, (int32_t *)b->d_sel.ptr, (int32_t *)b->d_nsel.ptr));
+    const long long E = (long long)B * Rf;
+    JV_TRY(reserve_edges(b, E));
+    BlApplyParams ap{};
+    ap.nodes = d_nodes;
+    ap.cand = d_cand;
+    ap.sel = (const int32_t *)b->d_sel.ptr;
+    ap.B = B;
+    ap.C = k;
+    ap.Rf = Rf;
+    ap.R = R;
+    ap.nbrs = b->d_nbrs;
+    ap.edge_keys = (unsigned long long *)b->d_keys.ptr;
+    ap.edge_src = (int32_t *)b->d_src.ptr;
+    JV_TRY(launch_bl_apply_selection(ctx->stream, ap));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    b->prune_s += now_s() - t0;
+
+    // ---- 5 - 7. backlinks ----
+    JV_TRY(link_back_edges(ctx, b, E));
     b->inserted += B;
     b->batches += 1;
+    return JV_OK;
+}
+
+// improveConnections for a batch of nodes that are IN the graph (GraphIndexBuilder.java:510-560, called by cleanup() :472-508 — the
+// reference runs it for the nodes of the upper layers and calls a pass over every node "empirically unnecessary"; here any node may be
+// given): search the finished graph for the node (beamWidth candidates, PQ scores), MERGE them with the neighbours it already has
+// (ConcurrentNeighborMap.insertDiverse :104-163 — a re-insertion that REPLACED the row measured worse), score the merged
+// list against the node with the PQ diversity function, robust-prune it to maxDegree, rewrite the row, then backlink the row's members
+// like an insert does (an edge its target already holds is dropped by the merge step).
+int jv_hip_builder_improve_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes, int B)
+{
+    clear_error();
+    JV_REQUIRE(ctx && b, "builder_improve_batch: NULL argument");
+    JV_REQUIRE(B >= 0, "builder_improve_batch: negative batch");
+    if (B == 0) return JV_OK;
+    JV_REQUIRE(nodes, "builder_improve_batch: NULL nodes");
+    JV_REQUIRE(b->entry >= 0 && b->inserted >= 2, "builder_improve_batch: nothing to improve in an empty graph");
+    JV_REQUIRE(ctx->device == b->device, "builder_improve_batch: the builder lives on device %d", b->device);
+    JV_TRY(use_device(ctx->device));
+    const int Rf = b->Rf, R = b->R;
+    const int k = (int)std::min<int64_t>(b->beam, b->inserted);
+    JV_TRY(check_batch(ctx, b, nodes, B, "builder_improve_batch"));
+    JV_TRY(b->d_nodes.reserve(sizeof(int32_t) * (size_t)B));
+    JV_HIP_CHECK(hipMemcpyAsync(b->d_nodes.ptr, nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));
+    if (!is_device_ptr(nodes)) JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int32_t *d_nodes = (const int32_t *)b->d_nodes.ptr;
+    JV_TRY(search_candidates(ctx, b, d_nodes, B, k));
+
+    double t0 = now_s();
+    const int L = R + k;
+    JV_TRY(b->d_imp_list.reserve(sizeof(int32_t) * (size_t)B * L));
+    BlImproveParams ip{};
+    ip.nodes = d_nodes;
+    ip.cand = (const int32_t *)b->d_cand.ptr;
+    ip.B = B;
+    ip.C = k;
+    ip.R = R;
+    ip.nbrs = b->d_nbrs;
+    ip.list = (int32_t *)b->d_imp_list.ptr;
+    JV_TRY(launch_bl_improve_list(ctx->stream, ip));
+    JV_TRY(reprune_lists(ctx, b, d_nodes, ip.list, B, L));
+    const long long E = (long long)B * Rf;
+    JV_TRY(reserve_edges(b, E));
+    BlRowEdgesParams ep{};
+    ep.nodes = d_nodes;
+    ep.B = B;
+    ep.Rf = Rf;
+    ep.R = R;
+    ep.nbrs = b->d_nbrs;
+    ep.edge_keys = (unsigned long long *)b->d_keys.ptr;
+    ep.edge_src = (int32_t *)b->d_src.ptr;
+    JV_TRY(launch_bl_row_edges(ctx->stream, ep));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    b->prune_s += now_s() - t0;
+    JV_TRY(link_back_edges(ctx, b, E));
+    b->batches += 1;
+    b->improved += B;
     return JV_OK;
 }
 

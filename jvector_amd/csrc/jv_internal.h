@@ -362,8 +362,12 @@ struct BlMergeParams;
 struct BlSortParams;
 struct BlRowsParams;
 struct BlOverParams;
+struct BlImproveParams;
+struct BlRowEdgesParams;
 int launch_bl_apply_selection(hipStream_t s, const BlApplyParams &p);
 int launch_bl_backlink_merge(hipStream_t s, const BlMergeParams &p);
+int launch_bl_improve_list(hipStream_t s, const BlImproveParams &p);
+int launch_bl_row_edges(hipStream_t s, const BlRowEdgesParams &p);
 int launch_bl_rank_sort(hipStream_t s, const BlSortParams &p);
 int launch_bl_rewrite_rows(hipStream_t s, const BlRowsParams &p);
 int launch_bl_list_over_degree(hipStream_t s, const BlOverParams &p);

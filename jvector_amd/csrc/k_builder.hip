@@ -50,6 +50,8 @@ int launch_bl_apply_selection(hipStream_t s, const BlApplyParams &p)
     JV_TRY((run_items<BlApplyParams, bl_apply_selection>(s, p, (long long)p.B * p.Rf)));
     return run_items<BlApplyParams, bl_pack_row>(s, p, p.B);
 }
+int launch_bl_improve_list(hipStream_t s, const BlImproveParams &p) { return run_items<BlImproveParams, bl_improve_list>(s, p, p.B); }
+int launch_bl_row_edges(hipStream_t s, const BlRowEdgesParams &p) { return run_items<BlRowEdgesParams, bl_row_edges>(s, p, (long long)p.B * p.Rf); }
 int launch_bl_backlink_merge(hipStream_t s, const BlMergeParams &p) { return run_items<BlMergeParams, bl_backlink_merge>(s, p, p.E); }
 int launch_bl_rank_sort(hipStream_t s, const BlSortParams &p) { return run_items<BlSortParams, bl_rank_sort>(s, p, (long long)p.P * p.L); }
 int launch_bl_rewrite_rows(hipStream_t s, const BlRowsParams &p) { return run_items<BlRowsParams, bl_rewrite_row>(s, p, p.P); }

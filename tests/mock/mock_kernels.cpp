@@ -598,6 +598,16 @@ int launch_bl_apply_selection(hipStream_t, const BlApplyParams &p)
     for (long long b = p.B - 1; b >= 0; --b) bl_pack_row(p, b);
     return JV_OK;
 }
+int launch_bl_improve_list(hipStream_t, const BlImproveParams &p)
+{
+    for (long long b = p.B - 1; b >= 0; --b) bl_improve_list(p, b);
+    return JV_OK;
+}
+int launch_bl_row_edges(hipStream_t, const BlRowEdgesParams &p)
+{
+    for (long long i = (long long)p.B * p.Rf - 1; i >= 0; --i) bl_row_edges(p, i);
+    return JV_OK;
+}
 int launch_bl_backlink_merge(hipStream_t, const BlMergeParams &p)
 {
     for (long long i = p.E - 1; i >= 0; --i) bl_backlink_merge(p, i);

@@ -79,6 +79,29 @@ def check_builder(J, ctx, dev, N, D, M, max_degree, beam, register=None, min_rec
     # re-inserted node's row is rebuilt from one search and loses the back edges the incremental build gave it.  The option stays
     # for experiments; what is pinned is the structural contract and that the graph still serves searches.
     assert r2p >= min_recall - 0.1, r2p
+    # ---- improveConnections over every node (jv_hip_builder_improve_batch: search + MERGE with the row + prune + backlink): the
+    #      structural contract holds, searches do at least as well as before (a merge cannot lose the edges a node had unless the
+    #      prune prefers the new ones), ids are validated
+    nb3, entry3, st3 = build_vamana(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, alpha=1.2, max_batch=2048, improve=1, overflow=2.0)
+    nb3 = nb3.cpu().numpy()
+    assert st3["inserted"] == N and nb3.shape == (N, max_degree) and nb3.max() < N and nb3.min() >= -1
+    for i in range(0, N, max(1, N // 100)):
+        row = nb3[i][nb3[i] >= 0]
+        assert i not in row and len(set(row.tolist())) == len(row) and (nb3[i][:len(row)] >= 0).all() and len(row) >= 1
+    g3 = J.GraphIndex(ctx, N, [(None, nb3)], entry3, 0)
+    ids3, _ = J.GraphSearcher(ctx, g3, pq, cv, None, vs, max_queries=64).search(q, VSF, 10, 4 * beam)
+    r3 = np.mean([len(set(a.tolist()) & set(b.tolist())) / 10.0 for a, b in zip(np.asarray(ids3), gt)])
+    assert r3 >= min_recall, r3
+    from jvector_amd.builder import GraphBuilder
+    gb = GraphBuilder(ctx, pq, cv, vs, VSF, max_degree, beam, 1.2, 2.0)
+    gb.seed(0)
+    gb.insert_batch(np.array([1], np.int32))
+    for bad in (np.array([N], np.int32), np.array([-1], np.int32), np.array([2, 2], np.int32)):
+        with pytest.raises(ValueError):
+            gb.insert_batch(bad)                       # ids outside the node range / listed twice are refused
+        with pytest.raises(ValueError):
+            gb.improve_batch(bad)
+    gb.close()
     # ---- layered variant (GraphIndexBuilder's hierarchy): nested levels of N / maxDegree^l nodes, searched top-down ----
     if True:
         levels, e2, el2, nb0, st2 = build_hierarchical(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, max_batch=2048, min_top=4)
