@@ -734,9 +734,11 @@ def main():
                     help="engine graph: largest insert batch (inserts of one batch do not see each other)")
     ap.add_argument("--build-passes", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_PASSES", "1")),
                     help="engine graph: 2 = re-insert every level-0 node against the finished graph (improveConnections for all nodes)")
-    ap.add_argument("--build-improve", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_IMPROVE", "0")),
+    ap.add_argument("--build-improve", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_IMPROVE", "1")),
                     help="engine graph: passes of improveConnections over every node of a level after its last insert (search the finished "
-                         "graph, MERGE with the node's neighbours, prune, backlink: jv_hip_builder_improve_batch)")
+                         "graph, MERGE with the node's neighbours, prune, backlink: jv_hip_builder_improve_batch).  Measured at 10M (profiles/"
+                         "r4_i): one pass takes the calibrated rerankK from 95 to 75 (108 -> 87 expansions per query, +19 % QPS) for +30 s of "
+                         "build; a second pass changes nothing")
     ap.add_argument("--torch-codebooks", action="store_true", help="codebooks from benchlib's torch Lloyd instead of the engine's "
                     "ProductQuantization.compute (round-1 behaviour)")
     ap.add_argument("--index-cache", default=os.environ.get("JVECTOR_BENCH_INDEX_CACHE", ""), help="npz file: synthetic graph + "
@@ -1075,7 +1077,7 @@ def main():
             "config": {"workload": (f"synthetic {N}x{D} cosine (latent-{args.latent} mixture of 1000 clusters, unit norm), PQ-{M} (k=256, " +
                                     ("torch Lloyd x6" if args.torch_codebooks else "engine ProductQuantization.compute: k-means++ + Lloyd x6") +
                                     " on a 128k sample), " +
-                                    (f"FusedADC graph search: " + (f"layered Vamana graph built by the engine's batched builder (jv_hip_builder_*: PQ scoring, beamWidth {args.build_beam}, alpha {args.build_alpha}, neighborOverflow {args.build_overflow}; maxDegree {args.degree}, {len(levels)} levels of N/{args.degree}^l nodes), "
+                                    (f"FusedADC graph search: " + (f"layered Vamana graph built by the engine's batched builder (jv_hip_builder_*: PQ scoring, beamWidth {args.build_beam}, alpha {args.build_alpha}, neighborOverflow {args.build_overflow}, {args.build_improve} improveConnections pass(es) per level; maxDegree {args.degree}, {len(levels)} levels drawn like getRandomGraphLevel), "
                                                                    if args.graph == "engine" else
                                                                    f"synthetic kNN+robust-prune graph (maxDegree {args.degree}, {len(levels)} nested levels), ") +
                                      f"{'device-resident GraphSearcher (one wavefront per query)' if args.traversal == 'device' else 'host batched GraphSearcher, GPU fused-block scoring'}, rerankK {rerank_k} -> exact rerank -> top-{K}"

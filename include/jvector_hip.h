@@ -483,6 +483,25 @@ JV_API int jv_hip_builder_finish(jv_ctx *ctx, jv_builder *b, int32_t *neighbors_
 JV_API int jv_hip_builder_stats(const jv_builder *b, double *seconds3, int64_t *counts5);
 JV_API const int32_t *jv_hip_builder_neighbors_device(const jv_builder *b, int *row_width);
 JV_API int jv_hip_builder_destroy(jv_builder *b);
+/* The whole LAYERED build in one call (GraphIndexBuilder with addHierarchy): levels drawn per node like getRandomGraphLevel (:562-575:
+ * floor(-ln(U) / ln(maxDegree)), U from a splitmix64 seeded with `seed`; levels with fewer than min_top nodes fold into the one
+ * below), every level a jv_builder of its own (inserts in a seeded random order with prefix-doubling batches of at most max_batch,
+ * then improve_passes passes of improveConnections over every node of the level, then enforceDegree), entry point = the top level's
+ * node most similar to the mean of the top level's vectors.  A function of (data, parameters, seed) only.
+ *   info   : n_levels, entry node / level, level_counts[n_levels] (level 0 = every ordinal)
+ *   level  : level >= 1: nodes_out[count] ascending node ids, neighbors_out[count x maxDegree] global ids (host memory);
+ *            level 0: nodes_out must be NULL, neighbors_out[n x maxDegree] may be host or device memory
+ *   level0_device : the level-0 rows in place, e.g. for jv_hip_fused_build
+ *   stats  : seconds4 = {search, prune, backlink, total}; counts5 as jv_hip_builder_stats, summed over the levels */
+typedef struct jv_layered jv_layered;
+JV_API int jv_hip_build_layered(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, const jv_vectors *vectors, jv_vsf vsf, int max_degree,
+                                int beam_width, float alpha, float neighbor_overflow, int max_batch, int improve_passes, uint64_t seed,
+                                int min_top, jv_layered **out);
+JV_API int jv_hip_layered_info(const jv_layered *l, int *n_levels, int32_t *entry_node, int *entry_level, int64_t *level_counts);
+JV_API int jv_hip_layered_level(jv_ctx *ctx, const jv_layered *l, int level, int32_t *nodes_out, int32_t *neighbors_out);
+JV_API const int32_t *jv_hip_layered_level0_device(const jv_layered *l);
+JV_API int jv_hip_layered_stats(const jv_layered *l, double *seconds4, int64_t *counts5);
+JV_API int jv_hip_layered_destroy(jv_layered *l);
 /* copy blocks (count x maxDegree*M bytes) and / or neighbour rows back; either output may be NULL */
 JV_API int jv_hip_fused_download(jv_ctx *ctx, const jv_fused *f, int64_t first, int64_t count, uint8_t *blocks_out,
                                  int32_t *neighbors_out);

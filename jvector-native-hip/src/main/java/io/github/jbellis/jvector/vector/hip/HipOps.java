@@ -134,6 +134,12 @@ public final class HipOps {
         static final MethodHandle builderStats = h("jv_hip_builder_stats", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle builderNeighborsDevice = h("jv_hip_builder_neighbors_device", FunctionDescriptor.of(ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle builderDestroy = h("jv_hip_builder_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
+        static final MethodHandle buildLayered = h("jv_hip_build_layered", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_FLOAT, JAVA_FLOAT, JAVA_INT, JAVA_INT, JAVA_LONG, JAVA_INT, ADDRESS));
+        static final MethodHandle layeredInfo = h("jv_hip_layered_info", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle layeredLevel = h("jv_hip_layered_level", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS));
+        static final MethodHandle layeredLevel0Device = h("jv_hip_layered_level0_device", FunctionDescriptor.of(ADDRESS, ADDRESS));
+        static final MethodHandle layeredStats = h("jv_hip_layered_stats", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle layeredDestroy = h("jv_hip_layered_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
         // per-context options (a JVM cannot set the JVECTOR_HIP_* environment per context) and counters
         static final MethodHandle ctxSetOption = h("jv_hip_ctx_set_option", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_LONG));
         static final MethodHandle ctxClearOption = h("jv_hip_ctx_clear_option", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS));
@@ -441,6 +447,26 @@ public final class HipOps {
         try { return (MemorySegment) H.builderNeighborsDevice.invokeExact(builder, rowWidthOutOrNull); } catch (Throwable t) { throw new AssertionError(t); }
     }
     public static void builderDestroy(MemorySegment builder) { check(st(() -> (int) H.builderDestroy.invokeExact(builder))); }
+    /** GraphIndexBuilder with addHierarchy in one call: seeded level draws, one Vamana graph per level, improveConnections passes, enforceDegree; outHandle receives the jv_layered */
+    public static void buildLayered(MemorySegment ctx, MemorySegment pq, MemorySegment codes, MemorySegment vectors, int vsf, int maxDegree, int beamWidth,
+                                    float alpha, float neighborOverflow, int maxBatch, int improvePasses, long seed, int minTop, MemorySegment outHandle) {
+        check(st(() -> (int) H.buildLayered.invokeExact(ctx, pq, codes, vectors, vsf, maxDegree, beamWidth, alpha, neighborOverflow, maxBatch, improvePasses, seed, minTop, outHandle)));
+    }
+    /** nLevels / entryNode / entryLevel: one int each; levelCounts: int64[nLevels] (any may be NULL) */
+    public static void layeredInfo(MemorySegment layered, MemorySegment nLevels, MemorySegment entryNode, MemorySegment entryLevel, MemorySegment levelCounts) {
+        check(st(() -> (int) H.layeredInfo.invokeExact(layered, nLevels, entryNode, entryLevel, levelCounts)));
+    }
+    /** level >= 1: nodesOut int32[count] + neighborsOut int32[count x maxDegree] (off-heap); level 0: nodesOut NULL, neighborsOut off-heap or device */
+    public static void layeredLevel(MemorySegment ctx, MemorySegment layered, int level, MemorySegment nodesOut, MemorySegment neighborsOut) {
+        check(st(() -> (int) H.layeredLevel.invokeExact(ctx, layered, level, nodesOut, neighborsOut)));
+    }
+    /** the level-0 rows in device memory (for fusedBuild) */
+    public static MemorySegment layeredLevel0Device(MemorySegment layered) { return st(() -> (MemorySegment) H.layeredLevel0Device.invokeExact(layered)); }
+    /** seconds4 = {search, prune, backlink, total}; counts5 as builderStats, summed over the levels */
+    public static void layeredStats(MemorySegment layered, MemorySegment seconds4, MemorySegment counts5) {
+        check(st(() -> (int) H.layeredStats.invokeExact(layered, seconds4, counts5)));
+    }
+    public static void layeredDestroy(MemorySegment layered) { check(st(() -> (int) H.layeredDestroy.invokeExact(layered))); }
 
     // ---- per-context options / counters, communicator introspection ----
     public static void ctxSetOption(Arena arena, MemorySegment ctx, String name, long value) {

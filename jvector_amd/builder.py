@@ -107,41 +107,45 @@ def build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=10
     return out, entry, stats
 
 
-def _nearest_to_mean(ctx, vs, vectors, nodes, vsf):
-    """the node of `nodes` most similar to the data mean under the index's own similarity function (the reference re-centres
-    its entry point on the medoid: GraphIndexBuilder.java updateEntryPoint / approximateCentroid)"""
-    mean = vectors[nodes[: min(int(nodes.shape[0]), 100000)].long()].mean(0, keepdim=True).contiguous()
-    sc = vs.scores(mean, vsf, nodes.to(torch.int32).view(1, -1).contiguous())
-    return int(nodes[int(torch.as_tensor(sc).reshape(-1).argmax())])
-
-
-def build_hierarchical(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=100, alpha=1.2, seed=11, log=None, min_top=8, **kw):
-    """The reference's layered graph (a node reaches level >= l with probability maxDegree^-l, ml = 1 / ln(degree)): nested random
-    subsets of N / maxDegree^l nodes, each level a Vamana graph over its own nodes.  Returns (levels, entry_node, entry_level,
-    level-0 neighbours on the device, stats) with levels[l] = (None | sorted int32 node ids, int32 neighbour rows) as host arrays."""
-    from .engine import PQVectors
+def build_hierarchical(ctx, pq, pq_vectors, vectors, vsf, max_degree=32, beam_width=100, alpha=1.2, seed=11, log=None, min_top=8, overflow=1.25,
+                       max_batch=131072, improve=0, passes=1, vector_set=None):
+    """The reference's layered graph — jv_hip_build_layered: level draws (getRandomGraphLevel, seeded), one Vamana graph per level,
+    `improve` passes of improveConnections per level, enforceDegree, entry point, all inside the library; this function only moves
+    the result into arrays.  Returns (levels, entry_node, entry_level, level-0 neighbours on the device, stats) with
+    levels[l] = (None | ascending int32 node ids, int32 neighbour rows) as host arrays.  (`passes` > 1 — whole-row re-insertion, measured
+    worse than an improve pass — is only available through build_vamana.)"""
+    if passes != 1:
+        raise ValueError("build_hierarchical: re-insertion passes are a build_vamana experiment; use improve=")
     dev, N = vectors.device, int(vectors.shape[0])
-    perm = torch.randperm(N, generator=torch.Generator(device="cpu").manual_seed(seed + 1)).to(dev)
-    vs0 = VectorSet(ctx, vectors)
-    nb0, entry, stats = build_vamana(ctx, pq, pq_vectors, vectors, vsf, max_degree, beam_width, alpha, seed=seed, log=log, vector_set=vs0, **kw)
-    levels, entry_level, all_stats = [(None, nb0.cpu().numpy())], 0, {"level0": dict(stats)}
-    n = N // max_degree
-    while n >= min_top:
-        nodes = torch.sort(perm[:n]).values          # nested: perm[:n_{l+1}] is a subset of perm[:n_l]
-        sub_vec = vectors[nodes].contiguous()
-        sub_vs = VectorSet(ctx, sub_vec)
-        sub_cv = PQVectors.encode_and_build(ctx, pq, sub_vs)      # same codes as level 0's rows
-        nbl, _, st = build_vamana(ctx, pq, sub_cv, sub_vec, vsf, max_degree, beam_width, alpha, seed=seed + len(levels), log=log,
-                                  vector_set=sub_vs, **kw)
-        glob = torch.where(nbl >= 0, nodes[nbl.clamp(min=0).long()].to(torch.int32), nbl)
-        levels.append((nodes.to(torch.int32).cpu().numpy(), glob.cpu().numpy()))
-        all_stats[f"level{len(levels) - 1}"] = dict(st)
-        entry_level = len(levels) - 1
-        entry = _nearest_to_mean(ctx, vs0, vectors, nodes, vsf)   # top level's node closest to the data mean
-        n //= max_degree
-    total = BuildStats(stats)
-    for k in ("search_s", "prune_s", "backlink_s", "total_s", "reprunes", "batches", "visited", "expanded", "inserted"):
-        total[k] = sum(v[k] for v in all_stats.values())
-    total["nodes_per_s"] = N / total["total_s"]
-    total["levels"] = [int(N)] + [int(l[0].shape[0]) for l in levels[1:]]
-    return levels, entry, entry_level, nb0, total
+    vs = vector_set if vector_set is not None else VectorSet(ctx, vectors)
+    lib = ctx._lib
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    check(lib.jv_hip_build_layered(ctx._h, pq._h, pq_vectors._h, vs._h, int(vsf), int(max_degree), int(beam_width), float(alpha), float(overflow),
+                                   int(max_batch), int(improve), int(seed), int(min_top), C.byref(h)))
+    try:
+        n_lv, entry, entry_level = C.c_int(), C.c_int32(), C.c_int()
+        check(lib.jv_hip_layered_info(h, C.byref(n_lv), C.byref(entry), C.byref(entry_level), None))
+        counts = (C.c_int64 * n_lv.value)()
+        check(lib.jv_hip_layered_info(h, None, None, None, counts))
+        nb0 = torch.empty((N, max_degree), dtype=torch.int32, device=dev)
+        p0, _k = _ptr(nb0, np.int32)
+        check(lib.jv_hip_layered_level(ctx._h, h, 0, None, p0))
+        levels = [(None, nb0.cpu().numpy())]
+        for l in range(1, n_lv.value):
+            ids = np.empty(int(counts[l]), np.int32)
+            rows = np.empty((int(counts[l]), max_degree), np.int32)
+            check(lib.jv_hip_layered_level(ctx._h, h, l, ids.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p)))
+            levels.append((ids, rows))
+        sec, cnt = (C.c_double * 4)(), (C.c_int64 * 5)()
+        check(lib.jv_hip_layered_stats(h, sec, cnt))
+    finally:
+        lib.jv_hip_layered_destroy(h)
+    total = BuildStats(search_s=sec[0], prune_s=sec[1], backlink_s=sec[2], batches=int(cnt[0]), reprunes=int(cnt[1]), inserted=int(cnt[2]),
+                       visited=int(cnt[3]), expanded=int(cnt[4]), total_s=sec[3], wall_s=time.perf_counter() - t0)
+    total["nodes_per_s"] = N / max(total["total_s"], 1e-9)
+    total["avg_degree"] = float((nb0 >= 0).sum().item()) / N
+    total["levels"] = [int(c) for c in counts]
+    if log:
+        log(f"[build] layered: {total['levels']} nodes per level in {total['total_s']:.1f}s (search {sec[0]:.1f}s prune {sec[1]:.1f}s backlink {sec[2]:.1f}s)")
+    return levels, int(entry.value), int(entry_level.value), nb0, total

@@ -24,9 +24,12 @@
 // Everything stays on the context's stream; the host reads back one counter per batch (how many lists overflowed).
 #include <algorithm>
 #include <chrono>
+#include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "bl_body.h"
+#include "gs_params.h"
 #include "jv_internal.h"
 #include "rd_params.h"
 
@@ -478,6 +481,278 @@ int jv_hip_builder_stats(const jv_builder *b, double *seconds3, int64_t *counts5
         counts5[3] = b->visited;
         counts5[4] = b->expanded;
     }
+    return JV_OK;
+}
+
+// ---- the whole layered build behind one call (verdict r3 #7: the hierarchy used to be assembled by the Python mirror) ----
+// GraphIndexBuilder with addHierarchy: a node's top level is floor(-ln(U) / ln(maxDegree)) (getRandomGraphLevel :562-575, HNSW's
+// sampling), a node is present on every level up to its own, each level is a Vamana graph over its nodes (here: one jv_builder per
+// level — inserts in a seeded random order, prefix-doubling batches — then `improve_passes` passes of improveConnections over every
+// node of the level, then enforceDegree), the entry point is a node of the top level (here: the one most similar to the mean of the
+// top level's vectors under the index's own similarity function — the reference re-centres its entry on the medoid).  The draws
+// come from a seeded splitmix64 instead of the reference's SplittableRandom: the build is a function of (data, parameters, seed).
+struct jv_layered {
+    int device = 0, max_degree = 0;
+    int64_t n = 0;
+    int32_t entry = -1;
+    int entry_level = 0;
+    std::vector<std::vector<int32_t>> nodes;   // level >= 1: ascending node ids (level 0: every ordinal, not stored)
+    std::vector<std::vector<int32_t>> nbrs;    // level >= 1: [count][max_degree] global ids, rows packed, -1 padded (host)
+    int32_t *d_level0 = nullptr;               // [n][max_degree] (device)
+    double seconds[3] = {0, 0, 0}, total_s = 0;
+    int64_t counts[5] = {0, 0, 0, 0, 0};
+    std::vector<int64_t> level_counts;
+};
+
+namespace {
+inline uint64_t splitmix64(uint64_t &s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// a seeded permutation of 0..n-1 (Fisher-Yates)
+std::vector<int32_t> seeded_permutation(int64_t n, uint64_t seed)
+{
+    std::vector<int32_t> p((size_t)n);
+    for (int64_t i = 0; i < n; ++i) p[(size_t)i] = (int32_t)i;
+    uint64_t st = seed;
+    for (int64_t i = n - 1; i > 0; --i) {
+        const int64_t j = (int64_t)(splitmix64(st) % (uint64_t)(i + 1));
+        std::swap(p[(size_t)i], p[(size_t)j]);
+    }
+    return p;
+}
+
+// one level: a builder over (codes, vectors) — n_l nodes with LOCAL ids 0..n_l-1 — inserts in `order`, improve passes, enforceDegree;
+// rows to out_rows (host or device memory, n_l x max_degree)
+int build_one_level(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, const jv_vectors *vectors, jv_vsf vsf, int max_degree, int beam,
+                    float alpha, float overflow, int max_batch, int improve_passes, uint64_t seed, int32_t *out_rows, jv_layered *acc)
+{
+    const int64_t n = codes->count;
+    jv_builder *b = nullptr;
+    JV_TRY(jv_hip_builder_create(ctx, pq, codes, vectors, vsf, max_degree, beam, alpha, overflow, &b));
+    auto run = [&]() -> int {
+        const std::vector<int32_t> perm = seeded_permutation(n, seed);
+        JV_TRY(jv_hip_builder_seed(ctx, b, perm[0]));
+        int64_t lo = 1;
+        while (lo < n) {   // prefix doubling: a batch never exceeds what the graph already holds
+            const int64_t hi = std::min<int64_t>(n, lo + std::min<int64_t>(max_batch, lo));
+            JV_TRY(jv_hip_builder_insert_batch(ctx, b, perm.data() + lo, (int)(hi - lo)));
+            lo = hi;
+        }
+        for (int pass = 0; pass < improve_passes && n >= 2; ++pass)
+            for (int64_t s = 0; s < n; s += max_batch)
+                JV_TRY(jv_hip_builder_improve_batch(ctx, b, perm.data() + s, (int)std::min<int64_t>(max_batch, n - s)));
+        JV_TRY(jv_hip_builder_finish(ctx, b, out_rows));
+        double sec[3];
+        int64_t cnt[5];
+        JV_TRY(jv_hip_builder_stats(b, sec, cnt));
+        for (int i = 0; i < 3; ++i) acc->seconds[i] += sec[i];
+        for (int i = 0; i < 5; ++i) acc->counts[i] += cnt[i];
+        return JV_OK;
+    };
+    const int rc = run();
+    jv_hip_builder_destroy(b);
+    return rc;
+}
+}  // namespace
+
+int jv_hip_build_layered(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, const jv_vectors *vectors, jv_vsf vsf, int max_degree,
+                         int beam_width, float alpha, float neighbor_overflow, int max_batch, int improve_passes, uint64_t seed, int min_top,
+                         jv_layered **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && pq && codes && vectors && out, "build_layered: NULL argument");
+    *out = nullptr;
+    JV_FLOAT_ROWS(vectors, "build_layered");
+    JV_REQUIRE(max_batch >= 1 && improve_passes >= 0 && improve_passes <= 8 && min_top >= 1, "build_layered: bad schedule (max_batch %d, improve passes %d, min_top %d)",
+               max_batch, improve_passes, min_top);
+    JV_REQUIRE(max_degree >= 2 && max_degree <= 64, "build_layered: maxDegree %d outside 2..64", max_degree);
+    JV_REQUIRE(codes->count >= 1 && codes->count <= 0x7fffffffLL && vectors->count >= codes->count, "build_layered: %lld nodes", (long long)codes->count);
+    JV_TRY(use_device(ctx->device));
+    const double t_start = now_s();
+    const int64_t n = codes->count;
+    const int D = pq->D;
+    jv_layered *L = new jv_layered();
+    L->device = ctx->device;
+    L->max_degree = max_degree;
+    L->n = n;
+    auto fail = [&](int rc) {
+        jv_hip_layered_destroy(L);
+        return rc;
+    };
+    // ---- levels: getRandomGraphLevel per node (seeded), levels too small to be worth a graph (< min_top nodes) fold into the one below
+    std::vector<int8_t> lvl((size_t)n);
+    {
+        const double ml = max_degree == 1 ? 1.0 : 1.0 / std::log((double)max_degree);
+        uint64_t st = seed ^ 0xA5A5A5A55A5A5A5Aull;
+        for (int64_t i = 0; i < n; ++i) {
+            double u;
+            do {
+                u = (double)(splitmix64(st) >> 11) * (1.0 / 9007199254740992.0);
+            } while (u == 0.0);   // log(0) is undefined
+            const int l = (int)(-std::log(u) * ml);
+            lvl[(size_t)i] = (int8_t)std::min(l, 31);
+        }
+    }
+    int top = 0;
+    {
+        int64_t at_least[33] = {0};
+        for (int64_t i = 0; i < n; ++i)
+            for (int l = 0; l <= lvl[(size_t)i]; ++l) at_least[l]++;
+        while (top + 1 < GS_MAX_LEVELS && top + 1 <= 31 && at_least[top + 1] >= min_top) ++top;
+    }
+    L->nodes.resize((size_t)top + 1);
+    L->nbrs.resize((size_t)top + 1);
+    L->level_counts.assign((size_t)top + 1, 0);
+    L->level_counts[0] = n;
+    for (int l = 1; l <= top; ++l) {
+        for (int64_t i = 0; i < n; ++i)
+            if (lvl[(size_t)i] >= l) L->nodes[(size_t)l].push_back((int32_t)i);
+        L->level_counts[(size_t)l] = (int64_t)L->nodes[(size_t)l].size();
+    }
+    // ---- level 0 over every node, rows straight into device memory (jv_hip_fused_build reads them there) ----
+    if (hipMalloc((void **)&L->d_level0, sizeof(int32_t) * (size_t)n * max_degree) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("build_layered: cannot allocate the %lld x %d level-0 rows", (long long)n, max_degree);
+        return fail(JV_ERR_OOM);
+    }
+    int rc = build_one_level(ctx, pq, codes, vectors, vsf, max_degree, beam_width, alpha, neighbor_overflow, max_batch, improve_passes, seed,
+                             L->d_level0, L);
+    if (rc != JV_OK) return fail(rc);
+    // ---- upper levels: the level's rows of the vectors gathered into a set of their own, encoded with the same quantizer (the same
+    //      codes as their level-0 rows), a builder over LOCAL ids, rows mapped back to global ids ----
+    for (int l = 1; l <= top; ++l) {
+        const std::vector<int32_t> &ids = L->nodes[(size_t)l];
+        const int64_t nl = (int64_t)ids.size();
+        jv_vectors *sv = nullptr;
+        jv_codes *sc = nullptr;
+        Buffer d_ids;
+        auto level = [&]() -> int {
+            JV_TRY(jv_hip_vectors_create(ctx, nl, D, &sv));
+            JV_TRY(d_ids.reserve(sizeof(int32_t) * (size_t)nl));
+            JV_HIP_CHECK(hipMemcpyAsync(d_ids.ptr, ids.data(), sizeof(int32_t) * (size_t)nl, hipMemcpyHostToDevice, ctx->stream));
+            for (int64_t s0 = 0; s0 < nl; s0 += (1 << 20)) {
+                const int pc = (int)std::min<int64_t>(1 << 20, nl - s0);
+                JV_TRY(launch_gather_rows(ctx->stream, vectors->d_vecs, vectors->count, D, (const int32_t *)d_ids.ptr + s0, pc,
+                                          sv->d_vecs + (size_t)s0 * D, nullptr, 0));
+            }
+            JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            JV_TRY(jv_hip_vectors_invalidate(sv));
+            JV_TRY(jv_hip_codes_create(ctx, pq, nl, &sc));
+            JV_TRY(jv_hip_pq_encode_into(ctx, pq, sv, 0, nl, sc));
+            std::vector<int32_t> &rows = L->nbrs[(size_t)l];
+            rows.assign((size_t)nl * max_degree, -1);
+            JV_TRY(build_one_level(ctx, pq, sc, sv, vsf, max_degree, beam_width, alpha, neighbor_overflow, max_batch, improve_passes,
+                                   seed + (uint64_t)l, rows.data(), L));
+            for (int32_t &x : rows)
+                if (x >= 0) x = ids[(size_t)x];
+            return JV_OK;
+        };
+        rc = level();
+        if (sc) jv_hip_codes_destroy(sc);
+        if (sv) jv_hip_vectors_destroy(sv);
+        d_ids.release();
+        if (rc != JV_OK) return fail(rc);
+    }
+    // ---- entry point: the top level's node most similar to the mean of (up to 4096 of) the top level's vectors ----
+    L->entry_level = top;
+    if (top == 0) {
+        L->entry = seeded_permutation(n, seed)[0];   // a flat graph is entered where its construction started
+    } else {
+        const std::vector<int32_t> &ids = L->nodes[(size_t)top];
+        const int cnt = (int)std::min<size_t>(ids.size(), 4096);
+        std::vector<float> rowsf((size_t)cnt * D), mean((size_t)D);
+        Buffer d_ids, d_rows, d_sc;
+        auto pick = [&]() -> int {
+            JV_TRY(d_ids.reserve(sizeof(int32_t) * ids.size()));
+            JV_TRY(d_rows.reserve(sizeof(float) * (size_t)cnt * D));
+            JV_TRY(d_sc.reserve(sizeof(float) * ids.size()));
+            JV_HIP_CHECK(hipMemcpyAsync(d_ids.ptr, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, ctx->stream));
+            JV_TRY(launch_gather_rows(ctx->stream, vectors->d_vecs, vectors->count, D, (const int32_t *)d_ids.ptr, cnt, (float *)d_rows.ptr, nullptr, 0));
+            JV_HIP_CHECK(hipMemcpyAsync(rowsf.data(), d_rows.ptr, sizeof(float) * (size_t)cnt * D, hipMemcpyDeviceToHost, ctx->stream));
+            JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            for (int d = 0; d < D; ++d) {
+                double acc = 0.0;
+                for (int r = 0; r < cnt; ++r) acc += (double)rowsf[(size_t)r * D + d];
+                mean[(size_t)d] = (float)(acc / cnt);
+            }
+            std::vector<float> sc(ids.size());
+            JV_TRY(jv_hip_exact_scores(ctx, vectors, mean.data(), 1, vsf, (const int32_t *)d_ids.ptr, (int)ids.size(), (float *)d_sc.ptr));
+            JV_HIP_CHECK(hipMemcpyAsync(sc.data(), d_sc.ptr, sizeof(float) * ids.size(), hipMemcpyDeviceToHost, ctx->stream));
+            JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            size_t best = 0;
+            for (size_t i = 1; i < ids.size(); ++i)
+                if (sc[i] > sc[best]) best = i;   // (a NaN never wins; ties keep the smaller id)
+            L->entry = ids[best];
+            return JV_OK;
+        };
+        rc = pick();
+        d_ids.release();
+        d_rows.release();
+        d_sc.release();
+        if (rc != JV_OK) return fail(rc);
+    }
+    L->total_s = now_s() - t_start;
+    *out = L;
+    return JV_OK;
+}
+
+int jv_hip_layered_info(const jv_layered *l, int *n_levels, int32_t *entry_node, int *entry_level, int64_t *level_counts)
+{
+    clear_error();
+    JV_REQUIRE(l, "layered_info: NULL argument");
+    if (n_levels) *n_levels = (int)l->level_counts.size();
+    if (entry_node) *entry_node = l->entry;
+    if (entry_level) *entry_level = l->entry_level;
+    if (level_counts)
+        for (size_t i = 0; i < l->level_counts.size(); ++i) level_counts[i] = l->level_counts[i];
+    return JV_OK;
+}
+
+int jv_hip_layered_level(jv_ctx *ctx, const jv_layered *l, int level, int32_t *nodes_out, int32_t *neighbors_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && l, "layered_level: NULL argument");
+    JV_REQUIRE(level >= 0 && level < (int)l->level_counts.size(), "layered_level: level %d of %d", level, (int)l->level_counts.size());
+    if (level == 0) {
+        JV_REQUIRE(!nodes_out, "layered_level: level 0 holds every ordinal (nodes_out must be NULL)");
+        if (neighbors_out) {
+            JV_REQUIRE(ctx->device == l->device, "layered_level: the graph lives on device %d", l->device);
+            JV_TRY(use_device(ctx->device));
+            JV_HIP_CHECK(hipMemcpyAsync(neighbors_out, l->d_level0, sizeof(int32_t) * (size_t)l->n * l->max_degree, hipMemcpyDefault, ctx->stream));
+            JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        return JV_OK;
+    }
+    const std::vector<int32_t> &ids = l->nodes[(size_t)level], &rows = l->nbrs[(size_t)level];
+    if (nodes_out) memcpy(nodes_out, ids.data(), sizeof(int32_t) * ids.size());
+    if (neighbors_out) memcpy(neighbors_out, rows.data(), sizeof(int32_t) * rows.size());
+    return JV_OK;
+}
+
+const int32_t *jv_hip_layered_level0_device(const jv_layered *l) { return l ? l->d_level0 : nullptr; }
+
+int jv_hip_layered_stats(const jv_layered *l, double *seconds4, int64_t *counts5)
+{
+    clear_error();
+    JV_REQUIRE(l, "layered_stats: NULL argument");
+    if (seconds4) {
+        for (int i = 0; i < 3; ++i) seconds4[i] = l->seconds[i];
+        seconds4[3] = l->total_s;
+    }
+    if (counts5)
+        for (int i = 0; i < 5; ++i) counts5[i] = l->counts[i];
+    return JV_OK;
+}
+
+int jv_hip_layered_destroy(jv_layered *l)
+{
+    if (!l) return JV_OK;
+    if (l->d_level0) (void)hipFree(l->d_level0);
+    delete l;
     return JV_OK;
 }
 

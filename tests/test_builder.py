@@ -115,6 +115,19 @@ def check_builder(J, ctx, dev, N, D, M, max_degree, beam, register=None, min_rec
         ids2, _ = J.GraphSearcher(ctx, g2, pq, cv, None, vs, max_queries=64).search(q, VSF, 10, 4 * beam)
         r2 = np.mean([len(set(a.tolist()) & set(b.tolist())) / 10.0 for a, b in zip(np.asarray(ids2), gt)])
         assert r2 >= min_recall, r2
+        # the whole hierarchy comes from ONE C-ABI call (jv_hip_build_layered: level draws, per-level builders, improve passes, entry
+        # point): a second call with the same seed — what any other FFI caller would get — is byte-identical, another seed is not
+        again = build_hierarchical(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, max_batch=2048, min_top=4)
+        assert again[1] == e2 and again[2] == el2 and len(again[0]) == len(levels)
+        for (ia, na), (ib, nb_) in zip(again[0], levels):
+            assert (ia is None and ib is None) or np.array_equal(ia, ib)
+            assert np.array_equal(na, nb_)
+        other = build_hierarchical(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, max_batch=2048, min_top=4, seed=12, improve=1)
+        assert not np.array_equal(other[0][0][1], levels[0][1]) and other[4]["levels"][0] == N
+        g3l = J.GraphIndex(ctx, N, other[0], other[1], other[2])
+        ids3l, _ = J.GraphSearcher(ctx, g3l, pq, cv, None, vs, max_queries=64).search(q, VSF, 10, 4 * beam)
+        r3l = np.mean([len(set(a.tolist()) & set(b.tolist())) / 10.0 for a, b in zip(np.asarray(ids3l), gt)])
+        assert r3l >= min_recall, r3l
     return stats, recall
 
 
