@@ -233,9 +233,9 @@ def cpu_baseline_build(cb, D, M, codes_h, nbrs_h, entry, base_dev, vsf, max_degr
 # helpers
 # ------------------------------------------------------------------------------------------------------------------
 def measured_traffic(kernel_key, cfg):
-    """HBM bytes per launch from the rocprofv3 PMC summary (profiles/traffic_r3.json, else traffic_r2.json) — only if it was collected on THIS
+    """HBM bytes per launch from the rocprofv3 PMC summary (profiles/traffic_r4.json, else traffic_r3.json / traffic_r2.json) — only if it was collected on THIS
     configuration (same kernel, N, D, M, queries per step, rerankK); else None."""
-    for name in ("traffic_r3.json", "traffic_r2.json"):   # the newest summary whose configuration matches
+    for name in ("traffic_r4.json", "traffic_r3.json", "traffic_r2.json"):   # the newest summary whose configuration matches
         try:
             table = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
