@@ -628,7 +628,7 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def batch_sweep(run, ctx, queries, rerank_k, sizes=(1, 16, 256, 4096, 131072)):
+def batch_sweep(run, ctx, queries, rerank_k, sizes=(1, 16, 256, 1024, 4096, 131072)):
     """End-to-end search time (traversal + rerank + top-k, inputs resident) as a function of the batch size: the engine picks the
     workgroup form of the traversal (one query per CU, ADC table in LDS) for small batches and the one-wave form (eight queries
     per CU, table-free) for large ones; each small size is also timed with the other form forced, so the line shows what the choice
@@ -723,7 +723,9 @@ def main():
     ap.add_argument("--queries", type=int, default=0, help="queries per step (0 = 131072 graph / 256 flat / 1024 c2)")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--rerank", type=int, default=0, help="rerankK; 0 = smallest of the ladder reaching recall>=0.95 on the calibration set")
-    ap.add_argument("--cal-queries", type=int, default=4096, help="calibration queries (rerankK ladder)")
+    ap.add_argument("--cal-queries", type=int, default=16384, help="calibration queries (rerankK ladder).  The rule — the smallest rung whose "
+                    "calibration recall clears 0.95 by TWO standard errors — costs a rung or two of headroom at 4096 queries (se 0.0017: the "
+                    "recall must reach 0.9534); 16384 halve the standard error")
     ap.add_argument("--eval-queries", type=int, default=10240, help="disjoint evaluation queries the reported recall is measured on")
     ap.add_argument("--gt-exact", action="store_true", help="ground truth by the bit-exact scalar-order scan only (slower; the "
                     "default takes 4k candidates from the MFMA dense scan and rescores them with the bit-exact kernel)")
