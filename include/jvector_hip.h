@@ -584,10 +584,20 @@ JV_API int jv_hip_searcher_destroy(jv_searcher *s);
  *                           different Q, a rejected argument) make EVERY rank return an error instead of hanging in a
  *                           collective the others never issue.  (A HIP failure inside one rank's scan is not covered.)
  * ------------------------------------------------------------------------------------------- */
+/*   jv_hip_comm_create_external : a communicator whose all-gathers are carried by the HOST's transport instead of RCCL — gloo, MPI, a
+ *                           JVM's own channel between its per-GPU threads: all_gather_fn(user, send, bytes, recv) must fill recv
+ *                           (world x bytes, rank-major, host memory) with every rank's `bytes` of send and return 0; the library
+ *                           stages its device buffers through host memory around the call.  Everything else — agreement header,
+ *                           NodeQueue-order merge, owner selection, kernels — is the same code as over RCCL.
+ *   jv_hip_sharded_merge_rerank : the exchange of jv_hip_sharded_search_flat for partial lists the CALLER produced (one graph index
+ *                           per shard, the way JVector deployments shard): part_ids / part_scores [n_local][Q][rerankK] with GLOBAL
+ *                           ids (host or device), counts[s] ordinals owned from id_base[s]; vectors == NULL: no exact rerank.  */
 #define JV_COMM_ID_BYTES 128
 typedef struct jv_comm jv_comm;
+typedef int (*jv_all_gather_fn)(void *user, const void *send, size_t bytes, void *recv);
 JV_API int jv_hip_comm_unique_id(uint8_t *id_out /* JV_COMM_ID_BYTES */);
 JV_API int jv_hip_comm_create(jv_ctx *ctx, const uint8_t *id, int rank, int world, jv_comm **out);
+JV_API int jv_hip_comm_create_external(jv_ctx *ctx, int rank, int world, jv_all_gather_fn all_gather_fn, void *user, jv_comm **out);
 JV_API int jv_hip_comm_destroy(jv_comm *comm);
 JV_API int jv_hip_comm_rank(const jv_comm *comm);
 JV_API int jv_hip_comm_world(const jv_comm *comm);
@@ -598,6 +608,10 @@ JV_API int jv_hip_sharded_topk(jv_ctx *ctx, jv_comm *comm, const float *scores, 
 JV_API int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts *luts, const jv_codes *const *codes,
                                       const jv_vectors *const *vectors, const int64_t *id_base, const float *queries, int Q,
                                       jv_vsf vsf, int topK, int rerankK, int32_t *out_ids, float *out_scores);
+
+JV_API int jv_hip_sharded_merge_rerank(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts *luts, const jv_vectors *const *vectors,
+                                       const int64_t *id_base, const int64_t *counts, const float *queries, int Q, jv_vsf vsf, int topK,
+                                       int rerankK, const int32_t *part_ids, const float *part_scores, int32_t *out_ids, float *out_scores);
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,8 @@ public final class HipOps {
         static final MethodHandle nvqVectorsDestroy = h("jv_hip_nvq_vectors_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
         static final MethodHandle nvqScores = h("jv_hip_nvq_scores", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, JAVA_INT, ADDRESS));
         static final MethodHandle vectorsFromNvq = h("jv_hip_vectors_from_nvq", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle commCreateExternal = h("jv_hip_comm_create_external", FunctionDescriptor.of(JAVA_INT, ADDRESS, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle shardedMergeRerank = h("jv_hip_sharded_merge_rerank", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle shardedSearchFlat = h("jv_hip_sharded_search_flat", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_INT, ADDRESS, ADDRESS));
     }
 
@@ -515,6 +517,17 @@ public final class HipOps {
     }
     public static MemorySegment commCreate(Arena arena, MemorySegment ctx, MemorySegment idOrNull, int rank, int world) {
         return outHandle(arena, out -> st(() -> (int) H.commCreate.invokeExact(ctx, idOrNull, rank, world, out)));
+    }
+    /** a communicator over the HOST's transport: allGatherFn = upcall stub int (void* user, void* send, size_t bytes, void* recv) filling recv with every rank's bytes (a JVM with one thread per GPU exchanges through its own memory) */
+    public static MemorySegment commCreateExternal(Arena arena, MemorySegment ctx, int rank, int world, MemorySegment allGatherFn, MemorySegment user) {
+        return outHandle(arena, out -> st(() -> (int) H.commCreateExternal.invokeExact(ctx, rank, world, allGatherFn, user, out)));
+    }
+    /** the sharded exchange for partial lists the caller produced (one graph index per shard): partIds / partScores [nLocal][q][rerankK], GLOBAL ids */
+    public static void shardedMergeRerank(MemorySegment ctx, MemorySegment comm, int nLocal, MemorySegment luts, MemorySegment vectorsArrayOrNull,
+                                          MemorySegment idBases, MemorySegment counts, MemorySegment queries, int q, int vsf, int topK, int rerankK,
+                                          MemorySegment partIds, MemorySegment partScores, MemorySegment outIds, MemorySegment outScores) {
+        check(st(() -> (int) H.shardedMergeRerank.invokeExact(ctx, comm, nLocal, luts, vectorsArrayOrNull, idBases, counts, queries, q, vsf, topK, rerankK,
+                                                              partIds, partScores, outIds, outScores)));
     }
     public static void commDestroy(MemorySegment comm) { check(st(() -> (int) H.commDestroy.invokeExact(comm))); }
     public static void shardedTopk(MemorySegment ctx, MemorySegment comm, MemorySegment scores, MemorySegment ids, int q, int kIn, int kOut,

@@ -129,6 +129,7 @@ SIGNATURES = {
     "jv_hip_layered_destroy": (_i, [_p]),
     "jv_hip_comm_unique_id": (_i, [_p]),
     "jv_hip_comm_create": (_i, [_p, _p, _i, _i, _p]),
+    "jv_hip_comm_create_external": (_i, [_p, _i, _i, _p, _p, _p]),
     "jv_hip_comm_destroy": (_i, [_p]),
     "jv_hip_comm_rank": (_i, [_p]),
     "jv_hip_comm_world": (_i, [_p]),
@@ -136,6 +137,7 @@ SIGNATURES = {
     "jv_hip_comm_all_gather": (_i, [_p, _p, _p, _sz, _p]),
     "jv_hip_sharded_topk": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "jv_hip_sharded_search_flat": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "jv_hip_sharded_merge_rerank": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "jv_hip_nvq_create": (_i, [_p, _i, _i, _p, C.POINTER(_p)]),
     "jv_hip_nvq_compute": (_i, [_p, _p, _i, C.POINTER(_p)]),
     "jv_hip_nvq_set_learn": (_i, [_p, _i]),

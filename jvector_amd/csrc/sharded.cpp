@@ -103,6 +103,11 @@ using namespace jv;
 struct jv_comm {
     const Rccl *rccl = nullptr;
     RcclComm comm = nullptr;
+    // an EXTERNAL transport instead of RCCL (jv_hip_comm_create_external): the host's own all-gather over host memory — gloo / MPI /
+    // a JVM's channel; the merge, the owner selection and every kernel stay the library's
+    jv_all_gather_fn ext_fn = nullptr;
+    void *ext_user = nullptr;
+    std::vector<char> ext_send, ext_recv;
     int rank = 0, world = 1, device = 0;
     std::vector<long long> h_ranges;  // host copy of the shard table (source of an async upload: must outlive the call)
     // device staging owned by the communicator (jv_hip_search_flat uses the context's scratch for itself)
@@ -121,6 +126,21 @@ namespace {
 // all-gather `count` elements of type `dt` per rank; local communicator: a device copy
 int all_gather(jv_ctx *ctx, jv_comm *c, const void *send, void *recv, size_t count, int dt, size_t elem)
 {
+    if (c->ext_fn) {   // the host's transport: device -> host, its all-gather, host -> device (latency-bound messages of < 1 MB)
+        const size_t bytes = count * elem;
+        c->ext_send.resize(bytes);
+        c->ext_recv.resize(bytes * (size_t)c->world);
+        JV_HIP_CHECK(hipMemcpyAsync(c->ext_send.data(), send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const int rc = c->ext_fn(c->ext_user, c->ext_send.data(), bytes, c->ext_recv.data());
+        if (rc != 0) {
+            set_error("sharded: the external all-gather returned %d", rc);
+            return JV_ERR_HIP;
+        }
+        JV_HIP_CHECK(hipMemcpyAsync(recv, c->ext_recv.data(), bytes * (size_t)c->world, hipMemcpyHostToDevice, ctx->stream));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // ext_recv is reused by the next exchange
+        return JV_OK;
+    }
     if (!c->comm) {  // local communicator; an RCCL communicator of one rank still goes through RCCL
         if (send != recv) JV_HIP_CHECK(hipMemcpyAsync(recv, send, count * elem, hipMemcpyDeviceToDevice, ctx->stream));
         return JV_OK;
@@ -189,6 +209,21 @@ int jv_hip_comm_create(jv_ctx *ctx, const uint8_t *id, int rank, int world, jv_c
     return JV_OK;
 }
 
+int jv_hip_comm_create_external(jv_ctx *ctx, int rank, int world, jv_all_gather_fn all_gather_fn, void *user, jv_comm **out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && out && all_gather_fn, "comm_create_external: NULL argument");
+    JV_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_create_external: rank %d outside world %d", rank, world);
+    jv_comm *c = new jv_comm();
+    c->rank = rank;
+    c->world = world;
+    c->device = ctx->device;
+    c->ext_fn = all_gather_fn;
+    c->ext_user = user;
+    *out = c;
+    return JV_OK;
+}
+
 int jv_hip_comm_destroy(jv_comm *c)
 {
     if (!c) return JV_OK;
@@ -205,6 +240,10 @@ int jv_hip_comm_count(const jv_comm *c, int *out)
 {
     clear_error();
     JV_REQUIRE(c && out, "comm_count: NULL argument");
+    if (c->ext_fn) {  // the host's transport: what the host said
+        *out = c->world;
+        return JV_OK;
+    }
     if (!c->comm) {  // local communicator: no RCCL object behind it
         *out = 1;
         return JV_OK;
@@ -266,45 +305,18 @@ int jv_hip_sharded_topk(jv_ctx *ctx, jv_comm *comm, const float *scores, const i
     return stage_out_end(ctx, os);
 }
 
-int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts *luts, const jv_codes *const *codes,
-                               const jv_vectors *const *vectors, const int64_t *id_base, const float *queries, int Q, jv_vsf vsf,
-                               int topK, int rerankK, int32_t *out_ids, float *out_scores)
+}  // extern "C"
+
+// The exchange every sharded search ends with, whatever produced the partial lists (an exhaustive ADC scan per shard, a graph search
+// per shard): agreement header -> all-gather of the partial top-rerankK (global ids) -> NodeQueue-order merge -> exact scores by the
+// owning shard -> all-gather + owner selection -> top-K.  counts[s] = ordinals shard s owns from id_base[s]; vectors == NULL: no rerank.
+// part_ids / part_sc: [n_local][Q][rerankK] in the communicator's part_* buffers (device).  Queries must be staged in `luts`
+// (luts_prepare) when reranking.
+static int sharded_exchange(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts *luts, const jv_vectors *const *vectors, const int64_t *id_base,
+                            const int64_t *counts, int Q, jv_vsf vsf, int topK, int rerankK, int local_status, const char *local_msg,
+                            bool rerank, int (*produce)(void *), void *produce_arg, int32_t *out_ids, float *out_scores)
 {
-    clear_error();
-    JV_REQUIRE(ctx && comm && luts && codes && id_base, "sharded_search_flat: NULL argument");
-    JV_TRY(use_device(ctx->device));
-    // ---- 0. agreement.  The collectives below must be issued by every rank the same number of times with the same sizes, so
-    //      nothing rank-local may decide whether a rank takes part: each rank validates its own arguments into a status word,
-    //      all ranks exchange one fixed-size header {n_local, Q, topK, rerankK, rerank?, vsf, D, status, ranges...} and then take
-    //      the SAME decision from the same table (a rank whose arguments are bad makes every rank fail, none hang).
     constexpr int kHdr = 8, kMaxLocal = 64, kRec = kHdr + 2 * kMaxLocal;
-    char local_msg[256] = {0};
-    int local_status = 0;
-    auto fail_local = [&](const char *fmt, auto... a) {
-        if (local_status == 0) {
-            if constexpr (sizeof...(a) == 0) snprintf(local_msg, sizeof(local_msg), "%s", fmt);
-            else snprintf(local_msg, sizeof(local_msg), fmt, a...);
-            local_status = 1;
-        }
-    };
-    if (n_local < 1 || n_local > kMaxLocal) fail_local("sharded_search_flat: %d local shards (1..64)", n_local);
-    if (!(topK > 0 && rerankK >= topK)) fail_local("rerankK %d must be >= topK %d", rerankK, topK);  // GraphSearcher.java:233
-    if (Q < 0 || (Q > 0 && !(queries && out_ids && out_scores))) fail_local("sharded_search_flat: NULL buffer");
-    bool rerank = vectors != nullptr;
-    for (int s = 0; s < n_local && local_status == 0; ++s) {
-        if (!codes[s]) {
-            fail_local("sharded_search_flat: shard %d has no codes", s);
-            break;
-        }
-        if (!(id_base[s] >= 0 && id_base[s] + codes[s]->count <= 0x7fffffffLL)) fail_local("sharded_search_flat: shard %d id range overflows int32", s);
-        if (codes[s]->M != luts->pq->M) fail_local("sharded_search_flat: shard %d codes have M = %d, the tables M = %d", s, codes[s]->M, luts->pq->M);
-        if (vectors && vectors[s]) {
-            if (vectors[s]->count < codes[s]->count) fail_local("sharded_search_flat: shard %d has fewer vectors than codes", s);
-            if (vectors[s]->D != luts->pq->D) fail_local("sharded_search_flat: shard %d vectors have D = %d, the quantizer D = %d", s, vectors[s]->D, luts->pq->D);
-        } else {
-            rerank = false;
-        }
-    }
     const int W = comm->world;
     std::vector<long long> h_rec(kRec, 0), h_all((size_t)kRec * W, 0);
     h_rec[0] = n_local;
@@ -317,9 +329,9 @@ int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts 
     h_rec[7] = local_status;
     for (int s = 0; s < n_local && s < kMaxLocal && local_status == 0; ++s) {
         h_rec[kHdr + 2 * s] = id_base[s];
-        h_rec[kHdr + 2 * s + 1] = codes[s]->count;
+        h_rec[kHdr + 2 * s + 1] = counts[s];
     }
-    if (comm->comm) {
+    if (comm->comm || comm->ext_fn) {
         JV_TRY(comm->ranges.reserve(sizeof(long long) * kRec));
         JV_TRY(comm->all_ranges.reserve(sizeof(long long) * (size_t)kRec * W));
         JV_HIP_CHECK(hipMemcpyAsync(comm->ranges.ptr, h_rec.data(), sizeof(long long) * kRec, hipMemcpyHostToDevice, ctx->stream));
@@ -335,12 +347,12 @@ int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts 
     }
     for (int r = 0; r < W; ++r) {
         const long long *o = h_all.data() + (size_t)kRec * r;
-        JV_REQUIRE(o[7] == 0, "sharded_search_flat: rank %d rejected its arguments (see that rank's error)", r);
+        JV_REQUIRE(o[7] == 0, "sharded search: rank %d rejected its arguments (see that rank's error)", r);
         JV_REQUIRE(o[0] == h_rec[0] && o[1] == h_rec[1] && o[2] == h_rec[2] && o[3] == h_rec[3] && o[5] == h_rec[5] && o[6] == h_rec[6],
-                   "sharded_search_flat: rank %d disagrees with rank %d on (n_local, Q, topK, rerankK, vsf, D) = (%lld, %lld, %lld, %lld, %lld, %lld) "
+                   "sharded search: rank %d disagrees with rank %d on (n_local, Q, topK, rerankK, vsf, D) = (%lld, %lld, %lld, %lld, %lld, %lld) "
                    "vs (%lld, %lld, %lld, %lld, %lld, %lld)", r, comm->rank, o[0], o[1], o[2], o[3], o[5], o[6], h_rec[0], h_rec[1], h_rec[2],
                    h_rec[3], h_rec[5], h_rec[6]);
-        JV_REQUIRE(o[4] == h_rec[4], "sharded_search_flat: rank %d %s full-resolution vectors for every shard, rank %d %s — either every "
+        JV_REQUIRE(o[4] == h_rec[4], "sharded search: rank %d %s full-resolution vectors for every shard, rank %d %s — either every "
                    "rank reranks or none", r, o[4] ? "has" : "lacks", comm->rank, h_rec[4] ? "has" : "lacks");
     }
     if (Q == 0) return JV_OK;
@@ -357,13 +369,10 @@ int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts 
     JV_TRY(comm->all_ranges.reserve(sizeof(long long) * std::max<size_t>(2 * (size_t)P, (size_t)kRec * W)));
     JV_HIP_CHECK(hipMemcpyAsync(comm->all_ranges.ptr, comm->h_ranges.data(), sizeof(long long) * 2 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
 
-    // 1. every local shard's partial top-rerankK of the ADC scan, GLOBAL ids (jv_hip_search_flat without a reranker)
+    // 1. every local shard's partial top-rerankK, GLOBAL ids, into part_ids / part_sc [n_local][Q][k]
     JV_TRY(comm->part_ids.reserve(sizeof(int32_t) * cells * n_local));
     JV_TRY(comm->part_sc.reserve(sizeof(float) * cells * n_local));
-    for (int s = 0; s < n_local; ++s) {
-        JV_TRY(jv_hip_search_flat(ctx, luts, codes[s], nullptr, queries, Q, vsf, k, 0, (int32_t)id_base[s],
-                                  (int32_t *)comm->part_ids.ptr + cells * s, (float *)comm->part_sc.ptr + cells * s));
-    }
+    JV_TRY(produce(produce_arg));
     // 2. all-gather (ids, scores), merge -> global top-rerankK
     JV_TRY(comm->all_ids.reserve(sizeof(int32_t) * cells * P));
     JV_TRY(comm->all_sc.reserve(sizeof(float) * cells * P));
@@ -390,7 +399,7 @@ int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts 
     JV_TRY(comm->all_exact.reserve(sizeof(float) * cells * P));
     JV_TRY(ctx->d_in.reserve(sizeof(float) * (size_t)Q));
     for (int s = 0; s < n_local; ++s) {
-        JV_TRY(launch_shard_localize(ctx->stream, (const int32_t *)comm->cand.ptr, (int64_t)cells, id_base[s], codes[s]->count,
+        JV_TRY(launch_shard_localize(ctx->stream, (const int32_t *)comm->cand.ptr, (int64_t)cells, id_base[s], counts[s],
                                      (int32_t *)comm->local.ptr));
         JV_TRY(rerank_gather(ctx, vectors[s], luts->d_raw_queries, Q, vsf, (const int32_t *)comm->local.ptr, k,
                              (float *)comm->exact.ptr + cells * s, (float *)ctx->d_in.ptr));
@@ -407,6 +416,131 @@ int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts 
     }
     JV_TRY(stage_out_end(ctx, oi));
     return stage_out_end(ctx, os);
+}
+
+namespace {
+struct Msg {   // a rank's own argument check: recorded, exchanged, and only then acted upon (every rank issues the same collectives)
+    char text[256] = {0};
+    int status = 0;
+    template <typename... A>
+    void fail(const char *fmt, A... a)
+    {
+        if (status == 0) {
+            if constexpr (sizeof...(a) == 0) snprintf(text, sizeof(text), "%s", fmt);
+            else snprintf(text, sizeof(text), fmt, a...);
+            status = 1;
+        }
+    }
+};
+struct FlatProduce {
+    jv_ctx *ctx;
+    jv_comm *comm;
+    jv_luts *luts;
+    const jv_codes *const *codes;
+    const int64_t *id_base;
+    const float *queries;
+    int n_local, Q, k;
+    jv_vsf vsf;
+};
+int flat_produce(void *a)
+{
+    const FlatProduce &f = *(const FlatProduce *)a;
+    const size_t cells = (size_t)f.Q * f.k;
+    for (int s = 0; s < f.n_local; ++s)
+        JV_TRY(jv_hip_search_flat(f.ctx, f.luts, f.codes[s], nullptr, f.queries, f.Q, f.vsf, f.k, 0, (int32_t)f.id_base[s],
+                                  (int32_t *)f.comm->part_ids.ptr + cells * s, (float *)f.comm->part_sc.ptr + cells * s));
+    return JV_OK;
+}
+struct GivenProduce {
+    jv_ctx *ctx;
+    jv_comm *comm;
+    jv_luts *luts;
+    const float *queries;
+    const int32_t *part_ids;
+    const float *part_sc;
+    int n_local, Q, k;
+    jv_vsf vsf;
+    bool rerank;
+};
+int given_produce(void *a)
+{
+    const GivenProduce &g = *(const GivenProduce *)a;
+    const size_t cells = (size_t)g.Q * g.k * g.n_local;
+    JV_HIP_CHECK(hipMemcpyAsync(g.comm->part_ids.ptr, g.part_ids, sizeof(int32_t) * cells, hipMemcpyDefault, g.ctx->stream));
+    JV_HIP_CHECK(hipMemcpyAsync(g.comm->part_sc.ptr, g.part_sc, sizeof(float) * cells, hipMemcpyDefault, g.ctx->stream));
+    // the raw queries the exact rerank scores against (jv_hip_search_flat stages them itself on the flat path)
+    if (g.rerank) JV_TRY(luts_prepare(g.ctx, g.luts, g.queries, g.Q, g.vsf, JV_DECODER_PQ, false));
+    return JV_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int jv_hip_sharded_search_flat(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts *luts, const jv_codes *const *codes,
+                               const jv_vectors *const *vectors, const int64_t *id_base, const float *queries, int Q, jv_vsf vsf,
+                               int topK, int rerankK, int32_t *out_ids, float *out_scores)
+{
+    clear_error();
+    JV_REQUIRE(ctx && comm && luts && codes && id_base, "sharded_search_flat: NULL argument");
+    JV_TRY(use_device(ctx->device));
+    // ---- 0. agreement.  The collectives must be issued by every rank the same number of times with the same sizes, so nothing
+    //      rank-local may decide whether a rank takes part: each rank validates its own arguments into a status word, all ranks
+    //      exchange one fixed-size header and then take the SAME decision from the same table (sharded_exchange).
+    Msg m;
+    if (n_local < 1 || n_local > 64) m.fail("sharded_search_flat: %d local shards (1..64)", n_local);
+    if (!(topK > 0 && rerankK >= topK)) m.fail("rerankK %d must be >= topK %d", rerankK, topK);  // GraphSearcher.java:233
+    if (Q < 0 || (Q > 0 && !(queries && out_ids && out_scores))) m.fail("sharded_search_flat: NULL buffer");
+    bool rerank = vectors != nullptr;
+    std::vector<int64_t> counts((size_t)std::max(n_local, 0), 0);
+    for (int s = 0; s < n_local && m.status == 0; ++s) {
+        if (!codes[s]) {
+            m.fail("sharded_search_flat: shard %d has no codes", s);
+            break;
+        }
+        counts[(size_t)s] = codes[s]->count;
+        if (!(id_base[s] >= 0 && id_base[s] + codes[s]->count <= 0x7fffffffLL)) m.fail("sharded_search_flat: shard %d id range overflows int32", s);
+        if (codes[s]->M != luts->pq->M) m.fail("sharded_search_flat: shard %d codes have M = %d, the tables M = %d", s, codes[s]->M, luts->pq->M);
+        if (vectors && vectors[s]) {
+            if (vectors[s]->count < codes[s]->count) m.fail("sharded_search_flat: shard %d has fewer vectors than codes", s);
+            if (vectors[s]->D != luts->pq->D) m.fail("sharded_search_flat: shard %d vectors have D = %d, the quantizer D = %d", s, vectors[s]->D, luts->pq->D);
+        } else {
+            rerank = false;
+        }
+    }
+    FlatProduce f{ctx, comm, luts, codes, id_base, queries, n_local, Q, rerankK, vsf};
+    return sharded_exchange(ctx, comm, n_local, luts, vectors, id_base, counts.data(), Q, vsf, topK, rerankK, m.status, m.text, rerank, flat_produce,
+                            &f, out_ids, out_scores);
+}
+
+// The same exchange for partial lists the CALLER produced (one graph index per shard — the way JVector deployments shard: a segment
+// index per partition — or anything else that yields a top-rerankK with global ids): part_ids / part_scores [n_local][Q][rerankK],
+// host or device memory.  vectors == NULL: the merged approximate top-K is the answer.
+int jv_hip_sharded_merge_rerank(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts *luts, const jv_vectors *const *vectors, const int64_t *id_base,
+                                const int64_t *counts, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK, const int32_t *part_ids,
+                                const float *part_scores, int32_t *out_ids, float *out_scores)
+{
+    clear_error();
+    JV_REQUIRE(ctx && comm && luts && id_base && counts, "sharded_merge_rerank: NULL argument");
+    JV_TRY(use_device(ctx->device));
+    Msg m;
+    if (n_local < 1 || n_local > 64) m.fail("sharded_merge_rerank: %d local shards (1..64)", n_local);
+    if (!(topK > 0 && rerankK >= topK)) m.fail("rerankK %d must be >= topK %d", rerankK, topK);
+    if (Q < 0 || Q > luts->capacity) m.fail("sharded_merge_rerank: %d queries, the tables hold %d", Q, luts->capacity);
+    if (Q > 0 && !(part_ids && part_scores && out_ids && out_scores)) m.fail("sharded_merge_rerank: NULL buffer");
+    bool rerank = vectors != nullptr;
+    for (int s = 0; s < n_local && m.status == 0; ++s) {
+        if (!(id_base[s] >= 0 && counts[s] >= 0 && id_base[s] + counts[s] <= 0x7fffffffLL)) m.fail("sharded_merge_rerank: shard %d id range overflows int32", s);
+        if (vectors && vectors[s]) {
+            if (vectors[s]->count < counts[s]) m.fail("sharded_merge_rerank: shard %d has fewer vectors than ordinals", s);
+            if (vectors[s]->D != luts->pq->D) m.fail("sharded_merge_rerank: shard %d vectors have D = %d, the quantizer D = %d", s, vectors[s]->D, luts->pq->D);
+        } else {
+            rerank = false;
+        }
+    }
+    if (rerank && Q > 0 && !queries) m.fail("sharded_merge_rerank: the exact rerank needs the queries");
+    GivenProduce g{ctx, comm, luts, queries, part_ids, part_scores, n_local, Q, rerankK, vsf, rerank};
+    return sharded_exchange(ctx, comm, n_local, luts, vectors, id_base, counts, Q, vsf, topK, rerankK, m.status, m.text, rerank, given_produce, &g,
+                            out_ids, out_scores);
 }
 
 }  // extern "C"

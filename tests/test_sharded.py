@@ -1,12 +1,14 @@
 """Sharded-index path (BASELINE config 4): N-shard merged result == single-index result, bit-identical ids and
 scores, including engineered score ties.
 
-* CPU, world_size 2, gloo: exercises the host logic (shard bounds, global ids, all_gather / MAX all_reduce, merge)
-  with a CPU checker backend built on the oracle (tests may use the oracle; the product backend is HIP-only).
+* CPU, world_size 2, gloo: two processes drive the library's ONE exchange implementation (csrc/sharded.cpp, on the mock device)
+  with torch.distributed carrying its all-gathers (jv_hip_comm_create_external); results equal the oracle's single index.
 * GPU: the same equality with the HIP backend, several shards resident on the one available GPU.
 """
 import os
+import platform
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -14,6 +16,8 @@ import torch
 
 from jvector_amd.sharded import ShardedFlatSearcher, shard_bounds
 from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def make_problem(seed, N=6000, D=64, M=8, Q=5, dup=True):
@@ -31,45 +35,6 @@ def make_problem(seed, N=6000, D=64, M=8, Q=5, dup=True):
     return vecs, queries, cb
 
 
-class OracleShardBackend:
-    """CPU checker backend (test infrastructure): same interface as HipShardBackend, oracle arithmetic."""
-
-    def __init__(self, opq, codes, vecs, lo):
-        self.opq, self.codes, self.vecs, self.lo, self.count = opq, codes, vecs, lo, codes.shape[0]
-
-    def adc_topk(self, queries, vsf, k):
-        q = queries.numpy()
-        ids = np.full((q.shape[0], k), -1, np.int32)
-        sc = np.full((q.shape[0], k), -np.inf, np.float32)
-        for i in range(q.shape[0]):
-            a = self.opq.adc_scores(q[i], int(vsf), self.codes)
-            ti, ts = O.topk(None, a, k)
-            ids[i, : len(ti)] = ti + self.lo
-            sc[i, : len(ti)] = ts
-        return torch.from_numpy(ids), torch.from_numpy(sc)
-
-    def exact_scores(self, queries, vsf, global_ids):
-        q, g = queries.numpy(), global_ids.numpy()
-        out = np.full(g.shape, -np.inf, np.float32)
-        for i in range(g.shape[0]):
-            for j in range(g.shape[1]):
-                loc = g[i, j] - self.lo
-                if 0 <= loc < self.count:
-                    out[i, j] = O.compare(int(vsf), q[i], self.vecs[loc])
-        return torch.from_numpy(out)
-
-    def topk(self, scores, ids, k):
-        s, d = scores.numpy(), ids.numpy()
-        oi = np.full((s.shape[0], k), -1, np.int32)
-        osc = np.full((s.shape[0], k), -np.inf, np.float32)
-        for i in range(s.shape[0]):
-            valid = d[i] >= 0
-            ti, ts = O.topk(d[i][valid], s[i][valid], k)
-            oi[i, : len(ti)] = ti
-            osc[i, : len(ti)] = ts
-        return torch.from_numpy(oi), torch.from_numpy(osc)
-
-
 def oracle_single(opq, codes, vecs, queries, vsf, top_k, rerank_k):
     return opq.search_flat(codes, vecs, queries, int(vsf), top_k, rerank_k, nthreads=2)
 
@@ -81,30 +46,57 @@ def test_shard_bounds():
     assert b[0] == (0, 12_500_000) and b[-1] == (87_500_000, 100_000_000)
 
 
+# The exchange (agreement header, all-gathers, NodeQueue-order merge, owners' exact rerank, owner selection, top-K) has ONE
+# implementation — csrc/sharded.cpp — whatever carries its all-gathers.  On the CPU the library's host code runs against the mock
+# device (tests/mock/): the shards' ADC scans and rerank kernels are the oracle's arithmetic there, the exchange is the real code.
+def _mock_shard(J, ctx, pq, vecs, lo, hi, max_queries=8):
+    from jvector_amd.sharded import HipShardBackend
+    vs = J.VectorSet(ctx, np.ascontiguousarray(vecs[lo:hi]))
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    return HipShardBackend(ctx, pq, cv, vs, lo, max_queries=max_queries)
+
+
 def _gloo_worker(rank, world, port, seed, results):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "mock"))
     import torch.distributed as dist
+    from mockbind import mock_jvector
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        vecs, queries, cb = make_problem(seed)
-        N, D, M = vecs.shape[0], vecs.shape[1], 8
-        opq = O.OraclePQ(D, M, cb)
-        codes = opq.encode_all(vecs, nthreads=1)
-        lo, hi = shard_bounds(N, world)[rank]
-        shard = OracleShardBackend(opq, codes[lo:hi], vecs[lo:hi], lo)
-        s = ShardedFlatSearcher([shard])
-        out = {}
-        for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
-            ids, sc = s.search(torch.from_numpy(queries), vsf, 10, 40)
-            wi, ws = oracle_single(opq, codes, vecs, queries, vsf, 10, 40)
-            out[vsf] = bool(np.array_equal(ids.numpy(), wi) and np.array_equal(sc.numpy(), ws))
-        results[rank] = out
+        with mock_jvector() as J:
+            vecs, queries, cb = make_problem(seed)
+            N, D, M = vecs.shape[0], vecs.shape[1], 8
+            opq = O.OraclePQ(D, M, cb)
+            codes = opq.encode_all(vecs, nthreads=1)
+            ctx = J.HipContext(0)
+            pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+            lo, hi = shard_bounds(N, world)[rank]
+            # no communicator given: the initialised process group (gloo) carries the library's all-gathers
+            s = ShardedFlatSearcher([_mock_shard(J, ctx, pq, vecs, lo, hi)])
+            assert s.comm.world == world and s.comm.count() == world
+            out = {}
+            for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
+                ids, sc = s.search(queries, J.VectorSimilarityFunction(vsf), 10, 40)
+                wi, ws = oracle_single(opq, codes, vecs, queries, vsf, 10, 40)
+                out[vsf] = bool(np.array_equal(np.asarray(ids), wi) and np.array_equal(np.asarray(sc), ws))
+            # ranks that disagree on their arguments all fail (none hangs in a collective the other never issues)
+            try:
+                s.search(queries, J.VectorSimilarityFunction.COSINE, 10, 40 if rank == 0 else 50)
+                out["disagreement refused"] = False
+            except Exception:
+                out["disagreement refused"] = True
+            results[rank] = out
+            s.close()
+            ctx.close()
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
 def test_sharded_two_ranks_gloo_equals_single_index():
+    """world_size 2 over gloo: two processes, one shard each, the library's exchange (csrc/sharded.cpp) with its all-gathers carried by
+    torch.distributed through jv_hip_comm_create_external: identical to the single index, ties included"""
     import torch.multiprocessing as mp
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
@@ -113,35 +105,31 @@ def test_sharded_two_ranks_gloo_equals_single_index():
     mgr = mp.Manager()
     results = mgr.dict()
     mp.spawn(_gloo_worker, args=(2, port, 11, results), nprocs=2, join=True)
-    assert dict(results) == {0: {0: True, 1: True, 2: True}, 1: {0: True, 1: True, 2: True}}
+    want = {0: True, 1: True, 2: True, "disagreement refused": True}
+    assert dict(results) == {0: want, 1: want}
 
 
-def test_sharded_local_shards_cpu_checker():
-    """several shards in one process (no collective): merge logic incl. ties, uneven shards, rerankK > shard size"""
-    vecs, queries, cb = make_problem(5, N=1000)
-    opq = O.OraclePQ(64, 8, cb)
-    codes = opq.encode_all(vecs, nthreads=1)
-    for world in (1, 3, 7):
-        shards = [OracleShardBackend(opq, codes[lo:hi], vecs[lo:hi], lo) for lo, hi in shard_bounds(1000, world)]
-        s = ShardedFlatSearcher(shards)
-        for vsf in (O.EUCLIDEAN, O.COSINE):
-            ids, sc = s.search(torch.from_numpy(queries), vsf, 10, 200)
-            wi, ws = oracle_single(opq, codes, vecs, queries, vsf, 10, 200)
-            assert np.array_equal(ids.numpy(), wi) and np.array_equal(sc.numpy(), ws)
-    with pytest.raises(ValueError):
-        s.search(torch.from_numpy(queries), O.COSINE, 10, 5)
-
-
-class OracleGraphShardBackend(OracleShardBackend):
-    """CPU checker for HipGraphShardBackend: the partial top-k comes from the oracle's graph search over the shard's graph."""
-
-    def __init__(self, opq, codes, vecs, lo, graph, fused):
-        super().__init__(opq, codes, vecs, lo)
-        self.graph, self.fused = graph, fused
-
-    def adc_topk(self, queries, vsf, k):
-        ids, sc, _ = self.graph.search(self.opq, self.codes, None, queries.numpy(), int(vsf), k, k, fused=self.fused)
-        return torch.from_numpy(np.where(ids >= 0, ids + self.lo, ids).astype(np.int32)), torch.from_numpy(sc)
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+def test_sharded_local_shards_on_the_mock():
+    """several shards in one process (local communicator: no collective): merge logic incl. ties, uneven shards, rerankK > shard size"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "mock"))
+    from mockbind import mock_jvector
+    with mock_jvector() as J:
+        vecs, queries, cb = make_problem(5, N=1000)
+        opq = O.OraclePQ(64, 8, cb)
+        codes = opq.encode_all(vecs, nthreads=1)
+        ctx = J.HipContext(0)
+        pq = J.ProductQuantization.from_codebooks(ctx, 64, 8, cb)
+        for world in (1, 3, 7):
+            s = ShardedFlatSearcher([_mock_shard(J, ctx, pq, vecs, lo, hi) for lo, hi in shard_bounds(1000, world)])
+            for vsf in (O.EUCLIDEAN, O.COSINE):
+                ids, sc = s.search(queries, J.VectorSimilarityFunction(vsf), 10, 200)
+                wi, ws = oracle_single(opq, codes, vecs, queries, vsf, 10, 200)
+                assert np.array_equal(np.asarray(ids), wi) and np.array_equal(np.asarray(sc), ws)
+            with pytest.raises(ValueError):
+                s.search(queries, J.VectorSimilarityFunction.COSINE, 10, 5)
+            s.close()
+        ctx.close()
 
 
 def _graph_shards(seed, n_shards, N=1500, D=64, M=8):
@@ -167,28 +155,6 @@ def _manual_merge(opq, shard_results, shard_vecs, q, vsf, top_k, rerank_k):
         out_i.append(ti)
         out_s.append(ts)
     return np.stack(out_i), np.stack(out_s)
-
-
-def test_sharded_graph_backends_cpu_checker():
-    """segment indexes: three shards, each with its own graph; sharded result == manual merge of the per-shard searches"""
-    shards, cb, q = _graph_shards(40, 3)
-    opq = O.OraclePQ(64, 8, cb)
-    backends, results, allv = [], {}, {}
-    for v, lv, entry, entry_level, lo in shards:
-        codes = opq.encode_all(v, nthreads=1)
-        og = O.OracleGraph(len(v), lv, entry, entry_level)
-        backends.append(OracleGraphShardBackend(opq, codes, v, lo, og, True))
-        for i in range(len(v)):
-            allv[lo + i] = v[i]
-    s = ShardedFlatSearcher(backends)
-    for vsf in (O.EUCLIDEAN, O.COSINE):
-        per = []
-        for b in backends:
-            ids, sc = b.adc_topk(torch.from_numpy(q), vsf, 30)
-            per.append((ids.numpy(), sc.numpy()))
-        wi, ws = _manual_merge(opq, per, allv, q, vsf, 10, 30)
-        gi, gs = s.search(torch.from_numpy(q), vsf, 10, 30)
-        assert np.array_equal(gi.numpy(), wi) and np.array_equal(gs.numpy(), ws)
 
 
 @pytest.mark.gpu
