@@ -745,7 +745,7 @@ def main():
     ap.add_argument("--build-improve", type=int, default=int(os.environ.get("JVECTOR_BENCH_BUILD_IMPROVE", "1")),
                     help="engine graph: passes of improveConnections over every node of a level after its last insert (search the finished "
                          "graph, MERGE with the node's neighbours, prune, backlink: jv_hip_builder_improve_batch).  Measured at 10M (profiles/"
-                         "r4_i): one pass takes the calibrated rerankK from 95 to 75 (108 -> 87 expansions per query, +19 % QPS) for +30 s of "
+                         "r4_i): one pass takes the calibrated rerankK from 95 to 75 (108 -> 87 expansions per query, 19 percent more QPS) for +30 s of "
                          "build; a second pass changes nothing")
     ap.add_argument("--torch-codebooks", action="store_true", help="codebooks from benchlib's torch Lloyd instead of the engine's "
                     "ProductQuantization.compute (round-1 behaviour)")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # AddressSanitizer pass over the library's HOST code (CPU only): builds the mock-device library (tests/mock/) with
 # -fsanitize=$SAN and runs the mock tests that do not use the fiber-based lane emulator (ASan cannot follow its
-# stack switches) plus the corrupted-input fuzz of the format readers.  Last run (round 3 final: + builder, NVQ, wide adjacency rows, padded quantizers with fewer than 256 clusters, PQ training): clean.
+# stack switches) plus the corrupted-input fuzz of the format readers.  Last run (round 4 final: + the sharded exchange over the external transport, two gloo ranks): clean.
 set -eu
 # SAN=undefined scripts/asan_mock.sh runs the same pass under UndefinedBehaviorSanitizer (round 2: clean as well)
 SAN=${SAN:-address}
@@ -41,6 +41,8 @@ ctx.close()
 print("searcher objects / wide rows / small cluster counts on the host searcher under the sanitizer: clean")
 PY
 python -m pytest tests/test_sharded_cabi.py -x -q -p no:cacheprovider -k "local_shards"
+# round 4: the one sharded exchange (jv_hip_sharded_merge_rerank) with local shards and with two gloo ranks over the external transport
+python -m pytest tests/test_sharded.py -x -q -p no:cacheprovider -k "local_shards_on_the_mock or two_ranks_gloo"
 python - <<'PY'
 import ctypes as C, os, sys
 sys.path.insert(0, "tests")
