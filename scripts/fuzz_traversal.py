@@ -37,7 +37,9 @@ VSF = J.VectorSimilarityFunction
 t_end = time.time() + budget
 cases = searches = 0
 knobs = ("JVECTOR_HIP_GS_VCAP_LOG2", "JVECTOR_HIP_GS_GROW", "JVECTOR_HIP_GS_RETRY", "JVECTOR_HIP_GS_CAND_CAP", "JVECTOR_HIP_GS_PUSH_LOG_CAP",
-         "JVECTOR_HIP_GS_GENERIC")
+         "JVECTOR_HIP_GS_GENERIC", "JVECTOR_HIP_GS_WGX", "JVECTOR_HIP_GS_WGX_WAVES", "JVECTOR_HIP_GS_WGX_SLOTS", "JVECTOR_HIP_GS_WGX_DEPTH",
+         "JVECTOR_HIP_GS_WGX_LUT_M", "JVECTOR_HIP_GS_WGX_PER_CU")
+wgx_searches = 0
 while time.time() < t_end:
     D = int(rng.choice([128, 256, 384, 512, 768] if not MOCK else [128, 256]))
     M = D // 8
@@ -114,6 +116,19 @@ while time.time() < t_end:
             env["JVECTOR_HIP_GS_GENERIC"] = "1"
         if traversal == "device" and rng.random() < 0.2:
             env["JVECTOR_HIP_GS_PUSH_LOG_CAP"] = str(int(rng.choice([4, 16, 64])))
+        # round 4: the workgroup form (one query per workgroup, ADC table in LDS, control wave + expanders) — forced with random
+        # launch shapes / slot counts / request depths / partial tables, or forbidden; left alone, AUTO picks it for these batch sizes
+        r = rng.random()
+        if traversal == "device" and r < 0.4:
+            env["JVECTOR_HIP_GS_WGX"] = "1"
+            env["JVECTOR_HIP_GS_WGX_WAVES"] = str(int(rng.choice([2, 3, 4] if MOCK else [2, 3, 4, 6, 8])))
+            env["JVECTOR_HIP_GS_WGX_SLOTS"] = str(int(rng.choice([2, 3, 8, 16, 40])))
+            env["JVECTOR_HIP_GS_WGX_DEPTH"] = str(int(rng.integers(0, 2)))
+            if rng.random() < 0.4 and M % 16 == 0 and M >= 32:
+                env["JVECTOR_HIP_GS_WGX_LUT_M"] = str(int(rng.integers(1, M // 16 + 1)) * 16)
+                env["JVECTOR_HIP_GS_WGX_PER_CU"] = str(int(rng.integers(1, 4)))
+        elif traversal == "device" and r < 0.5:
+            env["JVECTOR_HIP_GS_WGX"] = "0"
         for k in knobs:
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -133,8 +148,9 @@ while time.time() < t_end:
             print(" queries", bad[:5], "\n got", ids[bad[:2]], "\n want", wi[bad[:2]], "\n stats", st[bad[:2]], wst[bad[:2]])
             sys.exit(1)
         searches += 1
+        wgx_searches += ctx.stat("gs_last_wgx") if traversal == "device" else 0
         graph.close()
     cases += 1
 for k in knobs:
     os.environ.pop(k, None)
-print(f"fuzz: {cases} random problems, {searches} searches, all bit-identical to the oracle (seed {seed}, {budget:.0f} s)")
+print(f"fuzz: {cases} random problems, {searches} searches ({wgx_searches} through the workgroup form), all bit-identical to the oracle (seed {seed}, {budget:.0f} s)")
