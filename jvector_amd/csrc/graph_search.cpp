@@ -1346,6 +1346,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         wgx = wgx_bytes(0, wgx_lut_m) <= wgx_budget;
     }
     if (wgx) pair = false;
+    // gs_ub8 = 1: the pair-lane kernel with an 8-bit upper-bound table of the query's ADC entries per wave (gs_body.h "UB8": fresh
+    // neighbours that provably cannot be popped skip their exact score).  Costs M x 256 bytes of LDS per wave (fewer waves per CU).
+    const bool ub8 = !so && !wgx && pair && !lutr && fused && !dev_accept.bits && ctx_opt(ctx, "gs_ub8", 0) != 0 && graph_search_ub8_supported(pq->M, kvsf);
     const int pair_M = pair ? pq->M : 0;
     int cand_cap = wgx ? wgx_cand_cap : std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", lutr ? 256 : (occ == 4 ? 512 : (pair ? 256 : 1024)))) & ~63;
     while (!wgx && cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
@@ -1357,8 +1360,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // remainder bits) get none.
     const int idbits = gs_idbits(g->n_nodes);
     const int want_per_cu = lutr ? 4 : 4 * occ;
-    const size_t lut_lds = lutr ? gs_lutr_lds_bytes(pq->M) : (so ? gs_session_lds_bytes() : 0);  // (session kernels: the tracker's arrays)
-    const size_t lds_budget = (160 * 1024) / (size_t)want_per_cu - 256 - lut_lds;
+    const size_t lut_lds = lutr ? gs_lutr_lds_bytes(pq->M) : (so ? gs_session_lds_bytes() : (ub8 ? gs_ub8_lds_bytes(pq->M) : 0));  // (session kernels: the tracker's arrays)
+    // (UB8: 4 waves per CU instead of 8 — the bound table takes 24 KB at PQ-96)
+    const size_t lds_budget = (160 * 1024) / (size_t)(ub8 ? std::max(2, (int)ctx_opt(ctx, "gs_ub8_per_cu", 4)) : want_per_cu) - 256 - lut_lds;
     int v1_log2 = 0;
     if (wgx) {
         // the workgroup owns the CU's LDS: the largest tier that fits next to the table (16384 slots hold every search of the
@@ -1514,6 +1518,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.v1_idbits = idbits;
     p.prefetch = (ctx_opt(ctx, "gs_prefetch", 0) != 0 && evict_cap >= 48 && !generic) ? 1 : 0;  // (dword touches: aligned rows only)
     p.lutr = lutr ? 1 : 0;
+    p.ub8 = ub8 ? 1 : 0;
     if (wgx) {
         p.prefetch = 0;
         p.wgx = 1;

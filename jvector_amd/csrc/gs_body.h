@@ -469,6 +469,113 @@ GS_FN float gs_half_entries(const float *codebooks, const float *qs, const gs_u2
     return sum;
 }
 
+// ---- UB8: an 8-bit UPPER-BOUND table of the query's ADC entries (dot product / cosine; pair-lane kernels) --------------------------
+// Most neighbours a search scores are never popped: a node is only expanded if, at its turn, fewer than rerankK nodes with a
+// strictly greater score have been popped.  So once >= rerankK nodes with exact score >= T are known (queued or popped, all of them
+// able to become results: scores >= 0, no NaN, no acceptOrds filter), a neighbour whose score is < T can never be expanded — the
+// reference would mark it visited, score it, push it, and never look at it again.  Its exact score (M codebook gathers) is therefore
+// not needed IF a cheap rigorous upper bound already shows score < T: the table holds, per (subspace, code), the entry's upper
+// bucket edge in 8 bits (ub = lo_m + S_m * (b + 1) >= entry, checked entry by entry when the table is built), a row's bound is
+// sum_lo + sum_m S_m * (b_m + 1) + slack (slack covers every rounding of the reference's f32 chain and of this sum, 40x over), and the
+// finishing transform is monotone.  T comes from the candidate queue itself: after a partition every key of the LDS tier exceeds
+// the pivot, so when (LDS-tier keys + result keys above the pivot) >= rerankK the pivot's score is such a T; so is the worst kept
+// result once the result queue is full.  Dropped neighbours are counted in visitedCount (they were marked) and are simply not
+// pushed: results, scores, visitedCount and expandedCount are unchanged (tests: every parity test of the traversal runs with the
+// form on).  Measured on the headline index: 56-68 % of the scored neighbours qualify (scripts/ub8_study.py, profiles/r4_o).
+#ifndef GS_HAVE_WAVE_REDUCE_F32
+GS_FN float gs_wave_max_f32(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = gs_bits_float((int32_t)gs_shfl_xor((long long)gs_float_bits(v), o));
+        v = t > v ? t : v;
+    }
+    return v;
+}
+GS_FN float gs_wave_min_f32(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = gs_bits_float((int32_t)gs_shfl_xor((long long)gs_float_bits(v), o));
+        v = t < v ? t : v;
+    }
+    return v;
+}
+#endif
+
+struct GsUb8 {
+    uint8_t *tab;    // [M][256] bucket index of every entry
+    float *lo;       // [M] low edge of subspace m's entries
+    float *scale;    // [M] bucket width
+    float sum_lo;    // sum_m lo[m]
+    float slack;     // added to every bound: rounding of the reference chain and of the bound's own sum
+    bool ok;         // false: the query produced a NaN / inf entry — no bound, nothing is dropped
+};
+
+// the whole wave builds the table of one query; qs = the centred query in LDS
+template <int VSF, int CH16>
+GS_FN void gs_ub8_build(const float *codebooks, const float *qs, GsUb8 &u)
+{
+    constexpr int M = CH16 * 16;
+    const int lane = gs_lane();
+    float sum_lo = 0.0f, sum_abs = 0.0f;
+    bool ok = true;
+    for (int m = 0; m < M; ++m) {
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = gs_lut_entry<VSF>(codebooks, qs, m, r * 64 + lane);
+        float mn = e[0] < e[1] ? e[0] : e[1], mx = e[0] > e[1] ? e[0] : e[1];
+        mn = e[2] < mn ? e[2] : mn;
+        mn = e[3] < mn ? e[3] : mn;
+        mx = e[2] > mx ? e[2] : mx;
+        mx = e[3] > mx ? e[3] : mx;
+        const bool bad = !(e[0] - e[0] == 0.0f) || !(e[1] - e[1] == 0.0f) || !(e[2] - e[2] == 0.0f) || !(e[3] - e[3] == 0.0f);   // NaN / inf
+        ok = ok && gs_ballot(bad) == 0;
+        mn = gs_wave_min_f32(mn);
+        mx = gs_wave_max_f32(mx);
+        float S = (mx - mn) / 255.0f;
+        if (!(S > 1e-30f)) S = 1e-30f;
+        const float inv = 1.0f / S;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int b = (int)((e[r] - mn) * inv);
+            b = b < 0 ? 0 : (b > 255 ? 255 : b);
+            while (b < 255 && mn + S * (float)(b + 1) < e[r]) ++b;   // the bucket's upper edge really is an upper bound, in f32
+            u.tab[m * 256 + r * 64 + lane] = (uint8_t)b;
+        }
+        if (lane == 0) {
+            u.lo[m] = mn;
+            u.scale[m] = S;
+        }
+        sum_lo += mn;
+        const float amn = mn < 0.0f ? -mn : mn, amx = mx < 0.0f ? -mx : mx;
+        sum_abs += (amn > amx ? amn : amx) + 256.0f * S;
+    }
+    u.sum_lo = sum_lo;
+    u.slack = 4e-5f * sum_abs;
+    u.ok = ok && (sum_abs - sum_abs == 0.0f);
+    gs_barrier();
+}
+
+// this lane's half of a row's bound: sum over its HW * 8 subspaces of S_m * (b_m + 1)
+template <int HW>
+GS_FN float gs_ub8_half(const GsUb8 &u, const gs_u2 (&w)[HW], int m_base)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < HW; ++c) {
+        const uint32_t d[2] = {w[c].x, w[c].y};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int m = m_base + c * 8 + e * 4 + b;
+                const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
+                acc += u.scale[m] * (float)((int)u.tab[m * 256 + (int)code] + 1);
+            }
+        }
+    }
+    return acc;
+}
+
 // raw table sum -> similarity (jv_device.h score_from_raw / cosine_finish; PQDecoder.java:68,79,126)
 template <int VSF>
 GS_FN float gs_finish(float sum, float node_mag, float query_mag)
@@ -698,10 +805,11 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 //       through ScoreTracker.TwoPhaseTracker (ScoreTracker.java:80-140: a 500-score window + the 100 best scores, both in LDS);
 //       expandedCountBaseLayer is reported.  What reranking / resume need beyond that is rebuilt by the host from the
 //       addTopCandidate log (graph_search.cpp searcher_search_device).
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
     static_assert(!(LUTR && PAIR), "the register-resident table serves the one-lane-per-neighbour form");
+    static_assert(!UB8 || (PAIR && !SES && !LUTR && VSF != 0), "the upper-bound table serves the pair-lane kernels, dot product / cosine");
     static_assert(CH16 > 0 || !(LUTR || PAIR), "the generic form (CH16 = 0) is one lane per neighbour, table-free");
     constexpr int CW = CH16 > 0 ? CH16 : 1;  // code words a lane holds (the generic form reads its row from memory instead)
     constexpr int LUT_MR = CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB;
@@ -850,6 +958,22 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     }
     const float query_mag = (VSF == 2) ? p.bmag[q] : 0.0f;
     const unsigned long long *acc = p.accept ? p.accept + (long long)q * p.accept_stride : nullptr;
+    // ---- UB8: the query's upper-bound table, behind the worker's block; the pop threshold it is compared with (wave-uniform) ----
+    GsUb8 ub{};
+    float ub_T = -__builtin_inff();       // >= rerankK nodes with exact score >= ub_T are known (queued or popped)
+    long long ub_last_spill_max = GS_KEY_MIN;
+    bool ub_on = false;
+    unsigned long long ub_dropped = 0;
+    if constexpr (UB8) {
+        char *ub_base = lds + gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.M, evict_cap, p.v1_log2);
+        ub.tab = reinterpret_cast<uint8_t *>(ub_base);
+        ub.lo = reinterpret_cast<float *>(ub_base + (size_t)p.M * 256);
+        ub.scale = ub.lo + p.M;
+        gs_ub8_build<VSF, CH16>(p.codebooks, qs, ub);
+        ub_on = ub.ok && acc == nullptr && p.blocks != nullptr;   // (acceptOrds: rejected nodes never become results — no threshold)
+    }
+    (void)ub_last_spill_max;
+    (void)ub_dropped;
 
     // ---- initializeInternal :334-353: mark and score the entry node ----
     {
@@ -873,6 +997,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         sc = gs_finish<VSF>(sc, (VSF == 2) ? p.code_norms[e] : 0.0f, query_mag);
         if (lane == 0) s.cand[0] = gs_key(e, sc);
         s.cand_n = 1;
+        if (UB8 && sc != sc) ub_on = false;
         gs_barrier();
     }
 
@@ -1113,7 +1238,28 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     const int f = gs_popc(fm);
                     fh[f <= 8 ? 0 : (f <= 16 ? 1 : (f <= 24 ? 2 : 3))] += (unsigned long long)f;
                 }
-                const bool work = ((fm >> ni) & 1ull) != 0;  // this lane's pair has a fresh neighbour
+                uint64_t fm_score = fm;   // fresh neighbours that get an exact score
+                if constexpr (UB8) {
+                    // drop what provably cannot be popped: bound of every fresh neighbour (two half sums, joined through the exchange
+                    // area's first row), finished like a score, against the threshold
+                    if (ub_on && lvl == 0 && ub_T > -__builtin_inff()) {
+                        const bool wk = ((fm >> ni) & 1ull) != 0;
+                        const float half = wk ? gs_ub8_half<CH16>(ub, w, m_base) : 0.0f;
+                        if (hi && wk) xchg[ni] = half;
+                        gs_barrier();
+                        bool drop = false;
+                        if (fresh) {
+                            const float braw = ub.sum_lo + (half + xchg[ni]) + ub.slack;
+                            drop = gs_finish<VSF>(braw, node_mag, query_mag) < ub_T;
+                        }
+                        const uint64_t dm = gs_ballot(drop);
+                        gs_barrier();   // (the exchange area is written again by the scoring below)
+                        fm_score = fm & ~dm;
+                        ub_dropped += (unsigned long long)gs_popc(dm);
+                        if (drop) fresh = false;
+                    }
+                }
+                const bool work = ((fm_score >> ni) & 1ull) != 0;  // this lane's pair has a fresh neighbour that needs its score
                 float sum = 0.0f;
                 if (work) sum = gs_half_entries<VSF, CH16>(p.codebooks, qs, w, m_base, hi ? xchg + ni : nullptr);
                 gs_barrier();
@@ -1196,7 +1342,30 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             if constexpr (SES) {
                 if (thr_on) trk_track(fresh, gs_key_score(key));
             }
+            if constexpr (UB8) {   // a NaN score sorts above everything but never becomes a result: no threshold can be proven with one around
+                if (ub_on && gs_ballot(fresh && (int32_t)(key >> 32) == 0x7fc00000)) ub_on = false;
+            }
             gs_push(s, p, key, fresh);
+            if constexpr (UB8) {
+                // ---- the pop threshold: the worst kept result once the result queue is full; the partition pivot once the LDS
+                //      tier (every key above it) plus the results above it number rerankK ----
+                if (ub_on && lvl == 0 && s.status == GS_OK) {
+                    if (s.res_n >= rk) {
+                        const float t = gs_key_score(s.res_min);
+                        if (t > ub_T) ub_T = t;
+                    }
+                    if (s.spill_max != ub_last_spill_max) {
+                        ub_last_spill_max = s.spill_max;
+                        const float ps = gs_key_score(s.spill_max);
+                        if (s.spill_n > 0 && ps >= 0.0f && ps > ub_T) {
+                            int above = 0;
+                            for (int base = 0; base < s.res_n; base += 64)
+                                above += gs_popc(gs_ballot(base + lane < s.res_n && s.res[base + lane] > s.spill_max));
+                            if (s.cand_n + above >= rk) ub_T = ps;
+                        }
+                    }
+                }
+            }
             GS_PHASE(4);
             if (s.status != GS_OK) break;
         }
@@ -1281,11 +1450,12 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         gs_fetch_add64(p.prof + 13, px[1]);
         gs_fetch_add64(p.prof + 14, GS_CLOCK() - pep0);
     }
+    if (UB8 && p.prof && lane == 0) gs_fetch_add64(p.prof + 15, ub_dropped);   // (tests / studies / gs_prof read the drop count)
 #undef GS_PHASE
 }
 
 // Persistent worker: pulls queries off the shared counter until none are left.
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false>
 GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
 {
     for (;;) {
@@ -1293,7 +1463,7 @@ GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
         if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
         const int item = (int)gs_shfl(qv, 0);
         if (item >= p.Q) break;
-        gs_search_one<VSF, CH16, PAIR, PROF, LUTR, SES>(p, p.qmap ? p.qmap[item] : item, worker, lds);
+        gs_search_one<VSF, CH16, PAIR, PROF, LUTR, SES, UB8>(p, p.qmap ? p.qmap[item] : item, worker, lds);
     }
 }
 

@@ -82,6 +82,10 @@ struct GsParams {
     int32_t v1_idbits;        // node ids are < 1 << v1_idbits; v1_idbits - (v1_log2 - 2) <= 14 remainder bits + the choice bit
     // the workgroup form (gx_body.h, k_gsearch_wgx.hip): ONE query per workgroup — the query's ADC table (M x 256 f32) lives in LDS,
     // wave 0 runs the GraphSearcher loop and the other waves ("expanders") score whole adjacency rows it asks for ahead of time
+    // UB8 (one-wave pair-lane kernels, dot product / cosine, layer 0): every wave holds an 8-bit UPPER-BOUND table of its query's ADC
+    // entries in LDS; a fresh neighbour whose bound lies below a proven pop threshold is counted as visited and dropped without
+    // its exact score (gs_body.h "UB8")
+    int32_t ub8;
     int32_t wgx;              // 1: launch the workgroup form
     int32_t wgx_slots;        // scored-row slots in LDS (<= 64)
     int32_t wgx_kps;          // keys per slot: 32 or 64 (>= every level's degree)
@@ -118,6 +122,9 @@ constexpr size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M 
 
 // LDS bytes of the register/LDS split ADC table (gs_body.h gs_lut_build): the subspaces past the 64 held in registers
 constexpr size_t gs_lutr_lds_bytes(int M) { return M > 64 ? (size_t)(M - 64) * 256 * sizeof(float) : 0; }
+
+// LDS bytes of the UB8 form's per-wave bound table: M x 256 bytes + per-subspace {low edge, scale} floats
+constexpr size_t gs_ub8_lds_bytes(int M) { return (size_t)M * 256 + sizeof(float) * 2 * (size_t)M + 16; }
 
 // LDS bytes of the session kernels' TwoPhaseTracker state (500 recent scores + the 100 best)
 constexpr size_t gs_session_lds_bytes() { return sizeof(float) * 500 + sizeof(int32_t) * 100; }

@@ -388,6 +388,7 @@ bool graph_search_device_specialised(const jv_pq *pq, const jv_codes *codes, con
 size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap = 0, int v1_log2 = 0);
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy);
 bool graph_search_lutr_supported(int M);
+bool graph_search_ub8_supported(int M, int kernel_vsf);
 // the workgroup form (k_gsearch_wgx.hip): one query per workgroup, the ADC table in LDS
 bool graph_search_wgx_supported(int M);
 size_t graph_search_wgx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int logcap, int M);

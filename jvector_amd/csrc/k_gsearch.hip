@@ -41,6 +41,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     gs_worker<VSF, CH16, PAIR>(p, (int)blockIdx.x, gs_lds);
 }
 
+// UB8 (gs_body.h "UB8"): the pair-lane kernel with an 8-bit upper-bound table of the query's ADC entries in LDS (+ M x 256 bytes per
+// wave): fresh neighbours that provably cannot be popped are dropped without their M codebook gathers.  Dot product / cosine.
+template <int VSF, int CH16, bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void graph_search_ub8_kernel(GsParams p)   // (<= 4 waves per CU: a SIMD to itself, no register cap)
+{
+    extern __shared__ __attribute__((aligned(16))) char gs_lds[];
+    gs_worker<VSF, CH16, true, PROF, false, false, true>(p, (int)blockIdx.x, gs_lds);
+}
+
+template <int VSF>
+static int launch_gs_ub8(hipStream_t s, const GsParams &p, int ch, int workers, size_t lds)
+{
+    dim3 grid(workers), block(64);
+#define JV_UB8(CH)                                                                                              \
+    do {                                                                                                        \
+        if (p.prof) {                                                                                           \
+            auto kfn = graph_search_ub8_kernel<VSF, CH, true>;                                                  \
+            JV_HIP_CHECK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                    \
+        } else {                                                                                                \
+            auto kfn = graph_search_ub8_kernel<VSF, CH, false>;                                                 \
+            JV_HIP_CHECK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                    \
+        }                                                                                                       \
+    } while (0)
+    switch (ch) {
+    case 1: JV_UB8(1); break;
+    case 2: JV_UB8(2); break;
+    case 3: JV_UB8(3); break;
+    case 4: JV_UB8(4); break;
+    case 6: JV_UB8(6); break;
+    default:
+        set_error("graph search kernel: the upper-bound form is built for M = 16 ... 96 (M = %d)", ch * 16);
+        return JV_ERR_UNSUPPORTED;
+    }
+#undef JV_UB8
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+bool graph_search_ub8_supported(int M, int vsf) { return vsf != VSF_L2 && (M == 16 || M == 32 || M == 48 || M == 64 || M == 96); }
+
 // The register-resident-table form (gs_body.h gs_lut_build / gs_row_sum_lut): ONE wave per SIMD owns all 512 vector registers,
 // 4 M of them hold the query's ADC table, look-ups are ds_bpermute reads.  4 workers per CU instead of 8, but an expansion no
 // longer issues ~190 divergent 16-byte gathers into the CU's vector-memory path.
@@ -175,6 +217,14 @@ int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, 
             return JV_ERR_INVALID;
         }
         return launch_graph_search_session(s, vsf, p, workers, lds + gs_session_lds_bytes());
+    }
+    if (p.ub8) {
+        if (!p.pair || p.lutr || p.session || p.generic || vsf == VSF_L2) {
+            set_error("graph search kernel: the upper-bound form serves the pair-lane kernels, dot product / cosine");
+            return JV_ERR_INVALID;
+        }
+        const size_t lds8 = lds + gs_ub8_lds_bytes(p.M);
+        return vsf == VSF_DOT ? launch_gs_ub8<VSF_DOT>(s, p, ch, workers, lds8) : launch_gs_ub8<VSF_COS>(s, p, ch, workers, lds8);
     }
     if (p.lutr) {
         if (p.pair) {

@@ -100,6 +100,18 @@ void run_lutr(const Launch &L)
     }
 }
 template <int VSF>
+void run_ub8(const Launch &L)
+{
+    switch (L.ch) {
+    case 1: jv::gs_worker<VSF, 1, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 2: jv::gs_worker<VSF, 2, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 3: jv::gs_worker<VSF, 3, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 4: jv::gs_worker<VSF, 4, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gs_worker<VSF, 6, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
+template <int VSF>
 void run_wgx(const Launch &L)
 {
     switch (L.ch) {
@@ -120,6 +132,9 @@ void lane_main(void *arg)
         if (L.vsf == 0) run_wgx<0>(L);
         else if (L.vsf == 1) run_wgx<1>(L);
         else run_wgx<2>(L);
+    } else if (L.p->ub8) {
+        if (L.vsf == 1) run_ub8<1>(L);
+        else run_ub8<2>(L);
     } else if (L.p->lutr) {
         if (L.vsf == 0) run_lutr<0>(L);
         else if (L.vsf == 1) run_lutr<1>(L);
@@ -137,7 +152,9 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
                               int32_t *out_status, int v1_log2 /* LDS tier of the visited set: log2(slots), 0 = none */, int v1_idbits,
                               int evict_cap /* 0 = GS_EVICT_CAP */, int lutr /* 1: ADC table in registers + LDS (M <= 96) */,
                               int wgx_waves /* > 0: the workgroup form (gx_body.h) with this many waves (2..4 here), M <= 128 */,
-                              int wgx_slots, int wgx_depth, int wgx_lut_m /* 0 = M */)
+                              int wgx_slots, int wgx_depth, int wgx_lut_m /* 0 = M */,
+                              int ub8 /* 1: the pair-lane kernel with the 8-bit upper-bound table (dot / cosine, M <= 96, degrees <= 32) */,
+                              long long *ub8_dropped_out /* nullable */)
 {
     if (lutr && M > 96) return -4;
     if (wgx_waves && (M == 80 || M == 112 || wgx_waves < 2 || wgx_waves > emu::MAX_WAVES || lutr)) return -5;
@@ -170,6 +187,8 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     for (int l = 0; l < n_levels; ++l) pair = pair && lv_degree[l] <= 32;
     p.lutr = lutr ? 1 : 0;
     p.pair = pair ? 1 : 0;
+    if (ub8 && (!pair || vsf == 0 || M > 96 || wgx_waves || lutr)) return -7;
+    p.ub8 = ub8 ? 1 : 0;
     p.v1_log2 = v1_log2; p.v1_idbits = v1_idbits; p.evict_cap = evict_cap;
     p.prefetch = getenv("GS_EMU_PREFETCH") ? atoi(getenv("GS_EMU_PREFETCH")) : 1;  // on by default in the emulator: more code under test
     int kps = 32;
@@ -191,6 +210,8 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_stats = out_stats; p.out_status = out_status;
     uint32_t next = 0;
     p.next_query = &next;
+    unsigned long long prof[16] = {0};
+    if (ub8) p.prof = prof;   // (only slot 15 is written without the phase-clock build: neighbours dropped behind the bound)
     long collectives = 0;
     // "workers" waves run one after another; each drains part of the queue so that scratch reuse across queries and
     // distinct worker slices are both exercised
@@ -198,7 +219,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
         jv::GsParams pw = p;
         pw.Q = (int)((long long)Q * (w + 1) / workers);
         const size_t lds_bytes = wgx_waves ? jv::gx_lds_bytes(D, rerankK, cand_cap, ecap, v1_log2, wgx_slots, kps, p.wgx_log, p.wgx_lut_m)
-                                           : jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0);
+                                           : jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0) + (ub8 ? jv::gs_ub8_lds_bytes(M) : 0);
         char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
         memset(lds, 0xa5, lds_bytes);
         memset(lds + lds_bytes, 0x3c, 64);  // canary behind the block
@@ -211,6 +232,8 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     }
     free(visited);
     free(spill);
+    if (ub8 && getenv("GS_EMU_PRINT_UB8")) fprintf(stderr, "[gs_emu] ub8 dropped %llu neighbours\n", prof[15]);
+    if (ub8 && ub8_dropped_out) *ub8_dropped_out = (long long)prof[15];
     return collectives;
 }
 

@@ -43,7 +43,7 @@ def seq_sum_f32(table, codes):
 
 
 def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vcap_log2=14, spill_cap=8192, cand_cap=256,
-            workers=2, pair=1, v1_log2=9, v1_idbits=None, evict_cap=0, lutr=0, wgx_waves=0, wgx_slots=4, wgx_depth=1, wgx_lut_m=0):
+            workers=2, pair=1, v1_log2=9, v1_idbits=None, evict_cap=0, lutr=0, wgx_waves=0, wgx_slots=4, wgx_depth=1, wgx_lut_m=0, ub8=0):
     """v1_log2: slots of the visited set's LDS tier (default 512: small enough that the toy searches fill it, freeze it and go
     on in tier 2, so both tiers and the hand-over are exercised by every test); 0 = no LDS tier"""
     N, M, D = codes.shape[0], opq.M, opq.D
@@ -78,11 +78,13 @@ def run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rerank_k, fused, vc
     codes = np.ascontiguousarray(codes, np.uint8)
     if v1_idbits is None:
         v1_idbits = max(1, int(N - 1).bit_length())
+    dropped = C.c_longlong(0)
     n = emu.gs_emu_search(L, nodes, nbrs, count, degree, entry, entry_level, fp(cb), fp(cq), fp(bmag), fp(codes),
                           fp(code_norms), fp(blocks), fp(fnorms), D, M, deg0, Q, rerank_k, int(vsf), vcap_log2, spill_cap,
                           cand_cap, workers, pair, fp(out_ids), fp(out_sc), fp(stats), fp(status), v1_log2, v1_idbits, evict_cap, lutr,
-                          wgx_waves, wgx_slots, wgx_depth, wgx_lut_m)
+                          wgx_waves, wgx_slots, wgx_depth, wgx_lut_m, ub8, C.byref(dropped))
     assert n >= 0, n
+    run_emu.last_ub8_dropped = int(dropped.value)
     return out_ids, out_sc, stats, status, n
 
 
@@ -160,6 +162,41 @@ def test_workgroup_form_under_lane_reordering(emu, monkeypatch, order):
         ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, cand_cap=256, wgx_waves=4,
                                          wgx_slots=slots)
         check(ids, sc, st, status, wi, ws, wst)
+
+
+@pytest.mark.parametrize("levels,fused,M,deg,N", [(2, True, 96, 32, 2500), (1, True, 16, 16, 4000), (3, True, 48, 24, 3000), (2, True, 64, 32, 2500)])
+def test_upper_bound_table_form(emu, levels, fused, M, deg, N):
+    """UB8: the pair-lane kernel that drops fresh neighbours an 8-bit upper-bound table proves unpoppable — dropped nodes still count
+    as visited and nothing else may change: ids, scores and BOTH counters equal the oracle's, dot product and cosine, rerankK small
+    enough that the pivot / full-result thresholds become active long before the search ends (and rerankK 1)"""
+    D = 8 * M
+    lv, entry, entry_level, opq, codes, q = problem(700 + levels + M, N, D, M, levels, deg=deg, nq=8)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    dropped_total = scored_total = 0
+    for vsf in (O.DOT_PRODUCT, O.COSINE):
+        for rk in (10, 40, 150, 1):
+            wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
+            scored_total += 2 * int(wst[:, 0].sum())
+            for v1, cc in ((9, 256), (12, 128)):
+                ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, ub8=1, v1_log2=v1, cand_cap=cc)
+                check(ids, sc, st, status, wi, ws, wst)
+                dropped_total += run_emu.last_ub8_dropped
+    assert dropped_total > 0.05 * scored_total, (dropped_total, scored_total)   # the form really drops neighbours in these searches
+
+
+def test_upper_bound_table_form_with_equal_and_extreme_scores(emu, monkeypatch):
+    """duplicated vectors (equal scores around every threshold), a query that is a base vector, shuffled lane orders"""
+    lv, entry, entry_level, opq, codes, q = problem(19, 3000, 128, 16, 2, deg=24, nq=6)
+    codes = codes.copy()
+    codes[1::2] = codes[0:-1:2][: len(codes[1::2])]
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    for order in ("", "reverse", "random:9"):
+        if order:
+            monkeypatch.setenv("EMU_LANE_ORDER", order)
+        for vsf in (O.DOT_PRODUCT, O.COSINE):
+            wi, ws, wst = og.search(opq, codes, None, q, vsf, 30, 30, fused=True)
+            ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, 30, True, ub8=1)
+            check(ids, sc, st, status, wi, ws, wst)
 
 
 def test_workgroup_form_rare_paths(emu):

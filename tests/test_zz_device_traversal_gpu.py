@@ -353,3 +353,26 @@ def test_workgroup_form_large_batch_with_spills_and_overflow(ctx, n_queries=1500
     finally:
         for k in ("gs_wgx", "gs_cand_cap", "gs_vcap_log2", "gs_retry", "gs_grow"):
             ctx.set_option(k, None)
+
+
+@pytest.mark.parametrize("levels,D,M,deg,N", [(2, 768, 96, 32, 20000), (2, 128, 16, 16, 8000), (3, 384, 48, 24, 12000), (2, 512, 64, 32, 12000)])
+def test_upper_bound_table_kernel(ctx, levels, D, M, deg, N):
+    """gs_ub8 = 1: the pair-lane kernel that drops fresh neighbours an 8-bit upper-bound table proves unpoppable (dot product / cosine,
+    FusedPQ): ids, scores and both counters equal the oracle's — dropped neighbours still count as visited — at rerankK values where
+    the thresholds become active early; euclidean searches and filtered searches fall back to the plain kernel"""
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 13 * levels + M, N, D, M, levels, True, deg=deg)
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+    try:
+        ctx.set_option("gs_ub8", 1)
+        ctx.set_option("gs_wgx", 0)
+        for vsf in VSF:
+            for top_k, rk in ((10, 40), (10, 150), (1, 1)):
+                for per_cu in (3, 4):
+                    ctx.set_option("gs_ub8_per_cu", per_cu)
+                    ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True)
+                    wi, ws, wst = og.search(opq, codes, v, q, int(vsf), top_k, rk, fused=True)
+                    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rk, per_cu)
+    finally:
+        for k in ("gs_ub8", "gs_wgx", "gs_ub8_per_cu"):
+            ctx.set_option(k, None)
