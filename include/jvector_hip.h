@@ -327,7 +327,10 @@ JV_API int jv_hip_nvq_vectors_destroy(jv_nvq_vectors *nv);
  * [0, count) give -inf */
 JV_API int jv_hip_nvq_scores(jv_ctx *ctx, const jv_nvq_vectors *nv, const float *queries, int Q, jv_vsf vsf,
                              const int32_t *ordinals, int B, float *scores_out);
-/* a jv_vectors whose rows are `nv` (which must outlive it); destroy with jv_hip_vectors_destroy */
+/* a jv_vectors whose rows are `nv`; destroy with jv_hip_vectors_destroy.
+ * OWNERSHIP ORDER of the NVQ handles (nothing is reference-counted): a jv_nvq must outlive every jv_nvq_vectors created from it, a
+ * jv_nvq_vectors must outlive every jv_vectors view of it — destroy views, then rows, then the NVQuantization (the Python mirror keeps
+ * the parents alive for you).  Every handle of a call must live on the context's device (JV_ERR_INVALID otherwise). */
 JV_API int jv_hip_vectors_from_nvq(jv_ctx *ctx, jv_nvq_vectors *nv, jv_vectors **out);
 
 /* ---------------------------------------------------------------------------------------------

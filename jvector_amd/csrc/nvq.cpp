@@ -197,6 +197,7 @@ int jv_hip_nvq_vectors_create(jv_ctx *ctx, const jv_nvq *nvq, int64_t count, jv_
     clear_error();
     JV_REQUIRE(ctx && nvq && out, "nvq_vectors_create: NULL argument");
     JV_REQUIRE(count > 0, "nvq_vectors_create: count must be positive");
+    JV_REQUIRE(ctx->device == nvq->device, "nvq_vectors_create: the NVQuantization lives on device %d, the context on %d", nvq->device, ctx->device);
     JV_TRY(use_device(ctx->device));
     jv_nvq_vectors *nv = new jv_nvq_vectors();
     nv->device = ctx->device;
@@ -226,6 +227,9 @@ int jv_hip_nvq_encode(jv_ctx *ctx, const jv_nvq *nvq, const jv_vectors *v, int64
     clear_error();
     JV_REQUIRE(ctx && nvq && v && dst, "nvq_encode: NULL argument");
     JV_REQUIRE(dst->nvq == nvq, "nvq_encode: the destination belongs to another NVQuantization");
+    JV_REQUIRE(ctx->device == nvq->device && ctx->device == v->device && ctx->device == dst->device,
+               "nvq_encode: context, NVQuantization, vectors and destination must share a device (%d / %d / %d / %d)", ctx->device, nvq->device,
+               v->device, dst->device);
     if (v->nvq) {
         set_error("nvq_encode: the vector set holds NVQ rows, not floats");
         return JV_ERR_UNSUPPORTED;
@@ -309,6 +313,7 @@ int jv_hip_nvq_scores(jv_ctx *ctx, const jv_nvq_vectors *nv, const float *querie
     JV_REQUIRE(vsf == JV_EUCLIDEAN || vsf == JV_DOT_PRODUCT || vsf == JV_COSINE, "nvq_scores: unsupported similarity function %d", (int)vsf);
     if (Q == 0 || B == 0) return JV_OK;
     JV_REQUIRE(queries && ordinals && scores_out, "nvq_scores: NULL buffer");
+    JV_REQUIRE(ctx->device == nv->device, "nvq_scores: the NVQ rows live on device %d, the context on %d", nv->device, ctx->device);
     JV_TRY(use_device(ctx->device));
     const void *d_q = nullptr, *d_ord = nullptr;
     JV_TRY(stage_in(ctx, queries, sizeof(float) * (size_t)Q * nv->nvq->D, ctx->h_in, ctx->d_in, &d_q));
@@ -323,6 +328,7 @@ int jv_hip_vectors_from_nvq(jv_ctx *ctx, jv_nvq_vectors *nv, jv_vectors **out)
 {
     clear_error();
     JV_REQUIRE(ctx && nv && out, "vectors_from_nvq: NULL argument");
+    JV_REQUIRE(ctx->device == nv->device, "vectors_from_nvq: the NVQ rows live on device %d, the context on %d", nv->device, ctx->device);
     jv_vectors *v = new jv_vectors();
     v->device = nv->device;
     v->count = nv->count;
