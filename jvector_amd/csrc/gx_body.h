@@ -7,7 +7,7 @@
 // on a CU: the table (M x 256 f32 = 96 KB at PQ-96) is built once per query into LDS by the whole workgroup and every score is M
 // ds_read_b32 + M adds in ascending m (assembleAndSum, DefaultVectorUtilSupport.java:302-309,323-330).  One query per CU leaves
 // nothing to hide the HBM latency of an expansion's adjacency row + FusedPQ block behind, so the work is split by ROLE:
-//   wave 0           the control wave: GraphSearcher's loop (gs_search_one<..., WGX = true>) — candidate / result queues, visited set,
+//   wave 0           the control wave: GraphSearcher's loop (gx_control below) — candidate / result queues, visited set,
 //                    stop rule; it never touches an adjacency row or a code byte
 //   waves 1 .. E     expanders: take (node, level) requests from a ring in LDS, read the node's adjacency row + the neighbours' code
 //                    bytes (the FusedPQ block at level 0) from HBM, score EVERY neighbour of the row against the table and leave one
@@ -190,7 +190,11 @@ GS_FN void gx_control(const GsParams &p, int q, int worker, char *lds)
     int32_t sl_node = -1, sl_lvl = 0;
     long long sl_ckey = 0;
 
-    // ---- the scored-row slots (see gs_search_one's WGX notes: the same protocol) ----
+    // ---- the scored-row slots.  Slot t is managed by lane t: sl_node / sl_lvl / sl_ckey are PER-LANE registers (the (node, level) the
+    //      slot holds, -1 = free; the candidate key it was requested for, which decides evictions).  slot_find: the slot holding
+    //      (node, level) or -1.  slot_post: ask the expanders for a row; `must` (the popped node itself) evicts the READY slot whose
+    //      candidate is the worst when every slot is taken (its row is simply requested again should that candidate ever be popped);
+    //      a speculative request just gives up (-1). ----
     auto slot_find = [&](int32_t node, int lvl) -> int {
         const uint64_t m = gs_ballot(lane < p.wgx_slots && sl_node == node && sl_lvl == lvl);
         return m ? gs_first(m) : -1;

@@ -1,4 +1,4 @@
-// k_gsearch_wgx.hip — the WORKGROUP form of the device-resident traversal (body: gx_body.h + gs_body.h with WGX = true): one query
+// k_gsearch_wgx.hip — the WORKGROUP form of the device-resident traversal (body: gx_body.h on top of gs_body.h's helpers): one query
 // per workgroup, the query's ADC table [M][256] f32 in LDS, wave 0 = GraphSearcher's loop, the other waves score adjacency rows it
 // requests ahead of time.  A translation unit of its own: inside it gs_barrier() is a WAVE-scope sync point (the control wave is one
 // wave of a larger workgroup), everywhere else a workgroup barrier.
