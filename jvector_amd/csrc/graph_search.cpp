@@ -1346,11 +1346,17 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         wgx = wgx_bytes(0, wgx_lut_m) <= wgx_budget;
     }
     if (wgx) pair = false;
+    // Rows of 33 ... 64 neighbours with the codes read by ordinal (the builder's working rows: maxDegree x neighborOverflow): the
+    // compacted pair form — a lane per neighbour for the visited probe, two lanes per FRESH neighbour for the score (gs_body.h
+    // "PAIRC").  gs_pairc = 0 turns it off.
+    bool pairc = occ == 2 && !so && !wgx && !pair && !lutr && !generic && !fused && pq->M <= 96 && ctx_opt(ctx, "gs_pair", 1) != 0 &&
+                 ctx_opt(ctx, "gs_pairc", 1) != 0;
+    for (int lv = 0; lv <= g->entry_level; ++lv) pairc = pairc && g->levels[lv].degree <= 64;
     // gs_ub8 = 1: the pair-lane kernel with an 8-bit upper-bound table of the query's ADC entries per wave (gs_body.h "UB8": fresh
     // neighbours that provably cannot be popped skip their exact score).  Costs M x 256 bytes of LDS per wave (fewer waves per CU).
     const bool ub8 = !so && !wgx && pair && !lutr && fused && !dev_accept.bits && ctx_opt(ctx, "gs_ub8", 0) != 0 && graph_search_ub8_supported(pq->M, kvsf);
-    const int pair_M = pair ? pq->M : 0;
-    int cand_cap = wgx ? wgx_cand_cap : std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", lutr ? 256 : (occ == 4 ? 512 : (pair ? 256 : 1024)))) & ~63;
+    const int pair_M = (pair || pairc) ? pq->M : 0;
+    int cand_cap = wgx ? wgx_cand_cap : std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", lutr ? 256 : (occ == 4 ? 512 : ((pair || pairc) ? 256 : 1024)))) & ~63;
     while (!wgx && cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
     // Visited set, tier 1 (gs_body.h gs_visit1): a two-choice bucketed LDS table of 16-bit entries in whatever the other
     // per-worker structures leave of 160 KB / (4 x occ workers per CU).  Preference: the largest table first (4096 slots = 8 KB
@@ -1576,7 +1582,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p.big_log2 = big_log2;
         p.big_spill_cap = big_spill_cap;
     }
-    p.pair = pair ? 1 : 0;
+    p.pair = pair ? 1 : (pairc ? 2 : 0);
     p.out_ids = d_cand;
     p.out_scores = d_cand_sc;
     p.out_stats = d_stats;
@@ -1766,10 +1772,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     ctx_stat_set(ctx, "gs_last_v1_log2", v1_log2);
     ctx_stat_set(ctx, "gs_last_workers_per_cu", per_cu);
     ctx_stat_set(ctx, "gs_last_wgx", wgx ? 1 : 0);
+    ctx_stat_set(ctx, "gs_last_pair", pair ? 1 : (pairc ? 2 : 0));   // 1: pair lanes over the row, 2: over the compacted fresh list
     if (wgx) ctx_stat_add(ctx, "gs_calls_wgx", 1);
     if (ctx_opt(ctx, "graph_timing", 0) != 0)
         fprintf(stderr, "[jv graph_search device] Q=%d workers=%d (x%d/CU, occ %d, pair %d, wgx %d) lds=%zu cand_cap=%d evict_cap=%d v1_log2=%d vcap=%zu overflow=%zu rerank ties=%zu (+%zu to the host) -> host %zu\n", Q,
-                workers, per_cu, occ, (int)pair, wgx ? wgx_waves : 0, lds, cand_cap, evict_cap, v1_log2, vcap, n_overflow_first, n_ties_resolved, n_ties, redo.size());
+                workers, per_cu, occ, pair ? 1 : (pairc ? 2 : 0), wgx ? wgx_waves : 0, lds, cand_cap, evict_cap, v1_log2, vcap, n_overflow_first, n_ties_resolved, n_ties, redo.size());
     if (redo.empty()) return JV_OK;
 
     // ---- queries that outgrew the fixed-size device structures: same search on the host ----

@@ -805,9 +805,14 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 //       through ScoreTracker.TwoPhaseTracker (ScoreTracker.java:80-140: a 500-score window + the 100 best scores, both in LDS);
 //       expandedCountBaseLayer is reported.  What reranking / resume need beyond that is rebuilt by the host from the
 //       addTopCandidate log (graph_search.cpp searcher_search_device).
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false>
+// PAIRC: pair-lane scoring of the FRESH neighbours of rows up to 64 wide whose codes are read by ordinal (the builder's working
+//       rows, maxDegree x neighborOverflow): one lane per neighbour probes the visited set, the unvisited ids are compacted
+//       through LDS and scored two lanes each like PAIR (<= 32 per pass, a second pass for the rest).  LDS layout = PAIR's.
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false, bool PAIRC = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
+    static_assert(!PAIRC || (!PAIR && !LUTR && !UB8 && CH16 > 0), "the compacted pair form is a variant of the plain one-lane-per-neighbour kernel");
+    constexpr bool XA = PAIR || PAIRC;   // the worker's LDS block has the [M/2][32] exchange area
     static_assert(!(LUTR && PAIR), "the register-resident table serves the one-lane-per-neighbour form");
     static_assert(!UB8 || (PAIR && !SES && !LUTR && VSF != 0), "the upper-bound table serves the pair-lane kernels, dot product / cosine");
     static_assert(CH16 > 0 || !(LUTR || PAIR), "the generic form (CH16 = 0) is one lane per neighbour, table-free");
@@ -857,7 +862,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     const bool has_v1 = p.v1_log2 > 0;
     auto gs_v1_of = [&]() -> GsVis1 {
         GsVis1 t;
-        const size_t base = ((size_t)((char *)(xchg + 32 * (PAIR ? p.M / 2 : 0)) - lds) + (PAIR ? 0 : sizeof(long long) * 64) + 15) & ~(size_t)15;
+        const size_t base = ((size_t)((char *)(xchg + 32 * (XA ? p.M / 2 : 0)) - lds) + (XA ? 0 : sizeof(long long) * 64) + 15) & ~(size_t)15;
         t.w = reinterpret_cast<uint32_t *>(lds + base);
         t.bmask = (1u << (p.v1_log2 - 2)) - 1u;
         t.idmask = (p.v1_idbits >= 32) ? 0xFFFFFFFFu : ((1u << p.v1_idbits) - 1u);
@@ -1011,7 +1016,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     long long n_expanded_base = 0;
     float cur_thr = p.threshold;   // the running phase's threshold (SES with n_phases > 1: ph_threshold[phase])
     if constexpr (SES) {
-        trk_recent = reinterpret_cast<float *>(lds + gs_lds_bytes(p.D, p.rerankK, p.cand_cap, PAIR ? p.M : 0, evict_cap, p.v1_log2));
+        trk_recent = reinterpret_cast<float *>(lds + gs_lds_bytes(p.D, p.rerankK, p.cand_cap, XA ? p.M : 0, evict_cap, p.v1_log2));
         trk_best = reinterpret_cast<int32_t *>(trk_recent + TRK_RECENT);
     }
     auto trk_sortable = [](float f) -> int32_t {   // NumericUtils.floatToSortableInt
@@ -1268,6 +1273,61 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     for (int j = 0; j < CH16 * 8; ++j) sum += xchg[j * 32 + ni];
                     key = gs_key(nb, gs_finish<VSF>(sum, node_mag, query_mag));
                 }
+            } else if constexpr (PAIRC) {
+                // ---- rows of up to 64 neighbours, codes by ordinal: one lane per neighbour for the visited probe, then the fresh
+                //      ones — compacted in row order — two lanes each (low: subspaces [0, M/2), high: [M/2, M), the low lane adds
+                //      all M entries in ascending m).  The order of the pushes inside an expansion is immaterial (see below).
+                const int32_t nb0 = lane < deg ? row[lane] : -1;
+                const int first_neg = gs_first(gs_ballot(nb0 < 0));  // rows are packed: the first -1 ends the row
+                const bool fr0 = visit(lane < first_neg, nb0);
+                if (s.status != GS_OK) break;
+                const uint64_t fm = gs_ballot(fr0);
+                if (fm == 0) continue;
+                const int nf = gs_popc(fm);
+                n_visited += nf;
+                GS_PHASE(2);
+                int32_t *cmp = reinterpret_cast<int32_t *>(xchg);   // (consumed into registers before the exchange area is written)
+                if (fr0) cmp[gs_popc(fm & ((1ull << lane) - 1ull))] = nb0;
+                gs_barrier();
+                const int ni = lane & 31;
+                const bool hi = lane >= 32;
+                const int m_base = hi ? p.M / 2 : 0;
+                const int32_t cn0 = ni < nf ? cmp[ni] : -1;
+                const int32_t cn1 = 32 + ni < nf ? cmp[32 + ni] : -1;
+                gs_barrier();
+                bool give_up = false;
+#pragma unroll 1
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int32_t cn = pass ? cn1 : cn0;
+                    const bool work = cn >= 0;
+                    gs_u2 w[CH16];
+                    float node_mag = 0.0f, sum = 0.0f;
+                    if (work) {   // PQDecoder.similarityTo: the neighbour's own code
+                        gs_load_half<CH16>(p.codes + (int64_t)cn * p.M + m_base, w);
+                        if (VSF == 2 && !hi) node_mag = p.code_norms[cn];
+                        sum = gs_half_entries<VSF, CH16>(p.codebooks, qs, w, m_base, hi ? xchg + ni : nullptr);
+                    }
+                    gs_barrier();
+                    fresh = work && !hi;
+                    key = 0;
+                    if (fresh) {
+#pragma unroll
+                        for (int j = 0; j < CH16 * 8; ++j) sum += xchg[j * 32 + ni];
+                        key = gs_key(cn, gs_finish<VSF>(sum, node_mag, query_mag));
+                    }
+                    if (pass == 1 || nf <= 32) break;   // the shared tail below pushes this pass
+                    gs_barrier();   // every low lane has read its column before the push's sample buffer reuses the bytes
+                    if constexpr (SES) {
+                        if (thr_on) trk_track(fresh, gs_key_score(key));
+                    }
+                    gs_push(s, p, key, fresh);
+                    fresh = false;
+                    if (s.status != GS_OK) {
+                        give_up = true;
+                        break;
+                    }
+                }
+                if (give_up) break;
             } else {
                 // ---- one lane per neighbour, 64 neighbours at a time (degrees above 64: the next chunk of the row; inside an
                 //      expansion the order of visited.mark / push / track calls is immaterial — sets and a priority queue) ----
@@ -1455,7 +1515,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 }
 
 // Persistent worker: pulls queries off the shared counter until none are left.
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false, bool PAIRC = false>
 GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
 {
     for (;;) {
@@ -1463,7 +1523,7 @@ GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
         if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
         const int item = (int)gs_shfl(qv, 0);
         if (item >= p.Q) break;
-        gs_search_one<VSF, CH16, PAIR, PROF, LUTR, SES, UB8>(p, p.qmap ? p.qmap[item] : item, worker, lds);
+        gs_search_one<VSF, CH16, PAIR, PROF, LUTR, SES, UB8, PAIRC>(p, p.qmap ? p.qmap[item] : item, worker, lds);
     }
 }
 

@@ -41,6 +41,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
     gs_worker<VSF, CH16, PAIR>(p, (int)blockIdx.x, gs_lds);
 }
 
+// PAIRC (gs_body.h "PAIRC", GsParams::pair == 2): rows of 33 ... 64 neighbours whose codes are read by ordinal — the builder's
+// working rows.  One lane per neighbour probes the visited set, the fresh ones are scored two lanes each.
+template <int VSF, int CH16>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_pairc_kernel(GsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char gs_lds[];
+    gs_worker<VSF, CH16, false, false, false, false, false, true>(p, (int)blockIdx.x, gs_lds);
+}
+
 // UB8 (gs_body.h "UB8"): the pair-lane kernel with an 8-bit upper-bound table of the query's ADC entries in LDS (+ M x 256 bytes per
 // wave): fresh neighbours that provably cannot be popped are dropped without their M codebook gathers.  Dot product / cosine.
 template <int VSF, int CH16, bool PROF>
@@ -105,6 +114,25 @@ static int launch_gs_ch(hipStream_t s, const GsParams &p, int ch, int workers, s
 {
     dim3 grid(workers), block(64);
     const bool pair = p.pair != 0;
+    if (p.pair == 2) {   // the compacted pair form
+        if constexpr (OCC == 2) {
+            switch (ch) {
+            case 1: hipLaunchKernelGGL((graph_search_pairc_kernel<VSF, 1>), grid, block, lds, s, p); break;
+            case 2: hipLaunchKernelGGL((graph_search_pairc_kernel<VSF, 2>), grid, block, lds, s, p); break;
+            case 3: hipLaunchKernelGGL((graph_search_pairc_kernel<VSF, 3>), grid, block, lds, s, p); break;
+            case 4: hipLaunchKernelGGL((graph_search_pairc_kernel<VSF, 4>), grid, block, lds, s, p); break;
+            case 6: hipLaunchKernelGGL((graph_search_pairc_kernel<VSF, 6>), grid, block, lds, s, p); break;
+            default:
+                set_error("graph search kernel: the compacted pair form is built for M = 16 ... 96 (M = %d)", ch * 16);
+                return JV_ERR_UNSUPPORTED;
+            }
+            JV_HIP_CHECK(hipGetLastError());
+            return JV_OK;
+        } else {
+            set_error("graph search kernel: pair-lane scoring is only built for the 2-waves/SIMD variant");
+            return JV_ERR_INVALID;
+        }
+    }
     if (pair && OCC != 2) {
         set_error("graph search kernel: pair-lane scoring is only built for the 2-waves/SIMD variant");
         return JV_ERR_INVALID;

@@ -112,6 +112,18 @@ void run_ub8(const Launch &L)
     }
 }
 template <int VSF>
+void run_pairc(const Launch &L)
+{
+    switch (L.ch) {
+    case 1: jv::gs_worker<VSF, 1, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 2: jv::gs_worker<VSF, 2, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 3: jv::gs_worker<VSF, 3, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 4: jv::gs_worker<VSF, 4, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gs_worker<VSF, 6, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
+template <int VSF>
 void run_wgx(const Launch &L)
 {
     switch (L.ch) {
@@ -139,6 +151,10 @@ void lane_main(void *arg)
         if (L.vsf == 0) run_lutr<0>(L);
         else if (L.vsf == 1) run_lutr<1>(L);
         else run_lutr<2>(L);
+    } else if (L.p->pair == 2) {
+        if (L.vsf == 0) run_pairc<0>(L);
+        else if (L.vsf == 1) run_pairc<1>(L);
+        else run_pairc<2>(L);
     } else if (L.p->pair) run_vsf<true>(L);
     else run_vsf<false>(L);
 }
@@ -186,7 +202,11 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     bool pair = pair_mode != 0 && !lutr && !wgx_waves;  // same rule as graph_search.cpp
     for (int l = 0; l < n_levels; ++l) pair = pair && lv_degree[l] <= 32;
     p.lutr = lutr ? 1 : 0;
-    p.pair = pair ? 1 : 0;
+    // pair_mode 2: the compacted pair form (rows of up to 64 neighbours, codes by ordinal, M <= 96) where the plain pair form does not apply
+    bool pairc = pair_mode == 2 && !pair && !lutr && !wgx_waves && !blocks && M <= 96;
+    for (int l = 0; l < n_levels; ++l) pairc = pairc && lv_degree[l] <= 64;
+    if (pair_mode == 2 && !pair && !pairc) return -8;
+    p.pair = pair ? 1 : (pairc ? 2 : 0);
     if (ub8 && (!pair || vsf == 0 || M > 96 || wgx_waves || lutr)) return -7;
     p.ub8 = ub8 ? 1 : 0;
     p.v1_log2 = v1_log2; p.v1_idbits = v1_idbits; p.evict_cap = evict_cap;
@@ -219,7 +239,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
         jv::GsParams pw = p;
         pw.Q = (int)((long long)Q * (w + 1) / workers);
         const size_t lds_bytes = wgx_waves ? jv::gx_lds_bytes(D, rerankK, cand_cap, ecap, v1_log2, wgx_slots, kps, p.wgx_log, p.wgx_lut_m)
-                                           : jv::gs_lds_bytes(D, rerankK, cand_cap, pair ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0) + (ub8 ? jv::gs_ub8_lds_bytes(M) : 0);
+                                           : jv::gs_lds_bytes(D, rerankK, cand_cap, (pair || pairc) ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0) + (ub8 ? jv::gs_ub8_lds_bytes(M) : 0);
         char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
         memset(lds, 0xa5, lds_bytes);
         memset(lds + lds_bytes, 0x3c, 64);  // canary behind the block

@@ -699,6 +699,18 @@ void gs_run_lutr(const GsLaunch &L)
     }
 }
 template <int VSF>
+void gs_run_pairc(const GsLaunch &L)
+{
+    switch (L.p->M / 16) {
+    case 1: gs_worker<VSF, 1, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 2: gs_worker<VSF, 2, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 3: gs_worker<VSF, 3, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 4: gs_worker<VSF, 4, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: gs_worker<VSF, 6, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
+template <int VSF>
 void gs_run_ub8(const GsLaunch &L)
 {
     switch (L.p->M / 16) {
@@ -775,6 +787,10 @@ void gs_main(void *a)
         if (L.vsf == VSF_L2) gs_run_lutr<VSF_L2>(L);
         else if (L.vsf == VSF_DOT) gs_run_lutr<VSF_DOT>(L);
         else gs_run_lutr<VSF_COS>(L);
+    } else if (L.p->pair == 2) {
+        if (L.vsf == VSF_L2) gs_run_pairc<VSF_L2>(L);
+        else if (L.vsf == VSF_DOT) gs_run_pairc<VSF_DOT>(L);
+        else gs_run_pairc<VSF_COS>(L);
     } else if (L.p->pair) gs_run_vsf<true>(L);
     else gs_run_vsf<false>(L);
 }

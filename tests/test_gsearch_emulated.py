@@ -299,6 +299,28 @@ def test_degree_above_32_uses_one_lane_per_neighbour(emu):
         check(ids, sc, st, status, wi, ws, wst)
 
 
+@pytest.mark.parametrize("M,deg", [(16, 40), (32, 64), (48, 48), (64, 33), (96, 64)])
+def test_compacted_pair_form_matches_oracle(emu, M, deg):
+    """rows of 33 ... 64 neighbours with the codes read by ordinal (the builder's working rows): one lane per neighbour probes the
+    visited set, the fresh ones are scored two lanes each after a compaction through LDS — up to two passes per expansion.  Same
+    ids / scores / counters as the oracle, and as the one-lane-per-neighbour kernel."""
+    D = 8 * M
+    lv, entry, entry_level, opq, codes, q = problem(300 + M + deg, 2500, D, M, 2, deg=deg, nq=8)
+    assert lv[0][1].shape[1] == deg
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    two_pass = False
+    for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
+        for rk in (60, 1):
+            wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=False)
+            ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, False, pair=2, cand_cap=256)
+            check(ids, sc, st, status, wi, ws, wst)
+            two_pass = two_pass or (deg > 32)
+    # a fused graph has no compacted form: the launch is refused, not silently run in another form
+    if M == 16:
+        with pytest.raises(Exception):
+            run_emu(emu, lv, entry, entry_level, opq, codes, q, O.COSINE, 10, True, pair=2)
+
+
 def test_partition_and_spill_paths(emu):
     """rerankK large enough that far more than cand_cap=256 candidates are alive: the LDS tier must spill (several
     partitions per query) and results must not change."""

@@ -298,6 +298,29 @@ def test_register_resident_table_kernel(ctx, levels, use_fused, D, M, deg):
         ctx.set_option("gs_lutr", None)
 
 
+@pytest.mark.parametrize("levels,D,M,deg", [(1, 768, 96, 64), (2, 768, 96, 40), (2, 128, 16, 64), (2, 384, 48, 48), (1, 512, 64, 33)])
+def test_compacted_pair_kernel(ctx, levels, D, M, deg):
+    """rows of 33 ... 64 neighbours, codes by ordinal (the builder's working rows): graph_search_pairc_kernel — one lane per neighbour
+    probes the visited set, the fresh ones are scored two lanes each.  Same ids / scores / counters as the oracle and as the
+    one-lane-per-neighbour kernel (gs_pairc = 0)."""
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 13 * levels + M + deg, 6000, D, M, levels, False, deg=deg)
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=64)
+    try:
+        ctx.set_option("gs_wgx", 0)
+        for vsf in VSF:
+            for top_k, rk in ((10, 100), (1, 1)):
+                wi, ws, wst = og.search(opq, codes, v, q, int(vsf), top_k, rk, fused=False)
+                for pairc in (1, 0):
+                    ctx.set_option("gs_pairc", pairc)
+                    ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True)
+                    assert ctx.stat("gs_last_pair") == (2 if pairc else 0)
+                    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rk, pairc)
+    finally:
+        for k in ("gs_wgx", "gs_pairc"):
+            ctx.set_option(k, None)
+
+
 @pytest.mark.parametrize("levels,use_fused,D,M,deg", [(2, True, 768, 96, 32), (3, True, 768, 96, 24), (1, False, 768, 96, 40),
                                                       (2, True, 128, 16, 16), (2, False, 256, 32, 64), (2, True, 384, 48, 32),
                                                       (2, True, 512, 64, 32), (2, True, 1024, 128, 32)])
