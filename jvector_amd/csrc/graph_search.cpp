@@ -1347,9 +1347,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     }
     if (wgx) pair = false;
     // Rows of 33 ... 64 neighbours with the codes read by ordinal (the builder's working rows: maxDegree x neighborOverflow): the
-    // compacted pair form — a lane per neighbour for the visited probe, two lanes per FRESH neighbour for the score (gs_body.h
-    // "PAIRC").  gs_pairc = 0 turns it off.
-    bool pairc = occ == 2 && !so && !wgx && !pair && !lutr && !generic && !fused && pq->M <= 96 && ctx_opt(ctx, "gs_pair", 1) != 0 &&
+    // compacted pair form — a lane per neighbour for the visited probe, two lanes per FRESH neighbour for the score (four above
+    // M = 96; gs_body.h "PAIRC").  gs_pairc = 0 turns it off.
+    bool pairc = occ == 2 && !so && !wgx && !pair && !lutr && !generic && !fused && pq->M <= 192 && ctx_opt(ctx, "gs_pair", 1) != 0 &&
                  ctx_opt(ctx, "gs_pairc", 1) != 0;
     for (int lv = 0; lv <= g->entry_level; ++lv) pairc = pairc && g->levels[lv].degree <= 64;
     // gs_ub8 = 1: the pair-lane kernel with an 8-bit upper-bound table of the query's ADC entries per wave (gs_body.h "UB8": fresh
@@ -1583,6 +1583,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p.big_spill_cap = big_spill_cap;
     }
     p.pair = pair ? 1 : (pairc ? 2 : 0);
+    // gs_quad = 1: the pair-lane kernels score the fresh neighbours of an expansion with at most 16 of them FOUR lanes each (half the
+    // gather instructions, the same number of lane addresses).  Measured on the headline (10M x 768, rerankK 74, profiles/r4_s): 86.0 ms
+    // per 131 072 queries against 80.9 ms — the vector-memory path charges lane addresses, not instructions, and the redistribution
+    // (14 ds_bpermute, two barriers) comes on top.  Off by default; results are identical either way.
+    p.quad = ctx_opt(ctx, "gs_quad", 0) != 0 ? 1 : 0;
     p.out_ids = d_cand;
     p.out_scores = d_cand_sc;
     p.out_stats = d_stats;

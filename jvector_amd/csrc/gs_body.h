@@ -10,6 +10,7 @@
 //     gs_shfl(long long v, int src)           read lane src's v
 //     gs_shfl32(int32_t v, int src)           the same for 32 bits (one ds_bpermute_b32)
 //     gs_shfl_xor(long long v, int laneMask)  butterfly exchange
+//     GS_OPAQUE_I32(x)                        optimisation barrier on an int (no-op on the emulator)
 //     gs_cas(int32_t *p, int32_t expect, int32_t desired) -> old      (device-scope atomic)
 //     gs_fetch_add(uint32_t *p, uint32_t v) -> old                    (device-scope atomic)
 //     gs_fetch_add64(unsigned long long *p, unsigned long long v)     (device-scope atomic; profiling aid only)
@@ -422,8 +423,8 @@ GS_FN void gs_load_half(const uint8_t *rp, gs_u2 (&w)[HW])
 }
 
 // Entries of this lane's half of the subspaces.  Low lane (xw == nullptr): returns their running sum (ascending m).
-// High lane: writes entry j to xw[j * 32] (LDS exchange area, column = neighbour) for its partner and returns 0.
-template <int VSF, int HW>
+// High lane: writes entry j to xw[j * XS] (LDS exchange area, column = neighbour) for its partner and returns 0.
+template <int VSF, int HW, int XS = 32>
 GS_FN float gs_half_entries(const float *codebooks, const float *qs, const gs_u2 (&w)[HW], int m_base, float *xw)
 {
     float sum = 0.0f;
@@ -461,7 +462,7 @@ GS_FN float gs_half_entries(const float *codebooks, const float *qs, const gs_u2
                     v += c1.z * q[6];
                     v += c1.w * q[7];
                 }
-                if (xw) xw[j * 32] = v;
+                if (xw) xw[j * XS] = v;
                 else sum += v;
             }
         }
@@ -807,7 +808,8 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 //       addTopCandidate log (graph_search.cpp searcher_search_device).
 // PAIRC: pair-lane scoring of the FRESH neighbours of rows up to 64 wide whose codes are read by ordinal (the builder's working
 //       rows, maxDegree x neighborOverflow): one lane per neighbour probes the visited set, the unvisited ids are compacted
-//       through LDS and scored two lanes each like PAIR (<= 32 per pass, a second pass for the rest).  LDS layout = PAIR's.
+//       through LDS and scored two lanes each like PAIR (<= 32 per pass, a second pass for the rest; M > 96: four lanes each,
+//       16 per pass).  LDS layout = PAIR's.
 template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false, bool PAIRC = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
@@ -862,7 +864,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     const bool has_v1 = p.v1_log2 > 0;
     auto gs_v1_of = [&]() -> GsVis1 {
         GsVis1 t;
-        const size_t base = ((size_t)((char *)(xchg + 32 * (XA ? p.M / 2 : 0)) - lds) + (XA ? 0 : sizeof(long long) * 64) + 15) & ~(size_t)15;
+        const size_t base = ((size_t)((char *)(xchg + (XA ? gs_xchg_floats(p.M) : 0)) - lds) + (XA ? 0 : sizeof(long long) * 64) + 15) & ~(size_t)15;
         t.w = reinterpret_cast<uint32_t *>(lds + base);
         t.bmask = (1u << (p.v1_log2 - 2)) - 1u;
         t.idmask = (p.v1_idbits >= 32) ? 0xFFFFFFFFu : ((1u << p.v1_idbits) - 1u);
@@ -1264,6 +1266,51 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                         if (drop) fresh = false;
                     }
                 }
+                // ---- GsParams::quad (off by default): at most 16 fresh neighbours -> FOUR lanes each, spread over all 64 lanes: lane
+                //      16 t + g takes subspaces [t M/4, (t + 1) M/4) of the g-th fresh neighbour (row order), its code words come
+                //      from the pair lanes that loaded them (ds_bpermute), lanes 0 ... 15 add all M entries in ascending m.  Half
+                //      the gather INSTRUCTIONS for 61 % of the headline's expansions, the same number of lane addresses — measured
+                //      6 % slower (graph_search.cpp gs_quad): what one lane per neighbour loses against pair lanes (33.7 vs 19.0
+                //      ms) is the length of the dependent per-lane chain, not a per-instruction charge of the memory path.
+                constexpr bool QUAD_OK = !UB8 && CH16 % 2 == 0;   // (a lane's M/4 code bytes are whole 8-byte words)
+                bool quad = false;
+                if constexpr (QUAD_OK) quad = p.quad != 0 && gs_popc(fm) <= 16;
+                if (quad) {
+                    if constexpr (QUAD_OK) {
+                        constexpr int QW = CH16 / 2;   // 8-byte code words per lane
+                        constexpr int QS = QW * 8;     // subspaces per lane
+                        const int g = lane & 15;
+                        int t = lane >> 4;
+                        GS_OPAQUE_I32(t);   // (or 24 loop-invariant subspace pointers are hoisted out of the search loop and spilled)
+                        const int nfq = gs_popc(fm);
+                        int32_t *cmp = reinterpret_cast<int32_t *>(xchg);   // (read back before the exchange area is written)
+                        if (fresh) cmp[gs_popc(fm & ((1ull << lane) - 1ull))] = lane;
+                        gs_barrier();
+                        const int src = g < nfq ? cmp[g] : 0;               // the low lane that holds the g-th fresh neighbour
+                        gs_barrier();
+                        const int from = src + 32 * (t >> 1);               // ... and the lane that holds this quarter's code bytes
+                        gs_u2 qw[QW];
+#pragma unroll
+                        for (int k = 0; k < QW; ++k) {
+                            const uint32_t ax = (uint32_t)gs_shfl32((int32_t)w[k].x, from), ay = (uint32_t)gs_shfl32((int32_t)w[k].y, from);
+                            const uint32_t bx = (uint32_t)gs_shfl32((int32_t)w[k + QW].x, from), by = (uint32_t)gs_shfl32((int32_t)w[k + QW].y, from);
+                            qw[k].x = (t & 1) ? bx : ax;
+                            qw[k].y = (t & 1) ? by : ay;
+                        }
+                        const int32_t qnb = gs_shfl32(nb, src);
+                        const float qmag = gs_bits_float(gs_shfl32(gs_float_bits(node_mag), src));
+                        const bool qwork = g < nfq;
+                        float sum = 0.0f;
+                        if (qwork) sum = gs_half_entries<VSF, QW, 16>(p.codebooks, qs, qw, t * QS, t ? xchg + (t - 1) * QS * 16 + g : nullptr);
+                        gs_barrier();
+                        fresh = qwork && t == 0;
+                        if (fresh) {
+#pragma unroll
+                            for (int j = 0; j < 3 * QS; ++j) sum += xchg[j * 16 + g];
+                            key = gs_key(qnb, gs_finish<VSF>(sum, qmag, query_mag));
+                        }
+                    }
+                } else {
                 const bool work = ((fm_score >> ni) & 1ull) != 0;  // this lane's pair has a fresh neighbour that needs its score
                 float sum = 0.0f;
                 if (work) sum = gs_half_entries<VSF, CH16>(p.codebooks, qs, w, m_base, hi ? xchg + ni : nullptr);
@@ -1273,10 +1320,17 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     for (int j = 0; j < CH16 * 8; ++j) sum += xchg[j * 32 + ni];
                     key = gs_key(nb, gs_finish<VSF>(sum, node_mag, query_mag));
                 }
+                }
             } else if constexpr (PAIRC) {
                 // ---- rows of up to 64 neighbours, codes by ordinal: one lane per neighbour for the visited probe, then the fresh
-                //      ones — compacted in row order — two lanes each (low: subspaces [0, M/2), high: [M/2, M), the low lane adds
-                //      all M entries in ascending m).  The order of the pushes inside an expansion is immaterial (see below).
+                //      ones — compacted in row order — LPN lanes each (lane t of a group: subspaces [t M/LPN, (t+1) M/LPN); lane 0
+                //      adds all M entries in ascending m, the others hand theirs over through LDS).  LPN = 2 up to M = 96 (32
+                //      neighbours per pass), 4 above (a lane's share of the row must fit its registers: 16 per pass).  The order of
+                //      the pushes inside an expansion is immaterial (see below).
+                constexpr int LPN = CH16 > 6 ? 4 : 2;
+                constexpr int PER = 64 / LPN;            // neighbours per pass
+                constexpr int HW = CH16 * 2 / LPN;       // 8-byte code words per lane
+                constexpr int SUBS = HW * 8;             // subspaces per lane
                 const int32_t nb0 = lane < deg ? row[lane] : -1;
                 const int first_neg = gs_first(gs_ballot(nb0 < 0));  // rows are packed: the first -1 ends the row
                 const bool fr0 = visit(lane < first_neg, nb0);
@@ -1289,34 +1343,37 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 int32_t *cmp = reinterpret_cast<int32_t *>(xchg);   // (consumed into registers before the exchange area is written)
                 if (fr0) cmp[gs_popc(fm & ((1ull << lane) - 1ull))] = nb0;
                 gs_barrier();
-                const int ni = lane & 31;
-                const bool hi = lane >= 32;
-                const int m_base = hi ? p.M / 2 : 0;
-                const int32_t cn0 = ni < nf ? cmp[ni] : -1;
-                const int32_t cn1 = 32 + ni < nf ? cmp[32 + ni] : -1;
+                const int ni = lane & (PER - 1);
+                const int sub = lane / PER;              // 0: the lane that owns the neighbour's sum
+                const int m_base = sub * SUBS;
+                int32_t cn_[LPN];
+#pragma unroll
+                for (int t = 0; t < LPN; ++t) cn_[t] = t * PER + ni < nf ? cmp[t * PER + ni] : -1;
                 gs_barrier();
                 bool give_up = false;
 #pragma unroll 1
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int32_t cn = pass ? cn1 : cn0;
+                for (int pass = 0; pass < LPN; ++pass) {
+                    int32_t cn = cn_[0];
+#pragma unroll
+                    for (int t = 1; t < LPN; ++t) cn = pass == t ? cn_[t] : cn;
                     const bool work = cn >= 0;
-                    gs_u2 w[CH16];
+                    gs_u2 w[HW];
                     float node_mag = 0.0f, sum = 0.0f;
                     if (work) {   // PQDecoder.similarityTo: the neighbour's own code
-                        gs_load_half<CH16>(p.codes + (int64_t)cn * p.M + m_base, w);
-                        if (VSF == 2 && !hi) node_mag = p.code_norms[cn];
-                        sum = gs_half_entries<VSF, CH16>(p.codebooks, qs, w, m_base, hi ? xchg + ni : nullptr);
+                        gs_load_half<HW>(p.codes + (int64_t)cn * p.M + m_base, w);
+                        if (VSF == 2 && sub == 0) node_mag = p.code_norms[cn];
+                        sum = gs_half_entries<VSF, HW, PER>(p.codebooks, qs, w, m_base, sub ? xchg + (sub - 1) * SUBS * PER + ni : nullptr);
                     }
                     gs_barrier();
-                    fresh = work && !hi;
+                    fresh = work && sub == 0;
                     key = 0;
                     if (fresh) {
 #pragma unroll
-                        for (int j = 0; j < CH16 * 8; ++j) sum += xchg[j * 32 + ni];
+                        for (int j = 0; j < (LPN - 1) * SUBS; ++j) sum += xchg[j * PER + ni];
                         key = gs_key(cn, gs_finish<VSF>(sum, node_mag, query_mag));
                     }
-                    if (pass == 1 || nf <= 32) break;   // the shared tail below pushes this pass
-                    gs_barrier();   // every low lane has read its column before the push's sample buffer reuses the bytes
+                    if ((pass + 1) * PER >= nf) break;   // the shared tail below pushes the last pass
+                    gs_barrier();   // every owner lane has read its column before the push's sample buffer reuses the bytes
                     if constexpr (SES) {
                         if (thr_on) trk_track(fresh, gs_key_score(key));
                     }

@@ -58,7 +58,8 @@ struct GsParams {
     int32_t big_count, big_log2, big_spill_cap;
     int32_t cand_cap;         // LDS tier capacity (>= 256)
     int32_t evict_cap;        // capacity of the upper-layer evicted list in LDS (0 = GS_EVICT_CAP)
-    int32_t pair;             // 1: pair-lane scoring (every degree <= 32; LDS has the M/2 x 32 exchange area)
+    int32_t pair;             // 1: pair-lane scoring (every degree <= 32; LDS has the M/2 x 32 exchange area); 2: over the compacted fresh list
+    int32_t quad;             // pair == 1: expansions with at most 16 fresh neighbours score them FOUR lanes each (half the gather instructions)
     // visited set, tier 1: an open-addressing table of 16-bit entries in LDS (gs_body.h "two-tier visited set"); the global
     // table above is tier 2 and is only touched (and only then cleared) by a query whose tier 1 fills up.
     // GraphSearcher objects (session kernels, gs_body.h SES)
@@ -110,13 +111,17 @@ struct GsParams {
 // the centred query at the head of a worker's LDS block, padded so that the 8-byte arrays behind it stay aligned for any D
 constexpr size_t gs_q_bytes(int D) { return (sizeof(float) * (size_t)D + 15) & ~(size_t)15; }
 
+// floats of the pair-lane exchange area: [M/2][32] entries (two lanes per neighbour, 32 neighbours per pass); above M = 96 only the
+// compacted form exists and runs four lanes per neighbour, 16 per pass: [3 M/4][16]
+constexpr size_t gs_xchg_floats(int pair_M) { return pair_M <= 96 ? (size_t)32 * (size_t)(pair_M / 2) : (size_t)16 * (size_t)(3 * pair_M / 4); }
+
 // LDS bytes one worker needs
 constexpr size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M when pair-lane scoring is on, else 0 */,
                            int evict_cap = GS_EVICT_CAP, int v1_log2 = 0)
 {
     // (the 64-key sample buffer of the partition step shares the pair-lane exchange area when there is one)
     const size_t base = gs_q_bytes(D) + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + (size_t)evict_cap + (pair_M ? 0 : 64)) +
-                        sizeof(float) * 32 * (size_t)(pair_M / 2);
+                        sizeof(float) * gs_xchg_floats(pair_M);
     return v1_log2 > 0 ? ((base + 15) & ~(size_t)15) + ((size_t)2 << v1_log2) : base;
 }
 

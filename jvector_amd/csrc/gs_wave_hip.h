@@ -114,6 +114,9 @@ __device__ __forceinline__ int32_t gs_uniform(int32_t v) { return __builtin_amdg
 __device__ __forceinline__ long long gs_shfl(long long v, int src) { return __shfl(v, src, 64); }
 #endif
 __device__ __forceinline__ long long gs_shfl_xor(long long v, int m) { return __shfl_xor(v, m, 64); }
+// the value is what it was, but the compiler may not reason about where it came from (keeps per-lane address arithmetic inside the
+// loop that uses it instead of hoisting dozens of 64-bit pointers out of the search loop and spilling them)
+#define GS_OPAQUE_I32(x) asm volatile("" : "+v"(x))
 __device__ __forceinline__ int32_t gs_shfl32(int32_t v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
 __device__ __forceinline__ int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired) { return atomicCAS(p, expect, desired); }
 // LDS atomic (ds_cmpst_rtn_b32): p points into the workgroup's LDS block

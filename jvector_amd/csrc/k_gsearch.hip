@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) 
 }
 
 // PAIRC (gs_body.h "PAIRC", GsParams::pair == 2): rows of 33 ... 64 neighbours whose codes are read by ordinal — the builder's
-// working rows.  One lane per neighbour probes the visited set, the fresh ones are scored two lanes each.
+// working rows.  One lane per neighbour probes the visited set, the fresh ones are scored two lanes each (M > 96: four lanes each).
 template <int VSF, int CH16>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_pairc_kernel(GsParams p)
 {
@@ -122,8 +122,10 @@ static int launch_gs_ch(hipStream_t s, const GsParams &p, int ch, int workers, s
             case 3: hipLaunchKernelGGL((graph_search_pairc_kernel<VSF, 3>), grid, block, lds, s, p); break;
             case 4: hipLaunchKernelGGL((graph_search_pairc_kernel<VSF, 4>), grid, block, lds, s, p); break;
             case 6: hipLaunchKernelGGL((graph_search_pairc_kernel<VSF, 6>), grid, block, lds, s, p); break;
+            case 8: hipLaunchKernelGGL((graph_search_pairc_kernel<VSF, 8>), grid, block, lds, s, p); break;     // (four lanes per neighbour)
+            case 12: hipLaunchKernelGGL((graph_search_pairc_kernel<VSF, 12>), grid, block, lds, s, p); break;
             default:
-                set_error("graph search kernel: the compacted pair form is built for M = 16 ... 96 (M = %d)", ch * 16);
+                set_error("graph search kernel: the compacted pair form is built for M = 16 ... 192 (M = %d)", ch * 16);
                 return JV_ERR_UNSUPPORTED;
             }
             JV_HIP_CHECK(hipGetLastError());

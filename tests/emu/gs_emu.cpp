@@ -27,6 +27,7 @@ static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
 static inline int32_t gs_shfl32(int32_t v, int src) { return (int32_t)emu::shfl((long long)v, src); }
+#define GS_OPAQUE_I32(x) ((void)0)
 static inline int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired)
 {
     const int32_t old = *p;
@@ -120,6 +121,8 @@ void run_pairc(const Launch &L)
     case 3: jv::gs_worker<VSF, 3, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
     case 4: jv::gs_worker<VSF, 4, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
     case 6: jv::gs_worker<VSF, 6, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 8: jv::gs_worker<VSF, 8, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 12: jv::gs_worker<VSF, 12, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }
@@ -201,12 +204,14 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     memset(visited, 0x5a, sizeof(int32_t) * vcap * workers);  // garbage: the kernel must clear it itself
     bool pair = pair_mode != 0 && !lutr && !wgx_waves;  // same rule as graph_search.cpp
     for (int l = 0; l < n_levels; ++l) pair = pair && lv_degree[l] <= 32;
+    pair = pair && M <= 96;   // (graph_search.cpp: above, the two half rows no longer fit the registers; the exchange area is sized for the compacted form)
     p.lutr = lutr ? 1 : 0;
-    // pair_mode 2: the compacted pair form (rows of up to 64 neighbours, codes by ordinal, M <= 96) where the plain pair form does not apply
-    bool pairc = pair_mode == 2 && !pair && !lutr && !wgx_waves && !blocks && M <= 96;
+    // pair_mode 2: the compacted pair form (rows of up to 64 neighbours, codes by ordinal) where the plain pair form does not apply
+    bool pairc = pair_mode == 2 && !pair && !lutr && !wgx_waves && !blocks && M <= 192;
     for (int l = 0; l < n_levels; ++l) pairc = pairc && lv_degree[l] <= 64;
     if (pair_mode == 2 && !pair && !pairc) return -8;
     p.pair = pair ? 1 : (pairc ? 2 : 0);
+    p.quad = getenv("GS_EMU_QUAD") ? atoi(getenv("GS_EMU_QUAD")) : 1;   // (on in the emulator unless a test turns it off: more code under test)
     if (ub8 && (!pair || vsf == 0 || M > 96 || wgx_waves || lutr)) return -7;
     p.ub8 = ub8 ? 1 : 0;
     p.v1_log2 = v1_log2; p.v1_idbits = v1_idbits; p.evict_cap = evict_cap;

@@ -34,6 +34,7 @@ static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
 static inline int32_t gs_shfl32(int32_t v, int src) { return (int32_t)emu::shfl((long long)v, src); }
+#define GS_OPAQUE_I32(x) ((void)0)
 static inline int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired)
 {
     const int32_t old = *p;
@@ -707,6 +708,8 @@ void gs_run_pairc(const GsLaunch &L)
     case 3: gs_worker<VSF, 3, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
     case 4: gs_worker<VSF, 4, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
     case 6: gs_worker<VSF, 6, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 8: gs_worker<VSF, 8, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 12: gs_worker<VSF, 12, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }

@@ -127,8 +127,14 @@ def test_emulated_kernel_matches_oracle(emu, levels, fused, M):
     for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
         for rk in (40, 1):
             wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
-            for pair in (1, 0):  # two lanes per neighbour (degrees <= 32) and one lane per neighbour
-                ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, pair=pair)
+            # two lanes per neighbour (degrees <= 32; expansions with <= 16 fresh neighbours: four lanes each — every expansion of
+            # these degree-16 graphs), one lane per neighbour, and the pair form with the four-lane path switched off
+            for pair, quad in ((1, 1), (0, 1), (1, 0)):
+                os.environ["GS_EMU_QUAD"] = str(quad)
+                try:
+                    ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, pair=pair)
+                finally:
+                    os.environ.pop("GS_EMU_QUAD", None)
                 check(ids, sc, st, status, wi, ws, wst)
 
 
@@ -299,7 +305,7 @@ def test_degree_above_32_uses_one_lane_per_neighbour(emu):
         check(ids, sc, st, status, wi, ws, wst)
 
 
-@pytest.mark.parametrize("M,deg", [(16, 40), (32, 64), (48, 48), (64, 33), (96, 64)])
+@pytest.mark.parametrize("M,deg", [(16, 40), (32, 64), (48, 48), (64, 33), (96, 64), (128, 64), (192, 40)])
 def test_compacted_pair_form_matches_oracle(emu, M, deg):
     """rows of 33 ... 64 neighbours with the codes read by ordinal (the builder's working rows): one lane per neighbour probes the
     visited set, the fresh ones are scored two lanes each after a compaction through LDS — up to two passes per expansion.  Same

@@ -47,15 +47,18 @@ def test_device_traversal_matches_oracle(ctx, levels, use_fused, D, M):
                 s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs if rerank else None, max_queries=64)
                 wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused)
                 # the one-wave kernels, the workgroup form, and what AUTO picks for a batch this small (the workgroup form)
-                for form in (0, 1, None):
-                    ctx.set_option("gs_wgx", form)
+                # (and the one-wave kernels' four-lanes-per-neighbour path, gs_quad: every expansion of these degree-16 graphs)
+                for form in (0, 1, None, "quad"):
+                    ctx.set_option("gs_wgx", 0 if form == "quad" else form)
+                    ctx.set_option("gs_quad", 1 if form == "quad" else None)
                     ids, sc, stats = s.search(q, vsf, top_k, rk, return_stats=True)
-                    assert ctx.stat("gs_last_wgx") == (0 if form == 0 else 1)
+                    assert ctx.stat("gs_last_wgx") == (0 if form in (0, "quad") else 1)
                     assert np.array_equal(stats, wst), (vsf, rerank, form)
                     assert np.array_equal(ids, wi), (vsf, rerank, top_k, form)
                     assert np.array_equal(sc, ws), (vsf, rerank, top_k, form)
     finally:
         ctx.set_option("gs_wgx", None)
+        ctx.set_option("gs_quad", None)
 
 
 def test_device_equals_host_on_a_large_batch_with_spills_and_overflow(ctx, monkeypatch):
@@ -298,7 +301,8 @@ def test_register_resident_table_kernel(ctx, levels, use_fused, D, M, deg):
         ctx.set_option("gs_lutr", None)
 
 
-@pytest.mark.parametrize("levels,D,M,deg", [(1, 768, 96, 64), (2, 768, 96, 40), (2, 128, 16, 64), (2, 384, 48, 48), (1, 512, 64, 33)])
+@pytest.mark.parametrize("levels,D,M,deg", [(1, 768, 96, 64), (2, 768, 96, 40), (2, 128, 16, 64), (2, 384, 48, 48), (1, 512, 64, 33),
+                                            (1, 1024, 128, 64), (2, 1536, 192, 64), (1, 1536, 192, 17)])
 def test_compacted_pair_kernel(ctx, levels, D, M, deg):
     """rows of 33 ... 64 neighbours, codes by ordinal (the builder's working rows): graph_search_pairc_kernel — one lane per neighbour
     probes the visited set, the fresh ones are scored two lanes each.  Same ids / scores / counters as the oracle and as the
