@@ -82,6 +82,20 @@ int jv_hip_code_pair_scores(jv_ctx *ctx, const jv_pair_table *t, const jv_codes 
     return stage_out_end(ctx, os);
 }
 
+}  // extern "C"
+namespace jv {
+// rd_table_free = 1: the robust prune recomputes the pair-table entries from the codebook (rd_body.h rd_node<true>; every sub-vector
+// 8 dimensions — the shape its 16-byte centroid loads assume) instead of looking them up in the 12.6 / 25 MB table that misses L2
+// four times out of five.  Same selections bit for bit — and SLOWER on the MI355X (profiles/r4_t: headline build prune + backlink
+// 25.7 -> 35.3 s, C5 37.8 -> 64.3 s): two 16-byte gathers per (candidate, selected, subspace) cost more than one 4-byte look-up
+// that goes to the Infinity Cache.  Off by default.
+bool retain_diverse_table_free(const jv_ctx *ctx, const jv_pq *pq)
+{
+    return pq->uniform && pq->max_size == 8 && pq->D == 8 * pq->M && pq->k == kClusters && ctx_opt(ctx, "rd_table_free", 0) != 0;
+}
+}  // namespace jv
+extern "C" {
+
 int jv_hip_retain_diverse(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *codes, int P, int C, const int32_t *cand_nodes,
                           const float *cand_scores, const int32_t *cand_count, const int32_t *diverse_before, int maxDegree, float alpha,
                           int32_t *selected_out, int32_t *n_selected_out, float *short_edges_out)
@@ -109,6 +123,7 @@ int jv_hip_retain_diverse(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *c
     char *base = (char *)ctx->d_out.ptr;
     RdParams p{};
     p.tri = t->d_tri;
+    p.codebooks = retain_diverse_table_free(ctx, t->pq) ? t->pq->d_codebooks : nullptr;
     p.codes = codes->d_codes;
     p.n = codes->count;
     p.cand_nodes = (const int32_t *)d_nodes;

@@ -15,7 +15,15 @@ namespace jv {
 __global__ __launch_bounds__(64) void retain_diverse_kernel(RdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char rd_lds[];
-    for (int node = (int)blockIdx.x; node < p.P; node += (int)gridDim.x) rd_node(p, node, rd_lds);
+    for (int node = (int)blockIdx.x; node < p.P; node += (int)gridDim.x) rd_node<false>(p, node, rd_lds);
+}
+
+// table-free (RdParams::codebooks; uniform 8-dimensional sub-vectors): the entries recomputed from the L2-resident codebook
+// (measured slower than the look-ups, build_score.cpp retain_diverse_table_free: an option, off by default)
+__global__ __launch_bounds__(64) void retain_diverse_tf_kernel(RdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char rd_lds[];
+    for (int node = (int)blockIdx.x; node < p.P; node += (int)gridDim.x) rd_node<true>(p, node, rd_lds);
 }
 
 size_t retain_diverse_lds_bytes(int C, int M) { return rd_lds_bytes(C, M); }
@@ -23,17 +31,19 @@ size_t retain_diverse_lds_bytes(int C, int M) { return rd_lds_bytes(C, M); }
 int launch_retain_diverse(hipStream_t s, const jv_ctx *ctx, const RdParams &p)
 {
     if (p.P == 0) return JV_OK;
-    const size_t lds = rd_lds_bytes(p.C, p.M);
+    const bool tf = p.codebooks != nullptr;
+    const size_t lds = rd_lds_bytes(p.C, p.M, tf);
     if (lds > ctx->lds_per_block) {
         set_error("retain_diverse: %d candidates x %d code bytes need %zu bytes of LDS (limit %zu); prune in smaller candidate lists", p.C,
                   p.M, lds, ctx->lds_per_block);
         return JV_ERR_UNSUPPORTED;
     }
-    if (lds > 48 * 1024)
-        JV_HIP_CHECK(hipFuncSetAttribute((const void *)retain_diverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void *kfn = tf ? (const void *)retain_diverse_tf_kernel : (const void *)retain_diverse_kernel;
+    if (lds > 48 * 1024) JV_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 256)));
     const int blocks = std::min(p.P, ctx->num_cus * per_cu);
-    hipLaunchKernelGGL(retain_diverse_kernel, dim3(blocks), dim3(64), lds, s, p);
+    if (tf) hipLaunchKernelGGL(retain_diverse_tf_kernel, dim3(blocks), dim3(64), lds, s, p);
+    else hipLaunchKernelGGL(retain_diverse_kernel, dim3(blocks), dim3(64), lds, s, p);
     JV_HIP_CHECK(hipGetLastError());
     return JV_OK;
 }

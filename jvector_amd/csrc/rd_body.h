@@ -50,6 +50,68 @@ GS_FN float rd_pair_sum(const float *tri, int M, int k, const uint8_t *crow, con
     return res;
 }
 
+// The same sum TABLE-FREE (uniform 8-dimensional sub-vectors): entry (m, c1, c2) is recomputed with the arithmetic that filled the
+// table (bs_body.h bs_pair_table_row: one f32 chain over the 8 dimensions, a[d] * b[d] or (a[d] - b[d])^2 — both symmetric in the two
+// centroids, so which of them has the smaller index does not matter) from this lane's selected neighbour's centroid (two 16-byte
+// gathers into the L2-resident codebook, 768 KB at PQ-96 / 1.5 MB at PQ-192) and the candidate's, decoded once per test into LDS
+// (cvec, broadcast reads).  The pair table (12.6 / 25 MB) misses L2 four times out of five; the codebook does not —
+// and the form is still 1.4 - 1.7x SLOWER on the MI355X (profiles/r4_t): selectable (rd_table_free = 1), off by default.
+struct alignas(16) rd_f4 { float x, y, z, w; };
+
+template <bool L2>
+GS_FN float rd_entry_tf(const rd_f4 &a0, const rd_f4 &a1, const rd_f4 &c0, const rd_f4 &c1)
+{
+    float v = 0.0f;
+    if (L2) {
+        float t;
+        t = a0.x - c0.x; v += t * t;
+        t = a0.y - c0.y; v += t * t;
+        t = a0.z - c0.z; v += t * t;
+        t = a0.w - c0.w; v += t * t;
+        t = a1.x - c1.x; v += t * t;
+        t = a1.y - c1.y; v += t * t;
+        t = a1.z - c1.z; v += t * t;
+        t = a1.w - c1.w; v += t * t;
+    } else {
+        v += a0.x * c0.x;
+        v += a0.y * c0.y;
+        v += a0.z * c0.z;
+        v += a0.w * c0.w;
+        v += a1.x * c1.x;
+        v += a1.y * c1.y;
+        v += a1.z * c1.z;
+        v += a1.w * c1.w;
+    }
+    return v;
+}
+
+template <bool L2>
+GS_FN float rd_pair_sum_tf(const float *cb, int M, int k, const float *cvec, const uint8_t *scol /* stride 64 */)
+{
+    float res = 0.0f;
+    int m = 0;
+    for (; m + 8 <= M; m += 8) {   // 16 gathers in flight, then the 8 entries in ascending m
+        rd_f4 a0[8], a1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const rd_f4 *r = reinterpret_cast<const rd_f4 *>(cb + ((int64_t)(m + j) * k + scol[(size_t)(m + j) * 64]) * 8);
+            a0[j] = r[0];
+            a1[j] = r[1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const rd_f4 *c = reinterpret_cast<const rd_f4 *>(cvec + (size_t)(m + j) * 8);
+            res += rd_entry_tf<L2>(a0[j], a1[j], c[0], c[1]);
+        }
+    }
+    for (; m < M; ++m) {
+        const rd_f4 *r = reinterpret_cast<const rd_f4 *>(cb + ((int64_t)m * k + scol[(size_t)m * 64]) * 8);
+        const rd_f4 *c = reinterpret_cast<const rd_f4 *>(cvec + (size_t)m * 8);
+        res += rd_entry_tf<L2>(r[0], r[1], c[0], c[1]);
+    }
+    return res;
+}
+
 GS_FN float rd_self_sum(const float *tri, int M, int k, const uint8_t *crow)
 {
     const int64_t block = (int64_t)k * (k + 1) / 2;
@@ -70,7 +132,9 @@ GS_FN int rd_wave_min(int v)
     return v;
 }
 
-// lds: rd_lds_bytes(C, M) bytes, 16-byte aligned
+// lds: rd_lds_bytes(C, M, TF) bytes, 16-byte aligned.  TF: the table-free form (p.codebooks; the cosine self magnitudes still come
+// from the table's diagonal: M x k entries, L2-resident)
+template <bool TF = false>
 GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
 {
     const int lane = gs_lane();
@@ -81,6 +145,8 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
     float *snorm = cnorm + C;                                      // [64]
     int32_t *sidx = reinterpret_cast<int32_t *>(snorm + 64);       // [64] candidate index of slot j
     int32_t *snode = sidx + 64;                                    // [64]
+    float *cvec = reinterpret_cast<float *>(lds + rd_off_cvec(C, M));   // TF: [M][8] the candidate under test, decoded
+    (void)cvec;
     const int32_t *nodes = p.cand_nodes + (int64_t)node_idx * C;
     const float *scores = p.cand_scores + (int64_t)node_idx * C;
     int n = p.cand_count ? p.cand_count[node_idx] : C;
@@ -132,11 +198,24 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
             // ---- isDiverse: every selected slot in parallel, then the first event in ascending candidate index ----
             int ev_idx = 0x7fffffff;  // this lane's event index (none: INT_MAX)
             bool ev_fail = false;
+            if constexpr (TF) {
+                if (nSlots > 0) {   // (the previous test's readers are past their last wave-wide step: rd_wave_min / the ballot)
+                    for (int idx = lane; idx < 2 * M; idx += 64) {
+                        const int m = idx >> 1;
+                        const rd_f4 *r = reinterpret_cast<const rd_f4 *>(p.codebooks + ((int64_t)m * p.k + cc[(size_t)i * M + m]) * 8);
+                        reinterpret_cast<rd_f4 *>(cvec)[idx] = r[idx & 1];
+                    }
+                    gs_barrier();
+                }
+            }
             if (lane < nSlots) {
                 if (snode[lane] == cNode) {
                     ev_idx = sidx[lane];
                 } else {
-                    const float sum = rd_pair_sum(p.tri, M, p.k, cc + (size_t)i * M, st + lane);
+                    float sum;
+                    if constexpr (TF) sum = p.vsf == 0 ? rd_pair_sum_tf<true>(p.codebooks, M, p.k, cvec, st + lane)
+                                                       : rd_pair_sum_tf<false>(p.codebooks, M, p.k, cvec, st + lane);
+                    else sum = rd_pair_sum(p.tri, M, p.k, cc + (size_t)i * M, st + lane);
                     float sim;
                     if (p.vsf == 0) sim = 1.0f / (1.0f + sum);
                     else if (p.vsf == 1) sim = (1.0f + sum) / 2.0f;

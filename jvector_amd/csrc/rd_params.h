@@ -9,6 +9,7 @@ namespace jv {
 
 struct RdParams {
     const float *tri;          // pair table: M x k(k+1)/2 floats
+    const float *codebooks;    // table-free form (rd_node<true>): [M][k][8] centroids (uniform 8-dimensional sub-vectors), else nullptr
     const uint8_t *codes;      // [n][M]
     int64_t n;
     const int32_t *cand_nodes; // [P][C] sorted by score descending; entries >= count are ignored
@@ -23,9 +24,15 @@ struct RdParams {
 };
 
 // LDS bytes one wavefront needs: candidate code rows, transposed selected codes, self magnitudes, slot bookkeeping
-inline size_t rd_lds_bytes(int C, int M)
+// (table_free: + the current candidate's decoded sub-vectors, M x 8 floats, at rd_off_cvec)
+constexpr size_t rd_off_cvec(int C, int M)
 {
-    return (size_t)C * M + (size_t)M * 64 + sizeof(float) * ((size_t)C + 64) + sizeof(int32_t) * 64 * 2 + 16;
+    return ((((size_t)C * M + (size_t)M * 64 + 15) & ~(size_t)15) + sizeof(float) * ((size_t)C + 64) + sizeof(int32_t) * 64 * 2 + 15) & ~(size_t)15;
+}
+inline size_t rd_lds_bytes(int C, int M, bool table_free = false)
+{
+    const size_t base = (size_t)C * M + (size_t)M * 64 + sizeof(float) * ((size_t)C + 64) + sizeof(int32_t) * 64 * 2 + 16;
+    return table_free ? rd_off_cvec(C, M) + sizeof(float) * 8 * (size_t)M : base;
 }
 
 }  // namespace jv

@@ -25,19 +25,42 @@ struct Launch {
 void node_main(void *a)
 {
     const Launch &L = *(const Launch *)a;
-    jv::rd_node(*L.p, L.node, L.lds);
+    if (L.p->codebooks) jv::rd_node<true>(*L.p, L.node, L.lds);
+    else jv::rd_node<false>(*L.p, L.node, L.lds);
 }
 }  // namespace
+
+static int rd_emu_run_any(const float *tri, const float *codebooks, const uint8_t *codes, int64_t n, const int32_t *cand_nodes, const float *cand_scores,
+                          const int32_t *cand_count, const int32_t *diverse_before, int P, int C, int M, int k, int vsf, int maxDegree,
+                          float alpha, int32_t *selected_out, int32_t *n_selected_out, float *short_edges_out);
+
+// the table-free form: `codebooks` = [M][k][8] centroids (what RdParams::codebooks points at on the device)
+extern "C" int rd_emu_run_tf(const float *tri, const float *codebooks, const uint8_t *codes, int64_t n, const int32_t *cand_nodes, const float *cand_scores,
+                             const int32_t *cand_count, const int32_t *diverse_before, int P, int C, int M, int k, int vsf, int maxDegree,
+                             float alpha, int32_t *selected_out, int32_t *n_selected_out, float *short_edges_out)
+{
+    return rd_emu_run_any(tri, codebooks, codes, n, cand_nodes, cand_scores, cand_count, diverse_before, P, C, M, k, vsf, maxDegree, alpha,
+                          selected_out, n_selected_out, short_edges_out);
+}
 
 extern "C" int rd_emu_run(const float *tri, const uint8_t *codes, int64_t n, const int32_t *cand_nodes, const float *cand_scores,
                           const int32_t *cand_count, const int32_t *diverse_before, int P, int C, int M, int k, int vsf, int maxDegree,
                           float alpha, int32_t *selected_out, int32_t *n_selected_out, float *short_edges_out)
 {
+    return rd_emu_run_any(tri, nullptr, codes, n, cand_nodes, cand_scores, cand_count, diverse_before, P, C, M, k, vsf, maxDegree, alpha,
+                          selected_out, n_selected_out, short_edges_out);
+}
+
+static int rd_emu_run_any(const float *tri, const float *codebooks, const uint8_t *codes, int64_t n, const int32_t *cand_nodes, const float *cand_scores,
+                          const int32_t *cand_count, const int32_t *diverse_before, int P, int C, int M, int k, int vsf, int maxDegree,
+                          float alpha, int32_t *selected_out, int32_t *n_selected_out, float *short_edges_out)
+{
     jv::RdParams p{};
+    p.codebooks = codebooks;
     p.tri = tri; p.codes = codes; p.n = n; p.cand_nodes = cand_nodes; p.cand_scores = cand_scores; p.cand_count = cand_count;
     p.diverse_before = diverse_before; p.P = P; p.C = C; p.M = M; p.k = k; p.vsf = vsf; p.maxDegree = maxDegree; p.alpha = alpha;
     p.selected_out = selected_out; p.n_selected_out = n_selected_out; p.short_edges_out = short_edges_out;
-    const size_t lds_bytes = jv::rd_lds_bytes(C, M);
+    const size_t lds_bytes = jv::rd_lds_bytes(C, M, codebooks != nullptr);
     char *lds = (char *)aligned_alloc(64, (lds_bytes + 63) & ~(size_t)63);
     for (int node = 0; node < P; ++node) {
         for (size_t i = 0; i < lds_bytes; ++i) lds[i] = (char)0xA5;  // stale LDS must never reach a result

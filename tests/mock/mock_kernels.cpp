@@ -218,14 +218,15 @@ struct RdLaunch {
 void rd_main(void *a)
 {
     const RdLaunch &L = *(const RdLaunch *)a;
-    rd_node(*L.p, L.node, L.lds);
+    if (L.p->codebooks) rd_node<true>(*L.p, L.node, L.lds);
+    else rd_node<false>(*L.p, L.node, L.lds);
 }
 }  // namespace
 size_t retain_diverse_lds_bytes(int C, int M) { return rd_lds_bytes(C, M); }
 // the shared kernel body (rd_body.h) on the lane emulator, one wavefront per node
 int launch_retain_diverse(hipStream_t, const jv_ctx *ctx, const RdParams &p)
 {
-    const size_t lds_bytes = rd_lds_bytes(p.C, p.M);
+    const size_t lds_bytes = rd_lds_bytes(p.C, p.M, p.codebooks != nullptr);
     if (lds_bytes > ctx->lds_per_block) {
         set_error("retain_diverse: %d candidates x %d code bytes need %zu bytes of LDS (limit %zu)", p.C, p.M, lds_bytes, ctx->lds_per_block);
         return JV_ERR_UNSUPPORTED;

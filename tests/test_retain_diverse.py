@@ -88,11 +88,15 @@ def emu():
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", src[0], "-o", lib])
     L = C.CDLL(lib)
     L.rd_emu_run.restype = C.c_int
+    L.rd_emu_run_tf.restype = C.c_int
     return L
 
 
+@pytest.mark.parametrize("table_free", [False, True])
 @pytest.mark.parametrize("seed,N,D,M,P,Cn,max_degree,alpha", CASES)
-def test_retain_diverse_emulated(emu, monkeypatch, seed, N, D, M, P, Cn, max_degree, alpha):
+def test_retain_diverse_emulated(emu, monkeypatch, seed, N, D, M, P, Cn, max_degree, alpha, table_free):
+    """table_free: rd_node<true> — the pair-table entries recomputed from the codebook (uniform 8-dimensional sub-vectors: every
+    case here), bit for bit what the table holds, so the selections cannot differ"""
     monkeypatch.setenv("EMU_LANE_ORDER", ["", "reverse", "random:3"][seed % 3])
     for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
         opq, codes, tri, cand, sc, count, before = make_case(seed * 10 + vsf, N, D, M, P, Cn, vsf, max_degree)
@@ -101,8 +105,14 @@ def test_retain_diverse_emulated(emu, monkeypatch, seed, N, D, M, P, Cn, max_deg
         nsel = np.full(P, -7, np.int32)
         se = np.zeros(P, np.float32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-        emu.rd_emu_run(p(tri), p(codes), C.c_int64(N), p(cand), p(sc), p(count), p(before), P, Cn, M, 256, int(vsf), max_degree,
-                       C.c_float(alpha), p(sel), p(nsel), p(se))
+        if table_free:
+            assert D == 8 * M
+            cb = np.ascontiguousarray(opq.codebooks, np.float32)
+            emu.rd_emu_run_tf(p(tri), p(cb), p(codes), C.c_int64(N), p(cand), p(sc), p(count), p(before), P, Cn, M, 256, int(vsf), max_degree,
+                              C.c_float(alpha), p(sel), p(nsel), p(se))
+        else:
+            emu.rd_emu_run(p(tri), p(codes), C.c_int64(N), p(cand), p(sc), p(count), p(before), P, Cn, M, 256, int(vsf), max_degree,
+                           C.c_float(alpha), p(sel), p(nsel), p(se))
         assert np.array_equal(sel, want[0]), (vsf, sel, want[0])
         assert np.array_equal(nsel, want[1]) and np.array_equal(se, want[2], equal_nan=True), vsf
         assert (nsel > 1).any()                                      # the prune really selects ...
@@ -131,6 +141,11 @@ def test_retain_diverse_gpu():
     import jvector_amd as J
     ctx = J.HipContext(0)
     run_through_cabi(J, ctx, CASES + [(5, 3000, 768, 96, 64, 100, 32, 1.2), (6, 1500, 1536, 192, 32, 100, 32, 1.2)])
+    ctx.set_option("rd_table_free", 1)   # the table-free form of the kernel (off by default: measured slower): the same selections
+    try:
+        run_through_cabi(J, ctx, CASES[:2] + [(5, 3000, 768, 96, 64, 100, 32, 1.2), (6, 1500, 1536, 192, 32, 100, 32, 1.2)])
+    finally:
+        ctx.set_option("rd_table_free", None)
     # unsupported: candidate codes that do not fit LDS (1000 x 192 B > 160 KB) are refused, not truncated
     opq, codes, tri, cand, sc, count, before = make_case(77, 1200, 1536, 192, 2, 1000, 0, 32)
     pq = J.ProductQuantization.from_codebooks(ctx, 1536, 192, opq.codebooks)
