@@ -537,12 +537,18 @@ int build_one_level(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, const j
     auto run = [&]() -> int {
         const std::vector<int32_t> perm = seeded_permutation(n, seed);
         JV_TRY(jv_hip_builder_seed(ctx, b, perm[0]));
+        // experiment knobs: another alpha for the insert phase (DiskANN builds its first pass with alpha = 1), another
+        // beam for the improve passes; unset = the call's alpha / beam throughout
+        const long long ins_alpha = ctx_opt(ctx, "bl_insert_alpha_x100", 0), imp_beam = ctx_opt(ctx, "bl_improve_beam", 0);
+        if (ins_alpha >= 100 && ins_alpha <= 6400) b->alpha = (float)ins_alpha / 100.0f;
         int64_t lo = 1;
         while (lo < n) {   // prefix doubling: a batch never exceeds what the graph already holds
             const int64_t hi = std::min<int64_t>(n, lo + std::min<int64_t>(max_batch, lo));
             JV_TRY(jv_hip_builder_insert_batch(ctx, b, perm.data() + lo, (int)(hi - lo)));
             lo = hi;
         }
+        b->alpha = alpha;
+        if (imp_beam >= 1 && imp_beam <= 4096) b->beam = (int)imp_beam;
         for (int pass = 0; pass < improve_passes && n >= 2; ++pass)
             for (int64_t s = 0; s < n; s += max_batch)
                 JV_TRY(jv_hip_builder_improve_batch(ctx, b, perm.data() + s, (int)std::min<int64_t>(max_batch, n - s)));
