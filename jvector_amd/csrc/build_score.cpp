@@ -93,6 +93,13 @@ bool retain_diverse_table_free(const jv_ctx *ctx, const jv_pq *pq)
 {
     return pq->uniform && pq->max_size == 8 && pq->D == 8 * pq->M && pq->k == kClusters && ctx_opt(ctx, "rd_table_free", 0) != 0;
 }
+// rd_chunk > 0: selected slots a robust-prune test examines per step of its INCREMENTAL walk (rd_body.h; RdParams::chunk: a
+// candidate remembers the slots it has been tested against and their largest similarity; only new slots are examined, and the walk
+// stops at the first violation).  Selections are identical for every value.  Measured on the MI355X (profiles/r4_w, before the
+// kernel's instruction diet): 64 (memory of earlier tests only) changes nothing, 8 is 30 % SLOWER — a prune is a chain of ~200
+// dependent tests per wave and its cost is the length of that chain, not the lanes that take part.  0 (default): every test examines
+// every selected slot in one step.
+int retain_diverse_chunk(const jv_ctx *ctx) { return (int)std::max<long long>(0, std::min<long long>(64, ctx_opt(ctx, "rd_chunk", 0))); }
 }  // namespace jv
 extern "C" {
 
@@ -137,6 +144,7 @@ int jv_hip_retain_diverse(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *c
     p.vsf = to_kernel_vsf(t->vsf);
     p.maxDegree = maxDegree;
     p.alpha = alpha;
+    p.chunk = retain_diverse_chunk(ctx);
     p.selected_out = (int32_t *)base;
     p.n_selected_out = (int32_t *)(base + o_cnt);
     p.short_edges_out = (float *)(base + o_se);

@@ -351,6 +351,7 @@ struct RdParams;
 int launch_retain_diverse(hipStream_t s, const jv_ctx *ctx, const RdParams &p);
 size_t retain_diverse_lds_bytes(int C, int M);
 bool retain_diverse_table_free(const jv_ctx *ctx, const jv_pq *pq);
+int retain_diverse_chunk(const jv_ctx *ctx);
 int launch_pair_scores(hipStream_t s, const float *d_tri, int vsf, const jv_codes *codes, const int32_t *d_node1, int P,
                        const int32_t *d_node2, int B, float *d_out);
 int launch_fused_gather(hipStream_t s, const jv_codes *codes, const int32_t *d_neighbors, int maxDegree, int64_t count, uint8_t *d_blocks);

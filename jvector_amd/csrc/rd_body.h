@@ -10,8 +10,8 @@
 // ascending m into one f32, the association of assembleAndSumPQ (DefaultVectorUtilSupport.java:312-335) — followed by one
 // vote.  isDiverse (:82-96) walks the selected set in ascending candidate INDEX and stops at the first event (the candidate
 // itself -> diverse, a violation -> not diverse); the vote reproduces that with a minimum over the event lanes' indices.
-// LDS: the candidates' code rows (C x M bytes, staged once), the selected neighbours' codes transposed ([m][slot], so the 64
-// lanes read 64 consecutive bytes), cosine self-magnitudes.  Shared source: compiled for gfx950 through gs_wave_hip.h and for
+// LDS: the candidates' code rows (C x M bytes, staged once), the selected neighbours' codes transposed in 4-byte words ([m / 4][slot],
+// so the 64 lanes read 64 consecutive words), cosine self-magnitudes.  Shared source: compiled for gfx950 through gs_wave_hip.h and for
 // the CPU lane emulator (tests/emu/rd_emu.cpp).  Wave API: gs_lane, gs_barrier, gs_ballot, gs_shfl, gs_shfl_xor, gs_sqrt.
 #pragma once
 
@@ -25,27 +25,40 @@ GS_FN int64_t rd_tri_row(int r, int k) { return (int64_t)r * k - ((int64_t)r * (
 
 // assembleAndSumPQ of (candidate row in LDS, this lane's selected slot column in LDS).  The M table entries are independent
 // loads (L2 / Infinity Cache latency each) feeding one sequential f32 sum: they are fetched 16 at a time and only then added,
-// in ascending m, so the latency is paid once per 16 entries instead of once per entry.
-GS_FN float rd_pair_sum(const float *tri, int M, int k, const uint8_t *crow, const uint8_t *scol /* stride 64 */)
+// in ascending m, so the latency is paid once per 16 entries instead of once per entry.  Codes come four to an LDS word (crow4:
+// the candidate's row, the same word for every lane; scol4: this lane's slot, word w at scol4[w * 64]) and the entry index is
+// 32-bit arithmetic (M k (k + 1) / 2 < 2^31): round 4 — the byte-wise LDS reads with a wait behind each and the 64-bit index
+// arithmetic of rounds 2 - 3 were ~21 instructions per entry, and the kernel was bound by the issue of exactly those.
+GS_FN uint32_t rd_tri_index(uint32_t m_base, uint32_t k, uint32_t c1, uint32_t c2)
 {
-    const int64_t block = (int64_t)k * (k + 1) / 2;
+    const uint32_t r = c1 < c2 ? c1 : c2, c = c1 < c2 ? c2 : c1;
+    return m_base + r * k - ((r * (r - 1u)) >> 1) + (c - r);   // (r = 0: 0 * 0xFFFFFFFF = 0)
+}
+
+GS_FN float rd_pair_sum(const float *tri, int M, int k, const uint32_t *crow4, const uint32_t *scol4 /* stride 64 words */)
+{
+    const uint32_t block = (uint32_t)k * ((uint32_t)k + 1u) / 2u;
     float res = 0.0f;
     int m = 0;
     for (; m + 16 <= M; m += 16) {
+        uint32_t cw[4], sw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cw[q] = crow4[(m >> 2) + q];
+            sw[q] = scol4[(size_t)((m >> 2) + q) * 64];
+        }
         float e[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int c1 = crow[m + j], c2 = scol[(size_t)(m + j) * 64];
-            const int r = c1 < c2 ? c1 : c2, c = c1 < c2 ? c2 : c1;
-            e[j] = tri[(int64_t)(m + j) * block + rd_tri_row(r, k) + (c - r)];
+            const uint32_t c1 = (cw[j >> 2] >> (8 * (j & 3))) & 0xFFu, c2 = (sw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            e[j] = tri[rd_tri_index((uint32_t)(m + j) * block, (uint32_t)k, c1, c2)];
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) res += e[j];
     }
     for (; m < M; ++m) {
-        const int c1 = crow[m], c2 = scol[(size_t)m * 64];
-        const int r = c1 < c2 ? c1 : c2, c = c1 < c2 ? c2 : c1;
-        res += tri[(int64_t)m * block + rd_tri_row(r, k) + (c - r)];
+        const uint32_t c1 = (crow4[m >> 2] >> (8 * (m & 3))) & 0xFFu, c2 = (scol4[(size_t)(m >> 2) * 64] >> (8 * (m & 3))) & 0xFFu;
+        res += tri[rd_tri_index((uint32_t)m * block, (uint32_t)k, c1, c2)];
     }
     return res;
 }
@@ -86,7 +99,7 @@ GS_FN float rd_entry_tf(const rd_f4 &a0, const rd_f4 &a1, const rd_f4 &c0, const
 }
 
 template <bool L2>
-GS_FN float rd_pair_sum_tf(const float *cb, int M, int k, const float *cvec, const uint8_t *scol /* stride 64 */)
+GS_FN float rd_pair_sum_tf(const float *cb, int M, int k, const float *cvec, const uint32_t *scol4 /* stride 64 words */)
 {
     float res = 0.0f;
     int m = 0;
@@ -94,7 +107,8 @@ GS_FN float rd_pair_sum_tf(const float *cb, int M, int k, const float *cvec, con
         rd_f4 a0[8], a1[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const rd_f4 *r = reinterpret_cast<const rd_f4 *>(cb + ((int64_t)(m + j) * k + scol[(size_t)(m + j) * 64]) * 8);
+            const uint32_t code = (scol4[(size_t)((m + j) >> 2) * 64] >> (8 * ((m + j) & 3))) & 0xFFu;
+            const rd_f4 *r = reinterpret_cast<const rd_f4 *>(cb + ((int64_t)(m + j) * k + code) * 8);
             a0[j] = r[0];
             a1[j] = r[1];
         }
@@ -105,7 +119,8 @@ GS_FN float rd_pair_sum_tf(const float *cb, int M, int k, const float *cvec, con
         }
     }
     for (; m < M; ++m) {
-        const rd_f4 *r = reinterpret_cast<const rd_f4 *>(cb + ((int64_t)m * k + scol[(size_t)m * 64]) * 8);
+        const uint32_t code = (scol4[(size_t)(m >> 2) * 64] >> (8 * (m & 3))) & 0xFFu;
+        const rd_f4 *r = reinterpret_cast<const rd_f4 *>(cb + ((int64_t)m * k + code) * 8);
         const rd_f4 *c = reinterpret_cast<const rd_f4 *>(cvec + (size_t)m * 8);
         res += rd_entry_tf<L2>(r[0], r[1], c[0], c[1]);
     }
@@ -121,6 +136,20 @@ GS_FN float rd_self_sum(const float *tri, int M, int k, const uint8_t *crow)
         res += tri[(int64_t)m * block + rd_tri_row(c, k)];
     }
     return res;
+}
+
+// the largest lane value; NaN-free input (callers pass -inf for "nothing")
+GS_FN float rd_wave_max_f(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        int32_t b;
+        __builtin_memcpy(&b, &v, 4);
+        b = (int32_t)gs_shfl_xor((long long)b, o);
+        float t;
+        __builtin_memcpy(&t, &b, 4);
+        v = t > v ? t : v;
+    }
+    return v;
 }
 
 GS_FN int rd_wave_min(int v)
@@ -140,11 +169,14 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
     const int lane = gs_lane();
     const int M = p.M, C = p.C;
     uint8_t *cc = reinterpret_cast<uint8_t *>(lds);               // [C][M] candidate codes
-    uint8_t *st = cc + (size_t)C * M;                              // [M][64] selected codes, transposed
-    float *cnorm = reinterpret_cast<float *>(lds + (((size_t)C * M + (size_t)M * 64 + 15) & ~(size_t)15));  // [C]
+    const int Mp = rd_row_bytes(M);                                // row stride: whole 4-byte words
+    uint32_t *st = reinterpret_cast<uint32_t *>(cc + (size_t)C * Mp);   // [Mp/4][64] selected codes: word w of slot j at st[w * 64 + j]
+    float *cnorm = reinterpret_cast<float *>(lds + (((size_t)C * Mp + (size_t)Mp * 64 + 15) & ~(size_t)15));  // [C]
     float *snorm = cnorm + C;                                      // [64]
     int32_t *sidx = reinterpret_cast<int32_t *>(snorm + 64);       // [64] candidate index of slot j
     int32_t *snode = sidx + 64;                                    // [64]
+    int32_t *tested = reinterpret_cast<int32_t *>(lds + rd_off_tested(C, M));   // [C] leading selected slots candidate i has been tested against
+    float *best = reinterpret_cast<float *>(tested + C);                        // [C] the largest similarity among them (-inf: none)
     float *cvec = reinterpret_cast<float *>(lds + rd_off_cvec(C, M));   // TF: [M][8] the candidate under test, decoded
     (void)cvec;
     const int32_t *nodes = p.cand_nodes + (int64_t)node_idx * C;
@@ -160,11 +192,15 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
     for (int i = 0; i < n; ++i) {
         const int32_t nd = nodes[i];
         const bool ok = nd >= 0 && nd < p.n;
-        for (int b = lane; b < M; b += 64) cc[(size_t)i * M + b] = ok ? p.codes[(int64_t)nd * M + b] : (uint8_t)0;
+        for (int b = lane; b < Mp; b += 64) cc[(size_t)i * Mp + b] = (ok && b < M) ? p.codes[(int64_t)nd * M + b] : (uint8_t)0;
     }
     gs_barrier();
     if (p.vsf == 2)
-        for (int i = lane; i < n; i += 64) cnorm[i] = rd_self_sum(p.tri, M, p.k, cc + (size_t)i * M);
+        for (int i = lane; i < n; i += 64) cnorm[i] = rd_self_sum(p.tri, M, p.k, cc + (size_t)i * Mp);
+    for (int i = lane; i < n; i += 64) {
+        tested[i] = 0;
+        best[i] = -__builtin_inff();
+    }
     gs_barrier();
 
     // selected BitSet as two 64-bit words per 128 candidates would not cover C up to 1024: keep it as one bit per lane-chunk:
@@ -178,7 +214,7 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
             snode[nSlots] = nodes[i];
             if (p.vsf == 2) snorm[nSlots] = cnorm[i];
         }
-        for (int b = lane; b < M; b += 64) st[(size_t)b * 64 + nSlots] = cc[(size_t)i * M + b];
+        for (int b = lane; b < Mp / 4; b += 64) st[(size_t)b * 64 + nSlots] = reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp)[b];
         nSlots++;
         gs_barrier();
     };
@@ -195,43 +231,81 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
             if ((owner_bits >> (i >> 6)) & 1ull) continue;
             const int32_t cNode = nodes[i];
             const float cScore = scores[i];
-            // ---- isDiverse: every selected slot in parallel, then the first event in ascending candidate index ----
-            int ev_idx = 0x7fffffff;  // this lane's event index (none: INT_MAX)
-            bool ev_fail = false;
-            if constexpr (TF) {
-                if (nSlots > 0) {   // (the previous test's readers are past their last wave-wide step: rd_wave_min / the ballot)
+            // ---- isDiverse.  Events of the reference's walk over the selected set (ascending candidate index): the candidate itself
+            //      -> diverse, a violation -> not diverse; the first event decides.  Lane j owns selected slot j.
+            auto stage = [&]() {   // TF: the candidate's sub-vectors, decoded into LDS for this test
+                if constexpr (TF) {
                     for (int idx = lane; idx < 2 * M; idx += 64) {
                         const int m = idx >> 1;
-                        const rd_f4 *r = reinterpret_cast<const rd_f4 *>(p.codebooks + ((int64_t)m * p.k + cc[(size_t)i * M + m]) * 8);
+                        const rd_f4 *r = reinterpret_cast<const rd_f4 *>(p.codebooks + ((int64_t)m * p.k + cc[(size_t)i * Mp + m]) * 8);
                         reinterpret_cast<rd_f4 *>(cvec)[idx] = r[idx & 1];
                     }
                     gs_barrier();
                 }
-            }
-            if (lane < nSlots) {
-                if (snode[lane] == cNode) {
-                    ev_idx = sidx[lane];
-                } else {
-                    float sum;
-                    if constexpr (TF) sum = p.vsf == 0 ? rd_pair_sum_tf<true>(p.codebooks, M, p.k, cvec, st + lane)
-                                                       : rd_pair_sum_tf<false>(p.codebooks, M, p.k, cvec, st + lane);
-                    else sum = rd_pair_sum(p.tri, M, p.k, cc + (size_t)i * M, st + lane);
-                    float sim;
-                    if (p.vsf == 0) sim = 1.0f / (1.0f + sum);
-                    else if (p.vsf == 1) sim = (1.0f + sum) / 2.0f;
-                    else {
-                        const float prod = cnorm[i] * snorm[lane];
-                        const float cosine = sum / (float)gs_sqrt((double)prod);
-                        sim = (1.0f + cosine) / 2.0f;
-                    }
-                    if (sim > cScore * currentAlpha) {
+            };
+            auto sim_of = [&]() -> float {   // this lane's slot against candidate i
+                float sum;
+                if constexpr (TF) sum = p.vsf == 0 ? rd_pair_sum_tf<true>(p.codebooks, M, p.k, cvec, st + lane)
+                                                   : rd_pair_sum_tf<false>(p.codebooks, M, p.k, cvec, st + lane);
+                else sum = rd_pair_sum(p.tri, M, p.k, reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp), st + lane);
+                if (p.vsf == 0) return 1.0f / (1.0f + sum);
+                if (p.vsf == 1) return (1.0f + sum) / 2.0f;
+                const float prod = cnorm[i] * snorm[lane];
+                const float cosine = sum / (float)gs_sqrt((double)prod);
+                return (1.0f + cosine) / 2.0f;
+            };
+            bool not_diverse;
+            const bool dup = gs_ballot(lane < nSlots && snode[lane] == cNode) != 0;
+            if (dup || p.chunk <= 0) {
+                // every selected slot in parallel, then the first event in ascending candidate index (the candidate's node is in the
+                // selected set — a node listed twice — or incremental tests are off)
+                int ev_idx = 0x7fffffff;  // this lane's event index (none: INT_MAX)
+                bool ev_fail = false;
+                if (nSlots > 0) stage();   // (the previous test's readers are past their last wave-wide step)
+                if (lane < nSlots) {
+                    if (snode[lane] == cNode) {
+                        ev_idx = sidx[lane];
+                    } else if (sim_of() > cScore * currentAlpha) {
                         ev_idx = sidx[lane];
                         ev_fail = true;
                     }
                 }
+                const int first = rd_wave_min(ev_idx);
+                not_diverse = gs_ballot(ev_fail && ev_idx == first && first != 0x7fffffff) != 0;
+            } else {
+                // No selected slot holds the candidate's node: it is diverse iff NO selected slot violates, whatever the order.  Slots
+                // are only ever appended and a similarity does not depend on alpha, so what earlier tests of this candidate saw is
+                // still true: `tested[i]` leading slots with the largest similarity `best[i]` among them (NaN similarities never
+                // violate and never become the maximum).  Only the slots behind them are examined, `chunk` at a time, and the walk
+                // stops at the first violation — the reference's own early exit; the second alpha pass re-tests nothing it knows.
+                const float thr = cScore * currentAlpha;
+                int t = tested[i];
+                float mx = best[i];
+                bool viol = mx > thr;
+                bool staged = false;
+                while (!viol && t < nSlots) {
+                    if (!staged) {
+                        stage();
+                        staged = true;
+                    }
+                    const int hi = t + p.chunk < nSlots ? t + p.chunk : nSlots;
+                    float sv = -__builtin_inff();
+                    if (lane >= t && lane < hi) {
+                        const float sim = sim_of();
+                        if (sim == sim) sv = sim;
+                    }
+                    const float cm = rd_wave_max_f(sv);
+                    if (cm > mx) mx = cm;
+                    t = hi;
+                    viol = mx > thr;
+                }
+                if (lane == 0) {
+                    tested[i] = t;
+                    best[i] = mx;
+                }
+                gs_barrier();
+                not_diverse = viol;
             }
-            const int first = rd_wave_min(ev_idx);
-            const bool not_diverse = gs_ballot(ev_fail && ev_idx == first && first != 0x7fffffff) != 0;
             if (!not_diverse) {
                 if (nSlots < 64) take(i);
                 nSelected++;

@@ -18,6 +18,9 @@ struct RdParams {
     const int32_t *diverse_before;  // [P] or nullptr (= 0): the first diverse_before candidates are taken as already diverse
     int32_t P, C, M, k, vsf, maxDegree;
     float alpha;
+    int32_t chunk;             // > 0: incremental tests (rd_body.h): a candidate remembers how many leading selected slots it has been tested
+                               // against and the largest similarity among them; a test examines only the slots behind that, `chunk` at a
+                               // time, and stops at the first violation.  0: every test examines every selected slot.
     int32_t *selected_out;     // [P][maxDegree] selected candidate INDICES in ascending order, -1 padded
     int32_t *n_selected_out;   // [P]
     float *short_edges_out;    // [P] or nullptr: nSelected after the alpha = 1.0 pass / maxDegree (NaN if the loop never ran)
@@ -25,14 +28,18 @@ struct RdParams {
 
 // LDS bytes one wavefront needs: candidate code rows, transposed selected codes, self magnitudes, slot bookkeeping
 // (table_free: + the current candidate's decoded sub-vectors, M x 8 floats, at rd_off_cvec)
-constexpr size_t rd_off_cvec(int C, int M)
+// layout: [C][Mp] candidate codes | [Mp/4][64] words of selected codes | (16-byte aligned) cnorm [C] | snorm [64] | sidx [64] | snode [64] |
+//         tested [C] (int) | best [C] (float) | (16-byte aligned, table-free only) cvec [M][8]
+// (code rows are padded to whole 4-byte words: the kernel reads four codes per LDS word)
+constexpr int rd_row_bytes(int M) { return (M + 3) & ~3; }
+constexpr size_t rd_off_tested(int C, int M)
 {
-    return ((((size_t)C * M + (size_t)M * 64 + 15) & ~(size_t)15) + sizeof(float) * ((size_t)C + 64) + sizeof(int32_t) * 64 * 2 + 15) & ~(size_t)15;
+    return (((size_t)C * rd_row_bytes(M) + (size_t)rd_row_bytes(M) * 64 + 15) & ~(size_t)15) + sizeof(float) * ((size_t)C + 64) + sizeof(int32_t) * 64 * 2;
 }
+constexpr size_t rd_off_cvec(int C, int M) { return (rd_off_tested(C, M) + 8 * (size_t)C + 15) & ~(size_t)15; }
 inline size_t rd_lds_bytes(int C, int M, bool table_free = false)
 {
-    const size_t base = (size_t)C * M + (size_t)M * 64 + sizeof(float) * ((size_t)C + 64) + sizeof(int32_t) * 64 * 2 + 16;
-    return table_free ? rd_off_cvec(C, M) + sizeof(float) * 8 * (size_t)M : base;
+    return rd_off_cvec(C, M) + (table_free ? sizeof(float) * 8 * (size_t)M : 0);
 }
 
 }  // namespace jv

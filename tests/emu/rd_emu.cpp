@@ -57,6 +57,7 @@ static int rd_emu_run_any(const float *tri, const float *codebooks, const uint8_
 {
     jv::RdParams p{};
     p.codebooks = codebooks;
+    p.chunk = getenv("RD_EMU_CHUNK") ? atoi(getenv("RD_EMU_CHUNK")) : 8;   // (incremental tests; 0 = every test examines every slot)
     p.tri = tri; p.codes = codes; p.n = n; p.cand_nodes = cand_nodes; p.cand_scores = cand_scores; p.cand_count = cand_count;
     p.diverse_before = diverse_before; p.P = P; p.C = C; p.M = M; p.k = k; p.vsf = vsf; p.maxDegree = maxDegree; p.alpha = alpha;
     p.selected_out = selected_out; p.n_selected_out = n_selected_out; p.short_edges_out = short_edges_out;
