@@ -12,7 +12,7 @@
 // itself -> diverse, a violation -> not diverse); the vote reproduces that with a minimum over the event lanes' indices.
 // LDS: the candidates' code rows (C x M bytes, staged once), the selected neighbours' codes transposed in 4-byte words ([m / 4][slot],
 // so the 64 lanes read 64 consecutive words), cosine self-magnitudes.  Shared source: compiled for gfx950 through gs_wave_hip.h and for
-// the CPU lane emulator (tests/emu/rd_emu.cpp).  Wave API: gs_lane, gs_barrier, gs_ballot, gs_shfl, gs_shfl_xor, gs_sqrt.
+// the CPU lane emulator (tests/emu/rd_emu.cpp).  Wave API: gs_lane, gs_barrier, gs_ballot, gs_shfl, gs_shfl32, gs_shfl_xor, gs_sqrt.
 #pragma once
 
 #include <cstdint>
@@ -59,6 +59,77 @@ GS_FN float rd_pair_sum(const float *tri, int M, int k, const uint32_t *crow4, c
     for (; m < M; ++m) {
         const uint32_t c1 = (crow4[m >> 2] >> (8 * (m & 3))) & 0xFFu, c2 = (scol4[(size_t)(m >> 2) * 64] >> (8 * (m & 3))) & 0xFFu;
         res += tri[rd_tri_index((uint32_t)m * block, (uint32_t)k, c1, c2)];
+    }
+    return res;
+}
+
+// The same sum with the LANES THE TEST LEAVES IDLE (RdParams::split).  A prune is a chain of ~200 dependent tests run by one wave, a
+// test keeps one lane per selected slot busy (a dozen on average, 32 at most) with M entries each: the length of that per-lane
+// chain is the kernel's time.  With `parts` lanes per slot (lane q S + j: 16-entry blocks [q bpl, (q + 1) bpl) of
+// slot j, S = 64 / parts) the chain is M / parts entries; the sum stays the one sequential f32 chain in ascending m: lane j takes its
+// own entries, then lane S + j's, ... through ds_bpermute (no LDS storage: the entries wait in registers).  M a multiple of 16, one
+// to three blocks per lane.  Called by ALL lanes; the result is valid on lanes < nSlots.
+GS_FN int rd_split_parts(int M, int nSlots)
+{
+    if (M % 16 != 0 || nSlots <= 0) return 1;
+    const int nb = M / 16;
+    for (int parts = 6; parts >= 2; --parts)
+        if (parts != 5 && nb % parts == 0 && nb / parts <= 3 && nSlots * parts <= 64) return parts;
+    return 1;
+}
+
+GS_FN float rd_pair_sum_split(const float *tri, int M, int k, const uint32_t *crow4, const uint32_t *st4, int lane, int nSlots, int parts)
+{
+    const int S = 64 / parts;
+    const int part = lane / S, slot = lane - part * S;
+    const bool act = part < parts && slot < nSlots;
+    const int bpl = (M / 16) / parts;   // blocks per lane: 1 ... 3
+    const uint32_t block = (uint32_t)k * ((uint32_t)k + 1u) / 2u;
+    const uint32_t *scol4 = st4 + (act ? slot : 0);
+    float e[3][16];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) e[b][j] = 0.0f;
+        if (b < bpl && act) {
+            const int m = (part * bpl + b) * 16;
+            uint32_t cw[4], sw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cw[q] = crow4[(m >> 2) + q];
+                sw[q] = scol4[(size_t)((m >> 2) + q) * 64];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t c1 = (cw[j >> 2] >> (8 * (j & 3))) & 0xFFu, c2 = (sw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                e[b][j] = tri[rd_tri_index((uint32_t)(m + j) * block, (uint32_t)k, c1, c2)];
+            }
+        }
+    }
+    float res = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        if (b < bpl) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) res += e[b][j];
+        }
+    }
+    for (int q = 1; q < parts; ++q) {
+        const int src = (slot + q * S) & 63;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b < bpl) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    int32_t bits;
+                    __builtin_memcpy(&bits, &e[b][j], 4);
+                    bits = gs_shfl32(bits, src);
+                    float v;
+                    __builtin_memcpy(&v, &bits, 4);
+                    res += v;
+                }
+            }
+        }
     }
     return res;
 }
@@ -243,16 +314,19 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
                     gs_barrier();
                 }
             };
-            auto sim_of = [&]() -> float {   // this lane's slot against candidate i
-                float sum;
-                if constexpr (TF) sum = p.vsf == 0 ? rd_pair_sum_tf<true>(p.codebooks, M, p.k, cvec, st + lane)
-                                                   : rd_pair_sum_tf<false>(p.codebooks, M, p.k, cvec, st + lane);
-                else sum = rd_pair_sum(p.tri, M, p.k, reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp), st + lane);
+            auto sim_from = [&](float sum) -> float {
                 if (p.vsf == 0) return 1.0f / (1.0f + sum);
                 if (p.vsf == 1) return (1.0f + sum) / 2.0f;
                 const float prod = cnorm[i] * snorm[lane];
                 const float cosine = sum / (float)gs_sqrt((double)prod);
                 return (1.0f + cosine) / 2.0f;
+            };
+            auto sim_of = [&]() -> float {   // this lane's slot against candidate i
+                float sum;
+                if constexpr (TF) sum = p.vsf == 0 ? rd_pair_sum_tf<true>(p.codebooks, M, p.k, cvec, st + lane)
+                                                   : rd_pair_sum_tf<false>(p.codebooks, M, p.k, cvec, st + lane);
+                else sum = rd_pair_sum(p.tri, M, p.k, reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp), st + lane);
+                return sim_from(sum);
             };
             bool not_diverse;
             const bool dup = gs_ballot(lane < nSlots && snode[lane] == cNode) != 0;
@@ -262,10 +336,15 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
                 int ev_idx = 0x7fffffff;  // this lane's event index (none: INT_MAX)
                 bool ev_fail = false;
                 if (nSlots > 0) stage();   // (the previous test's readers are past their last wave-wide step)
+                int parts = 1;
+                if constexpr (!TF) parts = p.split ? rd_split_parts(M, nSlots) : 1;
+                float split_sum = 0.0f;
+                if (parts > 1)   // every lane takes part; lanes < nSlots end up with their slot's sum
+                    split_sum = rd_pair_sum_split(p.tri, M, p.k, reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp), st, lane, nSlots, parts);
                 if (lane < nSlots) {
                     if (snode[lane] == cNode) {
                         ev_idx = sidx[lane];
-                    } else if (sim_of() > cScore * currentAlpha) {
+                    } else if ((parts > 1 ? sim_from(split_sum) : sim_of()) > cScore * currentAlpha) {
                         ev_idx = sidx[lane];
                         ev_fail = true;
                     }

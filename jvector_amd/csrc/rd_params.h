@@ -18,6 +18,7 @@ struct RdParams {
     const int32_t *diverse_before;  // [P] or nullptr (= 0): the first diverse_before candidates are taken as already diverse
     int32_t P, C, M, k, vsf, maxDegree;
     float alpha;
+    int32_t split;             // != 0: a test spreads each selected slot's M entries over up to six lanes (rd_pair_sum_split)
     int32_t chunk;             // > 0: incremental tests (rd_body.h): a candidate remembers how many leading selected slots it has been tested
                                // against and the largest similarity among them; a test examines only the slots behind that, `chunk` at a
                                // time, and stops at the first violation.  0: every test examines every selected slot.

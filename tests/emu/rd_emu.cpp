@@ -12,6 +12,7 @@ static inline void gs_barrier() { emu::barrier(); }
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
+static inline int32_t gs_shfl32(int32_t v, int src) { return (int32_t)emu::shfl((long long)v, src); }
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
 
 #include "../../jvector_amd/csrc/rd_body.h"
@@ -57,6 +58,7 @@ static int rd_emu_run_any(const float *tri, const float *codebooks, const uint8_
 {
     jv::RdParams p{};
     p.codebooks = codebooks;
+    p.split = getenv("RD_EMU_SPLIT") ? atoi(getenv("RD_EMU_SPLIT")) : 1;   // (idle lanes share a slot's entries; 0 = one lane per slot)
     p.chunk = getenv("RD_EMU_CHUNK") ? atoi(getenv("RD_EMU_CHUNK")) : 8;   // (incremental tests; 0 = every test examines every slot)
     p.tri = tri; p.codes = codes; p.n = n; p.cand_nodes = cand_nodes; p.cand_scores = cand_scores; p.cand_count = cand_count;
     p.diverse_before = diverse_before; p.P = P; p.C = C; p.M = M; p.k = k; p.vsf = vsf; p.maxDegree = maxDegree; p.alpha = alpha;

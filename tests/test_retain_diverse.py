@@ -73,7 +73,9 @@ def oracle_selection(opq, codes, tri, vsf, cand, sc, count, before, max_degree, 
 
 
 CASES = [(1, 600, 64, 8, 9, 40, 16, 1.2), (2, 800, 128, 16, 7, 70, 32, 1.2), (3, 500, 64, 8, 6, 130, 8, 1.4), (4, 400, 96, 12, 5, 20, 64, 1.0),
-         (5, 400, 40, 5, 6, 50, 12, 1.2), (6, 500, 152, 19, 5, 60, 32, 1.2)]   # (M not a multiple of 4: padded code rows; 16 + 3 subspaces)
+         (5, 400, 40, 5, 6, 50, 12, 1.2), (6, 500, 152, 19, 5, 60, 32, 1.2),   # (M not a multiple of 4: padded code rows; 16 + 3 subspaces)
+         # M a multiple of 32 / 48 / 96: a test spreads a slot's entries over 2 ... 6 lanes while few slots are selected
+         (7, 400, 256, 32, 6, 60, 32, 1.2), (8, 300, 768, 96, 5, 80, 32, 1.2), (9, 300, 384, 48, 5, 40, 16, 1.2), (10, 300, 1536, 192, 4, 70, 32, 1.2)]
 
 
 # ---- CPU: lane emulator ---------------------------------------------------------------------------------------------
@@ -93,14 +95,15 @@ def emu():
     return L
 
 
-@pytest.mark.parametrize("table_free,chunk", [(False, 8), (True, 8), (False, 0), (False, 1), (False, 3), (True, 64)])
+@pytest.mark.parametrize("table_free,chunk,split", [(False, 0, 1), (False, 0, 0), (False, 8, 1), (True, 8, 1), (False, 1, 0), (False, 3, 1), (True, 64, 0)])
 @pytest.mark.parametrize("seed,N,D,M,P,Cn,max_degree,alpha", CASES)
-def test_retain_diverse_emulated(emu, monkeypatch, seed, N, D, M, P, Cn, max_degree, alpha, table_free, chunk):
+def test_retain_diverse_emulated(emu, monkeypatch, seed, N, D, M, P, Cn, max_degree, alpha, table_free, chunk, split):
     """table_free: rd_node<true> — the pair-table entries recomputed from the codebook (uniform 8-dimensional sub-vectors: every
     case here), bit for bit what the table holds, so the selections cannot differ"""
     # chunk: the incremental walk of a test over the selected slots (0: every test examines every slot — the rounds 2-3 form;
     # 1: the reference's own slot-by-slot walk; 64: no chunking, only the memory of earlier tests)
     monkeypatch.setenv("RD_EMU_CHUNK", str(chunk))
+    monkeypatch.setenv("RD_EMU_SPLIT", str(split))   # idle lanes share a slot's entries (chunk 0 / duplicate-node tests; M % 16 == 0)
     monkeypatch.setenv("EMU_LANE_ORDER", ["", "reverse", "random:3"][seed % 3])
     for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
         opq, codes, tri, cand, sc, count, before = make_case(seed * 10 + vsf, N, D, M, P, Cn, vsf, max_degree)
@@ -145,6 +148,11 @@ def test_retain_diverse_gpu():
     import jvector_amd as J
     ctx = J.HipContext(0)
     run_through_cabi(J, ctx, CASES + [(15, 3000, 768, 96, 64, 100, 32, 1.2), (16, 1500, 1536, 192, 32, 100, 32, 1.2)])
+    ctx.set_option("rd_split", 0)        # one lane per selected slot (the default spreads a slot's entries over the test's idle lanes)
+    try:
+        run_through_cabi(J, ctx, CASES[1:2] + CASES[6:] + [(15, 3000, 768, 96, 64, 100, 32, 1.2), (16, 1500, 1536, 192, 32, 100, 32, 1.2)])
+    finally:
+        ctx.set_option("rd_split", None)
     ctx.set_option("rd_table_free", 1)   # the table-free form of the kernel (off by default: measured slower): the same selections
     try:
         run_through_cabi(J, ctx, CASES[:2] + [(15, 3000, 768, 96, 64, 100, 32, 1.2), (16, 1500, 1536, 192, 32, 100, 32, 1.2)])
