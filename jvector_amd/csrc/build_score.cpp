@@ -146,6 +146,7 @@ int jv_hip_retain_diverse(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *c
     p.alpha = alpha;
     p.chunk = retain_diverse_chunk(ctx);
     p.split = ctx_opt(ctx, "rd_split", 1) != 0 ? 1 : 0;   // (rd_body.h rd_pair_sum_split: idle lanes share a slot's entries)
+    p.wide_stage = ctx_opt(ctx, "rd_wide_stage", 1) != 0 ? 1 : 0;   // (candidate rows staged 16 bytes per lane, every load independent)
     p.selected_out = (int32_t *)base;
     p.n_selected_out = (int32_t *)(base + o_cnt);
     p.short_edges_out = (float *)(base + o_se);

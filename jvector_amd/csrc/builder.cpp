@@ -89,6 +89,7 @@ int run_retain(jv_ctx *ctx, jv_builder *b, const int32_t *d_cand, const float *d
     p.alpha = b->alpha;
     p.chunk = retain_diverse_chunk(ctx);
     p.split = ctx_opt(ctx, "rd_split", 1) != 0 ? 1 : 0;
+    p.wide_stage = ctx_opt(ctx, "rd_wide_stage", 1) != 0 ? 1 : 0;
     p.selected_out = d_sel;
     p.n_selected_out = d_nsel;
     p.short_edges_out = nullptr;

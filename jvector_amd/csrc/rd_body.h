@@ -141,6 +141,7 @@ GS_FN float rd_pair_sum_split(const float *tri, int M, int k, const uint32_t *cr
 // (cvec, broadcast reads).  The pair table (12.6 / 25 MB) misses L2 four times out of five; the codebook does not —
 // and the form is still 1.4 - 1.7x SLOWER on the MI355X (profiles/r4_t): selectable (rd_table_free = 1), off by default.
 struct alignas(16) rd_f4 { float x, y, z, w; };
+struct alignas(16) rd_u4 { uint32_t x, y, z, w; };
 
 template <bool L2>
 GS_FN float rd_entry_tf(const rd_f4 &a0, const rd_f4 &a1, const rd_f4 &c0, const rd_f4 &c1)
@@ -200,11 +201,22 @@ GS_FN float rd_pair_sum_tf(const float *cb, int M, int k, const float *cvec, con
 
 GS_FN float rd_self_sum(const float *tri, int M, int k, const uint8_t *crow)
 {
-    const int64_t block = (int64_t)k * (k + 1) / 2;
+    const uint32_t block = (uint32_t)k * ((uint32_t)k + 1u) / 2u;
     float res = 0.0f;
-    for (int m = 0; m < M; ++m) {
-        const int c = crow[m];
-        res += tri[(int64_t)m * block + rd_tri_row(c, k)];
+    int m = 0;
+    for (; m + 16 <= M; m += 16) {   // 16 independent loads, then their sum in ascending m
+        float e[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t c = crow[m + j];
+            e[j] = tri[rd_tri_index((uint32_t)(m + j) * block, (uint32_t)k, c, c)];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) res += e[j];
+    }
+    for (; m < M; ++m) {
+        const uint32_t c = crow[m];
+        res += tri[rd_tri_index((uint32_t)m * block, (uint32_t)k, c, c)];
     }
     return res;
 }
@@ -248,6 +260,8 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
     int32_t *snode = sidx + 64;                                    // [64]
     int32_t *tested = reinterpret_cast<int32_t *>(lds + rd_off_tested(C, M));   // [C] leading selected slots candidate i has been tested against
     float *best = reinterpret_cast<float *>(tested + C);                        // [C] the largest similarity among them (-inf: none)
+    int32_t *cid = reinterpret_cast<int32_t *>(best + C);                       // [C] the candidates' node ids   } copies of the global rows: a test
+    float *csc = reinterpret_cast<float *>(cid + C);                            // [C] ... and scores             } starts without a global load
     float *cvec = reinterpret_cast<float *>(lds + rd_off_cvec(C, M));   // TF: [M][8] the candidate under test, decoded
     (void)cvec;
     const int32_t *nodes = p.cand_nodes + (int64_t)node_idx * C;
@@ -259,11 +273,29 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
     int diverseBefore = p.diverse_before ? p.diverse_before[node_idx] : 0;
     if (diverseBefore < 0) diverseBefore = 0;
 
-    // ---- stage the candidates' code rows (and, for cosine, their self magnitudes) ----
-    for (int i = 0; i < n; ++i) {
-        const int32_t nd = nodes[i];
-        const bool ok = nd >= 0 && nd < p.n;
-        for (int b = lane; b < Mp; b += 64) cc[(size_t)i * Mp + b] = (ok && b < M) ? p.codes[(int64_t)nd * M + b] : (uint8_t)0;
+    // ---- stage the candidates' ids, scores and code rows (and, for cosine, their self magnitudes) ----
+    for (int i = lane; i < n; i += 64) {
+        cid[i] = nodes[i];
+        csc[i] = scores[i];
+    }
+    gs_barrier();
+    if (p.wide_stage && (M & 15) == 0 && (reinterpret_cast<uintptr_t>(p.codes) & 15) == 0) {
+        // (row, 16-byte piece) items over the lanes: every load independent of every other — the row-by-row loop below is n
+        // dependent round trips (node id -> code bytes), which for 100 - 190 candidates was a large part of a prune's time
+        const int cpr = M >> 4, items = n * cpr;
+        for (int w = lane; w < items; w += 64) {
+            const int i = w / cpr, c = w - i * cpr;
+            const int32_t nd = cid[i];
+            rd_u4 v = {0u, 0u, 0u, 0u};
+            if (nd >= 0 && nd < p.n) v = *reinterpret_cast<const rd_u4 *>(p.codes + (int64_t)nd * M + 16 * c);
+            *reinterpret_cast<rd_u4 *>(cc + (size_t)i * Mp + 16 * c) = v;
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const int32_t nd = cid[i];
+            const bool ok = nd >= 0 && nd < p.n;
+            for (int b = lane; b < Mp; b += 64) cc[(size_t)i * Mp + b] = (ok && b < M) ? p.codes[(int64_t)nd * M + b] : (uint8_t)0;
+        }
     }
     gs_barrier();
     if (p.vsf == 2)
@@ -282,7 +314,7 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
         if (lane == (i & 63)) mine |= 1ull << (i >> 6);
         if (lane == 0) {
             sidx[nSlots] = i;
-            snode[nSlots] = nodes[i];
+            snode[nSlots] = cid[i];
             if (p.vsf == 2) snorm[nSlots] = cnorm[i];
         }
         for (int b = lane; b < Mp / 4; b += 64) st[(size_t)b * 64 + nSlots] = reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp)[b];
@@ -300,8 +332,8 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
         for (int i = diverseBefore; i < n && nSelected < maxDegree; ++i) {
             const unsigned long long owner_bits = (unsigned long long)gs_shfl((long long)mine, i & 63);
             if ((owner_bits >> (i >> 6)) & 1ull) continue;
-            const int32_t cNode = nodes[i];
-            const float cScore = scores[i];
+            const int32_t cNode = cid[i];
+            const float cScore = csc[i];
             // ---- isDiverse.  Events of the reference's walk over the selected set (ascending candidate index): the candidate itself
             //      -> diverse, a violation -> not diverse; the first event decides.  Lane j owns selected slot j.
             auto stage = [&]() {   // TF: the candidate's sub-vectors, decoded into LDS for this test

@@ -58,6 +58,7 @@ static int rd_emu_run_any(const float *tri, const float *codebooks, const uint8_
 {
     jv::RdParams p{};
     p.codebooks = codebooks;
+    p.wide_stage = getenv("RD_EMU_WIDE") ? atoi(getenv("RD_EMU_WIDE")) : 1;
     p.split = getenv("RD_EMU_SPLIT") ? atoi(getenv("RD_EMU_SPLIT")) : 1;   // (idle lanes share a slot's entries; 0 = one lane per slot)
     p.chunk = getenv("RD_EMU_CHUNK") ? atoi(getenv("RD_EMU_CHUNK")) : 8;   // (incremental tests; 0 = every test examines every slot)
     p.tri = tri; p.codes = codes; p.n = n; p.cand_nodes = cand_nodes; p.cand_scores = cand_scores; p.cand_count = cand_count;

@@ -103,6 +103,7 @@ def test_retain_diverse_emulated(emu, monkeypatch, seed, N, D, M, P, Cn, max_deg
     # chunk: the incremental walk of a test over the selected slots (0: every test examines every slot — the rounds 2-3 form;
     # 1: the reference's own slot-by-slot walk; 64: no chunking, only the memory of earlier tests)
     monkeypatch.setenv("RD_EMU_CHUNK", str(chunk))
+    monkeypatch.setenv("RD_EMU_WIDE", str(1 - (seed + chunk) % 2 if split else 1))   # row-by-row staging in some of the runs
     monkeypatch.setenv("RD_EMU_SPLIT", str(split))   # idle lanes share a slot's entries (chunk 0 / duplicate-node tests; M % 16 == 0)
     monkeypatch.setenv("EMU_LANE_ORDER", ["", "reverse", "random:3"][seed % 3])
     for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
