@@ -96,7 +96,17 @@ JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
  *                    growth pool and the retry passes off unless gs_grow / gs_retry = 1 ask for them
  *   gs_v1_log2       log2(slots) of the visited set's LDS tier; 0 = off, unset = the largest that keeps 8 waves per CU
  *   gs_grow, gs_retry, gs_tie_check, gs_push_log, gs_push_log_cap, gs_occ, gs_pair, gs_cand_cap, gs_waves_per_cu
- *                    device-traversal internals (DESIGN.md §8)
+ *                    device-traversal internals (DESIGN.md §4)
+ *   gs_wgx           the WORKGROUP form of the traversal (one query per workgroup, ADC table in LDS): unset = batches of up to 4
+ *                    queries per CU, 1 / 0 = always / never; gs_wgx_waves, gs_wgx_slots, gs_wgx_depth, gs_wgx_per_cu, gs_wgx_lut_m tune it
+ *   gs_pairc         0 = rows of 33 ... 64 neighbours (the builder's working rows) are scored one lane per neighbour instead of
+ *                    pair lanes over the compacted fresh list
+ *   gs_lutr, gs_ub8, gs_ub8_per_cu, gs_quad   measured-and-lost forms of the one-wave kernel, off by default:
+ *                    register-resident table, 8-bit upper-bound table, four lanes per neighbour in short expansions
+ *   rd_split, rd_wide_stage (default 1), rd_chunk, rd_table_free (default 0)   forms of the robust-prune kernel;
+ *                    selections are identical for every setting
+ *   bl_insert_alpha_x100, bl_improve_beam   jv_hip_build_layered experiments: another alpha (x 100) for the insert phase, another
+ *                    beam for the improveConnections passes
  *   gs_prof, graph_timing   1 = developer diagnostics on stderr
  *   no_filter        1 = jv_hip_search_flat materialises all scores instead of threshold-filtering them
  *   quiet            1 = no one-line notices on stderr (e.g. when AUTO traversal takes the host searcher)
@@ -104,7 +114,8 @@ JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
  *   gs_calls_device, gs_calls_host, gs_calls_host_auto (AUTO fell back to the host searcher: the shape is outside the device
  *   traversal's coverage), gs_queries_device, gs_queries_retried (re-run on the device with a bigger visited table),
  *   gs_queries_host_fallback (finished by the host searcher after the device passes), gs_ties_resolved_device,
- *   gs_ties_to_host, gs_last_v1_log2, gs_last_workers_per_cu. */
+ *   gs_ties_to_host, gs_last_v1_log2, gs_last_workers_per_cu, gs_calls_wgx, gs_last_wgx (1: the last search ran in the workgroup
+ *   form), gs_last_pair (1: pair lanes over the row, 2: over the compacted fresh list, 0: one lane per neighbour). */
 JV_API int jv_hip_ctx_set_option(jv_ctx *ctx, const char *name, int64_t value);
 JV_API int jv_hip_ctx_clear_option(jv_ctx *ctx, const char *name);
 JV_API int jv_hip_ctx_get_stat(jv_ctx *ctx, const char *name, int64_t *out);
