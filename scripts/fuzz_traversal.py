@@ -38,8 +38,8 @@ t_end = time.time() + budget
 cases = searches = 0
 knobs = ("JVECTOR_HIP_GS_VCAP_LOG2", "JVECTOR_HIP_GS_GROW", "JVECTOR_HIP_GS_RETRY", "JVECTOR_HIP_GS_CAND_CAP", "JVECTOR_HIP_GS_PUSH_LOG_CAP",
          "JVECTOR_HIP_GS_GENERIC", "JVECTOR_HIP_GS_WGX", "JVECTOR_HIP_GS_WGX_WAVES", "JVECTOR_HIP_GS_WGX_SLOTS", "JVECTOR_HIP_GS_WGX_DEPTH",
-         "JVECTOR_HIP_GS_WGX_LUT_M", "JVECTOR_HIP_GS_WGX_PER_CU")
-wgx_searches = 0
+         "JVECTOR_HIP_GS_WGX_LUT_M", "JVECTOR_HIP_GS_WGX_PER_CU", "JVECTOR_HIP_GS_PAIRC", "JVECTOR_HIP_GS_QUAD")
+wgx_searches = pairc_searches = 0
 while time.time() < t_end:
     D = int(rng.choice([128, 256, 384, 512, 768] if not MOCK else [128, 256]))
     M = D // 8
@@ -129,6 +129,12 @@ while time.time() < t_end:
                 env["JVECTOR_HIP_GS_WGX_PER_CU"] = str(int(rng.integers(1, 4)))
         elif traversal == "device" and r < 0.5:
             env["JVECTOR_HIP_GS_WGX"] = "0"
+        elif traversal == "device" and r < 0.85:
+            # round 4, the one-wave kernels' lane assignments: the compacted pair form (rows of 33 ... 64 neighbours, codes by ordinal)
+            # on / off, four lanes per neighbour in the pair kernels' short expansions on / off
+            env["JVECTOR_HIP_GS_WGX"] = "0"
+            env["JVECTOR_HIP_GS_PAIRC"] = str(int(rng.integers(0, 2)))
+            env["JVECTOR_HIP_GS_QUAD"] = str(int(rng.integers(0, 2)))
         for k in knobs:
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -149,8 +155,9 @@ while time.time() < t_end:
             sys.exit(1)
         searches += 1
         wgx_searches += ctx.stat("gs_last_wgx") if traversal == "device" else 0
+        pairc_searches += int(traversal == "device" and ctx.stat("gs_last_wgx") == 0 and ctx.stat("gs_last_pair") == 2)
         graph.close()
     cases += 1
 for k in knobs:
     os.environ.pop(k, None)
-print(f"fuzz: {cases} random problems, {searches} searches ({wgx_searches} through the workgroup form), all bit-identical to the oracle (seed {seed}, {budget:.0f} s)")
+print(f"fuzz: {cases} random problems, {searches} searches ({wgx_searches} through the workgroup form, {pairc_searches} through the compacted pair form), all bit-identical to the oracle (seed {seed}, {budget:.0f} s)")
