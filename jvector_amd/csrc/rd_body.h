@@ -246,9 +246,27 @@ GS_FN int rd_wave_min(int v)
 
 // lds: rd_lds_bytes(C, M, TF) bytes, 16-byte aligned.  TF: the table-free form (p.codebooks; the cosine self magnitudes still come
 // from the table's diagonal: M x k entries, L2-resident)
-template <bool TF = false>
+// PROF (developer aid, rd_prof = 1): shader-clock totals per phase, added to p.prof at the end of every node —
+//   [0] staging of ids / scores / code rows   [1] self magnitudes + init   [2] pre-selected prefix   [3] a test's sums (table
+//   entries + ordered sum)   [4] a test's decision (wave minimum / ballot)   [5] take()   [6] loop bookkeeping   [7] output
+//   [8] tests   [9] selected slots examined by them   [10] nodes   [11] candidates   [12] tests that ran split over idle lanes
+#ifndef GS_CLOCK
+#define GS_CLOCK() 0ull   // (the CPU lane emulator has no clock)
+#endif
+template <bool TF = false, bool PROF = false>
 GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
 {
+    unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pt = 0;
+    if (PROF) pt = GS_CLOCK();
+#define RD_PHASE(k)                                   \
+    do {                                              \
+        if (PROF) {                                   \
+            const unsigned long long now_ = GS_CLOCK(); \
+            pf[k] += now_ - pt;                       \
+            pt = now_;                                \
+        }                                             \
+    } while (0)
     const int lane = gs_lane();
     const int M = p.M, C = p.C;
     uint8_t *cc = reinterpret_cast<uint8_t *>(lds);               // [C][M] candidate codes
@@ -286,9 +304,13 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
         for (int w = lane; w < items; w += 64) {
             const int i = w / cpr, c = w - i * cpr;
             const int32_t nd = cid[i];
-            rd_u4 v = {0u, 0u, 0u, 0u};
-            if (nd >= 0 && nd < p.n) v = *reinterpret_cast<const rd_u4 *>(p.codes + (int64_t)nd * M + 16 * c);
-            *reinterpret_cast<rd_u4 *>(cc + (size_t)i * Mp + 16 * c) = v;
+            const bool ok = nd >= 0 && nd < p.n;   // (an id outside the store reads row 0 and is zeroed: no struct temporary — it went to scratch)
+            const rd_u4 v = *reinterpret_cast<const rd_u4 *>(p.codes + (ok ? (int64_t)nd : 0) * M + 16 * c);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(cc + (size_t)i * Mp + 16 * c);
+            dst[0] = ok ? v.x : 0u;
+            dst[1] = ok ? v.y : 0u;
+            dst[2] = ok ? v.z : 0u;
+            dst[3] = ok ? v.w : 0u;
         }
     } else {
         for (int i = 0; i < n; ++i) {
@@ -298,6 +320,7 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
         }
     }
     gs_barrier();
+    RD_PHASE(0);
     if (p.vsf == 2)
         for (int i = lane; i < n; i += 64) cnorm[i] = rd_self_sum(p.tri, M, p.k, cc + (size_t)i * Mp);
     for (int i = lane; i < n; i += 64) {
@@ -305,6 +328,7 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
         best[i] = -__builtin_inff();
     }
     gs_barrier();
+    RD_PHASE(1);
 
     // selected BitSet as two 64-bit words per 128 candidates would not cover C up to 1024: keep it as one bit per lane-chunk:
     // lane l holds the bits of candidates l, l + 64, l + 128, ... in `mine`
@@ -325,6 +349,7 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
         const int pre = diverseBefore < maxDegree ? diverseBefore : maxDegree;
         for (int i = 0; i < pre && i < n; ++i) take(i);
     }
+    RD_PHASE(2);
     int nSelected = diverseBefore;
     float shortEdges = __builtin_nanf("");
     float currentAlpha = 1.0f;
@@ -334,6 +359,11 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
             if ((owner_bits >> (i >> 6)) & 1ull) continue;
             const int32_t cNode = cid[i];
             const float cScore = csc[i];
+            RD_PHASE(6);
+            if (PROF) {
+                pf[8] += 1;
+                pf[9] += (unsigned long long)nSlots;
+            }
             // ---- isDiverse.  Events of the reference's walk over the selected set (ascending candidate index): the candidate itself
             //      -> diverse, a violation -> not diverse; the first event decides.  Lane j owns selected slot j.
             auto stage = [&]() {   // TF: the candidate's sub-vectors, decoded into LDS for this test
@@ -373,16 +403,25 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
                 float split_sum = 0.0f;
                 if (parts > 1)   // every lane takes part; lanes < nSlots end up with their slot's sum
                     split_sum = rd_pair_sum_split(p.tri, M, p.k, reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp), st, lane, nSlots, parts);
+                float simv = 0.0f;
+                const bool have = lane < nSlots && snode[lane] != cNode;
+                if (have) simv = parts > 1 ? sim_from(split_sum) : sim_of();
+                if (PROF) {   // the similarities must have arrived before the phase is closed
+                    if (gs_ballot(have && simv == 123456.7890625f) == 0xdeadbeefdeadbeefull) pf[12] += 1000000;
+                    if (parts > 1) pf[12] += 1;
+                }
+                RD_PHASE(3);
                 if (lane < nSlots) {
-                    if (snode[lane] == cNode) {
+                    if (!have) {
                         ev_idx = sidx[lane];
-                    } else if ((parts > 1 ? sim_from(split_sum) : sim_of()) > cScore * currentAlpha) {
+                    } else if (simv > cScore * currentAlpha) {
                         ev_idx = sidx[lane];
                         ev_fail = true;
                     }
                 }
                 const int first = rd_wave_min(ev_idx);
                 not_diverse = gs_ballot(ev_fail && ev_idx == first && first != 0x7fffffff) != 0;
+                RD_PHASE(4);
             } else {
                 // No selected slot holds the candidate's node: it is diverse iff NO selected slot violates, whatever the order.  Slots
                 // are only ever appended and a similarity does not depend on alpha, so what earlier tests of this candidate saw is
@@ -416,11 +455,13 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
                 }
                 gs_barrier();
                 not_diverse = viol;
+                RD_PHASE(3);
             }
             if (!not_diverse) {
                 if (nSlots < 64) take(i);
                 nSelected++;
             }
+            RD_PHASE(5);
         }
         if (currentAlpha == 1.0f) shortEdges = nSelected / (float)maxDegree;
         currentAlpha += 0.2f;
@@ -444,6 +485,14 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
         if (p.short_edges_out) p.short_edges_out[node_idx] = shortEdges;
     }
     gs_barrier();
+    RD_PHASE(7);
+    if (PROF) {
+        pf[10] = 1;
+        pf[11] = (unsigned long long)n;
+        if (lane == 0 && p.prof)
+            for (int k = 0; k < 13; ++k) gs_fetch_add64(p.prof + k, pf[k]);
+    }
+#undef RD_PHASE
 }
 
 }  // namespace jv

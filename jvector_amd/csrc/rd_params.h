@@ -25,6 +25,7 @@ struct RdParams {
                                // time, and stops at the first violation.  0: every test examines every selected slot.
     int32_t *selected_out;     // [P][maxDegree] selected candidate INDICES in ascending order, -1 padded
     int32_t *n_selected_out;   // [P]
+    unsigned long long *prof;  // rd_node<.., PROF = true>: 16 counters (rd_body.h RD_PHASE), else nullptr
     float *short_edges_out;    // [P] or nullptr: nSelected after the alpha = 1.0 pass / maxDegree (NaN if the loop never ran)
 };
 

@@ -13,6 +13,7 @@ static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
 static inline int32_t gs_shfl32(int32_t v, int src) { return (int32_t)emu::shfl((long long)v, src); }
+static inline void gs_fetch_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
 
 #include "../../jvector_amd/csrc/rd_body.h"
