@@ -55,6 +55,7 @@ int jv_hip_pair_table_destroy(jv_pair_table *t)
     if (!t) return JV_OK;
     (void)hipSetDevice(t->device);
     (void)hipFree(t->d_tri);
+    if (t->d_sq) (void)hipFree(t->d_sq);
     delete t;
     return JV_OK;
 }
@@ -89,6 +90,28 @@ namespace jv {
 // four times out of five.  Same selections bit for bit — and SLOWER on the MI355X (profiles/r4_t: headline build prune + backlink
 // 25.7 -> 35.3 s, C5 37.8 -> 64.3 s): two 16-byte gathers per (candidate, selected, subspace) cost more than one 4-byte look-up
 // that goes to the Infinity Cache.  Off by default.
+// rd_square = 1 (an experiment, off by default — not yet measured at scale): the robust prune reads the pair table's SQUARE form
+// (rd_body.h rd_node<.., SQ>; DESIGN.md §7: the kernel is bound by L2 -> L1 line fills, and a test's lanes then share one 1 KB row per
+// subspace).  Built once per table, on first use.
+const float *pair_table_square(jv_ctx *ctx, jv_pair_table *t)
+{
+    if (ctx_opt(ctx, "rd_square", 0) == 0) return nullptr;
+    if (t->d_sq) return t->d_sq;
+    const int M = t->pq->M, k = t->pq->k;
+    if ((int64_t)M * k * k >= (1ll << 31)) return nullptr;
+    float *sq = nullptr;
+    if (hipMalloc((void **)&sq, sizeof(float) * (size_t)M * k * k) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (launch_pair_table_square(ctx->stream, t->d_tri, M, k, sq) != JV_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipFree(sq);
+        return nullptr;
+    }
+    t->d_sq = sq;
+    return sq;
+}
+
 bool retain_diverse_table_free(const jv_ctx *ctx, const jv_pq *pq)
 {
     return pq->uniform && pq->max_size == 8 && pq->D == 8 * pq->M && pq->k == kClusters && ctx_opt(ctx, "rd_table_free", 0) != 0;
@@ -130,6 +153,7 @@ int jv_hip_retain_diverse(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *c
     char *base = (char *)ctx->d_out.ptr;
     RdParams p{};
     p.tri = t->d_tri;
+    p.sq = pair_table_square(ctx, const_cast<jv_pair_table *>(t));
     p.codebooks = retain_diverse_table_free(ctx, t->pq) ? t->pq->d_codebooks : nullptr;
     p.codes = codes->d_codes;
     p.n = codes->count;

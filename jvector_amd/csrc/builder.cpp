@@ -73,6 +73,7 @@ int run_retain(jv_ctx *ctx, jv_builder *b, const int32_t *d_cand, const float *d
 {
     RdParams p{};
     p.tri = b->tri->d_tri;
+    p.sq = pair_table_square(ctx, b->tri);
     p.codebooks = retain_diverse_table_free(ctx, b->pq) ? b->pq->d_codebooks : nullptr;
     p.codes = b->codes->d_codes;
     p.n = b->codes->count;

@@ -206,6 +206,7 @@ struct jv_pair_table {   // ProductQuantization.createCodebookPartialSums on the
     jv_vsf vsf = JV_EUCLIDEAN;
     float *d_tri = nullptr;
     int64_t floats = 0;
+    float *d_sq = nullptr;   // the same entries as [M][k][k] (rd_square = 1; built on first use by pair_table_square)
 };
 
 struct jv_fused {
@@ -347,6 +348,8 @@ int launch_km_aniso_round(hipStream_t s, const KmParams &p);
 int launch_km_reactivate(hipStream_t s, const KmParams &p);
 // build-time scoring (k_build_score.hip)
 int launch_pair_table(hipStream_t s, const jv_pq *pq, int vsf, float *d_out);
+int launch_pair_table_square(hipStream_t s, const float *d_tri, int M, int k, float *d_sq);
+const float *pair_table_square(jv_ctx *ctx, jv_pair_table *t);   // nullptr (and the error set) when it cannot be built
 struct RdParams;
 int launch_retain_diverse(hipStream_t s, const jv_ctx *ctx, const RdParams &p);
 size_t retain_diverse_lds_bytes(int C, int M);

@@ -65,6 +65,23 @@ int launch_pair_table(hipStream_t s, const jv_pq *pq, int vsf, float *d_out)
     return JV_OK;
 }
 
+// the triangular table expanded to [M][k][k]: entry (m, i, j) = the triangle's (m, min, max) — a copy, bit for bit
+__global__ __launch_bounds__(256) void pair_table_square_kernel(const float *tri, int M, int k, float *sq)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)M * k * k) return;
+    const int j = (int)(t % k), i = (int)((t / k) % k), m = (int)(t / ((int64_t)k * k));
+    const int r = i < j ? i : j, c = i < j ? j : i;
+    sq[t] = tri[(int64_t)m * ((int64_t)k * (k + 1) / 2) + bs_tri_row(r, k) + (c - r)];
+}
+
+int launch_pair_table_square(hipStream_t s, const float *d_tri, int M, int k, float *d_sq)
+{
+    hipLaunchKernelGGL(pair_table_square_kernel, flat_grid((int64_t)M * k * k), dim3(256), 0, s, d_tri, M, k, d_sq);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
 int launch_pair_scores(hipStream_t s, const float *d_tri, int vsf, const jv_codes *codes, const int32_t *d_node1, int P,
                        const int32_t *d_node2, int B, float *d_out)
 {

@@ -26,6 +26,18 @@ __global__ __launch_bounds__(64) void retain_diverse_tf_kernel(RdParams p)
     for (int node = (int)blockIdx.x; node < p.P; node += (int)gridDim.x) rd_node<true>(p, node, rd_lds);
 }
 
+// the square form of the table (RdParams::sq; rd_square = 1: an experiment)
+__global__ __launch_bounds__(64) void retain_diverse_sq_kernel(RdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char rd_lds[];
+    for (int node = (int)blockIdx.x; node < p.P; node += (int)gridDim.x) rd_node<false, false, true>(p, node, rd_lds);
+}
+__global__ __launch_bounds__(64) void retain_diverse_sq_prof_kernel(RdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char rd_lds[];
+    for (int node = (int)blockIdx.x; node < p.P; node += (int)gridDim.x) rd_node<false, true, true>(p, node, rd_lds);
+}
+
 // developer aid (rd_prof = 1): the table kernel with per-phase shader-clock counters (rd_body.h RD_PHASE), printed after every launch
 __global__ __launch_bounds__(64) void retain_diverse_prof_kernel(RdParams p)
 {
@@ -45,7 +57,8 @@ int launch_retain_diverse(hipStream_t s, const jv_ctx *ctx, const RdParams &p)
                   p.M, lds, ctx->lds_per_block);
         return JV_ERR_UNSUPPORTED;
     }
-    const void *kfn = tf ? (const void *)retain_diverse_tf_kernel : (const void *)retain_diverse_kernel;
+    const bool sqf = !tf && p.sq != nullptr;
+    const void *kfn = tf ? (const void *)retain_diverse_tf_kernel : (sqf ? (const void *)retain_diverse_sq_kernel : (const void *)retain_diverse_kernel);
     if (lds > 48 * 1024) JV_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 256)));
     const int blocks = std::min(p.P, ctx->num_cus * per_cu);
@@ -55,22 +68,24 @@ int launch_retain_diverse(hipStream_t s, const jv_ctx *ctx, const RdParams &p)
         JV_HIP_CHECK(hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 16, s));
         RdParams pp = p;
         pp.prof = d_prof;
-        if (lds > 48 * 1024)
-            JV_HIP_CHECK(hipFuncSetAttribute((const void *)retain_diverse_prof_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(retain_diverse_prof_kernel, dim3(blocks), dim3(64), lds, s, pp);
+        const void *pk = p.sq ? (const void *)retain_diverse_sq_prof_kernel : (const void *)retain_diverse_prof_kernel;
+        if (lds > 48 * 1024) JV_HIP_CHECK(hipFuncSetAttribute(pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (p.sq) hipLaunchKernelGGL(retain_diverse_sq_prof_kernel, dim3(blocks), dim3(64), lds, s, pp);
+        else hipLaunchKernelGGL(retain_diverse_prof_kernel, dim3(blocks), dim3(64), lds, s, pp);
         JV_HIP_CHECK(hipGetLastError());
         unsigned long long h[16];
         JV_HIP_CHECK(hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, s));
         JV_HIP_CHECK(hipStreamSynchronize(s));
         const double nodes = (double)std::max<unsigned long long>(1, h[10]), tests = (double)std::max<unsigned long long>(1, h[8]);
         fprintf(stderr,
-                "[jv rd prof] P=%d C=%d M=%d blocks=%d (x%d/CU): clocks per node: stage %.0f  self+init %.0f  prefix %.0f  output %.0f | per test: sums %.0f  decision %.0f  take %.0f  "
+                "[jv rd prof%s] P=%d C=%d M=%d blocks=%d (x%d/CU): clocks per node: stage %.0f  self+init %.0f  prefix %.0f  output %.0f | per test: sums %.0f  decision %.0f  take %.0f  "
                 "loop %.0f | tests/node %.1f  slots/test %.1f  candidates/node %.1f  split tests %.2f\n",
-                p.P, p.C, p.M, blocks, per_cu, h[0] / nodes, h[1] / nodes, h[2] / nodes, h[7] / nodes, h[3] / tests, h[4] / tests, h[5] / tests, h[6] / tests, tests / nodes,
+                p.sq ? " square" : "", p.P, p.C, p.M, blocks, per_cu, h[0] / nodes, h[1] / nodes, h[2] / nodes, h[7] / nodes, h[3] / tests, h[4] / tests, h[5] / tests, h[6] / tests, tests / nodes,
                 h[9] / tests, h[11] / nodes, (double)(h[12] % 1000000) / tests);
         return JV_OK;
     }
     if (tf) hipLaunchKernelGGL(retain_diverse_tf_kernel, dim3(blocks), dim3(64), lds, s, p);
+    else if (sqf) hipLaunchKernelGGL(retain_diverse_sq_kernel, dim3(blocks), dim3(64), lds, s, p);
     else hipLaunchKernelGGL(retain_diverse_kernel, dim3(blocks), dim3(64), lds, s, p);
     JV_HIP_CHECK(hipGetLastError());
     return JV_OK;

@@ -34,7 +34,15 @@ GS_FN uint32_t rd_tri_index(uint32_t m_base, uint32_t k, uint32_t c1, uint32_t c
     const uint32_t r = c1 < c2 ? c1 : c2, c = c1 < c2 ? c2 : c1;
     return m_base + r * k - ((r * (r - 1u)) >> 1) + (c - r);   // (r = 0: 0 * 0xFFFFFFFF = 0)
 }
+// SQ: the square table [M][k][k], row = the candidate's code (wave-uniform inside a test), column = the slot's (M k k < 2^31)
+template <bool SQ>
+GS_FN uint32_t rd_index(uint32_t m, uint32_t block, uint32_t k, uint32_t c1, uint32_t c2)
+{
+    if (SQ) return (m * k + c1) * k + c2;
+    return rd_tri_index(m * block, k, c1, c2);
+}
 
+template <bool SQ = false>
 GS_FN float rd_pair_sum(const float *tri, int M, int k, const uint32_t *crow4, const uint32_t *scol4 /* stride 64 words */)
 {
     const uint32_t block = (uint32_t)k * ((uint32_t)k + 1u) / 2u;
@@ -51,14 +59,14 @@ GS_FN float rd_pair_sum(const float *tri, int M, int k, const uint32_t *crow4, c
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const uint32_t c1 = (cw[j >> 2] >> (8 * (j & 3))) & 0xFFu, c2 = (sw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            e[j] = tri[rd_tri_index((uint32_t)(m + j) * block, (uint32_t)k, c1, c2)];
+            e[j] = tri[rd_index<SQ>((uint32_t)(m + j), block, (uint32_t)k, c1, c2)];
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) res += e[j];
     }
     for (; m < M; ++m) {
         const uint32_t c1 = (crow4[m >> 2] >> (8 * (m & 3))) & 0xFFu, c2 = (scol4[(size_t)(m >> 2) * 64] >> (8 * (m & 3))) & 0xFFu;
-        res += tri[rd_tri_index((uint32_t)m * block, (uint32_t)k, c1, c2)];
+        res += tri[rd_index<SQ>((uint32_t)m, block, (uint32_t)k, c1, c2)];
     }
     return res;
 }
@@ -78,6 +86,7 @@ GS_FN int rd_split_parts(int M, int nSlots)
     return 1;
 }
 
+template <bool SQ = false>
 GS_FN float rd_pair_sum_split(const float *tri, int M, int k, const uint32_t *crow4, const uint32_t *st4, int lane, int nSlots, int parts)
 {
     const int S = 64 / parts;
@@ -102,7 +111,7 @@ GS_FN float rd_pair_sum_split(const float *tri, int M, int k, const uint32_t *cr
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const uint32_t c1 = (cw[j >> 2] >> (8 * (j & 3))) & 0xFFu, c2 = (sw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                e[b][j] = tri[rd_tri_index((uint32_t)(m + j) * block, (uint32_t)k, c1, c2)];
+                e[b][j] = tri[rd_index<SQ>((uint32_t)(m + j), block, (uint32_t)k, c1, c2)];
             }
         }
     }
@@ -199,6 +208,7 @@ GS_FN float rd_pair_sum_tf(const float *cb, int M, int k, const float *cvec, con
     return res;
 }
 
+template <bool SQ = false>
 GS_FN float rd_self_sum(const float *tri, int M, int k, const uint8_t *crow)
 {
     const uint32_t block = (uint32_t)k * ((uint32_t)k + 1u) / 2u;
@@ -209,14 +219,14 @@ GS_FN float rd_self_sum(const float *tri, int M, int k, const uint8_t *crow)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const uint32_t c = crow[m + j];
-            e[j] = tri[rd_tri_index((uint32_t)(m + j) * block, (uint32_t)k, c, c)];
+            e[j] = tri[rd_index<SQ>((uint32_t)(m + j), block, (uint32_t)k, c, c)];
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) res += e[j];
     }
     for (; m < M; ++m) {
         const uint32_t c = crow[m];
-        res += tri[rd_tri_index((uint32_t)m * block, (uint32_t)k, c, c)];
+        res += tri[rd_index<SQ>((uint32_t)m, block, (uint32_t)k, c, c)];
     }
     return res;
 }
@@ -253,9 +263,10 @@ GS_FN int rd_wave_min(int v)
 #ifndef GS_CLOCK
 #define GS_CLOCK() 0ull   // (the CPU lane emulator has no clock)
 #endif
-template <bool TF = false, bool PROF = false>
+template <bool TF = false, bool PROF = false, bool SQ = false>
 GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
 {
+    const float *table = SQ ? p.sq : p.tri;   // (SQ: the square form of the same entries)
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long pt = 0;
     if (PROF) pt = GS_CLOCK();
@@ -322,7 +333,7 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
     gs_barrier();
     RD_PHASE(0);
     if (p.vsf == 2)
-        for (int i = lane; i < n; i += 64) cnorm[i] = rd_self_sum(p.tri, M, p.k, cc + (size_t)i * Mp);
+        for (int i = lane; i < n; i += 64) cnorm[i] = rd_self_sum<SQ>(table, M, p.k, cc + (size_t)i * Mp);
     for (int i = lane; i < n; i += 64) {
         tested[i] = 0;
         best[i] = -__builtin_inff();
@@ -387,7 +398,7 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
                 float sum;
                 if constexpr (TF) sum = p.vsf == 0 ? rd_pair_sum_tf<true>(p.codebooks, M, p.k, cvec, st + lane)
                                                    : rd_pair_sum_tf<false>(p.codebooks, M, p.k, cvec, st + lane);
-                else sum = rd_pair_sum(p.tri, M, p.k, reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp), st + lane);
+                else sum = rd_pair_sum<SQ>(table, M, p.k, reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp), st + lane);
                 return sim_from(sum);
             };
             bool not_diverse;
@@ -402,7 +413,7 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
                 if constexpr (!TF) parts = p.split ? rd_split_parts(M, nSlots) : 1;
                 float split_sum = 0.0f;
                 if (parts > 1)   // every lane takes part; lanes < nSlots end up with their slot's sum
-                    split_sum = rd_pair_sum_split(p.tri, M, p.k, reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp), st, lane, nSlots, parts);
+                    split_sum = rd_pair_sum_split<SQ>(table, M, p.k, reinterpret_cast<const uint32_t *>(cc + (size_t)i * Mp), st, lane, nSlots, parts);
                 float simv = 0.0f;
                 const bool have = lane < nSlots && snode[lane] != cNode;
                 if (have) simv = parts > 1 ? sim_from(split_sum) : sim_of();

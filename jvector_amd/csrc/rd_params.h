@@ -9,6 +9,8 @@ namespace jv {
 
 struct RdParams {
     const float *tri;          // pair table: M x k(k+1)/2 floats
+    const float *sq;           // the same entries as a SQUARE table [M][k][k] (rd_node<.., SQ = true>: a test's lanes read ONE row per
+                               // subspace — the candidate's code picks it — instead of up to one cache line each), else nullptr
     const float *codebooks;    // table-free form (rd_node<true>): [M][k][8] centroids (uniform 8-dimensional sub-vectors), else nullptr
     const uint8_t *codes;      // [n][M]
     int64_t n;

@@ -28,6 +28,7 @@ void node_main(void *a)
 {
     const Launch &L = *(const Launch *)a;
     if (L.p->codebooks) jv::rd_node<true>(*L.p, L.node, L.lds);
+    else if (L.p->sq) jv::rd_node<false, false, true>(*L.p, L.node, L.lds);
     else jv::rd_node<false>(*L.p, L.node, L.lds);
 }
 }  // namespace
@@ -65,6 +66,18 @@ static int rd_emu_run_any(const float *tri, const float *codebooks, const uint8_
     p.tri = tri; p.codes = codes; p.n = n; p.cand_nodes = cand_nodes; p.cand_scores = cand_scores; p.cand_count = cand_count;
     p.diverse_before = diverse_before; p.P = P; p.C = C; p.M = M; p.k = k; p.vsf = vsf; p.maxDegree = maxDegree; p.alpha = alpha;
     p.selected_out = selected_out; p.n_selected_out = n_selected_out; p.short_edges_out = short_edges_out;
+    float *sq = nullptr;
+    if (getenv("RD_EMU_SQUARE") && atoi(getenv("RD_EMU_SQUARE")) && !codebooks) {   // the square form of the same table
+        sq = (float *)malloc(sizeof(float) * (size_t)M * k * k);
+        const int64_t block = (int64_t)k * (k + 1) / 2;
+        for (int m = 0; m < M; ++m)
+            for (int i = 0; i < k; ++i)
+                for (int j = 0; j < k; ++j) {
+                    const int r = i < j ? i : j, c = i < j ? j : i;
+                    sq[((size_t)m * k + i) * k + j] = tri[m * block + jv::rd_tri_row(r, k) + (c - r)];
+                }
+        p.sq = sq;
+    }
     const size_t lds_bytes = jv::rd_lds_bytes(C, M, codebooks != nullptr);
     char *lds = (char *)aligned_alloc(64, (lds_bytes + 63) & ~(size_t)63);
     for (int node = 0; node < P; ++node) {
@@ -73,5 +86,6 @@ static int rd_emu_run_any(const float *tri, const float *codebooks, const uint8_
         emu::run_wave(node_main, &L);
     }
     free(lds);
+    free(sq);
     return 0;
 }

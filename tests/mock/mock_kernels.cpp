@@ -219,6 +219,7 @@ void rd_main(void *a)
 {
     const RdLaunch &L = *(const RdLaunch *)a;
     if (L.p->codebooks) rd_node<true>(*L.p, L.node, L.lds);
+    else if (L.p->sq) rd_node<false, false, true>(*L.p, L.node, L.lds);
     else rd_node<false>(*L.p, L.node, L.lds);
 }
 }  // namespace
@@ -494,6 +495,17 @@ int launch_pair_table(hipStream_t, const jv_pq *pq, int vsf, float *d_out)
 {
     const BsPq b = bs_pq_of(pq);
     for (int64_t t = 0; t < (int64_t)pq->M * pq->k; ++t) bs_pair_table_row(b, vsf, t, d_out);
+    return JV_OK;
+}
+int launch_pair_table_square(hipStream_t, const float *d_tri, int M, int k, float *d_sq)
+{
+    const int64_t block = (int64_t)k * (k + 1) / 2;
+    for (int m = 0; m < M; ++m)
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) {
+                const int r = i < j ? i : j, c = i < j ? j : i;
+                d_sq[((size_t)m * k + i) * k + j] = d_tri[m * block + bs_tri_row(r, k) + (c - r)];
+            }
     return JV_OK;
 }
 int launch_pair_scores(hipStream_t, const float *d_tri, int vsf, const jv_codes *codes, const int32_t *d_node1, int P, const int32_t *d_node2,

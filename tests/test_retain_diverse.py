@@ -95,7 +95,8 @@ def emu():
     return L
 
 
-@pytest.mark.parametrize("table_free,chunk,split", [(False, 0, 1), (False, 0, 0), (False, 8, 1), (True, 8, 1), (False, 1, 0), (False, 3, 1), (True, 64, 0)])
+@pytest.mark.parametrize("table_free,chunk,split", [(False, 0, 1), (False, 0, 0), (False, 8, 1), (True, 8, 1), (False, 1, 0), (False, 3, 1), (True, 64, 0),
+                                                    (False, 0, "square"), (False, 8, "square")])
 @pytest.mark.parametrize("seed,N,D,M,P,Cn,max_degree,alpha", CASES)
 def test_retain_diverse_emulated(emu, monkeypatch, seed, N, D, M, P, Cn, max_degree, alpha, table_free, chunk, split):
     """table_free: rd_node<true> — the pair-table entries recomputed from the codebook (uniform 8-dimensional sub-vectors: every
@@ -103,6 +104,9 @@ def test_retain_diverse_emulated(emu, monkeypatch, seed, N, D, M, P, Cn, max_deg
     # chunk: the incremental walk of a test over the selected slots (0: every test examines every slot — the rounds 2-3 form;
     # 1: the reference's own slot-by-slot walk; 64: no chunking, only the memory of earlier tests)
     monkeypatch.setenv("RD_EMU_CHUNK", str(chunk))
+    # "square": the pair table as [M][k][k] (rd_node<.., SQ>: a test's lanes share one row per subspace), with the split sums on
+    monkeypatch.setenv("RD_EMU_SQUARE", "1" if split == "square" else "0")
+    split = 1 if split == "square" else split
     monkeypatch.setenv("RD_EMU_WIDE", str(1 - (seed + chunk) % 2 if split else 1))   # row-by-row staging in some of the runs
     monkeypatch.setenv("RD_EMU_SPLIT", str(split))   # idle lanes share a slot's entries (chunk 0 / duplicate-node tests; M % 16 == 0)
     monkeypatch.setenv("EMU_LANE_ORDER", ["", "reverse", "random:3"][seed % 3])
@@ -154,6 +158,11 @@ def test_retain_diverse_gpu():
         run_through_cabi(J, ctx, CASES[1:2] + CASES[6:] + [(15, 3000, 768, 96, 64, 100, 32, 1.2), (16, 1500, 1536, 192, 32, 100, 32, 1.2)])
     finally:
         ctx.set_option("rd_split", None)
+    ctx.set_option("rd_square", 1)       # the square form of the pair table (an experiment, off by default)
+    try:
+        run_through_cabi(J, ctx, CASES[1:3] + CASES[6:8] + [(15, 3000, 768, 96, 64, 100, 32, 1.2)])
+    finally:
+        ctx.set_option("rd_square", None)
     ctx.set_option("rd_table_free", 1)   # the table-free form of the kernel (off by default: measured slower): the same selections
     try:
         run_through_cabi(J, ctx, CASES[:2] + [(15, 3000, 768, 96, 64, 100, 32, 1.2), (16, 1500, 1536, 192, 32, 100, 32, 1.2)])
