@@ -601,8 +601,8 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
     g_ms, g_n = prof["gsearch"]
     unit = M + 8
     ach = bstats["visited"] * unit / (g_ms / 1e3) / 1e9 if g_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": f"graph_search_kernel<COSINE,CH16={M // 16}> over the builder's device-resident adjacency (PQDecoder.similarityTo on the "
-                "neighbours' own codes, table-free)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+    roofline = {"bound": "hbm", "kernel": f"graph_search_pairc_kernel<COSINE,CH16={M // 16}> over the builder's device-resident adjacency (64-wide working rows: one lane "
+                f"per neighbour probes the visited set, the fresh ones are scored {2 if M <= 96 else 4} lanes each; PQDecoder.similarityTo on the neighbours' own codes, table-free)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "scored_nodes": bstats["visited"], "expansions": bstats["expanded"], "bytes_per_scored_node": unit, "kernel_ms": g_ms,
                 "launches": g_n, "prune_and_pair_score_kernel_ms": prof["adc"][0],
                 "note": "algorithmic bytes = scored nodes x (M + 8) (SURVEY §8d: ADC gather by ordinal); physically the kernel is bound by the L2 "
