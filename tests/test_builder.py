@@ -166,7 +166,7 @@ def _on_the_mock(fn):
 
 @pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
 def test_builder_on_the_mock():
-    _on_the_mock(lambda J, ctx, register: check_builder(J, ctx, torch.device("cpu"), 700, 128, 16, 16, 24, register=register))
+    _on_the_mock(lambda J, ctx, register: check_builder(J, ctx, torch.device("cpu"), 500, 128, 16, 16, 24, register=register))
 
 
 @pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")

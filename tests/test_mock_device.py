@@ -649,9 +649,9 @@ def test_standalone_canary_against_the_mock_library(J):
         assert line["identical"] is True and line["avg_expanded"] >= 50
 
 
-@pytest.mark.parametrize("mode,traversal,graph,n,extra", [("graph", "host", "synthetic", 3000, []), ("graph", "device", "engine", 2000, []),
+@pytest.mark.parametrize("mode,traversal,graph,n,extra", [("graph", "host", "synthetic", 3000, []), ("graph", "device", "engine", 1200, []),
                                                          ("flat", "host", "synthetic", 6000, []),
-                                                         ("graph", "device", "engine", 2000, ["--reranker", "nvq"])])
+                                                         ("graph", "device", "engine", 1200, ["--reranker", "nvq"])])
 def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, graph, n, extra):
     """bench.py end to end at toy size: torch runs on the CPU (a proxy maps the `cuda` device bench asks for to `cpu` and makes
     the stream / synchronize calls inert) and the engine is the mock device.  Numbers are meaningless; what is checked is the
