@@ -704,6 +704,141 @@ def run_sub_workloads(keys=None):
     return out
 
 
+COMPACT_LIMIT = 4096         # the driver keeps about 10 KB of stdout: the LAST line must fit with room to spare
+
+
+def _r(x, nd=5):
+    """A float rounded to `nd` significant digits (ints and None pass through) — the compact line's number format."""
+    if isinstance(x, bool) or x is None or isinstance(x, int):
+        return x
+    try:
+        x = float(x)
+    except (TypeError, ValueError):
+        return x
+    if x == 0.0 or not math.isfinite(x):
+        return x
+    return float(f"{x:.{nd}g}")
+
+
+def _short(s, n):
+    s = "" if s is None else str(s)
+    return s if len(s) <= n else s[: n - 3] + "..."
+
+
+def _compact_roofline(r, kernel_chars=72):
+    if not isinstance(r, dict):
+        return None
+    out = {"bound": r.get("bound"), "kernel": _short(r.get("kernel"), kernel_chars), "achieved": _r(r.get("achieved")),
+           "peak": _r(r.get("peak")), "unit": r.get("unit"), "frac": _r(r.get("frac"), 4), "traffic": _r(r.get("traffic"), 6),
+           "traffic_source": _short(r.get("traffic_source"), 64) if r.get("traffic_source") else None,
+           "avg_launch_ms": _r(r.get("avg_launch_ms")), "launches": r.get("launches"),
+           "bytes_per_launch": _r(r.get("bytes_per_launch"), 6)}
+    return out
+
+
+def _compact_cpu(c):
+    if not isinstance(c, dict):
+        return None
+    return {"value": _r(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"), "isa": c.get("isa"),
+            "matches_gpu_topk": c.get("matches_gpu_topk"), "sample": _short(c.get("sample"), 96)}
+
+
+def _compact_sub(sub):
+    """ONE short object per sub-run: value, unit, recall, rerankK, the dominant kernel's roofline fraction, the CPU leg."""
+    if not isinstance(sub, dict):
+        return None
+    if "error" in sub:
+        return {"error": _short(sub["error"], 80)}
+    rf = sub.get("roofline") or {}
+    cfg = sub.get("config") or {}
+    out = {"value": _r(sub.get("value")), "unit": sub.get("unit"), "recall": _r(sub.get("recall_at_10"), 4),
+           "rerankK": cfg.get("rerankK"), "roofline_bound": rf.get("bound"), "roofline_frac": _r(rf.get("frac"), 4),
+           "cpu_value": _r((sub.get("cpu_baseline") or {}).get("value"))}
+    for k in ("prune_roofline_frac",):
+        if k in sub:
+            out[k] = _r(sub[k], 4)
+    return out
+
+
+def compact_line(line):
+    """The driver-readable form of a full bench line: every key the contract names, the headline `roofline` and `cpu_baseline`
+    objects with their numbers (strings shortened), one short object per sub-workload under `workloads`, nothing else.  Everything
+    that was cut lives in bench_full.json (path under `full`).  Guaranteed <= COMPACT_LIMIT bytes."""
+    cfg = dict(line.get("config") or {})
+    cfg["workload"] = _short(cfg.get("workload"), 360)
+    out = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = cfg
+    for k in ("recall_at_10", "recall_se"):
+        if k in line:
+            out[k] = _r(line[k], 4)
+    for k in ("recall_ok", "recall_eval_queries"):
+        if k in line:
+            out[k] = line[k]
+    out["roofline"] = _compact_roofline(line.get("roofline"))
+    if "cpu_baseline" in line:      # rank 0 at N = 1 only
+        out["cpu_baseline"] = _compact_cpu(line["cpu_baseline"])
+    for k in ("avg_visited", "avg_expanded", "adc_distances_per_s", "graph_build_s", "kernel_fraction_of_step"):
+        if k in line and line[k] is not None:
+            out[k] = _r(line[k])
+    if isinstance(line.get("per_rank_qps"), list):
+        out["per_rank_qps"] = [_r(x) for x in line["per_rank_qps"]]
+    if isinstance(line.get("rerank"), dict):
+        out["rerank_roofline_frac"] = _r(line["rerank"].get("frac"), 4)
+    if isinstance(line.get("kernel_ms_per_step"), dict):
+        out["kernel_ms_per_step"] = {k: _r(v, 4) for k, v in line["kernel_ms_per_step"].items() if v}
+    wl = {}
+    for key, _argv, _what in SUB_RUNS:
+        if key in line:
+            wl[key] = _compact_sub(line[key])
+    if isinstance(line.get("flat_mode"), dict):
+        wl["flat_mode"] = _compact_sub({**line["flat_mode"], "config": {"rerankK": line["flat_mode"].get("rerankK")}})
+    if wl:
+        out["workloads"] = wl
+    if isinstance(line.get("batch_sweep"), list):
+        out["latency_ms"] = {str(e.get("queries")): _r((e.get("auto") or {}).get("ms_per_batch"), 4) for e in line["batch_sweep"]
+                             if isinstance(e, dict)}
+    out["full"] = line.get("full")
+    text = json.dumps(out, separators=(",", ":"))
+    # belt and braces: should the line still be too long (a very long workload string, many ranks), drop optional parts in turn
+    for drop in ("latency_ms", "kernel_ms_per_step", "per_rank_qps", "workloads"):
+        if len(text) <= COMPACT_LIMIT:
+            break
+        out.pop(drop, None)
+        text = json.dumps(out, separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:
+        out["config"]["workload"] = _short(out["config"]["workload"], 120)
+        text = json.dumps(out, separators=(",", ":"))
+    assert len(text) <= COMPACT_LIMIT, len(text)
+    return text
+
+
+def emit(line, args):
+    """Rank 0's output.  A sub-run (--sub-line) prints its FULL line for the parent process to parse.  Every other run writes the
+    full line to bench_full.json (repo root, and gpurun_out/ when that exists so that it travels back from the GPU box), echoes
+    it on stderr, and prints the compact line as the LAST line of stdout."""
+    if getattr(args, "sub_line", False):
+        print(json.dumps(line), flush=True)
+        return
+    full = json.dumps(line)
+    paths = [os.environ.get("JVECTOR_BENCH_FULL") or os.path.join(ROOT, "bench_full.json")]
+    if not os.environ.get("JVECTOR_BENCH_FULL") and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_full.json"))
+    written = None
+    for path in paths:
+        try:
+            with open(path, "w") as f:
+                f.write(full + "\n")
+            written = written or (os.path.relpath(path, ROOT) if path.startswith(ROOT) else path)
+        except OSError:
+            pass
+    line = dict(line)
+    line["full"] = written
+    log("[full line] " + full)
+    sys.stdout.flush()
+    print(compact_line(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -787,7 +922,7 @@ def main():
     if args.workload in ("c2", "c4", "c5"):
         line = {"c2": run_c2, "c4": run_c4, "c5": run_c5}[args.workload](args, ctx, J, dev, world, rank, barrier, ranks)
         if rank == 0:
-            print(json.dumps(line))
+            emit(line, args)
         ranks.close()
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -1158,7 +1293,7 @@ def main():
             del base, codes_t
             torch.cuda.empty_cache()
             line.update(run_sub_workloads())
-        print(json.dumps(line))
+        emit(line, args)
     ranks.close()
     if world > 1:
         torch.distributed.destroy_process_group()

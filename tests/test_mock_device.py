@@ -652,7 +652,7 @@ def test_standalone_canary_against_the_mock_library(J):
 @pytest.mark.parametrize("mode,traversal,graph,n,extra", [("graph", "host", "synthetic", 3000, []), ("graph", "device", "engine", 1200, []),
                                                          ("flat", "host", "synthetic", 6000, []),
                                                          ("graph", "device", "engine", 1200, ["--reranker", "nvq"])])
-def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, graph, n, extra):
+def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, tmp_path, mode, traversal, graph, n, extra):
     """bench.py end to end at toy size: torch runs on the CPU (a proxy maps the `cuda` device bench asks for to `cpu` and makes
     the stream / synchronize calls inert) and the engine is the mock device.  Numbers are meaningless; what is checked is the
     control flow — index build, rerankK calibration against exact ground truth, the timed loop, the secondary flat
@@ -679,11 +679,20 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, grap
     monkeypatch.setattr(sys, "argv", argv)
     monkeypatch.delenv("RANK", raising=False)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("JVECTOR_BENCH_FULL", str(tmp_path / "bench_full.json"))
     bench.main()
     out = capsys.readouterr().out.strip().splitlines()
-    line = json.loads(out[-1])
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                "dtype", "data", "config", "roofline", "cpu_baseline"):
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline")
+    # the LAST stdout line is the compact, driver-readable one (< 4 KB); the full line is in the file it names
+    assert len(out[-1]) < 4096
+    compact = json.loads(out[-1])
+    for key in contract:
+        assert key in compact, key
+    assert compact["roofline"]["frac"] is not None and compact["cpu_baseline"]["value"] > 0 and "workload" in compact["config"]
+    line = json.load(open(compact["full"]))
+    assert abs(compact["value"] - line["value"]) <= 1e-5 * line["value"] and compact["config"]["rerankK"] == line["config"]["rerankK"]
+    for key in contract:
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["higher_is_better"] is True
     assert line["config"]["mode"] == mode and line["config"]["n_vectors"] == n and "workload" in line["config"]
@@ -707,7 +716,7 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, mode, traversal, grap
 @pytest.mark.parametrize("workload,extra", [("c2", ["--n", "3000", "--queries", "32", "--eval-queries", "64", "--rerank", "100"]),
                                             ("c4", ["--n", "3000", "--dim", "128", "--m", "16", "--queries", "16", "--rerank", "40"]),
                                             ("c5", ["--n", "1500", "--dim", "128", "--m", "16", "--degree", "16", "--eval-queries", "32"])])
-def test_bench_other_workloads_dry_run(J, monkeypatch, capsys, workload, extra):
+def test_bench_other_workloads_dry_run(J, monkeypatch, capsys, tmp_path, workload, extra):
     """the secondary workloads of bench.py (C2 flat SIFT-like, C4 sharded through the C ABI's communicator — here a one-rank
     communicator on the shared-memory RCCL shim —, C5 index build) end to end at toy size on the mock: control flow + JSON contract"""
     import json
@@ -732,10 +741,15 @@ def test_bench_other_workloads_dry_run(J, monkeypatch, capsys, workload, extra):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", workload, "--steps", "2", "--warmup", "1"] + extra)
     monkeypatch.delenv("RANK", raising=False)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("JVECTOR_BENCH_FULL", str(tmp_path / "bench_full.json"))
     bench.main()
-    line = json.loads([x for x in capsys.readouterr().out.strip().splitlines() if x.startswith("{")][-1])
+    last = capsys.readouterr().out.strip().splitlines()[-1]
+    assert len(last) < 4096
+    compact = json.loads(last)
+    line = json.load(open(compact["full"]))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
-        assert key in line, key
+        assert key in line and key in compact, key
+    assert compact["roofline"]["frac"] is not None
     assert line["value"] > 0 and "workload" in line["config"]
     if workload == "c2":
         assert line["roofline"]["bound"] == "lds" and line["cpu_baseline"]["matches_gpu_topk"] is True
