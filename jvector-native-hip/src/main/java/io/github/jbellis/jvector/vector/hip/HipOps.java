@@ -463,7 +463,9 @@ public final class HipOps {
         check(st(() -> (int) H.layeredLevel.invokeExact(ctx, layered, level, nodesOut, neighborsOut)));
     }
     /** the level-0 rows in device memory (for fusedBuild) */
-    public static MemorySegment layeredLevel0Device(MemorySegment layered) { return st(() -> (MemorySegment) H.layeredLevel0Device.invokeExact(layered)); }
+    public static MemorySegment layeredLevel0Device(MemorySegment layered) {
+        try { return (MemorySegment) H.layeredLevel0Device.invokeExact(layered); } catch (Throwable t) { throw new AssertionError(t); }
+    }
     /** seconds4 = {search, prune, backlink, total}; counts5 as builderStats, summed over the levels */
     public static void layeredStats(MemorySegment layered, MemorySegment seconds4, MemorySegment counts5) {
         check(st(() -> (int) H.layeredStats.invokeExact(layered, seconds4, counts5)));
