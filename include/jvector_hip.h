@@ -226,6 +226,10 @@ JV_API int jv_hip_luts_build(jv_ctx *ctx, jv_luts *luts, const float *queries, i
 JV_API int jv_hip_luts_destroy(jv_luts *luts);
 /* test/diagnostic access: copies query q's table (M*256 floats) and bMagnitude to host */
 JV_API int jv_hip_luts_download(jv_ctx *ctx, const jv_luts *luts, int q, float *lut_out, float *bmag_out);
+/* test/diagnostic access: the 8-bit upper-bound tables the register-table traversal (option gs_ubr) loads for the queries last
+ * staged by jv_hip_luts_build (dot product / cosine, uniform 8-dim sub-vectors): tab_out = Q x M x 64 dwords in the register
+ * layout of gs_host.h gs_ubr_build_ref, meta_out = Q x 4 floats {sum of low edges + slack, scale, usable, 0} */
+JV_API int jv_hip_luts_bound_tables(jv_ctx *ctx, const jv_luts *luts, uint32_t *tab_out, float *meta_out);
 /* copies the PQ's cosine self-magnitude table (M*256 floats; calculatePartialSelfMagnitudes) to host */
 JV_API int jv_hip_pq_self_magnitudes(jv_ctx *ctx, const jv_pq *pq, float *out);
 

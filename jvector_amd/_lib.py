@@ -77,6 +77,7 @@ SIGNATURES = {
     "jv_hip_luts_build": (_i, [_p, _p, _p, _i, _i, _i]),
     "jv_hip_luts_destroy": (_i, [_p]),
     "jv_hip_luts_download": (_i, [_p, _p, _i, _p, _p]),
+    "jv_hip_luts_bound_tables": (_i, [_p, _p, _p, _p]),
     "jv_hip_adc_scan": (_i, [_p, _p, _p, _i64, _i64, _p]),
     "jv_hip_adc_scores": (_i, [_p, _p, _p, _p, _i, _p]),
     "jv_hip_fused_create": (_i, [_p, _p, _i64, _i, C.POINTER(_p)]),

@@ -9,6 +9,7 @@
 
 #include "jv_device.h"
 #include "jv_internal.h"
+#include "gs_params.h"
 #include "../../include/jvector_formats.h"
 
 namespace jv {
@@ -353,7 +354,7 @@ int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, i
 namespace jv {
 namespace {
 // every option a context understands; the environment default of option x is JVECTOR_HIP_<X>
-const char *const kOptions[] = {"graph_traversal", "gs_occ", "gs_pair", "gs_pairc", "gs_quad", "rd_table_free", "rd_chunk", "rd_split", "rd_wide_stage", "rd_prof", "rd_square", "bl_insert_alpha_x100", "bl_improve_beam", "gs_cand_cap", "gs_waves_per_cu", "gs_vcap_log2", "gs_v1_log2", "gs_prefetch", "gs_lutr", "gs_generic", "gs_wgx", "gs_wgx_waves", "gs_wgx_slots", "gs_wgx_depth", "gs_wgx_per_cu", "gs_wgx_lut_m", "gs_ub8", "gs_ub8_per_cu",
+const char *const kOptions[] = {"graph_traversal", "gs_occ", "gs_pair", "gs_pairc", "gs_quad", "rd_table_free", "rd_chunk", "rd_split", "rd_wide_stage", "rd_prof", "rd_square", "bl_insert_alpha_x100", "bl_improve_beam", "gs_cand_cap", "gs_waves_per_cu", "gs_vcap_log2", "gs_v1_log2", "gs_prefetch", "gs_lutr", "gs_generic", "gs_wgx", "gs_wgx_waves", "gs_wgx_slots", "gs_wgx_depth", "gs_wgx_per_cu", "gs_wgx_lut_m", "gs_ub8", "gs_ub8_per_cu", "gs_ubr", "gs_ubr_trim",
                                 "gs_grow", "gs_retry", "gs_prof", "gs_tie_check", "gs_push_log", "gs_push_log_cap", "graph_timing",
                                 "no_filter", "quiet"};
 std::string env_name(const char *name)
@@ -1011,6 +1012,28 @@ int jv_hip_luts_download(jv_ctx *ctx, const jv_luts *l, int q, float *lut_out, f
         if (l->vsf == JV_COSINE) JV_HIP_CHECK(hipMemcpy(bmag_out, l->d_bmag + q, sizeof(float), hipMemcpyDefault));
         else *bmag_out = 0.0f;
     }
+    return JV_OK;
+}
+
+// The upper-bound tables the register-table traversal (gs_body.h "UBR") would load for the queries of `l`: built by the dense
+// kernel of k_gsearch_ubr.hip from the centred queries luts_build staged.  An accessor for tests and studies.
+int jv_hip_luts_bound_tables(jv_ctx *ctx, const jv_luts *l, uint32_t *tab_out, float *meta_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && l && tab_out && meta_out, "luts_bound_tables: NULL argument");
+    JV_REQUIRE(l->Q > 0, "luts_bound_tables: no queries staged (call jv_hip_luts_build first)");
+    const jv_pq *pq = l->pq;
+    JV_REQUIRE(l->vsf != JV_EUCLIDEAN && pq->uniform && pq->max_size == 8 && pq->k == kClusters && pq->M % 8 == 0,
+               "luts_bound_tables: dot product / cosine, 256 clusters, uniform 8-dim sub-vectors, M a multiple of 8");
+    JV_TRY(use_device(ctx->device));
+    const size_t tab_bytes = (gs_ubr_tab_bytes(pq->M) * (size_t)l->Q + 255) & ~(size_t)255;
+    JV_TRY(ctx->d_gs_ubr.reserve(tab_bytes + sizeof(float) * 4 * (size_t)l->Q));
+    uint32_t *d_tab = (uint32_t *)ctx->d_gs_ubr.ptr;
+    float *d_meta = (float *)((char *)ctx->d_gs_ubr.ptr + tab_bytes);
+    JV_TRY(launch_ubr_tables(ctx->stream, l->vsf == JV_DOT_PRODUCT ? VSF_DOT : VSF_COS, pq->d_codebooks, l->d_queries, l->Q, pq->M, d_tab, d_meta));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    JV_HIP_CHECK(hipMemcpy(tab_out, d_tab, gs_ubr_tab_bytes(pq->M) * (size_t)l->Q, hipMemcpyDefault));
+    JV_HIP_CHECK(hipMemcpy(meta_out, d_meta, sizeof(float) * 4 * (size_t)l->Q, hipMemcpyDefault));
     return JV_OK;
 }
 

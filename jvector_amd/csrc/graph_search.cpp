@@ -31,6 +31,9 @@
 #include "jv_internal.h"
 
 namespace jv {
+// gs_ubr unset: the register-table bound form (gs_body.h "UBR") serves every launch it applies to
+constexpr long long kGsUbrDefault = 0;
+
 
 // ---------------------------------------------------------------------------------------------
 // worker pool: persistent threads, static partition of [0, n)
@@ -1355,6 +1358,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // gs_ub8 = 1: the pair-lane kernel with an 8-bit upper-bound table of the query's ADC entries per wave (gs_body.h "UB8": fresh
     // neighbours that provably cannot be popped skip their exact score).  Costs M x 256 bytes of LDS per wave (fewer waves per CU).
     const bool ub8 = !so && !wgx && pair && !lutr && fused && !dev_accept.bits && ctx_opt(ctx, "gs_ub8", 0) != 0 && graph_search_ub8_supported(pq->M, kvsf);
+    // gs_ubr (default: on where it applies): the pair-lane kernel with the batch's upper-bound tables PREBUILT by a dense kernel and
+    // held in the wave's registers, survivors compacted and scored eight lanes each, the candidate tier trimmed to what can still be
+    // popped (gs_body.h "UBR").  No LDS beyond the pair form's.  Tables: M x 256 bytes per query of the batch.
+    const bool ubr = !so && !wgx && pair && !lutr && !ub8 && occ == 2 && !dev_accept.bits && ctx_opt(ctx, "gs_ubr", kGsUbrDefault) != 0 &&
+                     graph_search_ubr_supported(pq->M, kvsf) && ctx_opt(ctx, "gs_quad", 0) == 0;
     const int pair_M = (pair || pairc) ? pq->M : 0;
     int cand_cap = wgx ? wgx_cand_cap : std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", lutr ? 256 : (occ == 4 ? 512 : ((pair || pairc) ? 256 : 1024)))) & ~63;
     while (!wgx && cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
@@ -1480,7 +1488,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     int32_t *d_status = (int32_t *)(base + o_status);
     uint32_t *d_counter = (uint32_t *)(base + o_counter);
     JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
-    if (gs_prof) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 16, ctx->stream));
+    if (gs_prof || ubr) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 16, ctx->stream));
 
     GsParams p{};
     for (int lv = 0; lv <= g->entry_level; ++lv) {
@@ -1525,6 +1533,18 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.prefetch = (ctx_opt(ctx, "gs_prefetch", 0) != 0 && evict_cap >= 48 && !generic) ? 1 : 0;  // (dword touches: aligned rows only)
     p.lutr = lutr ? 1 : 0;
     p.ub8 = ub8 ? 1 : 0;
+    if (ubr) {
+        const size_t tab_bytes = (gs_ubr_tab_bytes(pq->M) * (size_t)Q + 255) & ~(size_t)255;
+        JV_TRY(ctx->d_gs_ubr.reserve(tab_bytes + sizeof(float) * 4 * (size_t)Q));
+        p.ubr = 1;
+        p.ubr_tab = (const uint32_t *)ctx->d_gs_ubr.ptr;
+        p.ubr_meta = (const float *)((const char *)ctx->d_gs_ubr.ptr + tab_bytes);
+        p.ubr_trim = std::max(1, (int)ctx_opt(ctx, "gs_ubr_trim", 24));
+        p.ubr_count = (unsigned long long *)(base + o_prof) + 15;
+        ProfScope ps(ctx, R_LUT);
+        JV_TRY(launch_ubr_tables(ctx->stream, kvsf, pq->d_codebooks, l->d_queries, Q, pq->M, (uint32_t *)ctx->d_gs_ubr.ptr,
+                                 (float *)((char *)ctx->d_gs_ubr.ptr + tab_bytes)));
+    }
     if (wgx) {
         p.prefetch = 0;
         p.wgx = 1;
@@ -1535,6 +1555,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p.wgx_depth = (int)ctx_opt(ctx, "gs_wgx_depth", 1);
     }
     auto launch = [&](const GsParams &pp, int w) -> int {
+        if (pp.ubr) return launch_graph_search_ubr(ctx->stream, kvsf, pp, w, lds);
         return wgx ? launch_graph_search_wgx(ctx->stream, kvsf, pp, w, 64 * wgx_waves) : launch_graph_search(ctx->stream, kvsf, pp, w, occ);
     };
     if (so) {
@@ -1612,7 +1633,10 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     {
         JV_TRY(ctx->h_out.reserve(sizeof(int32_t) * (size_t)Q));
         JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_status, sizeof(int32_t) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long ubr_dropped = 0;
+        if (ubr) JV_HIP_CHECK(hipMemcpyAsync(&ubr_dropped, base + o_prof + 15 * sizeof(unsigned long long), sizeof(ubr_dropped), hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ubr) ctx_stat_add(ctx, "gs_ubr_dropped", (long long)ubr_dropped);
         memcpy(status.data(), ctx->h_out.ptr, sizeof(int32_t) * (size_t)Q);
         for (int q = 0; q < Q; ++q)
             if (status[q] != GS_OK) redo.push_back(q);
@@ -1674,6 +1698,10 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         if (wgx)
             fprintf(stderr, "[jv gs prof] workgroup form, per expansion: row found in a slot %.3f (of those still being scored at use: %.3f of all)  "
                             "requested at the pop %.3f  rows requested ahead %.3f\n", h[8] / e, h[9] / e, h[10] / e, h[11] / e);
+        else if (ubr) {
+            fprintf(stderr, "[jv gs prof] register-table bound form, per expansion: bound + staging %.0f clocks  bound + staging + exact scores %.0f clocks  "
+                            "trims %.0f clocks | dropped %.2f  exactly scored %.2f neighbours\n", h[8] / e, h[9] / e, h[10] / e, h[15] / e, h[11] / e);
+        }
         else
         fprintf(stderr, "[jv gs prof] scored neighbours by fresh count of their expansion: <=8 %.3f  <=16 %.3f  <=24 %.3f  <=32 %.3f\n", h[8] / fs,
                 h[9] / fs, h[10] / fs, h[11] / fs);
@@ -1777,6 +1805,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     ctx_stat_set(ctx, "gs_last_v1_log2", v1_log2);
     ctx_stat_set(ctx, "gs_last_workers_per_cu", per_cu);
     ctx_stat_set(ctx, "gs_last_wgx", wgx ? 1 : 0);
+    ctx_stat_set(ctx, "gs_last_ubr", ubr ? 1 : 0);
     ctx_stat_set(ctx, "gs_last_pair", pair ? 1 : (pairc ? 2 : 0));   // 1: pair lanes over the row, 2: over the compacted fresh list
     if (wgx) ctx_stat_add(ctx, "gs_calls_wgx", 1);
     if (ctx_opt(ctx, "graph_timing", 0) != 0)

@@ -577,6 +577,64 @@ GS_FN float gs_ub8_half(const GsUb8 &u, const gs_u2 (&w)[HW], int m_base)
     return acc;
 }
 
+// ---- UBR: the upper-bound form that finishes what UB8 started (round 5) -------------------------------------------------------------
+// UB8 was sound and dropped 60 % of the scored neighbours, and was 2.3x slower: its table was built by the traversal wave itself
+// (355 k clocks per query), took 24 KB of LDS per wave (4 waves per CU, no room for the visited set's LDS tier) and the neighbours it
+// kept were scored in place (dead lanes free no gather instructions).  UBR removes the three:
+//   * the tables of the whole batch are PREBUILT by a dense kernel (k_gsearch_ubr.hip ubr_table_kernel; the same arithmetic as
+//     gs_ubr_build_ref in gs_host.h) with ONE scale per query: entry (m, c) -> b = bucket of (entry - lo_m) / S, upper edge
+//     lo_m + S (b + 1) >= entry checked in f32, so a row's bound is  base + S * sum_m (b_m + 1)  — an integer sum;
+//   * a query's table lives in the wave's REGISTERS, M dwords per lane: for step r < M/2 register 2r of lane s holds the bytes
+//     {t[r][s], t[r][s+64], t[r+M/2][s], t[r+M/2][s+64]}, register 2r+1 the same for codes s+128 / s+192.  In the pair-lane
+//     arrangement (low lane: subspaces [0, M/2), high lane: [M/2, M) of the same neighbour) both lanes look up step r at once: two
+//     ds_bpermute_b32 (source lane = code & 63) + a byte select.  No LDS bytes: 8 waves per CU and the LDS tier stay;
+//   * the neighbours the bound cannot drop are COMPACTED: their code bytes go to LDS and eight lanes score each of them (lane t of a
+//     group: subspaces [t M/8, (t + 1) M/8); lane 0 adds all M entries in ascending m, the others hand theirs over through LDS) —
+//     a pass of 8 survivors costs 2 M/8 gather instructions instead of the pair form's M;
+//   * the threshold: T = the score of a candidate such that >= rerankK known nodes (queued or kept results) score strictly higher —
+//     found every `ubr_trim` pushes among 64 samples of the candidate tier by bisection on exact counts — and the candidates at or
+//     below it are DISCARDED with it (they can never be popped either), so the tier stays around rerankK keys and pops scan little.
+// Soundness is UB8's (see above); every parity test of the pair-lane traversal runs with this form as well.
+template <int CH16>
+GS_FN void gs_ubr_load(const uint32_t *tab_q, uint32_t (&tab)[CH16 * 16])
+{
+    const gs_u4 *src = reinterpret_cast<const gs_u4 *>(tab_q) + gs_lane();
+#pragma unroll
+    for (int k = 0; k < CH16 * 4; ++k) {
+        const gs_u4 v = src[k * 64];
+        tab[4 * k + 0] = v.x;
+        tab[4 * k + 1] = v.y;
+        tab[4 * k + 2] = v.z;
+        tab[4 * k + 3] = v.w;
+    }
+}
+
+// this lane's half of sum_m (b_m + 1): the low lane of a pair (hi = 0) holds the codes of subspaces [0, M/2) in w, the high lane
+// (hi = 1) those of [M/2, M).  EVERY lane of the wave must execute it (a ds_bpermute reads the registers of active lanes only).
+template <int CH16>
+GS_FN int32_t gs_ubr_half(const uint32_t (&tab)[CH16 * 16], const gs_u2 (&w)[CH16], int hi)
+{
+    int32_t acc = CH16 * 8;   // the "+ 1" of every bucket
+    const int hsh = hi * 16;
+#pragma unroll
+    for (int c = 0; c < CH16; ++c) {
+        const uint32_t d[2] = {w[c].x, w[c].y};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int r = c * 8 + e * 4 + b;
+                const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
+                const int src = (int)(code & 63u);
+                const uint32_t lo = (uint32_t)gs_shfl32((int32_t)tab[2 * r], src), up = (uint32_t)gs_shfl32((int32_t)tab[2 * r + 1], src);
+                const uint32_t v = (code & 128u) ? up : lo;
+                acc += (int32_t)((v >> (((code >> 6) & 1u) * 8u + (uint32_t)hsh)) & 0xFFu);
+            }
+        }
+    }
+    return acc;
+}
+
 // raw table sum -> similarity (jv_device.h score_from_raw / cosine_finish; PQDecoder.java:68,79,126)
 template <int VSF>
 GS_FN float gs_finish(float sum, float node_mag, float query_mag)
@@ -793,6 +851,66 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
     gs_barrier();
 }
 
+// UBR: raise the pop threshold T and drop what it rules out.  Among 64 samples of the LDS candidate tier, find — by bisection over
+// the sample ranks, each step an exact count over the tier and the kept results — the HIGHEST sample such that at least rk known
+// keys are strictly greater: its score becomes T, and every candidate whose SCORE is below T can never be popped (rk nodes with a
+// strictly higher score are popped or kept first, then stopSearch — a comparison of scores — ends the layer), so it is discarded.  Keys of the spill tier (all below every LDS key)
+// are not counted: the count can only be too small.  Wave-uniform; leaves T alone when no sample qualifies.
+GS_FN void gs_ubr_trim(GsState &s, int rk, float &T)
+{
+    const int lane = gs_lane();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const int n = s.cand_n;
+    // (a key's high word is never 0x80000000 — gs_key canonicalises NaN — so these sentinels are unique and below every real key)
+    const long long mine = n >= 64 ? s.cand[(int)(((long long)lane * n) >> 6)] : (lane < n ? s.cand[lane] : GS_KEY_MIN + 1 + lane);
+    s.samp[lane] = mine;
+    gs_barrier();
+    int rank = 0;
+    for (int j = 0; j < 64; ++j) rank += (s.samp[j] < mine) ? 1 : 0;   // keys are unique: the ranks are 0..63, each once
+    auto above = [&](long long pv) -> int {
+        int c = 0;
+        for (int b = 0; b < n; b += 64) c += gs_popc(gs_ballot(b + lane < n && s.cand[b + lane] > pv));
+        for (int b = 0; b < s.res_n; b += 64) c += gs_popc(gs_ballot(b + lane < s.res_n && s.res[b + lane] > pv));
+        return c;
+    };
+    auto sample = [&](int r) -> long long { return gs_shfl(mine, gs_first(gs_ballot(rank == r))); };
+    long long pv = sample(0);
+    if (above(pv) < rk) {
+        gs_barrier();
+        return;
+    }
+    int lo = 0, hi = 63;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const long long pm = sample(mid);
+        if (above(pm) >= rk) {
+            lo = mid;
+            pv = pm;
+        } else {
+            hi = mid - 1;
+        }
+    }
+    const float ps = gs_key_score(pv);
+    if (!(ps >= 0.0f) || !(ps > T)) {   // (a sentinel decodes to NaN; a negative score never becomes a result: no threshold from it)
+        gs_barrier();
+        return;
+    }
+    int new_n = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool in = i < n;
+        const long long k = in ? s.cand[i] : 0;
+        // (by SCORE, not by key: stopSearch compares scores, so a candidate that ties with the threshold may still be popped)
+        const bool keep = in && (int32_t)(k >> 32) >= (int32_t)(pv >> 32);
+        const uint64_t mk = gs_ballot(keep);   // every lane has read its key before any lane writes
+        if (keep) s.cand[new_n + gs_popc(mk & lt)] = k;   // in place: target index <= i
+        new_n += gs_popc(mk);
+        gs_barrier();
+    }
+    s.cand_n = new_n;
+    T = ps;
+}
+
 #ifndef GS_CLOCK
 #define GS_CLOCK() 0ull  // the GPU build maps it to the shader clock (gs_wave_hip.h); the emulator has no clock
 #endif
@@ -810,9 +928,11 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 //       rows, maxDegree x neighborOverflow): one lane per neighbour probes the visited set, the unvisited ids are compacted
 //       through LDS and scored two lanes each like PAIR (<= 32 per pass, a second pass for the rest; M > 96: four lanes each,
 //       16 per pass).  LDS layout = PAIR's.
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false, bool PAIRC = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false, bool PAIRC = false, bool UBR = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
+    static_assert(!UBR || (PAIR && !SES && !LUTR && !UB8 && !PAIRC && VSF != 0 && CH16 % 2 == 0 && 60 * CH16 * 16 + 256 <= 64 * CH16 * 16),
+                  "the register-table bound form serves the pair-lane kernels, dot product / cosine, M a multiple of 32 and >= 64");
     static_assert(!PAIRC || (!PAIR && !LUTR && !UB8 && CH16 > 0), "the compacted pair form is a variant of the plain one-lane-per-neighbour kernel");
     constexpr bool XA = PAIR || PAIRC;   // the worker's LDS block has the [M/2][32] exchange area
     static_assert(!(LUTR && PAIR), "the register-resident table serves the one-lane-per-neighbour form");
@@ -981,6 +1101,21 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     }
     (void)ub_last_spill_max;
     (void)ub_dropped;
+    // ---- UBR: the query's prebuilt bound table in registers; base / scale of its bounds; pushes since the last trim ----
+    uint32_t ubtab[UBR ? CH16 * 16 : 1];
+    float ubr_base = 0.0f, ubr_scale = 0.0f;
+    int ubr_since = 0;
+    if constexpr (UBR) {
+        gs_ubr_load<CH16>(p.ubr_tab + (int64_t)q * (CH16 * 16) * 64, ubtab);
+        const float *meta = p.ubr_meta + (int64_t)q * 4;
+        ubr_base = meta[0];
+        ubr_scale = meta[1];
+        ub_on = meta[2] != 0.0f && acc == nullptr;   // (acceptOrds: rejected nodes never become results — no threshold)
+    }
+    (void)ubtab;
+    (void)ubr_base;
+    (void)ubr_scale;
+    (void)ubr_since;
 
     // ---- initializeInternal :334-353: mark and score the entry node ----
     {
@@ -1004,7 +1139,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         sc = gs_finish<VSF>(sc, (VSF == 2) ? p.code_norms[e] : 0.0f, query_mag);
         if (lane == 0) s.cand[0] = gs_key(e, sc);
         s.cand_n = 1;
-        if (UB8 && sc != sc) ub_on = false;
+        if ((UB8 || UBR) && sc != sc) ub_on = false;
         gs_barrier();
     }
 
@@ -1223,6 +1358,10 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 const int m_base = hi ? p.M / 2 : 0;
                 const int32_t nb = ni < deg ? row[ni] : -1;
                 gs_u2 w[CH16];
+                if constexpr (UBR) {   // every lane takes part in the bound's cross-lane reads: no uninitialised code words
+#pragma unroll
+                    for (int c = 0; c < CH16; ++c) w[c] = gs_u2{0u, 0u};
+                }
                 float node_mag = 0.0f;
                 if (fused0 && ni < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
                     const int64_t r = (int64_t)node * p.deg0 + ni;
@@ -1241,10 +1380,100 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 if (fm == 0) continue;
                 n_visited += gs_popc(fm);
                 GS_PHASE(2);
-                if (PROF) {
+                if (PROF && !UBR) {
                     const int f = gs_popc(fm);
                     fh[f <= 8 ? 0 : (f <= 16 ? 1 : (f <= 24 ? 2 : 3))] += (unsigned long long)f;
                 }
+                if constexpr (UBR) {
+                    constexpr int M_ = CH16 * 16, SUBS = M_ / 8;   // eight lanes per kept neighbour, SUBS subspaces each
+                    unsigned long long ubc0 = 0;
+                    if (PROF) ubc0 = GS_CLOCK();
+                    // ---- the bound of every fresh neighbour against the pop threshold ----
+                    uint64_t sm = fm;   // the fresh neighbours that need their exact score (bits of the low lanes)
+                    const bool ub_active = ub_on && lvl == 0 && ub_T > -__builtin_inff();
+                    if (ub_active) {
+                        const int32_t part = gs_ubr_half<CH16>(ubtab, w, hi ? 1 : 0);   // all 64 lanes
+                        const int32_t other = gs_shfl32(part, lane ^ 32);
+                        bool drop = false;
+                        if (fresh) drop = gs_finish<VSF>(ubr_base + ubr_scale * (float)(part + other), node_mag, query_mag) < ub_T;
+                        const uint64_t dm = gs_ballot(drop);
+                        sm = fm & ~dm;
+                        ub_dropped += (unsigned long long)gs_popc(dm);
+                    }
+                    const int ns = gs_popc(sm);
+                    ubr_since += ns;
+                    // ---- compact the survivors: code bytes, node id and magnitude of survivor j (row order) into LDS ----
+                    float *xf = xchg;                                              // [SUBS][7][8] entries handed to the owner lanes
+                    int32_t *st_nb = reinterpret_cast<int32_t *>(xchg + 7 * M_);   // [32]
+                    float *st_mag = reinterpret_cast<float *>(st_nb + 32);          // [32]
+                    uint8_t *st_code = reinterpret_cast<uint8_t *>(st_mag + 32);    // [32][M]
+                    if ((sm >> ni) & 1ull) {
+                        const int j = gs_popc(sm & ((1ull << ni) - 1ull));
+                        gs_u2 *dst = reinterpret_cast<gs_u2 *>(st_code + j * M_ + (hi ? M_ / 2 : 0));
+#pragma unroll
+                        for (int c = 0; c < CH16; ++c) dst[c] = w[c];
+                        if (!hi) {
+                            st_nb[j] = nb;
+                            st_mag[j] = node_mag;
+                        }
+                    }
+                    gs_barrier();
+                    if (PROF) {
+                        const unsigned long long now_ = GS_CLOCK();
+                        fh[0] += now_ - ubc0;   // (the UBR build reuses the fresh-count histogram's slots: bound + staging clocks,
+                        fh[3] += (unsigned long long)ns;   // ... survivors)
+                    }
+                    // ---- score them, eight per pass: lane 8 g + t takes subspaces [t SUBS, (t + 1) SUBS) of survivor base + g ----
+                    const int g = lane >> 3;
+                    int t = lane & 7;
+                    GS_OPAQUE_I32(t);   // (or the per-lane subspace pointers are hoisted out of the search loop and spilled)
+                    fresh = false;
+                    key = 0;
+                    bool give_up = false;
+#pragma unroll 1
+                    for (int base = 0; base < ns; base += 8) {
+                        const int j = base + g;
+                        const bool work = j < ns;
+                        float sum = 0.0f;
+                        if (work) {
+                            const uint32_t *cw = reinterpret_cast<const uint32_t *>(st_code + j * M_ + t * SUBS);
+                            uint32_t d[SUBS / 4];
+#pragma unroll
+                            for (int i = 0; i < SUBS / 4; ++i) d[i] = cw[i];
+#pragma unroll
+                            for (int k = 0; k < SUBS; ++k) {
+                                const uint32_t code = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                                const float v = gs_lut_entry<VSF>(p.codebooks, qs, t * SUBS + k, (int)code);
+                                if (t == 0) sum += v;
+                                else xf[(k * 7 + (t - 1)) * 8 + g] = v;
+                            }
+                        }
+                        gs_barrier();
+                        fresh = work && t == 0;
+                        key = 0;
+                        if (fresh) {   // the owner: its own subspaces are summed; now the other seven lanes' in ascending m
+#pragma unroll
+                            for (int tt = 1; tt < 8; ++tt) {
+#pragma unroll
+                                for (int k = 0; k < SUBS; ++k) sum += xf[(k * 7 + (tt - 1)) * 8 + g];
+                            }
+                            const float sc = gs_finish<VSF>(sum, st_mag[j], query_mag);
+                            key = gs_key(st_nb[j], sc);
+                            if (ub_active && sc < ub_T) fresh = false;   // exactly scored and still below the threshold: never popped
+                        }
+                        if (base + 8 >= ns) break;   // the shared tail below pushes the last pass
+                        gs_barrier();   // every owner lane has read its column before the push's sample buffer reuses the bytes
+                        if (ub_on && gs_ballot(fresh && (int32_t)(key >> 32) == 0x7fc00000)) ub_on = false;
+                        gs_push(s, p, key, fresh);
+                        fresh = false;
+                        if (s.status != GS_OK) {
+                            give_up = true;
+                            break;
+                        }
+                    }
+                    if (give_up) break;
+                    if (PROF) fh[1] += GS_CLOCK() - ubc0;
+                } else {
                 uint64_t fm_score = fm;   // fresh neighbours that get an exact score
                 if constexpr (UB8) {
                     // drop what provably cannot be popped: bound of every fresh neighbour (two half sums, joined through the exchange
@@ -1321,6 +1550,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     key = gs_key(nb, gs_finish<VSF>(sum, node_mag, query_mag));
                 }
                 }
+                }   // (!UBR)
             } else if constexpr (PAIRC) {
                 // ---- rows of up to 64 neighbours, codes by ordinal: one lane per neighbour for the visited probe, then the fresh
                 //      ones — compacted in row order — LPN lanes each (lane t of a group: subspaces [t M/LPN, (t+1) M/LPN); lane 0
@@ -1459,10 +1689,27 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             if constexpr (SES) {
                 if (thr_on) trk_track(fresh, gs_key_score(key));
             }
-            if constexpr (UB8) {   // a NaN score sorts above everything but never becomes a result: no threshold can be proven with one around
+            if constexpr (UB8 || UBR) {   // a NaN score sorts above everything but never becomes a result: no threshold can be proven with one around
                 if (ub_on && gs_ballot(fresh && (int32_t)(key >> 32) == 0x7fc00000)) ub_on = false;
             }
             gs_push(s, p, key, fresh);
+            if constexpr (UBR) {
+                // ---- the pop threshold: the worst kept result once the result queue is full; every ubr_trim pushes the candidate
+                //      tier is searched for a higher one and loses what it rules out (gs_ubr_trim) ----
+                if (ub_on && lvl == 0 && s.status == GS_OK) {
+                    if (s.res_n >= rk) {
+                        const float t = gs_key_score(s.res_min);
+                        if (t > ub_T) ub_T = t;
+                    }
+                    if (ubr_since >= p.ubr_trim && s.cand_n > 0 && s.cand_n + s.res_n >= rk) {
+                        unsigned long long tc0 = 0;
+                        if (PROF) tc0 = GS_CLOCK();
+                        gs_ubr_trim(s, rk, ub_T);
+                        ubr_since = 0;
+                        if (PROF) fh[2] += GS_CLOCK() - tc0;
+                    }
+                }
+            }
             if constexpr (UB8) {
                 // ---- the pop threshold: the worst kept result once the result queue is full; the partition pivot once the LDS
                 //      tier (every key above it) plus the results above it number rerankK ----
@@ -1568,11 +1815,12 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         gs_fetch_add64(p.prof + 14, GS_CLOCK() - pep0);
     }
     if (UB8 && p.prof && lane == 0) gs_fetch_add64(p.prof + 15, ub_dropped);   // (tests / studies / gs_prof read the drop count)
+    if (UBR && p.ubr_count && lane == 0) gs_fetch_add64(p.ubr_count, ub_dropped);
 #undef GS_PHASE
 }
 
 // Persistent worker: pulls queries off the shared counter until none are left.
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false, bool PAIRC = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false, bool PAIRC = false, bool UBR = false>
 GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
 {
     for (;;) {
@@ -1580,7 +1828,7 @@ GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
         if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
         const int item = (int)gs_shfl(qv, 0);
         if (item >= p.Q) break;
-        gs_search_one<VSF, CH16, PAIR, PROF, LUTR, SES, UB8, PAIRC>(p, p.qmap ? p.qmap[item] : item, worker, lds);
+        gs_search_one<VSF, CH16, PAIR, PROF, LUTR, SES, UB8, PAIRC, UBR>(p, p.qmap ? p.qmap[item] : item, worker, lds);
     }
 }
 

@@ -33,6 +33,70 @@ inline GsLevelMap gs_build_level_map(const int32_t *nodes, int count)
     return m;
 }
 
+// ---- UBR (gs_body.h "UBR"): the 8-bit upper-bound table of ONE query's ADC entries, the way ubr_table_kernel (k_gsearch_ubr.hip)
+// builds it for a batch — this restatement serves the lane emulator, the mock device and the GPU test that compares the kernel's
+// bytes with it.  Dot product / cosine entries (calculatePartialSums' chain, mul and add separate); per subspace lo_m / hi_m = the
+// extreme entries; ONE scale S = max_m (hi_m - lo_m) / 255; entry -> bucket b with lo_m + S (b + 1) >= entry verified in f32.
+// tab: M x 64 dwords in the register layout (register k of lane s at ((k / 4) * 64 + s) * 4 + k % 4; for step r < M / 2 register 2r
+// holds {t[r][s], t[r][s + 64], t[r + M/2][s], t[r + M/2][s + 64]} and 2r + 1 the same for codes s + 128 / s + 192);
+// meta4 = {sum_m lo_m + slack, S, usable (1 / 0), 0}.  Compile with -ffp-contract=off.
+inline void gs_ubr_build_ref(const float *codebooks /* [M][256][8] */, const float *cq /* [8 M] centred query */, int M, uint32_t *tab, float *meta4)
+{
+    std::vector<float> e((size_t)M * 256), lo((size_t)M), hi((size_t)M);
+    bool ok = true;
+    float range = 0.0f;
+    for (int m = 0; m < M; ++m) {
+        float mn = 0.0f, mx = 0.0f;
+        for (int c = 0; c < 256; ++c) {
+            const float *row = codebooks + ((size_t)m * 256 + (size_t)c) * 8;
+            const float *q = cq + (size_t)m * 8;
+            float ent = 0.0f;
+            for (int j = 0; j < 8; ++j) {
+                const float pr = row[j] * q[j];
+                ent += pr;
+            }
+            e[(size_t)m * 256 + c] = ent;
+            if (!(ent - ent == 0.0f)) ok = false;
+            if (c == 0 || ent < mn) mn = ent;
+            if (c == 0 || ent > mx) mx = ent;
+        }
+        lo[m] = mn;
+        hi[m] = mx;
+        const float r = mx - mn;
+        if (r > range) range = r;
+    }
+    float S = range / 255.0f;
+    if (!(S > 1e-30f)) S = 1e-30f;
+    const float inv = 1.0f / S;
+    float sum_lo = 0.0f, sum_abs = 0.0f;
+    for (int m = 0; m < M; ++m) {
+        sum_lo += lo[m];
+        const float amn = lo[m] < 0.0f ? -lo[m] : lo[m], amx = hi[m] < 0.0f ? -hi[m] : hi[m];
+        sum_abs += (amn > amx ? amn : amx) + 256.0f * S;
+    }
+    auto bucket = [&](int m, int c) -> uint32_t {
+        const float ent = e[(size_t)m * 256 + c];
+        int b = (int)((ent - lo[m]) * inv);
+        b = b < 0 ? 0 : (b > 255 ? 255 : b);
+        while (b < 255 && lo[m] + S * (float)(b + 1) < ent) ++b;   // the bucket's upper edge really is an upper bound, in f32
+        return (uint32_t)b;
+    };
+    const int H = M / 2;
+    for (int r = 0; r < H; ++r)
+        for (int s = 0; s < 64; ++s)
+            for (int u = 0; u < 2; ++u) {   // u = 0: codes s, s + 64; u = 1: codes s + 128, s + 192
+                const int k = 2 * r + u, c0 = s + 128 * u;
+                uint32_t v = 0;
+                if (ok) v = bucket(r, c0) | (bucket(r, c0 + 64) << 8) | (bucket(r + H, c0) << 16) | (bucket(r + H, c0 + 64) << 24);
+                tab[((size_t)(k / 4) * 64 + (size_t)s) * 4 + (size_t)(k % 4)] = v;
+            }
+    ok = ok && (sum_abs - sum_abs == 0.0f);
+    meta4[0] = sum_lo + 4e-5f * sum_abs;
+    meta4[1] = S;
+    meta4[2] = ok ? 1.0f : 0.0f;
+    meta4[3] = 0.0f;
+}
+
 // visited-table size for a search that keeps rerankK results: a search marks ~18 x rerankK nodes at maxDegree 32
 // (measured, 10M x 768); 64 x leaves the table under half full for all but pathological queries (those overflow
 // and are re-run on the host).

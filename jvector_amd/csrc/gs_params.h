@@ -87,6 +87,16 @@ struct GsParams {
     // entries in LDS; a fresh neighbour whose bound lies below a proven pop threshold is counted as visited and dropped without
     // its exact score (gs_body.h "UB8")
     int32_t ub8;
+    // UBR (gs_body.h "UBR", k_gsearch_ubr.hip; dot product / cosine, layer 0, M = 96): the 8-bit upper-bound table of every query is
+    // PREBUILT by a dense kernel (ubr_table_kernel: [Q][M / 4][64] x 16 bytes, one scale per query) and held in the wave's
+    // REGISTERS (M dwords per lane, looked up with ds_bpermute) — no LDS, the visited set's LDS tier and 8 waves per CU stay; the
+    // neighbours the bound cannot drop are compacted through LDS and scored EIGHT lanes each; the candidate queue is trimmed to
+    // what can still be popped.  Results, scores, visitedCount and expandedCount are the reference's.
+    int32_t ubr;
+    const uint32_t *ubr_tab;  // [Q][M][64] dwords: register k of lane s for query q at ((q * (M / 4) + k / 4) * 64 + s) * 4 + k % 4
+    const float *ubr_meta;    // [Q][4]: {sum of the low edges + slack, scale, 1 = usable (every entry finite), unused}
+    int32_t ubr_trim;         // candidates pushed between two trims of the queue (>= 1)
+    unsigned long long *ubr_count;  // += neighbours dropped behind their bound (one atomic per query), or nullptr
     int32_t wgx;              // 1: launch the workgroup form
     int32_t wgx_slots;        // scored-row slots in LDS (<= 64)
     int32_t wgx_kps;          // keys per slot: 32 or 64 (>= every level's degree)
@@ -130,6 +140,12 @@ constexpr size_t gs_lutr_lds_bytes(int M) { return M > 64 ? (size_t)(M - 64) * 2
 
 // LDS bytes of the UB8 form's per-wave bound table: M x 256 bytes + per-subspace {low edge, scale} floats
 constexpr size_t gs_ub8_lds_bytes(int M) { return (size_t)M * 256 + sizeof(float) * 2 * (size_t)M + 16; }
+
+// UBR lives in the pair-lane exchange area: [7 M / 8 entries x 8 owners of f32][32 node ids][32 magnitudes][32 x M code bytes]
+constexpr size_t gs_ubr_xchg_bytes(int M) { return sizeof(float) * 7 * (size_t)M + 256 + 32 * (size_t)M; }
+static_assert(gs_ubr_xchg_bytes(96) <= sizeof(float) * gs_xchg_floats(96), "UBR's staging must fit the pair-lane exchange area");
+// device bytes of one query's prebuilt bound table / all of them
+constexpr size_t gs_ubr_tab_bytes(int M) { return (size_t)M * 64 * sizeof(uint32_t); }
 
 // LDS bytes of the session kernels' TwoPhaseTracker state (500 recent scores + the 100 best)
 constexpr size_t gs_session_lds_bytes() { return sizeof(float) * 500 + sizeof(int32_t) * 100; }

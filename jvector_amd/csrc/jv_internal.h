@@ -93,6 +93,7 @@ struct jv_ctx {
     // device-resident graph traversal: per-worker visited tables / spill tiers and the per-query result staging
     jv::Buffer d_gs_visited, d_gs_spill, d_gs_out, d_gs_mask, d_gs_big;
     jv::Buffer d_gs_extra;   // session kernels: the evictedResults a resume() pushes back (graph_search.cpp)
+    jv::Buffer d_gs_ubr;     // UBR: the batch's upper-bound tables (M x 256 bytes per query) + 4 floats of meta per query
     jv::Buffer d_nvq_q;   // NVQ rerank: shifted queries + per-query scalars (nvq.cpp)
     // host batched graph searcher: worker pool (graph_search.cpp owns the type) and its destructor
     void *host_pool = nullptr;
@@ -394,6 +395,10 @@ size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int 
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy);
 bool graph_search_lutr_supported(int M);
 bool graph_search_ub8_supported(int M, int kernel_vsf);
+// the register-table bound form (gs_body.h "UBR", k_gsearch_ubr.hip): tables of a batch, then the traversal
+bool graph_search_ubr_supported(int M, int kernel_vsf);
+int launch_ubr_tables(hipStream_t s, int vsf, const float *codebooks, const float *cq, int Q, int M, uint32_t *tab, float *meta);
+int launch_graph_search_ubr(hipStream_t s, int vsf, const GsParams &p, int workers, size_t lds);
 // the workgroup form (k_gsearch_wgx.hip): one query per workgroup, the ADC table in LDS
 bool graph_search_wgx_supported(int M);
 size_t graph_search_wgx_lds_bytes(int D, int rerankK, int cand_cap, int evict_cap, int v1_log2, int slots, int kps, int logcap, int M);

@@ -619,6 +619,14 @@ class QueryTables:
                                              C.cast(C.byref(bm), C.c_void_p)))
         return lut, float(bm.value)
 
+    def bound_tables(self):
+        """the 8-bit upper-bound tables of the staged queries as the register-table traversal loads them (diagnostic accessor):
+        (tab uint32[Q, M * 64], meta float32[Q, 4])"""
+        tab = np.empty((self.Q, self.pq.M * 64), np.uint32)
+        meta = np.empty((self.Q, 4), np.float32)
+        check(self._lib.jv_hip_luts_bound_tables(self.ctx._h, self._h, tab.ctypes.data_as(C.c_void_p), meta.ctypes.data_as(C.c_void_p)))
+        return tab, meta
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.jv_hip_luts_destroy(self._h)

@@ -113,6 +113,15 @@ void run_ub8(const Launch &L)
     }
 }
 template <int VSF>
+void run_ubr(const Launch &L)
+{
+    switch (L.ch) {
+    case 4: jv::gs_worker<VSF, 4, true, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gs_worker<VSF, 6, true, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
+template <int VSF>
 void run_pairc(const Launch &L)
 {
     switch (L.ch) {
@@ -147,6 +156,9 @@ void lane_main(void *arg)
         if (L.vsf == 0) run_wgx<0>(L);
         else if (L.vsf == 1) run_wgx<1>(L);
         else run_wgx<2>(L);
+    } else if (L.p->ubr) {
+        if (L.vsf == 1) run_ubr<1>(L);
+        else run_ubr<2>(L);
     } else if (L.p->ub8) {
         if (L.vsf == 1) run_ub8<1>(L);
         else run_ub8<2>(L);
@@ -172,7 +184,8 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
                               int evict_cap /* 0 = GS_EVICT_CAP */, int lutr /* 1: ADC table in registers + LDS (M <= 96) */,
                               int wgx_waves /* > 0: the workgroup form (gx_body.h) with this many waves (2..4 here), M <= 128 */,
                               int wgx_slots, int wgx_depth, int wgx_lut_m /* 0 = M */,
-                              int ub8 /* 1: the pair-lane kernel with the 8-bit upper-bound table (dot / cosine, M <= 96, degrees <= 32) */,
+                              int ub8 /* 1: the pair-lane kernel with the 8-bit upper-bound table (dot / cosine, M <= 96, degrees <= 32);
+                                         2: UBR — the table prebuilt (gs_ubr_build_ref) and held in registers, survivors compacted, eight lanes each (M = 64 / 96) */,
                               long long *ub8_dropped_out /* nullable */)
 {
     if (lutr && M > 96) return -4;
@@ -213,7 +226,19 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     p.pair = pair ? 1 : (pairc ? 2 : 0);
     p.quad = getenv("GS_EMU_QUAD") ? atoi(getenv("GS_EMU_QUAD")) : 1;   // (on in the emulator unless a test turns it off: more code under test)
     if (ub8 && (!pair || vsf == 0 || M > 96 || wgx_waves || lutr)) return -7;
-    p.ub8 = ub8 ? 1 : 0;
+    if (ub8 == 2 && M != 64 && M != 96) return -9;
+    p.ub8 = ub8 == 1 ? 1 : 0;
+    std::vector<uint32_t> ubr_tab;
+    std::vector<float> ubr_meta;
+    if (ub8 == 2) {
+        p.ubr = 1;
+        p.ubr_trim = getenv("GS_EMU_UBR_TRIM") ? atoi(getenv("GS_EMU_UBR_TRIM")) : 8;   // (small: many trims per search under test)
+        ubr_tab.resize((size_t)Q * M * 64);
+        ubr_meta.resize((size_t)Q * 4);
+        for (int q = 0; q < Q; ++q) jv::gs_ubr_build_ref(codebooks, cq + (size_t)q * D, M, ubr_tab.data() + (size_t)q * M * 64, ubr_meta.data() + (size_t)q * 4);
+        p.ubr_tab = ubr_tab.data();
+        p.ubr_meta = ubr_meta.data();
+    }
     p.v1_log2 = v1_log2; p.v1_idbits = v1_idbits; p.evict_cap = evict_cap;
     p.prefetch = getenv("GS_EMU_PREFETCH") ? atoi(getenv("GS_EMU_PREFETCH")) : 1;  // on by default in the emulator: more code under test
     int kps = 32;
@@ -236,7 +261,8 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     uint32_t next = 0;
     p.next_query = &next;
     unsigned long long prof[16] = {0};
-    if (ub8) p.prof = prof;   // (only slot 15 is written without the phase-clock build: neighbours dropped behind the bound)
+    if (ub8 == 1) p.prof = prof;   // (only slot 15 is written without the phase-clock build: neighbours dropped behind the bound)
+    if (ub8 == 2) p.ubr_count = prof + 15;
     long collectives = 0;
     // "workers" waves run one after another; each drains part of the queue so that scratch reuse across queries and
     // distinct worker slices are both exercised
@@ -244,7 +270,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
         jv::GsParams pw = p;
         pw.Q = (int)((long long)Q * (w + 1) / workers);
         const size_t lds_bytes = wgx_waves ? jv::gx_lds_bytes(D, rerankK, cand_cap, ecap, v1_log2, wgx_slots, kps, p.wgx_log, p.wgx_lut_m)
-                                           : jv::gs_lds_bytes(D, rerankK, cand_cap, (pair || pairc) ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0) + (ub8 ? jv::gs_ub8_lds_bytes(M) : 0);
+                                           : jv::gs_lds_bytes(D, rerankK, cand_cap, (pair || pairc) ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0) + (ub8 == 1 ? jv::gs_ub8_lds_bytes(M) : 0);
         char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
         memset(lds, 0xa5, lds_bytes);
         memset(lds + lds_bytes, 0x3c, 64);  // canary behind the block
@@ -272,4 +298,10 @@ extern "C" int gs_emu_level_lookup(const int32_t *nodes, int count, int32_t node
         if (m.keys[h] == -1) return -1;
         h = (h + 1) & m.mask;
     }
+}
+
+// gs_host.h's restatement of ubr_table_kernel (the GPU test compares the kernel's bytes with it)
+extern "C" void gs_emu_ubr_table(const float *codebooks, const float *cq, int M, uint32_t *tab, float *meta4)
+{
+    jv::gs_ubr_build_ref(codebooks, cq, M, tab, meta4);
 }

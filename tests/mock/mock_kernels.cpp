@@ -76,6 +76,7 @@ static inline gs_f32x16 gs_mfma_32x32x2(float a, float b, gs_f32x16 c) { return 
 #include "../../jvector_amd/csrc/ed_body.h"
 #include "../../jvector_amd/csrc/gs_body.h"
 #include "../../jvector_amd/csrc/gx_body.h"
+#include "../../jvector_amd/csrc/gs_host.h"
 #include "../../jvector_amd/csrc/km_body.h"
 #include "../../jvector_amd/csrc/rd_body.h"
 #include "../../jvector_amd/csrc/rt_body.h"
@@ -796,6 +797,9 @@ void gs_main(void *a)
             else if (L.vsf == VSF_DOT) gs_run_session<VSF_DOT, false>(L);
             else gs_run_session<VSF_COS, false>(L);
         }
+    } else if (L.p->ubr) {
+        if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, true, false, false, false, false, false, true>(*L.p, L.worker, L.lds);
+        else gs_worker<VSF_COS, 6, true, false, false, false, false, false, true>(*L.p, L.worker, L.lds);
     } else if (L.p->ub8) {
         if (L.vsf == VSF_DOT) gs_run_ub8<VSF_DOT>(L);
         else gs_run_ub8<VSF_COS>(L);
@@ -861,6 +865,17 @@ int launch_graph_search_wgx(hipStream_t, int vsf, const GsParams &p, int workgro
     }
     return JV_OK;
 }
+
+// the register-table bound form: the tables by gs_host.h's restatement of ubr_table_kernel, the traversal on the lane emulator
+bool graph_search_ubr_supported(int M, int vsf) { return vsf != VSF_L2 && M == 96; }
+int launch_ubr_tables(hipStream_t, int vsf, const float *codebooks, const float *cq, int Q, int M, uint32_t *tab, float *meta)
+{
+    if (vsf == VSF_L2 || M % 8 != 0) return JV_ERR_INVALID;
+    for (int q = 0; q < Q; ++q) gs_ubr_build_ref(codebooks, cq + (size_t)q * 8 * M, M, tab + (size_t)q * M * 64, meta + (size_t)q * 4);
+    return JV_OK;
+}
+int launch_graph_search(hipStream_t, int vsf, const GsParams &p, int workers, int /*occupancy*/);
+int launch_graph_search_ubr(hipStream_t s, int vsf, const GsParams &p, int workers, size_t /*lds*/) { return launch_graph_search(s, vsf, p, workers, 2); }
 
 int launch_graph_search(hipStream_t, int vsf, const GsParams &p, int workers, int /*occupancy*/)
 {

@@ -205,6 +205,51 @@ def test_upper_bound_table_form_with_equal_and_extreme_scores(emu, monkeypatch):
             check(ids, sc, st, status, wi, ws, wst)
 
 
+@pytest.mark.parametrize("levels,fused,M,deg,N", [(2, True, 96, 32, 2500), (2, False, 96, 32, 2000), (3, True, 64, 24, 3000), (1, True, 96, 16, 3000)])
+def test_register_table_bound_form(emu, monkeypatch, levels, fused, M, deg, N):
+    """UBR (round 5): the bound table prebuilt (gs_ubr_build_ref) and held in registers, survivors compacted and scored eight lanes
+    each, the candidate tier trimmed to what can still be popped — ids, scores and BOTH counters equal the oracle's, dot product and
+    cosine, fused blocks and codes by ordinal, rerankK from 1 to well above the degree, trims every 1 / 8 / 64 pushes"""
+    D = 8 * M
+    lv, entry, entry_level, opq, codes, q = problem(900 + levels + M, N, D, M, levels, deg=deg, nq=8)
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    dropped_total = scored_total = 0
+    for vsf in (O.DOT_PRODUCT, O.COSINE):
+        for rk in (10, 40, 150, 1):
+            wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
+            for trim, v1, cc in (("8", 9, 256), ("1", 12, 128), ("64", 9, 256)):
+                monkeypatch.setenv("GS_EMU_UBR_TRIM", trim)
+                ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, ub8=2, v1_log2=v1, cand_cap=cc)
+                check(ids, sc, st, status, wi, ws, wst)
+                scored_total += int(wst[:, 0].sum())
+                dropped_total += run_emu.last_ub8_dropped
+    assert dropped_total > 0.1 * scored_total, (dropped_total, scored_total)   # the form really drops neighbours in these searches
+
+
+def test_register_table_bound_form_with_equal_and_extreme_scores(emu, monkeypatch):
+    """duplicated vectors (equal scores around every threshold and every trim pivot), shuffled lane orders, a NaN in the query
+    (no table: nothing may be dropped, the answer is still the oracle's)"""
+    lv, entry, entry_level, opq, codes, q = problem(23, 3000, 768, 96, 2, deg=24, nq=6)
+    codes = codes.copy()
+    codes[1::2] = codes[0:-1:2][: len(codes[1::2])]
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    for order in ("", "reverse", "random:9"):
+        if order:
+            monkeypatch.setenv("EMU_LANE_ORDER", order)
+        for vsf in (O.DOT_PRODUCT, O.COSINE):
+            wi, ws, wst = og.search(opq, codes, None, q, vsf, 30, 30, fused=True)
+            ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, 30, True, ub8=2)
+            check(ids, sc, st, status, wi, ws, wst)
+    monkeypatch.delenv("EMU_LANE_ORDER", raising=False)
+    qn = q.copy()
+    qn[0, 5] = np.nan
+    qn[1, :] = 0.0
+    for vsf in (O.DOT_PRODUCT, O.COSINE):
+        wi, ws, wst = og.search(opq, codes, None, qn, vsf, 30, 30, fused=True)
+        ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, qn, vsf, 30, True, ub8=2)
+        check(ids, sc, st, status, wi, ws, wst)
+
+
 def test_workgroup_form_rare_paths(emu):
     """the control wave's own queue code (gx_body.h gx_control): candidate-tier partitions into the spill tier, an exhaustive search
     that drains the LDS tier and refills it from the spill tier again and again, every size class of the visited set's LDS tier

@@ -894,3 +894,12 @@ def test_reference_native_comparison_runs_on_the_mock(J, ctx):
     T.test_encode_code_bytes_vs_reference_native(ctx, 50, 7)
     T.test_pair_scores_vs_reference_native(ctx, 128, 16)
     T.test_nvq_scores_vs_reference_native(ctx, 100, 3)
+
+
+def test_register_table_bound_form_on_the_mock(J, ctx):
+    """tests/test_zz_ubr_gpu.py on the mock device (the traversal on the lane emulator, the tables by gs_host.h's restatement): the
+    driver's side of the form — option gs_ubr, table scratch, the drop counter, stats, the fall-backs for euclidean / filtered searches"""
+    import test_zz_ubr_gpu as T
+    T.test_bound_tables_equal_the_restatement(ctx, J.VectorSimilarityFunction.COSINE)
+    T.test_register_table_bound_kernel(ctx, 2, True, 32, 2500)
+    T.test_register_table_bound_kernel_ties_and_degenerate_queries(ctx)

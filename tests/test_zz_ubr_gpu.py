@@ -1,0 +1,150 @@
+"""The register-table bound form of the device traversal (gs_body.h "UBR", k_gsearch_ubr.hip; option gs_ubr) on the GPU:
+  * ubr_table_kernel's tables == gs_host.h's restatement, byte for byte (and the meta floats bit for bit);
+  * searches == the oracle's sequential GraphSearcher: ids, scores, visitedCount and expandedCount — while the form really drops
+    neighbours (gs_ubr_dropped) — dot product and cosine, fused blocks and codes by ordinal, trims every 1 / 24 / 200 pushes,
+    rerankK from 1 to 150; euclidean and filtered searches take the plain kernel.
+The CPU twin (lane emulator) is tests/test_gsearch_emulated.py::test_register_table_bound_form*."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import jvector_amd as J
+from jvector_amd import VectorSimilarityFunction as VSF
+from oracle import oracle as O
+from test_graph_search import build_problem, fused_blocks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = J.HipContext(0)
+    yield c
+    c.close()
+
+
+def emu_lib():
+    import test_gsearch_emulated as E
+    if not os.path.exists(E.LIB) or any(os.path.getmtime(s) > os.path.getmtime(E.LIB) for s in E.SRC):
+        os.makedirs(os.path.dirname(E.LIB), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", E.SRC[0], "-o", E.LIB])
+    return C.CDLL(E.LIB)
+
+
+@pytest.mark.parametrize("vsf", [VSF.DOT_PRODUCT, VSF.COSINE])
+def test_bound_tables_equal_the_restatement(ctx, vsf):
+    D, M, Q = 768, 96, 21           # (21: a ragged last block of the 8-queries-per-block kernel)
+    rng = np.random.default_rng(int(vsf))
+    cb = (rng.standard_normal(256 * D) * 0.3).astype(np.float32)
+    centroid = (rng.standard_normal(D) * 0.05).astype(np.float32)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb, centroid)
+    q = rng.standard_normal((Q, D)).astype(np.float32)
+    q[3] = 0.0                      # every entry 0: the scale floor
+    q[5, 17] = np.nan               # no usable table
+    q[7, 100] = np.inf
+    luts = J.QueryTables(ctx, pq, Q).build(q, vsf, J.DecoderKind.FUSED)
+    tab, meta = luts.bound_tables()
+    L = emu_lib()
+    cq = (q - centroid).astype(np.float32)
+    for i in range(Q):
+        wt = np.empty(M * 64, np.uint32)
+        wm = np.empty(4, np.float32)
+        L.gs_emu_ubr_table(cb.ctypes.data_as(C.c_void_p), np.ascontiguousarray(cq[i]).ctypes.data_as(C.c_void_p), M, wt.ctypes.data_as(C.c_void_p),
+                           wm.ctypes.data_as(C.c_void_p))
+        if i in (5, 7):
+            assert meta[i, 2] == 0.0 and wm[2] == 0.0
+            continue
+        assert meta[i, 2] == 1.0
+        assert np.array_equal(meta[i].view(np.uint32), wm.view(np.uint32)), (i, meta[i], wm)
+        assert np.array_equal(tab[i], wt), (i, np.argwhere(tab[i] != wt)[:4])
+        # and the table really bounds: for random codes, base + S * sum(b + 1) >= the exact sum of entries
+        codes = rng.integers(0, 256, (50, M))
+        ent = np.einsum("mcj,mj->mc", cb.reshape(M, 256, 8).astype(np.float64), cq[i].reshape(M, 8).astype(np.float64))
+        for c in codes:
+            exact = ent[np.arange(M), c].sum()
+            k = 2 * (np.arange(M) % (M // 2)) + (c >= 128)
+            lane = c & 63
+            word = tab[i][((k // 4) * 64 + lane) * 4 + k % 4]
+            b = (word >> (8 * (((c >> 6) & 1) + 2 * (np.arange(M) >= M // 2)))) & 0xFF
+            assert meta[i, 0] + meta[i, 1] * float((b + 1).sum()) >= exact
+
+
+def _setup(ctx, seed, N, D, M, levels, use_fused, deg):
+    v, lv, entry, entry_level, cb, q = build_problem(seed, N=N, D=D, M=M, deg=deg, levels=levels)
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal("device")
+    fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1]) if use_fused else None
+    return v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q
+
+
+@pytest.mark.parametrize("levels,use_fused,deg,N", [(2, True, 32, 20000), (2, False, 32, 8000), (3, True, 16, 12000)])
+def test_register_table_bound_kernel(ctx, levels, use_fused, deg, N):
+    D, M = 768, 96
+    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 17 * levels + deg, N, D, M, levels, use_fused, deg)
+    og = O.OracleGraph(len(v), lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+    try:
+        ctx.set_option("gs_ubr", 1)
+        ctx.set_option("gs_wgx", 0)
+        for vsf in VSF:
+            for top_k, rk in ((10, 40), (10, 74), (10, 150), (1, 1)):
+                wi, ws, wst = og.search(opq, codes, v, q, int(vsf), top_k, rk, fused=use_fused)
+                for trim in (1, 24, 200):
+                    ctx.set_option("gs_ubr_trim", trim)
+                    before = ctx.stat("gs_ubr_dropped")
+                    ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True)
+                    assert ctx.stat("gs_last_ubr") == (0 if vsf == VSF.EUCLIDEAN else 1)
+                    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rk, trim)
+                    if vsf != VSF.EUCLIDEAN and rk >= 40:
+                        assert ctx.stat("gs_ubr_dropped") - before > 0.1 * wst[:, 0].sum(), (vsf, rk, trim)
+        # a filtered search: no threshold can be proven with rejected nodes around — the plain kernel
+        accept = np.ones(len(v), bool)
+        accept[::3] = False
+        ids, sc, st = s.search(q, VSF.COSINE, 10, 60, return_stats=True, accept=accept)
+        wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, 60, fused=use_fused, accept=accept)
+        assert ctx.stat("gs_last_ubr") == 0 and np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+    finally:
+        for k in ("gs_ubr", "gs_wgx", "gs_ubr_trim"):
+            ctx.set_option(k, None)
+
+
+def test_register_table_bound_kernel_ties_and_degenerate_queries(ctx):
+    """duplicated vectors (equal scores around every threshold and trim pivot), a zero query, a NaN in a query"""
+    D, M, N = 768, 96, 6000
+    v, lv, entry, entry_level, cb, q = build_problem(5, N=N, D=D, M=M, deg=24, levels=2)
+    v = v.copy()
+    v[1::2] = v[0:-1:2][: len(v[1::2])]
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+    vs = J.VectorSet(ctx, v)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = cv.get(0, N)
+    graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal("device")
+    fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1])
+    og = O.OracleGraph(N, lv, entry, entry_level)
+    s = J.GraphSearcher(ctx, graph, pq, cv, fused, None, max_queries=64)
+    q = q.copy()
+    q[1] = 0.0
+    q[2, 9] = np.nan
+    try:
+        ctx.set_option("gs_ubr", 1)
+        ctx.set_option("gs_wgx", 0)
+        for vsf in (VSF.DOT_PRODUCT, VSF.COSINE):
+            for trim in (1, 24):
+                ctx.set_option("gs_ubr_trim", trim)
+                ids, sc, st = s.search(q, vsf, 30, 30, return_stats=True)
+                wi, ws, wst = og.search(opq, codes, None, q, int(vsf), 30, 30, fused=True)
+                assert ctx.stat("gs_last_ubr") == 1
+                assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws, equal_nan=True), (vsf, trim)
+    finally:
+        for k in ("gs_ubr", "gs_wgx", "gs_ubr_trim"):
+            ctx.set_option(k, None)
