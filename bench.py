@@ -235,7 +235,7 @@ def cpu_baseline_build(cb, D, M, codes_h, nbrs_h, entry, base_dev, vsf, max_degr
 def measured_traffic(kernel_key, cfg, want_entry=False):
     """HBM bytes per launch from the rocprofv3 PMC summary (profiles/traffic_r4.json, else traffic_r3.json / traffic_r2.json) — only if it was collected on THIS
     configuration (same kernel, N, D, M, queries per step, rerankK); else None."""
-    for name in ("traffic_r4.json", "traffic_r3.json", "traffic_r2.json"):   # the newest summary whose configuration matches
+    for name in ("traffic_r5.json", "traffic_r4.json", "traffic_r3.json", "traffic_r2.json"):   # the newest summary whose configuration matches
         try:
             table = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -1129,7 +1129,10 @@ def main():
     graph_stats, extra_roof = None, {}
     if graph_mode:
         # expansions / visited of exactly the timed steps (untimed repeat: the search is deterministic)
+        dropped0 = ctx.stat("gs_ubr_dropped")
         st = [run(timed_q[s * Q:(s + 1) * Q], rerank_k, stats=True)[2] for s in range(args.steps)]
+        ubr_dropped = ctx.stat("gs_ubr_dropped") - dropped0    # neighbours the register-table bound form dropped unscored in those steps
+        ubr_form = ctx.stat("gs_last_ubr") == 1
         graph_stats = np.concatenate(st)
         expansions = float(graph_stats[:, 1].sum())
         unit_bytes = args.degree * M + 4 * args.degree    # fused block (padding is read) + maxDegree scores
@@ -1143,6 +1146,16 @@ def main():
                     "scores); the kernel additionally reads the 132 B adjacency row per expansion and gathers 32 B of the "
                     "L2-resident codebook per (fresh neighbour, subspace) — it is bound by those L2 gathers and the dependent "
                     "pop -> load -> probe -> score -> push chain, not by HBM (DESIGN.md §4)")
+            if ubr_form:
+                kernel_key = "gsearch_ubr"
+                kernel = (f"graph_search_ubr_kernel<COSINE,CH16={M // 16}> (device-resident GraphSearcher, one wavefront per query; round 5: an "
+                          "8-bit upper-bound table of the query's ADC entries, prebuilt per batch by ubr_table_kernel — the `lut` time of "
+                          "kernel_ms_per_step — and held in the wave's registers, drops the fresh neighbours that provably can never be "
+                          "popped; the others are compacted through LDS and scored table-free, eight lanes each)")
+                note = (f"algorithmic bytes = expansions x {unit_bytes} B as before (SURVEY §8d row 7: the fused block is still read whole); "
+                        f"{ubr_dropped / max(float(graph_stats[:, 0].sum()), 1.0):.3f} of the visited neighbours are dropped behind their bound "
+                        "without the M codebook gathers of an exact score; ids, scores, visitedCount and expandedCount are unchanged "
+                        "(DESIGN.md §4 'UBR')")
         else:
             k_ms, k_n = prof["adc"]
             kernel_key = "frontier"
@@ -1256,7 +1269,7 @@ def main():
             # the kernel's physical bound: 32-byte codebook rows gathered from L2, one per (scored neighbour, subspace);
             # ceiling = tools/gather_bench.hip on this GPU (profiles/r2_gather_bench.log: 396 G rows/s, 12.7 TB/s)
             if args.traversal == "device" and k_ms > 0:
-                rows = float(st[:, 0].sum()) * M
+                rows = (float(st[:, 0].sum()) - (float(ubr_dropped) if ubr_form else 0.0)) * M
                 line["l2_gather"] = {"rows_per_s": rows / (k_ms / 1e3), "ceiling_rows_per_s": 395.9e9,
                                      "frac": rows / (k_ms / 1e3) / 395.9e9, "bytes_per_row": 32,
                                      "note": "scored neighbours x M codebook rows of 32 B (L2-resident 768 KB table) over the traversal "

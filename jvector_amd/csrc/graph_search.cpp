@@ -32,7 +32,7 @@
 
 namespace jv {
 // gs_ubr unset: the register-table bound form (gs_body.h "UBR") serves every launch it applies to
-constexpr long long kGsUbrDefault = 0;
+constexpr long long kGsUbrDefault = 1;
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1539,7 +1539,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p.ubr = 1;
         p.ubr_tab = (const uint32_t *)ctx->d_gs_ubr.ptr;
         p.ubr_meta = (const float *)((const char *)ctx->d_gs_ubr.ptr + tab_bytes);
-        p.ubr_trim = std::max(1, (int)ctx_opt(ctx, "gs_ubr_trim", 24));
+        p.ubr_trim = std::max(1, (int)ctx_opt(ctx, "gs_ubr_trim", 48));
         p.ubr_count = (unsigned long long *)(base + o_prof) + 15;
         ProfScope ps(ctx, R_LUT);
         JV_TRY(launch_ubr_tables(ctx->stream, kvsf, pq->d_codebooks, l->d_queries, Q, pq->M, (uint32_t *)ctx->d_gs_ubr.ptr,

@@ -9,6 +9,8 @@
 //     gs_ballot(bool) -> uint64_t             wave vote
 //     gs_shfl(long long v, int src)           read lane src's v
 //     gs_shfl32(int32_t v, int src)           the same for 32 bits (one ds_bpermute_b32)
+//     gs_perm(uint32_t hi, uint32_t lo, uint32_t sel)   v_perm_b32: result byte i = byte sel.byte[i] of the eight bytes {hi : lo}
+//                                             (0..3 = lo, 4..7 = hi), 0x0c = the constant 0
 //     gs_shfl_xor(long long v, int laneMask)  butterfly exchange
 //     GS_OPAQUE_I32(x)                        optimisation barrier on an int (no-op on the emulator)
 //     gs_cas(int32_t *p, int32_t expect, int32_t desired) -> old      (device-scope atomic)
@@ -326,6 +328,33 @@ GS_FN float gs_lut_entry_from(const gs_f4 c0, const gs_f4 c1, const float *q)
     return ent;
 }
 
+// two table entries at once: rows (a0, a1) x qa and (b0, b1) x qb.  The GPU build (GS_HAVE_PK_F32, gs_wave_hip.h) runs the two chains in
+// the halves of v_pk_mul_f32 / v_pk_add_f32 — per half the same IEEE operations in the same order as gs_lut_entry_from.
+template <int VSF>
+GS_FN void gs_lut_entry_pair(const gs_f4 a0, const gs_f4 a1, const float *qa, const gs_f4 b0, const gs_f4 b1, const float *qb, float &ea, float &eb)
+{
+#ifdef GS_HAVE_PK_F32
+    if (VSF != 0) {
+        const gs_f4 qa0 = reinterpret_cast<const gs_f4 *>(qa)[0], qa1 = reinterpret_cast<const gs_f4 *>(qa)[1];
+        const gs_f4 qb0 = reinterpret_cast<const gs_f4 *>(qb)[0], qb1 = reinterpret_cast<const gs_f4 *>(qb)[1];
+        gs_pk2 acc = {0.0f, 0.0f};
+        acc = acc + gs_pk2{a0.x, b0.x} * gs_pk2{qa0.x, qb0.x};
+        acc = acc + gs_pk2{a0.y, b0.y} * gs_pk2{qa0.y, qb0.y};
+        acc = acc + gs_pk2{a0.z, b0.z} * gs_pk2{qa0.z, qb0.z};
+        acc = acc + gs_pk2{a0.w, b0.w} * gs_pk2{qa0.w, qb0.w};
+        acc = acc + gs_pk2{a1.x, b1.x} * gs_pk2{qa1.x, qb1.x};
+        acc = acc + gs_pk2{a1.y, b1.y} * gs_pk2{qa1.y, qb1.y};
+        acc = acc + gs_pk2{a1.z, b1.z} * gs_pk2{qa1.z, qb1.z};
+        acc = acc + gs_pk2{a1.w, b1.w} * gs_pk2{qa1.w, qb1.w};
+        ea = acc.x;
+        eb = acc.y;
+        return;
+    }
+#endif
+    ea = gs_lut_entry_from<VSF>(a0, a1, qa);
+    eb = gs_lut_entry_from<VSF>(b0, b1, qb);
+}
+
 template <int VSF, int CH16>
 GS_FN void gs_lut_build(const float *codebooks, const float *qs, float (&lut)[(CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB) * 4],
                         float *lut_lds)
@@ -615,22 +644,26 @@ template <int CH16>
 GS_FN int32_t gs_ubr_half(const uint32_t (&tab)[CH16 * 16], const gs_u2 (&w)[CH16], int hi)
 {
     int32_t acc = CH16 * 8;   // the "+ 1" of every bucket
-    const int hsh = hi * 16;
+    // byte selector of gs_perm: the looked-up pair {upper word (codes >= 128) : lower word} holds the entry's byte at index
+    // (code >> 6 & 1) + 4 (code >> 7) + 2 hi; the other three result bytes are the constant 0
+    const uint32_t selbase = 0x0c0c0c00u + 2u * (uint32_t)hi;
 #pragma unroll
     for (int c = 0; c < CH16; ++c) {
+        // the eight look-ups of one code word: all sixteen cross-lane reads are issued before the first result is used
         const uint32_t d[2] = {w[c].x, w[c].y};
+        uint32_t lo[8], up[8], sel[8];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int r = c * 8 + e * 4 + b;
-                const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
-                const int src = (int)(code & 63u);
-                const uint32_t lo = (uint32_t)gs_shfl32((int32_t)tab[2 * r], src), up = (uint32_t)gs_shfl32((int32_t)tab[2 * r + 1], src);
-                const uint32_t v = (code & 128u) ? up : lo;
-                acc += (int32_t)((v >> (((code >> 6) & 1u) * 8u + (uint32_t)hsh)) & 0xFFu);
-            }
+        for (int i = 0; i < 8; ++i) {
+            const int r = c * 8 + i;
+            const uint32_t code = (d[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            const int src = (int)(code & 63u);
+            lo[i] = (uint32_t)gs_shfl32((int32_t)tab[2 * r], src);
+            up[i] = (uint32_t)gs_shfl32((int32_t)tab[2 * r + 1], src);
+            const uint32_t t2 = code >> 6;
+            sel[i] = selbase + t2 + (t2 & 2u);
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += (int32_t)gs_perm(up[i], lo[i], sel[i]);
     }
     return acc;
 }
@@ -1403,7 +1436,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     const int ns = gs_popc(sm);
                     ubr_since += ns;
                     // ---- compact the survivors: code bytes, node id and magnitude of survivor j (row order) into LDS ----
-                    float *xf = xchg;                                              // [SUBS][7][8] entries handed to the owner lanes
+                    float *xf = xchg;                                              // [8 owners][7 SUBS] entries handed to the owner lanes
                     int32_t *st_nb = reinterpret_cast<int32_t *>(xchg + 7 * M_);   // [32]
                     float *st_mag = reinterpret_cast<float *>(st_nb + 32);          // [32]
                     uint8_t *st_code = reinterpret_cast<uint8_t *>(st_mag + 32);    // [32][M]
@@ -1440,22 +1473,54 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                             uint32_t d[SUBS / 4];
 #pragma unroll
                             for (int i = 0; i < SUBS / 4; ++i) d[i] = cw[i];
+                            // the codebook rows of half the lane's share are requested before the first entry is formed (a branch on
+                            // the lane's role between two look-ups makes the compiler wait for each pair of loads in turn; the whole
+                            // share at once — 24 x 16 bytes — does not fit next to the table's registers)
+                            // The codebook rows of HALF the lane's share are requested before the first entry is formed (a branch on the
+                            // lane's role between two look-ups makes the compiler wait for each pair of loads in turn: 13.9 k -> 9.7 k
+                            // clocks per expansion; the whole share at once — 24 x 16 bytes — does not fit next to the table's registers:
+                            // the compiler then parks 16 of them in scratch around every pass, measured 60.6 vs 57.3 ms, profiles/r5_f).
+                            // Two entries at a time in the halves of packed f32 operations (each chain still multiplies and adds its
+                            // eight products in ascending dimension, one rounding per operation: the same bits).
+                            float v[SUBS];
 #pragma unroll
-                            for (int k = 0; k < SUBS; ++k) {
-                                const uint32_t code = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                                const float v = gs_lut_entry<VSF>(p.codebooks, qs, t * SUBS + k, (int)code);
-                                if (t == 0) sum += v;
-                                else xf[(k * 7 + (t - 1)) * 8 + g] = v;
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                gs_f4 c0[SUBS / 2], c1[SUBS / 2];
+#pragma unroll
+                                for (int kk = 0; kk < SUBS / 2; ++kk) {
+                                    const int k = h2 * (SUBS / 2) + kk;
+                                    const uint32_t code = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                                    const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(p.codebooks + ((int64_t)((t * SUBS + k) * 256) + code) * 8);
+                                    c0[kk] = cp[0];
+                                    c1[kk] = cp[1];
+                                }
+#pragma unroll
+                                for (int kk = 0; kk < SUBS / 2; kk += 2) {
+                                    const int k = h2 * (SUBS / 2) + kk;
+                                    gs_lut_entry_pair<VSF>(c0[kk], c1[kk], qs + (t * SUBS + k) * 8, c0[kk + 1], c1[kk + 1], qs + (t * SUBS + k + 1) * 8,
+                                                           v[k], v[k + 1]);
+                                }
+                            }
+                            if (t == 0) {
+#pragma unroll
+                                for (int k = 0; k < SUBS; ++k) sum += v[k];
+                            } else {   // column g of the hand-over area: the owner reads its 7 SUBS entries as contiguous 16-byte words
+#pragma unroll
+                                for (int k = 0; k < SUBS; ++k) xf[g * (7 * SUBS) + (t - 1) * SUBS + k] = v[k];
                             }
                         }
                         gs_barrier();
                         fresh = work && t == 0;
                         key = 0;
                         if (fresh) {   // the owner: its own subspaces are summed; now the other seven lanes' in ascending m
+                            const gs_f4 *col = reinterpret_cast<const gs_f4 *>(xf + g * (7 * SUBS));
 #pragma unroll
-                            for (int tt = 1; tt < 8; ++tt) {
-#pragma unroll
-                                for (int k = 0; k < SUBS; ++k) sum += xf[(k * 7 + (tt - 1)) * 8 + g];
+                            for (int i = 0; i < 7 * SUBS / 4; ++i) {
+                                const gs_f4 e4 = col[i];
+                                sum += e4.x;
+                                sum += e4.y;
+                                sum += e4.z;
+                                sum += e4.w;
                             }
                             const float sc = gs_finish<VSF>(sum, st_mag[j], query_mag);
                             key = gs_key(st_nb[j], sc);

@@ -118,6 +118,10 @@ __device__ __forceinline__ long long gs_shfl_xor(long long v, int m) { return __
 // loop that uses it instead of hoisting dozens of 64-bit pointers out of the search loop and spilling them)
 #define GS_OPAQUE_I32(x) asm volatile("" : "+v"(x))
 __device__ __forceinline__ int32_t gs_shfl32(int32_t v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+// packed f32 pairs (v_pk_mul_f32 / v_pk_add_f32; -ffp-contract=off keeps the multiply and the add apart)
+#define GS_HAVE_PK_F32 1
+typedef float gs_pk2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t gs_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired) { return atomicCAS(p, expect, desired); }
 // LDS atomic (ds_cmpst_rtn_b32): p points into the workgroup's LDS block
 __device__ __forceinline__ uint32_t gs_lds_cas(uint32_t *p, uint32_t expect, uint32_t desired)

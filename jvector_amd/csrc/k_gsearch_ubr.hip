@@ -82,9 +82,12 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
                 const float *q = qs + j * D + m * 8;
                 int32_t smin = 0x7fffffff, smax = (int32_t)0x80000000;
                 bool bad = false;
+                float e4[4];
+                gs_lut_entry_pair<VSF>(c0[0], c1[0], q, c0[1], c1[1], q, e4[0], e4[1]);
+                gs_lut_entry_pair<VSF>(c0[2], c1[2], q, c0[3], c1[3], q, e4[2], e4[3]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float e = gs_lut_entry_from<VSF>(c0[k], c1[k], q);
+                    const float e = e4[k];
                     bad = bad || !(e - e == 0.0f);
                     const int32_t se = ubr_sortable(e);
                     smin = se < smin ? se : smin;
@@ -152,9 +155,12 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
                 const int m = r + half * H;
                 const float l = lo[j * M + m];
                 const float *q = qs + j * D + m * 8;
+                float e4[4];
+                gs_lut_entry_pair<VSF>(c0[half][0], c1[half][0], q, c0[half][1], c1[half][1], q, e4[0], e4[1]);
+                gs_lut_entry_pair<VSF>(c0[half][2], c1[half][2], q, c0[half][3], c1[half][3], q, e4[2], e4[3]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float e = gs_lut_entry_from<VSF>(c0[half][k], c1[half][k], q);
+                    const float e = e4[k];
                     int bb = (int)((e - l) * inv);
                     bb = bb < 0 ? 0 : (bb > 255 ? 255 : bb);
                     while (bb < 255 && l + S * (float)(bb + 1) < e) ++bb;   // the bucket's upper edge really is an upper bound, in f32

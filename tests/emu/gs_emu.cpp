@@ -27,6 +27,17 @@ static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
 static inline int32_t gs_shfl32(int32_t v, int src) { return (int32_t)emu::shfl((long long)v, src); }
+static inline uint32_t gs_perm(uint32_t hi, uint32_t lo, uint32_t sel)   // v_perm_b32 (selectors 0..7 and 0x0c only)
+{
+    const uint64_t pool = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t sb = (sel >> (8 * i)) & 0xFFu;
+        const uint32_t byte = sb < 8 ? (uint32_t)((pool >> (8 * sb)) & 0xFFu) : (sb == 0x0c ? 0u : 0xFFu);
+        r |= byte << (8 * i);
+    }
+    return r;
+}
 #define GS_OPAQUE_I32(x) ((void)0)
 static inline int32_t gs_cas(int32_t *p, int32_t expect, int32_t desired)
 {
