@@ -68,17 +68,24 @@ inline void gs_ubr_build_ref(const float *codebooks /* [M][256][8] */, const flo
     float S = range / 255.0f;
     if (!(S > 1e-30f)) S = 1e-30f;
     const float inv = 1.0f / S;
-    float sum_lo = 0.0f, sum_abs = 0.0f;
+    float sum_lo = 0.0f, sum_abs = 0.0f, max_abs = 0.0f;
     for (int m = 0; m < M; ++m) {
         sum_lo += lo[m];
         const float amn = lo[m] < 0.0f ? -lo[m] : lo[m], amx = hi[m] < 0.0f ? -hi[m] : hi[m];
-        sum_abs += (amn > amx ? amn : amx) + 256.0f * S;
+        const float a = amn > amx ? amn : amx;
+        sum_abs += a + 256.0f * S;
+        if (a > max_abs) max_abs = a;
     }
+    // usable only if a bucket is not lost in the rounding of an edge: then lo + 256 S >= every entry of the subspace in f32 as well
+    ok = ok && (sum_abs - sum_abs == 0.0f) && S * 1e6f >= max_abs;
     auto bucket = [&](int m, int c) -> uint32_t {
         const float ent = e[(size_t)m * 256 + c];
         int b = (int)((ent - lo[m]) * inv);
         b = b < 0 ? 0 : (b > 255 ? 255 : b);
-        while (b < 255 && lo[m] + S * (float)(b + 1) < ent) ++b;   // the bucket's upper edge really is an upper bound, in f32
+        // the bucket's upper edge really is an upper bound, in f32: the truncated quotient is at most two buckets short
+        if (b < 255 && lo[m] + S * (float)(b + 1) < ent) ++b;
+        if (b < 255 && lo[m] + S * (float)(b + 1) < ent) ++b;
+        if (lo[m] + S * (float)(b + 1) < ent) b = 255;
         return (uint32_t)b;
     };
     const int H = M / 2;
@@ -90,7 +97,6 @@ inline void gs_ubr_build_ref(const float *codebooks /* [M][256][8] */, const flo
                 if (ok) v = bucket(r, c0) | (bucket(r, c0 + 64) << 8) | (bucket(r + H, c0) << 16) | (bucket(r + H, c0 + 64) << 24);
                 tab[((size_t)(k / 4) * 64 + (size_t)s) * 4 + (size_t)(k % 4)] = v;
             }
-    ok = ok && (sum_abs - sum_abs == 0.0f);
     meta4[0] = sum_lo + 4e-5f * sum_abs;
     meta4[1] = S;
     meta4[2] = ok ? 1.0f : 0.0f;

@@ -80,21 +80,19 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
             }
             for (int j = 0; j < UBR_QB; ++j) {
                 const float *q = qs + j * D + m * 8;
-                int32_t smin = 0x7fffffff, smax = (int32_t)0x80000000;
-                bool bad = false;
                 float e4[4];
                 gs_lut_entry_pair<VSF>(c0[0], c1[0], q, c0[1], c1[1], q, e4[0], e4[1]);
                 gs_lut_entry_pair<VSF>(c0[2], c1[2], q, c0[3], c1[3], q, e4[2], e4[3]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float e = e4[k];
-                    bad = bad || !(e - e == 0.0f);
-                    const int32_t se = ubr_sortable(e);
-                    smin = se < smin ? se : smin;
-                    smax = se > smax ? se : smax;
-                }
-                smin = gs_wave_min_i32(smin);
-                smax = gs_wave_max_i32(smax);
+                const bool bad = !(e4[0] - e4[0] == 0.0f) || !(e4[1] - e4[1] == 0.0f) || !(e4[2] - e4[2] == 0.0f) || !(e4[3] - e4[3] == 0.0f);
+                // the lane's extremes as floats (a NaN marks the query unusable anyway), ONE conversion each to the order-preserving
+                // integer image, six single-instruction DPP steps per reduction
+                float fmn = e4[0] < e4[1] ? e4[0] : e4[1], fmx = e4[0] > e4[1] ? e4[0] : e4[1];
+                fmn = e4[2] < fmn ? e4[2] : fmn;
+                fmx = e4[2] > fmx ? e4[2] : fmx;
+                fmn = e4[3] < fmn ? e4[3] : fmn;
+                fmx = e4[3] > fmx ? e4[3] : fmx;
+                const int32_t smin = gs_wave_min_i32(ubr_sortable(fmn));
+                const int32_t smax = gs_wave_max_i32(ubr_sortable(fmx));
                 const bool any_bad = __ballot(bad ? 1 : 0) != 0;
                 if (lane == 0) {
                     lo[j * M + m] = ubr_unsortable(smin);
@@ -115,14 +113,17 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
         }
         float S = range / 255.0f;
         if (!(S > 1e-30f)) S = 1e-30f;
-        float sum_lo = 0.0f, sum_abs = 0.0f;
+        float sum_lo = 0.0f, sum_abs = 0.0f, max_abs = 0.0f;
         for (int m = 0; m < M; ++m) {
             const float l = lo[j * M + m], h = hi[j * M + m];
             sum_lo += l;
             const float amn = l < 0.0f ? -l : l, amx = h < 0.0f ? -h : h;
-            sum_abs += (amn > amx ? amn : amx) + 256.0f * S;
+            const float a = amn > amx ? amn : amx;
+            sum_abs += a + 256.0f * S;
+            if (a > max_abs) max_abs = a;
         }
-        const bool ok = qbad[j] == 0 && (sum_abs - sum_abs == 0.0f);
+        // (usable only if a bucket is not lost in the rounding of an edge: lo + 256 S then bounds every entry of a subspace in f32 too)
+        const bool ok = qbad[j] == 0 && (sum_abs - sum_abs == 0.0f) && S * 1e6f >= max_abs;
         qS[j] = S;
         if (!ok) qbad[j] = 1;
         if (j < nq) {
@@ -163,7 +164,10 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
                     const float e = e4[k];
                     int bb = (int)((e - l) * inv);
                     bb = bb < 0 ? 0 : (bb > 255 ? 255 : bb);
-                    while (bb < 255 && l + S * (float)(bb + 1) < e) ++bb;   // the bucket's upper edge really is an upper bound, in f32
+                    // the bucket's upper edge really is an upper bound, in f32: the truncated quotient is at most two buckets short
+                    if (bb < 255 && l + S * (float)(bb + 1) < e) ++bb;
+                    if (bb < 255 && l + S * (float)(bb + 1) < e) ++bb;
+                    if (l + S * (float)(bb + 1) < e) bb = 255;
                     b[half][k] = (uint32_t)bb;
                 }
             }
