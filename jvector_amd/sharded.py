@@ -146,8 +146,10 @@ class Communicator:
 
     @classmethod
     def over_torch_distributed(cls, ctx, group=None):
-        """jv_hip_comm_create_external: the library's exchange carried by an initialised torch.distributed process group (gloo on
-        CPU hosts, nccl = RCCL on GPUs) — the host's transport, the library's merge."""
+        """jv_hip_comm_create_external: the library's exchange carried by an initialised torch.distributed process group — the
+        host's transport, the library's merge.  gloo: the staging bytes are gathered as CPU tensors (tested: world_size 2 on the
+        mock device).  nccl (= RCCL): they are copied to this rank's GPU, gathered there and copied back (the path an nccl-only
+        group needs; exercised on one rank only — this pool has no multi-GPU node)."""
         import ctypes as C
         import numpy as np
         import torch.distributed as dist
@@ -157,14 +159,21 @@ class Communicator:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
+        # an nccl (= RCCL) group moves device tensors only: the staging bytes take a round trip through this rank's GPU there
+        # (a CPU tensor handed to an nccl-only group made every sharded search fail with JV_ERR_HIP); gloo gathers them as is
+        backend = str(dist.get_backend(group)).lower()
+        stage_dev = torch.device("cuda", torch.cuda.current_device()) if "nccl" in backend else None
+
         def all_gather(_user, send, nbytes, recv):
             try:
                 mine = torch.from_numpy(np.ctypeslib.as_array((C.c_ubyte * nbytes).from_address(send)).copy())
+                if stage_dev is not None:
+                    mine = mine.to(stage_dev)
                 parts = [torch.empty_like(mine) for _ in range(world)]
                 dist.all_gather(parts, mine, group=group)
                 out = np.ctypeslib.as_array((C.c_ubyte * (nbytes * world)).from_address(recv))
                 for r, t in enumerate(parts):
-                    out[r * nbytes:(r + 1) * nbytes] = t.numpy()
+                    out[r * nbytes:(r + 1) * nbytes] = t.cpu().numpy()
                 return 0
             except Exception:   # never unwind through the C frame
                 import traceback
