@@ -776,7 +776,7 @@ def compact_line(line):
         if k in line:
             out[k] = line[k]
     out["roofline"] = _compact_roofline(line.get("roofline"))
-    if "cpu_baseline" in line:      # rank 0 at N = 1 only
+    if line.get("cpu_baseline") is not None:      # rank 0 at N = 1 only
         out["cpu_baseline"] = _compact_cpu(line["cpu_baseline"])
     for k in ("avg_visited", "avg_expanded", "adc_distances_per_s", "graph_build_s", "kernel_fraction_of_step"):
         if k in line and line[k] is not None:

@@ -864,6 +864,23 @@ def test_bench_gpus_flag_spawns_its_own_ranks(J, workload):
         assert abs(line["value"] - 16 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]   # every rank answers every query
 
 
+def test_bench_eight_ranks_sharded_c4_on_the_mock(J):
+    """`bench.py --gpus 8 --workload c4` as ONE command: eight ranks started by the script itself, the engine's own
+    communicator joined by all of them (rccl_ranks == 8, here the shared-memory RCCL shim), eight shards of 1 000 vectors answered
+    through jv_hip_sharded_search_flat; recall against the exact ground truth of the whole 8 000-vector index says the exchange merged
+    the right lists"""
+    argv = ["--gpus", "8", "--workload", "c4", "--n", "1000", "--dim", "128", "--m", "16", "--queries", "16", "--steps", "2",
+            "--warmup", "1", "--eval-queries", "32", "--rerank", "40"]
+    rc, lines, err = _run_bench_on_mock(argv, timeout=1500)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, (lines, err[-2000:])
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and len(line["per_rank_qps"]) == 8 and all(v > 0 for v in line["per_rank_qps"])
+    assert line["config"]["n_vectors"] == 8000 and line["config"]["shard"] == 1000 and line["recall_at_10"] > 0.8
+    assert line["scaling"] == "weak" and "cpu_baseline" not in line and line["roofline"]["bound"] == "lds"
+    assert abs(line["value"] - 16 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]   # every rank answers every query
+
+
 def test_bench_refuses_a_launcher_that_disagrees_with_gpus(J):
     """WORLD_SIZE from the launcher != --gpus: no line at all rather than one with the wrong n_gpus"""
     import subprocess

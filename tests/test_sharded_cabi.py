@@ -28,11 +28,21 @@ def shard_bounds(total, world):
     return [(min(total, g * per), min(total, (g + 1) * per)) for g in range(world)]
 
 
-def run_sharded_equals_single(J, ctx, comm, n_shards_local, rank=0, world=1, N=6000, D=64, M=8, rerank_k=40, check_oracle=True):
+def run_sharded_equals_single(J, ctx, comm, n_shards_local, rank=0, world=1, N=6000, D=64, M=8, rerank_k=40, check_oracle=True,
+                              straddling_ties=False):
     """shared by the CPU and GPU tests: this rank holds n_shards_local consecutive pieces of a (world x n_shards_local)-way split"""
     from jvector_amd.sharded import CShardedFlatSearcher
     vecs, queries, cb = make_problem(11, N=N, D=D, M=M)
     vecs[17] = 0.0                                           # a zero row: cosine NaN must survive the exchange
+    if straddling_ties:
+        # one vector copied into EVERY shard (equal approximate and exact scores on every rank) and the first query aimed at it: the
+        # copies fill the top-k, so the merge and the owners' rerank must break the tie by global id exactly like the single index
+        bounds = shard_bounds(N, world * n_shards_local)
+        for lo, hi in bounds:
+            if hi - lo > 9:
+                vecs[lo + 9] = vecs[7]
+        queries = queries.copy()
+        queries[0] = vecs[7] + np.float32(0.01) * queries[0]
     pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
     vs_all = J.VectorSet(ctx, vecs)
     cv_all = J.PQVectors.encode_and_build(ctx, pq, vs_all)
@@ -111,7 +121,7 @@ def test_sharded_cabi_local_shards_on_the_mock(n_local):
         L._lib = saved
 
 
-def _rank_main(rank, world, id_path, n_local):
+def _rank_main(rank, world, id_path, n_local, N=3000, straddling_ties=False):
     """one rank of the world_size-2 CPU run (its own process: the shim's barrier is process-shared)"""
     os.environ["JVECTOR_HIP_RCCL_PATH"] = build_shim()
     os.environ["JVECTOR_HIP_HOST_THREADS"] = "1"
@@ -131,7 +141,8 @@ def _rank_main(rank, world, id_path, n_local):
             time.sleep(0.001)
         uid = open(id_path, "rb").read()
     comm = Communicator(ctx, rank, world, uid)
-    run_sharded_equals_single(J, ctx, comm, n_local, rank=rank, world=world, N=3000)
+    assert comm.count() == world                                              # what the communicator itself says (ncclCommCount)
+    run_sharded_equals_single(J, ctx, comm, n_local, rank=rank, world=world, N=N, straddling_ties=straddling_ties)
     comm.close()
     ctx.close()
 
@@ -149,6 +160,26 @@ def test_sharded_cabi_two_ranks_on_the_mock(tmp_path, n_local):
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+
+
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+def test_sharded_cabi_eight_ranks_on_the_mock(tmp_path):
+    """BASELINE config 4's world size without the hardware: EIGHT processes, one rank each, through the C ABI's
+    exchange on the shared-memory RCCL shim — 2995 vectors in shards of 375 with an uneven last one (370), a vector copied into
+    every shard so that the top-k of a query is one tie straddling all eight ranks; every rank must return the single index's ids
+    and scores (and the oracle's), for the three similarity functions, with and without the owners' exact rerank"""
+    import build_mock
+    build_mock.build()
+    build_shim()
+    id_path = str(tmp_path / "uid")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_sharded_cabi as T; "
+            "T._rank_main(int(sys.argv[1]), 8, %r, 1, N=2995, straddling_ties=True)") % (ROOT, os.path.join(ROOT, "tests"), id_path)
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(8)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
 
