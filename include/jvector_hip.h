@@ -115,7 +115,12 @@ JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
  *   traversal's coverage), gs_queries_device, gs_queries_retried (re-run on the device with a bigger visited table),
  *   gs_queries_host_fallback (finished by the host searcher after the device passes), gs_ties_resolved_device,
  *   gs_ties_to_host, gs_last_v1_log2, gs_last_workers_per_cu, gs_calls_wgx, gs_last_wgx (1: the last search ran in the workgroup
- *   form), gs_last_pair (1: pair lanes over the row, 2: over the compacted fresh list, 0: one lane per neighbour). */
+ *   form), gs_last_pair (1: pair lanes over the row, 2: over the compacted fresh list, 0: one lane per neighbour), gs_last_ubr (1: the
+ *   last search ran the register-table bound form — option gs_ubr, on by default where it applies: pair-lane kernels, dot product /
+ *   cosine, PQ-96; gs_ubr_trim = candidates pushed between two trims of its queue), gs_ubr_dropped (neighbours that form dropped
+ *   behind their bound, unscored); experimental_build (1: the library was built with make EXPERIMENTAL=1 and also holds the
+ *   measured-and-switched-off variants gs_lutr, gs_quad, gs_ub8, rd_table_free, rd_chunk, rd_square — the default build accepts
+ *   and ignores their options). */
 JV_API int jv_hip_ctx_set_option(jv_ctx *ctx, const char *name, int64_t value);
 JV_API int jv_hip_ctx_clear_option(jv_ctx *ctx, const char *name);
 JV_API int jv_hip_ctx_get_stat(jv_ctx *ctx, const char *name, int64_t *out);

@@ -93,8 +93,14 @@ namespace jv {
 // rd_square = 1 (an experiment, off by default — not yet measured at scale): the robust prune reads the pair table's SQUARE form
 // (rd_body.h rd_node<.., SQ>; DESIGN.md §7: the kernel is bound by L2 -> L1 line fills, and a test's lanes then share one 1 KB row per
 // subspace).  Built once per table, on first use.
+// (rd_table_free / rd_square / rd_chunk are measured-and-switched-off variants: compiled only with JV_EXPERIMENTAL, make EXPERIMENTAL=1)
 const float *pair_table_square(jv_ctx *ctx, jv_pair_table *t)
 {
+#ifndef JV_EXPERIMENTAL
+    (void)ctx;
+    (void)t;
+    return nullptr;
+#else
     if (ctx_opt(ctx, "rd_square", 0) == 0) return nullptr;
     if (t->d_sq) return t->d_sq;
     const int M = t->pq->M, k = t->pq->k;
@@ -110,11 +116,18 @@ const float *pair_table_square(jv_ctx *ctx, jv_pair_table *t)
     }
     t->d_sq = sq;
     return sq;
+#endif
 }
 
 bool retain_diverse_table_free(const jv_ctx *ctx, const jv_pq *pq)
 {
+#ifndef JV_EXPERIMENTAL
+    (void)ctx;
+    (void)pq;
+    return false;
+#else
     return pq->uniform && pq->max_size == 8 && pq->D == 8 * pq->M && pq->k == kClusters && ctx_opt(ctx, "rd_table_free", 0) != 0;
+#endif
 }
 // rd_chunk > 0: selected slots a robust-prune test examines per step of its INCREMENTAL walk (rd_body.h; RdParams::chunk: a
 // candidate remembers the slots it has been tested against and their largest similarity; only new slots are examined, and the walk
@@ -122,7 +135,15 @@ bool retain_diverse_table_free(const jv_ctx *ctx, const jv_pq *pq)
 // kernel's instruction diet): 64 (memory of earlier tests only) changes nothing, 8 is 30 % SLOWER — a prune is a chain of ~200
 // dependent tests per wave and its cost is the length of that chain, not the lanes that take part.  0 (default): every test examines
 // every selected slot in one step.
-int retain_diverse_chunk(const jv_ctx *ctx) { return (int)std::max<long long>(0, std::min<long long>(64, ctx_opt(ctx, "rd_chunk", 0))); }
+int retain_diverse_chunk(const jv_ctx *ctx)
+{
+#ifndef JV_EXPERIMENTAL
+    (void)ctx;
+    return 0;
+#else
+    return (int)std::max<long long>(0, std::min<long long>(64, ctx_opt(ctx, "rd_chunk", 0)));
+#endif
+}
 }  // namespace jv
 extern "C" {
 

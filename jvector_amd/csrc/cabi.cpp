@@ -5,6 +5,7 @@
 // fails with JV_ERR_NO_DEVICE / JV_ERR_HIP when that is impossible.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <mutex>
 
 #include "jv_device.h"
@@ -408,6 +409,14 @@ int jv_hip_ctx_get_stat(jv_ctx *ctx, const char *name, int64_t *out)
 {
     clear_error();
     JV_REQUIRE(ctx && name && out, "ctx_get_stat: NULL argument");
+    if (strcmp(name, "experimental_build") == 0) {   // 1: the library also holds the measured-and-switched-off kernel variants
+#ifdef JV_EXPERIMENTAL
+        *out = 1;
+#else
+        *out = 0;
+#endif
+        return JV_OK;
+    }
     auto it = ctx->stats.find(name);
     *out = it == ctx->stats.end() ? 0 : (int64_t)it->second;
     return JV_OK;

@@ -1362,7 +1362,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // held in the wave's registers, survivors compacted and scored eight lanes each, the candidate tier trimmed to what can still be
     // popped (gs_body.h "UBR").  No LDS beyond the pair form's.  Tables: M x 256 bytes per query of the batch.
     const bool ubr = !so && !wgx && pair && !lutr && !ub8 && occ == 2 && !dev_accept.bits && ctx_opt(ctx, "gs_ubr", kGsUbrDefault) != 0 &&
-                     graph_search_ubr_supported(pq->M, kvsf) && ctx_opt(ctx, "gs_quad", 0) == 0;
+                     graph_search_ubr_supported(pq->M, kvsf)
+#ifdef JV_EXPERIMENTAL
+                     && ctx_opt(ctx, "gs_quad", 0) == 0   // (a launch that asks for the four-lane path of the plain pair kernel means that kernel)
+#endif
+        ;
     const int pair_M = (pair || pairc) ? pq->M : 0;
     int cand_cap = wgx ? wgx_cand_cap : std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", lutr ? 256 : (occ == 4 ? 512 : ((pair || pairc) ? 256 : 1024)))) & ~63;
     while (!wgx && cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
@@ -1608,7 +1612,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // gather instructions, the same number of lane addresses).  Measured on the headline (10M x 768, rerankK 74, profiles/r4_s): 86.0 ms
     // per 131 072 queries against 80.9 ms — the vector-memory path charges lane addresses, not instructions, and the redistribution
     // (14 ds_bpermute, two barriers) comes on top.  Off by default; results are identical either way.
+#ifdef JV_EXPERIMENTAL
     p.quad = ctx_opt(ctx, "gs_quad", 0) != 0 ? 1 : 0;
+#else
+    p.quad = 0;   // (an experimental variant: make EXPERIMENTAL=1)
+#endif
     p.out_ids = d_cand;
     p.out_scores = d_cand_sc;
     p.out_stats = d_stats;

@@ -1566,7 +1566,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 //      the gather INSTRUCTIONS for 61 % of the headline's expansions, the same number of lane addresses — measured
                 //      6 % slower (graph_search.cpp gs_quad): what one lane per neighbour loses against pair lanes (33.7 vs 19.0
                 //      ms) is the length of the dependent per-lane chain, not a per-instruction charge of the memory path.
+#ifdef JV_EXPERIMENTAL   // (gs_quad is a measured-and-switched-off variant: experimental builds and the CPU test harnesses only)
                 constexpr bool QUAD_OK = !UB8 && CH16 % 2 == 0;   // (a lane's M/4 code bytes are whole 8-byte words)
+#else
+                constexpr bool QUAD_OK = false;
+#endif
                 bool quad = false;
                 if constexpr (QUAD_OK) quad = p.quad != 0 && gs_popc(fm) <= 16;
                 if (quad) {

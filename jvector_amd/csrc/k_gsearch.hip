@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     gs_worker<VSF, CH16, false, false, false, false, false, true>(p, (int)blockIdx.x, gs_lds);
 }
 
+#ifdef JV_EXPERIMENTAL   // ---- measured-and-switched-off variants: UB8 (superseded by UBR, k_gsearch_ubr.hip) and the register-resident ADC table
 // UB8 (gs_body.h "UB8"): the pair-lane kernel with an 8-bit upper-bound table of the query's ADC entries in LDS (+ M x 256 bytes per
 // wave): fresh neighbours that provably cannot be popped are dropped without their M codebook gathers.  Dot product / cosine.
 template <int VSF, int CH16, bool PROF>
@@ -91,7 +92,11 @@ static int launch_gs_ub8(hipStream_t s, const GsParams &p, int ch, int workers, 
 }
 
 bool graph_search_ub8_supported(int M, int vsf) { return vsf != VSF_L2 && (M == 16 || M == 32 || M == 48 || M == 64 || M == 96); }
+#else
+bool graph_search_ub8_supported(int, int) { return false; }
+#endif
 
+#ifdef JV_EXPERIMENTAL
 // The register-resident-table form (gs_body.h gs_lut_build / gs_row_sum_lut): ONE wave per SIMD owns all 512 vector registers,
 // 4 M of them hold the query's ADC table, look-ups are ds_bpermute reads.  4 workers per CU instead of 8, but an expansion no
 // longer issues ~190 divergent 16-byte gathers into the CU's vector-memory path.
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     gs_worker<VSF, CH16, false, PROF, true>(p, (int)blockIdx.x, gs_lds);
 }
 
+#endif
 // developer aid (JVECTOR_HIP_GS_PROF=1): the benched instance with per-phase shader-clock counters (GsParams::prof)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_prof_kernel(GsParams p)
 {
@@ -195,6 +201,7 @@ size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int 
     return gs_lds_bytes(D, rerankK, cand_cap, pair_M, evict_cap > 0 ? evict_cap : GS_EVICT_CAP, v1_log2);
 }
 
+#ifdef JV_EXPERIMENTAL
 // Built for the headline shape only (PQ-96 x the three similarity functions; the phase-clock variant for cosine): an experiment
 // kept selectable (option gs_lutr), measured SLOWER than the table-free form — other M would only cost compile time.
 template <int VSF>
@@ -230,6 +237,9 @@ static int launch_gs_lutr(hipStream_t s, const GsParams &p, int ch, int workers,
 }
 
 bool graph_search_lutr_supported(int M) { return M == 96; }
+#else
+bool graph_search_lutr_supported(int) { return false; }
+#endif
 
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy)
 {
@@ -248,6 +258,12 @@ int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, 
         }
         return launch_graph_search_session(s, vsf, p, workers, lds + gs_session_lds_bytes());
     }
+#ifndef JV_EXPERIMENTAL
+    if (p.ub8 || p.lutr) {
+        set_error("graph search kernel: gs_ub8 / gs_lutr are experimental variants (build with make EXPERIMENTAL=1)");
+        return JV_ERR_UNSUPPORTED;
+    }
+#else
     if (p.ub8) {
         if (!p.pair || p.lutr || p.session || p.generic || vsf == VSF_L2) {
             set_error("graph search kernel: the upper-bound form serves the pair-lane kernels, dot product / cosine");
@@ -267,6 +283,7 @@ int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, 
         default: return launch_gs_lutr<VSF_COS>(s, p, ch, workers, lds);
         }
     }
+#endif
     if (p.prof) {
         if (!(vsf == VSF_COS && ch == 6 && p.pair && occupancy < 4)) {
             set_error("graph search kernel: the profiling variant is built for cosine, M = 96, pair-lane scoring only");

@@ -18,6 +18,7 @@ __global__ __launch_bounds__(64) void retain_diverse_kernel(RdParams p)
     for (int node = (int)blockIdx.x; node < p.P; node += (int)gridDim.x) rd_node<false>(p, node, rd_lds);
 }
 
+#ifdef JV_EXPERIMENTAL   // the measured-and-switched-off forms (make EXPERIMENTAL=1)
 // table-free (RdParams::codebooks; uniform 8-dimensional sub-vectors): the entries recomputed from the L2-resident codebook
 // (measured slower than the look-ups, build_score.cpp retain_diverse_table_free: an option, off by default)
 __global__ __launch_bounds__(64) void retain_diverse_tf_kernel(RdParams p)
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(64) void retain_diverse_sq_prof_kernel(RdParams p)
     for (int node = (int)blockIdx.x; node < p.P; node += (int)gridDim.x) rd_node<false, true, true>(p, node, rd_lds);
 }
 
+#endif
 // developer aid (rd_prof = 1): the table kernel with per-phase shader-clock counters (rd_body.h RD_PHASE), printed after every launch
 __global__ __launch_bounds__(64) void retain_diverse_prof_kernel(RdParams p)
 {
@@ -58,7 +60,15 @@ int launch_retain_diverse(hipStream_t s, const jv_ctx *ctx, const RdParams &p)
         return JV_ERR_UNSUPPORTED;
     }
     const bool sqf = !tf && p.sq != nullptr;
+#ifdef JV_EXPERIMENTAL
     const void *kfn = tf ? (const void *)retain_diverse_tf_kernel : (sqf ? (const void *)retain_diverse_sq_kernel : (const void *)retain_diverse_kernel);
+#else
+    if (tf || sqf) {
+        set_error("retain_diverse: the table-free / square-table forms are experimental variants (build with make EXPERIMENTAL=1)");
+        return JV_ERR_UNSUPPORTED;
+    }
+    const void *kfn = (const void *)retain_diverse_kernel;
+#endif
     if (lds > 48 * 1024) JV_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 256)));
     const int blocks = std::min(p.P, ctx->num_cus * per_cu);
@@ -68,10 +78,15 @@ int launch_retain_diverse(hipStream_t s, const jv_ctx *ctx, const RdParams &p)
         JV_HIP_CHECK(hipMemsetAsync(d_prof, 0, sizeof(unsigned long long) * 16, s));
         RdParams pp = p;
         pp.prof = d_prof;
+#ifdef JV_EXPERIMENTAL
         const void *pk = p.sq ? (const void *)retain_diverse_sq_prof_kernel : (const void *)retain_diverse_prof_kernel;
         if (lds > 48 * 1024) JV_HIP_CHECK(hipFuncSetAttribute(pk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (p.sq) hipLaunchKernelGGL(retain_diverse_sq_prof_kernel, dim3(blocks), dim3(64), lds, s, pp);
         else hipLaunchKernelGGL(retain_diverse_prof_kernel, dim3(blocks), dim3(64), lds, s, pp);
+#else
+        if (lds > 48 * 1024) JV_HIP_CHECK(hipFuncSetAttribute((const void *)retain_diverse_prof_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(retain_diverse_prof_kernel, dim3(blocks), dim3(64), lds, s, pp);
+#endif
         JV_HIP_CHECK(hipGetLastError());
         unsigned long long h[16];
         JV_HIP_CHECK(hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -84,9 +99,12 @@ int launch_retain_diverse(hipStream_t s, const jv_ctx *ctx, const RdParams &p)
                 h[9] / tests, h[11] / nodes, (double)(h[12] % 1000000) / tests);
         return JV_OK;
     }
+#ifdef JV_EXPERIMENTAL
     if (tf) hipLaunchKernelGGL(retain_diverse_tf_kernel, dim3(blocks), dim3(64), lds, s, p);
     else if (sqf) hipLaunchKernelGGL(retain_diverse_sq_kernel, dim3(blocks), dim3(64), lds, s, p);
-    else hipLaunchKernelGGL(retain_diverse_kernel, dim3(blocks), dim3(64), lds, s, p);
+    else
+#endif
+    hipLaunchKernelGGL(retain_diverse_kernel, dim3(blocks), dim3(64), lds, s, p);
     JV_HIP_CHECK(hipGetLastError());
     return JV_OK;
 }

@@ -21,6 +21,14 @@
 
 namespace jv {
 
+// the incremental (chunked) test walk is a measured-and-switched-off variant (rd_chunk): compiled only into
+// experimental builds (make EXPERIMENTAL=1) and into the CPU test harnesses
+#ifdef JV_EXPERIMENTAL
+constexpr bool RD_HAVE_CHUNK = true;
+#else
+constexpr bool RD_HAVE_CHUNK = false;
+#endif
+
 GS_FN int64_t rd_tri_row(int r, int k) { return (int64_t)r * k - ((int64_t)r * (r - 1)) / 2; }
 
 // assembleAndSumPQ of (candidate row in LDS, this lane's selected slot column in LDS).  The M table entries are independent
@@ -403,7 +411,7 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
             };
             bool not_diverse;
             const bool dup = gs_ballot(lane < nSlots && snode[lane] == cNode) != 0;
-            if (dup || p.chunk <= 0) {
+            if (dup || !RD_HAVE_CHUNK || p.chunk <= 0) {
                 // every selected slot in parallel, then the first event in ascending candidate index (the candidate's node is in the
                 // selected set — a node listed twice — or incremental tests are off)
                 int ev_idx = 0x7fffffff;  // this lane's event index (none: INT_MAX)

@@ -1,3 +1,5 @@
+// (the test harness keeps the measured-and-switched-off kernel variants compiled: they stay under test)
+#define JV_EXPERIMENTAL 1
 // gs_emu.cpp — compiles the device-resident graph search body (jvector_amd/csrc/gs_body.h) for the lane emulator and
 // exposes one C entry point to the CPU tests.  TEST HARNESS: g++ -O2 -ffp-contract=off, never linked into the product.
 #include <vector>

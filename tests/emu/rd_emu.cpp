@@ -1,3 +1,5 @@
+// (the test harness keeps the measured-and-switched-off kernel variants compiled: they stay under test)
+#define JV_EXPERIMENTAL 1
 // rd_emu.cpp — TEST HARNESS: runs the body of retain_diverse_kernel (jvector_amd/csrc/rd_body.h, unchanged) on the lane
 // emulator, one emulated wavefront per node.
 #include <cmath>

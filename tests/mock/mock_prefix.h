@@ -5,3 +5,8 @@
 #include <cstring>
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+
+// the mock device keeps the measured-and-switched-off kernel variants compiled (make EXPERIMENTAL=1 on the GPU side): they stay under test
+#ifndef JV_EXPERIMENTAL
+#define JV_EXPERIMENTAL 1
+#endif

@@ -158,16 +158,18 @@ def test_retain_diverse_gpu():
         run_through_cabi(J, ctx, CASES[1:2] + CASES[6:] + [(15, 3000, 768, 96, 64, 100, 32, 1.2), (16, 1500, 1536, 192, 32, 100, 32, 1.2)])
     finally:
         ctx.set_option("rd_split", None)
-    ctx.set_option("rd_square", 1)       # the square form of the pair table (an experiment, off by default)
-    try:
-        run_through_cabi(J, ctx, CASES[1:3] + CASES[6:8] + [(15, 3000, 768, 96, 64, 100, 32, 1.2)])
-    finally:
-        ctx.set_option("rd_square", None)
-    ctx.set_option("rd_table_free", 1)   # the table-free form of the kernel (off by default: measured slower): the same selections
-    try:
-        run_through_cabi(J, ctx, CASES[:2] + [(15, 3000, 768, 96, 64, 100, 32, 1.2), (16, 1500, 1536, 192, 32, 100, 32, 1.2)])
-    finally:
-        ctx.set_option("rd_table_free", None)
+    # the measured-and-switched-off forms (square pair table, table-free entries, incremental test walk) are compiled into experimental
+    # builds only (make EXPERIMENTAL=1); the default library accepts and ignores their options — the selections are the same either way
+    for opt, cases in (("rd_square", CASES[1:3] + CASES[6:8] + [(15, 3000, 768, 96, 64, 100, 32, 1.2)]),
+                       ("rd_table_free", CASES[:2] + [(15, 3000, 768, 96, 64, 100, 32, 1.2), (16, 1500, 1536, 192, 32, 100, 32, 1.2)]),
+                       ("rd_chunk", CASES[1:3])):
+        if not ctx.stat("experimental_build") and opt != "rd_square":
+            continue
+        ctx.set_option(opt, 8 if opt == "rd_chunk" else 1)
+        try:
+            run_through_cabi(J, ctx, cases)
+        finally:
+            ctx.set_option(opt, None)
     # unsupported: candidate codes that do not fit LDS (1000 x 192 B > 160 KB) are refused, not truncated
     opq, codes, tri, cand, sc, count, before = make_case(77, 1200, 1536, 192, 2, 1000, 0, 32)
     pq = J.ProductQuantization.from_codebooks(ctx, 1536, 192, opq.codebooks)

@@ -48,6 +48,7 @@ def test_device_traversal_matches_oracle(ctx, levels, use_fused, D, M):
                 wi, ws, wst = og.search(opq, codes, v if rerank else None, q, int(vsf), top_k, rk, fused=use_fused)
                 # the one-wave kernels, the workgroup form, and what AUTO picks for a batch this small (the workgroup form)
                 # (and the one-wave kernels' four-lanes-per-neighbour path, gs_quad: every expansion of these degree-16 graphs)
+                # (gs_quad is compiled into experimental builds only: the default library ignores the option and runs the plain pair form)
                 for form in (0, 1, None, "quad"):
                     ctx.set_option("gs_wgx", 0 if form == "quad" else form)
                     ctx.set_option("gs_quad", 1 if form == "quad" else None)
@@ -287,6 +288,8 @@ def test_auto_traversal_reports_the_host_fallback(ctx, capfd):
 def test_register_resident_table_kernel(ctx, levels, use_fused, D, M, deg):
     """gs_lutr = 1: the traversal kernel whose ADC table lives in the wave's registers + LDS (graph_search_lutr_kernel) — ids,
     scores and counters equal the oracle's (and therefore the table-free kernel's) for every similarity function"""
+    if not ctx.stat("experimental_build"):
+        pytest.skip("gs_lutr is a measured-and-switched-off variant: compiled with make EXPERIMENTAL=1 only (evidence: profiles/r3_*, DESIGN.md §4)")
     v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 7 * levels + M, 4000, D, M, levels, use_fused, deg=deg)
     og = O.OracleGraph(len(v), lv, entry, entry_level)
     s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
@@ -387,6 +390,8 @@ def test_upper_bound_table_kernel(ctx, levels, D, M, deg, N):
     """gs_ub8 = 1: the pair-lane kernel that drops fresh neighbours an 8-bit upper-bound table proves unpoppable (dot product / cosine,
     FusedPQ): ids, scores and both counters equal the oracle's — dropped neighbours still count as visited — at rerankK values where
     the thresholds become active early; euclidean searches and filtered searches fall back to the plain kernel"""
+    if not ctx.stat("experimental_build"):
+        pytest.skip("gs_ub8 is superseded by the register-table form (gs_ubr, tests/test_zz_ubr_gpu.py): compiled with make EXPERIMENTAL=1 only")
     v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 13 * levels + M, N, D, M, levels, True, deg=deg)
     og = O.OracleGraph(len(v), lv, entry, entry_level)
     s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
