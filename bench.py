@@ -575,9 +575,11 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
     ctx.sync()
     encode_s = time.perf_counter() - t0
     ctx.profile(True)
+    rd0 = (ctx.stat("rd_tests"), ctx.stat("rd_pairs"))
     nbrs, entry, bstats = build_vamana(ctx, pq, cv, base, VSF, max_degree=args.degree, beam_width=args.build_beam, alpha=args.build_alpha, log=log,
                                        vector_set=vs, overflow=args.build_overflow, max_batch=args.build_max_batch)
-    prof = {r: ctx.profile_read(r) for r in ("gsearch", "adc")}
+    prof = {r: ctx.profile_read(r) for r in ("gsearch", "adc", "prune")}
+    rd_tests, rd_pairs = ctx.stat("rd_tests") - rd0[0], ctx.stat("rd_pairs") - rd0[1]   # the robust prune's own work counters
     ctx.profile(False)
     barrier()
     total_s = time.perf_counter() - t_all
@@ -604,10 +606,24 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
     roofline = {"bound": "hbm", "kernel": f"graph_search_pairc_kernel<COSINE,CH16={M // 16}> over the builder's device-resident adjacency (64-wide working rows: one lane "
                 f"per neighbour probes the visited set, the fresh ones are scored {2 if M <= 96 else 4} lanes each; PQDecoder.similarityTo on the neighbours' own codes, table-free)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "scored_nodes": bstats["visited"], "expansions": bstats["expanded"], "bytes_per_scored_node": unit, "kernel_ms": g_ms,
-                "launches": g_n, "prune_and_pair_score_kernel_ms": prof["adc"][0],
+                "launches": g_n, "prune_and_pair_score_kernel_ms": prof["adc"][0] + prof["prune"][0],
                 "note": "algorithmic bytes = scored nodes x (M + 8) (SURVEY §8d: ADC gather by ordinal); physically the kernel is bound by the L2 "
                         "gather rate of its table-free scoring, like the search kernel of the headline (DESIGN.md §4); the robust-prune / pair-score "
                         "kernels gather M pair-table entries of 4 B per (candidate, selected) pair from L2 / MALL"}
+    # the kernel that dominates the rest of the build: the robust prune (VamanaDiversityProvider.retainDiverse over the candidate lists and
+    # the overflowed back-link lists).  Unit: one (candidate, selected neighbour) pair of an isDiverse test = M pair-table
+    # entries of 4 B, gathered from the M x 256 x 257 / 2 x 4 B triangular table (12.6 MB at PQ-96, 25.3 MB at PQ-192: L2 / MALL resident,
+    # not HBM) — priced against the measured 32-byte L2 gather ceiling of this GPU (tools/gather_bench.hip: 396 G rows/s), one row per entry.
+    p_ms, p_n = prof["prune"]
+    entries_per_s = rd_pairs * M / (p_ms / 1e3) if p_ms > 0 else 0.0
+    prune_roofline = {"bound": "l2_gather", "kernel": "retain_diverse_kernel (one wavefront per candidate list; a test's lanes each gather the M "
+                      "pair-table entries of one selected slot — 4 B from a 128-byte line of the L2 / Infinity-Cache resident triangular table)",
+                      "achieved": entries_per_s / 1e9, "peak": 395.9, "unit": "G gathered entries/s", "frac": entries_per_s / 395.9e9, "traffic": None,
+                      "pairs": rd_pairs, "tests": rd_tests, "entries_per_pair": M, "bytes_per_pair": 4 * M, "kernel_ms": p_ms, "launches": p_n,
+                      "table_bytes": M * 256 * 257 // 2 * 4, "algorithmic_GBps": rd_pairs * 4.0 * M / (p_ms / 1e3) / 1e9 if p_ms > 0 else 0.0,
+                      "note": "pairs / tests are counted by the kernel itself (jv_hip_ctx_get_stat rd_pairs / rd_tests); the ceiling is the divergent-"
+                              "gather rate of the vector-memory pipe for L2 hits (profiles/r2_gather_bench.log), the table's MALL share makes the real "
+                              "ceiling lower (DESIGN.md §7)"}
     line = {"metric": "index build: nodes/s (batched Vamana, PQ scoring) incl. PQ training + encode", "value": N * world / total_s,
             "unit": "nodes/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "per_rank_nodes_per_s": per_rank, "steps": 1, "warmup": 0,
             "ms_per_step": total_s * 1e3, "higher_is_better": True,
@@ -621,7 +637,7 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
                         "backlink": bstats["backlink_s"], "total": total_s},
             "build": {"batches": bstats["batches"], "reprunes": bstats["reprunes"], "avg_degree": bstats["avg_degree"]},
             "recall_at_10_by_rerankK": rec, "recall_eval_queries": int(eval_q.shape[0]),
-            "roofline": roofline, "cpu_baseline": None}
+            "roofline": roofline, "prune_roofline": prune_roofline, "prune_roofline_frac": prune_roofline["frac"], "cpu_baseline": None}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_build(pq.codebooks(), D, M, cv.get(0, N), nbrs_h, entry, base, VSF, args.degree, args.build_beam, 1.2)
     return line

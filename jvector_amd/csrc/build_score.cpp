@@ -195,8 +195,13 @@ int jv_hip_retain_diverse(jv_ctx *ctx, const jv_pair_table *t, const jv_codes *c
     p.selected_out = (int32_t *)base;
     p.n_selected_out = (int32_t *)(base + o_cnt);
     p.short_edges_out = (float *)(base + o_se);
+    if (!ctx->d_rd_counts.ptr) {
+        JV_TRY(ctx->d_rd_counts.reserve(2 * sizeof(unsigned long long)));
+        JV_HIP_CHECK(hipMemsetAsync(ctx->d_rd_counts.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    }
+    p.counts = (unsigned long long *)ctx->d_rd_counts.ptr;
     {
-        ProfScope ps(ctx, R_ADC);
+        ProfScope ps(ctx, R_PRUNE);
         JV_TRY(launch_retain_diverse(ctx->stream, ctx, p));
     }
     JV_HIP_CHECK(hipMemcpyAsync(selected_out, p.selected_out, sel_bytes, hipMemcpyDefault, ctx->stream));

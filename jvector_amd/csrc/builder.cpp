@@ -94,7 +94,12 @@ int run_retain(jv_ctx *ctx, jv_builder *b, const int32_t *d_cand, const float *d
     p.selected_out = d_sel;
     p.n_selected_out = d_nsel;
     p.short_edges_out = nullptr;
-    ProfScope ps(ctx, R_ADC);
+    if (!ctx->d_rd_counts.ptr) {   // (zeroed once per context: the counters accumulate; jv_hip_ctx_get_stat "rd_tests" / "rd_pairs" reads them)
+        JV_TRY(ctx->d_rd_counts.reserve(2 * sizeof(unsigned long long)));
+        JV_HIP_CHECK(hipMemsetAsync(ctx->d_rd_counts.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    }
+    p.counts = (unsigned long long *)ctx->d_rd_counts.ptr;
+    ProfScope ps(ctx, R_PRUNE);   // (its own region: the pair-score kernel of the backlinks stays under "adc")
     return launch_retain_diverse(ctx->stream, ctx, p);
 }
 

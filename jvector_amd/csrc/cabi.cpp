@@ -282,6 +282,8 @@ int jv_hip_ctx_destroy(jv_ctx *ctx)
     ctx->d_gs_big.release();
     ctx->d_nvq_q.release();
     ctx->d_gs_extra.release();
+    ctx->d_gs_ubr.release();
+    ctx->d_rd_counts.release();
     for (auto &e : ctx->prof_pending) {
         (void)hipEventDestroy(e.start);
         (void)hipEventDestroy(e.stop);
@@ -338,7 +340,7 @@ int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, i
 {
     clear_error();
     JV_REQUIRE(ctx && region, "NULL argument");
-    static const char *names[R_COUNT] = {"adc", "topk", "exact", "lut", "encode", "norms", "sample", "gsearch"};
+    static const char *names[R_COUNT] = {"adc", "topk", "exact", "lut", "encode", "norms", "sample", "gsearch", "prune"};
     int r = -1;
     for (int i = 0; i < R_COUNT; ++i)
         if (strcmp(names[i], region) == 0) r = i;
@@ -415,6 +417,17 @@ int jv_hip_ctx_get_stat(jv_ctx *ctx, const char *name, int64_t *out)
 #else
         *out = 0;
 #endif
+        return JV_OK;
+    }
+    if (strcmp(name, "rd_tests") == 0 || strcmp(name, "rd_pairs") == 0) {   // the robust prune's device-side work counters
+        *out = 0;
+        if (ctx->d_rd_counts.ptr) {
+            unsigned long long h[2] = {0, 0};
+            JV_TRY(use_device(ctx->device));
+            JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            JV_HIP_CHECK(hipMemcpy(h, ctx->d_rd_counts.ptr, sizeof(h), hipMemcpyDeviceToHost));
+            *out = (int64_t)h[name[3] == 't' ? 0 : 1];
+        }
         return JV_OK;
     }
     auto it = ctx->stats.find(name);

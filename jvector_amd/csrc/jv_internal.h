@@ -70,7 +70,7 @@ struct Buffer {
 }  // namespace jv
 
 namespace jv {
-enum Region : int { R_ADC = 0, R_TOPK, R_EXACT, R_LUT, R_ENCODE, R_NORMS, R_SAMPLE, R_GSEARCH, R_COUNT };
+enum Region : int { R_ADC = 0, R_TOPK, R_EXACT, R_LUT, R_ENCODE, R_NORMS, R_SAMPLE, R_GSEARCH, R_PRUNE, R_COUNT };
 struct ProfEvent {
     int region;
     hipEvent_t start, stop;
@@ -94,6 +94,7 @@ struct jv_ctx {
     jv::Buffer d_gs_visited, d_gs_spill, d_gs_out, d_gs_mask, d_gs_big;
     jv::Buffer d_gs_extra;   // session kernels: the evictedResults a resume() pushes back (graph_search.cpp)
     jv::Buffer d_gs_ubr;     // UBR: the batch's upper-bound tables (M x 256 bytes per query) + 4 floats of meta per query
+    jv::Buffer d_rd_counts;  // robust prune: {isDiverse tests, (candidate, selected slot) pairs summed by them}, accumulated by every launch
     jv::Buffer d_nvq_q;   // NVQ rerank: shifted queries + per-query scalars (nvq.cpp)
     // host batched graph searcher: worker pool (graph_search.cpp owns the type) and its destructor
     void *host_pool = nullptr;

@@ -15,7 +15,12 @@ namespace jv {
 __global__ __launch_bounds__(64) void retain_diverse_kernel(RdParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char rd_lds[];
-    for (int node = (int)blockIdx.x; node < p.P; node += (int)gridDim.x) rd_node<false>(p, node, rd_lds);
+    unsigned long long work2[2] = {0, 0};   // (wave-uniform: tests and (candidate, selected slot) pairs of this block's nodes)
+    for (int node = (int)blockIdx.x; node < p.P; node += (int)gridDim.x) rd_node<false>(p, node, rd_lds, work2);
+    if (p.counts && threadIdx.x == 0) {
+        atomicAdd(p.counts, work2[0]);
+        atomicAdd(p.counts + 1, work2[1]);
+    }
 }
 
 #ifdef JV_EXPERIMENTAL   // the measured-and-switched-off forms (make EXPERIMENTAL=1)

@@ -272,7 +272,7 @@ GS_FN int rd_wave_min(int v)
 #define GS_CLOCK() 0ull   // (the CPU lane emulator has no clock)
 #endif
 template <bool TF = false, bool PROF = false, bool SQ = false>
-GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
+GS_FN void rd_node(const RdParams &p, int node_idx, char *lds, unsigned long long *work2 = nullptr /* += {tests, pairs} (wave-uniform) */)
 {
     const float *table = SQ ? p.sq : p.tri;   // (SQ: the square form of the same entries)
     unsigned long long pf[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -382,6 +382,10 @@ GS_FN void rd_node(const RdParams &p, int node_idx, char *lds)
             if (PROF) {
                 pf[8] += 1;
                 pf[9] += (unsigned long long)nSlots;
+            }
+            if (work2) {
+                work2[0] += 1;
+                work2[1] += (unsigned long long)nSlots;
             }
             // ---- isDiverse.  Events of the reference's walk over the selected set (ascending candidate index): the candidate itself
             //      -> diverse, a violation -> not diverse; the first event decides.  Lane j owns selected slot j.

@@ -29,6 +29,7 @@ struct RdParams {
     int32_t *n_selected_out;   // [P]
     unsigned long long *prof;  // rd_node<.., PROF = true>: 16 counters (rd_body.h RD_PHASE), else nullptr
     float *short_edges_out;    // [P] or nullptr: nSelected after the alpha = 1.0 pass / maxDegree (NaN if the loop never ran)
+    unsigned long long *counts; // [2] or nullptr: += {isDiverse tests, selected slots examined by them = (candidate, selected) pairs summed}
 };
 
 // LDS bytes one wavefront needs: candidate code rows, transposed selected codes, self magnitudes, slot bookkeeping
