@@ -1770,7 +1770,8 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                         const float t = gs_key_score(s.res_min);
                         if (t > ub_T) ub_T = t;
                     }
-                    if (ubr_since >= p.ubr_trim && s.cand_n > 0 && s.cand_n + s.res_n >= rk) {
+                    // (also before the LDS tier would have to spill: a partition costs more than a trim and frees less)
+                    if ((ubr_since >= p.ubr_trim || s.cand_n + 40 > p.cand_cap) && s.cand_n > 0 && s.cand_n + s.res_n >= rk) {
                         unsigned long long tc0 = 0;
                         if (PROF) tc0 = GS_CLOCK();
                         gs_ubr_trim(s, rk, ub_T);
