@@ -328,31 +328,32 @@ GS_FN float gs_lut_entry_from(const gs_f4 c0, const gs_f4 c1, const float *q)
     return ent;
 }
 
-// two table entries at once: rows (a0, a1) x qa and (b0, b1) x qb.  The GPU build (GS_HAVE_PK_F32, gs_wave_hip.h) runs the two chains in
-// the halves of v_pk_mul_f32 / v_pk_add_f32 — per half the same IEEE operations in the same order as gs_lut_entry_from.
+// one table entry with its eight products formed two at a time: v_pk_mul_f32 on the register pairs the 16-byte loads delivered (the
+// row's (x, y) / (z, w) against the query's — no operand has to be moved), then the reference's chain of eight additions in ascending
+// dimension.  Same IEEE operations, same order, same bits as gs_lut_entry_from; 12 instructions instead of 16.  (Running TWO entries'
+// chains in the halves of packed operations costs more than it saves: the operand pairs would have to be assembled with moves — 144
+// v_mov for 96 packed operations in the first version of the UBR scoring loop.)
 template <int VSF>
-GS_FN void gs_lut_entry_pair(const gs_f4 a0, const gs_f4 a1, const float *qa, const gs_f4 b0, const gs_f4 b1, const float *qb, float &ea, float &eb)
+GS_FN float gs_lut_entry_pk(const gs_f4 c0, const gs_f4 c1, const float *q)
 {
 #ifdef GS_HAVE_PK_F32
     if (VSF != 0) {
-        const gs_f4 qa0 = reinterpret_cast<const gs_f4 *>(qa)[0], qa1 = reinterpret_cast<const gs_f4 *>(qa)[1];
-        const gs_f4 qb0 = reinterpret_cast<const gs_f4 *>(qb)[0], qb1 = reinterpret_cast<const gs_f4 *>(qb)[1];
-        gs_pk2 acc = {0.0f, 0.0f};
-        acc = acc + gs_pk2{a0.x, b0.x} * gs_pk2{qa0.x, qb0.x};
-        acc = acc + gs_pk2{a0.y, b0.y} * gs_pk2{qa0.y, qb0.y};
-        acc = acc + gs_pk2{a0.z, b0.z} * gs_pk2{qa0.z, qb0.z};
-        acc = acc + gs_pk2{a0.w, b0.w} * gs_pk2{qa0.w, qb0.w};
-        acc = acc + gs_pk2{a1.x, b1.x} * gs_pk2{qa1.x, qb1.x};
-        acc = acc + gs_pk2{a1.y, b1.y} * gs_pk2{qa1.y, qb1.y};
-        acc = acc + gs_pk2{a1.z, b1.z} * gs_pk2{qa1.z, qb1.z};
-        acc = acc + gs_pk2{a1.w, b1.w} * gs_pk2{qa1.w, qb1.w};
-        ea = acc.x;
-        eb = acc.y;
-        return;
+        const gs_f4 q0 = reinterpret_cast<const gs_f4 *>(q)[0], q1 = reinterpret_cast<const gs_f4 *>(q)[1];
+        const gs_pk2 p01 = gs_pk2{c0.x, c0.y} * gs_pk2{q0.x, q0.y}, p23 = gs_pk2{c0.z, c0.w} * gs_pk2{q0.z, q0.w};
+        const gs_pk2 p45 = gs_pk2{c1.x, c1.y} * gs_pk2{q1.x, q1.y}, p67 = gs_pk2{c1.z, c1.w} * gs_pk2{q1.z, q1.w};
+        float ent = 0.0f;
+        ent += p01.x;
+        ent += p01.y;
+        ent += p23.x;
+        ent += p23.y;
+        ent += p45.x;
+        ent += p45.y;
+        ent += p67.x;
+        ent += p67.y;
+        return ent;
     }
 #endif
-    ea = gs_lut_entry_from<VSF>(a0, a1, qa);
-    eb = gs_lut_entry_from<VSF>(b0, b1, qb);
+    return gs_lut_entry_from<VSF>(c0, c1, q);
 }
 
 template <int VSF, int CH16>
@@ -1480,8 +1481,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                             // lane's role between two look-ups makes the compiler wait for each pair of loads in turn: 13.9 k -> 9.7 k
                             // clocks per expansion; the whole share at once — 24 x 16 bytes — does not fit next to the table's registers:
                             // the compiler then parks 16 of them in scratch around every pass, measured 60.6 vs 57.3 ms, profiles/r5_f).
-                            // Two entries at a time in the halves of packed f32 operations (each chain still multiplies and adds its
-                            // eight products in ascending dimension, one rounding per operation: the same bits).
+                            // An entry's products two at a time (gs_lut_entry_pk), its additions in the reference's order: the same bits.
                             float v[SUBS];
 #pragma unroll
                             for (int h2 = 0; h2 < 2; ++h2) {
@@ -1495,10 +1495,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                                     c1[kk] = cp[1];
                                 }
 #pragma unroll
-                                for (int kk = 0; kk < SUBS / 2; kk += 2) {
+                                for (int kk = 0; kk < SUBS / 2; ++kk) {
                                     const int k = h2 * (SUBS / 2) + kk;
-                                    gs_lut_entry_pair<VSF>(c0[kk], c1[kk], qs + (t * SUBS + k) * 8, c0[kk + 1], c1[kk + 1], qs + (t * SUBS + k + 1) * 8,
-                                                           v[k], v[k + 1]);
+                                    v[k] = gs_lut_entry_pk<VSF>(c0[kk], c1[kk], qs + (t * SUBS + k) * 8);
                                 }
                             }
                             if (t == 0) {

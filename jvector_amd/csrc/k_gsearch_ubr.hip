@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
             for (int j = 0; j < UBR_QB; ++j) {
                 const float *q = qs + j * D + m * 8;
                 float e4[4];
-                gs_lut_entry_pair<VSF>(c0[0], c1[0], q, c0[1], c1[1], q, e4[0], e4[1]);
-                gs_lut_entry_pair<VSF>(c0[2], c1[2], q, c0[3], c1[3], q, e4[2], e4[3]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e4[k] = gs_lut_entry_pk<VSF>(c0[k], c1[k], q);
                 const bool bad = !(e4[0] - e4[0] == 0.0f) || !(e4[1] - e4[1] == 0.0f) || !(e4[2] - e4[2] == 0.0f) || !(e4[3] - e4[3] == 0.0f);
                 // the lane's extremes as floats (a NaN marks the query unusable anyway), ONE conversion each to the order-preserving
                 // integer image, six single-instruction DPP steps per reduction
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
                 const float l = lo[j * M + m];
                 const float *q = qs + j * D + m * 8;
                 float e4[4];
-                gs_lut_entry_pair<VSF>(c0[half][0], c1[half][0], q, c0[half][1], c1[half][1], q, e4[0], e4[1]);
-                gs_lut_entry_pair<VSF>(c0[half][2], c1[half][2], q, c0[half][3], c1[half][3], q, e4[2], e4[3]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e4[k] = gs_lut_entry_pk<VSF>(c0[half][k], c1[half][k], q);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float e = e4[k];
