@@ -1165,10 +1165,25 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         if constexpr (CH16 == 0) {
             sc = gs_row_sum_any<VSF>(p, qs, p.codes + (int64_t)e * p.M);
         } else {
-            gs_u4 we[CW];
-            gs_load_row<CW>(p.codes + (int64_t)e * p.M, we);
-            if constexpr (LUTR) sc = gs_row_sum_lut<CW>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, we);
-            else sc = gs_row_sum<VSF, CW>(p.codebooks, qs, we);
+            if constexpr (LUTR) {
+                gs_u4 we[CW];
+                gs_load_row<CW>(p.codes + (int64_t)e * p.M, we);
+                sc = gs_row_sum_lut<CW>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, we);
+            } else {
+                // The entry row's M table entries are formed by the lanes side by side (lane l: subspaces l, l + 64, ...) and parked in
+                // the still empty candidate tier; every lane then adds them in ascending m — assembleAndSum's order, the same bits.
+                // (One lane walking the row waited for M dependent-in-practice L2 round trips: ~55 k of a query's ~2 M clocks, round 5.)
+                constexpr int M_ = CH16 * 16;
+                static_assert(M_ * 4 <= 128 * 8, "the candidate tier (>= 128 keys) is the scratch of the entry row");
+                float *ent = reinterpret_cast<float *>(s.cand);
+                const uint8_t *erow = p.codes + (int64_t)e * p.M;
+                for (int m = lane; m < M_; m += 64) ent[m] = gs_lut_entry<VSF>(p.codebooks, qs, m, (int)erow[m]);
+                gs_barrier();
+                sc = 0.0f;
+#pragma unroll 8
+                for (int m = 0; m < M_; ++m) sc += ent[m];
+                gs_barrier();
+            }
         }
         sc = gs_finish<VSF>(sc, (VSF == 2) ? p.code_norms[e] : 0.0f, query_mag);
         if (lane == 0) s.cand[0] = gs_key(e, sc);
