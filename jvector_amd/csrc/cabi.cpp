@@ -283,6 +283,7 @@ int jv_hip_ctx_destroy(jv_ctx *ctx)
     ctx->d_nvq_q.release();
     ctx->d_gs_extra.release();
     ctx->d_gs_ubr.release();
+    ctx->d_bq_work.release();
     ctx->d_rd_counts.release();
     for (auto &e : ctx->prof_pending) {
         (void)hipEventDestroy(e.start);
@@ -357,7 +358,7 @@ int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, i
 namespace jv {
 namespace {
 // every option a context understands; the environment default of option x is JVECTOR_HIP_<X>
-const char *const kOptions[] = {"graph_traversal", "gs_occ", "gs_pair", "gs_pairc", "gs_quad", "rd_table_free", "rd_chunk", "rd_split", "rd_wide_stage", "rd_prof", "rd_square", "bl_insert_alpha_x100", "bl_improve_beam", "gs_cand_cap", "gs_waves_per_cu", "gs_vcap_log2", "gs_v1_log2", "gs_prefetch", "gs_lutr", "gs_generic", "gs_wgx", "gs_wgx_waves", "gs_wgx_slots", "gs_wgx_depth", "gs_wgx_per_cu", "gs_wgx_lut_m", "gs_ub8", "gs_ub8_per_cu", "gs_ubr", "gs_ubr_trim",
+const char *const kOptions[] = {"graph_traversal", "gs_occ", "gs_pair", "gs_pairc", "gs_quad", "rd_table_free", "rd_chunk", "rd_split", "rd_wide_stage", "rd_prof", "rd_square", "bl_insert_alpha_x100", "bl_improve_beam", "gs_cand_cap", "gs_waves_per_cu", "gs_vcap_log2", "gs_v1_log2", "gs_prefetch", "gs_lutr", "gs_generic", "gs_wgx", "gs_wgx_waves", "gs_wgx_slots", "gs_wgx_depth", "gs_wgx_per_cu", "gs_wgx_lut_m", "gs_ub8", "gs_ub8_per_cu", "gs_ubr", "gs_ubr_trim", "adc_bq",
                                 "gs_grow", "gs_retry", "gs_prof", "gs_tie_check", "gs_push_log", "gs_push_log_cap", "graph_timing",
                                 "no_filter", "quiet"};
 std::string env_name(const char *name)
@@ -1387,7 +1388,11 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
     bool done1 = false;
     const bool mq = adc_mq_supported(codes->M, codes->d_codes) && Q >= 2;
     if (mq && N >= (1 << 18) && (int64_t)k1 * 64 <= N && ctx_opt(ctx, "no_filter", 0) == 0) {
-        const int64_t c_target = std::max<int64_t>(8 * (int64_t)k1, 4096);
+        // expected candidates per query behind the threshold.  The threshold is the k_s-th best of a strided sample (k_s = c_target x
+        // sample / N >= 16 and >= 100 at these sizes), so the count it yields scatters by ~1 / sqrt(k_s) <= 10 % around c_target: 3 x
+        // rerankK leaves the `>= k1` check twenty standard deviations of room (round 4 used 8 x: 2.7 x the lists, the gather and the
+        // top-k input for nothing — at C2's rerankK 3200 that was 0.6 ms of a 3 ms step)
+        const int64_t c_target = std::max<int64_t>(3 * (int64_t)k1, 4096);
         int64_t S_target = std::max<int64_t>(16384, next_pow2_i64(32 * N / c_target));
         const int64_t stride = std::max<int64_t>(1, N / S_target);
         const int64_t S = N / stride;  // sampled rows: 0, stride, 2*stride, ...
@@ -1415,6 +1420,56 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
                 ProfScope ps(ctx, R_TOPK);
                 JV_TRY(launch_topk(ctx->stream, ctx, d_samp, nullptr, Q, S, S, 0, k_s, d_ks_ids, d_ks_sc, ctx->d_scratch.ptr));
             }
+            // adc_bq (default 1): the filter in two stages — a 7-bit bound scan for sixteen queries per LDS word, then exact scores of the
+            // survivors only (k_adc_bq.hip); the lists hold a superset of {score >= tau} with exact scores, so the top-k1 below is the
+            // same.  A query whose bound keeps more than cap2 candidates (or that has no usable bound) sends the call to the exact filter.
+            bool bq_done = false;
+            if (adc_bq_supported(codes->M, codes->d_codes) && ctx_opt(ctx, "adc_bq", 1) != 0) {
+                // (the exact filter aims at cap / 4 candidates per query; the bound keeps a few more: the same list size leaves 2-3x room)
+                const int cap2 = cap;
+                const size_t b_cap2 = sizeof(float) * (size_t)Q * cap2;
+                JV_TRY(ctx->d_bq_work.reserve(adc_bq_scratch_bytes(Q, codes->M) + 2 * b_cap2 + 2 * sizeof(unsigned int) * (size_t)Q + 1024));
+                char *wb = (char *)ctx->d_bq_work.ptr;
+                int32_t *d_b_ids = (int32_t *)wb;
+                float *d_b_sc = (float *)(wb + b_cap2);
+                unsigned int *d_b_cnt2 = (unsigned int *)(wb + 2 * b_cap2);
+                unsigned int *d_b_cnt = d_b_cnt2 + Q;
+                void *d_b_work = wb + ((2 * b_cap2 + 2 * sizeof(unsigned int) * (size_t)Q + 255) & ~(size_t)255);
+                JV_TRY(ctx->h_out.reserve(sizeof(unsigned int) * (size_t)Q));
+                {
+                    ProfScope ps(ctx, R_ADC);
+                    JV_TRY(launch_adc_bq_scan(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes, codes->d_norms, 0, N,
+                                              d_ks_sc + (k_s - 1), k_s, d_b_ids, d_b_cnt2, cap2, d_b_work));
+                }
+                // one small D2H + sync: the longest survivor list bounds the exact stage's work; a list that outgrew its slots -> fall back
+                JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_b_cnt2, sizeof(unsigned int) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+                JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                unsigned int longest = 0;
+                bool ok = true;
+                for (int q = 0; q < Q; ++q) {
+                    const unsigned int c = ((const unsigned int *)ctx->h_out.ptr)[q];
+                    longest = std::max(longest, c);
+                    ok = ok && c >= (unsigned int)k1 && c <= (unsigned int)cap2;
+                }
+                if (ok) {
+                    const int slots = (int)std::min<int64_t>(cap2, ((int64_t)longest + 63) & ~(int64_t)63);
+                    {
+                        ProfScope ps(ctx, R_ADC);
+                        JV_TRY(launch_adc_bq_exact(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes, codes->d_norms, N,
+                                                   d_ks_sc + (k_s - 1), k_s, d_b_ids, d_b_sc, d_b_cnt2, d_b_cnt, cap2, slots));
+                    }
+                    JV_HIP_CHECK(hipMemcpyAsync(ctx->h_out.ptr, d_b_cnt, sizeof(unsigned int) * (size_t)Q, hipMemcpyDeviceToHost, ctx->stream));
+                    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    for (int q = 0; q < Q; ++q) ok = ok && ((const unsigned int *)ctx->h_out.ptr)[q] >= (unsigned int)k1;
+                }
+                ctx_stat_add(ctx, ok ? "adc_bq_calls" : "adc_bq_fallbacks", 1);
+                if (ok) {
+                    ProfScope ps(ctx, R_TOPK);
+                    JV_TRY(launch_topk(ctx->stream, ctx, d_b_sc, d_b_ids, Q, cap2, cap2, 0, k1, d_k1_ids, d_k1_sc, ctx->d_scratch.ptr, d_b_cnt2));
+                    done1 = bq_done = true;
+                }
+            }
+            if (!bq_done) {
             JV_HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(unsigned int) * (size_t)Q, ctx->stream));
             {
                 ProfScope ps(ctx, R_ADC);
@@ -1434,6 +1489,7 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
                 JV_TRY(launch_topk(ctx->stream, ctx, d_f_sc, d_f_ids, Q, cap, cap, 0, k1, d_k1_ids, d_k1_sc,
                                    ctx->d_scratch.ptr, d_cnt));
                 done1 = true;
+            }
             }
         }
     }

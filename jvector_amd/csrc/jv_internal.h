@@ -94,6 +94,7 @@ struct jv_ctx {
     jv::Buffer d_gs_visited, d_gs_spill, d_gs_out, d_gs_mask, d_gs_big;
     jv::Buffer d_gs_extra;   // session kernels: the evictedResults a resume() pushes back (graph_search.cpp)
     jv::Buffer d_gs_ubr;     // UBR: the batch's upper-bound tables (M x 256 bytes per query) + 4 floats of meta per query
+    jv::Buffer d_bq_work;    // flat search: bound tables of the query batch (k_adc_bq.hip)
     jv::Buffer d_rd_counts;  // robust prune: {isDiverse tests, (candidate, selected slot) pairs summed by them}, accumulated by every launch
     jv::Buffer d_nvq_q;   // NVQ rerank: shifted queries + per-query scalars (nvq.cpp)
     // host batched graph searcher: worker pool (graph_search.cpp owns the type) and its destructor
@@ -420,6 +421,18 @@ int launch_adc_mq_filter(hipStream_t s, const jv_ctx *ctx, const float *d_luts, 
                          int vsf, const uint8_t *d_codes, const float *d_norms, int64_t first, int64_t count,
                          const float *d_tau, int tau_stride, int32_t *d_cand_ids, float *d_cand_scores,
                          unsigned int *d_cand_count, int cap);
+// the same filter in two stages (k_adc_bq.hip): 7-bit bound tables for sixteen queries per LDS word drop what cannot reach tau, the
+// exact ADC score is computed for the survivors only
+bool adc_bq_supported(int M, const uint8_t *d_codes);
+size_t adc_bq_scratch_bytes(int Q, int M);
+int launch_adc_bq_scan(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const float *d_bmag, int Q, int M, int vsf, const uint8_t *d_codes,
+                       const float *d_norms, int64_t first, int64_t count, const float *d_tau, int tau_stride, int32_t *d_ids,
+                       unsigned int *d_surv_cnt, int cap2, void *d_work);
+int launch_adc_bq_exact(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const float *d_bmag, int Q, int M, int vsf, const uint8_t *d_codes,
+                        const float *d_norms, int64_t n_codes, const float *d_tau, int tau_stride, const int32_t *d_ids, float *d_scores,
+                        const unsigned int *d_surv_cnt, unsigned int *d_cnt, int cap2, int slots);
+int launch_adc_pitched(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const float *d_bmag, int Q, int M, int vsf, const uint8_t *d_codes,
+                       const float *d_norms, int64_t n_codes, int64_t count, int64_t ld, const int32_t *d_ordinals, float *d_out);
 int launch_add_id_base(hipStream_t s, int32_t *d_ids, int64_t n, int32_t base);
 
 }  // namespace jv

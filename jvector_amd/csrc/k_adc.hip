@@ -37,6 +37,7 @@ struct AdcParams {
     int64_t n_rows;         // number of valid rows in codes (bounds for gather)
     int64_t first;          // scan: first row
     int64_t count;          // candidates per query
+    int64_t ld;             // gather: rows of `ordinals` and `out` are ld entries apart (0 = count)
     int64_t seg_len;        // candidates per workgroup
     int M_total;            // bytes per row
     int m_begin, m_count;   // subspace range handled by this pass
@@ -123,12 +124,12 @@ __global__ __launch_bounds__(THREADS) void adc_kernel(AdcParams p)
                 p.neighbors_out[(int64_t)q * p.count + i] = -1;
             }
         } else if (p.ordinals) {
-            row = p.ordinals[(int64_t)q * p.count + i];
+            row = p.ordinals[(int64_t)q * (p.ld ? p.ld : p.count) + i];
             valid = row >= 0 && row < p.n_rows;
         } else {
             row = p.first + i;
         }
-        float *o = p.out + (int64_t)q * p.count + i;
+        float *o = p.out + (int64_t)q * ((p.ordinals && p.ld) ? p.ld : p.count) + i;
         if (!valid) {
             *o = -INFINITY;
             continue;
@@ -244,6 +245,25 @@ int launch_adc(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const floa
     p.n_rows = n_codes;
     p.first = first;
     p.count = count;
+    p.M_total = M;
+    return run_adc(s, ctx, p, Q, vsf);
+}
+
+// gather over the first `count` entries of ordinal rows that are `ld` entries apart (scores land at the same pitch)
+int launch_adc_pitched(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const float *d_bmag, int Q, int M, int vsf, const uint8_t *d_codes,
+                       const float *d_norms, int64_t n_codes, int64_t count, int64_t ld, const int32_t *d_ordinals, float *d_out)
+{
+    AdcParams p{};
+    p.luts = d_luts;
+    p.bmag = d_bmag;
+    p.codes = d_codes;
+    p.norms = d_norms;
+    p.ordinals = d_ordinals;
+    p.out = d_out;
+    p.n_rows = n_codes;
+    p.first = 0;
+    p.count = count;
+    p.ld = ld;
     p.M_total = M;
     return run_adc(s, ctx, p, Q, vsf);
 }
