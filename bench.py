@@ -292,23 +292,29 @@ def timed_steps(run, queries, Q, steps, rk, barrier):
     return time.perf_counter() - t0
 
 
-def flat_roofline(QF, N, M, f_ms, f_n, cfg, vsf_name="COSINE"):
-    """adc_mq_kernel: one (query, candidate) pair = M look-ups of 4 B served 4 queries at a time by ds_read_b128 from the
-    LDS-resident tables; the kernel's physical bound is the LDS gather rate, its HBM side is one pass over the codes."""
+def flat_roofline(QF, N, M, f_ms, f_n, cfg, vsf_name="COSINE", bq=False):
+    """The flat scan's threshold filter.  Round 5 (bq): adc_bq_kernel — one (query, candidate) pair = M look-ups of ONE byte, sixteen
+    queries served by one ds_read_b128 from 7-bit bound tables in LDS — followed by the exact ADC gather of the survivors; `f_ms` is the
+    whole `adc` region (bound tables + bound scan + exact gather + count), so `achieved` under-reports the scan kernel alone by
+    10-25 %.  Before (adc_mq_kernel): M look-ups of 4 B, four queries per ds_read_b128.  Bound: the LDS gather rate either way."""
     f_avg = f_ms / 1e3 / max(f_n, 1)
-    lds_bytes = float(QF) * N * M * 4.0            # bytes the ds_read_b128 stream delivers per launch
+    bytes_per_lookup = 1.0 if bq else 4.0
+    lds_bytes = float(QF) * N * M * bytes_per_lookup   # bytes the ds_read_b128 stream delivers per launch
     compulsory = float(N) * (M + 4)                # codes (+ code norms) read once
     ach = lds_bytes / f_avg / 1e9 if f_avg > 0 else 0.0
-    traffic = measured_traffic("adc_mq", cfg)
-    return {"bound": "lds", "kernel": f"adc_mq_kernel<{vsf_name},M={M},R=8,FILTER> (threshold-filtered multi-query ADC scan of all N "
-            "codes; tables of 4 queries interleaved in LDS, one ds_read_b128 = 4 look-ups)",
+    traffic = measured_traffic("adc_bq" if bq else "adc_mq", cfg)
+    kernel = (f"adc_bq_kernel<{vsf_name},M={M},R=8> + adc_kernel gather (two-stage threshold filter: 7-bit bound tables of 16 queries per "
+              "LDS word drop what cannot reach the threshold, exact ADC sums for the survivors only)") if bq else \
+             (f"adc_mq_kernel<{vsf_name},M={M},R=8,FILTER> (threshold-filtered multi-query ADC scan of all N "
+              "codes; tables of 4 queries interleaved in LDS, one ds_read_b128 = 4 look-ups)")
+    return {"bound": "lds", "kernel": kernel,
             "achieved": ach, "peak": LDS_B128_PEAK_GBS, "unit": "GB/s", "frac": ach / LDS_B128_PEAK_GBS,
             "traffic": traffic, "hbm_compulsory_bytes": compulsory,
             "hbm_traffic_over_compulsory": (traffic / compulsory) if traffic else None,
-            "pairs_per_launch": float(QF) * N, "avg_launch_ms": f_avg * 1e3, "launches": f_n,
-            "note": "bound = LDS gather rate (ds_read_b128 peak 256 B/clk/CU x 256 CUs x 2.4 GHz); HBM side: counter bytes vs the "
-                    "compulsory one pass over the codes"}
-
+            "pairs_per_launch": float(QF) * N, "pairs_per_s": float(QF) * N / f_avg if f_avg > 0 else 0.0, "lds_bytes_per_lookup": bytes_per_lookup,
+            "avg_launch_ms": f_avg * 1e3, "launches": f_n,
+            "note": "bound = LDS gather rate (ds_read_b128 peak 256 B/clk/CU x 256 CUs x 2.4 GHz; random 16-byte gathers conflict ~2.8x); "
+                    "HBM side: counter bytes vs the compulsory one pass over the codes"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -433,7 +439,7 @@ def run_c2(args, ctx, J, dev, world, rank, barrier, ranks):
                        "parallelism": "1 GPU" if world == 1 else f"{world} replicas"},
             "recall_at_10": rec, "recall_se": rec_se, "recall_ok": rec >= 0.95, "recall_eval_queries": int(eval_q.shape[0]),
             "recall_calibration": {"queries": int(cal_q.shape[0]), "recall": cal_rec, "disjoint_from_eval": True},
-            "roofline": flat_roofline(QF, N, M, prof["adc"][0], prof["adc"][1], cfg, "L2"),
+            "roofline": flat_roofline(QF, N, M, prof["adc"][0], prof["adc"][1], cfg, "L2", bq=ctx.stat("adc_bq_calls") > 0),
             "kernel_ms_per_step": {r: prof[r][0] / args.steps for r in prof},
             "adc_distances_per_s": float(QF) * N * args.steps * world / elapsed, "pq_train_s": train_s, "setup_s": setup_s}
     if world == 1 and not args.no_cpu_baseline:
@@ -536,7 +542,7 @@ def run_c4(args, ctx, J, dev, world, rank, barrier, ranks):
             "adc_distances_per_s": float(QF) * N * args.steps / elapsed,
             "kernel_ms_per_step": {r: prof[r][0] / args.steps for r in prof},
             # the per-shard kernel: every rank scans ITS shard for every query, so the kernel roofline is per GPU
-            "roofline": flat_roofline(QF, n_shard, M, prof["adc"][0], prof["adc"][1], cfg), "cpu_baseline": None}
+            "roofline": flat_roofline(QF, n_shard, M, prof["adc"][0], prof["adc"][1], cfg, bq=ctx.stat("adc_bq_calls") > 0), "cpu_baseline": None}
     if world == 1 and not args.no_cpu_baseline:
         tq = queries[args.warmup * QF:]
         ids_gpu, _ = run(tq[:QF], rerank_k)
@@ -1223,7 +1229,7 @@ def main():
         flat_info = {"value": QF * f_steps / f_el, "unit": "queries/s", "ms_per_step": f_el / f_steps * 1e3,
                      "queries_per_step": QF, "rerankK": f_rk, "recall_at_10": f_rec, "recall_se": f_se,
                      "adc_distances_per_s": float(QF) * N * f_steps / f_el,
-                     "roofline": flat_roofline(QF, N, M, f_ms, f_n, {**cfg_key, "queries_per_step": QF, "rerankK": f_rk})}
+                     "roofline": flat_roofline(QF, N, M, f_ms, f_n, {**cfg_key, "queries_per_step": QF, "rerankK": f_rk}, bq=ctx.stat("adc_bq_calls") > 0)}
 
     if rank == 0:
         if graph_mode:
@@ -1238,7 +1244,7 @@ def main():
         elif flat_info is not None:
             roofline = flat_info["roofline"]
         else:
-            roofline = flat_roofline(Q, N, M, k_ms, k_n, cfg_key)
+            roofline = flat_roofline(Q, N, M, k_ms, k_n, cfg_key, bq=ctx.stat("adc_bq_calls") > 0)
         line = {
             "metric": "QPS@recall10>=0.95 (10Mx768); distances/sec as % HBM roofline",
             "value": total_queries / elapsed,
