@@ -614,7 +614,11 @@ JV_API int jv_hip_searcher_destroy(jv_searcher *s);
  *                           NodeQueue-order merge, owner selection, kernels — is the same code as over RCCL.
  *   jv_hip_sharded_merge_rerank : the exchange of jv_hip_sharded_search_flat for partial lists the CALLER produced (one graph index
  *                           per shard, the way JVector deployments shard): part_ids / part_scores [n_local][Q][rerankK] with GLOBAL
- *                           ids (host or device), counts[s] ordinals owned from id_base[s]; vectors == NULL: no exact rerank.  */
+ *                           ids (host or device), counts[s] ordinals owned from id_base[s]; vectors == NULL: no exact rerank.
+ *                           An id of list s outside [id_base[s], id_base[s] + counts[s]) is dropped ((-1, -inf)) before the merge.
+ *                           After the agreement header a rank-local failure (a HIP error in one rank's scan, a non-zero return of
+ *                           the external all-gather on one rank) is NOT recoverable: the other ranks are inside the next collective.
+ *                           Such failures must be collective — tear the communicator down on every rank.  */
 #define JV_COMM_ID_BYTES 128
 typedef struct jv_comm jv_comm;
 typedef int (*jv_all_gather_fn)(void *user, const void *send, size_t bytes, void *recv);

@@ -395,6 +395,11 @@ int jv_hip_builder_improve_batch(jv_ctx *ctx, jv_builder *b, const int32_t *node
     JV_TRY(use_device(ctx->device));
     const int Rf = b->Rf, R = b->R;
     const int k = (int)std::min<int64_t>(b->beam, b->inserted);
+    {   // the merged lists (row + beam candidates) must fit the robust prune's LDS block: refused up front, not after the searches
+        const size_t need = retain_diverse_lds_bytes(R + k, b->codes->M);
+        JV_REQUIRE(need <= ctx->lds_per_block, "builder_improve_batch: lists of %d + %d candidates x %d code bytes need %zu bytes of LDS (limit %zu); lower the beam width",
+                   R, k, b->codes->M, need, ctx->lds_per_block);
+    }
     JV_TRY(check_batch(ctx, b, nodes, B, "builder_improve_batch"));
     JV_TRY(b->d_nodes.reserve(sizeof(int32_t) * (size_t)B));
     JV_HIP_CHECK(hipMemcpyAsync(b->d_nodes.ptr, nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));
@@ -586,6 +591,12 @@ int jv_hip_build_layered(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, co
     JV_REQUIRE(max_batch >= 1 && improve_passes >= 0 && improve_passes <= 8 && min_top >= 1, "build_layered: bad schedule (max_batch %d, improve passes %d, min_top %d)",
                max_batch, improve_passes, min_top);
     JV_REQUIRE(max_degree >= 2 && max_degree <= 64, "build_layered: maxDegree %d outside 2..64", max_degree);
+    if (improve_passes > 0) {   // (the improve pass prunes row + beam candidates: checked before the insert phase runs)
+        const int Rw = std::max(max_degree, std::min(64, (int)(max_degree * neighbor_overflow)));
+        const size_t need = retain_diverse_lds_bytes(Rw + beam_width, codes->M);
+        JV_REQUIRE(need <= ctx->lds_per_block, "build_layered: an improveConnections pass over lists of %d + %d candidates x %d code bytes needs %zu bytes of LDS (limit %zu); "
+                   "lower the beam width or pass improve_passes = 0", Rw, beam_width, codes->M, need, ctx->lds_per_block);
+    }
     JV_REQUIRE(codes->count >= 1 && codes->count <= 0x7fffffffLL && vectors->count >= codes->count, "build_layered: %lld nodes", (long long)codes->count);
     JV_TRY(use_device(ctx->device));
     const double t_start = now_s();

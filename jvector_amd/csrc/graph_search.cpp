@@ -1466,7 +1466,12 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const size_t o_stats = carve(sizeof(long long) * 2 * (size_t)Q), o_status = carve(sizeof(int32_t) * (size_t)Q);
     const size_t o_counter = carve(sizeof(uint32_t) * 2);
     const size_t o_qmap = carve(sizeof(int32_t) * (size_t)Q);
-    const bool gs_prof = !so && ctx_opt(ctx, "gs_prof", 0) != 0;
+    bool gs_prof = !so && ctx_opt(ctx, "gs_prof", 0) != 0;
+    if (gs_prof && pairc) {   // (the compacted pair form has no phase-clock build: say so instead of printing sixteen zeros)
+        if (ctx_opt(ctx, "quiet", 0) == 0)
+            fprintf(stderr, "[jv gs prof] the compacted pair form (rows of 33..64 neighbours: the builder's searches) has no phase-clock variant; gs_prof ignored for this launch\n");
+        gs_prof = false;
+    }
     const size_t o_prof = carve(sizeof(unsigned long long) * 16);
     // exact-score ties across the K-th place of the rerank are decided by the order of the reference's result-heap array
     // (NodeQueue.java:197-214): the traversal logs its addTopCandidate sequence (avg ~1 entry per expansion) and

@@ -53,6 +53,26 @@ __global__ void shard_select_kernel(const int32_t *__restrict__ gids, const floa
 }  // namespace jv
 
 namespace jv {
+// caller-produced partial lists (jv_hip_sharded_merge_rerank): an id outside the shard that is said to own its list can have no owner in
+// the exchange — it becomes (-1, -inf) before the merge
+__global__ void shard_sanitize_kernel(int32_t *__restrict__ ids, float *__restrict__ sc, int64_t n, int64_t lo, int64_t hi)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t g = ids[i];
+    if (g < lo || g >= hi) {
+        ids[i] = -1;
+        sc[i] = -INFINITY;
+    }
+}
+int launch_shard_sanitize(hipStream_t s, int32_t *d_ids, float *d_sc, int64_t n, int64_t lo, int64_t hi)
+{
+    if (n == 0) return JV_OK;
+    hipLaunchKernelGGL(shard_sanitize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_ids, d_sc, n, lo, hi);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
 int launch_shard_interleave(hipStream_t s, const int32_t *d_ids, const float *d_sc, int P, int Q, int k, int32_t *d_out_ids,
                             float *d_out_sc)
 {

@@ -25,6 +25,7 @@ namespace jv {
 
 int launch_shard_interleave(hipStream_t s, const int32_t *d_ids, const float *d_sc, int P, int Q, int k, int32_t *d_out_ids,
                             float *d_out_sc);
+int launch_shard_sanitize(hipStream_t s, int32_t *d_ids, float *d_sc, int64_t n, int64_t lo, int64_t hi);
 int launch_shard_localize(hipStream_t s, const int32_t *d_gids, int64_t n, int64_t base, int64_t count, int32_t *d_local);
 int launch_shard_select(hipStream_t s, const int32_t *d_gids, const float *d_exact, const long long *d_ranges, int P, int64_t n,
                         float *d_out);
@@ -461,6 +462,7 @@ struct GivenProduce {
     int n_local, Q, k;
     jv_vsf vsf;
     bool rerank;
+    const int64_t *id_base, *counts;
 };
 int given_produce(void *a)
 {
@@ -468,6 +470,11 @@ int given_produce(void *a)
     const size_t cells = (size_t)g.Q * g.k * g.n_local;
     JV_HIP_CHECK(hipMemcpyAsync(g.comm->part_ids.ptr, g.part_ids, sizeof(int32_t) * cells, hipMemcpyDefault, g.ctx->stream));
     JV_HIP_CHECK(hipMemcpyAsync(g.comm->part_sc.ptr, g.part_sc, sizeof(float) * cells, hipMemcpyDefault, g.ctx->stream));
+    // the caller's lists are taken at their word only inside the shard's own range: an id nobody owns leaves the exchange here
+    const size_t per = (size_t)g.Q * g.k;
+    for (int s = 0; s < g.n_local; ++s)
+        JV_TRY(launch_shard_sanitize(g.ctx->stream, (int32_t *)g.comm->part_ids.ptr + per * s, (float *)g.comm->part_sc.ptr + per * s, (int64_t)per,
+                                     g.id_base[s], g.id_base[s] + g.counts[s]));
     // the raw queries the exact rerank scores against (jv_hip_search_flat stages them itself on the flat path)
     if (g.rerank) JV_TRY(luts_prepare(g.ctx, g.luts, g.queries, g.Q, g.vsf, JV_DECODER_PQ, false));
     return JV_OK;
@@ -538,7 +545,7 @@ int jv_hip_sharded_merge_rerank(jv_ctx *ctx, jv_comm *comm, int n_local, jv_luts
         }
     }
     if (rerank && Q > 0 && !queries) m.fail("sharded_merge_rerank: the exact rerank needs the queries");
-    GivenProduce g{ctx, comm, luts, queries, part_ids, part_scores, n_local, Q, rerankK, vsf, rerank};
+    GivenProduce g{ctx, comm, luts, queries, part_ids, part_scores, n_local, Q, rerankK, vsf, rerank, id_base, counts};
     return sharded_exchange(ctx, comm, n_local, luts, vectors, id_base, counts, Q, vsf, topK, rerankK, m.status, m.text, rerank, given_produce, &g,
                             out_ids, out_scores);
 }

@@ -263,6 +263,15 @@ int launch_shard_interleave(hipStream_t, const int32_t *d_ids, const float *d_sc
             }
     return JV_OK;
 }
+int launch_shard_sanitize(hipStream_t, int32_t *d_ids, float *d_sc, int64_t n, int64_t lo, int64_t hi)
+{
+    for (int64_t i = 0; i < n; ++i)
+        if (d_ids[i] < lo || d_ids[i] >= hi) {
+            d_ids[i] = -1;
+            d_sc[i] = -INFINITY;
+        }
+    return JV_OK;
+}
 int launch_shard_localize(hipStream_t, const int32_t *d_gids, int64_t n, int64_t base, int64_t count, int32_t *d_local)
 {
     for (int64_t i = 0; i < n; ++i) d_local[i] = (d_gids[i] >= base && d_gids[i] < base + count) ? (int32_t)(d_gids[i] - base) : -1;

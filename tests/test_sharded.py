@@ -128,6 +128,27 @@ def test_sharded_local_shards_on_the_mock():
                 assert np.array_equal(np.asarray(ids), wi) and np.array_equal(np.asarray(sc), ws)
             with pytest.raises(ValueError):
                 s.search(queries, J.VectorSimilarityFunction.COSINE, 10, 5)
+            if world == 3:
+                # a backend that hands over ids its shard does not own: they leave the exchange before the merge — the
+                # answer is the one without them, never an id with no owner
+                bad = s.shards[1]
+                real = bad.adc_topk
+
+                def lying(queries_, vsf_, k_, real=real):
+                    import torch
+                    ids_, sc_ = real(queries_, vsf_, k_)
+                    ids_ = torch.as_tensor(np.array(ids_)).clone()
+                    sc_ = torch.as_tensor(np.array(sc_)).clone()
+                    ids_[:, 0] = 999_999          # outside every shard
+                    sc_[:, 0] = 1e9
+                    ids_[:, 1] = 3                 # a real id — of ANOTHER shard
+                    sc_[:, 1] = 1e9
+                    return ids_, sc_
+                bad.adc_topk = lying
+                ids, sc = s.search(queries, J.VectorSimilarityFunction.COSINE, 10, 200)
+                assert (np.asarray(ids) < 1000).all() and (np.asarray(ids) >= 0).all() and np.isfinite(np.asarray(sc)).all()
+                assert not (np.asarray(sc) > 1.0).any()
+                bad.adc_topk = real
             s.close()
         ctx.close()
 
