@@ -505,6 +505,15 @@ JV_API int jv_hip_builder_improve_batch(jv_ctx *ctx, jv_builder *b, const int32_
 JV_API int jv_hip_builder_finish(jv_ctx *ctx, jv_builder *b, int32_t *neighbors_out);
 JV_API int jv_hip_builder_stats(const jv_builder *b, double *seconds3, int64_t *counts5);
 JV_API const int32_t *jv_hip_builder_neighbors_device(const jv_builder *b, int *row_width);
+/* REFERENCE ORDER (context option bl_ref_order = 1, read by jv_hip_builder_create): the builder keeps its lists the way
+ * ConcurrentNeighborMap.Neighbors does — every entry with the score it was inserted under, NodeArray order, the diverseBefore mark —
+ * and performs insertDiverse / backlink -> Neighbors.insert / retainDiverse(diverseBefore) / enforceDegree as the reference does
+ * (ConcurrentNeighborMap.java:139-146,190-200,222-296; NodeArray.java:166-228).  With ONE node per batch that is addGraphNode
+ * (GraphIndexBuilder.java:605-659) operation for operation: the adjacency equals the reference's one-thread build (oracle:
+ * jvo_builder_*, tests/test_builder_reference_order.py).  working_lists copies the lists as they stand: ids_out [n x row_width] (-1
+ * padded), scores_out [n x row_width] and diverse_before_out [n] (each nullable; host or device memory; the last two only in
+ * reference order). */
+JV_API int jv_hip_builder_working_lists(jv_ctx *ctx, const jv_builder *b, int32_t *ids_out, float *scores_out, int32_t *diverse_before_out);
 JV_API int jv_hip_builder_destroy(jv_builder *b);
 /* The whole LAYERED build in one call (GraphIndexBuilder with addHierarchy): levels drawn per node like getRandomGraphLevel (:562-575:
  * floor(-ln(U) / ln(maxDegree)), U from a splitmix64 seeded with `seed`; levels with fewer than min_top nodes fold into the one

@@ -121,6 +121,7 @@ SIGNATURES = {
     "jv_hip_builder_finish": (_i, [_p, _p, _p]),
     "jv_hip_builder_stats": (_i, [_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "jv_hip_builder_neighbors_device": (_p, [_p, C.POINTER(_i)]),
+    "jv_hip_builder_working_lists": (_i, [_p, _p, _p, _p, _p]),
     "jv_hip_builder_destroy": (_i, [_p]),
     "jv_hip_build_layered": (_i, [_p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _i, _i, C.c_uint64, _i, C.POINTER(_p)]),
     "jv_hip_layered_info": (_i, [_p, C.POINTER(_i), C.POINTER(C.c_int32), C.POINTER(_i), C.POINTER(_i64)]),

@@ -49,6 +49,21 @@ class GraphBuilder:
         check(self._lib.jv_hip_builder_finish(self.ctx._h, self._h, p))
         return out
 
+    def row_width(self):
+        w = C.c_int()
+        self._lib.jv_hip_builder_neighbors_device(self._h, C.byref(w))
+        return int(w.value)
+
+    def working_rows(self):
+        """the lists as they stand (host arrays): ids [n, row_width]; in reference order also their scores and diverseBefore marks"""
+        R = self.row_width()
+        ids = np.empty((self.n, R), np.int32)
+        sc = np.empty((self.n, R), np.float32)
+        db = np.empty(self.n, np.int32)
+        check(self._lib.jv_hip_builder_working_lists(self.ctx._h, self._h, ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+                                                    db.ctypes.data_as(C.c_void_p)))
+        return ids, sc, db
+
     def stats(self):
         s, c = (C.c_double * 3)(), (C.c_int64 * 5)()
         check(self._lib.jv_hip_builder_stats(self._h, s, c))

@@ -227,6 +227,225 @@ BL_FN void bl_rewrite_row(const BlRowsParams &p, long long r)
     for (; w < p.R; ++w) row[w] = -1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// REFERENCE ORDER (builder option bl_ref_order): the lists are kept the way ConcurrentNeighborMap.Neighbors keeps them — every entry
+// with the score it was inserted under, in NodeArray order (score descending, a new entry BEHIND its equals), and with the
+// diverseBefore mark — so that a batch of ONE node performs addGraphNode's list operations exactly (oracle: jv_oracle.c
+// "GraphIndexBuilder, one thread"; tests/test_builder_reference_order*.py compare the adjacency byte for byte):
+//   insertDiverse on the new node's empty list        ConcurrentNeighborMap.java:222-243   bl_ro_apply_selection
+//   backlink -> Neighbors.insert                      :139-146, :262-296                    bl_ro_backlink_merge
+//       insertionPoint / duplicateExistsNear          NodeArray.java:166-171, :212-228, :308-318
+//       diverseBefore = min(insertionPoint, diverseBefore); size > (int) (overflow x maxDegree) -> retainDiverse(diverseBefore)
+//   the re-pruned list replaces the row, diverseBefore = size                                  bl_ro_rewrite_row
+//   enforceDegree                                     :190-200                              bl_ro_copy_row + the same prune
+// A batch of B > 1 nodes is the concurrent case: the batch's nodes do not see each other's edges during their searches, a target's
+// back edges are applied in batch order, and a list that outgrows the limit inside one batch is pruned ONCE, after the batch's last
+// edge to it went in (the reference would prune at every crossing).
+struct BlRoApplyParams {
+    const int32_t *nodes;     // [B]
+    const int32_t *cand;      // [B][C] best first
+    const float *cand_sc;     // [B][C]
+    const int32_t *sel;       // [B][Rf] selected positions, ascending, -1 padded
+    int B, C, Rf, R;
+    int32_t *nbrs;            // [N][R]
+    float *nsc;               // [N][R]
+    int32_t *db;              // [N] diverseBefore
+    unsigned long long *edge_keys;   // [B * Rf] (target << 32 | item), ~0 = none
+    int32_t *edge_src;               // [B * Rf]
+    float *edge_sc;                  // [B * Rf] the score the target is listed under = the score the back edge is inserted with (:143-144)
+};
+
+// item = b
+BL_FN void bl_ro_apply_selection(const BlRoApplyParams &p, long long b)
+{
+    const int32_t v = p.nodes[b];
+    int32_t *row = p.nbrs + (long long)v * p.R;
+    float *rsc = p.nsc + (long long)v * p.R;
+    int w = 0;
+    for (int j = 0; j < p.Rf; ++j) {
+        const long long item = b * p.Rf + j;
+        const int32_t s = p.sel[item];
+        int32_t chosen = s >= 0 && s < p.C ? p.cand[b * (long long)p.C + s] : -1;
+        if (chosen == v) chosen = -1;
+        if (chosen >= 0) {
+            const float x = p.cand_sc[b * (long long)p.C + s];
+            row[w] = chosen;
+            rsc[w] = x;
+            ++w;
+            p.edge_keys[item] = (((unsigned long long)(uint32_t)chosen) << 32) | (unsigned long long)(uint32_t)item;
+            p.edge_sc[item] = x;
+        } else {
+            p.edge_keys[item] = ~0ull;
+            p.edge_sc[item] = 0.0f;
+        }
+        p.edge_src[item] = v;
+    }
+    p.db[v] = w;   // new Neighbors(...): diverseBefore = size()
+    for (; w < p.R; ++w) {
+        row[w] = -1;
+        rsc[w] = 0.0f;
+    }
+}
+
+constexpr int BL_RO_MAX_LIST = 192;   // R <= 64 and at most 2 R appended entries are kept
+
+struct BlRoMergeParams {
+    const unsigned long long *keys;  // [E] sorted ascending (target, item)
+    const int32_t *src;              // [E] UNSORTED: indexed by the key's item
+    const float *esc;                // [E] UNSORTED
+    long long E;
+    int R, hard_max, Knew, dedupe_ids;   // hard_max = (int) (overflow x maxDegree), <= R
+    int32_t *nbrs;
+    float *nsc;
+    int32_t *db;
+    int32_t *over_tgt;               // [cap]
+    int32_t *over_list;              // [cap][R + Knew]
+    float *over_sc;                  // [cap][R + Knew]
+    int32_t *over_db;                // [cap]
+    int32_t *over_n;                 // [cap]
+    unsigned int *over_count;
+    unsigned int over_cap;
+};
+
+// NodeArray.insertionPoint: -1 = (node, score) already listed
+BL_FN int bl_ro_insertion_point(const int32_t *ids, const float *sc, int n, int32_t node, float x)
+{
+    int at = 0;
+    while (at < n && !(sc[at] < x)) ++at;   // descSortFindRightMostInsertionPoint on a descending array
+    for (int i = at - 1; i >= 0 && sc[i] == x; --i)
+        if (ids[i] == node) return -1;
+    for (int i = at; i < n && sc[i] == x; ++i)
+        if (ids[i] == node) return -1;
+    return at;
+}
+
+// item = index into the sorted keys; the first edge of a target's run applies the whole run
+BL_FN void bl_ro_backlink_merge(const BlRoMergeParams &p, long long i)
+{
+    const unsigned long long k = p.keys[i];
+    if (k == ~0ull) return;
+    const int32_t tgt = (int32_t)(k >> 32);
+    if (i > 0 && (int32_t)(p.keys[i - 1] >> 32) == tgt) return;
+    int32_t ids[BL_RO_MAX_LIST];
+    float sc[BL_RO_MAX_LIST];
+    int32_t *row = p.nbrs + (long long)tgt * p.R;
+    float *rsc = p.nsc + (long long)tgt * p.R;
+    int n = 0;
+    while (n < p.R && row[n] >= 0) {
+        ids[n] = row[n];
+        sc[n] = rsc[n];
+        ++n;
+    }
+    const int L = p.R + p.Knew;
+    int dbv = p.db[tgt];
+    bool changed = false;
+    for (long long e = i; e < p.E && (int32_t)(p.keys[e] >> 32) == tgt; ++e) {
+        const long long item = (long long)(uint32_t)p.keys[e];
+        const int32_t s = p.src[item];
+        const float x = p.esc[item];
+        const int at = bl_ro_insertion_point(ids, sc, n, s, x);
+        if (at < 0) continue;                                  // "new" node already existed (:275-278)
+        if (p.dedupe_ids) {
+            bool have = false;
+            for (int t = 0; t < n; ++t) have = have || ids[t] == s;
+            if (have) continue;
+        }
+        if (n == L) continue;                                  // (a batch larger than the working list: the edge is dropped)
+        for (int t = n; t > at; --t) {
+            ids[t] = ids[t - 1];
+            sc[t] = sc[t - 1];
+        }
+        ids[at] = s;
+        sc[at] = x;
+        ++n;
+        dbv = at < dbv ? at : dbv;
+        changed = true;
+    }
+    if (!changed) return;
+    if (n <= p.hard_max) {
+        for (int t = 0; t < n; ++t) {
+            row[t] = ids[t];
+            rsc[t] = sc[t];
+        }
+        p.db[tgt] = dbv;
+        return;
+    }
+    const unsigned int slot = BL_ATOMIC_INC(p.over_count);
+    if (slot >= p.over_cap) return;   // cannot happen (cap = number of targets)
+    int32_t *lst = p.over_list + (long long)slot * L;
+    float *lsc = p.over_sc + (long long)slot * L;
+    for (int t = 0; t < L; ++t) {
+        lst[t] = t < n ? ids[t] : -1;
+        lsc[t] = t < n ? sc[t] : 0.0f;
+    }
+    p.over_tgt[slot] = tgt;
+    p.over_db[slot] = dbv;
+    p.over_n[slot] = n;
+}
+
+struct BlRoRowsParams {
+    const int32_t *tgt;     // [P]
+    const int32_t *lst;     // [P][L]
+    const float *lsc;       // [P][L]
+    const int32_t *sel;     // [P][Rf]
+    int P, L, Rf, R;
+    int32_t *nbrs;
+    float *nsc;
+    int32_t *db;
+};
+
+// item = r: retain(selected) + diverseBefore = size
+BL_FN void bl_ro_rewrite_row(const BlRoRowsParams &p, long long r)
+{
+    const int32_t v = p.tgt[r];
+    int32_t *row = p.nbrs + (long long)v * p.R;
+    float *rsc = p.nsc + (long long)v * p.R;
+    int w = 0;
+    for (int j = 0; j < p.Rf; ++j) {
+        const int32_t s = p.sel[r * p.Rf + j];
+        if (s >= 0 && s < p.L) {
+            const int32_t x = p.lst[r * (long long)p.L + s];
+            if (x >= 0) {
+                row[w] = x;
+                rsc[w] = p.lsc[r * (long long)p.L + s];
+                ++w;
+            }
+        }
+    }
+    p.db[v] = w;
+    for (; w < p.R; ++w) {
+        row[w] = -1;
+        rsc[w] = 0.0f;
+    }
+}
+
+struct BlRoCopyParams {
+    const int32_t *tgt;     // [P]
+    int P, R;
+    const int32_t *nbrs;
+    const float *nsc;
+    const int32_t *db;
+    int32_t *lst;           // [P][R]
+    float *lsc;             // [P][R]
+    int32_t *ldb;           // [P]
+    int32_t *ln;            // [P]
+};
+
+// item = r: a row with its scores and mark, for enforceDegree's prune
+BL_FN void bl_ro_copy_row(const BlRoCopyParams &p, long long r)
+{
+    const int32_t v = p.tgt[r];
+    int n = 0;
+    for (int t = 0; t < p.R; ++t) {
+        const int32_t x = p.nbrs[(long long)v * p.R + t];
+        p.lst[r * (long long)p.R + t] = x;
+        p.lsc[r * (long long)p.R + t] = p.nsc[(long long)v * p.R + t];
+        n += x >= 0 ? 1 : 0;
+    }
+    p.ldb[r] = p.db[v];
+    p.ln[r] = n;
+}
+
 struct BlOverParams {
     const int32_t *nbrs;    // [N][R]
     long long N;

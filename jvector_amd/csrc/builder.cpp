@@ -22,6 +22,13 @@
 //   7. overflowed lists: PQ diversity scores, NodeArray order, robust prune, row rewrite  launch_pair_scores, bl_rank_sort,
 //                                                                                        launch_retain_diverse, bl_rewrite_row
 // Everything stays on the context's stream; the host reads back one counter per batch (how many lists overflowed).
+//
+// REFERENCE ORDER (context option bl_ref_order = 1): the lists additionally carry the score every entry was inserted under, stay
+// in NodeArray order and keep ConcurrentNeighborMap's diverseBefore mark (bl_body.h "REFERENCE ORDER"); steps 4, 6 and 7 become
+// insertDiverse / Neighbors.insert / retainDiverse(diverseBefore) as the reference performs them — nothing is re-scored or
+// re-sorted — and a build whose batches hold ONE node is addGraphNode + cleanup's enforceDegree operation for operation: the
+// adjacency equals the oracle's one-thread restatement of GraphIndexBuilder byte for byte (tests/test_builder_reference_order.py
+// on the CPU mock, tests/test_zz_builder_reference_order_gpu.py on the MI355X).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -45,6 +52,10 @@ struct jv_builder {
     int Rf = 32, R = 40, beam = 100;
     float alpha = 1.2f;
     int32_t *d_nbrs = nullptr;       // [n][R]
+    bool ref = false;                // reference order: the three arrays below exist, rows are NodeArray-ordered
+    float *d_nsc = nullptr;          // [n][R] the score each entry was inserted under
+    int32_t *d_db = nullptr;         // [n] diverseBefore
+    int hard_max = 0;                // (int) (neighborOverflow x maxDegree), capped at R: a list longer than this is pruned
     jv_graph *graph = nullptr;       // level 0 = d_nbrs, read in place by the device traversal
     jv_luts *luts = nullptr;
     int luts_cap = 0;
@@ -52,24 +63,26 @@ struct jv_builder {
     int64_t inserted = 0;            // nodes that have a row (the search cannot return more than that)
     int32_t entry = -1;
     Buffer d_nodes, d_q, d_cand, d_csc, d_count, d_sel, d_nsel, d_keys, d_keys2, d_src, d_src2, d_sort_tmp, d_over_tgt, d_over_list, d_over_sc,
-        d_sorted_ids, d_sorted_sc, d_ctr, d_imp_list;
+        d_sorted_ids, d_sorted_sc, d_ctr, d_imp_list, d_esc, d_over_db, d_over_n;
     double search_s = 0, prune_s = 0, backlink_s = 0;
     int64_t reprunes = 0, batches = 0, visited = 0, expanded = 0, improved = 0;  // (visited / expanded: SearchResult counters summed over the inserts)
     std::vector<int64_t> h_stats;
     ~jv_builder()
     {
         for (Buffer *b : {&d_nodes, &d_q, &d_cand, &d_csc, &d_count, &d_sel, &d_nsel, &d_keys, &d_keys2, &d_src, &d_src2, &d_sort_tmp, &d_over_tgt,
-                          &d_over_list, &d_over_sc, &d_sorted_ids, &d_sorted_sc, &d_ctr, &d_imp_list})
+                          &d_over_list, &d_over_sc, &d_sorted_ids, &d_sorted_sc, &d_ctr, &d_imp_list, &d_esc, &d_over_db, &d_over_n})
             b->release();
     }
 };
 
 namespace {
 
+constexpr long long kBlRefOrderDefault = 0;
+
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int run_retain(jv_ctx *ctx, jv_builder *b, const int32_t *d_cand, const float *d_sc, const int32_t *d_count, int P, int C, int32_t *d_sel,
-               int32_t *d_nsel)
+               int32_t *d_nsel, const int32_t *d_before = nullptr)
 {
     RdParams p{};
     p.tri = b->tri->d_tri;
@@ -80,7 +93,7 @@ int run_retain(jv_ctx *ctx, jv_builder *b, const int32_t *d_cand, const float *d
     p.cand_nodes = d_cand;
     p.cand_scores = d_sc;
     p.cand_count = d_count;
-    p.diverse_before = nullptr;
+    p.diverse_before = d_before;
     p.P = P;
     p.C = C;
     p.M = b->codes->M;
@@ -142,6 +155,32 @@ int reprune_lists(jv_ctx *ctx, jv_builder *b, const int32_t *d_tgt, const int32_
     return JV_OK;
 }
 
+// reference order: lists d_list / d_lsc [P][L] (already in NodeArray order, with the scores their entries were inserted under) of the
+// targets d_tgt: retainDiverse(list, diverseBefore), the selection replaces the row, diverseBefore = size
+int reprune_lists_ro(jv_ctx *ctx, jv_builder *b, const int32_t *d_tgt, const int32_t *d_list, const float *d_lsc, const int32_t *d_n,
+                     const int32_t *d_before, int P, int L)
+{
+    if (P == 0) return JV_OK;
+    JV_TRY(b->d_sel.reserve(sizeof(int32_t) * (size_t)P * b->Rf));
+    JV_TRY(b->d_nsel.reserve(sizeof(int32_t) * (size_t)P));
+    JV_TRY(run_retain(ctx, b, d_list, d_lsc, d_n, P, L, (int32_t *)b->d_sel.ptr, (int32_t *)b->d_nsel.ptr, d_before));
+    BlRoRowsParams rp{};
+    rp.tgt = d_tgt;
+    rp.lst = d_list;
+    rp.lsc = d_lsc;
+    rp.sel = (const int32_t *)b->d_sel.ptr;
+    rp.P = P;
+    rp.L = L;
+    rp.Rf = b->Rf;
+    rp.R = b->R;
+    rp.nbrs = b->d_nbrs;
+    rp.nsc = b->d_nsc;
+    rp.db = b->d_db;
+    JV_TRY(launch_bl_ro_rewrite_rows(ctx->stream, rp));
+    b->reprunes += P;
+    return JV_OK;
+}
+
 int read_counter(jv_ctx *ctx, jv_builder *b, unsigned int *out)
 {
     JV_TRY(ctx->h_out.reserve(64));
@@ -193,6 +232,19 @@ int jv_hip_builder_create(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, c
         return fail(JV_ERR_OOM);
     }
     if (hipMemsetAsync(b->d_nbrs, 0xFF, sizeof(int32_t) * (size_t)b->n * b->R, ctx->stream) != hipSuccess) return fail(JV_ERR_HIP);
+    b->ref = ctx_opt(ctx, "bl_ref_order", kBlRefOrderDefault) != 0;
+    b->hard_max = std::min(b->R, (int)(neighbor_overflow * (float)max_degree));   // Neighbors.insert :270
+    if (b->ref) {
+        if (hipMalloc((void **)&b->d_nsc, sizeof(float) * (size_t)b->n * b->R) != hipSuccess ||
+            hipMalloc((void **)&b->d_db, sizeof(int32_t) * (size_t)b->n) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("builder_create: cannot allocate the %lld x %d score rows", (long long)b->n, b->R);
+            return fail(JV_ERR_OOM);
+        }
+        if (hipMemsetAsync(b->d_nsc, 0, sizeof(float) * (size_t)b->n * b->R, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(b->d_db, 0, sizeof(int32_t) * (size_t)b->n, ctx->stream) != hipSuccess)
+            return fail(JV_ERR_HIP);
+    }
     int rc = jv_hip_graph_create(ctx, b->n, 1, &b->graph);
     if (rc == JV_OK) rc = jv_hip_graph_set_level0_device(ctx, b->graph, b->d_nbrs, b->R);
     if (rc == JV_OK) rc = jv_hip_graph_set_traversal(b->graph, JV_TRAVERSAL_DEVICE);
@@ -211,6 +263,8 @@ int jv_hip_builder_destroy(jv_builder *b)
     if (b->graph) jv_hip_graph_destroy(b->graph);
     if (b->tri) jv_hip_pair_table_destroy(b->tri);
     if (b->d_nbrs) (void)hipFree(b->d_nbrs);
+    if (b->d_nsc) (void)hipFree(b->d_nsc);
+    if (b->d_db) (void)hipFree(b->d_db);
     delete b;
     return JV_OK;
 }
@@ -314,6 +368,54 @@ static int link_back_edges(jv_ctx *ctx, jv_builder *b, long long E)
     return JV_OK;
 }
 
+// reference order: the E back edges (keys / src / scores in d_keys / d_src / d_esc) -> Neighbors.insert per target, in batch order
+static int link_back_edges_ro(jv_ctx *ctx, jv_builder *b, long long E, int dedupe_ids)
+{
+    const int R = b->R;
+    const double t0 = now_s();
+    size_t tmp_bytes = 0;
+    JV_TRY(launch_bl_sort_edges(ctx->stream, nullptr, &tmp_bytes, nullptr, nullptr, nullptr, nullptr, E, 64));
+    JV_TRY(b->d_sort_tmp.reserve(tmp_bytes + 256));
+    JV_TRY(launch_bl_sort_edges(ctx->stream, b->d_sort_tmp.ptr, &tmp_bytes, (const unsigned long long *)b->d_keys.ptr,
+                                (unsigned long long *)b->d_keys2.ptr, (const int32_t *)b->d_src.ptr, (int32_t *)b->d_src2.ptr, E, 64));
+    const int Knew = 2 * R, L = R + Knew;
+    static_assert(BL_RO_MAX_LIST >= 3 * 64, "the merge step's working list holds R + 2 R entries, R <= 64");
+    const unsigned int over_cap = (unsigned int)std::min<long long>(E, b->n);
+    JV_TRY(b->d_over_tgt.reserve(sizeof(int32_t) * (size_t)over_cap));
+    JV_TRY(b->d_over_db.reserve(sizeof(int32_t) * (size_t)over_cap));
+    JV_TRY(b->d_over_n.reserve(sizeof(int32_t) * (size_t)over_cap));
+    JV_TRY(b->d_over_list.reserve(sizeof(int32_t) * (size_t)over_cap * L));
+    JV_TRY(b->d_over_sc.reserve(sizeof(float) * (size_t)over_cap * L));
+    JV_HIP_CHECK(hipMemsetAsync(b->d_ctr.ptr, 0, sizeof(unsigned int), ctx->stream));
+    BlRoMergeParams mp{};
+    mp.keys = (const unsigned long long *)b->d_keys2.ptr;
+    mp.src = (const int32_t *)b->d_src.ptr;
+    mp.esc = (const float *)b->d_esc.ptr;
+    mp.E = E;
+    mp.R = R;
+    mp.hard_max = b->hard_max;
+    mp.Knew = Knew;
+    mp.dedupe_ids = dedupe_ids;
+    mp.nbrs = b->d_nbrs;
+    mp.nsc = b->d_nsc;
+    mp.db = b->d_db;
+    mp.over_tgt = (int32_t *)b->d_over_tgt.ptr;
+    mp.over_list = (int32_t *)b->d_over_list.ptr;
+    mp.over_sc = (float *)b->d_over_sc.ptr;
+    mp.over_db = (int32_t *)b->d_over_db.ptr;
+    mp.over_n = (int32_t *)b->d_over_n.ptr;
+    mp.over_count = (unsigned int *)b->d_ctr.ptr;
+    mp.over_cap = over_cap;
+    JV_TRY(launch_bl_ro_backlink_merge(ctx->stream, mp));
+    unsigned int n_over = 0;
+    JV_TRY(read_counter(ctx, b, &n_over));
+    n_over = std::min(n_over, over_cap);
+    JV_TRY(reprune_lists_ro(ctx, b, mp.over_tgt, mp.over_list, mp.over_sc, mp.over_n, mp.over_db, (int)n_over, L));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    b->backlink_s += now_s() - t0;
+    return JV_OK;
+}
+
 static int reserve_edges(jv_builder *b, long long E)
 {
     JV_TRY(b->d_keys.reserve(sizeof(unsigned long long) * (size_t)E));
@@ -355,6 +457,31 @@ int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes
     JV_TRY(run_retain(ctx, b, d_cand, d_csc, (const int32_t *)b->d_count.ptr, B, k, (int32_t *)b->d_sel.ptr, (int32_t *)b->d_nsel.ptr));
     const long long E = (long long)B * Rf;
     JV_TRY(reserve_edges(b, E));
+    if (b->ref) {   // insertDiverse on the new nodes' empty lists, then backlink -> Neighbors.insert
+        JV_TRY(b->d_esc.reserve(sizeof(float) * (size_t)E));
+        BlRoApplyParams rp{};
+        rp.nodes = d_nodes;
+        rp.cand = d_cand;
+        rp.cand_sc = d_csc;
+        rp.sel = (const int32_t *)b->d_sel.ptr;
+        rp.B = B;
+        rp.C = k;
+        rp.Rf = Rf;
+        rp.R = R;
+        rp.nbrs = b->d_nbrs;
+        rp.nsc = b->d_nsc;
+        rp.db = b->d_db;
+        rp.edge_keys = (unsigned long long *)b->d_keys.ptr;
+        rp.edge_src = (int32_t *)b->d_src.ptr;
+        rp.edge_sc = (float *)b->d_esc.ptr;
+        JV_TRY(launch_bl_ro_apply_selection(ctx->stream, rp));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        b->prune_s += now_s() - t0;
+        JV_TRY(link_back_edges_ro(ctx, b, E, 0));
+        b->inserted += B;
+        b->batches += 1;
+        return JV_OK;
+    }
     BlApplyParams ap{};
     ap.nodes = d_nodes;
     ap.cand = d_cand;
@@ -391,6 +518,7 @@ int jv_hip_builder_improve_batch(jv_ctx *ctx, jv_builder *b, const int32_t *node
     if (B == 0) return JV_OK;
     JV_REQUIRE(nodes, "builder_improve_batch: NULL nodes");
     JV_REQUIRE(b->entry >= 0 && b->inserted >= 2, "builder_improve_batch: nothing to improve in an empty graph");
+    JV_REQUIRE(!b->ref, "builder_improve_batch: not available in reference order (bl_ref_order = 1) yet");
     JV_REQUIRE(ctx->device == b->device, "builder_improve_batch: the builder lives on device %d", b->device);
     JV_TRY(use_device(ctx->device));
     const int Rf = b->Rf, R = b->R;
@@ -462,9 +590,31 @@ int jv_hip_builder_finish(jv_ctx *ctx, jv_builder *b, int32_t *neighbors_out)
         JV_TRY(read_counter(ctx, b, &n_over));
         const int piece = 1 << 20;
         JV_TRY(b->d_over_list.reserve(sizeof(int32_t) * (size_t)std::min<unsigned int>(n_over, piece) * b->R));
+        if (b->ref) {   // enforceDegree: retainDiverse(copy, diverseBefore) over the stored scores (ConcurrentNeighborMap.java:190-200)
+            const size_t pc = (size_t)std::min<unsigned int>(n_over, piece);
+            JV_TRY(b->d_over_sc.reserve(sizeof(float) * pc * b->R));
+            JV_TRY(b->d_over_db.reserve(sizeof(int32_t) * pc));
+            JV_TRY(b->d_over_n.reserve(sizeof(int32_t) * pc));
+        }
         for (unsigned int s = 0; s < n_over; s += piece) {
             const int P = (int)std::min<unsigned int>(piece, n_over - s);
             const int32_t *tgt = (const int32_t *)b->d_over_tgt.ptr + s;
+            if (b->ref) {
+                BlRoCopyParams cp{};
+                cp.tgt = tgt;
+                cp.P = P;
+                cp.R = b->R;
+                cp.nbrs = b->d_nbrs;
+                cp.nsc = b->d_nsc;
+                cp.db = b->d_db;
+                cp.lst = (int32_t *)b->d_over_list.ptr;
+                cp.lsc = (float *)b->d_over_sc.ptr;
+                cp.ldb = (int32_t *)b->d_over_db.ptr;
+                cp.ln = (int32_t *)b->d_over_n.ptr;
+                JV_TRY(launch_bl_ro_copy_rows(ctx->stream, cp));
+                JV_TRY(reprune_lists_ro(ctx, b, tgt, cp.lst, cp.lsc, cp.ln, cp.ldb, P, b->R));
+                continue;
+            }
             JV_TRY(launch_bl_copy_rows(ctx->stream, b->d_nbrs, b->R, tgt, P, (int32_t *)b->d_over_list.ptr));
             JV_TRY(reprune_lists(ctx, b, tgt, (const int32_t *)b->d_over_list.ptr, P, b->R));
         }
@@ -780,6 +930,21 @@ int jv_hip_layered_destroy(jv_layered *l)
     if (!l) return JV_OK;
     if (l->d_level0) (void)hipFree(l->d_level0);
     delete l;
+    return JV_OK;
+}
+
+int jv_hip_builder_working_lists(jv_ctx *ctx, const jv_builder *b, int32_t *ids_out, float *scores_out, int32_t *diverse_before_out)
+{
+    clear_error();
+    JV_REQUIRE(ctx && b, "builder_working_lists: NULL argument");
+    JV_REQUIRE(ctx->device == b->device, "builder_working_lists: the builder lives on device %d", b->device);
+    JV_REQUIRE(b->ref || (!scores_out && !diverse_before_out), "builder_working_lists: scores and marks exist in reference order only (bl_ref_order = 1)");
+    JV_TRY(use_device(ctx->device));
+    const size_t cells = (size_t)b->n * b->R;
+    if (ids_out) JV_HIP_CHECK(hipMemcpyAsync(ids_out, b->d_nbrs, sizeof(int32_t) * cells, hipMemcpyDefault, ctx->stream));
+    if (scores_out) JV_HIP_CHECK(hipMemcpyAsync(scores_out, b->d_nsc, sizeof(float) * cells, hipMemcpyDefault, ctx->stream));
+    if (diverse_before_out) JV_HIP_CHECK(hipMemcpyAsync(diverse_before_out, b->d_db, sizeof(int32_t) * (size_t)b->n, hipMemcpyDefault, ctx->stream));
+    JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return JV_OK;
 }
 

@@ -372,6 +372,14 @@ struct BlRowsParams;
 struct BlOverParams;
 struct BlImproveParams;
 struct BlRowEdgesParams;
+struct BlRoApplyParams;
+struct BlRoMergeParams;
+struct BlRoRowsParams;
+struct BlRoCopyParams;
+int launch_bl_ro_apply_selection(hipStream_t s, const BlRoApplyParams &p);
+int launch_bl_ro_backlink_merge(hipStream_t s, const BlRoMergeParams &p);
+int launch_bl_ro_rewrite_rows(hipStream_t s, const BlRoRowsParams &p);
+int launch_bl_ro_copy_rows(hipStream_t s, const BlRoCopyParams &p);
 int launch_bl_apply_selection(hipStream_t s, const BlApplyParams &p);
 int launch_bl_backlink_merge(hipStream_t s, const BlMergeParams &p);
 int launch_bl_improve_list(hipStream_t s, const BlImproveParams &p);

@@ -57,6 +57,12 @@ int launch_bl_rank_sort(hipStream_t s, const BlSortParams &p) { return run_items
 int launch_bl_rewrite_rows(hipStream_t s, const BlRowsParams &p) { return run_items<BlRowsParams, bl_rewrite_row>(s, p, p.P); }
 int launch_bl_list_over_degree(hipStream_t s, const BlOverParams &p) { return run_items<BlOverParams, bl_list_over_degree>(s, p, p.N); }
 
+// reference order (bl_body.h "REFERENCE ORDER")
+int launch_bl_ro_apply_selection(hipStream_t s, const BlRoApplyParams &p) { return run_items<BlRoApplyParams, bl_ro_apply_selection>(s, p, p.B); }
+int launch_bl_ro_backlink_merge(hipStream_t s, const BlRoMergeParams &p) { return run_items<BlRoMergeParams, bl_ro_backlink_merge>(s, p, p.E); }
+int launch_bl_ro_rewrite_rows(hipStream_t s, const BlRoRowsParams &p) { return run_items<BlRoRowsParams, bl_ro_rewrite_row>(s, p, p.P); }
+int launch_bl_ro_copy_rows(hipStream_t s, const BlRoCopyParams &p) { return run_items<BlRoCopyParams, bl_ro_copy_row>(s, p, p.P); }
+
 int launch_bl_count_valid(hipStream_t s, const int32_t *cand, int C, int32_t *count, long long B)
 {
     if (B <= 0) return JV_OK;

@@ -1766,3 +1766,367 @@ int jvo_searcher_resume(jvo_searcher *s, int additionalK, int rerankK, int32_t *
     searcher_layer0(s, additionalK, rerankK, 0.0f);
     return searcher_reranking(s, additionalK, 0.0f, out_ids, out_scores, stats, worst_out);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * GraphIndexBuilder, one thread (checker for jv_hip_builder_* / jv_hip_build_layered in reference order).
+ *   java.util.Random(0) + getRandomGraphLevel                     B/graph/GraphIndexBuilder.java:337,562-575
+ *   addGraphNode / updateNeighborsOneLayer / updateNeighbors       :605-659, :800-825 (no concurrent candidates with one thread)
+ *   cleanup / improveConnections                                   :472-545
+ *   OnHeapGraphIndex.addNode / markComplete / addEdges             B/graph/OnHeapGraphIndex.java:161-168,214-225,279-282
+ *   ConcurrentNeighborMap.Neighbors.insertDiverse / insert / enforceDegree / retainDiverseInternal / backlink
+ *                                                                 B/graph/ConcurrentNeighborMap.java:139-146,190-200,222-243,262-296
+ *   NodeArray.merge / insertionPoint / duplicateExistsNear / insertSorted / retain
+ *                                                                 B/graph/NodeArray.java:63-143,166-238,240-256,308-318
+ *   scores: BuildScoreProvider.pqBuildScoreProvider (:171-205) — searches with the precomputed ADC tables of the node's
+ *   full-resolution vector, no rerank; diversity with the PQ pair function (jvo_retain_diverse above).
+ * One degree for every level (the List.of(M) the reference's callers pass).  Rows live in dense per-level arrays indexed by node id
+ * (the reference's SparseIntMap for the upper levels holds the same rows), packed and -1 padded so that the searcher above reads
+ * them in place — in NodeArray order, which is the order the reference's neighbour iterator walks.
+ * ---------------------------------------------------------------------------------------- */
+#define JVO_BUILD_MAX_LEVELS 32
+
+void jvo_java_random_seed(int64_t *state, int64_t seed) { *state = (seed ^ 0x5DEECE66DLL) & ((1LL << 48) - 1); }
+static int32_t java_random_next(int64_t *state, int bits)
+{
+    *state = (int64_t)(((uint64_t)*state * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1));
+    return (int32_t)((uint64_t)*state >> (48 - bits));
+}
+double jvo_java_random_next_double(int64_t *state)
+{
+    const int64_t hi = (int64_t)java_random_next(state, 26), lo = (int64_t)java_random_next(state, 27);
+    return (double)((hi << 27) + lo) * 0x1.0p-53;
+}
+/* getRandomGraphLevel :562-575 */
+int jvo_random_graph_level(int64_t *state, int degree0, int addHierarchy)
+{
+    double ml, r;
+    if (addHierarchy) {
+        ml = degree0 == 1 ? 1.0 : 1.0 / log(1.0 * degree0);
+        do { r = jvo_java_random_next_double(state); } while (r == 0.0);
+    } else { ml = 0; r = 0; }
+    if (!addHierarchy) return 0;   /* (int) (-log(0) * 0) = (int) NaN = 0 in Java */
+    return (int)(-log(r) * ml);
+}
+
+typedef struct { int32_t *node; float *score; int size; } nodearr;   /* views into caller-sized storage */
+
+/* NodeArray.merge :63-143 — out must hold a.size + b.size entries */
+static void na_merge(const nodearr *a1, const nodearr *a2, nodearr *m)
+{
+    int i = 0, j = 0, nl = 0;
+    int32_t *last = (int32_t *)malloc(sizeof(int32_t) * (size_t)(a1->size + a2->size + 1));   /* nodesWithLastScore */
+    float lastScore = NAN;
+    m->size = 0;
+#define NA_LAST_ADD(x, ok) do { ok = 1; for (int t_ = 0; t_ < nl; t_++) if (last[t_] == (x)) { ok = 0; break; } if (ok) last[nl++] = (x); } while (0)
+#define NA_TAKE(arr, idx) do { if ((arr)->score[idx] != lastScore) { nl = 0; lastScore = (arr)->score[idx]; } int ok_; NA_LAST_ADD((arr)->node[idx], ok_); \
+        if (ok_) { m->node[m->size] = (arr)->node[idx]; m->score[m->size] = (arr)->score[idx]; m->size++; } } while (0)
+    while (i < a1->size && j < a2->size) {
+        if (a1->score[i] < a2->score[j]) { NA_TAKE(a2, j); j++; }
+        else if (a1->score[i] > a2->score[j]) { NA_TAKE(a1, i); i++; }
+        else { NA_TAKE(a1, i); { int ok_; NA_LAST_ADD(a2->node[j], ok_); if (ok_) { m->node[m->size] = a2->node[j]; m->score[m->size] = a2->score[j]; m->size++; } } i++; j++; }
+    }
+    const nodearr *rest = i < a1->size ? a1 : a2;
+    int r = i < a1->size ? i : j;
+    if (r < rest->size) {
+        while (r < rest->size && rest->score[r] == lastScore) {
+            int seen = 0;
+            for (int t = 0; t < nl; t++) if (last[t] == rest->node[r]) { seen = 1; break; }
+            if (!seen) { m->node[m->size] = rest->node[r]; m->score[m->size] = rest->score[r]; m->size++; }   /* (contains(), not add(): :123,137) */
+            r++;
+        }
+        for (; r < rest->size; r++) { m->node[m->size] = rest->node[r]; m->score[m->size] = rest->score[r]; m->size++; }
+    }
+#undef NA_TAKE
+#undef NA_LAST_ADD
+    free(last);
+}
+/* descSortFindRightMostInsertionPoint :308-318 + duplicateExistsNear :212-228: -1 = (node, score) already there */
+static int na_insertion_point(const nodearr *a, int32_t node, float score)
+{
+    int start = 0, end = a->size - 1;
+    while (start <= end) {
+        int mid = (start + end) / 2;
+        if (a->score[mid] < score) end = mid - 1; else start = mid + 1;
+    }
+    for (int i = start - 1; i >= 0 && a->score[i] == score; i--) if (a->node[i] == node) return -1;
+    for (int i = start; i < a->size && a->score[i] == score; i++) if (a->node[i] == node) return -1;
+    return start;
+}
+static void na_insert_at(nodearr *a, int at, int32_t node, float score)
+{
+    memmove(a->node + at + 1, a->node + at, sizeof(int32_t) * (size_t)(a->size - at));
+    memmove(a->score + at + 1, a->score + at, sizeof(float) * (size_t)(a->size - at));
+    a->node[at] = node; a->score[at] = score; a->size++;
+}
+
+struct jvo_builder {
+    const jvo_pq *pq; const uint8_t *codes; const float *vecs; int64_t n; int vsf;
+    int maxDegree, beam, W, hardMaxDegree, addHierarchy, refine, dedupe_ids, improve_full_vectors;
+    float alpha, overflow;
+    float *tri;
+    int n_levels;                                   /* layers.size() */
+    int32_t *ids[JVO_BUILD_MAX_LEVELS]; float *sc[JVO_BUILD_MAX_LEVELS];   /* [n][W] */
+    int32_t *size[JVO_BUILD_MAX_LEVELS], *db[JVO_BUILD_MAX_LEVELS];        /* [n]; size -1 = the node is not on the level */
+    int32_t entry_node; int entry_level;
+    int64_t rng;
+    const int8_t *forced_levels;
+    jvo_graph g; int lcount[JVO_BUILD_MAX_LEVELS], ldeg[JVO_BUILD_MAX_LEVELS];
+    const int32_t *lnodes[JVO_BUILD_MAX_LEVELS]; const int32_t *lnbrs[JVO_BUILD_MAX_LEVELS];
+    jvo_searcher *s;
+    int64_t reprunes;
+};
+
+static void bld_ensure_level(jvo_builder *b, int level)   /* ensureLayersExist :180-193 */
+{
+    for (int l = b->n_levels; l <= level; l++) {
+        b->ids[l] = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->n * b->W);
+        memset(b->ids[l], 0xFF, sizeof(int32_t) * (size_t)b->n * b->W);
+        b->sc[l] = (float *)calloc((size_t)b->n * b->W, sizeof(float));
+        b->size[l] = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->n);
+        b->db[l] = (int32_t *)calloc((size_t)b->n, sizeof(int32_t));
+        for (int64_t i = 0; i < b->n; i++) b->size[l][i] = -1;
+        b->lcount[l] = (int)b->n; b->ldeg[l] = b->W; b->lnodes[l] = NULL; b->lnbrs[l] = b->ids[l];
+        b->n_levels = l + 1;
+    }
+    b->g.n_levels = b->n_levels;
+}
+
+jvo_builder *jvo_builder_new(const jvo_pq *pq, const uint8_t *codes, const float *vecs, int64_t n, int vsf, int maxDegree, int beamWidth,
+                             float alpha, float neighborOverflow, int addHierarchy, int refineFinalGraph)
+{
+    jvo_builder *b = (jvo_builder *)calloc(1, sizeof(jvo_builder));
+    b->pq = pq; b->codes = codes; b->vecs = vecs; b->n = n; b->vsf = vsf;
+    b->maxDegree = maxDegree; b->beam = beamWidth; b->alpha = alpha; b->overflow = neighborOverflow;
+    b->hardMaxDegree = (int)(neighborOverflow * maxDegree);       /* Neighbors.insert :270 ((int) (overflow * map.maxDegree)) */
+    b->W = (int)(maxDegree * neighborOverflow) + 1;               /* nodeArrayLength :128-131 over maxOverflowDegree (OnHeapGraphIndex :187) */
+    if (b->W < b->hardMaxDegree + 1) b->W = b->hardMaxDegree + 1;
+    b->addHierarchy = addHierarchy; b->refine = refineFinalGraph;
+    b->tri = (float *)malloc(sizeof(float) * (size_t)pq->M * ((size_t)pq->k * (pq->k + 1) / 2));
+    jvo_pq_codebook_partial_sums(pq, vsf, b->tri);
+    b->entry_node = -1; b->entry_level = -1;
+    jvo_java_random_seed(&b->rng, 0);
+    b->g.n_nodes = n; b->g.level_count = b->lcount; b->g.level_degree = b->ldeg; b->g.level_nodes = b->lnodes; b->g.level_neighbors = b->lnbrs;
+    bld_ensure_level(b, 0);
+    b->s = jvo_searcher_new(&b->g, pq, codes, NULL, vsf, 0);      /* "deliberately skips reranking" :197-200 */
+    return b;
+}
+void jvo_builder_free(jvo_builder *b)
+{
+    if (!b) return;
+    for (int l = 0; l < b->n_levels; l++) { free(b->ids[l]); free(b->sc[l]); free(b->size[l]); free(b->db[l]); }
+    jvo_searcher_free(b->s);
+    free(b->tri);
+    free(b);
+}
+/* per-node levels instead of the Random(0) draws (NULL = draw); and the two places where the engine's improve pass leaves the
+ * reference ON PURPOSE: dedupe_ids != 0 — a candidate whose node the merged list already holds is dropped whatever its
+ * score (the reference's merge drops it only at an equal score, so a node can sit in a list twice); full_vectors != 0 — the improve
+ * search is given the node's full-resolution vector, not its decoded code (searchProviderFor(int) :189-194). */
+void jvo_builder_set_levels(jvo_builder *b, const int8_t *levels) { b->forced_levels = levels; }
+void jvo_builder_set_deviations(jvo_builder *b, int dedupe_ids, int full_vectors) { b->dedupe_ids = dedupe_ids; b->improve_full_vectors = full_vectors; }
+
+static nodearr bld_row(jvo_builder *b, int level, int32_t node)
+{
+    nodearr a = { b->ids[level] + (size_t)node * b->W, b->sc[level] + (size_t)node * b->W, b->size[level][node] };
+    return a;
+}
+static void bld_store(jvo_builder *b, int level, int32_t node, const nodearr *a, int diverseBefore)
+{
+    int32_t *ids = b->ids[level] + (size_t)node * b->W; float *sc = b->sc[level] + (size_t)node * b->W;
+    if (a->node != ids) { memcpy(ids, a->node, sizeof(int32_t) * (size_t)a->size); memcpy(sc, a->score, sizeof(float) * (size_t)a->size); }
+    for (int i = a->size; i < b->W; i++) { ids[i] = -1; sc[i] = 0.0f; }
+    b->size[level][node] = a->size; b->db[level][node] = diverseBefore;
+}
+/* retainDiverseInternal :262-267: neighbors updated in place */
+static void bld_retain(jvo_builder *b, nodearr *a, int diverseBefore)
+{
+    uint8_t *sel = (uint8_t *)malloc((size_t)a->size + 1);
+    jvo_retain_diverse(b->tri, b->pq->M, b->pq->k, b->vsf, b->codes, a->node, a->score, a->size, b->maxDegree, diverseBefore, b->alpha, sel, NULL);
+    int w = 0;
+    for (int r = 0; r < a->size; r++) if (sel[r]) { a->node[w] = a->node[r]; a->score[w] = a->score[r]; w++; }
+    a->size = w;
+    free(sel);
+    b->reprunes++;
+}
+/* addEdges :279-282 = insertDiverse(node, candidates) :222-243, then backlink(newNeighbors, node, overflow) :139-146 -> insert :262-296 */
+static void bld_add_edges(jvo_builder *b, int level, int32_t node, const nodearr *cand)
+{
+    nodearr cur = bld_row(b, level, node);
+    if (cand->size > 0) {
+        nodearr merged; merged.node = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cur.size + cand->size + 1));
+        merged.score = (float *)malloc(sizeof(float) * (size_t)(cur.size + cand->size + 1));
+        if (cur.size > 0) {
+            na_merge(&cur, cand, &merged);
+            if (b->dedupe_ids) {   /* (deviation, see jvo_builder_set_deviations: the first = better-scored entry of a node stays) */
+                int w = 0;
+                for (int r = 0; r < merged.size; r++) {
+                    int dup = 0;
+                    for (int t = 0; t < w; t++) if (merged.node[t] == merged.node[r]) { dup = 1; break; }
+                    if (!dup) { merged.node[w] = merged.node[r]; merged.score[w] = merged.score[r]; w++; }
+                }
+                merged.size = w;
+            }
+        } else {
+            memcpy(merged.node, cand->node, sizeof(int32_t) * (size_t)cand->size);
+            memcpy(merged.score, cand->score, sizeof(float) * (size_t)cand->size);
+            merged.size = cand->size;
+        }
+        bld_retain(b, &merged, 0);
+        bld_store(b, level, node, &merged, merged.size);           /* new Neighbors(...): diverseBefore = size() :161-165 */
+        free(merged.node); free(merged.score);
+    }
+    /* backlink over the (new or unchanged) neighbours — a private copy: a list never holds its own node, so the loop below cannot
+     * change it, but the reference iterates the snapshot insertDiverse returned */
+    cur = bld_row(b, level, node);
+    int32_t *nn = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cur.size + 1)); float *ns = (float *)malloc(sizeof(float) * (size_t)(cur.size + 1));
+    memcpy(nn, cur.node, sizeof(int32_t) * (size_t)cur.size); memcpy(ns, cur.score, sizeof(float) * (size_t)cur.size);
+    const int cnt = cur.size;
+    for (int i = 0; i < cnt; i++) {
+        const int32_t nbr = nn[i];
+        nodearr t = bld_row(b, level, nbr);
+        if (t.size < 0) continue;                                 /* (cannot happen: a result of the level's search is on the level) */
+        const int at = na_insertion_point(&t, node, ns[i]);
+        if (at == -1) continue;                                   /* "new" node already existed :275-278 */
+        na_insert_at(&t, at, node, ns[i]);
+        int dbf = b->db[level][nbr] < at ? b->db[level][nbr] : at;   /* min(insertionPoint, diverseBefore) :285 */
+        if (t.size > b->hardMaxDegree) { bld_retain(b, &t, dbf); dbf = t.size; }
+        bld_store(b, level, nbr, &t, dbf);
+    }
+    free(nn); free(ns);
+}
+
+static void bld_search_init(jvo_builder *b, const float *query, int32_t exclude)   /* initializeInternal :334-353, acceptOrds = ExcludingBits(node) */
+{
+    jvo_searcher *s = b->s;
+    memcpy(s->query, query, sizeof(float) * (size_t)s->pq->D);
+    s->am = (s->vsf == JVO_COSINE && s->pq->self_magnitudes) ? s->pq->self_magnitudes : s->amag;
+    jvo_pqdecoder_init(s->pq, query, s->vsf, s->lut, s->am == s->amag ? s->amag : NULL, &s->bmag);
+    s->has_accept = 1;
+    memset(s->accept, 0xFF, sizeof(uint64_t) * (size_t)((b->n + 63) / 64));
+    s->accept[exclude >> 6] &= ~(1ULL << (exclude & 63));
+    s->res.n = s->evicted.n = s->cand.n = s->rer.n = 0;
+    memset(s->visited, 0, (size_t)b->n);
+    s->visited[b->entry_node] = 1;
+    lh_push(&s->cand, -1 - jvo_nodequeue_encode(b->entry_node, searcher_score(s, b->entry_node)));
+    s->visitedCount = s->expandedCount = s->expandedBase = 0;
+    s->searched = 1;
+}
+static void bld_entry_points_from_previous_layer(jvo_searcher *s)   /* :324-331 */
+{
+    for (int i = 0; i < s->res.n; i++) lh_push(&s->cand, -1 - s->res.a[i]);
+    for (int i = 0; i < s->evicted.n; i++) lh_push(&s->cand, -1 - s->evicted.a[i]);
+    s->res.n = s->evicted.n = 0;
+}
+static int cmp_nodescore(const void *x, const void *y)   /* SearchResult.NodeScore.compareTo :101-106 (keys: NodeQueue.encode) */
+{
+    const int64_t a = *(const int64_t *)x, c = *(const int64_t *)y;
+    const float sa = key_score(a), sc = key_score(c);
+    if (sa != sc) return sa > sc ? -1 : 1;
+    const int32_t na = key_node(a), nc = key_node(c);
+    return na < nc ? -1 : (na > nc ? 1 : 0);
+}
+
+/* addGraphNode(node, vector) :605-659.  Returns the node's level. */
+int jvo_builder_add(jvo_builder *b, int32_t node)
+{
+    const int level = b->forced_levels ? (int)b->forced_levels[node] : jvo_random_graph_level(&b->rng, b->maxDegree, b->addHierarchy);
+    bld_ensure_level(b, level);
+    for (int l = 0; l <= level; l++) { b->size[l][node] = 0; b->db[l][node] = 0; }   /* graph.addNode :161-168 */
+    b->g.entry_node = b->entry_node; b->g.entry_level = b->entry_level;
+    nodearr cand; cand.node = (int32_t *)malloc(sizeof(int32_t) * (size_t)(b->beam + 1)); cand.score = (float *)malloc(sizeof(float) * (size_t)(b->beam + 1));
+    cand.size = 0;
+    if (b->entry_node >= 0) {
+        jvo_searcher *s = b->s;
+        bld_search_init(b, b->vecs + (size_t)node * b->pq->D, node);
+        for (int lvl = b->entry_level; lvl > 0; lvl--) {
+            if (lvl > level) searcher_one_layer(s, 1, 0.0f, lvl, 0);
+            else {
+                searcher_one_layer(s, b->beam, 0.0f, lvl, 0);
+                int64_t *keys = (int64_t *)malloc(sizeof(int64_t) * (size_t)(s->res.n + 1));
+                memcpy(keys, s->res.a, sizeof(int64_t) * (size_t)s->res.n);     /* approximateResults.foreach: heap array order */
+                qsort(keys, (size_t)s->res.n, sizeof(int64_t), cmp_nodescore);   /* Arrays.sort(neighbors): total order, no ties left */
+                nodearr up; up.node = (int32_t *)malloc(sizeof(int32_t) * (size_t)(s->res.n + 1)); up.score = (float *)malloc(sizeof(float) * (size_t)(s->res.n + 1));
+                up.size = s->res.n;
+                for (int i = 0; i < s->res.n; i++) { up.node[i] = key_node(keys[i]); up.score[i] = key_score(keys[i]); }
+                bld_add_edges(b, lvl, node, &up);
+                free(keys); free(up.node); free(up.score);
+            }
+            bld_entry_points_from_previous_layer(s);
+        }
+        /* gs.resume(beamWidth, beamWidth, 0, 0) :509-512 */
+        searcher_layer0(s, b->beam, b->beam, 0.0f);
+        int32_t *oi = (int32_t *)malloc(sizeof(int32_t) * (size_t)b->beam); float *os = (float *)malloc(sizeof(float) * (size_t)b->beam);
+        const int nres = searcher_reranking(s, b->beam, 0.0f, oi, os, NULL, NULL);
+        for (int i = 0; i < nres; i++) { cand.node[i] = oi[i]; cand.score[i] = os[i]; }
+        cand.size = nres;
+        free(oi); free(os);
+    }
+    bld_add_edges(b, 0, node, &cand);
+    free(cand.node); free(cand.score);
+    if (b->entry_node < 0 || level > b->entry_level) { b->entry_node = node; b->entry_level = level; }   /* markComplete :214-225 */
+    return level;
+}
+
+/* improveConnections(node) :510-545 */
+void jvo_builder_improve(jvo_builder *b, int32_t node)
+{
+    jvo_searcher *s = b->s;
+    float *q = (float *)malloc(sizeof(float) * (size_t)b->pq->D);
+    if (b->improve_full_vectors) memcpy(q, b->vecs + (size_t)node * b->pq->D, sizeof(float) * (size_t)b->pq->D);
+    else jvo_pq_decode(b->pq, b->codes + (size_t)node * b->pq->M, q);   /* searchProviderFor(int node1) :189-194 */
+    b->g.entry_node = b->entry_node; b->g.entry_level = b->entry_level;
+    bld_search_init(b, q, node);
+    for (int lvl = b->entry_level; lvl >= 0; lvl--) {
+        if (b->size[lvl][node] > 0) {
+            searcher_one_layer(s, b->beam, 0.0f, lvl, 1);
+            nodearr c; c.node = (int32_t *)malloc(sizeof(int32_t) * (size_t)(s->res.n + 1)); c.score = (float *)malloc(sizeof(float) * (size_t)(s->res.n + 1));
+            c.size = 0;
+            for (int i = 0; i < s->res.n; i++) {   /* approximateResults.foreach(candidates::insertSorted): heap array order */
+                const int32_t nd = key_node(s->res.a[i]); const float sc = key_score(s->res.a[i]);
+                const int at = na_insertion_point(&c, nd, sc);
+                if (at >= 0) na_insert_at(&c, at, nd, sc);
+            }
+            bld_add_edges(b, lvl, node, &c);
+            free(c.node); free(c.score);
+        } else searcher_one_layer(s, 1, 0.0f, lvl, 1);
+        bld_entry_points_from_previous_layer(s);
+    }
+    free(q);
+}
+/* enforceDegree(node) on every level :79-90, :190-200 */
+void jvo_builder_enforce_degree(jvo_builder *b, int32_t node)
+{
+    for (int l = 0; l < b->n_levels; l++) {
+        if (b->size[l][node] <= b->maxDegree) continue;
+        nodearr t = bld_row(b, l, node);
+        bld_retain(b, &t, b->db[l][node]);
+        bld_store(b, l, node, &t, t.size);
+    }
+}
+/* cleanup() :472-508 without deletions: improveConnections over the nodes of level 1 when the graph has levels and refineFinalGraph is
+ * set, then enforceDegree over every id (both in ascending id order here; the reference runs them from a parallel stream) */
+void jvo_builder_cleanup(jvo_builder *b)
+{
+    if (b->entry_node < 0) return;
+    if (b->refine && b->n_levels - 1 > 0)
+        for (int64_t i = 0; i < b->n; i++) if (b->size[1][i] >= 0) jvo_builder_improve(b, (int32_t)i);
+    for (int64_t i = 0; i < b->n; i++) if (b->size[0][i] >= 0) jvo_builder_enforce_degree(b, (int32_t)i);
+}
+/* a node's list on a level: returns its size (-1: not on the level); ids / scores (nullable) get `size` entries, *diverseBefore too */
+int jvo_builder_row(const jvo_builder *b, int level, int32_t node, int32_t *ids, float *scores, int *diverseBefore)
+{
+    if (level < 0 || level >= b->n_levels) return -1;
+    const int sz = b->size[level][node];
+    if (sz < 0) return -1;
+    if (ids) memcpy(ids, b->ids[level] + (size_t)node * b->W, sizeof(int32_t) * (size_t)sz);
+    if (scores) memcpy(scores, b->sc[level] + (size_t)node * b->W, sizeof(float) * (size_t)sz);
+    if (diverseBefore) *diverseBefore = b->db[level][node];
+    return sz;
+}
+void jvo_builder_info(const jvo_builder *b, int32_t *entry_node, int *entry_level, int *n_levels, int64_t *reprunes)
+{
+    if (entry_node) *entry_node = b->entry_node;
+    if (entry_level) *entry_level = b->entry_level;
+    if (n_levels) *n_levels = b->n_levels;
+    if (reprunes) *reprunes = b->reprunes;
+}

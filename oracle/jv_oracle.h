@@ -178,6 +178,24 @@ int jvo_searcher_resume(jvo_searcher *s, int additionalK, int rerankK, int32_t *
 /* org.apache.commons.math3 (3.6.1) StatUtils.percentile = Percentile, EstimationType.LEGACY, restated from its documentation */
 double jvo_percentile_legacy(const double *values, int n, double p);
 
+/* ---- GraphIndexBuilder with one thread (jv_oracle.c "GraphIndexBuilder, one thread"): java.util.Random(0) level draws, addGraphNode,
+ * insertDiverse / backlink / enforceDegree, improveConnections, cleanup — the checker of the engine's builder in reference order ---- */
+void   jvo_java_random_seed(int64_t *state, int64_t seed);
+double jvo_java_random_next_double(int64_t *state);
+int    jvo_random_graph_level(int64_t *state, int degree0, int addHierarchy);
+typedef struct jvo_builder jvo_builder;
+jvo_builder *jvo_builder_new(const jvo_pq *pq, const uint8_t *codes, const float *vecs, int64_t n, int vsf, int maxDegree, int beamWidth,
+                             float alpha, float neighborOverflow, int addHierarchy, int refineFinalGraph);
+void jvo_builder_free(jvo_builder *b);
+void jvo_builder_set_levels(jvo_builder *b, const int8_t *levels);
+void jvo_builder_set_deviations(jvo_builder *b, int dedupe_ids, int full_vectors);
+int  jvo_builder_add(jvo_builder *b, int32_t node);
+void jvo_builder_improve(jvo_builder *b, int32_t node);
+void jvo_builder_enforce_degree(jvo_builder *b, int32_t node);
+void jvo_builder_cleanup(jvo_builder *b);
+int  jvo_builder_row(const jvo_builder *b, int level, int32_t node, int32_t *ids, float *scores, int *diverseBefore);
+void jvo_builder_info(const jvo_builder *b, int32_t *entry_node, int *entry_level, int *n_levels, int64_t *reprunes);
+
 /* exact rerank of pre-gathered candidate rows (Q x R x D), one query per worker thread */
 void jvo_rerank(const float *queries, const float *cand_vecs, const int32_t *cand_ids, int Q, int R, int D, int vsf,
                 int topK, int32_t *out_ids, float *out_scores, int nthreads);

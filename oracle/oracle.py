@@ -255,6 +255,19 @@ def lib():
         sig("jvo_nvq_reconstruction_error", C.c_double, fp, C.c_int, C.c_int, fp, C.c_int)
         sig("jvo_set_nvq_reranker", None, u8p, fp, fp, C.c_int, C.c_int)
         sig("jvo_nvq_reranker_active", C.c_int)
+        sig("jvo_java_random_seed", None, C.POINTER(C.c_int64), C.c_int64)
+        sig("jvo_java_random_next_double", C.c_double, C.POINTER(C.c_int64))
+        sig("jvo_random_graph_level", C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int)
+        sig("jvo_builder_new", C.c_void_p, pqp, u8p, fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int)
+        sig("jvo_builder_free", None, C.c_void_p)
+        sig("jvo_builder_set_levels", None, C.c_void_p, C.POINTER(C.c_int8))
+        sig("jvo_builder_set_deviations", None, C.c_void_p, C.c_int, C.c_int)
+        sig("jvo_builder_add", C.c_int, C.c_void_p, C.c_int32)
+        sig("jvo_builder_improve", None, C.c_void_p, C.c_int32)
+        sig("jvo_builder_enforce_degree", None, C.c_void_p, C.c_int32)
+        sig("jvo_builder_cleanup", None, C.c_void_p)
+        sig("jvo_builder_row", C.c_int, C.c_void_p, C.c_int, C.c_int32, i32p, fp, C.POINTER(C.c_int))
+        sig("jvo_builder_info", None, C.c_void_p, i32p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64))
         _lib = L
     return _lib
 
@@ -681,3 +694,80 @@ class OraclePQ:
         pq = OraclePQ(D.value, M.value, cbs[:total].copy(),
                       centroid[:cl.value].copy() if cl.value > 0 else None, k.value, sizes=szs)
         return pq, ver.value, float(aniso.value), consumed.value
+
+
+class JavaRandom:
+    """java.util.Random (the builder's level draws: new Random(0), GraphIndexBuilder.java:337)"""
+
+    def __init__(self, seed=0):
+        self._st = C.c_int64()
+        lib().jvo_java_random_seed(C.byref(self._st), int(seed))
+
+    def next_double(self):
+        return float(lib().jvo_java_random_next_double(C.byref(self._st)))
+
+    def graph_level(self, degree0, add_hierarchy=True):
+        return int(lib().jvo_random_graph_level(C.byref(self._st), int(degree0), int(bool(add_hierarchy))))
+
+
+class OracleBuilder:
+    """GraphIndexBuilder driven by ONE thread over PQ build scores (jv_oracle.c "GraphIndexBuilder, one thread"): add() =
+    addGraphNode, cleanup() = cleanup; rows come back in NodeArray order with their scores and diverseBefore mark."""
+
+    def __init__(self, pq, codes, vecs, vsf, max_degree, beam_width, alpha=1.2, neighbor_overflow=1.2, add_hierarchy=False,
+                 refine_final_graph=True, levels=None, dedupe_ids=False, improve_full_vectors=False):
+        self.pq = pq
+        self.codes = np.ascontiguousarray(codes, np.uint8)
+        self.vecs = f32(vecs)
+        self.n = int(self.codes.shape[0])
+        self.max_degree = int(max_degree)
+        self._h = lib().jvo_builder_new(pq.ref, _u8(self.codes), _f(self.vecs), self.n, int(vsf), int(max_degree), int(beam_width),
+                                        C.c_float(alpha), C.c_float(neighbor_overflow), int(bool(add_hierarchy)), int(bool(refine_final_graph)))
+        self._levels = None
+        if levels is not None:
+            self._levels = np.ascontiguousarray(levels, np.int8)
+            lib().jvo_builder_set_levels(self._h, self._levels.ctypes.data_as(C.POINTER(C.c_int8)))
+        if dedupe_ids or improve_full_vectors:
+            lib().jvo_builder_set_deviations(self._h, int(bool(dedupe_ids)), int(bool(improve_full_vectors)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().jvo_builder_free(self._h)
+            self._h = None
+
+    def add(self, node):
+        return int(lib().jvo_builder_add(self._h, int(node)))
+
+    def improve(self, node):
+        lib().jvo_builder_improve(self._h, int(node))
+
+    def enforce_degree(self, node):
+        lib().jvo_builder_enforce_degree(self._h, int(node))
+
+    def cleanup(self):
+        lib().jvo_builder_cleanup(self._h)
+
+    def info(self):
+        e, el, nl, rp = C.c_int32(), C.c_int(), C.c_int(), C.c_int64()
+        lib().jvo_builder_info(self._h, C.byref(e), C.byref(el), C.byref(nl), C.byref(rp))
+        return {"entry_node": e.value, "entry_level": el.value, "n_levels": nl.value, "reprunes": rp.value}
+
+    def row(self, level, node):
+        """(ids, scores, diverseBefore) or None when the node is not on the level"""
+        ids = np.empty(4 * self.max_degree + 8, np.int32)
+        sc = np.empty(4 * self.max_degree + 8, np.float32)
+        db = C.c_int()
+        n = lib().jvo_builder_row(self._h, int(level), int(node), ids.ctypes.data_as(C.POINTER(C.c_int32)), _f(sc), C.byref(db))
+        if n < 0:
+            return None
+        return ids[:n].copy(), sc[:n].copy(), db.value
+
+    def rows(self, level, width):
+        """[n, width] packed ids, -1 padded (the lists must fit)"""
+        out = np.full((self.n, width), -1, np.int32)
+        for v in range(self.n):
+            r = self.row(level, v)
+            if r is not None:
+                assert r[0].size <= width
+                out[v, :r[0].size] = r[0]
+        return out

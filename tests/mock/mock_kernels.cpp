@@ -677,6 +677,26 @@ int launch_bl_list_over_degree(hipStream_t, const BlOverParams &p)
     for (long long i = p.N - 1; i >= 0; --i) bl_list_over_degree(p, i);
     return JV_OK;
 }
+int launch_bl_ro_apply_selection(hipStream_t, const BlRoApplyParams &p)
+{
+    for (long long b = p.B - 1; b >= 0; --b) bl_ro_apply_selection(p, b);
+    return JV_OK;
+}
+int launch_bl_ro_backlink_merge(hipStream_t, const BlRoMergeParams &p)
+{
+    for (long long i = p.E - 1; i >= 0; --i) bl_ro_backlink_merge(p, i);
+    return JV_OK;
+}
+int launch_bl_ro_rewrite_rows(hipStream_t, const BlRoRowsParams &p)
+{
+    for (long long i = p.P - 1; i >= 0; --i) bl_ro_rewrite_row(p, i);
+    return JV_OK;
+}
+int launch_bl_ro_copy_rows(hipStream_t, const BlRoCopyParams &p)
+{
+    for (long long i = p.P - 1; i >= 0; --i) bl_ro_copy_row(p, i);
+    return JV_OK;
+}
 int launch_bl_count_valid(hipStream_t, const int32_t *cand, int C, int32_t *count, long long B)
 {
     for (long long b = 0; b < B; ++b) bl_count_valid(cand, C, count, b);
