@@ -419,6 +419,92 @@ BL_FN void bl_ro_rewrite_row(const BlRoRowsParams &p, long long r)
     }
 }
 
+// improveConnections in reference order (GraphIndexBuilder.java:510-545 -> addEdges -> Neighbors.insertDiverse :222-243): the node's
+// list and the search's candidates merged the way NodeArray.merge walks them (:63-143: the better score first; at EQUAL scores one
+// entry of the list, then one of the candidates), except that a node the merged list already holds is dropped whatever its score —
+// the reference drops it only at an equal score and so can list a node twice (the oracle restates both: jvo_builder_set_deviations).
+struct BlRoImproveParams {
+    const int32_t *nodes;     // [B]
+    const int32_t *cand;      // [B][C] best first, -1 padded
+    const float *cand_sc;     // [B][C]
+    int B, C, R;
+    const int32_t *nbrs;      // [N][R]
+    const float *nsc;         // [N][R]
+    int32_t *list;            // [B][R + C]
+    float *lsc;               // [B][R + C]
+    int32_t *ln;              // [B] merged entries
+};
+
+BL_FN void bl_ro_take(int32_t *out, float *osc, int &w, int32_t x, float s, int32_t self)
+{
+    if (x < 0 || x == self) return;
+    for (int t = 0; t < w; ++t)
+        if (out[t] == x) return;
+    out[w] = x;
+    osc[w] = s;
+    ++w;
+}
+
+// item = b
+BL_FN void bl_ro_improve_list(const BlRoImproveParams &p, long long b)
+{
+    const int32_t v = p.nodes[b];
+    const int32_t *a1 = p.nbrs + (long long)v * p.R;
+    const float *s1 = p.nsc + (long long)v * p.R;
+    const int32_t *a2 = p.cand + b * (long long)p.C;
+    const float *s2 = p.cand_sc + b * (long long)p.C;
+    int n1 = 0, n2 = 0;
+    while (n1 < p.R && a1[n1] >= 0) ++n1;
+    while (n2 < p.C && a2[n2] >= 0) ++n2;
+    if (n1 == 0) n2 = 0;   // "if (graph.getNeighborsIterator(lvl, node).size() > 0)" (:527): a node without neighbours is left alone
+    const int L = p.R + p.C;
+    int32_t *out = p.list + b * (long long)L;
+    float *osc = p.lsc + b * (long long)L;
+    int w = 0, i = 0, j = 0;
+    while (i < n1 && j < n2) {
+        if (s1[i] < s2[j]) {
+            bl_ro_take(out, osc, w, a2[j], s2[j], v);
+            ++j;
+        } else if (s1[i] > s2[j]) {
+            bl_ro_take(out, osc, w, a1[i], s1[i], v);
+            ++i;
+        } else {
+            bl_ro_take(out, osc, w, a1[i], s1[i], v);
+            bl_ro_take(out, osc, w, a2[j], s2[j], v);
+            ++i;
+            ++j;
+        }
+    }
+    for (; i < n1; ++i) bl_ro_take(out, osc, w, a1[i], s1[i], v);
+    for (; j < n2; ++j) bl_ro_take(out, osc, w, a2[j], s2[j], v);
+    p.ln[b] = w;
+    for (; w < L; ++w) {
+        out[w] = -1;
+        osc[w] = 0.0f;
+    }
+}
+
+// back edges of rows that were just rewritten, with the score each member is listed under: item = b * Rf + j
+struct BlRoRowEdgesParams {
+    const int32_t *nodes;     // [B]
+    int B, Rf, R;
+    const int32_t *nbrs;
+    const float *nsc;
+    unsigned long long *edge_keys;
+    int32_t *edge_src;
+    float *edge_sc;
+};
+
+BL_FN void bl_ro_row_edges(const BlRoRowEdgesParams &p, long long item)
+{
+    const int b = (int)(item / p.Rf), j = (int)(item % p.Rf);
+    const int32_t v = p.nodes[b];
+    const int32_t u = p.nbrs[(long long)v * p.R + j];
+    p.edge_keys[item] = u >= 0 ? (((unsigned long long)(uint32_t)u) << 32) | (unsigned long long)(uint32_t)item : ~0ull;
+    p.edge_src[item] = v;
+    p.edge_sc[item] = u >= 0 ? p.nsc[(long long)v * p.R + j] : 0.0f;
+}
+
 struct BlRoCopyParams {
     const int32_t *tgt;     // [P]
     int P, R;

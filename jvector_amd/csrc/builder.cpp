@@ -300,7 +300,7 @@ static int check_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes, int B, 
 }
 
 // 1 + 2: the batch's vectors as queries, GraphSearcher.search(topK = rerankK = k) over the graph built so far -> d_cand / d_csc [B][k]
-static int search_candidates(jv_ctx *ctx, jv_builder *b, const int32_t *d_nodes, int B, int k)
+static int search_candidates(jv_ctx *ctx, jv_builder *b, const int32_t *d_nodes, int B, int k, bool exclude_self = false)
 {
     const int D = b->pq->D;
     const int search_chunk = 65536;
@@ -320,8 +320,12 @@ static int search_candidates(jv_ctx *ctx, jv_builder *b, const int32_t *d_nodes,
         const int bc = std::min(search_chunk, B - s);
         JV_TRY(launch_gather_rows(ctx->stream, b->vectors->d_vecs, b->vectors->count, D, d_nodes + s, bc, (float *)b->d_q.ptr, nullptr, 0));
         b->h_stats.resize(2 * (size_t)bc);
-        JV_TRY(jv_hip_graph_search(ctx, b->graph, b->luts, b->codes, nullptr, nullptr, (const float *)b->d_q.ptr, bc, b->vsf, k, k,
-                                   d_cand + (size_t)s * k, d_csc + (size_t)s * k, b->h_stats.data()));
+        if (exclude_self)   // acceptOrds = ExcludingBits(node) (improveConnections :518): the node is traversed, never returned
+            JV_TRY(graph_search_excluding(ctx, b->graph, b->luts, b->codes, (const float *)b->d_q.ptr, bc, b->vsf, k, k, d_nodes + s,
+                                          d_cand + (size_t)s * k, d_csc + (size_t)s * k, b->h_stats.data()));
+        else
+            JV_TRY(jv_hip_graph_search(ctx, b->graph, b->luts, b->codes, nullptr, nullptr, (const float *)b->d_q.ptr, bc, b->vsf, k, k,
+                                       d_cand + (size_t)s * k, d_csc + (size_t)s * k, b->h_stats.data()));
         for (int q = 0; q < bc; ++q) {
             b->visited += b->h_stats[2 * (size_t)q];
             b->expanded += b->h_stats[2 * (size_t)q + 1];
@@ -477,7 +481,9 @@ int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes
         JV_TRY(launch_bl_ro_apply_selection(ctx->stream, rp));
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         b->prune_s += now_s() - t0;
-        JV_TRY(link_back_edges_ro(ctx, b, E, 0));
+        // (dedupe: a fresh node is in nobody's list, so this changes nothing for an insert — it keeps a RE-insertion of a node the
+        //  graph already holds, build_vamana's `passes` experiment, from listing it twice under two scores)
+        JV_TRY(link_back_edges_ro(ctx, b, E, 1));
         b->inserted += B;
         b->batches += 1;
         return JV_OK;
@@ -518,7 +524,7 @@ int jv_hip_builder_improve_batch(jv_ctx *ctx, jv_builder *b, const int32_t *node
     if (B == 0) return JV_OK;
     JV_REQUIRE(nodes, "builder_improve_batch: NULL nodes");
     JV_REQUIRE(b->entry >= 0 && b->inserted >= 2, "builder_improve_batch: nothing to improve in an empty graph");
-    JV_REQUIRE(!b->ref, "builder_improve_batch: not available in reference order (bl_ref_order = 1) yet");
+
     JV_REQUIRE(ctx->device == b->device, "builder_improve_batch: the builder lives on device %d", b->device);
     JV_TRY(use_device(ctx->device));
     const int Rf = b->Rf, R = b->R;
@@ -533,10 +539,49 @@ int jv_hip_builder_improve_batch(jv_ctx *ctx, jv_builder *b, const int32_t *node
     JV_HIP_CHECK(hipMemcpyAsync(b->d_nodes.ptr, nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));
     if (!is_device_ptr(nodes)) JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const int32_t *d_nodes = (const int32_t *)b->d_nodes.ptr;
-    JV_TRY(search_candidates(ctx, b, d_nodes, B, k));
+    JV_TRY(search_candidates(ctx, b, d_nodes, B, k, b->ref));
 
     double t0 = now_s();
     const int L = R + k;
+    if (b->ref) {   // insertDiverse(merge(list, candidates)) with the stored / search scores, then backlink every member of the new list
+        JV_TRY(b->d_imp_list.reserve(sizeof(int32_t) * (size_t)B * L));
+        JV_TRY(b->d_over_sc.reserve(sizeof(float) * (size_t)B * L));
+        JV_TRY(b->d_over_n.reserve(sizeof(int32_t) * (size_t)B));
+        BlRoImproveParams ip{};
+        ip.nodes = d_nodes;
+        ip.cand = (const int32_t *)b->d_cand.ptr;
+        ip.cand_sc = (const float *)b->d_csc.ptr;
+        ip.B = B;
+        ip.C = k;
+        ip.R = R;
+        ip.nbrs = b->d_nbrs;
+        ip.nsc = b->d_nsc;
+        ip.list = (int32_t *)b->d_imp_list.ptr;
+        ip.lsc = (float *)b->d_over_sc.ptr;
+        ip.ln = (int32_t *)b->d_over_n.ptr;
+        JV_TRY(launch_bl_ro_improve_list(ctx->stream, ip));
+        JV_TRY(reprune_lists_ro(ctx, b, d_nodes, ip.list, ip.lsc, ip.ln, nullptr, B, L));
+        const long long E = (long long)B * Rf;
+        JV_TRY(reserve_edges(b, E));
+        JV_TRY(b->d_esc.reserve(sizeof(float) * (size_t)E));
+        BlRoRowEdgesParams ep{};
+        ep.nodes = d_nodes;
+        ep.B = B;
+        ep.Rf = Rf;
+        ep.R = R;
+        ep.nbrs = b->d_nbrs;
+        ep.nsc = b->d_nsc;
+        ep.edge_keys = (unsigned long long *)b->d_keys.ptr;
+        ep.edge_src = (int32_t *)b->d_src.ptr;
+        ep.edge_sc = (float *)b->d_esc.ptr;
+        JV_TRY(launch_bl_ro_row_edges(ctx->stream, ep));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        b->prune_s += now_s() - t0;
+        JV_TRY(link_back_edges_ro(ctx, b, E, 1));
+        b->batches += 1;
+        b->improved += B;
+        return JV_OK;
+    }
     JV_TRY(b->d_imp_list.reserve(sizeof(int32_t) * (size_t)B * L));
     BlImproveParams ip{};
     ip.nodes = d_nodes;

@@ -622,8 +622,10 @@ static int check_fused_matches_graph(jv_ctx *ctx, jv_graph *g, const jv_fused *f
 struct AcceptMask {
     const uint64_t *bits = nullptr;  // HOST memory for the host traversal, DEVICE memory for the device traversal
     int64_t stride_words = 0;
+    const int32_t *exclude = nullptr;   // [Q] ExcludingBits(node) of the builder's searches: query q never returns exclude[q] (same memory rule)
     bool accepts(int q, int32_t node) const
     {
+        if (exclude && exclude[q] == node) return false;
         return !bits || ((bits[(int64_t)q * stride_words + (node >> 6)] >> (node & 63)) & 1ull);
     }
 };
@@ -1357,11 +1359,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     for (int lv = 0; lv <= g->entry_level; ++lv) pairc = pairc && g->levels[lv].degree <= 64;
     // gs_ub8 = 1: the pair-lane kernel with an 8-bit upper-bound table of the query's ADC entries per wave (gs_body.h "UB8": fresh
     // neighbours that provably cannot be popped skip their exact score).  Costs M x 256 bytes of LDS per wave (fewer waves per CU).
-    const bool ub8 = !so && !wgx && pair && !lutr && fused && !dev_accept.bits && ctx_opt(ctx, "gs_ub8", 0) != 0 && graph_search_ub8_supported(pq->M, kvsf);
+    const bool ub8 = !so && !wgx && pair && !lutr && fused && !dev_accept.bits && !dev_accept.exclude && ctx_opt(ctx, "gs_ub8", 0) != 0 && graph_search_ub8_supported(pq->M, kvsf);
     // gs_ubr (default: on where it applies): the pair-lane kernel with the batch's upper-bound tables PREBUILT by a dense kernel and
     // held in the wave's registers, survivors compacted and scored eight lanes each, the candidate tier trimmed to what can still be
     // popped (gs_body.h "UBR").  No LDS beyond the pair form's.  Tables: M x 256 bytes per query of the batch.
-    const bool ubr = !so && !wgx && pair && !lutr && !ub8 && occ == 2 && !dev_accept.bits && ctx_opt(ctx, "gs_ubr", kGsUbrDefault) != 0 &&
+    const bool ubr = !so && !wgx && pair && !lutr && !ub8 && occ == 2 && !dev_accept.bits && !dev_accept.exclude && ctx_opt(ctx, "gs_ubr", kGsUbrDefault) != 0 &&
                      graph_search_ubr_supported(pq->M, kvsf)
 #ifdef JV_EXPERIMENTAL
                      && ctx_opt(ctx, "gs_quad", 0) == 0   // (a launch that asks for the four-lane path of the plain pair kernel means that kernel)
@@ -1531,6 +1533,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.rerankK = rerankK;
     p.accept = (const unsigned long long *)dev_accept.bits;
     p.accept_stride = dev_accept.stride_words;
+    p.exclude = dev_accept.exclude;
     p.visited = (int32_t *)ctx->d_gs_visited.ptr;
     p.vcap_log2 = vcap_log2;
     p.spill = (long long *)ctx->d_gs_spill.ptr;
@@ -1875,6 +1878,12 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
                    sizeof(uint64_t) * (size_t)host_accept.stride_words);
         sub_accept.bits = sub_mask.data();
     }
+    std::vector<int32_t> sub_excl;
+    if (host_accept.exclude) {
+        sub_excl.resize((size_t)R);
+        for (int i = 0; i < R; ++i) sub_excl[(size_t)i] = host_accept.exclude[redo[i]];
+        sub_accept.exclude = sub_excl.data();
+    }
     HostSearchOpts sub_opt;
     sub_opt.accept = sub_accept;
     JV_TRY(graph_search_host(ctx, g, l, codes, fused, vectors, sub.data(), R, vsf, topK, rerankK, sub_ids.data(), sub_sc.data(),
@@ -1902,10 +1911,25 @@ int jv_hip_graph_search(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_cod
                                         stats);
 }
 
+static int graph_search_filtered_impl(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
+                                      const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
+                                      const uint64_t *accept_bits, int64_t accept_stride_words, const int32_t *exclude_dev, int32_t *out_ids,
+                                      float *out_scores, int64_t *stats);
+
 int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
                                  const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
                                  const uint64_t *accept_bits, int64_t accept_stride_words, int32_t *out_ids, float *out_scores,
                                  int64_t *stats)
+{
+    return graph_search_filtered_impl(ctx, g, l, codes, fused, vectors, queries, Q, vsf, topK, rerankK, accept_bits, accept_stride_words, nullptr,
+                                      out_ids, out_scores, stats);
+}
+
+// exclude_dev: [Q] node ids in DEVICE memory or nullptr — ExcludingBits(node) of the builder's own searches (jv::graph_search_excluding)
+static int graph_search_filtered_impl(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const jv_fused *fused,
+                                      const jv_vectors *vectors, const float *queries, int Q, jv_vsf vsf, int topK, int rerankK,
+                                      const uint64_t *accept_bits, int64_t accept_stride_words, const int32_t *exclude_dev, int32_t *out_ids,
+                                      float *out_scores, int64_t *stats)
 {
     clear_error();
     JV_REQUIRE(ctx && g && l && codes, "graph_search: NULL argument");
@@ -1933,6 +1957,14 @@ int jv_hip_graph_search_filtered(jv_ctx *ctx, const jv_graph *g, jv_luts *l, con
     const size_t mask_words = !accept_bits ? 0 : (accept_stride_words == 0 ? (size_t)words : (size_t)accept_stride_words * (size_t)std::max(Q, 0));
     AcceptMask host_accept, dev_accept;
     std::vector<uint64_t> host_copy;
+    std::vector<int32_t> host_excl;
+    if (exclude_dev && Q > 0) {   // (the host copy serves the few queries the device traversal hands back, and the host traversal)
+        JV_TRY(use_device(ctx->device));
+        host_excl.resize((size_t)Q);
+        JV_HIP_CHECK(hipMemcpy(host_excl.data(), exclude_dev, sizeof(int32_t) * (size_t)Q, hipMemcpyDefault));
+        host_accept.exclude = host_excl.data();
+        dev_accept.exclude = exclude_dev;
+    }
     if (accept_bits && Q > 0) {
         JV_TRY(use_device(ctx->device));
         host_accept.stride_words = dev_accept.stride_words = accept_stride_words;
@@ -2298,3 +2330,14 @@ int jv_hip_searcher_resume(jv_ctx *ctx, jv_searcher *s, int additionalK, int rer
 }
 
 }  // extern "C"
+
+namespace jv {
+// GraphSearcher.search with acceptOrds = ExcludingBits(exclude[q]) per query (GraphIndexBuilder.improveConnections :518): for the
+// builder, whose batches make a per-query bit mask over every node impractical.  exclude: [Q] ids in device memory.
+int graph_search_excluding(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const float *queries, int Q, jv_vsf vsf, int topK,
+                           int rerankK, const int32_t *exclude, int32_t *out_ids, float *out_scores, int64_t *stats)
+{
+    return graph_search_filtered_impl(ctx, g, l, codes, nullptr, nullptr, queries, Q, vsf, topK, rerankK, nullptr, 0, exclude, out_ids, out_scores,
+                                      stats);
+}
+}  // namespace jv

@@ -1119,6 +1119,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     }
     const float query_mag = (VSF == 2) ? p.bmag[q] : 0.0f;
     const unsigned long long *acc = p.accept ? p.accept + (long long)q * p.accept_stride : nullptr;
+    const int32_t excl = p.exclude ? p.exclude[q] : -1;
     // ---- UB8: the query's upper-bound table, behind the worker's block; the pop threshold it is compared with (wave-uniform) ----
     GsUb8 ub{};
     float ub_T = -__builtin_inff();       // >= rerankK nodes with exact score >= ub_T are known (queued or popped)
@@ -1131,7 +1132,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         ub.lo = reinterpret_cast<float *>(ub_base + (size_t)p.M * 256);
         ub.scale = ub.lo + p.M;
         gs_ub8_build<VSF, CH16>(p.codebooks, qs, ub);
-        ub_on = ub.ok && acc == nullptr && p.blocks != nullptr;   // (acceptOrds: rejected nodes never become results — no threshold)
+        ub_on = ub.ok && acc == nullptr && excl < 0 && p.blocks != nullptr;   // (acceptOrds: rejected nodes never become results — no threshold)
     }
     (void)ub_last_spill_max;
     (void)ub_dropped;
@@ -1144,7 +1145,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         const float *meta = p.ubr_meta + (int64_t)q * 4;
         ubr_base = meta[0];
         ubr_scale = meta[1];
-        ub_on = meta[2] != 0.0f && acc == nullptr;   // (acceptOrds: rejected nodes never become results — no threshold)
+        ub_on = meta[2] != 0.0f && acc == nullptr && excl < 0;   // (acceptOrds: rejected nodes never become results — no threshold)
     }
     (void)ubtab;
     (void)ubr_base;
@@ -1354,6 +1355,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 const int32_t tn = gs_key_node(top);
                 result = ((acc[tn >> 6] >> (tn & 63)) & 1ull) != 0;
             }
+            if (result && lvl == 0 && excl >= 0) result = gs_key_node(top) != excl;
             if (result && lvl == 0 && p.push_log && lane == 0) {  // the addTopCandidate sequence, for rt_body.h's tie resolution
                 const int n_log = *reinterpret_cast<int *>(s.evicted);
                 if (n_log < p.push_log_cap) p.push_log[(int64_t)q * p.push_log_cap + n_log] = top;

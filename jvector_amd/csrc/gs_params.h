@@ -45,6 +45,8 @@ struct GsParams {
     const int32_t *qmap;      // nullptr: work items 0..Q-1 ARE the query indices; else item i runs query qmap[i] (retry pass)
     const unsigned long long *accept;  // acceptOrds bit array (bit n of word n / 64) or nullptr = Bits.ALL; layer 0 only
     long long accept_stride;           // words between the masks of consecutive queries; 0 = one mask for the batch
+    const int32_t *exclude;            // [Q] or nullptr: ExcludingBits(node) — query q's own node may be traversed but never becomes a result
+                                       // (GraphIndexBuilder.java:518,623: the builder's searches); layer 0 only, like accept
     // per-worker scratch
     int32_t *visited;         // [workers][1 << vcap_log2]
     int32_t vcap_log2;

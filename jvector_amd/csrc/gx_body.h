@@ -420,6 +420,7 @@ GS_FN void gx_control(const GsParams &p, int q, int worker, char *lds)
     gs_barrier();
     const float query_mag = (VSF == 2) ? p.bmag[q] : 0.0f;
     const unsigned long long *acc = p.accept ? p.accept + (long long)q * p.accept_stride : nullptr;
+    const int32_t excl = p.exclude ? p.exclude[q] : -1;
 
     // ---- initializeInternal :334-353: mark and score the entry node ----
     {
@@ -513,6 +514,7 @@ GS_FN void gx_control(const GsParams &p, int q, int worker, char *lds)
             // layer 0 only (:276); then addTopCandidate :515-530
             bool result = top_score >= 0.0f;
             if (result && lvl == 0 && acc) result = ((acc[node >> 6] >> (node & 63)) & 1ull) != 0;
+            if (result && lvl == 0 && excl >= 0) result = node != excl;
             if (result && lvl == 0 && p.push_log) {   // the addTopCandidate sequence, for rt_body.h's tie resolution
                 if (lane == 0) {
                     if (log_n < p.wgx_log) log_lds[log_n] = top;

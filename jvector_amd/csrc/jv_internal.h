@@ -372,6 +372,8 @@ struct BlRowsParams;
 struct BlOverParams;
 struct BlImproveParams;
 struct BlRowEdgesParams;
+int graph_search_excluding(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const jv_codes *codes, const float *queries, int Q, jv_vsf vsf, int topK,
+                           int rerankK, const int32_t *exclude, int32_t *out_ids, float *out_scores, int64_t *stats);
 struct BlRoApplyParams;
 struct BlRoMergeParams;
 struct BlRoRowsParams;
@@ -380,6 +382,10 @@ int launch_bl_ro_apply_selection(hipStream_t s, const BlRoApplyParams &p);
 int launch_bl_ro_backlink_merge(hipStream_t s, const BlRoMergeParams &p);
 int launch_bl_ro_rewrite_rows(hipStream_t s, const BlRoRowsParams &p);
 int launch_bl_ro_copy_rows(hipStream_t s, const BlRoCopyParams &p);
+struct BlRoImproveParams;
+struct BlRoRowEdgesParams;
+int launch_bl_ro_improve_list(hipStream_t s, const BlRoImproveParams &p);
+int launch_bl_ro_row_edges(hipStream_t s, const BlRoRowEdgesParams &p);
 int launch_bl_apply_selection(hipStream_t s, const BlApplyParams &p);
 int launch_bl_backlink_merge(hipStream_t s, const BlMergeParams &p);
 int launch_bl_improve_list(hipStream_t s, const BlImproveParams &p);

@@ -1861,7 +1861,7 @@ static void na_insert_at(nodearr *a, int at, int32_t node, float score)
 
 struct jvo_builder {
     const jvo_pq *pq; const uint8_t *codes; const float *vecs; int64_t n; int vsf;
-    int maxDegree, beam, W, hardMaxDegree, addHierarchy, refine, dedupe_ids, improve_full_vectors;
+    int maxDegree, beam, W, hardMaxDegree, addHierarchy, refine, dedupe_ids, improve_full_vectors, improve_sorted_candidates;
     float alpha, overflow;
     float *tri;
     int n_levels;                                   /* layers.size() */
@@ -1918,12 +1918,18 @@ void jvo_builder_free(jvo_builder *b)
     free(b->tri);
     free(b);
 }
-/* per-node levels instead of the Random(0) draws (NULL = draw); and the two places where the engine's improve pass leaves the
- * reference ON PURPOSE: dedupe_ids != 0 — a candidate whose node the merged list already holds is dropped whatever its
- * score (the reference's merge drops it only at an equal score, so a node can sit in a list twice); full_vectors != 0 — the improve
- * search is given the node's full-resolution vector, not its decoded code (searchProviderFor(int) :189-194). */
+/* per-node levels instead of the Random(0) draws (NULL = draw); and the three places where the engine's improve pass leaves the
+ * reference ON PURPOSE: dedupe_ids != 0 — an entry whose node a list already holds is dropped whatever its score, in
+ * insertDiverse's merge and in the backlink's insert (the reference drops it only at an equal score, so a node can sit in a list twice:
+ * an improve search scores a pair differently from the insert that linked it); full_vectors != 0 — the improve search is given the
+ * node's full-resolution vector, not its decoded code (searchProviderFor(int) :189-194); sorted_candidates != 0 — the improve search's
+ * results are taken in SearchResult order (score descending, EQUAL scores by ascending node id) instead of the result heap's array
+ * order, which decides the order among equal scores only. */
 void jvo_builder_set_levels(jvo_builder *b, const int8_t *levels) { b->forced_levels = levels; }
-void jvo_builder_set_deviations(jvo_builder *b, int dedupe_ids, int full_vectors) { b->dedupe_ids = dedupe_ids; b->improve_full_vectors = full_vectors; }
+void jvo_builder_set_deviations(jvo_builder *b, int dedupe_ids, int full_vectors, int sorted_candidates)
+{
+    b->dedupe_ids = dedupe_ids; b->improve_full_vectors = full_vectors; b->improve_sorted_candidates = sorted_candidates;
+}
 
 static nodearr bld_row(jvo_builder *b, int level, int32_t node)
 {
@@ -1987,6 +1993,11 @@ static void bld_add_edges(jvo_builder *b, int level, int32_t node, const nodearr
         if (t.size < 0) continue;                                 /* (cannot happen: a result of the level's search is on the level) */
         const int at = na_insertion_point(&t, node, ns[i]);
         if (at == -1) continue;                                   /* "new" node already existed :275-278 */
+        if (b->dedupe_ids) {                                      /* (deviation, see jvo_builder_set_deviations) */
+            int have = 0;
+            for (int r = 0; r < t.size; r++) if (t.node[r] == node) { have = 1; break; }
+            if (have) continue;
+        }
         na_insert_at(&t, at, node, ns[i]);
         int dbf = b->db[level][nbr] < at ? b->db[level][nbr] : at;   /* min(insertionPoint, diverseBefore) :285 */
         if (t.size > b->hardMaxDegree) { bld_retain(b, &t, dbf); dbf = t.size; }
@@ -2081,11 +2092,15 @@ void jvo_builder_improve(jvo_builder *b, int32_t node)
             searcher_one_layer(s, b->beam, 0.0f, lvl, 1);
             nodearr c; c.node = (int32_t *)malloc(sizeof(int32_t) * (size_t)(s->res.n + 1)); c.score = (float *)malloc(sizeof(float) * (size_t)(s->res.n + 1));
             c.size = 0;
+            int64_t *keys = (int64_t *)malloc(sizeof(int64_t) * (size_t)(s->res.n + 1));
+            memcpy(keys, s->res.a, sizeof(int64_t) * (size_t)s->res.n);
+            if (b->improve_sorted_candidates) qsort(keys, (size_t)s->res.n, sizeof(int64_t), cmp_nodescore);   /* (deviation) */
             for (int i = 0; i < s->res.n; i++) {   /* approximateResults.foreach(candidates::insertSorted): heap array order */
-                const int32_t nd = key_node(s->res.a[i]); const float sc = key_score(s->res.a[i]);
+                const int32_t nd = key_node(keys[i]); const float sc = key_score(keys[i]);
                 const int at = na_insertion_point(&c, nd, sc);
                 if (at >= 0) na_insert_at(&c, at, nd, sc);
             }
+            free(keys);
             bld_add_edges(b, lvl, node, &c);
             free(c.node); free(c.score);
         } else searcher_one_layer(s, 1, 0.0f, lvl, 1);

@@ -188,7 +188,7 @@ jvo_builder *jvo_builder_new(const jvo_pq *pq, const uint8_t *codes, const float
                              float alpha, float neighborOverflow, int addHierarchy, int refineFinalGraph);
 void jvo_builder_free(jvo_builder *b);
 void jvo_builder_set_levels(jvo_builder *b, const int8_t *levels);
-void jvo_builder_set_deviations(jvo_builder *b, int dedupe_ids, int full_vectors);
+void jvo_builder_set_deviations(jvo_builder *b, int dedupe_ids, int full_vectors, int sorted_candidates);
 int  jvo_builder_add(jvo_builder *b, int32_t node);
 void jvo_builder_improve(jvo_builder *b, int32_t node);
 void jvo_builder_enforce_degree(jvo_builder *b, int32_t node);

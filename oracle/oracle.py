@@ -261,7 +261,7 @@ def lib():
         sig("jvo_builder_new", C.c_void_p, pqp, u8p, fp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int)
         sig("jvo_builder_free", None, C.c_void_p)
         sig("jvo_builder_set_levels", None, C.c_void_p, C.POINTER(C.c_int8))
-        sig("jvo_builder_set_deviations", None, C.c_void_p, C.c_int, C.c_int)
+        sig("jvo_builder_set_deviations", None, C.c_void_p, C.c_int, C.c_int, C.c_int)
         sig("jvo_builder_add", C.c_int, C.c_void_p, C.c_int32)
         sig("jvo_builder_improve", None, C.c_void_p, C.c_int32)
         sig("jvo_builder_enforce_degree", None, C.c_void_p, C.c_int32)
@@ -715,7 +715,7 @@ class OracleBuilder:
     addGraphNode, cleanup() = cleanup; rows come back in NodeArray order with their scores and diverseBefore mark."""
 
     def __init__(self, pq, codes, vecs, vsf, max_degree, beam_width, alpha=1.2, neighbor_overflow=1.2, add_hierarchy=False,
-                 refine_final_graph=True, levels=None, dedupe_ids=False, improve_full_vectors=False):
+                 refine_final_graph=True, levels=None, dedupe_ids=False, improve_full_vectors=False, improve_sorted_candidates=False):
         self.pq = pq
         self.codes = np.ascontiguousarray(codes, np.uint8)
         self.vecs = f32(vecs)
@@ -727,8 +727,8 @@ class OracleBuilder:
         if levels is not None:
             self._levels = np.ascontiguousarray(levels, np.int8)
             lib().jvo_builder_set_levels(self._h, self._levels.ctypes.data_as(C.POINTER(C.c_int8)))
-        if dedupe_ids or improve_full_vectors:
-            lib().jvo_builder_set_deviations(self._h, int(bool(dedupe_ids)), int(bool(improve_full_vectors)))
+        if dedupe_ids or improve_full_vectors or improve_sorted_candidates:
+            lib().jvo_builder_set_deviations(self._h, int(bool(dedupe_ids)), int(bool(improve_full_vectors)), int(bool(improve_sorted_candidates)))
 
     def __del__(self):
         if getattr(self, "_h", None):

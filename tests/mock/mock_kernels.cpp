@@ -697,6 +697,16 @@ int launch_bl_ro_copy_rows(hipStream_t, const BlRoCopyParams &p)
     for (long long i = p.P - 1; i >= 0; --i) bl_ro_copy_row(p, i);
     return JV_OK;
 }
+int launch_bl_ro_improve_list(hipStream_t, const BlRoImproveParams &p)
+{
+    for (long long b = p.B - 1; b >= 0; --b) bl_ro_improve_list(p, b);
+    return JV_OK;
+}
+int launch_bl_ro_row_edges(hipStream_t, const BlRoRowEdgesParams &p)
+{
+    for (long long i = (long long)p.B * p.Rf - 1; i >= 0; --i) bl_ro_row_edges(p, i);
+    return JV_OK;
+}
 int launch_bl_count_valid(hipStream_t, const int32_t *cand, int C, int32_t *count, long long B)
 {
     for (long long b = 0; b < B; ++b) bl_count_valid(cand, C, count, b);

@@ -197,3 +197,16 @@ def test_builder_gpu_ragged_quantizer():
     assert ctx.stat("gs_calls_host") == 0
     print("builder (ragged PQ):", dict(stats), "recall@10", recall)
     ctx.close()
+
+
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+def test_builder_in_reference_order_batched_on_the_mock():
+    """bl_ref_order = 1 with batches of many nodes (the concurrent case; one-node batches are pinned against the oracle in
+    test_builder_reference_order.py): the structural contract, recall, re-insertion and improve passes, the layered build"""
+    def run(J, ctx, register):
+        ctx.set_option("bl_ref_order", 1)
+        try:
+            check_builder(J, ctx, torch.device("cpu"), 500, 128, 16, 16, 24, register=register)
+        finally:
+            ctx.set_option("bl_ref_order", 0)
+    _on_the_mock(run)

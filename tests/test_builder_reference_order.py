@@ -80,8 +80,10 @@ def test_oracle_builder_contract():
         del b
 
 
-def check_reference_order(J, ctx, dev, N, D, M, max_degree, beam, vsf, dup=0, register=None):
-    """ONE node per batch == addGraphNode; finish == cleanup's enforceDegree.  Returns (engine rows, oracle rows) for the caller's report."""
+def check_reference_order(J, ctx, dev, N, D, M, max_degree, beam, vsf, dup=0, improve=0, register=None):
+    """ONE node per batch == addGraphNode; finish == cleanup's enforceDegree; `improve` passes of improveConnections over EVERY node
+    in between (the engine's extension of cleanup(), which refines the upper levels' nodes only: the oracle runs the reference's
+    improveConnections with the engine's three stated deviations).  Returns (engine rows, oracle rows) for the caller's report."""
     from jvector_amd.builder import GraphBuilder
     v = _data(N, D, 7 + M, dup=dup)
     cb = _oracle_pq(N, D, M, 7, v)
@@ -95,7 +97,8 @@ def check_reference_order(J, ctx, dev, N, D, M, max_degree, beam, vsf, dup=0, re
     try:
         gb = GraphBuilder(ctx, pq, cv, vs, vsf, max_degree, beam, 1.2, 1.2)
         gb.seed(0)
-        ob = O.OracleBuilder(opq, codes, v, int(vsf), max_degree, beam, 1.2, 1.2, add_hierarchy=False)
+        ob = O.OracleBuilder(opq, codes, v, int(vsf), max_degree, beam, 1.2, 1.2, add_hierarchy=False, dedupe_ids=improve > 0,
+                             improve_full_vectors=improve > 0, improve_sorted_candidates=improve > 0)
         ob.add(0)
         R = gb.row_width()
         for i in range(1, N):
@@ -108,6 +111,20 @@ def check_reference_order(J, ctx, dev, N, D, M, max_degree, beam, vsf, dup=0, re
                     n = int((ids[u] >= 0).sum())
                     assert n == oi.size and np.array_equal(ids[u, :n], oi), (i, u, ids[u], oi)
                     assert np.array_equal(sc[u, :n].view(np.int32), osc.view(np.int32)) and int(db[u]) == odb, (i, u)
+        n_imp = 0
+        for _ in range(improve):
+            for i in range(N):
+                gb.improve_batch(np.array([i], np.int32))
+                ob.improve(i)
+                n_imp += 1
+                if i in (0, 1, N // 2, N - 1):
+                    ids, sc, db = gb.working_rows()
+                    for u in range(N):
+                        oi, osc, odb = ob.row(0, u)
+                        n = int((ids[u] >= 0).sum())
+                        assert n == oi.size and np.array_equal(ids[u, :n], oi), ("improve", i, u, ids[u], oi)
+                        assert np.array_equal(sc[u, :n].view(np.int32), osc.view(np.int32)) and int(db[u]) == odb, ("improve", i, u)
+                        assert len(set(oi.tolist())) == oi.size
         out = gb.finish(torch.empty((N, max_degree), dtype=torch.int32, device=dev)).cpu().numpy().copy()
         st = gb.stats()
         gb.close()
@@ -116,7 +133,7 @@ def check_reference_order(J, ctx, dev, N, D, M, max_degree, beam, vsf, dup=0, re
     ob.cleanup()
     want = ob.rows(0, max_degree)
     assert np.array_equal(out, want), np.argwhere((out != want).any(axis=1))[:5]
-    assert st["reprunes"] == ob.info()["reprunes"] - (N - 1)     # (the oracle also counts the N - 1 insertDiverse prunes)
+    assert st["reprunes"] == ob.info()["reprunes"] - (N - 1)     # (the oracle also counts the N - 1 insertDiverse prunes of the inserts)
     assert (out >= 0).sum(axis=1).max() <= max_degree
     return out, want
 
@@ -146,4 +163,79 @@ def _on_the_mock(fn):
 def test_one_node_batches_equal_the_reference_on_the_mock(vsf, dup):
     def run(J, ctx):
         check_reference_order(J, ctx, torch.device("cpu"), 400, 64, 8, 8, 20, J.VectorSimilarityFunction(vsf), dup=dup)
+    _on_the_mock(run)
+
+
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+@pytest.mark.parametrize("vsf,dup,wgx", [(O.COSINE, 0, 0), (O.EUCLIDEAN, 16, 1)])
+def test_improve_pass_in_reference_order_on_the_mock(vsf, dup, wgx):
+    """(the improve search excludes its own node — ExcludingBits — in the one-wave form, wgx = 0, and in the workgroup form, 1)"""
+    def run(J, ctx):
+        ctx.set_option("gs_wgx", wgx)
+        ctx.reset_stats()
+        check_reference_order(J, ctx, torch.device("cpu"), 300, 64, 8, 8, 20, J.VectorSimilarityFunction(vsf), dup=dup, improve=1)
+        assert ctx.stat("gs_calls_host") == 0
+    _on_the_mock(run)
+
+
+def _splitmix_permutation(n, seed):
+    """builder.cpp seeded_permutation: Fisher-Yates over splitmix64 draws"""
+    mask = (1 << 64) - 1
+    st = seed & mask
+    p = list(range(n))
+    for i in range(n - 1, 0, -1):
+        st = (st + 0x9E3779B97F4A7C15) & mask
+        z = st
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+        z ^= z >> 31
+        j = z % (i + 1)
+        p[i], p[j] = p[j], p[i]
+    return p
+
+
+def check_layered_reference_order(J, ctx, dev, N, D, M, max_degree, beam, vsf, improve, seed=11):
+    """jv_hip_build_layered with max_batch = 1 in reference order: EVERY level's adjacency equals the oracle's one-thread build of that
+    level's nodes (inserted in the engine's seeded order, then `improve` passes, then enforceDegree).  What stays the engine's own
+    design is how the levels are composed: each level is a graph of its own (the reference hands entry points from level to level
+    inside one insert) and the level draws come from splitmix64, not java.util.Random."""
+    from jvector_amd.builder import build_hierarchical
+    v = _data(N, D, 21 + M)
+    cb = _oracle_pq(N, D, M, 21, v)
+    opq = O.OraclePQ(D, M, cb)
+    pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb, None)
+    tv = torch.from_numpy(v).to(dev)
+    vs = J.VectorSet(ctx, tv)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    codes = opq.encode_all(v)
+    ctx.set_option("bl_ref_order", 1)
+    try:
+        levels, entry, entry_level, _nb0, stats = build_hierarchical(ctx, pq, cv, tv, vsf, max_degree=max_degree, beam_width=beam, alpha=1.2, seed=seed,
+                                                                     min_top=4, overflow=1.2, max_batch=1, improve=improve, vector_set=vs)
+    finally:
+        ctx.set_option("bl_ref_order", 0)
+    assert len(levels) >= 2 and entry_level == len(levels) - 1
+    for l, (ids, rows) in enumerate(levels):
+        gids = np.arange(N, dtype=np.int32) if ids is None else np.asarray(ids)
+        n_l = gids.size
+        sub_v, sub_c = v[gids], codes[gids]
+        ob = O.OracleBuilder(opq, sub_c, sub_v, int(vsf), max_degree, beam, 1.2, 1.2, add_hierarchy=False, dedupe_ids=True,
+                             improve_full_vectors=True, improve_sorted_candidates=True)
+        order = _splitmix_permutation(n_l, seed + l)
+        for i in order:
+            ob.add(i)
+        for _ in range(improve):
+            for i in order:
+                ob.improve(i)
+        ob.cleanup()
+        want = ob.rows(0, max_degree)
+        want = np.where(want >= 0, gids[np.maximum(want, 0)], -1).astype(np.int32)
+        assert np.array_equal(np.asarray(rows), want), (l, np.argwhere((np.asarray(rows) != want).any(axis=1))[:5])
+    return stats
+
+
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+def test_layered_build_with_one_node_batches_on_the_mock():
+    def run(J, ctx):
+        check_layered_reference_order(J, ctx, torch.device("cpu"), 260, 64, 8, 6, 16, J.VectorSimilarityFunction.DOT_PRODUCT, improve=1)
     _on_the_mock(run)
