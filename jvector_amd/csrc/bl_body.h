@@ -230,7 +230,7 @@ BL_FN void bl_rewrite_row(const BlRowsParams &p, long long r)
 // ---------------------------------------------------------------------------------------------------------------------------------
 // REFERENCE ORDER (builder option bl_ref_order): the lists are kept the way ConcurrentNeighborMap.Neighbors keeps them — every entry
 // with the score it was inserted under, in NodeArray order (score descending, a new entry BEHIND its equals), and with the
-// diverseBefore mark — so that a batch of ONE node performs addGraphNode's list operations exactly (oracle: jv_oracle.c
+// diverseBefore mark — so that a batch of ONE node performs addGraphNode's list operations exactly (CPU checker: jvo_builder_*,
 // "GraphIndexBuilder, one thread"; tests/test_builder_reference_order*.py compare the adjacency byte for byte):
 //   insertDiverse on the new node's empty list        ConcurrentNeighborMap.java:222-243   bl_ro_apply_selection
 //   backlink -> Neighbors.insert                      :139-146, :262-296                    bl_ro_backlink_merge
@@ -422,7 +422,7 @@ BL_FN void bl_ro_rewrite_row(const BlRoRowsParams &p, long long r)
 // improveConnections in reference order (GraphIndexBuilder.java:510-545 -> addEdges -> Neighbors.insertDiverse :222-243): the node's
 // list and the search's candidates merged the way NodeArray.merge walks them (:63-143: the better score first; at EQUAL scores one
 // entry of the list, then one of the candidates), except that a node the merged list already holds is dropped whatever its score —
-// the reference drops it only at an equal score and so can list a node twice (the oracle restates both: jvo_builder_set_deviations).
+// the reference drops it only at an equal score and so can list a node twice (the CPU checker restates both: jvo_builder_set_deviations).
 struct BlRoImproveParams {
     const int32_t *nodes;     // [B]
     const int32_t *cand;      // [B][C] best first, -1 padded

@@ -27,7 +27,7 @@
 // in NodeArray order and keep ConcurrentNeighborMap's diverseBefore mark (bl_body.h "REFERENCE ORDER"); steps 4, 6 and 7 become
 // insertDiverse / Neighbors.insert / retainDiverse(diverseBefore) as the reference performs them — nothing is re-scored or
 // re-sorted — and a build whose batches hold ONE node is addGraphNode + cleanup's enforceDegree operation for operation: the
-// adjacency equals the oracle's one-thread restatement of GraphIndexBuilder byte for byte (tests/test_builder_reference_order.py
+// adjacency equals the CPU checker's one-thread restatement of GraphIndexBuilder byte for byte (tests/test_builder_reference_order.py
 // on the CPU mock, tests/test_zz_builder_reference_order_gpu.py on the MI355X).
 #include <algorithm>
 #include <chrono>
