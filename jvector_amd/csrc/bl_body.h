@@ -287,6 +287,70 @@ BL_FN void bl_ro_apply_selection(const BlRoApplyParams &p, long long b)
     }
 }
 
+// SORTED LISTS (builder option bl_sorted_lists): the same list mechanics with the scores the classic path would compute — the PQ
+// diversity function of (node, member), symmetric, so a back edge carries the score its forward edge has — stored instead of
+// recomputed: what a re-prune of the classic path does first (score the whole merged list against its node, sort it) is already
+// there.  The selection of a new node's row, in candidate order: item = b * Rf + j -> out_ids (-1: no entry / the node itself).
+struct BlSelIdsParams {
+    const int32_t *nodes;     // [B]
+    const int32_t *cand;      // [B][C]
+    const int32_t *sel;       // [B][Rf]
+    int B, C, Rf;
+    int32_t *out_ids;         // [B][Rf]
+};
+
+BL_FN void bl_sel_ids(const BlSelIdsParams &p, long long item)
+{
+    const long long b = item / p.Rf;
+    const int32_t s = p.sel[item];
+    int32_t chosen = s >= 0 && s < p.C ? p.cand[b * (long long)p.C + s] : -1;
+    if (chosen == p.nodes[b]) chosen = -1;
+    p.out_ids[item] = chosen;
+}
+
+// rows from lists that are already in NodeArray order under the scores to store ([B][Rf], -1 last); edges as bl_ro_apply_selection
+struct BlRoApplySortedParams {
+    const int32_t *nodes;     // [B]
+    const int32_t *ids;       // [B][Rf]
+    const float *sc;          // [B][Rf]
+    int B, Rf, R;
+    int32_t *nbrs;
+    float *nsc;
+    int32_t *db;
+    unsigned long long *edge_keys;
+    int32_t *edge_src;
+    float *edge_sc;
+};
+
+// item = b
+BL_FN void bl_ro_apply_sorted(const BlRoApplySortedParams &p, long long b)
+{
+    const int32_t v = p.nodes[b];
+    int32_t *row = p.nbrs + (long long)v * p.R;
+    float *rsc = p.nsc + (long long)v * p.R;
+    int w = 0;
+    for (int j = 0; j < p.Rf; ++j) {
+        const long long item = b * p.Rf + j;
+        const int32_t chosen = p.ids[item];
+        if (chosen >= 0) {
+            row[w] = chosen;
+            rsc[w] = p.sc[item];
+            ++w;
+            p.edge_keys[item] = (((unsigned long long)(uint32_t)chosen) << 32) | (unsigned long long)(uint32_t)item;
+            p.edge_sc[item] = p.sc[item];
+        } else {
+            p.edge_keys[item] = ~0ull;
+            p.edge_sc[item] = 0.0f;
+        }
+        p.edge_src[item] = v;
+    }
+    p.db[v] = w;
+    for (; w < p.R; ++w) {
+        row[w] = -1;
+        rsc[w] = 0.0f;
+    }
+}
+
 constexpr int BL_RO_MAX_LIST = 192;   // R <= 64 and at most 2 R appended entries are kept
 
 struct BlRoMergeParams {
@@ -428,6 +492,7 @@ struct BlRoImproveParams {
     const int32_t *cand;      // [B][C] best first, -1 padded
     const float *cand_sc;     // [B][C]
     int B, C, R;
+    int skip_empty;           // reference order: "if (graph.getNeighborsIterator(lvl, node).size() > 0)" (:527) — a node without neighbours is left alone
     const int32_t *nbrs;      // [N][R]
     const float *nsc;         // [N][R]
     int32_t *list;            // [B][R + C]
@@ -456,7 +521,7 @@ BL_FN void bl_ro_improve_list(const BlRoImproveParams &p, long long b)
     int n1 = 0, n2 = 0;
     while (n1 < p.R && a1[n1] >= 0) ++n1;
     while (n2 < p.C && a2[n2] >= 0) ++n2;
-    if (n1 == 0) n2 = 0;   // "if (graph.getNeighborsIterator(lvl, node).size() > 0)" (:527): a node without neighbours is left alone
+    if (n1 == 0 && p.skip_empty) n2 = 0;
     const int L = p.R + p.C;
     int32_t *out = p.list + b * (long long)L;
     float *osc = p.lsc + b * (long long)L;

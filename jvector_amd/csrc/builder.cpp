@@ -52,7 +52,9 @@ struct jv_builder {
     int Rf = 32, R = 40, beam = 100;
     float alpha = 1.2f;
     int32_t *d_nbrs = nullptr;       // [n][R]
-    bool ref = false;                // reference order: the three arrays below exist, rows are NodeArray-ordered
+    bool stored = false;             // the three arrays below exist, rows are NodeArray-ordered under the stored scores (sorted lists / reference order)
+    bool sym = false;                // stored && sym: SORTED LISTS — the classic path's symmetric PQ diversity scores, stored; every prune re-tests the
+                                     // whole list (diverseBefore unused).  stored && !sym: REFERENCE ORDER
     float *d_nsc = nullptr;          // [n][R] the score each entry was inserted under
     int32_t *d_db = nullptr;         // [n] diverseBefore
     int hard_max = 0;                // (int) (neighborOverflow x maxDegree), capped at R: a list longer than this is pruned
@@ -78,6 +80,7 @@ struct jv_builder {
 namespace {
 
 constexpr long long kBlRefOrderDefault = 0;
+constexpr long long kBlSortedListsDefault = 0;
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -232,9 +235,11 @@ int jv_hip_builder_create(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, c
         return fail(JV_ERR_OOM);
     }
     if (hipMemsetAsync(b->d_nbrs, 0xFF, sizeof(int32_t) * (size_t)b->n * b->R, ctx->stream) != hipSuccess) return fail(JV_ERR_HIP);
-    b->ref = ctx_opt(ctx, "bl_ref_order", kBlRefOrderDefault) != 0;
+    const bool ref_order = ctx_opt(ctx, "bl_ref_order", kBlRefOrderDefault) != 0;
+    b->sym = !ref_order && ctx_opt(ctx, "bl_sorted_lists", kBlSortedListsDefault) != 0;
+    b->stored = ref_order || b->sym;
     b->hard_max = std::min(b->R, (int)(neighbor_overflow * (float)max_degree));   // Neighbors.insert :270
-    if (b->ref) {
+    if (b->stored) {
         if (hipMalloc((void **)&b->d_nsc, sizeof(float) * (size_t)b->n * b->R) != hipSuccess ||
             hipMalloc((void **)&b->d_db, sizeof(int32_t) * (size_t)b->n) != hipSuccess) {
             (void)hipGetLastError();
@@ -414,7 +419,7 @@ static int link_back_edges_ro(jv_ctx *ctx, jv_builder *b, long long E, int dedup
     unsigned int n_over = 0;
     JV_TRY(read_counter(ctx, b, &n_over));
     n_over = std::min(n_over, over_cap);
-    JV_TRY(reprune_lists_ro(ctx, b, mp.over_tgt, mp.over_list, mp.over_sc, mp.over_n, mp.over_db, (int)n_over, L));
+    JV_TRY(reprune_lists_ro(ctx, b, mp.over_tgt, mp.over_list, mp.over_sc, mp.over_n, b->sym ? nullptr : mp.over_db, (int)n_over, L));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     b->backlink_s += now_s() - t0;
     return JV_OK;
@@ -461,7 +466,57 @@ int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes
     JV_TRY(run_retain(ctx, b, d_cand, d_csc, (const int32_t *)b->d_count.ptr, B, k, (int32_t *)b->d_sel.ptr, (int32_t *)b->d_nsel.ptr));
     const long long E = (long long)B * Rf;
     JV_TRY(reserve_edges(b, E));
-    if (b->ref) {   // insertDiverse on the new nodes' empty lists, then backlink -> Neighbors.insert
+    if (b->sym) {   // sorted lists: the row under the symmetric scores (what the classic path's first re-prune of it would compute), sorted
+        JV_TRY(b->d_esc.reserve(sizeof(float) * (size_t)E));
+        JV_TRY(b->d_imp_list.reserve(sizeof(int32_t) * (size_t)E));
+        JV_TRY(b->d_over_sc.reserve(sizeof(float) * (size_t)E));
+        JV_TRY(b->d_sorted_ids.reserve(sizeof(int32_t) * (size_t)E));
+        JV_TRY(b->d_sorted_sc.reserve(sizeof(float) * (size_t)E));
+        JV_TRY(b->d_over_n.reserve(sizeof(int32_t) * (size_t)B));
+        BlSelIdsParams ip{};
+        ip.nodes = d_nodes;
+        ip.cand = d_cand;
+        ip.sel = (const int32_t *)b->d_sel.ptr;
+        ip.B = B;
+        ip.C = k;
+        ip.Rf = Rf;
+        ip.out_ids = (int32_t *)b->d_imp_list.ptr;
+        JV_TRY(launch_bl_sel_ids(ctx->stream, ip));
+        {
+            ProfScope ps(ctx, R_ADC);
+            JV_TRY(launch_pair_scores(ctx->stream, b->tri->d_tri, to_kernel_vsf(b->vsf), b->codes, d_nodes, B, ip.out_ids, Rf, (float *)b->d_over_sc.ptr));
+        }
+        BlSortParams sp{};
+        sp.ids = ip.out_ids;
+        sp.scores = (const float *)b->d_over_sc.ptr;
+        sp.P = B;
+        sp.L = Rf;
+        sp.out_ids = (int32_t *)b->d_sorted_ids.ptr;
+        sp.out_scores = (float *)b->d_sorted_sc.ptr;
+        sp.out_count = (int32_t *)b->d_over_n.ptr;
+        JV_TRY(launch_bl_rank_sort(ctx->stream, sp));
+        BlRoApplySortedParams rp{};
+        rp.nodes = d_nodes;
+        rp.ids = sp.out_ids;
+        rp.sc = sp.out_scores;
+        rp.B = B;
+        rp.Rf = Rf;
+        rp.R = R;
+        rp.nbrs = b->d_nbrs;
+        rp.nsc = b->d_nsc;
+        rp.db = b->d_db;
+        rp.edge_keys = (unsigned long long *)b->d_keys.ptr;
+        rp.edge_src = (int32_t *)b->d_src.ptr;
+        rp.edge_sc = (float *)b->d_esc.ptr;
+        JV_TRY(launch_bl_ro_apply_sorted(ctx->stream, rp));
+        JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        b->prune_s += now_s() - t0;
+        JV_TRY(link_back_edges_ro(ctx, b, E, 1));
+        b->inserted += B;
+        b->batches += 1;
+        return JV_OK;
+    }
+    if (b->stored) {   // insertDiverse on the new nodes' empty lists, then backlink -> Neighbors.insert
         JV_TRY(b->d_esc.reserve(sizeof(float) * (size_t)E));
         BlRoApplyParams rp{};
         rp.nodes = d_nodes;
@@ -539,18 +594,40 @@ int jv_hip_builder_improve_batch(jv_ctx *ctx, jv_builder *b, const int32_t *node
     JV_HIP_CHECK(hipMemcpyAsync(b->d_nodes.ptr, nodes, sizeof(int32_t) * (size_t)B, hipMemcpyDefault, ctx->stream));
     if (!is_device_ptr(nodes)) JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const int32_t *d_nodes = (const int32_t *)b->d_nodes.ptr;
-    JV_TRY(search_candidates(ctx, b, d_nodes, B, k, b->ref));
+    JV_TRY(search_candidates(ctx, b, d_nodes, B, k, b->stored && !b->sym));
 
     double t0 = now_s();
     const int L = R + k;
-    if (b->ref) {   // insertDiverse(merge(list, candidates)) with the stored / search scores, then backlink every member of the new list
+    if (b->stored) {   // insertDiverse(merge(list, candidates)) with the stored / search scores, then backlink every member of the new list
         JV_TRY(b->d_imp_list.reserve(sizeof(int32_t) * (size_t)B * L));
         JV_TRY(b->d_over_sc.reserve(sizeof(float) * (size_t)B * L));
         JV_TRY(b->d_over_n.reserve(sizeof(int32_t) * (size_t)B));
+        const int32_t *cand_ids = (const int32_t *)b->d_cand.ptr;
+        const float *cand_sc = (const float *)b->d_csc.ptr;
+        if (b->sym) {   // the candidates under the symmetric score against their node, in NodeArray order (the classic path scores and sorts row + candidates)
+            JV_TRY(b->d_sorted_ids.reserve(sizeof(int32_t) * (size_t)B * k));
+            JV_TRY(b->d_sorted_sc.reserve(sizeof(float) * (size_t)B * k));
+            {
+                ProfScope ps(ctx, R_ADC);
+                JV_TRY(launch_pair_scores(ctx->stream, b->tri->d_tri, to_kernel_vsf(b->vsf), b->codes, d_nodes, B, cand_ids, k, (float *)b->d_over_sc.ptr));
+            }
+            BlSortParams sp{};
+            sp.ids = cand_ids;
+            sp.scores = (const float *)b->d_over_sc.ptr;
+            sp.P = B;
+            sp.L = k;
+            sp.out_ids = (int32_t *)b->d_sorted_ids.ptr;
+            sp.out_scores = (float *)b->d_sorted_sc.ptr;
+            sp.out_count = (int32_t *)b->d_over_n.ptr;
+            JV_TRY(launch_bl_rank_sort(ctx->stream, sp));
+            cand_ids = sp.out_ids;
+            cand_sc = sp.out_scores;
+        }
         BlRoImproveParams ip{};
         ip.nodes = d_nodes;
-        ip.cand = (const int32_t *)b->d_cand.ptr;
-        ip.cand_sc = (const float *)b->d_csc.ptr;
+        ip.cand = cand_ids;
+        ip.cand_sc = cand_sc;
+        ip.skip_empty = b->sym ? 0 : 1;
         ip.B = B;
         ip.C = k;
         ip.R = R;
@@ -635,7 +712,7 @@ int jv_hip_builder_finish(jv_ctx *ctx, jv_builder *b, int32_t *neighbors_out)
         JV_TRY(read_counter(ctx, b, &n_over));
         const int piece = 1 << 20;
         JV_TRY(b->d_over_list.reserve(sizeof(int32_t) * (size_t)std::min<unsigned int>(n_over, piece) * b->R));
-        if (b->ref) {   // enforceDegree: retainDiverse(copy, diverseBefore) over the stored scores (ConcurrentNeighborMap.java:190-200)
+        if (b->stored) {   // enforceDegree: retainDiverse(copy, diverseBefore) over the stored scores (ConcurrentNeighborMap.java:190-200)
             const size_t pc = (size_t)std::min<unsigned int>(n_over, piece);
             JV_TRY(b->d_over_sc.reserve(sizeof(float) * pc * b->R));
             JV_TRY(b->d_over_db.reserve(sizeof(int32_t) * pc));
@@ -644,7 +721,7 @@ int jv_hip_builder_finish(jv_ctx *ctx, jv_builder *b, int32_t *neighbors_out)
         for (unsigned int s = 0; s < n_over; s += piece) {
             const int P = (int)std::min<unsigned int>(piece, n_over - s);
             const int32_t *tgt = (const int32_t *)b->d_over_tgt.ptr + s;
-            if (b->ref) {
+            if (b->stored) {
                 BlRoCopyParams cp{};
                 cp.tgt = tgt;
                 cp.P = P;
@@ -657,7 +734,7 @@ int jv_hip_builder_finish(jv_ctx *ctx, jv_builder *b, int32_t *neighbors_out)
                 cp.ldb = (int32_t *)b->d_over_db.ptr;
                 cp.ln = (int32_t *)b->d_over_n.ptr;
                 JV_TRY(launch_bl_ro_copy_rows(ctx->stream, cp));
-                JV_TRY(reprune_lists_ro(ctx, b, tgt, cp.lst, cp.lsc, cp.ln, cp.ldb, P, b->R));
+                JV_TRY(reprune_lists_ro(ctx, b, tgt, cp.lst, cp.lsc, cp.ln, b->sym ? nullptr : cp.ldb, P, b->R));
                 continue;
             }
             JV_TRY(launch_bl_copy_rows(ctx->stream, b->d_nbrs, b->R, tgt, P, (int32_t *)b->d_over_list.ptr));
@@ -983,7 +1060,7 @@ int jv_hip_builder_working_lists(jv_ctx *ctx, const jv_builder *b, int32_t *ids_
     clear_error();
     JV_REQUIRE(ctx && b, "builder_working_lists: NULL argument");
     JV_REQUIRE(ctx->device == b->device, "builder_working_lists: the builder lives on device %d", b->device);
-    JV_REQUIRE(b->ref || (!scores_out && !diverse_before_out), "builder_working_lists: scores and marks exist in reference order only (bl_ref_order = 1)");
+    JV_REQUIRE(b->stored || (!scores_out && !diverse_before_out), "builder_working_lists: scores and marks exist with sorted lists / in reference order only (bl_sorted_lists / bl_ref_order)");
     JV_TRY(use_device(ctx->device));
     const size_t cells = (size_t)b->n * b->R;
     if (ids_out) JV_HIP_CHECK(hipMemcpyAsync(ids_out, b->d_nbrs, sizeof(int32_t) * cells, hipMemcpyDefault, ctx->stream));

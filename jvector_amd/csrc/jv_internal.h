@@ -383,6 +383,10 @@ int launch_bl_ro_backlink_merge(hipStream_t s, const BlRoMergeParams &p);
 int launch_bl_ro_rewrite_rows(hipStream_t s, const BlRoRowsParams &p);
 int launch_bl_ro_copy_rows(hipStream_t s, const BlRoCopyParams &p);
 struct BlRoImproveParams;
+struct BlSelIdsParams;
+struct BlRoApplySortedParams;
+int launch_bl_sel_ids(hipStream_t s, const BlSelIdsParams &p);
+int launch_bl_ro_apply_sorted(hipStream_t s, const BlRoApplySortedParams &p);
 struct BlRoRowEdgesParams;
 int launch_bl_ro_improve_list(hipStream_t s, const BlRoImproveParams &p);
 int launch_bl_ro_row_edges(hipStream_t s, const BlRoRowEdgesParams &p);

@@ -62,6 +62,8 @@ int launch_bl_ro_apply_selection(hipStream_t s, const BlRoApplyParams &p) { retu
 int launch_bl_ro_backlink_merge(hipStream_t s, const BlRoMergeParams &p) { return run_items<BlRoMergeParams, bl_ro_backlink_merge>(s, p, p.E); }
 int launch_bl_ro_rewrite_rows(hipStream_t s, const BlRoRowsParams &p) { return run_items<BlRoRowsParams, bl_ro_rewrite_row>(s, p, p.P); }
 int launch_bl_ro_copy_rows(hipStream_t s, const BlRoCopyParams &p) { return run_items<BlRoCopyParams, bl_ro_copy_row>(s, p, p.P); }
+int launch_bl_sel_ids(hipStream_t s, const BlSelIdsParams &p) { return run_items<BlSelIdsParams, bl_sel_ids>(s, p, (long long)p.B * p.Rf); }
+int launch_bl_ro_apply_sorted(hipStream_t s, const BlRoApplySortedParams &p) { return run_items<BlRoApplySortedParams, bl_ro_apply_sorted>(s, p, p.B); }
 int launch_bl_ro_improve_list(hipStream_t s, const BlRoImproveParams &p) { return run_items<BlRoImproveParams, bl_ro_improve_list>(s, p, p.B); }
 int launch_bl_ro_row_edges(hipStream_t s, const BlRoRowEdgesParams &p) { return run_items<BlRoRowEdgesParams, bl_ro_row_edges>(s, p, (long long)p.B * p.Rf); }
 

@@ -697,6 +697,16 @@ int launch_bl_ro_copy_rows(hipStream_t, const BlRoCopyParams &p)
     for (long long i = p.P - 1; i >= 0; --i) bl_ro_copy_row(p, i);
     return JV_OK;
 }
+int launch_bl_sel_ids(hipStream_t, const BlSelIdsParams &p)
+{
+    for (long long i = (long long)p.B * p.Rf - 1; i >= 0; --i) bl_sel_ids(p, i);
+    return JV_OK;
+}
+int launch_bl_ro_apply_sorted(hipStream_t, const BlRoApplySortedParams &p)
+{
+    for (long long b = p.B - 1; b >= 0; --b) bl_ro_apply_sorted(p, b);
+    return JV_OK;
+}
 int launch_bl_ro_improve_list(hipStream_t, const BlRoImproveParams &p)
 {
     for (long long b = p.B - 1; b >= 0; --b) bl_ro_improve_list(p, b);

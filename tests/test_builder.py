@@ -210,3 +210,50 @@ def test_builder_in_reference_order_batched_on_the_mock():
         finally:
             ctx.set_option("bl_ref_order", 0)
     _on_the_mock(run)
+
+
+def check_sorted_lists_equal_classic(J, ctx, dev, N, D, M, max_degree, beam, max_batch, vsf=None, overflow=2.0):
+    """bl_sorted_lists = 1 stores the symmetric scores the classic path recomputes at every re-prune and keeps the lists sorted: the
+    SAME graph must come out (rows as sets — the classic path leaves rows that were never re-pruned in arrival order), insert phase,
+    improve pass and layered build alike"""
+    from jvector_amd.builder import build_hierarchical, build_vamana
+    VSF = vsf if vsf is not None else J.VectorSimilarityFunction.COSINE
+    v, _ = _data(N, D, 9)
+    tv = torch.from_numpy(v).to(dev)
+    pq = J.ProductQuantization.compute(ctx, tv, M, seed=2)
+    vs = J.VectorSet(ctx, tv)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    got = {}
+    for mode in (0, 1):
+        ctx.set_option("bl_sorted_lists", mode)
+        try:
+            for improve in (0, 1):
+                nb, entry, st = build_vamana(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, alpha=1.2, max_batch=max_batch, improve=improve,
+                                             overflow=overflow, vector_set=vs)
+                got[(mode, "flat", improve)] = (np.sort(nb.cpu().numpy().copy(), axis=1), entry, st["reprunes"])
+            levels, e, el, _nb0, _st = build_hierarchical(ctx, pq, cv, tv, VSF, max_degree=max_degree, beam_width=beam, max_batch=max_batch, min_top=4,
+                                                          improve=1, overflow=overflow, vector_set=vs)
+            got[(mode, "layered", 1)] = ([np.sort(np.asarray(r), axis=1) for _, r in levels], (e, el), 0)
+        finally:
+            ctx.set_option("bl_sorted_lists", 0)
+    for improve in (0, 1):
+        a, b = got[(0, "flat", improve)], got[(1, "flat", improve)]
+        assert a[1] == b[1] and a[2] == b[2] and np.array_equal(a[0], b[0]), (improve, np.argwhere((a[0] != b[0]).any(axis=1))[:5])
+    a, b = got[(0, "layered", 1)], got[(1, "layered", 1)]
+    assert a[1] == b[1] and len(a[0]) == len(b[0]) and all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+
+
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+def test_sorted_lists_build_the_classic_graph_on_the_mock():
+    def run(J, ctx, register):
+        check_sorted_lists_equal_classic(J, ctx, torch.device("cpu"), 700, 64, 8, 8, 24, 128, overflow=1.5)
+        check_sorted_lists_equal_classic(J, ctx, torch.device("cpu"), 400, 64, 8, 8, 24, 64, vsf=J.VectorSimilarityFunction.EUCLIDEAN, overflow=2.0)
+    _on_the_mock(run)
+
+
+@pytest.mark.gpu
+def test_sorted_lists_build_the_classic_graph_gpu():
+    import jvector_amd as J
+    ctx = J.HipContext(0)
+    check_sorted_lists_equal_classic(J, ctx, torch.device("cuda", 0), 40000, 128, 16, 32, 100, 4096)
+    ctx.close()
