@@ -512,7 +512,10 @@ JV_API const int32_t *jv_hip_builder_neighbors_device(const jv_builder *b, int *
  * (GraphIndexBuilder.java:605-659) operation for operation: the adjacency equals the reference's one-thread build (oracle:
  * jvo_builder_*, tests/test_builder_reference_order.py).  working_lists copies the lists as they stand: ids_out [n x row_width] (-1
  * padded), scores_out [n x row_width] and diverse_before_out [n] (each nullable; host or device memory; the last two only in
- * reference order). */
+ * reference order / with sorted lists).
+ * bl_sorted_lists = 1: the DEFAULT build's own scores (the symmetric PQ diversity function of node and member) stored and the lists
+ * kept sorted instead of re-scored and re-sorted at every re-prune — the identical graph (rows as sets); = 2 adds the diverseBefore
+ * shortcut, bl_ref_order = 2 removes it from reference order: the two ablations of DESIGN.md §7. */
 JV_API int jv_hip_builder_working_lists(jv_ctx *ctx, const jv_builder *b, int32_t *ids_out, float *scores_out, int32_t *diverse_before_out);
 JV_API int jv_hip_builder_destroy(jv_builder *b);
 /* The whole LAYERED build in one call (GraphIndexBuilder with addHierarchy): levels drawn per node like getRandomGraphLevel (:562-575:

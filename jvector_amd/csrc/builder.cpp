@@ -53,6 +53,8 @@ struct jv_builder {
     float alpha = 1.2f;
     int32_t *d_nbrs = nullptr;       // [n][R]
     bool stored = false;             // the three arrays below exist, rows are NodeArray-ordered under the stored scores (sorted lists / reference order)
+    bool use_db = false;             // stored: prunes of back-linked lists and enforceDegree start behind the diverseBefore mark (reference order: yes;
+                                     // sorted lists: no, unless bl_sorted_lists = 2; bl_ref_order = 2 switches it off there — the two ablations of DESIGN.md §7)
     bool sym = false;                // stored && sym: SORTED LISTS — the classic path's symmetric PQ diversity scores, stored; every prune re-tests the
                                      // whole list (diverseBefore unused).  stored && !sym: REFERENCE ORDER
     float *d_nsc = nullptr;          // [n][R] the score each entry was inserted under
@@ -235,9 +237,11 @@ int jv_hip_builder_create(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, c
         return fail(JV_ERR_OOM);
     }
     if (hipMemsetAsync(b->d_nbrs, 0xFF, sizeof(int32_t) * (size_t)b->n * b->R, ctx->stream) != hipSuccess) return fail(JV_ERR_HIP);
-    const bool ref_order = ctx_opt(ctx, "bl_ref_order", kBlRefOrderDefault) != 0;
-    b->sym = !ref_order && ctx_opt(ctx, "bl_sorted_lists", kBlSortedListsDefault) != 0;
+    const long long ref_opt = ctx_opt(ctx, "bl_ref_order", kBlRefOrderDefault), sorted_opt = ctx_opt(ctx, "bl_sorted_lists", kBlSortedListsDefault);
+    const bool ref_order = ref_opt != 0;
+    b->sym = !ref_order && sorted_opt != 0;
     b->stored = ref_order || b->sym;
+    b->use_db = ref_order ? ref_opt != 2 : sorted_opt == 2;
     b->hard_max = std::min(b->R, (int)(neighbor_overflow * (float)max_degree));   // Neighbors.insert :270
     if (b->stored) {
         if (hipMalloc((void **)&b->d_nsc, sizeof(float) * (size_t)b->n * b->R) != hipSuccess ||
@@ -419,7 +423,7 @@ static int link_back_edges_ro(jv_ctx *ctx, jv_builder *b, long long E, int dedup
     unsigned int n_over = 0;
     JV_TRY(read_counter(ctx, b, &n_over));
     n_over = std::min(n_over, over_cap);
-    JV_TRY(reprune_lists_ro(ctx, b, mp.over_tgt, mp.over_list, mp.over_sc, mp.over_n, b->sym ? nullptr : mp.over_db, (int)n_over, L));
+    JV_TRY(reprune_lists_ro(ctx, b, mp.over_tgt, mp.over_list, mp.over_sc, mp.over_n, b->use_db ? mp.over_db : nullptr, (int)n_over, L));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     b->backlink_s += now_s() - t0;
     return JV_OK;
@@ -734,7 +738,7 @@ int jv_hip_builder_finish(jv_ctx *ctx, jv_builder *b, int32_t *neighbors_out)
                 cp.ldb = (int32_t *)b->d_over_db.ptr;
                 cp.ln = (int32_t *)b->d_over_n.ptr;
                 JV_TRY(launch_bl_ro_copy_rows(ctx->stream, cp));
-                JV_TRY(reprune_lists_ro(ctx, b, tgt, cp.lst, cp.lsc, cp.ln, b->sym ? nullptr : cp.ldb, P, b->R));
+                JV_TRY(reprune_lists_ro(ctx, b, tgt, cp.lst, cp.lsc, cp.ln, b->use_db ? cp.ldb : nullptr, P, b->R));
                 continue;
             }
             JV_TRY(launch_bl_copy_rows(ctx->stream, b->d_nbrs, b->R, tgt, P, (int32_t *)b->d_over_list.ptr));
