@@ -33,6 +33,7 @@
 namespace jv {
 // gs_ubr unset: the register-table bound form (gs_body.h "UBR") serves every launch it applies to
 constexpr long long kGsUbrDefault = 1;
+constexpr long long kGsUbrcDefault = 0;   // the same form over the builder's compacted 33 ... 64-wide rows (gs_ubrc)
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1363,8 +1364,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // gs_ubr (default: on where it applies): the pair-lane kernel with the batch's upper-bound tables PREBUILT by a dense kernel and
     // held in the wave's registers, survivors compacted and scored eight lanes each, the candidate tier trimmed to what can still be
     // popped (gs_body.h "UBR").  No LDS beyond the pair form's.  Tables: M x 256 bytes per query of the batch.
-    const bool ubr = !so && !wgx && pair && !lutr && !ub8 && occ == 2 && !dev_accept.bits && !dev_accept.exclude && ctx_opt(ctx, "gs_ubr", kGsUbrDefault) != 0 &&
-                     graph_search_ubr_supported(pq->M, kvsf)
+    // ... and over the compacted fresh list of the builder's 33 ... 64-wide rows (gs_ubrc, default on): PAIRC + UBR
+    const bool ubr = !so && !wgx && (pair || (pairc && ctx_opt(ctx, "gs_ubrc", kGsUbrcDefault) != 0)) && !lutr && !ub8 && occ == 2 && !dev_accept.bits && !dev_accept.exclude &&
+                     ctx_opt(ctx, "gs_ubr", kGsUbrDefault) != 0 && graph_search_ubr_supported(pq->M, kvsf)
 #ifdef JV_EXPERIMENTAL
                      && ctx_opt(ctx, "gs_quad", 0) == 0   // (a launch that asks for the four-lane path of the plain pair kernel means that kernel)
 #endif

@@ -965,8 +965,9 @@ GS_FN void gs_ubr_trim(GsState &s, int rk, float &T)
 template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false, bool PAIRC = false, bool UBR = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
-    static_assert(!UBR || (PAIR && !SES && !LUTR && !UB8 && !PAIRC && VSF != 0 && CH16 % 2 == 0 && 60 * CH16 * 16 + 256 <= 64 * CH16 * 16),
-                  "the register-table bound form serves the pair-lane kernels, dot product / cosine, M a multiple of 32 and >= 64");
+    static_assert(!UBR || ((PAIR != PAIRC) && !SES && !LUTR && !UB8 && VSF != 0 && CH16 % 2 == 0 && 60 * CH16 * 16 + 256 <= 64 * CH16 * 16),
+                  "the register-table bound form serves the pair-lane kernels (over the row, or over the compacted fresh list), dot product / cosine, M a multiple of 32 and >= 64");
+    static_assert(!(UBR && PAIRC) || CH16 <= 6, "the bound form of the compacted pair kernel: two lanes per neighbour (M <= 96)");
     static_assert(!PAIRC || (!PAIR && !LUTR && !UB8 && CH16 > 0), "the compacted pair form is a variant of the plain one-lane-per-neighbour kernel");
     constexpr bool XA = PAIR || PAIRC;   // the worker's LDS block has the [M/2][32] exchange area
     static_assert(!(LUTR && PAIR), "the register-resident table serves the one-lane-per-neighbour form");
@@ -1672,6 +1673,122 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 #pragma unroll
                     for (int t = 1; t < LPN; ++t) cn = pass == t ? cn_[t] : cn;
                     const bool work = cn >= 0;
+                    if constexpr (UBR) {
+                        // ---- UBR over the compacted list (the builder's searches): a pass's <= 32 fresh neighbours are laid out like the
+                        //      pair form's row — lane ni low half, lane ni + 32 high half of the code — so the bound, the staging of
+                        //      the survivors and their eight-lane scoring are the pair form's (above), per pass ----
+                        constexpr int M_ = CH16 * 16, SUBS8 = M_ / 8;
+                        const bool hi = sub != 0;
+                        const bool last_pass = (pass + 1) * PER >= nf;
+                        gs_u2 w[CH16];
+#pragma unroll
+                        for (int c = 0; c < CH16; ++c) w[c] = gs_u2{0u, 0u};
+                        float node_mag = 0.0f;
+                        if (work) {
+                            gs_load_half<CH16>(p.codes + (int64_t)cn * p.M + m_base, w);
+                            if (VSF == 2 && !hi) node_mag = p.code_norms[cn];
+                        }
+                        const bool lowf = work && !hi;
+                        const uint64_t fmp = gs_ballot(lowf);
+                        uint64_t sm = fmp;
+                        const bool ub_active = ub_on && lvl == 0 && ub_T > -__builtin_inff();
+                        if (ub_active) {
+                            const int32_t part = gs_ubr_half<CH16>(ubtab, w, hi ? 1 : 0);   // all 64 lanes
+                            const int32_t other = gs_shfl32(part, lane ^ 32);
+                            bool drop = false;
+                            if (lowf) drop = gs_finish<VSF>(ubr_base + ubr_scale * (float)(part + other), node_mag, query_mag) < ub_T;
+                            const uint64_t dm = gs_ballot(drop);
+                            sm = fmp & ~dm;
+                            ub_dropped += (unsigned long long)gs_popc(dm);
+                        }
+                        const int ns = gs_popc(sm);
+                        ubr_since += ns;
+                        float *xf = xchg;
+                        int32_t *st_nb = reinterpret_cast<int32_t *>(xchg + 7 * M_);
+                        float *st_mag = reinterpret_cast<float *>(st_nb + 32);
+                        uint8_t *st_code = reinterpret_cast<uint8_t *>(st_mag + 32);
+                        if ((sm >> ni) & 1ull) {
+                            const int j = gs_popc(sm & ((1ull << ni) - 1ull));
+                            gs_u2 *dst = reinterpret_cast<gs_u2 *>(st_code + j * M_ + (hi ? M_ / 2 : 0));
+#pragma unroll
+                            for (int c = 0; c < CH16; ++c) dst[c] = w[c];
+                            if (!hi) {
+                                st_nb[j] = cn;
+                                st_mag[j] = node_mag;
+                            }
+                        }
+                        gs_barrier();
+                        const int g = lane >> 3;
+                        int t = lane & 7;
+                        GS_OPAQUE_I32(t);
+                        fresh = false;
+                        key = 0;
+#pragma unroll 1
+                        for (int base = 0; base < ns; base += 8) {
+                            const int j = base + g;
+                            const bool wk = j < ns;
+                            float sum = 0.0f;
+                            if (wk) {
+                                const uint32_t *cw = reinterpret_cast<const uint32_t *>(st_code + j * M_ + t * SUBS8);
+                                uint32_t d[SUBS8 / 4];
+#pragma unroll
+                                for (int i = 0; i < SUBS8 / 4; ++i) d[i] = cw[i];
+                                float v[SUBS8];
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+                                    gs_f4 c0[SUBS8 / 2], c1[SUBS8 / 2];
+#pragma unroll
+                                    for (int kk = 0; kk < SUBS8 / 2; ++kk) {
+                                        const int k = h2 * (SUBS8 / 2) + kk;
+                                        const uint32_t code = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                                        const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(p.codebooks + ((int64_t)((t * SUBS8 + k) * 256) + code) * 8);
+                                        c0[kk] = cp[0];
+                                        c1[kk] = cp[1];
+                                    }
+#pragma unroll
+                                    for (int kk = 0; kk < SUBS8 / 2; ++kk) {
+                                        const int k = h2 * (SUBS8 / 2) + kk;
+                                        v[k] = gs_lut_entry_pk<VSF>(c0[kk], c1[kk], qs + (t * SUBS8 + k) * 8);
+                                    }
+                                }
+                                if (t == 0) {
+#pragma unroll
+                                    for (int k = 0; k < SUBS8; ++k) sum += v[k];
+                                } else {
+#pragma unroll
+                                    for (int k = 0; k < SUBS8; ++k) xf[g * (7 * SUBS8) + (t - 1) * SUBS8 + k] = v[k];
+                                }
+                            }
+                            gs_barrier();
+                            fresh = wk && t == 0;
+                            key = 0;
+                            if (fresh) {
+                                const gs_f4 *col = reinterpret_cast<const gs_f4 *>(xf + g * (7 * SUBS8));
+#pragma unroll
+                                for (int i = 0; i < 7 * SUBS8 / 4; ++i) {
+                                    const gs_f4 e4 = col[i];
+                                    sum += e4.x;
+                                    sum += e4.y;
+                                    sum += e4.z;
+                                    sum += e4.w;
+                                }
+                                const float sc = gs_finish<VSF>(sum, st_mag[j], query_mag);
+                                key = gs_key(st_nb[j], sc);
+                                if (ub_active && sc < ub_T) fresh = false;
+                            }
+                            if (base + 8 >= ns && last_pass) break;   // the shared tail below pushes the expansion's last scores
+                            gs_barrier();
+                            if (ub_on && gs_ballot(fresh && (int32_t)(key >> 32) == 0x7fc00000)) ub_on = false;
+                            gs_push(s, p, key, fresh);
+                            fresh = false;
+                            if (s.status != GS_OK) {
+                                give_up = true;
+                                break;
+                            }
+                        }
+                        if (give_up || last_pass) break;
+                        continue;
+                    }
                     gs_u2 w[HW];
                     float node_mag = 0.0f, sum = 0.0f;
                     if (work) {   // PQDecoder.similarityTo: the neighbour's own code

@@ -27,6 +27,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     gs_worker<VSF, CH16, true, PROF, false, false, false, false, true>(p, (int)blockIdx.x, gs_lds);
 }
 
+// the same bound form over the COMPACTED fresh list of rows up to 64 wide, codes by ordinal (gs_body.h PAIRC + UBR): the builder's searches
+template <int VSF, int CH16, bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_ubrc_kernel(GsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char gs_lds[];
+    gs_worker<VSF, CH16, false, PROF, false, false, false, true, true>(p, (int)blockIdx.x, gs_lds);
+}
+
 // ---- the tables of a batch --------------------------------------------------------------------------------------------------------
 // One block = UBR_QB queries x all M subspaces, 4 waves.  Wave w takes the steps r in [w M/8, (w + 1) M/8) — i.e. the subspaces r and
 // r + M/2, whose bytes share a register pair of the table — and lane s the codes s, s + 64, s + 128, s + 192 of each: a codebook row
@@ -217,7 +225,9 @@ int launch_graph_search_ubr(hipStream_t s, int vsf, const GsParams &p, int worke
     dim3 grid(workers), block(64);
 #define JV_UBR(VSFV)                                                                                             \
     do {                                                                                                         \
-        if (p.prof) hipLaunchKernelGGL((graph_search_ubr_kernel<VSFV, 6, true>), grid, block, lds, s, p);        \
+        if (p.pair == 2) {   /* over the compacted fresh list (no phase-clock build) */                           \
+            hipLaunchKernelGGL((graph_search_ubrc_kernel<VSFV, 6, false>), grid, block, lds, s, p);               \
+        } else if (p.prof) hipLaunchKernelGGL((graph_search_ubr_kernel<VSFV, 6, true>), grid, block, lds, s, p);  \
         else hipLaunchKernelGGL((graph_search_ubr_kernel<VSFV, 6, false>), grid, block, lds, s, p);              \
     } while (0)
     if (vsf == VSF_DOT) JV_UBR(VSF_DOT);

@@ -135,6 +135,15 @@ void run_ubr(const Launch &L)
     }
 }
 template <int VSF>
+void run_ubrc(const Launch &L)   // the bound form over the compacted fresh list (rows up to 64 wide, codes by ordinal)
+{
+    switch (L.ch) {
+    case 4: jv::gs_worker<VSF, 4, false, false, false, false, false, true, true>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gs_worker<VSF, 6, false, false, false, false, false, true, true>(*L.p, L.worker, L.lds); break;
+    default: abort();
+    }
+}
+template <int VSF>
 void run_pairc(const Launch &L)
 {
     switch (L.ch) {
@@ -169,6 +178,9 @@ void lane_main(void *arg)
         if (L.vsf == 0) run_wgx<0>(L);
         else if (L.vsf == 1) run_wgx<1>(L);
         else run_wgx<2>(L);
+    } else if (L.p->ubr && L.p->pair == 2) {
+        if (L.vsf == 1) run_ubrc<1>(L);
+        else run_ubrc<2>(L);
     } else if (L.p->ubr) {
         if (L.vsf == 1) run_ubr<1>(L);
         else run_ubr<2>(L);
@@ -238,7 +250,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     if (pair_mode == 2 && !pair && !pairc) return -8;
     p.pair = pair ? 1 : (pairc ? 2 : 0);
     p.quad = getenv("GS_EMU_QUAD") ? atoi(getenv("GS_EMU_QUAD")) : 1;   // (on in the emulator unless a test turns it off: more code under test)
-    if (ub8 && (!pair || vsf == 0 || M > 96 || wgx_waves || lutr)) return -7;
+    if (ub8 && (!(pair || (pairc && ub8 == 2)) || vsf == 0 || M > 96 || wgx_waves || lutr)) return -7;
     if (ub8 == 2 && M != 64 && M != 96) return -9;
     p.ub8 = ub8 == 1 ? 1 : 0;
     std::vector<uint32_t> ubr_tab;

@@ -871,6 +871,9 @@ void gs_main(void *a)
             else if (L.vsf == VSF_DOT) gs_run_session<VSF_DOT, false>(L);
             else gs_run_session<VSF_COS, false>(L);
         }
+    } else if (L.p->ubr && L.p->pair == 2) {
+        if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, false, false, false, false, false, true, true>(*L.p, L.worker, L.lds);
+        else gs_worker<VSF_COS, 6, false, false, false, false, false, true, true>(*L.p, L.worker, L.lds);
     } else if (L.p->ubr) {
         if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, true, false, false, false, false, false, true>(*L.p, L.worker, L.lds);
         else gs_worker<VSF_COS, 6, true, false, false, false, false, false, true>(*L.p, L.worker, L.lds);

@@ -257,3 +257,43 @@ def test_sorted_lists_build_the_classic_graph_gpu():
     ctx = J.HipContext(0)
     check_sorted_lists_equal_classic(J, ctx, torch.device("cuda", 0), 40000, 128, 16, 32, 100, 4096)
     ctx.close()
+
+
+def check_builder_with_bound_form(J, ctx, dev, N, max_batch):
+    """gs_ubrc = 1: the builder's searches run the register-table bound form over the compacted fresh list (PQ-96, dot product /
+    cosine) — every search returns what the plain compacted form returns, so the SAME graph must come out, byte for byte"""
+    from jvector_amd.builder import build_vamana
+    D, M = 768, 96
+    v, _ = _data(N, D, 5)
+    tv = torch.from_numpy(v).to(dev)
+    pq = J.ProductQuantization.compute(ctx, tv, M, seed=2)
+    vs = J.VectorSet(ctx, tv)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    out = {}
+    for vsf in (J.VectorSimilarityFunction.COSINE, J.VectorSimilarityFunction.DOT_PRODUCT):
+        for mode in (0, 1):
+            ctx.set_option("gs_ubrc", mode)
+            ctx.set_option("gs_wgx", 0)          # (small batches would otherwise take the workgroup form)
+            ctx.reset_stats()
+            try:
+                nb, entry, st = build_vamana(ctx, pq, cv, tv, vsf, max_degree=32, beam_width=60, alpha=1.2, max_batch=max_batch, improve=1, overflow=2.0, vector_set=vs)
+                dropped = ctx.stat("gs_ubr_dropped")
+            finally:
+                ctx.set_option("gs_ubrc", 0)
+                ctx.set_option("gs_wgx", -1)
+            out[mode] = (nb.cpu().numpy().copy(), entry, st["visited"], st["expanded"], dropped)
+        assert out[0][4] == 0 and out[1][4] > 0.2 * out[1][2], (out[0][4], out[1][4], out[1][2])   # the form ran and dropped neighbours
+        assert out[0][1] == out[1][1] and out[0][2] == out[1][2] and out[0][3] == out[1][3] and np.array_equal(out[0][0], out[1][0])
+
+
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+def test_builder_searches_in_the_bound_form_on_the_mock():
+    _on_the_mock(lambda J, ctx, register: check_builder_with_bound_form(J, ctx, torch.device("cpu"), 260, 64))
+
+
+@pytest.mark.gpu
+def test_builder_searches_in_the_bound_form_gpu():
+    import jvector_amd as J
+    ctx = J.HipContext(0)
+    check_builder_with_bound_form(J, ctx, torch.device("cuda", 0), 40000, 4096)
+    ctx.close()

@@ -372,6 +372,41 @@ def test_compacted_pair_form_matches_oracle(emu, M, deg):
             run_emu(emu, lv, entry, entry_level, opq, codes, q, O.COSINE, 10, True, pair=2)
 
 
+@pytest.mark.parametrize("M,deg,N", [(96, 64, 2500), (96, 40, 2000), (64, 48, 2500)])
+def test_register_table_bound_form_over_the_compacted_list(emu, monkeypatch, M, deg, N):
+    """UBR over the compacted pair form (the builder's searches: rows of 33 ... 64 neighbours, codes by ordinal): a pass's fresh
+    neighbours are bounded, the survivors staged and scored eight lanes each, pass by pass — ids, scores and both counters equal the
+    oracle's; trims every 1 / 8 / 64 pushes; duplicated vectors; shuffled lane orders"""
+    D = 8 * M
+    lv, entry, entry_level, opq, codes, q = problem(500 + M + deg, N, D, M, 1, deg=deg, nq=8)
+    assert lv[0][1].shape[1] == deg
+    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
+    dropped_total = scored_total = 0
+    for vsf in (O.DOT_PRODUCT, O.COSINE):
+        for rk in (100, 10, 1):
+            wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=False)
+            for trim, v1, cc in (("8", 9, 256), ("1", 12, 128), ("64", 9, 256)):
+                monkeypatch.setenv("GS_EMU_UBR_TRIM", trim)
+                ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, False, pair=2, ub8=2, v1_log2=v1, cand_cap=cc)
+                check(ids, sc, st, status, wi, ws, wst)
+                scored_total += int(wst[:, 0].sum())
+                dropped_total += run_emu.last_ub8_dropped
+    assert dropped_total > 0.1 * scored_total, (dropped_total, scored_total)
+    if M == 96 and deg == 64:
+        codes2 = codes.copy()
+        codes2[1::2] = codes2[0:-1:2][: len(codes2[1::2])]
+        og2 = O.OracleGraph(codes2.shape[0], lv, entry, entry_level)
+        monkeypatch.setenv("GS_EMU_UBR_TRIM", "8")
+        for order in ("", "reverse", "random:5"):
+            if order:
+                monkeypatch.setenv("EMU_LANE_ORDER", order)
+            for vsf in (O.DOT_PRODUCT, O.COSINE):
+                wi, ws, wst = og2.search(opq, codes2, None, q, vsf, 40, 40, fused=False)
+                ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes2, q, vsf, 40, False, pair=2, ub8=2)
+                check(ids, sc, st, status, wi, ws, wst)
+        monkeypatch.delenv("EMU_LANE_ORDER", raising=False)
+
+
 def test_partition_and_spill_paths(emu):
     """rerankK large enough that far more than cand_cap=256 candidates are alive: the LDS tier must spill (several
     partitions per query) and results must not change."""
