@@ -38,10 +38,11 @@ t_end = time.time() + budget
 cases = searches = 0
 knobs = ("JVECTOR_HIP_GS_VCAP_LOG2", "JVECTOR_HIP_GS_GROW", "JVECTOR_HIP_GS_RETRY", "JVECTOR_HIP_GS_CAND_CAP", "JVECTOR_HIP_GS_PUSH_LOG_CAP",
          "JVECTOR_HIP_GS_GENERIC", "JVECTOR_HIP_GS_WGX", "JVECTOR_HIP_GS_WGX_WAVES", "JVECTOR_HIP_GS_WGX_SLOTS", "JVECTOR_HIP_GS_WGX_DEPTH",
-         "JVECTOR_HIP_GS_WGX_LUT_M", "JVECTOR_HIP_GS_WGX_PER_CU", "JVECTOR_HIP_GS_PAIRC", "JVECTOR_HIP_GS_QUAD")
-wgx_searches = pairc_searches = 0
+         "JVECTOR_HIP_GS_WGX_LUT_M", "JVECTOR_HIP_GS_WGX_PER_CU", "JVECTOR_HIP_GS_PAIRC", "JVECTOR_HIP_GS_QUAD", "JVECTOR_HIP_GS_UBR", "JVECTOR_HIP_GS_UBRC",
+         "JVECTOR_HIP_GS_UBR_TRIM")
+wgx_searches = pairc_searches = ubr_searches = 0
 while time.time() < t_end:
-    D = int(rng.choice([128, 256, 384, 512, 768] if not MOCK else [128, 256]))
+    D = int(rng.choice([128, 256, 384, 512, 768, 768, 768] if not MOCK else [128, 256]))   # (768 = PQ-96: the register-table bound forms)
     M = D // 8
     if rng.random() < 0.3:                                   # any other quantizer (ragged / small / odd): the generic kernels
         D = int(rng.integers(6, 260))
@@ -135,6 +136,11 @@ while time.time() < t_end:
             env["JVECTOR_HIP_GS_WGX"] = "0"
             env["JVECTOR_HIP_GS_PAIRC"] = str(int(rng.integers(0, 2)))
             env["JVECTOR_HIP_GS_QUAD"] = str(int(rng.integers(0, 2)))
+            # round 5: the register-table bound forms (PQ-96, dot product / cosine: over the row, and over the compacted fresh list) on / off,
+            # trims every 1 ... 64 pushes
+            env["JVECTOR_HIP_GS_UBR"] = str(int(rng.random() < 0.8))
+            env["JVECTOR_HIP_GS_UBRC"] = str(int(rng.random() < 0.8))
+            env["JVECTOR_HIP_GS_UBR_TRIM"] = str(int(rng.choice([1, 8, 48, 64])))
         for k in knobs:
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -156,8 +162,9 @@ while time.time() < t_end:
         searches += 1
         wgx_searches += ctx.stat("gs_last_wgx") if traversal == "device" else 0
         pairc_searches += int(traversal == "device" and ctx.stat("gs_last_wgx") == 0 and ctx.stat("gs_last_pair") == 2)
+        ubr_searches += int(traversal == "device" and ctx.stat("gs_last_wgx") == 0 and ctx.stat("gs_last_ubr") == 1)
         graph.close()
     cases += 1
 for k in knobs:
     os.environ.pop(k, None)
-print(f"fuzz: {cases} random problems, {searches} searches ({wgx_searches} through the workgroup form, {pairc_searches} through the compacted pair form), all bit-identical to the oracle (seed {seed}, {budget:.0f} s)")
+print(f"fuzz: {cases} random problems, {searches} searches ({wgx_searches} through the workgroup form, {pairc_searches} through the compacted pair form, {ubr_searches} through a register-table bound form), all bit-identical to the oracle (seed {seed}, {budget:.0f} s)")
