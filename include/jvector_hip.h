@@ -117,7 +117,8 @@ JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
  *   gs_ties_to_host, gs_last_v1_log2, gs_last_workers_per_cu, gs_calls_wgx, gs_last_wgx (1: the last search ran in the workgroup
  *   form), gs_last_pair (1: pair lanes over the row, 2: over the compacted fresh list, 0: one lane per neighbour), gs_last_ubr (1: the
  *   last search ran the register-table bound form — option gs_ubr, on by default where it applies: pair-lane kernels, dot product /
- *   cosine, PQ-96; gs_ubr_trim = candidates pushed between two trims of its queue), gs_ubr_dropped (neighbours that form dropped
+ *   cosine, PQ-96; gs_ubrc, also on by default: the same form over the compacted fresh list of rows 33 ... 64 wide read by ordinal, i.e. the
+ *   builder's own searches; gs_ubr_trim = candidates pushed between two trims of its queue), gs_ubr_dropped (neighbours that form dropped
  *   behind their bound, unscored); experimental_build (1: the library was built with make EXPERIMENTAL=1 and also holds the
  *   measured-and-switched-off variants gs_lutr, gs_quad, gs_ub8, rd_table_free, rd_chunk, rd_square — the default build accepts
  *   and ignores their options). */

@@ -795,6 +795,8 @@ struct jv_layered {
     std::vector<int64_t> level_counts;
 };
 
+}  // extern "C"
+
 namespace {
 inline uint64_t splitmix64(uint64_t &s)
 {
@@ -855,6 +857,8 @@ int build_one_level(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, const j
     return rc;
 }
 }  // namespace
+
+extern "C" {
 
 int jv_hip_build_layered(jv_ctx *ctx, const jv_pq *pq, const jv_codes *codes, const jv_vectors *vectors, jv_vsf vsf, int max_degree,
                          int beam_width, float alpha, float neighbor_overflow, int max_batch, int improve_passes, uint64_t seed, int min_top,
