@@ -463,30 +463,6 @@ int jv_hip_builder_insert_batch(jv_ctx *ctx, jv_builder *b, const int32_t *nodes
 
     // ---- 3 + 4. robust prune of every new node's candidates (best first), rows + back edges ----
     double t0 = now_s();
-    if (!b->stored && ctx_opt(ctx, "bl_sym_insert", 0) != 0) {
-        // experiment: the candidates of a NEW node re-scored with the symmetric pair function against the node's own code
-        // and re-ordered before its first prune — the prune then compares like with like (pair(c, j) against pair(node, c)), as every
-        // later re-prune of the classic path does; the reference compares pair(c, j) with ADC(node's vector, c)
-        JV_TRY(b->d_over_sc.reserve(sizeof(float) * (size_t)B * k));
-        JV_TRY(b->d_sorted_ids.reserve(sizeof(int32_t) * (size_t)B * k));
-        JV_TRY(b->d_sorted_sc.reserve(sizeof(float) * (size_t)B * k));
-        JV_TRY(b->d_over_n.reserve(sizeof(int32_t) * (size_t)B));
-        {
-            ProfScope ps(ctx, R_ADC);
-            JV_TRY(launch_pair_scores(ctx->stream, b->tri->d_tri, to_kernel_vsf(b->vsf), b->codes, d_nodes, B, d_cand, k, (float *)b->d_over_sc.ptr));
-        }
-        BlSortParams sp{};
-        sp.ids = d_cand;
-        sp.scores = (const float *)b->d_over_sc.ptr;
-        sp.P = B;
-        sp.L = k;
-        sp.out_ids = (int32_t *)b->d_sorted_ids.ptr;
-        sp.out_scores = (float *)b->d_sorted_sc.ptr;
-        sp.out_count = (int32_t *)b->d_over_n.ptr;
-        JV_TRY(launch_bl_rank_sort(ctx->stream, sp));
-        d_cand = sp.out_ids;
-        d_csc = sp.out_scores;
-    }
     JV_TRY(b->d_count.reserve(sizeof(int32_t) * (size_t)B));
     JV_TRY(b->d_sel.reserve(sizeof(int32_t) * (size_t)B * Rf));
     JV_TRY(b->d_nsel.reserve(sizeof(int32_t) * (size_t)B));
