@@ -36,7 +36,7 @@ inline GsLevelMap gs_build_level_map(const int32_t *nodes, int count)
 // ---- UBR (gs_body.h "UBR"): the 8-bit upper-bound table of ONE query's ADC entries, the way ubr_table_kernel (k_gsearch_ubr.hip)
 // builds it for a batch — this restatement serves the lane emulator, the mock device and the GPU test that compares the kernel's
 // bytes with it.  Dot product / cosine entries (calculatePartialSums' chain, mul and add separate); per subspace lo_m / hi_m = the
-// extreme entries; ONE scale S = max_m (hi_m - lo_m) / 255; entry -> bucket b with lo_m + S (b + 1) >= entry verified in f32.
+// extreme entries; ONE scale S = max_m (hi_m - lo_m) / 255; entry -> bucket b with lo_m + S (b + 1) > entry (see `bucket` below).
 // tab: M x 64 dwords in the register layout (register k of lane s at ((k / 4) * 64 + s) * 4 + k % 4; for step r < M / 2 register 2r
 // holds {t[r][s], t[r][s + 64], t[r + M/2][s], t[r + M/2][s + 64]} and 2r + 1 the same for codes s + 128 / s + 192);
 // meta4 = {sum_m lo_m + slack, S, usable (1 / 0), 0}.  Compile with -ffp-contract=off.
@@ -80,12 +80,13 @@ inline void gs_ubr_build_ref(const float *codebooks /* [M][256][8] */, const flo
     ok = ok && (sum_abs - sum_abs == 0.0f) && S * 1e6f >= max_abs;
     auto bucket = [&](int m, int c) -> uint32_t {
         const float ent = e[(size_t)m * 256 + c];
-        int b = (int)((ent - lo[m]) * inv);
+        // b = floor(t + 2^-10), t = (ent - lo) / S as f32 evaluates it: three roundings put t within 256 x 3.1 x 2^-24 < 5e-5 of the real
+        // quotient (and the addition within 8e-6 more), so b + 1 exceeds the real quotient and lo + S (b + 1) > ent in real arithmetic;
+        // a clamped b = 255 bounds too: 256 S >= (256 / 255)(1 - 2^-24) x the widest range > hi - lo.  (The traversal's f32 evaluation
+        // of sum lo + S sum (b + 1) is covered by the slack in meta4[0], as before.)  One entry in a thousand lands a bucket higher
+        // than the tightest choice.
+        int b = (int)((ent - lo[m]) * inv + 0x1p-10f);
         b = b < 0 ? 0 : (b > 255 ? 255 : b);
-        // the bucket's upper edge really is an upper bound, in f32: the truncated quotient is at most two buckets short
-        if (b < 255 && lo[m] + S * (float)(b + 1) < ent) ++b;
-        if (b < 255 && lo[m] + S * (float)(b + 1) < ent) ++b;
-        if (lo[m] + S * (float)(b + 1) < ent) b = 255;
         return (uint32_t)b;
     };
     const int H = M / 2;

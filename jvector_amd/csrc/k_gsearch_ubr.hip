@@ -170,12 +170,9 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float e = e4[k];
-                    int bb = (int)((e - l) * inv);
+                    // (gs_host.h gs_ubr_build_ref: floor of the f32 quotient plus 2^-10 — its upper edge bounds the entry)
+                    int bb = (int)((e - l) * inv + 0x1p-10f);
                     bb = bb < 0 ? 0 : (bb > 255 ? 255 : bb);
-                    // the bucket's upper edge really is an upper bound, in f32: the truncated quotient is at most two buckets short
-                    if (bb < 255 && l + S * (float)(bb + 1) < e) ++bb;
-                    if (bb < 255 && l + S * (float)(bb + 1) < e) ++bb;
-                    if (l + S * (float)(bb + 1) < e) bb = 255;
                     b[half][k] = (uint32_t)bb;
                 }
             }
