@@ -1,7 +1,8 @@
 """Batched Vamana construction (jv_hip_builder_* behind jvector_amd/builder.py: BASELINE config 5) — the engine searches the graph it is
 building (device traversal over a device-resident, mutable adjacency), prunes with the retain_diverse kernel and backlinks with the
-PQ diversity scores, all inside the library.  The reference's builder is concurrent and nondeterministic, so there is nothing to be bit-identical WITH;
-what is checked is the contract a Vamana graph has to meet: degrees within maxDegree, no self loops / duplicates / dangling
+PQ diversity scores, all inside the library.  The reference's builder run by many threads is nondeterministic; what one thread builds IS
+pinned — byte for byte, with the builder in reference order and one node per batch — in tests/test_builder_reference_order.py.  Here, for
+batches of many nodes and the default list form, what is checked is the contract a Vamana graph has to meet: degrees within maxDegree, no self loops / duplicates / dangling
 ids, every node reachable from the entry point, and — the point of the exercise — a search over the built graph finds the
 true nearest neighbours (recall against brute force), while every call it is made of is separately parity-tested."""
 import ctypes as C
