@@ -33,6 +33,25 @@ float parallel_cost_multiplier(float threshold, int dimensions)
     return (float)std::max(1.0, parallelCost / perpendicularCost);
 }
 
+// getNearestCluster for every (training point, subspace) = closestCentroidIndex of the point under the CURRENT centroids: the same
+// squareL2Distance chain, the same strict `<` / first minimum (KMeansPlusPlusClusterer.java:330-343 against ProductQuantization.java:
+// 507-520) — so a round's assignment is an encode of the centred sample with the work quantizer, and runs on the encode kernel
+// (57 TFLOP/s, k_pq.hip) instead of one thread per (point, subspace) walking 256 centroids through divergent global loads (0.5
+// TFLOP/s: 1.5 of the 3.7 s of a PQ-192 training).  A converged subspace's centroids no longer move, so re-encoding it reproduces the
+// assignment km_assign would copy.  Uniform sub-vectors of the encode kernel's sizes and 256 clusters; anything else, or
+// JVECTOR_HIP_KM_ASSIGN_PLAIN=1, takes km_assign.
+static int assign_points(hipStream_t s, const jv_pq *work, const KmParams &p)
+{
+    const int sz = work->max_size;
+    const bool fast = work->uniform && work->d_cb_paired && work->k == kClusters && work->k_user == kClusters &&
+                      (sz == 2 || sz == 4 || sz == 6 || sz == 8 || sz == 12 || sz == 16) && !getenv("JVECTOR_HIP_KM_ASSIGN_PLAIN");
+    if (!fast) return launch_km_assign(s, p);
+    jv_pq view = *work;            // (a shallow copy: the handle owns nothing through its destructor)
+    view.d_centroid = nullptr;     // the sample is centred already
+    JV_TRY(launch_self_magnitudes(s, &view));   // refreshes the paired copy of the centroids the encode kernel reads
+    return launch_pq_encode(s, &view, p.X, p.n, p.assign_new);
+}
+
 int run_training(jv_ctx *ctx, jv_pq *work /* layout + d_codebooks in/out */, const float *vectors, int64_t n, const float *d_centroid,
                  bool compute_centroid, float *d_centroid_out, bool seed_with_kmeans_pp, int rounds, uint64_t seed,
                  int aniso_rounds = 0, float aniso_threshold = -1.0f)
@@ -74,12 +93,12 @@ int run_training(jv_ctx *ctx, jv_pq *work /* layout + d_codebooks in/out */, con
                (float *)dist.p, (float *)cnorm.p, (const float *)pcm.p, n, D, M, k};
     if (seed_with_kmeans_pp) JV_TRY(launch_km_pp_init(s, p));
     // KMeansPlusPlusClusterer constructor: initializeAssignedPoints
-    JV_TRY(launch_km_assign(s, p));
+    JV_TRY(assign_points(s, work, p));
     JV_TRY(launch_km_replay(s, p, 1));
     for (int it = 0; it < rounds; ++it) {  // cluster(rounds, 0): subspaces that converged (<= 1 % moved) go inactive
         std::swap(p.assign_old, p.assign_new);
         JV_TRY(launch_km_update_centroids(s, p));
-        JV_TRY(launch_km_assign(s, p));
+        JV_TRY(assign_points(s, work, p));
         JV_TRY(launch_km_replay(s, p, 0));
         JV_TRY(launch_km_finish_round(s, p));
     }
