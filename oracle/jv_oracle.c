@@ -2145,3 +2145,15 @@ void jvo_builder_info(const jvo_builder *b, int32_t *entry_node, int *entry_leve
     if (n_levels) *n_levels = b->n_levels;
     if (reprunes) *reprunes = b->reprunes;
 }
+
+/* NodeArray.insertSorted (:181-193) on caller-owned arrays with room for one more entry — for the reference's TestNodeArray literals.
+ * Returns the insertion point, -1 when the (node, score) pair is already listed. */
+int jvo_nodearray_insert_sorted(int32_t *nodes, float *scores, int *size, int32_t node, float score)
+{
+    nodearr a = { nodes, scores, *size };
+    const int at = na_insertion_point(&a, node, score);
+    if (at < 0) return -1;
+    na_insert_at(&a, at, node, score);
+    *size = a.size;
+    return at;
+}

@@ -267,6 +267,7 @@ def lib():
         sig("jvo_builder_enforce_degree", None, C.c_void_p, C.c_int32)
         sig("jvo_builder_cleanup", None, C.c_void_p)
         sig("jvo_builder_row", C.c_int, C.c_void_p, C.c_int, C.c_int32, i32p, fp, C.POINTER(C.c_int))
+        sig("jvo_nodearray_insert_sorted", C.c_int, i32p, fp, C.POINTER(C.c_int), C.c_int32, C.c_float)
         sig("jvo_builder_info", None, C.c_void_p, i32p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64))
         _lib = L
     return _lib
@@ -771,3 +772,27 @@ class OracleBuilder:
                 assert r[0].size <= width
                 out[v, :r[0].size] = r[0]
         return out
+
+
+class NodeArrayProbe:
+    """NodeArray's ordered insert on plain arrays (jvo_nodearray_insert_sorted): what the reference's TestNodeArray literals exercise"""
+
+    def __init__(self, capacity=64):
+        self._n = np.full(capacity, -1, np.int32)
+        self._s = np.zeros(capacity, np.float32)
+        self._size = C.c_int(0)
+
+    def add_in_order(self, node, score):
+        assert self._size.value == 0 or self._s[self._size.value - 1] >= np.float32(score)      # NodeArray.addInOrder :149-164
+        self._n[self._size.value], self._s[self._size.value] = node, score
+        self._size.value += 1
+
+    def insert_sorted(self, node, score):
+        return int(lib().jvo_nodearray_insert_sorted(self._n.ctypes.data_as(C.POINTER(C.c_int32)), _f(self._s), C.byref(self._size), int(node),
+                                                     C.c_float(score)))
+
+    def nodes(self):
+        return self._n[:self._size.value].tolist()
+
+    def scores(self):
+        return self._s[:self._size.value].tolist()

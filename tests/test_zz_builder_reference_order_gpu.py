@@ -91,3 +91,13 @@ def test_batched_build_in_reference_order_serves_searches(ctx):
     r_ref, r_cls = {rk: recall_of(nb, entry, rk) for rk in (100, 400)}, {rk: recall_of(nb_c, entry_c, rk) for rk in (100, 400)}
     print("reference order, batched:", dict(st), "recall@10 by rerankK", r_ref, "| default build:", r_cls)
     assert r_ref[400] >= 0.5 and r_ref[400] >= 0.6 * r_cls[400] and r_ref[400] >= r_ref[100], (r_ref, r_cls)
+
+
+@pytest.mark.parametrize("name", ["testDiversity", "testDiversity3d", "testDiversityFallback"])
+def test_engine_reproduces_the_reference_literals(ctx, name):
+    """the reference's own literal expectations for a one-thread GraphIndexBuilder (TestVectorGraph.java:455-613), on the device"""
+    import jvector_amd as J
+    from test_builder_reference_goldens import check_engine_reproduces_the_reference_literals
+    ctx.reset_stats()
+    check_engine_reproduces_the_reference_literals(J, ctx, torch.device("cuda", 0), name)
+    assert ctx.stat("gs_calls_host") == 0
