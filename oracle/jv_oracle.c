@@ -2157,3 +2157,11 @@ int jvo_nodearray_insert_sorted(int32_t *nodes, float *scores, int *size, int32_
     *size = a.size;
     return at;
 }
+
+/* NodeArray.merge (:63-143); out arrays hold size1 + size2 entries; returns the merged size */
+int jvo_nodearray_merge(const int32_t *n1, const float *s1, int size1, const int32_t *n2, const float *s2, int size2, int32_t *out_n, float *out_s)
+{
+    nodearr a1 = { (int32_t *)n1, (float *)s1, size1 }, a2 = { (int32_t *)n2, (float *)s2, size2 }, m = { out_n, out_s, 0 };
+    na_merge(&a1, &a2, &m);
+    return m.size;
+}

@@ -196,6 +196,7 @@ void jvo_builder_cleanup(jvo_builder *b);
 int  jvo_builder_row(const jvo_builder *b, int level, int32_t node, int32_t *ids, float *scores, int *diverseBefore);
 void jvo_builder_info(const jvo_builder *b, int32_t *entry_node, int *entry_level, int *n_levels, int64_t *reprunes);
 int  jvo_nodearray_insert_sorted(int32_t *nodes, float *scores, int *size, int32_t node, float score);
+int  jvo_nodearray_merge(const int32_t *n1, const float *s1, int size1, const int32_t *n2, const float *s2, int size2, int32_t *out_n, float *out_s);
 
 /* exact rerank of pre-gathered candidate rows (Q x R x D), one query per worker thread */
 void jvo_rerank(const float *queries, const float *cand_vecs, const int32_t *cand_ids, int Q, int R, int D, int vsf,

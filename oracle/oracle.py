@@ -267,6 +267,7 @@ def lib():
         sig("jvo_builder_enforce_degree", None, C.c_void_p, C.c_int32)
         sig("jvo_builder_cleanup", None, C.c_void_p)
         sig("jvo_builder_row", C.c_int, C.c_void_p, C.c_int, C.c_int32, i32p, fp, C.POINTER(C.c_int))
+        sig("jvo_nodearray_merge", C.c_int, i32p, fp, C.c_int, i32p, fp, C.c_int, i32p, fp)
         sig("jvo_nodearray_insert_sorted", C.c_int, i32p, fp, C.POINTER(C.c_int), C.c_int32, C.c_float)
         sig("jvo_builder_info", None, C.c_void_p, i32p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64))
         _lib = L
@@ -796,3 +797,11 @@ class NodeArrayProbe:
 
     def scores(self):
         return self._s[:self._size.value].tolist()
+
+    def merge(self, other):
+        """NodeArray.merge(this, other) -> (nodes, scores)"""
+        n1, s1, n2, s2 = self._n[:self._size.value].copy(), self._s[:self._size.value].copy(), other._n[:other._size.value].copy(), other._s[:other._size.value].copy()
+        on, osc = np.empty(n1.size + n2.size + 1, np.int32), np.empty(n1.size + n2.size + 1, np.float32)
+        p = C.POINTER(C.c_int32)
+        m = lib().jvo_nodearray_merge(n1.ctypes.data_as(p), _f(s1), n1.size, n2.ctypes.data_as(p), _f(s2), n2.size, on.ctypes.data_as(p), _f(osc))
+        return on[:m].tolist(), osc[:m].tolist()

@@ -88,6 +88,48 @@ def test_node_array_literals():
     assert st.insert_sorted(7, 0.85) >= 0 and st.nodes() == [5, 0, 4, 3, 7, 1, 6, 7]       # another score: listed twice (NodeArray.java:212-228)
 
 
+def _array(pairs):
+    a = O.NodeArrayProbe()
+    for node, score in pairs:
+        a.add_in_order(node, score)
+    return a
+
+
+def test_node_array_duplicates_and_merge_literals():
+    """TestNodeArray.testNoDuplicatesDescOrder / testNoDuplicatesSameScores / testMergeCandidatesSimple (:163-228) literally, and
+    testMergeCandidatesRandom's recipe and properties (:230-300) over 5 000 seeded cases"""
+    for scores in ((10.0, 9.0, 8.0), (10.0, 10.0, 10.0)):
+        a = O.NodeArrayProbe()
+        for node, sc in zip((1, 2, 3), scores):
+            a.insert_sorted(node, sc)
+        assert a.insert_sorted(1, scores[0]) == -1 and a.insert_sorted(3, scores[2]) == -1
+        assert a.nodes() == [1, 2, 3] and a.scores() == list(scores)
+    assert _array([(1, 1.0)]).merge(_array([(0, 2.0)]))[0] == [0, 1]
+    assert _array([(3, 3.0), (2, 2.0), (1, 1.0)]).merge(_array([(4, 4.0), (2, 2.0), (1, 1.0)])) == ([4, 3, 2, 1], [4.0, 3.0, 2.0, 1.0])
+    assert _array([(3, 3.0), (2, 2.0)]).merge(_array([(2, 2.0)])) == ([3, 2], [3.0, 2.0])
+    rng = np.random.default_rng(4)
+    for _ in range(5000):
+        max_size = 1 + int(rng.integers(0, 5))
+        a1 = O.NodeArrayProbe()
+        a1_size = max_size if rng.random() < 0.5 else 1 + int(rng.integers(0, max_size))
+        for i in range(a1_size):
+            a1.insert_sorted(i, float(np.float32(rng.random())))
+        a2 = O.NodeArrayProbe()
+        a2_size = max_size if rng.random() < 0.5 else 1 + int(rng.integers(0, max_size))
+        for i in range(a2_size):
+            if i < a1_size and rng.random() < 0.5:
+                j = int(rng.integers(0, a1_size))
+                if a1.nodes()[j] not in a2.nodes():
+                    a2.insert_sorted(a1.nodes()[j], a1.scores()[j])
+            else:
+                score = float(np.float32(rng.random())) if rng.random() < 0.5 else a1.scores()[int(rng.integers(0, a1_size))]
+                a2.insert_sorted(i + a1_size, score)
+        nodes, scores = a1.merge(a2)
+        assert max(len(a1.nodes()), len(a2.nodes())) <= len(nodes) <= len(a1.nodes()) + len(a2.nodes())
+        assert all(x >= y for x, y in zip(scores, scores[1:])) and len(set(nodes)) == len(nodes)
+        assert set(a1.nodes()) | set(a2.nodes()) == set(nodes)
+
+
 def check_engine_reproduces_the_reference_literals(J, ctx, dev, name):
     from jvector_amd.builder import GraphBuilder
     vsf, max_degree, vectors, steps = CASES[name]
