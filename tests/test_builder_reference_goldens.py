@@ -47,6 +47,18 @@ CASES = {
 }
 
 
+def test_rescore_literals_first_half():
+    """GraphIndexBuilderTest.testRescore (:82-104), the part before the rescore: three 2-d vectors, EUCLIDEAN, maxDegree 2 — node 0's list
+    is [1, 2] IN THAT ORDER with the scores 0.5 and 0.2 (the list carries its scores, sorted)"""
+    v, opq, codes = _quantizer([[0, 0], [0, 1], [2, 0]])
+    for hierarchy in (False, True):
+        b = O.OracleBuilder(opq, codes, v, O.EUCLIDEAN, 2, 10, alpha=1.0, neighbor_overflow=1.0, add_hierarchy=hierarchy)
+        for node in range(3):
+            b.add(node)
+        ids, sc, _ = b.row(0, 0)
+        assert ids.tolist() == [1, 2] and abs(sc[0] - 0.5) < 1e-6 and abs(sc[1] - 0.2) < 1e-6
+
+
 def _quantizer(vectors):
     v = np.asarray(vectors, np.float32)
     n, D = v.shape
