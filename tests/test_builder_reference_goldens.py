@@ -100,6 +100,44 @@ def test_node_array_literals():
     assert st.insert_sorted(7, 0.85) >= 0 and st.nodes() == [5, 0, 4, 3, 7, 1, 6, 7]       # another score: listed twice (NodeArray.java:212-228)
 
 
+def _circular(n):
+    """TestVectorGraph.CircularFloatVectorValues :735-761"""
+    return np.array([unit_vector_2d(i / n) for i in range(n)], np.float32)
+
+
+def _oracle_graph(b, n, max_degree):
+    info = b.info()
+    levels = [(None, b.rows(0, max_degree))]
+    for l in range(1, info["n_levels"]):
+        ids = np.array([i for i in range(n) if b.row(l, i) is not None], np.int32)
+        rows = np.full((ids.size, max_degree), -1, np.int32)
+        for r, i in enumerate(ids):
+            got = b.row(l, int(i))[0]
+            rows[r, :got.size] = got
+        levels.append((ids, rows))
+    return O.OracleGraph(n, levels, info["entry_node"], info["entry_level"])
+
+
+@pytest.mark.parametrize("hierarchy", [False, True])
+def test_aknn_diverse_and_accept_ords_properties(hierarchy):
+    """TestVectorGraph.testAknnDiverse (:322-347) and testSearchWithAcceptOrds (:355-382): 100 vectors on the unit circle, DOT_PRODUCT,
+    GraphIndexBuilder(M 20, beamWidth 100, overflow 1.0, alpha 1.4), built sequentially + cleanup(); the 10 results for (1, 0) must be
+    (nearly) the ten lowest ids — sum < 75 — also when only the even ids are accepted: 10 results, all accepted, sum < 170"""
+    n = 100
+    v, opq, codes = _quantizer(_circular(n))
+    b = O.OracleBuilder(opq, codes, v, O.DOT_PRODUCT, 20, 100, alpha=1.4, neighbor_overflow=1.0, add_hierarchy=hierarchy)
+    for i in range(n):
+        b.add(i)
+    b.cleanup()
+    g = _oracle_graph(b, n, 20)
+    q = np.array([[1.0, 0.0]], np.float32)
+    ids, _sc, _st = g.search(opq, codes, v, q, O.DOT_PRODUCT, 10, 10)
+    assert (ids[0] >= 0).sum() == 10 and int(ids[0].sum()) < 75, ids
+    accept = np.arange(n) % 2 == 0        # (the reference test draws a random acceptance set and bounds the sum by the accepted ids' own sum)
+    ids, _sc, _st = g.search(opq, codes, v, q, O.DOT_PRODUCT, 10, 10, accept=accept)
+    assert (ids[0] >= 0).sum() == 10 and accept[ids[0]].all() and int(ids[0].sum()) < 170, ids
+
+
 def _array(pairs):
     a = O.NodeArrayProbe()
     for node, score in pairs:
@@ -174,6 +212,44 @@ def check_engine_reproduces_the_reference_literals(J, ctx, dev, name):
         gb.close()
     finally:
         ctx.set_option("bl_ref_order", 0)
+
+
+def check_engine_aknn_diverse(J, ctx, dev):
+    """testAknnDiverse on the engine: built in reference order, one node per batch, finish() = cleanup()'s enforceDegree — the adjacency is
+    the oracle's, and the engine's own search over it returns the ten lowest ids"""
+    from jvector_amd.builder import GraphBuilder
+    n = 100
+    v, opq, codes = _quantizer(_circular(n))
+    pq = J.ProductQuantization.from_codebooks(ctx, 2, 1, v.reshape(-1).copy(), None, cluster_count=n)
+    tv = torch.from_numpy(v).to(dev)
+    vs = J.VectorSet(ctx, tv)
+    cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+    assert np.array_equal(np.asarray(cv.get(0, n)), codes)
+    VSF = J.VectorSimilarityFunction.DOT_PRODUCT
+    ob = O.OracleBuilder(opq, codes, v, O.DOT_PRODUCT, 20, 100, alpha=1.4, neighbor_overflow=1.0)
+    ctx.set_option("bl_ref_order", 1)
+    try:
+        gb = GraphBuilder(ctx, pq, cv, vs, VSF, 20, 100, 1.4, 1.0)
+        gb.seed(0)
+        ob.add(0)
+        for i in range(1, n):
+            gb.insert_batch(np.array([i], np.int32))
+            ob.add(i)
+        rows = gb.finish(torch.empty((n, 20), dtype=torch.int32, device=dev)).cpu().numpy().copy()
+        gb.close()
+    finally:
+        ctx.set_option("bl_ref_order", 0)
+    ob.cleanup()
+    assert np.array_equal(rows, ob.rows(0, 20))
+    graph = J.GraphIndex(ctx, n, [(None, rows)], 0, 0)
+    ids, _ = J.GraphSearcher(ctx, graph, pq, cv, None, vs, max_queries=4).search(np.array([[1.0, 0.0]], np.float32), VSF, 10, 10)
+    ids = np.asarray(ids)[0]
+    assert (ids >= 0).sum() == 10 and int(ids.sum()) < 75, ids
+
+
+@pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")
+def test_engine_aknn_diverse_on_the_mock():
+    _on_the_mock(lambda J, ctx: check_engine_aknn_diverse(J, ctx, torch.device("cpu")))
 
 
 @pytest.mark.skipif(platform.machine() != "x86_64", reason="the mock build needs the x86-64 lane emulator")

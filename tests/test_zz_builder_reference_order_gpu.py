@@ -101,3 +101,10 @@ def test_engine_reproduces_the_reference_literals(ctx, name):
     ctx.reset_stats()
     check_engine_reproduces_the_reference_literals(J, ctx, torch.device("cuda", 0), name)
     assert ctx.stat("gs_calls_host") == 0
+
+
+def test_engine_aknn_diverse(ctx):
+    """TestVectorGraph.testAknnDiverse (:322-347) on the device: built in reference order (== the oracle's adjacency), searched by the engine"""
+    import jvector_amd as J
+    from test_builder_reference_goldens import check_engine_aknn_diverse
+    check_engine_aknn_diverse(J, ctx, torch.device("cuda", 0))
