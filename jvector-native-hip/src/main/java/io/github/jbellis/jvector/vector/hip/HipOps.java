@@ -133,6 +133,7 @@ public final class HipOps {
         static final MethodHandle builderFinish = h("jv_hip_builder_finish", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle builderStats = h("jv_hip_builder_stats", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle builderNeighborsDevice = h("jv_hip_builder_neighbors_device", FunctionDescriptor.of(ADDRESS, ADDRESS, ADDRESS));
+        static final MethodHandle builderWorkingLists = h("jv_hip_builder_working_lists", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
         static final MethodHandle builderDestroy = h("jv_hip_builder_destroy", FunctionDescriptor.of(JAVA_INT, ADDRESS));
         static final MethodHandle buildLayered = h("jv_hip_build_layered", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, JAVA_INT, JAVA_INT, JAVA_INT, JAVA_FLOAT, JAVA_FLOAT, JAVA_INT, JAVA_INT, JAVA_LONG, JAVA_INT, ADDRESS));
         static final MethodHandle layeredInfo = h("jv_hip_layered_info", FunctionDescriptor.of(JAVA_INT, ADDRESS, ADDRESS, ADDRESS, ADDRESS, ADDRESS));
@@ -447,6 +448,13 @@ public final class HipOps {
     }
     public static MemorySegment builderNeighborsDevice(MemorySegment builder, MemorySegment rowWidthOutOrNull) {
         try { return (MemorySegment) H.builderNeighborsDevice.invokeExact(builder, rowWidthOutOrNull); } catch (Throwable t) { throw new AssertionError(t); }
+    }
+    /** the lists as they stand: idsOut int32[n x rowWidth] (-1 padded); with ctxSetOption("bl_ref_order", 1) before builderCreate also
+     *  scoresOut float[n x rowWidth] (the score every entry was inserted under, NodeArray order) and diverseBeforeOut int32[n] —
+     *  ConcurrentNeighborMap.Neighbors' state, for a comparison against OnHeapGraphIndex.getNeighbors of a one-thread GraphIndexBuilder */
+    public static void builderWorkingLists(MemorySegment ctx, MemorySegment builder, MemorySegment idsOut, MemorySegment scoresOutOrNull,
+                                           MemorySegment diverseBeforeOutOrNull) {
+        check(st(() -> (int) H.builderWorkingLists.invokeExact(ctx, builder, idsOut, scoresOutOrNull, diverseBeforeOutOrNull)));
     }
     public static void builderDestroy(MemorySegment builder) { check(st(() -> (int) H.builderDestroy.invokeExact(builder))); }
     /** GraphIndexBuilder with addHierarchy in one call: seeded level draws, one Vamana graph per level, improveConnections passes, enforceDegree; outHandle receives the jv_layered */
