@@ -21,6 +21,7 @@
 //                                             result lands (whenever) at lds + 4 * lane and is never read — no register waits for it
 //     gs_fence()                              device-scope memory fence
 //     gs_sqrt(double)
+//     gs_rsq_approx(float)                    1 / sqrt(x) to a few ulps (v_rsq_f32); only ever used with a margin around it
 //     GS_SCHED_FENCE()                        instruction-scheduling fence (may be empty)
 // and, for the workgroup form (WGX, gx_body.h — several wavefronts per query; gs_barrier() is then a WAVE-scope sync point):
 //     gs_tid()                                thread index inside the workgroup
@@ -356,6 +357,30 @@ GS_FN float gs_lut_entry_pk(const gs_f4 c0, const gs_f4 c1, const float *q)
     return gs_lut_entry_from<VSF>(c0, c1, q);
 }
 
+// the same with the query's sub-vector already in registers (q0, q1): callers that batch their LDS reads (UBR's scoring loop)
+template <int VSF>
+GS_FN float gs_lut_entry_pk_q(const gs_f4 c0, const gs_f4 c1, const gs_f4 q0, const gs_f4 q1)
+{
+#ifdef GS_HAVE_PK_F32
+    if (VSF != 0) {
+        const gs_pk2 p01 = gs_pk2{c0.x, c0.y} * gs_pk2{q0.x, q0.y}, p23 = gs_pk2{c0.z, c0.w} * gs_pk2{q0.z, q0.w};
+        const gs_pk2 p45 = gs_pk2{c1.x, c1.y} * gs_pk2{q1.x, q1.y}, p67 = gs_pk2{c1.z, c1.w} * gs_pk2{q1.z, q1.w};
+        float ent = 0.0f;
+        ent += p01.x;
+        ent += p01.y;
+        ent += p23.x;
+        ent += p23.y;
+        ent += p45.x;
+        ent += p45.y;
+        ent += p67.x;
+        ent += p67.y;
+        return ent;
+    }
+#endif
+    const float q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    return gs_lut_entry_from<VSF>(c0, c1, q);
+}
+
 template <int VSF, int CH16>
 GS_FN void gs_lut_build(const float *codebooks, const float *qs, float (&lut)[(CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB) * 4],
                         float *lut_lds)
@@ -681,6 +706,23 @@ GS_FN float gs_finish(float sum, float node_mag, float query_mag)
     return (1.0f + sum) / 2.0f;
 }
 
+// UBR's drop test: is gs_finish(bound_raw, ...) CERTAINLY below the pop threshold T?  For the dot product that is the finish itself.
+// For cosine the finish divides by a double-precision square root (45 f64 instructions executed by all 64 lanes per expansion);
+// the test needs no such care — a neighbour wrongly KEPT is only scored exactly, never lost: x = raw * rsq(|a||b|) in f32 (a few
+// ulps off the real quotient, < 1e-6 relative) against 2 T - 1 with a margin of 1e-5 (1 + |x|), twenty times those errors and the
+// finish's own three roundings together; a product that is not a positive finite number keeps the neighbour.  The bound moves by
+// 1e-5 of a score: the drop rate does not (tests/test_zz_ubr_gpu.py counts it).
+template <int VSF>
+GS_FN bool gs_bound_below(float bound_raw, float node_mag, float query_mag, float T)
+{
+    if (VSF != 2) return gs_finish<VSF>(bound_raw, node_mag, query_mag) < T;
+    const float prod = node_mag * query_mag;
+    if (!(prod > 0.0f) || !(prod < 3.0e38f)) return false;
+    const float x = bound_raw * gs_rsq_approx(prod);
+    const float ax = x < 0.0f ? -x : x;
+    return x + 1e-5f * (1.0f + ax) < 2.0f * T - 1.0f;
+}
+
 // visited.add: true iff the node was not in the set.  Linear probing; callers keep the load <= 1/2.
 GS_FN bool gs_visit(int32_t *tab, uint32_t mask, int shift, int32_t node)
 {
@@ -890,7 +932,7 @@ GS_FN void gs_push(GsState &s, const GsParams &p, long long key, bool has)
 // keys are strictly greater: its score becomes T, and every candidate whose SCORE is below T can never be popped (rk nodes with a
 // strictly higher score are popped or kept first, then stopSearch — a comparison of scores — ends the layer), so it is discarded.  Keys of the spill tier (all below every LDS key)
 // are not counted: the count can only be too small.  Wave-uniform; leaves T alone when no sample qualifies.
-GS_FN void gs_ubr_trim(GsState &s, int rk, float &T)
+GS_FN void gs_ubr_trim_lds(GsState &s, int rk, float &T)
 {
     const int lane = gs_lane();
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -941,6 +983,75 @@ GS_FN void gs_ubr_trim(GsState &s, int rk, float &T)
         new_n += gs_popc(mk);
         gs_barrier();
     }
+    s.cand_n = new_n;
+    T = ps;
+}
+
+// Round 6: the same trim with the keys held in REGISTERS.  The LDS form above re-read the candidate tier and the result queue for
+// every step of the bisection (7 steps x 4-6 passes of ds_read + compare + ballot, each waited for in turn) and found the sample
+// ranks through 64 broadcast reads: 8.7 k clocks per trim, 1.2 k per expansion of the headline.  Here every lane loads its <= 4
+// candidate keys and <= 2 result keys ONCE, the sample ranks come from 64 v_readlane pairs, a bisection step is six compares +
+// s_bcnt1, and the compaction writes straight from the registers.  Same pivot, same survivors, same T as gs_ubr_trim_lds (the
+// emulator test runs both); tiers of more than 256 keys / result queues of more than 128 take the LDS form.
+GS_FN void gs_ubr_trim(GsState &s, int rk, float &T)
+{
+    const int n = s.cand_n;
+    if (n > 256 || s.res_n > 128) {
+        gs_ubr_trim_lds(s, rk, T);
+        return;
+    }
+    const int lane = gs_lane();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    long long ck[4], rr[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ck[u] = lane + 64 * u < n ? s.cand[lane + 64 * u] : GS_KEY_MIN;   // (GS_KEY_MIN is above no pivot)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) rr[u] = lane + 64 * u < s.res_n ? s.res[lane + 64 * u] : GS_KEY_MIN;
+    // (a key's high word is never 0x80000000 — gs_key canonicalises NaN — so these sentinels are unique and below every real key)
+    const long long mine = n >= 64 ? s.cand[(int)(((long long)lane * n) >> 6)] : (lane < n ? ck[0] : GS_KEY_MIN + 1 + lane);
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) rank += (gs_shfl(mine, j) < mine) ? 1 : 0;   // keys are unique: the ranks are 0..63, each once
+    auto above = [&](long long pv) -> int {
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += gs_popc(gs_ballot(ck[u] > pv));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) c += gs_popc(gs_ballot(rr[u] > pv));
+        return c;
+    };
+    auto sample = [&](int r) -> long long { return gs_shfl(mine, gs_first(gs_ballot(rank == r))); };
+    long long pv = sample(0);
+    if (above(pv) < rk) {
+        gs_barrier();
+        return;
+    }
+    int lo = 0, hi = 63;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const long long pm = sample(mid);
+        if (above(pm) >= rk) {
+            lo = mid;
+            pv = pm;
+        } else {
+            hi = mid - 1;
+        }
+    }
+    const float ps = gs_key_score(pv);
+    if (!(ps >= 0.0f) || !(ps > T)) {   // (a sentinel decodes to NaN; a negative score never becomes a result: no threshold from it)
+        gs_barrier();
+        return;
+    }
+    int new_n = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        // (by SCORE, not by key: stopSearch compares scores, so a candidate that ties with the threshold may still be popped)
+        const bool keep = lane + 64 * u < n && (int32_t)(ck[u] >> 32) >= (int32_t)(pv >> 32);
+        const uint64_t mk = gs_ballot(keep);
+        if (keep) s.cand[new_n + gs_popc(mk & lt)] = ck[u];   // (every key was read into registers before the first write)
+        new_n += gs_popc(mk);
+    }
+    gs_barrier();
     s.cand_n = new_n;
     T = ps;
 }
@@ -1348,6 +1459,37 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 else if (VSF == 2 && p.blocks && lane == row_lines + blk_lines) addr = reinterpret_cast<const char *>(p.fused_norms + (int64_t)rn * p.deg0);
                 if (addr) gs_prefetch_lds(addr, reinterpret_cast<char *>(s.evicted) + 64);
             }
+            // ---- round 6: the popped node's adjacency row, FusedPQ block and magnitudes are REQUESTED here, before the result queue is
+            //      touched — the HBM round trip at the head of the expansion's dependent chain (~900 clocks unloaded, more under load)
+            //      runs while addTopCandidate, the rescan of the result minimum and (UBR) the trim of the candidate tier work in LDS.
+            //      Pair-lane forms at level 0 (the row is found without a map look-up); nothing is consumed before the expansion
+            //      below, and a search that stops or skips the expansion simply drops the registers.
+            int32_t pre_nb = -1;
+            gs_u2 pre_w[PAIR ? (CH16 > 0 ? CH16 : 1) : 1];
+            float pre_mag = 0.0f;
+            bool pre_loaded = false;
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int c = 0; c < CH16; ++c) pre_w[c] = gs_u2{0u, 0u};
+                if (lvl == 0 && !L.hkeys) {
+                    const int32_t pn = gs_key_node(top);
+                    if (pn >= 0 && pn < L.count) {
+                        const int pni = lane & 31;
+                        const bool phi = lane >= 32;
+                        if (pni < L.degree) pre_nb = (L.nbrs + (int64_t)pn * L.degree)[pni];
+                        if (p.blocks != nullptr && pni < L.degree) {
+                            const int64_t r = (int64_t)pn * p.deg0 + pni;
+                            gs_load_half<CH16>(p.blocks + r * p.M + (phi ? p.M / 2 : 0), pre_w);
+                            if (VSF == 2 && !phi) pre_mag = p.fused_norms[r];
+                        }
+                        pre_loaded = true;
+                    }
+                }
+            }
+            (void)pre_nb;
+            (void)pre_w;
+            (void)pre_mag;
+            (void)pre_loaded;
             GS_PHASE(0);
             // threshold 0.0f: `topCandidateScore >= threshold` (:437) keeps negative / NaN scores out of the results (the
             // node is expanded all the same); then addTopCandidate :515-530 (BoundedLongHeap.push / updateTop)
@@ -1387,6 +1529,27 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             } else {
                 gs_barrier();
             }
+            if constexpr (UBR) {
+                // ---- the pop threshold: the worst kept result once the result queue is full; every ubr_trim pushes the candidate
+                //      tier is searched for a higher one and loses what it rules out (gs_ubr_trim).  Round 6: here, between the
+                //      request for the popped node's row + block and their first use, instead of behind the push — the trim works in
+                //      LDS while the HBM round trip runs.  (The popped key already sits in the result queue or was turned away: the
+                //      trim's count of known better nodes can only be smaller than behind the push — still a proof.) ----
+                if (ub_on && lvl == 0 && s.status == GS_OK) {
+                    if (s.res_n >= rk) {
+                        const float t = gs_key_score(s.res_min);
+                        if (t > ub_T) ub_T = t;
+                    }
+                    // (also before the LDS tier would have to spill: a partition costs more than a trim and frees less)
+                    if ((ubr_since >= p.ubr_trim || s.cand_n + 40 > p.cand_cap) && s.cand_n > 0 && s.cand_n + s.res_n >= rk) {
+                        unsigned long long tc0 = 0;
+                        if (PROF) tc0 = GS_CLOCK();
+                        gs_ubr_trim(s, rk, ub_T);
+                        ubr_since = 0;
+                        if (PROF) fh[2] += GS_CLOCK() - tc0;
+                    }
+                }
+            }
             if constexpr (SES) {
                 // "skip edge loading if we've found a local maximum and we have enough results" (:441-444)
                 if (trk_should_stop() && (long long)s.cand_n + s.spill_n >= (long long)rk - s.res_n) continue;
@@ -1408,17 +1571,25 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 const int ni = lane & 31;
                 const bool hi = lane >= 32;
                 const int m_base = hi ? p.M / 2 : 0;
-                const int32_t nb = ni < deg ? row[ni] : -1;
+                int32_t nb;
                 gs_u2 w[CH16];
-                if constexpr (UBR) {   // every lane takes part in the bound's cross-lane reads: no uninitialised code words
-#pragma unroll
-                    for (int c = 0; c < CH16; ++c) w[c] = gs_u2{0u, 0u};
-                }
                 float node_mag = 0.0f;
-                if (fused0 && ni < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
-                    const int64_t r = (int64_t)node * p.deg0 + ni;
-                    gs_load_half<CH16>(p.blocks + r * p.M + m_base, w);
-                    if (VSF == 2 && !hi) node_mag = p.fused_norms[r];
+                if (pre_loaded) {   // (requested right after the pop, see above; uniform)
+                    nb = pre_nb;
+#pragma unroll
+                    for (int c = 0; c < CH16; ++c) w[c] = pre_w[c];
+                    node_mag = pre_mag;
+                } else {
+                    nb = ni < deg ? row[ni] : -1;
+                    if constexpr (UBR) {   // every lane takes part in the bound's cross-lane reads: no uninitialised code words
+#pragma unroll
+                        for (int c = 0; c < CH16; ++c) w[c] = gs_u2{0u, 0u};
+                    }
+                    if (fused0 && ni < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
+                        const int64_t r = (int64_t)node * p.deg0 + ni;
+                        gs_load_half<CH16>(p.blocks + r * p.M + m_base, w);
+                        if (VSF == 2 && !hi) node_mag = p.fused_norms[r];
+                    }
                 }
                 const int first_neg = gs_first(gs_ballot(!hi && nb < 0));  // rows are packed: the first -1 ends the row
                 const bool valid = ni < first_neg;
@@ -1447,7 +1618,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                         const int32_t part = gs_ubr_half<CH16>(ubtab, w, hi ? 1 : 0);   // all 64 lanes
                         const int32_t other = gs_shfl32(part, lane ^ 32);
                         bool drop = false;
-                        if (fresh) drop = gs_finish<VSF>(ubr_base + ubr_scale * (float)(part + other), node_mag, query_mag) < ub_T;
+                        if (fresh) drop = gs_bound_below<VSF>(ubr_base + ubr_scale * (float)(part + other), node_mag, query_mag, ub_T);
                         const uint64_t dm = gs_ballot(drop);
                         sm = fm & ~dm;
                         ub_dropped += (unsigned long long)gs_popc(dm);
@@ -1512,10 +1683,28 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                                     c0[kk] = cp[0];
                                     c1[kk] = cp[1];
                                 }
+                                // (round 6) the query's sub-vectors of the half are read from LDS in ONE batch behind the codebook requests:
+                                // left to itself the compiler — at its 255-register limit — read them entry by entry and waited for
+                                // each pair in turn, a full LDS latency per entry
+                                // each pair in turn, a full LDS latency per entry.  (Three entries' worth at a time: all six of the half
+                                // at once cost 34 spilled table registers, reloaded in front of every bound phase.)
+                                constexpr int QB = SUBS / 4;
 #pragma unroll
-                                for (int kk = 0; kk < SUBS / 2; ++kk) {
-                                    const int k = h2 * (SUBS / 2) + kk;
-                                    v[k] = gs_lut_entry_pk<VSF>(c0[kk], c1[kk], qs + (t * SUBS + k) * 8);
+                                for (int b3 = 0; b3 < 2; ++b3) {
+                                    gs_f4 q0[QB], q1[QB];
+#pragma unroll
+                                    for (int kk = 0; kk < QB; ++kk) {
+                                        const gs_f4 *qp = reinterpret_cast<const gs_f4 *>(qs + (t * SUBS + h2 * (SUBS / 2) + b3 * QB + kk) * 8);
+                                        q0[kk] = qp[0];
+                                        q1[kk] = qp[1];
+                                    }
+                                    GS_SCHED_FENCE();
+#pragma unroll
+                                    for (int kk = 0; kk < QB; ++kk) {
+                                        const int k = h2 * (SUBS / 2) + b3 * QB + kk;
+                                        v[k] = gs_lut_entry_pk_q<VSF>(c0[b3 * QB + kk], c1[b3 * QB + kk], q0[kk], q1[kk]);
+                                    }
+                                    GS_SCHED_FENCE();
                                 }
                             }
                             if (t == 0) {
@@ -1530,14 +1719,25 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                         fresh = work && t == 0;
                         key = 0;
                         if (fresh) {   // the owner: its own subspaces are summed; now the other seven lanes' in ascending m
+                            // (round 6) all of the column's 16-byte words are requested before the first is added: the compiler had
+                            // issued four and then one at a time, each waited for — 17 exposed LDS latencies in front of the finish
                             const gs_f4 *col = reinterpret_cast<const gs_f4 *>(xf + g * (7 * SUBS));
+                            constexpr int EB = 7;   // words per batch (28 registers)
+                            static_assert((7 * SUBS / 4) % EB == 0, "the owner's column is read in whole batches");
 #pragma unroll
-                            for (int i = 0; i < 7 * SUBS / 4; ++i) {
-                                const gs_f4 e4 = col[i];
-                                sum += e4.x;
-                                sum += e4.y;
-                                sum += e4.z;
-                                sum += e4.w;
+                            for (int b7 = 0; b7 < 7 * SUBS / 4 / EB; ++b7) {
+                                gs_f4 e4[EB];
+#pragma unroll
+                                for (int i = 0; i < EB; ++i) e4[i] = col[b7 * EB + i];
+                                GS_SCHED_FENCE();
+#pragma unroll
+                                for (int i = 0; i < EB; ++i) {
+                                    sum += e4[i].x;
+                                    sum += e4[i].y;
+                                    sum += e4[i].z;
+                                    sum += e4[i].w;
+                                }
+                                GS_SCHED_FENCE();
                             }
                             const float sc = gs_finish<VSF>(sum, st_mag[j], query_mag);
                             key = gs_key(st_nb[j], sc);
@@ -1696,7 +1896,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                             const int32_t part = gs_ubr_half<CH16>(ubtab, w, hi ? 1 : 0);   // all 64 lanes
                             const int32_t other = gs_shfl32(part, lane ^ 32);
                             bool drop = false;
-                            if (lowf) drop = gs_finish<VSF>(ubr_base + ubr_scale * (float)(part + other), node_mag, query_mag) < ub_T;
+                            if (lowf) drop = gs_bound_below<VSF>(ubr_base + ubr_scale * (float)(part + other), node_mag, query_mag, ub_T);
                             const uint64_t dm = gs_ballot(drop);
                             sm = fmp & ~dm;
                             ub_dropped += (unsigned long long)gs_popc(dm);
@@ -1895,24 +2095,6 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 if (ub_on && gs_ballot(fresh && (int32_t)(key >> 32) == 0x7fc00000)) ub_on = false;
             }
             gs_push(s, p, key, fresh);
-            if constexpr (UBR) {
-                // ---- the pop threshold: the worst kept result once the result queue is full; every ubr_trim pushes the candidate
-                //      tier is searched for a higher one and loses what it rules out (gs_ubr_trim) ----
-                if (ub_on && lvl == 0 && s.status == GS_OK) {
-                    if (s.res_n >= rk) {
-                        const float t = gs_key_score(s.res_min);
-                        if (t > ub_T) ub_T = t;
-                    }
-                    // (also before the LDS tier would have to spill: a partition costs more than a trim and frees less)
-                    if ((ubr_since >= p.ubr_trim || s.cand_n + 40 > p.cand_cap) && s.cand_n > 0 && s.cand_n + s.res_n >= rk) {
-                        unsigned long long tc0 = 0;
-                        if (PROF) tc0 = GS_CLOCK();
-                        gs_ubr_trim(s, rk, ub_T);
-                        ubr_since = 0;
-                        if (PROF) fh[2] += GS_CLOCK() - tc0;
-                    }
-                }
-            }
             if constexpr (UB8) {
                 // ---- the pop threshold: the worst kept result once the result queue is full; the partition pivot once the LDS
                 //      tier (every key above it) plus the results above it number rerankK ----

@@ -144,6 +144,7 @@ __device__ __forceinline__ void gs_fetch_add64(unsigned long long *p, unsigned l
 #define GS_CLOCK() ((unsigned long long)__builtin_readcyclecounter())
 __device__ __forceinline__ void gs_fence() { __threadfence(); }
 __device__ __forceinline__ double gs_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float gs_rsq_approx(float x) { return __builtin_amdgcn_rsqf(x); }
 // ed_body.h: f32-input MFMA (bitwise a k-ordered fmaf chain; A: lane l holds A[l & 31][l >> 5], B: B[l >> 5][l & 31]) and fmaf
 typedef float gs_f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ gs_f32x16 gs_mfma_32x32x2(float a, float b, gs_f32x16 c)

@@ -68,6 +68,7 @@ static inline uint32_t gs_fetch_add(uint32_t *p, uint32_t v)
 static inline void gs_fetch_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 static inline void gs_fence() {}
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
+static inline float gs_rsq_approx(float x) { return 1.0f / std::sqrt(x); }
 
 #include "../../jvector_amd/csrc/gs_body.h"
 #include "../../jvector_amd/csrc/gx_body.h"

@@ -74,6 +74,7 @@ static inline void gs_fetch_add64(unsigned long long *p, unsigned long long v) {
 static inline void gs_fence() {}
 static inline void gs_gather64(float v, float (&out)[64]) { emu::gather64(v, out); }
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
+static inline float gs_rsq_approx(float x) { return 1.0f / std::sqrt(x); }
 static inline double bs_sqrt(double x) { return std::sqrt(x); }
 static inline float gs_fmaf(float a, float b, float c) { return fmaf(a, b, c); }
 typedef emu::f32x16 gs_f32x16;
