@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjvector_hip.so")
+# (JVECTOR_HIP_LIBRARY: developer aid — an A/B build of the same C ABI, scripts/build_variant.sh)
+LIB_PATH = os.environ.get("JVECTOR_HIP_LIBRARY") or os.path.join(_HERE, "libjvector_hip.so")
 
 JV_OK, JV_ERR_INVALID, JV_ERR_NO_DEVICE, JV_ERR_HIP, JV_ERR_OOM, JV_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 

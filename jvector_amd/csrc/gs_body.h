@@ -1395,6 +1395,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     if (PROF) px[0] = GS_CLOCK() - pq0;
     for (int lvl = p.entry_level; lvl >= 0 && s.status == GS_OK; --lvl) {
         int rk = lvl > 0 ? 1 : p.rerankK;
+        // (Round 6, measured and not kept: the descriptor copied into registers of its own behind an optimisation barrier removes 14 of
+        // the loop's 16 kernel-argument re-reads — and costs 188 bytes of scratch, 40 table registers reloaded in front of every
+        // bound phase: 59.2 vs 50.0 ms, profiles/r6_c.)
         const GsLevel &L = p.lv[lvl];
         int phase = 0;
         if (SES && lvl == 0 && p.n_phases > 1) {

@@ -180,16 +180,16 @@ __global__ __launch_bounds__(64) void exact_gather_kernel(const float *__restric
 // Cosine: norm2 = sum of e2*e2 (DefaultVectorUtilSupport.cosine :131-137) is query independent and a separate
 // accumulator, so it is read from a per-row table built once by row_sqnorm_kernel in the same order (same bits).
 // ------------------------------------------------------------------------------------------------
-constexpr int TR_CH = 64;          // floats of a row per chunk
+constexpr int TR_CH = 64;          // floats of a row per chunk (the norm-table kernel and the default rerank shape)
 constexpr int TR_LS = TR_CH + 4;   // LDS row stride (dwords)
 
 // chain over one chunk of `len` floats (multiple of 8) of the lane's row in LDS against the uniform query slice a[]
-template <int VSF>
+template <int VSF, int CH>
 __device__ __forceinline__ void tr_chunk(const float *__restrict__ row, const float *__restrict__ a, int len, float &acc)
 {
-    if (len == TR_CH) {
+    if (len == CH) {
 #pragma unroll
-        for (int i = 0; i < TR_CH; i += 8) {
+        for (int i = 0; i < CH; i += 8) {
             const float4 v0 = *reinterpret_cast<const float4 *>(row + i);
             const float4 v1 = *reinterpret_cast<const float4 *>(row + i + 4);
             if (VSF == VSF_DOT) acc += dot8(a + i, v0, v1);
@@ -217,51 +217,56 @@ __device__ __forceinline__ void tr_chunk(const float *__restrict__ row, const fl
     }
 }
 
-// SQ = true: acc = sum of e*e over the row (no query) — builds the cosine norm table
-template <int VSF, bool SQ>
+// SQ = true: acc = sum of e*e over the row (no query) — builds the cosine norm table.
+// R rows per wavefront (lanes >= R carry none), CH floats of a row per chunk, R x CH = 4096: sixteen 1 KB load instructions per
+// chunk in every shape — 64 x 64 (four rows x 256 B per instruction), 32 x 128 (two rows x 512 B), 16 x 256 (one row x 1 KB): the
+// longer a row's contiguous piece, the fewer DRAM pages a gathered row opens.  LDS row stride CH + 4 dwords: conflict-free b128 reads.
+template <int VSF, bool SQ, int R = 64, int CH = TR_CH>
 __device__ __forceinline__ float tr_rows(const float *__restrict__ vecs, int D, int64_t my_row /* -1 = none */,
                                          const float *__restrict__ a, float *tile)
 {
+    static_assert(R * CH == 4096 && (CH == 64 || CH == 128 || CH == 256), "sixteen 1 KB load instructions per chunk");
+    constexpr int LS = CH + 4, LPR = CH / 4, RPI = 64 / LPR;   // lanes per row piece, rows per load instruction
     const int lane = threadIdx.x;
-    const int seg = (lane & 15) * 4;   // this lane's 16 bytes inside a row's 256-byte chunk
-    const int sub = lane >> 4;         // load instruction k fetches rows 4k + sub
+    const int seg = (lane % LPR) * 4;   // this lane's 16 bytes inside a row's chunk
+    const int sub = lane / LPR;         // load instruction k fetches rows RPI k + sub
     const float *rp[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const int64_t ro = __shfl(my_row, 4 * k + sub, 64);
+        const int64_t ro = __shfl(my_row, RPI * k + sub, 64);
         rp[k] = ro >= 0 ? vecs + ro * D + seg : nullptr;
     }
-    const int nc = (D + TR_CH - 1) / TR_CH;
+    const int nc = (D + CH - 1) / CH;
     float4 r[16];
     auto issue = [&](int c) {
-        const bool in = c * TR_CH + seg < D;
+        const bool in = c * CH + seg < D;
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            r[k] = (rp[k] && in) ? *reinterpret_cast<const float4 *>(rp[k] + c * TR_CH) : make_float4(0.f, 0.f, 0.f, 0.f);
+            r[k] = (rp[k] && in) ? *reinterpret_cast<const float4 *>(rp[k] + c * CH) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     issue(0);
     float acc = 0.0f;
     for (int c = 0; c < nc; ++c) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) *reinterpret_cast<float4 *>(tile + (4 * k + sub) * TR_LS + seg) = r[k];
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<float4 *>(tile + (RPI * k + sub) * LS + seg) = r[k];
         __syncthreads();
         if (c + 1 < nc) issue(c + 1);
-        const int len = (D - c * TR_CH < TR_CH) ? (D - c * TR_CH) : TR_CH;
-        const float *row = tile + lane * TR_LS;
+        const int len = (D - c * CH < CH) ? (D - c * CH) : CH;
+        const float *row = tile + (lane % R) * LS;
         if (SQ) {
             for (int i = 0; i < len; i += 4) {
                 const float4 v = *reinterpret_cast<const float4 *>(row + i);
                 acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
             }
-        } else {
-            tr_chunk<VSF>(row, a + c * TR_CH, len, acc);
+        } else if (lane < R) {
+            tr_chunk<VSF, CH>(row, a + c * CH, len, acc);
         }
         __syncthreads();
     }
     return acc;
 }
 
-template <int VSF>
+template <int VSF, int R, int CH>
 __global__ __launch_bounds__(64) void exact_gather_tr_kernel(const float *__restrict__ vecs, int64_t n, int D,
                                                              const float *__restrict__ queries,
                                                              const float *__restrict__ qnorm,
@@ -269,16 +274,17 @@ __global__ __launch_bounds__(64) void exact_gather_tr_kernel(const float *__rest
                                                              const int32_t *__restrict__ ord, int B,
                                                              float *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) float tile[64 * TR_LS];
+    __shared__ __attribute__((aligned(16))) float tile[R * (CH + 4)];
     const int q = blockIdx.x;
-    const int j = blockIdx.y * 64 + threadIdx.x;
+    const bool mine = (int)threadIdx.x < R;
+    const int j = blockIdx.y * R + threadIdx.x;
     int64_t o = -1;
-    if (j < B) {
+    if (mine && j < B) {
         o = ord[(int64_t)q * B + j];
         if (o >= n) o = -1;
     }
-    const float raw0 = tr_rows<VSF, false>(vecs, D, o, queries + (int64_t)q * D, tile);
-    if (j >= B) return;
+    const float raw0 = tr_rows<VSF, false, R, CH>(vecs, D, o, queries + (int64_t)q * D, tile);
+    if (!mine || j >= B) return;
     float *dst = out + (int64_t)q * B + j;
     if (o < 0) {
         *dst = -INFINITY;
@@ -309,6 +315,8 @@ __global__ void row_sqnorm_kernel(const float *__restrict__ vecs, int64_t n, int
     out[i] = s;
 }
 
+constexpr int kExactTrShapeDefault = 0;
+
 bool exact_tr_supported(const float *d_vecs, int D) { return D % 8 == 0 && D >= 8 && (reinterpret_cast<uintptr_t>(d_vecs) & 15) == 0; }
 
 int launch_row_sqnorms(hipStream_t s, const float *d_vecs, int64_t n, int D, float *d_out)
@@ -334,17 +342,24 @@ int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, co
     dim3 grid(Q, (B + 63) / 64), block(64);
     if (exact_tr_supported(d_vecs, D) && (reinterpret_cast<uintptr_t>(d_q) & 15) == 0 && (vsf != VSF_COS || d_vnorm) &&
         !getenv("JVECTOR_HIP_EXACT_LANE_ROWS")) {
+        // rows per wavefront x floats per chunk (see tr_rows); JVECTOR_HIP_EXACT_TR_SHAPE = 0 / 1 / 2 pins 64 x 64 / 32 x 128 / 16 x 256
+        const int shape_env = getenv("JVECTOR_HIP_EXACT_TR_SHAPE") ? atoi(getenv("JVECTOR_HIP_EXACT_TR_SHAPE")) : -1;
+        const int shape = shape_env >= 0 ? shape_env : kExactTrShapeDefault;
+#define JV_TR_LAUNCH(VSFV, R, CH) \
+    hipLaunchKernelGGL((exact_gather_tr_kernel<VSFV, R, CH>), dim3(Q, (B + R - 1) / R), block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out)
+#define JV_TR_SHAPES(VSFV)                          \
+    do {                                            \
+        if (shape == 1) JV_TR_LAUNCH(VSFV, 32, 128); \
+        else if (shape == 2) JV_TR_LAUNCH(VSFV, 16, 256); \
+        else JV_TR_LAUNCH(VSFV, 64, 64);            \
+    } while (0)
         switch (vsf) {
-        case VSF_L2:
-            hipLaunchKernelGGL(exact_gather_tr_kernel<VSF_L2>, grid, block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out);
-            break;
-        case VSF_DOT:
-            hipLaunchKernelGGL(exact_gather_tr_kernel<VSF_DOT>, grid, block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out);
-            break;
-        default:
-            hipLaunchKernelGGL(exact_gather_tr_kernel<VSF_COS>, grid, block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out);
-            break;
+        case VSF_L2: JV_TR_SHAPES(VSF_L2); break;
+        case VSF_DOT: JV_TR_SHAPES(VSF_DOT); break;
+        default: JV_TR_SHAPES(VSF_COS); break;
         }
+#undef JV_TR_SHAPES
+#undef JV_TR_LAUNCH
         JV_HIP_CHECK(hipGetLastError());
         return JV_OK;
     }

@@ -50,6 +50,22 @@ __device__ __forceinline__ int32_t ubr_sortable(float f)
 }
 __device__ __forceinline__ float ubr_unsortable(int32_t s) { return __builtin_bit_cast(float, s ^ ((s >> 31) & 0x7fffffff)); }
 
+// min of a and max of b over the wave, the two DPP chains interleaved (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, row_bcast15 /
+// row_bcast31 across them): lane 63 ends up with both results.  A DPP operand must not be read within two wait states of the VALU
+// write that produced it: the partner chain's instruction is one, an s_nop the other.  All 64 lanes must be active.
+__device__ __forceinline__ void ubr_wave_minmax(float &a, float &b)
+{
+#define JV_MM_STEP(CTRL)                                      \
+    "v_min_f32_dpp %0, %0, %0 " CTRL "\n"                     \
+    "v_max_f32_dpp %1, %1, %1 " CTRL "\n"                     \
+    "s_nop 0\n"
+    asm volatile("s_nop 1\n" JV_MM_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") JV_MM_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     JV_MM_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") JV_MM_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                         JV_MM_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") JV_MM_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(a), "+v"(b));
+#undef JV_MM_STEP
+}
+
 template <int VSF>
 __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict__ codebooks, const float *__restrict__ cq, int Q, int M,
                                                         uint32_t *__restrict__ tab, float *__restrict__ meta)
@@ -74,6 +90,19 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
     __syncthreads();
     const int H = M / 2, per_wave = H / 4;
     // ---- pass 1: lo / hi of every (query, subspace) ----
+    // Round 6: 170 -> ~95 instructions per (query, subspace).  The extremes are float minima / maxima (v_min3 / v_max3 per lane, then
+    // ONE interleaved chain of v_min_f32_dpp / v_max_f32_dpp: 12 DPP operations + 7 s_nop, where the compiler's rendering of two
+    // update_dpp reductions over order-preserving integers took 56); a non-finite entry is found through the largest |entry| bit
+    // pattern of each query, accumulated over ALL the wave's subspaces and voted on once (was: four f - f tests and a ballot per
+    // pair); the wave's results ride in the lanes of 16 registers and reach LDS once per wave.
+    float lo_acc[UBR_QB], hi_acc[UBR_QB];
+    uint32_t amax[UBR_QB];
+#pragma unroll
+    for (int j = 0; j < UBR_QB; ++j) {
+        lo_acc[j] = 0.0f;
+        hi_acc[j] = 0.0f;
+        amax[j] = 0u;
+    }
     for (int rr = 0; rr < per_wave; ++rr) {
         const int r = wave * per_wave + rr;
 #pragma unroll
@@ -86,29 +115,39 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
                 c0[k] = cp[0];
                 c1[k] = cp[1];
             }
+            const int slot = 2 * rr + half;   // this wave's slot of the pair: lane `slot` of lo_acc[j] / hi_acc[j]
+#pragma unroll
             for (int j = 0; j < UBR_QB; ++j) {
                 const float *q = qs + j * D + m * 8;
                 float e4[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) e4[k] = gs_lut_entry_pk<VSF>(c0[k], c1[k], q);
-                const bool bad = !(e4[0] - e4[0] == 0.0f) || !(e4[1] - e4[1] == 0.0f) || !(e4[2] - e4[2] == 0.0f) || !(e4[3] - e4[3] == 0.0f);
-                // the lane's extremes as floats (a NaN marks the query unusable anyway), ONE conversion each to the order-preserving
-                // integer image, six single-instruction DPP steps per reduction
-                float fmn = e4[0] < e4[1] ? e4[0] : e4[1], fmx = e4[0] > e4[1] ? e4[0] : e4[1];
-                fmn = e4[2] < fmn ? e4[2] : fmn;
-                fmx = e4[2] > fmx ? e4[2] : fmx;
-                fmn = e4[3] < fmn ? e4[3] : fmn;
-                fmx = e4[3] > fmx ? e4[3] : fmx;
-                const int32_t smin = gs_wave_min_i32(ubr_sortable(fmn));
-                const int32_t smax = gs_wave_max_i32(ubr_sortable(fmx));
-                const bool any_bad = __ballot(bad ? 1 : 0) != 0;
-                if (lane == 0) {
-                    lo[j * M + m] = ubr_unsortable(smin);
-                    hi[j * M + m] = ubr_unsortable(smax);
-                    if (any_bad) qbad[j] = 1;   // (benign race: every writer stores 1)
+                // (NaN entries are skipped by v_min / v_max; the bit pattern below marks their query unusable)
+                float fmn = __builtin_fminf(__builtin_fminf(e4[0], e4[1]), __builtin_fminf(e4[2], e4[3]));
+                float fmx = __builtin_fmaxf(__builtin_fmaxf(e4[0], e4[1]), __builtin_fmaxf(e4[2], e4[3]));
+                uint32_t a = amax[j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t b = __builtin_bit_cast(uint32_t, e4[k]) & 0x7fffffffu;
+                    a = b > a ? b : a;
                 }
+                amax[j] = a;
+                ubr_wave_minmax(fmn, fmx);   // lane 63 holds the wave's extremes
+                const float wmn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fmn), 63));
+                const float wmx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fmx), 63));
+                lo_acc[j] = lane == slot ? wmn : lo_acc[j];
+                hi_acc[j] = lane == slot ? wmx : hi_acc[j];
             }
         }
+    }
+#pragma unroll
+    for (int j = 0; j < UBR_QB; ++j) {
+        if (lane < 2 * per_wave) {
+            const int m = wave * per_wave + (lane >> 1) + (lane & 1) * H;
+            lo[j * M + m] = lo_acc[j];
+            hi[j * M + m] = hi_acc[j];
+        }
+        if (__ballot(amax[j] >= 0x7f800000u ? 1 : 0) != 0 && lane == 0) qbad[j] = 1;   // (benign race: every writer stores 1)
     }
     __syncthreads();
     // ---- one scale per query; base = sum of the low edges + slack ----

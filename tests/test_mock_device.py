@@ -898,21 +898,6 @@ def test_golden_checker_through_the_c_abi_on_the_mock(J):
     T.check_goldens(g, T.HipSide(g), exact=True)
 
 
-def test_reference_native_comparison_runs_on_the_mock(J, ctx):
-    """tests/test_zz_ref_native_gpu.py (HIP kernels vs the reference's own native kernels, executed) on the mock device: the
-    mock's arithmetic is the oracle's, so this is the oracle-vs-`_ref` comparison through the C ABI's plumbing — it keeps the
-    GPU test's API usage and its reference-side assembly (tables, NVQScorer) runnable until the GPU box does it for real"""
-    import test_zz_ref_native_gpu as T
-    if T.R is None:
-        pytest.skip("oracle/_ref not built")
-    T.test_exact_scores_vs_reference_native(ctx, 128)
-    T.test_adc_tables_and_scores_vs_reference_native(ctx, 128, 16)
-    T.test_adc_tables_and_scores_vs_reference_native(ctx, 50, 7)
-    T.test_encode_code_bytes_vs_reference_native(ctx, 50, 7)
-    T.test_pair_scores_vs_reference_native(ctx, 128, 16)
-    T.test_nvq_scores_vs_reference_native(ctx, 100, 3)
-
-
 def test_register_table_bound_form_on_the_mock(J, ctx):
     """tests/test_zz_ubr_gpu.py on the mock device (the traversal on the lane emulator, the tables by gs_host.h's restatement): the
     driver's side of the form — option gs_ubr, table scratch, the drop counter, stats, the fall-backs for euclidean / filtered searches"""
