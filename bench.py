@@ -687,12 +687,16 @@ def batch_sweep(run, ctx, queries, rerank_k, sizes=(1, 16, 256, 1024, 4096, 1310
 
 
 SUB_RUNS = (
-    # key, argv, what it is
-    ("hard_case", ["--latent", "64", "--queries", "65536", "--steps", "3", "--warmup", "1", "--no-flat", "--no-cpu-baseline"],
+    # key, argv, what it is[, extra environment]
+    ("reference_order", ["--queries", "131072", "--steps", "3", "--warmup", "1", "--no-flat", "--no-cpu-baseline"],
+     "the headline at 10M built in the REFERENCE's order (bl_ref_order = 1: NodeArray lists with their stored insertion scores, diverseBefore, "
+     "improveConnections as the reference runs it — the order that equals the oracle's one-thread GraphIndexBuilder byte for byte on one-node "
+     "batches): what the reference would build, same calibration rule", {"JVECTOR_HIP_BL_REF_ORDER": "1"}),
+    ("hard_case", ["--latent", "64", "--queries", "65536", "--steps", "3", "--warmup", "1", "--no-flat"],
      "the headline pipeline on a HARDER distribution (intrinsic dimension 64 instead of 32): same code, same builder, same calibration rule"),
-    ("literal_c3", ["--generator", "literal", "--n", "1000000", "--queries", "16384", "--steps", "3", "--warmup", "1", "--cal-queries", "1024",
+    ("literal_c3", ["--generator", "literal", "--queries", "16384", "--steps", "3", "--warmup", "1", "--cal-queries", "1024",
                     "--eval-queries", "2048", "--no-flat", "--no-cpu-baseline"],
-     "SURVEY §8d's literal C3 generator (sigma 0.1 per coordinate in all 768 dimensions) at 1M vectors: an isotropic cloud"),
+     "SURVEY §8d's literal C3 generator (sigma 0.1 per coordinate in all 768 dimensions) at the metric's size, 10M vectors: an isotropic cloud"),
     ("c2", ["--workload", "c2"], "BASELINE config 2"),
     ("c5", ["--workload", "c5", "--n", "10000000"], "BASELINE config 5 at its full size (10M x 1536)"),
     ("c4_one_shard", ["--workload", "c4"], "BASELINE config 4, one of its eight 12.5M shards on one GPU"),
@@ -703,14 +707,15 @@ def run_sub_workloads(keys=None):
     """The other single-GPU BASELINE configurations and the data-sensitivity points, each as its own process of this script (its
     own device memory, its own calibration), timed inside the same driver run.  Returns {key: line or {"error": ...}}."""
     out = {}
-    for key, argv, what in SUB_RUNS:
+    for key, argv, what, *more in SUB_RUNS:
         if keys is not None and key not in keys:
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--sub-line"] + argv
         t0 = time.perf_counter()
         try:
-            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env={k: v for k, v in os.environ.items()
-                                                                                                      if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+            env.update(more[0] if more else {})
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
             lines = [x for x in p.stdout.decode(errors="replace").splitlines() if x.startswith("{")]
             if p.returncode != 0 or not lines:
                 out[key] = {"error": f"rc {p.returncode}", "stderr_tail": p.stderr.decode(errors="replace")[-600:]}
@@ -779,6 +784,9 @@ def _compact_sub(sub):
     for k in ("prune_roofline_frac",):
         if k in sub:
             out[k] = _r(sub[k], 4)
+    if sub.get("graph_build_s") is not None:     # the graph sub-runs: what the build cost and how long a search is
+        out["build_s"] = _r(sub["graph_build_s"], 4)
+        out["expanded"] = _r(sub.get("avg_expanded"), 4)
     return out
 
 
@@ -810,7 +818,7 @@ def compact_line(line):
     if isinstance(line.get("kernel_ms_per_step"), dict):
         out["kernel_ms_per_step"] = {k: _r(v, 4) for k, v in line["kernel_ms_per_step"].items() if v}
     wl = {}
-    for key, _argv, _what in SUB_RUNS:
+    for key, *_rest in SUB_RUNS:
         if key in line:
             wl[key] = _compact_sub(line[key])
     if isinstance(line.get("flat_mode"), dict):

@@ -513,7 +513,12 @@ JV_API const int32_t *jv_hip_builder_neighbors_device(const jv_builder *b, int *
  * (GraphIndexBuilder.java:605-659) operation for operation: the adjacency equals the reference's one-thread build (oracle:
  * jvo_builder_*, tests/test_builder_reference_order.py).  working_lists copies the lists as they stand: ids_out [n x row_width] (-1
  * padded), scores_out [n x row_width] and diverse_before_out [n] (each nullable; host or device memory; the last two only in
- * reference order / with sorted lists).
+ * reference order / with sorted lists: JV_ERR_INVALID otherwise).
+ * LIMITS of the byte-for-byte claim: it holds for one node per batch, without re-inserts, with maxDegree x overflow <= 64.
+ * Three places differ from Neighbors.insert beyond that: (1) back edges and improve candidates are de-duplicated BY ID, the reference
+ * rejects a duplicate only at an equal score (insertionPoint == -1) and can list a node twice under two PQ scores — it does so on
+ * improve passes; (2) a back-link merge drops what does not fit a working list of R + 2R entries, the reference's list grows;
+ * (3) the hard maximum is clamped to 64 entries, the reference uses (int)(overflow x maxDegree) uncapped.
  * bl_sorted_lists = 1: the DEFAULT build's own scores (the symmetric PQ diversity function of node and member) stored and the lists
  * kept sorted instead of re-scored and re-sorted at every re-prune — the identical graph (rows as sets); = 2 adds the diverseBefore
  * shortcut, bl_ref_order = 2 removes it from reference order: the two ablations of DESIGN.md §7. */

@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-from ._lib import check
+from ._lib import JV_ERR_INVALID, check
 from .engine import VectorSet, _ptr
 
 
@@ -60,8 +60,12 @@ class GraphBuilder:
         ids = np.empty((self.n, R), np.int32)
         sc = np.empty((self.n, R), np.float32)
         db = np.empty(self.n, np.int32)
-        check(self._lib.jv_hip_builder_working_lists(self.ctx._h, self._h, ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
-                                                    db.ctypes.data_as(C.c_void_p)))
+        rc = self._lib.jv_hip_builder_working_lists(self.ctx._h, self._h, ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p),
+                                                   db.ctypes.data_as(C.c_void_p))
+        if rc == JV_ERR_INVALID:   # a default builder stores no list scores (only bl_ref_order / bl_sorted_lists do): ids alone
+            check(self._lib.jv_hip_builder_working_lists(self.ctx._h, self._h, ids.ctypes.data_as(C.c_void_p), None, None))
+            return ids, None, None
+        check(rc)
         return ids, sc, db
 
     def stats(self):

@@ -1389,9 +1389,11 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
     const bool mq = adc_mq_supported(codes->M, codes->d_codes) && Q >= 2;
     if (mq && N >= (1 << 18) && (int64_t)k1 * 64 <= N && ctx_opt(ctx, "no_filter", 0) == 0) {
         // expected candidates per query behind the threshold.  The threshold is the k_s-th best of a strided sample (k_s = c_target x
-        // sample / N >= 16 and >= 100 at these sizes), so the count it yields scatters by ~1 / sqrt(k_s) <= 10 % around c_target: 3 x
-        // rerankK leaves the `>= k1` check twenty standard deviations of room (round 4 used 8 x: 2.7 x the lists, the gather and the
-        // top-k input for nothing — at C2's rerankK 3200 that was 0.6 ms of a 3 ms step)
+        // sample / N: 43 at C4's shard, 157 at C2), so the count it yields is Gamma(k_s)-distributed, ~1 / sqrt(k_s) = 8 - 15 % around
+        // c_target: with c_target = 3 x rerankK the `>= k1` check sits 4.4 (C4) to 8 (C2) standard deviations away — a query fails it
+        // about once in 2 x 10^5 at C4, i.e. about one CALL in 800 at Q = 256 pays the unfiltered scan (results are the same).
+        // (Round 4 used 8 x: 2.7 x the lists, the gather and the top-k input for nothing — at C2's rerankK 3200 that was 0.6 ms of a
+        // 3 ms step.)
         const int64_t c_target = std::max<int64_t>(3 * (int64_t)k1, 4096);
         int64_t S_target = std::max<int64_t>(16384, next_pow2_i64(32 * N / c_target));
         const int64_t stride = std::max<int64_t>(1, N / S_target);
@@ -1424,7 +1426,7 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
             // survivors only (k_adc_bq.hip); the lists hold a superset of {score >= tau} with exact scores, so the top-k1 below is the
             // same.  A query whose bound keeps more than cap2 candidates (or that has no usable bound) sends the call to the exact filter.
             bool bq_done = false;
-            if (adc_bq_supported(codes->M, codes->d_codes) && ctx_opt(ctx, "adc_bq", 1) != 0) {
+            if (adc_bq_supported(codes->M, codes->d_codes, ctx->lds_per_block) && ctx_opt(ctx, "adc_bq", 1) != 0) {
                 // (the exact filter aims at cap / 4 candidates per query; the bound keeps a few more: the same list size leaves 2-3x room)
                 const int cap2 = cap;
                 const size_t b_cap2 = sizeof(float) * (size_t)Q * cap2;

@@ -1477,7 +1477,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
             fprintf(stderr, "[jv gs prof] the compacted pair form (rows of 33..64 neighbours: the builder's searches) has no phase-clock variant; gs_prof ignored for this launch\n");
         gs_prof = false;
     }
-    const size_t o_prof = carve(sizeof(unsigned long long) * 16);
+    const size_t o_prof = carve(sizeof(unsigned long long) * 24);
     // exact-score ties across the K-th place of the rerank are decided by the order of the reference's result-heap array
     // (NodeQueue.java:197-214): the traversal logs its addTopCandidate sequence (avg ~1 entry per expansion) and
     // rerank_tie_kernel rebuilds the reference's answer for the (rare) tied queries; an overflowed log sends the query to
@@ -1502,7 +1502,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     int32_t *d_status = (int32_t *)(base + o_status);
     uint32_t *d_counter = (uint32_t *)(base + o_counter);
     JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
-    if (gs_prof || ubr) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 16, ctx->stream));
+    if (gs_prof || ubr) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 24, ctx->stream));
 
     GsParams p{};
     for (int lv = 0; lv <= g->entry_level; ++lv) {
@@ -1701,7 +1701,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         redo.swap(still);
     }
     if (gs_prof) {
-        unsigned long long h[16];
+        unsigned long long h[24];
         JV_HIP_CHECK(hipMemcpyAsync(h, base + o_prof, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         const double e = (double)std::max<unsigned long long>(h[5], 1);
@@ -1720,6 +1720,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         else if (ubr) {
             fprintf(stderr, "[jv gs prof] register-table bound form, per expansion: bound + staging %.0f clocks  bound + staging + exact scores %.0f clocks  "
                             "trims %.0f clocks | dropped %.2f  exactly scored %.2f neighbours\n", h[8] / e, h[9] / e, h[10] / e, h[15] / e, h[11] / e);
+            fprintf(stderr, "[jv gs prof] register-table bound form, per expansion: wait for the row %.0f clocks  scoring rounds %.0f  owner sum + finish %.0f  "
+                            "passes %.2f | expansions with <= 4 / <= 8 / <= 16 survivors: %.3f / %.3f / %.3f\n", h[16] / e, h[17] / e, h[18] / e, h[19] / e,
+                    h[20] / e, h[21] / e, h[22] / e);
         }
         else
         fprintf(stderr, "[jv gs prof] scored neighbours by fresh count of their expansion: <=8 %.3f  <=16 %.3f  <=24 %.3f  <=32 %.3f\n", h[8] / fs,

@@ -60,6 +60,10 @@
 
 #include "gs_params.h"
 
+#ifndef GS_UBR_VAR_LPS
+#define GS_UBR_VAR_LPS 0   // 1: 32 / 16 / 8 lanes per survivor by survivor count (bit-identical, measured slower: profiles/r6_f)
+#endif
+
 namespace jv {
 
 struct alignas(16) gs_f4 { float x, y, z, w; };
@@ -723,6 +727,120 @@ GS_FN bool gs_bound_below(float bound_raw, float node_mag, float query_mag, floa
     return x + 1e-5f * (1.0f + ax) < 2.0f * T - 1.0f;
 }
 
+// UBR: one scoring pass over the survivors [base, base + 64 / LPS) of an expansion, LPS lanes each (round 6: 8, 16 or 32 — picked by
+// how many survived; two thirds of the headline's expansions keep at most FOUR of their ~21 fresh neighbours, and eight lanes each
+// left half the wave idle while every lane walked twelve subspaces in two rounds of codebook requests).  Lane LPS g + t takes the
+// subspaces [t SUBS, (t + 1) SUBS) of survivor base + g, SUBS = M / LPS: its code bytes from the staging area, its codebook rows in
+// rounds of at most six (requested before the first entry is formed), the query's sub-vectors from LDS up to three entries at a time;
+// lane t = 0 (the owner) adds its own entries, then — behind the barrier — the other lanes' in ascending m from its column of the
+// hand-over area: assembleAndSum's order, the same bits whatever LPS is.  Returns the owner lanes' keys (fresh = the lane holds one
+// that is to be pushed).  Wave-uniform call; xf: [64 / LPS columns][column stride] floats, columns 16-byte aligned.
+template <int VSF, int M_, int LPS>
+GS_FN void gs_ubr_pass(const float *codebooks, const float *qs, float *xf, const int32_t *st_nb, const float *st_mag, const uint8_t *st_code,
+                       int base, int ns, float query_mag, bool ub_active, float ub_T, bool &fresh, long long &key)
+{
+    static_assert(M_ % LPS == 0 && (LPS == 8 || LPS == 16 || LPS == 32), "lanes per survivor");
+    constexpr int SUBS = M_ / LPS;                      // subspaces per lane
+    constexpr int RH = SUBS % 6 == 0 ? 6 : (SUBS % 4 == 0 ? 4 : SUBS);   // codebook rows per round (PQ-96: 6, 6, 3)
+    constexpr int QB = RH % 3 == 0 ? 3 : (RH % 2 == 0 ? 2 : 1);          // entries per batch of query reads
+    static_assert(SUBS % RH == 0 && RH % QB == 0 && RH <= 6, "whole rounds of whole batches");
+    constexpr int NB = (LPS - 1) * SUBS;                // entries the owner takes over
+    constexpr int CS = (NB + 3) & ~3;                   // column stride (floats)
+    const int lane = gs_lane();
+    const int g = lane / LPS;
+    int t = lane % LPS;
+    GS_OPAQUE_I32(t);   // (or the per-lane subspace pointers are hoisted out of the search loop and spilled)
+    const int j = base + g;
+    const bool work = j < ns;
+    float sum = 0.0f;
+    if (work) {
+        // the lane's SUBS code bytes: an aligned 8-byte window (12-byte for SUBS = 12) of the survivor's staged row, shifted into place
+        const int off = t * SUBS;
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(st_code + j * M_ + (off & ~3));
+        uint32_t d[SUBS / 4 > 3 ? SUBS / 4 : 3];
+        if (SUBS % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < SUBS / 4; ++i) d[i] = cw[i];
+        } else {
+            const unsigned long long win = (unsigned long long)cw[0] | ((unsigned long long)cw[1] << 32);
+            const unsigned long long sh = win >> (8 * (off & 3));
+            d[0] = (uint32_t)sh;
+            d[1] = (uint32_t)(sh >> 32);
+            d[2] = 0u;
+        }
+        float v[SUBS];
+#pragma unroll
+        for (int h2 = 0; h2 < SUBS / RH; ++h2) {
+            gs_f4 c0[RH], c1[RH];
+#pragma unroll
+            for (int kk = 0; kk < RH; ++kk) {
+                const int k = h2 * RH + kk;
+                const uint32_t code = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(codebooks + ((int64_t)((t * SUBS + k) * 256) + code) * 8);
+                c0[kk] = cp[0];
+                c1[kk] = cp[1];
+            }
+            // the query's sub-vectors are read from LDS three entries at a time behind the codebook requests: left to itself the
+            // compiler — at its 255-register limit — read them entry by entry and waited for each pair in turn (all six of a round at
+            // once cost 34 spilled table registers, reloaded in front of every bound phase)
+#pragma unroll
+            for (int b3 = 0; b3 < RH / QB; ++b3) {
+                gs_f4 q0[QB], q1[QB];
+#pragma unroll
+                for (int kk = 0; kk < QB; ++kk) {
+                    const gs_f4 *qp = reinterpret_cast<const gs_f4 *>(qs + (t * SUBS + h2 * RH + b3 * QB + kk) * 8);
+                    q0[kk] = qp[0];
+                    q1[kk] = qp[1];
+                }
+                GS_SCHED_FENCE();
+#pragma unroll
+                for (int kk = 0; kk < QB; ++kk) {
+                    const int k = h2 * RH + b3 * QB + kk;
+                    v[k] = gs_lut_entry_pk_q<VSF>(c0[b3 * QB + kk], c1[b3 * QB + kk], q0[kk], q1[kk]);
+                }
+                GS_SCHED_FENCE();
+            }
+        }
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < SUBS; ++k) sum += v[k];
+        } else {   // column g of the hand-over area: the owner reads its entries as contiguous 16-byte words
+#pragma unroll
+            for (int k = 0; k < SUBS; ++k) xf[g * CS + (t - 1) * SUBS + k] = v[k];
+        }
+    }
+    gs_barrier();
+    fresh = work && t == 0;
+    key = 0;
+    if (fresh) {   // the owner: its own subspaces are summed; now the other lanes' in ascending m — the column's 16-byte words are
+        // requested a batch at a time before the first of the batch is added (the compiler had issued four and then one at a time,
+        // each waited for: 17 exposed LDS latencies in front of the finish)
+        const gs_f4 *col = reinterpret_cast<const gs_f4 *>(xf + g * CS);
+        constexpr int NW = CS / 4;                          // 16-byte words of the column (the last may hold 1 .. 4 entries)
+        constexpr int EB = NW % 7 == 0 ? 7 : 8;             // words per batch (28 / 32 registers; the last batch may be short)
+#pragma unroll
+        for (int b7 = 0; b7 < (NW + EB - 1) / EB; ++b7) {
+            gs_f4 e4[EB];
+#pragma unroll
+            for (int i = 0; i < EB; ++i)
+                if (b7 * EB + i < NW) e4[i] = col[b7 * EB + i];
+            GS_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < EB; ++i) {
+                const int w0 = (b7 * EB + i) * 4;            // (entries past NB are the column's padding: never added)
+                if (w0 + 0 < NB) sum += e4[i].x;
+                if (w0 + 1 < NB) sum += e4[i].y;
+                if (w0 + 2 < NB) sum += e4[i].z;
+                if (w0 + 3 < NB) sum += e4[i].w;
+            }
+            GS_SCHED_FENCE();
+        }
+        const float sc = gs_finish<VSF>(sum, st_mag[j], query_mag);
+        key = gs_key(st_nb[j], sc);
+        if (ub_active && sc < ub_T) fresh = false;   // exactly scored and still below the threshold: never popped
+    }
+}
+
 // visited.add: true iff the node was not in the set.  Linear probing; callers keep the load <= 1/2.
 GS_FN bool gs_visit(int32_t *tab, uint32_t mask, int shift, int32_t node)
 {
@@ -1092,6 +1210,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     unsigned long long fh[4] = {0, 0, 0, 0};  // PROF: scored neighbours in expansions with <= 8 / <= 16 / <= 24 / <= 32 fresh ones
     unsigned long long pt = 0, pq0 = 0;
     unsigned long long px[3] = {0, 0, 0};   // PROF: setup (entry -> first pop), level transitions, epilogue
+    unsigned long long py[7] = {0, 0, 0, 0, 0, 0, 0};   // PROF (UBR): wait for the row, scoring rounds, owner sum + finish, passes, expansions with <= 4 / <= 8 / <= 16 survivors
     if (PROF) pq0 = GS_CLOCK();
 #define GS_PHASE(i)                          \
     do {                                     \
@@ -1110,7 +1229,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     const int evict_cap = p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP;
     // PAIR: [M/2][32] entries handed from high to low lanes; the partition step's 64-key sample buffer lives in the same
     // bytes (it is only touched inside gs_push, after every lane has consumed the exchange area)
-    float *xchg = reinterpret_cast<float *>(s.evicted + evict_cap);
+    // (with an exchange area: at the next 16-byte boundary — its hand-over columns are read as 16-byte words; gs_lds_bytes has the 8 bytes)
+    float *xchg = XA ? reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(s.evicted + evict_cap) + 15) & ~(uintptr_t)15)
+                     : reinterpret_cast<float *>(s.evicted + evict_cap);
     s.samp = s.evicted + evict_cap;
     (void)xchg;
     s.spill = p.spill + (int64_t)worker * p.spill_cap;
@@ -1595,6 +1716,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     }
                 }
                 const int first_neg = gs_first(gs_ballot(!hi && nb < 0));  // rows are packed: the first -1 ends the row
+                if (PROF && UBR) py[0] += GS_CLOCK() - pt;   // (the row's ids have arrived)
                 const bool valid = ni < first_neg;
                 if (!fused0 && valid) {    // PQDecoder.similarityTo: the neighbour's own code
                     gs_load_half<CH16>(p.codes + (int64_t)nb * p.M + m_base, w);
@@ -1611,7 +1733,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     fh[f <= 8 ? 0 : (f <= 16 ? 1 : (f <= 24 ? 2 : 3))] += (unsigned long long)f;
                 }
                 if constexpr (UBR) {
-                    constexpr int M_ = CH16 * 16, SUBS = M_ / 8;   // eight lanes per kept neighbour, SUBS subspaces each
+                    constexpr int M_ = CH16 * 16;
                     unsigned long long ubc0 = 0;
                     if (PROF) ubc0 = GS_CLOCK();
                     // ---- the bound of every fresh neighbour against the pop threshold ----
@@ -1628,6 +1750,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     }
                     const int ns = gs_popc(sm);
                     ubr_since += ns;
+                    if (PROF) {
+                        py[4] += ns <= 4 ? 1 : 0;
+                        py[5] += ns <= 8 ? 1 : 0;
+                        py[6] += ns <= 16 ? 1 : 0;
+                    }
                     // ---- compact the survivors: code bytes, node id and magnitude of survivor j (row order) into LDS ----
                     float *xf = xchg;                                              // [8 owners][7 SUBS] entries handed to the owner lanes
                     int32_t *st_nb = reinterpret_cast<int32_t *>(xchg + 7 * M_);   // [32]
@@ -1649,104 +1776,37 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                         fh[0] += now_ - ubc0;   // (the UBR build reuses the fresh-count histogram's slots: bound + staging clocks,
                         fh[3] += (unsigned long long)ns;   // ... survivors)
                     }
-                    // ---- score them, eight per pass: lane 8 g + t takes subspaces [t SUBS, (t + 1) SUBS) of survivor base + g ----
-                    const int g = lane >> 3;
-                    int t = lane & 7;
-                    GS_OPAQUE_I32(t);   // (or the per-lane subspace pointers are hoisted out of the search loop and spilled)
+                    // ---- score them: 8, 16 or 32 lanes per survivor (gs_ubr_pass), 8 / 4 / 2 survivors per pass ----
                     fresh = false;
                     key = 0;
                     bool give_up = false;
+                    // (Measured and left off, profiles/r6_f: 32 / 16 lanes per survivor when at most 2 / 4 survive — two thirds of the
+                    // headline's expansions, one round of codebook requests instead of two — 53.4 vs 49.0 ms per 131 072 queries: slower
+                    // even with four waves per CU.  GS_UBR_VAR_LPS = 1 compiles it in.)
+#if GS_UBR_VAR_LPS
+                    const int per = ns <= 2 ? 2 : (ns <= 4 ? 4 : 8);
+#else
+                    const int per = 8;
+#endif
 #pragma unroll 1
-                    for (int base = 0; base < ns; base += 8) {
-                        const int j = base + g;
-                        const bool work = j < ns;
-                        float sum = 0.0f;
-                        if (work) {
-                            const uint32_t *cw = reinterpret_cast<const uint32_t *>(st_code + j * M_ + t * SUBS);
-                            uint32_t d[SUBS / 4];
-#pragma unroll
-                            for (int i = 0; i < SUBS / 4; ++i) d[i] = cw[i];
-                            // the codebook rows of half the lane's share are requested before the first entry is formed (a branch on
-                            // the lane's role between two look-ups makes the compiler wait for each pair of loads in turn; the whole
-                            // share at once — 24 x 16 bytes — does not fit next to the table's registers)
-                            // The codebook rows of HALF the lane's share are requested before the first entry is formed (a branch on the
-                            // lane's role between two look-ups makes the compiler wait for each pair of loads in turn: 13.9 k -> 9.7 k
-                            // clocks per expansion; the whole share at once — 24 x 16 bytes — does not fit next to the table's registers:
-                            // the compiler then parks 16 of them in scratch around every pass, measured 60.6 vs 57.3 ms, profiles/r5_f).
-                            // An entry's products two at a time (gs_lut_entry_pk), its additions in the reference's order: the same bits.
-                            float v[SUBS];
-#pragma unroll
-                            for (int h2 = 0; h2 < 2; ++h2) {
-                                gs_f4 c0[SUBS / 2], c1[SUBS / 2];
-#pragma unroll
-                                for (int kk = 0; kk < SUBS / 2; ++kk) {
-                                    const int k = h2 * (SUBS / 2) + kk;
-                                    const uint32_t code = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                                    const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(p.codebooks + ((int64_t)((t * SUBS + k) * 256) + code) * 8);
-                                    c0[kk] = cp[0];
-                                    c1[kk] = cp[1];
-                                }
-                                // (round 6) the query's sub-vectors of the half are read from LDS in ONE batch behind the codebook requests:
-                                // left to itself the compiler — at its 255-register limit — read them entry by entry and waited for
-                                // each pair in turn, a full LDS latency per entry
-                                // each pair in turn, a full LDS latency per entry.  (Three entries' worth at a time: all six of the half
-                                // at once cost 34 spilled table registers, reloaded in front of every bound phase.)
-                                constexpr int QB = SUBS / 4;
-#pragma unroll
-                                for (int b3 = 0; b3 < 2; ++b3) {
-                                    gs_f4 q0[QB], q1[QB];
-#pragma unroll
-                                    for (int kk = 0; kk < QB; ++kk) {
-                                        const gs_f4 *qp = reinterpret_cast<const gs_f4 *>(qs + (t * SUBS + h2 * (SUBS / 2) + b3 * QB + kk) * 8);
-                                        q0[kk] = qp[0];
-                                        q1[kk] = qp[1];
-                                    }
-                                    GS_SCHED_FENCE();
-#pragma unroll
-                                    for (int kk = 0; kk < QB; ++kk) {
-                                        const int k = h2 * (SUBS / 2) + b3 * QB + kk;
-                                        v[k] = gs_lut_entry_pk_q<VSF>(c0[b3 * QB + kk], c1[b3 * QB + kk], q0[kk], q1[kk]);
-                                    }
-                                    GS_SCHED_FENCE();
-                                }
-                            }
-                            if (t == 0) {
-#pragma unroll
-                                for (int k = 0; k < SUBS; ++k) sum += v[k];
-                            } else {   // column g of the hand-over area: the owner reads its 7 SUBS entries as contiguous 16-byte words
-#pragma unroll
-                                for (int k = 0; k < SUBS; ++k) xf[g * (7 * SUBS) + (t - 1) * SUBS + k] = v[k];
-                            }
+                    for (int base = 0; base < ns; base += per) {
+                        unsigned long long pyc = 0;
+                        if (PROF) {
+                            pyc = GS_CLOCK();
+                            py[3]++;
                         }
-                        gs_barrier();
-                        fresh = work && t == 0;
-                        key = 0;
-                        if (fresh) {   // the owner: its own subspaces are summed; now the other seven lanes' in ascending m
-                            // (round 6) all of the column's 16-byte words are requested before the first is added: the compiler had
-                            // issued four and then one at a time, each waited for — 17 exposed LDS latencies in front of the finish
-                            const gs_f4 *col = reinterpret_cast<const gs_f4 *>(xf + g * (7 * SUBS));
-                            constexpr int EB = 7;   // words per batch (28 registers)
-                            static_assert((7 * SUBS / 4) % EB == 0, "the owner's column is read in whole batches");
-#pragma unroll
-                            for (int b7 = 0; b7 < 7 * SUBS / 4 / EB; ++b7) {
-                                gs_f4 e4[EB];
-#pragma unroll
-                                for (int i = 0; i < EB; ++i) e4[i] = col[b7 * EB + i];
-                                GS_SCHED_FENCE();
-#pragma unroll
-                                for (int i = 0; i < EB; ++i) {
-                                    sum += e4[i].x;
-                                    sum += e4[i].y;
-                                    sum += e4[i].z;
-                                    sum += e4[i].w;
-                                }
-                                GS_SCHED_FENCE();
-                            }
-                            const float sc = gs_finish<VSF>(sum, st_mag[j], query_mag);
-                            key = gs_key(st_nb[j], sc);
-                            if (ub_active && sc < ub_T) fresh = false;   // exactly scored and still below the threshold: never popped
+#if GS_UBR_VAR_LPS
+                        if (ns <= 2) gs_ubr_pass<VSF, M_, 32>(p.codebooks, qs, xf, st_nb, st_mag, st_code, base, ns, query_mag, ub_active, ub_T, fresh, key);
+                        else if (ns <= 4) gs_ubr_pass<VSF, M_, 16>(p.codebooks, qs, xf, st_nb, st_mag, st_code, base, ns, query_mag, ub_active, ub_T, fresh, key);
+                        else
+#endif
+                        gs_ubr_pass<VSF, M_, 8>(p.codebooks, qs, xf, st_nb, st_mag, st_code, base, ns, query_mag, ub_active, ub_T, fresh, key);
+                        if (PROF) {
+                            const uint64_t done_ = gs_ballot(fresh && key != 0);   // (the owners' keys exist before the clock is read)
+                            if (done_ == 0xdeadbeefdeadbeefull) py[3]++;
+                            py[1] += GS_CLOCK() - pyc;
                         }
-                        if (base + 8 >= ns) break;   // the shared tail below pushes the last pass
+                        if (base + per >= ns) break;   // the shared tail below pushes the last pass
                         gs_barrier();   // every owner lane has read its column before the push's sample buffer reuses the bytes
                         if (ub_on && gs_ballot(fresh && (int32_t)(key >> 32) == 0x7fc00000)) ub_on = false;
                         gs_push(s, p, key, fresh);
@@ -2201,6 +2261,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         gs_fetch_add64(p.prof + 12, px[0]);
         gs_fetch_add64(p.prof + 13, px[1]);
         gs_fetch_add64(p.prof + 14, GS_CLOCK() - pep0);
+        if (UBR) for (int i = 0; i < 7; ++i) gs_fetch_add64(p.prof + 16 + i, py[i]);
     }
     if (UB8 && p.prof && lane == 0) gs_fetch_add64(p.prof + 15, ub_dropped);   // (tests / studies / gs_prof read the drop count)
     if (UBR && p.ubr_count && lane == 0) gs_fetch_add64(p.ubr_count, ub_dropped);

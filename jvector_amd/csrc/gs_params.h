@@ -132,8 +132,10 @@ constexpr size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M 
                            int evict_cap = GS_EVICT_CAP, int v1_log2 = 0)
 {
     // (the 64-key sample buffer of the partition step shares the pair-lane exchange area when there is one)
+    // (+ 8 with an exchange area: it starts at the next 16-byte boundary behind the 8-byte queues — its hand-over columns are read as
+    // 16-byte words — whatever the parity of rerankK + cand_cap + evict_cap)
     const size_t base = gs_q_bytes(D) + sizeof(long long) * ((size_t)rerankK + (size_t)cand_cap + (size_t)evict_cap + (pair_M ? 0 : 64)) +
-                        sizeof(float) * gs_xchg_floats(pair_M);
+                        sizeof(float) * gs_xchg_floats(pair_M) + (pair_M ? 8 : 0);
     return v1_log2 > 0 ? ((base + 15) & ~(size_t)15) + ((size_t)2 << v1_log2) : base;
 }
 

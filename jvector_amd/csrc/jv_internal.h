@@ -441,7 +441,7 @@ int launch_adc_mq_filter(hipStream_t s, const jv_ctx *ctx, const float *d_luts, 
                          unsigned int *d_cand_count, int cap);
 // the same filter in two stages (k_adc_bq.hip): 7-bit bound tables for sixteen queries per LDS word drop what cannot reach tau, the
 // exact ADC score is computed for the survivors only
-bool adc_bq_supported(int M, const uint8_t *d_codes);
+bool adc_bq_supported(int M, const uint8_t *d_codes, size_t lds_per_block);
 size_t adc_bq_scratch_bytes(int Q, int M);
 int launch_adc_bq_scan(hipStream_t s, const jv_ctx *ctx, const float *d_luts, const float *d_bmag, int Q, int M, int vsf, const uint8_t *d_codes,
                        const float *d_norms, int64_t first, int64_t count, const float *d_tau, int tau_stride, int32_t *d_ids,

@@ -304,7 +304,13 @@ __global__ __launch_bounds__(256) void adc_bq_count_kernel(const float *__restri
     if (threadIdx.x == 0) out_cnt[q] = s_n;
 }
 
-bool adc_bq_supported(int M, const uint8_t *d_codes) { return M % 16 == 0 && M <= 192 && (reinterpret_cast<uintptr_t>(d_codes) & 15) == 0; }
+// (lds_per_block: the bound scan stages 16 x SLCH x 256 16-byte words — 64 KB, 128 KB when M % 32 == 0 — of dynamic LDS; a device
+// that does not have them keeps the exact filter)
+bool adc_bq_supported(int M, const uint8_t *d_codes, size_t lds_per_block)
+{
+    const size_t lds = (size_t)16 * ((M % 32 == 0) ? 2 : 1) * kClusters * sizeof(uint4);
+    return M % 16 == 0 && M <= 192 && (reinterpret_cast<uintptr_t>(d_codes) & 15) == 0 && lds + 1024 <= lds_per_block;
+}
 size_t adc_bq_scratch_bytes(int Q, int M) { return (size_t)((Q + BQ_P - 1) / BQ_P) * M * kClusters * BQ_P + sizeof(float) * 4 * (size_t)Q + 256; }
 
 template <int VSF, int SLCH>

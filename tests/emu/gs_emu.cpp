@@ -286,7 +286,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     p.out_ids = out_ids; p.out_scores = out_scores; p.out_stats = out_stats; p.out_status = out_status;
     uint32_t next = 0;
     p.next_query = &next;
-    unsigned long long prof[16] = {0};
+    unsigned long long prof[24] = {0};
     if (ub8 == 1) p.prof = prof;   // (only slot 15 is written without the phase-clock build: neighbours dropped behind the bound)
     if (ub8 == 2) p.ubr_count = prof + 15;
     long collectives = 0;

@@ -501,7 +501,7 @@ int launch_adc_mq_filter(hipStream_t, const jv_ctx *, const float *, const float
     set_error("mock device: adc_mq_filter is not available");
     return JV_ERR_UNSUPPORTED;
 }
-bool adc_bq_supported(int, const uint8_t *) { return false; }   // (the flat scan's filter kernels are not mocked)
+bool adc_bq_supported(int, const uint8_t *, size_t) { return false; }   // (the flat scan's filter kernels are not mocked)
 size_t adc_bq_scratch_bytes(int, int) { return 0; }
 int launch_adc_bq_scan(hipStream_t, const jv_ctx *, const float *, const float *, int, int, int, const uint8_t *, const float *, int64_t, int64_t, const float *, int,
                        int32_t *, unsigned int *, int, void *)
