@@ -61,7 +61,7 @@
 #include "gs_params.h"
 
 #ifndef GS_UBR_VAR_LPS
-#define GS_UBR_VAR_LPS 0   // 1: 32 / 16 / 8 lanes per survivor by survivor count (bit-identical, measured slower: profiles/r6_f)
+#define GS_UBR_VAR_LPS 1   // 32 / 16 / 8 lanes per survivor by survivor count (0: always 8; bit-identical; 47.8 vs 48.8 ms, profiles/r6_h)
 #endif
 
 namespace jv {
@@ -1230,8 +1230,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     // PAIR: [M/2][32] entries handed from high to low lanes; the partition step's 64-key sample buffer lives in the same
     // bytes (it is only touched inside gs_push, after every lane has consumed the exchange area)
     // (with an exchange area: at the next 16-byte boundary — its hand-over columns are read as 16-byte words; gs_lds_bytes has the 8 bytes)
-    float *xchg = XA ? reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(s.evicted + evict_cap) + 15) & ~(uintptr_t)15)
-                     : reinterpret_cast<float *>(s.evicted + evict_cap);
+    // (an OFFSET from lds rounded up, not the pointer's integer value: a pointer that went through an integer is a flat pointer to
+    // the compiler — every access of the exchange area became a flat_load / flat_store instead of a ds_ operation: 53.5 vs 49.0 ms for
+    // the headline and 40 s instead of 17.6 s of builder searches at C5, profiles/r6_g)
+    float *xchg = reinterpret_cast<float *>(lds + (XA ? (((size_t)(reinterpret_cast<char *>(s.evicted + evict_cap) - lds) + 15) & ~(size_t)15)
+                                                      : (size_t)(reinterpret_cast<char *>(s.evicted + evict_cap) - lds)));
     s.samp = s.evicted + evict_cap;
     (void)xchg;
     s.spill = p.spill + (int64_t)worker * p.spill_cap;
@@ -1780,9 +1783,8 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     fresh = false;
                     key = 0;
                     bool give_up = false;
-                    // (Measured and left off, profiles/r6_f: 32 / 16 lanes per survivor when at most 2 / 4 survive — two thirds of the
-                    // headline's expansions, one round of codebook requests instead of two — 53.4 vs 49.0 ms per 131 072 queries: slower
-                    // even with four waves per CU.  GS_UBR_VAR_LPS = 1 compiles it in.)
+                    // (32 / 16 lanes per survivor when at most 2 / 4 survive — two thirds of the headline's expansions — is one round of
+                    // codebook requests instead of two: 47.8 vs 48.8 ms per 131 072 queries, profiles/r6_h.  GS_UBR_VAR_LPS = 0: always 8.)
 #if GS_UBR_VAR_LPS
                     const int per = ns <= 2 ? 2 : (ns <= 4 ? 4 : 8);
 #else
