@@ -235,7 +235,7 @@ def cpu_baseline_build(cb, D, M, codes_h, nbrs_h, entry, base_dev, vsf, max_degr
 def measured_traffic(kernel_key, cfg, want_entry=False):
     """HBM bytes per launch from the rocprofv3 PMC summary (profiles/traffic_r4.json, else traffic_r3.json / traffic_r2.json) — only if it was collected on THIS
     configuration (same kernel, N, D, M, queries per step, rerankK); else None."""
-    for name in ("traffic_r5.json", "traffic_r4.json", "traffic_r3.json", "traffic_r2.json"):   # the newest summary whose configuration matches
+    for name in ("traffic_r6.json", "traffic_r5.json", "traffic_r4.json", "traffic_r3.json", "traffic_r2.json"):   # the newest summary whose configuration matches
         try:
             table = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -292,11 +292,12 @@ def timed_steps(run, queries, Q, steps, rk, barrier):
     return time.perf_counter() - t0
 
 
-def flat_roofline(QF, N, M, f_ms, f_n, cfg, vsf_name="COSINE", bq=False):
+def flat_roofline(QF, N, M, f_ms, f_n, cfg, vsf_name="COSINE", bq=False, exact_ms=None):
     """The flat scan's threshold filter.  Round 5 (bq): adc_bq_kernel — one (query, candidate) pair = M look-ups of ONE byte, sixteen
     queries served by one ds_read_b128 from 7-bit bound tables in LDS — followed by the exact ADC gather of the survivors; `f_ms` is the
-    whole `adc` region (bound tables + bound scan + exact gather + count), so `achieved` under-reports the scan kernel alone by
-    10-25 %.  Before (adc_mq_kernel): M look-ups of 4 B, four queries per ds_read_b128.  Bound: the LDS gather rate either way."""
+    `adc` region = bound tables + bound scan (round 6: the survivors' exact stage is a region of its own, `adc_exact`, reported as
+    `exact_stage_ms_per_launch`).  Before (adc_mq_kernel): M look-ups of 4 B, four queries per ds_read_b128.  Bound: the LDS gather rate
+    either way."""
     f_avg = f_ms / 1e3 / max(f_n, 1)
     bytes_per_lookup = 1.0 if bq else 4.0
     lds_bytes = float(QF) * N * M * bytes_per_lookup   # bytes the ds_read_b128 stream delivers per launch
@@ -313,6 +314,9 @@ def flat_roofline(QF, N, M, f_ms, f_n, cfg, vsf_name="COSINE", bq=False):
             "hbm_traffic_over_compulsory": (traffic / compulsory) if traffic else None,
             "pairs_per_launch": float(QF) * N, "pairs_per_s": float(QF) * N / f_avg if f_avg > 0 else 0.0, "lds_bytes_per_lookup": bytes_per_lookup,
             "avg_launch_ms": f_avg * 1e3, "launches": f_n,
+            "bound_scan_ms_per_launch": f_avg * 1e3 if bq else None,
+            "exact_stage_ms_per_launch": (exact_ms[0] / max(exact_ms[1], 1)) if (bq and exact_ms) else None,
+            "lds_bank_conflict_fraction": (measured_traffic("adc_bq" if bq else "adc_mq", cfg, True) or {}).get("lds_bank_conflict_fraction"),
             "note": "bound = LDS gather rate (ds_read_b128 peak 256 B/clk/CU x 256 CUs x 2.4 GHz; random 16-byte gathers conflict ~2.8x); "
                     "HBM side: counter bytes vs the compulsory one pass over the codes"}
 
@@ -421,7 +425,7 @@ def run_c2(args, ctx, J, dev, world, rank, barrier, ranks):
         run(queries[w * QF:(w + 1) * QF], rerank_k)
     ctx.profile(True)
     elapsed = timed_steps(run, queries[args.warmup * QF:], QF, args.steps, rerank_k, barrier)
-    prof = {r: ctx.profile_read(r) for r in ("adc", "sample", "topk", "exact", "lut")}
+    prof = {r: ctx.profile_read(r) for r in ("adc", "adc_exact", "sample", "topk", "exact", "lut")}
     ctx.profile(False)
     rccl_ranks = ranks.rccl_ranks()
     elapsed, total_q, per_rank = aggregate(ranks, elapsed, QF * args.steps)
@@ -439,7 +443,7 @@ def run_c2(args, ctx, J, dev, world, rank, barrier, ranks):
                        "parallelism": "1 GPU" if world == 1 else f"{world} replicas"},
             "recall_at_10": rec, "recall_se": rec_se, "recall_ok": rec >= 0.95, "recall_eval_queries": int(eval_q.shape[0]),
             "recall_calibration": {"queries": int(cal_q.shape[0]), "recall": cal_rec, "disjoint_from_eval": True},
-            "roofline": flat_roofline(QF, N, M, prof["adc"][0], prof["adc"][1], cfg, "L2", bq=ctx.stat("adc_bq_calls") > 0),
+            "roofline": flat_roofline(QF, N, M, prof["adc"][0], prof["adc"][1], cfg, "L2", bq=ctx.stat("adc_bq_calls") > 0, exact_ms=prof["adc_exact"]),
             "kernel_ms_per_step": {r: prof[r][0] / args.steps for r in prof},
             "adc_distances_per_s": float(QF) * N * args.steps * world / elapsed, "pq_train_s": train_s, "setup_s": setup_s}
     if world == 1 and not args.no_cpu_baseline:
@@ -517,7 +521,7 @@ def run_c4(args, ctx, J, dev, world, rank, barrier, ranks):
         run(queries[w * QF:(w + 1) * QF], rerank_k)
     ctx.profile(True)
     elapsed = timed_steps(run, queries[args.warmup * QF:], QF, args.steps, rerank_k, barrier)
-    prof = {r: ctx.profile_read(r) for r in ("adc", "sample", "topk", "exact", "lut")}
+    prof = {r: ctx.profile_read(r) for r in ("adc", "adc_exact", "sample", "topk", "exact", "lut")}
     ctx.profile(False)
     # every rank answers every query (one index, one answer): the job's throughput is queries / max-over-ranks time
     elapsed, _, per_rank = aggregate(ranks, elapsed, QF * args.steps)
@@ -542,7 +546,7 @@ def run_c4(args, ctx, J, dev, world, rank, barrier, ranks):
             "adc_distances_per_s": float(QF) * N * args.steps / elapsed,
             "kernel_ms_per_step": {r: prof[r][0] / args.steps for r in prof},
             # the per-shard kernel: every rank scans ITS shard for every query, so the kernel roofline is per GPU
-            "roofline": flat_roofline(QF, n_shard, M, prof["adc"][0], prof["adc"][1], cfg, bq=ctx.stat("adc_bq_calls") > 0), "cpu_baseline": None}
+            "roofline": flat_roofline(QF, n_shard, M, prof["adc"][0], prof["adc"][1], cfg, bq=ctx.stat("adc_bq_calls") > 0, exact_ms=prof["adc_exact"]), "cpu_baseline": None}
     if world == 1 and not args.no_cpu_baseline:
         tq = queries[args.warmup * QF:]
         ids_gpu, _ = run(tq[:QF], rerank_k)
@@ -784,6 +788,8 @@ def _compact_sub(sub):
     for k in ("prune_roofline_frac",):
         if k in sub:
             out[k] = _r(sub[k], 4)
+    if rf.get("hbm_traffic_over_compulsory") is not None:   # the flat scans: counter HBM bytes over one pass over the codes
+        out["hbm_over_compulsory"] = _r(rf["hbm_traffic_over_compulsory"], 4)
     if sub.get("graph_build_s") is not None:     # the graph sub-runs: what the build cost and how long a search is
         out["build_s"] = _r(sub["graph_build_s"], 4)
         out["expanded"] = _r(sub.get("avg_expanded"), 4)
@@ -1099,7 +1105,7 @@ def main():
         run(queries_all[w * Q:(w + 1) * Q], rerank_k)
     ctx.profile(True)
     elapsed = timed_steps(run, timed_q, Q, args.steps, rerank_k, barrier)
-    regions = ("gsearch", "adc", "sample", "topk", "exact", "lut")
+    regions = ("gsearch", "adc", "adc_exact", "sample", "topk", "exact", "lut")
     prof = {r: ctx.profile_read(r) for r in regions}
     ctx.profile(False)
 
@@ -1231,13 +1237,15 @@ def main():
             ctx.profile(True)
             f_el = timed_steps(frun, timed_q, QF, f_steps, f_rk, barrier)
             f_ms, f_n = ctx.profile_read("adc")
+            f_ex = ctx.profile_read("adc_exact")
             ctx.profile(False)
         else:
             f_rk, f_rec, f_se, f_steps, f_el, (f_ms, f_n), QF = rerank_k, rec, rec_se, args.steps, elapsed, prof["adc"], Q
+            f_ex = prof.get("adc_exact")
         flat_info = {"value": QF * f_steps / f_el, "unit": "queries/s", "ms_per_step": f_el / f_steps * 1e3,
                      "queries_per_step": QF, "rerankK": f_rk, "recall_at_10": f_rec, "recall_se": f_se,
                      "adc_distances_per_s": float(QF) * N * f_steps / f_el,
-                     "roofline": flat_roofline(QF, N, M, f_ms, f_n, {**cfg_key, "queries_per_step": QF, "rerankK": f_rk}, bq=ctx.stat("adc_bq_calls") > 0)}
+                     "roofline": flat_roofline(QF, N, M, f_ms, f_n, {**cfg_key, "queries_per_step": QF, "rerankK": f_rk}, bq=ctx.stat("adc_bq_calls") > 0, exact_ms=f_ex)}
 
     if rank == 0:
         if graph_mode:

@@ -341,7 +341,7 @@ int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, i
 {
     clear_error();
     JV_REQUIRE(ctx && region, "NULL argument");
-    static const char *names[R_COUNT] = {"adc", "topk", "exact", "lut", "encode", "norms", "sample", "gsearch", "prune"};
+    static const char *names[R_COUNT] = {"adc", "topk", "exact", "lut", "encode", "norms", "sample", "gsearch", "prune", "adc_exact"};
     int r = -1;
     for (int i = 0; i < R_COUNT; ++i)
         if (strcmp(names[i], region) == 0) r = i;
@@ -1456,7 +1456,7 @@ int jv_hip_search_flat(jv_ctx *ctx, jv_luts *l, const jv_codes *codes, const jv_
                 if (ok) {
                     const int slots = (int)std::min<int64_t>(cap2, ((int64_t)longest + 63) & ~(int64_t)63);
                     {
-                        ProfScope ps(ctx, R_ADC);
+                        ProfScope ps(ctx, R_ADC_EXACT);   // (a region of its own: the exact ADC sums of the bound scan's survivors + the count)
                         JV_TRY(launch_adc_bq_exact(ctx->stream, ctx, l->d_luts, l->d_bmag, Q, codes->M, kvsf, codes->d_codes, codes->d_norms, N,
                                                    d_ks_sc + (k_s - 1), k_s, d_b_ids, d_b_sc, d_b_cnt2, d_b_cnt, cap2, slots));
                     }

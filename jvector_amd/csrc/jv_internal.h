@@ -70,7 +70,7 @@ struct Buffer {
 }  // namespace jv
 
 namespace jv {
-enum Region : int { R_ADC = 0, R_TOPK, R_EXACT, R_LUT, R_ENCODE, R_NORMS, R_SAMPLE, R_GSEARCH, R_PRUNE, R_COUNT };
+enum Region : int { R_ADC = 0, R_TOPK, R_EXACT, R_LUT, R_ENCODE, R_NORMS, R_SAMPLE, R_GSEARCH, R_PRUNE, R_ADC_EXACT, R_COUNT };
 struct ProfEvent {
     int region;
     hipEvent_t start, stop;

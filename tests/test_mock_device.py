@@ -713,6 +713,47 @@ def test_bench_dry_run_on_the_mock(J, monkeypatch, capsys, tmp_path, mode, trave
         assert line["graph"] == graph and (graph != "engine" or line["graph_build"]["nodes_per_s"] > 0)
 
 
+def test_bench_index_cache_hand_over_on_the_mock(J, monkeypatch, capsys, tmp_path):
+    """`bench.py --index-cache FILE` (the hand-over that lets ONE rank build the 10M index and the others load it): the
+    first run builds the graph and writes the npz (graph levels + the quantizer's wire bytes), the second finds it, builds nothing and
+    serves the same index — same calibrated rerankK, same recall, same adjacency statistics."""
+    import json
+    import types
+    import torch
+    import bench
+
+    class TorchProxy:
+        cuda = types.SimpleNamespace(set_device=lambda *_a: None, synchronize=lambda *_a: None,
+                                     current_stream=lambda *_a: types.SimpleNamespace(cuda_stream=0))
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        @staticmethod
+        def device(*_a, **_k):
+            return torch.device("cpu")
+
+    monkeypatch.setattr(bench, "torch", TorchProxy())
+    cache = str(tmp_path / "index.npz")
+    argv = ["bench.py", "--mode", "graph", "--traversal", "device", "--graph", "engine", "--n", "1200", "--dim", "128", "--m", "16", "--degree", "16",
+            "--queries", "48", "--steps", "1", "--warmup", "1", "--eval-queries", "48", "--cal-queries", "48", "--no-flat", "--no-cpu-baseline",
+            "--index-cache", cache]
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("JVECTOR_BENCH_FULL", str(tmp_path / "bench_full.json"))
+    lines = []
+    for _ in range(2):
+        monkeypatch.setattr(sys, "argv", argv)
+        bench.main()
+        compact = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        lines.append(json.load(open(compact["full"])))
+        assert os.path.exists(cache)
+    built, loaded = lines
+    assert built["graph_build"]["nodes_per_s"] > 0 and not loaded.get("graph_build")      # the second run built nothing
+    assert built["config"]["rerankK"] == loaded["config"]["rerankK"] and built["recall_at_10"] == loaded["recall_at_10"]
+    assert built["avg_expanded"] == loaded["avg_expanded"] and built["avg_visited"] == loaded["avg_visited"]
+
+
 @pytest.mark.parametrize("workload,extra", [("c2", ["--n", "3000", "--queries", "32", "--eval-queries", "64", "--rerank", "100"]),
                                             ("c4", ["--n", "3000", "--dim", "128", "--m", "16", "--queries", "16", "--rerank", "40"]),
                                             ("c5", ["--n", "1500", "--dim", "128", "--m", "16", "--degree", "16", "--eval-queries", "32"])])
