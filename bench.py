@@ -632,8 +632,10 @@ def run_c5(args, ctx, J, dev, world, rank, barrier, ranks):
                       "pairs": rd_pairs, "tests": rd_tests, "entries_per_pair": M, "bytes_per_pair": 4 * M, "kernel_ms": p_ms, "launches": p_n,
                       "table_bytes": M * 256 * 257 // 2 * 4, "algorithmic_GBps": rd_pairs * 4.0 * M / (p_ms / 1e3) / 1e9 if p_ms > 0 else 0.0,
                       "note": "pairs / tests are counted by the kernel itself (jv_hip_ctx_get_stat rd_pairs / rd_tests); the ceiling is the divergent-"
-                              "gather rate of the vector-memory pipe for L2 hits (profiles/r2_gather_bench.log), the table's MALL share makes the real "
-                              "ceiling lower (DESIGN.md §7)"}
+                              "gather rate of the vector-memory pipe for L2 HITS (profiles/r2_gather_bench.log) — a ceiling this kernel's access "
+                              "pattern does not have: at the C5 shape its L2 hit rate is 0.19 (profiles/traffic_r5.json, retain_diverse), four of five "
+                              "look-ups are served by the Infinity Cache; read `frac` as an upper bound of what an L2-resident table would allow",
+                      "l2_hit_rate_measured": 0.187}
     line = {"metric": "index build: nodes/s (batched Vamana, PQ scoring) incl. PQ training + encode", "value": N * world / total_s,
             "unit": "nodes/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "per_rank_nodes_per_s": per_rank, "steps": 1, "warmup": 0,
             "ms_per_step": total_s * 1e3, "higher_is_better": True,
