@@ -101,8 +101,8 @@ JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
  *                    queries per CU, 1 / 0 = always / never; gs_wgx_waves, gs_wgx_slots, gs_wgx_depth, gs_wgx_per_cu, gs_wgx_lut_m tune it
  *   gs_pairc         0 = rows of 33 ... 64 neighbours (the builder's working rows) are scored one lane per neighbour instead of
  *                    pair lanes over the compacted fresh list
- *   gs_lutr, gs_ub8, gs_ub8_per_cu, gs_quad   measured-and-lost forms of the one-wave kernel, off by default:
- *                    register-resident table, 8-bit upper-bound table, four lanes per neighbour in short expansions
+ *   gs_quad          a measured-and-lost form of the one-wave kernel (four lanes per neighbour in short expansions), experimental builds
+ *                    only.  (gs_lutr and gs_ub8 — register-resident ADC table, in-kernel 8-bit bound table — left the source in round 6.)
  *   rd_split, rd_wide_stage (default 1), rd_chunk, rd_table_free (default 0)   forms of the robust-prune kernel;
  *                    selections are identical for every setting
  *   bl_insert_alpha_x100, bl_improve_beam   jv_hip_build_layered experiments: another alpha (x 100) for the insert phase, another
@@ -120,7 +120,7 @@ JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
  *   cosine, PQ-96; gs_ubrc, also on by default: the same form over the compacted fresh list of rows 33 ... 64 wide read by ordinal, i.e. the
  *   builder's own searches; gs_ubr_trim = candidates pushed between two trims of its queue), gs_ubr_dropped (neighbours that form dropped
  *   behind their bound, unscored); experimental_build (1: the library was built with make EXPERIMENTAL=1 and also holds the
- *   measured-and-switched-off variants gs_lutr, gs_quad, gs_ub8, rd_table_free, rd_chunk, rd_square — the default build accepts
+ *   measured-and-switched-off variants gs_quad, rd_table_free, rd_chunk, rd_square — the default build accepts
  *   and ignores their options). */
 JV_API int jv_hip_ctx_set_option(jv_ctx *ctx, const char *name, int64_t value);
 JV_API int jv_hip_ctx_clear_option(jv_ctx *ctx, const char *name);

@@ -1297,19 +1297,15 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // in flight per wave) or 4 (JVECTOR_HIP_GS_OCC=4: 128 VGPRs, no pair-lane scoring).  Measured on MI355X at 1M x 768:
     // 2 waves/SIMD + pair lanes 19.0 ms per 16384-query batch; 4 waves/SIMD 25.1 ms; a 3 waves/SIMD build (168 VGPRs, 12 waves
     // per CU) 28.3 ms — fewer gathers in flight per wave cost more than the extra waves hide (profiles/r2_sweeps.md).
-    // gs_lutr = 1: the query's ADC table lives in the wave's registers (64 subspaces, cross-lane reads) + LDS (the rest) instead
-    // of being recomputed from the L2-resident codebook per scored neighbour; one wave per SIMD (4 workers per CU), one lane per
-    // neighbour (k_gsearch.hip graph_search_lutr_kernel).  M <= 96 only.
     // PQ shapes outside the specialised builds (ragged / non-8 sub-vectors, other M) run the generic kernels: one lane per
     // neighbour, the per-subspace geometry read from the quantizer's device tables
     const bool generic = !graph_search_device_specialised(pq, codes, fused) || ctx_opt(ctx, "gs_generic", 0) != 0;  // (option: tests / benches)
     // (the generic kernels need 113 VGPRs: 4 waves per SIMD by default — their byte-wise code reads and short gathers are
     // latency-bound, more resident queries hide more of it)
     const int occ = ctx_opt(ctx, "gs_occ", generic ? 4 : 2) >= 4 ? 4 : 2;
-    const bool lutr = !so && !generic && ctx_opt(ctx, "gs_lutr", 0) != 0 && graph_search_lutr_supported(pq->M);
     // pair-lane scoring (two lanes per neighbour) when no level has more than 32 neighbours; it needs an M/2 x 32 float
     // exchange area in LDS.  gs_pair = 0 turns it off.
-    bool pair = occ == 2 && !lutr && !generic && ctx_opt(ctx, "gs_pair", 1) != 0;
+    bool pair = occ == 2 && !generic && ctx_opt(ctx, "gs_pair", 1) != 0;
     for (int lv = 0; lv <= g->entry_level; ++lv) pair = pair && g->levels[lv].degree <= 32;
     // M >= 128: the pair form's two half rows + exchange indices no longer fit 256 VGPRs (156 / 588 bytes of scratch per
     // lane at M = 128 / 192, -Rpass-analysis=kernel-resource-usage) while the one-lane-per-neighbour form still does
@@ -1323,7 +1319,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     bool one_wave_tuned = false;
     for (const char *o : {"gs_vcap_log2", "gs_v1_log2", "gs_grow", "gs_retry", "gs_occ", "gs_pair", "gs_cand_cap", "gs_waves_per_cu", "gs_prefetch", "gs_prof"})
         one_wave_tuned = one_wave_tuned || ctx_opt_is_set(ctx, o);
-    bool wgx = !so && !generic && !lutr && graph_search_wgx_supported(pq->M) &&
+    bool wgx = !so && !generic && graph_search_wgx_supported(pq->M) &&
                (wgx_opt > 0 || (wgx_opt < 0 && !one_wave_tuned && Q <= 4 * ctx->num_cus));
     for (int lv = 0; lv <= g->entry_level; ++lv) wgx = wgx && g->levels[lv].degree <= 64;
     const int wgx_log = std::min(512, std::max(256, 4 * rerankK));   // push-log entries buffered in LDS (8 bytes each)
@@ -1356,24 +1352,21 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // Rows of 33 ... 64 neighbours with the codes read by ordinal (the builder's working rows: maxDegree x neighborOverflow): the
     // compacted pair form — a lane per neighbour for the visited probe, two lanes per FRESH neighbour for the score (four above
     // M = 96; gs_body.h "PAIRC").  gs_pairc = 0 turns it off.
-    bool pairc = occ == 2 && !so && !wgx && !pair && !lutr && !generic && !fused && pq->M <= 192 && ctx_opt(ctx, "gs_pair", 1) != 0 &&
+    bool pairc = occ == 2 && !so && !wgx && !pair && !generic && !fused && pq->M <= 192 && ctx_opt(ctx, "gs_pair", 1) != 0 &&
                  ctx_opt(ctx, "gs_pairc", 1) != 0;
     for (int lv = 0; lv <= g->entry_level; ++lv) pairc = pairc && g->levels[lv].degree <= 64;
-    // gs_ub8 = 1: the pair-lane kernel with an 8-bit upper-bound table of the query's ADC entries per wave (gs_body.h "UB8": fresh
-    // neighbours that provably cannot be popped skip their exact score).  Costs M x 256 bytes of LDS per wave (fewer waves per CU).
-    const bool ub8 = !so && !wgx && pair && !lutr && fused && !dev_accept.bits && !dev_accept.exclude && ctx_opt(ctx, "gs_ub8", 0) != 0 && graph_search_ub8_supported(pq->M, kvsf);
     // gs_ubr (default: on where it applies): the pair-lane kernel with the batch's upper-bound tables PREBUILT by a dense kernel and
     // held in the wave's registers, survivors compacted and scored eight lanes each, the candidate tier trimmed to what can still be
     // popped (gs_body.h "UBR").  No LDS beyond the pair form's.  Tables: M x 256 bytes per query of the batch.
     // ... and over the compacted fresh list of the builder's 33 ... 64-wide rows (gs_ubrc, default on): PAIRC + UBR
-    const bool ubr = !so && !wgx && (pair || (pairc && ctx_opt(ctx, "gs_ubrc", kGsUbrcDefault) != 0)) && !lutr && !ub8 && occ == 2 && !dev_accept.bits && !dev_accept.exclude &&
+    const bool ubr = !so && !wgx && (pair || (pairc && ctx_opt(ctx, "gs_ubrc", kGsUbrcDefault) != 0)) && occ == 2 && !dev_accept.bits && !dev_accept.exclude &&
                      ctx_opt(ctx, "gs_ubr", kGsUbrDefault) != 0 && graph_search_ubr_supported(pq->M, kvsf)
 #ifdef JV_EXPERIMENTAL
                      && ctx_opt(ctx, "gs_quad", 0) == 0   // (a launch that asks for the four-lane path of the plain pair kernel means that kernel)
 #endif
         ;
     const int pair_M = (pair || pairc) ? pq->M : 0;
-    int cand_cap = wgx ? wgx_cand_cap : std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", lutr ? 256 : (occ == 4 ? 512 : ((pair || pairc) ? 256 : 1024)))) & ~63;
+    int cand_cap = wgx ? wgx_cand_cap : std::max(128, (int)ctx_opt(ctx, "gs_cand_cap", (occ == 4 ? 512 : ((pair || pairc) ? 256 : 1024)))) & ~63;
     while (!wgx && cand_cap > 256 && graph_search_lds_bytes(pq->D, rerankK, cand_cap, pair_M, evict_cap) > 40 * 1024) cand_cap = (cand_cap / 2) & ~63;
     // Visited set, tier 1 (gs_body.h gs_visit1): a two-choice bucketed LDS table of 16-bit entries in whatever the other
     // per-worker structures leave of 160 KB / (4 x occ workers per CU).  Preference: the largest table first (4096 slots = 8 KB
@@ -1382,10 +1375,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // gs_v1_log2 = 0 turns the tier off, a positive value pins it.  Graphs too large for the entry format (more than 14
     // remainder bits) get none.
     const int idbits = gs_idbits(g->n_nodes);
-    const int want_per_cu = lutr ? 4 : 4 * occ;
-    const size_t lut_lds = lutr ? gs_lutr_lds_bytes(pq->M) : (so ? gs_session_lds_bytes() : (ub8 ? gs_ub8_lds_bytes(pq->M) : 0));  // (session kernels: the tracker's arrays)
-    // (UB8: 4 waves per CU instead of 8 — the bound table takes 24 KB at PQ-96)
-    const size_t lds_budget = (160 * 1024) / (size_t)(ub8 ? std::max(2, (int)ctx_opt(ctx, "gs_ub8_per_cu", 4)) : want_per_cu) - 256 - lut_lds;
+    const int want_per_cu = 4 * occ;
+    const size_t lut_lds = so ? gs_session_lds_bytes() : 0;  // (session kernels: the tracker's arrays)
+    const size_t lds_budget = (160 * 1024) / (size_t)want_per_cu - 256 - lut_lds;
     int v1_log2 = 0;
     if (wgx) {
         // the workgroup owns the CU's LDS: the largest tier that fits next to the table (16384 slots hold every search of the
@@ -1546,15 +1538,13 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.v1_log2 = v1_log2;
     p.v1_idbits = idbits;
     p.prefetch = (ctx_opt(ctx, "gs_prefetch", 0) != 0 && evict_cap >= 48 && !generic) ? 1 : 0;  // (dword touches: aligned rows only)
-    p.lutr = lutr ? 1 : 0;
-    p.ub8 = ub8 ? 1 : 0;
     if (ubr) {
         const size_t tab_bytes = (gs_ubr_tab_bytes(pq->M) * (size_t)Q + 255) & ~(size_t)255;
         JV_TRY(ctx->d_gs_ubr.reserve(tab_bytes + sizeof(float) * 4 * (size_t)Q));
         p.ubr = 1;
         p.ubr_tab = (const uint32_t *)ctx->d_gs_ubr.ptr;
         p.ubr_meta = (const float *)((const char *)ctx->d_gs_ubr.ptr + tab_bytes);
-        p.ubr_trim = std::max(1, (int)ctx_opt(ctx, "gs_ubr_trim", 48));
+        p.ubr_trim = std::max(1, (int)ctx_opt(ctx, "gs_ubr_trim", 16));   // (round 6: trims run from registers and cost a fifth of what they did: 16 is 0.6 % faster than 48, profiles/r6_l)
         p.ubr_count = (unsigned long long *)(base + o_prof) + 15;
         ProfScope ps(ctx, R_LUT);
         JV_TRY(launch_ubr_tables(ctx->stream, kvsf, pq->d_codebooks, l->d_queries, Q, pq->M, (uint32_t *)ctx->d_gs_ubr.ptr,

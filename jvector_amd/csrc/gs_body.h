@@ -285,18 +285,6 @@ GS_FN float gs_row_sum_any(const GsParams &p, const float *qs, const uint8_t *rp
     return sum;
 }
 
-// ---- the query's ADC table held by the wave itself (M <= 96): M x 256 f32 = 96 KB at PQ-96 — too large for a wave's LDS
-//      share — split between the wave's VECTOR REGISTERS and LDS.  Subspaces m < GS_LUT_REG_SUB (64): entry (m, code) lives in
-//      lane code & 63, register 4 m + (code >> 6) — 256 registers per lane, half of the 512 a wave owns at one wave per SIMD — and
-//      a look-up is a cross-lane read (gs_shfl32 -> ds_bpermute_b32: the LDS crossbar, no storage, no bank conflicts): the four
-//      registers of subspace m are fetched from lane code & 63 and code >> 6 picks one.  Subspaces m >= 64 (32 of them at
-//      PQ-96): a plain [m - 64][256] f32 table in LDS (32 KB).  This replaces the table-free form's 2 x 16-byte gathers per
-//      (neighbour, subspace) from the L2-resident codebook — the traffic that saturates a CU's vector-memory path.
-//      The entries are computed ONCE per query by the very arithmetic of gs_row_sum (calculatePartialSums entry by entry) and
-//      summed in ascending m, so scores keep their bits.  Every lane must execute the cross-lane reads (a lane's registers are
-//      only readable while it is active): callers do not branch around gs_row_sum_lut.
-constexpr int GS_LUT_REG_SUB = 64;
-
 template <int VSF>
 GS_FN float gs_lut_entry_from(const gs_f4 c0, const gs_f4 c1, const float *q);
 template <int VSF>
@@ -383,52 +371,6 @@ GS_FN float gs_lut_entry_pk_q(const gs_f4 c0, const gs_f4 c1, const gs_f4 q0, co
 #endif
     const float q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
     return gs_lut_entry_from<VSF>(c0, c1, q);
-}
-
-template <int VSF, int CH16>
-GS_FN void gs_lut_build(const float *codebooks, const float *qs, float (&lut)[(CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB) * 4],
-                        float *lut_lds)
-{
-    constexpr int M = CH16 * 16, MR = M < GS_LUT_REG_SUB ? M : GS_LUT_REG_SUB;
-    const int lane = gs_lane();
-#pragma unroll
-    for (int m = 0; m < MR; ++m) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lut[m * 4 + r] = gs_lut_entry<VSF>(codebooks, qs, m, r * 64 + lane);
-    }
-    for (int m = MR; m < M; ++m)   // the LDS part: coalesced stores, lane = code & 63
-        for (int r = 0; r < 4; ++r) lut_lds[(m - MR) * 256 + r * 64 + lane] = gs_lut_entry<VSF>(codebooks, qs, m, r * 64 + lane);
-}
-
-template <int CH16>
-GS_FN float gs_row_sum_lut(const float (&lut)[(CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB) * 4], const float *lut_lds,
-                           const gs_u4 (&w)[CH16])
-{
-    constexpr int M = CH16 * 16, MR = M < GS_LUT_REG_SUB ? M : GS_LUT_REG_SUB;
-    float sum = 0.0f;
-#pragma unroll
-    for (int c = 0; c < CH16; ++c) {
-        const uint32_t d[4] = {w[c].x, w[c].y, w[c].z, w[c].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int m = c * 16 + e * 4 + b;
-                const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
-                if (m < MR) {
-                    const int src = (int)(code & 63u);
-                    const int mr = m < MR ? m : 0;
-                    const int32_t v0 = gs_shfl32(gs_float_bits(lut[mr * 4 + 0]), src), v1 = gs_shfl32(gs_float_bits(lut[mr * 4 + 1]), src);
-                    const int32_t v2 = gs_shfl32(gs_float_bits(lut[mr * 4 + 2]), src), v3 = gs_shfl32(gs_float_bits(lut[mr * 4 + 3]), src);
-                    const uint32_t r = code >> 6;
-                    sum += gs_bits_float(r < 2u ? (r == 0u ? v0 : v1) : (r == 2u ? v2 : v3));
-                } else {
-                    sum += lut_lds[(m - MR) * 256 + (int)code];
-                }
-            }
-        }
-    }
-    return sum;
 }
 
 // ---- the workgroup form's score: the query's whole ADC table [M][256] f32 sits in LDS (gx_body.h gx_lut_build wrote it with
@@ -529,114 +471,19 @@ GS_FN float gs_half_entries(const float *codebooks, const float *qs, const gs_u2
     return sum;
 }
 
-// ---- UB8: an 8-bit UPPER-BOUND table of the query's ADC entries (dot product / cosine; pair-lane kernels) --------------------------
+// ---- why a bound may drop a neighbour (the argument UBR rests on; round 4's UB8 form introduced it) ------------------------------
 // Most neighbours a search scores are never popped: a node is only expanded if, at its turn, fewer than rerankK nodes with a
 // strictly greater score have been popped.  So once >= rerankK nodes with exact score >= T are known (queued or popped, all of them
 // able to become results: scores >= 0, no NaN, no acceptOrds filter), a neighbour whose score is < T can never be expanded — the
 // reference would mark it visited, score it, push it, and never look at it again.  Its exact score (M codebook gathers) is therefore
 // not needed IF a cheap rigorous upper bound already shows score < T: the table holds, per (subspace, code), the entry's upper
-// bucket edge in 8 bits (ub = lo_m + S_m * (b + 1) >= entry, checked entry by entry when the table is built), a row's bound is
-// sum_lo + sum_m S_m * (b_m + 1) + slack (slack covers every rounding of the reference's f32 chain and of this sum, 40x over), and the
-// finishing transform is monotone.  T comes from the candidate queue itself: after a partition every key of the LDS tier exceeds
-// the pivot, so when (LDS-tier keys + result keys above the pivot) >= rerankK the pivot's score is such a T; so is the worst kept
-// result once the result queue is full.  Dropped neighbours are counted in visitedCount (they were marked) and are simply not
-// pushed: results, scores, visitedCount and expandedCount are unchanged (tests: every parity test of the traversal runs with the
-// form on).  Measured on the headline index: 56-68 % of the scored neighbours qualify (scripts/ub8_study.py, profiles/r4_o).
-#ifndef GS_HAVE_WAVE_REDUCE_F32
-GS_FN float gs_wave_max_f32(float v)
-{
-    for (int o = 32; o > 0; o >>= 1) {
-        const float t = gs_bits_float((int32_t)gs_shfl_xor((long long)gs_float_bits(v), o));
-        v = t > v ? t : v;
-    }
-    return v;
-}
-GS_FN float gs_wave_min_f32(float v)
-{
-    for (int o = 32; o > 0; o >>= 1) {
-        const float t = gs_bits_float((int32_t)gs_shfl_xor((long long)gs_float_bits(v), o));
-        v = t < v ? t : v;
-    }
-    return v;
-}
-#endif
+// bucket edge in 8 bits (ub = lo_m + S * (b + 1) >= entry), a row's bound is base + S * sum_m (b_m + 1) (base carries a slack that
+// covers every rounding of the reference's f32 chain and of this sum), and the finishing transform is monotone.  Dropped neighbours
+// are counted in visitedCount (they were marked) and are simply not pushed: results, scores, visitedCount and expandedCount are
+// unchanged.  (UB8 — the table built by the traversal wave itself, 24 KB of LDS per wave, survivors scored in place — was 2.3x
+// slower than the plain pair form and left the source in round 6; its measurements: profiles/r4_o ... r4_zz, scripts/ub8_study.py.)
 
-struct GsUb8 {
-    uint8_t *tab;    // [M][256] bucket index of every entry
-    float *lo;       // [M] low edge of subspace m's entries
-    float *scale;    // [M] bucket width
-    float sum_lo;    // sum_m lo[m]
-    float slack;     // added to every bound: rounding of the reference chain and of the bound's own sum
-    bool ok;         // false: the query produced a NaN / inf entry — no bound, nothing is dropped
-};
-
-// the whole wave builds the table of one query; qs = the centred query in LDS
-template <int VSF, int CH16>
-GS_FN void gs_ub8_build(const float *codebooks, const float *qs, GsUb8 &u)
-{
-    constexpr int M = CH16 * 16;
-    const int lane = gs_lane();
-    float sum_lo = 0.0f, sum_abs = 0.0f;
-    bool ok = true;
-    for (int m = 0; m < M; ++m) {
-        float e[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = gs_lut_entry<VSF>(codebooks, qs, m, r * 64 + lane);
-        float mn = e[0] < e[1] ? e[0] : e[1], mx = e[0] > e[1] ? e[0] : e[1];
-        mn = e[2] < mn ? e[2] : mn;
-        mn = e[3] < mn ? e[3] : mn;
-        mx = e[2] > mx ? e[2] : mx;
-        mx = e[3] > mx ? e[3] : mx;
-        const bool bad = !(e[0] - e[0] == 0.0f) || !(e[1] - e[1] == 0.0f) || !(e[2] - e[2] == 0.0f) || !(e[3] - e[3] == 0.0f);   // NaN / inf
-        ok = ok && gs_ballot(bad) == 0;
-        mn = gs_wave_min_f32(mn);
-        mx = gs_wave_max_f32(mx);
-        float S = (mx - mn) / 255.0f;
-        if (!(S > 1e-30f)) S = 1e-30f;
-        const float inv = 1.0f / S;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int b = (int)((e[r] - mn) * inv);
-            b = b < 0 ? 0 : (b > 255 ? 255 : b);
-            while (b < 255 && mn + S * (float)(b + 1) < e[r]) ++b;   // the bucket's upper edge really is an upper bound, in f32
-            u.tab[m * 256 + r * 64 + lane] = (uint8_t)b;
-        }
-        if (lane == 0) {
-            u.lo[m] = mn;
-            u.scale[m] = S;
-        }
-        sum_lo += mn;
-        const float amn = mn < 0.0f ? -mn : mn, amx = mx < 0.0f ? -mx : mx;
-        sum_abs += (amn > amx ? amn : amx) + 256.0f * S;
-    }
-    u.sum_lo = sum_lo;
-    u.slack = 4e-5f * sum_abs;
-    u.ok = ok && (sum_abs - sum_abs == 0.0f);
-    gs_barrier();
-}
-
-// this lane's half of a row's bound: sum over its HW * 8 subspaces of S_m * (b_m + 1)
-template <int HW>
-GS_FN float gs_ub8_half(const GsUb8 &u, const gs_u2 (&w)[HW], int m_base)
-{
-    float acc = 0.0f;
-#pragma unroll
-    for (int c = 0; c < HW; ++c) {
-        const uint32_t d[2] = {w[c].x, w[c].y};
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int m = m_base + c * 8 + e * 4 + b;
-                const uint32_t code = (d[e] >> (8 * b)) & 0xFFu;
-                acc += u.scale[m] * (float)((int)u.tab[m * 256 + (int)code] + 1);
-            }
-        }
-    }
-    return acc;
-}
-
-// ---- UBR: the upper-bound form that finishes what UB8 started (round 5) -------------------------------------------------------------
+// ---- UBR: the upper-bound form (round 5; it finishes what round 4's UB8 started) -------------------------------------------------------------
 // UB8 was sound and dropped 60 % of the scored neighbours, and was 2.3x slower: its table was built by the traversal wave itself
 // (355 k clocks per query), took 24 KB of LDS per wave (4 waves per CU, no room for the visited set's LDS tier) and the neighbours it
 // kept were scored in place (dead lanes free no gather instructions).  UBR removes the three:
@@ -653,7 +500,7 @@ GS_FN float gs_ub8_half(const GsUb8 &u, const gs_u2 (&w)[HW], int m_base)
 //   * the threshold: T = the score of a candidate such that >= rerankK known nodes (queued or kept results) score strictly higher —
 //     found every `ubr_trim` pushes among 64 samples of the candidate tier by bisection on exact counts — and the candidates at or
 //     below it are DISCARDED with it (they can never be popped either), so the tier stays around rerankK keys and pops scan little.
-// Soundness is UB8's (see above); every parity test of the pair-lane traversal runs with this form as well.
+// Soundness: see above; every parity test of the pair-lane traversal runs with this form as well.
 template <int CH16>
 GS_FN void gs_ubr_load(const uint32_t *tab_q, uint32_t (&tab)[CH16 * 16])
 {
@@ -1182,7 +1029,6 @@ GS_FN void gs_ubr_trim(GsState &s, int rk, float &T)
 // PAIR: every level's degree is <= 32 -> pair-lane scoring (decided by the host at launch)
 // PROF: developer aid — per-phase shader-clock totals of the expansion loop are added to p.prof[0..7]
 //       (pop, result insert, row + block + visited probes, scoring, push, expansions, queries, setup + epilogue)
-// LUTR: the query's ADC table lives in registers (gs_lut_build / gs_row_sum_lut; one lane per neighbour, PAIR must be false)
 // SES:  GraphSearcher OBJECTS (jv_hip_searcher_*): layer 0 admits `score >= p.threshold` (:437) and, for threshold > 0, stops
 //       through ScoreTracker.TwoPhaseTracker (ScoreTracker.java:80-140: a 500-score window + the 100 best scores, both in LDS);
 //       expandedCountBaseLayer is reported.  What reranking / resume need beyond that is rebuilt by the host from the
@@ -1191,21 +1037,16 @@ GS_FN void gs_ubr_trim(GsState &s, int rk, float &T)
 //       rows, maxDegree x neighborOverflow): one lane per neighbour probes the visited set, the unvisited ids are compacted
 //       through LDS and scored two lanes each like PAIR (<= 32 per pass, a second pass for the rest; M > 96: four lanes each,
 //       16 per pass).  LDS layout = PAIR's.
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false, bool PAIRC = false, bool UBR = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool SES = false, bool PAIRC = false, bool UBR = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
-    static_assert(!UBR || ((PAIR != PAIRC) && !SES && !LUTR && !UB8 && VSF != 0 && CH16 % 2 == 0 && 60 * CH16 * 16 + 256 <= 64 * CH16 * 16),
+    static_assert(!UBR || ((PAIR != PAIRC) && !SES && VSF != 0 && CH16 % 2 == 0 && 60 * CH16 * 16 + 256 <= 64 * CH16 * 16),
                   "the register-table bound form serves the pair-lane kernels (over the row, or over the compacted fresh list), dot product / cosine, M a multiple of 32 and >= 64");
     static_assert(!(UBR && PAIRC) || CH16 <= 6, "the bound form of the compacted pair kernel: two lanes per neighbour (M <= 96)");
-    static_assert(!PAIRC || (!PAIR && !LUTR && !UB8 && CH16 > 0), "the compacted pair form is a variant of the plain one-lane-per-neighbour kernel");
+    static_assert(!PAIRC || (!PAIR && CH16 > 0), "the compacted pair form is a variant of the plain one-lane-per-neighbour kernel");
     constexpr bool XA = PAIR || PAIRC;   // the worker's LDS block has the [M/2][32] exchange area
-    static_assert(!(LUTR && PAIR), "the register-resident table serves the one-lane-per-neighbour form");
-    static_assert(!UB8 || (PAIR && !SES && !LUTR && VSF != 0), "the upper-bound table serves the pair-lane kernels, dot product / cosine");
-    static_assert(CH16 > 0 || !(LUTR || PAIR), "the generic form (CH16 = 0) is one lane per neighbour, table-free");
+    static_assert(CH16 > 0 || !PAIR, "the generic form (CH16 = 0) is one lane per neighbour, table-free");
     constexpr int CW = CH16 > 0 ? CH16 : 1;  // code words a lane holds (the generic form reads its row from memory instead)
-    constexpr int LUT_MR = CH16 * 16 < GS_LUT_REG_SUB ? CH16 * 16 : GS_LUT_REG_SUB;
-    float lut[LUTR ? LUT_MR * 4 : 1];
-    float *lut_lds = nullptr;  // LUTR: the table of subspaces >= GS_LUT_REG_SUB, at the very end of the worker's LDS block
     unsigned long long pf[5] = {0, 0, 0, 0, 0};
     unsigned long long fh[4] = {0, 0, 0, 0};  // PROF: scored neighbours in expansions with <= 8 / <= 16 / <= 24 / <= 32 fresh ones
     unsigned long long pt = 0, pq0 = 0;
@@ -1348,29 +1189,14 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     }
     gs_fence();
     gs_barrier();
-    if constexpr (LUTR) {
-        lut_lds = reinterpret_cast<float *>(lds + gs_lds_bytes(p.D, p.rerankK, p.cand_cap, 0, evict_cap, p.v1_log2));
-        gs_lut_build<VSF, CH16>(p.codebooks, qs, reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds);
-        gs_barrier();
-    }
     const float query_mag = (VSF == 2) ? p.bmag[q] : 0.0f;
     const unsigned long long *acc = p.accept ? p.accept + (long long)q * p.accept_stride : nullptr;
     const int32_t excl = p.exclude ? p.exclude[q] : -1;
-    // ---- UB8: the query's upper-bound table, behind the worker's block; the pop threshold it is compared with (wave-uniform) ----
-    GsUb8 ub{};
-    float ub_T = -__builtin_inff();       // >= rerankK nodes with exact score >= ub_T are known (queued or popped)
-    long long ub_last_spill_max = GS_KEY_MIN;
+    // ---- the bound form's pop threshold (wave-uniform): >= rerankK nodes with exact score >= ub_T are known (queued or popped) ----
+    float ub_T = -__builtin_inff();
     bool ub_on = false;
     unsigned long long ub_dropped = 0;
-    if constexpr (UB8) {
-        char *ub_base = lds + gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.M, evict_cap, p.v1_log2);
-        ub.tab = reinterpret_cast<uint8_t *>(ub_base);
-        ub.lo = reinterpret_cast<float *>(ub_base + (size_t)p.M * 256);
-        ub.scale = ub.lo + p.M;
-        gs_ub8_build<VSF, CH16>(p.codebooks, qs, ub);
-        ub_on = ub.ok && acc == nullptr && excl < 0 && p.blocks != nullptr;   // (acceptOrds: rejected nodes never become results — no threshold)
-    }
-    (void)ub_last_spill_max;
+    (void)ub_T;
     (void)ub_dropped;
     // ---- UBR: the query's prebuilt bound table in registers; base / scale of its bounds; pushes since the last trim ----
     uint32_t ubtab[UBR ? CH16 * 16 : 1];
@@ -1402,11 +1228,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         if constexpr (CH16 == 0) {
             sc = gs_row_sum_any<VSF>(p, qs, p.codes + (int64_t)e * p.M);
         } else {
-            if constexpr (LUTR) {
-                gs_u4 we[CW];
-                gs_load_row<CW>(p.codes + (int64_t)e * p.M, we);
-                sc = gs_row_sum_lut<CW>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, we);
-            } else {
+            {
                 // The entry row's M table entries are formed by the lanes side by side (lane l: subspaces l, l + 64, ...) and parked in
                 // the still empty candidate tier; every lane then adds them in ascending m — assembleAndSum's order, the same bits.
                 // (One lane walking the row waited for M dependent-in-practice L2 round trips: ~55 k of a query's ~2 M clocks, round 5.)
@@ -1425,7 +1247,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         sc = gs_finish<VSF>(sc, (VSF == 2) ? p.code_norms[e] : 0.0f, query_mag);
         if (lane == 0) s.cand[0] = gs_key(e, sc);
         s.cand_n = 1;
-        if ((UB8 || UBR) && sc != sc) ub_on = false;
+        if (UBR && sc != sc) ub_on = false;
         gs_barrier();
     }
 
@@ -1822,26 +1644,6 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     if (PROF) fh[1] += GS_CLOCK() - ubc0;
                 } else {
                 uint64_t fm_score = fm;   // fresh neighbours that get an exact score
-                if constexpr (UB8) {
-                    // drop what provably cannot be popped: bound of every fresh neighbour (two half sums, joined through the exchange
-                    // area's first row), finished like a score, against the threshold
-                    if (ub_on && lvl == 0 && ub_T > -__builtin_inff()) {
-                        const bool wk = ((fm >> ni) & 1ull) != 0;
-                        const float half = wk ? gs_ub8_half<CH16>(ub, w, m_base) : 0.0f;
-                        if (hi && wk) xchg[ni] = half;
-                        gs_barrier();
-                        bool drop = false;
-                        if (fresh) {
-                            const float braw = ub.sum_lo + (half + xchg[ni]) + ub.slack;
-                            drop = gs_finish<VSF>(braw, node_mag, query_mag) < ub_T;
-                        }
-                        const uint64_t dm = gs_ballot(drop);
-                        gs_barrier();   // (the exchange area is written again by the scoring below)
-                        fm_score = fm & ~dm;
-                        ub_dropped += (unsigned long long)gs_popc(dm);
-                        if (drop) fresh = false;
-                    }
-                }
                 // ---- GsParams::quad (off by default): at most 16 fresh neighbours -> FOUR lanes each, spread over all 64 lanes: lane
                 //      16 t + g takes subspaces [t M/4, (t + 1) M/4) of the g-th fresh neighbour (row order), its code words come
                 //      from the pair lanes that loaded them (ds_bpermute), lanes 0 ... 15 add all M entries in ascending m.  Half
@@ -1849,7 +1651,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 //      6 % slower (graph_search.cpp gs_quad): what one lane per neighbour loses against pair lanes (33.7 vs 19.0
                 //      ms) is the length of the dependent per-lane chain, not a per-instruction charge of the memory path.
 #ifdef JV_EXPERIMENTAL   // (gs_quad is a measured-and-switched-off variant: experimental builds and the CPU test harnesses only)
-                constexpr bool QUAD_OK = !UB8 && CH16 % 2 == 0;   // (a lane's M/4 code bytes are whole 8-byte words)
+                constexpr bool QUAD_OK = CH16 % 2 == 0;   // (a lane's M/4 code bytes are whole 8-byte words)
 #else
                 constexpr bool QUAD_OK = false;
 #endif
@@ -2094,10 +1896,6 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     const uint8_t *rp = nullptr;  // generic form: where the lane's code row lives
                     (void)w;
                     (void)rp;
-                    if constexpr (LUTR) {  // every lane takes part in the cross-lane reads below: no uninitialised code words
-#pragma unroll
-                        for (int c = 0; c < CW; ++c) w[c] = gs_u4{0u, 0u, 0u, 0u};
-                    }
                     float node_mag = 0.0f;
                     if (fused0 && li < deg) {  // FusedPQDecoder.similarityToNeighbor: the origin's packed block (zero padded)
                         const int64_t r = (int64_t)node * p.deg0 + li;
@@ -2128,9 +1926,6 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     key = 0;
                     if constexpr (CH16 == 0) {
                         if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum_any<VSF>(p, qs, rp), node_mag, query_mag));
-                    } else if constexpr (LUTR) {
-                        const float raw = gs_row_sum_lut<CW>(reinterpret_cast<float (&)[LUT_MR * 4]>(lut), lut_lds, w);  // all lanes
-                        if (fresh) key = gs_key(nb, gs_finish<VSF>(raw, node_mag, query_mag));
                     } else {
                         if (fresh) key = gs_key(nb, gs_finish<VSF>(gs_row_sum<VSF, CW>(p.codebooks, qs, w), node_mag, query_mag));
                     }
@@ -2156,30 +1951,10 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             if constexpr (SES) {
                 if (thr_on) trk_track(fresh, gs_key_score(key));
             }
-            if constexpr (UB8 || UBR) {   // a NaN score sorts above everything but never becomes a result: no threshold can be proven with one around
+            if constexpr (UBR) {   // a NaN score sorts above everything but never becomes a result: no threshold can be proven with one around
                 if (ub_on && gs_ballot(fresh && (int32_t)(key >> 32) == 0x7fc00000)) ub_on = false;
             }
             gs_push(s, p, key, fresh);
-            if constexpr (UB8) {
-                // ---- the pop threshold: the worst kept result once the result queue is full; the partition pivot once the LDS
-                //      tier (every key above it) plus the results above it number rerankK ----
-                if (ub_on && lvl == 0 && s.status == GS_OK) {
-                    if (s.res_n >= rk) {
-                        const float t = gs_key_score(s.res_min);
-                        if (t > ub_T) ub_T = t;
-                    }
-                    if (s.spill_max != ub_last_spill_max) {
-                        ub_last_spill_max = s.spill_max;
-                        const float ps = gs_key_score(s.spill_max);
-                        if (s.spill_n > 0 && ps >= 0.0f && ps > ub_T) {
-                            int above = 0;
-                            for (int base = 0; base < s.res_n; base += 64)
-                                above += gs_popc(gs_ballot(base + lane < s.res_n && s.res[base + lane] > s.spill_max));
-                            if (s.cand_n + above >= rk) ub_T = ps;
-                        }
-                    }
-                }
-            }
             GS_PHASE(4);
             if (s.status != GS_OK) break;
         }
@@ -2265,13 +2040,12 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         gs_fetch_add64(p.prof + 14, GS_CLOCK() - pep0);
         if (UBR) for (int i = 0; i < 7; ++i) gs_fetch_add64(p.prof + 16 + i, py[i]);
     }
-    if (UB8 && p.prof && lane == 0) gs_fetch_add64(p.prof + 15, ub_dropped);   // (tests / studies / gs_prof read the drop count)
     if (UBR && p.ubr_count && lane == 0) gs_fetch_add64(p.ubr_count, ub_dropped);
 #undef GS_PHASE
 }
 
 // Persistent worker: pulls queries off the shared counter until none are left.
-template <int VSF, int CH16, bool PAIR, bool PROF = false, bool LUTR = false, bool SES = false, bool UB8 = false, bool PAIRC = false, bool UBR = false>
+template <int VSF, int CH16, bool PAIR, bool PROF = false, bool SES = false, bool PAIRC = false, bool UBR = false>
 GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
 {
     for (;;) {
@@ -2279,7 +2053,7 @@ GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
         if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
         const int item = (int)gs_shfl(qv, 0);
         if (item >= p.Q) break;
-        gs_search_one<VSF, CH16, PAIR, PROF, LUTR, SES, UB8, PAIRC, UBR>(p, p.qmap ? p.qmap[item] : item, worker, lds);
+        gs_search_one<VSF, CH16, PAIR, PROF, SES, PAIRC, UBR>(p, p.qmap ? p.qmap[item] : item, worker, lds);
     }
 }
 

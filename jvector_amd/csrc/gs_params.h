@@ -79,16 +79,11 @@ struct GsParams {
     const long long *ph_extra;      // keys of all transitions, query-major inside a phase
     const int32_t *ph_extra_off;    // (n_phases - 1) * ph_Q + 1 offsets into ph_extra: transition t of query q = [t * ph_Q + q, t * ph_Q + q + 1)
     int32_t ph_Q;                   // queries of the searcher (a launch may cover a part of them: Q / qmap above)
-    int32_t lutr;             // 1: the query's ADC table lives in the wave's registers (M <= 96; one wave per SIMD; no pair lanes)
     int32_t prefetch;         // 1: touch the runner-up candidate's adjacency row + fused block while the popped one is scored (layer 0)
     int32_t v1_log2;          // log2(slots) of the LDS tier (slots / 4 buckets of four 16-bit entries), 0 = no LDS tier
     int32_t v1_idbits;        // node ids are < 1 << v1_idbits; v1_idbits - (v1_log2 - 2) <= 14 remainder bits + the choice bit
     // the workgroup form (gx_body.h, k_gsearch_wgx.hip): ONE query per workgroup — the query's ADC table (M x 256 f32) lives in LDS,
     // wave 0 runs the GraphSearcher loop and the other waves ("expanders") score whole adjacency rows it asks for ahead of time
-    // UB8 (one-wave pair-lane kernels, dot product / cosine, layer 0): every wave holds an 8-bit UPPER-BOUND table of its query's ADC
-    // entries in LDS; a fresh neighbour whose bound lies below a proven pop threshold is counted as visited and dropped without
-    // its exact score (gs_body.h "UB8")
-    int32_t ub8;
     // UBR (gs_body.h "UBR", k_gsearch_ubr.hip; dot product / cosine, layer 0, M = 96): the 8-bit upper-bound table of every query is
     // PREBUILT by a dense kernel (ubr_table_kernel: [Q][M / 4][64] x 16 bytes, one scale per query) and held in the wave's
     // REGISTERS (M dwords per lane, looked up with ds_bpermute) — no LDS, the visited set's LDS tier and 8 waves per CU stay; the
@@ -138,12 +133,6 @@ constexpr size_t gs_lds_bytes(int D, int rerankK, int cand_cap, int pair_M /* M 
                         sizeof(float) * gs_xchg_floats(pair_M) + (pair_M ? 8 : 0);
     return v1_log2 > 0 ? ((base + 15) & ~(size_t)15) + ((size_t)2 << v1_log2) : base;
 }
-
-// LDS bytes of the register/LDS split ADC table (gs_body.h gs_lut_build): the subspaces past the 64 held in registers
-constexpr size_t gs_lutr_lds_bytes(int M) { return M > 64 ? (size_t)(M - 64) * 256 * sizeof(float) : 0; }
-
-// LDS bytes of the UB8 form's per-wave bound table: M x 256 bytes + per-subspace {low edge, scale} floats
-constexpr size_t gs_ub8_lds_bytes(int M) { return (size_t)M * 256 + sizeof(float) * 2 * (size_t)M + 16; }
 
 // UBR lives in the pair-lane exchange area: [7 M / 8 entries x 8 owners of f32][32 node ids][32 magnitudes][32 x M code bytes]
 constexpr size_t gs_ubr_xchg_bytes(int M) { return sizeof(float) * 7 * (size_t)M + 256 + 32 * (size_t)M; }

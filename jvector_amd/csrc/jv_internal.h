@@ -413,8 +413,6 @@ bool graph_search_device_supported(const jv_pq *pq, const jv_codes *codes, const
 bool graph_search_device_specialised(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused);  // else: the generic kernels
 size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int evict_cap = 0, int v1_log2 = 0);
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy);
-bool graph_search_lutr_supported(int M);
-bool graph_search_ub8_supported(int M, int kernel_vsf);
 // the register-table bound form (gs_body.h "UBR", k_gsearch_ubr.hip): tables of a batch, then the traversal
 bool graph_search_ubr_supported(int M, int kernel_vsf);
 int launch_ubr_tables(hipStream_t s, int vsf, const float *codebooks, const float *cq, int Q, int M, uint32_t *tab, float *meta);

@@ -33,6 +33,7 @@ struct AdcBqParams {
     int cap2;
     int64_t first, count;
     int Q, M_total;
+    int xcd_order;           // 1: tiles dealt to XCDs, a tile's query groups back to back (adc_bq_kernel)
 };
 
 __device__ __forceinline__ float bq_wave_min(float v)
@@ -137,8 +138,25 @@ __global__ __launch_bounds__(1024) void adc_bq_kernel(AdcBqParams p)
 {
     constexpr int SL = 16 * SLCH;   // subspaces per LDS slice
     extern __shared__ __attribute__((aligned(16))) uint4 lds16[];   // [SL * 256] words of sixteen buckets
-    const int g = (int)blockIdx.x, q0 = g * BQ_P;
-    const int64_t tile_base = (int64_t)blockIdx.y * (1024 * R);
+    // XCD-aware block order (round 6).  Workgroups are dealt to the 8 XCDs round-robin by linear id; with the plain (group, tile) grid an
+    // XCD served the query groups = its number (mod 8) and every tile of codes was pulled into all eight L2s — and, because the blocks
+    // of one tile ran at different times, mostly from HBM again: FETCH_SIZE 30 GB per launch at the C4 shard, 24x one pass over the
+    // codes (profiles/traffic_r6.json).  Remapped: XCD k takes the tiles = k (mod 8) and runs ALL query groups of a tile back to back,
+    // so a tile (786 KB at PQ-96) is read from HBM once and served to the other groups by that XCD's L2.  (The last T % 8 tiles keep
+    // the plain order.)
+    int g = (int)blockIdx.x, tile = (int)blockIdx.y;
+    {
+        const int G = (int)gridDim.x, T = (int)gridDim.y, Tfull = T & ~7;
+        const int64_t L = (int64_t)blockIdx.x + (int64_t)G * blockIdx.y;
+        if (p.xcd_order && L < (int64_t)G * Tfull) {
+            const int k = (int)(L & 7);
+            const int64_t pos = L >> 3;
+            g = (int)(pos % G);
+            tile = (int)(pos / G) * 8 + k;
+        }
+    }
+    const int q0 = g * BQ_P;
+    const int64_t tile_base = (int64_t)tile * (1024 * R);
     const int tid = (int)threadIdx.x;
     const int nslices = p.M_total / SL;
     const uint4 *gtab = reinterpret_cast<const uint4 *>(p.tab) + (int64_t)g * p.M_total * kClusters;
@@ -353,6 +371,10 @@ int launch_adc_bq_scan(hipStream_t s, const jv_ctx *ctx, const float *d_luts, co
     p.surv_ids = d_ids; p.surv_cnt = d_surv_cnt; p.cap2 = cap2; p.first = first; p.count = count; p.Q = Q; p.M_total = M;
     const int slch = (M % 32 == 0) ? 2 : 1;
     const int64_t groups = (Q + BQ_P - 1) / BQ_P;
+    // tile-wise XCD order when a tile's query groups are few (<= 32: C4 / flat_mode, 16 groups — FETCH_SIZE 24x -> 5x one pass over the
+    // codes); with many groups (C2: 64) one XCD would cycle through every group's table per tile and the plain order, where an XCD
+    // keeps the tables of ITS eight groups, misses less (9x against 28x; profiles/traffic_r6.json).  Neither changes the scan's time.
+    p.xcd_order = (getenv("JVECTOR_HIP_ADC_BQ_PLAIN_ORDER") || groups > 32) ? 0 : 1;
     const int R = groups * ((count + 1024 * 8 - 1) / (1024 * 8)) >= 2 * (int64_t)ctx->num_cus ? 8 : 4;
 #define JV_BQV(V)                                                      \
     do {                                                               \

@@ -47,67 +47,9 @@ template <int VSF, int CH16>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_pairc_kernel(GsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_lds[];
-    gs_worker<VSF, CH16, false, false, false, false, false, true>(p, (int)blockIdx.x, gs_lds);
+    gs_worker<VSF, CH16, false, false, false, true>(p, (int)blockIdx.x, gs_lds);
 }
 
-#ifdef JV_EXPERIMENTAL   // ---- measured-and-switched-off variants: UB8 (superseded by UBR, k_gsearch_ubr.hip) and the register-resident ADC table
-// UB8 (gs_body.h "UB8"): the pair-lane kernel with an 8-bit upper-bound table of the query's ADC entries in LDS (+ M x 256 bytes per
-// wave): fresh neighbours that provably cannot be popped are dropped without their M codebook gathers.  Dot product / cosine.
-template <int VSF, int CH16, bool PROF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void graph_search_ub8_kernel(GsParams p)   // (<= 4 waves per CU: a SIMD to itself, no register cap)
-{
-    extern __shared__ __attribute__((aligned(16))) char gs_lds[];
-    gs_worker<VSF, CH16, true, PROF, false, false, true>(p, (int)blockIdx.x, gs_lds);
-}
-
-template <int VSF>
-static int launch_gs_ub8(hipStream_t s, const GsParams &p, int ch, int workers, size_t lds)
-{
-    dim3 grid(workers), block(64);
-#define JV_UB8(CH)                                                                                              \
-    do {                                                                                                        \
-        if (p.prof) {                                                                                           \
-            auto kfn = graph_search_ub8_kernel<VSF, CH, true>;                                                  \
-            JV_HIP_CHECK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                    \
-        } else {                                                                                                \
-            auto kfn = graph_search_ub8_kernel<VSF, CH, false>;                                                 \
-            JV_HIP_CHECK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                    \
-        }                                                                                                       \
-    } while (0)
-    switch (ch) {
-    case 1: JV_UB8(1); break;
-    case 2: JV_UB8(2); break;
-    case 3: JV_UB8(3); break;
-    case 4: JV_UB8(4); break;
-    case 6: JV_UB8(6); break;
-    default:
-        set_error("graph search kernel: the upper-bound form is built for M = 16 ... 96 (M = %d)", ch * 16);
-        return JV_ERR_UNSUPPORTED;
-    }
-#undef JV_UB8
-    JV_HIP_CHECK(hipGetLastError());
-    return JV_OK;
-}
-
-bool graph_search_ub8_supported(int M, int vsf) { return vsf != VSF_L2 && (M == 16 || M == 32 || M == 48 || M == 64 || M == 96); }
-#else
-bool graph_search_ub8_supported(int, int) { return false; }
-#endif
-
-#ifdef JV_EXPERIMENTAL
-// The register-resident-table form (gs_body.h gs_lut_build / gs_row_sum_lut): ONE wave per SIMD owns all 512 vector registers,
-// 4 M of them hold the query's ADC table, look-ups are ds_bpermute reads.  4 workers per CU instead of 8, but an expansion no
-// longer issues ~190 divergent 16-byte gathers into the CU's vector-memory path.
-template <int VSF, int CH16, bool PROF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void graph_search_lutr_kernel(GsParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) char gs_lds[];
-    gs_worker<VSF, CH16, false, PROF, true>(p, (int)blockIdx.x, gs_lds);
-}
-
-#endif
 // developer aid (JVECTOR_HIP_GS_PROF=1): the benched instance with per-phase shader-clock counters (GsParams::prof)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_prof_kernel(GsParams p)
 {
@@ -201,89 +143,22 @@ size_t graph_search_lds_bytes(int D, int rerankK, int cand_cap, int pair_M, int 
     return gs_lds_bytes(D, rerankK, cand_cap, pair_M, evict_cap > 0 ? evict_cap : GS_EVICT_CAP, v1_log2);
 }
 
-#ifdef JV_EXPERIMENTAL
-// Built for the headline shape only (PQ-96 x the three similarity functions; the phase-clock variant for cosine): an experiment
-// kept selectable (option gs_lutr), measured SLOWER than the table-free form — other M would only cost compile time.
-template <int VSF>
-static int launch_gs_lutr(hipStream_t s, const GsParams &p, int ch, int workers, size_t lds)
-{
-    dim3 grid(workers), block(64);
-#define JV_LUTR(CH, PROFV)                                                                                     \
-    do {                                                                                                        \
-        auto kfn = graph_search_lutr_kernel<VSF, CH, PROFV>;                                                    \
-        JV_HIP_CHECK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kfn, grid, block, lds, s, p);                                                        \
-    } while (0)
-    if (p.prof) {
-        if constexpr (VSF == VSF_COS) {
-            if (ch == 6) {
-                JV_LUTR(6, true);
-                JV_HIP_CHECK(hipGetLastError());
-                return JV_OK;
-            }
-        }
-        set_error("graph search kernel: the phase-clock variant of the register-resident table form is built for cosine, M = 96 only");
-        return JV_ERR_UNSUPPORTED;
-    }
-    switch (ch) {
-    case 6: JV_LUTR(6, false); break;
-    default:
-        set_error("graph search kernel: the register-resident table form is built for M = 96 (M = %d)", ch * 16);
-        return JV_ERR_UNSUPPORTED;
-    }
-#undef JV_LUTR
-    JV_HIP_CHECK(hipGetLastError());
-    return JV_OK;
-}
-
-bool graph_search_lutr_supported(int M) { return M == 96; }
-#else
-bool graph_search_lutr_supported(int) { return false; }
-#endif
-
 int launch_graph_search(hipStream_t s, int vsf, const GsParams &p, int workers, int occupancy)
 {
     if (p.Q == 0) return JV_OK;
-    const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2) +
-                       (p.lutr ? gs_lutr_lds_bytes(p.M) : 0);
+    const size_t lds = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2);
     const int ch = p.generic ? 0 : p.M / 16;
-    if (p.generic && (p.lutr || p.prof || p.pair)) {
-        set_error("graph search kernel: the generic form has no register-table / phase-clock / pair-lane variant");
+    if (p.generic && (p.prof || p.pair)) {
+        set_error("graph search kernel: the generic form has no phase-clock / pair-lane variant");
         return JV_ERR_INVALID;
     }
     if (p.session) {
-        if (p.lutr || p.prof) {
-            set_error("graph search kernel: the GraphSearcher-object form has no register-table / phase-clock variant");
+        if (p.prof) {
+            set_error("graph search kernel: the GraphSearcher-object form has no phase-clock variant");
             return JV_ERR_INVALID;
         }
         return launch_graph_search_session(s, vsf, p, workers, lds + gs_session_lds_bytes());
     }
-#ifndef JV_EXPERIMENTAL
-    if (p.ub8 || p.lutr) {
-        set_error("graph search kernel: gs_ub8 / gs_lutr are experimental variants (build with make EXPERIMENTAL=1)");
-        return JV_ERR_UNSUPPORTED;
-    }
-#else
-    if (p.ub8) {
-        if (!p.pair || p.lutr || p.session || p.generic || vsf == VSF_L2) {
-            set_error("graph search kernel: the upper-bound form serves the pair-lane kernels, dot product / cosine");
-            return JV_ERR_INVALID;
-        }
-        const size_t lds8 = lds + gs_ub8_lds_bytes(p.M);
-        return vsf == VSF_DOT ? launch_gs_ub8<VSF_DOT>(s, p, ch, workers, lds8) : launch_gs_ub8<VSF_COS>(s, p, ch, workers, lds8);
-    }
-    if (p.lutr) {
-        if (p.pair) {
-            set_error("graph search kernel: the register-resident table form has no pair-lane scoring");
-            return JV_ERR_INVALID;
-        }
-        switch (vsf) {
-        case VSF_L2: return launch_gs_lutr<VSF_L2>(s, p, ch, workers, lds);
-        case VSF_DOT: return launch_gs_lutr<VSF_DOT>(s, p, ch, workers, lds);
-        default: return launch_gs_lutr<VSF_COS>(s, p, ch, workers, lds);
-        }
-    }
-#endif
     if (p.prof) {
         if (!(vsf == VSF_COS && ch == 6 && p.pair && occupancy < 4)) {
             set_error("graph search kernel: the profiling variant is built for cosine, M = 96, pair-lane scoring only");

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CH16 == 0 ? 
 void graph_search_session_kernel(GsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_lds[];
-    gs_worker<VSF, CH16, PAIR, false, false, true>(p, (int)blockIdx.x, gs_lds);
+    gs_worker<VSF, CH16, PAIR, false, true>(p, (int)blockIdx.x, gs_lds);
 }
 
 template <int VSF>

@@ -1,7 +1,7 @@
 // k_gsearch_ubr.hip — the one-wave traversal with a REGISTER-resident upper-bound table (gs_body.h "UBR") and the dense kernel that
 // builds the tables of a whole batch.  A translation unit of its own: the traversal's other instantiations compile in parallel.
 //
-// Why: UB8 proved that 60 % of the neighbours a search scores can soundly be dropped behind an 8-bit upper bound of
+// Why: round 4's UB8 form (gone from the source since round 6) proved that 60 % of the neighbours a search scores can soundly be dropped behind an 8-bit upper bound of
 // their score, and lost 2.3x to three removable overheads — the table built inside the traversal wave, 24 KB of LDS per wave, and
 // survivors scored in place.  Here the table is built by ubr_table_kernel for all queries at once (codebook rows reused across 8
 // queries, ~25 GB of L2 reads and 3.2 GB of HBM writes per 131 072 queries instead of 355 k clocks per query), lives in 96 of the
@@ -24,7 +24,7 @@ template <int VSF, int CH16, bool PROF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_ubr_kernel(GsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_lds[];
-    gs_worker<VSF, CH16, true, PROF, false, false, false, false, true>(p, (int)blockIdx.x, gs_lds);
+    gs_worker<VSF, CH16, true, PROF, false, false, true>(p, (int)blockIdx.x, gs_lds);
 }
 
 // the same bound form over the COMPACTED fresh list of rows up to 64 wide, codes by ordinal (gs_body.h PAIRC + UBR): the builder's searches
@@ -32,7 +32,7 @@ template <int VSF, int CH16, bool PROF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void graph_search_ubrc_kernel(GsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char gs_lds[];
-    gs_worker<VSF, CH16, false, PROF, false, false, false, true, true>(p, (int)blockIdx.x, gs_lds);
+    gs_worker<VSF, CH16, false, PROF, false, true, true>(p, (int)blockIdx.x, gs_lds);
 }
 
 // ---- the tables of a batch --------------------------------------------------------------------------------------------------------
@@ -254,7 +254,7 @@ int launch_ubr_tables(hipStream_t s, int vsf, const float *codebooks, const floa
 int launch_graph_search_ubr(hipStream_t s, int vsf, const GsParams &p, int workers, size_t lds)
 {
     if (p.Q == 0) return JV_OK;
-    if (!p.pair || p.lutr || p.session || p.generic || p.ub8 || !graph_search_ubr_supported(p.M, vsf) || !p.ubr_tab || !p.ubr_meta) {
+    if (!p.pair || p.session || p.generic || !graph_search_ubr_supported(p.M, vsf) || !p.ubr_tab || !p.ubr_meta) {
         set_error("graph search kernel: the register-table bound form serves the pair-lane kernels, dot product / cosine, M = 96");
         return JV_ERR_INVALID;
     }

@@ -73,7 +73,7 @@ size_t graph_search_wgx_lds_bytes(int D, int rerankK, int cand_cap, int evict_ca
 int launch_graph_search_wgx(hipStream_t s, int vsf, const GsParams &p, int workgroups, int threads)
 {
     if (p.Q == 0) return JV_OK;
-    if (p.generic || p.pair || p.lutr || p.session || p.prefetch) {
+    if (p.generic || p.pair || p.session || p.prefetch) {
         set_error("graph search kernel (workgroup form): plain searches over the specialised PQ shapes only");
         return JV_ERR_INVALID;
     }

@@ -103,35 +103,11 @@ void run_vsf(const Launch &L)
     else run_ch<2, PAIR>(L);
 }
 template <int VSF>
-void run_lutr(const Launch &L)
-{
-    switch (L.ch) {
-    case 1: jv::gs_worker<VSF, 1, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 2: jv::gs_worker<VSF, 2, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 3: jv::gs_worker<VSF, 3, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 4: jv::gs_worker<VSF, 4, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 6: jv::gs_worker<VSF, 6, false, false, true>(*L.p, L.worker, L.lds); break;
-    default: abort();
-    }
-}
-template <int VSF>
-void run_ub8(const Launch &L)
-{
-    switch (L.ch) {
-    case 1: jv::gs_worker<VSF, 1, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 2: jv::gs_worker<VSF, 2, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 3: jv::gs_worker<VSF, 3, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 4: jv::gs_worker<VSF, 4, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 6: jv::gs_worker<VSF, 6, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    default: abort();
-    }
-}
-template <int VSF>
 void run_ubr(const Launch &L)
 {
     switch (L.ch) {
-    case 4: jv::gs_worker<VSF, 4, true, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 6: jv::gs_worker<VSF, 6, true, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 4: jv::gs_worker<VSF, 4, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gs_worker<VSF, 6, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }
@@ -139,8 +115,8 @@ template <int VSF>
 void run_ubrc(const Launch &L)   // the bound form over the compacted fresh list (rows up to 64 wide, codes by ordinal)
 {
     switch (L.ch) {
-    case 4: jv::gs_worker<VSF, 4, false, false, false, false, false, true, true>(*L.p, L.worker, L.lds); break;
-    case 6: jv::gs_worker<VSF, 6, false, false, false, false, false, true, true>(*L.p, L.worker, L.lds); break;
+    case 4: jv::gs_worker<VSF, 4, false, false, false, true, true>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gs_worker<VSF, 6, false, false, false, true, true>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }
@@ -148,13 +124,13 @@ template <int VSF>
 void run_pairc(const Launch &L)
 {
     switch (L.ch) {
-    case 1: jv::gs_worker<VSF, 1, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 2: jv::gs_worker<VSF, 2, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 3: jv::gs_worker<VSF, 3, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 4: jv::gs_worker<VSF, 4, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 6: jv::gs_worker<VSF, 6, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 8: jv::gs_worker<VSF, 8, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 12: jv::gs_worker<VSF, 12, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 1: jv::gs_worker<VSF, 1, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 2: jv::gs_worker<VSF, 2, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 3: jv::gs_worker<VSF, 3, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 4: jv::gs_worker<VSF, 4, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: jv::gs_worker<VSF, 6, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 8: jv::gs_worker<VSF, 8, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 12: jv::gs_worker<VSF, 12, false, false, false, true>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }
@@ -185,13 +161,6 @@ void lane_main(void *arg)
     } else if (L.p->ubr) {
         if (L.vsf == 1) run_ubr<1>(L);
         else run_ubr<2>(L);
-    } else if (L.p->ub8) {
-        if (L.vsf == 1) run_ub8<1>(L);
-        else run_ub8<2>(L);
-    } else if (L.p->lutr) {
-        if (L.vsf == 0) run_lutr<0>(L);
-        else if (L.vsf == 1) run_lutr<1>(L);
-        else run_lutr<2>(L);
     } else if (L.p->pair == 2) {
         if (L.vsf == 0) run_pairc<0>(L);
         else if (L.vsf == 1) run_pairc<1>(L);
@@ -207,15 +176,15 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
                               const float *fused_norms, int D, int M, int deg0, int Q, int rerankK, int vsf, int vcap_log2,
                               int spill_cap, int cand_cap, int workers, int pair_mode /* 0 off, 1 when degrees allow */, int32_t *out_ids, float *out_scores, long long *out_stats,
                               int32_t *out_status, int v1_log2 /* LDS tier of the visited set: log2(slots), 0 = none */, int v1_idbits,
-                              int evict_cap /* 0 = GS_EVICT_CAP */, int lutr /* 1: ADC table in registers + LDS (M <= 96) */,
+                              int evict_cap /* 0 = GS_EVICT_CAP */, int lutr /* must be 0 (the register-resident ADC table form left the source in round 6) */,
                               int wgx_waves /* > 0: the workgroup form (gx_body.h) with this many waves (2..4 here), M <= 128 */,
                               int wgx_slots, int wgx_depth, int wgx_lut_m /* 0 = M */,
                               int ub8 /* 1: the pair-lane kernel with the 8-bit upper-bound table (dot / cosine, M <= 96, degrees <= 32);
                                          2: UBR — the table prebuilt (gs_ubr_build_ref) and held in registers, survivors compacted, eight lanes each (M = 64 / 96) */,
                               long long *ub8_dropped_out /* nullable */)
 {
-    if (lutr && M > 96) return -4;
-    if (wgx_waves && (M == 80 || M == 112 || wgx_waves < 2 || wgx_waves > emu::MAX_WAVES || lutr)) return -5;
+    if (lutr) return -4;
+    if (wgx_waves && (M == 80 || M == 112 || wgx_waves < 2 || wgx_waves > emu::MAX_WAVES)) return -5;
     if (n_levels < 1 || n_levels > jv::GS_MAX_LEVELS || M % 16 != 0 || D != 8 * M || cand_cap < 128) return -1;
     if (v1_log2 > 0 && !jv::gs_v1_fits(v1_log2, v1_idbits)) return -2;
     jv::GsParams p{};
@@ -241,19 +210,17 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     int32_t *visited = (int32_t *)aligned_alloc(64, sizeof(int32_t) * vcap * workers);
     long long *spill = (long long *)aligned_alloc(64, sizeof(long long) * (size_t)(spill_cap > 0 ? spill_cap : 1) * workers + 64);
     memset(visited, 0x5a, sizeof(int32_t) * vcap * workers);  // garbage: the kernel must clear it itself
-    bool pair = pair_mode != 0 && !lutr && !wgx_waves;  // same rule as graph_search.cpp
+    bool pair = pair_mode != 0 && !wgx_waves;  // same rule as graph_search.cpp
     for (int l = 0; l < n_levels; ++l) pair = pair && lv_degree[l] <= 32;
     pair = pair && M <= 96;   // (graph_search.cpp: above, the two half rows no longer fit the registers; the exchange area is sized for the compacted form)
-    p.lutr = lutr ? 1 : 0;
     // pair_mode 2: the compacted pair form (rows of up to 64 neighbours, codes by ordinal) where the plain pair form does not apply
-    bool pairc = pair_mode == 2 && !pair && !lutr && !wgx_waves && !blocks && M <= 192;
+    bool pairc = pair_mode == 2 && !pair && !wgx_waves && !blocks && M <= 192;
     for (int l = 0; l < n_levels; ++l) pairc = pairc && lv_degree[l] <= 64;
     if (pair_mode == 2 && !pair && !pairc) return -8;
     p.pair = pair ? 1 : (pairc ? 2 : 0);
     p.quad = getenv("GS_EMU_QUAD") ? atoi(getenv("GS_EMU_QUAD")) : 1;   // (on in the emulator unless a test turns it off: more code under test)
-    if (ub8 && (!(pair || (pairc && ub8 == 2)) || vsf == 0 || M > 96 || wgx_waves || lutr)) return -7;
+    if (ub8 && (ub8 != 2 || !(pair || pairc) || vsf == 0 || M > 96 || wgx_waves)) return -7;   // (2 = the register-table bound form; 1 = round 4's UB8, gone)
     if (ub8 == 2 && M != 64 && M != 96) return -9;
-    p.ub8 = ub8 == 1 ? 1 : 0;
     std::vector<uint32_t> ubr_tab;
     std::vector<float> ubr_meta;
     if (ub8 == 2) {
@@ -287,7 +254,6 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     uint32_t next = 0;
     p.next_query = &next;
     unsigned long long prof[24] = {0};
-    if (ub8 == 1) p.prof = prof;   // (only slot 15 is written without the phase-clock build: neighbours dropped behind the bound)
     if (ub8 == 2) p.ubr_count = prof + 15;
     long collectives = 0;
     // "workers" waves run one after another; each drains part of the queue so that scratch reuse across queries and
@@ -296,7 +262,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
         jv::GsParams pw = p;
         pw.Q = (int)((long long)Q * (w + 1) / workers);
         const size_t lds_bytes = wgx_waves ? jv::gx_lds_bytes(D, rerankK, cand_cap, ecap, v1_log2, wgx_slots, kps, p.wgx_log, p.wgx_lut_m)
-                                           : jv::gs_lds_bytes(D, rerankK, cand_cap, (pair || pairc) ? M : 0, ecap, v1_log2) + (lutr ? jv::gs_lutr_lds_bytes(M) : 0) + (ub8 == 1 ? jv::gs_ub8_lds_bytes(M) : 0);
+                                           : jv::gs_lds_bytes(D, rerankK, cand_cap, (pair || pairc) ? M : 0, ecap, v1_log2);
         char *lds = (char *)aligned_alloc(64, lds_bytes + 64);
         memset(lds, 0xa5, lds_bytes);
         memset(lds + lds_bytes, 0x3c, 64);  // canary behind the block

@@ -751,8 +751,6 @@ int launch_bl_sort_edges(hipStream_t, void *temp, size_t *temp_bytes, const unsi
 }
 
 // ---- device-resident traversal: gs_body.h on the lane emulator ----
-bool graph_search_lutr_supported(int M) { return M == 96; }  // (the shape k_gsearch.hip builds)
-bool graph_search_ub8_supported(int M, int vsf) { return vsf != VSF_L2 && (M == 16 || M == 32 || M == 48 || M == 64 || M == 96); }
 bool graph_search_session_supported(int M) { return M >= 1; }
 bool graph_search_device_specialised(const jv_pq *pq, const jv_codes *codes, const jv_fused *fused)
 {
@@ -777,40 +775,16 @@ struct GsLaunch {
     char *lds;
 };
 template <int VSF>
-void gs_run_lutr(const GsLaunch &L)
-{
-    switch (L.p->M / 16) {
-    case 1: gs_worker<VSF, 1, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 2: gs_worker<VSF, 2, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 3: gs_worker<VSF, 3, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 4: gs_worker<VSF, 4, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 6: gs_worker<VSF, 6, false, false, true>(*L.p, L.worker, L.lds); break;
-    default: abort();
-    }
-}
-template <int VSF>
 void gs_run_pairc(const GsLaunch &L)
 {
     switch (L.p->M / 16) {
-    case 1: gs_worker<VSF, 1, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 2: gs_worker<VSF, 2, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 3: gs_worker<VSF, 3, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 4: gs_worker<VSF, 4, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 6: gs_worker<VSF, 6, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 8: gs_worker<VSF, 8, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 12: gs_worker<VSF, 12, false, false, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    default: abort();
-    }
-}
-template <int VSF>
-void gs_run_ub8(const GsLaunch &L)
-{
-    switch (L.p->M / 16) {
-    case 1: gs_worker<VSF, 1, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 2: gs_worker<VSF, 2, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 3: gs_worker<VSF, 3, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 4: gs_worker<VSF, 4, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 6: gs_worker<VSF, 6, true, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 1: gs_worker<VSF, 1, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 2: gs_worker<VSF, 2, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 3: gs_worker<VSF, 3, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 4: gs_worker<VSF, 4, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: gs_worker<VSF, 6, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 8: gs_worker<VSF, 8, false, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 12: gs_worker<VSF, 12, false, false, false, true>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }
@@ -818,18 +792,18 @@ template <int VSF, bool PAIR>
 void gs_run_session(const GsLaunch &L)
 {
     if (L.p->generic) {
-        if constexpr (!PAIR) gs_worker<VSF, 0, false, false, false, true>(*L.p, L.worker, L.lds);
+        if constexpr (!PAIR) gs_worker<VSF, 0, false, false, true>(*L.p, L.worker, L.lds);
         else abort();
         return;
     }
     switch (L.p->M / 16) {
-    case 1: gs_worker<VSF, 1, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 2: gs_worker<VSF, 2, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 3: gs_worker<VSF, 3, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 4: gs_worker<VSF, 4, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 6: gs_worker<VSF, 6, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 8: gs_worker<VSF, 8, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
-    case 12: gs_worker<VSF, 12, PAIR, false, false, true>(*L.p, L.worker, L.lds); break;
+    case 1: gs_worker<VSF, 1, PAIR, false, true>(*L.p, L.worker, L.lds); break;
+    case 2: gs_worker<VSF, 2, PAIR, false, true>(*L.p, L.worker, L.lds); break;
+    case 3: gs_worker<VSF, 3, PAIR, false, true>(*L.p, L.worker, L.lds); break;
+    case 4: gs_worker<VSF, 4, PAIR, false, true>(*L.p, L.worker, L.lds); break;
+    case 6: gs_worker<VSF, 6, PAIR, false, true>(*L.p, L.worker, L.lds); break;
+    case 8: gs_worker<VSF, 8, PAIR, false, true>(*L.p, L.worker, L.lds); break;
+    case 12: gs_worker<VSF, 12, PAIR, false, true>(*L.p, L.worker, L.lds); break;
     default: abort();
     }
 }
@@ -873,18 +847,11 @@ void gs_main(void *a)
             else gs_run_session<VSF_COS, false>(L);
         }
     } else if (L.p->ubr && L.p->pair == 2) {
-        if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, false, false, false, false, false, true, true>(*L.p, L.worker, L.lds);
-        else gs_worker<VSF_COS, 6, false, false, false, false, false, true, true>(*L.p, L.worker, L.lds);
+        if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, false, false, false, true, true>(*L.p, L.worker, L.lds);
+        else gs_worker<VSF_COS, 6, false, false, false, true, true>(*L.p, L.worker, L.lds);
     } else if (L.p->ubr) {
-        if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, true, false, false, false, false, false, true>(*L.p, L.worker, L.lds);
-        else gs_worker<VSF_COS, 6, true, false, false, false, false, false, true>(*L.p, L.worker, L.lds);
-    } else if (L.p->ub8) {
-        if (L.vsf == VSF_DOT) gs_run_ub8<VSF_DOT>(L);
-        else gs_run_ub8<VSF_COS>(L);
-    } else if (L.p->lutr) {
-        if (L.vsf == VSF_L2) gs_run_lutr<VSF_L2>(L);
-        else if (L.vsf == VSF_DOT) gs_run_lutr<VSF_DOT>(L);
-        else gs_run_lutr<VSF_COS>(L);
+        if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, true, false, false, false, true>(*L.p, L.worker, L.lds);
+        else gs_worker<VSF_COS, 6, true, false, false, false, true>(*L.p, L.worker, L.lds);
     } else if (L.p->pair == 2) {
         if (L.vsf == VSF_L2) gs_run_pairc<VSF_L2>(L);
         else if (L.vsf == VSF_DOT) gs_run_pairc<VSF_DOT>(L);
@@ -959,7 +926,7 @@ int launch_graph_search(hipStream_t, int vsf, const GsParams &p, int workers, in
 {
     if (p.Q == 0) return JV_OK;
     const size_t lds_bytes = gs_lds_bytes(p.D, p.rerankK, p.cand_cap, p.pair ? p.M : 0, p.evict_cap > 0 ? p.evict_cap : GS_EVICT_CAP, p.v1_log2) +
-                             (p.lutr ? gs_lutr_lds_bytes(p.M) : 0) + (p.session ? gs_session_lds_bytes() : 0) + (p.ub8 ? gs_ub8_lds_bytes(p.M) : 0);
+                             (p.session ? gs_session_lds_bytes() : 0);
     // the waves of a persistent launch, one after another; wave w stops after its share so that several workers'
     // scratch slices are exercised (a real launch interleaves them).  The lane emulator keeps one wave's context in statics:
     // launches from several host threads (one context each) take turns (run_wave_locked).

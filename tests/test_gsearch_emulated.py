@@ -170,41 +170,6 @@ def test_workgroup_form_under_lane_reordering(emu, monkeypatch, order):
         check(ids, sc, st, status, wi, ws, wst)
 
 
-@pytest.mark.parametrize("levels,fused,M,deg,N", [(2, True, 96, 32, 2500), (1, True, 16, 16, 4000), (3, True, 48, 24, 3000), (2, True, 64, 32, 2500)])
-def test_upper_bound_table_form(emu, levels, fused, M, deg, N):
-    """UB8: the pair-lane kernel that drops fresh neighbours an 8-bit upper-bound table proves unpoppable — dropped nodes still count
-    as visited and nothing else may change: ids, scores and BOTH counters equal the oracle's, dot product and cosine, rerankK small
-    enough that the pivot / full-result thresholds become active long before the search ends (and rerankK 1)"""
-    D = 8 * M
-    lv, entry, entry_level, opq, codes, q = problem(700 + levels + M, N, D, M, levels, deg=deg, nq=8)
-    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
-    dropped_total = scored_total = 0
-    for vsf in (O.DOT_PRODUCT, O.COSINE):
-        for rk in (10, 40, 150, 1):
-            wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
-            scored_total += 2 * int(wst[:, 0].sum())
-            for v1, cc in ((9, 256), (12, 128)):
-                ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, ub8=1, v1_log2=v1, cand_cap=cc)
-                check(ids, sc, st, status, wi, ws, wst)
-                dropped_total += run_emu.last_ub8_dropped
-    assert dropped_total > 0.05 * scored_total, (dropped_total, scored_total)   # the form really drops neighbours in these searches
-
-
-def test_upper_bound_table_form_with_equal_and_extreme_scores(emu, monkeypatch):
-    """duplicated vectors (equal scores around every threshold), a query that is a base vector, shuffled lane orders"""
-    lv, entry, entry_level, opq, codes, q = problem(19, 3000, 128, 16, 2, deg=24, nq=6)
-    codes = codes.copy()
-    codes[1::2] = codes[0:-1:2][: len(codes[1::2])]
-    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
-    for order in ("", "reverse", "random:9"):
-        if order:
-            monkeypatch.setenv("EMU_LANE_ORDER", order)
-        for vsf in (O.DOT_PRODUCT, O.COSINE):
-            wi, ws, wst = og.search(opq, codes, None, q, vsf, 30, 30, fused=True)
-            ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, 30, True, ub8=1)
-            check(ids, sc, st, status, wi, ws, wst)
-
-
 @pytest.mark.parametrize("levels,fused,M,deg,N", [(2, True, 96, 32, 2500), (2, False, 96, 32, 2000), (3, True, 64, 24, 3000), (1, True, 96, 16, 3000)])
 def test_register_table_bound_form(emu, monkeypatch, levels, fused, M, deg, N):
     """UBR (round 5): the bound table prebuilt (gs_ubr_build_ref) and held in registers, survivors compacted and scored eight lanes
@@ -298,31 +263,6 @@ def test_workgroup_form_equal_scores(emu):
     for vsf, fused in ((O.COSINE, True), (O.EUCLIDEAN, False)):
         wi, ws, wst = og.search(opq, codes, None, q, vsf, 60, 60, fused=fused)
         ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, 60, fused, wgx_waves=4)
-        check(ids, sc, st, status, wi, ws, wst)
-
-
-@pytest.mark.parametrize("levels,fused,M,deg", [(1, False, 16, 16), (2, True, 32, 16), (2, False, 48, 40), (2, True, 64, 24), (2, True, 96, 32),
-                                                (3, False, 96, 16)])
-def test_register_resident_table_matches_oracle(emu, levels, fused, M, deg):
-    """LUTR: the query's ADC table split between the wave's registers (cross-lane reads) and LDS — every M it is built for,
-    degrees up to 64 (one lane per neighbour), all three similarity functions: bit-identical to the oracle like the table-free form"""
-    D = 8 * M
-    lv, entry, entry_level, opq, codes, q = problem(300 + levels + M, 2000, D, M, levels, deg=deg, nq=6)
-    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
-    for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
-        for rk in (40, 1):
-            wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
-            ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, rk, fused, lutr=1)
-            check(ids, sc, st, status, wi, ws, wst)
-
-
-def test_register_resident_table_under_lane_reordering(emu, monkeypatch):
-    lv, entry, entry_level, opq, codes, q = problem(41, 2000, 768, 96, 2, deg=24, nq=3)
-    og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
-    wi, ws, wst = og.search(opq, codes, None, q, O.COSINE, 60, 60, fused=True)
-    for order in ("reverse", "random:5"):
-        monkeypatch.setenv("EMU_LANE_ORDER", order)
-        ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, O.COSINE, 60, True, lutr=1, v1_log2=10)
         check(ids, sc, st, status, wi, ws, wst)
 
 

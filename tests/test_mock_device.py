@@ -181,7 +181,6 @@ def test_device_traversal_tiers_fallbacks_and_counters(J, ctx, capfd):
         for p in ptrs:
             lib.mock_hip_unregister_device(C.c_void_p(p))
     T.test_auto_traversal_reports_the_host_fallback(ctx, capfd)
-    T.test_register_resident_table_kernel(ctx, 2, False, 768, 96, 40)
 
 
 def test_workgroup_form_driver_on_the_mock(J, ctx):

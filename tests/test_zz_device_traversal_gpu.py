@@ -284,26 +284,6 @@ def test_auto_traversal_reports_the_host_fallback(ctx, capfd):
     assert err.count("JV_TRAVERSAL_AUTO takes the HOST searcher") == 1
 
 
-@pytest.mark.parametrize("levels,use_fused,D,M,deg", [(2, True, 768, 96, 32), (3, True, 768, 96, 24), (1, False, 768, 96, 40)])
-def test_register_resident_table_kernel(ctx, levels, use_fused, D, M, deg):
-    """gs_lutr = 1: the traversal kernel whose ADC table lives in the wave's registers + LDS (graph_search_lutr_kernel) — ids,
-    scores and counters equal the oracle's (and therefore the table-free kernel's) for every similarity function"""
-    if not ctx.stat("experimental_build"):
-        pytest.skip("gs_lutr is a measured-and-switched-off variant: compiled with make EXPERIMENTAL=1 only (evidence: profiles/r3_*, DESIGN.md §4)")
-    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 7 * levels + M, 4000, D, M, levels, use_fused, deg=deg)
-    og = O.OracleGraph(len(v), lv, entry, entry_level)
-    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
-    try:
-        ctx.set_option("gs_lutr", 1)
-        for vsf in VSF:
-            for top_k, rk in ((10, 80), (1, 1)):
-                ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True)
-                wi, ws, wst = og.search(opq, codes, v, q, int(vsf), top_k, rk, fused=use_fused)
-                assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rk)
-    finally:
-        ctx.set_option("gs_lutr", None)
-
-
 @pytest.mark.parametrize("levels,D,M,deg", [(1, 768, 96, 64), (2, 768, 96, 40), (2, 128, 16, 64), (2, 384, 48, 48), (1, 512, 64, 33),
                                             (1, 1024, 128, 64), (2, 1536, 192, 64), (1, 1536, 192, 17)])
 def test_compacted_pair_kernel(ctx, levels, D, M, deg):
@@ -382,29 +362,4 @@ def test_workgroup_form_large_batch_with_spills_and_overflow(ctx, n_queries=1500
         assert ctx.stat("gs_last_wgx") == 1
     finally:
         for k in ("gs_wgx", "gs_cand_cap", "gs_vcap_log2", "gs_retry", "gs_grow"):
-            ctx.set_option(k, None)
-
-
-@pytest.mark.parametrize("levels,D,M,deg,N", [(2, 768, 96, 32, 20000), (2, 128, 16, 16, 8000), (3, 384, 48, 24, 12000), (2, 512, 64, 32, 12000)])
-def test_upper_bound_table_kernel(ctx, levels, D, M, deg, N):
-    """gs_ub8 = 1: the pair-lane kernel that drops fresh neighbours an 8-bit upper-bound table proves unpoppable (dot product / cosine,
-    FusedPQ): ids, scores and both counters equal the oracle's — dropped neighbours still count as visited — at rerankK values where
-    the thresholds become active early; euclidean searches and filtered searches fall back to the plain kernel"""
-    if not ctx.stat("experimental_build"):
-        pytest.skip("gs_ub8 is superseded by the register-table form (gs_ubr, tests/test_zz_ubr_gpu.py): compiled with make EXPERIMENTAL=1 only")
-    v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 13 * levels + M, N, D, M, levels, True, deg=deg)
-    og = O.OracleGraph(len(v), lv, entry, entry_level)
-    s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
-    try:
-        ctx.set_option("gs_ub8", 1)
-        ctx.set_option("gs_wgx", 0)
-        for vsf in VSF:
-            for top_k, rk in ((10, 40), (10, 150), (1, 1)):
-                for per_cu in (3, 4):
-                    ctx.set_option("gs_ub8_per_cu", per_cu)
-                    ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True)
-                    wi, ws, wst = og.search(opq, codes, v, q, int(vsf), top_k, rk, fused=True)
-                    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rk, per_cu)
-    finally:
-        for k in ("gs_ub8", "gs_wgx", "gs_ub8_per_cu"):
             ctx.set_option(k, None)
