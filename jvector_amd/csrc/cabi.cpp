@@ -1046,14 +1046,14 @@ int jv_hip_luts_bound_tables(jv_ctx *ctx, const jv_luts *l, uint32_t *tab_out, f
     JV_REQUIRE(ctx && l && tab_out && meta_out, "luts_bound_tables: NULL argument");
     JV_REQUIRE(l->Q > 0, "luts_bound_tables: no queries staged (call jv_hip_luts_build first)");
     const jv_pq *pq = l->pq;
-    JV_REQUIRE(l->vsf != JV_EUCLIDEAN && pq->uniform && pq->max_size == 8 && pq->k == kClusters && pq->M % 8 == 0,
-               "luts_bound_tables: dot product / cosine, 256 clusters, uniform 8-dim sub-vectors, M a multiple of 8");
+    JV_REQUIRE(pq->uniform && pq->max_size == 8 && pq->k == kClusters && pq->M % 8 == 0,
+               "luts_bound_tables: 256 clusters, uniform 8-dim sub-vectors, M a multiple of 8");
     JV_TRY(use_device(ctx->device));
     const size_t tab_bytes = (gs_ubr_tab_bytes(pq->M) * (size_t)l->Q + 255) & ~(size_t)255;
     JV_TRY(ctx->d_gs_ubr.reserve(tab_bytes + sizeof(float) * 4 * (size_t)l->Q));
     uint32_t *d_tab = (uint32_t *)ctx->d_gs_ubr.ptr;
     float *d_meta = (float *)((char *)ctx->d_gs_ubr.ptr + tab_bytes);
-    JV_TRY(launch_ubr_tables(ctx->stream, l->vsf == JV_DOT_PRODUCT ? VSF_DOT : VSF_COS, pq->d_codebooks, l->d_queries, l->Q, pq->M, d_tab, d_meta));
+    JV_TRY(launch_ubr_tables(ctx->stream, l->vsf == JV_EUCLIDEAN ? VSF_L2 : (l->vsf == JV_DOT_PRODUCT ? VSF_DOT : VSF_COS), pq->d_codebooks, l->d_queries, l->Q, pq->M, d_tab, d_meta));
     JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     JV_HIP_CHECK(hipMemcpy(tab_out, d_tab, gs_ubr_tab_bytes(pq->M) * (size_t)l->Q, hipMemcpyDefault));
     JV_HIP_CHECK(hipMemcpy(meta_out, d_meta, sizeof(float) * 4 * (size_t)l->Q, hipMemcpyDefault));

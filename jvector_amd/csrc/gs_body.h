@@ -518,9 +518,9 @@ GS_FN void gs_ubr_load(const uint32_t *tab_q, uint32_t (&tab)[CH16 * 16])
 // this lane's half of sum_m (b_m + 1): the low lane of a pair (hi = 0) holds the codes of subspaces [0, M/2) in w, the high lane
 // (hi = 1) those of [M/2, M).  EVERY lane of the wave must execute it (a ds_bpermute reads the registers of active lanes only).
 template <int CH16>
-GS_FN int32_t gs_ubr_half(const uint32_t (&tab)[CH16 * 16], const gs_u2 (&w)[CH16], int hi)
+GS_FN int32_t gs_ubr_half(const uint32_t (&tab)[CH16 * 16], const gs_u2 (&w)[CH16], int hi, bool lower = false)
 {
-    int32_t acc = CH16 * 8;   // the "+ 1" of every bucket
+    int32_t acc = lower ? 0 : CH16 * 8;   // the "+ 1" of every bucket (upper edges; the euclidean form sums LOWER edges)
     // byte selector of gs_perm: the looked-up pair {upper word (codes >= 128) : lower word} holds the entry's byte at index
     // (code >> 6 & 1) + 4 (code >> 7) + 2 hi; the other three result bytes are the constant 0
     const uint32_t selbase = 0x0c0c0c00u + 2u * (uint32_t)hi;
@@ -566,6 +566,7 @@ GS_FN float gs_finish(float sum, float node_mag, float query_mag)
 template <int VSF>
 GS_FN bool gs_bound_below(float bound_raw, float node_mag, float query_mag, float T)
 {
+    if (VSF == 0) return bound_raw > 0.0f && gs_finish<VSF>(bound_raw, node_mag, query_mag) < T;   // (a LOWER bound of the distance: 1 / (1 + d) falls)
     if (VSF != 2) return gs_finish<VSF>(bound_raw, node_mag, query_mag) < T;
     const float prod = node_mag * query_mag;
     if (!(prod > 0.0f) || !(prod < 3.0e38f)) return false;
@@ -1040,8 +1041,8 @@ GS_FN void gs_ubr_trim(GsState &s, int rk, float &T)
 template <int VSF, int CH16, bool PAIR, bool PROF = false, bool SES = false, bool PAIRC = false, bool UBR = false>
 GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 {
-    static_assert(!UBR || ((PAIR != PAIRC) && !SES && VSF != 0 && CH16 % 2 == 0 && 60 * CH16 * 16 + 256 <= 64 * CH16 * 16),
-                  "the register-table bound form serves the pair-lane kernels (over the row, or over the compacted fresh list), dot product / cosine, M a multiple of 32 and >= 64");
+    static_assert(!UBR || ((PAIR != PAIRC) && !SES && CH16 % 2 == 0 && 60 * CH16 * 16 + 256 <= 64 * CH16 * 16),
+                  "the register-table bound form serves the pair-lane kernels (over the row, or over the compacted fresh list), M a multiple of 32 and >= 64");
     static_assert(!(UBR && PAIRC) || CH16 <= 6, "the bound form of the compacted pair kernel: two lanes per neighbour (M <= 96)");
     static_assert(!PAIRC || (!PAIR && CH16 > 0), "the compacted pair form is a variant of the plain one-lane-per-neighbour kernel");
     constexpr bool XA = PAIR || PAIRC;   // the worker's LDS block has the [M/2][32] exchange area
@@ -1565,7 +1566,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     uint64_t sm = fm;   // the fresh neighbours that need their exact score (bits of the low lanes)
                     const bool ub_active = ub_on && lvl == 0 && ub_T > -__builtin_inff();
                     if (ub_active) {
-                        const int32_t part = gs_ubr_half<CH16>(ubtab, w, hi ? 1 : 0);   // all 64 lanes
+                        const int32_t part = gs_ubr_half<CH16>(ubtab, w, hi ? 1 : 0, VSF == 0);   // all 64 lanes
                         const int32_t other = gs_shfl32(part, lane ^ 32);
                         bool drop = false;
                         if (fresh) drop = gs_bound_below<VSF>(ubr_base + ubr_scale * (float)(part + other), node_mag, query_mag, ub_T);
@@ -1760,7 +1761,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                         uint64_t sm = fmp;
                         const bool ub_active = ub_on && lvl == 0 && ub_T > -__builtin_inff();
                         if (ub_active) {
-                            const int32_t part = gs_ubr_half<CH16>(ubtab, w, hi ? 1 : 0);   // all 64 lanes
+                            const int32_t part = gs_ubr_half<CH16>(ubtab, w, hi ? 1 : 0, VSF == 0);   // all 64 lanes
                             const int32_t other = gs_shfl32(part, lane ^ 32);
                             bool drop = false;
                             if (lowf) drop = gs_bound_below<VSF>(ubr_base + ubr_scale * (float)(part + other), node_mag, query_mag, ub_T);

@@ -40,7 +40,12 @@ inline GsLevelMap gs_build_level_map(const int32_t *nodes, int count)
 // tab: M x 64 dwords in the register layout (register k of lane s at ((k / 4) * 64 + s) * 4 + k % 4; for step r < M / 2 register 2r
 // holds {t[r][s], t[r][s + 64], t[r + M/2][s], t[r + M/2][s + 64]} and 2r + 1 the same for codes s + 128 / s + 192);
 // meta4 = {sum_m lo_m + slack, S, usable (1 / 0), 0}.  Compile with -ffp-contract=off.
-inline void gs_ubr_build_ref(const float *codebooks /* [M][256][8] */, const float *cq /* [8 M] centred query */, int M, uint32_t *tab, float *meta4)
+// l2 (round 6): the EUCLIDEAN form — entries are squared distances (sequential t = c - q; ent += t * t, squareDistance's offset form),
+// the score 1 / (1 + d) FALLS with the sum, so the table holds LOWER bucket edges: b = floor((e - lo) / S - 2^-10) (the three roundings of the
+// quotient stay below 5e-5: lo + S b <= e in real arithmetic), a row's bound is base + S sum b_m with base = sum lo - slack, and a
+// neighbour is dropped when 1 / (1 + that) < T.
+inline void gs_ubr_build_ref(const float *codebooks /* [M][256][8] */, const float *cq /* [8 M] centred query */, int M, uint32_t *tab, float *meta4,
+                             bool l2 = false)
 {
     std::vector<float> e((size_t)M * 256), lo((size_t)M), hi((size_t)M);
     bool ok = true;
@@ -52,8 +57,14 @@ inline void gs_ubr_build_ref(const float *codebooks /* [M][256][8] */, const flo
             const float *q = cq + (size_t)m * 8;
             float ent = 0.0f;
             for (int j = 0; j < 8; ++j) {
-                const float pr = row[j] * q[j];
-                ent += pr;
+                if (l2) {
+                    const float t = row[j] - q[j];
+                    const float pr = t * t;
+                    ent += pr;
+                } else {
+                    const float pr = row[j] * q[j];
+                    ent += pr;
+                }
             }
             e[(size_t)m * 256 + c] = ent;
             if (!(ent - ent == 0.0f)) ok = false;
@@ -85,7 +96,7 @@ inline void gs_ubr_build_ref(const float *codebooks /* [M][256][8] */, const flo
         // a clamped b = 255 bounds too: 256 S >= (256 / 255)(1 - 2^-24) x the widest range > hi - lo.  (The traversal's f32 evaluation
         // of sum lo + S sum (b + 1) is covered by the slack in meta4[0], as before.)  One entry in a thousand lands a bucket higher
         // than the tightest choice.
-        int b = (int)((ent - lo[m]) * inv + 0x1p-10f);
+        int b = l2 ? (int)((ent - lo[m]) * inv - 0x1p-10f) : (int)((ent - lo[m]) * inv + 0x1p-10f);
         b = b < 0 ? 0 : (b > 255 ? 255 : b);
         return (uint32_t)b;
     };
@@ -98,7 +109,7 @@ inline void gs_ubr_build_ref(const float *codebooks /* [M][256][8] */, const flo
                 if (ok) v = bucket(r, c0) | (bucket(r, c0 + 64) << 8) | (bucket(r + H, c0) << 16) | (bucket(r + H, c0 + 64) << 24);
                 tab[((size_t)(k / 4) * 64 + (size_t)s) * 4 + (size_t)(k % 4)] = v;
             }
-    meta4[0] = sum_lo + 4e-5f * sum_abs;
+    meta4[0] = l2 ? sum_lo - 4e-5f * sum_abs : sum_lo + 4e-5f * sum_abs;
     meta4[1] = S;
     meta4[2] = ok ? 1.0f : 0.0f;
     meta4[3] = 0.0f;

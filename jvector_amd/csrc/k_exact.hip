@@ -272,25 +272,100 @@ __global__ __launch_bounds__(64) void exact_gather_tr_kernel(const float *__rest
                                                              const float *__restrict__ qnorm,
                                                              const float *__restrict__ vnorm,
                                                              const int32_t *__restrict__ ord, int B,
-                                                             float *__restrict__ out)
+                                                             float *__restrict__ out, int B_rows /* rows [0, B_rows) of every list */)
 {
     __shared__ __attribute__((aligned(16))) float tile[R * (CH + 4)];
     const int q = blockIdx.x;
     const bool mine = (int)threadIdx.x < R;
     const int j = blockIdx.y * R + threadIdx.x;
     int64_t o = -1;
-    if (mine && j < B) {
+    if (mine && j < B_rows) {
         o = ord[(int64_t)q * B + j];
         if (o >= n) o = -1;
     }
     const float raw0 = tr_rows<VSF, false, R, CH>(vecs, D, o, queries + (int64_t)q * D, tile);
-    if (!mine || j >= B) return;
+    if (!mine || j >= B_rows) return;
     float *dst = out + (int64_t)q * B + j;
     if (o < 0) {
         *dst = -INFINITY;
         return;
     }
     const float raw = (VSF == VSF_COS) ? cosine_finish(raw0, qnorm[q], vnorm[o]) : raw0;
+    *dst = score_from_raw(VSF, raw);
+}
+
+// ---- the REMAINDERS of several queries' lists in one wavefront (round 6) ----
+// A list of B = 76 candidates is a full wavefront and one with 12 rows; the second one holds a workgroup slot about as long as the first
+// and moves a fifth of the bytes: 1.9 of the rerank's 6.7 ms for 16 % of its rows (profiles/r6_m: B = 64 / 76 / 128 -> 4.77 / 6.69 /
+// 8.93 ms).  Here a wavefront carries the last `rem` rows of G = 64 / rem CONSECUTIVE queries (lane = g rem + i).  The rows travel
+// exactly as in tr_rows; the queries cannot come through scalar loads any more (a lane group per query), so the G query slices of a
+// chunk are staged in LDS next to the tile (requested one chunk ahead, like the rows) and every lane reads ITS query's slice — the
+// same chain against the same values, the same bits.
+constexpr int TRQ_MAXG = 16;   // queries per wavefront (rem >= 4)
+template <int VSF>
+__global__ __launch_bounds__(64) void exact_gather_trq_kernel(const float *__restrict__ vecs, int64_t n, int D, const float *__restrict__ queries,
+                                                              const float *__restrict__ qnorm, const float *__restrict__ vnorm,
+                                                              const int32_t *__restrict__ ord, int B, float *__restrict__ out, int Q, int first,
+                                                              int rem, int G)
+{
+    constexpr int CH = TR_CH, LS = TR_LS;
+    __shared__ __attribute__((aligned(16))) float tile[64 * LS];
+    __shared__ __attribute__((aligned(16))) float qsl[TRQ_MAXG * CH];
+    const int lane = threadIdx.x;
+    const int g = lane / rem, i = lane - g * rem;
+    const int q0 = (int)blockIdx.x * G;
+    const int q = q0 + g;
+    const bool mine = g < G && q < Q;
+    int64_t o = -1;
+    if (mine) {
+        o = ord[(int64_t)q * B + first + i];
+        if (o >= n) o = -1;
+    }
+    const int seg = (lane & 15) * 4, sub = lane >> 4;
+    const float *rp[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t ro = __shfl(o, 4 * k + sub, 64);
+        rp[k] = ro >= 0 ? vecs + ro * D + seg : nullptr;
+    }
+    // staging of the query slices: float4 slot s = lane + 64 j covers query s / 16, floats (s % 16) * 4 .. + 4 of the chunk
+    const float *qp[TRQ_MAXG * CH / 4 / 64];
+#pragma unroll
+    for (int j = 0; j < TRQ_MAXG * CH / 4 / 64; ++j) {
+        const int sl = lane + 64 * j, gq = sl >> 4;
+        qp[j] = (gq < G && q0 + gq < Q) ? queries + (int64_t)(q0 + gq) * D + (sl & 15) * 4 : nullptr;
+    }
+    const int nc = (D + CH - 1) / CH;
+    float4 r[16], qr[TRQ_MAXG * CH / 4 / 64];
+    auto issue = [&](int c) {
+        const bool in = c * CH + seg < D;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            r[k] = (rp[k] && in) ? *reinterpret_cast<const float4 *>(rp[k] + c * CH) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < TRQ_MAXG * CH / 4 / 64; ++j)
+            qr[j] = (qp[j] && c * CH + (lane & 15) * 4 < D) ? *reinterpret_cast<const float4 *>(qp[j] + c * CH) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    issue(0);
+    float acc = 0.0f;
+    for (int c = 0; c < nc; ++c) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<float4 *>(tile + (4 * k + sub) * LS + seg) = r[k];
+#pragma unroll
+        for (int j = 0; j < TRQ_MAXG * CH / 4 / 64; ++j) *reinterpret_cast<float4 *>(qsl + (lane + 64 * j) * 4) = qr[j];
+        __syncthreads();
+        if (c + 1 < nc) issue(c + 1);
+        const int len = (D - c * CH < CH) ? (D - c * CH) : CH;
+        if (mine) tr_chunk<VSF, CH>(tile + lane * LS, qsl + g * CH, len, acc);
+        __syncthreads();
+    }
+    if (!mine) return;
+    float *dst = out + (int64_t)q * B + first + i;
+    if (o < 0) {
+        *dst = -INFINITY;
+        return;
+    }
+    const float raw = (VSF == VSF_COS) ? cosine_finish(acc, qnorm[q], vnorm[o]) : acc;
     *dst = score_from_raw(VSF, raw);
 }
 
@@ -345,8 +420,21 @@ int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, co
         // rows per wavefront x floats per chunk (see tr_rows); JVECTOR_HIP_EXACT_TR_SHAPE = 0 / 1 / 2 pins 64 x 64 / 32 x 128 / 16 x 256
         const int shape_env = getenv("JVECTOR_HIP_EXACT_TR_SHAPE") ? atoi(getenv("JVECTOR_HIP_EXACT_TR_SHAPE")) : -1;
         const int shape = shape_env >= 0 ? shape_env : kExactTrShapeDefault;
-#define JV_TR_LAUNCH(VSFV, R, CH) \
-    hipLaunchKernelGGL((exact_gather_tr_kernel<VSFV, R, CH>), dim3(Q, (B + R - 1) / R), block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out)
+        // remainders packed (exact_gather_trq_kernel): B = 64 f + rem with 4 <= rem <= 32 and more than one query — the main launch then
+        // covers the f full wavefronts of every list only (its rows past 64 f are left to the second launch)
+        const int rq_rem = B % 64, rq_full = B / 64;
+        const bool rq = shape == 0 && Q >= 2 && rq_rem >= 4 && rq_rem <= 32 && !getenv("JVECTOR_HIP_EXACT_NO_PACK");
+        const int rq_G = rq ? std::min(TRQ_MAXG, 64 / rq_rem) : 0;
+        const int B_main = rq ? 64 * rq_full : B;   // rows the main launch scores
+#define JV_TR_LAUNCH(VSFV, R, CH)                                                                                                        \
+    do {                                                                                                                                 \
+        if (B_main > 0)                                                                                                                  \
+            hipLaunchKernelGGL((exact_gather_tr_kernel<VSFV, R, CH>), dim3(Q, (B_main + R - 1) / R), block, 0, s, d_vecs, n, D, d_q, d_qnorm, \
+                               d_vnorm, d_ord, B, d_out, B_main);                                                                        \
+        if (rq)                                                                                                                          \
+            hipLaunchKernelGGL((exact_gather_trq_kernel<VSFV>), dim3((Q + rq_G - 1) / rq_G), block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, \
+                               d_ord, B, d_out, Q, 64 * rq_full, rq_rem, rq_G);                                                          \
+    } while (0)
 #define JV_TR_SHAPES(VSFV)                          \
     do {                                            \
         if (shape == 1) JV_TR_LAUNCH(VSFV, 32, 128); \

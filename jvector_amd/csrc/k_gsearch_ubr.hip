@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
         if (!ok) qbad[j] = 1;
         if (j < nq) {
             float *mq = meta + (int64_t)(q0 + j) * 4;
-            mq[0] = sum_lo + 4e-5f * sum_abs;
+            mq[0] = (VSF == VSF_L2) ? sum_lo - 4e-5f * sum_abs : sum_lo + 4e-5f * sum_abs;   // (euclidean: a LOWER bound of the distance)
             mq[1] = S;
             mq[2] = ok ? 1.0f : 0.0f;
             mq[3] = 0.0f;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
                 for (int k = 0; k < 4; ++k) {
                     const float e = e4[k];
                     // (gs_host.h gs_ubr_build_ref: floor of the f32 quotient plus 2^-10 — its upper edge bounds the entry)
-                    int bb = (int)((e - l) * inv + 0x1p-10f);
+                    int bb = (VSF == VSF_L2) ? (int)((e - l) * inv - 0x1p-10f) : (int)((e - l) * inv + 0x1p-10f);   // (L2: lower bucket edges)
                     bb = bb < 0 ? 0 : (bb > 255 ? 255 : bb);
                     b[half][k] = (uint32_t)bb;
                 }
@@ -228,19 +228,22 @@ __global__ __launch_bounds__(256) void ubr_table_kernel(const float *__restrict_
 
 size_t ubr_table_lds_bytes(int M) { return sizeof(float) * ((size_t)UBR_QB * 8 * M + 2 * (size_t)UBR_QB * M + UBR_QB) + sizeof(int) * UBR_QB; }
 
-bool graph_search_ubr_supported(int M, int vsf) { return vsf != VSF_L2 && M == 96; }
+bool graph_search_ubr_supported(int M, int /*vsf*/) { return M == 96; }   // (round 6: euclidean too — lower bucket edges, gs_host.h)
 
 // tables + meta of queries [0, Q): tab = Q x gs_ubr_tab_bytes(M), meta = Q x 4 floats
 int launch_ubr_tables(hipStream_t s, int vsf, const float *codebooks, const float *cq, int Q, int M, uint32_t *tab, float *meta)
 {
     if (Q == 0) return JV_OK;
-    if (M % 8 != 0 || vsf == VSF_L2) {
-        set_error("ubr tables: dot product / cosine, M a multiple of 8 (M = %d)", M);
+    if (M % 8 != 0) {
+        set_error("ubr tables: M a multiple of 8 (M = %d)", M);
         return JV_ERR_INVALID;
     }
     const size_t lds = ubr_table_lds_bytes(M);
     dim3 grid((unsigned)((Q + UBR_QB - 1) / UBR_QB)), block(256);
-    if (vsf == VSF_DOT) {
+    if (vsf == VSF_L2) {
+        JV_HIP_CHECK(hipFuncSetAttribute((const void *)ubr_table_kernel<VSF_L2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ubr_table_kernel<VSF_L2>, grid, block, lds, s, codebooks, cq, Q, M, tab, meta);
+    } else if (vsf == VSF_DOT) {
         JV_HIP_CHECK(hipFuncSetAttribute((const void *)ubr_table_kernel<VSF_DOT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(ubr_table_kernel<VSF_DOT>, grid, block, lds, s, codebooks, cq, Q, M, tab, meta);
     } else {
@@ -255,7 +258,7 @@ int launch_graph_search_ubr(hipStream_t s, int vsf, const GsParams &p, int worke
 {
     if (p.Q == 0) return JV_OK;
     if (!p.pair || p.session || p.generic || !graph_search_ubr_supported(p.M, vsf) || !p.ubr_tab || !p.ubr_meta) {
-        set_error("graph search kernel: the register-table bound form serves the pair-lane kernels, dot product / cosine, M = 96");
+        set_error("graph search kernel: the register-table bound form serves the pair-lane kernels at M = 96");
         return JV_ERR_INVALID;
     }
     dim3 grid(workers), block(64);
@@ -266,7 +269,8 @@ int launch_graph_search_ubr(hipStream_t s, int vsf, const GsParams &p, int worke
         } else if (p.prof) hipLaunchKernelGGL((graph_search_ubr_kernel<VSFV, 6, true>), grid, block, lds, s, p);  \
         else hipLaunchKernelGGL((graph_search_ubr_kernel<VSFV, 6, false>), grid, block, lds, s, p);              \
     } while (0)
-    if (vsf == VSF_DOT) JV_UBR(VSF_DOT);
+    if (vsf == VSF_L2) JV_UBR(VSF_L2);
+    else if (vsf == VSF_DOT) JV_UBR(VSF_DOT);
     else JV_UBR(VSF_COS);
 #undef JV_UBR
     JV_HIP_CHECK(hipGetLastError());

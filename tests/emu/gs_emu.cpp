@@ -156,10 +156,12 @@ void lane_main(void *arg)
         else if (L.vsf == 1) run_wgx<1>(L);
         else run_wgx<2>(L);
     } else if (L.p->ubr && L.p->pair == 2) {
-        if (L.vsf == 1) run_ubrc<1>(L);
+        if (L.vsf == 0) run_ubrc<0>(L);
+        else if (L.vsf == 1) run_ubrc<1>(L);
         else run_ubrc<2>(L);
     } else if (L.p->ubr) {
-        if (L.vsf == 1) run_ubr<1>(L);
+        if (L.vsf == 0) run_ubr<0>(L);
+        else if (L.vsf == 1) run_ubr<1>(L);
         else run_ubr<2>(L);
     } else if (L.p->pair == 2) {
         if (L.vsf == 0) run_pairc<0>(L);
@@ -219,7 +221,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     if (pair_mode == 2 && !pair && !pairc) return -8;
     p.pair = pair ? 1 : (pairc ? 2 : 0);
     p.quad = getenv("GS_EMU_QUAD") ? atoi(getenv("GS_EMU_QUAD")) : 1;   // (on in the emulator unless a test turns it off: more code under test)
-    if (ub8 && (ub8 != 2 || !(pair || pairc) || vsf == 0 || M > 96 || wgx_waves)) return -7;   // (2 = the register-table bound form; 1 = round 4's UB8, gone)
+    if (ub8 && (ub8 != 2 || !(pair || pairc) || M > 96 || wgx_waves)) return -7;   // (2 = the register-table bound form; 1 = round 4's UB8, gone)
     if (ub8 == 2 && M != 64 && M != 96) return -9;
     std::vector<uint32_t> ubr_tab;
     std::vector<float> ubr_meta;
@@ -228,7 +230,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
         p.ubr_trim = getenv("GS_EMU_UBR_TRIM") ? atoi(getenv("GS_EMU_UBR_TRIM")) : 8;   // (small: many trims per search under test)
         ubr_tab.resize((size_t)Q * M * 64);
         ubr_meta.resize((size_t)Q * 4);
-        for (int q = 0; q < Q; ++q) jv::gs_ubr_build_ref(codebooks, cq + (size_t)q * D, M, ubr_tab.data() + (size_t)q * M * 64, ubr_meta.data() + (size_t)q * 4);
+        for (int q = 0; q < Q; ++q) jv::gs_ubr_build_ref(codebooks, cq + (size_t)q * D, M, ubr_tab.data() + (size_t)q * M * 64, ubr_meta.data() + (size_t)q * 4, vsf == 0);
         p.ubr_tab = ubr_tab.data();
         p.ubr_meta = ubr_meta.data();
     }
@@ -296,4 +298,8 @@ extern "C" int gs_emu_level_lookup(const int32_t *nodes, int count, int32_t node
 extern "C" void gs_emu_ubr_table(const float *codebooks, const float *cq, int M, uint32_t *tab, float *meta4)
 {
     jv::gs_ubr_build_ref(codebooks, cq, M, tab, meta4);
+}
+extern "C" void gs_emu_ubr_table_vsf(const float *codebooks, const float *cq, int M, uint32_t *tab, float *meta4, int vsf /* 0 = euclidean */)
+{
+    jv::gs_ubr_build_ref(codebooks, cq, M, tab, meta4, vsf == 0);
 }

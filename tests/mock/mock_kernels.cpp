@@ -847,10 +847,12 @@ void gs_main(void *a)
             else gs_run_session<VSF_COS, false>(L);
         }
     } else if (L.p->ubr && L.p->pair == 2) {
-        if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, false, false, false, true, true>(*L.p, L.worker, L.lds);
+        if (L.vsf == VSF_L2) gs_worker<VSF_L2, 6, false, false, false, true, true>(*L.p, L.worker, L.lds);
+        else if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, false, false, false, true, true>(*L.p, L.worker, L.lds);
         else gs_worker<VSF_COS, 6, false, false, false, true, true>(*L.p, L.worker, L.lds);
     } else if (L.p->ubr) {
-        if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, true, false, false, false, true>(*L.p, L.worker, L.lds);
+        if (L.vsf == VSF_L2) gs_worker<VSF_L2, 6, true, false, false, false, true>(*L.p, L.worker, L.lds);
+        else if (L.vsf == VSF_DOT) gs_worker<VSF_DOT, 6, true, false, false, false, true>(*L.p, L.worker, L.lds);
         else gs_worker<VSF_COS, 6, true, false, false, false, true>(*L.p, L.worker, L.lds);
     } else if (L.p->pair == 2) {
         if (L.vsf == VSF_L2) gs_run_pairc<VSF_L2>(L);
@@ -912,11 +914,11 @@ int launch_graph_search_wgx(hipStream_t, int vsf, const GsParams &p, int workgro
 }
 
 // the register-table bound form: the tables by gs_host.h's restatement of ubr_table_kernel, the traversal on the lane emulator
-bool graph_search_ubr_supported(int M, int vsf) { return vsf != VSF_L2 && M == 96; }
+bool graph_search_ubr_supported(int M, int /*vsf*/) { return M == 96; }
 int launch_ubr_tables(hipStream_t, int vsf, const float *codebooks, const float *cq, int Q, int M, uint32_t *tab, float *meta)
 {
-    if (vsf == VSF_L2 || M % 8 != 0) return JV_ERR_INVALID;
-    for (int q = 0; q < Q; ++q) gs_ubr_build_ref(codebooks, cq + (size_t)q * 8 * M, M, tab + (size_t)q * M * 64, meta + (size_t)q * 4);
+    if (M % 8 != 0) return JV_ERR_INVALID;
+    for (int q = 0; q < Q; ++q) gs_ubr_build_ref(codebooks, cq + (size_t)q * 8 * M, M, tab + (size_t)q * M * 64, meta + (size_t)q * 4, vsf == VSF_L2);
     return JV_OK;
 }
 int launch_graph_search(hipStream_t, int vsf, const GsParams &p, int workers, int /*occupancy*/);

@@ -257,6 +257,34 @@ def test_exact_gather_and_scan_bit_exact(ctx, D):
             assert np.all(np.isneginf(g[q][~valid]))
 
 
+@pytest.mark.parametrize("D,B", [(768, 76), (768, 12), (768, 68), (768, 96), (768, 100), (768, 140), (40, 76), (1536, 74), (128, 5)])
+def test_exact_gather_list_lengths_and_packed_remainders(ctx, D, B):
+    """the rerank gather over lists of every shape: B = 64 f + rem — full wavefronts by exact_gather_tr_kernel, remainders of 4 .. 32 rows
+    PACKED several queries per wavefront (exact_gather_trq_kernel, round 6), longer / shorter remainders in a wavefront of their own;
+    invalid ordinals in both parts, a query count that does not fill the last packed wavefront: every score equals the oracle's"""
+    rng = np.random.default_rng(D + B)
+    N, Q = 2000, 23
+    vecs = rng.standard_normal((N, D)).astype(np.float32)
+    queries = rng.standard_normal((Q, D)).astype(np.float32)
+    vs = J.VectorSet(ctx, vecs)
+    ords = rng.integers(0, N, (Q, B)).astype(np.int32)
+    ords[0, B - 1] = -1
+    ords[Q - 1, 0] = -1
+    ords[7, B // 2] = N + 5          # outside the set: -inf like a -1
+    for vsf in ALL_VSF:
+        g = vs.scores(queries, vsf, ords)
+        for q in range(Q):
+            want_all = O.compare_many(int(vsf), queries[q], vecs)
+            valid = (ords[q] >= 0) & (ords[q] < N)
+            assert np.array_equal(g[q][valid], want_all[ords[q][valid]]), (vsf, q)
+            assert np.all(np.isneginf(g[q][~valid]))
+    # one query: no packing (a single list's remainder has nobody to share a wavefront with)
+    g1 = vs.scores(queries[:1], VSF.COSINE, ords[:1])
+    want = O.compare_many(int(VSF.COSINE), queries[0], vecs)
+    v0 = (ords[0] >= 0) & (ords[0] < N)
+    assert np.array_equal(g1[0][v0], want[ords[0][v0]])
+
+
 def test_wrapped_vectors_edited_in_place_need_invalidate(ctx):
     """a VectorSet that WRAPS caller-owned device memory caches one float per row for the cosine rerank; after the
     caller rewrites rows in place, jv_hip_vectors_invalidate makes the next cosine score see the new rows (== the oracle)"""

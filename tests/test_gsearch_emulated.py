@@ -173,13 +173,13 @@ def test_workgroup_form_under_lane_reordering(emu, monkeypatch, order):
 @pytest.mark.parametrize("levels,fused,M,deg,N", [(2, True, 96, 32, 2500), (2, False, 96, 32, 2000), (3, True, 64, 24, 3000), (1, True, 96, 16, 3000)])
 def test_register_table_bound_form(emu, monkeypatch, levels, fused, M, deg, N):
     """UBR (round 5): the bound table prebuilt (gs_ubr_build_ref) and held in registers, survivors compacted and scored eight lanes
-    each, the candidate tier trimmed to what can still be popped — ids, scores and BOTH counters equal the oracle's, dot product and
-    cosine, fused blocks and codes by ordinal, rerankK from 1 to well above the degree, trims every 1 / 8 / 64 pushes"""
+    each, the candidate tier trimmed to what can still be popped — ids, scores and BOTH counters equal the oracle's, euclidean (round 6: lower bucket edges), dot
+    product and cosine, fused blocks and codes by ordinal, rerankK from 1 to well above the degree, trims every 1 / 8 / 64 pushes"""
     D = 8 * M
     lv, entry, entry_level, opq, codes, q = problem(900 + levels + M, N, D, M, levels, deg=deg, nq=8)
     og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
     dropped_total = scored_total = 0
-    for vsf in (O.DOT_PRODUCT, O.COSINE):
+    for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
         for rk in (10, 40, 150, 1):
             wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=fused)
             for trim, v1, cc in (("8", 9, 256), ("1", 12, 128), ("64", 9, 256)):
@@ -201,7 +201,7 @@ def test_register_table_bound_form_with_equal_and_extreme_scores(emu, monkeypatc
     for order in ("", "reverse", "random:9"):
         if order:
             monkeypatch.setenv("EMU_LANE_ORDER", order)
-        for vsf in (O.DOT_PRODUCT, O.COSINE):
+        for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
             wi, ws, wst = og.search(opq, codes, None, q, vsf, 30, 30, fused=True)
             ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, q, vsf, 30, True, ub8=2)
             check(ids, sc, st, status, wi, ws, wst)
@@ -209,7 +209,7 @@ def test_register_table_bound_form_with_equal_and_extreme_scores(emu, monkeypatc
     qn = q.copy()
     qn[0, 5] = np.nan
     qn[1, :] = 0.0
-    for vsf in (O.DOT_PRODUCT, O.COSINE):
+    for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
         wi, ws, wst = og.search(opq, codes, None, qn, vsf, 30, 30, fused=True)
         ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes, qn, vsf, 30, True, ub8=2)
         check(ids, sc, st, status, wi, ws, wst)
@@ -322,7 +322,7 @@ def test_register_table_bound_form_over_the_compacted_list(emu, monkeypatch, M, 
     assert lv[0][1].shape[1] == deg
     og = O.OracleGraph(codes.shape[0], lv, entry, entry_level)
     dropped_total = scored_total = 0
-    for vsf in (O.DOT_PRODUCT, O.COSINE):
+    for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
         for rk in (100, 10, 1):
             wi, ws, wst = og.search(opq, codes, None, q, vsf, rk, rk, fused=False)
             for trim, v1, cc in (("8", 9, 256), ("1", 12, 128), ("64", 9, 256)):
@@ -340,7 +340,7 @@ def test_register_table_bound_form_over_the_compacted_list(emu, monkeypatch, M, 
         for order in ("", "reverse", "random:5"):
             if order:
                 monkeypatch.setenv("EMU_LANE_ORDER", order)
-            for vsf in (O.DOT_PRODUCT, O.COSINE):
+            for vsf in (O.EUCLIDEAN, O.DOT_PRODUCT, O.COSINE):
                 wi, ws, wst = og2.search(opq, codes2, None, q, vsf, 40, 40, fused=False)
                 ids, sc, st, status, _ = run_emu(emu, lv, entry, entry_level, opq, codes2, q, vsf, 40, False, pair=2, ub8=2)
                 check(ids, sc, st, status, wi, ws, wst)

@@ -2,7 +2,7 @@
   * ubr_table_kernel's tables == gs_host.h's restatement, byte for byte (and the meta floats bit for bit);
   * searches == the oracle's sequential GraphSearcher: ids, scores, visitedCount and expandedCount — while the form really drops
     neighbours (gs_ubr_dropped) — dot product and cosine, fused blocks and codes by ordinal, trims every 1 / 24 / 200 pushes,
-    rerankK from 1 to 150; euclidean and filtered searches take the plain kernel.
+    rerankK from 1 to 150; filtered searches take the plain kernel (euclidean runs the bound form since round 6: lower bucket edges).
 The CPU twin (lane emulator) is tests/test_gsearch_emulated.py::test_register_table_bound_form*."""
 import ctypes as C
 import os
@@ -36,7 +36,7 @@ def emu_lib():
     return C.CDLL(E.LIB)
 
 
-@pytest.mark.parametrize("vsf", [VSF.DOT_PRODUCT, VSF.COSINE])
+@pytest.mark.parametrize("vsf", [VSF.EUCLIDEAN, VSF.DOT_PRODUCT, VSF.COSINE])
 def test_bound_tables_equal_the_restatement(ctx, vsf):
     D, M, Q = 768, 96, 21           # (21: a ragged last block of the 8-queries-per-block kernel)
     rng = np.random.default_rng(int(vsf))
@@ -54,24 +54,31 @@ def test_bound_tables_equal_the_restatement(ctx, vsf):
     for i in range(Q):
         wt = np.empty(M * 64, np.uint32)
         wm = np.empty(4, np.float32)
-        L.gs_emu_ubr_table(cb.ctypes.data_as(C.c_void_p), np.ascontiguousarray(cq[i]).ctypes.data_as(C.c_void_p), M, wt.ctypes.data_as(C.c_void_p),
-                           wm.ctypes.data_as(C.c_void_p))
+        L.gs_emu_ubr_table_vsf(cb.ctypes.data_as(C.c_void_p), np.ascontiguousarray(cq[i]).ctypes.data_as(C.c_void_p), M, wt.ctypes.data_as(C.c_void_p),
+                               wm.ctypes.data_as(C.c_void_p), 0 if vsf == VSF.EUCLIDEAN else 1)
         if i in (5, 7):
             assert meta[i, 2] == 0.0 and wm[2] == 0.0
             continue
         assert meta[i, 2] == 1.0
         assert np.array_equal(meta[i].view(np.uint32), wm.view(np.uint32)), (i, meta[i], wm)
         assert np.array_equal(tab[i], wt), (i, np.argwhere(tab[i] != wt)[:4])
-        # and the table really bounds: for random codes, base + S * sum(b + 1) >= the exact sum of entries
+        # and the table really bounds: for random codes, base + S * sum(b + 1) >= the exact sum of entries (euclidean: the LOWER
+        # edges, base + S * sum(b) <= the exact squared distance)
         codes = rng.integers(0, 256, (50, M))
-        ent = np.einsum("mcj,mj->mc", cb.reshape(M, 256, 8).astype(np.float64), cq[i].reshape(M, 8).astype(np.float64))
+        if vsf == VSF.EUCLIDEAN:
+            ent = ((cb.reshape(M, 256, 8).astype(np.float64) - cq[i].reshape(M, 1, 8).astype(np.float64)) ** 2).sum(-1)
+        else:
+            ent = np.einsum("mcj,mj->mc", cb.reshape(M, 256, 8).astype(np.float64), cq[i].reshape(M, 8).astype(np.float64))
         for c in codes:
             exact = ent[np.arange(M), c].sum()
             k = 2 * (np.arange(M) % (M // 2)) + (c >= 128)
             lane = c & 63
             word = tab[i][((k // 4) * 64 + lane) * 4 + k % 4]
             b = (word >> (8 * (((c >> 6) & 1) + 2 * (np.arange(M) >= M // 2)))) & 0xFF
-            assert meta[i, 0] + meta[i, 1] * float((b + 1).sum()) >= exact
+            if vsf == VSF.EUCLIDEAN:
+                assert meta[i, 0] + meta[i, 1] * float(b.sum()) <= exact
+            else:
+                assert meta[i, 0] + meta[i, 1] * float((b + 1).sum()) >= exact
 
 
 def _setup(ctx, seed, N, D, M, levels, use_fused, deg):
@@ -102,9 +109,9 @@ def test_register_table_bound_kernel(ctx, levels, use_fused, deg, N):
                     ctx.set_option("gs_ubr_trim", trim)
                     before = ctx.stat("gs_ubr_dropped")
                     ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True)
-                    assert ctx.stat("gs_last_ubr") == (0 if vsf == VSF.EUCLIDEAN else 1)
+                    assert ctx.stat("gs_last_ubr") == 1   # (round 6: euclidean too)
                     assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rk, trim)
-                    if vsf != VSF.EUCLIDEAN and rk >= 40:
+                    if rk >= 40:
                         assert ctx.stat("gs_ubr_dropped") - before > 0.1 * wst[:, 0].sum(), (vsf, rk, trim)
         # a filtered search: no threshold can be proven with rejected nodes around — the plain kernel
         accept = np.ones(len(v), bool)
@@ -138,7 +145,7 @@ def test_register_table_bound_kernel_ties_and_degenerate_queries(ctx):
     try:
         ctx.set_option("gs_ubr", 1)
         ctx.set_option("gs_wgx", 0)
-        for vsf in (VSF.DOT_PRODUCT, VSF.COSINE):
+        for vsf in VSF:
             for trim in (1, 24):
                 ctx.set_option("gs_ubr_trim", trim)
                 ids, sc, st = s.search(q, vsf, 30, 30, return_stats=True)
