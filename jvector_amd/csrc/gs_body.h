@@ -1745,7 +1745,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                         // ---- UBR over the compacted list (the builder's searches): a pass's <= 32 fresh neighbours are laid out like the
                         //      pair form's row — lane ni low half, lane ni + 32 high half of the code — so the bound, the staging of
                         //      the survivors and their eight-lane scoring are the pair form's (above), per pass ----
-                        constexpr int M_ = CH16 * 16, SUBS8 = M_ / 8;
+                        constexpr int M_ = CH16 * 16;
                         const bool hi = sub != 0;
                         const bool last_pass = (pass + 1) * PER >= nf;
                         gs_u2 w[CH16];
@@ -1786,65 +1786,23 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                             }
                         }
                         gs_barrier();
-                        const int g = lane >> 3;
-                        int t = lane & 7;
-                        GS_OPAQUE_I32(t);
+                        // (round 6: the scoring passes are the pair form's — gs_ubr_pass: batched LDS reads, 32 / 16 / 8 lanes per survivor)
                         fresh = false;
                         key = 0;
+#if GS_UBR_VAR_LPS
+                        const int per = ns <= 2 ? 2 : (ns <= 4 ? 4 : 8);
+#else
+                        const int per = 8;
+#endif
 #pragma unroll 1
-                        for (int base = 0; base < ns; base += 8) {
-                            const int j = base + g;
-                            const bool wk = j < ns;
-                            float sum = 0.0f;
-                            if (wk) {
-                                const uint32_t *cw = reinterpret_cast<const uint32_t *>(st_code + j * M_ + t * SUBS8);
-                                uint32_t d[SUBS8 / 4];
-#pragma unroll
-                                for (int i = 0; i < SUBS8 / 4; ++i) d[i] = cw[i];
-                                float v[SUBS8];
-#pragma unroll
-                                for (int h2 = 0; h2 < 2; ++h2) {
-                                    gs_f4 c0[SUBS8 / 2], c1[SUBS8 / 2];
-#pragma unroll
-                                    for (int kk = 0; kk < SUBS8 / 2; ++kk) {
-                                        const int k = h2 * (SUBS8 / 2) + kk;
-                                        const uint32_t code = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                                        const gs_f4 *cp = reinterpret_cast<const gs_f4 *>(p.codebooks + ((int64_t)((t * SUBS8 + k) * 256) + code) * 8);
-                                        c0[kk] = cp[0];
-                                        c1[kk] = cp[1];
-                                    }
-#pragma unroll
-                                    for (int kk = 0; kk < SUBS8 / 2; ++kk) {
-                                        const int k = h2 * (SUBS8 / 2) + kk;
-                                        v[k] = gs_lut_entry_pk<VSF>(c0[kk], c1[kk], qs + (t * SUBS8 + k) * 8);
-                                    }
-                                }
-                                if (t == 0) {
-#pragma unroll
-                                    for (int k = 0; k < SUBS8; ++k) sum += v[k];
-                                } else {
-#pragma unroll
-                                    for (int k = 0; k < SUBS8; ++k) xf[g * (7 * SUBS8) + (t - 1) * SUBS8 + k] = v[k];
-                                }
-                            }
-                            gs_barrier();
-                            fresh = wk && t == 0;
-                            key = 0;
-                            if (fresh) {
-                                const gs_f4 *col = reinterpret_cast<const gs_f4 *>(xf + g * (7 * SUBS8));
-#pragma unroll
-                                for (int i = 0; i < 7 * SUBS8 / 4; ++i) {
-                                    const gs_f4 e4 = col[i];
-                                    sum += e4.x;
-                                    sum += e4.y;
-                                    sum += e4.z;
-                                    sum += e4.w;
-                                }
-                                const float sc = gs_finish<VSF>(sum, st_mag[j], query_mag);
-                                key = gs_key(st_nb[j], sc);
-                                if (ub_active && sc < ub_T) fresh = false;
-                            }
-                            if (base + 8 >= ns && last_pass) break;   // the shared tail below pushes the expansion's last scores
+                        for (int base = 0; base < ns; base += per) {
+#if GS_UBR_VAR_LPS
+                            if (ns <= 2) gs_ubr_pass<VSF, M_, 32>(p.codebooks, qs, xf, st_nb, st_mag, st_code, base, ns, query_mag, ub_active, ub_T, fresh, key);
+                            else if (ns <= 4) gs_ubr_pass<VSF, M_, 16>(p.codebooks, qs, xf, st_nb, st_mag, st_code, base, ns, query_mag, ub_active, ub_T, fresh, key);
+                            else
+#endif
+                            gs_ubr_pass<VSF, M_, 8>(p.codebooks, qs, xf, st_nb, st_mag, st_code, base, ns, query_mag, ub_active, ub_T, fresh, key);
+                            if (base + per >= ns && last_pass) break;   // the shared tail below pushes the expansion's last scores
                             gs_barrier();
                             if (ub_on && gs_ballot(fresh && (int32_t)(key >> 32) == 0x7fc00000)) ub_on = false;
                             gs_push(s, p, key, fresh);
