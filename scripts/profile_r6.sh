@@ -32,7 +32,8 @@ for G in "$G1" "$G2" "$G3"; do
   timeout 600 rocprofv3 --pmc $G --output-format csv -d $O/g$i -o bench -- python $R/bench.py $SHORT > $K/g$i.log 2>&1
   extract g$i
 done
-# ---- B. the flat filter at its three shapes ----
+# ---- B. the flat filter at its three shapes (SKIP_FLAT=1: section A only) ----
+[ "${SKIP_FLAT:-0}" = 1 ] && { ls $K | wc -l; exit 0; }
 FLATC2="--workload c2 --no-cpu-baseline --steps 5 --warmup 1"
 FLATC4="--workload c4 --no-cpu-baseline --steps 3 --warmup 1"
 FLATFM="--n $N --index-cache $C --no-cpu-baseline --no-sub-workloads --steps 1 --warmup 1 --cal-queries 256 --eval-queries 256 --rerank 74"

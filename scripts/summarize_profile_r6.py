@@ -15,7 +15,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 # round 5: the headline traversal is the register-table bound form (graph_search_ubr_kernel) + its table kernel; a C5 run adds the robust prune
-KEYS = {"gsearch_ubr": "graph_search_ubr_kernel", "ubr_table": "ubr_table_kernel", "gsearch": "graph_search_kernel", "exact_gather": "exact_gather_tr_kernel",
+KEYS = {"gsearch_ubr": "graph_search_ubr_kernel", "ubr_table": "ubr_table_kernel", "gsearch": "graph_search_kernel", "exact_gather": "exact_gather_tr_kernel", "exact_gather_trq": "exact_gather_trq_kernel",
         "adc_mq": "adc_mq_kernel", "retain_diverse": "retain_diverse_kernel", "gsearch_pairc": "graph_search_pairc_kernel"}
 
 for f, t in (("bench_kernel_stats.csv", f"{tag}_kernel_stats.csv"), ("rocminfo.txt", f"{tag}_rocminfo.txt")):
