@@ -163,7 +163,7 @@ def last_line(name):
 
 for w, kcfg in FLAT.items():
     line = last_line(f"{w}_trace.log") or last_line(f"{w}_FETCH_SIZE.log")
-    rk = (line.get("flat_mode") or {}).get("rerankK") if w == "fm" else (line.get("config") or {}).get("rerankK")
+    rk = ((line.get("flat_mode") or (line.get("workloads") or {}).get("flat_mode") or {}).get("rerankK")) if w == "fm" else (line.get("config") or {}).get("rerankK")
     e = {"kernel_key": "adc_bq", "kernel": "adc_bq_kernel (+ adc_bq_table_kernel, the survivors' exact gather, adc_bq_count_kernel)", "tag": tag, "shape": w,
          "config": {**kcfg, "rerankK": rk}}
 
