@@ -244,8 +244,9 @@ def measured_traffic(kernel_key, cfg, want_entry=False):
             ec = e.get("config", {})
             # (rerankK may differ by a rung of the calibration ladder between the profiled run and this one: within 10 % the counters
             #  still describe this kernel on this index; the line names the profiled rerankK next to the number)
+            # (the flat filter's bound scan reads the same codes and tables whatever rerankK is: its entries match on the shape alone)
             if e.get("kernel_key") == kernel_key and all(ec.get(k) == v for k, v in cfg.items() if k != "rerankK") and \
-                    ec.get("rerankK") and abs(ec["rerankK"] - cfg.get("rerankK", 0)) <= 0.1 * ec["rerankK"]:
+                    (kernel_key == "adc_bq" or (ec.get("rerankK") and abs(ec["rerankK"] - cfg.get("rerankK", 0)) <= 0.1 * ec["rerankK"])):
                 if want_entry:
                     return e
                 return e.get("hbm_bytes_per_launch")

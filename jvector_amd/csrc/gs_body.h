@@ -1143,6 +1143,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         return true;
     };
     long long n_visited = 0, n_expanded = 0;
+    int n_log = 0;   // push-log entries offered at layer 0 (wave-uniform)
 
     // tier 2 is cleared by the first probe that needs it (wave-uniform call)
     auto t2_init = [&]() {
@@ -1359,9 +1360,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             trk_min = 0x7fffffff;
             trk_min_idx = -1;
         }
-        // layer 0 evicts nothing, so the evicted area's first word counts the push-log entries there (lane 0 only: no
-        // register stays live across the loop for it)
-        if (lvl == 0 && p.push_log && lane == 0) *reinterpret_cast<int *>(s.evicted) = 0;
+        // the push log's entry count: wave-uniform, in a scalar register (round 6; it sat in the evicted area's first LDS word, read
+        // and written by lane 0 at every addTopCandidate — two LDS round trips on the expansion's chain)
+        if (lvl == 0) n_log = 0;
         // ---- searchOneLayer :406-457 (layer 0 of a session with a history: once per phase) ----
         for (;;) {
         for (;;) {
@@ -1449,10 +1450,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 result = ((acc[tn >> 6] >> (tn & 63)) & 1ull) != 0;
             }
             if (result && lvl == 0 && excl >= 0) result = gs_key_node(top) != excl;
-            if (result && lvl == 0 && p.push_log && lane == 0) {  // the addTopCandidate sequence, for rt_body.h's tie resolution
-                const int n_log = *reinterpret_cast<int *>(s.evicted);
-                if (n_log < p.push_log_cap) p.push_log[(int64_t)q * p.push_log_cap + n_log] = top;
-                *reinterpret_cast<int *>(s.evicted) = n_log + 1;
+            if (result && lvl == 0 && p.push_log) {  // the addTopCandidate sequence, for rt_body.h's tie resolution
+                if (lane == 0 && n_log < p.push_log_cap) p.push_log[(int64_t)q * p.push_log_cap + n_log] = top;
+                n_log++;
             }
             if (!result) {
                 gs_barrier();
@@ -1942,7 +1942,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             n_visited = 0;
             n_expanded = 0;
             n_expanded_base = 0;
-            if (p.push_log && lane == 0) *reinterpret_cast<int *>(s.evicted) = 0;
+            n_log = 0;
             gs_barrier();
         }
         }
@@ -1981,7 +1981,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         p.out_stats[2 * (int64_t)q + 1] = n_expanded;
         p.out_status[q] = s.status;
         if (SES && p.out_base) p.out_base[q] = (int32_t)n_expanded_base;
-        if (p.push_log) p.push_log_n[q] = s.status == GS_OK ? *reinterpret_cast<int *>(s.evicted) : -1;
+        if (p.push_log) p.push_log_n[q] = s.status == GS_OK ? n_log : -1;
     }
     gs_barrier();
     if (PROF && p.prof && lane == 0) {
