@@ -767,6 +767,10 @@ def _compact_roofline(r, kernel_chars=72):
            "traffic_source": _short(r.get("traffic_source"), 64) if r.get("traffic_source") else None,
            "avg_launch_ms": _r(r.get("avg_launch_ms")), "launches": r.get("launches"),
            "bytes_per_launch": _r(r.get("bytes_per_launch"), 6)}
+    if r.get("fused_rerank_rows"):   # round 6: the traversal kernel also reranks; both byte terms and the round-5 definition of frac
+        out.update({"fused_rerank_rows": r["fused_rerank_rows"], "traversal_bytes_per_launch": _r(r.get("traversal_bytes_per_launch"), 6),
+                    "rerank_bytes_per_launch": _r(r.get("rerank_bytes_per_launch"), 6),
+                    "frac_traversal_bytes_only": _r(r.get("frac_traversal_bytes_only"), 4)})
     return out
 
 
@@ -1202,7 +1206,20 @@ def main():
                       "scoring; one launch per traversal round of a slot group; traversal on the host)")
             note = "host traversal: bound by the host cores, not by this kernel"
         bytes_total = expansions * unit_bytes
+        # round 6: rows [0, rr_rows) of every query's kept results get their exact rerank score INSIDE the traversal wave (gs_body.h
+        # gs_rr_round; counter gs_last_rr_rows): the kernel then also moves SURVEY §8d row 1's 4 D + 4 bytes per reranked candidate,
+        # and its time includes that work — both terms are carried separately in the roofline object
+        rr_rows = int(ctx.stat("gs_last_rr_rows")) if args.traversal == "device" and args.reranker == "full" else 0
+        trav_bytes = bytes_total
+        fused_rr_bytes = float(Q) * args.steps * rr_rows * (4 * D + 4)
+        if rr_rows > 0:
+            bytes_total += fused_rr_bytes
+            kernel += (f"; round 6: the wave also computes the exact rerank score of rows [0, {rr_rows}) of its query's {rerank_k} kept results "
+                       "(rows transposed through the idle LDS block, the scalar provider's chain)")
+            note += (f"; + {rr_rows} reranked candidates per query x {4 * D + 4} B (SURVEY §8d row 1) scored inside this kernel: "
+                     "frac = (traversal + rerank bytes) / kernel time, frac_traversal_bytes_only = the round-5 definition over the same time")
     else:
+        rr_rows, trav_bytes, fused_rr_bytes = 0, 0.0, 0.0
         k_ms, k_n = prof["adc"]
         kernel_key, kernel, note, bytes_total = "adc_mq", "", "", 0.0
     k_avg_s = k_ms / 1e3 / max(k_n, 1)
@@ -1211,14 +1228,18 @@ def main():
     e_ms, e_n = prof["exact"]
     if e_n > 0 and e_ms > 0:
         row_bytes = (D + 16 * args.nvq_subvectors + 4 + 4) if args.reranker == "nvq" else (4 * D + 4)
-        rr_bytes = float(Q) * rerank_k * args.steps * row_bytes
+        rr_bytes = float(Q) * (rerank_k - rr_rows) * args.steps * row_bytes   # (fused rerank: only the lists' remainders are left to this region)
+        if rr_rows > 0:
+            e_n = args.steps   # (two scopes per step: the query norms, the packed remainders)
         ach = rr_bytes / (e_ms / 1e3) / 1e9
         rr_kernel = ("nvq_gather_kernel<COSINE> (NVQ.rerankerFor: NVQ rows of the kept candidates — one byte per dimension + 16 B per "
                      "sub-vector + the row's normalisation sum — de-quantised and chained in the scalar provider's order; VALU-bound "
                      "(~26 instructions per dimension incl. an IEEE divide), priced against HBM for comparability)"
                      if args.reranker == "nvq" else
-                     "exact_gather_tr_kernel<COSINE> (NodeQueue.rerank: full-resolution cosine of the "
-                     "kept candidates; rows gathered by ordinal in coalesced 256-byte pieces and transposed through LDS)")
+                     (f"exact_gather_trq_kernel<COSINE> + query_sqnorm_kernel (what is left of NodeQueue.rerank outside the traversal kernel: rows "
+                      f"[{rr_rows}, {rerank_k}) of every list, several queries per wavefront, and the queries' norms)" if rr_rows > 0 else
+                      "exact_gather_tr_kernel<COSINE> (NodeQueue.rerank: full-resolution cosine of the "
+                      "kept candidates; rows gathered by ordinal in coalesced 256-byte pieces and transposed through LDS)"))
         extra_roof["rerank"] = {"bound": "hbm", "kernel": rr_kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("exact_gather", cfg_key),
                                 "bytes_per_launch": rr_bytes / e_n, "avg_launch_ms": e_ms / e_n, "launches": e_n}
@@ -1260,6 +1281,10 @@ def main():
                                            "(replayed, not measured by this run)") if measured_traffic(kernel_key, cfg_key) is not None else None,
                         "bytes_per_launch": bytes_total / max(k_n, 1), "avg_launch_ms": k_avg_s * 1e3, "launches": k_n,
                         "expansions_per_launch": expansions / max(k_n, 1), "bytes_per_expansion": unit_bytes, "note": note}
+            if rr_rows > 0:
+                roofline.update({"fused_rerank_rows": rr_rows, "traversal_bytes_per_launch": trav_bytes / max(k_n, 1),
+                                 "rerank_bytes_per_launch": fused_rr_bytes / max(k_n, 1),
+                                 "frac_traversal_bytes_only": (trav_bytes / (k_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else 0.0})
         elif flat_info is not None:
             roofline = flat_info["roofline"]
         else:

@@ -119,7 +119,10 @@ JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
  *   last search ran the register-table bound form — option gs_ubr, on by default where it applies: pair-lane kernels, dot product /
  *   cosine, PQ-96; gs_ubrc, also on by default: the same form over the compacted fresh list of rows 33 ... 64 wide read by ordinal, i.e. the
  *   builder's own searches; gs_ubr_trim = candidates pushed between two trims of its queue), gs_ubr_dropped (neighbours that form dropped
- *   behind their bound, unscored); experimental_build (1: the library was built with make EXPERIMENTAL=1 and also holds the
+ *   behind their bound, unscored), gs_last_rr_rows (rows [0, r) of every query's kept approximate results whose exact rerank score the
+ *   traversal wave computed itself in the last search — option gs_fused_rerank, on by default where the rerank's transposing kernel
+ *   applies: 16-byte aligned rows, D % 8 == 0, lists of <= 256, one-wave forms; the same scalar-order chain, the same bits;
+ *   0: the rerank was a kernel of its own); experimental_build (1: the library was built with make EXPERIMENTAL=1 and also holds the
  *   measured-and-switched-off variants gs_quad, rd_table_free, rd_chunk, rd_square — the default build accepts
  *   and ignores their options). */
 JV_API int jv_hip_ctx_set_option(jv_ctx *ctx, const char *name, int64_t value);

@@ -1629,6 +1629,28 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p.push_log_cap = log_cap;
     }
     p.prof = gs_prof ? (unsigned long long *)(base + o_prof) : nullptr;
+    // ---- round 6: the rerank's exact scores inside the traversal wave (gs_body.h gs_rr_round).  Full-resolution rows that
+    //      exact_gather_tr_kernel would take (16-byte aligned, D % 8 == 0, the norm table for cosine), lists of <= 256 results, the
+    //      one-wave forms (the workgroup form's control block is smaller than the tile; GraphSearcher objects rerank on their own):
+    //      rows [0, rr_rows) of every list leave the kernel with their exact score, the packed-remainder launch does the rest.
+    //      gs_fused_rerank = 0: the rerank stays a kernel of its own.  Same arithmetic, same bits either way.
+    int rr_rows = 0;
+    if (!so && !wgx && vectors && !vectors->nvq && vectors->D == pq->D && gs_rr_lds_bytes() <= lds && ctx_opt(ctx, "gs_fused_rerank", 1) != 0) {
+        if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
+        rr_rows = exact_fused_rows(vectors->d_vecs, vectors->D, l->d_raw_queries, Q, kvsf, rerankK, vectors->d_sqnorm);
+    }
+    if (rr_rows > 0) {
+        if (vsf == JV_COSINE) {
+            ProfScope ps(ctx, R_EXACT);
+            JV_TRY(launch_query_sqnorms(ctx->stream, l->d_raw_queries, vectors->D, Q, d_qnorm));
+        }
+        p.rr_vecs = vectors->d_vecs;
+        p.rr_queries = l->d_raw_queries;
+        p.rr_qnorm = d_qnorm;
+        p.rr_vnorm = vectors->d_sqnorm;
+        p.rr_n = vectors->count;
+        p.rr_rows = rr_rows;
+    }
     {
         ProfScope ps(ctx, R_GSEARCH);
         JV_TRY(launch(p, workers));
@@ -1752,7 +1774,15 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     JV_TRY(stage_out_begin(ctx, out_ids, sizeof(int32_t) * (size_t)Q * topK, ctx->d_scratch2, &oi));
     JV_TRY(stage_out_begin(ctx, out_scores, sizeof(float) * (size_t)Q * topK, ctx->d_scratch3, &osc));
     JV_TRY(ctx->d_scratch.reserve(topk_scratch_bytes(Q, topK)));
-    if (vectors) JV_TRY(rerank_gather(ctx, vectors, l->d_raw_queries, Q, vsf, d_cand, rerankK, d_cand_sc, d_qnorm));
+    if (vectors && rr_rows > 0) {   // (the traversal scored rows [0, rr_rows) itself)
+        if (rr_rows < rerankK) {
+            ProfScope ps(ctx, R_EXACT);
+            JV_TRY(launch_exact_gather_tail(ctx->stream, vectors->d_vecs, vectors->count, vectors->D, l->d_raw_queries, Q, kvsf, d_cand, rerankK, rr_rows,
+                                            d_cand_sc, d_qnorm, vectors->d_sqnorm));
+        }
+    } else if (vectors) {
+        JV_TRY(rerank_gather(ctx, vectors, l->d_raw_queries, Q, vsf, d_cand, rerankK, d_cand_sc, d_qnorm));
+    }
     {
         ProfScope ps(ctx, R_TOPK);
         JV_TRY(launch_topk(ctx->stream, ctx, d_cand_sc, d_cand, Q, rerankK, rerankK, 0, topK, (int32_t *)oi.dev,
@@ -1818,6 +1848,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     ctx_stat_set(ctx, "gs_last_workers_per_cu", per_cu);
     ctx_stat_set(ctx, "gs_last_wgx", wgx ? 1 : 0);
     ctx_stat_set(ctx, "gs_last_ubr", ubr ? 1 : 0);
+    ctx_stat_set(ctx, "gs_last_rr_rows", rr_rows);   // rows of every list the traversal wave reranked itself (0: the rerank was a kernel of its own)
     ctx_stat_set(ctx, "gs_last_pair", pair ? 1 : (pairc ? 2 : 0));   // 1: pair lanes over the row, 2: over the compacted fresh list
     if (wgx) ctx_stat_add(ctx, "gs_calls_wgx", 1);
     if (ctx_opt(ctx, "graph_timing", 0) != 0)

@@ -1022,6 +1022,128 @@ GS_FN void gs_ubr_trim(GsState &s, int rk, float &T)
     T = ps;
 }
 
+// ---- round 6: the exact rerank inside the traversal wave (GraphSearcher.reranking :471-507 / NodeQueue.rerank :160-230: the exact
+//      similarity of every kept approximate result; the selection stays with topk / rerank_tie_kernel) --------------------------------
+// One round = up to 64 of the query's kept results, lane = row.  The rows travel exactly as in exact_gather_tr_kernel (k_exact.hip
+// tr_rows, the 64 x 64 shape): load instruction k fetches 64-float chunks of rows 4 k + sub, 16 bytes per lane, the chunk is
+// transposed through an LDS tile (row stride 68 dwords), and lane r walks row r's chunk in index order with the reference's
+// association per block of eight (DefaultVectorUtilSupport.java:38-105 dot, :158-193 L2, :121-139 cosine; dot8 / l28 / the cosine
+// chain of k_exact.hip) — non-fused, the same bits.  The query's chunk sits one float per lane in a register and reaches the chain
+// through gs_shfl from a wave-uniform lane (v_readlane_b32: the scalar operand of the multiply).  Why here: the separate kernel cost
+// 5.4 ms of a 57.6 ms step behind a traversal that leaves HBM at 13 % and the SIMDs' issue slots at 38 %; inside the wave the same
+// work fills those gaps (the search has ended: its 96 table registers and its LDS block are free).  Every lane takes part in every
+// step (the shuffles are wave collectives): a lane without a row walks zeros.
+typedef float gs_v4f __attribute__((vector_size(16)));   // (a builtin vector: loadable through an address-space-qualified pointer)
+
+template <int VSF>
+GS_FN float gs_rr_block8(float acc, const float (&a)[8], const gs_v4f v0, const gs_v4f v1)
+{
+    if (VSF == 1) {
+        float t = v0[0] * a[0] + v0[1] * a[1];
+        t = t + v0[2] * a[2];
+        t = t + v0[3] * a[3];
+        t = t + v1[0] * a[4];
+        t = t + v1[1] * a[5];
+        t = t + v1[2] * a[6];
+        t = t + v1[3] * a[7];
+        return acc + t;
+    } else if (VSF == 0) {
+        const float d0 = a[0] - v0[0], d1 = a[1] - v0[1], d2 = a[2] - v0[2], d3 = a[3] - v0[3];
+        const float d4 = a[4] - v1[0], d5 = a[5] - v1[1], d6 = a[6] - v1[2], d7 = a[7] - v1[3];
+        float t = d0 * d0 + d1 * d1;
+        t = t + d2 * d2;
+        t = t + d3 * d3;
+        t = t + d4 * d4;
+        t = t + d5 * d5;
+        t = t + d6 * d6;
+        t = t + d7 * d7;
+        return acc + t;
+    } else {
+        float s = acc;
+        s += a[0] * v0[0];
+        s += a[1] * v0[1];
+        s += a[2] * v0[2];
+        s += a[3] * v0[3];
+        s += a[4] * v1[0];
+        s += a[5] * v1[1];
+        s += a[6] * v1[2];
+        s += a[7] * v1[3];
+        return s;
+    }
+}
+
+// my_row: the ordinal of this lane's row, -1 = none; qraw: the query's raw vector (wave-uniform); tile: gs_rr_lds_bytes() of LDS.
+// First version (profiles/r6_s): inlined, one chunk requested ahead, the chain a runtime loop of eight blocks, each behind its own pair
+// of LDS reads and sixteen lane broadcasts — 12.5 k clocks per chunk, 150 k per query: the fused rerank cost the traversal what the
+// kernel of its own had cost the step.  Now: TWO chunks in flight, one v_readlane_b32 per query element (gs_bcast32), the chain
+// unrolled so that its LDS reads are issued together — and a CALL (GS_NOINLINE): inlined, the 130 staging registers pushed three
+// per-query values of the expansion loop into scratch (two scratch loads per expansion in front of the drop test).
+template <int VSF>
+GS_NOINLINE float gs_rr_round(const float *vecs_generic, int D, const float *qraw_generic, int32_t my_row, float *tile_generic)
+{
+    GS_LDS_AS float *tile = (GS_LDS_AS float *)tile_generic;
+    GS_GLOBAL_AS const float *vecs = (GS_GLOBAL_AS const float *)vecs_generic;
+    GS_GLOBAL_AS const float *qraw = (GS_GLOBAL_AS const float *)qraw_generic;
+    const int lane = gs_lane();
+    const int seg = (lane & 15) * 4, sub = lane >> 4;
+    int32_t ro[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) ro[k] = gs_shfl32(my_row, 4 * k + sub);
+    const int nc = (D + GS_RR_CH - 1) / GS_RR_CH;
+    gs_v4f rA[16], rB[16];
+    float qA = 0.0f, qB = 0.0f;
+    // (requests are unconditional — sixteen loads back to back, no branch around each: a lane without a row reads row 0, a piece past
+    //  the end of a ragged last chunk reads the row's last 16 bytes; neither value is ever used — the chain skips the blocks past D
+    //  and the caller discards the score of a lane without a row)
+    auto issue = [&](int c, gs_v4f (&r)[16], float &qv) {
+        const int off = c * GS_RR_CH + seg < D ? c * GS_RR_CH + seg : D - 4;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            r[k] = *reinterpret_cast<GS_GLOBAL_AS const gs_v4f *>(vecs + (int64_t)(ro[k] >= 0 ? ro[k] : 0) * D + off);
+        qv = qraw[c * GS_RR_CH + lane < D ? c * GS_RR_CH + lane : D - 1];
+    };
+    float acc = 0.0f;
+    // chunk c: the staged rows leave their registers, the registers take chunk c + 2, the lane walks its row's 64 floats
+    auto step = [&](int c, gs_v4f (&r)[16], float &qv) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<GS_LDS_AS gs_v4f *>(tile + (4 * k + sub) * GS_RR_LS + seg) = r[k];
+        const uint32_t qc = __builtin_bit_cast(uint32_t, qv);
+        gs_barrier();
+        if (c + 2 < nc) issue(c + 2, r, qv);
+        const int len = (D - c * GS_RR_CH < GS_RR_CH) ? (D - c * GS_RR_CH) : GS_RR_CH;   // (a multiple of 8: exact_tr_supported)
+        GS_LDS_AS const float *row = tile + lane * GS_RR_LS;
+        auto block = [&](int i, const gs_v4f v0, const gs_v4f v1) {
+            float a8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a8[j] = __builtin_bit_cast(float, gs_bcast32(qc, i + j));
+            acc = gs_rr_block8<VSF>(acc, a8, v0, v1);
+        };
+        if (len == GS_RR_CH) {   // the LDS reads of half a chunk issued together (the fence keeps them in front of the chain); all sixteen
+                                 // at once made the callee touch every register and the CALLER spill inside its expansion loop
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                gs_v4f t[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = *reinterpret_cast<GS_LDS_AS const gs_v4f *>(row + 32 * h + 4 * i);
+                GS_SCHED_FENCE();
+#pragma unroll
+                for (int i = 0; i < 32; i += 8) block(32 * h + i, t[i / 4], t[i / 4 + 1]);
+            }
+        } else {
+            for (int i = 0; i < len; i += 8)
+                block(i, *reinterpret_cast<GS_LDS_AS const gs_v4f *>(row + i), *reinterpret_cast<GS_LDS_AS const gs_v4f *>(row + i + 4));
+        }
+        gs_barrier();
+    };
+    issue(0, rA, qA);
+    if (nc > 1) issue(1, rB, qB);
+    for (int c = 0; c < nc; c += 2) {
+        step(c, rA, qA);
+        if (c + 1 < nc) step(c + 1, rB, qB);
+    }
+    return acc;
+}
+
 #ifndef GS_CLOCK
 #define GS_CLOCK() 0ull  // the GPU build maps it to the shader clock (gs_wave_hip.h); the emulator has no clock
 #endif
@@ -1970,11 +2092,34 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 
     // ---- hand the kept approximate results to the rerank stage ----
     gs_barrier();
+    // (round 6: rows [0, rr_rows) get their EXACT similarity right here, below — their ordinals leave LDS first: the tile overwrites it)
+    const bool rr = !SES && p.rr_vecs != nullptr;
+    int32_t rr_node[GS_RR_MAX_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < GS_RR_MAX_ROUNDS; ++r) {
+        const int i = 64 * r + lane;
+        rr_node[r] = (rr && s.status == GS_OK && i < s.res_n && i < p.rr_rows) ? gs_key_node(s.res[i]) : -1;
+    }
     for (int i = lane; i < p.rerankK; i += 64) {
         const bool have = s.status == GS_OK && i < s.res_n;
         const long long k = have ? s.res[i] : 0;
         p.out_ids[(int64_t)q * p.rerankK + i] = have ? gs_key_node(k) : -1;
-        p.out_scores[(int64_t)q * p.rerankK + i] = have ? gs_key_score(k) : -__builtin_inff();
+        if (!(rr && i < p.rr_rows)) p.out_scores[(int64_t)q * p.rerankK + i] = have ? gs_key_score(k) : -__builtin_inff();
+    }
+    if (rr) {
+        gs_barrier();   // every lane has read its keys: the LDS block is the tile's now
+        const float *qraw = p.rr_queries + (int64_t)q * p.D;
+        for (int r = 0; 64 * r < p.rr_rows; ++r) {
+            int32_t o = rr_node[0];   // (a select chain, not an indexed read: the array stays in registers)
+#pragma unroll
+            for (int t = 1; t < GS_RR_MAX_ROUNDS; ++t) o = r == t ? rr_node[t] : o;
+            if ((long long)o >= p.rr_n) o = -1;
+            const float raw = gs_rr_round<VSF>(p.rr_vecs, p.D, qraw, o, reinterpret_cast<float *>(lds));
+            const int i = 64 * r + lane;
+            if (i < p.rr_rows)
+                p.out_scores[(int64_t)q * p.rerankK + i] =
+                    o < 0 ? -__builtin_inff() : gs_finish<VSF>(raw, VSF == 2 ? p.rr_vnorm[o] : 0.0f, VSF == 2 ? p.rr_qnorm[q] : 0.0f);
+        }
     }
     if (lane == 0) {
         p.out_stats[2 * (int64_t)q] = n_visited;

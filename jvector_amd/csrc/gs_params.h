@@ -111,9 +111,25 @@ struct GsParams {
     long long *push_log;      // [Q][push_log_cap]
     int32_t *push_log_n;      // [Q] entries offered (> push_log_cap: the log overflowed)
     int push_log_cap;
+    // round 6: NodeQueue.rerank's exact scores INSIDE the traversal wave (gs_body.h gs_rr_round): once a query's search has ended its
+    // wave gathers the full-resolution rows of the kept results [0, rr_rows) — 64 per round, the rows transposed through the (now
+    // idle) LDS block exactly as exact_gather_tr_kernel does, the same sequential chain per row — and out_scores receives the EXACT
+    // similarity instead of the approximate one; rows [rr_rows, rerankK) keep the approximate score for the packed-remainder kernel
+    // (launch_exact_gather_tail).  nullptr = the rerank is a kernel of its own.
+    const float *rr_vecs;     // [rr_n][D] full-resolution vectors (16-byte aligned, D % 8 == 0)
+    const float *rr_queries;  // [Q][D] the raw queries
+    const float *rr_qnorm;    // [Q] sum of squares of a query (cosine), query_sqnorm_kernel
+    const float *rr_vnorm;    // [rr_n] sum of squares of a row (cosine), launch_row_sqnorms
+    long long rr_n;
+    int32_t rr_rows;          // <= 64 * GS_RR_MAX_ROUNDS
     uint32_t *next_query;     // work counter (zeroed by the host before the launch)
     unsigned long long *prof; // developer aid (JVECTOR_HIP_GS_PROF=1): 8 phase counters, see gs_search_one; else nullptr
 };
+
+// the fused rerank's LDS tile: 64 rows x (64 + 4) floats (the row stride of exact_gather_tr_kernel: conflict-free 16-byte reads), laid
+// over the head of the worker's block once the search has ended
+constexpr int GS_RR_CH = 64, GS_RR_LS = GS_RR_CH + 4, GS_RR_MAX_ROUNDS = 4;
+constexpr size_t gs_rr_lds_bytes() { return sizeof(float) * 64 * (size_t)GS_RR_LS; }
 
 // the centred query at the head of a worker's LDS block, padded so that the 8-byte arrays behind it stay aligned for any D
 constexpr size_t gs_q_bytes(int D) { return (sizeof(float) * (size_t)D + 15) & ~(size_t)15; }

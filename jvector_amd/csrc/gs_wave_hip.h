@@ -7,6 +7,14 @@
 
 #define GS_FN __device__ __forceinline__
 #define GS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// a device function that stays a CALL: its registers are allocated on their own (gs_rr_round — the fused rerank's 130 staging registers
+// must not weigh on the allocation of the expansion loop, which sits at the 256-register wall).  Callable from the 2-waves-per-SIMD kernels.
+#define GS_NOINLINE __device__ __attribute__((noinline))
+// a pointer into the workgroup's LDS block that went through a call is a flat pointer to the compiler; cast back, the accesses are ds_ again
+#define GS_LDS_AS __attribute__((address_space(3)))
+// likewise a pointer into device memory: global_load instead of flat_load (a flat load counts on the LDS counter too: every wait for an
+// LDS read would wait for the row requests in flight)
+#define GS_GLOBAL_AS __attribute__((address_space(1)))
 __device__ __forceinline__ int gs_lane() { return (int)threadIdx.x; }
 #ifdef GS_WAVE_SCOPE_BARRIER
 // the workgroup form (gx_body.h): gs_body.h runs in ONE wave of a larger workgroup, so its sync points are wave-scope — LDS
@@ -113,6 +121,8 @@ __device__ __forceinline__ int32_t gs_uniform(int32_t v) { return __builtin_amdg
 #else
 __device__ __forceinline__ long long gs_shfl(long long v, int src) { return __shfl(v, src, 64); }
 #endif
+// the 32-bit value of ONE lane, `src` wave-uniform: v_readlane_b32 — the result is a scalar register (gs_rr_round: the operand of a multiply)
+__device__ __forceinline__ uint32_t gs_bcast32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 __device__ __forceinline__ long long gs_shfl_xor(long long v, int m) { return __shfl_xor(v, m, 64); }
 // the value is what it was, but the compiler may not reason about where it came from (keeps per-lane address arithmetic inside the
 // loop that uses it instead of hoisting dozens of 64-bit pointers out of the search loop and spilling them)

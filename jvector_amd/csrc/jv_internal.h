@@ -313,6 +313,14 @@ int launch_gather_rows(hipStream_t s, const float *d_vecs, int64_t n, int D, con
 int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf,
                         const int32_t *d_ord, int B, float *d_out, float *d_qnorm, const float *d_vnorm);
 int launch_row_sqnorms(hipStream_t s, const float *d_vecs, int64_t n, int D, float *d_out);
+// the rerank fused into the traversal wave (gs_body.h gs_rr_round, round 6): how many rows [0, r) of every list of B the wave scores
+// itself — 0 = this shape keeps the kernel of its own (rows not 16-byte aligned / D % 8 != 0 / no norm table / B > 256 / the
+// developer selectors of launch_exact_gather); r < B: the remainder [r, B) is one packed launch of launch_exact_gather_tail
+// (4 <= B - r <= 32, Q >= 2).  The query norms of a cosine search must exist before the traversal starts: launch_query_sqnorms.
+int exact_fused_rows(const float *d_vecs, int D, const float *d_q, int Q, int vsf, int B, const float *d_vnorm);
+int launch_query_sqnorms(hipStream_t s, const float *d_q, int D, int Q, float *d_qnorm);
+int launch_exact_gather_tail(hipStream_t s, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf, const int32_t *d_ord,
+                             int B, int first, float *d_out, const float *d_qnorm, const float *d_vnorm);
 // NVQ (k_nvq.hip)
 int launch_nvq_mean(hipStream_t s, const float *d_vecs, int64_t n, int D, float *d_mean);
 size_t nvq_encode_lds_bytes(int D, int S);

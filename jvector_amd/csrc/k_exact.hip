@@ -9,8 +9,10 @@
 //
 //   gather form (rerank):  grid (Q, ceil(B/64)), block 64.  query in LDS (broadcast reads).
 //   scan form (brute force / ground truth): grid (ceil(count/256)), block 256, loops over query tiles.
+#include <algorithm>
 #include <cstdlib>
 
+#include "gs_params.h"
 #include "jv_device.h"
 #include "jv_internal.h"
 
@@ -401,6 +403,46 @@ int launch_row_sqnorms(hipStream_t s, const float *d_vecs, int64_t n, int D, flo
         hipLaunchKernelGGL(row_sqnorm_tr_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_vecs, n, D, d_out);
     else
         hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_vecs, n, D, d_out);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+// ---- the rerank fused into the traversal wave (gs_body.h gs_rr_round): what is left for this file ----
+int exact_fused_rows(const float *d_vecs, int D, const float *d_q, int Q, int vsf, int B, const float *d_vnorm)
+{
+    if (!exact_tr_supported(d_vecs, D) || (reinterpret_cast<uintptr_t>(d_q) & 15) != 0 || (vsf == VSF_COS && !d_vnorm)) return 0;
+    if (getenv("JVECTOR_HIP_EXACT_LANE_ROWS") || (getenv("JVECTOR_HIP_EXACT_TR_SHAPE") && atoi(getenv("JVECTOR_HIP_EXACT_TR_SHAPE")) != 0)) return 0;
+    if (B < 1 || B > 64 * GS_RR_MAX_ROUNDS) return 0;
+    const int rem = B % 64;
+    if (B >= 64 && rem >= 4 && rem <= 32 && Q >= 2 && !getenv("JVECTOR_HIP_EXACT_NO_PACK")) return B - rem;
+    return B;
+}
+
+int launch_query_sqnorms(hipStream_t s, const float *d_q, int D, int Q, float *d_qnorm)
+{
+    if (Q == 0) return JV_OK;
+    hipLaunchKernelGGL(query_sqnorm_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, d_q, D, Q, d_qnorm);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+// rows [first, B) of every list, several queries per wavefront (exact_gather_trq_kernel); d_qnorm is READ (launch_query_sqnorms)
+int launch_exact_gather_tail(hipStream_t s, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf, const int32_t *d_ord,
+                             int B, int first, float *d_out, const float *d_qnorm, const float *d_vnorm)
+{
+    const int rem = B - first;
+    if (Q == 0 || rem <= 0) return JV_OK;
+    if (rem < 4 || rem > 32 || Q < 2 || !exact_tr_supported(d_vecs, D)) {
+        set_error("exact_gather_tail: %d rows per list x %d queries is not a packed-remainder shape", rem, Q);
+        return JV_ERR_INVALID;
+    }
+    const int G = std::min(TRQ_MAXG, 64 / rem);
+    const dim3 grid((Q + G - 1) / G), block(64);
+    switch (vsf) {
+    case VSF_L2: hipLaunchKernelGGL((exact_gather_trq_kernel<VSF_L2>), grid, block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out, Q, first, rem, G); break;
+    case VSF_DOT: hipLaunchKernelGGL((exact_gather_trq_kernel<VSF_DOT>), grid, block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out, Q, first, rem, G); break;
+    default: hipLaunchKernelGGL((exact_gather_trq_kernel<VSF_COS>), grid, block, 0, s, d_vecs, n, D, d_q, d_qnorm, d_vnorm, d_ord, B, d_out, Q, first, rem, G); break;
+    }
     JV_HIP_CHECK(hipGetLastError());
     return JV_OK;
 }

@@ -8,6 +8,9 @@
 
 #define GS_FN inline
 #define GS_SCHED_FENCE() ((void)0)
+#define GS_NOINLINE static
+#define GS_LDS_AS
+#define GS_GLOBAL_AS
 static inline int gs_lane() { return emu::lane(); }
 // gs_body.h's sync point is wave-scope here: in a one-wave block (every form but WGX) that IS the block barrier, and in the
 // workgroup form (gx_body.h) the control wave must not wait for the expander waves
@@ -27,6 +30,7 @@ static inline int32_t gs_lds_add(int32_t *p, int32_t v)
 static inline void gs_spin_pause() { emu::switch_to_next_live(); }
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
+static inline uint32_t gs_bcast32(uint32_t v, int src) { return (uint32_t)emu::shfl((long long)v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
 static inline int32_t gs_shfl32(int32_t v, int src) { return (int32_t)emu::shfl((long long)v, src); }
 static inline uint32_t gs_perm(uint32_t hi, uint32_t lo, uint32_t sel)   // v_perm_b32 (selectors 0..7 and 0x0c only)
@@ -69,6 +73,7 @@ static inline void gs_fetch_add64(unsigned long long *p, unsigned long long v) {
 static inline void gs_fence() {}
 static inline double gs_sqrt(double x) { return std::sqrt(x); }
 static inline float gs_rsq_approx(float x) { return 1.0f / std::sqrt(x); }
+static inline void gs_gather64(float v, float (&out)[64]) { emu::gather64(v, out); }
 
 #include "../../jvector_amd/csrc/gs_body.h"
 #include "../../jvector_amd/csrc/gx_body.h"

@@ -13,6 +13,9 @@
 #define GS_SCHED_FENCE() ((void)0)
 #define BS_FN static inline
 #define KM_FN static inline
+#define GS_NOINLINE static
+#define GS_LDS_AS
+#define GS_GLOBAL_AS
 static inline int gs_lane() { return emu::lane(); }
 // gs_body.h's sync point: wave scope (= the block barrier in a one-wave block; the control wave of the workgroup form must not
 // wait for the expanders).  Bodies written for several waves use gs_block_barrier().
@@ -32,6 +35,7 @@ static inline void gs_spin_pause() { emu::switch_to_next_live(); }
 static inline void gs_sched_fence() {}
 static inline uint64_t gs_ballot(bool p) { return emu::ballot(p); }
 static inline long long gs_shfl(long long v, int src) { return emu::shfl(v, src); }
+static inline uint32_t gs_bcast32(uint32_t v, int src) { return (uint32_t)emu::shfl((long long)v, src); }
 static inline long long gs_shfl_xor(long long v, int m) { return emu::shfl(v, emu::lane() ^ m); }
 static inline int32_t gs_shfl32(int32_t v, int src) { return (int32_t)emu::shfl((long long)v, src); }
 static inline uint32_t gs_perm(uint32_t hi, uint32_t lo, uint32_t sel)   // v_perm_b32 (selectors 0..7 and 0x0c only)
@@ -316,6 +320,34 @@ int launch_exact_gather(hipStream_t, const float *d_vecs, int64_t n, int D, cons
 {
     for (int q = 0; q < Q; ++q)
         for (int b = 0; b < B; ++b) {
+            const int64_t o = d_ord[(int64_t)q * B + b];
+            d_out[(int64_t)q * B + b] = (o < 0 || o >= n) ? NEG_INF : jvo_compare(vsf, d_q + (size_t)q * D, d_vecs + o * D, D);
+        }
+    return JV_OK;
+}
+// the rerank fused into the traversal wave (the emulated gs_body.h does the arithmetic): the same shape rule as k_exact.hip
+int exact_fused_rows(const float *d_vecs, int D, const float *d_q, int Q, int vsf, int B, const float *d_vnorm)
+{
+    if (D % 8 != 0 || D < 8 || (reinterpret_cast<uintptr_t>(d_vecs) & 15) != 0 || (reinterpret_cast<uintptr_t>(d_q) & 15) != 0 || (vsf == VSF_COS && !d_vnorm)) return 0;
+    if (B < 1 || B > 64 * GS_RR_MAX_ROUNDS) return 0;
+    const int rem = B % 64;
+    if (B >= 64 && rem >= 4 && rem <= 32 && Q >= 2) return B - rem;
+    return B;
+}
+int launch_query_sqnorms(hipStream_t, const float *d_q, int D, int Q, float *d_qnorm)
+{
+    for (int q = 0; q < Q; ++q) {
+        float n1 = 0.0f;
+        for (int j = 0; j < D; ++j) n1 += d_q[(size_t)q * D + j] * d_q[(size_t)q * D + j];
+        d_qnorm[q] = n1;
+    }
+    return JV_OK;
+}
+int launch_exact_gather_tail(hipStream_t, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf, const int32_t *d_ord, int B,
+                             int first, float *d_out, const float *, const float *)
+{
+    for (int q = 0; q < Q; ++q)
+        for (int b = first; b < B; ++b) {
             const int64_t o = d_ord[(int64_t)q * B + b];
             d_out[(int64_t)q * B + b] = (o < 0 || o >= n) ? NEG_INF : jvo_compare(vsf, d_q + (size_t)q * D, d_vecs + o * D, D);
         }

@@ -945,3 +945,10 @@ def test_register_table_bound_form_on_the_mock(J, ctx):
     T.test_bound_tables_equal_the_restatement(ctx, J.VectorSimilarityFunction.COSINE)
     T.test_register_table_bound_kernel(ctx, 2, True, 32, 2500)
     T.test_register_table_bound_kernel_ties_and_degenerate_queries(ctx)
+
+
+def test_fused_rerank_on_the_mock(J, ctx):
+    """the rerank inside the traversal wave (gs_body.h gs_rr_round on the lane emulator; the kernel of its own is the oracle's arithmetic
+    here): fused == unfused == the oracle, and the driver's shape rule (gs_last_rr_rows)"""
+    import test_zz_ubr_gpu as T
+    T.test_fused_rerank_equals_the_rerank_kernel(ctx, N=3000, quick=True)

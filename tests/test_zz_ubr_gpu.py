@@ -155,3 +155,38 @@ def test_register_table_bound_kernel_ties_and_degenerate_queries(ctx):
     finally:
         for k in ("gs_ubr", "gs_wgx", "gs_ubr_trim"):
             ctx.set_option(k, None)
+
+
+def test_fused_rerank_equals_the_rerank_kernel(ctx, N=12000, quick=False):
+    """Round 6: the rerank's exact scores inside the traversal wave (gs_body.h gs_rr_round; option gs_fused_rerank, default on).  For
+    every similarity and for list lengths on both sides of every rule of exact_fused_rows — one partial round (1, 40), whole rounds (64,
+    128), a packed remainder behind whole rounds (74 -> 64 + 10, 150 -> 128 + 22), a partial last round where the remainder does not pack
+    (100 -> 100), the cap (256), beyond it (300 -> the kernel of its own) — the results with the option on, with it off and the
+    oracle's sequential GraphSearcher + NodeQueue.rerank are the same ids, the same score bits and the same counters; vectors that are
+    duplicated force exact-score ties through the tie resolution behind it; codes by ordinal (the plain pair kernel) take the same path."""
+    D, M = 768, 96
+    for use_fused in (True, False):
+        v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q = _setup(ctx, 23 + use_fused, N if use_fused else N // 2, D, M, 2, use_fused, 32)
+        og = O.OracleGraph(len(v), lv, entry, entry_level)
+        s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=64)
+        try:
+            ctx.set_option("gs_wgx", 0)
+            cases = ((1, 1, 1), (10, 40, 40), (10, 64, 64), (10, 74, 64), (10, 100, 100), (20, 150, 128), (10, 256, 256), (10, 300, 0))
+            if quick:
+                cases = ((10, 40, 40), (10, 74, 64), (10, 100, 100), (10, 300, 0))
+            for vsf in VSF:
+                for top_k, rk, want_rows in cases:
+                    if not use_fused and rk in (64, 256, 300):
+                        continue
+                    wi, ws, wst = og.search(opq, codes, v, q, int(vsf), top_k, rk, fused=use_fused)
+                    ctx.set_option("gs_fused_rerank", 1)
+                    ids, sc, st = s.search(q, vsf, top_k, rk, return_stats=True)
+                    assert ctx.stat("gs_last_rr_rows") == want_rows, (vsf, rk, ctx.stat("gs_last_rr_rows"))
+                    ctx.set_option("gs_fused_rerank", 0)
+                    ids0, sc0, st0 = s.search(q, vsf, top_k, rk, return_stats=True)
+                    assert ctx.stat("gs_last_rr_rows") == 0
+                    assert np.array_equal(ids, ids0) and np.array_equal(sc.view(np.uint32), sc0.view(np.uint32)) and np.array_equal(st, st0), (vsf, rk)
+                    assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (vsf, rk)
+        finally:
+            for k in ("gs_wgx", "gs_fused_rerank"):
+                ctx.set_option(k, None)
