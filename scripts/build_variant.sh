@@ -8,7 +8,7 @@ NAME=$1; TU=$2; FLAGS=${3:-}
 make -C $R/jvector_amd/csrc -j8 >/dev/null
 D=$R/build/variants/$NAME; mkdir -p $D
 BASE=$(basename ${TU%.*})
-EXTRA=""; [ "$BASE" = "k_gsearch_ubr" ] && EXTRA="-fno-slp-vectorize"
+EXTRA=""; [ "$BASE" = "k_gsearch_ubr" ] && EXTRA="-fno-slp-vectorize -mllvm -enable-ipra=0"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-function $EXTRA $FLAGS \
   -Rpass-analysis=kernel-resource-usage -c $R/jvector_amd/csrc/$TU -o $D/$BASE.o 2> $D/resources.txt || { cat $D/resources.txt; exit 1; }
 OBJS=$(ls $R/build/csrc/*.o | grep -v "/$BASE.o")
