@@ -1099,11 +1099,7 @@ GS_NOINLINE float gs_rr_round(const float *vecs_generic, int D, const float *qra
         const int off = c * GS_RR_CH + seg < D ? c * GS_RR_CH + seg : D - 4;
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-#ifdef GS_NT_RR
-            r[k] = gs_nt_load(reinterpret_cast<GS_GLOBAL_AS const gs_v4f *>(vecs + (int64_t)(ro[k] >= 0 ? ro[k] : 0) * D + off));
-#else
             r[k] = *reinterpret_cast<GS_GLOBAL_AS const gs_v4f *>(vecs + (int64_t)(ro[k] >= 0 ? ro[k] : 0) * D + off);
-#endif
         qv = qraw[c * GS_RR_CH + lane < D ? c * GS_RR_CH + lane : D - 1];
     };
     float acc = 0.0f;
@@ -1553,26 +1549,12 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     if (pn >= 0 && pn < L.count) {
                         const int pni = lane & 31;
                         const bool phi = lane >= 32;
-#ifdef GS_NT_BLOCKS   // (experiment: the popped node's row, block and magnitudes are used once — keep them from displacing the codebook in L2)
-                        if (pni < L.degree) pre_nb = gs_nt_load(L.nbrs + (int64_t)pn * L.degree + pni);
-                        if (p.blocks != nullptr && pni < L.degree) {
-                            const int64_t r = (int64_t)pn * p.deg0 + pni;
-                            const unsigned long long *r8 = reinterpret_cast<const unsigned long long *>(p.blocks + r * p.M + (phi ? p.M / 2 : 0));
-#pragma unroll
-                            for (int c = 0; c < CH16; ++c) {
-                                const unsigned long long v = gs_nt_load(r8 + c);
-                                pre_w[c] = gs_u2{(uint32_t)v, (uint32_t)(v >> 32)};
-                            }
-                            if (VSF == 2 && !phi) pre_mag = gs_nt_load(p.fused_norms + r);
-                        }
-#else
                         if (pni < L.degree) pre_nb = (L.nbrs + (int64_t)pn * L.degree)[pni];
                         if (p.blocks != nullptr && pni < L.degree) {
                             const int64_t r = (int64_t)pn * p.deg0 + pni;
                             gs_load_half<CH16>(p.blocks + r * p.M + (phi ? p.M / 2 : 0), pre_w);
                             if (VSF == 2 && !phi) pre_mag = p.fused_norms[r];
                         }
-#endif
                         pre_loaded = true;
                     }
                 }

@@ -12,11 +12,6 @@
 #define GS_NOINLINE __device__ __attribute__((noinline))
 // a pointer into the workgroup's LDS block that went through a call is a flat pointer to the compiler; cast back, the accesses are ds_ again
 #define GS_LDS_AS __attribute__((address_space(3)))
-// a load whose line should not stay in the caches (global_load ... nt): streamed rows that are used once
-template <class T>
-__device__ __forceinline__ T gs_nt_load(const T *p) { return __builtin_nontemporal_load(p); }
-template <class T>
-__device__ __forceinline__ T gs_nt_load(const __attribute__((address_space(1))) T *p) { return __builtin_nontemporal_load(p); }
 // likewise a pointer into device memory: global_load instead of flat_load (a flat load counts on the LDS counter too: every wait for an
 // LDS read would wait for the row requests in flight)
 #define GS_GLOBAL_AS __attribute__((address_space(1)))

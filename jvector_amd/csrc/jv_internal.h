@@ -319,6 +319,8 @@ int launch_row_sqnorms(hipStream_t s, const float *d_vecs, int64_t n, int D, flo
 // (4 <= B - r <= 32, Q >= 2).  The query norms of a cosine search must exist before the traversal starts: launch_query_sqnorms.
 int exact_fused_rows(const float *d_vecs, int D, const float *d_q, int Q, int vsf, int B, const float *d_vnorm);
 int launch_query_sqnorms(hipStream_t s, const float *d_q, int D, int Q, float *d_qnorm);
+bool exact_tr_supported(const float *d_vecs, int D);
+int launch_block8_sqnorms(hipStream_t s, const float *d_rows, int64_t n, int D, float *d_out);
 int launch_exact_gather_tail(hipStream_t s, const float *d_vecs, int64_t n, int D, const float *d_q, int Q, int vsf, const int32_t *d_ord,
                              int B, int first, float *d_out, const float *d_qnorm, const float *d_vnorm);
 // NVQ (k_nvq.hip)

@@ -223,7 +223,10 @@ __device__ __forceinline__ void tr_chunk(const float *__restrict__ row, const fl
 // R rows per wavefront (lanes >= R carry none), CH floats of a row per chunk, R x CH = 4096: sixteen 1 KB load instructions per
 // chunk in every shape — 64 x 64 (four rows x 256 B per instruction), 32 x 128 (two rows x 512 B), 16 x 256 (one row x 1 KB): the
 // longer a row's contiguous piece, the fewer DRAM pages a gathered row opens.  LDS row stride CH + 4 dwords: conflict-free b128 reads.
-template <int VSF, bool SQ, int R = 64, int CH = TR_CH>
+// SQ8: the squares summed in BLOCKS OF EIGHT — t = e0 e0 + e1 e1, t += e2 e2 ... t += e7 e7, acc += t: the order of the dot product of a
+// vector with itself (DefaultVectorUtilSupport.dotProduct, k_pq.hip dot_full_order at D % 8 == 0) and of the per-subspace partial sums
+// of 8-float sub-vectors (query_mag_kernel kind 1) alike.
+template <int VSF, bool SQ, int R = 64, int CH = TR_CH, bool SQ8 = false>
 __device__ __forceinline__ float tr_rows(const float *__restrict__ vecs, int D, int64_t my_row /* -1 = none */,
                                          const float *__restrict__ a, float *tile)
 {
@@ -255,7 +258,19 @@ __device__ __forceinline__ float tr_rows(const float *__restrict__ vecs, int D, 
         if (c + 1 < nc) issue(c + 1);
         const int len = (D - c * CH < CH) ? (D - c * CH) : CH;
         const float *row = tile + (lane % R) * LS;
-        if (SQ) {
+        if (SQ && SQ8) {
+            for (int i = 0; i < len; i += 8) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(row + i), v1 = *reinterpret_cast<const float4 *>(row + i + 4);
+                float t = v0.x * v0.x + v0.y * v0.y;
+                t = t + v0.z * v0.z;
+                t = t + v0.w * v0.w;
+                t = t + v1.x * v1.x;
+                t = t + v1.y * v1.y;
+                t = t + v1.z * v1.z;
+                t = t + v1.w * v1.w;
+                acc += t;
+            }
+        } else if (SQ) {
             for (int i = 0; i < len; i += 4) {
                 const float4 v = *reinterpret_cast<const float4 *>(row + i);
                 acc += v.x * v.x; acc += v.y * v.y; acc += v.z * v.z; acc += v.w * v.w;
@@ -382,6 +397,14 @@ __global__ __launch_bounds__(64) void row_sqnorm_tr_kernel(const float *__restri
 }
 
 // generic-D fallback of the table: one thread per row
+__global__ __launch_bounds__(64) void row_sqnorm8_tr_kernel(const float *__restrict__ vecs, int64_t n, int D, float *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float tile[64 * TR_LS];
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const float s = tr_rows<VSF_COS, true, 64, TR_CH, true>(vecs, D, i < n ? i : -1, nullptr, tile);
+    if (i < n) out[i] = s;
+}
+
 __global__ void row_sqnorm_kernel(const float *__restrict__ vecs, int64_t n, int D, float *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -418,10 +441,28 @@ int exact_fused_rows(const float *d_vecs, int D, const float *d_q, int Q, int vs
     return B;
 }
 
+// (round 6: 64 queries per wavefront through the transposing norm kernel — the same running sum per row, coalesced: 0.45 -> 0.1 ms per
+//  131 072 queries of 768 floats; one thread walking its own 3 KB row touched 64 different lines per load instruction)
 int launch_query_sqnorms(hipStream_t s, const float *d_q, int D, int Q, float *d_qnorm)
 {
     if (Q == 0) return JV_OK;
-    hipLaunchKernelGGL(query_sqnorm_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, d_q, D, Q, d_qnorm);
+    if (exact_tr_supported(d_q, D))
+        hipLaunchKernelGGL(row_sqnorm_tr_kernel, dim3((unsigned)((Q + 63) / 64)), dim3(64), 0, s, d_q, (int64_t)Q, D, d_qnorm);
+    else
+        hipLaunchKernelGGL(query_sqnorm_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, d_q, D, Q, d_qnorm);
+    JV_HIP_CHECK(hipGetLastError());
+    return JV_OK;
+}
+
+// out[i] = the squares of row i summed in blocks of eight (tr_rows SQ8); rows 16-byte aligned, D % 8 == 0
+int launch_block8_sqnorms(hipStream_t s, const float *d_rows, int64_t n, int D, float *d_out)
+{
+    if (n == 0) return JV_OK;
+    if (!exact_tr_supported(d_rows, D)) {
+        set_error("block8_sqnorms: rows must be 16-byte aligned with D %% 8 == 0");
+        return JV_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(row_sqnorm8_tr_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_rows, n, D, d_out);
     JV_HIP_CHECK(hipGetLastError());
     return JV_OK;
 }
@@ -454,8 +495,7 @@ int launch_exact_gather(hipStream_t s, const float *d_vecs, int64_t n, int D, co
 {
     if (Q == 0 || B == 0) return JV_OK;
     // d_qnorm: caller-provided scratch of Q floats (query-side cosine norms)
-    if (vsf == VSF_COS)
-        hipLaunchKernelGGL(query_sqnorm_kernel, dim3((Q + 63) / 64), dim3(64), 0, s, d_q, D, Q, d_qnorm);
+    if (vsf == VSF_COS) JV_TRY(launch_query_sqnorms(s, d_q, D, Q, d_qnorm));
     dim3 grid(Q, (B + 63) / 64), block(64);
     if (exact_tr_supported(d_vecs, D) && (reinterpret_cast<uintptr_t>(d_q) & 15) == 0 && (vsf != VSF_COS || d_vnorm) &&
         !getenv("JVECTOR_HIP_EXACT_LANE_ROWS")) {

@@ -210,8 +210,18 @@ for w, kcfg in FLAT.items():
         for f2 in ("FETCH_SIZE", "WRITE_SIZE", "SQ_LDS_BANK_CONFLICT"):
             write_pmc([r for r in rows_of(f"{w}_{f2}_jv.csv") if "adc" in r["Kernel_Name"]], f"{tag}_pmc_{w}_{f2.lower()}.csv")
 
+# entries of earlier passes that this pass did not collect again stay (e.g. the flat filter's shapes when SKIP_FLAT=1 profiled the headline
+# alone); an entry collected again replaces its predecessor — same kernel_key and shape
+tj = os.path.join(dst, "traffic_r6.json")
+if os.path.exists(tj):
+    fresh = {(e["kernel_key"], e.get("shape")) for e in entries}
+    entries += [e for e in json.load(open(tj)).get("entries", []) if (e["kernel_key"], e.get("shape")) not in fresh]
+if bench.get("roofline", {}).get("fused_rerank_rows"):   # the traversal kernel of this pass also reranked (gs_body.h gs_rr_round)
+    for e in entries:
+        if e["kernel_key"] == "gsearch_ubr" and e["tag"] == tag:
+            e["fused_rerank_rows"] = bench["roofline"]["fused_rerank_rows"]
 out = {"source": f"rocprofv3 on `python bench.py` (default 10M workload, index cached so that only search steps are traced): "
-                 f"scripts/profile_r6.sh {tag}; separate --pmc passes; profiles/{tag}_pmc_*.csv, profiles/{tag}_kernel_stats.csv",
+                 f"scripts/profile_r6.sh <tag>; separate --pmc passes; profiles/<tag>_pmc_*.csv, profiles/<tag>_kernel_stats.csv; every entry names its tag",
        "entries": entries}
 json.dump(out, open(os.path.join(dst, "traffic_r6.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

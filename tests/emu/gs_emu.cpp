@@ -10,8 +10,6 @@
 #define GS_SCHED_FENCE() ((void)0)
 #define GS_NOINLINE static
 #define GS_LDS_AS
-template <class T>
-static inline T gs_nt_load(const T *p) { return *p; }
 #define GS_GLOBAL_AS
 static inline int gs_lane() { return emu::lane(); }
 // gs_body.h's sync point is wave-scope here: in a one-wave block (every form but WGX) that IS the block barrier, and in the

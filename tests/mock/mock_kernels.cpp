@@ -15,8 +15,6 @@
 #define KM_FN static inline
 #define GS_NOINLINE static
 #define GS_LDS_AS
-template <class T>
-static inline T gs_nt_load(const T *p) { return *p; }
 #define GS_GLOBAL_AS
 static inline int gs_lane() { return emu::lane(); }
 // gs_body.h's sync point: wave scope (= the block barrier in a one-wave block; the control wave of the workgroup form must not
