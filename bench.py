@@ -1241,7 +1241,7 @@ def main():
                       "exact_gather_tr_kernel<COSINE> (NodeQueue.rerank: full-resolution cosine of the "
                       "kept candidates; rows gathered by ordinal in coalesced 256-byte pieces and transposed through LDS)"))
         extra_roof["rerank"] = {"bound": "hbm", "kernel": rr_kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("exact_gather", cfg_key),
+                                "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("exact_gather_trq" if rr_rows > 0 else "exact_gather", cfg_key),
                                 "bytes_per_launch": rr_bytes / e_n, "avg_launch_ms": e_ms / e_n, "launches": e_n}
 
     # secondary measurement (single GPU, graph mode): the flat two-pass path on the same index, so that the ADC-scan
