@@ -1631,11 +1631,11 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     p.prof = gs_prof ? (unsigned long long *)(base + o_prof) : nullptr;
     // ---- round 6: the rerank's exact scores inside the traversal wave (gs_body.h gs_rr_round).  Full-resolution rows that
     //      exact_gather_tr_kernel would take (16-byte aligned, D % 8 == 0, the norm table for cosine), lists of <= 256 results, the
-    //      one-wave forms (the workgroup form's control block is smaller than the tile; GraphSearcher objects rerank on their own):
+    //      the register-table bound form over the row (the only kernel that carries the code: gs_body.h RR):
     //      rows [0, rr_rows) of every list leave the kernel with their exact score, the packed-remainder launch does the rest.
     //      gs_fused_rerank = 0: the rerank stays a kernel of its own.  Same arithmetic, same bits either way.
     int rr_rows = 0;
-    if (!so && !wgx && vectors && !vectors->nvq && vectors->D == pq->D && gs_rr_lds_bytes() <= lds && ctx_opt(ctx, "gs_fused_rerank", 1) != 0) {
+    if (!so && !wgx && ubr && pair && vectors && !vectors->nvq && vectors->D == pq->D && gs_rr_lds_bytes() <= lds && ctx_opt(ctx, "gs_fused_rerank", 1) != 0) {
         if (vsf == JV_COSINE) JV_TRY(ensure_vector_norms(ctx, const_cast<jv_vectors *>(vectors)));
         rr_rows = exact_fused_rows(vectors->d_vecs, vectors->D, l->d_raw_queries, Q, kvsf, rerankK, vectors->d_sqnorm);
     }

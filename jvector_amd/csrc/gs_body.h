@@ -2093,7 +2093,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     // ---- hand the kept approximate results to the rerank stage ----
     gs_barrier();
     // (round 6: rows [0, rr_rows) get their EXACT similarity right here, below — their ordinals leave LDS first: the tile overwrites it)
-    const bool rr = !SES && p.rr_vecs != nullptr;
+    // (compiled into the register-table bound form over the row — the headline's kernel — ONLY: in every other instantiation the mere
+    //  presence of the call cost the expansion loop registers — the compacted pair kernels went from 0 to 95 spilled VGPRs and C5's
+    //  builder searches from 17.6 to 30 s, profiles/r6_final — and those forms never asked for it)
+    constexpr bool RR = UBR && PAIR && !PAIRC && !SES;
+    const bool rr = RR && p.rr_vecs != nullptr;
     int32_t rr_node[GS_RR_MAX_ROUNDS];
 #pragma unroll
     for (int r = 0; r < GS_RR_MAX_ROUNDS; ++r) {
@@ -2106,7 +2110,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         p.out_ids[(int64_t)q * p.rerankK + i] = have ? gs_key_node(k) : -1;
         if (!(rr && i < p.rr_rows)) p.out_scores[(int64_t)q * p.rerankK + i] = have ? gs_key_score(k) : -__builtin_inff();
     }
-    if (rr) {
+    if constexpr (RR) if (rr) {
         gs_barrier();   // every lane has read its keys: the LDS block is the tile's now
         const float *qraw = p.rr_queries + (int64_t)q * p.D;
         for (int r = 0; 64 * r < p.rr_rows; ++r) {
