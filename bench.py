@@ -1132,6 +1132,33 @@ def main():
             for k in kv:
                 os.environ.pop(k, None)
 
+    # developer aid: JVECTOR_BENCH_SORT_QUERIES=1 re-times the steps with every batch's queries ordered by the mixture cluster nearest to them
+    # (an upper bound of what query-locality ordering could buy the traversal: concurrent waves then walk the same region of the graph);
+    # stderr only
+    if graph_mode and os.environ.get("JVECTOR_BENCH_SORT_QUERIES") and hasattr(mix, "proj"):
+        nst = min(3, args.steps)
+        gk = torch.Generator(device=dev).manual_seed(99)
+        keyers = {"mixture cluster (generator knowledge)": lambda blk: ((blk @ mix.proj.t()) @ mix.centers.t()).argmax(1)}
+        for C_ in (64, 256, 1024):   # nearest of C base vectors taken at a fixed stride: no training, no knowledge of the generator
+            piv = base[:: max(1, N // C_)][:C_].contiguous()
+            keyers[f"nearest of {C_} strided base vectors"] = (lambda blk, piv=piv: (blk @ piv.t()).argmax(1))
+        for bits in (8, 12):
+            Rm = torch.randn(D, bits, generator=gk, device=dev)
+            w = (2 ** torch.arange(bits, device=dev)).float()
+            keyers[f"{bits} random-hyperplane sign bits"] = (lambda blk, Rm=Rm, w=w: ((blk @ Rm > 0).float() @ w).long())
+        keyers = {"nothing (arrival order)": None, **keyers}
+        for name, keyer in keyers.items():
+            sq = timed_q[:nst * Q].clone()
+            for s_ in range(nst if keyer else 0):
+                blk = sq[s_ * Q:(s_ + 1) * Q]
+                sq[s_ * Q:(s_ + 1) * Q] = blk[torch.argsort(keyer(blk), stable=True)]
+            run(sq[:Q], rerank_k)
+            ctx.profile(True)
+            dt = timed_steps(run, sq, Q, nst, rerank_k, barrier) / nst
+            pr = {r: ctx.profile_read(r)[0] / nst for r in regions}
+            ctx.profile(False)
+            log(f"[sorted queries] by {name}: {dt * 1e3:.2f} ms/step, {Q / dt:.0f} QPS, kernels " + ", ".join(f"{r} {v:.2f}" for r, v in pr.items() if v > 0))
+
     # developer aid: JVECTOR_BENCH_IN_FLIGHT=n re-times the steps with n batches in flight — n host threads, each with its own
     # context (= its own HIP stream and scratch) and searcher over the SAME index, taking the steps round-robin — so that one
     # batch's HBM-bound rerank can overlap another's gather-bound traversal.  stderr only; the reported line stays one batch at a time.

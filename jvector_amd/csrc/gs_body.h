@@ -1033,9 +1033,6 @@ GS_FN void gs_ubr_trim(GsState &s, int rk, float &T)
 // 5.4 ms of a 57.6 ms step behind a traversal that leaves HBM at 13 % and the SIMDs' issue slots at 38 %; inside the wave the same
 // work fills those gaps (the search has ended: its 96 table registers and its LDS block are free).  Every lane takes part in every
 // step (the shuffles are wave collectives): a lane without a row walks zeros.
-#ifndef GS_RR_DEPTH
-#define GS_RR_DEPTH 2   // chunks of a rerank round in flight (3 = experiment, profiles/r6_z)
-#endif
 typedef float gs_v4f __attribute__((vector_size(16)));   // (a builtin vector: loadable through an address-space-qualified pointer)
 
 template <int VSF>
@@ -1112,7 +1109,7 @@ GS_NOINLINE float gs_rr_round(const float *vecs_generic, int D, const float *qra
         for (int k = 0; k < 16; ++k) *reinterpret_cast<GS_LDS_AS gs_v4f *>(tile + (4 * k + sub) * GS_RR_LS + seg) = r[k];
         const uint32_t qc = __builtin_bit_cast(uint32_t, qv);
         gs_barrier();
-        if (c + GS_RR_DEPTH < nc) issue(c + GS_RR_DEPTH, r, qv);
+        if (c + 2 < nc) issue(c + 2, r, qv);
         const int len = (D - c * GS_RR_CH < GS_RR_CH) ? (D - c * GS_RR_CH) : GS_RR_CH;   // (a multiple of 8: exact_tr_supported)
         GS_LDS_AS const float *row = tile + lane * GS_RR_LS;
         auto block = [&](int i, const gs_v4f v0, const gs_v4f v1) {
@@ -1140,21 +1137,11 @@ GS_NOINLINE float gs_rr_round(const float *vecs_generic, int D, const float *qra
     };
     issue(0, rA, qA);
     if (nc > 1) issue(1, rB, qB);
-#if GS_RR_DEPTH == 3
-    gs_v4f rC[16];
-    float qC = 0.0f;
-    if (nc > 2) issue(2, rC, qC);
-    for (int c = 0; c < nc; c += 3) {
-        step(c, rA, qA);
-        if (c + 1 < nc) step(c + 1, rB, qB);
-        if (c + 2 < nc) step(c + 2, rC, qC);
-    }
-#else
+    // (three chunks in flight — 192 staging registers — measured slower: 52.3 vs 51.1 ms, profiles/r6_z)
     for (int c = 0; c < nc; c += 2) {
         step(c, rA, qA);
         if (c + 1 < nc) step(c + 1, rB, qB);
     }
-#endif
     return acc;
 }
 
@@ -2170,6 +2157,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
 template <int VSF, int CH16, bool PAIR, bool PROF = false, bool SES = false, bool PAIRC = false, bool UBR = false>
 GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
 {
+    // (measured and not kept, profiles/r6_z2: work items dealt per XCD — eight ranges, stolen when one runs dry — so that a batch ordered
+    //  by locality keeps neighbouring searches under one L2: no gain, 0.2 - 0.5 ms worse; what ordering buys comes from the whole chip
+    //  walking one region at a time, not from one L2)
     for (;;) {
         long long qv = 0;
         if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
