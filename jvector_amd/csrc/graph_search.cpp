@@ -1469,7 +1469,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
             fprintf(stderr, "[jv gs prof] the compacted pair form (rows of 33..64 neighbours: the builder's searches) has no phase-clock variant; gs_prof ignored for this launch\n");
         gs_prof = false;
     }
-    const size_t o_prof = carve(sizeof(unsigned long long) * 24);
+    const size_t o_prof = carve(sizeof(unsigned long long) * 33);
     // exact-score ties across the K-th place of the rerank are decided by the order of the reference's result-heap array
     // (NodeQueue.java:197-214): the traversal logs its addTopCandidate sequence (avg ~1 entry per expansion) and
     // rerank_tie_kernel rebuilds the reference's answer for the (rare) tied queries; an overflowed log sends the query to
@@ -1494,7 +1494,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     int32_t *d_status = (int32_t *)(base + o_status);
     uint32_t *d_counter = (uint32_t *)(base + o_counter);
     JV_HIP_CHECK(hipMemsetAsync(d_counter, 0, sizeof(uint32_t), ctx->stream));
-    if (gs_prof || ubr) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 24, ctx->stream));
+    if (gs_prof || ubr) JV_HIP_CHECK(hipMemsetAsync(base + o_prof, 0, sizeof(unsigned long long) * 33, ctx->stream));
 
     GsParams p{};
     for (int lv = 0; lv <= g->entry_level; ++lv) {
@@ -1713,7 +1713,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         redo.swap(still);
     }
     if (gs_prof) {
-        unsigned long long h[24];
+        unsigned long long h[33];
         JV_HIP_CHECK(hipMemcpyAsync(h, base + o_prof, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         const double e = (double)std::max<unsigned long long>(h[5], 1);
@@ -1725,6 +1725,13 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
             const double nq = (double)std::max<unsigned long long>(h[6], 1);
             fprintf(stderr, "[jv gs prof] clocks/query outside the expansion loop: setup %.0f  level transitions %.0f  epilogue %.0f  table build %.0f\n",
                     h[12] / nq, h[13] / nq, h[14] / nq, h[15] / nq);
+            fprintf(stderr, "[jv gs prof] levels above 0: %.2f expansions per query, %.0f clocks per query (searchOneLayer + transitions) = %.0f per expansion\n",
+                    h[24] / nq, h[25] / nq, (double)h[25] / (double)std::max<unsigned long long>(h[24], 1));
+            {
+                const double eu = (double)std::max<unsigned long long>(h[24], 1);
+                fprintf(stderr, "[jv gs prof] levels above 0, clocks/expansion: pop %.0f  result %.0f  row+visited %.0f  score %.0f  push %.0f | scoring passes %.2f per expansion, %.0f clocks per pass\n",
+                        h[26] / eu, h[27] / eu, h[28] / eu, h[29] / eu, h[30] / eu, h[32] / eu, (double)h[31] / (double)std::max<unsigned long long>(h[32], 1));
+            }
         }
         if (wgx)
             fprintf(stderr, "[jv gs prof] workgroup form, per expansion: row found in a slot %.3f (of those still being scored at use: %.3f of all)  "

@@ -1175,6 +1175,9 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     unsigned long long fh[4] = {0, 0, 0, 0};  // PROF: scored neighbours in expansions with <= 8 / <= 16 / <= 24 / <= 32 fresh ones
     unsigned long long pt = 0, pq0 = 0;
     unsigned long long px[3] = {0, 0, 0};   // PROF: setup (entry -> first pop), level transitions, epilogue
+    unsigned long long pz[2] = {0, 0}, pzf[5] = {0, 0, 0, 0, 0}, pzp[2] = {0, 0};   // (pzf: the five phases at the levels above 0; pzp: their scoring passes' clocks, passes)
+    bool prof_upper = false;
+    unsigned long long pz_[2] = {0, 0};   // PROF: expansions at the levels above 0, clocks spent there (searchOneLayer + the transition)
     unsigned long long py[7] = {0, 0, 0, 0, 0, 0, 0};   // PROF (UBR): wait for the row, scoring rounds, owner sum + finish, passes, expansions with <= 4 / <= 8 / <= 16 survivors
     if (PROF) pq0 = GS_CLOCK();
 #define GS_PHASE(i)                          \
@@ -1182,6 +1185,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         if (PROF) {                          \
             const unsigned long long now_ = GS_CLOCK(); \
             pf[i] += now_ - pt;              \
+            if (prof_upper) pzf[i] += now_ - pt; \
             pt = now_;                       \
         }                                    \
     } while (0)
@@ -1471,6 +1475,10 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         // bound phase: 59.2 vs 50.0 ms, profiles/r6_c.)
         const GsLevel &L = p.lv[lvl];
         int phase = 0;
+        unsigned long long plv0 = 0;
+        const long long plv_e0 = n_expanded;
+        if (PROF) plv0 = GS_CLOCK();
+        if (PROF) prof_upper = lvl > 0;
         if (SES && lvl == 0 && p.n_phases > 1) {
             rk = p.ph_rerankK[0];
             cur_thr = p.ph_threshold[0];
@@ -1742,6 +1750,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                         if (PROF) {
                             pyc = GS_CLOCK();
                             py[3]++;
+                            if (prof_upper) pzp[1]++;
                         }
 #if GS_UBR_VAR_LPS
                         if (ns <= 2) gs_ubr_pass<VSF, M_, 32>(p.codebooks, qs, xf, st_nb, st_mag, st_code, base, ns, query_mag, ub_active, ub_T, fresh, key);
@@ -1753,6 +1762,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                             const uint64_t done_ = gs_ballot(fresh && key != 0);   // (the owners' keys exist before the clock is read)
                             if (done_ == 0xdeadbeefdeadbeefull) py[3]++;
                             py[1] += GS_CLOCK() - pyc;
+                            if (prof_upper) pzp[0] += GS_CLOCK() - pyc;
                         }
                         if (base + per >= ns) break;   // the shared tail below pushes the last pass
                         gs_barrier();   // every owner lane has read its column before the push's sample buffer reuses the bytes
@@ -2087,6 +2097,10 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             s.res_min_idx = -1;
         }
         if (PROF) px[1] += GS_CLOCK() - ptr0;
+        if (PROF && lvl > 0) {
+            pz[0] += (unsigned long long)(n_expanded - plv_e0);
+            pz[1] += GS_CLOCK() - plv0;
+        }
     }
     unsigned long long pep0 = 0;
     if (PROF) pep0 = GS_CLOCK();
@@ -2148,6 +2162,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         gs_fetch_add64(p.prof + 13, px[1]);
         gs_fetch_add64(p.prof + 14, GS_CLOCK() - pep0);
         if (UBR) for (int i = 0; i < 7; ++i) gs_fetch_add64(p.prof + 16 + i, py[i]);
+        gs_fetch_add64(p.prof + 24, pz[0]);
+        gs_fetch_add64(p.prof + 25, pz[1]);
+        for (int i = 0; i < 5; ++i) gs_fetch_add64(p.prof + 26 + i, pzf[i]);
+        gs_fetch_add64(p.prof + 31, pzp[0]);
+        gs_fetch_add64(p.prof + 32, pzp[1]);
     }
     if (UBR && p.ubr_count && lane == 0) gs_fetch_add64(p.ubr_count, ub_dropped);
 #undef GS_PHASE
