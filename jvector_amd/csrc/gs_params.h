@@ -122,6 +122,16 @@ struct GsParams {
     const float *rr_vnorm;    // [rr_n] sum of squares of a row (cosine), launch_row_sqnorms
     long long rr_n;
     int32_t rr_rows;          // <= 64 * GS_RR_MAX_ROUNDS
+    // round 6, last: DEFERRED exact scores above level 0 (gs_body.h DEFER; the register-table bound form over the row only).  A fresh
+    // neighbour met at a level >= defer_min_level whose bound lies below that layer's best result (topK = 1) is not scored: (node, an
+    // upper bound U of its score, exact < U) goes to the worker's list.  It can never be popped above level 0 (the result minimum only
+    // grows and the next layer's first pop is at least the last layer's best); at level 0 a pop is valid only while its score >= the
+    // largest U in the list — otherwise what the pop threshold does not rule out is scored exactly (codes by ordinal) and pushed
+    // first.  Pops, results, visitedCount and expandedCount are the reference's.  nullptr = every fresh neighbour above level 0 is scored at once.
+    long long *defer;         // [workers][defer_cap] NodeQueue-encoded (U, node) keys
+    int32_t defer_cap;
+    int32_t defer_min_level;  // >= 1
+    unsigned long long *defer_count;  // += {deferred, of those scored later, sweeps of the list} (one atomic each per query), or nullptr
     uint32_t *next_query;     // work counter (zeroed by the host before the launch)
     unsigned long long *prof; // developer aid (JVECTOR_HIP_GS_PROF=1): 8 phase counters, see gs_search_one; else nullptr
 };

@@ -177,6 +177,9 @@ void lane_main(void *arg)
 }
 }  // namespace
 
+static unsigned long long g_last_defer[3] = {0, 0, 0};   // DEFER counters of the last gs_emu_search: deferred, scored later, sweeps
+extern "C" void gs_emu_last_defer(unsigned long long *out) { for (int i = 0; i < 3; ++i) out[i] = g_last_defer[i]; }
+
 extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, const int32_t *const *lv_nbrs, const int32_t *lv_count,
                               const int32_t *lv_degree, int entry_node, int entry_level, const float *codebooks, const float *cq,
                               const float *bmag, const uint8_t *codes, const float *code_norms, const uint8_t *blocks,
@@ -262,6 +265,16 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     p.next_query = &next;
     unsigned long long prof[24] = {0};
     if (ub8 == 2) p.ubr_count = prof + 15;
+    // DEFER (gs_body.h): on in the emulator from level 1 up (the product defers from level 2: more code under test here);
+    // GS_EMU_DEFER=0 turns it off, GS_EMU_DEFER_CAP / GS_EMU_DEFER_MIN_LEVEL size it
+    std::vector<long long> defer_buf;
+    if (ub8 == 2 && !(getenv("GS_EMU_DEFER") && atoi(getenv("GS_EMU_DEFER")) == 0)) {
+        p.defer_cap = getenv("GS_EMU_DEFER_CAP") ? atoi(getenv("GS_EMU_DEFER_CAP")) : 256;
+        p.defer_min_level = getenv("GS_EMU_DEFER_MIN_LEVEL") ? atoi(getenv("GS_EMU_DEFER_MIN_LEVEL")) : 1;
+        defer_buf.assign((size_t)workers * p.defer_cap, 0);
+        p.defer = defer_buf.data();
+        p.defer_count = prof + 20;
+    }
     long collectives = 0;
     // "workers" waves run one after another; each drains part of the queue so that scratch reuse across queries and
     // distinct worker slices are both exercised
@@ -283,7 +296,9 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     free(visited);
     free(spill);
     if (ub8 && getenv("GS_EMU_PRINT_UB8")) fprintf(stderr, "[gs_emu] ub8 dropped %llu neighbours\n", prof[15]);
+    if (ub8 && getenv("GS_EMU_PRINT_UB8")) fprintf(stderr, "[gs_emu] deferred %llu, of those scored later %llu, sweeps %llu\n", prof[20], prof[21], prof[22]);
     if (ub8 && ub8_dropped_out) *ub8_dropped_out = (long long)prof[15];
+    for (int i = 0; i < 3; ++i) g_last_defer[i] = prof[20 + i];
     return collectives;
 }
 
