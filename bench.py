@@ -1124,14 +1124,14 @@ def main():
             os.environ.update(kv)
             run(timed_q[:Q], rerank_k)
             ctx.profile(True)
-            d0 = [ctx.stat(k) for k in ("gs_deferred", "gs_deferred_scored_later", "gs_defer_sweeps")]
+            d0 = [ctx.stat(k) for k in ("gs_deferred", "gs_defer_restarts")]
             dt = timed_steps(run, timed_q, Q, min(3, args.steps), rerank_k, barrier) / min(3, args.steps)
             pr = {r: ctx.profile_read(r)[0] / min(3, args.steps) for r in regions}
             ctx.profile(False)
-            dq_ = [(ctx.stat(k) - v) / (Q * min(3, args.steps)) for k, v in zip(("gs_deferred", "gs_deferred_scored_later", "gs_defer_sweeps"), d0)]
+            dq_ = [(ctx.stat(k) - v) / (Q * min(3, args.steps)) for k, v in zip(("gs_deferred", "gs_defer_restarts"), d0)]
             log(f"[sweep] {cfg}: {dt * 1e3:.2f} ms/step, {Q / dt:.0f} QPS, kernels " +
                 ", ".join(f"{r} {v:.2f}" for r, v in pr.items() if v > 0) +
-                f" | per query: deferred {dq_[0]:.1f}, of those scored later {dq_[1]:.2f}, sweeps {dq_[2]:.3f}")
+                f" | per query: deferred {dq_[0]:.1f}, started over {dq_[1]:.4f}")
             for k in kv:
                 os.environ.pop(k, None)
 

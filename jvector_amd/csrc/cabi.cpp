@@ -358,7 +358,7 @@ int jv_hip_ctx_profile_read(jv_ctx *ctx, const char *region, double *total_ms, i
 namespace jv {
 namespace {
 // every option a context understands; the environment default of option x is JVECTOR_HIP_<X>
-const char *const kOptions[] = {"graph_traversal", "gs_occ", "gs_pair", "gs_pairc", "gs_quad", "rd_table_free", "rd_chunk", "rd_split", "rd_wide_stage", "rd_prof", "rd_square", "bl_insert_alpha_x100", "bl_improve_beam", "bl_ref_order", "bl_sorted_lists", "gs_cand_cap", "gs_waves_per_cu", "gs_vcap_log2", "gs_v1_log2", "gs_prefetch", "gs_generic", "gs_wgx", "gs_wgx_waves", "gs_wgx_slots", "gs_wgx_depth", "gs_wgx_per_cu", "gs_wgx_lut_m", "gs_ubr", "gs_ubrc", "gs_ubr_trim", "gs_fused_rerank", "gs_defer", "gs_defer_cap", "gs_defer_min_level", "adc_bq",
+const char *const kOptions[] = {"graph_traversal", "gs_occ", "gs_pair", "gs_pairc", "gs_quad", "rd_table_free", "rd_chunk", "rd_split", "rd_wide_stage", "rd_prof", "rd_square", "bl_insert_alpha_x100", "bl_improve_beam", "bl_ref_order", "bl_sorted_lists", "gs_cand_cap", "gs_waves_per_cu", "gs_vcap_log2", "gs_v1_log2", "gs_prefetch", "gs_generic", "gs_wgx", "gs_wgx_waves", "gs_wgx_slots", "gs_wgx_depth", "gs_wgx_per_cu", "gs_wgx_lut_m", "gs_ubr", "gs_ubrc", "gs_ubr_trim", "gs_fused_rerank", "gs_defer", "gs_defer_min_level", "adc_bq",
                                 "gs_grow", "gs_retry", "gs_prof", "gs_tie_check", "gs_push_log", "gs_push_log_cap", "graph_timing",
                                 "no_filter", "quiet"};
 std::string env_name(const char *name)

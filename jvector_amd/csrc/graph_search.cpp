@@ -1472,8 +1472,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const size_t o_prof = carve(sizeof(unsigned long long) * 36);
     // DEFER (gs_body.h, GsParams::defer): the register-table bound form over the row puts off the exact scores of what it meets above
     // level 1 behind the layer's best result; gs_defer = 0 scores everything at once (results are identical either way)
-    const int defer_cap = (!so && !wgx && ubr && pair && ctx_opt(ctx, "gs_defer", 1) != 0) ? (int)std::max<long long>(32, std::min<long long>(4096, ctx_opt(ctx, "gs_defer_cap", 256))) : 0;
-    const size_t o_defer = carve(sizeof(long long) * (size_t)defer_cap * (size_t)workers);
+    const bool defer_on = !so && !wgx && ubr && pair && ctx_opt(ctx, "gs_defer", 1) != 0;
     // exact-score ties across the K-th place of the rerank are decided by the order of the reference's result-heap array
     // (NodeQueue.java:197-214): the traversal logs its addTopCandidate sequence (avg ~1 entry per expansion) and
     // rerank_tie_kernel rebuilds the reference's answer for the (rare) tied queries; an overflowed log sends the query to
@@ -1633,10 +1632,9 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p.push_log_cap = log_cap;
     }
     p.prof = gs_prof ? (unsigned long long *)(base + o_prof) : nullptr;
-    if (defer_cap > 0) {
-        p.defer = (long long *)(base + o_defer);
+    if (defer_on) {
+        p.defer = 1;
         p.defer_count = (unsigned long long *)(base + o_prof) + 33;
-        p.defer_cap = defer_cap;
         p.defer_min_level = (int)std::max<long long>(1, ctx_opt(ctx, "gs_defer_min_level", 2));
     }
     // ---- round 6: the rerank's exact scores inside the traversal wave (gs_body.h gs_rr_round).  Full-resolution rows that
@@ -1677,13 +1675,12 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         unsigned long long ubr_dropped = 0;
         if (ubr) JV_HIP_CHECK(hipMemcpyAsync(&ubr_dropped, base + o_prof + 15 * sizeof(unsigned long long), sizeof(ubr_dropped), hipMemcpyDeviceToHost, ctx->stream));
         unsigned long long defer_counts[3] = {0, 0, 0};
-        if (defer_cap > 0) JV_HIP_CHECK(hipMemcpyAsync(defer_counts, base + o_prof + 33 * sizeof(unsigned long long), sizeof(defer_counts), hipMemcpyDeviceToHost, ctx->stream));
+        if (defer_on) JV_HIP_CHECK(hipMemcpyAsync(defer_counts, base + o_prof + 33 * sizeof(unsigned long long), sizeof(defer_counts), hipMemcpyDeviceToHost, ctx->stream));
         JV_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (ubr) ctx_stat_add(ctx, "gs_ubr_dropped", (long long)ubr_dropped);
-        if (defer_cap > 0) {
+        if (defer_on) {
             ctx_stat_add(ctx, "gs_deferred", (long long)defer_counts[0]);
-            ctx_stat_add(ctx, "gs_deferred_scored_later", (long long)defer_counts[1]);
-            ctx_stat_add(ctx, "gs_defer_sweeps", (long long)defer_counts[2]);
+            ctx_stat_add(ctx, "gs_defer_restarts", (long long)defer_counts[1]);
         }
         memcpy(status.data(), ctx->h_out.ptr, sizeof(int32_t) * (size_t)Q);
         for (int q = 0; q < Q; ++q)
@@ -1716,8 +1713,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         p2.big_count = 0;
         p2.big_log2 = 0;
         p2.prof = nullptr;
-        p2.defer = nullptr;   // (the retry pass: few queries, nothing to win)
-        p2.defer_cap = 0;
+        p2.defer = 0;   // (the retry pass: few queries, nothing to win)
         {
             ProfScope ps(ctx, R_GSEARCH);
             JV_TRY(launch(p2, workers2));

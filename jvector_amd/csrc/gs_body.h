@@ -1181,7 +1181,7 @@ GS_NOINLINE float gs_rr_round(const float *vecs_generic, int D, const float *qra
 //       through LDS and scored two lanes each like PAIR (<= 32 per pass, a second pass for the rest; M > 96: four lanes each,
 //       16 per pass).  LDS layout = PAIR's.
 template <int VSF, int CH16, bool PAIR, bool PROF = false, bool SES = false, bool PAIRC = false, bool UBR = false>
-GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
+GS_FN bool gs_search_one(const GsParams &p, int q, int worker, char *lds, bool nodefer)
 {
     static_assert(!UBR || ((PAIR != PAIRC) && !SES && CH16 % 2 == 0 && 60 * CH16 * 16 + 256 <= 64 * CH16 * 16),
                   "the register-table bound form serves the pair-lane kernels (over the row, or over the compacted fresh list), M a multiple of 32 and >= 64");
@@ -1194,7 +1194,6 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     unsigned long long fh[4] = {0, 0, 0, 0};  // PROF: scored neighbours in expansions with <= 8 / <= 16 / <= 24 / <= 32 fresh ones
     unsigned long long pt = 0, pq0 = 0;
     unsigned long long px[3] = {0, 0, 0};   // PROF: setup (entry -> first pop), level transitions, epilogue
-    // PROF: expansions at the levels above 0 and the clocks spent there (searchOneLayer + the transition)
     unsigned long long pz[2] = {0, 0}, pzf[5] = {0, 0, 0, 0, 0}, pzp[2] = {0, 0};   // (pzf: the five phases at the levels above 0; pzp: their scoring passes' clocks, passes)
     bool prof_upper = false;
     unsigned long long py[7] = {0, 0, 0, 0, 0, 0, 0};   // PROF (UBR): wait for the row, scoring rounds, owner sum + finish, passes, expansions with <= 4 / <= 8 / <= 16 survivors
@@ -1357,21 +1356,18 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         ubr_scale = meta[1];
         ub_on = meta[2] != 0.0f && acc == nullptr && excl < 0;   // (acceptOrds: rejected nodes never become results — no threshold)
     }
-    // ---- DEFER (GsParams::defer): the worker's list of (U, node) keys whose exact score was put off above level 0 ----
-    constexpr bool DEFER = UBR && PAIR && !PAIRC && !SES;
-    long long *dq = nullptr;
-    int d_n = 0;                       // entries (wave-uniform)
-    long long d_maxk = GS_KEY_MIN;     // the largest key among them
-    int rs_pos = -1;                   // >= 0: the list is being scored, 32 entries per turn of the loop
-    unsigned long long d_stat[3] = {0, 0, 0};   // deferred, of those scored later, sweeps
-    if constexpr (DEFER) {
-        if (p.defer != nullptr && p.defer_cap > 0) dq = p.defer + (int64_t)worker * p.defer_cap;
-    }
-    (void)dq;
-    (void)d_n;
+    // ---- DEFER (GsParams::defer): exact scores put off above level 0; all that is kept of them is the largest upper bound ----
+#ifndef GS_DEFER_ENABLE
+#define GS_DEFER_ENABLE 1
+#endif
+    constexpr bool DEFER = GS_DEFER_ENABLE && UBR && PAIR && !PAIRC && !SES;
+    bool d_on = false;
+    long long d_maxk = GS_KEY_MIN;     // the largest (U, node) key among the deferred neighbours; GS_KEY_MIN = none (wave-uniform)
+    uint32_t d_deferred = 0u;
+    if constexpr (DEFER) d_on = !nodefer && p.defer != 0;
+    (void)d_on;
     (void)d_maxk;
-    (void)rs_pos;
-    (void)d_stat;
+    (void)d_deferred;
     (void)ubtab;
     (void)ubr_base;
     (void)ubr_scale;
@@ -1531,41 +1527,19 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
         // ---- searchOneLayer :406-457 (layer 0 of a session with a history: once per phase) ----
         for (;;) {
         for (;;) {
-            bool resolving = false;   // DEFER: this turn scores 32 entries of the deferred list instead of popping a candidate
-            if constexpr (DEFER) {
-                if (rs_pos >= 0) {
-                    if (rs_pos >= d_n) {   // the sweep is over: everything was scored or ruled out
-                        d_n = 0;
-                        d_maxk = GS_KEY_MIN;
-                        rs_pos = -1;
-                    } else {
-                        resolving = true;
-                    }
-                }
-            }
-            long long top = GS_KEY_MIN;
-            int32_t pre_nb = -1;
-            gs_u2 pre_w[PAIR ? (CH16 > 0 ? CH16 : 1) : 1];
-            float pre_mag = 0.0f;
-            bool pre_loaded = false;
-            if (!resolving) {
             if (s.cand_n == 0 && s.spill_n == 0) {
                 if constexpr (DEFER) {
                     // the reference's queue would still hold the deferred nodes: they are popped unless the stop rule fires on them
-                    if (d_n > 0 && !(s.res_n >= rk && gs_key_score(d_maxk) < gs_key_score(s.res_min)) &&
-                        !(lvl == 0 && ub_T > -__builtin_inff() && gs_key_score(d_maxk) < ub_T)) {
-                        rs_pos = 0;
-                        d_stat[2]++;
-                        gs_fence();
-                        continue;
-                    }
+                    if (d_maxk != GS_KEY_MIN && !(s.res_n >= rk && gs_key_score(d_maxk) < gs_key_score(s.res_min)) &&
+                        !(lvl == 0 && ub_T > -__builtin_inff() && gs_key_score(d_maxk) < ub_T))
+                        s.status = GS_RESTART;
                 }
                 break;
             }
             if (s.cand_n == 0) gs_refill(s, p);
             if (PROF) pt = GS_CLOCK();
             int idx;
-            long long runner_up = GS_KEY_MIN;
+            long long top, runner_up = GS_KEY_MIN;
             const bool from_lds = s.cand_n > 0;
             if (from_lds) {
                 if (p.prefetch && lvl == 0) top = gs_scan_top2(s.cand, s.cand_n, &idx, &runner_up);
@@ -1576,17 +1550,15 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             }
             const float top_score = gs_key_score(top);
             if constexpr (DEFER) {
-                if (d_n > 0) {
+                if (d_maxk != GS_KEY_MIN) {
                     const float dmax = gs_key_score(d_maxk);
                     if (lvl == 0 && ub_T > -__builtin_inff() && dmax < ub_T) {   // no deferred node can ever be popped
-                        d_n = 0;
                         d_maxk = GS_KEY_MIN;
                     } else if (!(top_score >= dmax) && !(s.res_n >= rk && dmax < gs_key_score(s.res_min))) {
-                        // a deferred node may outrank the top of the queue (exact < U <= dmax is all that is known): score the list first
-                        rs_pos = 0;
-                        d_stat[2]++;
-                        gs_fence();
-                        continue;
+                        // a deferred node may outrank the top of the queue (exact < U <= dmax is all that is known): the query starts over
+                        // with every neighbour scored when it is met
+                        s.status = GS_RESTART;
+                        break;
                     }
                 }
             }
@@ -1625,6 +1597,10 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             //      runs while addTopCandidate, the rescan of the result minimum and (UBR) the trim of the candidate tier work in LDS.
             //      Pair-lane forms at level 0 (the row is found without a map look-up); nothing is consumed before the expansion
             //      below, and a search that stops or skips the expansion simply drops the registers.
+            int32_t pre_nb = -1;
+            gs_u2 pre_w[PAIR ? (CH16 > 0 ? CH16 : 1) : 1];
+            float pre_mag = 0.0f;
+            bool pre_loaded = false;
             if constexpr (PAIR) {
 #pragma unroll
                 for (int c = 0; c < CH16; ++c) pre_w[c] = gs_u2{0u, 0u};
@@ -1713,14 +1689,13 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             }
             n_expanded++;
             GS_PHASE(1);
-            }   // (!resolving)
 
             // ---- expand: visited.mark + score + candidates.push for every unvisited neighbour ----
             const int32_t node = gs_key_node(top);
-            const int32_t *row = resolving ? nullptr : gs_level_row(L, node);
-            if (!resolving && !row) continue;
-            const int deg = resolving ? 32 : L.degree;
-            const bool fused0 = !resolving && lvl == 0 && p.blocks != nullptr;
+            const int32_t *row = gs_level_row(L, node);
+            if (!row) continue;
+            const int deg = L.degree;
+            const bool fused0 = lvl == 0 && p.blocks != nullptr;
             long long key = 0;
             bool fresh = false;
             if constexpr (PAIR) {
@@ -1731,17 +1706,7 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 int32_t nb;
                 gs_u2 w[CH16];
                 float node_mag = 0.0f;
-                bool d_sel = true;
-                if (DEFER && resolving) {   // the next 32 entries of the deferred list: node ids from the list, codes by ordinal below
-                    const int di = rs_pos + ni;
-                    const long long dkey = di < d_n ? dq[di] : 0;
-                    nb = di < d_n ? gs_key_node(dkey) : -1;
-                    // (what the pop threshold rules out by now is dropped instead of scored: exact < U < T)
-                    d_sel = di < d_n && !(lvl == 0 && ub_T > -__builtin_inff() && gs_key_score(dkey) < ub_T);
-#pragma unroll
-                    for (int c = 0; c < CH16; ++c) w[c] = gs_u2{0u, 0u};
-                    rs_pos += 32;
-                } else if (pre_loaded) {   // (requested right after the pop, see above; uniform)
+                if (pre_loaded) {   // (requested right after the pop, see above; uniform)
                     nb = pre_nb;
 #pragma unroll
                     for (int c = 0; c < CH16; ++c) w[c] = pre_w[c];
@@ -1760,18 +1725,16 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                 }
                 const int first_neg = gs_first(gs_ballot(!hi && nb < 0));  // rows are packed: the first -1 ends the row
                 if (PROF && UBR) py[0] += GS_CLOCK() - pt;   // (the row's ids have arrived)
-                const bool valid = ni < first_neg && d_sel;
+                const bool valid = ni < first_neg;
                 if (!fused0 && valid) {    // PQDecoder.similarityTo: the neighbour's own code
                     gs_load_half<CH16>(p.codes + (int64_t)nb * p.M + m_base, w);
                     if (VSF == 2 && !hi) node_mag = p.code_norms[nb];
                 }
-                if (DEFER && resolving) fresh = !hi && valid;   // (marked visited when they were met)
-                else fresh = visit(!hi && valid, nb);  // one probe per neighbour: the low lane's
+                fresh = visit(!hi && valid, nb);  // one probe per neighbour: the low lane's
                 if (s.status != GS_OK) break;
                 const uint64_t fm = gs_ballot(fresh);
                 if (fm == 0) continue;
-                if (!(DEFER && resolving)) n_visited += gs_popc(fm);
-                else d_stat[1] += (unsigned long long)gs_popc(fm);
+                n_visited += gs_popc(fm);
                 GS_PHASE(2);
                 if (PROF && !UBR) {
                     const int f = gs_popc(fm);
@@ -1783,9 +1746,11 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                     if (PROF) ubc0 = GS_CLOCK();
                     // ---- the bound of every fresh neighbour against the pop threshold ----
                     uint64_t sm = fm;   // the fresh neighbours that need their exact score (bits of the low lanes)
-                    const bool ub_active = !(DEFER && resolving) && ub_on && lvl == 0 && ub_T > -__builtin_inff();
-                    bool ub_up = false;   // DEFER: above level 0 the layer's best result (topK = 1) is the threshold, and "dropped" means deferred
-                    if constexpr (DEFER) ub_up = !resolving && ub_on && dq != nullptr && lvl > 0 && lvl >= p.defer_min_level && s.res_n >= rk;
+                    const bool ub_active = ub_on && lvl == 0 && ub_T > -__builtin_inff();
+                    // DEFER: above level 0 the layer's best result (topK = 1) is the threshold, and what lies below it is DEFERRED — no exact
+                    // score now, only the largest upper bound U of the deferred scores is kept (GsParams::defer has the argument)
+                    bool ub_up = false;
+                    if constexpr (DEFER) ub_up = ub_on && d_on && lvl > 0 && lvl >= p.defer_min_level && s.res_n >= rk;
                     if (ub_active || ub_up) {
                         const float thrT = ub_active ? ub_T : gs_key_score(s.res_min);
                         const int32_t part = gs_ubr_half<CH16>(ubtab, w, hi ? 1 : 0, VSF == 0);   // all 64 lanes
@@ -1800,23 +1765,14 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
                                     U = gs_bound_score<VSF>(braw, node_mag, query_mag);
                                     drop = U < thrT && gs_bound_below<VSF>(braw, node_mag, query_mag, U);
                                 }
-                                const uint64_t dmk = gs_ballot(drop);
-                                const int cnt = gs_popc(dmk);
-                                if (d_n + cnt > p.defer_cap) {
-                                    drop = false;   // the list is full: this expansion's neighbours are scored at once
-                                } else if (cnt > 0) {
-                                    const long long dk = gs_key(nb, U);
-                                    if (drop) dq[d_n + gs_popc(dmk & ((1ull << lane) - 1ull))] = dk;
-                                    const long long mk = gs_wave_max(drop ? dk : GS_KEY_MIN);
-                                    if (mk > d_maxk) d_maxk = mk;
-                                    d_n += cnt;
-                                    d_stat[0] += (unsigned long long)cnt;
-                                }
+                                const long long mk = gs_wave_max(drop ? gs_key(nb, U) : GS_KEY_MIN);
+                                if (mk > d_maxk) d_maxk = mk;
                             }
                         }
                         const uint64_t dm = gs_ballot(drop);
                         sm = fm & ~dm;
                         if (ub_active) ub_dropped += (unsigned long long)gs_popc(dm);
+                        else d_deferred += (uint32_t)gs_popc(dm);
                     }
                     const int ns = gs_popc(sm);
                     ubr_since += ns;
@@ -2215,6 +2171,13 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
             pz[1] += GS_CLOCK() - plv0;
         }
     }
+    if constexpr (DEFER) {
+        if (s.status == GS_RESTART) {   // nothing has left the wave yet (results, counters and status are written below)
+            gs_barrier();
+            if (p.defer_count && lane == 0) gs_fetch_add64(p.defer_count + 1, 1ull);
+            return true;
+        }
+    }
     unsigned long long pep0 = 0;
     if (PROF) pep0 = GS_CLOCK();
 
@@ -2283,10 +2246,10 @@ GS_FN void gs_search_one(const GsParams &p, int q, int worker, char *lds)
     }
     if (UBR && p.ubr_count && lane == 0) gs_fetch_add64(p.ubr_count, ub_dropped);
     if constexpr (DEFER) {
-        if (p.defer_count && lane == 0)
-            for (int i = 0; i < 3; ++i) gs_fetch_add64(p.defer_count + i, d_stat[i]);
+        if (p.defer_count && lane == 0) gs_fetch_add64(p.defer_count, (unsigned long long)d_deferred);
     }
 #undef GS_PHASE
+    return false;
 }
 
 // Persistent worker: pulls queries off the shared counter until none are left.
@@ -2301,7 +2264,11 @@ GS_FN void gs_worker(const GsParams &p, int worker, char *lds)
         if (gs_lane() == 0) qv = (long long)gs_fetch_add(p.next_query, 1u);
         const int item = (int)gs_shfl(qv, 0);
         if (item >= p.Q) break;
-        gs_search_one<VSF, CH16, PAIR, PROF, SES, PAIRC, UBR>(p, p.qmap ? p.qmap[item] : item, worker, lds);
+        // (DEFER: a query whose deferred neighbours turned out to matter starts over with every neighbour scored when it is met)
+        bool again = false;
+        do {
+            again = gs_search_one<VSF, CH16, PAIR, PROF, SES, PAIRC, UBR>(p, p.qmap ? p.qmap[item] : item, worker, lds, again);
+        } while (again);
     }
 }
 

@@ -11,6 +11,7 @@ constexpr int GS_MAX_LEVELS = 32;
 constexpr int GS_EVICT_CAP = 128;
 constexpr int GS_MAX_PHASES = 8;   // session kernels: a search() and up to 7 resume() calls replayed in one launch
 enum : int32_t { GS_OK = 0, GS_OVERFLOW = 1, GS_RERANK_TIE = 2 /* set by rerank_tie_kernel, not by the traversal */ };
+enum : int32_t { GS_RESTART = 3 };   // internal to gs_search_one (DEFER): the query starts over without deferral; never written out
 
 struct GsLevel {
     const int32_t *nbrs;    // count x degree, packed rows padded with -1
@@ -124,14 +125,15 @@ struct GsParams {
     int32_t rr_rows;          // <= 64 * GS_RR_MAX_ROUNDS
     // round 6, last: DEFERRED exact scores above level 0 (gs_body.h DEFER; the register-table bound form over the row only).  A fresh
     // neighbour met at a level >= defer_min_level whose bound lies below that layer's best result (topK = 1) is not scored: (node, an
-    // upper bound U of its score, exact < U) goes to the worker's list.  It can never be popped above level 0 (the result minimum only
-    // grows and the next layer's first pop is at least the last layer's best); at level 0 a pop is valid only while its score >= the
-    // largest U in the list — otherwise what the pop threshold does not rule out is scored exactly (codes by ordinal) and pushed
-    // first.  Pops, results, visitedCount and expandedCount are the reference's.  nullptr = every fresh neighbour above level 0 is scored at once.
-    long long *defer;         // [workers][defer_cap] NodeQueue-encoded (U, node) keys
-    int32_t defer_cap;
+    // upper bound U of its score, exact < U) is remembered only through the largest such U.  It can never be popped above level 0 (the result minimum only
+    // grows and the next layer's first pop is at least the last layer's best); at level 0 a pop is valid while its score >= the
+    // largest U, and they are all forgotten once the pop threshold exceeds that U.  A pop that a deferred node
+    // might outrank (0.6 % of the headline's queries) makes the worker START THE QUERY OVER without deferral — no rarely-run scoring
+    // code in the expansion loop, whose registers are all taken.  Pops, results, visitedCount and expandedCount are the reference's.
+    // nullptr = every fresh neighbour above level 0 is scored at once.
+    int32_t defer;            // 1 = on
     int32_t defer_min_level;  // >= 1
-    unsigned long long *defer_count;  // += {deferred, of those scored later, sweeps of the list} (one atomic each per query), or nullptr
+    unsigned long long *defer_count;  // += {deferred, queries started over, unused} (one atomic each per query), or nullptr
     uint32_t *next_query;     // work counter (zeroed by the host before the launch)
     unsigned long long *prof; // developer aid (JVECTOR_HIP_GS_PROF=1): 8 phase counters, see gs_search_one; else nullptr
 };

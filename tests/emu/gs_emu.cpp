@@ -177,7 +177,7 @@ void lane_main(void *arg)
 }
 }  // namespace
 
-static unsigned long long g_last_defer[3] = {0, 0, 0};   // DEFER counters of the last gs_emu_search: deferred, scored later, sweeps
+static unsigned long long g_last_defer[3] = {0, 0, 0};   // DEFER counters of the last gs_emu_search: deferred, queries started over, unused
 extern "C" void gs_emu_last_defer(unsigned long long *out) { for (int i = 0; i < 3; ++i) out[i] = g_last_defer[i]; }
 
 extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, const int32_t *const *lv_nbrs, const int32_t *lv_count,
@@ -266,13 +266,10 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     unsigned long long prof[24] = {0};
     if (ub8 == 2) p.ubr_count = prof + 15;
     // DEFER (gs_body.h): on in the emulator from level 1 up (the product defers from level 2: more code under test here);
-    // GS_EMU_DEFER=0 turns it off, GS_EMU_DEFER_CAP / GS_EMU_DEFER_MIN_LEVEL size it
-    std::vector<long long> defer_buf;
+    // GS_EMU_DEFER=0 turns it off, GS_EMU_DEFER_MIN_LEVEL moves the first deferring level
     if (ub8 == 2 && !(getenv("GS_EMU_DEFER") && atoi(getenv("GS_EMU_DEFER")) == 0)) {
-        p.defer_cap = getenv("GS_EMU_DEFER_CAP") ? atoi(getenv("GS_EMU_DEFER_CAP")) : 256;
+        p.defer = 1;
         p.defer_min_level = getenv("GS_EMU_DEFER_MIN_LEVEL") ? atoi(getenv("GS_EMU_DEFER_MIN_LEVEL")) : 1;
-        defer_buf.assign((size_t)workers * p.defer_cap, 0);
-        p.defer = defer_buf.data();
         p.defer_count = prof + 20;
     }
     long collectives = 0;
@@ -296,7 +293,7 @@ extern "C" long gs_emu_search(int n_levels, const int32_t *const *lv_nodes, cons
     free(visited);
     free(spill);
     if (ub8 && getenv("GS_EMU_PRINT_UB8")) fprintf(stderr, "[gs_emu] ub8 dropped %llu neighbours\n", prof[15]);
-    if (ub8 && getenv("GS_EMU_PRINT_UB8")) fprintf(stderr, "[gs_emu] deferred %llu, of those scored later %llu, sweeps %llu\n", prof[20], prof[21], prof[22]);
+    if (ub8 && getenv("GS_EMU_PRINT_UB8")) fprintf(stderr, "[gs_emu] deferred %llu, queries started over %llu (%llu)\n", prof[20], prof[21], prof[22]);
     if (ub8 && ub8_dropped_out) *ub8_dropped_out = (long long)prof[15];
     for (int i = 0; i < 3; ++i) g_last_defer[i] = prof[20 + i];
     return collectives;
