@@ -1203,8 +1203,11 @@ def main():
     if graph_mode:
         # expansions / visited of exactly the timed steps (untimed repeat: the search is deterministic)
         dropped0 = ctx.stat("gs_ubr_dropped")
+        defer0 = (ctx.stat("gs_deferred"), ctx.stat("gs_defer_restarts"))
         st = [run(timed_q[s * Q:(s + 1) * Q], rerank_k, stats=True)[2] for s in range(args.steps)]
         ubr_dropped = ctx.stat("gs_ubr_dropped") - dropped0    # neighbours the register-table bound form dropped unscored in those steps
+        # round 6 (gs_defer): neighbours met above level 1 whose exact score was put off for good; queries that had to start over
+        deferred, defer_restarts = ctx.stat("gs_deferred") - defer0[0], ctx.stat("gs_defer_restarts") - defer0[1]
         ubr_form = ctx.stat("gs_last_ubr") == 1
         graph_stats = np.concatenate(st)
         expansions = float(graph_stats[:, 1].sum())
@@ -1228,7 +1231,10 @@ def main():
                 note = (f"algorithmic bytes = expansions x {unit_bytes} B as before (SURVEY §8d row 7: the fused block is still read whole); "
                         f"{ubr_dropped / max(float(graph_stats[:, 0].sum()), 1.0):.3f} of the visited neighbours are dropped behind their bound "
                         "without the M codebook gathers of an exact score; ids, scores, visitedCount and expandedCount are unchanged "
-                        "(DESIGN.md §4 'UBR')")
+                        "(DESIGN.md §4 'UBR'); above level 1 "
+                        f"{deferred / max(float(graph_stats.shape[0]), 1.0):.1f} neighbours per query have their exact score deferred behind the "
+                        f"layer's best result and never computed, {defer_restarts / max(float(graph_stats.shape[0]), 1.0):.4f} of the queries "
+                        "start over without deferral (DESIGN.md §4 'DEFER')")
         else:
             k_ms, k_n = prof["adc"]
             kernel_key = "frontier"
@@ -1357,6 +1363,8 @@ def main():
             line["traversal_stats"] = {k: ctx.stat(k) for k in ("gs_calls_device", "gs_calls_host", "gs_calls_host_auto", "gs_queries_device",
                                                                 "gs_queries_retried", "gs_queries_host_fallback", "gs_ties_resolved_device",
                                                                 "gs_ties_to_host", "gs_last_v1_log2", "gs_last_workers_per_cu")}
+            line["traversal_stats"]["deferred_per_query"] = deferred / max(float(st.shape[0]), 1.0)
+            line["traversal_stats"]["defer_restart_fraction"] = defer_restarts / max(float(st.shape[0]), 1.0)
             line["avg_visited"] = float(st[:, 0].mean())
             line["avg_expanded"] = float(st[:, 1].mean())
             line["adc_distances_per_s"] = float(st[:, 0].mean()) * total_queries / elapsed

@@ -122,7 +122,10 @@ JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
  *   behind their bound, unscored), gs_last_rr_rows (rows [0, r) of every query's kept approximate results whose exact rerank score the
  *   traversal wave computed itself in the last search — option gs_fused_rerank, on by default where the rerank's transposing kernel
  *   applies: 16-byte aligned rows, D % 8 == 0, lists of <= 256, one-wave forms; the same scalar-order chain, the same bits;
- *   0: the rerank was a kernel of its own); experimental_build (1: the library was built with make EXPERIMENTAL=1 and also holds the
+ *   0: the rerank was a kernel of its own), gs_deferred / gs_defer_restarts (option gs_defer, on by default with that form over the
+ *   row: fresh neighbours met at a level >= gs_defer_min_level (2) whose bound lies below the layer's best result are not scored —
+ *   only the largest upper bound of their scores is kept; a pop such a node might outrank makes the query start over without
+ *   deferral (gs_defer_restarts); ids, scores and both counters are unchanged: GraphSearcher.java:263-282,324-331); experimental_build (1: the library was built with make EXPERIMENTAL=1 and also holds the
  *   measured-and-switched-off variants gs_quad, rd_table_free, rd_chunk, rd_square — the default build accepts
  *   and ignores their options). */
 JV_API int jv_hip_ctx_set_option(jv_ctx *ctx, const char *name, int64_t value);
