@@ -1531,7 +1531,7 @@ GS_FN bool gs_search_one(const GsParams &p, int q, int worker, char *lds, bool n
                 if constexpr (DEFER) {
                     // the reference's queue would still hold the deferred nodes: they are popped unless the stop rule fires on them
                     if (d_maxk != GS_KEY_MIN && !(s.res_n >= rk && gs_key_score(d_maxk) < gs_key_score(s.res_min)) &&
-                        !(lvl == 0 && ub_T > -__builtin_inff() && gs_key_score(d_maxk) < ub_T))
+                        !(ub_on && lvl == 0 && ub_T > -__builtin_inff() && gs_key_score(d_maxk) < ub_T))
                         s.status = GS_RESTART;
                 }
                 break;
@@ -1552,7 +1552,7 @@ GS_FN bool gs_search_one(const GsParams &p, int q, int worker, char *lds, bool n
             if constexpr (DEFER) {
                 if (d_maxk != GS_KEY_MIN) {
                     const float dmax = gs_key_score(d_maxk);
-                    if (lvl == 0 && ub_T > -__builtin_inff() && dmax < ub_T) {   // no deferred node can ever be popped
+                    if (ub_on && lvl == 0 && ub_T > -__builtin_inff() && dmax < ub_T) {   // no deferred node can ever be popped
                         d_maxk = GS_KEY_MIN;
                     } else if (!(top_score >= dmax) && !(s.res_n >= rk && dmax < gs_key_score(s.res_min))) {
                         // a deferred node may outrank the top of the queue (exact < U <= dmax is all that is known): the query starts over
