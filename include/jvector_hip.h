@@ -125,7 +125,9 @@ JV_API int jv_hip_ctx_profile(jv_ctx *ctx, int enable);
  *   0: the rerank was a kernel of its own), gs_deferred / gs_defer_restarts (option gs_defer, on by default with that form over the
  *   row: fresh neighbours met at a level >= gs_defer_min_level (2) whose bound lies below the layer's best result are not scored —
  *   only the largest upper bound of their scores is kept; a pop such a node might outrank makes the query start over without
- *   deferral (gs_defer_restarts); ids, scores and both counters are unchanged: GraphSearcher.java:263-282,324-331); experimental_build (1: the library was built with make EXPERIMENTAL=1 and also holds the
+ *   deferral (gs_defer_restarts); an index on which more than a tenth of a batch started over is searched without deferral from
+ *   then on unless gs_defer is set explicitly (gs_defer_switched_off); ids, scores and both counters are unchanged:
+ *   GraphSearcher.java:263-282,324-331); experimental_build (1: the library was built with make EXPERIMENTAL=1 and also holds the
  *   measured-and-switched-off variants gs_quad, rd_table_free, rd_chunk, rd_square — the default build accepts
  *   and ignores their options). */
 JV_API int jv_hip_ctx_set_option(jv_ctx *ctx, const char *name, int64_t value);

@@ -1472,7 +1472,10 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     const size_t o_prof = carve(sizeof(unsigned long long) * 36);
     // DEFER (gs_body.h, GsParams::defer): the register-table bound form over the row puts off the exact scores of what it meets above
     // level 1 behind the layer's best result; gs_defer = 0 scores everything at once (results are identical either way)
-    const bool defer_on = !so && !wgx && ubr && pair && ctx_opt(ctx, "gs_defer", 1) != 0;
+    // (an index on which more than a tenth of a batch's queries had to start over — data without neighbourhood structure above level 1 —
+    //  searches without deferral from then on, unless gs_defer is set explicitly: the restarts cost more than the deferred scores save)
+    const bool defer_on = !so && !wgx && ubr && pair && ctx_opt(ctx, "gs_defer", 1) != 0 &&
+                          (ctx_opt_is_set(ctx, "gs_defer") || ctx->gs_defer_off.count((const void *)g) == 0);
     // exact-score ties across the K-th place of the rerank are decided by the order of the reference's result-heap array
     // (NodeQueue.java:197-214): the traversal logs its addTopCandidate sequence (avg ~1 entry per expansion) and
     // rerank_tie_kernel rebuilds the reference's answer for the (rare) tied queries; an overflowed log sends the query to
@@ -1681,6 +1684,10 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         if (defer_on) {
             ctx_stat_add(ctx, "gs_deferred", (long long)defer_counts[0]);
             ctx_stat_add(ctx, "gs_defer_restarts", (long long)defer_counts[1]);
+            if (Q >= 64 && defer_counts[1] * 10 > (unsigned long long)Q && ctx->gs_defer_off.count((const void *)g) == 0) {
+                ctx->gs_defer_off[(const void *)g] = 1;
+                ctx_stat_add(ctx, "gs_defer_switched_off", 1);
+            }
         }
         memcpy(status.data(), ctx->h_out.ptr, sizeof(int32_t) * (size_t)Q);
         for (int q = 0; q < Q; ++q)

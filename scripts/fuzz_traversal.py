@@ -39,8 +39,9 @@ cases = searches = 0
 knobs = ("JVECTOR_HIP_GS_VCAP_LOG2", "JVECTOR_HIP_GS_GROW", "JVECTOR_HIP_GS_RETRY", "JVECTOR_HIP_GS_CAND_CAP", "JVECTOR_HIP_GS_PUSH_LOG_CAP",
          "JVECTOR_HIP_GS_GENERIC", "JVECTOR_HIP_GS_WGX", "JVECTOR_HIP_GS_WGX_WAVES", "JVECTOR_HIP_GS_WGX_SLOTS", "JVECTOR_HIP_GS_WGX_DEPTH",
          "JVECTOR_HIP_GS_WGX_LUT_M", "JVECTOR_HIP_GS_WGX_PER_CU", "JVECTOR_HIP_GS_PAIRC", "JVECTOR_HIP_GS_QUAD", "JVECTOR_HIP_GS_UBR", "JVECTOR_HIP_GS_UBRC",
-         "JVECTOR_HIP_GS_UBR_TRIM")
+         "JVECTOR_HIP_GS_UBR_TRIM", "JVECTOR_HIP_GS_DEFER", "JVECTOR_HIP_GS_DEFER_MIN_LEVEL")
 wgx_searches = pairc_searches = ubr_searches = 0
+defer0 = (ctx.stat("gs_deferred"), ctx.stat("gs_defer_restarts"))
 while time.time() < t_end:
     D = int(rng.choice([128, 256, 384, 512, 768, 768, 768] if not MOCK else [128, 256]))   # (768 = PQ-96: the register-table bound forms)
     M = D // 8
@@ -141,6 +142,8 @@ while time.time() < t_end:
             env["JVECTOR_HIP_GS_UBR"] = str(int(rng.random() < 0.8))
             env["JVECTOR_HIP_GS_UBRC"] = str(int(rng.random() < 0.8))
             env["JVECTOR_HIP_GS_UBR_TRIM"] = str(int(rng.choice([1, 8, 48, 64])))
+            env["JVECTOR_HIP_GS_DEFER"] = str(int(rng.random() < 0.85))                # deferred scores above level 0 (round 6)
+            env["JVECTOR_HIP_GS_DEFER_MIN_LEVEL"] = str(int(rng.choice([1, 1, 2])))    # (from level 1: restarts are common on these graphs)
         for k in knobs:
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -167,4 +170,5 @@ while time.time() < t_end:
     cases += 1
 for k in knobs:
     os.environ.pop(k, None)
+print(f"fuzz: deferred neighbours {ctx.stat('gs_deferred') - defer0[0]}, queries started over {ctx.stat('gs_defer_restarts') - defer0[1]}")
 print(f"fuzz: {cases} random problems, {searches} searches ({wgx_searches} through the workgroup form, {pairc_searches} through the compacted pair form, {ubr_searches} through a register-table bound form), all bit-identical to the oracle (seed {seed}, {budget:.0f} s)")

@@ -93,6 +93,59 @@ def _setup(ctx, seed, N, D, M, levels, use_fused, deg):
     return v, lv, entry, entry_level, opq, pq, vs, cv, codes, graph, fused, q
 
 
+def test_deferred_scores_above_level_0_on_the_device(ctx):
+    """DEFER (round 6, last; gs_body.h, option gs_defer, default on): above level 0 (from gs_defer_min_level) a fresh neighbour whose bound
+    lies below the layer's best result is not scored; a level-0 pop it might outrank starts the query over without deferral.  Three
+    layers; (1) a proper graph: neighbours ARE deferred and the answer is the oracle's; (2) a RANDOM level-0 graph: most queries start
+    over, the answer is still the oracle's, and the context stops deferring on that index (gs_defer_switched_off) unless gs_defer is set
+    explicitly — ids, scores, visitedCount and expandedCount == the oracle's GraphSearcher every time"""
+    D, M, N = 768, 96, 6000
+    for scramble in (False, True):
+        v, lv, entry, entry_level, cb, q = build_problem(31, N=N, D=D, M=M, deg=32, top_n=400, top_deg=32, levels=3)
+        if scramble:
+            lv[0] = (None, np.random.default_rng(5).integers(0, N, lv[0][1].shape).astype(np.int32))
+        q = np.concatenate([q, q[::-1] * 0.5 + q * 0.5, -q[:16]]).astype(np.float32)   # 96 queries (>= 64: the switch looks at whole batches)
+        opq = O.OraclePQ(D, M, cb)
+        pq = J.ProductQuantization.from_codebooks(ctx, D, M, cb)
+        vs = J.VectorSet(ctx, v)
+        cv = J.PQVectors.encode_and_build(ctx, pq, vs)
+        codes = cv.get(0, N)
+        graph = J.GraphIndex(ctx, N, lv, entry, entry_level).set_traversal("device")
+        fused = J.FusedPQ(ctx, pq, fused_blocks(codes, lv[0][1]), lv[0][1])
+        og = O.OracleGraph(N, lv, entry, entry_level)
+        s = J.GraphSearcher(ctx, graph, pq, cv, fused, vs, max_queries=len(q))
+        try:
+            ctx.set_option("gs_wgx", 0)
+            ctx.set_option("gs_defer_min_level", 1)
+            for vsf in VSF:
+                wi, ws, wst = og.search(opq, codes, v, q, int(vsf), 10, 40, fused=True)
+                d0, r0, off0 = ctx.stat("gs_deferred"), ctx.stat("gs_defer_restarts"), ctx.stat("gs_defer_switched_off")
+                ids, sc, st = s.search(q, vsf, 10, 40, return_stats=True)
+                assert ctx.stat("gs_last_ubr") == 1
+                assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws), (scramble, vsf)
+                if not scramble:
+                    assert ctx.stat("gs_deferred") - d0 > 10 * len(q) and ctx.stat("gs_defer_switched_off") == off0, (vsf,)
+                elif vsf == list(VSF)[0]:
+                    # the first batch on the random graph: restarts, and the index is marked
+                    assert ctx.stat("gs_defer_restarts") - r0 > len(q) // 10 and ctx.stat("gs_defer_switched_off") == off0 + 1
+                else:
+                    assert ctx.stat("gs_defer_restarts") == r0 and ctx.stat("gs_deferred") == d0   # no deferral on this index any more
+            if scramble:   # set explicitly, the option wins: deferral (and the restarts) are back, the answer stays
+                ctx.set_option("gs_defer", 1)
+                r0 = ctx.stat("gs_defer_restarts")
+                wi, ws, wst = og.search(opq, codes, v, q, O.COSINE, 10, 40, fused=True)
+                ids, sc, st = s.search(q, VSF.COSINE, 10, 40, return_stats=True)
+                assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws)
+                assert ctx.stat("gs_defer_restarts") > r0
+                ctx.set_option("gs_defer", 0)
+                d0 = ctx.stat("gs_deferred")
+                ids, sc, st = s.search(q, VSF.COSINE, 10, 40, return_stats=True)
+                assert np.array_equal(st, wst) and np.array_equal(ids, wi) and np.array_equal(sc, ws) and ctx.stat("gs_deferred") == d0
+        finally:
+            for k in ("gs_wgx", "gs_defer_min_level", "gs_defer"):
+                ctx.set_option(k, None)
+
+
 @pytest.mark.parametrize("levels,use_fused,deg,N", [(2, True, 32, 20000), (2, False, 32, 8000), (3, True, 16, 12000)])
 def test_register_table_bound_kernel(ctx, levels, use_fused, deg, N):
     D, M = 768, 96
