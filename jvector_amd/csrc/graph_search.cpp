@@ -462,6 +462,8 @@ struct jv_graph {
         std::vector<int32_t> nbrs;    // count x degree, packed, -1 padded
     };
     std::vector<Level> levels;
+    // gs_defer: a batch on this graph had more than a tenth of its queries start over — its searches run without deferral from then on
+    mutable std::atomic<int> defer_off{0};
     // device mirror for the device-resident traversal (k_gsearch.hip), built on first use; immutable afterwards
     struct DevLevel {
         int32_t *nbrs = nullptr, *hkeys = nullptr, *hvals = nullptr;
@@ -1475,7 +1477,7 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
     // (an index on which more than a tenth of a batch's queries had to start over — data without neighbourhood structure above level 1 —
     //  searches without deferral from then on, unless gs_defer is set explicitly: the restarts cost more than the deferred scores save)
     const bool defer_on = !so && !wgx && ubr && pair && ctx_opt(ctx, "gs_defer", 1) != 0 &&
-                          (ctx_opt_is_set(ctx, "gs_defer") || ctx->gs_defer_off.count((const void *)g) == 0);
+                          (ctx_opt_is_set(ctx, "gs_defer") || g->defer_off.load(std::memory_order_relaxed) == 0);
     // exact-score ties across the K-th place of the rerank are decided by the order of the reference's result-heap array
     // (NodeQueue.java:197-214): the traversal logs its addTopCandidate sequence (avg ~1 entry per expansion) and
     // rerank_tie_kernel rebuilds the reference's answer for the (rare) tied queries; an overflowed log sends the query to
@@ -1684,10 +1686,8 @@ static int graph_search_device(jv_ctx *ctx, const jv_graph *g, jv_luts *l, const
         if (defer_on) {
             ctx_stat_add(ctx, "gs_deferred", (long long)defer_counts[0]);
             ctx_stat_add(ctx, "gs_defer_restarts", (long long)defer_counts[1]);
-            if (Q >= 64 && defer_counts[1] * 10 > (unsigned long long)Q && ctx->gs_defer_off.count((const void *)g) == 0) {
-                ctx->gs_defer_off[(const void *)g] = 1;
+            if (Q >= 64 && defer_counts[1] * 10 > (unsigned long long)Q && g->defer_off.exchange(1, std::memory_order_relaxed) == 0)
                 ctx_stat_add(ctx, "gs_defer_switched_off", 1);
-            }
         }
         memcpy(status.data(), ctx->h_out.ptr, sizeof(int32_t) * (size_t)Q);
         for (int q = 0; q < Q; ++q)

@@ -106,7 +106,6 @@ struct jv_ctx {
     // jv_hip_ctx_set_option / jv_hip_ctx_get_stat (jvector_hip.h): per-context tuning options (they win over the process-wide
     // JVECTOR_HIP_* environment defaults) and event counters of the searches that ran on this context
     std::map<std::string, long long> opts, stats;
-    std::map<const void *, int> gs_defer_off;   // graphs whose searches restarted too often under gs_defer (graph_search.cpp): deferral stays off for them
 };
 
 namespace jv {
